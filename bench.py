@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the Stereo-DSO photometric-alignment hot path on MI355X.
+
+A "step" is ONE pass of the hot path over ONE batch of synthetic KITTI-shaped input that is
+already resident in HBM:
+  --workload ba      (default) one windowed-BA Gauss-Newton iteration (linearize + accumulate A/L/SC
+                     + stitch + solve + resubstitute) for a batch of independent 8-keyframe windows;
+                     unit = point-residual (8-pixel patch, one (point,target) pair)   [BASELINE configs[2]/[4]]
+  --workload tracker one fused calcRes+calcGSSSE evaluation at every pyramid level for a batch of
+                     independent tracking problems; unit = template point               [BASELINE configs[1]]
+  --workload trace   ImmaturePoint::traceStereo over a batch of stereo pairs; unit = point [configs[3]]
+
+Contract (one JSON line on rank 0): see the task statement; plus "roofline" (dominant kernel,
+HIP-event timed inside libsdso_hip.so on the stream the kernel runs on) and "cpu_baseline"
+(the oracle port, -O3 -march=native, timed on a bounded sample on this box's host cores).
+Multi-GPU: one process per GPU (torch.distributed, backend nccl == RCCL).  BA shards the points of
+every window across ranks and all-reduces the packed accumulators once per iteration (weak scaling:
+per-GPU work fixed, windows scale with N); tracker / trace are replicas (no collective).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "stereo-dso-g2o_amd"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def log(*a):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(*a, file=sys.stderr, flush=True)
+
+
+# ---------------------------------------------------------------------------------------------
+class TrackerWorkload:
+    """configs[1]: CoarseTracker full 5-level pyramid, KITTI 1232x368, ~2k active points."""
+    name = "tracker_full_pyramid_kitti1232x368_2kpts"
+    kernel = "k_track_eval"
+    unit = "point-residuals/s"
+    bytes_per_unit = 64.0  # 16 B template point + 4 taps x 12 B
+
+    def __init__(self, ctx, args, rank):
+        from sdso_amd import abi, synth
+        self.ctx, self.abi = ctx, abi
+        t0 = time.time()
+        prob = synth.tracker_problem(w=1232, h=368, npts=2000, seed=2002 + rank)
+        self.prob = prob
+        L = prob["levels"]
+        nframes = args.batch or 128
+        ctx.set_ref(1, prob["pc"])
+        base = np.ascontiguousarray(prob["pyr_new"][0][..., 0])
+        rs = np.random.RandomState(77 + rank)
+        for f in range(nframes):
+            img = np.clip(base + rs.uniform(-1.0, 1.0, base.shape).astype(np.float32), 0, 255).astype(np.float32)
+            ctx.check(ctx.L.sdso_make_pyramid(ctx.h, 100 + f, 1232, 368, abi.fp(img)))
+        from sdso_amd import params
+        prm = params.track_params(prob)
+        evs, refs, frames = [], [], []
+        for f in range(nframes):
+            for lvl in range(L):
+                xi = np.array([0.02, -0.01, 0.35, 0.004, -0.006, 0.002]) + rs.normal(0, 2e-3, 6)
+                T = abi.SE3.from_Rt(*synth.se3_exp(xi))
+                ev = abi.TrackEval()
+                ctx.L.sdso_track_make_eval(C.byref(prm), lvl, C.byref(T), C.byref(abi.Aff(0.02, 1.0)), 1.0, C.byref(ev))
+                evs.append(ev); refs.append(1); frames.append(100 + f)
+        self.nprob = len(evs)
+        self.evs = (abi.TrackEval * self.nprob)(*evs)
+        self.refs = np.array(refs, np.int32)
+        self.frames = np.array(frames, np.int32)
+        ctx.check(ctx.L.sdso_track_batch_prepare(ctx.h, self.nprob, abi.ip(self.refs), abi.ip(self.frames), self.evs))
+        self.units_per_step = nframes * sum(len(p["u"]) for p in prob["pc"])
+        self.config = {"workload": self.name, "problems_per_step": self.nprob, "frames": nframes, "levels": L,
+                       "points_per_level": [len(p["u"]) for p in prob["pc"]], "parallelism": "replicas"}
+        log("tracker setup %.1fs, %d problems, %d points/step" % (time.time() - t0, self.nprob, self.units_per_step))
+
+    def step(self):
+        self.ctx.check(self.ctx.L.sdso_track_batch_enqueue(self.ctx.h))
+
+    def verify(self):
+        abi = self.abi
+        n = self.nprob
+        H = np.zeros((n, 64)); res = np.zeros((n, 6)); nw = np.zeros(n, np.int32)
+        self.ctx.check(self.ctx.L.sdso_track_batch_fetch(self.ctx.h, abi.dp(H), None, abi.dp(res), abi.ip(nw)))
+        assert np.isfinite(H).all() and (nw > 0).all()
+        return {"mean_inliers_per_problem": float(nw.mean())}
+
+    def cpu_baseline(self, budget_s=12.0):
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import pyoracle  # the only place bench.py touches oracle/: the reported CPU baseline
+        abi = self.abi
+        orc = pyoracle.load(fast=True)
+        prob = self.prob
+        pts, t0, reps = 0, time.perf_counter(), 0
+        H = np.zeros(64); b = np.zeros(8); res = np.zeros(6); nw = C.c_int(0)
+        arrs = []
+        for lvl in range(prob["levels"]):
+            pc = prob["pc"][lvl]
+            arrs.append([np.ascontiguousarray(pc[k], np.float32) for k in ("u", "v", "idepth", "color")] + [np.ascontiguousarray(prob["pyr_new"][lvl], np.float32)])
+        while time.perf_counter() - t0 < budget_s:
+            for lvl in range(prob["levels"]):
+                u, v, i, c, img = arrs[lvl]
+                orc.orc_track_calc_res_gs(len(u), abi.fp(u), abi.fp(v), abi.fp(i), abi.fp(c), abi.fp(img), C.byref(self.evs[lvl]),
+                                          abi.dp(H), abi.dp(b), abi.dp(res), C.byref(nw), None, None, 0)
+                pts += len(u)
+            reps += 1
+        dt = time.perf_counter() - t0
+        return {"value": pts / dt, "unit": self.unit, "cores": 1, "kind": "port",
+                "sample": "%d full-pyramid evaluations of one problem (%d points) in %.1f s, oracle -O3 -march=native" % (reps, pts, dt)}
+
+
+WORKLOADS = {"tracker": TrackerWorkload}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default=os.environ.get("SDSO_BENCH_WORKLOAD", "tracker"))
+    ap.add_argument("--batch", type=int, default=0, help="independent problems (frames / windows / pairs) per step and GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from sdso_amd import abi
+    ctx = abi.Context(local_rank)
+    wl = WORKLOADS[args.workload](ctx, args, rank) if args.workload != "ba" else None
+    if wl is None:
+        from bench_ba import BAWorkload
+        wl = BAWorkload(ctx, args, rank, world)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ctx.sync()
+
+    for _ in range(args.warmup):
+        wl.step()
+    barrier()
+    ctx.check(ctx.L.sdso_prof_reset(ctx.h))
+    ctx.check(ctx.L.sdso_prof_enable(ctx.h, 1))
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        wl.step()
+    barrier()
+    dt = time.perf_counter() - t0
+    ctx.check(ctx.L.sdso_prof_enable(ctx.h, 0))
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+        units = torch.tensor([float(wl.units_per_step)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(units, op=dist.ReduceOp.SUM)
+        units_per_step = float(units.item())
+    else:
+        units_per_step = float(wl.units_per_step)
+    kms, klaunch = ctx.prof_read(wl.kernel)
+    extra = wl.verify()
+
+    if rank == 0:
+        value = units_per_step * args.steps / dt
+        per_launch_units = wl.units_per_step * args.steps / max(klaunch, 1)
+        avg_ms = kms / max(klaunch, 1)
+        achieved = per_launch_units * wl.bytes_per_unit / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        out = {
+            "metric": "point-residuals/sec (8-pix patches) per GN iter; windowed-BA iters/sec, 8KF window",
+            "value": value, "unit": wl.unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": wl.config,
+            "roofline": {"bound": "hbm", "kernel": wl.kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel_avg_ms": avg_ms, "launches": klaunch, "algorithmic_bytes_per_unit": wl.bytes_per_unit},
+            "extra": extra,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = wl.cpu_baseline()
+            out["extra"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

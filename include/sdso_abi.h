@@ -1,0 +1,290 @@
+/*
+ * sdso_abi.h — C-ABI of libsdso_hip.so, the MI355X (gfx950) implementation of Stereo-DSO's
+ * photometric direct-alignment hot path.
+ *
+ * The reference (gyubeomim/stereo-dso-g2o) has no FFI layer: the path sits behind plain C++
+ * member functions called by FullSystem.  Each entry point below names the reference member
+ * function (file:line under /root/reference) whose work it performs; the header-only C++ shims
+ * in stereo-dso-g2o_amd/host/ keep the reference's class/method names on top of these calls
+ * (see INTEGRATION.md).
+ *
+ * Conventions
+ *   - every function returns 0 (SDSO_OK) or a negative SDSO_ERR_* code; nothing throws;
+ *     sdso_last_error() returns a static/ctx-owned message for the last failure on that ctx.
+ *   - all pointers are caller-owned HOST buffers unless the name ends in _dev (device pointer).
+ *   - matrices are row-major unless stated; SE3 = 3x3 rotation (row-major) + translation.
+ *   - one ctx = one GPU + one HIP stream; calls on one ctx must come from one thread at a time
+ *     (the reference serialises the same objects under trackMutex / mapMutex,
+ *     src/FullSystem/FullSystem.cpp:1063, :1345).
+ *   - there is NO CPU fallback: without a usable HIP device sdso_ctx_create fails with
+ *     SDSO_ERR_NODEV and every other call fails with SDSO_ERR_STATE.
+ */
+#ifndef SDSO_ABI_H
+#define SDSO_ABI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SDSO_OK 0
+#define SDSO_ERR_ARG (-1)
+#define SDSO_ERR_HIP (-2)
+#define SDSO_ERR_NODEV (-3)
+#define SDSO_ERR_STATE (-4)
+
+#define SDSO_PYR_LEVELS 6      /* src/util/settings.h:46  PYR_LEVELS */
+#define SDSO_PATTERN 8         /* src/util/settings.h:177 patternNum */
+#define SDSO_MAX_RES 8         /* src/util/NumType.h:37  MAX_RES_PER_POINT */
+#define SDSO_CPARS 4           /* src/util/NumType.h:47  CPARS */
+#define SDSO_J_FLOATS 74       /* RawResidualJacobian payload, src/OptimizationBackend/RawResidualJacobian.h:32-65 */
+#define SDSO_TOP_FLOATS 91     /* AccumulatorApprox packed sums 55+30+6, MatrixAccumulators.h:595-614 */
+
+typedef struct sdso_ctx sdso_ctx;
+
+/* ------------------------------------------------------------------ context */
+int sdso_ctx_create(int device_ordinal, sdso_ctx** out);
+void sdso_ctx_destroy(sdso_ctx* ctx);
+const char* sdso_last_error(const sdso_ctx* ctx);
+/* the HIP stream (hipStream_t) all kernels of this ctx are launched on */
+void* sdso_ctx_stream(sdso_ctx* ctx);
+int sdso_ctx_sync(sdso_ctx* ctx);
+
+/* Optional kernel timing with HIP events recorded on the ctx stream around the launches of the
+ * dominant kernels ("k_track_eval", "k_ba_linearize", "k_ba_accum_top", "k_ba_sc", "k_trace_stereo").
+ * sdso_prof_read synchronises the stream and returns the accumulated milliseconds / launch count. */
+int sdso_prof_enable(sdso_ctx* ctx, int on);
+int sdso_prof_reset(sdso_ctx* ctx);
+int sdso_prof_read(sdso_ctx* ctx, const char* kernel, double* total_ms, long* launches);
+
+/* ------------------------------------------------------------------ pyramids
+ * FrameHessian::dIp[lvl] (src/FullSystem/HessianBlocks.h:107-108): Vector3f {I, dx, dy} per pixel.
+ * Images are immutable after FrameHessian::makeImages (HessianBlocks.cpp:141-203), so they are
+ * mirrored once into device memory and addressed by an integer slot. */
+int sdso_pyramid_levels(int w, int h); /* src/util/globalCalib.cpp:52-58 */
+int sdso_upload_pyramid(sdso_ctx* ctx, int frame_slot, int levels, const int* w, const int* h,
+                        const float* const* dIp /* [levels] AoS float3, w*h*3 floats each */);
+/* FrameHessian::makeImages on the device from the level-0 irradiance image (w*h floats). */
+int sdso_make_pyramid(sdso_ctx* ctx, int frame_slot, int w, int h, const float* color);
+/* copy level `lvl` back as AoS float3 (tests) */
+int sdso_download_pyramid_level(sdso_ctx* ctx, int frame_slot, int lvl, float* dI_out);
+int sdso_release_pyramid(sdso_ctx* ctx, int frame_slot);
+
+/* ------------------------------------------------------------------ coarse tracker
+ * CoarseTracker::calcRes + calcGSSSE (src/FullSystem/CoarseTracker.cpp:600-792, :537-596),
+ * DSO-native arithmetic (the residual/Huber/buffer code kept as comments at :699-775). */
+typedef struct {
+  int lvl;
+  int w, h;              /* w[lvl], h[lvl]                       CoarseTracker.cpp:609-610 */
+  float fx, fy, cx, cy;  /* fx[lvl]..cy[lvl]                     CoarseTracker.cpp:612-615 */
+  float Ki[9];           /* Ki[lvl] = K[lvl].inverse()           CoarseTracker.cpp:130     */
+  float RKi[9];          /* R.cast<float>() * Ki[lvl]            CoarseTracker.cpp:617     */
+  float t[3];            /* refToNew.translation().cast<float>() CoarseTracker.cpp:618     */
+  float affLL[2];        /* AffLight::fromToVecExposure(...).cast<float>()  :621           */
+  float ref_b0;          /* lastRef_aff_g2l.b                    CoarseTracker.cpp:542     */
+  float cutoffTH;        /* setting_coarseCutoffTH*levelCutoffRepeat        :894           */
+  float huberTH;         /* setting_huberTH                      settings.cpp:95           */
+} sdso_track_eval_t;
+
+/* pc_u/pc_v/pc_idepth/pc_color[lvl], pc_n[lvl] (CoarseTracker.h:132-140) */
+int sdso_track_set_ref(sdso_ctx* ctx, int ref_slot, int lvl, int n, const float* pc_u,
+                       const float* pc_v, const float* pc_idepth, const float* pc_color);
+int sdso_track_release_ref(sdso_ctx* ctx, int ref_slot);
+
+/* Host-only helper (no GPU work): fill the evaluation parameters for (level, pose, affine) the way
+ * CoarseTracker::makeK (:108-136) and calcRes (:617-621) derive them; cutoffTH =
+ * prm->coarseCutoffTH * levelCutoffRepeat. Declared after sdso_track_params_t below. */
+
+/* One fused evaluation = calcRes followed by calcGSSSE on the buffers it filled.
+ *   H[64], b[8]  : H_out / b_out after the scaling at CoarseTracker.cpp:581-595 (double)
+ *   res[6]       : Vec6 (double) returned by calcRes (:783-789)
+ *   n_warped     : buf_warped_n INCLUDING the zero padding to a multiple of 4 (:763-775)
+ *   inlier_mask  : optional, n bytes; 1 where the point was appended to buf_warped_*          */
+int sdso_track_calc_res_gs(sdso_ctx* ctx, int ref_slot, int frame_slot,
+                           const sdso_track_eval_t* ev, double* H, double* b, double* res,
+                           int* n_warped, uint8_t* inlier_mask);
+
+/* The same for `nprob` independent (reference, frame, pose) problems in ONE launch. Outputs are
+ * arrays of nprob entries (H: nprob*64, b: nprob*8, res: nprob*6, n_warped: nprob). */
+int sdso_track_calc_res_gs_batch(sdso_ctx* ctx, int nprob, const int* ref_slots,
+                                 const int* frame_slots, const sdso_track_eval_t* evs, double* H,
+                                 double* b, double* res, int* n_warped);
+/* Asynchronous form used by the benchmark: enqueue only (no host copy, no sync); results stay in
+ * the ctx's device result buffer and are fetched with sdso_track_batch_fetch. */
+int sdso_track_batch_prepare(sdso_ctx* ctx, int nprob, const int* ref_slots,
+                             const int* frame_slots, const sdso_track_eval_t* evs);
+int sdso_track_batch_enqueue(sdso_ctx* ctx);
+int sdso_track_batch_fetch(sdso_ctx* ctx, double* H, double* b, double* res, int* n_warped);
+
+typedef struct { double R[9]; double t[3]; } sdso_se3_t;
+typedef struct { double a, b; } sdso_aff_t;
+
+typedef struct {
+  int levels;                               /* pyrLevelsUsed */
+  int w[SDSO_PYR_LEVELS], h[SDSO_PYR_LEVELS];
+  float fx[SDSO_PYR_LEVELS], fy[SDSO_PYR_LEVELS], cx[SDSO_PYR_LEVELS], cy[SDSO_PYR_LEVELS]; /* makeK :108-136 */
+  float ref_exposure, new_exposure;         /* lastRef->ab_exposure, newFrame->ab_exposure */
+  sdso_aff_t ref_aff_g2l;                   /* lastRef_aff_g2l */
+  int coarsestLvl;
+  double minResForAbort[5];
+  float coarseCutoffTH;                     /* setting_coarseCutoffTH = 20 */
+  float huberTH;                            /* setting_huberTH = 9 */
+  int maxIterations[5];                     /* DSO-native {10,20,50,50,50} (CoarseTracker.cpp:861) */
+  double affineOptModeA, affineOptModeB;    /* setting_affineOptModeA/B */
+} sdso_track_params_t;
+
+typedef struct {
+  int good;                    /* the bool trackNewestCoarse returns */
+  double lastResiduals[5];     /* NaN where the level was not reached */
+  double lastFlowIndicators[3];
+  int iterations[5];           /* LM iterations actually run per level */
+  int evaluations;             /* total calcRes evaluations */
+  long long point_evals;       /* sum of pc_n[lvl] over all evaluations */
+} sdso_track_result_t;
+
+void sdso_track_make_eval(const sdso_track_params_t* prm, int lvl, const sdso_se3_t* refToNew,
+                          const sdso_aff_t* aff_g2l, float levelCutoffRepeat, sdso_track_eval_t* ev);
+
+/* CoarseTracker::trackNewestCoarse (CoarseTracker.cpp:827-1069), DSO-native LM (the loop kept as
+ * comments at :908-1024).  lastToNew / aff_g2l are in/out exactly like the reference's references. */
+int sdso_track_newest_coarse(sdso_ctx* ctx, int ref_slot, int frame_slot,
+                             const sdso_track_params_t* prm, sdso_se3_t* lastToNew,
+                             sdso_aff_t* aff_g2l, sdso_track_result_t* out);
+
+/* ------------------------------------------------------------------ windowed bundle adjustment
+ * One "window" mirrors an EnergyFunctional (src/OptimizationBackend/EnergyFunctional.h:49-150) with
+ * its frames / points / residuals flattened in EnergyFunctional::makeIDX order (:998-1018):
+ * points in allPoints order, residuals grouped by point in residualsAll order. */
+typedef struct {
+  int nf, np, nr;
+  int w, h;                        /* wG[0], hG[0] */
+  double calib_value_scaled[4];    /* CalibHessian::value_scaled  fx fy cx cy   HessianBlocks.h:276-349 */
+  double calib_value_zero[4];      /* CalibHessian::value_zero (unscaled)                              */
+  /* frames */
+  const double* evalPT;            /* nf*12  worldToCam_evalPT: R (9) then t (3)      HessianBlocks.h:132 */
+  const double* state;             /* nf*10  FrameHessian::state                      HessianBlocks.h:137 */
+  const double* state_zero;        /* nf*10  FrameHessian::state_zero                                     */
+  const float* ab_exposure;        /* nf */
+  const float* frameEnergyTH;      /* nf */
+  const int* frameID;              /* nf     frameID==0 carries the pose prior        HessianBlocks.h:239-265 */
+  const int* frame_slot;           /* nf     device pyramid slot of each keyframe (product) */
+  const float* const* dI;          /* nf     host level-0 images (oracle only; product ignores) */
+  /* points */
+  const float* u;                  /* np */
+  const float* v;                  /* np */
+  const float* idepth;             /* np     PointHessian::idepth (== idepth_scaled, SCALE_IDEPTH=1) */
+  const float* idepth_zero;        /* np */
+  const float* color;              /* np*8 */
+  const float* weights;            /* np*8 */
+  const int* host;                 /* np     host frame index (EFFrame::idx) */
+  const uint8_t* hasDepthPrior;    /* np */
+  /* residuals */
+  const int* res_point;            /* nr     non-decreasing */
+  const int* res_target;           /* nr */
+  const uint8_t* res_state;        /* nr     ResState {IN=0,OOB=1,OUTLIER=2}          Residuals.h:49 */
+  /* marginalisation prior and nullspaces */
+  const double* HM;                /* (8nf+4)^2 */
+  const double* bM;                /* 8nf+4 */
+  /* settings */
+  int solverMode;                  /* setting_solverMode (settings.h:32-43) */
+  double affineOptModeA, affineOptModeB;
+  int forceAcceptStep;             /* setting_forceAceptStep */
+} sdso_ba_window_t;
+
+int sdso_ba_upload_window(sdso_ctx* ctx, int win, const sdso_ba_window_t* W);
+int sdso_ba_release_window(sdso_ctx* ctx, int win);
+
+/* FullSystem::linearizeAll(false) over every residual (FullSystemOptimize.cpp:142-203) =
+ * PointFrameResidual::linearize (Residuals.cpp:83-336).  Returns the summed energy (stats[0]). */
+int sdso_ba_linearize(sdso_ctx* ctx, int win, double* energy);
+/* fetch what linearize produced (any pointer may be NULL):
+ *   J[nr*74] in RawResidualJacobian field order: resF8 Jpdxi0(6) Jpdxi1(6) Jpdc0(4) Jpdc1(4) Jpdd(2)
+ *            JIdx0(8) JIdx1(8) JabF0(8) JabF1(8) JIdx2(4) JabJIdx(4) Jab2(4)
+ *   newState[nr], newEnergy[nr], newEnergyWithOutlier[nr], projectedTo[nr*16], centerProjectedTo[nr*3] */
+int sdso_ba_get_linearization(sdso_ctx* ctx, int win, float* J, uint8_t* newState, float* newEnergy,
+                              float* newEnergyWithOutlier, float* projectedTo,
+                              float* centerProjectedTo);
+/* PointFrameResidual::applyRes(true) for every residual (Residuals.cpp:367-385) incl.
+ * EFResidual::takeDataF (EnergyFunctionalStructs.cpp:37-51). */
+int sdso_ba_apply_res(sdso_ctx* ctx, int win);
+int sdso_ba_get_residual_state(sdso_ctx* ctx, int win, uint8_t* state, uint8_t* isActive,
+                               float* JpJdF /* nr*8 */);
+
+/* accumulateAF_MT + accumulateLF_MT + accumulateSCF_MT up to (not including) the stitch
+ * (EnergyFunctional.cpp:212-269; AccumulatedTopHessian.cpp:36-198; AccumulatedSCHessian.cpp:34-103). */
+int sdso_ba_accumulate(sdso_ctx* ctx, int win);
+/* packed accumulator block of this window, as all-reduced across ranks:
+ *   [ topA nf*nf*91 | topL nf*nf*91 | accD nf^3*64 | accE nf*nf*32 | accEB nf*nf*8 | accHcc 16 | accbc 4 | nresA nresL ]
+ * sdso_ba_accum_floats gives its length; _dev returns the device pointer (float*) for RCCL. */
+int sdso_ba_accum_floats(int nf);
+int sdso_ba_accum_dev(sdso_ctx* ctx, int win, void** dev_ptr);
+int sdso_ba_get_accumulators(sdso_ctx* ctx, int win, float* packed);
+int sdso_ba_get_point_terms(sdso_ctx* ctx, int win, float* HdiF, float* bdSumF, float* Hdd_accAF,
+                            float* bd_accAF, float* Hcd_accAF /* np*4 */);
+
+/* stitch (AccumulatedTopHessian.cpp:265-337, AccumulatedSCHessian.cpp:106-195) + the rest of
+ * EnergyFunctional::solveSystemF (EnergyFunctional.cpp:838-995) + resubstituteF_MT (:272-341).
+ *   x[8nf+4]     : lastX
+ *   H,b          : lastHS, lastbS (may be NULL)
+ *   frame_step   : nf*8  (FrameHessian::step head<8>), calib_step: 4 */
+int sdso_ba_solve(sdso_ctx* ctx, int win, int iteration, double lambda, double* x, double* HS,
+                  double* bS, double* frame_step, double* calib_step);
+int sdso_ba_get_point_steps(sdso_ctx* ctx, int win, float* step /* np */);
+
+/* FullSystem::optimize, DSO-native GN loop (FullSystemOptimize.cpp:871-1041, the un-compiled #else):
+ * returns final frame states, point idepths and residual states. */
+typedef struct {
+  int iterations;
+  double lastEnergy;      /* lastEnergy[0] */
+  double rmse;            /* sqrt(lastEnergy[0]/(patternNum*resInA)) */
+  int resInA;
+} sdso_ba_opt_result_t;
+int sdso_ba_optimize(sdso_ctx* ctx, int win, int mnumOptIts, double* state_out /* nf*10 */,
+                     float* idepth_out /* np */, uint8_t* res_state_out /* nr */,
+                     sdso_ba_opt_result_t* out);
+
+/* EnergyFunctional::marginalizePointsF (EnergyFunctional.cpp:663-736) for the points flagged in
+ * marg_flag[np] (after flagPointsForRemoval's linearize + fixLinearizationF, FullSystem.cpp:1012-1021):
+ * returns the updated HM / bM. */
+int sdso_ba_marginalize_points(sdso_ctx* ctx, int win, const uint8_t* marg_flag, double* HM_out,
+                               double* bM_out);
+
+/* host tables derived from the frame states (tests): precalc nf*nf*27 floats per (host*nf+target)
+ * {PRE_KRKiTll 9, PRE_KtTll 3, PRE_RTll_0 9, PRE_tTll_0 3, PRE_aff_mode 2, PRE_b0_mode 1}
+ * (FrameFramePrecalc::set, HessianBlocks.cpp:206-242); adHost/adTarget nf*nf*64 doubles and
+ * adHTdeltaF nf*nf*8 floats indexed h+t*nf (EnergyFunctional.cpp:41-119, :173-207). */
+int sdso_ba_get_tables(sdso_ctx* ctx, int win, float* precalc, double* adHost, double* adTarget,
+                       float* adHTdeltaF);
+
+/* ------------------------------------------------------------------ static stereo
+ * ImmaturePoint::ImmaturePoint (src/FullSystem/ImmaturePoint.cpp:33-62) for n pixels of a frame:
+ * color[n*8], weights[n*8], gradH[n*4], energyTH[n] (NaN marks a rejected point). */
+int sdso_immature_init_batch(sdso_ctx* ctx, int frame_slot, int n, const float* u, const float* v,
+                             float* color, float* weights, float* gradH, float* energyTH);
+
+/* in/out point state of ImmaturePoint::traceStereo (ImmaturePoint.h:60-102), SoA */
+typedef struct {
+  int n;
+  float* u_stereo; float* v_stereo;
+  float* idepth_min; /* the (unused by stereo) temporal idepth_min tested at ImmaturePoint.cpp:195 */
+  float* idepth_min_stereo; float* idepth_max_stereo; float* idepth_stereo;
+  float* color;      /* n*8 */
+  float* weights;    /* n*8 */
+  float* gradH;      /* n*4 */
+  float* energyTH;
+  float* quality;
+  uint8_t* lastTraceStatus;     /* ImmaturePointStatus, in/out */
+  float* lastTraceUV;           /* n*2 */
+  float* lastTracePixelInterval;
+} sdso_trace_points_t;
+
+/* ImmaturePoint::traceStereo (ImmaturePoint.cpp:94-451) for every point; the sub-pixel GN is the
+ * DSO-native one (twin at :707-769).  K = {fx,fy,cx,cy}. status[n] = returned ImmaturePointStatus. */
+int sdso_trace_stereo_batch(sdso_ctx* ctx, int frame_slot, const float K[4], float baseline,
+                            int mode_right, sdso_trace_points_t* pts, uint8_t* status);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDSO_ABI_H */

@@ -1,0 +1,176 @@
+/* ORACLE — TEST INFRASTRUCTURE ONLY.
+ * C API of liboracle.so: a dependency-free CPU restatement of the reference's DSO-native
+ * arithmetic for the hot path.  It is the parity checker for libsdso_hip.so and
+ * the "port" CPU baseline of bench.py; the product never links, loads or calls it.
+ *
+ * PARITY PINNING: the reference holds no golden vectors for this path and cannot be built here
+ * (Eigen/Boost/g2o/OpenCV absent — SURVEY.md §8c).  The only reference test data, the Sophus SE3
+ * group elements/tangents (thirdparty/Sophus/sophus/test_se3.cpp:40-82), pin se3 exp/log/Adj
+ * (tests/test_oracle_se3.py).  Everything else is "parity unpinned": checked by finite-difference
+ * Jacobians, double-precision re-evaluation and invariants only.
+ *
+ * The struct layouts mirror include/sdso_abi.h one-to-one so that the tests drive both libraries
+ * with the same ctypes structures; the definitions are repeated here on purpose (the oracle does
+ * not include product headers).
+ */
+#ifndef ORC_API_H
+#define ORC_API_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+  int lvl;
+  int w, h;
+  float fx, fy, cx, cy;
+  float Ki[9];
+  float RKi[9];
+  float t[3];
+  float affLL[2];
+  float ref_b0;
+  float cutoffTH;
+  float huberTH;
+} orc_track_eval_t;
+
+typedef struct { double R[9]; double t[3]; } orc_se3_t;
+typedef struct { double a, b; } orc_aff_t;
+
+typedef struct {
+  int levels;
+  int w[6], h[6];
+  float fx[6], fy[6], cx[6], cy[6];
+  float ref_exposure, new_exposure;
+  orc_aff_t ref_aff_g2l;
+  int coarsestLvl;
+  double minResForAbort[5];
+  float coarseCutoffTH;
+  float huberTH;
+  int maxIterations[5];
+  double affineOptModeA, affineOptModeB;
+} orc_track_params_t;
+
+typedef struct {
+  int good;
+  double lastResiduals[5];
+  double lastFlowIndicators[3];
+  int iterations[5];
+  int evaluations;
+  long long point_evals;
+} orc_track_result_t;
+
+typedef struct {
+  int nf, np, nr;
+  int w, h;
+  double calib_value_scaled[4];
+  double calib_value_zero[4];
+  const double* evalPT;
+  const double* state;
+  const double* state_zero;
+  const float* ab_exposure;
+  const float* frameEnergyTH;
+  const int* frameID;
+  const int* frame_slot;
+  const float* const* dI;
+  const float* u;
+  const float* v;
+  const float* idepth;
+  const float* idepth_zero;
+  const float* color;
+  const float* weights;
+  const int* host;
+  const uint8_t* hasDepthPrior;
+  const int* res_point;
+  const int* res_target;
+  const uint8_t* res_state;
+  const double* HM;
+  const double* bM;
+  int solverMode;
+  double affineOptModeA, affineOptModeB;
+  int forceAcceptStep;
+} orc_ba_window_t;
+
+typedef struct {
+  int iterations;
+  double lastEnergy;
+  double rmse;
+  int resInA;
+} orc_ba_opt_result_t;
+
+typedef struct {
+  int n;
+  float* u_stereo; float* v_stereo;
+  float* idepth_min;
+  float* idepth_min_stereo; float* idepth_max_stereo; float* idepth_stereo;
+  float* color;
+  float* weights;
+  float* gradH;
+  float* energyTH;
+  float* quality;
+  uint8_t* lastTraceStatus;
+  float* lastTraceUV;
+  float* lastTracePixelInterval;
+} orc_trace_points_t;
+
+/* ---- math (Sophus restatement) */
+void orc_se3_exp(const double xi[6], orc_se3_t* T);
+void orc_se3_log(const orc_se3_t* T, double xi[6]);
+void orc_se3_adj(const orc_se3_t* T, double A[36]);
+void orc_se3_mul(const orc_se3_t* A, const orc_se3_t* B, orc_se3_t* C);
+void orc_se3_inv(const orc_se3_t* A, orc_se3_t* C);
+void orc_mat3f_inv(const float m[9], float inv[9]);
+int orc_ldlt_solve(int n, const double* A, const double* rhs, double* x);
+
+/* ---- pyramid: globalCalib.cpp:52-58 and HessianBlocks.cpp:141-203 */
+int orc_pyramid_levels(int w, int h);
+void orc_make_images(const float* color, int w, int h, int levels, float* const* dIp_out);
+
+/* ---- tracker */
+int orc_track_calc_res_gs(int n, const float* pc_u, const float* pc_v, const float* pc_idepth,
+                          const float* pc_color, const float* dI, const orc_track_eval_t* ev,
+                          double* H, double* b, double* res, int* n_warped, uint8_t* inlier_mask,
+                          float* buf_warped /* optional 8*n_cap SoA: idepth,u,v,dx,dy,residual,weight,refColor */,
+                          int n_cap);
+/* host-side construction of one evaluation's parameters (CoarseTracker.cpp:108-136, :617-621) */
+void orc_track_make_eval(const orc_track_params_t* prm, int lvl, const orc_se3_t* refToNew,
+                         const orc_aff_t* aff_g2l, float levelCutoffRepeat, orc_track_eval_t* ev);
+int orc_track_newest_coarse(const int* pc_n, const float* const* pc_u, const float* const* pc_v,
+                            const float* const* pc_idepth, const float* const* pc_color,
+                            const float* const* dIp, const orc_track_params_t* prm,
+                            orc_se3_t* lastToNew, orc_aff_t* aff_g2l, orc_track_result_t* out);
+
+/* ---- windowed BA (handle based; the handle deep-copies the window description) */
+typedef struct orc_ba orc_ba;
+orc_ba* orc_ba_create(const orc_ba_window_t* W);
+void orc_ba_destroy(orc_ba* h);
+int orc_ba_linearize(orc_ba* h, double* energy);
+int orc_ba_get_linearization(orc_ba* h, float* J, uint8_t* newState, float* newEnergy,
+                             float* newEnergyWithOutlier, float* projectedTo,
+                             float* centerProjectedTo);
+int orc_ba_apply_res(orc_ba* h);
+int orc_ba_get_residual_state(orc_ba* h, uint8_t* state, uint8_t* isActive, float* JpJdF);
+int orc_ba_accumulate(orc_ba* h);
+int orc_ba_accum_floats(int nf);
+int orc_ba_get_accumulators(orc_ba* h, float* packed);
+int orc_ba_get_point_terms(orc_ba* h, float* HdiF, float* bdSumF, float* Hdd_accAF, float* bd_accAF,
+                           float* Hcd_accAF);
+int orc_ba_solve(orc_ba* h, int iteration, double lambda, double* x, double* HS, double* bS,
+                 double* frame_step, double* calib_step);
+int orc_ba_get_point_steps(orc_ba* h, float* step);
+int orc_ba_optimize(orc_ba* h, int mnumOptIts, double* state_out, float* idepth_out,
+                    uint8_t* res_state_out, orc_ba_opt_result_t* out);
+int orc_ba_marginalize_points(orc_ba* h, const uint8_t* marg_flag, double* HM_out, double* bM_out);
+/* host tables the product also derives (for table-level parity): precalc nf*nf*27 floats
+ * {KRKi9,Kt3,R0 9,t0 3,aff2,b0 1}, adHost/adTarget nf*nf*64 doubles, adHTdeltaF nf*nf*8 floats */
+int orc_ba_get_tables(orc_ba* h, float* precalc, double* adHost, double* adTarget, float* adHTdeltaF);
+
+/* ---- static stereo */
+int orc_immature_init_batch(const float* dI, int w, int h, int n, const float* u, const float* v,
+                            float* color, float* weights, float* gradH, float* energyTH);
+int orc_trace_stereo_batch(const float* dI, int w, int h, const float K[4], float baseline,
+                           int mode_right, orc_trace_points_t* pts, uint8_t* status);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

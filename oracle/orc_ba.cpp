@@ -1,0 +1,1237 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see orc_api.h).
+// Windowed bundle adjustment, DSO-native arithmetic.  Follows (paths under /root/reference):
+//   src/FullSystem/Residuals.cpp:83-385                 PointFrameResidual::linearize / applyRes
+//   src/FullSystem/ResidualProjections.h:45-96          projectPoint (both overloads)
+//   src/FullSystem/HessianBlocks.{h,cpp}                setState, setStateZero, FrameFramePrecalc::set, getPrior
+//   src/OptimizationBackend/EnergyFunctionalStructs.cpp:37-123   takeDataF, takeData, fixLinearizationF
+//   src/OptimizationBackend/AccumulatedTopHessian.{h,cpp}        addPoint<mode>, stitchDouble(Internal/MT)
+//   src/OptimizationBackend/AccumulatedSCHessian.{h,cpp}         addPoint, stitchDouble(Internal/MT)
+//   src/OptimizationBackend/EnergyFunctional.cpp:41-119, 173-207, 212-442, 663-736, 775-995, 1021-1032
+//   src/FullSystem/FullSystemOptimize.cpp:52-370, 871-1041, 1087-1147   GN driver, nullspaces
+//   src/FullSystem/FullSystem.cpp:1004-1021, 1633-1644            flagPointsForRemoval core, setPrecalcValues
+#include "orc_api.h"
+#include "orc_math.h"
+#include "orc_acc.h"
+#include "orc_common.h"
+#include <cmath>
+#include <cstdio>
+#include <vector>
+#include <algorithm>
+
+using namespace orc;
+
+namespace {
+
+enum ResState { RS_IN = 0, RS_OOB = 1, RS_OUTLIER = 2 };
+
+struct RawJ {  // RawResidualJacobian.h:32-65, flattened in the ABI's field order (74 floats)
+  float resF[8];
+  float Jpdxi[2][6];
+  float Jpdc[2][4];
+  float Jpdd[2];
+  float JIdx[2][8];
+  float JabF[2][8];
+  float JIdx2[4];    // (0,0) (0,1) (1,0) (1,1)
+  float JabJIdx[4];
+  float Jab2[4];
+};
+static_assert(sizeof(RawJ) == 74 * 4, "RawJ must be 74 floats");
+
+struct Calib {
+  double value_zero[4], value_scaled[4], value[4], step[4], value_backup[4], value_minus_value_zero[4];
+  float value_scaledf[4], value_scaledi[4];
+  float fxl() const { return value_scaledf[0]; }
+  float fyl() const { return value_scaledf[1]; }
+  float cxl() const { return value_scaledf[2]; }
+  float cyl() const { return value_scaledf[3]; }
+  float fxli() const { return value_scaledi[0]; }
+  float fyli() const { return value_scaledi[1]; }
+  void finishScaled() {
+    for (int i = 0; i < 4; i++) value_scaledf[i] = (float)value_scaled[i];
+    value_scaledi[0] = 1.0f / value_scaledf[0];
+    value_scaledi[1] = 1.0f / value_scaledf[1];
+    value_scaledi[2] = -value_scaledf[2] / value_scaledf[0];
+    value_scaledi[3] = -value_scaledf[3] / value_scaledf[1];
+    for (int i = 0; i < 4; i++) value_minus_value_zero[i] = value[i] - value_zero[i];
+  }
+  void setValue(const double* v) {  // HessianBlocks.h:318-333
+    for (int i = 0; i < 4; i++) value[i] = v[i];
+    value_scaled[0] = SCALE_F * value[0];
+    value_scaled[1] = SCALE_F * value[1];
+    value_scaled[2] = SCALE_C * value[2];
+    value_scaled[3] = SCALE_C * value[3];
+    finishScaled();
+  }
+  void setValueScaled(const double* vs) {  // HessianBlocks.h:335-349
+    for (int i = 0; i < 4; i++) value_scaled[i] = vs[i];
+    value[0] = SCALE_F_INVERSE * value_scaled[0];
+    value[1] = SCALE_F_INVERSE * value_scaled[1];
+    value[2] = SCALE_C_INVERSE * value_scaled[2];
+    value[3] = SCALE_C_INVERSE * value_scaled[3];
+    finishScaled();
+  }
+};
+
+struct Frame {
+  SE3 worldToCam_evalPT;
+  double state_zero[10], state_scaled[10], state[10], step[10], state_backup[10];
+  SE3 PRE_worldToCam, PRE_camToWorld;
+  float ab_exposure, frameEnergyTH;
+  int frameID;
+  const float* dI;
+  double nullspaces_pose[6][6];  // [row][col]
+  double nullspaces_scale[6];
+  double nullspaces_affine[4][2];
+  // EFFrame
+  double prior[8], delta_prior[8], delta[8];
+
+  double aff_a() const { return state_scaled[6]; }
+  double aff_b() const { return state_scaled[7]; }
+  double aff0_a() const { return state_zero[6] * SCALE_A; }
+  double aff0_b() const { return state_zero[7] * SCALE_B; }
+
+  void setState(const double* s) {  // HessianBlocks.h:161-181
+    for (int i = 0; i < 10; i++) state[i] = s[i];
+    for (int i = 0; i < 3; i++) state_scaled[i] = SCALE_XI_TRANS * state[i];
+    for (int i = 3; i < 6; i++) state_scaled[i] = SCALE_XI_ROT * state[i];
+    state_scaled[6] = SCALE_A * state[6];
+    state_scaled[7] = SCALE_B * state[7];
+    state_scaled[8] = SCALE_A * state[8];
+    state_scaled[9] = SCALE_B * state[9];
+    PRE_worldToCam = se3_mul(se3_exp(state_scaled), worldToCam_evalPT);
+    PRE_camToWorld = se3_inv(PRE_worldToCam);
+  }
+  void setStateZero(const double* sz) {  // HessianBlocks.cpp:78-123
+    for (int i = 0; i < 10; i++) state_zero[i] = sz[i];
+    SE3 Tinv = se3_inv(worldToCam_evalPT);
+    for (int i = 0; i < 6; i++) {
+      double eps[6] = {0, 0, 0, 0, 0, 0};
+      eps[i] = 1e-3;
+      SE3 EepsP = se3_exp(eps);
+      eps[i] = -1e-3;
+      SE3 EepsM = se3_exp(eps);
+      SE3 P = se3_mul(se3_mul(worldToCam_evalPT, EepsP), Tinv);
+      SE3 M = se3_mul(se3_mul(worldToCam_evalPT, EepsM), Tinv);
+      double lp[6], lm[6];
+      se3_log(P, lp); se3_log(M, lm);
+      for (int r = 0; r < 6; r++) nullspaces_pose[r][i] = (lp[r] - lm[r]) / (2e-3);
+    }
+    SE3 P = worldToCam_evalPT;
+    for (int i = 0; i < 3; i++) P.t[i] *= 1.00001;
+    P = se3_mul(P, Tinv);
+    SE3 M = worldToCam_evalPT;
+    for (int i = 0; i < 3; i++) M.t[i] /= 1.00001;
+    M = se3_mul(M, Tinv);
+    double lp[6], lm[6];
+    se3_log(P, lp); se3_log(M, lm);
+    for (int r = 0; r < 6; r++) nullspaces_scale[r] = (lp[r] - lm[r]) / (2e-3);
+    for (int r = 0; r < 4; r++) nullspaces_affine[r][0] = nullspaces_affine[r][1] = 0;
+    nullspaces_affine[0][0] = 1; nullspaces_affine[1][0] = 0;
+    nullspaces_affine[0][1] = 0; nullspaces_affine[1][1] = expf((float)aff0_a()) * ab_exposure;
+  }
+  void setEvalPT(const SE3& T, const double* s) { worldToCam_evalPT = T; setState(s); setStateZero(s); }
+  void getPrior(double* p, double optA, double optB, int solverMode) const {  // HessianBlocks.h:239-265
+    for (int i = 0; i < 10; i++) p[i] = 0;
+    if (frameID == 0) {
+      for (int i = 0; i < 3; i++) p[i] = setting_initialTransPrior;
+      for (int i = 3; i < 6; i++) p[i] = setting_initialRotPrior;
+      if (solverMode & SOLVER_REMOVE_POSEPRIOR) for (int i = 0; i < 6; i++) p[i] = 0;
+      p[6] = setting_initialAffAPrior;
+      p[7] = setting_initialAffBPrior;
+    } else {
+      p[6] = (optA < 0) ? (double)setting_initialAffAPrior : optA;
+      p[7] = (optB < 0) ? (double)setting_initialAffBPrior : optB;
+    }
+    p[8] = setting_initialAffAPrior;
+    p[9] = setting_initialAffBPrior;
+  }
+};
+
+struct Precalc {  // HessianBlocks.h:72-97
+  float PRE_RTll[9], PRE_KRKiTll[9], PRE_RKiTll[9], PRE_RTll_0[9];
+  float PRE_aff_mode[2], PRE_b0_mode;
+  float PRE_tTll[3], PRE_KtTll[3], PRE_tTll_0[3];
+};
+
+struct Point {
+  float u, v, idepth, idepth_zero, idepth_scaled, idepth_zero_scaled;
+  float color[8], weights[8];
+  int host;
+  bool hasDepthPrior;
+  float step, idepth_backup;
+  float idepth_hessian;
+  int rbeg, rend;
+  // EFPoint
+  float priorF, deltaF, bdSumF, HdiF;
+  float Hdd_accLF, Hcd_accLF[4], bd_accLF;
+  float Hdd_accAF, Hcd_accAF[4], bd_accAF;
+  void setIdepth(float id) { idepth = id; idepth_scaled = SCALE_IDEPTH * id; }
+  void setIdepthZero(float id) { idepth_zero = id; idepth_zero_scaled = SCALE_IDEPTH * id; }
+};
+
+struct Residual {
+  int point, host, target;
+  ResState state_state, state_NewState;
+  double state_energy, state_NewEnergy, state_NewEnergyWithOutlier;
+  RawJ Jnew;  // PointFrameResidual::J
+  RawJ Jef;   // EFResidual::J
+  float res_toZeroF[8], JpJdF[8];
+  bool isLinearized, isActive;
+  float projectedTo[8][2], centerProjectedTo[3];
+  void resetOOB() { state_NewEnergy = state_energy = 0; state_NewState = RS_OUTLIER; state_state = RS_IN; }
+};
+
+}  // namespace
+
+struct orc_ba {
+  int nf, np, nr, w, h;
+  float wM3G, hM3G;
+  Calib HCalib;
+  std::vector<Frame> frames;
+  std::vector<Point> points;
+  std::vector<Residual> res;
+  std::vector<Precalc> precalc;  // [host*nf + target]  (host->targetPrecalc[target->idx])
+  std::vector<double> adHost, adTarget;  // [h + t*nf][64]
+  std::vector<float> adHostF, adTargetF;
+  std::vector<float> adHTdeltaF;  // [h+t*nf][8]
+  float cDeltaF[4];
+  double cPrior[4];
+  float cPriorF[4];
+  MatX HM;
+  VecX bM;
+  int solverMode;
+  double affineOptModeA, affineOptModeB;
+  bool forceAcceptStep;
+  // accumulators
+  std::vector<AccumulatorApprox> accTopA, accTopL;
+  std::vector<AccumulatorXX<8, 8>> accD;
+  std::vector<AccumulatorXX<8, 4>> accE;
+  std::vector<AccumulatorX<8>> accEB;
+  AccumulatorXX<4, 4> accHcc;
+  AccumulatorX<4> accbc;
+  int nresA, nresL, resInM;
+  MatX lastHS;
+  VecX lastbS, lastX;
+  std::vector<VecX> lastNullspaces_pose, lastNullspaces_scale;
+
+  // ---------------------------------------------------------------- host tables
+  void setPrecalc(int hi, int ti) {  // HessianBlocks.cpp:206-242
+    Frame& host = frames[hi];
+    Frame& target = frames[ti];
+    Precalc& P = precalc[hi * nf + ti];
+    SE3 leftToLeft_0 = se3_mul(target.worldToCam_evalPT, se3_inv(host.worldToCam_evalPT));
+    for (int i = 0; i < 9; i++) P.PRE_RTll_0[i] = (float)leftToLeft_0.R[i];
+    for (int i = 0; i < 3; i++) P.PRE_tTll_0[i] = (float)leftToLeft_0.t[i];
+    SE3 leftToLeft = se3_mul(target.PRE_worldToCam, host.PRE_camToWorld);
+    for (int i = 0; i < 9; i++) P.PRE_RTll[i] = (float)leftToLeft.R[i];
+    for (int i = 0; i < 3; i++) P.PRE_tTll[i] = (float)leftToLeft.t[i];
+    float K[9] = {HCalib.fxl(), 0, HCalib.cxl(), 0, HCalib.fyl(), HCalib.cyl(), 0, 0, 1};
+    float Ki[9];
+    mat3_inv<float>(K, Ki);
+    float KR[9];
+    mat3_mul<float>(K, P.PRE_RTll, KR);
+    mat3_mul<float>(KR, Ki, P.PRE_KRKiTll);
+    mat3_mul<float>(P.PRE_RTll, Ki, P.PRE_RKiTll);
+    mat3_vec<float>(K, P.PRE_tTll, P.PRE_KtTll);
+    double aff[2];
+    fromToVecExposure(host.ab_exposure, target.ab_exposure, host.aff_a(), host.aff_b(), target.aff_a(), target.aff_b(), aff);
+    P.PRE_aff_mode[0] = (float)aff[0];
+    P.PRE_aff_mode[1] = (float)aff[1];
+    P.PRE_b0_mode = (float)host.aff0_b();
+  }
+  void setAdjointsF() {  // EnergyFunctional.cpp:41-119
+    adHost.assign((size_t)nf * nf * 64, 0.0);
+    adTarget.assign((size_t)nf * nf * 64, 0.0);
+    for (int h = 0; h < nf; h++)
+      for (int t = 0; t < nf; t++) {
+        SE3 hostToTarget = se3_mul(frames[t].worldToCam_evalPT, se3_inv(frames[h].worldToCam_evalPT));
+        double AH[8][8] = {{0}}, AT[8][8] = {{0}};
+        for (int i = 0; i < 8; i++) AH[i][i] = AT[i][i] = 1;
+        double Adj[36];
+        se3_adj(hostToTarget, Adj);
+        for (int i = 0; i < 6; i++)
+          for (int j = 0; j < 6; j++) AH[i][j] = -Adj[j * 6 + i];
+        double aff[2];
+        fromToVecExposure(frames[h].ab_exposure, frames[t].ab_exposure, frames[h].aff0_a(), frames[h].aff0_b(),
+                          frames[t].aff0_a(), frames[t].aff0_b(), aff);
+        float affLL0 = (float)aff[0];
+        AT[6][6] = -affLL0;
+        AT[7][7] = -1;
+        AH[6][6] = affLL0;
+        AH[7][7] = affLL0;
+        for (int j = 0; j < 8; j++) {
+          for (int i = 0; i < 3; i++) { AH[i][j] *= SCALE_XI_TRANS; AT[i][j] *= SCALE_XI_TRANS; }
+          for (int i = 3; i < 6; i++) { AH[i][j] *= SCALE_XI_ROT; AT[i][j] *= SCALE_XI_ROT; }
+          AH[6][j] *= SCALE_A; AT[6][j] *= SCALE_A;
+          AH[7][j] *= SCALE_B; AT[7][j] *= SCALE_B;
+        }
+        for (int i = 0; i < 8; i++)
+          for (int j = 0; j < 8; j++) {
+            adHost[(size_t)(h + t * nf) * 64 + i * 8 + j] = AH[i][j];
+            adTarget[(size_t)(h + t * nf) * 64 + i * 8 + j] = AT[i][j];
+          }
+      }
+    for (int i = 0; i < 4; i++) { cPrior[i] = setting_initialCalibHessian; cPriorF[i] = (float)cPrior[i]; }
+    adHostF.resize(adHost.size()); adTargetF.resize(adTarget.size());
+    for (size_t i = 0; i < adHost.size(); i++) { adHostF[i] = (float)adHost[i]; adTargetF[i] = (float)adTarget[i]; }
+  }
+  void setDeltaF() {  // EnergyFunctional.cpp:173-207
+    adHTdeltaF.assign((size_t)nf * nf * 8, 0.f);
+    for (int h = 0; h < nf; h++)
+      for (int t = 0; t < nf; t++) {
+        int idx = h + t * nf;
+        float dh[8], dt[8];
+        for (int i = 0; i < 8; i++) {
+          dh[i] = (float)(frames[h].state[i] - frames[h].state_zero[i]);
+          dt[i] = (float)(frames[t].state[i] - frames[t].state_zero[i]);
+        }
+        // row-vector * matrix, each a float dot product evaluated left to right; then summed
+        for (int j = 0; j < 8; j++) {
+          float sh = 0, st = 0;
+          for (int i = 0; i < 8; i++) { sh += dh[i] * adHostF[(size_t)idx * 64 + i * 8 + j]; st += dt[i] * adTargetF[(size_t)idx * 64 + i * 8 + j]; }
+          adHTdeltaF[(size_t)idx * 8 + j] = sh + st;
+        }
+      }
+    for (int i = 0; i < 4; i++) cDeltaF[i] = (float)HCalib.value_minus_value_zero[i];
+    for (Frame& f : frames) {
+      for (int i = 0; i < 8; i++) { f.delta[i] = f.state[i] - f.state_zero[i]; f.delta_prior[i] = f.state[i]; }
+    }
+    for (Point& p : points) p.deltaF = p.idepth - p.idepth_zero;
+  }
+  void setPrecalcValues() {  // FullSystem.cpp:1633-1644
+    for (int h = 0; h < nf; h++)
+      for (int t = 0; t < nf; t++) setPrecalc(h, t);
+    setDeltaF();
+  }
+
+  // ---------------------------------------------------------------- linearize
+  // ResidualProjections.h:45-58
+  bool projectPoint2(float u_pt, float v_pt, float idepth, const float* KRKi, const float* Kt, float& Ku, float& Kv) const {
+    float ptp[3];
+    for (int r = 0; r < 3; r++) ptp[r] = ((KRKi[r * 3 + 0] * u_pt + KRKi[r * 3 + 1] * v_pt) + KRKi[r * 3 + 2] * 1.0f) + Kt[r] * idepth;
+    Ku = ptp[0] / ptp[2];
+    Kv = ptp[1] / ptp[2];
+    return Ku > 1.1f && Kv > 1.1f && Ku < wM3G && Kv < hM3G;
+  }
+  // ResidualProjections.h:64-96
+  bool projectPointFull(float u_pt, float v_pt, float idepth, int dx, int dy, const float* R, const float* t,
+                        float& drescale, float& u, float& v, float& Ku, float& Kv, float* KliP, float& new_idepth) const {
+    KliP[0] = (u_pt + dx - HCalib.cxl()) * HCalib.fxli();
+    KliP[1] = (v_pt + dy - HCalib.cyl()) * HCalib.fyli();
+    KliP[2] = 1;
+    float ptp[3];
+    for (int r = 0; r < 3; r++) ptp[r] = ((R[r * 3 + 0] * KliP[0] + R[r * 3 + 1] * KliP[1]) + R[r * 3 + 2] * KliP[2]) + t[r] * idepth;
+    drescale = 1.0f / ptp[2];
+    new_idepth = idepth * drescale;
+    if (!(drescale > 0)) return false;
+    u = ptp[0] * drescale;
+    v = ptp[1] * drescale;
+    Ku = u * HCalib.fxl() + HCalib.cxl();
+    Kv = v * HCalib.fyl() + HCalib.cyl();
+    return Ku > 1.1f && Kv > 1.1f && Ku < wM3G && Kv < hM3G;
+  }
+
+  // Residuals.cpp:83-336
+  double linearize(Residual& r) {
+    r.state_NewEnergyWithOutlier = -1;
+    if (r.state_state == RS_OOB) { r.state_NewState = RS_OOB; return r.state_energy; }
+    const Point& point = points[r.point];
+    const Precalc& precalc_ = precalc[r.host * nf + r.target];
+    const Frame& host = frames[r.host];
+    const Frame& target = frames[r.target];
+    float energyLeft = 0;
+    const float* dIl = target.dI;
+    const float* PRE_KRKiTll = precalc_.PRE_KRKiTll;
+    const float* PRE_KtTll = precalc_.PRE_KtTll;
+    const float* PRE_RTll_0 = precalc_.PRE_RTll_0;
+    const float* PRE_tTll_0 = precalc_.PRE_tTll_0;
+    const float* color = point.color;
+    const float* weights = point.weights;
+    float affLL0 = precalc_.PRE_aff_mode[0], affLL1 = precalc_.PRE_aff_mode[1];
+    float b0 = precalc_.PRE_b0_mode;
+    RawJ* J = &r.Jnew;
+
+    float d_xi_x[6], d_xi_y[6], d_C_x[4], d_C_y[4], d_d_x, d_d_y;
+    {
+      float drescale, u, v, new_idepth, Ku, Kv, KliP[3];
+      if (!projectPointFull(point.u, point.v, point.idepth_zero_scaled, 0, 0, PRE_RTll_0, PRE_tTll_0, drescale, u, v, Ku, Kv, KliP, new_idepth)) {
+        r.state_NewState = RS_OOB;
+        return r.state_energy;
+      }
+      r.centerProjectedTo[0] = Ku; r.centerProjectedTo[1] = Kv; r.centerProjectedTo[2] = new_idepth;
+      const float fxl = HCalib.fxl(), fyl = HCalib.fyl(), fxli = HCalib.fxli(), fyli = HCalib.fyli();
+#define R0(i, j) PRE_RTll_0[(i) * 3 + (j)]
+      d_d_x = drescale * (PRE_tTll_0[0] - PRE_tTll_0[2] * u) * SCALE_IDEPTH * fxl;
+      d_d_y = drescale * (PRE_tTll_0[1] - PRE_tTll_0[2] * v) * SCALE_IDEPTH * fyl;
+      d_C_x[2] = drescale * (R0(2, 0) * u - R0(0, 0));
+      d_C_x[3] = fxl * drescale * (R0(2, 1) * u - R0(0, 1)) * fyli;
+      d_C_x[0] = KliP[0] * d_C_x[2];
+      d_C_x[1] = KliP[1] * d_C_x[3];
+      d_C_y[2] = fyl * drescale * (R0(2, 0) * v - R0(1, 0)) * fxli;
+      d_C_y[3] = drescale * (R0(2, 1) * v - R0(1, 1));
+      d_C_y[0] = KliP[0] * d_C_y[2];
+      d_C_y[1] = KliP[1] * d_C_y[3];
+#undef R0
+      d_C_x[0] = (d_C_x[0] + u) * SCALE_F;
+      d_C_x[1] *= SCALE_F;
+      d_C_x[2] = (d_C_x[2] + 1) * SCALE_C;
+      d_C_x[3] *= SCALE_C;
+      d_C_y[0] *= SCALE_F;
+      d_C_y[1] = (d_C_y[1] + v) * SCALE_F;
+      d_C_y[2] *= SCALE_C;
+      d_C_y[3] = (d_C_y[3] + 1) * SCALE_C;
+      d_xi_x[0] = new_idepth * fxl;
+      d_xi_x[1] = 0;
+      d_xi_x[2] = -new_idepth * u * fxl;
+      d_xi_x[3] = -u * v * fxl;
+      d_xi_x[4] = (1 + u * u) * fxl;
+      d_xi_x[5] = -v * fxl;
+      d_xi_y[0] = 0;
+      d_xi_y[1] = new_idepth * fyl;
+      d_xi_y[2] = -new_idepth * v * fyl;
+      d_xi_y[3] = -(1 + v * v) * fyl;
+      d_xi_y[4] = u * v * fyl;
+      d_xi_y[5] = u * fyl;
+    }
+    for (int i = 0; i < 6; i++) { J->Jpdxi[0][i] = d_xi_x[i]; J->Jpdxi[1][i] = d_xi_y[i]; }
+    for (int i = 0; i < 4; i++) { J->Jpdc[0][i] = d_C_x[i]; J->Jpdc[1][i] = d_C_y[i]; }
+    J->Jpdd[0] = d_d_x; J->Jpdd[1] = d_d_y;
+
+    float JIdxJIdx_00 = 0, JIdxJIdx_11 = 0, JIdxJIdx_10 = 0;
+    float JabJIdx_00 = 0, JabJIdx_01 = 0, JabJIdx_10 = 0, JabJIdx_11 = 0;
+    float JabJab_00 = 0, JabJab_01 = 0, JabJab_11 = 0;
+    float wJI2_sum = 0;
+    for (int idx = 0; idx < patternNum; idx++) {
+      float Ku, Kv;
+      if (!projectPoint2(point.u + patternP[idx][0], point.v + patternP[idx][1], point.idepth_scaled, PRE_KRKiTll, PRE_KtTll, Ku, Kv)) {
+        r.state_NewState = RS_OOB;
+        return r.state_energy;
+      }
+      r.projectedTo[idx][0] = Ku;
+      r.projectedTo[idx][1] = Kv;
+      float hitColor[3];
+      interp33(dIl, Ku, Kv, w, hitColor);
+      float residual = hitColor[0] - (float)(affLL0 * color[idx] + affLL1);
+      float drdA = (color[idx] - b0);
+      if (!std::isfinite((float)hitColor[0])) { r.state_NewState = RS_OOB; return r.state_energy; }
+      float wgt = sqrtf(setting_outlierTHSumComponent / (setting_outlierTHSumComponent + (hitColor[1] * hitColor[1] + hitColor[2] * hitColor[2])));
+      wgt = 0.5f * (wgt + weights[idx]);
+      float hw = fabsf(residual) < setting_huberTH ? 1 : setting_huberTH / fabsf(residual);
+      energyLeft += wgt * wgt * hw * residual * residual * (2 - hw);
+      {
+        if (hw < 1) hw = sqrtf(hw);
+        hw = hw * wgt;
+        hitColor[1] *= hw;
+        hitColor[2] *= hw;
+        J->resF[idx] = residual * hw;
+        J->JIdx[0][idx] = hitColor[1];
+        J->JIdx[1][idx] = hitColor[2];
+        J->JabF[0][idx] = drdA * hw;
+        J->JabF[1][idx] = hw;
+        JIdxJIdx_00 += hitColor[1] * hitColor[1];
+        JIdxJIdx_11 += hitColor[2] * hitColor[2];
+        JIdxJIdx_10 += hitColor[1] * hitColor[2];
+        JabJIdx_00 += drdA * hw * hitColor[1];
+        JabJIdx_01 += drdA * hw * hitColor[2];
+        JabJIdx_10 += hw * hitColor[1];
+        JabJIdx_11 += hw * hitColor[2];
+        JabJab_00 += drdA * drdA * hw * hw;
+        JabJab_01 += drdA * hw * hw;
+        JabJab_11 += hw * hw;
+        wJI2_sum += hw * hw * (hitColor[1] * hitColor[1] + hitColor[2] * hitColor[2]);
+        if (affineOptModeA < 0) J->JabF[0][idx] = 0;
+        if (affineOptModeB < 0) J->JabF[1][idx] = 0;
+      }
+    }
+    J->JIdx2[0] = JIdxJIdx_00; J->JIdx2[1] = JIdxJIdx_10; J->JIdx2[2] = JIdxJIdx_10; J->JIdx2[3] = JIdxJIdx_11;
+    J->JabJIdx[0] = JabJIdx_00; J->JabJIdx[1] = JabJIdx_01; J->JabJIdx[2] = JabJIdx_10; J->JabJIdx[3] = JabJIdx_11;
+    J->Jab2[0] = JabJab_00; J->Jab2[1] = JabJab_01; J->Jab2[2] = JabJab_01; J->Jab2[3] = JabJab_11;
+
+    r.state_NewEnergyWithOutlier = energyLeft;
+    float th = std::max<float>(host.frameEnergyTH, target.frameEnergyTH);
+    if (energyLeft > th || wJI2_sum < 2) {
+      energyLeft = th;
+      r.state_NewState = RS_OUTLIER;
+    } else {
+      r.state_NewState = RS_IN;
+    }
+    r.state_NewEnergy = energyLeft;
+    return energyLeft;
+  }
+
+  void takeDataF(Residual& r) {  // EnergyFunctionalStructs.cpp:37-51
+    std::swap(r.Jef, r.Jnew);
+    const RawJ* J = &r.Jef;
+    float JI_JI_Jd[2];
+    JI_JI_Jd[0] = J->JIdx2[0] * J->Jpdd[0] + J->JIdx2[1] * J->Jpdd[1];
+    JI_JI_Jd[1] = J->JIdx2[2] * J->Jpdd[0] + J->JIdx2[3] * J->Jpdd[1];
+    for (int i = 0; i < 6; i++) r.JpJdF[i] = J->Jpdxi[0][i] * JI_JI_Jd[0] + J->Jpdxi[1][i] * JI_JI_Jd[1];
+    r.JpJdF[6] = J->JabJIdx[0] * J->Jpdd[0] + J->JabJIdx[1] * J->Jpdd[1];
+    r.JpJdF[7] = J->JabJIdx[2] * J->Jpdd[0] + J->JabJIdx[3] * J->Jpdd[1];
+  }
+  void applyRes(Residual& r) {  // Residuals.cpp:367-385 (copyJacobians = true)
+    if (r.state_state == RS_OOB) return;
+    if (r.state_NewState == RS_IN) { r.isActive = true; takeDataF(r); }
+    else r.isActive = false;
+    r.state_state = r.state_NewState;
+    r.state_energy = r.state_NewEnergy;
+  }
+  void fixLinearizationF(Residual& r) {  // EnergyFunctionalStructs.cpp:96-123
+    const float* dp = &adHTdeltaF[(size_t)(r.host + nf * r.target) * 8];
+    const RawJ* J = &r.Jef;
+    float dx = dot6(J->Jpdxi[0], dp) + dot4(J->Jpdc[0], cDeltaF) + J->Jpdd[0] * points[r.point].deltaF;
+    float dy = dot6(J->Jpdxi[1], dp) + dot4(J->Jpdc[1], cDeltaF) + J->Jpdd[1] * points[r.point].deltaF;
+    for (int i = 0; i < 8; i++) {
+      float rtz = J->resF[i];
+      rtz = rtz - J->JIdx[0][i] * dx;
+      rtz = rtz - J->JIdx[1][i] * dy;
+      rtz = rtz - J->JabF[0][i] * dp[6];
+      rtz = rtz - J->JabF[1][i] * dp[7];
+      r.res_toZeroF[i] = rtz;
+    }
+    r.isLinearized = true;
+  }
+  static float dot6(const float* a, const float* b) { float s = 0; for (int i = 0; i < 6; i++) s += a[i] * b[i]; return s; }
+  static float dot4(const float* a, const float* b) { float s = 0; for (int i = 0; i < 4; i++) s += a[i] * b[i]; return s; }
+
+  void setNewFrameEnergyTH() {  // FullSystemOptimize.cpp:98-139
+    std::vector<float> allResVec;
+    int newFrame = nf - 1;
+    for (Residual& r : res)
+      if (!r.isLinearized && r.state_NewEnergyWithOutlier >= 0 && r.target == newFrame) allResVec.push_back((float)r.state_NewEnergyWithOutlier);
+    if (allResVec.empty()) { frames[newFrame].frameEnergyTH = 12 * 12 * patternNum; return; }
+    int nthIdx = setting_frameEnergyTHN * allResVec.size();
+    std::nth_element(allResVec.begin(), allResVec.begin() + nthIdx, allResVec.end());
+    float nthElement = sqrtf(allResVec[nthIdx]);
+    float th = nthElement * setting_frameEnergyTHFacMedian;
+    th = 26.0f * setting_frameEnergyTHConstWeight + th * (1 - setting_frameEnergyTHConstWeight);
+    th = th * th;
+    th *= setting_overallEnergyTHWeight * setting_overallEnergyTHWeight;
+    frames[newFrame].frameEnergyTH = th;
+  }
+  // FullSystemOptimize.cpp:142-203 (activeResiduals = residuals that are not linearized)
+  double linearizeAll(bool fixLinearization) {
+    double lastEnergyP = 0;
+    for (Residual& r : res) {
+      if (r.isLinearized) continue;
+      lastEnergyP += linearize(r);
+      if (fixLinearization) applyRes(r);
+    }
+    setNewFrameEnergyTH();
+    return lastEnergyP;
+  }
+
+  // ---------------------------------------------------------------- accumulate
+  template <int mode>
+  void addPointTop(Point& p, std::vector<AccumulatorApprox>& acc, int& nres) {  // AccumulatedTopHessian.cpp:36-198
+    const float* dc = cDeltaF;
+    float dd = p.deltaF;
+    float bd_acc = 0, Hdd_acc = 0, Hcd_acc[4] = {0, 0, 0, 0};
+    for (int ri = p.rbeg; ri < p.rend; ri++) {
+      Residual& r = res[ri];
+      if (mode == 0) { if (r.isLinearized || !r.isActive) continue; }
+      if (mode == 1) { if (!r.isLinearized || !r.isActive) continue; }
+      if (mode == 2) { if (!r.isActive) continue; }
+      const RawJ* rJ = &r.Jef;
+      int htIDX = r.host + r.target * nf;
+      const float* dp = &adHTdeltaF[(size_t)htIDX * 8];
+      float resApprox[8];
+      if (mode == 0) for (int i = 0; i < 8; i++) resApprox[i] = rJ->resF[i];
+      if (mode == 1) {
+        float dx = dot6(rJ->Jpdxi[0], dp) + dot4(rJ->Jpdc[0], dc) + rJ->Jpdd[0] * dd;
+        float dy = dot6(rJ->Jpdxi[1], dp) + dot4(rJ->Jpdc[1], dc) + rJ->Jpdd[1] * dd;
+        for (int i = 0; i < 8; i++) {
+          float rtz = r.res_toZeroF[i];
+          rtz = rtz + rJ->JIdx[0][i] * dx;
+          rtz = rtz + rJ->JIdx[1][i] * dy;
+          rtz = rtz + rJ->JabF[0][i] * dp[6];
+          rtz = rtz + rJ->JabF[1][i] * dp[7];
+          resApprox[i] = rtz;
+        }
+      }
+      if (mode == 2) for (int i = 0; i < 8; i++) resApprox[i] = r.res_toZeroF[i];
+
+      float JI_r[2] = {0, 0}, Jab_r[2] = {0, 0}, rr = 0;
+      for (int i = 0; i < patternNum; i++) {
+        JI_r[0] += resApprox[i] * rJ->JIdx[0][i];
+        JI_r[1] += resApprox[i] * rJ->JIdx[1][i];
+        Jab_r[0] += resApprox[i] * rJ->JabF[0][i];
+        Jab_r[1] += resApprox[i] * rJ->JabF[1][i];
+        rr += resApprox[i] * resApprox[i];
+      }
+      acc[htIDX].update(rJ->Jpdc[0], rJ->Jpdxi[0], rJ->Jpdc[1], rJ->Jpdxi[1], rJ->JIdx2[0], rJ->JIdx2[1], rJ->JIdx2[3]);
+      acc[htIDX].updateBotRight(rJ->Jab2[0], rJ->Jab2[1], Jab_r[0], rJ->Jab2[3], Jab_r[1], rr);
+      acc[htIDX].updateTopRight(rJ->Jpdc[0], rJ->Jpdxi[0], rJ->Jpdc[1], rJ->Jpdxi[1], rJ->JabJIdx[0], rJ->JabJIdx[1],
+                                rJ->JabJIdx[2], rJ->JabJIdx[3], JI_r[0], JI_r[1]);
+      float Ji2_Jpdd[2];
+      Ji2_Jpdd[0] = rJ->JIdx2[0] * rJ->Jpdd[0] + rJ->JIdx2[1] * rJ->Jpdd[1];
+      Ji2_Jpdd[1] = rJ->JIdx2[2] * rJ->Jpdd[0] + rJ->JIdx2[3] * rJ->Jpdd[1];
+      bd_acc += JI_r[0] * rJ->Jpdd[0] + JI_r[1] * rJ->Jpdd[1];
+      Hdd_acc += Ji2_Jpdd[0] * rJ->Jpdd[0] + Ji2_Jpdd[1] * rJ->Jpdd[1];
+      for (int i = 0; i < 4; i++) Hcd_acc[i] += rJ->Jpdc[0][i] * Ji2_Jpdd[0] + rJ->Jpdc[1][i] * Ji2_Jpdd[1];
+      nres++;
+    }
+    if (mode == 0) {
+      p.Hdd_accAF = Hdd_acc; p.bd_accAF = bd_acc;
+      for (int i = 0; i < 4; i++) p.Hcd_accAF[i] = Hcd_acc[i];
+    }
+    if (mode == 1 || mode == 2) {
+      p.Hdd_accLF = Hdd_acc; p.bd_accLF = bd_acc;
+      for (int i = 0; i < 4; i++) p.Hcd_accLF[i] = Hcd_acc[i];
+    }
+    if (mode == 2) {
+      for (int i = 0; i < 4; i++) p.Hcd_accAF[i] = 0;
+      p.Hdd_accAF = 0; p.bd_accAF = 0;
+    }
+  }
+  void addPointSC(Point& p, bool shiftPriorToZero) {  // AccumulatedSCHessian.cpp:34-103
+    int ngoodres = 0;
+    for (int ri = p.rbeg; ri < p.rend; ri++) if (res[ri].isActive) ngoodres++;
+    if (ngoodres == 0) { p.HdiF = 0; p.bdSumF = 0; p.idepth_hessian = 0; return; }
+    float H = p.Hdd_accAF + p.Hdd_accLF + p.priorF;
+    if (H < 1e-10) H = 1e-10;
+    p.idepth_hessian = H;
+    p.HdiF = 1.0 / H;
+    p.bdSumF = p.bd_accAF + p.bd_accLF;
+    if (shiftPriorToZero) p.bdSumF += p.priorF * p.deltaF;
+    float Hcd[4];
+    for (int i = 0; i < 4; i++) Hcd[i] = p.Hcd_accAF[i] + p.Hcd_accLF[i];
+    accHcc.update(Hcd, Hcd, p.HdiF);
+    accbc.update(Hcd, p.bdSumF * p.HdiF);
+    int nFrames2 = nf * nf;
+    for (int r1i = p.rbeg; r1i < p.rend; r1i++) {
+      Residual& r1 = res[r1i];
+      if (!r1.isActive) continue;
+      int r1ht = r1.host + r1.target * nf;
+      for (int r2i = p.rbeg; r2i < p.rend; r2i++) {
+        Residual& r2 = res[r2i];
+        if (!r2.isActive) continue;
+        accD[r1ht + r2.target * nFrames2].update(r1.JpJdF, r2.JpJdF, p.HdiF);
+      }
+      accE[r1ht].update(r1.JpJdF, Hcd, p.HdiF);
+      accEB[r1ht].update(r1.JpJdF, p.HdiF * p.bdSumF);
+    }
+  }
+  void zeroTop(std::vector<AccumulatorApprox>& a) { a.resize((size_t)nf * nf); for (auto& x : a) x.initialize(); }
+  void zeroSC() {
+    accD.resize((size_t)nf * nf * nf); accE.resize((size_t)nf * nf); accEB.resize((size_t)nf * nf);
+    for (auto& x : accD) x.initialize();
+    for (auto& x : accE) x.initialize();
+    for (auto& x : accEB) x.initialize();
+    accHcc.initialize(); accbc.initialize();
+  }
+  void accumulateAll() {  // the addPoint loops of EnergyFunctional.cpp:212-269 (single accumulator copy, tid 0)
+    zeroTop(accTopA); nresA = 0;
+    for (Point& p : points) addPointTop<0>(p, accTopA, nresA);
+    zeroTop(accTopL); nresL = 0;
+    for (Point& p : points) addPointTop<1>(p, accTopL, nresL);
+    zeroSC();
+    for (Point& p : points) addPointSC(p, true);
+  }
+
+  // ---------------------------------------------------------------- stitch
+  static void mul88(const double* A, const double* B, double* C, bool transB) {  // 8x8
+    for (int i = 0; i < 8; i++)
+      for (int j = 0; j < 8; j++) {
+        double s = 0;
+        for (int k = 0; k < 8; k++) s += A[i * 8 + k] * (transB ? B[j * 8 + k] : B[k * 8 + j]);
+        C[i * 8 + j] = s;
+      }
+  }
+  // AccumulatedTopHessian.cpp:265-337 + the symmetrisation of AccumulatedTopHessian.h:133-147
+  void stitchTop(std::vector<AccumulatorApprox>& acc, MatX& H, VecX& b, bool usePrior) {
+    int n = nf * 8 + 4;
+    H = MatX(n, n); b.assign(n, 0.0);
+    for (int k = 0; k < nf * nf; k++) {
+      int h = k % nf, t = k / nf;
+      int hIdx = 4 + h * 8, tIdx = 4 + t * 8, aidx = h + nf * t;
+      double accH[13][13];
+      for (int i = 0; i < 13; i++) for (int j = 0; j < 13; j++) accH[i][j] = 0;
+      acc[aidx].finish();
+      if (acc[aidx].num != 0)
+        for (int i = 0; i < 13; i++) for (int j = 0; j < 13; j++) accH[i][j] += (double)acc[aidx].H[i][j];
+      const double* AH = &adHost[(size_t)aidx * 64];
+      const double* AT = &adTarget[(size_t)aidx * 64];
+      double A88[64], tmp[64], out[64];
+      for (int i = 0; i < 8; i++) for (int j = 0; j < 8; j++) A88[i * 8 + j] = accH[4 + i][4 + j];
+      mul88(AH, A88, tmp, false); mul88(tmp, AH, out, true);
+      for (int i = 0; i < 8; i++) for (int j = 0; j < 8; j++) H(hIdx + i, hIdx + j) += out[i * 8 + j];
+      mul88(AT, A88, tmp, false); mul88(tmp, AT, out, true);
+      for (int i = 0; i < 8; i++) for (int j = 0; j < 8; j++) H(tIdx + i, tIdx + j) += out[i * 8 + j];
+      mul88(AH, A88, tmp, false); mul88(tmp, AT, out, true);
+      for (int i = 0; i < 8; i++) for (int j = 0; j < 8; j++) H(hIdx + i, tIdx + j) += out[i * 8 + j];
+      for (int i = 0; i < 8; i++)
+        for (int c = 0; c < 4; c++) {
+          double sh = 0, st = 0;
+          for (int kk = 0; kk < 8; kk++) { sh += AH[i * 8 + kk] * accH[4 + kk][c]; st += AT[i * 8 + kk] * accH[4 + kk][c]; }
+          H(hIdx + i, c) += sh;
+          H(tIdx + i, c) += st;
+        }
+      for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) H(i, j) += accH[i][j];
+      for (int i = 0; i < 8; i++) {
+        double sh = 0, st = 0;
+        for (int kk = 0; kk < 8; kk++) { sh += AH[i * 8 + kk] * accH[4 + kk][12]; st += AT[i * 8 + kk] * accH[4 + kk][12]; }
+        b[hIdx + i] += sh;
+        b[tIdx + i] += st;
+      }
+      for (int i = 0; i < 4; i++) b[i] += accH[i][12];
+    }
+    if (usePrior) {
+      for (int i = 0; i < 4; i++) { H(i, i) += cPrior[i]; b[i] += cPrior[i] * (double)cDeltaF[i]; }
+      for (int h = 0; h < nf; h++)
+        for (int i = 0; i < 8; i++) {
+          H(4 + h * 8 + i, 4 + h * 8 + i) += frames[h].prior[i];
+          b[4 + h * 8 + i] += frames[h].prior[i] * frames[h].delta_prior[i];
+        }
+    }
+    for (int h = 0; h < nf; h++) {
+      int hIdx = 4 + h * 8;
+      for (int i = 0; i < 8; i++) for (int c = 0; c < 4; c++) H(c, hIdx + i) = H(hIdx + i, c);
+      for (int t = h + 1; t < nf; t++) {
+        int tIdx = 4 + t * 8;
+        for (int i = 0; i < 8; i++) for (int j = 0; j < 8; j++) H(hIdx + i, tIdx + j) += H(tIdx + j, hIdx + i);
+        for (int i = 0; i < 8; i++) for (int j = 0; j < 8; j++) H(tIdx + j, hIdx + i) = H(hIdx + i, tIdx + j);
+      }
+    }
+  }
+  // AccumulatedSCHessian.cpp:106-195 + AccumulatedSCHessian.h:129-134
+  void stitchSC(MatX& H, VecX& b) {
+    int n = nf * 8 + 4;
+    H = MatX(n, n); b.assign(n, 0.0);
+    int nframes2 = nf * nf;
+    for (int k0 = 0; k0 < nf * nf; k0++) {
+      int i = k0 % nf, j = k0 / nf;
+      int iIdx = 4 + i * 8, jIdx = 4 + j * 8, ijIdx = i + nf * j;
+      accE[ijIdx].finish(); accEB[ijIdx].finish();
+      const double* AHij = &adHost[(size_t)ijIdx * 64];
+      const double* ATij = &adTarget[(size_t)ijIdx * 64];
+      for (int a = 0; a < 8; a++)
+        for (int c = 0; c < 4; c++) {
+          double sh = 0, st = 0;
+          for (int kk = 0; kk < 8; kk++) { sh += AHij[a * 8 + kk] * (double)accE[ijIdx].A1m[kk][c]; st += ATij[a * 8 + kk] * (double)accE[ijIdx].A1m[kk][c]; }
+          H(iIdx + a, c) += sh;
+          H(jIdx + a, c) += st;
+        }
+      for (int a = 0; a < 8; a++) {
+        double sh = 0, st = 0;
+        for (int kk = 0; kk < 8; kk++) { sh += AHij[a * 8 + kk] * (double)accEB[ijIdx].A1m[kk]; st += ATij[a * 8 + kk] * (double)accEB[ijIdx].A1m[kk]; }
+        b[iIdx + a] += sh;
+        b[jIdx + a] += st;
+      }
+      for (int k = 0; k < nf; k++) {
+        int kIdx = 4 + k * 8, ijkIdx = ijIdx + k * nframes2, ikIdx = i + nf * k;
+        accD[ijkIdx].finish();
+        if (accD[ijkIdx].num == 0) continue;
+        double D[64], tmp[64], out[64];
+        for (int a = 0; a < 8; a++) for (int c = 0; c < 8; c++) D[a * 8 + c] = (double)accD[ijkIdx].A1m[a][c];
+        const double* AHik = &adHost[(size_t)ikIdx * 64];
+        const double* ATik = &adTarget[(size_t)ikIdx * 64];
+        mul88(AHij, D, tmp, false); mul88(tmp, AHik, out, true);
+        for (int a = 0; a < 8; a++) for (int c = 0; c < 8; c++) H(iIdx + a, iIdx + c) += out[a * 8 + c];
+        mul88(ATij, D, tmp, false); mul88(tmp, ATik, out, true);
+        for (int a = 0; a < 8; a++) for (int c = 0; c < 8; c++) H(jIdx + a, kIdx + c) += out[a * 8 + c];
+        mul88(ATij, D, tmp, false); mul88(tmp, AHik, out, true);
+        for (int a = 0; a < 8; a++) for (int c = 0; c < 8; c++) H(jIdx + a, iIdx + c) += out[a * 8 + c];
+        mul88(AHij, D, tmp, false); mul88(tmp, ATik, out, true);
+        for (int a = 0; a < 8; a++) for (int c = 0; c < 8; c++) H(iIdx + a, kIdx + c) += out[a * 8 + c];
+      }
+    }
+    accHcc.finish(); accbc.finish();
+    for (int a = 0; a < 4; a++) { for (int c = 0; c < 4; c++) H(a, c) += (double)accHcc.A1m[a][c]; b[a] += (double)accbc.A1m[a]; }
+    for (int h = 0; h < nf; h++) {
+      int hIdx = 4 + h * 8;
+      for (int a = 0; a < 8; a++) for (int c = 0; c < 4; c++) H(c, hIdx + a) = H(hIdx + a, c);
+    }
+  }
+
+  // ---------------------------------------------------------------- solve
+  void getNullspaces() {  // FullSystemOptimize.cpp:1087-1147
+    int n = 4 + nf * 8;
+    lastNullspaces_pose.clear(); lastNullspaces_scale.clear();
+    for (int i = 0; i < 6; i++) {
+      VecX ns(n, 0.0);
+      for (int f = 0; f < nf; f++) {
+        for (int r = 0; r < 6; r++) ns[4 + f * 8 + r] = frames[f].nullspaces_pose[r][i];
+        for (int r = 0; r < 3; r++) ns[4 + f * 8 + r] *= SCALE_XI_TRANS_INVERSE;
+        for (int r = 3; r < 6; r++) ns[4 + f * 8 + r] *= SCALE_XI_ROT_INVERSE;
+      }
+      lastNullspaces_pose.push_back(ns);
+    }
+    VecX ns(n, 0.0);
+    for (int f = 0; f < nf; f++) {
+      for (int r = 0; r < 6; r++) ns[4 + f * 8 + r] = frames[f].nullspaces_scale[r];
+      for (int r = 0; r < 3; r++) ns[4 + f * 8 + r] *= SCALE_XI_TRANS_INVERSE;
+      for (int r = 3; r < 6; r++) ns[4 + f * 8 + r] *= SCALE_XI_ROT_INVERSE;
+    }
+    lastNullspaces_scale.push_back(ns);
+  }
+  void orthogonalize(VecX* b, MatX* H) {  // EnergyFunctional.cpp:775-835
+    std::vector<VecX> ns;
+    ns.insert(ns.end(), lastNullspaces_pose.begin(), lastNullspaces_pose.end());
+    ns.insert(ns.end(), lastNullspaces_scale.begin(), lastNullspaces_scale.end());
+    int dim = (int)ns[0].size(), m = (int)ns.size();
+    MatX N(dim, m);
+    for (int i = 0; i < m; i++) {
+      double nrm = 0;
+      for (int k = 0; k < dim; k++) nrm += ns[i][k] * ns[i][k];
+      nrm = std::sqrt(nrm);
+      for (int k = 0; k < dim; k++) N(k, i) = ns[i][k] / nrm;
+    }
+    MatX P;
+    span_projector(N, setting_solverModeDelta, P);  // = 0.5*(NNpiT + NNpiT^T)
+    if (b) {
+      VecX Pb(dim, 0.0);
+      for (int i = 0; i < dim; i++) { double s = 0; for (int k = 0; k < dim; k++) s += P(i, k) * (*b)[k]; Pb[i] = s; }
+      for (int i = 0; i < dim; i++) (*b)[i] -= Pb[i];
+    }
+    if (H) {
+      MatX PH(dim, dim), PHP(dim, dim);
+      for (int i = 0; i < dim; i++) for (int j = 0; j < dim; j++) { double s = 0; for (int k = 0; k < dim; k++) s += P(i, k) * (*H)(k, j); PH(i, j) = s; }
+      for (int i = 0; i < dim; i++) for (int j = 0; j < dim; j++) { double s = 0; for (int k = 0; k < dim; k++) s += PH(i, k) * P(k, j); PHP(i, j) = s; }
+      for (int i = 0; i < dim; i++) for (int j = 0; j < dim; j++) (*H)(i, j) -= PHP(i, j);
+    }
+  }
+  VecX getStitchedDeltaF() const {  // EnergyFunctional.cpp:1021-1032
+    VecX d(4 + nf * 8);
+    for (int i = 0; i < 4; i++) d[i] = (double)cDeltaF[i];
+    for (int h = 0; h < nf; h++) for (int i = 0; i < 8; i++) d[4 + 8 * h + i] = frames[h].delta[i];
+    return d;
+  }
+  // EnergyFunctional.cpp:272-341
+  void resubstituteF(const VecX& x) {
+    int n = 4 + nf * 8;
+    std::vector<float> xF(n);
+    for (int i = 0; i < n; i++) xF[i] = (float)x[i];
+    for (int i = 0; i < 4; i++) HCalib.step[i] = -x[i];
+    std::vector<float> xAd((size_t)nf * nf * 8);
+    for (int h = 0; h < nf; h++) {
+      for (int i = 0; i < 8; i++) frames[h].step[i] = -x[4 + 8 * h + i];
+      frames[h].step[8] = frames[h].step[9] = 0;
+      for (int t = 0; t < nf; t++)
+        for (int j = 0; j < 8; j++) {
+          float sh = 0, st = 0;
+          for (int i = 0; i < 8; i++) {
+            sh += xF[4 + 8 * h + i] * adHostF[(size_t)(h + nf * t) * 64 + i * 8 + j];
+            st += xF[4 + 8 * t + i] * adTargetF[(size_t)(h + nf * t) * 64 + i * 8 + j];
+          }
+          xAd[(size_t)(nf * h + t) * 8 + j] = sh + st;
+        }
+    }
+    const float* xc = xF.data();
+    for (Point& p : points) {
+      int ngoodres = 0;
+      for (int ri = p.rbeg; ri < p.rend; ri++) if (res[ri].isActive) ngoodres++;
+      if (ngoodres == 0) { p.step = 0; continue; }
+      float b = p.bdSumF;
+      float hs[4];
+      for (int i = 0; i < 4; i++) hs[i] = p.Hcd_accAF[i] + p.Hcd_accLF[i];
+      b -= dot4(xc, hs);
+      for (int ri = p.rbeg; ri < p.rend; ri++) {
+        Residual& r = res[ri];
+        if (!r.isActive) continue;
+        const float* xa = &xAd[(size_t)(r.host * nf + r.target) * 8];
+        float s = 0;
+        for (int i = 0; i < 8; i++) s += xa[i] * r.JpJdF[i];
+        b -= s;
+      }
+      p.step = -b * p.HdiF;
+    }
+  }
+  // EnergyFunctional.cpp:838-995
+  void solveSystemF(int iteration, double lambda) {
+    if (solverMode & SOLVER_USE_GN) lambda = 0;
+    if (solverMode & SOLVER_FIX_LAMBDA) lambda = 1e-5;
+    int n = 4 + nf * 8;
+    accumulateAll();
+    MatX HL_top, HA_top, H_sc;
+    VecX bL_top, bA_top, b_sc;
+    stitchTop(accTopA, HA_top, bA_top, false);
+    stitchTop(accTopL, HL_top, bL_top, true);
+    stitchSC(H_sc, b_sc);
+    VecX delta = getStitchedDeltaF();
+    VecX bM_top(n);
+    for (int i = 0; i < n; i++) { double s = 0; for (int k = 0; k < n; k++) s += HM(i, k) * delta[k]; bM_top[i] = bM[i] + s; }
+    MatX HFinal_top(n, n);
+    VecX bFinal_top(n);
+    if (solverMode & SOLVER_ORTHOGONALIZE_SYSTEM) {
+      bool haveFirstFrame = false;
+      for (Frame& f : frames) if (f.frameID == 0) haveFirstFrame = true;
+      MatX HT_act(n, n); VecX bT_act(n);
+      for (int i = 0; i < n; i++) { for (int j = 0; j < n; j++) HT_act(i, j) = HL_top(i, j) + HA_top(i, j) - H_sc(i, j); bT_act[i] = bL_top[i] + bA_top[i] - b_sc[i]; }
+      if (!haveFirstFrame) orthogonalize(&bT_act, &HT_act);
+      for (int i = 0; i < n; i++) { for (int j = 0; j < n; j++) HFinal_top(i, j) = HT_act(i, j) + HM(i, j); bFinal_top[i] = bT_act[i] + bM_top[i]; }
+      lastHS = HFinal_top; lastbS = bFinal_top;
+      for (int i = 0; i < n; i++) HFinal_top(i, i) *= (1 + lambda);
+    } else {
+      for (int i = 0; i < n; i++) {
+        for (int j = 0; j < n; j++) HFinal_top(i, j) = HL_top(i, j) + HM(i, j) + HA_top(i, j);
+        bFinal_top[i] = bL_top[i] + bM_top[i] + bA_top[i] - b_sc[i];
+      }
+      lastHS = MatX(n, n);
+      for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) lastHS(i, j) = HFinal_top(i, j) - H_sc(i, j);
+      lastbS = bFinal_top;
+      for (int i = 0; i < n; i++) HFinal_top(i, i) *= (1 + lambda);
+      double f = (double)(1.0f / (1 + lambda));
+      for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) HFinal_top(i, j) -= H_sc(i, j) * f;
+    }
+    VecX x;
+    {  // LDLT branch (:966-977); the SVD branch (:924-965) is not restated (SOLVER_SVD is off by default)
+      VecX SVecI(n);
+      for (int i = 0; i < n; i++) SVecI[i] = 1.0 / std::sqrt(HFinal_top(i, i) + 10);
+      MatX HFinalScaled(n, n);
+      VecX bs(n);
+      for (int i = 0; i < n; i++) { for (int j = 0; j < n; j++) HFinalScaled(i, j) = SVecI[i] * HFinal_top(i, j) * SVecI[j]; bs[i] = SVecI[i] * bFinal_top[i]; }
+      VecX y;
+      ldlt_solve(HFinalScaled, bs, y);
+      x.resize(n);
+      for (int i = 0; i < n; i++) x[i] = SVecI[i] * y[i];
+    }
+    if ((solverMode & SOLVER_ORTHOGONALIZE_X) || (iteration >= 2 && (solverMode & SOLVER_ORTHOGONALIZE_X_LATER))) orthogonalize(&x, 0);
+    lastX = x;
+    resubstituteF(x);
+  }
+
+  // ---------------------------------------------------------------- energies (EnergyFunctional.cpp:344-442)
+  double calcMEnergyF() {
+    VecX delta = getStitchedDeltaF();
+    int n = (int)delta.size();
+    double e = 0;
+    for (int i = 0; i < n; i++) { double s = 0; for (int k = 0; k < n; k++) s += HM(i, k) * delta[k]; e += delta[i] * (2 * bM[i] + s); }
+    return e;
+  }
+  double calcLEnergyF() {
+    double E = 0;
+    for (Frame& f : frames) for (int i = 0; i < 8; i++) E += f.delta_prior[i] * f.prior[i] * f.delta_prior[i];
+    { float s = 0; for (int i = 0; i < 4; i++) s += cDeltaF[i] * cPriorF[i] * cDeltaF[i]; E += s; }
+    float Ept = 0;  // single Accumulator11 over all points (one thread)
+    for (Point& p : points) {
+      float dd = p.deltaF;
+      for (int ri = p.rbeg; ri < p.rend; ri++) {
+        Residual& r = res[ri];
+        if (!r.isLinearized || !r.isActive) continue;
+        const float* dp = &adHTdeltaF[(size_t)(r.host + nf * r.target) * 8];
+        const RawJ* rJ = &r.Jef;
+        float dx = dot6(rJ->Jpdxi[0], dp) + dot4(rJ->Jpdc[0], cDeltaF) + rJ->Jpdd[0] * dd;
+        float dy = dot6(rJ->Jpdxi[1], dp) + dot4(rJ->Jpdc[1], cDeltaF) + rJ->Jpdd[1] * dd;
+        for (int i = 0; i < 8; i++) {
+          float Jdelta = rJ->JIdx[0][i] * dx;
+          Jdelta = Jdelta + rJ->JIdx[1][i] * dy;
+          Jdelta = Jdelta + rJ->JabF[0][i] * dp[6];
+          Jdelta = Jdelta + rJ->JabF[1][i] * dp[7];
+          float r0 = r.res_toZeroF[i];
+          r0 = r0 + r0;
+          r0 = r0 + Jdelta;
+          Ept += Jdelta * r0;
+        }
+      }
+      Ept += p.deltaF * p.deltaF * p.priorF;
+    }
+    return E + Ept;
+  }
+
+  // ---------------------------------------------------------------- GN driver (FullSystemOptimize.cpp)
+  void backupState() {  // :309-351 (non-momentum branch)
+    for (int i = 0; i < 4; i++) HCalib.value_backup[i] = HCalib.value[i];
+    for (Frame& f : frames) for (int i = 0; i < 10; i++) f.state_backup[i] = f.state[i];
+    for (Point& p : points) p.idepth_backup = p.idepth;
+  }
+  bool doStepFromBackup(float stepfacC, float stepfacT, float stepfacR, float stepfacA, float stepfacD) {  // :207-305
+    double pstepfac[10];
+    for (int i = 0; i < 3; i++) pstepfac[i] = stepfacT;
+    for (int i = 3; i < 6; i++) pstepfac[i] = stepfacR;
+    for (int i = 6; i < 10; i++) pstepfac[i] = stepfacA;
+    float sumA = 0, sumB = 0, sumT = 0, sumR = 0, sumID = 0, numID = 0, sumNID = 0;
+    double nv[4];
+    for (int i = 0; i < 4; i++) nv[i] = HCalib.value_backup[i] + stepfacC * HCalib.step[i];
+    HCalib.setValue(nv);
+    for (int fi = 0; fi < nf; fi++) {
+      Frame& fh = frames[fi];
+      double ns[10];
+      for (int i = 0; i < 10; i++) ns[i] = fh.state_backup[i] + pstepfac[i] * fh.step[i];
+      fh.setState(ns);
+      sumA += fh.step[6] * fh.step[6];
+      sumB += fh.step[7] * fh.step[7];
+      sumT += fh.step[0] * fh.step[0] + fh.step[1] * fh.step[1] + fh.step[2] * fh.step[2];
+      sumR += fh.step[3] * fh.step[3] + fh.step[4] * fh.step[4] + fh.step[5] * fh.step[5];
+      for (Point& ph : points) {
+        if (ph.host != fi) continue;
+        ph.setIdepth(ph.idepth_backup + stepfacD * ph.step);
+        sumID += ph.step * ph.step;
+        sumNID += fabsf(ph.idepth_backup);
+        numID++;
+        ph.setIdepthZero(ph.idepth_backup + stepfacD * ph.step);
+      }
+    }
+    sumA /= nf; sumB /= nf; sumR /= nf; sumT /= nf;
+    sumID /= numID; sumNID /= numID;
+    setPrecalcValues();
+    return sqrtf(sumA) < 0.0005 * setting_thOptIterations && sqrtf(sumB) < 0.00005 * setting_thOptIterations &&
+           sqrtf(sumR) < 0.00005 * setting_thOptIterations && sqrtf(sumT) * sumNID < 0.00005 * setting_thOptIterations;
+  }
+  void loadStateBackup() {  // :355-370
+    HCalib.setValue(HCalib.value_backup);
+    for (Frame& f : frames) f.setState(f.state_backup);
+    for (Point& p : points) { p.setIdepth(p.idepth_backup); p.setIdepthZero(p.idepth_backup); }
+    setPrecalcValues();
+  }
+  double calcLEnergy() { return forceAcceptStep ? 0 : calcLEnergyF(); }
+  double calcMEnergy() { return forceAcceptStep ? 0 : calcMEnergyF(); }
+  void applyAll() { for (Residual& r : res) if (!r.isLinearized) applyRes(r); }
+
+  float optimize(int mnumOptIts, orc_ba_opt_result_t* out) {  // :871-1041
+    out->iterations = 0; out->lastEnergy = 0; out->rmse = 0; out->resInA = 0;
+    if (nf < 2) return 0;
+    if (nf < 3) mnumOptIts = 20;
+    if (nf < 4) mnumOptIts = 15;
+    for (Residual& r : res) if (!r.isLinearized) r.resetOOB();
+    double lastEnergy = linearizeAll(false);
+    double lastEnergyL = calcLEnergy();
+    double lastEnergyM = calcMEnergy();
+    applyAll();
+    double lambda = 1e-1;
+    float stepsize = 1;
+    for (int iteration = 0; iteration < mnumOptIts; iteration++) {
+      out->iterations++;
+      backupState();
+      getNullspaces();
+      solveSystemF(iteration, lambda);
+      bool canbreak = doStepFromBackup(stepsize, stepsize, stepsize, stepsize, stepsize);
+      double newEnergy = linearizeAll(false);
+      double newEnergyL = calcLEnergy();
+      double newEnergyM = calcMEnergy();
+      if (forceAcceptStep || (newEnergy + newEnergyL + newEnergyM < lastEnergy + lastEnergyL + lastEnergyM)) {
+        applyAll();
+        lastEnergy = newEnergy; lastEnergyL = newEnergyL; lastEnergyM = newEnergyM;
+        lambda *= 0.25;
+      } else {
+        loadStateBackup();
+        lastEnergy = linearizeAll(false);
+        lastEnergyL = calcLEnergy();
+        lastEnergyM = calcMEnergy();
+        lambda *= 1e2;
+      }
+      if (canbreak && iteration >= setting_minOptIterations) break;
+    }
+    double newStateZero[10] = {0};
+    newStateZero[6] = frames[nf - 1].state[6];
+    newStateZero[7] = frames[nf - 1].state[7];
+    frames[nf - 1].setEvalPT(frames[nf - 1].PRE_worldToCam, newStateZero);
+    setAdjointsF();
+    setPrecalcValues();
+    lastEnergy = linearizeAll(true);
+    out->lastEnergy = lastEnergy;
+    out->resInA = nresA;
+    out->rmse = sqrtf((float)(lastEnergy / (patternNum * nresA)));
+    return (float)out->rmse;
+  }
+
+  // ---------------------------------------------------------------- marginalisation of points
+  // FullSystem.cpp:1004-1021 (per flagged point) then EnergyFunctional.cpp:663-736.
+  void marginalizePoints(const uint8_t* marg_flag) {
+    for (int pi = 0; pi < np; pi++) {
+      if (!marg_flag[pi]) continue;
+      Point& p = points[pi];
+      for (int ri = p.rbeg; ri < p.rend; ri++) {
+        Residual& r = res[ri];
+        r.resetOOB();
+        linearize(r);
+        r.isLinearized = false;
+        applyRes(r);
+        if (r.isActive) fixLinearizationF(r);
+      }
+    }
+    zeroSC(); zeroTop(accTopA); nresA = 0;
+    for (int pi = 0; pi < np; pi++) {
+      if (!marg_flag[pi]) continue;
+      Point& p = points[pi];
+      p.priorF *= setting_idepthFixPriorMargFac;
+      addPointTop<2>(p, accTopA, nresA);
+      addPointSC(p, false);
+    }
+    // stitchDouble (single-thread variants, AccumulatedTopHessian.cpp:201-262 / AccumulatedSCHessian.cpp:198-256):
+    // identical block arithmetic to stitchTop/stitchSC above with usePrior=false; the SC variant
+    // assigns (not adds) Hcc/bc, which is the same on a zeroed matrix.
+    MatX M, Msc; VecX Mb, Mbsc;
+    stitchTop(accTopA, M, Mb, false);
+    stitchSC(Msc, Mbsc);
+    resInM += nresA;
+    int n = 4 + nf * 8;
+    for (int i = 0; i < n; i++) {
+      for (int j = 0; j < n; j++) HM(i, j) += setting_margWeightFac * (M(i, j) - Msc(i, j));
+      bM[i] += setting_margWeightFac * (Mb[i] - Mbsc[i]);
+    }
+  }
+};
+
+// =================================================================== C API
+extern "C" orc_ba* orc_ba_create(const orc_ba_window_t* W) {
+  orc_ba* h = new orc_ba();
+  h->nf = W->nf; h->np = W->np; h->nr = W->nr; h->w = W->w; h->h = W->h;
+  h->wM3G = W->w - 3; h->hM3G = W->h - 3;
+  h->solverMode = W->solverMode;
+  h->affineOptModeA = W->affineOptModeA; h->affineOptModeB = W->affineOptModeB;
+  h->forceAcceptStep = W->forceAcceptStep != 0;
+  for (int i = 0; i < 4; i++) h->HCalib.value_zero[i] = W->calib_value_zero[i];
+  h->HCalib.setValueScaled(W->calib_value_scaled);
+  for (int i = 0; i < 4; i++) h->HCalib.step[i] = 0;
+  h->frames.resize(h->nf);
+  for (int f = 0; f < h->nf; f++) {
+    Frame& F = h->frames[f];
+    std::memcpy(F.worldToCam_evalPT.R, W->evalPT + f * 12, 9 * sizeof(double));
+    std::memcpy(F.worldToCam_evalPT.t, W->evalPT + f * 12 + 9, 3 * sizeof(double));
+    F.ab_exposure = W->ab_exposure[f];
+    F.frameEnergyTH = W->frameEnergyTH[f];
+    F.frameID = W->frameID[f];
+    F.dI = W->dI ? W->dI[f] : nullptr;
+    F.setState(W->state + f * 10);
+    F.setStateZero(W->state_zero + f * 10);
+    for (int i = 0; i < 10; i++) F.step[i] = 0;
+    double p10[10];
+    F.getPrior(p10, h->affineOptModeA, h->affineOptModeB, h->solverMode);
+    for (int i = 0; i < 8; i++) F.prior[i] = p10[i];
+  }
+  h->points.resize(h->np);
+  for (int i = 0; i < h->np; i++) {
+    Point& p = h->points[i];
+    p.u = W->u[i]; p.v = W->v[i];
+    p.setIdepth(W->idepth[i]); p.setIdepthZero(W->idepth_zero[i]);
+    for (int k = 0; k < 8; k++) { p.color[k] = W->color[i * 8 + k]; p.weights[k] = W->weights[i * 8 + k]; }
+    p.host = W->host[i];
+    p.hasDepthPrior = W->hasDepthPrior[i] != 0;
+    p.step = 0; p.idepth_backup = p.idepth; p.idepth_hessian = 0;
+    p.rbeg = p.rend = 0;
+    p.priorF = p.hasDepthPrior ? setting_idepthFixPrior * SCALE_IDEPTH * SCALE_IDEPTH : 0;  // EFPoint::takeData
+    if (h->solverMode & SOLVER_REMOVE_POSEPRIOR) p.priorF = 0;
+    p.deltaF = p.idepth - p.idepth_zero;
+    p.bdSumF = p.HdiF = 0;
+    p.Hdd_accLF = p.bd_accLF = p.Hdd_accAF = p.bd_accAF = 0;
+    for (int k = 0; k < 4; k++) p.Hcd_accLF[k] = p.Hcd_accAF[k] = 0;
+  }
+  h->res.resize(h->nr);
+  int prev = -1;
+  for (int i = 0; i < h->nr; i++) {
+    Residual& r = h->res[i];
+    std::memset(&r, 0, sizeof(r));
+    r.point = W->res_point[i];
+    r.host = h->points[r.point].host;
+    r.target = W->res_target[i];
+    r.state_state = (ResState)W->res_state[i];
+    r.state_NewState = RS_OUTLIER;
+    r.state_NewEnergyWithOutlier = -1;
+    r.isLinearized = false; r.isActive = false;
+    if (r.point != prev) { h->points[r.point].rbeg = i; prev = r.point; }
+    h->points[r.point].rend = i + 1;
+  }
+  int n = 4 + 8 * h->nf;
+  h->HM = MatX(n, n); h->bM.assign(n, 0.0);
+  if (W->HM) for (int i = 0; i < n * n; i++) h->HM.d[i] = W->HM[i];
+  if (W->bM) for (int i = 0; i < n; i++) h->bM[i] = W->bM[i];
+  h->precalc.resize((size_t)h->nf * h->nf);
+  h->setAdjointsF();
+  h->setPrecalcValues();
+  h->nresA = h->nresL = h->resInM = 0;
+  h->zeroTop(h->accTopA); h->zeroTop(h->accTopL); h->zeroSC();
+  h->getNullspaces();
+  return h;
+}
+extern "C" void orc_ba_destroy(orc_ba* h) { delete h; }
+extern "C" int orc_ba_linearize(orc_ba* h, double* energy) { double e = h->linearizeAll(false); if (energy) *energy = e; return 0; }
+extern "C" int orc_ba_get_linearization(orc_ba* h, float* J, uint8_t* newState, float* newEnergy, float* newEnergyWithOutlier,
+                                        float* projectedTo, float* centerProjectedTo) {
+  for (int i = 0; i < h->nr; i++) {
+    const Residual& r = h->res[i];
+    if (J) std::memcpy(J + (size_t)i * 74, &r.Jnew, sizeof(RawJ));
+    if (newState) newState[i] = (uint8_t)r.state_NewState;
+    if (newEnergy) newEnergy[i] = (float)r.state_NewEnergy;
+    if (newEnergyWithOutlier) newEnergyWithOutlier[i] = (float)r.state_NewEnergyWithOutlier;
+    if (projectedTo) std::memcpy(projectedTo + (size_t)i * 16, r.projectedTo, 16 * sizeof(float));
+    if (centerProjectedTo) std::memcpy(centerProjectedTo + (size_t)i * 3, r.centerProjectedTo, 3 * sizeof(float));
+  }
+  return 0;
+}
+extern "C" int orc_ba_apply_res(orc_ba* h) { h->applyAll(); return 0; }
+extern "C" int orc_ba_get_residual_state(orc_ba* h, uint8_t* state, uint8_t* isActive, float* JpJdF) {
+  for (int i = 0; i < h->nr; i++) {
+    if (state) state[i] = (uint8_t)h->res[i].state_state;
+    if (isActive) isActive[i] = h->res[i].isActive ? 1 : 0;
+    if (JpJdF) std::memcpy(JpJdF + (size_t)i * 8, h->res[i].JpJdF, 8 * sizeof(float));
+  }
+  return 0;
+}
+extern "C" int orc_ba_accumulate(orc_ba* h) { h->accumulateAll(); return 0; }
+extern "C" int orc_ba_accum_floats(int nf) { return nf * nf * 91 * 2 + nf * nf * nf * 64 + nf * nf * 32 + nf * nf * 8 + 16 + 4 + 2; }
+
+static void packTop(AccumulatorApprox& a, float* out) {
+  a.finish();
+  int k = 0;
+  for (int r = 0; r < 10; r++) for (int c = r; c < 10; c++) out[k++] = a.H[r][c];
+  for (int r = 0; r < 10; r++) for (int c = 0; c < 3; c++) out[k++] = a.H[r][10 + c];
+  out[k++] = a.H[10][10]; out[k++] = a.H[10][11]; out[k++] = a.H[10][12];
+  out[k++] = a.H[11][11]; out[k++] = a.H[11][12]; out[k++] = a.H[12][12];
+}
+extern "C" int orc_ba_get_accumulators(orc_ba* h, float* packed) {
+  int nf = h->nf;
+  float* p = packed;
+  for (int i = 0; i < nf * nf; i++, p += 91) packTop(h->accTopA[i], p);
+  for (int i = 0; i < nf * nf; i++, p += 91) packTop(h->accTopL[i], p);
+  for (int i = 0; i < nf * nf * nf; i++) { h->accD[i].finish(); for (int a = 0; a < 8; a++) for (int c = 0; c < 8; c++) *p++ = h->accD[i].A1m[a][c]; }
+  for (int i = 0; i < nf * nf; i++) { h->accE[i].finish(); for (int a = 0; a < 8; a++) for (int c = 0; c < 4; c++) *p++ = h->accE[i].A1m[a][c]; }
+  for (int i = 0; i < nf * nf; i++) { h->accEB[i].finish(); for (int a = 0; a < 8; a++) *p++ = h->accEB[i].A1m[a]; }
+  h->accHcc.finish(); h->accbc.finish();
+  for (int a = 0; a < 4; a++) for (int c = 0; c < 4; c++) *p++ = h->accHcc.A1m[a][c];
+  for (int a = 0; a < 4; a++) *p++ = h->accbc.A1m[a];
+  *p++ = (float)h->nresA; *p++ = (float)h->nresL;
+  return 0;
+}
+extern "C" int orc_ba_get_point_terms(orc_ba* h, float* HdiF, float* bdSumF, float* Hdd_accAF, float* bd_accAF, float* Hcd_accAF) {
+  for (int i = 0; i < h->np; i++) {
+    const Point& p = h->points[i];
+    if (HdiF) HdiF[i] = p.HdiF;
+    if (bdSumF) bdSumF[i] = p.bdSumF;
+    if (Hdd_accAF) Hdd_accAF[i] = p.Hdd_accAF;
+    if (bd_accAF) bd_accAF[i] = p.bd_accAF;
+    if (Hcd_accAF) for (int k = 0; k < 4; k++) Hcd_accAF[i * 4 + k] = p.Hcd_accAF[k];
+  }
+  return 0;
+}
+extern "C" int orc_ba_solve(orc_ba* h, int iteration, double lambda, double* x, double* HS, double* bS, double* frame_step, double* calib_step) {
+  h->getNullspaces();
+  h->solveSystemF(iteration, lambda);
+  int n = 4 + 8 * h->nf;
+  if (x) for (int i = 0; i < n; i++) x[i] = h->lastX[i];
+  if (HS) for (int i = 0; i < n * n; i++) HS[i] = h->lastHS.d[i];
+  if (bS) for (int i = 0; i < n; i++) bS[i] = h->lastbS[i];
+  if (frame_step) for (int f = 0; f < h->nf; f++) for (int i = 0; i < 8; i++) frame_step[f * 8 + i] = h->frames[f].step[i];
+  if (calib_step) for (int i = 0; i < 4; i++) calib_step[i] = h->HCalib.step[i];
+  return 0;
+}
+extern "C" int orc_ba_get_point_steps(orc_ba* h, float* step) { for (int i = 0; i < h->np; i++) step[i] = h->points[i].step; return 0; }
+extern "C" int orc_ba_optimize(orc_ba* h, int mnumOptIts, double* state_out, float* idepth_out, uint8_t* res_state_out, orc_ba_opt_result_t* out) {
+  orc_ba_opt_result_t tmp;
+  h->optimize(mnumOptIts, out ? out : &tmp);
+  if (state_out) for (int f = 0; f < h->nf; f++) for (int i = 0; i < 10; i++) state_out[f * 10 + i] = h->frames[f].state[i];
+  if (idepth_out) for (int i = 0; i < h->np; i++) idepth_out[i] = h->points[i].idepth;
+  if (res_state_out) for (int i = 0; i < h->nr; i++) res_state_out[i] = (uint8_t)h->res[i].state_state;
+  return 0;
+}
+extern "C" int orc_ba_marginalize_points(orc_ba* h, const uint8_t* marg_flag, double* HM_out, double* bM_out) {
+  h->marginalizePoints(marg_flag);
+  int n = 4 + 8 * h->nf;
+  if (HM_out) for (int i = 0; i < n * n; i++) HM_out[i] = h->HM.d[i];
+  if (bM_out) for (int i = 0; i < n; i++) bM_out[i] = h->bM[i];
+  return 0;
+}
+extern "C" int orc_ba_get_tables(orc_ba* h, float* precalc, double* adHost, double* adTarget, float* adHTdeltaF) {
+  int nf = h->nf;
+  if (precalc)
+    for (int i = 0; i < nf * nf; i++) {
+      const Precalc& P = h->precalc[i];
+      float* o = precalc + (size_t)i * 27;
+      std::memcpy(o, P.PRE_KRKiTll, 36); std::memcpy(o + 9, P.PRE_KtTll, 12); std::memcpy(o + 12, P.PRE_RTll_0, 36);
+      std::memcpy(o + 21, P.PRE_tTll_0, 12); o[24] = P.PRE_aff_mode[0]; o[25] = P.PRE_aff_mode[1]; o[26] = P.PRE_b0_mode;
+    }
+  if (adHost) std::memcpy(adHost, h->adHost.data(), h->adHost.size() * 8);
+  if (adTarget) std::memcpy(adTarget, h->adTarget.data(), h->adTarget.size() * 8);
+  if (adHTdeltaF) std::memcpy(adHTdeltaF, h->adHTdeltaF.data(), h->adHTdeltaF.size() * 4);
+  return 0;
+}

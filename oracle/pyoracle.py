@@ -1,0 +1,75 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.
+
+ctypes loader for oracle/liboracle.so (strict-IEEE CPU restatement, the parity checker) and
+oracle/liboracle_fast.so (same sources, -O3 -march=native: bench.py's cpu_baseline "port").
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(os.path.dirname(_HERE), "stereo-dso-g2o_amd"))
+from sdso_amd.abi import (TrackEval, SE3, Aff, TrackParams, TrackResult, BAWindow, BAOptResult, TracePoints,  # noqa: E402
+                          c_float_p, c_double_p, c_int_p, c_u8_p)
+
+_libs = {}
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def load(fast=False):
+    name = "liboracle_fast.so" if fast else "liboracle.so"
+    if name in _libs:
+        return _libs[name]
+    path = os.path.join(_HERE, name)
+    if not os.path.exists(path):
+        build()
+    L = C.CDLL(path)
+    vp = C.c_void_p
+    L.orc_se3_exp.argtypes = [c_double_p, C.POINTER(SE3)]
+    L.orc_se3_exp.restype = None
+    L.orc_se3_log.argtypes = [C.POINTER(SE3), c_double_p]
+    L.orc_se3_log.restype = None
+    L.orc_se3_adj.argtypes = [C.POINTER(SE3), c_double_p]
+    L.orc_se3_adj.restype = None
+    L.orc_se3_mul.argtypes = [C.POINTER(SE3), C.POINTER(SE3), C.POINTER(SE3)]
+    L.orc_se3_mul.restype = None
+    L.orc_se3_inv.argtypes = [C.POINTER(SE3), C.POINTER(SE3)]
+    L.orc_se3_inv.restype = None
+    L.orc_mat3f_inv.argtypes = [c_float_p, c_float_p]
+    L.orc_mat3f_inv.restype = None
+    L.orc_ldlt_solve.argtypes = [C.c_int, c_double_p, c_double_p, c_double_p]
+    L.orc_pyramid_levels.argtypes = [C.c_int, C.c_int]
+    L.orc_make_images.argtypes = [c_float_p, C.c_int, C.c_int, C.c_int, C.POINTER(c_float_p)]
+    L.orc_make_images.restype = None
+    L.orc_track_calc_res_gs.argtypes = [C.c_int, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, C.POINTER(TrackEval),
+                                        c_double_p, c_double_p, c_double_p, c_int_p, c_u8_p, c_float_p, C.c_int]
+    L.orc_track_make_eval.argtypes = [C.POINTER(TrackParams), C.c_int, C.POINTER(SE3), C.POINTER(Aff), C.c_float, C.POINTER(TrackEval)]
+    L.orc_track_make_eval.restype = None
+    L.orc_track_newest_coarse.argtypes = [c_int_p, C.POINTER(c_float_p), C.POINTER(c_float_p), C.POINTER(c_float_p), C.POINTER(c_float_p),
+                                          C.POINTER(c_float_p), C.POINTER(TrackParams), C.POINTER(SE3), C.POINTER(Aff), C.POINTER(TrackResult)]
+    L.orc_ba_create.argtypes = [C.POINTER(BAWindow)]
+    L.orc_ba_create.restype = vp
+    L.orc_ba_destroy.argtypes = [vp]
+    L.orc_ba_destroy.restype = None
+    L.orc_ba_linearize.argtypes = [vp, c_double_p]
+    L.orc_ba_get_linearization.argtypes = [vp, c_float_p, c_u8_p, c_float_p, c_float_p, c_float_p, c_float_p]
+    L.orc_ba_apply_res.argtypes = [vp]
+    L.orc_ba_get_residual_state.argtypes = [vp, c_u8_p, c_u8_p, c_float_p]
+    L.orc_ba_accumulate.argtypes = [vp]
+    L.orc_ba_accum_floats.argtypes = [C.c_int]
+    L.orc_ba_get_accumulators.argtypes = [vp, c_float_p]
+    L.orc_ba_get_point_terms.argtypes = [vp, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p]
+    L.orc_ba_solve.argtypes = [vp, C.c_int, C.c_double, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]
+    L.orc_ba_get_point_steps.argtypes = [vp, c_float_p]
+    L.orc_ba_optimize.argtypes = [vp, C.c_int, c_double_p, c_float_p, c_u8_p, C.POINTER(BAOptResult)]
+    L.orc_ba_marginalize_points.argtypes = [vp, c_u8_p, c_double_p, c_double_p]
+    L.orc_ba_get_tables.argtypes = [vp, c_float_p, c_double_p, c_double_p, c_float_p]
+    L.orc_immature_init_batch.argtypes = [c_float_p, C.c_int, C.c_int, C.c_int, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p]
+    L.orc_trace_stereo_batch.argtypes = [c_float_p, C.c_int, C.c_int, c_float_p, C.c_float, C.c_int, C.POINTER(TracePoints), c_u8_p]
+    _libs[name] = L
+    return L

@@ -1,0 +1,233 @@
+// Context, device pyramids (FrameHessian::dIp mirrors) and FrameHessian::makeImages on the device.
+#include "sdso_internal.h"
+#include <cmath>
+#include <cstring>
+
+using namespace sdso;
+
+namespace sdso {
+int ensure_scratch(sdso_ctx* ctx, size_t bytes) {
+  if (ctx->scratch_bytes >= bytes) return SDSO_OK;
+  if (ctx->scratch) { SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream)); SDSO_HIP(ctx, hipFree(ctx->scratch)); ctx->scratch = nullptr; ctx->scratch_bytes = 0; }
+  size_t want = bytes + bytes / 2 + 4096;
+  SDSO_HIP(ctx, hipMalloc(&ctx->scratch, want));
+  ctx->scratch_bytes = want;
+  return SDSO_OK;
+}
+int ensure_pinned(sdso_ctx* ctx, size_t bytes) {
+  if (ctx->pinned_bytes >= bytes) return SDSO_OK;
+  if (ctx->pinned) { SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream)); SDSO_HIP(ctx, hipHostFree(ctx->pinned)); ctx->pinned = nullptr; ctx->pinned_bytes = 0; }
+  size_t want = bytes + bytes / 2 + 4096;
+  SDSO_HIP(ctx, hipHostMalloc(&ctx->pinned, want, hipHostMallocDefault));
+  ctx->pinned_bytes = want;
+  return SDSO_OK;
+}
+}  // namespace sdso
+
+// ------------------------------------------------------------------ kernels
+// AoS float3 {I,dx,dy} -> float4 {I,dx,dy,0}
+__global__ void k_expand3to4(const float* __restrict__ src, float4* __restrict__ dst, int npix) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < npix) dst[i] = make_float4(src[3 * i], src[3 * i + 1], src[3 * i + 2], 0.f);
+}
+__global__ void k_pack4to3(const float4* __restrict__ src, float* __restrict__ dst, int npix) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < npix) { float4 p = src[i]; dst[3 * i] = p.x; dst[3 * i + 1] = p.y; dst[3 * i + 2] = p.z; }
+}
+// HessianBlocks.cpp:156-157 — level-0 intensities
+__global__ void k_set_level0(const float* __restrict__ color, float4* __restrict__ dst, int npix) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < npix) dst[i] = make_float4(color[i], 0.f, 0.f, 0.f);
+}
+// HessianBlocks.cpp:172-178 — 2x2 box mean of the level below
+__global__ void k_downsample(const float4* __restrict__ src, int wsrc, float4* __restrict__ dst, int wl, int hl) {
+  int x = blockIdx.x * blockDim.x + threadIdx.x;
+  int y = blockIdx.y;
+  if (x >= wl || y >= hl) return;
+  const float4* r0 = src + 2 * x + 2 * y * wsrc;
+  float v = 0.25f * (((r0[0].x + r0[1].x) + r0[wsrc].x) + r0[wsrc + 1].x);
+  dst[x + y * wl] = make_float4(v, 0.f, 0.f, 0.f);
+}
+// HessianBlocks.cpp:182-192 — central differences on rows 1..h-2 (linear index wl .. wl*(hl-1)-1)
+__global__ void k_gradients(float4* __restrict__ img, int wl, int hl) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x + wl;
+  if (idx >= wl * (hl - 1)) return;
+  float dx = 0.5f * (img[idx + 1].x - img[idx - 1].x);
+  float dy = 0.5f * (img[idx + wl].x - img[idx - wl].x);
+  if (!isfinite(dx)) dx = 0;
+  if (!isfinite(dy)) dy = 0;
+  img[idx].y = dx;
+  img[idx].z = dy;
+}
+
+// ------------------------------------------------------------------ API
+extern "C" int sdso_ctx_create(int device_ordinal, sdso_ctx** out) {
+  if (!out) return SDSO_ERR_ARG;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return SDSO_ERR_NODEV;
+  if (device_ordinal < 0 || device_ordinal >= ndev) return SDSO_ERR_NODEV;
+  if (hipSetDevice(device_ordinal) != hipSuccess) return SDSO_ERR_NODEV;
+  sdso_ctx* ctx = new sdso_ctx();
+  ctx->device = device_ordinal;
+  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return SDSO_ERR_HIP; }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess) ctx->n_cu = prop.multiProcessorCount;
+  *out = ctx;
+  return SDSO_OK;
+}
+
+namespace sdso {
+void release_all_windows(sdso_ctx* ctx);
+void release_track_batch(sdso_ctx* ctx);
+}
+
+extern "C" void sdso_ctx_destroy(sdso_ctx* ctx) {
+  if (!ctx) return;
+  hipSetDevice(ctx->device);
+  hipStreamSynchronize(ctx->stream);
+  for (auto& kv : ctx->pyr)
+    for (int l = 0; l < kv.second.levels; l++) hipFree(kv.second.d[l]);
+  for (auto& kv : ctx->refs)
+    for (int l = 0; l < SDSO_PYR_LEVELS; l++) if (kv.second.pc[l]) hipFree(kv.second.pc[l]);
+  release_all_windows(ctx);
+  release_track_batch(ctx);
+  if (ctx->scratch) hipFree(ctx->scratch);
+  if (ctx->pinned) hipHostFree(ctx->pinned);
+  hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+extern "C" const char* sdso_last_error(const sdso_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+extern "C" void* sdso_ctx_stream(sdso_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+extern "C" int sdso_ctx_sync(sdso_ctx* ctx) {
+  if (!ctx) return SDSO_ERR_STATE;
+  SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SDSO_OK;
+}
+
+extern "C" int sdso_prof_enable(sdso_ctx* ctx, int on) {
+  if (!ctx) return SDSO_ERR_STATE;
+  ctx->prof_on = on != 0;
+  return SDSO_OK;
+}
+extern "C" int sdso_prof_reset(sdso_ctx* ctx) {
+  if (!ctx) return SDSO_ERR_STATE;
+  SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (auto& kv : ctx->prof) {
+    for (auto& e : kv.second.ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+  }
+  ctx->prof.clear();
+  return SDSO_OK;
+}
+extern "C" int sdso_prof_read(sdso_ctx* ctx, const char* kernel, double* total_ms, long* launches) {
+  if (!ctx || !kernel) return SDSO_ERR_STATE;
+  SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  auto it = ctx->prof.find(kernel);
+  if (it == ctx->prof.end()) { if (total_ms) *total_ms = 0; if (launches) *launches = 0; return SDSO_OK; }
+  for (auto& e : it->second.ev) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) { it->second.total_ms += ms; it->second.launches++; }
+    hipEventDestroy(e.first); hipEventDestroy(e.second);
+  }
+  it->second.ev.clear();
+  if (total_ms) *total_ms = it->second.total_ms;
+  if (launches) *launches = it->second.launches;
+  return SDSO_OK;
+}
+
+extern "C" int sdso_pyramid_levels(int w, int h) {  // globalCalib.cpp:52-58
+  int wl = w, hl = h, n = 1;
+  while (wl % 2 == 0 && hl % 2 == 0 && wl * hl > 5000 && n < SDSO_PYR_LEVELS) { wl /= 2; hl /= 2; n++; }
+  return n;
+}
+
+extern "C" int sdso_release_pyramid(sdso_ctx* ctx, int frame_slot) {
+  if (!ctx) return SDSO_ERR_STATE;
+  auto it = ctx->pyr.find(frame_slot);
+  if (it == ctx->pyr.end()) return SDSO_OK;
+  SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (int l = 0; l < it->second.levels; l++) hipFree(it->second.d[l]);
+  ctx->pyr.erase(it);
+  return SDSO_OK;
+}
+
+static int alloc_pyramid(sdso_ctx* ctx, int frame_slot, int levels, const int* w, const int* h) {
+  SDSO_REQUIRE(ctx, levels >= 1 && levels <= SDSO_PYR_LEVELS, "levels out of range");
+  auto it = ctx->pyr.find(frame_slot);
+  if (it != ctx->pyr.end()) {
+    bool same = it->second.levels == levels;
+    for (int l = 0; same && l < levels; l++) same = it->second.w[l] == w[l] && it->second.h[l] == h[l];
+    if (same) return SDSO_OK;
+    int rc = sdso_release_pyramid(ctx, frame_slot);
+    if (rc) return rc;
+  }
+  PyramidDev P;
+  P.levels = levels;
+  for (int l = 0; l < levels; l++) {
+    SDSO_REQUIRE(ctx, w[l] >= 8 && h[l] >= 8, "pyramid level too small");
+    P.w[l] = w[l]; P.h[l] = h[l];
+    SDSO_HIP(ctx, hipMalloc(&P.d[l], sizeof(float4) * (size_t)w[l] * h[l]));
+  }
+  ctx->pyr[frame_slot] = P;
+  return SDSO_OK;
+}
+
+extern "C" int sdso_upload_pyramid(sdso_ctx* ctx, int frame_slot, int levels, const int* w, const int* h, const float* const* dIp) {
+  if (!ctx) return SDSO_ERR_STATE;
+  SDSO_HIP(ctx, hipSetDevice(ctx->device));
+  SDSO_REQUIRE(ctx, w && h && dIp, "null argument");
+  int rc = alloc_pyramid(ctx, frame_slot, levels, w, h);
+  if (rc) return rc;
+  PyramidDev& P = ctx->pyr[frame_slot];
+  size_t maxb = 0;
+  for (int l = 0; l < levels; l++) maxb = std::max(maxb, (size_t)w[l] * h[l] * 3 * sizeof(float));
+  rc = ensure_scratch(ctx, maxb);
+  if (rc) return rc;
+  for (int l = 0; l < levels; l++) {
+    int npix = w[l] * h[l];
+    SDSO_HIP(ctx, hipMemcpyAsync(ctx->scratch, dIp[l], (size_t)npix * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_expand3to4, dim3((npix + 255) / 256), dim3(256), 0, ctx->stream, (const float*)ctx->scratch, P.d[l], npix);
+    SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));  // scratch is reused by the next level / caller buffer may go away
+  }
+  SDSO_HIP(ctx, hipGetLastError());
+  return SDSO_OK;
+}
+
+extern "C" int sdso_make_pyramid(sdso_ctx* ctx, int frame_slot, int w, int h, const float* color) {
+  if (!ctx) return SDSO_ERR_STATE;
+  SDSO_HIP(ctx, hipSetDevice(ctx->device));
+  SDSO_REQUIRE(ctx, color, "null argument");
+  int levels = sdso_pyramid_levels(w, h);
+  int ws[SDSO_PYR_LEVELS], hs[SDSO_PYR_LEVELS];
+  for (int l = 0; l < levels; l++) { ws[l] = w >> l; hs[l] = h >> l; }
+  int rc = alloc_pyramid(ctx, frame_slot, levels, ws, hs);
+  if (rc) return rc;
+  PyramidDev& P = ctx->pyr[frame_slot];
+  rc = ensure_scratch(ctx, (size_t)w * h * sizeof(float));
+  if (rc) return rc;
+  SDSO_HIP(ctx, hipMemcpyAsync(ctx->scratch, color, (size_t)w * h * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_set_level0, dim3((w * h + 255) / 256), dim3(256), 0, ctx->stream, (const float*)ctx->scratch, P.d[0], w * h);
+  for (int l = 0; l < levels; l++) {
+    if (l > 0) hipLaunchKernelGGL(k_downsample, dim3((ws[l] + 255) / 256, hs[l]), dim3(256), 0, ctx->stream, P.d[l - 1], ws[l - 1], P.d[l], ws[l], hs[l]);
+    int ng = ws[l] * (hs[l] - 2);
+    hipLaunchKernelGGL(k_gradients, dim3((ng + 255) / 256), dim3(256), 0, ctx->stream, P.d[l], ws[l], hs[l]);
+  }
+  SDSO_HIP(ctx, hipGetLastError());
+  SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SDSO_OK;
+}
+
+extern "C" int sdso_download_pyramid_level(sdso_ctx* ctx, int frame_slot, int lvl, float* dI_out) {
+  if (!ctx) return SDSO_ERR_STATE;
+  SDSO_HIP(ctx, hipSetDevice(ctx->device));
+  auto it = ctx->pyr.find(frame_slot);
+  SDSO_REQUIRE(ctx, it != ctx->pyr.end(), "unknown frame slot");
+  SDSO_REQUIRE(ctx, lvl >= 0 && lvl < it->second.levels && dI_out, "bad level");
+  int npix = it->second.w[lvl] * it->second.h[lvl];
+  int rc = ensure_scratch(ctx, (size_t)npix * 3 * sizeof(float));
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_pack4to3, dim3((npix + 255) / 256), dim3(256), 0, ctx->stream, it->second.d[lvl], (float*)ctx->scratch, npix);
+  SDSO_HIP(ctx, hipMemcpyAsync(dI_out, ctx->scratch, (size_t)npix * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SDSO_OK;
+}

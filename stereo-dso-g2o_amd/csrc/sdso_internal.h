@@ -1,0 +1,145 @@
+// Internal definitions of libsdso_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <string>
+#include <vector>
+#include "../../include/sdso_abi.h"
+
+namespace sdso {
+
+// ---- constants of the reference (values @ file:line in SURVEY.md Appendix A)
+#define SCALE_IDEPTH 1.0f
+#define SCALE_XI_ROT 1.0f
+#define SCALE_XI_TRANS 0.5f
+#define SCALE_F 50.0f
+#define SCALE_C 50.0f
+#define SCALE_A 10.0f
+#define SCALE_B 1000.0f
+constexpr float kHuberTH = 9.0f;                 // settings.cpp:95
+constexpr float kOutlierTHSumComponent = 2500.f; // settings.cpp:73
+
+// A pyramid level on the device: one float4 {I, dx, dy, 0} per pixel (16-byte taps).
+struct PyramidDev {
+  int levels = 0;
+  int w[SDSO_PYR_LEVELS] = {0}, h[SDSO_PYR_LEVELS] = {0};
+  float4* d[SDSO_PYR_LEVELS] = {nullptr};
+};
+// pc_* of one reference keyframe: one float4 {u, v, idepth, color} per template point.
+struct RefDev {
+  int n[SDSO_PYR_LEVELS] = {0};
+  float4* pc[SDSO_PYR_LEVELS] = {nullptr};
+};
+
+struct ProfEntry {
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;  // pending (start, stop) pairs
+  double total_ms = 0;
+  long launches = 0;
+};
+
+struct BaWindowDev;  // ba.hip
+struct TrackBatch;   // tracker.hip
+
+}  // namespace sdso
+
+struct sdso_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  std::map<int, sdso::PyramidDev> pyr;
+  std::map<int, sdso::RefDev> refs;
+  std::map<int, sdso::BaWindowDev*> wins;
+  sdso::TrackBatch* tb = nullptr;
+  // generic scratch
+  void* scratch = nullptr;
+  size_t scratch_bytes = 0;
+  void* pinned = nullptr;
+  size_t pinned_bytes = 0;
+  int n_cu = 256;
+  // optional in-library kernel timing (HIP events on ctx->stream), see sdso_prof_*
+  bool prof_on = false;
+  std::map<std::string, sdso::ProfEntry> prof;
+};
+
+namespace sdso {
+
+inline int fail(sdso_ctx* ctx, int code, const std::string& msg) {
+  if (ctx) ctx->err = msg;
+  return code;
+}
+
+#define SDSO_HIP(ctx, expr)                                                                  \
+  do {                                                                                       \
+    hipError_t _e = (expr);                                                                  \
+    if (_e != hipSuccess)                                                                    \
+      return sdso::fail(ctx, SDSO_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+  } while (0)
+
+#define SDSO_REQUIRE(ctx, cond, msg) \
+  do {                               \
+    if (!(cond)) return sdso::fail(ctx, SDSO_ERR_ARG, msg); \
+  } while (0)
+
+int ensure_scratch(sdso_ctx* ctx, size_t bytes);
+// Bracket the launches of one named kernel with HIP events when profiling is enabled.
+struct ProfScope {
+  sdso_ctx* ctx;
+  hipEvent_t a = nullptr, b = nullptr;
+  const char* name;
+  ProfScope(sdso_ctx* c, const char* n) : ctx(c), name(n) {
+    if (!ctx->prof_on) return;
+    hipEventCreate(&a); hipEventCreate(&b);
+    hipEventRecord(a, ctx->stream);
+  }
+  ~ProfScope() {
+    if (!a) return;
+    hipEventRecord(b, ctx->stream);
+    ctx->prof[name].ev.emplace_back(a, b);
+  }
+};
+int ensure_pinned(sdso_ctx* ctx, size_t bytes);
+
+// ------------------------------------------------------------------ device helpers
+// getInterpolatedElement33 (src/util/globalFuncs.h:73-86) on the float4 image.
+// Same operation order as the reference so that per-point results are bit-identical to the CPU.
+__device__ __forceinline__ float3 interp33(const float4* __restrict__ img, float x, float y, int width) {
+  const int ix = (int)x;
+  const int iy = (int)y;
+  const float dx = x - ix;
+  const float dy = y - iy;
+  const float dxdy = dx * dy;
+  const float4* bp = img + ix + iy * width;
+  const float4 p00 = bp[0], p10 = bp[1], p01 = bp[width], p11 = bp[1 + width];
+  const float w11 = dxdy, w01 = dy - dxdy, w10 = dx - dxdy, w00 = 1 - dx - dy + dxdy;
+  float3 r;
+  r.x = w11 * p11.x + w01 * p01.x + w10 * p10.x + w00 * p00.x;
+  r.y = w11 * p11.y + w01 * p01.y + w10 * p10.y + w00 * p00.y;
+  r.z = w11 * p11.z + w01 * p01.z + w10 * p10.z + w00 * p00.z;
+  return r;
+}
+// getInterpolatedElement31 (globalFuncs.h:122-135)
+__device__ __forceinline__ float interp31(const float4* __restrict__ img, float x, float y, int width) {
+  const int ix = (int)x;
+  const int iy = (int)y;
+  const float dx = x - ix;
+  const float dy = y - iy;
+  const float dxdy = dx * dy;
+  const float4* bp = img + ix + iy * width;
+  return dxdy * bp[1 + width].x + (dy - dxdy) * bp[width].x + (dx - dxdy) * bp[1].x + (1 - dx - dy + dxdy) * bp[0].x;
+}
+
+// 64-lane butterfly sum
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+}  // namespace sdso

@@ -1,0 +1,62 @@
+"""CPU-side checks of the product library: it loads, exports every symbol include/sdso_abi.h
+declares, fails loudly without a GPU, and its host-only helpers agree with the oracle."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import helpers
+from sdso_amd import abi, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    txt = open(os.path.join(ROOT, "include", "sdso_abi.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(sdso_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = abi.load()
+    names = _declared()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(L, n), "libsdso_hip.so does not export %s" % n
+    assert sorted(abi.EXPORTED_SYMBOLS) == names
+
+
+def test_no_cpu_fallback_without_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(abi.SdsoError):
+        abi.Context(0)
+    L = abi.load()
+    assert L.sdso_ctx_sync(None) != 0
+    assert L.sdso_ba_linearize(None, 0, None) != 0
+
+
+def test_pyramid_levels_rule(oracle):
+    L = abi.load()
+    for w, h in ((1241, 376), (1232, 368), (640, 480), (64, 48), (4096, 2048)):
+        assert L.sdso_pyramid_levels(w, h) == oracle.orc_pyramid_levels(w, h) == synth.pyramid_levels(w, h)
+
+
+def test_make_eval_matches_oracle_bitwise(oracle):
+    L = abi.load()
+    prob = dict(levels=5, pyr_ref=[np.zeros((368 >> l, 1232 >> l, 3), np.float32) for l in range(5)])
+    cal = synth.kitti_calib(1232, 368)
+    prob["fx"], prob["fy"], prob["cx"], prob["cy"] = synth.level_intrinsics(cal["fx"], cal["fy"], cal["cx"], cal["cy"], 5)
+    prm = helpers.track_params(prob, ref_aff=(0.03, -2.0), exposure=(0.8, 1.3))
+    rs = np.random.RandomState(3)
+    for lvl in range(5):
+        T = abi.SE3.from_Rt(*synth.se3_exp(rs.normal(0, 0.05, 6)))
+        aff = abi.Aff(rs.normal(0, 0.1), rs.normal(0, 5))
+        a, b = abi.TrackEval(), abi.TrackEval()
+        L.sdso_track_make_eval(C.byref(prm), lvl, C.byref(T), C.byref(aff), 2.0, C.byref(a))
+        oracle.orc_track_make_eval(C.byref(prm), lvl, C.byref(T), C.byref(aff), 2.0, C.byref(b))
+        assert bytes(a) == bytes(b)
+        assert a.cutoffTH == 40.0 and a.w == 1232 >> lvl

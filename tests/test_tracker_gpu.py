@@ -1,0 +1,180 @@
+"""GPU parity of the coarse tracker (BASELINE configs[0] and [1]) against the oracle, through the C-ABI.
+
+Tolerances: inlier masks, point counts and n_warped are bit-exact; H, b, E differ only by the order
+of the float sums (<= 2e-5 relative to the largest entry of the same kind, the reference itself
+sums in float with carry buckets); pose after the full LM within 1e-5 (north_star)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import helpers
+from sdso_amd import abi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def prob_small():
+    return synth.tracker_problem(w=640, h=480, npts=2000, seed=2001)        # configs[0]
+
+
+@pytest.fixture(scope="module")
+def prob_kitti():
+    return synth.tracker_problem(w=1232, h=368, npts=2000, seed=2002)       # configs[1]
+
+
+def _setup(ctx, prob, ref_slot, new_slot):
+    ctx.upload_pyramid(new_slot, prob["pyr_new"])
+    ctx.set_ref(ref_slot, prob["pc"])
+
+
+def _cmp_eval(ctx, oracle, prob, prm, lvl, T, aff, repeat=1.0, ref_slot=1, new_slot=2):
+    ev = abi.TrackEval()
+    ctx.L.sdso_track_make_eval(C.byref(prm), lvl, C.byref(abi.SE3.from_Rt(*T)), C.byref(abi.Aff(*aff)), repeat, C.byref(ev))
+    Ho, bo, reso, nwo, masko = helpers.oracle_eval(oracle, prob["pc"][lvl], prob["pyr_new"][lvl], ev)
+    n = len(prob["pc"][lvl]["u"])
+    H = np.zeros(64); b = np.zeros(8); res = np.zeros(6); nw = C.c_int(0); mask = np.zeros(n, np.uint8)
+    ctx.check(ctx.L.sdso_track_calc_res_gs(ctx.h, ref_slot, new_slot, C.byref(ev), abi.dp(H), abi.dp(b), abi.dp(res), C.byref(nw), abi.bp(mask)))
+    H = H.reshape(8, 8)
+    assert np.array_equal(mask, masko)
+    assert nw.value == nwo and res[1] == reso[1] and res[5] == reso[5]
+    assert abs(res[0] - reso[0]) <= 2e-5 * abs(reso[0])
+    assert np.allclose(res[2:5], reso[2:5], rtol=1e-4, atol=1e-7)
+    assert np.abs(H - Ho).max() <= 2e-5 * np.abs(Ho).max()
+    # entries of H and b span many decades after the SCALE_* scaling: compare per scale block too
+    d = np.sqrt(np.abs(np.diag(Ho))) + 1e-30
+    assert np.abs((H - Ho) / np.outer(d, d)).max() <= 5e-5
+    assert np.abs((b - bo) / d).max() <= 5e-5 * max(1.0, np.abs(bo / d).max())
+    return H, b, res, nw.value
+
+
+def test_calc_res_gs_all_levels_640x480(gpu_ctx, oracle, prob_small):
+    prob = prob_small
+    _setup(gpu_ctx, prob, 1, 2)
+    prm = helpers.track_params(prob)
+    T = synth.se3_exp(np.array([0.015, -0.008, 0.3, 0.003, -0.005, 0.0015]))
+    for lvl in range(prob["levels"]):
+        _cmp_eval(gpu_ctx, oracle, prob, prm, lvl, T, (0.01, 1.0))
+    # identity start (configs[0]: level 0, one GN iteration from identity)
+    _cmp_eval(gpu_ctx, oracle, prob, prm, 0, (np.eye(3), np.zeros(3)), (0.0, 0.0))
+    # saturation path: tiny cutoff makes most residuals saturate
+    _cmp_eval(gpu_ctx, oracle, prob, prm, 0, (np.eye(3), np.zeros(3)), (0.0, 0.0), repeat=0.05)
+
+
+def test_calc_res_gs_kitti_all_levels(gpu_ctx, oracle, prob_kitti):
+    prob = prob_kitti
+    _setup(gpu_ctx, prob, 3, 4)
+    prm = helpers.track_params(prob)
+    rs = np.random.RandomState(9)
+    for lvl in range(prob["levels"]):
+        T = synth.se3_exp(np.array(prob_motion()) + rs.normal(0, 2e-3, 6))
+        _cmp_eval(gpu_ctx, oracle, prob, prm, lvl, T, (0.02, 1.0), ref_slot=3, new_slot=4)
+
+
+def prob_motion():
+    return [0.02, -0.01, 0.35, 0.004, -0.006, 0.002]
+
+
+def test_edge_cases(gpu_ctx, oracle, prob_small):
+    prob = prob_small
+    _setup(gpu_ctx, prob, 1, 2)
+    prm = helpers.track_params(prob)
+    # (a) every point out of bounds: huge translation -> zero inliers, zero H/b, n_warped 0
+    T = (np.eye(3), np.array([500.0, 0.0, 0.0]))
+    H, b, res, nw = _cmp_eval(gpu_ctx, oracle, prob, prm, 0, T, (0.0, 0.0))
+    assert nw == 0 and not H.any()
+    # (b) empty template level
+    empty = dict(u=np.zeros(0, np.float32), v=np.zeros(0, np.float32), idepth=np.zeros(0, np.float32), color=np.zeros(0, np.float32))
+    p2 = dict(prob)
+    p2["pc"] = [empty] + list(prob["pc"][1:])
+    gpu_ctx.set_ref(7, p2["pc"])
+    _cmp_eval(gpu_ctx, oracle, p2, prm, 0, (np.eye(3), np.zeros(3)), (0.0, 0.0), ref_slot=7)
+    # (c) ragged sizes: n = 1, 3, 65, 257 points (padding of n_warped to a multiple of 4)
+    for n in (1, 3, 65, 257):
+        sub = {k: v[:n] for k, v in prob["pc"][0].items()}
+        p3 = dict(prob)
+        p3["pc"] = [sub] + list(prob["pc"][1:])
+        gpu_ctx.set_ref(8, p3["pc"])
+        _cmp_eval(gpu_ctx, oracle, p3, prm, 0, (np.eye(3), np.zeros(3)), (0.0, 0.0), ref_slot=8)
+    # (d) error behaviour: unknown slots and a w/h mismatch are refused, not executed
+    ev = abi.TrackEval()
+    gpu_ctx.L.sdso_track_make_eval(C.byref(prm), 0, C.byref(abi.SE3.from_Rt(np.eye(3), np.zeros(3))), C.byref(abi.Aff(0, 0)), 1.0, C.byref(ev))
+    assert gpu_ctx.L.sdso_track_calc_res_gs(gpu_ctx.h, 999, 2, C.byref(ev), None, None, None, None, None) == -1
+    ev.w += 2
+    assert gpu_ctx.L.sdso_track_calc_res_gs(gpu_ctx.h, 1, 2, C.byref(ev), None, None, None, None, None) == -1
+
+
+def test_batch_matches_single(gpu_ctx, oracle, prob_small, prob_kitti):
+    _setup(gpu_ctx, prob_small, 1, 2)
+    _setup(gpu_ctx, prob_kitti, 3, 4)
+    rs = np.random.RandomState(4)
+    evs, refs, frames, exp = [], [], [], []
+    for i in range(19):   # not a multiple of 8: exercises the XCD-group tail
+        prob, r, f = (prob_small, 1, 2) if i % 2 == 0 else (prob_kitti, 3, 4)
+        prm = helpers.track_params(prob)
+        lvl = i % prob["levels"]
+        T = synth.se3_exp(np.array(prob_motion()) + rs.normal(0, 3e-3, 6))
+        ev = abi.TrackEval()
+        gpu_ctx.L.sdso_track_make_eval(C.byref(prm), lvl, C.byref(abi.SE3.from_Rt(*T)), C.byref(abi.Aff(0.01, 0.5)), 1.0, C.byref(ev))
+        evs.append(ev); refs.append(r); frames.append(f)
+        exp.append(helpers.oracle_eval(oracle, prob["pc"][lvl], prob["pyr_new"][lvl], ev))
+    n = len(evs)
+    arr = (abi.TrackEval * n)(*evs)
+    H = np.zeros((n, 64)); b = np.zeros((n, 8)); res = np.zeros((n, 6)); nw = np.zeros(n, np.int32)
+    gpu_ctx.check(gpu_ctx.L.sdso_track_calc_res_gs_batch(gpu_ctx.h, n, abi.ip(np.array(refs, np.int32)), abi.ip(np.array(frames, np.int32)),
+                                                         arr, abi.dp(H), abi.dp(b), abi.dp(res), abi.ip(nw)))
+    for i in range(n):
+        Ho, bo, reso, nwo, _ = exp[i]
+        assert nw[i] == nwo and res[i, 1] == reso[1]
+        assert np.abs(H[i].reshape(8, 8) - Ho).max() <= 2e-5 * np.abs(Ho).max()
+        assert abs(res[i, 0] - reso[0]) <= 2e-5 * abs(reso[0])
+
+
+@pytest.mark.parametrize("which", ["small", "kitti"])
+def test_track_newest_coarse_pose_within_1e5(gpu_ctx, oracle, prob_small, prob_kitti, which):
+    prob = prob_small if which == "small" else prob_kitti
+    _setup(gpu_ctx, prob, 1, 2)
+    prm = helpers.track_params(prob)
+    To, affo, outo = helpers.oracle_track(oracle, prob, prm, (np.eye(3), np.zeros(3)), (0.0, 0.0))
+    T = abi.SE3.from_Rt(np.eye(3), np.zeros(3)); aff = abi.Aff(0, 0); out = abi.TrackResult()
+    gpu_ctx.check(gpu_ctx.L.sdso_track_newest_coarse(gpu_ctx.h, 1, 2, C.byref(prm), C.byref(T), C.byref(aff), C.byref(out)))
+    assert out.good == outo.good == 1
+    assert list(out.iterations) == list(outo.iterations) and out.evaluations == outo.evaluations and out.point_evals == outo.point_evals
+    R, t = T.Rt(); Ro, to = To.Rt()
+    assert np.abs(t - to).max() <= 1e-5 and np.abs(R - Ro).max() <= 1e-5          # north_star: pose deltas within 1e-5
+    assert abs(aff.a - affo.a) <= 1e-5 and abs(aff.b - affo.b) <= 1e-3
+    for l in range(prob["levels"]):
+        assert abs(out.lastResiduals[l] - outo.lastResiduals[l]) <= 1e-4 * outo.lastResiduals[l]
+    Rt, tt = prob["refToNew_true"]
+    assert np.abs(t - tt).max() < 5e-3                                          # and it is the right pose
+
+
+def test_track_abort_and_error(gpu_ctx, oracle, prob_small):
+    prob = prob_small
+    _setup(gpu_ctx, prob, 1, 2)
+    prm = helpers.track_params(prob)
+    for i in range(5):
+        prm.minResForAbort[i] = 0.01
+    T = abi.SE3.from_Rt(np.eye(3), np.zeros(3)); aff = abi.Aff(0, 0); out = abi.TrackResult()
+    gpu_ctx.check(gpu_ctx.L.sdso_track_newest_coarse(gpu_ctx.h, 1, 2, C.byref(prm), C.byref(T), C.byref(aff), C.byref(out)))
+    To, affo, outo = helpers.oracle_track(oracle, prob, prm, (np.eye(3), np.zeros(3)), (0.0, 0.0))
+    assert out.good == outo.good == 0 and np.array_equal(T.Rt()[0], np.eye(3))
+    assert np.isnan(out.lastResiduals[0])
+    prm.coarsestLvl = 7
+    assert gpu_ctx.L.sdso_track_newest_coarse(gpu_ctx.h, 1, 2, C.byref(prm), C.byref(T), C.byref(aff), C.byref(out)) == -1
+
+
+def test_make_pyramid_bit_exact(gpu_ctx, oracle, prob_kitti):
+    img = np.ascontiguousarray(prob_kitti["pyr_new"][0][..., 0])
+    h, w = img.shape
+    gpu_ctx.check(gpu_ctx.L.sdso_make_pyramid(gpu_ctx.h, 11, w, h, abi.fp(img)))
+    for l in range(prob_kitti["levels"]):
+        out = np.zeros((h >> l, w >> l, 3), np.float32)
+        gpu_ctx.check(gpu_ctx.L.sdso_download_pyramid_level(gpu_ctx.h, 11, l, abi.fp(out)))
+        assert np.array_equal(out, prob_kitti["pyr_new"][l])
+    # upload -> download round trip
+    gpu_ctx.upload_pyramid(12, prob_kitti["pyr_ref"])
+    out = np.zeros_like(prob_kitti["pyr_ref"][2])
+    gpu_ctx.check(gpu_ctx.L.sdso_download_pyramid_level(gpu_ctx.h, 12, 2, abi.fp(out)))
+    assert np.array_equal(out, prob_kitti["pyr_ref"][2])
