@@ -250,6 +250,24 @@ int sdso_ba_optimize(sdso_ctx* ctx, int win, int mnumOptIts, double* state_out /
 int sdso_ba_marginalize_points(sdso_ctx* ctx, int win, const uint8_t* marg_flag, double* HM_out,
                                double* bM_out);
 
+/* keep projectedTo / centerProjectedTo of PointFrameResidual (Residuals.h:96-99) for
+ * sdso_ba_get_linearization; off by default (76 B of extra stores per residual). */
+int sdso_ba_keep_projections(sdso_ctx* ctx, int win, int on);
+
+/* Batches: any number of uploaded windows (same nf) advance through one GN iteration with ONE
+ * launch per phase.  The packed accumulators of the batch are contiguous so that one RCCL
+ * all-reduce over xGMI covers every window when the points of each window are sharded across
+ * ranks:
+ *   sdso_ba_batch_accumulate : linearizeAll + applyRes + accumulateAF/LF/SCF      (enqueue only)
+ *   [all-reduce(sum) of sdso_ba_batch_accum_dev across ranks]
+ *   sdso_ba_batch_solve      : stitch + solveSystemF + resubstituteF              (enqueue only)
+ *   sdso_ba_batch_get_x      : lastX of every window (synchronises)                          */
+int sdso_ba_batch_create(sdso_ctx* ctx, int nwin, const int* wins);
+int sdso_ba_batch_accumulate(sdso_ctx* ctx);
+int sdso_ba_batch_solve(sdso_ctx* ctx, double lambda, int orthogonalize_x);
+int sdso_ba_batch_accum_dev(sdso_ctx* ctx, void** dev_ptr, long* nfloats);
+int sdso_ba_batch_get_x(sdso_ctx* ctx, double* x /* nwin*(8nf+4) */);
+
 /* host tables derived from the frame states (tests): precalc nf*nf*27 floats per (host*nf+target)
  * {PRE_KRKiTll 9, PRE_KtTll 3, PRE_RTll_0 9, PRE_tTll_0 3, PRE_aff_mode 2, PRE_b0_mode 1}
  * (FrameFramePrecalc::set, HessianBlocks.cpp:206-242); adHost/adTarget nf*nf*64 doubles and
@@ -283,6 +301,13 @@ typedef struct {
  * DSO-native one (twin at :707-769).  K = {fx,fy,cx,cy}. status[n] = returned ImmaturePointStatus. */
 int sdso_trace_stereo_batch(sdso_ctx* ctx, int frame_slot, const float K[4], float baseline,
                             int mode_right, sdso_trace_points_t* pts, uint8_t* status);
+/* The same in three steps, for callers that keep the point state resident in HBM:
+ * prepare uploads it once, enqueue launches the trace (no copy, no sync; may be repeated),
+ * fetch copies the in/out fields and the returned statuses back. */
+int sdso_trace_stereo_prepare(sdso_ctx* ctx, int frame_slot, const float K[4], float baseline,
+                              int mode_right, const sdso_trace_points_t* pts);
+int sdso_trace_stereo_enqueue(sdso_ctx* ctx);
+int sdso_trace_stereo_fetch(sdso_ctx* ctx, sdso_trace_points_t* pts, uint8_t* status);
 
 #ifdef __cplusplus
 }

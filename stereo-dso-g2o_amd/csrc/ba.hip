@@ -1,20 +1,791 @@
-// placeholder until the BA kernels land
-#include "sdso_internal.h"
-namespace sdso { struct BaWindowDev {}; void release_all_windows(sdso_ctx*) {} }
-#define NI(ctx) return sdso::fail(ctx, SDSO_ERR_STATE, "not implemented")
-extern "C" int sdso_ba_upload_window(sdso_ctx* ctx, int, const sdso_ba_window_t*) { NI(ctx); }
-extern "C" int sdso_ba_release_window(sdso_ctx* ctx, int) { NI(ctx); }
-extern "C" int sdso_ba_linearize(sdso_ctx* ctx, int, double*) { NI(ctx); }
-extern "C" int sdso_ba_get_linearization(sdso_ctx* ctx, int, float*, uint8_t*, float*, float*, float*, float*) { NI(ctx); }
-extern "C" int sdso_ba_apply_res(sdso_ctx* ctx, int) { NI(ctx); }
-extern "C" int sdso_ba_get_residual_state(sdso_ctx* ctx, int, uint8_t*, uint8_t*, float*) { NI(ctx); }
-extern "C" int sdso_ba_accumulate(sdso_ctx* ctx, int) { NI(ctx); }
-extern "C" int sdso_ba_accum_floats(int nf) { return nf * nf * 91 * 2 + nf * nf * nf * 64 + nf * nf * 32 + nf * nf * 8 + 16 + 4 + 2; }
-extern "C" int sdso_ba_accum_dev(sdso_ctx* ctx, int, void**) { NI(ctx); }
-extern "C" int sdso_ba_get_accumulators(sdso_ctx* ctx, int, float*) { NI(ctx); }
-extern "C" int sdso_ba_get_point_terms(sdso_ctx* ctx, int, float*, float*, float*, float*, float*) { NI(ctx); }
-extern "C" int sdso_ba_solve(sdso_ctx* ctx, int, int, double, double*, double*, double*, double*, double*) { NI(ctx); }
-extern "C" int sdso_ba_get_point_steps(sdso_ctx* ctx, int, float*) { NI(ctx); }
-extern "C" int sdso_ba_optimize(sdso_ctx* ctx, int, int, double*, float*, uint8_t*, sdso_ba_opt_result_t*) { NI(ctx); }
-extern "C" int sdso_ba_marginalize_points(sdso_ctx* ctx, int, const uint8_t*, double*, double*) { NI(ctx); }
-extern "C" int sdso_ba_get_tables(sdso_ctx* ctx, int, float*, double*, double*, float*) { NI(ctx); }
+// Host API of the windowed bundle adjustment (C-ABI entry points sdso_ba_*).
+// The window mirrors an EnergyFunctional (src/OptimizationBackend/EnergyFunctional.h:49-150):
+// frames / calibration live on the host in double (ba_host.h), points and residuals live in HBM
+// (ba_kernels.h).  Call-surface mapping: see include/sdso_abi.h and INTEGRATION.md.
+#include "ba_kernels.hip"   // single translation unit: kernels + host API
+#include "ba_solve.hip"
+#include "ba_host.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+
+namespace sdso {
+
+struct BaBatch;
+
+struct BaWindowDev {
+  BaDev d;                 // host copy of the device descriptor
+  BaDev* d_self = nullptr; // device copy (array of 1)
+  std::vector<void*> allocs;
+  // host mirror
+  HostCalib calib;
+  std::vector<HostFrame> frames;
+  HostTables tab;
+  Dense P;
+  std::vector<double> HM, bM;
+  int solverMode = 0, forceAccept = 1;
+  double affA = 0, affB = 0;
+  std::vector<int> perm, inv;     // sorted -> original, original -> sorted
+  std::vector<uint8_t> h_target;  // sorted order
+  std::vector<uint8_t> h_lin;     // sorted order mirror of isLinearized
+  std::vector<float> h_prior;
+  int nblk_res = 0, nblk_pts = 0;
+  // device table blocks that are re-uploaded when frame states change
+  float* dt_precalc = nullptr; float* dt_adHTdelta = nullptr; float* dt_cdelta = nullptr; float* dt_frameTH = nullptr;
+  double* dt_adHost = nullptr; double* dt_adTarget = nullptr; double* dt_prior = nullptr; double* dt_HM = nullptr; double* dt_bM = nullptr; double* dt_P = nullptr;
+  float* dt_xAd = nullptr;
+  uint8_t* d_pflag = nullptr;
+  float* d_sums = nullptr;
+  bool own_accum = true;
+  bool accumulated = false;
+};
+
+static int dmalloc(sdso_ctx* ctx, BaWindowDev* W, void** p, size_t bytes) {
+  SDSO_HIP(ctx, hipMalloc(p, bytes ? bytes : 16));
+  SDSO_HIP(ctx, hipMemsetAsync(*p, 0, bytes ? bytes : 16, ctx->stream));
+  W->allocs.push_back(*p);
+  return SDSO_OK;
+}
+#define DM(ptr, T, count)                                                   \
+  do {                                                                      \
+    void* _p = nullptr;                                                     \
+    int _rc = dmalloc(ctx, W, &_p, sizeof(T) * (size_t)(count));            \
+    if (_rc) return _rc;                                                    \
+    ptr = (T*)_p;                                                           \
+  } while (0)
+#define H2D(dst, src, bytes) SDSO_HIP(ctx, hipMemcpyAsync((void*)(dst), (src), (bytes), hipMemcpyHostToDevice, ctx->stream))
+
+static void free_window(BaWindowDev* W) {
+  for (void* p : W->allocs) hipFree(p);
+  delete W;
+}
+struct BaLaunch {
+  const BaDev* d_arr; int nwin; int max_nblk_res, max_nblk_pts, max_chunks, max_items, nf, n;
+};
+struct BaBatch {
+  std::vector<int> wins;
+  BaDev* d_arr = nullptr;
+  float* d_accum = nullptr;
+  BaLaunch L;
+};
+static std::map<sdso_ctx*, BaBatch*> g_batches;
+static void free_batch(sdso_ctx* ctx) {
+  auto it = g_batches.find(ctx);
+  if (it == g_batches.end() || !it->second) return;
+  hipFree(it->second->d_arr); hipFree(it->second->d_accum);
+  delete it->second;
+  g_batches.erase(it);
+}
+void release_all_windows(sdso_ctx* ctx) {
+  for (auto& kv : ctx->wins) free_window(kv.second);
+  ctx->wins.clear();
+  free_batch(ctx);
+}
+
+static int upload_tables(sdso_ctx* ctx, BaWindowDev* W, bool adjoints) {
+  const int nf = W->d.nf, n = W->d.n;
+  buildPrecalc(W->calib, W->frames, W->tab);
+  if (adjoints) { buildAdjoints(W->frames, W->tab); W->P = buildNullspaceProjector(W->frames); }
+  buildDelta(W->calib, W->frames, W->tab);
+  H2D(W->dt_precalc, W->tab.precalc.data(), sizeof(float) * nf * nf * 27);
+  H2D(W->dt_adHTdelta, W->tab.adHTdeltaF.data(), sizeof(float) * nf * nf * 8);
+  H2D(W->dt_cdelta, W->tab.cDeltaF, sizeof(float) * 4);
+  if (adjoints) {
+    H2D(W->dt_adHost, W->tab.adHost.data(), sizeof(double) * nf * nf * 64);
+    H2D(W->dt_adTarget, W->tab.adTarget.data(), sizeof(double) * nf * nf * 64);
+    H2D(W->dt_P, W->P.a.data(), sizeof(double) * n * n);
+  }
+  std::vector<double> pr((size_t)nf * 16 + 4 + n);
+  for (int f = 0; f < nf; f++)
+    for (int i = 0; i < 8; i++) { pr[f * 8 + i] = W->frames[f].prior[i]; pr[nf * 8 + f * 8 + i] = W->frames[f].delta_prior[i]; }
+  for (int i = 0; i < 4; i++) pr[nf * 16 + i] = W->tab.cPrior[i];
+  for (int i = 0; i < 4; i++) pr[nf * 16 + 4 + i] = (double)W->tab.cDeltaF[i];
+  for (int f = 0; f < nf; f++) for (int i = 0; i < 8; i++) pr[nf * 16 + 4 + 4 + f * 8 + i] = W->frames[f].delta[i];
+  H2D(W->dt_prior, pr.data(), sizeof(double) * pr.size());
+  // calibration scalars live in the descriptor
+  W->d.fxl = W->calib.value_scaledf[0]; W->d.fyl = W->calib.value_scaledf[1];
+  W->d.cxl = W->calib.value_scaledf[2]; W->d.cyl = W->calib.value_scaledf[3];
+  W->d.fxli = W->calib.value_scaledi[0]; W->d.fyli = W->calib.value_scaledi[1];
+  H2D(W->d_self, &W->d, sizeof(BaDev));
+  SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));  // host staging vectors go out of scope
+  return SDSO_OK;
+}
+
+static BaWindowDev* find_win(sdso_ctx* ctx, int win) {
+  auto it = ctx->wins.find(win);
+  return it == ctx->wins.end() ? nullptr : it->second;
+}
+
+}  // namespace sdso
+
+using namespace sdso;
+
+extern "C" int sdso_ba_accum_floats(int nf) { return (int)acc_floats(nf); }
+
+extern "C" int sdso_ba_release_window(sdso_ctx* ctx, int win) {
+  if (!ctx) return SDSO_ERR_STATE;
+  auto it = ctx->wins.find(win);
+  if (it == ctx->wins.end()) return SDSO_OK;
+  SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  free_window(it->second);
+  ctx->wins.erase(it);
+  return SDSO_OK;
+}
+
+extern "C" int sdso_ba_upload_window(sdso_ctx* ctx, int win, const sdso_ba_window_t* Win) {
+  if (!ctx) return SDSO_ERR_STATE;
+  SDSO_HIP(ctx, hipSetDevice(ctx->device));
+  SDSO_REQUIRE(ctx, Win, "null window");
+  const int nf = Win->nf, np = Win->np, nr = Win->nr;
+  SDSO_REQUIRE(ctx, nf >= 1 && nf <= 16 && np >= 0 && nr >= 0, "window sizes out of range (nf <= 16)");
+  SDSO_REQUIRE(ctx, Win->evalPT && Win->state && Win->state_zero && Win->ab_exposure && Win->frameEnergyTH && Win->frameID && Win->frame_slot, "null frame arrays");
+  SDSO_REQUIRE(ctx, np == 0 || (Win->u && Win->v && Win->idepth && Win->idepth_zero && Win->color && Win->weights && Win->host && Win->hasDepthPrior), "null point arrays");
+  SDSO_REQUIRE(ctx, nr == 0 || (Win->res_point && Win->res_target && Win->res_state), "null residual arrays");
+  const int unsupported = SOLVER_SVD | SOLVER_ORTHOGONALIZE_SYSTEM | SOLVER_ORTHOGONALIZE_POINTMARG | SOLVER_ORTHOGONALIZE_FULL | SOLVER_MOMENTUM | SOLVER_STEPMOMENTUM;
+  SDSO_REQUIRE(ctx, (Win->solverMode & unsupported) == 0, "solverMode bit not supported on the device path (only the reference default FIX_LAMBDA|ORTHOGONALIZE_X_LATER family)");
+  int rc = sdso_ba_release_window(ctx, win);
+  if (rc) return rc;
+
+  BaWindowDev* W = new BaWindowDev();
+  ctx->wins[win] = W;
+  BaDev& d = W->d;
+  std::memset(&d, 0, sizeof(d));
+  d.nf = nf; d.np = np; d.nr = nr; d.nrp = (nr + 63) & ~63; d.w = Win->w; d.h = Win->h; d.n = 8 * nf + 4;
+  d.wM3 = (float)(Win->w - 3); d.hM3 = (float)(Win->h - 3);
+  d.affA_fixed = Win->affineOptModeA < 0; d.affB_fixed = Win->affineOptModeB < 0;
+  W->solverMode = Win->solverMode; W->forceAccept = Win->forceAcceptStep; W->affA = Win->affineOptModeA; W->affB = Win->affineOptModeB;
+  const int n = d.n;
+
+  // ---- host mirror
+  for (int i = 0; i < 4; i++) W->calib.value_zero[i] = Win->calib_value_zero[i];
+  W->calib.setValueScaled(Win->calib_value_scaled);
+  W->frames.resize(nf);
+  std::vector<const float4*> imgs(nf);
+  for (int f = 0; f < nf; f++) {
+    HostFrame& F = W->frames[f];
+    std::memcpy(F.evalPT.R.data(), Win->evalPT + f * 12, 72);
+    std::memcpy(F.evalPT.t.data(), Win->evalPT + f * 12 + 9, 24);
+    F.ab_exposure = Win->ab_exposure[f]; F.frameEnergyTH = Win->frameEnergyTH[f]; F.frameID = Win->frameID[f]; F.frame_slot = Win->frame_slot[f];
+    F.setState(Win->state + f * 10);
+    F.setStateZero(Win->state_zero + f * 10);
+    for (int i = 0; i < 10; i++) F.step[i] = 0;
+    F.fillPrior(W->affA, W->affB, W->solverMode);
+    auto ip = ctx->pyr.find(F.frame_slot);
+    SDSO_REQUIRE(ctx, ip != ctx->pyr.end(), "window references a frame slot without an uploaded pyramid");
+    SDSO_REQUIRE(ctx, ip->second.w[0] == Win->w && ip->second.h[0] == Win->h, "pyramid level-0 size differs from the window's w/h");
+    imgs[f] = ip->second.d[0];
+  }
+  W->HM.assign((size_t)n * n, 0.0); W->bM.assign(n, 0.0);
+  if (Win->HM) std::memcpy(W->HM.data(), Win->HM, sizeof(double) * n * n);
+  if (Win->bM) std::memcpy(W->bM.data(), Win->bM, sizeof(double) * n);
+
+  // ---- validate + sort residuals by (host,target) pair, stable
+  std::vector<int> rhost(nr);
+  for (int p = 1; p < np; p++) SDSO_REQUIRE(ctx, Win->host[p] >= Win->host[p - 1], "points must be in allPoints order (host index non-decreasing)");
+  for (int p = 0; p < np; p++) SDSO_REQUIRE(ctx, Win->host[p] >= 0 && Win->host[p] < nf, "point host out of range");
+  std::vector<int> rbeg(np, 0), rcnt(np, 0);
+  for (int i = 0; i < nr; i++) {
+    const int p = Win->res_point[i];
+    SDSO_REQUIRE(ctx, p >= 0 && p < np && (i == 0 || p >= Win->res_point[i - 1]), "residuals must be grouped by point in point order");
+    SDSO_REQUIRE(ctx, Win->res_target[i] >= 0 && Win->res_target[i] < nf, "residual target out of range");
+    rhost[i] = Win->host[p];
+    if (rcnt[p] == 0) rbeg[p] = i;
+    rcnt[p]++;
+    SDSO_REQUIRE(ctx, rcnt[p] <= SDSO_MAX_RES, "more than MAX_RES_PER_POINT residuals on a point");
+  }
+  W->perm.resize(nr); W->inv.resize(nr);
+  std::iota(W->perm.begin(), W->perm.end(), 0);
+  std::stable_sort(W->perm.begin(), W->perm.end(), [&](int a, int b) {
+    return rhost[a] + Win->res_target[a] * nf < rhost[b] + Win->res_target[b] * nf;
+  });
+  for (int j = 0; j < nr; j++) W->inv[W->perm[j]] = j;
+  std::vector<int> s_point(nr);
+  std::vector<uint8_t> s_host(nr), s_target(nr), s_state(nr);
+  for (int j = 0; j < nr; j++) {
+    const int o = W->perm[j];
+    s_point[j] = Win->res_point[o]; s_host[j] = (uint8_t)rhost[o]; s_target[j] = (uint8_t)Win->res_target[o]; s_state[j] = Win->res_state[o];
+  }
+  W->h_target = s_target;
+  W->h_lin.assign(nr, 0);
+  // chunks per pair
+  std::vector<int4> chunks;
+  std::vector<int> pair_beg(nf * nf + 1, 0);
+  {
+    int j = 0;
+    for (int pair = 0; pair < nf * nf; pair++) {
+      pair_beg[pair] = (int)chunks.size();
+      int start = j;
+      while (j < nr && s_host[j] + s_target[j] * nf == pair) j++;
+      for (int s = start; s < j; s += BA_CHUNK) chunks.push_back(make_int4(pair, s, std::min(BA_CHUNK, j - s), 0));
+    }
+    pair_beg[nf * nf] = (int)chunks.size();
+  }
+  // SC items per host
+  std::vector<int4> items;
+  std::vector<int> host_beg(nf + 1, 0);
+  {
+    int p = 0;
+    for (int h = 0; h < nf; h++) {
+      host_beg[h] = (int)items.size();
+      int start = p;
+      while (p < np && Win->host[p] == h) p++;
+      for (int s = start; s < p; s += BA_SC_PTS) items.push_back(make_int4(h, s, std::min(s + BA_SC_PTS, p), 0));
+    }
+    host_beg[nf] = (int)items.size();
+  }
+  d.nchunks = (int)chunks.size();
+  d.nitems = (int)items.size();
+  W->nblk_res = (nr + BA_BLOCK - 1) / BA_BLOCK;
+  W->nblk_pts = (np + BA_BLOCK - 1) / BA_BLOCK;
+
+  // ---- device allocations
+  float4* p_geo; float *p_color, *p_weights, *p_prior, *p_delta, *p_out; int *p_host, *p_rbeg, *p_rcnt, *p_rlist;
+  DM(p_geo, float4, np); DM(p_color, float, np * 8); DM(p_weights, float, np * 8); DM(p_host, int, np);
+  DM(p_prior, float, np); DM(p_delta, float, np); DM(p_rbeg, int, np); DM(p_rcnt, int, np); DM(p_rlist, int, nr); DM(p_out, float, (size_t)np * 16);
+  int* r_point; uint8_t *r_host, *r_target;
+  DM(r_point, int, nr); DM(r_host, uint8_t, nr); DM(r_target, uint8_t, nr);
+  DM(d.r_state, uint8_t, nr); DM(d.r_newState, uint8_t, nr); DM(d.r_lin, uint8_t, nr); DM(d.r_act, uint8_t, nr); DM(d.r_jsel, uint8_t, nr);
+  DM(d.r_energy, float, nr); DM(d.r_newEnergy, float, nr); DM(d.r_newEnergyWO, float, nr);
+  DM(d.J[0], float, (size_t)74 * d.nrp); DM(d.J[1], float, (size_t)74 * d.nrp); DM(d.r_toZero, float, (size_t)8 * d.nrp);
+  DM(d.r_rec, float, (size_t)nr * 16);
+  d.r_proj = nullptr;
+  DM(W->dt_precalc, float, nf * nf * 27); DM(W->dt_adHTdelta, float, nf * nf * 8); DM(W->dt_cdelta, float, 4); DM(W->dt_frameTH, float, nf);
+  DM(W->dt_adHost, double, nf * nf * 64); DM(W->dt_adTarget, double, nf * nf * 64); DM(W->dt_prior, double, nf * 16 + 4 + n);
+  DM(W->dt_HM, double, (size_t)n * n); DM(W->dt_bM, double, n); DM(W->dt_P, double, (size_t)n * n); DM(W->dt_xAd, float, nf * nf * 8);
+  const float4** d_img; DM(d_img, const float4*, nf);
+  int4* d_chunks; int* d_pair_beg; int4* d_items; int* d_host_beg;
+  DM(d_chunks, int4, chunks.size()); DM(d_pair_beg, int, nf * nf + 1); DM(d_items, int4, items.size()); DM(d_host_beg, int, nf + 1);
+  DM(d.top_part, float, (size_t)d.nchunks * 92); DM(d.sc_part, float, (size_t)d.nitems * sc_part_floats(nf)); DM(d.e_part, double, W->nblk_res + 1);
+  DM(d.accum, float, acc_floats(nf));
+  DM(d.sol, double, 4 * ((size_t)n * n + n) + n);
+  DM(W->d_pflag, uint8_t, np); DM(W->d_sums, float, 2 * (W->nblk_pts + 1));
+  DM(W->d_self, BaDev, 1);
+
+  d.p_geo = p_geo; d.p_color = p_color; d.p_weights = p_weights; d.p_host = p_host; d.p_prior = p_prior; d.p_delta = p_delta;
+  d.p_rbeg = p_rbeg; d.p_rcnt = p_rcnt; d.p_rlist = p_rlist; d.p_out = p_out;
+  d.r_point = r_point; d.r_host = r_host; d.r_target = r_target;
+  d.t_precalc = W->dt_precalc; d.t_adHTdelta = W->dt_adHTdelta; d.t_cdelta = W->dt_cdelta; d.t_frameTH = W->dt_frameTH; d.t_img = d_img;
+  d.t_adHost = W->dt_adHost; d.t_adTarget = W->dt_adTarget; d.t_xAd = W->dt_xAd; d.t_prior = W->dt_prior; d.t_HM = W->dt_HM; d.t_bM = W->dt_bM; d.t_P = W->dt_P;
+  d.chunks = d_chunks; d.pair_chunk_beg = d_pair_beg; d.items = d_items; d.host_item_beg = d_host_beg;
+
+  // ---- uploads
+  std::vector<float4> geo(np);
+  W->h_prior.resize(np);
+  std::vector<float> delta(np);
+  for (int p = 0; p < np; p++) {
+    geo[p] = make_float4(Win->u[p], Win->v[p], SCALE_IDEPTH * Win->idepth[p], SCALE_IDEPTH * Win->idepth_zero[p]);
+    float pr = Win->hasDepthPrior[p] ? 50.f * 50.f * SCALE_IDEPTH * SCALE_IDEPTH : 0.f;  // EFPoint::takeData, setting_idepthFixPrior
+    if (W->solverMode & SOLVER_REMOVE_POSEPRIOR) pr = 0;
+    W->h_prior[p] = pr;
+    delta[p] = Win->idepth[p] - Win->idepth_zero[p];
+  }
+  std::vector<int> rlist(nr);
+  for (int i = 0; i < nr; i++) rlist[i] = W->inv[i];   // slot order == original order (grouped by point)
+  std::vector<float> frameTH(nf);
+  for (int f = 0; f < nf; f++) frameTH[f] = W->frames[f].frameEnergyTH;
+  H2D(p_geo, geo.data(), sizeof(float4) * np); H2D(p_color, Win->color, sizeof(float) * np * 8); H2D(p_weights, Win->weights, sizeof(float) * np * 8);
+  H2D(p_host, Win->host, sizeof(int) * np); H2D(p_prior, W->h_prior.data(), sizeof(float) * np); H2D(p_delta, delta.data(), sizeof(float) * np);
+  H2D(p_rbeg, rbeg.data(), sizeof(int) * np); H2D(p_rcnt, rcnt.data(), sizeof(int) * np); H2D(p_rlist, rlist.data(), sizeof(int) * nr);
+  H2D(r_point, s_point.data(), sizeof(int) * nr); H2D(r_host, s_host.data(), nr); H2D(r_target, s_target.data(), nr); H2D(d.r_state, s_state.data(), nr);
+  H2D(W->dt_frameTH, frameTH.data(), sizeof(float) * nf); H2D(d_img, imgs.data(), sizeof(float4*) * nf);
+  H2D(d_chunks, chunks.data(), sizeof(int4) * chunks.size()); H2D(d_pair_beg, pair_beg.data(), sizeof(int) * (nf * nf + 1));
+  H2D(d_items, items.data(), sizeof(int4) * items.size()); H2D(d_host_beg, host_beg.data(), sizeof(int) * (nf + 1));
+  H2D(W->dt_HM, W->HM.data(), sizeof(double) * n * n); H2D(W->dt_bM, W->bM.data(), sizeof(double) * n);
+  // per-residual record: target in slot 15, newState OUTLIER, newEnergyWO -1
+  {
+    std::vector<float> rec((size_t)nr * 16, 0.f);
+    for (int j = 0; j < nr; j++) rec[(size_t)j * 16 + RR_TARGET] = (float)s_target[j];
+    H2D(d.r_rec, rec.data(), sizeof(float) * rec.size());
+    std::vector<uint8_t> ns(nr, 2);
+    H2D(d.r_newState, ns.data(), nr);
+    std::vector<float> m1(nr, -1.f);
+    H2D(d.r_newEnergyWO, m1.data(), sizeof(float) * nr);
+    SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return upload_tables(ctx, W, true);
+}
+
+// optional: keep projectedTo / centerProjectedTo (tests); costs 76 B of stores per residual
+extern "C" int sdso_ba_keep_projections(sdso_ctx* ctx, int win, int on) {
+  if (!ctx) return SDSO_ERR_STATE;
+  BaWindowDev* W = find_win(ctx, win);
+  SDSO_REQUIRE(ctx, W, "unknown window");
+  if (on && !W->d.r_proj) { DM(W->d.r_proj, float, (size_t)W->d.nr * 19); }
+  if (!on) W->d.r_proj = nullptr;
+  H2D(W->d_self, &W->d, sizeof(BaDev));
+  SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SDSO_OK;
+}
+
+// ------------------------------------------------------------------ launches on an array of windows
+namespace sdso {
+static void launch_linearize(sdso_ctx* ctx, const BaLaunch& L) {
+  ProfScope ps(ctx, "k_ba_linearize");
+  hipLaunchKernelGGL(k_ba_linearize, dim3(L.max_nblk_res, L.nwin), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr);
+}
+static void launch_apply(sdso_ctx* ctx, const BaLaunch& L) {
+  hipLaunchKernelGGL(k_ba_apply, dim3(L.max_nblk_res, L.nwin), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr);
+}
+static void launch_accumulate(sdso_ctx* ctx, const BaLaunch& L, const uint8_t* pflag, bool marg) {
+  const int nf = L.nf;
+  if (L.max_chunks > 0) {
+    if (!marg) {
+      { ProfScope ps(ctx, "k_ba_accum_top"); hipLaunchKernelGGL(k_ba_accum_top, dim3(L.max_chunks, L.nwin), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr, 0, (const uint8_t*)nullptr); }
+      hipLaunchKernelGGL(k_ba_fold_top, dim3(nf * nf, L.nwin), dim3(128), 0, ctx->stream, L.d_arr, 0);
+      hipLaunchKernelGGL(k_ba_accum_top, dim3(L.max_chunks, L.nwin), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr, 1, (const uint8_t*)nullptr);
+      hipLaunchKernelGGL(k_ba_fold_top, dim3(nf * nf, L.nwin), dim3(128), 0, ctx->stream, L.d_arr, 1);
+    } else {
+      hipLaunchKernelGGL(k_ba_accum_top, dim3(L.max_chunks, L.nwin), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr, 2, pflag);
+      hipLaunchKernelGGL(k_ba_fold_top, dim3(nf * nf, L.nwin), dim3(128), 0, ctx->stream, L.d_arr, 0);
+    }
+  }
+  const size_t lds = sizeof(float) * (BA_BLOCK / 64) * (size_t)(nf * nf * 64 + nf * 32 + nf * 8);
+  if (L.max_items > 0) {
+    ProfScope ps(ctx, "k_ba_sc");
+    hipLaunchKernelGGL(k_ba_sc, dim3((L.max_items + BA_BLOCK / 64 - 1) / (BA_BLOCK / 64), L.nwin), dim3(BA_BLOCK), lds, ctx->stream, L.d_arr, pflag, marg ? 0 : 1, marg ? 1 : 0);
+  }
+  hipLaunchKernelGGL(k_ba_fold_sc, dim3(nf * nf * nf + nf * nf + 1, L.nwin), dim3(64), 0, ctx->stream, L.d_arr);
+}
+static void launch_solve(sdso_ctx* ctx, const BaLaunch& L, double lambda, int orth) {
+  const int nf = L.nf, n = L.n;
+  hipLaunchKernelGGL(k_ba_stitch, dim3(3 * (nf * nf + nf + 1), L.nwin), dim3(64), 0, ctx->stream, L.d_arr);
+  const size_t lds = sizeof(double) * ((size_t)n * n + 5 * n) + sizeof(int) * n;
+  hipLaunchKernelGGL(k_ba_solve, dim3(1, L.nwin), dim3(BA_BLOCK), lds, ctx->stream, L.d_arr, lambda, orth);
+  if (L.max_nblk_pts > 0) hipLaunchKernelGGL(k_ba_resub, dim3(L.max_nblk_pts, L.nwin), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr);
+}
+static BaLaunch single(BaWindowDev* W) {
+  BaLaunch L;
+  L.d_arr = W->d_self; L.nwin = 1; L.max_nblk_res = std::max(W->nblk_res, 1); L.max_nblk_pts = W->nblk_pts;
+  L.max_chunks = W->d.nchunks; L.max_items = W->d.nitems; L.nf = W->d.nf; L.n = W->d.n;
+  return L;
+}
+
+// setNewFrameEnergyTH (FullSystemOptimize.cpp:98-139) from the energies the linearize kernel wrote
+static int update_frame_energy_th(sdso_ctx* ctx, BaWindowDev* W) {
+  const int nr = W->d.nr, nf = W->d.nf;
+  std::vector<float> e(nr);
+  if (nr) SDSO_HIP(ctx, hipMemcpyAsync(e.data(), W->d.r_newEnergyWO, sizeof(float) * nr, hipMemcpyDeviceToHost, ctx->stream));
+  SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  std::vector<float> all;
+  all.reserve(nr);
+  for (int j = 0; j < nr; j++)
+    if (!W->h_lin[j] && e[j] >= 0 && W->h_target[j] == nf - 1) all.push_back(e[j]);
+  float th;
+  if (all.empty()) th = 12 * 12 * 8;
+  else {
+    const int nth = (int)(0.7f * all.size());
+    std::nth_element(all.begin(), all.begin() + nth, all.end());
+    const float nthElement = sqrtf(all[nth]);
+    th = nthElement * 1.5f;
+    th = 26.0f * 0.5f + th * (1 - 0.5f);
+    th = th * th;
+    th *= 1.0f * 1.0f;
+  }
+  W->frames[nf - 1].frameEnergyTH = th;
+  SDSO_HIP(ctx, hipMemcpyAsync(W->dt_frameTH + (nf - 1), &W->frames[nf - 1].frameEnergyTH, sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SDSO_OK;
+}
+
+// FullSystem::linearizeAll(fixLinearization) (FullSystemOptimize.cpp:142-203)
+static int linearize_all(sdso_ctx* ctx, BaWindowDev* W, bool fix, double* energy) {
+  BaLaunch L = single(W);
+  launch_linearize(ctx, L);
+  if (fix) launch_apply(ctx, L);
+  SDSO_HIP(ctx, hipGetLastError());
+  std::vector<double> ep(W->nblk_res);
+  if (W->nblk_res) SDSO_HIP(ctx, hipMemcpyAsync(ep.data(), W->d.e_part, sizeof(double) * W->nblk_res, hipMemcpyDeviceToHost, ctx->stream));
+  int rc = update_frame_energy_th(ctx, W);  // synchronises
+  if (rc) return rc;
+  double s = 0;
+  for (double v : ep) s += v;
+  if (energy) *energy = s;
+  W->accumulated = false;
+  return SDSO_OK;
+}
+}  // namespace sdso
+
+#define GET_WIN()                                   \
+  if (!ctx) return SDSO_ERR_STATE;                  \
+  SDSO_HIP(ctx, hipSetDevice(ctx->device));         \
+  BaWindowDev* W = find_win(ctx, win);              \
+  SDSO_REQUIRE(ctx, W, "unknown window")
+
+extern "C" int sdso_ba_linearize(sdso_ctx* ctx, int win, double* energy) {
+  GET_WIN();
+  return linearize_all(ctx, W, false, energy);
+}
+
+extern "C" int sdso_ba_get_linearization(sdso_ctx* ctx, int win, float* J, uint8_t* newState, float* newEnergy, float* newEnergyWithOutlier,
+                                         float* projectedTo, float* centerProjectedTo) {
+  GET_WIN();
+  const int nr = W->d.nr, S = W->d.nrp;
+  SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (J) {
+    std::vector<float> j0((size_t)74 * S), j1((size_t)74 * S);
+    std::vector<uint8_t> sel(nr);
+    SDSO_HIP(ctx, hipMemcpy(j0.data(), W->d.J[0], sizeof(float) * j0.size(), hipMemcpyDeviceToHost));
+    SDSO_HIP(ctx, hipMemcpy(j1.data(), W->d.J[1], sizeof(float) * j1.size(), hipMemcpyDeviceToHost));
+    if (nr) SDSO_HIP(ctx, hipMemcpy(sel.data(), W->d.r_jsel, nr, hipMemcpyDeviceToHost));
+    for (int j = 0; j < nr; j++) {
+      const std::vector<float>& src = sel[j] ? j0 : j1;  // PointFrameResidual::J = J[1 - jsel]
+      float* o = J + (size_t)W->perm[j] * 74;
+      for (int f = 0; f < 74; f++) o[f] = src[(size_t)f * S + j];
+    }
+  }
+  auto fetch = [&](auto* dst, const auto* dsrc, int width) -> int {
+    using T = std::remove_pointer_t<decltype(dst)>;
+    std::vector<T> tmp((size_t)nr * width);
+    if (nr) SDSO_HIP(ctx, hipMemcpy(tmp.data(), dsrc, sizeof(T) * tmp.size(), hipMemcpyDeviceToHost));
+    for (int j = 0; j < nr; j++) std::memcpy(dst + (size_t)W->perm[j] * width, tmp.data() + (size_t)j * width, sizeof(T) * width);
+    return SDSO_OK;
+  };
+  int rc = SDSO_OK;
+  if (newState) rc |= fetch(newState, W->d.r_newState, 1);
+  if (newEnergy) rc |= fetch(newEnergy, W->d.r_newEnergy, 1);
+  if (newEnergyWithOutlier) rc |= fetch(newEnergyWithOutlier, W->d.r_newEnergyWO, 1);
+  if (projectedTo || centerProjectedTo) {
+    SDSO_REQUIRE(ctx, W->d.r_proj, "projections were not kept: call sdso_ba_keep_projections(ctx, win, 1) before linearize");
+    std::vector<float> tmp((size_t)nr * 19);
+    if (nr) SDSO_HIP(ctx, hipMemcpy(tmp.data(), W->d.r_proj, sizeof(float) * tmp.size(), hipMemcpyDeviceToHost));
+    for (int j = 0; j < nr; j++) {
+      if (projectedTo) std::memcpy(projectedTo + (size_t)W->perm[j] * 16, &tmp[(size_t)j * 19], 64);
+      if (centerProjectedTo) std::memcpy(centerProjectedTo + (size_t)W->perm[j] * 3, &tmp[(size_t)j * 19 + 16], 12);
+    }
+  }
+  return rc;
+}
+
+extern "C" int sdso_ba_apply_res(sdso_ctx* ctx, int win) {
+  GET_WIN();
+  launch_apply(ctx, single(W));
+  SDSO_HIP(ctx, hipGetLastError());
+  W->accumulated = false;
+  return SDSO_OK;
+}
+
+extern "C" int sdso_ba_get_residual_state(sdso_ctx* ctx, int win, uint8_t* state, uint8_t* isActive, float* JpJdF) {
+  GET_WIN();
+  const int nr = W->d.nr;
+  SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  std::vector<uint8_t> t(nr);
+  if (state && nr) { SDSO_HIP(ctx, hipMemcpy(t.data(), W->d.r_state, nr, hipMemcpyDeviceToHost)); for (int j = 0; j < nr; j++) state[W->perm[j]] = t[j]; }
+  if (isActive && nr) { SDSO_HIP(ctx, hipMemcpy(t.data(), W->d.r_act, nr, hipMemcpyDeviceToHost)); for (int j = 0; j < nr; j++) isActive[W->perm[j]] = t[j]; }
+  if (JpJdF && nr) {
+    std::vector<float> rec((size_t)nr * 16);
+    SDSO_HIP(ctx, hipMemcpy(rec.data(), W->d.r_rec, sizeof(float) * rec.size(), hipMemcpyDeviceToHost));
+    for (int j = 0; j < nr; j++) std::memcpy(JpJdF + (size_t)W->perm[j] * 8, &rec[(size_t)j * 16], 32);
+  }
+  return SDSO_OK;
+}
+
+extern "C" int sdso_ba_accumulate(sdso_ctx* ctx, int win) {
+  GET_WIN();
+  launch_accumulate(ctx, single(W), nullptr, false);
+  SDSO_HIP(ctx, hipGetLastError());
+  W->accumulated = true;
+  return SDSO_OK;
+}
+
+extern "C" int sdso_ba_accum_dev(sdso_ctx* ctx, int win, void** dev_ptr) {
+  GET_WIN();
+  SDSO_REQUIRE(ctx, dev_ptr, "null out pointer");
+  *dev_ptr = W->d.accum;
+  return SDSO_OK;
+}
+
+extern "C" int sdso_ba_get_accumulators(sdso_ctx* ctx, int win, float* packed) {
+  GET_WIN();
+  SDSO_REQUIRE(ctx, packed, "null buffer");
+  SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  SDSO_HIP(ctx, hipMemcpy(packed, W->d.accum, sizeof(float) * acc_floats(W->d.nf), hipMemcpyDeviceToHost));
+  return SDSO_OK;
+}
+
+extern "C" int sdso_ba_get_point_terms(sdso_ctx* ctx, int win, float* HdiF, float* bdSumF, float* Hdd_accAF, float* bd_accAF, float* Hcd_accAF) {
+  GET_WIN();
+  const int np = W->d.np;
+  std::vector<float> po((size_t)np * 16);
+  SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (np) SDSO_HIP(ctx, hipMemcpy(po.data(), W->d.p_out, sizeof(float) * po.size(), hipMemcpyDeviceToHost));
+  for (int p = 0; p < np; p++) {
+    const float* o = &po[(size_t)p * 16];
+    if (HdiF) HdiF[p] = o[PO_HDI];
+    if (bdSumF) bdSumF[p] = o[PO_BDSUM];
+    if (Hdd_accAF) Hdd_accAF[p] = o[PO_HDD_A];
+    if (bd_accAF) bd_accAF[p] = o[PO_BD_A];
+    if (Hcd_accAF) for (int k = 0; k < 4; k++) Hcd_accAF[p * 4 + k] = o[PO_HCD_A + k];
+  }
+  return SDSO_OK;
+}
+
+namespace sdso {
+static int solve_system(sdso_ctx* ctx, BaWindowDev* W, int iteration, double lambda) {
+  if (W->solverMode & SOLVER_USE_GN) lambda = 0;
+  if (W->solverMode & SOLVER_FIX_LAMBDA) lambda = 1e-5;
+  const int orth = (W->solverMode & SOLVER_ORTHOGONALIZE_X) || (iteration >= 2 && (W->solverMode & SOLVER_ORTHOGONALIZE_X_LATER));
+  launch_solve(ctx, single(W), lambda, orth ? 1 : 0);
+  SDSO_HIP(ctx, hipGetLastError());
+  return SDSO_OK;
+}
+static int fetch_x(sdso_ctx* ctx, BaWindowDev* W, std::vector<double>& x) {
+  const int n = W->d.n;
+  x.resize(n);
+  SDSO_HIP(ctx, hipMemcpyAsync(x.data(), W->d.sol + 3 * ((size_t)n * n + n), sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+  SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (int i = 0; i < 4; i++) W->calib.step[i] = -x[i];
+  for (int f = 0; f < W->d.nf; f++) {
+    for (int i = 0; i < 8; i++) W->frames[f].step[i] = -x[4 + 8 * f + i];
+    W->frames[f].step[8] = W->frames[f].step[9] = 0;
+  }
+  return SDSO_OK;
+}
+}  // namespace sdso
+
+extern "C" int sdso_ba_solve(sdso_ctx* ctx, int win, int iteration, double lambda, double* x, double* HS, double* bS, double* frame_step, double* calib_step) {
+  GET_WIN();
+  SDSO_REQUIRE(ctx, W->accumulated, "sdso_ba_solve needs sdso_ba_accumulate (and, across ranks, the all-reduce of the packed accumulators) first");
+  int rc = solve_system(ctx, W, iteration, lambda);
+  if (rc) return rc;
+  std::vector<double> xs;
+  rc = fetch_x(ctx, W, xs);
+  if (rc) return rc;
+  const int n = W->d.n;
+  if (x) std::memcpy(x, xs.data(), sizeof(double) * n);
+  const double* base = W->d.sol + 3 * ((size_t)n * n + n) + n;
+  if (HS) SDSO_HIP(ctx, hipMemcpy(HS, base, sizeof(double) * n * n, hipMemcpyDeviceToHost));
+  if (bS) SDSO_HIP(ctx, hipMemcpy(bS, base + (size_t)n * n, sizeof(double) * n, hipMemcpyDeviceToHost));
+  if (frame_step) for (int f = 0; f < W->d.nf; f++) for (int i = 0; i < 8; i++) frame_step[f * 8 + i] = W->frames[f].step[i];
+  if (calib_step) for (int i = 0; i < 4; i++) calib_step[i] = W->calib.step[i];
+  return SDSO_OK;
+}
+
+extern "C" int sdso_ba_get_point_steps(sdso_ctx* ctx, int win, float* step) {
+  GET_WIN();
+  const int np = W->d.np;
+  std::vector<float> po((size_t)np * 16);
+  SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (np) SDSO_HIP(ctx, hipMemcpy(po.data(), W->d.p_out, sizeof(float) * po.size(), hipMemcpyDeviceToHost));
+  for (int p = 0; p < np; p++) step[p] = po[(size_t)p * 16 + PO_STEP];
+  return SDSO_OK;
+}
+
+extern "C" int sdso_ba_get_tables(sdso_ctx* ctx, int win, float* precalc, double* adHost, double* adTarget, float* adHTdeltaF) {
+  GET_WIN();
+  const int nf = W->d.nf;
+  if (precalc) std::memcpy(precalc, W->tab.precalc.data(), sizeof(float) * nf * nf * 27);
+  if (adHost) std::memcpy(adHost, W->tab.adHost.data(), sizeof(double) * nf * nf * 64);
+  if (adTarget) std::memcpy(adTarget, W->tab.adTarget.data(), sizeof(double) * nf * nf * 64);
+  if (adHTdeltaF) std::memcpy(adHTdeltaF, W->tab.adHTdeltaF.data(), sizeof(float) * nf * nf * 8);
+  return SDSO_OK;
+}
+
+// FullSystem::optimize, DSO-native GN loop (FullSystemOptimize.cpp:871-1041)
+extern "C" int sdso_ba_optimize(sdso_ctx* ctx, int win, int mnumOptIts, double* state_out, float* idepth_out, uint8_t* res_state_out, sdso_ba_opt_result_t* out) {
+  GET_WIN();
+  SDSO_REQUIRE(ctx, W->forceAccept, "forceAcceptStep=0 (energy-gated steps, calcLEnergy/calcMEnergy) is not on the device path yet");
+  const int nf = W->d.nf, np = W->d.np, nr = W->d.nr;
+  sdso_ba_opt_result_t res{0, 0, 0, 0};
+  BaLaunch L = single(W);
+  if (nf >= 2) {
+    if (nf < 3) mnumOptIts = 20;
+    if (nf < 4) mnumOptIts = 15;
+    hipLaunchKernelGGL(k_ba_reset_all, dim3(L.max_nblk_res, 1), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr);
+    double lastEnergy = 0;
+    int rc = linearize_all(ctx, W, false, &lastEnergy);
+    if (rc) return rc;
+    launch_apply(ctx, L);
+    double lambda = 1e-1;
+    const float stepsize = 1;
+    std::vector<double> x;
+    std::vector<float> sums(2 * (W->nblk_pts + 1));
+    for (int iteration = 0; iteration < mnumOptIts; iteration++) {
+      res.iterations++;
+      // backupState (:309-351)
+      for (int i = 0; i < 4; i++) W->calib.value_backup[i] = W->calib.value[i];
+      for (HostFrame& f : W->frames) for (int i = 0; i < 10; i++) f.state_backup[i] = f.state[i];
+      if (L.max_nblk_pts) hipLaunchKernelGGL(k_ba_points_op, dim3(L.max_nblk_pts, 1), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr, 0, 0.f, (float*)nullptr);
+      // solveSystem
+      launch_accumulate(ctx, L, nullptr, false);
+      rc = solve_system(ctx, W, iteration, lambda);
+      if (rc) return rc;
+      rc = fetch_x(ctx, W, x);
+      if (rc) return rc;
+      // doStepFromBackup (:207-305)
+      double nv[4];
+      for (int i = 0; i < 4; i++) nv[i] = W->calib.value_backup[i] + stepsize * W->calib.step[i];
+      W->calib.setValue(nv);
+      float sumA = 0, sumB = 0, sumT = 0, sumR = 0;
+      for (HostFrame& fh : W->frames) {
+        double ns[10];
+        for (int i = 0; i < 10; i++) ns[i] = fh.state_backup[i] + (double)stepsize * fh.step[i];
+        fh.setState(ns);
+        sumA += fh.step[6] * fh.step[6];
+        sumB += fh.step[7] * fh.step[7];
+        sumT += fh.step[0] * fh.step[0] + fh.step[1] * fh.step[1] + fh.step[2] * fh.step[2];
+        sumR += fh.step[3] * fh.step[3] + fh.step[4] * fh.step[4] + fh.step[5] * fh.step[5];
+      }
+      float sumNID = 0, numID = (float)np;
+      if (L.max_nblk_pts) {
+        hipLaunchKernelGGL(k_ba_points_op, dim3(L.max_nblk_pts, 1), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr, 1, stepsize, W->d_sums);
+        SDSO_HIP(ctx, hipMemcpyAsync(sums.data(), W->d_sums, sizeof(float) * 2 * W->nblk_pts, hipMemcpyDeviceToHost, ctx->stream));
+        SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (int b = 0; b < W->nblk_pts; b++) sumNID += sums[2 * b + 1];
+      }
+      sumA /= nf; sumB /= nf; sumR /= nf; sumT /= nf;
+      sumNID /= numID;
+      rc = upload_tables(ctx, W, false);  // setPrecalcValues
+      if (rc) return rc;
+      const bool canbreak = sqrtf(sumA) < 0.0005 * 1.2f && sqrtf(sumB) < 0.00005 * 1.2f && sqrtf(sumR) < 0.00005 * 1.2f && sqrtf(sumT) * sumNID < 0.00005 * 1.2f;
+      double newEnergy = 0;
+      rc = linearize_all(ctx, W, false, &newEnergy);
+      if (rc) return rc;
+      launch_apply(ctx, L);  // setting_forceAceptStep
+      lastEnergy = newEnergy;
+      lambda *= 0.25;
+      if (canbreak && iteration >= 1) break;
+    }
+    double nsz[10] = {0};
+    nsz[6] = W->frames[nf - 1].state[6];
+    nsz[7] = W->frames[nf - 1].state[7];
+    W->frames[nf - 1].setEvalPT(W->frames[nf - 1].PRE_worldToCam, nsz);
+    rc = upload_tables(ctx, W, true);
+    if (rc) return rc;
+    rc = linearize_all(ctx, W, true, &lastEnergy);
+    if (rc) return rc;
+    float nresA = 0;
+    SDSO_HIP(ctx, hipMemcpy(&nresA, W->d.accum + acc_off_nres(nf), sizeof(float), hipMemcpyDeviceToHost));
+    res.lastEnergy = lastEnergy;
+    res.resInA = (int)nresA;
+    res.rmse = sqrtf((float)(lastEnergy / (8 * res.resInA)));
+  }
+  SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (state_out) for (int f = 0; f < nf; f++) for (int i = 0; i < 10; i++) state_out[f * 10 + i] = W->frames[f].state[i];
+  if (idepth_out && np) {
+    std::vector<float4> geo(np);
+    SDSO_HIP(ctx, hipMemcpy(geo.data(), W->d.p_geo, sizeof(float4) * np, hipMemcpyDeviceToHost));
+    for (int p = 0; p < np; p++) idepth_out[p] = geo[p].z;
+  }
+  if (res_state_out && nr) {
+    std::vector<uint8_t> t(nr);
+    SDSO_HIP(ctx, hipMemcpy(t.data(), W->d.r_state, nr, hipMemcpyDeviceToHost));
+    for (int j = 0; j < nr; j++) res_state_out[W->perm[j]] = t[j];
+  }
+  if (out) *out = res;
+  return SDSO_OK;
+}
+
+// flagPointsForRemoval core (FullSystem.cpp:1004-1021) + EnergyFunctional::marginalizePointsF (:663-736)
+extern "C" int sdso_ba_marginalize_points(sdso_ctx* ctx, int win, const uint8_t* marg_flag, double* HM_out, double* bM_out) {
+  GET_WIN();
+  SDSO_REQUIRE(ctx, marg_flag, "null flags");
+  const int np = W->d.np, nr = W->d.nr, nf = W->d.nf, n = W->d.n;
+  BaLaunch L = single(W);
+  H2D(W->d_pflag, marg_flag, np);
+  hipLaunchKernelGGL(k_ba_reset_flagged, dim3(L.max_nblk_res, 1), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr, W->d_pflag);
+  hipLaunchKernelGGL(k_ba_linearize, dim3(L.max_nblk_res, 1), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr);
+  launch_apply(ctx, L);
+  hipLaunchKernelGGL(k_ba_unmask, dim3(L.max_nblk_res, 1), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr);
+  hipLaunchKernelGGL(k_ba_fixlin, dim3(L.max_nblk_res, 1), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr, W->d_pflag);
+  for (int p = 0; p < np; p++) if (marg_flag[p]) W->h_prior[p] *= 600.f * 600.f;   // setting_idepthFixPriorMargFac (:674)
+  H2D(W->d.p_prior, W->h_prior.data(), sizeof(float) * np);
+  launch_accumulate(ctx, L, W->d_pflag, true);
+  hipLaunchKernelGGL(k_ba_stitch, dim3(3 * (nf * nf + nf + 1), 1), dim3(64), 0, ctx->stream, L.d_arr);
+  SDSO_HIP(ctx, hipGetLastError());
+  const size_t blk = (size_t)n * n + n;
+  std::vector<double> MA(blk), MS(blk);
+  SDSO_HIP(ctx, hipMemcpyAsync(MA.data(), W->d.sol, sizeof(double) * blk, hipMemcpyDeviceToHost, ctx->stream));
+  SDSO_HIP(ctx, hipMemcpyAsync(MS.data(), W->d.sol + 2 * blk, sizeof(double) * blk, hipMemcpyDeviceToHost, ctx->stream));
+  std::vector<uint8_t> lin(nr);
+  if (nr) SDSO_HIP(ctx, hipMemcpyAsync(lin.data(), W->d.r_lin, nr, hipMemcpyDeviceToHost, ctx->stream));
+  SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  W->h_lin = lin;
+  const float fac = 0.5f * 0.5f;  // setting_margWeightFac
+  for (size_t i = 0; i < (size_t)n * n; i++) W->HM[i] += fac * (MA[i] - MS[i]);
+  for (int i = 0; i < n; i++) W->bM[i] += fac * (MA[(size_t)n * n + i] - MS[(size_t)n * n + i]);
+  H2D(W->dt_HM, W->HM.data(), sizeof(double) * n * n);
+  H2D(W->dt_bM, W->bM.data(), sizeof(double) * n);
+  SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (HM_out) std::memcpy(HM_out, W->HM.data(), sizeof(double) * n * n);
+  if (bM_out) std::memcpy(bM_out, W->bM.data(), sizeof(double) * n);
+  W->accumulated = false;
+  return SDSO_OK;
+}
+
+// ------------------------------------------------------------------ batches of windows (one launch per phase)
+
+extern "C" int sdso_ba_batch_create(sdso_ctx* ctx, int nwin, const int* wins) {
+  if (!ctx) return SDSO_ERR_STATE;
+  SDSO_HIP(ctx, hipSetDevice(ctx->device));
+  SDSO_REQUIRE(ctx, nwin > 0 && wins, "bad batch");
+  SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  free_batch(ctx);
+  BaBatch* Bt = new BaBatch();
+  g_batches[ctx] = Bt;
+  BaWindowDev* W0 = find_win(ctx, wins[0]);
+  SDSO_REQUIRE(ctx, W0, "unknown window in batch");
+  const int nf = W0->d.nf;
+  const size_t af = acc_floats(nf);
+  SDSO_HIP(ctx, hipMalloc(&Bt->d_arr, sizeof(BaDev) * nwin));
+  SDSO_HIP(ctx, hipMalloc(&Bt->d_accum, sizeof(float) * af * nwin));
+  SDSO_HIP(ctx, hipMemsetAsync(Bt->d_accum, 0, sizeof(float) * af * nwin, ctx->stream));
+  std::vector<BaDev> h(nwin);
+  BaLaunch L{};
+  L.nwin = nwin; L.nf = nf; L.n = W0->d.n;
+  for (int i = 0; i < nwin; i++) {
+    BaWindowDev* W = find_win(ctx, wins[i]);
+    SDSO_REQUIRE(ctx, W && W->d.nf == nf, "batch windows must exist and share nf");
+    W->d.accum = Bt->d_accum + af * i;   // contiguous accumulators: ONE all-reduce covers the batch
+    W->own_accum = false;
+    h[i] = W->d;
+    SDSO_HIP(ctx, hipMemcpyAsync(W->d_self, &W->d, sizeof(BaDev), hipMemcpyHostToDevice, ctx->stream));
+    L.max_nblk_res = std::max(L.max_nblk_res, std::max(W->nblk_res, 1)); L.max_nblk_pts = std::max(L.max_nblk_pts, W->nblk_pts);
+    L.max_chunks = std::max(L.max_chunks, W->d.nchunks); L.max_items = std::max(L.max_items, W->d.nitems);
+    W->accumulated = true;
+  }
+  SDSO_HIP(ctx, hipMemcpyAsync(Bt->d_arr, h.data(), sizeof(BaDev) * nwin, hipMemcpyHostToDevice, ctx->stream));
+  SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  L.d_arr = Bt->d_arr;
+  Bt->L = L;
+  Bt->wins.assign(wins, wins + nwin);
+  return SDSO_OK;
+}
+// phase 1 of one GN iteration for every window of the batch: linearize + applyRes + accumulate A/L/SC (enqueue only)
+extern "C" int sdso_ba_batch_accumulate(sdso_ctx* ctx) {
+  if (!ctx || !g_batches.count(ctx) || !g_batches[ctx]) return sdso::fail(ctx, SDSO_ERR_STATE, "no batch");
+  BaBatch* Bt = g_batches[ctx];
+  launch_linearize(ctx, Bt->L);
+  launch_apply(ctx, Bt->L);
+  launch_accumulate(ctx, Bt->L, nullptr, false);
+  SDSO_HIP(ctx, hipGetLastError());
+  return SDSO_OK;
+}
+// phase 2: stitch + solve + resubstitute (enqueue only). Between the phases the caller may all-reduce
+// the packed accumulators (sdso_ba_batch_accum_dev) across ranks.
+extern "C" int sdso_ba_batch_solve(sdso_ctx* ctx, double lambda, int orthogonalize_x) {
+  if (!ctx || !g_batches.count(ctx) || !g_batches[ctx]) return sdso::fail(ctx, SDSO_ERR_STATE, "no batch");
+  BaBatch* Bt = g_batches[ctx];
+  launch_solve(ctx, Bt->L, lambda, orthogonalize_x);
+  SDSO_HIP(ctx, hipGetLastError());
+  return SDSO_OK;
+}
+extern "C" int sdso_ba_batch_accum_dev(sdso_ctx* ctx, void** dev_ptr, long* nfloats) {
+  if (!ctx || !g_batches.count(ctx) || !g_batches[ctx]) return sdso::fail(ctx, SDSO_ERR_STATE, "no batch");
+  BaBatch* Bt = g_batches[ctx];
+  if (dev_ptr) *dev_ptr = Bt->d_accum;
+  if (nfloats) *nfloats = (long)(acc_floats(Bt->L.nf) * Bt->wins.size());
+  return SDSO_OK;
+}
+extern "C" int sdso_ba_batch_get_x(sdso_ctx* ctx, double* x /* nwin * (8nf+4) */) {
+  if (!ctx || !g_batches.count(ctx) || !g_batches[ctx]) return sdso::fail(ctx, SDSO_ERR_STATE, "no batch");
+  BaBatch* Bt = g_batches[ctx];
+  SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const int n = Bt->L.n;
+  for (size_t i = 0; i < Bt->wins.size(); i++) {
+    BaWindowDev* W = find_win(ctx, Bt->wins[i]);
+    SDSO_HIP(ctx, hipMemcpy(x + i * n, W->d.sol + 3 * ((size_t)n * n + n), sizeof(double) * n, hipMemcpyDeviceToHost));
+  }
+  return SDSO_OK;
+}

@@ -1,0 +1,87 @@
+// Device side of the windowed BA (gfx950).  One BaDev describes one EnergyFunctional window that
+// is resident in HBM; kernels take an array of BaDev and use blockIdx.y as the window index so
+// that any number of independent windows run in ONE launch.
+//
+// Residual order on the device is (host,target)-pair sorted (htIDX = host + target*nf, stable in
+// the reference's residualsAll order): every workgroup of the linearize / accumulate kernels
+// sees one pair -> wave-uniform precalc tables, one target image, and a plain block reduction of
+// the 91 AccumulatorApprox sums (no atomics).  Points keep the reference's allPoints order and
+// reach their residuals through 64-byte per-residual records.
+//
+// Per-residual / per-point float arithmetic follows the reference's operation order (compiled
+// with -ffp-contract=off), so J, energies, states, HdiF, steps are bit-identical to the CPU path;
+// only cross-residual sums differ in order.
+#pragma once
+#include "sdso_internal.h"
+
+namespace sdso {
+
+constexpr int BA_BLOCK = 256;
+constexpr int BA_CHUNK = 256;      // residuals per accumulate workgroup
+constexpr int BA_SC_PTS = 16;      // points per SC wave item
+constexpr int J_RESF = 0, J_XI0 = 8, J_XI1 = 14, J_C0 = 20, J_C1 = 24, J_DD = 28, J_IDX0 = 30, J_IDX1 = 38, J_AB0 = 46, J_AB1 = 54,
+              J_IDX2 = 62, J_ABIDX = 66, J_AB2 = 70;
+// p_out record (16 floats per point)
+constexpr int PO_HDD_A = 0, PO_BD_A = 1, PO_HCD_A = 2, PO_HDD_L = 6, PO_BD_L = 7, PO_HCD_L = 8, PO_HDI = 12, PO_BDSUM = 13, PO_STEP = 14, PO_BACKUP = 15;
+// r_rec record (16 floats per residual): JpJdF[8], bd, Hdd, Hcd[4], flags, target
+constexpr int RR_BD = 8, RR_HDD = 9, RR_HCD = 10, RR_FLAGS = 14, RR_TARGET = 15;
+
+struct BaDev {
+  int nf, np, nr, nrp, w, h, nchunks, nitems, n;
+  float wM3, hM3, fxl, fyl, cxl, cyl, fxli, fyli;
+  int affA_fixed, affB_fixed;
+  // points
+  float4* p_geo;            // u, v, idepth, idepth_zero
+  const float* p_color;     // np*8
+  const float* p_weights;   // np*8
+  const int* p_host;
+  float* p_prior;
+  float* p_delta;
+  const int* p_rbeg;
+  const int* p_rcnt;
+  const int* p_rlist;       // sorted residual index of every (point, slot)
+  float* p_out;             // np*16
+  // residuals (pair-sorted)
+  const int* r_point;
+  const uint8_t* r_host;
+  const uint8_t* r_target;
+  uint8_t* r_state; uint8_t* r_newState; uint8_t* r_lin; uint8_t* r_act; uint8_t* r_jsel;
+  float* r_energy; float* r_newEnergy; float* r_newEnergyWO;
+  float* J[2];              // 74 x nrp SoA each; EFResidual::J = J[jsel], PointFrameResidual::J = J[1-jsel]
+  float* r_toZero;          // 8 x nrp SoA
+  float* r_rec;             // nr x 16
+  float* r_proj;            // nr x 19 (projectedTo 16, centerProjectedTo 3)
+  // tables
+  const float* t_precalc;   // [host*nf+target][27]
+  const float* t_adHTdelta; // [h+t*nf][8]
+  const float* t_cdelta;    // 4
+  float* t_frameTH;         // nf
+  const float4* const* t_img;  // nf level-0 images
+  const double* t_adHost; const double* t_adTarget;  // [h+t*nf][64]
+  const float* t_xAd;       // [h*nf+t][8]  (resubstitute)
+  const double* t_prior;    // nf*8 prior, nf*8 delta_prior, 4 cPrior, then delta (4+8nf)
+  const double* t_HM; const double* t_bM; const double* t_P;   // marginalisation prior, nullspace projector
+  // work lists
+  const int4* chunks;       // {pair, start, count, 0}
+  const int* pair_chunk_beg;  // nf*nf+1
+  const int4* items;        // {host, pbeg, pend, 0}
+  const int* host_item_beg; // nf+1
+  float* top_part;          // nchunks x 92 (91 sums + count)
+  float* sc_part;           // nitems x SC_PART
+  double* e_part;           // energy partials of linearize (per workgroup)
+  float* accum;             // packed accumulators (see sdso_ba_accum_floats)
+  double* sol;              // Htop_A n*n | btop_A n | Htop_L n*n | btop_L n | Hsc n*n | bsc n | x n | HS n*n | bS n
+};
+
+__host__ __device__ inline int sc_part_floats(int nf) { return nf * nf * 64 + nf * 32 + nf * 8 + 16 + 4; }
+__host__ __device__ inline size_t acc_off_topA(int nf) { return 0; }
+__host__ __device__ inline size_t acc_off_topL(int nf) { return (size_t)nf * nf * 91; }
+__host__ __device__ inline size_t acc_off_D(int nf) { return (size_t)nf * nf * 91 * 2; }
+__host__ __device__ inline size_t acc_off_E(int nf) { return acc_off_D(nf) + (size_t)nf * nf * nf * 64; }
+__host__ __device__ inline size_t acc_off_EB(int nf) { return acc_off_E(nf) + (size_t)nf * nf * 32; }
+__host__ __device__ inline size_t acc_off_Hcc(int nf) { return acc_off_EB(nf) + (size_t)nf * nf * 8; }
+__host__ __device__ inline size_t acc_off_bc(int nf) { return acc_off_Hcc(nf) + 16; }
+__host__ __device__ inline size_t acc_off_nres(int nf) { return acc_off_bc(nf) + 4; }
+__host__ __device__ inline size_t acc_floats(int nf) { return acc_off_nres(nf) + 2; }
+
+}  // namespace sdso

@@ -1,0 +1,411 @@
+// Second half of the windowed-BA iteration on gfx950: fold of the Schur partials, the double
+// precision stitch into the (8nf+4)^2 systems, the damped pivoted-LDLT solve and the
+// back-substitution.  Reference (paths under /root/reference):
+//   AccumulatedTopHessianSSE::stitchDoubleInternal / stitchDoubleMT   AccumulatedTopHessian.cpp:265-337, .h:95-148
+//   AccumulatedSCHessianSSE::stitchDoubleInternal / stitchDoubleMT    AccumulatedSCHessian.cpp:106-195, .h:96-135
+//   EnergyFunctional::solveSystemF (default LDLT branch)              EnergyFunctional.cpp:838-995
+//   EnergyFunctional::resubstituteF_MT / resubstituteFPt             EnergyFunctional.cpp:272-341
+// The dense work here is tiny (<= 68x68): it is organised "owner computes" — one wave per 8x8
+// output tile, fixed summation order, no atomics — so results are run-to-run reproducible.
+#include "ba_kernels.h"
+
+namespace sdso {
+
+// ------------------------------------------------------------------ fold of the Schur partials
+// grid.x = nf^3 (D bins, 64 threads each) + nf^2 (E/EB per pair) + 1 (Hcc, bc)
+__global__ __launch_bounds__(64) void k_ba_fold_sc(const BaDev* __restrict__ wins) {
+  const BaDev& B = wins[blockIdx.y];
+  const int nf = B.nf, nf2 = nf * nf, nf3 = nf2 * nf;
+  const int pf = sc_part_floats(nf);
+  const int lane = threadIdx.x;
+  int b = blockIdx.x;
+  if (b < nf3) {
+    // accD[h + t1*nf + t2*nf^2] <- items of host h, tile (t1,t2)
+    const int h = b % nf, t1 = (b / nf) % nf, t2 = b / nf2;
+    float s = 0;
+    for (int it = B.host_item_beg[h]; it < B.host_item_beg[h + 1]; it++) s += B.sc_part[(size_t)it * pf + (t1 * nf + t2) * 64 + lane];
+    B.accum[acc_off_D(nf) + (size_t)b * 64 + lane] = s;
+    return;
+  }
+  b -= nf3;
+  if (b < nf2) {
+    const int h = b % nf, t1 = b / nf;
+    if (lane < 40) {
+      const int off = lane < 32 ? nf2 * 64 + t1 * 32 + lane : nf2 * 64 + nf * 32 + t1 * 8 + (lane - 32);
+      float s = 0;
+      for (int it = B.host_item_beg[h]; it < B.host_item_beg[h + 1]; it++) s += B.sc_part[(size_t)it * pf + off];
+      if (lane < 32) B.accum[acc_off_E(nf) + (size_t)b * 32 + lane] = s;
+      else B.accum[acc_off_EB(nf) + (size_t)b * 8 + (lane - 32)] = s;
+    }
+    return;
+  }
+  if (lane < 20) {
+    const int off = nf2 * 64 + nf * 32 + nf * 8 + lane;
+    float s = 0;
+    for (int it = 0; it < B.nitems; it++) s += B.sc_part[(size_t)it * pf + off];
+    B.accum[acc_off_Hcc(nf) + lane] = s;  // Hcc 16 then bc 4 are contiguous
+  }
+}
+
+// ------------------------------------------------------------------ stitch
+// element (r,c) of the 13x13 AccumulatorApprox matrix from its 91 packed sums (MatrixAccumulators.h:589-618)
+__device__ __forceinline__ double acc13(const float* __restrict__ p, int r, int c) {
+  if (r > c) { const int t = r; r = c; c = t; }
+  if (c < 10) return (double)p[r * 10 - r * (r - 1) / 2 + (c - r)];
+  if (r < 10) return (double)p[55 + 3 * r + (c - 10)];
+  const int k = (r == 10) ? (c - 10) : (r == 11 ? 3 + (c - 11) : 5);
+  return (double)p[85 + k];
+}
+
+// One wave computes out[a][c] += sum_{m,n} L[a][m] X[m][n] R[c][n] for 8x8 row-major L, X, R held in LDS.
+struct TileWork {
+  double* Ls; double* Xs; double* Rs; double* Ts;  // 64 doubles each (LDS)
+};
+__device__ __forceinline__ double lxr(const TileWork& W, int a, int c) {
+  double t = 0;
+#pragma unroll
+  for (int m = 0; m < 8; m++) t += W.Ls[a * 8 + m] * W.Xs[m * 8 + c];
+  W.Ts[a * 8 + c] = t;
+  __syncthreads();
+  double o = 0;
+#pragma unroll
+  for (int n = 0; n < 8; n++) o += W.Ts[a * 8 + n] * W.Rs[c * 8 + n];
+  __syncthreads();
+  return o;
+}
+
+// grid.x = 3 * (nf*nf + nf + 1) tiles: matrix m in {0: top A, 1: top L (with priors), 2: SC};
+// tile kinds: frame-frame (x,y) 8x8; frame-calib x: 8x4 + b(8); calib: 4x4 + b(4).
+// sol layout: [H_A n*n | b_A n | H_L n*n | b_L n | H_sc n*n | b_sc n | ...]
+__global__ __launch_bounds__(64) void k_ba_stitch(const BaDev* __restrict__ wins) {
+  const BaDev& B = wins[blockIdx.y];
+  const int nf = B.nf, nf2 = nf * nf, n = B.n;
+  const int per = nf2 + nf + 1;
+  const int m = blockIdx.x / per;
+  int tile = blockIdx.x % per;
+  if (m >= 3) return;
+  double* H = B.sol + (size_t)m * ((size_t)n * n + n);
+  double* bvec = H + (size_t)n * n;
+  const int lane = threadIdx.x, a = lane >> 3, c = lane & 7;
+  __shared__ double sL[64], sX[64], sR[64], sT[64];
+  TileWork W{sL, sX, sR, sT};
+  const double* adH = B.t_adHost;
+  const double* adT = B.t_adTarget;
+
+  if (m < 2) {
+    const float* acc = B.accum + (m ? acc_off_topL(nf) : acc_off_topA(nf));
+    if (tile < nf2) {
+      const int x = tile % nf, y = tile / nf;  // block row x, block col y
+      double out = 0;
+      auto pairprod = [&](int h, int t, const double* Lm, const double* Rm) {
+        const int aidx = h + nf * t;
+        sL[lane] = Lm[(size_t)aidx * 64 + lane];
+        sR[lane] = Rm[(size_t)aidx * 64 + lane];
+        sX[lane] = acc13(acc + (size_t)aidx * 91, 4 + a, 4 + c);
+        __syncthreads();
+        return lxr(W, a, c);
+      };
+      if (x == y) {
+        for (int t = 0; t < nf; t++) out += pairprod(x, t, adH, adH);   // H[h,h] += AH A AH^T
+        for (int h = 0; h < nf; h++) out += pairprod(h, x, adT, adT);   // H[t,t] += AT A AT^T
+        out += pairprod(x, x, adH, adT);                                // H[h,t] with h==t
+        if (m == 1 && a == c) out += B.t_prior[x * 8 + a];
+      } else {
+        // after the symmetrisation of AccumulatedTopHessian.h:133-147: for lo<hi
+        //   H[lo,hi] = M(lo,hi) + M(hi,lo)^T ;  H[hi,lo] = H[lo,hi]^T,  M(h,t) = AH_ht A_ht AT_ht^T
+        const int lo = x < y ? x : y, hi = x < y ? y : x;
+        const double m1 = pairprod(lo, hi, adH, adT);   // element (a,c) of M(lo,hi)
+        const double m2 = pairprod(hi, lo, adH, adT);   // element (a,c) of M(hi,lo)
+        // need m1[a][c] + m2[c][a] for tile (lo,hi); transpose through LDS
+        sT[a * 8 + c] = m2;
+        __syncthreads();
+        const double up = m1 + sT[c * 8 + a];           // (lo,hi)[a][c]
+        __syncthreads();
+        if (x < y) out = up;
+        else { sT[a * 8 + c] = up; __syncthreads(); out = sT[c * 8 + a]; __syncthreads(); }
+      }
+      H[(size_t)(4 + x * 8 + a) * n + (4 + y * 8 + c)] = out;
+      return;
+    }
+    tile -= nf2;
+    if (tile < nf) {
+      // frame-calib column block and b segment of frame x
+      const int x = tile;
+      // lane -> (a, c4) for c4 < 4 : H[x-rows, calib cols]; lanes with c in 4..7: c==4 -> b
+      double hv = 0;
+      for (int k = 0; k < 2 * nf; k++) {
+        const int h = k < nf ? x : k - nf, t = k < nf ? k : x;
+        const double* Am = (k < nf ? adH : adT) + (size_t)(h + nf * t) * 64;
+        const float* ap = acc + (size_t)(h + nf * t) * 91;
+        if (c < 5) {
+          const int col = c < 4 ? c : 12;
+          double s = 0;
+#pragma unroll
+          for (int kk = 0; kk < 8; kk++) s += Am[a * 8 + kk] * acc13(ap, 4 + kk, col);
+          hv += s;
+        }
+      }
+      if (c < 4) {
+        H[(size_t)(4 + x * 8 + a) * n + c] = hv;
+        H[(size_t)c * n + (4 + x * 8 + a)] = hv;
+      } else if (c == 4) {
+        if (m == 1) hv += B.t_prior[x * 8 + a] * B.t_prior[nf * 8 + x * 8 + a];
+        bvec[4 + x * 8 + a] = hv;
+      }
+      return;
+    }
+    // calib-calib
+    if (lane < 20) {
+      const int r = lane < 16 ? lane >> 2 : lane - 16, col = lane < 16 ? (lane & 3) : 12;
+      double s = 0;
+      for (int p = 0; p < nf2; p++) s += acc13(acc + (size_t)p * 91, r, col);
+      if (lane < 16) {
+        if (m == 1 && r == col) s += B.t_prior[nf * 16 + r];
+        H[(size_t)r * n + col] = s;
+      } else {
+        if (m == 1) s += B.t_prior[nf * 16 + r] * (double)B.t_cdelta[r];
+        bvec[r] = s;
+      }
+    }
+    return;
+  }
+
+  // ---- Schur complement part (AccumulatedSCHessian.cpp:124-186)
+  const float* accD = B.accum + acc_off_D(nf);
+  const float* accE = B.accum + acc_off_E(nf);
+  const float* accEB = B.accum + acc_off_EB(nf);
+  if (tile < nf2) {
+    const int x = tile % nf, y = tile / nf;
+    double out = 0;
+    auto prod = [&](const double* Lm, int li, int lj, int di, int dj, int dk, const double* Rm, int ri, int rj) {
+      sL[lane] = Lm[(size_t)(li + nf * lj) * 64 + lane];
+      sR[lane] = Rm[(size_t)(ri + nf * rj) * 64 + lane];
+      sX[lane] = (double)accD[(size_t)(di + nf * dj + nf2 * dk) * 64 + lane];
+      __syncthreads();
+      return lxr(W, a, c);
+    };
+    if (x == y)
+      for (int j = 0; j < nf; j++)
+        for (int k = 0; k < nf; k++) out += prod(adH, x, j, x, j, k, adH, x, k);      // H[i,i] += AH_ij D_ijk AH_ik^T
+    for (int i = 0; i < nf; i++) out += prod(adT, i, x, i, x, y, adT, i, y);          // H[j,k] += AT_ij D_ijk AT_ik^T  (j=x,k=y)
+    for (int k = 0; k < nf; k++) out += prod(adT, y, x, y, x, k, adH, y, k);          // H[j,i] += AT_ij D_ijk AH_ik^T  (j=x,i=y)
+    for (int j = 0; j < nf; j++) out += prod(adH, x, j, x, j, y, adT, x, y);          // H[i,k] += AH_ij D_ijk AT_ik^T  (i=x,k=y)
+    H[(size_t)(4 + x * 8 + a) * n + (4 + y * 8 + c)] = out;
+    return;
+  }
+  tile -= nf2;
+  if (tile < nf) {
+    const int x = tile;
+    double hv = 0;
+    for (int k = 0; k < 2 * nf; k++) {
+      const int i = k < nf ? x : k - nf, j = k < nf ? k : x;   // pair (i host, j target); frame x is host (AH) or target (AT)
+      const int ij = i + nf * j;
+      const double* Am = (k < nf ? adH : adT) + (size_t)ij * 64;
+      if (c < 5) {
+        double s = 0;
+#pragma unroll
+        for (int kk = 0; kk < 8; kk++) s += Am[a * 8 + kk] * (double)(c < 4 ? accE[(size_t)ij * 32 + kk * 4 + c] : accEB[(size_t)ij * 8 + kk]);
+        hv += s;
+      }
+    }
+    if (c < 4) {
+      H[(size_t)(4 + x * 8 + a) * n + c] = hv;
+      H[(size_t)c * n + (4 + x * 8 + a)] = hv;
+    } else if (c == 4) bvec[4 + x * 8 + a] = hv;
+    return;
+  }
+  if (lane < 20) {
+    const float v = B.accum[acc_off_Hcc(nf) + lane];
+    if (lane < 16) H[(size_t)(lane >> 2) * n + (lane & 3)] = (double)v;
+    else bvec[lane - 16] = (double)v;
+  }
+}
+
+// ------------------------------------------------------------------ solve
+// One workgroup per window.  LDS: HFinal n*n + vectors.  The LDL^T (symmetric pivoting on the largest
+// remaining |diagonal|, like Eigen::LDLT) is executed by wave 0 with the same operation order as the
+// host reference, the other waves help with assembly / scaling / projections.
+__global__ __launch_bounds__(BA_BLOCK) void k_ba_solve(const BaDev* __restrict__ wins, double lambda, int orthogonalize_x) {
+  const BaDev& B = wins[blockIdx.y];
+  const int n = B.n, nf = B.nf;
+  extern __shared__ double sm[];
+  double* A = sm;                 // n*n
+  double* bF = A + n * n;         // n
+  double* sv = bF + n;            // n  SVecI
+  double* yv = sv + n;            // n
+  double* Dg = yv + n;            // n
+  double* xv = Dg + n;            // n
+  int* perm = (int*)(xv + n);     // n
+  const size_t blk = (size_t)n * n + n;
+  const double* HA = B.sol; const double* bA = HA + (size_t)n * n;
+  const double* HL = B.sol + blk; const double* bL = HL + (size_t)n * n;
+  const double* HS = B.sol + 2 * blk; const double* bS = HS + (size_t)n * n;
+  double* xout = B.sol + 3 * blk;
+  double* lastHS = xout + n;
+  double* lastbS = lastHS + (size_t)n * n;
+  const double* delta = B.t_prior + nf * 16 + 4;
+  const int tid = threadIdx.x;
+  const double f = (double)1.0f / (1 + lambda);
+  // bM_top = bM + HM*delta ; HFinal_top = HL + HM + HA ; bFinal = bL + bM_top + bA - b_sc   (:870, :906-907)
+  for (int i = tid; i < n; i += BA_BLOCK) {
+    double s = 0;
+    for (int k = 0; k < n; k++) s += B.t_HM[(size_t)i * n + k] * delta[k];
+    const double bMtop = B.t_bM[i] + s;
+    const double v = bL[i] + bMtop + bA[i] - bS[i];
+    bF[i] = v;
+    lastbS[i] = v;
+  }
+  for (int e = tid; e < n * n; e += BA_BLOCK) {
+    const int i = e / n, j = e % n;
+    double v = HL[e] + B.t_HM[e] + HA[e];
+    lastHS[e] = v - HS[e];                   // :909
+    if (i == j) v *= (1 + lambda);           // :914-916
+    v -= HS[e] * f;                          // :918
+    A[e] = v;
+  }
+  __syncthreads();
+  for (int i = tid; i < n; i += BA_BLOCK) sv[i] = 1.0 / sqrt(A[i * n + i] + 10);   // :967
+  __syncthreads();
+  for (int e = tid; e < n * n; e += BA_BLOCK) { const int i = e / n, j = e % n; A[e] = sv[i] * A[e] * sv[j]; }
+  for (int i = tid; i < n; i += BA_BLOCK) { bF[i] = sv[i] * bF[i]; perm[i] = i; }
+  __syncthreads();
+
+  if (tid < 64) {  // wave 0: factorisation + triangular solves (LDS ops of one wave execute in order)
+    const int lane = tid;
+    for (int k = 0; k < n; k++) {
+      // pivot: first index with the largest |A(i,i)|, i >= k
+      double best = -1.0; int p = k;
+      for (int i = k + lane; i < n; i += 64) { const double v = fabs(A[i * n + i]); if (v > best) { best = v; p = i; } }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const double ob = __shfl_xor(best, o, 64); const int op = __shfl_xor(p, o, 64);
+        if (ob > best || (ob == best && op < p)) { best = ob; p = op; }
+      }
+      if (p != k) {
+        for (int j = lane; j < n; j += 64) { const double t = A[k * n + j]; A[k * n + j] = A[p * n + j]; A[p * n + j] = t; }
+        __builtin_amdgcn_wave_barrier();
+        for (int i = lane; i < n; i += 64) { const double t = A[i * n + k]; A[i * n + k] = A[i * n + p]; A[i * n + p] = t; }
+        if (lane == 0) { const int t = perm[k]; perm[k] = perm[p]; perm[p] = t; }
+      }
+      __builtin_amdgcn_wave_barrier();
+      const double dk = A[k * n + k];
+      if (lane == 0) Dg[k] = dk;
+      if (dk == 0.0) { for (int i = k + 1 + lane; i < n; i += 64) A[i * n + k] = 0; continue; }
+      for (int i = k + 1 + lane; i < n; i += 64) A[i * n + k] = A[i * n + k] / dk;
+      __builtin_amdgcn_wave_barrier();
+      const int rem = n - k - 1;
+      for (int e = lane; e < rem * rem; e += 64) {
+        const int i = k + 1 + e / rem, j = k + 1 + e % rem;
+        if (j <= i) {
+          const double lik = A[i * n + k];
+          if (lik != 0.0) A[i * n + j] -= lik * dk * A[j * n + k];
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      for (int e = lane; e < rem * rem; e += 64) {
+        const int i = k + 1 + e / rem, j = k + 1 + e % rem;
+        if (j > i) A[i * n + j] = A[j * n + i];
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (lane == 0) {  // serial substitutions: n is 68, the data is in LDS
+      for (int i = 0; i < n; i++) yv[i] = bF[perm[i]];
+      for (int i = 0; i < n; i++) { double s = yv[i]; for (int j = 0; j < i; j++) s -= A[i * n + j] * yv[j]; yv[i] = s; }
+      for (int i = 0; i < n; i++) yv[i] = Dg[i] != 0.0 ? yv[i] / Dg[i] : 0.0;
+      for (int i = n - 1; i >= 0; i--) { double s = yv[i]; for (int j = i + 1; j < n; j++) s -= A[j * n + i] * yv[j]; yv[i] = s; }
+      for (int i = 0; i < n; i++) xv[perm[i]] = yv[i];
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < n; i += BA_BLOCK) xv[i] = sv[i] * xv[i];   // x = SVecI * solve(...)  (:976)
+  __syncthreads();
+  if (orthogonalize_x) {  // x -= P x   (:980-984, :824-826)
+    for (int i = tid; i < n; i += BA_BLOCK) {
+      double s = 0;
+      for (int k = 0; k < n; k++) s += B.t_P[(size_t)i * n + k] * xv[k];
+      yv[i] = xv[i] - s;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += BA_BLOCK) xv[i] = yv[i];
+    __syncthreads();
+  }
+  for (int i = tid; i < n; i += BA_BLOCK) xout[i] = xv[i];
+  // xAd[nf*h+t] = xF(h)^T adHostF[h+nf*t] + xF(t)^T adTargetF[h+nf*t]   (:289-291), float arithmetic
+  float* xAd = const_cast<float*>(B.t_xAd);
+  for (int e = tid; e < nf * nf * 8; e += BA_BLOCK) {
+    const int j = e & 7, ht = e >> 3, h = ht / nf, t = ht % nf;
+    const double* AH = B.t_adHost + (size_t)(h + nf * t) * 64;
+    const double* AT = B.t_adTarget + (size_t)(h + nf * t) * 64;
+    float sh = 0, st = 0;
+    for (int i = 0; i < 8; i++) { sh += (float)xv[4 + 8 * h + i] * (float)AH[i * 8 + j]; st += (float)xv[4 + 8 * t + i] * (float)AT[i * 8 + j]; }
+    xAd[e] = sh + st;
+  }
+}
+
+// ------------------------------------------------------------------ back-substitution, one lane per point
+__global__ __launch_bounds__(BA_BLOCK) void k_ba_resub(const BaDev* __restrict__ wins) {
+  const BaDev& B = wins[blockIdx.y];
+  const int p = blockIdx.x * BA_BLOCK + threadIdx.x;
+  if (p >= B.np) return;
+  float* po = B.p_out + (size_t)p * 16;
+  const int cnt = B.p_rcnt[p], beg = B.p_rbeg[p];
+  const double* x = B.sol + 3 * ((size_t)B.n * B.n + B.n);
+  int ngood = 0;
+  for (int s = 0; s < cnt; s++) if (((int)B.r_rec[(size_t)B.p_rlist[beg + s] * 16 + RR_FLAGS]) & 1) ngood++;
+  if (ngood == 0) { po[PO_STEP] = 0; return; }
+  float b = po[PO_BDSUM];
+  float d = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) d += (float)x[k] * (po[PO_HCD_A + k] + po[PO_HCD_L + k]);
+  b -= d;
+  const int h = B.p_host[p];
+  for (int s = 0; s < cnt; s++) {
+    const int ri = B.p_rlist[beg + s];
+    const float* rec = B.r_rec + (size_t)ri * 16;
+    if (!(((int)rec[RR_FLAGS]) & 1)) continue;
+    const float* xa = B.t_xAd + (size_t)(h * B.nf + B.r_target[ri]) * 8;
+    float sacc = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) sacc += xa[k] * rec[k];
+    b -= sacc;
+  }
+  po[PO_STEP] = -b * po[PO_HDI];
+}
+
+// FullSystem::backupState / doStepFromBackup / loadSateBackup for the points.  op: 0 backup, 1 step, 2 restore
+__global__ __launch_bounds__(BA_BLOCK) void k_ba_points_op(const BaDev* __restrict__ wins, int op, float stepfacD, float* __restrict__ sums /* per block: sumID, sumNID */) {
+  const BaDev& B = wins[blockIdx.y];
+  const int p = blockIdx.x * BA_BLOCK + threadIdx.x;
+  float sID = 0, sNID = 0;
+  if (p < B.np) {
+    float* po = B.p_out + (size_t)p * 16;
+    float4 g = B.p_geo[p];
+    if (op == 0) po[PO_BACKUP] = g.z;
+    else if (op == 1) {
+      const float st = po[PO_STEP], bk = po[PO_BACKUP];
+      const float nid = bk + stepfacD * st;
+      g.z = nid; g.w = nid;     // setIdepth + setIdepthZero
+      B.p_geo[p] = g;
+      B.p_delta[p] = nid - nid;
+      sID = st * st; sNID = fabsf(bk);
+    } else {
+      const float bk = po[PO_BACKUP];
+      g.z = bk; g.w = bk;
+      B.p_geo[p] = g;
+      B.p_delta[p] = 0;
+    }
+  }
+  if (sums) {
+    __shared__ float r0[BA_BLOCK / 64], r1[BA_BLOCK / 64];
+    const float a = wave_sum(sID), b = wave_sum(sNID);
+    if ((threadIdx.x & 63) == 0) { r0[threadIdx.x >> 6] = a; r1[threadIdx.x >> 6] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float s0 = 0, s1 = 0;
+      for (int w = 0; w < BA_BLOCK / 64; w++) { s0 += r0[w]; s1 += r1[w]; }
+      sums[blockIdx.x * 2] = s0; sums[blockIdx.x * 2 + 1] = s1;
+    }
+  }
+}
+
+}  // namespace sdso

@@ -80,6 +80,7 @@ extern "C" int sdso_ctx_create(int device_ordinal, sdso_ctx** out) {
 namespace sdso {
 void release_all_windows(sdso_ctx* ctx);
 void release_track_batch(sdso_ctx* ctx);
+void release_trace(sdso_ctx* ctx);
 }
 
 extern "C" void sdso_ctx_destroy(sdso_ctx* ctx) {
@@ -92,6 +93,7 @@ extern "C" void sdso_ctx_destroy(sdso_ctx* ctx) {
     for (int l = 0; l < SDSO_PYR_LEVELS; l++) if (kv.second.pc[l]) hipFree(kv.second.pc[l]);
   release_all_windows(ctx);
   release_track_batch(ctx);
+  release_trace(ctx);
   if (ctx->scratch) hipFree(ctx->scratch);
   if (ctx->pinned) hipHostFree(ctx->pinned);
   hipStreamDestroy(ctx->stream);

@@ -221,8 +221,17 @@ def load():
     L.sdso_ba_optimize.argtypes = [vp, C.c_int, C.c_int, c_double_p, c_float_p, c_u8_p, C.POINTER(BAOptResult)]
     L.sdso_ba_marginalize_points.argtypes = [vp, C.c_int, c_u8_p, c_double_p, c_double_p]
     L.sdso_ba_get_tables.argtypes = [vp, C.c_int, c_float_p, c_double_p, c_double_p, c_float_p]
+    L.sdso_ba_keep_projections.argtypes = [vp, C.c_int, C.c_int]
+    L.sdso_ba_batch_create.argtypes = [vp, C.c_int, c_int_p]
+    L.sdso_ba_batch_accumulate.argtypes = [vp]
+    L.sdso_ba_batch_solve.argtypes = [vp, C.c_double, C.c_int]
+    L.sdso_ba_batch_accum_dev.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_long)]
+    L.sdso_ba_batch_get_x.argtypes = [vp, c_double_p]
     L.sdso_immature_init_batch.argtypes = [vp, C.c_int, C.c_int, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p]
     L.sdso_trace_stereo_batch.argtypes = [vp, C.c_int, c_float_p, C.c_float, C.c_int, C.POINTER(TracePoints), c_u8_p]
+    L.sdso_trace_stereo_prepare.argtypes = [vp, C.c_int, c_float_p, C.c_float, C.c_int, C.POINTER(TracePoints)]
+    L.sdso_trace_stereo_enqueue.argtypes = [vp]
+    L.sdso_trace_stereo_fetch.argtypes = [vp, C.POINTER(TracePoints), c_u8_p]
     _lib = L
     return L
 
@@ -238,7 +247,10 @@ EXPORTED_SYMBOLS = [
     "sdso_ba_apply_res", "sdso_ba_get_residual_state", "sdso_ba_accumulate", "sdso_ba_accum_floats",
     "sdso_ba_accum_dev", "sdso_ba_get_accumulators", "sdso_ba_get_point_terms", "sdso_ba_solve",
     "sdso_ba_get_point_steps", "sdso_ba_optimize", "sdso_ba_marginalize_points", "sdso_ba_get_tables",
-    "sdso_immature_init_batch", "sdso_trace_stereo_batch",
+    "sdso_ba_keep_projections", "sdso_ba_batch_create", "sdso_ba_batch_accumulate", "sdso_ba_batch_solve",
+    "sdso_ba_batch_accum_dev", "sdso_ba_batch_get_x",
+    "sdso_immature_init_batch", "sdso_trace_stereo_batch", "sdso_trace_stereo_prepare", "sdso_trace_stereo_enqueue",
+    "sdso_trace_stereo_fetch",
 ]
 
 

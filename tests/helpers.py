@@ -62,3 +62,23 @@ def oracle_eval(L, pc_l, dI_l, ev, want_mask=True):
     L.orc_track_calc_res_gs(n, abi.fp(u), abi.fp(v), abi.fp(idp), abi.fp(col), abi.fp(img), C.byref(ev), abi.dp(H), abi.dp(b),
                             abi.dp(res), C.byref(nw), abi.bp(mask), None, 0)
     return H.reshape(8, 8), b, res, nw.value, mask[:n]
+
+
+def permuted_window(win, seed):
+    """The same BA window with the points shuffled inside every host group (residuals follow their
+    points).  Mathematically identical problem; only the order of the float sums changes — used to
+    measure the reference arithmetic's own sensitivity to summation order."""
+    rs = np.random.RandomState(seed)
+    order = np.concatenate([rs.permutation(np.nonzero(win["host"] == h)[0]) for h in range(win["nf"])])
+    w2 = dict(win)
+    for k in ("u", "v", "idepth", "idepth_zero", "color", "weights", "host", "hasDepthPrior"):
+        w2[k] = win[k][order]
+    rp, rt = [], []
+    starts = np.searchsorted(win["res_point"], np.arange(win["np"]), side="left")
+    ends = np.searchsorted(win["res_point"], np.arange(win["np"]), side="right")
+    for p_new, p_old in enumerate(order):
+        rp += [p_new] * int(ends[p_old] - starts[p_old])
+        rt += list(win["res_target"][starts[p_old]:ends[p_old]])
+    w2["res_point"] = np.array(rp, np.int32)
+    w2["res_target"] = np.array(rt, np.int32)
+    return w2, order

@@ -1,0 +1,125 @@
+"""Static stereo (BASELINE configs[3]): oracle sanity on CPU, GPU parity through the C-ABI.
+
+traceStereo works per point with a fixed float operation order, so every output — status enum,
+lastTraceUV, the idepth interval, idepth_stereo, quality — must be bit-identical to the CPU path."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from sdso_amd import abi, synth
+
+FIELDS = ("idepth_min_stereo", "idepth_max_stereo", "idepth_stereo", "quality", "lastTraceStatus", "lastTraceUV", "lastTracePixelInterval")
+
+
+@pytest.fixture(scope="module")
+def pair():
+    return synth.stereo_problem(w=640, h=480, npts=3000, seed=4001)
+
+
+def _oracle_init(oracle, pr, img, u, v):
+    n = len(u)
+    col, wgt, gH, eth = np.zeros((n, 8), np.float32), np.zeros((n, 8), np.float32), np.zeros((n, 4), np.float32), np.zeros(n, np.float32)
+    oracle.orc_immature_init_batch(abi.fp(img), pr["w"], pr["h"], n, abi.fp(u), abi.fp(v), abi.fp(col), abi.fp(wgt), abi.fp(gH), abi.fp(eth))
+    return col, wgt, gH, eth
+
+
+def _oracle_trace(oracle, pr, img, P, mode_right):
+    K = np.array(pr["K"], np.float32)
+    st = np.zeros(P.n, np.uint8)
+    oracle.orc_trace_stereo_batch(abi.fp(img), pr["w"], pr["h"], abi.fp(K), float(pr["calib"]["baseline"]), mode_right, C.byref(P), abi.bp(st))
+    return st
+
+
+def test_oracle_trace_recovers_depth(oracle, pair):
+    pr = pair
+    left = np.ascontiguousarray(pr["pyr_l"][0]); right = np.ascontiguousarray(pr["pyr_r"][0])
+    col, wgt, gH, eth = _oracle_init(oracle, pr, left, pr["u"], pr["v"])
+    assert np.isfinite(eth).all() and eth[0] == 8 * 144
+    P, d = abi.make_trace_points(len(pr["u"]), pr["u"], pr["v"], col, wgt, gH, eth)
+    st = _oracle_trace(oracle, pr, right, P, 1)
+    good = st == 0
+    assert good.mean() > 0.5
+    rel = np.abs(d["idepth_stereo"][good] - pr["idepth_true"][good]) / pr["idepth_true"][good]
+    assert np.median(rel) < 0.05                       # sub-pixel disparity -> a few per cent in inverse depth
+    assert set(np.unique(st)) <= {0, 1, 2, 3, 4}
+    # status bookkeeping: a second OUTLIER in a row becomes OOB (ImmaturePoint.cpp:418-421)
+    out = np.nonzero(st == 2)[0]
+    if len(out):
+        P2, d2 = abi.make_trace_points(len(pr["u"]), pr["u"], pr["v"], col, wgt, gH, eth)
+        d2["lastTraceStatus"][:] = 2
+        st2 = _oracle_trace(oracle, pr, right, P2, 1)
+        assert (st2[out] == 1).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size", ["small", "kitti"])
+def test_gpu_trace_bit_exact(gpu_ctx, oracle, pair, size):
+    pr = pair if size == "small" else synth.stereo_problem(w=1232, h=368, npts=20000, seed=4001)     # configs[3]
+    left = np.ascontiguousarray(pr["pyr_l"][0]); right = np.ascontiguousarray(pr["pyr_r"][0])
+    gpu_ctx.upload_pyramid(80, [left]); gpu_ctx.upload_pyramid(81, [right])
+    n = len(pr["u"])
+    co, wo, go, eo = _oracle_init(oracle, pr, left, pr["u"], pr["v"])
+    cg, wg, gg, eg = np.zeros_like(co), np.zeros_like(wo), np.zeros_like(go), np.zeros_like(eo)
+    gpu_ctx.check(gpu_ctx.L.sdso_immature_init_batch(gpu_ctx.h, 80, n, abi.fp(pr["u"]), abi.fp(pr["v"]), abi.fp(cg), abi.fp(wg), abi.fp(gg), abi.fp(eg)))
+    assert np.array_equal(co, cg) and np.array_equal(wo, wg) and np.array_equal(go, gg) and np.array_equal(eo, eg)
+    K = np.array(pr["K"], np.float32)
+    bl = float(pr["calib"]["baseline"])
+    # L -> R, fresh points (idepth_max = NaN: full 0.027*(w+h) pixel search)
+    Po, do = abi.make_trace_points(n, pr["u"], pr["v"], co, wo, go, eo)
+    Pg, dg = abi.make_trace_points(n, pr["u"], pr["v"], co, wo, go, eo)
+    so = _oracle_trace(oracle, pr, right, Po, 1)
+    sg = np.zeros(n, np.uint8)
+    gpu_ctx.check(gpu_ctx.L.sdso_trace_stereo_batch(gpu_ctx.h, 81, abi.fp(K), bl, 1, C.byref(Pg), abi.bp(sg)))
+    assert np.array_equal(so, sg)
+    for k in FIELDS:
+        assert np.array_equal(do[k], dg[k], equal_nan=True), k
+    assert (so == 0).mean() > 0.5
+    # R -> L back-trace from the traced position with a finite interval (FullSystem.cpp:590-600 stereoMatch)
+    good = np.nonzero(so == 0)[0]
+    ub, vb = do["lastTraceUV"][good, 0].copy(), do["lastTraceUV"][good, 1].copy()
+    inb = (ub > 6) & (vb > 6) & (ub < pr["w"] - 7) & (vb < pr["h"] - 7)
+    ub, vb, good = ub[inb], vb[inb], good[inb]
+    c2, w2, g2, e2 = _oracle_init(oracle, pr, right, ub, vb)
+    imin = (do["idepth_stereo"][good] * 0.1).astype(np.float32); imax = (do["idepth_stereo"][good] * 1.9).astype(np.float32)
+    Po2, do2 = abi.make_trace_points(len(ub), ub, vb, c2, w2, g2, e2, imin, imax)
+    Pg2, dg2 = abi.make_trace_points(len(ub), ub, vb, c2, w2, g2, e2, imin, imax)
+    so2 = _oracle_trace(oracle, pr, left, Po2, 0)
+    sg2 = np.zeros(len(ub), np.uint8)
+    gpu_ctx.check(gpu_ctx.L.sdso_trace_stereo_batch(gpu_ctx.h, 80, abi.fp(K), bl, 0, C.byref(Pg2), abi.bp(sg2)))
+    assert np.array_equal(so2, sg2)
+    for k in FIELDS:
+        assert np.array_equal(do2[k], dg2[k], equal_nan=True), k
+    ok = so2 == 0
+    assert ok.mean() > 0.5
+    assert np.median(np.abs(do2["lastTraceUV"][ok, 0] - pr["u"][good][ok])) < 1.0      # left-right consistency
+
+
+@pytest.mark.gpu
+def test_gpu_trace_edge_cases(gpu_ctx, oracle, pair):
+    pr = pair
+    left = np.ascontiguousarray(pr["pyr_l"][0]); right = np.ascontiguousarray(pr["pyr_r"][0])
+    gpu_ctx.upload_pyramid(81, [right])
+    K = np.array(pr["K"], np.float32)
+    bl = float(pr["calib"]["baseline"])
+    # points at the border (OOB at once), at the far right (search leaves the image), with tiny and huge intervals (SKIPPED / BADCONDITION)
+    u = np.array([5.0, 630.0, 320.0, 320.0, 320.0, 100.0, 5.5, 300.0], np.float32)
+    v = np.array([240.0, 240.0, 6.0, 240.0, 240.0, 470.0, 5.5, 200.0], np.float32)
+    col, wgt, gH, eth = _oracle_init(oracle, pr, left, u, v)
+    imin = np.array([0, 0, 0, 0.05, 0.01, 0, 0, 0.02], np.float32)
+    imax = np.array([np.nan, np.nan, np.nan, 0.0501, 0.2, np.nan, np.nan, 0.0232], np.float32)
+    for prev in (5, 2):
+        Po, do = abi.make_trace_points(len(u), u, v, col, wgt, gH, eth, imin, imax)
+        Pg, dg = abi.make_trace_points(len(u), u, v, col, wgt, gH, eth, imin, imax)
+        do["lastTraceStatus"][:] = prev; dg["lastTraceStatus"][:] = prev
+        so = _oracle_trace(oracle, pr, right, Po, 1)
+        sg = np.zeros(len(u), np.uint8)
+        gpu_ctx.check(gpu_ctx.L.sdso_trace_stereo_batch(gpu_ctx.h, 81, abi.fp(K), bl, 1, C.byref(Pg), abi.bp(sg)))
+        assert np.array_equal(so, sg)
+        for k in FIELDS:
+            assert np.array_equal(do[k], dg[k], equal_nan=True), k
+        assert 1 in so and 3 in so
+    # n = 0 and an unknown slot
+    P0, d0 = abi.make_trace_points(0, u[:0], v[:0], col[:0], wgt[:0], gH[:0], eth[:0])
+    gpu_ctx.check(gpu_ctx.L.sdso_trace_stereo_batch(gpu_ctx.h, 81, abi.fp(K), bl, 1, C.byref(P0), None))
+    assert gpu_ctx.L.sdso_trace_stereo_batch(gpu_ctx.h, 999, abi.fp(K), bl, 1, C.byref(P0), None) == -1

@@ -38,7 +38,8 @@ def _cmp_eval(ctx, oracle, prob, prm, lvl, T, aff, repeat=1.0, ref_slot=1, new_s
     ctx.check(ctx.L.sdso_track_calc_res_gs(ctx.h, ref_slot, new_slot, C.byref(ev), abi.dp(H), abi.dp(b), abi.dp(res), C.byref(nw), abi.bp(mask)))
     H = H.reshape(8, 8)
     assert np.array_equal(mask, masko)
-    assert nw.value == nwo and res[1] == reso[1] and res[5] == reso[5]
+    assert nw.value == nwo and res[1] == reso[1]
+    assert res[5] == reso[5] or (np.isnan(res[5]) and np.isnan(reso[5]))   # 0/0 when nothing is in bounds, like the reference
     assert abs(res[0] - reso[0]) <= 2e-5 * abs(reso[0])
     assert np.allclose(res[2:5], reso[2:5], rtol=1e-4, atol=1e-7)
     assert np.abs(H - Ho).max() <= 2e-5 * np.abs(Ho).max()
