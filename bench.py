@@ -114,7 +114,56 @@ class TrackerWorkload:
                 "sample": "%d full-pyramid evaluations of one problem (%d points) in %.1f s, oracle -O3 -march=native" % (reps, pts, dt)}
 
 
-WORKLOADS = {"tracker": TrackerWorkload}
+class TraceWorkload:
+    """configs[3]: ImmaturePoint::traceStereo, ~20k fresh immature points on a KITTI-shaped stereo pair."""
+    name = "trace_stereo_kitti1232x368_20kpts"
+    kernel = "k_trace_stereo"
+    unit = "points/s"
+    # SURVEY §8d: 100 B in + 32 B out per point + every touched image pixel once (whole L0 image, 12 B/px)
+    bytes_per_unit = 132.0 + 1232 * 368 * 12.0 / 20000.0
+
+    def __init__(self, ctx, args, rank):
+        from sdso_amd import abi, synth
+        self.ctx, self.abi = ctx, abi
+        pr = synth.stereo_problem(w=1232, h=368, npts=args.batch or 20000, seed=4001 + rank)
+        self.pr = pr
+        left = np.ascontiguousarray(pr["pyr_l"][0]); right = np.ascontiguousarray(pr["pyr_r"][0])
+        ctx.upload_pyramid(80, [left]); ctx.upload_pyramid(81, [right])
+        n = len(pr["u"])
+        col, wgt, gH, eth = np.zeros((n, 8), np.float32), np.zeros((n, 8), np.float32), np.zeros((n, 4), np.float32), np.zeros(n, np.float32)
+        ctx.check(ctx.L.sdso_immature_init_batch(ctx.h, 80, n, abi.fp(pr["u"]), abi.fp(pr["v"]), abi.fp(col), abi.fp(wgt), abi.fp(gH), abi.fp(eth)))
+        self.P, self.d = abi.make_trace_points(n, pr["u"], pr["v"], col, wgt, gH, eth)
+        self.K = np.array(pr["K"], np.float32)
+        ctx.check(ctx.L.sdso_trace_stereo_prepare(ctx.h, 81, abi.fp(self.K), float(pr["calib"]["baseline"]), 1, C.byref(self.P)))
+        self.units_per_step = n
+        self.config = {"workload": self.name, "points": n, "search_steps_per_point": 45, "parallelism": "replicas"}
+        self.init = (col, wgt, gH, eth)
+
+    def step(self):
+        self.ctx.check(self.ctx.L.sdso_trace_stereo_enqueue(self.ctx.h))
+
+    def verify(self):
+        st = np.zeros(self.P.n, np.uint8)
+        self.ctx.check(self.ctx.L.sdso_trace_stereo_fetch(self.ctx.h, C.byref(self.P), self.abi.bp(st)))
+        return {"good_fraction": float((st == 0).mean())}
+
+    def cpu_baseline(self, budget_s=10.0):
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import pyoracle  # cpu_baseline leg only
+        abi, pr = self.abi, self.pr
+        orc = pyoracle.load(fast=True)
+        right = np.ascontiguousarray(pr["pyr_r"][0])
+        n, t0, pts = len(pr["u"]), time.perf_counter(), 0
+        while time.perf_counter() - t0 < budget_s:
+            P, d = abi.make_trace_points(n, pr["u"], pr["v"], *self.init)
+            st = np.zeros(n, np.uint8)
+            orc.orc_trace_stereo_batch(abi.fp(right), pr["w"], pr["h"], abi.fp(self.K), float(pr["calib"]["baseline"]), 1, C.byref(P), abi.bp(st))
+            pts += n
+        dt = time.perf_counter() - t0
+        return {"value": pts / dt, "unit": self.unit, "cores": 1, "kind": "port", "sample": "%d points traced in %.1f s, oracle -O3 -march=native" % (pts, dt)}
+
+
+WORKLOADS = {"tracker": TrackerWorkload, "trace": TraceWorkload}
 
 
 def main():
@@ -122,7 +171,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default=os.environ.get("SDSO_BENCH_WORKLOAD", "tracker"))
+    ap.add_argument("--workload", default=os.environ.get("SDSO_BENCH_WORKLOAD", "ba"), choices=["ba", "tracker", "trace"])
     ap.add_argument("--batch", type=int, default=0, help="independent problems (frames / windows / pairs) per step and GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -195,6 +244,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = wl.cpu_baseline()
             out["extra"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        if args.workload == "ba":
+            out["extra"]["ba_window_iters_per_s"] = wl.nwin * world * args.steps / dt
         print(json.dumps(out), flush=True)
     ctx.close()
     if world > 1:

@@ -276,7 +276,7 @@ def tracker_problem(w=1232, h=368, npts=2000, seed=2002, scene_seed=1001,
 
 
 def ba_window(w=1232, h=368, nf=8, pts_per_kf=250, seed=3001, scene_seed=1001, step_z=0.8,
-              rot_jitter=0.01, idepth_noise=0.03, state_noise=1e-3, max_res_per_point=7):
+              rot_jitter=0.01, idepth_noise=0.03, state_noise=1e-3, max_res_per_point=7, point_seed=None):
     """nf keyframes on a forward trajectory, pts_per_kf points hosted per KF, a residual
     to every other KF in which the whole 8-pixel pattern projects inside the image.
     Returns a dict of numpy arrays laid out like sdso_ba_window_t plus the rendered level-0 pyramids."""
@@ -325,9 +325,13 @@ def ba_window(w=1232, h=368, nf=8, pts_per_kf=250, seed=3001, scene_seed=1001, s
     res_point, res_target = [], []
     c2 = np.float32(50 * 50)
     for k in range(nf):
-        u, v = select_points(pyrs[k][0], pts_per_kf, seed + 500 + k, idepth=idmaps[k], min_idepth=0.0075)
+        # point_seed decouples the point draw from the frame draw: ranks of a sharded window share the
+        # frames (same seed) and own disjoint point sets (different point_seed)
+        pseed = seed if point_seed is None else point_seed
+        u, v = select_points(pyrs[k][0], pts_per_kf, pseed + 500 + k, idepth=idmaps[k], min_idepth=0.0075)
         idp_true = idmaps[k][v, u].astype(np.float64)
-        idp = (idp_true * (1 + rs.normal(0, idepth_noise, len(u)))).astype(np.float32)
+        prs = rs if point_seed is None else np.random.RandomState(pseed + 900 + k)
+        idp = (idp_true * (1 + prs.normal(0, idepth_noise, len(u)))).astype(np.float32)
         dI = pyrs[k][0]
         for i in range(len(u)):
             pi = len(us)
