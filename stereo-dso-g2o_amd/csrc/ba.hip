@@ -62,6 +62,7 @@ static void free_window(BaWindowDev* W) {
 }
 struct BaLaunch {
   const BaDev* d_arr; int nwin; int max_nblk_res, max_nblk_pts, max_chunks, max_items, nf, n;
+  bool any_lin;   // some window holds linearized residuals -> the mode-1 accumulation has work to do
 };
 struct BaBatch {
   std::vector<int> wins;
@@ -334,24 +335,38 @@ static void launch_accumulate(sdso_ctx* ctx, const BaLaunch& L, const uint8_t* p
     if (!marg) {
       { ProfScope ps(ctx, "k_ba_accum_top"); hipLaunchKernelGGL(k_ba_accum_top, dim3(L.max_chunks, L.nwin), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr, 0, (const uint8_t*)nullptr); }
       hipLaunchKernelGGL(k_ba_fold_top, dim3(nf * nf, L.nwin), dim3(128), 0, ctx->stream, L.d_arr, 0);
-      hipLaunchKernelGGL(k_ba_accum_top, dim3(L.max_chunks, L.nwin), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr, 1, (const uint8_t*)nullptr);
-      hipLaunchKernelGGL(k_ba_fold_top, dim3(nf * nf, L.nwin), dim3(128), 0, ctx->stream, L.d_arr, 1);
+      if (L.any_lin) {
+        hipLaunchKernelGGL(k_ba_accum_top, dim3(L.max_chunks, L.nwin), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr, 1, (const uint8_t*)nullptr);
+        hipLaunchKernelGGL(k_ba_fold_top, dim3(nf * nf, L.nwin), dim3(128), 0, ctx->stream, L.d_arr, 1);
+      } else {
+        // accumulateLF_MT over zero linearized residuals: only the priors survive (added in the stitch)
+        hipLaunchKernelGGL(k_ba_zero_topL, dim3(nf * nf, L.nwin), dim3(128), 0, ctx->stream, L.d_arr);
+      }
     } else {
       hipLaunchKernelGGL(k_ba_accum_top, dim3(L.max_chunks, L.nwin), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr, 2, pflag);
       hipLaunchKernelGGL(k_ba_fold_top, dim3(nf * nf, L.nwin), dim3(128), 0, ctx->stream, L.d_arr, 0);
     }
   }
-  const size_t lds = sizeof(float) * (BA_BLOCK / 64) * (size_t)(nf * nf * 64 + nf * 32 + nf * 8);
   if (L.max_items > 0) {
     ProfScope ps(ctx, "k_ba_sc");
-    hipLaunchKernelGGL(k_ba_sc, dim3((L.max_items + BA_BLOCK / 64 - 1) / (BA_BLOCK / 64), L.nwin), dim3(BA_BLOCK), lds, ctx->stream, L.d_arr, pflag, marg ? 0 : 1, marg ? 1 : 0);
+    const dim3 grid((L.max_items + BA_BLOCK / 64 - 1) / (BA_BLOCK / 64), L.nwin), blk(BA_BLOCK);
+    const int shift = marg ? 0 : 1, mm = marg ? 1 : 0;
+    switch (nf) {
+#define SC_CASE(N) case N: hipLaunchKernelGGL(k_ba_sc_reg<N>, grid, blk, 0, ctx->stream, L.d_arr, pflag, shift, mm); break;
+      SC_CASE(1) SC_CASE(2) SC_CASE(3) SC_CASE(4) SC_CASE(5) SC_CASE(6) SC_CASE(7) SC_CASE(8)
+#undef SC_CASE
+      default: {
+        const size_t lds = sizeof(float) * (BA_BLOCK / 64) * (size_t)(nf * nf * 64 + nf * 32 + nf * 8);
+        hipLaunchKernelGGL(k_ba_sc, grid, blk, lds, ctx->stream, L.d_arr, pflag, shift, mm);
+      }
+    }
   }
   hipLaunchKernelGGL(k_ba_fold_sc, dim3(nf * nf * nf + nf * nf + 1, L.nwin), dim3(64), 0, ctx->stream, L.d_arr);
 }
 static void launch_solve(sdso_ctx* ctx, const BaLaunch& L, double lambda, int orth) {
   const int nf = L.nf, n = L.n;
   hipLaunchKernelGGL(k_ba_stitch, dim3(3 * (nf * nf + nf + 1), L.nwin), dim3(64), 0, ctx->stream, L.d_arr);
-  const size_t lds = sizeof(double) * ((size_t)n * n + 5 * n) + sizeof(int) * n;
+  const size_t lds = sizeof(double) * ((size_t)n * (n + 1) + 5 * n) + sizeof(int) * n;
   hipLaunchKernelGGL(k_ba_solve, dim3(1, L.nwin), dim3(BA_BLOCK), lds, ctx->stream, L.d_arr, lambda, orth);
   if (L.max_nblk_pts > 0) hipLaunchKernelGGL(k_ba_resub, dim3(L.max_nblk_pts, L.nwin), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr);
 }
@@ -359,6 +374,7 @@ static BaLaunch single(BaWindowDev* W) {
   BaLaunch L;
   L.d_arr = W->d_self; L.nwin = 1; L.max_nblk_res = std::max(W->nblk_res, 1); L.max_nblk_pts = W->nblk_pts;
   L.max_chunks = W->d.nchunks; L.max_items = W->d.nitems; L.nf = W->d.nf; L.n = W->d.n;
+  L.any_lin = std::any_of(W->h_lin.begin(), W->h_lin.end(), [](uint8_t v) { return v != 0; });
   return L;
 }
 
@@ -743,6 +759,7 @@ extern "C" int sdso_ba_batch_create(sdso_ctx* ctx, int nwin, const int* wins) {
     SDSO_HIP(ctx, hipMemcpyAsync(W->d_self, &W->d, sizeof(BaDev), hipMemcpyHostToDevice, ctx->stream));
     L.max_nblk_res = std::max(L.max_nblk_res, std::max(W->nblk_res, 1)); L.max_nblk_pts = std::max(L.max_nblk_pts, W->nblk_pts);
     L.max_chunks = std::max(L.max_chunks, W->d.nchunks); L.max_items = std::max(L.max_items, W->d.nitems);
+    L.any_lin = L.any_lin || std::any_of(W->h_lin.begin(), W->h_lin.end(), [](uint8_t v) { return v != 0; });
     W->accumulated = true;
   }
   SDSO_HIP(ctx, hipMemcpyAsync(Bt->d_arr, h.data(), sizeof(BaDev) * nwin, hipMemcpyHostToDevice, ctx->stream));

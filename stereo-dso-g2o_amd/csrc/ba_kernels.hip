@@ -399,6 +399,14 @@ __global__ __launch_bounds__(128) void k_ba_fold_top(const BaDev* __restrict__ w
   }
 }
 
+__global__ __launch_bounds__(128) void k_ba_zero_topL(const BaDev* __restrict__ wins) {
+  const BaDev& B = wins[blockIdx.y];
+  const int pair = blockIdx.x;
+  if (pair >= B.nf * B.nf) return;
+  if (threadIdx.x < 91) B.accum[acc_off_topL(B.nf) + (size_t)pair * 91 + threadIdx.x] = 0.f;
+  if (pair == 0 && threadIdx.x == 127) B.accum[acc_off_nres(B.nf) + 1] = 0.f;
+}
+
 // ------------------------------------------------------------------ per-point Schur accumulation
 // One wave per item (= up to BA_SC_PTS consecutive points of ONE host).  Lane (a,c)=(lane>>3,lane&7)
 // owns element (a,c) of every 8x8 D block; the item's nf x nf D tiles live in LDS.
@@ -500,6 +508,106 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_sc(const BaDev* __restrict__ wi
   // flush this item's partial tiles
   float* out = B.sc_part + (size_t)item * sc_part_floats(nf);
   for (int k = lane; k < per_wave; k += 64) out[k] = D[k];
+  if (lane < 16) out[per_wave + lane] = hcc;
+  if (lane < 4) out[per_wave + 16 + lane] = bcv;
+}
+
+// Register-tile variant for nf known at compile time (nf <= 8): lane (a,c) keeps its element of all
+// NF x NF D tiles in VGPRs; a point's residual vectors are first scattered to per-TARGET slots (a point
+// has at most one residual per target), so the tile index is a compile-time constant and targets
+// without a residual add an exact +0.  Same accumulation order per tile as the LDS variant.
+template <int NF>
+__global__ __launch_bounds__(BA_BLOCK) void k_ba_sc_reg(const BaDev* __restrict__ wins, const uint8_t* __restrict__ pflag, int shiftPriorToZero, int margMode) {
+  const BaDev& B = wins[blockIdx.y];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int item = blockIdx.x * (BA_BLOCK / 64) + wv;
+  if (item >= B.nitems) return;
+  const int4 it = B.items[item];
+  const int la = lane >> 3, lc = lane & 7, le = (lane >> 2) & 7;
+  float D[NF][NF], E[NF], EB[NF];
+#pragma unroll
+  for (int i = 0; i < NF; i++) {
+    E[i] = 0.f; EB[i] = 0.f;
+#pragma unroll
+    for (int j = 0; j < NF; j++) D[i][j] = 0.f;
+  }
+  float hcc = 0.f, bcv = 0.f;
+  for (int p = it.y; p < it.z; p++) {
+    if (pflag && !pflag[p]) continue;
+    const int cnt = B.p_rcnt[p], beg = B.p_rbeg[p];
+    float* po = B.p_out + (size_t)p * 16;
+    float JaT[NF], JcT[NF], JeT[NF];
+    bool has[NF];
+#pragma unroll
+    for (int t = 0; t < NF; t++) { JaT[t] = 0.f; JcT[t] = 0.f; JeT[t] = 0.f; has[t] = false; }
+    float Hdd_A = 0, bd_A = 0, Hdd_L = 0, bd_L = 0, HcdA[4] = {0, 0, 0, 0}, HcdL[4] = {0, 0, 0, 0};
+    int ngood = 0;
+#pragma unroll
+    for (int s = 0; s < 8; s++) {
+      if (s < cnt) {
+        const int ri = __builtin_amdgcn_readfirstlane(B.p_rlist[beg + s]);
+        const float* rec = B.r_rec + (size_t)ri * 16;
+        const int fl = (int)rec[RR_FLAGS];
+        if (fl & 1) {
+          ngood++;
+          const int tg = __builtin_amdgcn_readfirstlane((int)B.r_target[ri]);
+          const float ja = rec[la], jc = rec[lc], je = rec[le];
+#pragma unroll
+          for (int t = 0; t < NF; t++)
+            if (t == tg) { JaT[t] = ja; JcT[t] = jc; JeT[t] = je; has[t] = true; }
+          if (!(fl & 2) && !margMode) {
+            bd_A += rec[RR_BD]; Hdd_A += rec[RR_HDD];
+#pragma unroll
+            for (int k = 0; k < 4; k++) HcdA[k] += rec[RR_HCD + k];
+          } else {
+            bd_L += rec[RR_BD]; Hdd_L += rec[RR_HDD];
+#pragma unroll
+            for (int k = 0; k < 4; k++) HcdL[k] += rec[RR_HCD + k];
+          }
+        }
+      }
+    }
+    float HdiF = 0, bdSumF = 0;
+    float Hcd[4] = {0, 0, 0, 0};
+    if (ngood > 0) {
+      float H = Hdd_A + Hdd_L + B.p_prior[p];
+      if (H < 1e-10) H = 1e-10;
+      HdiF = 1.0 / H;
+      bdSumF = bd_A + bd_L;
+      if (shiftPriorToZero) bdSumF += B.p_prior[p] * B.p_delta[p];
+#pragma unroll
+      for (int k = 0; k < 4; k++) Hcd[k] = HcdA[k] + HcdL[k];
+    }
+    if (lane == 0) {
+      *(float4*)(po + 0) = make_float4(Hdd_A, bd_A, HcdA[0], HcdA[1]);
+      *(float4*)(po + 4) = make_float4(HcdA[2], HcdA[3], Hdd_L, bd_L);
+      *(float4*)(po + 8) = make_float4(HcdL[0], HcdL[1], HcdL[2], HcdL[3]);
+      po[PO_HDI] = HdiF; po[PO_BDSUM] = bdSumF;
+    }
+    if (ngood == 0) continue;
+    if (lane < 16) hcc += (HdiF * Hcd[lane >> 2]) * Hcd[lane & 3];
+    if (lane < 4) bcv += (bdSumF * HdiF) * Hcd[lane];
+    const float hb = HdiF * bdSumF;
+    const float hc = Hcd[lane & 3];
+#pragma unroll
+    for (int t1 = 0; t1 < NF; t1++) {
+      if (!has[t1]) continue;   // wave-uniform: targets without a residual contribute exact zeros
+      const float wl = HdiF * JaT[t1];
+#pragma unroll
+      for (int t2 = 0; t2 < NF; t2++) D[t1][t2] = D[t1][t2] + wl * JcT[t2];
+      E[t1] = E[t1] + (HdiF * JeT[t1]) * hc;
+      EB[t1] = EB[t1] + hb * JcT[t1];
+    }
+  }
+  float* out = B.sc_part + (size_t)item * sc_part_floats(NF);
+#pragma unroll
+  for (int t1 = 0; t1 < NF; t1++) {
+#pragma unroll
+    for (int t2 = 0; t2 < NF; t2++) out[(t1 * NF + t2) * 64 + lane] = D[t1][t2];
+    if (lane < 32) out[NF * NF * 64 + t1 * 32 + lane] = E[t1];
+    if (lane < 8) out[NF * NF * 64 + NF * 32 + t1 * 8 + lane] = EB[t1];
+  }
+  const int per_wave = NF * NF * 64 + NF * 32 + NF * 8;
   if (lane < 16) out[per_wave + lane] = hcc;
   if (lane < 4) out[per_wave + 16 + lane] = bcv;
 }

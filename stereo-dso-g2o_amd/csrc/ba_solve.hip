@@ -222,20 +222,23 @@ __global__ __launch_bounds__(64) void k_ba_stitch(const BaDev* __restrict__ wins
 }
 
 // ------------------------------------------------------------------ solve
-// One workgroup per window.  LDS: HFinal n*n + vectors.  The LDL^T (symmetric pivoting on the largest
-// remaining |diagonal|, like Eigen::LDLT) is executed by wave 0 with the same operation order as the
-// host reference, the other waves help with assembly / scaling / projections.
+// One 256-thread workgroup per window; the (8nf+4)^2 system lives in LDS (row stride n+1: conflict-free
+// column walks).  LDL^T with symmetric pivoting on the largest remaining |diagonal| (the strategy of
+// Eigen::LDLT, EnergyFunctional.cpp:976), same arithmetic per element as the host reference; the
+// rank-1 updates are spread over a 16x16 thread grid and keep the matrix symmetric in place, the
+// triangular solves run on wave 0 with the unknowns in registers.
 __global__ __launch_bounds__(BA_BLOCK) void k_ba_solve(const BaDev* __restrict__ wins, double lambda, int orthogonalize_x) {
   const BaDev& B = wins[blockIdx.y];
-  const int n = B.n, nf = B.nf;
+  const int n = B.n, nf = B.nf, ld = n + 1;
   extern __shared__ double sm[];
-  double* A = sm;                 // n*n
-  double* bF = A + n * n;         // n
+  double* A = sm;                 // n*(n+1)
+  double* bF = A + n * ld;        // n
   double* sv = bF + n;            // n  SVecI
   double* yv = sv + n;            // n
   double* Dg = yv + n;            // n
   double* xv = Dg + n;            // n
   int* perm = (int*)(xv + n);     // n
+  __shared__ int s_p;
   const size_t blk = (size_t)n * n + n;
   const double* HA = B.sol; const double* bA = HA + (size_t)n * n;
   const double* HL = B.sol + blk; const double* bL = HL + (size_t)n * n;
@@ -244,7 +247,7 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_solve(const BaDev* __restrict__
   double* lastHS = xout + n;
   double* lastbS = lastHS + (size_t)n * n;
   const double* delta = B.t_prior + nf * 16 + 4;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const double f = (double)1.0f / (1 + lambda);
   // bM_top = bM + HM*delta ; HFinal_top = HL + HM + HA ; bFinal = bL + bM_top + bA - b_sc   (:870, :906-907)
   for (int i = tid; i < n; i += BA_BLOCK) {
@@ -256,65 +259,79 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_solve(const BaDev* __restrict__
     lastbS[i] = v;
   }
   for (int e = tid; e < n * n; e += BA_BLOCK) {
-    const int i = e / n, j = e % n;
+    const int i = e / n, j = e - i * n;
     double v = HL[e] + B.t_HM[e] + HA[e];
     lastHS[e] = v - HS[e];                   // :909
     if (i == j) v *= (1 + lambda);           // :914-916
     v -= HS[e] * f;                          // :918
-    A[e] = v;
+    A[i * ld + j] = v;
   }
   __syncthreads();
-  for (int i = tid; i < n; i += BA_BLOCK) sv[i] = 1.0 / sqrt(A[i * n + i] + 10);   // :967
+  for (int i = tid; i < n; i += BA_BLOCK) sv[i] = 1.0 / sqrt(A[i * ld + i] + 10);   // :967
   __syncthreads();
-  for (int e = tid; e < n * n; e += BA_BLOCK) { const int i = e / n, j = e % n; A[e] = sv[i] * A[e] * sv[j]; }
+  for (int e = tid; e < n * n; e += BA_BLOCK) { const int i = e / n, j = e - i * n; A[i * ld + j] = sv[i] * A[i * ld + j] * sv[j]; }
   for (int i = tid; i < n; i += BA_BLOCK) { bF[i] = sv[i] * bF[i]; perm[i] = i; }
   __syncthreads();
 
-  if (tid < 64) {  // wave 0: factorisation + triangular solves (LDS ops of one wave execute in order)
-    const int lane = tid;
-    for (int k = 0; k < n; k++) {
-      // pivot: first index with the largest |A(i,i)|, i >= k
+  const int ti = tid >> 4, tj = tid & 15;
+  for (int k = 0; k < n; k++) {
+    if (wv == 0) {  // pivot: first index with the largest |A(i,i)|, i >= k
       double best = -1.0; int p = k;
-      for (int i = k + lane; i < n; i += 64) { const double v = fabs(A[i * n + i]); if (v > best) { best = v; p = i; } }
+      for (int i = k + lane; i < n; i += 64) { const double v = fabs(A[i * ld + i]); if (v > best) { best = v; p = i; } }
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) {
         const double ob = __shfl_xor(best, o, 64); const int op = __shfl_xor(p, o, 64);
         if (ob > best || (ob == best && op < p)) { best = ob; p = op; }
       }
-      if (p != k) {
-        for (int j = lane; j < n; j += 64) { const double t = A[k * n + j]; A[k * n + j] = A[p * n + j]; A[p * n + j] = t; }
-        __builtin_amdgcn_wave_barrier();
-        for (int i = lane; i < n; i += 64) { const double t = A[i * n + k]; A[i * n + k] = A[i * n + p]; A[i * n + p] = t; }
-        if (lane == 0) { const int t = perm[k]; perm[k] = perm[p]; perm[p] = t; }
-      }
-      __builtin_amdgcn_wave_barrier();
-      const double dk = A[k * n + k];
-      if (lane == 0) Dg[k] = dk;
-      if (dk == 0.0) { for (int i = k + 1 + lane; i < n; i += 64) A[i * n + k] = 0; continue; }
-      for (int i = k + 1 + lane; i < n; i += 64) A[i * n + k] = A[i * n + k] / dk;
-      __builtin_amdgcn_wave_barrier();
-      const int rem = n - k - 1;
-      for (int e = lane; e < rem * rem; e += 64) {
-        const int i = k + 1 + e / rem, j = k + 1 + e % rem;
-        if (j <= i) {
-          const double lik = A[i * n + k];
-          if (lik != 0.0) A[i * n + j] -= lik * dk * A[j * n + k];
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
-      for (int e = lane; e < rem * rem; e += 64) {
-        const int i = k + 1 + e / rem, j = k + 1 + e % rem;
-        if (j > i) A[i * n + j] = A[j * n + i];
-      }
-      __builtin_amdgcn_wave_barrier();
+      if (lane == 0) s_p = p;
     }
-    if (lane == 0) {  // serial substitutions: n is 68, the data is in LDS
-      for (int i = 0; i < n; i++) yv[i] = bF[perm[i]];
-      for (int i = 0; i < n; i++) { double s = yv[i]; for (int j = 0; j < i; j++) s -= A[i * n + j] * yv[j]; yv[i] = s; }
-      for (int i = 0; i < n; i++) yv[i] = Dg[i] != 0.0 ? yv[i] / Dg[i] : 0.0;
-      for (int i = n - 1; i >= 0; i--) { double s = yv[i]; for (int j = i + 1; j < n; j++) s -= A[j * n + i] * yv[j]; yv[i] = s; }
-      for (int i = 0; i < n; i++) xv[perm[i]] = yv[i];
+    __syncthreads();
+    const int p = s_p;
+    if (p != k) {
+      if (tid < n) { const double t = A[k * ld + tid]; A[k * ld + tid] = A[p * ld + tid]; A[p * ld + tid] = t; }
+      __syncthreads();
+      if (tid < n) { const double t = A[tid * ld + k]; A[tid * ld + k] = A[tid * ld + p]; A[tid * ld + p] = t; }
+      if (tid == 0) { const int t = perm[k]; perm[k] = perm[p]; perm[p] = t; }
+      __syncthreads();
     }
+    const double dk = A[k * ld + k];
+    if (tid == 0) Dg[k] = dk;
+    if (dk == 0.0) {
+      for (int i = k + 1 + tid; i < n; i += BA_BLOCK) A[i * ld + k] = 0;
+      __syncthreads();
+      continue;
+    }
+    for (int i = k + 1 + tid; i < n; i += BA_BLOCK) A[i * ld + k] = A[i * ld + k] / dk;
+    __syncthreads();
+    for (int i = k + 1 + ti; i < n; i += 16) {
+      const double lik = A[i * ld + k];
+      if (lik == 0.0) continue;
+      const double ld_ = lik * dk;
+      for (int j = k + 1 + tj; j <= i; j += 16) {
+        const double v = A[i * ld + j] - ld_ * A[j * ld + k];
+        A[i * ld + j] = v;
+        A[j * ld + i] = v;   // keep the trailing block symmetric (the reference mirrors after every step)
+      }
+    }
+    __syncthreads();
+  }
+  if (wv == 0) {  // triangular solves: lane owns unknowns lane and lane+64
+    const int i0 = lane, i1 = lane + 64;
+    double y0 = i0 < n ? bF[perm[i0]] : 0.0, y1 = i1 < n ? bF[perm[i1]] : 0.0;
+    for (int j = 0; j < n; j++) {  // forward, column sweep: y[i] -= L(i,j) y[j], i > j  (j ascending like the reference)
+      const double yj = __shfl(j < 64 ? y0 : y1, j & 63, 64);
+      if (i0 > j && i0 < n) y0 -= A[i0 * ld + j] * yj;
+      if (i1 > j && i1 < n) y1 -= A[i1 * ld + j] * yj;
+    }
+    if (i0 < n) y0 = Dg[i0] != 0.0 ? y0 / Dg[i0] : 0.0;
+    if (i1 < n) y1 = Dg[i1] != 0.0 ? y1 / Dg[i1] : 0.0;
+    for (int j = n - 1; j >= 0; j--) {  // backward, column sweep: y[i] -= L(j,i) y[j], i < j
+      const double yj = __shfl(j < 64 ? y0 : y1, j & 63, 64);
+      if (i0 < j) y0 -= A[j * ld + i0] * yj;
+      if (i1 < j && i1 < n) y1 -= A[j * ld + i1] * yj;
+    }
+    if (i0 < n) xv[perm[i0]] = y0;
+    if (i1 < n) xv[perm[i1]] = y1;
   }
   __syncthreads();
   for (int i = tid; i < n; i += BA_BLOCK) xv[i] = sv[i] * xv[i];   // x = SVecI * solve(...)  (:976)
