@@ -244,11 +244,11 @@ extern "C" int sdso_ba_upload_window(sdso_ctx* ctx, int win, const sdso_ba_windo
   float4* p_geo; float *p_color, *p_weights, *p_prior, *p_delta, *p_out; int *p_host, *p_rbeg, *p_rcnt, *p_rlist;
   DM(p_geo, float4, np); DM(p_color, float, np * 8); DM(p_weights, float, np * 8); DM(p_host, int, np);
   DM(p_prior, float, np); DM(p_delta, float, np); DM(p_rbeg, int, np); DM(p_rcnt, int, np); DM(p_rlist, int, nr); DM(p_out, float, (size_t)np * 16);
-  int* r_point; uint8_t *r_host, *r_target;
-  DM(r_point, int, nr); DM(r_host, uint8_t, nr); DM(r_target, uint8_t, nr);
+  int* r_point; int* r_orig; uint8_t *r_host, *r_target;
+  DM(r_point, int, nr); DM(r_orig, int, nr); DM(r_host, uint8_t, nr); DM(r_target, uint8_t, nr);
   DM(d.r_state, uint8_t, nr); DM(d.r_newState, uint8_t, nr); DM(d.r_lin, uint8_t, nr); DM(d.r_act, uint8_t, nr); DM(d.r_jsel, uint8_t, nr);
   DM(d.r_energy, float, nr); DM(d.r_newEnergy, float, nr); DM(d.r_newEnergyWO, float, nr);
-  DM(d.J[0], float, (size_t)74 * d.nrp); DM(d.J[1], float, (size_t)74 * d.nrp); DM(d.r_toZero, float, (size_t)8 * d.nrp);
+  DM(d.J[0], float, (size_t)76 * d.nrp); DM(d.J[1], float, (size_t)76 * d.nrp); DM(d.r_toZero, float, (size_t)8 * d.nrp);
   DM(d.r_rec, float, (size_t)nr * 16);
   d.r_proj = nullptr;
   DM(W->dt_precalc, float, nf * nf * 27); DM(W->dt_adHTdelta, float, nf * nf * 8); DM(W->dt_cdelta, float, 4); DM(W->dt_frameTH, float, nf);
@@ -265,7 +265,7 @@ extern "C" int sdso_ba_upload_window(sdso_ctx* ctx, int win, const sdso_ba_windo
 
   d.p_geo = p_geo; d.p_color = p_color; d.p_weights = p_weights; d.p_host = p_host; d.p_prior = p_prior; d.p_delta = p_delta;
   d.p_rbeg = p_rbeg; d.p_rcnt = p_rcnt; d.p_rlist = p_rlist; d.p_out = p_out;
-  d.r_point = r_point; d.r_host = r_host; d.r_target = r_target;
+  d.r_point = r_point; d.r_orig = r_orig; d.r_host = r_host; d.r_target = r_target;
   d.t_precalc = W->dt_precalc; d.t_adHTdelta = W->dt_adHTdelta; d.t_cdelta = W->dt_cdelta; d.t_frameTH = W->dt_frameTH; d.t_img = d_img;
   d.t_adHost = W->dt_adHost; d.t_adTarget = W->dt_adTarget; d.t_xAd = W->dt_xAd; d.t_prior = W->dt_prior; d.t_HM = W->dt_HM; d.t_bM = W->dt_bM; d.t_P = W->dt_P;
   d.chunks = d_chunks; d.pair_chunk_beg = d_pair_beg; d.items = d_items; d.host_item_beg = d_host_beg;
@@ -288,7 +288,7 @@ extern "C" int sdso_ba_upload_window(sdso_ctx* ctx, int win, const sdso_ba_windo
   H2D(p_geo, geo.data(), sizeof(float4) * np); H2D(p_color, Win->color, sizeof(float) * np * 8); H2D(p_weights, Win->weights, sizeof(float) * np * 8);
   H2D(p_host, Win->host, sizeof(int) * np); H2D(p_prior, W->h_prior.data(), sizeof(float) * np); H2D(p_delta, delta.data(), sizeof(float) * np);
   H2D(p_rbeg, rbeg.data(), sizeof(int) * np); H2D(p_rcnt, rcnt.data(), sizeof(int) * np); H2D(p_rlist, rlist.data(), sizeof(int) * nr);
-  H2D(r_point, s_point.data(), sizeof(int) * nr); H2D(r_host, s_host.data(), nr); H2D(r_target, s_target.data(), nr); H2D(d.r_state, s_state.data(), nr);
+  H2D(r_point, s_point.data(), sizeof(int) * nr); H2D(r_orig, W->perm.data(), sizeof(int) * nr); H2D(r_host, s_host.data(), nr); H2D(r_target, s_target.data(), nr); H2D(d.r_state, s_state.data(), nr);
   H2D(W->dt_frameTH, frameTH.data(), sizeof(float) * nf); H2D(d_img, imgs.data(), sizeof(float4*) * nf);
   H2D(d_chunks, chunks.data(), sizeof(int4) * chunks.size()); H2D(d_pair_beg, pair_beg.data(), sizeof(int) * (nf * nf + 1));
   H2D(d_items, items.data(), sizeof(int4) * items.size()); H2D(d_host_beg, host_beg.data(), sizeof(int) * (nf + 1));
@@ -296,7 +296,7 @@ extern "C" int sdso_ba_upload_window(sdso_ctx* ctx, int win, const sdso_ba_windo
   // per-residual record: target in slot 15, newState OUTLIER, newEnergyWO -1
   {
     std::vector<float> rec((size_t)nr * 16, 0.f);
-    for (int j = 0; j < nr; j++) rec[(size_t)j * 16 + RR_TARGET] = (float)s_target[j];
+    for (int o = 0; o < nr; o++) rec[(size_t)o * 16 + RR_TARGET] = (float)Win->res_target[o];
     H2D(d.r_rec, rec.data(), sizeof(float) * rec.size());
     std::vector<uint8_t> ns(nr, 2);
     H2D(d.r_newState, ns.data(), nr);
@@ -440,7 +440,7 @@ extern "C" int sdso_ba_get_linearization(sdso_ctx* ctx, int win, float* J, uint8
   const int nr = W->d.nr, S = W->d.nrp;
   SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (J) {
-    std::vector<float> j0((size_t)74 * S), j1((size_t)74 * S);
+    std::vector<float> j0((size_t)76 * S), j1((size_t)76 * S);
     std::vector<uint8_t> sel(nr);
     SDSO_HIP(ctx, hipMemcpy(j0.data(), W->d.J[0], sizeof(float) * j0.size(), hipMemcpyDeviceToHost));
     SDSO_HIP(ctx, hipMemcpy(j1.data(), W->d.J[1], sizeof(float) * j1.size(), hipMemcpyDeviceToHost));
@@ -448,7 +448,7 @@ extern "C" int sdso_ba_get_linearization(sdso_ctx* ctx, int win, float* J, uint8
     for (int j = 0; j < nr; j++) {
       const std::vector<float>& src = sel[j] ? j0 : j1;  // PointFrameResidual::J = J[1 - jsel]
       float* o = J + (size_t)W->perm[j] * 74;
-      for (int f = 0; f < 74; f++) o[f] = src[(size_t)f * S + j];
+      for (int f = 0; f < 74; f++) { const int dv = jdev(f); o[f] = src[(size_t)(dv >> 2) * 4 * S + 4 * (size_t)j + (dv & 3)]; }
     }
   }
   auto fetch = [&](auto* dst, const auto* dsrc, int width) -> int {
@@ -492,7 +492,7 @@ extern "C" int sdso_ba_get_residual_state(sdso_ctx* ctx, int win, uint8_t* state
   if (JpJdF && nr) {
     std::vector<float> rec((size_t)nr * 16);
     SDSO_HIP(ctx, hipMemcpy(rec.data(), W->d.r_rec, sizeof(float) * rec.size(), hipMemcpyDeviceToHost));
-    for (int j = 0; j < nr; j++) std::memcpy(JpJdF + (size_t)W->perm[j] * 8, &rec[(size_t)j * 16], 32);
+    for (int o = 0; o < nr; o++) std::memcpy(JpJdF + (size_t)o * 8, &rec[(size_t)o * 16], 32);
   }
   return SDSO_OK;
 }

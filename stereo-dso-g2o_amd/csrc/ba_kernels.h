@@ -18,7 +18,7 @@ namespace sdso {
 
 constexpr int BA_BLOCK = 256;
 constexpr int BA_CHUNK = 256;      // residuals per accumulate workgroup
-constexpr int BA_SC_PTS = 16;      // points per SC wave item
+constexpr int BA_SC_PTS = 32;      // points per SC wave item (<= 64)
 constexpr int J_RESF = 0, J_XI0 = 8, J_XI1 = 14, J_C0 = 20, J_C1 = 24, J_DD = 28, J_IDX0 = 30, J_IDX1 = 38, J_AB0 = 46, J_AB1 = 54,
               J_IDX2 = 62, J_ABIDX = 66, J_AB2 = 70;
 // p_out record (16 floats per point)
@@ -39,17 +39,19 @@ struct BaDev {
   float* p_delta;
   const int* p_rbeg;
   const int* p_rcnt;
-  const int* p_rlist;       // sorted residual index of every (point, slot)
+  const int* p_rlist;       // sorted residual index of every (point, slot)   (host bookkeeping / debug)
   float* p_out;             // np*16
   // residuals (pair-sorted)
   const int* r_point;
+  const int* r_orig;        // original (residualsAll-order) index: r_rec is laid out in THAT order, so the
+                            // records of one point are contiguous (one coalesced read per point)
   const uint8_t* r_host;
   const uint8_t* r_target;
   uint8_t* r_state; uint8_t* r_newState; uint8_t* r_lin; uint8_t* r_act; uint8_t* r_jsel;
   float* r_energy; float* r_newEnergy; float* r_newEnergyWO;
-  float* J[2];              // 74 x nrp SoA each; EFResidual::J = J[jsel], PointFrameResidual::J = J[1-jsel]
+  float* J[2];              // 19 float4 groups x nrp each (layout: ba_kernels.hip); EFResidual::J = J[jsel], PointFrameResidual::J = J[1-jsel]
   float* r_toZero;          // 8 x nrp SoA
-  float* r_rec;             // nr x 16
+  float* r_rec;             // nr x 16, indexed by the ORIGINAL residual index
   float* r_proj;            // nr x 19 (projectedTo 16, centerProjectedTo 3)
   // tables
   const float* t_precalc;   // [host*nf+target][27]

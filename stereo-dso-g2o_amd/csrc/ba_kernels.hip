@@ -25,6 +25,27 @@ __device__ __forceinline__ double block_sum_d(double v, double* lds) {
   return s;
 }
 
+// Device layout of one RawResidualJacobian: 19 float4 groups (76 floats, SoA over residuals: group g of
+// residual i at J + g*4*S + 4*i), ordered so that linearize can store every group as soon as it is known:
+//   g0..g2 Jpdxi[0][0..5],Jpdxi[1][0..5] | g3 Jpdc[0] | g4 Jpdc[1] | g5 {Jpdd[0],Jpdd[1],-,-}
+//   g6+k {resF[k], JIdx[0][k], JIdx[1][k], JabF[0][k]} k=0..7 | g14,g15 JabF[1][0..7] | g16 JIdx2 | g17 JabJIdx | g18 Jab2
+__device__ __forceinline__ float4& JQ(float* J, int S, int i, int g) { return *(float4*)(J + (size_t)g * 4 * S + 4 * (size_t)i); }
+__device__ __forceinline__ float4 JQ(const float* J, int S, int i, int g) { return *(const float4*)(J + (size_t)g * 4 * S + 4 * (size_t)i); }
+__device__ __forceinline__ void load_J(const float* J, int S, int i, float* jl) {
+#pragma unroll
+  for (int g = 0; g < 19; g++) {
+    const float4 q = *(const float4*)(J + (size_t)g * 4 * S + 4 * (size_t)i);
+    jl[4 * g] = q.x; jl[4 * g + 1] = q.y; jl[4 * g + 2] = q.z; jl[4 * g + 3] = q.w;
+  }
+}
+// ABI field index (include/sdso_abi.h order) -> index in the device layout
+__host__ __device__ constexpr int jdev(int f) {
+  return f < 8 ? 24 + 4 * f : f < 14 ? (f - 8) : f < 20 ? 6 + (f - 14) : f < 24 ? 12 + (f - 20) : f < 28 ? 16 + (f - 24) : f < 30 ? 20 + (f - 28)
+       : f < 38 ? 24 + 4 * (f - 30) + 1 : f < 46 ? 24 + 4 * (f - 38) + 2 : f < 54 ? 24 + 4 * (f - 46) + 3 : f < 62 ? 56 + (f - 54)
+       : f < 66 ? 64 + (f - 62) : f < 70 ? 68 + (f - 66) : 72 + (f - 70);
+}
+#define JV(f) jl[jdev(f)]
+
 // ------------------------------------------------------------------ linearize
 __device__ double linearize_one(const BaDev& B, int i) {
   B.r_newEnergyWO[i] = -1.f;
@@ -79,22 +100,12 @@ __device__ double linearize_one(const BaDev& B, int i) {
     d_C_y[1] = (d_C_y[1] + v) * SCALE_F;
     d_C_y[2] *= SCALE_C;
     d_C_y[3] = (d_C_y[3] + 1) * SCALE_C;
-    J[(J_XI0 + 0) * S + i] = new_idepth * fxl;
-    J[(J_XI0 + 1) * S + i] = 0;
-    J[(J_XI0 + 2) * S + i] = -new_idepth * u * fxl;
-    J[(J_XI0 + 3) * S + i] = -u * v * fxl;
-    J[(J_XI0 + 4) * S + i] = (1 + u * u) * fxl;
-    J[(J_XI0 + 5) * S + i] = -v * fxl;
-    J[(J_XI1 + 0) * S + i] = 0;
-    J[(J_XI1 + 1) * S + i] = new_idepth * fyl;
-    J[(J_XI1 + 2) * S + i] = -new_idepth * v * fyl;
-    J[(J_XI1 + 3) * S + i] = -(1 + v * v) * fyl;
-    J[(J_XI1 + 4) * S + i] = u * v * fyl;
-    J[(J_XI1 + 5) * S + i] = u * fyl;
-#pragma unroll
-    for (int k = 0; k < 4; k++) { J[(J_C0 + k) * S + i] = d_C_x[k]; J[(J_C1 + k) * S + i] = d_C_y[k]; }
-    J[(J_DD + 0) * S + i] = d_d_x;
-    J[(J_DD + 1) * S + i] = d_d_y;
+    JQ(J, S, i, 0) = make_float4(new_idepth * fxl, 0, -new_idepth * u * fxl, -u * v * fxl);                       // Jpdxi[0][0..3]
+    JQ(J, S, i, 1) = make_float4((1 + u * u) * fxl, -v * fxl, 0, new_idepth * fyl);                                // Jpdxi[0][4..5], Jpdxi[1][0..1]
+    JQ(J, S, i, 2) = make_float4(-new_idepth * v * fyl, -(1 + v * v) * fyl, u * v * fyl, u * fyl);                 // Jpdxi[1][2..5]
+    JQ(J, S, i, 3) = make_float4(d_C_x[0], d_C_x[1], d_C_x[2], d_C_x[3]);
+    JQ(J, S, i, 4) = make_float4(d_C_y[0], d_C_y[1], d_C_y[2], d_C_y[3]);
+    JQ(J, S, i, 5) = make_float4(d_d_x, d_d_y, 0.f, 0.f);
   }
 
   float JIdxJIdx_00 = 0, JIdxJIdx_11 = 0, JIdxJIdx_10 = 0;
@@ -106,6 +117,7 @@ __device__ double linearize_one(const BaDev& B, int i) {
   const float color[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
   const float weights[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
   bool oob = false;
+  float jab1[8];
 #pragma unroll
   for (int idx = 0; idx < 8; idx++) {
     if (oob) break;
@@ -129,11 +141,8 @@ __device__ double linearize_one(const BaDev& B, int i) {
     hw = hw * wgt;
     hit.y *= hw;
     hit.z *= hw;
-    J[(J_RESF + idx) * S + i] = residual * hw;
-    J[(J_IDX0 + idx) * S + i] = hit.y;
-    J[(J_IDX1 + idx) * S + i] = hit.z;
-    J[(J_AB0 + idx) * S + i] = B.affA_fixed ? 0.f : drdA * hw;
-    J[(J_AB1 + idx) * S + i] = B.affB_fixed ? 0.f : hw;
+    JQ(J, S, i, 6 + idx) = make_float4(residual * hw, hit.y, hit.z, B.affA_fixed ? 0.f : drdA * hw);   // resF, JIdx[0], JIdx[1], JabF[0]
+    jab1[idx] = B.affB_fixed ? 0.f : hw;
     JIdxJIdx_00 += hit.y * hit.y;
     JIdxJIdx_11 += hit.z * hit.z;
     JIdxJIdx_10 += hit.y * hit.z;
@@ -147,12 +156,11 @@ __device__ double linearize_one(const BaDev& B, int i) {
     wJI2_sum += hw * hw * (hit.y * hit.y + hit.z * hit.z);
   }
   if (oob) { B.r_newState[i] = 1; return (double)B.r_energy[i]; }
-  J[(J_IDX2 + 0) * S + i] = JIdxJIdx_00; J[(J_IDX2 + 1) * S + i] = JIdxJIdx_10;
-  J[(J_IDX2 + 2) * S + i] = JIdxJIdx_10; J[(J_IDX2 + 3) * S + i] = JIdxJIdx_11;
-  J[(J_ABIDX + 0) * S + i] = JabJIdx_00; J[(J_ABIDX + 1) * S + i] = JabJIdx_01;
-  J[(J_ABIDX + 2) * S + i] = JabJIdx_10; J[(J_ABIDX + 3) * S + i] = JabJIdx_11;
-  J[(J_AB2 + 0) * S + i] = JabJab_00; J[(J_AB2 + 1) * S + i] = JabJab_01;
-  J[(J_AB2 + 2) * S + i] = JabJab_01; J[(J_AB2 + 3) * S + i] = JabJab_11;
+  JQ(J, S, i, 14) = make_float4(jab1[0], jab1[1], jab1[2], jab1[3]);
+  JQ(J, S, i, 15) = make_float4(jab1[4], jab1[5], jab1[6], jab1[7]);
+  JQ(J, S, i, 16) = make_float4(JIdxJIdx_00, JIdxJIdx_10, JIdxJIdx_10, JIdxJIdx_11);
+  JQ(J, S, i, 17) = make_float4(JabJIdx_00, JabJIdx_01, JabJIdx_10, JabJIdx_11);
+  JQ(J, S, i, 18) = make_float4(JabJab_00, JabJab_01, JabJab_01, JabJab_11);
 
   B.r_newEnergyWO[i] = energyLeft;
   const float th = fmaxf(B.t_frameTH[h], B.t_frameTH[t]);
@@ -179,7 +187,7 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_apply(const BaDev* __restrict__
   const BaDev& B = wins[blockIdx.y];
   const int i = blockIdx.x * BA_BLOCK + threadIdx.x;
   if (i >= B.nr) return;
-  float* rec = B.r_rec + (size_t)i * 16;
+  float* rec = B.r_rec + (size_t)B.r_orig[i] * 16;
   if (B.r_lin[i]) return;
   const uint8_t st = B.r_state[i];
   if (st == 1) return;  // can never go back from OOB
@@ -191,15 +199,16 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_apply(const BaDev* __restrict__
     B.r_jsel[i] = sel;
     const float* __restrict__ J = B.J[sel];
     const int S = B.nrp;
-    const float jdd0 = J[(J_DD + 0) * S + i], jdd1 = J[(J_DD + 1) * S + i];
-    const float a00 = J[(J_IDX2 + 0) * S + i], a01 = J[(J_IDX2 + 1) * S + i], a10 = J[(J_IDX2 + 2) * S + i], a11 = J[(J_IDX2 + 3) * S + i];
-    const float v0 = a00 * jdd0 + a01 * jdd1;
-    const float v1 = a10 * jdd0 + a11 * jdd1;
+    const float4 g0 = JQ(J, S, i, 0), g1 = JQ(J, S, i, 1), g2 = JQ(J, S, i, 2), gd = JQ(J, S, i, 5), i2 = JQ(J, S, i, 16), ai = JQ(J, S, i, 17);
+    const float jdd0 = gd.x, jdd1 = gd.y;
+    const float v0 = i2.x * jdd0 + i2.y * jdd1;
+    const float v1 = i2.z * jdd0 + i2.w * jdd1;
+    const float xi0[6] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y}, xi1[6] = {g1.z, g1.w, g2.x, g2.y, g2.z, g2.w};
     float out[8];
 #pragma unroll
-    for (int k = 0; k < 6; k++) out[k] = J[(J_XI0 + k) * S + i] * v0 + J[(J_XI1 + k) * S + i] * v1;
-    out[6] = J[(J_ABIDX + 0) * S + i] * jdd0 + J[(J_ABIDX + 1) * S + i] * jdd1;
-    out[7] = J[(J_ABIDX + 2) * S + i] * jdd0 + J[(J_ABIDX + 3) * S + i] * jdd1;
+    for (int k = 0; k < 6; k++) out[k] = xi0[k] * v0 + xi1[k] * v1;
+    out[6] = ai.x * jdd0 + ai.y * jdd1;
+    out[7] = ai.z * jdd0 + ai.w * jdd1;
     *(float4*)(rec) = make_float4(out[0], out[1], out[2], out[3]);
     *(float4*)(rec + 4) = make_float4(out[4], out[5], out[6], out[7]);
   }
@@ -216,29 +225,30 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_fixlin(const BaDev* __restrict_
   if (i >= B.nr) return;
   const int pt = B.r_point[i];
   if (!pflag[pt] || !B.r_act[i]) return;
-  const float* __restrict__ J = B.J[B.r_jsel[i]];
+  float jl[76];
+  load_J(B.J[B.r_jsel[i]], B.nrp, i, jl);
   const int S = B.nrp;
   const float* dp = B.t_adHTdelta + (size_t)(B.r_host[i] + B.nf * B.r_target[i]) * 8;
   const float* dc = B.t_cdelta;
   float sx = 0, sy = 0, cx = 0, cy = 0;
 #pragma unroll
-  for (int k = 0; k < 6; k++) { sx += J[(J_XI0 + k) * S + i] * dp[k]; sy += J[(J_XI1 + k) * S + i] * dp[k]; }
+  for (int k = 0; k < 6; k++) { sx += JV(J_XI0 + k) * dp[k]; sy += JV(J_XI1 + k) * dp[k]; }
 #pragma unroll
-  for (int k = 0; k < 4; k++) { cx += J[(J_C0 + k) * S + i] * dc[k]; cy += J[(J_C1 + k) * S + i] * dc[k]; }
+  for (int k = 0; k < 4; k++) { cx += JV(J_C0 + k) * dc[k]; cy += JV(J_C1 + k) * dc[k]; }
   const float dd = B.p_delta[pt];
-  const float dx = sx + cx + J[(J_DD + 0) * S + i] * dd;
-  const float dy = sy + cy + J[(J_DD + 1) * S + i] * dd;
+  const float dx = sx + cx + JV(J_DD + 0) * dd;
+  const float dy = sy + cy + JV(J_DD + 1) * dd;
 #pragma unroll
   for (int k = 0; k < 8; k++) {
-    float rtz = J[(J_RESF + k) * S + i];
-    rtz = rtz - J[(J_IDX0 + k) * S + i] * dx;
-    rtz = rtz - J[(J_IDX1 + k) * S + i] * dy;
-    rtz = rtz - J[(J_AB0 + k) * S + i] * dp[6];
-    rtz = rtz - J[(J_AB1 + k) * S + i] * dp[7];
+    float rtz = JV(J_RESF + k);
+    rtz = rtz - JV(J_IDX0 + k) * dx;
+    rtz = rtz - JV(J_IDX1 + k) * dy;
+    rtz = rtz - JV(J_AB0 + k) * dp[6];
+    rtz = rtz - JV(J_AB1 + k) * dp[7];
     B.r_toZero[k * S + i] = rtz;
   }
   B.r_lin[i] = 1;
-  B.r_rec[(size_t)i * 16 + RR_FLAGS] = 3.f;  // active | linearized
+  B.r_rec[(size_t)B.r_orig[i] * 16 + RR_FLAGS] = 3.f;  // active | linearized
 }
 
 // resetOOB + isLinearized=false for the residuals of flagged points (FullSystem.cpp:1012-1016)
@@ -285,12 +295,13 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_accum_top(const BaDev* __restri
 #pragma unroll
   for (int k = 0; k < 10; k++) { x[k] = 0; y[k] = 0; }
   if (on) {
-    const float* __restrict__ J = B.J[B.r_jsel[i]];
+    float jl[76];
+    load_J(B.J[B.r_jsel[i]], S, i, jl);
     const int pt = B.r_point[i];
     float resApprox[8];
     if (mode == 0) {
 #pragma unroll
-      for (int k = 0; k < 8; k++) resApprox[k] = J[(J_RESF + k) * S + i];
+      for (int k = 0; k < 8; k++) resApprox[k] = JV(J_RESF + k);
     } else if (mode == 2) {
 #pragma unroll
       for (int k = 0; k < 8; k++) resApprox[k] = B.r_toZero[k * S + i];
@@ -299,45 +310,45 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_accum_top(const BaDev* __restri
       const float* dc = B.t_cdelta;
       float sx = 0, sy = 0, cx = 0, cy = 0;
 #pragma unroll
-      for (int k = 0; k < 6; k++) { sx += J[(J_XI0 + k) * S + i] * dp[k]; sy += J[(J_XI1 + k) * S + i] * dp[k]; }
+      for (int k = 0; k < 6; k++) { sx += JV(J_XI0 + k) * dp[k]; sy += JV(J_XI1 + k) * dp[k]; }
 #pragma unroll
-      for (int k = 0; k < 4; k++) { cx += J[(J_C0 + k) * S + i] * dc[k]; cy += J[(J_C1 + k) * S + i] * dc[k]; }
+      for (int k = 0; k < 4; k++) { cx += JV(J_C0 + k) * dc[k]; cy += JV(J_C1 + k) * dc[k]; }
       const float dd = B.p_delta[pt];
-      const float dx = sx + cx + J[(J_DD + 0) * S + i] * dd;
-      const float dy = sy + cy + J[(J_DD + 1) * S + i] * dd;
+      const float dx = sx + cx + JV(J_DD + 0) * dd;
+      const float dy = sy + cy + JV(J_DD + 1) * dd;
 #pragma unroll
       for (int k = 0; k < 8; k++) {
         float rtz = B.r_toZero[k * S + i];
-        rtz = rtz + J[(J_IDX0 + k) * S + i] * dx;
-        rtz = rtz + J[(J_IDX1 + k) * S + i] * dy;
-        rtz = rtz + J[(J_AB0 + k) * S + i] * dp[6];
-        rtz = rtz + J[(J_AB1 + k) * S + i] * dp[7];
+        rtz = rtz + JV(J_IDX0 + k) * dx;
+        rtz = rtz + JV(J_IDX1 + k) * dy;
+        rtz = rtz + JV(J_AB0 + k) * dp[6];
+        rtz = rtz + JV(J_AB1 + k) * dp[7];
         resApprox[k] = rtz;
       }
     }
     float JI_r0 = 0, JI_r1 = 0, Jab_r0 = 0, Jab_r1 = 0, rr = 0;
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-      JI_r0 += resApprox[k] * J[(J_IDX0 + k) * S + i];
-      JI_r1 += resApprox[k] * J[(J_IDX1 + k) * S + i];
-      Jab_r0 += resApprox[k] * J[(J_AB0 + k) * S + i];
-      Jab_r1 += resApprox[k] * J[(J_AB1 + k) * S + i];
+      JI_r0 += resApprox[k] * JV(J_IDX0 + k);
+      JI_r1 += resApprox[k] * JV(J_IDX1 + k);
+      Jab_r0 += resApprox[k] * JV(J_AB0 + k);
+      Jab_r1 += resApprox[k] * JV(J_AB1 + k);
       rr += resApprox[k] * resApprox[k];
     }
 #pragma unroll
-    for (int k = 0; k < 4; k++) { x[k] = J[(J_C0 + k) * S + i]; y[k] = J[(J_C1 + k) * S + i]; }
+    for (int k = 0; k < 4; k++) { x[k] = JV(J_C0 + k); y[k] = JV(J_C1 + k); }
 #pragma unroll
-    for (int k = 0; k < 6; k++) { x[4 + k] = J[(J_XI0 + k) * S + i]; y[4 + k] = J[(J_XI1 + k) * S + i]; }
-    a = J[(J_IDX2 + 0) * S + i]; b = J[(J_IDX2 + 1) * S + i]; c = J[(J_IDX2 + 3) * S + i];
-    TR00 = J[(J_ABIDX + 0) * S + i]; TR10 = J[(J_ABIDX + 1) * S + i]; TR01 = J[(J_ABIDX + 2) * S + i]; TR11 = J[(J_ABIDX + 3) * S + i];
+    for (int k = 0; k < 6; k++) { x[4 + k] = JV(J_XI0 + k); y[4 + k] = JV(J_XI1 + k); }
+    a = JV(J_IDX2 + 0); b = JV(J_IDX2 + 1); c = JV(J_IDX2 + 3);
+    TR00 = JV(J_ABIDX + 0); TR10 = JV(J_ABIDX + 1); TR01 = JV(J_ABIDX + 2); TR11 = JV(J_ABIDX + 3);
     TR02 = JI_r0; TR12 = JI_r1;
-    br[0] = J[(J_AB2 + 0) * S + i]; br[1] = J[(J_AB2 + 1) * S + i]; br[2] = Jab_r0; br[3] = J[(J_AB2 + 3) * S + i]; br[4] = Jab_r1; br[5] = rr;
+    br[0] = JV(J_AB2 + 0); br[1] = JV(J_AB2 + 1); br[2] = Jab_r0; br[3] = JV(J_AB2 + 3); br[4] = Jab_r1; br[5] = rr;
     // per-residual idepth terms (AccumulatedTopHessian.cpp:160-172) -> record
-    const float jdd0 = J[(J_DD + 0) * S + i], jdd1 = J[(J_DD + 1) * S + i];
-    const float a10 = J[(J_IDX2 + 2) * S + i];
+    const float jdd0 = JV(J_DD + 0), jdd1 = JV(J_DD + 1);
+    const float a10 = JV(J_IDX2 + 2);
     const float q0 = a * jdd0 + b * jdd1;
     const float q1 = a10 * jdd0 + c * jdd1;
-    float* rec = B.r_rec + (size_t)i * 16;
+    float* rec = B.r_rec + (size_t)B.r_orig[i] * 16;
     rec[RR_BD] = JI_r0 * jdd0 + JI_r1 * jdd1;
     rec[RR_HDD] = q0 * jdd0 + q1 * jdd1;
 #pragma unroll
@@ -440,13 +451,12 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_sc(const BaDev* __restrict__ wi
     for (int s = 0; s < 8; s++) {
       act[s] = false; Ja[s] = 0; Jc[s] = 0; Je[s] = 0; tg[s] = 0;
       if (s < cnt) {
-        const int ri = __builtin_amdgcn_readfirstlane(B.p_rlist[beg + s]);
-        const float* rec = B.r_rec + (size_t)ri * 16;
+        const float* rec = B.r_rec + (size_t)(beg + s) * 16;
         const int fl = (int)rec[RR_FLAGS];
         if (fl & 1) {
           act[s] = true;
           ngood++;
-          tg[s] = B.r_target[ri];
+          tg[s] = (int)rec[RR_TARGET];
           Ja[s] = rec[la];
           Jc[s] = rec[lc];
           Je[s] = rec[(lane >> 2) & 7];
@@ -516,6 +526,8 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_sc(const BaDev* __restrict__ wi
 // NF x NF D tiles in VGPRs; a point's residual vectors are first scattered to per-TARGET slots (a point
 // has at most one residual per target), so the tile index is a compile-time constant and targets
 // without a residual add an exact +0.  Same accumulation order per tile as the LDS variant.
+// Memory: the <=8 records of a point are contiguous (r_rec is in point order): two coalesced 256-B
+// loads fetch them all, issued one point ahead of their use; fields reach their lanes by shuffles.
 template <int NF>
 __global__ __launch_bounds__(BA_BLOCK) void k_ba_sc_reg(const BaDev* __restrict__ wins, const uint8_t* __restrict__ pflag, int shiftPriorToZero, int margMode) {
   const BaDev& B = wins[blockIdx.y];
@@ -532,72 +544,95 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_sc_reg(const BaDev* __restrict_
     for (int j = 0; j < NF; j++) D[i][j] = 0.f;
   }
   float hcc = 0.f, bcv = 0.f;
-  for (int p = it.y; p < it.z; p++) {
-    if (pflag && !pflag[p]) continue;
-    const int cnt = B.p_rcnt[p], beg = B.p_rbeg[p];
+  // per-lane copy of (count, begin, prior, delta, flag) of point it.y + lane  (items hold <= 64 points)
+  const int npts = it.z - it.y;
+  int my_cnt = 0, my_beg = 0; float my_prior = 0.f, my_delta = 0.f; int my_on = 0;
+  if (lane < npts) {
+    const int p = it.y + lane;
+    my_cnt = B.p_rcnt[p]; my_beg = B.p_rbeg[p]; my_prior = B.p_prior[p]; my_delta = B.p_delta[p];
+    my_on = pflag ? (int)pflag[p] : 1;
+    if (!my_on) my_cnt = 0;
+  }
+  auto fetch = [&](int q, float& a, float& b) {   // records of point q (index inside the item) -> two coalesced loads
+    const int cnt = __shfl(my_cnt, q, 64), beg = __shfl(my_beg, q, 64);
+    const float* base = B.r_rec + (size_t)beg * 16;
+    a = lane < cnt * 16 ? base[lane] : 0.f;
+    b = lane + 64 < cnt * 16 ? base[lane + 64] : 0.f;
+  };
+  float vA = 0.f, vB = 0.f, nA = 0.f, nB = 0.f;
+  if (npts > 0) fetch(0, vA, vB);
+  for (int q = 0; q < npts; q++) {
+    if (q + 1 < npts) fetch(q + 1, nA, nB);   // in flight while point q is processed
+    const int cnt = __shfl(my_cnt, q, 64);
+    const float prior = __shfl(my_prior, q, 64), delta = __shfl(my_delta, q, 64);
+    const int on = __shfl(my_on, q, 64);
+    const int p = it.y + q;
     float* po = B.p_out + (size_t)p * 16;
-    float JaT[NF], JcT[NF], JeT[NF];
-    bool has[NF];
+    if (on) {
+      float JaT[NF], JcT[NF], JeT[NF];
+      bool has[NF];
 #pragma unroll
-    for (int t = 0; t < NF; t++) { JaT[t] = 0.f; JcT[t] = 0.f; JeT[t] = 0.f; has[t] = false; }
-    float Hdd_A = 0, bd_A = 0, Hdd_L = 0, bd_L = 0, HcdA[4] = {0, 0, 0, 0}, HcdL[4] = {0, 0, 0, 0};
-    int ngood = 0;
+      for (int t = 0; t < NF; t++) { JaT[t] = 0.f; JcT[t] = 0.f; JeT[t] = 0.f; has[t] = false; }
+      float Hdd_A = 0, bd_A = 0, Hdd_L = 0, bd_L = 0, HcdA[4] = {0, 0, 0, 0}, HcdL[4] = {0, 0, 0, 0};
+      int ngood = 0;
 #pragma unroll
-    for (int s = 0; s < 8; s++) {
-      if (s < cnt) {
-        const int ri = __builtin_amdgcn_readfirstlane(B.p_rlist[beg + s]);
-        const float* rec = B.r_rec + (size_t)ri * 16;
-        const int fl = (int)rec[RR_FLAGS];
-        if (fl & 1) {
-          ngood++;
-          const int tg = __builtin_amdgcn_readfirstlane((int)B.r_target[ri]);
-          const float ja = rec[la], jc = rec[lc], je = rec[le];
+      for (int s = 0; s < 8; s++) {
+        if (s < cnt) {
+          const float src = s < 4 ? vA : vB;
+          const int o = (s & 3) * 16;
+          const int fl = (int)__shfl(src, o + RR_FLAGS, 64);
+          if (fl & 1) {
+            ngood++;
+            const int tg = (int)__shfl(src, o + RR_TARGET, 64);
+            const float ja = __shfl(src, o + la, 64), jc = __shfl(src, o + lc, 64), je = __shfl(src, o + le, 64);
 #pragma unroll
-          for (int t = 0; t < NF; t++)
-            if (t == tg) { JaT[t] = ja; JcT[t] = jc; JeT[t] = je; has[t] = true; }
-          if (!(fl & 2) && !margMode) {
-            bd_A += rec[RR_BD]; Hdd_A += rec[RR_HDD];
-#pragma unroll
-            for (int k = 0; k < 4; k++) HcdA[k] += rec[RR_HCD + k];
-          } else {
-            bd_L += rec[RR_BD]; Hdd_L += rec[RR_HDD];
-#pragma unroll
-            for (int k = 0; k < 4; k++) HcdL[k] += rec[RR_HCD + k];
+            for (int t = 0; t < NF; t++)
+              if (t == tg) { JaT[t] = ja; JcT[t] = jc; JeT[t] = je; has[t] = true; }
+            const float rbd = __shfl(src, o + RR_BD, 64), rhdd = __shfl(src, o + RR_HDD, 64);
+            const float h0 = __shfl(src, o + RR_HCD, 64), h1 = __shfl(src, o + RR_HCD + 1, 64), h2 = __shfl(src, o + RR_HCD + 2, 64), h3 = __shfl(src, o + RR_HCD + 3, 64);
+            // mode 0 sums the non-linearized, mode 1/2 the linearized residuals (AccumulatedTopHessian.cpp:54-71, 177-192)
+            if (!(fl & 2) && !margMode) {
+              bd_A += rbd; Hdd_A += rhdd; HcdA[0] += h0; HcdA[1] += h1; HcdA[2] += h2; HcdA[3] += h3;
+            } else {
+              bd_L += rbd; Hdd_L += rhdd; HcdL[0] += h0; HcdL[1] += h1; HcdL[2] += h2; HcdL[3] += h3;
+            }
           }
         }
       }
-    }
-    float HdiF = 0, bdSumF = 0;
-    float Hcd[4] = {0, 0, 0, 0};
-    if (ngood > 0) {
-      float H = Hdd_A + Hdd_L + B.p_prior[p];
-      if (H < 1e-10) H = 1e-10;
-      HdiF = 1.0 / H;
-      bdSumF = bd_A + bd_L;
-      if (shiftPriorToZero) bdSumF += B.p_prior[p] * B.p_delta[p];
+      float HdiF = 0, bdSumF = 0;
+      float Hcd[4] = {0, 0, 0, 0};
+      if (ngood > 0) {
+        float H = Hdd_A + Hdd_L + prior;
+        if (H < 1e-10) H = 1e-10;
+        HdiF = 1.0 / H;
+        bdSumF = bd_A + bd_L;
+        if (shiftPriorToZero) bdSumF += prior * delta;
 #pragma unroll
-      for (int k = 0; k < 4; k++) Hcd[k] = HcdA[k] + HcdL[k];
-    }
-    if (lane == 0) {
-      *(float4*)(po + 0) = make_float4(Hdd_A, bd_A, HcdA[0], HcdA[1]);
-      *(float4*)(po + 4) = make_float4(HcdA[2], HcdA[3], Hdd_L, bd_L);
-      *(float4*)(po + 8) = make_float4(HcdL[0], HcdL[1], HcdL[2], HcdL[3]);
-      po[PO_HDI] = HdiF; po[PO_BDSUM] = bdSumF;
-    }
-    if (ngood == 0) continue;
-    if (lane < 16) hcc += (HdiF * Hcd[lane >> 2]) * Hcd[lane & 3];
-    if (lane < 4) bcv += (bdSumF * HdiF) * Hcd[lane];
-    const float hb = HdiF * bdSumF;
-    const float hc = Hcd[lane & 3];
+        for (int k = 0; k < 4; k++) Hcd[k] = HcdA[k] + HcdL[k];
+      }
+      if (lane == 0) {
+        *(float4*)(po + 0) = make_float4(Hdd_A, bd_A, HcdA[0], HcdA[1]);
+        *(float4*)(po + 4) = make_float4(HcdA[2], HcdA[3], Hdd_L, bd_L);
+        *(float4*)(po + 8) = make_float4(HcdL[0], HcdL[1], HcdL[2], HcdL[3]);
+        po[PO_HDI] = HdiF; po[PO_BDSUM] = bdSumF;
+      }
+      if (ngood > 0) {
+        if (lane < 16) hcc += (HdiF * Hcd[lane >> 2]) * Hcd[lane & 3];
+        if (lane < 4) bcv += (bdSumF * HdiF) * Hcd[lane];
+        const float hb = HdiF * bdSumF;
+        const float hc = Hcd[lane & 3];
 #pragma unroll
-    for (int t1 = 0; t1 < NF; t1++) {
-      if (!has[t1]) continue;   // wave-uniform: targets without a residual contribute exact zeros
-      const float wl = HdiF * JaT[t1];
+        for (int t1 = 0; t1 < NF; t1++) {
+          if (!has[t1]) continue;   // wave-uniform: targets without a residual contribute exact zeros
+          const float wl = HdiF * JaT[t1];
 #pragma unroll
-      for (int t2 = 0; t2 < NF; t2++) D[t1][t2] = D[t1][t2] + wl * JcT[t2];
-      E[t1] = E[t1] + (HdiF * JeT[t1]) * hc;
-      EB[t1] = EB[t1] + hb * JcT[t1];
+          for (int t2 = 0; t2 < NF; t2++) D[t1][t2] = D[t1][t2] + wl * JcT[t2];
+          E[t1] = E[t1] + (HdiF * JeT[t1]) * hc;
+          EB[t1] = EB[t1] + hb * JcT[t1];
+        }
+      }
     }
+    vA = nA; vB = nB;
   }
   float* out = B.sc_part + (size_t)item * sc_part_floats(NF);
 #pragma unroll

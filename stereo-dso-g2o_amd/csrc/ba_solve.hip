@@ -368,7 +368,7 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_resub(const BaDev* __restrict__
   const int cnt = B.p_rcnt[p], beg = B.p_rbeg[p];
   const double* x = B.sol + 3 * ((size_t)B.n * B.n + B.n);
   int ngood = 0;
-  for (int s = 0; s < cnt; s++) if (((int)B.r_rec[(size_t)B.p_rlist[beg + s] * 16 + RR_FLAGS]) & 1) ngood++;
+  for (int s = 0; s < cnt; s++) if (((int)B.r_rec[(size_t)(beg + s) * 16 + RR_FLAGS]) & 1) ngood++;
   if (ngood == 0) { po[PO_STEP] = 0; return; }
   float b = po[PO_BDSUM];
   float d = 0;
@@ -377,10 +377,9 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_resub(const BaDev* __restrict__
   b -= d;
   const int h = B.p_host[p];
   for (int s = 0; s < cnt; s++) {
-    const int ri = B.p_rlist[beg + s];
-    const float* rec = B.r_rec + (size_t)ri * 16;
+    const float* rec = B.r_rec + (size_t)(beg + s) * 16;
     if (!(((int)rec[RR_FLAGS]) & 1)) continue;
-    const float* xa = B.t_xAd + (size_t)(h * B.nf + B.r_target[ri]) * 8;
+    const float* xa = B.t_xAd + (size_t)(h * B.nf + (int)rec[RR_TARGET]) * 8;
     float sacc = 0;
 #pragma unroll
     for (int k = 0; k < 8; k++) sacc += xa[k] * rec[k];
