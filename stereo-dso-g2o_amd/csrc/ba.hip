@@ -28,6 +28,7 @@ struct BaWindowDev {
   double affA = 0, affB = 0;
   std::vector<int> perm, inv;     // sorted -> original, original -> sorted
   std::vector<uint8_t> h_target;  // sorted order
+  std::vector<int> h_point;       // sorted order
   std::vector<uint8_t> h_lin;     // sorted order mirror of isLinearized
   std::vector<float> h_prior;
   int nblk_res = 0, nblk_pts = 0;
@@ -139,7 +140,7 @@ extern "C" int sdso_ba_upload_window(sdso_ctx* ctx, int win, const sdso_ba_windo
   SDSO_HIP(ctx, hipSetDevice(ctx->device));
   SDSO_REQUIRE(ctx, Win, "null window");
   const int nf = Win->nf, np = Win->np, nr = Win->nr;
-  SDSO_REQUIRE(ctx, nf >= 1 && nf <= 16 && np >= 0 && nr >= 0, "window sizes out of range (nf <= 16)");
+  SDSO_REQUIRE(ctx, nf >= 1 && nf <= 8 && np >= 0 && nr >= 0, "window sizes out of range (nf <= 8: setting_maxFrames is 7, settings.cpp:65)");
   SDSO_REQUIRE(ctx, Win->evalPT && Win->state && Win->state_zero && Win->ab_exposure && Win->frameEnergyTH && Win->frameID && Win->frame_slot, "null frame arrays");
   SDSO_REQUIRE(ctx, np == 0 || (Win->u && Win->v && Win->idepth && Win->idepth_zero && Win->color && Win->weights && Win->host && Win->hasDepthPrior), "null point arrays");
   SDSO_REQUIRE(ctx, nr == 0 || (Win->res_point && Win->res_target && Win->res_state), "null residual arrays");
@@ -208,6 +209,7 @@ extern "C" int sdso_ba_upload_window(sdso_ctx* ctx, int win, const sdso_ba_windo
     s_point[j] = Win->res_point[o]; s_host[j] = (uint8_t)rhost[o]; s_target[j] = (uint8_t)Win->res_target[o]; s_state[j] = Win->res_state[o];
   }
   W->h_target = s_target;
+  W->h_point = s_point;
   W->h_lin.assign(nr, 0);
   // chunks per pair
   std::vector<int4> chunks;
@@ -222,7 +224,9 @@ extern "C" int sdso_ba_upload_window(sdso_ctx* ctx, int win, const sdso_ba_windo
     }
     pair_beg[nf * nf] = (int)chunks.size();
   }
-  // SC items per host
+  // SC items per host (tunable for experiments: SDSO_SC_PTS in [1,64])
+  int sc_pts = BA_SC_PTS;
+  if (const char* e = getenv("SDSO_SC_PTS")) sc_pts = std::max(1, std::min(64, atoi(e)));
   std::vector<int4> items;
   std::vector<int> host_beg(nf + 1, 0);
   {
@@ -231,7 +235,7 @@ extern "C" int sdso_ba_upload_window(sdso_ctx* ctx, int win, const sdso_ba_windo
       host_beg[h] = (int)items.size();
       int start = p;
       while (p < np && Win->host[p] == h) p++;
-      for (int s = start; s < p; s += BA_SC_PTS) items.push_back(make_int4(h, s, std::min(s + BA_SC_PTS, p), 0));
+      for (int s = start; s < p; s += sc_pts) items.push_back(make_int4(h, s, std::min(s + sc_pts, p), 0));
     }
     host_beg[nf] = (int)items.size();
   }
@@ -249,7 +253,7 @@ extern "C" int sdso_ba_upload_window(sdso_ctx* ctx, int win, const sdso_ba_windo
   DM(d.r_state, uint8_t, nr); DM(d.r_newState, uint8_t, nr); DM(d.r_lin, uint8_t, nr); DM(d.r_act, uint8_t, nr); DM(d.r_jsel, uint8_t, nr);
   DM(d.r_energy, float, nr); DM(d.r_newEnergy, float, nr); DM(d.r_newEnergyWO, float, nr);
   DM(d.J[0], float, (size_t)76 * d.nrp); DM(d.J[1], float, (size_t)76 * d.nrp); DM(d.r_toZero, float, (size_t)8 * d.nrp);
-  DM(d.r_rec, float, (size_t)nr * 16);
+  DM(d.r_rec, float, (size_t)np * nf * 16);   // dense [point][target] records
   d.r_proj = nullptr;
   DM(W->dt_precalc, float, nf * nf * 27); DM(W->dt_adHTdelta, float, nf * nf * 8); DM(W->dt_cdelta, float, 4); DM(W->dt_frameTH, float, nf);
   DM(W->dt_adHost, double, nf * nf * 64); DM(W->dt_adTarget, double, nf * nf * 64); DM(W->dt_prior, double, nf * 16 + 4 + n);
@@ -295,8 +299,14 @@ extern "C" int sdso_ba_upload_window(sdso_ctx* ctx, int win, const sdso_ba_windo
   H2D(W->dt_HM, W->HM.data(), sizeof(double) * n * n); H2D(W->dt_bM, W->bM.data(), sizeof(double) * n);
   // per-residual record: target in slot 15, newState OUTLIER, newEnergyWO -1
   {
-    std::vector<float> rec((size_t)nr * 16, 0.f);
-    for (int o = 0; o < nr; o++) rec[(size_t)o * 16 + RR_TARGET] = (float)Win->res_target[o];
+    std::vector<float> rec((size_t)np * nf * 16, 0.f);
+    std::vector<uint8_t> seen((size_t)np * nf, 0);
+    for (int o = 0; o < nr; o++) {
+      const size_t slot = (size_t)Win->res_point[o] * nf + Win->res_target[o];
+      SDSO_REQUIRE(ctx, !seen[slot], "two residuals of one point observe the same target frame");
+      seen[slot] = 1;
+      rec[slot * 16 + RR_TARGET] = (float)Win->res_target[o];
+    }
     H2D(d.r_rec, rec.data(), sizeof(float) * rec.size());
     std::vector<uint8_t> ns(nr, 2);
     H2D(d.r_newState, ns.data(), nr);
@@ -355,10 +365,7 @@ static void launch_accumulate(sdso_ctx* ctx, const BaLaunch& L, const uint8_t* p
 #define SC_CASE(N) case N: hipLaunchKernelGGL(k_ba_sc_reg<N>, grid, blk, 0, ctx->stream, L.d_arr, pflag, shift, mm); break;
       SC_CASE(1) SC_CASE(2) SC_CASE(3) SC_CASE(4) SC_CASE(5) SC_CASE(6) SC_CASE(7) SC_CASE(8)
 #undef SC_CASE
-      default: {
-        const size_t lds = sizeof(float) * (BA_BLOCK / 64) * (size_t)(nf * nf * 64 + nf * 32 + nf * 8);
-        hipLaunchKernelGGL(k_ba_sc, grid, blk, lds, ctx->stream, L.d_arr, pflag, shift, mm);
-      }
+      default: break;   // nf <= 8 is enforced at upload
     }
   }
   hipLaunchKernelGGL(k_ba_fold_sc, dim3(nf * nf * nf + nf * nf + 1, L.nwin), dim3(64), 0, ctx->stream, L.d_arr);
@@ -490,9 +497,9 @@ extern "C" int sdso_ba_get_residual_state(sdso_ctx* ctx, int win, uint8_t* state
   if (state && nr) { SDSO_HIP(ctx, hipMemcpy(t.data(), W->d.r_state, nr, hipMemcpyDeviceToHost)); for (int j = 0; j < nr; j++) state[W->perm[j]] = t[j]; }
   if (isActive && nr) { SDSO_HIP(ctx, hipMemcpy(t.data(), W->d.r_act, nr, hipMemcpyDeviceToHost)); for (int j = 0; j < nr; j++) isActive[W->perm[j]] = t[j]; }
   if (JpJdF && nr) {
-    std::vector<float> rec((size_t)nr * 16);
+    std::vector<float> rec((size_t)W->d.np * W->d.nf * 16);
     SDSO_HIP(ctx, hipMemcpy(rec.data(), W->d.r_rec, sizeof(float) * rec.size(), hipMemcpyDeviceToHost));
-    for (int o = 0; o < nr; o++) std::memcpy(JpJdF + (size_t)o * 8, &rec[(size_t)o * 16], 32);
+    for (int j = 0; j < nr; j++) std::memcpy(JpJdF + (size_t)W->perm[j] * 8, &rec[((size_t)W->h_point[j] * W->d.nf + W->h_target[j]) * 16], 32);
   }
   return SDSO_OK;
 }

@@ -116,23 +116,34 @@ __device__ double linearize_one(const BaDev& B, int i) {
   const float4 w0 = *(const float4*)(B.p_weights + (size_t)pt * 8), w1 = *(const float4*)(B.p_weights + (size_t)pt * 8 + 4);
   const float color[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
   const float weights[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+  // Pass 1 (no memory traffic): project the 8 pattern pixels; the residual is OOB as soon as one leaves
+  // the image (Residuals.cpp:215-225).  Doing this first removes the early exit from the sampling loop, so
+  // the 32 bilinear taps below are independent loads the hardware can keep in flight together.
+  float Kus[8], Kvs[8];
   bool oob = false;
-  float jab1[8];
 #pragma unroll
   for (int idx = 0; idx < 8; idx++) {
-    if (oob) break;
     const float up = pu + c_pattern[idx][0], vp = pv + c_pattern[idx][1];
     float q[3];
 #pragma unroll
     for (int r = 0; r < 3; r++) q[r] = ((KRKi[r * 3 + 0] * up + KRKi[r * 3 + 1] * vp) + KRKi[r * 3 + 2]) + Kt[r] * idepth_scaled;
-    const float Ku = q[0] / q[2];
-    const float Kv = q[1] / q[2];
-    if (!(Ku > 1.1f && Kv > 1.1f && Ku < B.wM3 && Kv < B.hM3)) { oob = true; break; }
+    Kus[idx] = q[0] / q[2];
+    Kvs[idx] = q[1] / q[2];
+    if (!(Kus[idx] > 1.1f && Kvs[idx] > 1.1f && Kus[idx] < B.wM3 && Kvs[idx] < B.hM3)) oob = true;
+  }
+  if (oob) { B.r_newState[i] = 1; return (double)B.r_energy[i]; }
+  float3 hits[8];
+#pragma unroll
+  for (int idx = 0; idx < 8; idx++) hits[idx] = interp33(dIl, Kus[idx], Kvs[idx], B.w);
+  float jab1[8];
+#pragma unroll
+  for (int idx = 0; idx < 8; idx++) {
+    const float Ku = Kus[idx], Kv = Kvs[idx];
     if (B.r_proj) { B.r_proj[(size_t)i * 19 + idx * 2] = Ku; B.r_proj[(size_t)i * 19 + idx * 2 + 1] = Kv; }
-    float3 hit = interp33(dIl, Ku, Kv, B.w);
+    float3 hit = hits[idx];
+    if (!isfinite(hit.x)) oob = true;
     const float residual = hit.x - (affLL0 * color[idx] + affLL1);
     const float drdA = (color[idx] - b0);
-    if (!isfinite(hit.x)) { oob = true; break; }
     float wgt = sqrtf(kOutlierTHSumComponent / (kOutlierTHSumComponent + (hit.y * hit.y + hit.z * hit.z)));
     wgt = 0.5f * (wgt + weights[idx]);
     float hw = fabsf(residual) < kHuberTH ? 1 : kHuberTH / fabsf(residual);
@@ -187,7 +198,7 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_apply(const BaDev* __restrict__
   const BaDev& B = wins[blockIdx.y];
   const int i = blockIdx.x * BA_BLOCK + threadIdx.x;
   if (i >= B.nr) return;
-  float* rec = B.r_rec + (size_t)B.r_orig[i] * 16;
+  float* rec = B.r_rec + ((size_t)B.r_point[i] * B.nf + B.r_target[i]) * 16;
   if (B.r_lin[i]) return;
   const uint8_t st = B.r_state[i];
   if (st == 1) return;  // can never go back from OOB
@@ -248,7 +259,7 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_fixlin(const BaDev* __restrict_
     B.r_toZero[k * S + i] = rtz;
   }
   B.r_lin[i] = 1;
-  B.r_rec[(size_t)B.r_orig[i] * 16 + RR_FLAGS] = 3.f;  // active | linearized
+  B.r_rec[((size_t)pt * B.nf + B.r_target[i]) * 16 + RR_FLAGS] = 3.f;  // active | linearized
 }
 
 // resetOOB + isLinearized=false for the residuals of flagged points (FullSystem.cpp:1012-1016)
@@ -348,7 +359,7 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_accum_top(const BaDev* __restri
     const float a10 = JV(J_IDX2 + 2);
     const float q0 = a * jdd0 + b * jdd1;
     const float q1 = a10 * jdd0 + c * jdd1;
-    float* rec = B.r_rec + (size_t)B.r_orig[i] * 16;
+    float* rec = B.r_rec + ((size_t)pt * B.nf + ch.x / B.nf) * 16;   // pair = host + target*nf
     rec[RR_BD] = JI_r0 * jdd0 + JI_r1 * jdd1;
     rec[RR_HDD] = q0 * jdd0 + q1 * jdd1;
 #pragma unroll
@@ -419,115 +430,14 @@ __global__ __launch_bounds__(128) void k_ba_zero_topL(const BaDev* __restrict__ 
 }
 
 // ------------------------------------------------------------------ per-point Schur accumulation
-// One wave per item (= up to BA_SC_PTS consecutive points of ONE host).  Lane (a,c)=(lane>>3,lane&7)
-// owns element (a,c) of every 8x8 D block; the item's nf x nf D tiles live in LDS.
-// pflag: when non-null only flagged points are processed (marginalizePointsF) and shiftPriorToZero=false.
-__global__ __launch_bounds__(BA_BLOCK) void k_ba_sc(const BaDev* __restrict__ wins, const uint8_t* __restrict__ pflag, int shiftPriorToZero, int margMode) {
-  const BaDev& B = wins[blockIdx.y];
-  extern __shared__ float lds_all[];
-  const int nf = B.nf;
-  const int per_wave = nf * nf * 64 + nf * 32 + nf * 8;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int item = blockIdx.x * (BA_BLOCK / 64) + wv;
-  if (item >= B.nitems) return;
-  volatile float* D = lds_all + (size_t)wv * per_wave;
-  volatile float* E = D + nf * nf * 64;
-  volatile float* EB = E + nf * 32;
-  for (int k = lane; k < per_wave; k += 64) D[k] = 0.f;
-  const int4 it = B.items[item];
-  const int la = lane >> 3, lc = lane & 7;
-  float hcc = 0.f, bcv = 0.f;  // lanes 0..15: Hcc[a][c] (a=lane>>2,c=lane&3); lanes 0..3: bc
-  for (int p = it.y; p < it.z; p++) {
-    const int cnt = B.p_rcnt[p], beg = B.p_rbeg[p];
-    float* po = B.p_out + (size_t)p * 16;
-    if (pflag && !pflag[p]) continue;
-    // gather the point's residual records (uniform addresses -> broadcast loads)
-    float Ja[8], Jc[8], Je[8];
-    int tg[8];
-    bool act[8];
-    float Hdd_A = 0, bd_A = 0, Hdd_L = 0, bd_L = 0, HcdA[4] = {0, 0, 0, 0}, HcdL[4] = {0, 0, 0, 0};
-    int ngood = 0;
-#pragma unroll
-    for (int s = 0; s < 8; s++) {
-      act[s] = false; Ja[s] = 0; Jc[s] = 0; Je[s] = 0; tg[s] = 0;
-      if (s < cnt) {
-        const float* rec = B.r_rec + (size_t)(beg + s) * 16;
-        const int fl = (int)rec[RR_FLAGS];
-        if (fl & 1) {
-          act[s] = true;
-          ngood++;
-          tg[s] = (int)rec[RR_TARGET];
-          Ja[s] = rec[la];
-          Jc[s] = rec[lc];
-          Je[s] = rec[(lane >> 2) & 7];
-          const bool lin = (fl & 2) != 0;
-          // mode 0 sums non-linearized, mode 1/2 linearized residuals (AccumulatedTopHessian.cpp:54-71, 177-192)
-          if (!lin && !margMode) {
-            bd_A += rec[RR_BD]; Hdd_A += rec[RR_HDD];
-#pragma unroll
-            for (int k = 0; k < 4; k++) HcdA[k] += rec[RR_HCD + k];
-          } else {
-            bd_L += rec[RR_BD]; Hdd_L += rec[RR_HDD];
-#pragma unroll
-            for (int k = 0; k < 4; k++) HcdL[k] += rec[RR_HCD + k];
-          }
-        }
-      }
-    }
-    float HdiF = 0, bdSumF = 0;
-    float Hcd[4] = {0, 0, 0, 0};
-    if (ngood > 0) {
-      float H = Hdd_A + Hdd_L + B.p_prior[p];
-      if (H < 1e-10) H = 1e-10;
-      HdiF = 1.0 / H;
-      bdSumF = bd_A + bd_L;
-      if (shiftPriorToZero) bdSumF += B.p_prior[p] * B.p_delta[p];
-#pragma unroll
-      for (int k = 0; k < 4; k++) Hcd[k] = HcdA[k] + HcdL[k];
-    }
-    if (lane == 0) {
-      po[PO_HDD_A] = Hdd_A; po[PO_BD_A] = bd_A; po[PO_HDD_L] = Hdd_L; po[PO_BD_L] = bd_L;
-#pragma unroll
-      for (int k = 0; k < 4; k++) { po[PO_HCD_A + k] = HcdA[k]; po[PO_HCD_L + k] = HcdL[k]; }
-      po[PO_HDI] = HdiF; po[PO_BDSUM] = bdSumF;
-    }
-    if (ngood == 0) continue;
-    if (lane < 16) hcc += (HdiF * Hcd[lane >> 2]) * Hcd[lane & 3];
-    if (lane < 4) bcv += (bdSumF * HdiF) * Hcd[lane];
-#pragma unroll
-    for (int s1 = 0; s1 < 8; s1++) {
-      if (!act[s1]) continue;
-      const float wl = HdiF * Ja[s1];
-      const int t1 = tg[s1];
-#pragma unroll
-      for (int s2 = 0; s2 < 8; s2++) {
-        if (!act[s2]) continue;
-        const int bin = t1 * nf + tg[s2];
-        D[bin * 64 + lane] = D[bin * 64 + lane] + wl * Jc[s2];
-      }
-    }
-    // accE: (HdiF*JpJdF[a]) * Hcd[c], a = lane>>2 (0..7), c = lane&3 ; accEB: (HdiF*bdSumF) * JpJdF[a], a = lane (0..7)
-#pragma unroll
-    for (int s1 = 0; s1 < 8; s1++) {
-      if (!act[s1]) continue;
-      const int t1 = tg[s1];
-      if (lane < 32) E[t1 * 32 + lane] = E[t1 * 32 + lane] + (HdiF * Je[s1]) * Hcd[lane & 3];
-      if (lane < 8) EB[t1 * 8 + lane] = EB[t1 * 8 + lane] + (HdiF * bdSumF) * Jc[s1];
-    }
-  }
-  // flush this item's partial tiles
-  float* out = B.sc_part + (size_t)item * sc_part_floats(nf);
-  for (int k = lane; k < per_wave; k += 64) out[k] = D[k];
-  if (lane < 16) out[per_wave + lane] = hcc;
-  if (lane < 4) out[per_wave + 16 + lane] = bcv;
-}
-
-// Register-tile variant for nf known at compile time (nf <= 8): lane (a,c) keeps its element of all
-// NF x NF D tiles in VGPRs; a point's residual vectors are first scattered to per-TARGET slots (a point
-// has at most one residual per target), so the tile index is a compile-time constant and targets
-// without a residual add an exact +0.  Same accumulation order per tile as the LDS variant.
-// Memory: the <=8 records of a point are contiguous (r_rec is in point order): two coalesced 256-B
-// loads fetch them all, issued one point ahead of their use; fields reach their lanes by shuffles.
+// AccumulatedSCHessianSSE::addPoint for nf <= 8 (template NF).  One wave per item (<= 64 consecutive
+// points of ONE host); lane (a,c) = (lane>>3, lane&7) keeps element (a,c) of all NF x NF 8x8 D tiles of
+// that host in VGPRs, lanes 0..31 / 0..7 the E / EB rows.
+// The per-residual records of a point form a dense [target] table (r_rec[p][t], 64 B each, flags 0 when
+// the point has no residual to t), so "slot == target": tile indices are compile-time constants, nothing
+// is scattered, there is no branch in the loop, and one point costs two coalesced 256-B loads (issued one
+// point ahead) + cross-lane moves.  Absent residuals contribute exact zeros.
+// Per-point sums (Hdd/bd/Hcd) run in TARGET order.
 template <int NF>
 __global__ __launch_bounds__(BA_BLOCK) void k_ba_sc_reg(const BaDev* __restrict__ wins, const uint8_t* __restrict__ pflag, int shiftPriorToZero, int margMode) {
   const BaDev& B = wins[blockIdx.y];
@@ -544,95 +454,91 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_sc_reg(const BaDev* __restrict_
     for (int j = 0; j < NF; j++) D[i][j] = 0.f;
   }
   float hcc = 0.f, bcv = 0.f;
-  // per-lane copy of (count, begin, prior, delta, flag) of point it.y + lane  (items hold <= 64 points)
   const int npts = it.z - it.y;
-  int my_cnt = 0, my_beg = 0; float my_prior = 0.f, my_delta = 0.f; int my_on = 0;
+  float my_prior = 0.f, my_delta = 0.f; int my_on = 0;
   if (lane < npts) {
     const int p = it.y + lane;
-    my_cnt = B.p_rcnt[p]; my_beg = B.p_rbeg[p]; my_prior = B.p_prior[p]; my_delta = B.p_delta[p];
+    my_prior = B.p_prior[p]; my_delta = B.p_delta[p];
     my_on = pflag ? (int)pflag[p] : 1;
-    if (!my_on) my_cnt = 0;
   }
-  auto fetch = [&](int q, float& a, float& b) {   // records of point q (index inside the item) -> two coalesced loads
-    const int cnt = __shfl(my_cnt, q, 64), beg = __shfl(my_beg, q, 64);
-    const float* base = B.r_rec + (size_t)beg * 16;
-    a = lane < cnt * 16 ? base[lane] : 0.f;
-    b = lane + 64 < cnt * 16 ? base[lane + 64] : 0.f;
+  auto fetch = [&](int q, float& a, float& b) {
+    const float* base = B.r_rec + (size_t)(it.y + q) * NF * 16;
+    a = lane < NF * 16 ? base[lane] : 0.f;
+    b = lane + 64 < NF * 16 ? base[lane + 64] : 0.f;
   };
   float vA = 0.f, vB = 0.f, nA = 0.f, nB = 0.f;
+  // per-point outputs are parked in the registers of lane q and stored once after the loop
+  float o_hddA = 0, o_bdA = 0, o_hddL = 0, o_bdL = 0, o_hdi = 0, o_bds = 0;
+  float o_hcA0 = 0, o_hcA1 = 0, o_hcA2 = 0, o_hcA3 = 0, o_hcL0 = 0, o_hcL1 = 0, o_hcL2 = 0, o_hcL3 = 0;
   if (npts > 0) fetch(0, vA, vB);
   for (int q = 0; q < npts; q++) {
     if (q + 1 < npts) fetch(q + 1, nA, nB);   // in flight while point q is processed
-    const int cnt = __shfl(my_cnt, q, 64);
     const float prior = __shfl(my_prior, q, 64), delta = __shfl(my_delta, q, 64);
-    const int on = __shfl(my_on, q, 64);
-    const int p = it.y + q;
-    float* po = B.p_out + (size_t)p * 16;
-    if (on) {
-      float JaT[NF], JcT[NF], JeT[NF];
-      bool has[NF];
+    const float onf = __shfl(my_on, q, 64) ? 1.f : 0.f;
+    float ja[NF], jc[NF], je[NF];
+    float Hdd_A = 0, bd_A = 0, Hdd_L = 0, bd_L = 0, HcdA[4] = {0, 0, 0, 0}, HcdL[4] = {0, 0, 0, 0};
+    float ngood = 0;
 #pragma unroll
-      for (int t = 0; t < NF; t++) { JaT[t] = 0.f; JcT[t] = 0.f; JeT[t] = 0.f; has[t] = false; }
-      float Hdd_A = 0, bd_A = 0, Hdd_L = 0, bd_L = 0, HcdA[4] = {0, 0, 0, 0}, HcdL[4] = {0, 0, 0, 0};
-      int ngood = 0;
+    for (int t = 0; t < NF; t++) {
+      const float src = t < 4 ? vA : vB;
+      const int o = (t & 3) * 16;
+      const int isrc = __float_as_int(src);
+      const int fl = (int)__int_as_float(__builtin_amdgcn_readlane(isrc, o + RR_FLAGS));
+      const float m = ((fl & 1) ? 1.f : 0.f) * onf;                          // residual present and active
+      const float mA = (!(fl & 2) && !margMode) ? m : 0.f, mL = m - mA;      // mode 0 vs mode 1/2 sums (AccumulatedTopHessian.cpp:54-71)
+      const float rbd = __int_as_float(__builtin_amdgcn_readlane(isrc, o + RR_BD));
+      const float rhdd = __int_as_float(__builtin_amdgcn_readlane(isrc, o + RR_HDD));
+      float rh[4];
 #pragma unroll
-      for (int s = 0; s < 8; s++) {
-        if (s < cnt) {
-          const float src = s < 4 ? vA : vB;
-          const int o = (s & 3) * 16;
-          const int fl = (int)__shfl(src, o + RR_FLAGS, 64);
-          if (fl & 1) {
-            ngood++;
-            const int tg = (int)__shfl(src, o + RR_TARGET, 64);
-            const float ja = __shfl(src, o + la, 64), jc = __shfl(src, o + lc, 64), je = __shfl(src, o + le, 64);
+      for (int k = 0; k < 4; k++) rh[k] = __int_as_float(__builtin_amdgcn_readlane(isrc, o + RR_HCD + k));
+      ngood += m;
+      // masked adds: x + 0 is exact, so inactive / absent slots leave the sums untouched
+      bd_A += mA != 0.f ? rbd : 0.f; Hdd_A += mA != 0.f ? rhdd : 0.f;
+      bd_L += mL != 0.f ? rbd : 0.f; Hdd_L += mL != 0.f ? rhdd : 0.f;
 #pragma unroll
-            for (int t = 0; t < NF; t++)
-              if (t == tg) { JaT[t] = ja; JcT[t] = jc; JeT[t] = je; has[t] = true; }
-            const float rbd = __shfl(src, o + RR_BD, 64), rhdd = __shfl(src, o + RR_HDD, 64);
-            const float h0 = __shfl(src, o + RR_HCD, 64), h1 = __shfl(src, o + RR_HCD + 1, 64), h2 = __shfl(src, o + RR_HCD + 2, 64), h3 = __shfl(src, o + RR_HCD + 3, 64);
-            // mode 0 sums the non-linearized, mode 1/2 the linearized residuals (AccumulatedTopHessian.cpp:54-71, 177-192)
-            if (!(fl & 2) && !margMode) {
-              bd_A += rbd; Hdd_A += rhdd; HcdA[0] += h0; HcdA[1] += h1; HcdA[2] += h2; HcdA[3] += h3;
-            } else {
-              bd_L += rbd; Hdd_L += rhdd; HcdL[0] += h0; HcdL[1] += h1; HcdL[2] += h2; HcdL[3] += h3;
-            }
-          }
-        }
-      }
-      float HdiF = 0, bdSumF = 0;
-      float Hcd[4] = {0, 0, 0, 0};
-      if (ngood > 0) {
-        float H = Hdd_A + Hdd_L + prior;
-        if (H < 1e-10) H = 1e-10;
-        HdiF = 1.0 / H;
-        bdSumF = bd_A + bd_L;
-        if (shiftPriorToZero) bdSumF += prior * delta;
+      for (int k = 0; k < 4; k++) { HcdA[k] += mA != 0.f ? rh[k] : 0.f; HcdL[k] += mL != 0.f ? rh[k] : 0.f; }
+      const float sa = __shfl(src, o + la, 64), sc = __shfl(src, o + lc, 64), se = __shfl(src, o + le, 64);
+      ja[t] = m != 0.f ? sa : 0.f; jc[t] = m != 0.f ? sc : 0.f; je[t] = m != 0.f ? se : 0.f;
+    }
+    float HdiF = 0, bdSumF = 0;
+    float Hcd[4] = {0, 0, 0, 0};
+    {
+      float H = Hdd_A + Hdd_L + prior;
+      if (H < 1e-10) H = 1e-10;
+      const float hdi = 1.0 / H;
+      float bds = bd_A + bd_L;
+      if (shiftPriorToZero) bds += prior * delta;
+      const bool any = ngood > 0.f;
+      HdiF = any ? hdi : 0.f; bdSumF = any ? bds : 0.f;
 #pragma unroll
-        for (int k = 0; k < 4; k++) Hcd[k] = HcdA[k] + HcdL[k];
-      }
-      if (lane == 0) {
-        *(float4*)(po + 0) = make_float4(Hdd_A, bd_A, HcdA[0], HcdA[1]);
-        *(float4*)(po + 4) = make_float4(HcdA[2], HcdA[3], Hdd_L, bd_L);
-        *(float4*)(po + 8) = make_float4(HcdL[0], HcdL[1], HcdL[2], HcdL[3]);
-        po[PO_HDI] = HdiF; po[PO_BDSUM] = bdSumF;
-      }
-      if (ngood > 0) {
-        if (lane < 16) hcc += (HdiF * Hcd[lane >> 2]) * Hcd[lane & 3];
-        if (lane < 4) bcv += (bdSumF * HdiF) * Hcd[lane];
-        const float hb = HdiF * bdSumF;
-        const float hc = Hcd[lane & 3];
+      for (int k = 0; k < 4; k++) Hcd[k] = any ? HcdA[k] + HcdL[k] : 0.f;
+    }
+    if (lane == q) {
+      o_hddA = Hdd_A; o_bdA = bd_A; o_hddL = Hdd_L; o_bdL = bd_L; o_hdi = HdiF; o_bds = bdSumF;
+      o_hcA0 = HcdA[0]; o_hcA1 = HcdA[1]; o_hcA2 = HcdA[2]; o_hcA3 = HcdA[3];
+      o_hcL0 = HcdL[0]; o_hcL1 = HcdL[1]; o_hcL2 = HcdL[2]; o_hcL3 = HcdL[3];
+    }
+    // ngood == 0 => HdiF = 0 and every ja/jc/je is 0: all updates below add exact zeros
+    hcc += (HdiF * Hcd[(lane >> 2) & 3]) * Hcd[lane & 3];
+    bcv += (bdSumF * HdiF) * Hcd[lane & 3];
+    const float hb = HdiF * bdSumF;
+    const float hc = Hcd[lane & 3];
 #pragma unroll
-        for (int t1 = 0; t1 < NF; t1++) {
-          if (!has[t1]) continue;   // wave-uniform: targets without a residual contribute exact zeros
-          const float wl = HdiF * JaT[t1];
+    for (int t1 = 0; t1 < NF; t1++) {
+      const float wl = HdiF * ja[t1];
 #pragma unroll
-          for (int t2 = 0; t2 < NF; t2++) D[t1][t2] = D[t1][t2] + wl * JcT[t2];
-          E[t1] = E[t1] + (HdiF * JeT[t1]) * hc;
-          EB[t1] = EB[t1] + hb * JcT[t1];
-        }
-      }
+      for (int t2 = 0; t2 < NF; t2++) D[t1][t2] = D[t1][t2] + wl * jc[t2];
+      E[t1] = E[t1] + (HdiF * je[t1]) * hc;
+      EB[t1] = EB[t1] + hb * jc[t1];
     }
     vA = nA; vB = nB;
+  }
+  if (lane < npts && my_on) {
+    float* po = B.p_out + (size_t)(it.y + lane) * 16;
+    *(float4*)(po + 0) = make_float4(o_hddA, o_bdA, o_hcA0, o_hcA1);
+    *(float4*)(po + 4) = make_float4(o_hcA2, o_hcA3, o_hddL, o_bdL);
+    *(float4*)(po + 8) = make_float4(o_hcL0, o_hcL1, o_hcL2, o_hcL3);
+    po[PO_HDI] = o_hdi; po[PO_BDSUM] = o_bds;
   }
   float* out = B.sc_part + (size_t)item * sc_part_floats(NF);
 #pragma unroll

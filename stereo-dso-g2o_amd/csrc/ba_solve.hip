@@ -365,10 +365,11 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_resub(const BaDev* __restrict__
   const int p = blockIdx.x * BA_BLOCK + threadIdx.x;
   if (p >= B.np) return;
   float* po = B.p_out + (size_t)p * 16;
-  const int cnt = B.p_rcnt[p], beg = B.p_rbeg[p];
   const double* x = B.sol + 3 * ((size_t)B.n * B.n + B.n);
+  const int nf = B.nf;
+  const float* recs = B.r_rec + (size_t)p * nf * 16;
   int ngood = 0;
-  for (int s = 0; s < cnt; s++) if (((int)B.r_rec[(size_t)(beg + s) * 16 + RR_FLAGS]) & 1) ngood++;
+  for (int t = 0; t < nf; t++) if (((int)recs[t * 16 + RR_FLAGS]) & 1) ngood++;
   if (ngood == 0) { po[PO_STEP] = 0; return; }
   float b = po[PO_BDSUM];
   float d = 0;
@@ -376,10 +377,10 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_resub(const BaDev* __restrict__
   for (int k = 0; k < 4; k++) d += (float)x[k] * (po[PO_HCD_A + k] + po[PO_HCD_L + k]);
   b -= d;
   const int h = B.p_host[p];
-  for (int s = 0; s < cnt; s++) {
-    const float* rec = B.r_rec + (size_t)(beg + s) * 16;
+  for (int t = 0; t < nf; t++) {       // residuals in target order
+    const float* rec = recs + t * 16;
     if (!(((int)rec[RR_FLAGS]) & 1)) continue;
-    const float* xa = B.t_xAd + (size_t)(h * B.nf + (int)rec[RR_TARGET]) * 8;
+    const float* xa = B.t_xAd + (size_t)(h * nf + t) * 8;
     float sacc = 0;
 #pragma unroll
     for (int k = 0; k < 8; k++) sacc += xa[k] * rec[k];
