@@ -22,7 +22,7 @@ class _DevBlob:
 
 class BAWorkload:
     name = "windowed_ba_8kf_2kpts_per_gpu_kitti1232x368"
-    kernel = "k_ba_linearize"
+    kernel = "k_ba_lin_fused"
     unit = "point-residuals/s"
     bytes_per_unit = 760.0  # 80 B point + 8x4 taps x 12 B + 296 B RawResidualJacobian written
 
@@ -50,6 +50,10 @@ class BAWorkload:
         self.ids = np.array(ids, np.int32)
         ctx.check(ctx.L.sdso_ba_batch_create(ctx.h, nwin, abi.ip(self.ids)))
         self.nwin = nwin
+        self.materialize = 0 if os.environ.get("SDSO_BA_NO_J") == "1" else 1
+        ctx.check(ctx.L.sdso_ba_batch_set_materialize(ctx.h, self.materialize))
+        if not self.materialize:
+            self.bytes_per_unit = 464.0  # SURVEY §8d figure without the Jacobian record
         self.units_per_step = nwin * win["nr"]
         ptr, nfl = C.c_void_p(), C.c_long(0)
         ctx.check(ctx.L.sdso_ba_batch_accum_dev(ctx.h, C.byref(ptr), C.byref(nfl)))
@@ -58,7 +62,7 @@ class BAWorkload:
             self.accum = torch.as_tensor(_DevBlob(ptr.value, nfl.value), device="cuda")
             self.stream = torch.cuda.ExternalStream(ctx.L.sdso_ctx_stream(ctx.h))
         self.config = {"workload": self.name, "windows_per_step": nwin, "keyframes": nf, "points_per_window_per_gpu": win["np"],
-                       "residuals_per_window_per_gpu": win["nr"], "allreduce_floats": int(nfl.value) if world > 1 else 0,
+                       "residuals_per_window_per_gpu": win["nr"], "jacobians_materialized": bool(self.materialize), "allreduce_floats": int(nfl.value) if world > 1 else 0,
                        "parallelism": ("points sharded over %d ranks, 1 RCCL all-reduce of the packed accumulators per iteration" % world) if world > 1 else "single GPU"}
         print("[rank %d] BA setup %.1fs: %d windows x %d residuals" % (rank, time.time() - t0, nwin, win["nr"]), file=sys.stderr, flush=True)
 
@@ -76,7 +80,8 @@ class BAWorkload:
         self.ctx.check(self.ctx.L.sdso_ba_batch_get_x(self.ctx.h, self.abi.dp(x)))
         assert np.isfinite(x).all() and np.abs(x).max() > 0
         out = {"ba_window_iters_per_s_per_gpu": None, "max_abs_x": float(np.abs(x).max())}
-        for k in ("k_ba_linearize", "k_ba_accum_top", "k_ba_sc"):
+        out["jacobians_materialized"] = bool(self.materialize)
+        for k in ("k_ba_lin_fused", "k_ba_sc"):
             ms, n = self.ctx.prof_read(k)
             out[k + "_avg_ms"] = ms / max(n, 1)
         return out

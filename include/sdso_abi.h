@@ -52,7 +52,7 @@ void* sdso_ctx_stream(sdso_ctx* ctx);
 int sdso_ctx_sync(sdso_ctx* ctx);
 
 /* Optional kernel timing with HIP events recorded on the ctx stream around the launches of the
- * dominant kernels ("k_track_eval", "k_ba_linearize", "k_ba_accum_top", "k_ba_sc", "k_trace_stereo").
+ * dominant kernels ("k_track_eval", "k_ba_lin_fused", "k_ba_linearize", "k_ba_accum_top", "k_ba_sc", "k_trace_stereo").
  * sdso_prof_read synchronises the stream and returns the accumulated milliseconds / launch count. */
 int sdso_prof_enable(sdso_ctx* ctx, int on);
 int sdso_prof_reset(sdso_ctx* ctx);
@@ -264,6 +264,9 @@ int sdso_ba_keep_projections(sdso_ctx* ctx, int win, int on);
  *   sdso_ba_batch_get_x      : lastX of every window (synchronises)                          */
 int sdso_ba_batch_create(sdso_ctx* ctx, int nwin, const int* wins);
 int sdso_ba_batch_accumulate(sdso_ctx* ctx);
+/* 1 (default): every linearization writes the RawResidualJacobian records to HBM like
+ * PointFrameResidual::J; 0: they stay in registers of the fused linearize+accumulate kernel. */
+int sdso_ba_batch_set_materialize(sdso_ctx* ctx, int materialize);
 int sdso_ba_batch_solve(sdso_ctx* ctx, double lambda, int orthogonalize_x);
 int sdso_ba_batch_accum_dev(sdso_ctx* ctx, void** dev_ptr, long* nfloats);
 int sdso_ba_batch_get_x(sdso_ctx* ctx, double* x /* nwin*(8nf+4) */);

@@ -70,6 +70,7 @@ struct BaBatch {
   BaDev* d_arr = nullptr;
   float* d_accum = nullptr;
   BaLaunch L;
+  bool materialize = true;
 };
 static std::map<sdso_ctx*, BaBatch*> g_batches;
 static void free_batch(sdso_ctx* ctx) {
@@ -261,7 +262,7 @@ extern "C" int sdso_ba_upload_window(sdso_ctx* ctx, int win, const sdso_ba_windo
   const float4** d_img; DM(d_img, const float4*, nf);
   int4* d_chunks; int* d_pair_beg; int4* d_items; int* d_host_beg;
   DM(d_chunks, int4, chunks.size()); DM(d_pair_beg, int, nf * nf + 1); DM(d_items, int4, items.size()); DM(d_host_beg, int, nf + 1);
-  DM(d.top_part, float, (size_t)d.nchunks * 92); DM(d.sc_part, float, (size_t)d.nitems * sc_part_floats(nf)); DM(d.e_part, double, W->nblk_res + 1);
+  DM(d.top_part, float, (size_t)d.nchunks * 92); DM(d.sc_part, float, (size_t)d.nitems * sc_part_floats(nf)); DM(d.e_part, double, std::max(W->nblk_res, d.nchunks) + 1);
   DM(d.accum, float, acc_floats(nf));
   DM(d.sol, double, 4 * ((size_t)n * n + n) + n);
   DM(W->d_pflag, uint8_t, np); DM(W->d_sums, float, 2 * (W->nblk_pts + 1));
@@ -339,6 +340,7 @@ static void launch_linearize(sdso_ctx* ctx, const BaLaunch& L) {
 static void launch_apply(sdso_ctx* ctx, const BaLaunch& L) {
   hipLaunchKernelGGL(k_ba_apply, dim3(L.max_nblk_res, L.nwin), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr);
 }
+static void launch_sc_and_folds(sdso_ctx* ctx, const BaLaunch& L, const uint8_t* pflag, bool marg);
 static void launch_accumulate(sdso_ctx* ctx, const BaLaunch& L, const uint8_t* pflag, bool marg) {
   const int nf = L.nf;
   if (L.max_chunks > 0) {
@@ -357,6 +359,10 @@ static void launch_accumulate(sdso_ctx* ctx, const BaLaunch& L, const uint8_t* p
       hipLaunchKernelGGL(k_ba_fold_top, dim3(nf * nf, L.nwin), dim3(128), 0, ctx->stream, L.d_arr, 0);
     }
   }
+  launch_sc_and_folds(ctx, L, pflag, marg);
+}
+static void launch_sc_and_folds(sdso_ctx* ctx, const BaLaunch& L, const uint8_t* pflag, bool marg) {
+  const int nf = L.nf;
   if (L.max_items > 0) {
     ProfScope ps(ctx, "k_ba_sc");
     const dim3 grid((L.max_items + BA_BLOCK / 64 - 1) / (BA_BLOCK / 64), L.nwin), blk(BA_BLOCK);
@@ -369,6 +375,25 @@ static void launch_accumulate(sdso_ctx* ctx, const BaLaunch& L, const uint8_t* p
     }
   }
   hipLaunchKernelGGL(k_ba_fold_sc, dim3(nf * nf * nf + nf * nf + 1, L.nwin), dim3(64), 0, ctx->stream, L.d_arr);
+}
+// linearizeAll + applyRes + accumulateAF in one kernel, then the (normally empty) linearized pass and the Schur part
+static void launch_fused(sdso_ctx* ctx, const BaLaunch& L, bool materialize) {
+  const int nf = L.nf;
+  if (L.max_chunks > 0) {
+    {
+      ProfScope ps(ctx, "k_ba_lin_fused");
+      if (materialize) hipLaunchKernelGGL(k_ba_lin_fused<true>, dim3(L.max_chunks, L.nwin), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr);
+      else hipLaunchKernelGGL(k_ba_lin_fused<false>, dim3(L.max_chunks, L.nwin), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr);
+    }
+    hipLaunchKernelGGL(k_ba_fold_top, dim3(nf * nf, L.nwin), dim3(128), 0, ctx->stream, L.d_arr, 0);
+    if (L.any_lin) {
+      hipLaunchKernelGGL(k_ba_accum_top, dim3(L.max_chunks, L.nwin), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr, 1, (const uint8_t*)nullptr);
+      hipLaunchKernelGGL(k_ba_fold_top, dim3(nf * nf, L.nwin), dim3(128), 0, ctx->stream, L.d_arr, 1);
+    } else {
+      hipLaunchKernelGGL(k_ba_zero_topL, dim3(nf * nf, L.nwin), dim3(128), 0, ctx->stream, L.d_arr);
+    }
+  }
+  launch_sc_and_folds(ctx, L, nullptr, false);
 }
 static void launch_solve(sdso_ctx* ctx, const BaLaunch& L, double lambda, int orth) {
   const int nf = L.nf, n = L.n;
@@ -780,10 +805,16 @@ extern "C" int sdso_ba_batch_create(sdso_ctx* ctx, int nwin, const int* wins) {
 extern "C" int sdso_ba_batch_accumulate(sdso_ctx* ctx) {
   if (!ctx || !g_batches.count(ctx) || !g_batches[ctx]) return sdso::fail(ctx, SDSO_ERR_STATE, "no batch");
   BaBatch* Bt = g_batches[ctx];
-  launch_linearize(ctx, Bt->L);
-  launch_apply(ctx, Bt->L);
-  launch_accumulate(ctx, Bt->L, nullptr, false);
+  launch_fused(ctx, Bt->L, Bt->materialize);
   SDSO_HIP(ctx, hipGetLastError());
+  return SDSO_OK;
+}
+// materialize = 1 (default): every linearization also writes the RawResidualJacobian records to HBM
+// (what PointFrameResidual::J holds in the reference); 0: they stay in registers (the solver never
+// re-reads them) — 296 B less store traffic per point-residual.
+extern "C" int sdso_ba_batch_set_materialize(sdso_ctx* ctx, int materialize) {
+  if (!ctx || !g_batches.count(ctx) || !g_batches[ctx]) return sdso::fail(ctx, SDSO_ERR_STATE, "no batch");
+  g_batches[ctx]->materialize = materialize != 0;
   return SDSO_OK;
 }
 // phase 2: stitch + solve + resubstitute (enqueue only). Between the phases the caller may all-reduce

@@ -47,8 +47,18 @@ __host__ __device__ constexpr int jdev(int f) {
 #define JV(f) jl[jdev(f)]
 
 // ------------------------------------------------------------------ linearize
-__device__ double linearize_one(const BaDev& B, int i) {
+// STORE: write the RawResidualJacobian groups to HBM (PointFrameResidual::J);  KEEP: leave them in jl[76]
+// (device layout) for the caller.  ns_out = state_NewState.
+#define SETQ(g, a, b, c, d)                                                              \
+  do {                                                                                   \
+    const float4 _q = make_float4(a, b, c, d);                                           \
+    if (STORE) JQ(J, S, i, g) = _q;                                                      \
+    if (KEEP) { jl[4 * (g)] = _q.x; jl[4 * (g) + 1] = _q.y; jl[4 * (g) + 2] = _q.z; jl[4 * (g) + 3] = _q.w; } \
+  } while (0)
+template <bool STORE, bool KEEP>
+__device__ __forceinline__ double linearize_one(const BaDev& B, int i, float* jl, int& ns_out) {
   B.r_newEnergyWO[i] = -1.f;
+  ns_out = 1;
   const uint8_t st = B.r_state[i];
   if (st == 1) { B.r_newState[i] = 1; return (double)B.r_energy[i]; }
   const int pt = B.r_point[i], h = B.r_host[i], t = B.r_target[i];
@@ -100,12 +110,12 @@ __device__ double linearize_one(const BaDev& B, int i) {
     d_C_y[1] = (d_C_y[1] + v) * SCALE_F;
     d_C_y[2] *= SCALE_C;
     d_C_y[3] = (d_C_y[3] + 1) * SCALE_C;
-    JQ(J, S, i, 0) = make_float4(new_idepth * fxl, 0, -new_idepth * u * fxl, -u * v * fxl);                       // Jpdxi[0][0..3]
-    JQ(J, S, i, 1) = make_float4((1 + u * u) * fxl, -v * fxl, 0, new_idepth * fyl);                                // Jpdxi[0][4..5], Jpdxi[1][0..1]
-    JQ(J, S, i, 2) = make_float4(-new_idepth * v * fyl, -(1 + v * v) * fyl, u * v * fyl, u * fyl);                 // Jpdxi[1][2..5]
-    JQ(J, S, i, 3) = make_float4(d_C_x[0], d_C_x[1], d_C_x[2], d_C_x[3]);
-    JQ(J, S, i, 4) = make_float4(d_C_y[0], d_C_y[1], d_C_y[2], d_C_y[3]);
-    JQ(J, S, i, 5) = make_float4(d_d_x, d_d_y, 0.f, 0.f);
+    SETQ(0, new_idepth * fxl, 0, -new_idepth * u * fxl, -u * v * fxl);                       // Jpdxi[0][0..3]
+    SETQ(1, (1 + u * u) * fxl, -v * fxl, 0, new_idepth * fyl);                                // Jpdxi[0][4..5], Jpdxi[1][0..1]
+    SETQ(2, -new_idepth * v * fyl, -(1 + v * v) * fyl, u * v * fyl, u * fyl);                 // Jpdxi[1][2..5]
+    SETQ(3, d_C_x[0], d_C_x[1], d_C_x[2], d_C_x[3]);
+    SETQ(4, d_C_y[0], d_C_y[1], d_C_y[2], d_C_y[3]);
+    SETQ(5, d_d_x, d_d_y, 0.f, 0.f);
   }
 
   float JIdxJIdx_00 = 0, JIdxJIdx_11 = 0, JIdxJIdx_10 = 0;
@@ -152,7 +162,7 @@ __device__ double linearize_one(const BaDev& B, int i) {
     hw = hw * wgt;
     hit.y *= hw;
     hit.z *= hw;
-    JQ(J, S, i, 6 + idx) = make_float4(residual * hw, hit.y, hit.z, B.affA_fixed ? 0.f : drdA * hw);   // resF, JIdx[0], JIdx[1], JabF[0]
+    SETQ(6 + idx, residual * hw, hit.y, hit.z, B.affA_fixed ? 0.f : drdA * hw);   // resF, JIdx[0], JIdx[1], JabF[0]
     jab1[idx] = B.affB_fixed ? 0.f : hw;
     JIdxJIdx_00 += hit.y * hit.y;
     JIdxJIdx_11 += hit.z * hit.z;
@@ -167,19 +177,21 @@ __device__ double linearize_one(const BaDev& B, int i) {
     wJI2_sum += hw * hw * (hit.y * hit.y + hit.z * hit.z);
   }
   if (oob) { B.r_newState[i] = 1; return (double)B.r_energy[i]; }
-  JQ(J, S, i, 14) = make_float4(jab1[0], jab1[1], jab1[2], jab1[3]);
-  JQ(J, S, i, 15) = make_float4(jab1[4], jab1[5], jab1[6], jab1[7]);
-  JQ(J, S, i, 16) = make_float4(JIdxJIdx_00, JIdxJIdx_10, JIdxJIdx_10, JIdxJIdx_11);
-  JQ(J, S, i, 17) = make_float4(JabJIdx_00, JabJIdx_01, JabJIdx_10, JabJIdx_11);
-  JQ(J, S, i, 18) = make_float4(JabJab_00, JabJab_01, JabJab_01, JabJab_11);
+  SETQ(14, jab1[0], jab1[1], jab1[2], jab1[3]);
+  SETQ(15, jab1[4], jab1[5], jab1[6], jab1[7]);
+  SETQ(16, JIdxJIdx_00, JIdxJIdx_10, JIdxJIdx_10, JIdxJIdx_11);
+  SETQ(17, JabJIdx_00, JabJIdx_01, JabJIdx_10, JabJIdx_11);
+  SETQ(18, JabJab_00, JabJab_01, JabJab_01, JabJab_11);
 
   B.r_newEnergyWO[i] = energyLeft;
   const float th = fmaxf(B.t_frameTH[h], B.t_frameTH[t]);
-  if (energyLeft > th || wJI2_sum < 2) { energyLeft = th; B.r_newState[i] = 2; }
-  else B.r_newState[i] = 0;
+  if (energyLeft > th || wJI2_sum < 2) { energyLeft = th; ns_out = 2; }
+  else ns_out = 0;
+  B.r_newState[i] = (uint8_t)ns_out;
   B.r_newEnergy[i] = energyLeft;
   return (double)energyLeft;
 }
+#undef SETQ
 
 __global__ __launch_bounds__(BA_BLOCK) void k_ba_linearize(const BaDev* __restrict__ wins) {
   const BaDev& B = wins[blockIdx.y];
@@ -187,7 +199,8 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_linearize(const BaDev* __restri
   __shared__ double lds[BA_BLOCK / 64];
   const int i = blockIdx.x * BA_BLOCK + threadIdx.x;
   double e = 0;
-  if (i < B.nr && !B.r_lin[i]) e = linearize_one(B, i);
+  int ns;
+  if (i < B.nr && !B.r_lin[i]) e = linearize_one<true, false>(B, i, nullptr, ns);
   e = block_sum_d(e, lds);
   if (threadIdx.x == 0) B.e_part[blockIdx.x] = e;
 }
@@ -284,6 +297,47 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_reset_all(const BaDev* __restri
 }
 
 // ------------------------------------------------------------------ top accumulation
+// Block reduction of the 55 + 30 + 6 AccumulatorApprox sums (+ residual count) of one chunk -> top_part[chunk]
+__device__ __forceinline__ void top_emit(const BaDev& B, const float* x, const float* y, float a, float b, float c, float TR00, float TR10, float TR01,
+                                         float TR11, float TR02, float TR12, const float* br, bool on, float (*red)[92]) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  // 55 + 30 + 6 sums (AccumulatorApprox::update / updateTopRight / updateBotRight) + residual count
+  int idx = 0;
+#pragma unroll
+  for (int r = 0; r < 10; r++) {
+#pragma unroll
+    for (int cc = r; cc < 10; cc++) {
+      const float val = a * x[cc] * x[r] + c * y[cc] * y[r] + b * (x[cc] * y[r] + y[cc] * x[r]);
+      const float s = wave_sum(val);
+      if (lane == 0) red[wv][idx] = s;
+      idx++;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 10; r++) {
+    const float s0 = wave_sum(x[r] * TR00 + y[r] * TR10);
+    const float s1 = wave_sum(x[r] * TR01 + y[r] * TR11);
+    const float s2 = wave_sum(x[r] * TR02 + y[r] * TR12);
+    if (lane == 0) { red[wv][55 + 3 * r] = s0; red[wv][55 + 3 * r + 1] = s1; red[wv][55 + 3 * r + 2] = s2; }
+  }
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    const float s = wave_sum(br[k]);
+    if (lane == 0) red[wv][85 + k] = s;
+  }
+  {
+    const float s = wave_sum(on ? 1.f : 0.f);
+    if (lane == 0) red[wv][91] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < 92) {
+    float s = red[0][threadIdx.x];
+#pragma unroll
+    for (int w = 1; w < BA_BLOCK / 64; w++) s += red[w][threadIdx.x];
+    B.top_part[(size_t)blockIdx.x * 92 + threadIdx.x] = s;
+  }
+}
+
 // One workgroup per chunk of <=256 residuals of ONE (host,target) pair.  mode: 0 active, 1 linearized, 2 marginalise.
 __global__ __launch_bounds__(BA_BLOCK) void k_ba_accum_top(const BaDev* __restrict__ wins, int mode, const uint8_t* __restrict__ pflag) {
   const BaDev& B = wins[blockIdx.y];
@@ -365,41 +419,93 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_accum_top(const BaDev* __restri
 #pragma unroll
     for (int k = 0; k < 4; k++) rec[RR_HCD + k] = x[k] * q0 + y[k] * q1;
   }
-  // 55 + 30 + 6 sums (AccumulatorApprox::update / updateTopRight / updateBotRight) + residual count
-  int idx = 0;
+  top_emit(B, x, y, a, b, c, TR00, TR10, TR01, TR11, TR02, TR12, br, on, red);
+}
+
+// ------------------------------------------------------------------ fused linearize + applyRes + accumulate (mode 0)
+// FullSystem::optimize with setting_forceAceptStep (the reference default, settings.cpp:53) always applies
+// the fresh linearization, so linearizeAll -> applyRes_Reductor(true) -> accumulateAF of the next
+// solveSystemF can run back to back on the same residual while its Jacobian is still in registers:
+// one workgroup per chunk of one (host,target) pair, J is written to HBM only when MATERIALIZE
+// (the reference API keeps RawResidualJacobian; the solver itself never reads it again).
+// Linearized residuals are untouched (their accumulation is the separate mode-1 pass).
+template <bool MATERIALIZE>
+__global__ __launch_bounds__(BA_BLOCK) void k_ba_lin_fused(const BaDev* __restrict__ wins) {
+  const BaDev& B = wins[blockIdx.y];
+  if ((int)blockIdx.x >= B.nchunks) return;
+  const int4 ch = B.chunks[blockIdx.x];
+  const int i = ch.y + threadIdx.x;
+  __shared__ float red[BA_BLOCK / 64][92];
+  __shared__ double lds[BA_BLOCK / 64];
+  float x[10], y[10], a = 0, b = 0, c = 0;
+  float TR00 = 0, TR10 = 0, TR01 = 0, TR11 = 0, TR02 = 0, TR12 = 0;
+  float br[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
-  for (int r = 0; r < 10; r++) {
+  for (int k = 0; k < 10; k++) { x[k] = 0; y[k] = 0; }
+  bool on = false;
+  double e = 0;
+  if ((int)threadIdx.x < ch.z && !B.r_lin[i]) {
+    float jl[76];
+    int ns;
+    const uint8_t st = B.r_state[i];
+    e = linearize_one<MATERIALIZE, true>(B, i, jl, ns);
+    const int pt = B.r_point[i];
+    float* rec = B.r_rec + ((size_t)pt * B.nf + ch.x / B.nf) * 16;
+    if (st != 1) {  // applyRes(true): OOB is sticky
+      uint8_t act = 0;
+      if (ns == 0) {
+        act = 1;
+        if (MATERIALIZE) B.r_jsel[i] ^= 1;
+        const float jdd0 = JV(J_DD + 0), jdd1 = JV(J_DD + 1);
+        const float v0 = JV(J_IDX2 + 0) * jdd0 + JV(J_IDX2 + 1) * jdd1;
+        const float v1 = JV(J_IDX2 + 2) * jdd0 + JV(J_IDX2 + 3) * jdd1;
+        float o8[8];
 #pragma unroll
-    for (int cc = r; cc < 10; cc++) {
-      const float val = a * x[cc] * x[r] + c * y[cc] * y[r] + b * (x[cc] * y[r] + y[cc] * x[r]);
-      const float s = wave_sum(val);
-      if (lane == 0) red[wv][idx] = s;
-      idx++;
+        for (int k = 0; k < 6; k++) o8[k] = JV(J_XI0 + k) * v0 + JV(J_XI1 + k) * v1;
+        o8[6] = JV(J_ABIDX + 0) * jdd0 + JV(J_ABIDX + 1) * jdd1;
+        o8[7] = JV(J_ABIDX + 2) * jdd0 + JV(J_ABIDX + 3) * jdd1;
+        *(float4*)(rec) = make_float4(o8[0], o8[1], o8[2], o8[3]);
+        *(float4*)(rec + 4) = make_float4(o8[4], o8[5], o8[6], o8[7]);
+      }
+      B.r_act[i] = act;
+      rec[RR_FLAGS] = (float)act;
+      B.r_state[i] = (uint8_t)ns;
+      B.r_energy[i] = B.r_newEnergy[i];
+      on = act != 0;
+    } else {
+      on = B.r_act[i] != 0;   // (an OOB residual is never active)
+    }
+    if (on) {   // AccumulatedTopHessianSSE::addPoint<0>, resApprox = resF
+      float JI_r0 = 0, JI_r1 = 0, Jab_r0 = 0, Jab_r1 = 0, rr = 0;
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const float ra = JV(J_RESF + k);
+        JI_r0 += ra * JV(J_IDX0 + k);
+        JI_r1 += ra * JV(J_IDX1 + k);
+        Jab_r0 += ra * JV(J_AB0 + k);
+        Jab_r1 += ra * JV(J_AB1 + k);
+        rr += ra * ra;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++) { x[k] = JV(J_C0 + k); y[k] = JV(J_C1 + k); }
+#pragma unroll
+      for (int k = 0; k < 6; k++) { x[4 + k] = JV(J_XI0 + k); y[4 + k] = JV(J_XI1 + k); }
+      a = JV(J_IDX2 + 0); b = JV(J_IDX2 + 1); c = JV(J_IDX2 + 3);
+      TR00 = JV(J_ABIDX + 0); TR10 = JV(J_ABIDX + 1); TR01 = JV(J_ABIDX + 2); TR11 = JV(J_ABIDX + 3);
+      TR02 = JI_r0; TR12 = JI_r1;
+      br[0] = JV(J_AB2 + 0); br[1] = JV(J_AB2 + 1); br[2] = Jab_r0; br[3] = JV(J_AB2 + 3); br[4] = Jab_r1; br[5] = rr;
+      const float jdd0 = JV(J_DD + 0), jdd1 = JV(J_DD + 1);
+      const float q0 = a * jdd0 + b * jdd1;
+      const float q1 = JV(J_IDX2 + 2) * jdd0 + c * jdd1;
+      rec[RR_BD] = JI_r0 * jdd0 + JI_r1 * jdd1;
+      rec[RR_HDD] = q0 * jdd0 + q1 * jdd1;
+#pragma unroll
+      for (int k = 0; k < 4; k++) rec[RR_HCD + k] = x[k] * q0 + y[k] * q1;
     }
   }
-#pragma unroll
-  for (int r = 0; r < 10; r++) {
-    const float s0 = wave_sum(x[r] * TR00 + y[r] * TR10);
-    const float s1 = wave_sum(x[r] * TR01 + y[r] * TR11);
-    const float s2 = wave_sum(x[r] * TR02 + y[r] * TR12);
-    if (lane == 0) { red[wv][55 + 3 * r] = s0; red[wv][55 + 3 * r + 1] = s1; red[wv][55 + 3 * r + 2] = s2; }
-  }
-#pragma unroll
-  for (int k = 0; k < 6; k++) {
-    const float s = wave_sum(br[k]);
-    if (lane == 0) red[wv][85 + k] = s;
-  }
-  {
-    const float s = wave_sum(on ? 1.f : 0.f);
-    if (lane == 0) red[wv][91] = s;
-  }
-  __syncthreads();
-  if (threadIdx.x < 92) {
-    float s = red[0][threadIdx.x];
-#pragma unroll
-    for (int w = 1; w < BA_BLOCK / 64; w++) s += red[w][threadIdx.x];
-    B.top_part[(size_t)blockIdx.x * 92 + threadIdx.x] = s;
-  }
+  e = block_sum_d(e, lds);
+  if (threadIdx.x == 0) B.e_part[blockIdx.x] = e;
+  top_emit(B, x, y, a, b, c, TR00, TR10, TR01, TR11, TR02, TR12, br, on, red);
 }
 
 // fold chunk partials per pair (fixed order) into the packed accumulator; grid.x = nf*nf

@@ -224,6 +224,7 @@ def load():
     L.sdso_ba_keep_projections.argtypes = [vp, C.c_int, C.c_int]
     L.sdso_ba_batch_create.argtypes = [vp, C.c_int, c_int_p]
     L.sdso_ba_batch_accumulate.argtypes = [vp]
+    L.sdso_ba_batch_set_materialize.argtypes = [vp, C.c_int]
     L.sdso_ba_batch_solve.argtypes = [vp, C.c_double, C.c_int]
     L.sdso_ba_batch_accum_dev.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_long)]
     L.sdso_ba_batch_get_x.argtypes = [vp, c_double_p]
@@ -248,7 +249,7 @@ EXPORTED_SYMBOLS = [
     "sdso_ba_accum_dev", "sdso_ba_get_accumulators", "sdso_ba_get_point_terms", "sdso_ba_solve",
     "sdso_ba_get_point_steps", "sdso_ba_optimize", "sdso_ba_marginalize_points", "sdso_ba_get_tables",
     "sdso_ba_keep_projections", "sdso_ba_batch_create", "sdso_ba_batch_accumulate", "sdso_ba_batch_solve",
-    "sdso_ba_batch_accum_dev", "sdso_ba_batch_get_x",
+    "sdso_ba_batch_accum_dev", "sdso_ba_batch_get_x", "sdso_ba_batch_set_materialize",
     "sdso_immature_init_batch", "sdso_trace_stereo_batch", "sdso_trace_stereo_prepare", "sdso_trace_stereo_enqueue",
     "sdso_trace_stereo_fetch",
 ]
