@@ -220,6 +220,7 @@ int sdso_ba_accumulate(sdso_ctx* ctx, int win);
 int sdso_ba_accum_floats(int nf);
 int sdso_ba_accum_dev(sdso_ctx* ctx, int win, void** dev_ptr);
 int sdso_ba_get_accumulators(sdso_ctx* ctx, int win, float* packed);
+int sdso_ba_set_accumulators(sdso_ctx* ctx, int win, const float* packed); /* after a host-side reduction */
 int sdso_ba_get_point_terms(sdso_ctx* ctx, int win, float* HdiF, float* bdSumF, float* Hdd_accAF,
                             float* bd_accAF, float* Hcd_accAF /* np*4 */);
 

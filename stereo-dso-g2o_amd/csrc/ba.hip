@@ -552,6 +552,16 @@ extern "C" int sdso_ba_get_accumulators(sdso_ctx* ctx, int win, float* packed) {
   return SDSO_OK;
 }
 
+// overwrite the packed accumulators (after a host-side / non-RCCL reduction across ranks)
+extern "C" int sdso_ba_set_accumulators(sdso_ctx* ctx, int win, const float* packed) {
+  GET_WIN();
+  SDSO_REQUIRE(ctx, packed, "null buffer");
+  SDSO_HIP(ctx, hipMemcpyAsync(W->d.accum, packed, sizeof(float) * acc_floats(W->d.nf), hipMemcpyHostToDevice, ctx->stream));
+  SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  W->accumulated = true;
+  return SDSO_OK;
+}
+
 extern "C" int sdso_ba_get_point_terms(sdso_ctx* ctx, int win, float* HdiF, float* bdSumF, float* Hdd_accAF, float* bd_accAF, float* Hcd_accAF) {
   GET_WIN();
   const int np = W->d.np;

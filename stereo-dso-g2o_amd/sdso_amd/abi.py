@@ -215,6 +215,7 @@ def load():
     L.sdso_ba_accum_floats.argtypes = [C.c_int]
     L.sdso_ba_accum_dev.argtypes = [vp, C.c_int, C.POINTER(vp)]
     L.sdso_ba_get_accumulators.argtypes = [vp, C.c_int, c_float_p]
+    L.sdso_ba_set_accumulators.argtypes = [vp, C.c_int, c_float_p]
     L.sdso_ba_get_point_terms.argtypes = [vp, C.c_int, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p]
     L.sdso_ba_solve.argtypes = [vp, C.c_int, C.c_int, C.c_double, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]
     L.sdso_ba_get_point_steps.argtypes = [vp, C.c_int, c_float_p]
@@ -246,7 +247,7 @@ EXPORTED_SYMBOLS = [
     "sdso_track_batch_enqueue", "sdso_track_batch_fetch", "sdso_track_newest_coarse",
     "sdso_ba_upload_window", "sdso_ba_release_window", "sdso_ba_linearize", "sdso_ba_get_linearization",
     "sdso_ba_apply_res", "sdso_ba_get_residual_state", "sdso_ba_accumulate", "sdso_ba_accum_floats",
-    "sdso_ba_accum_dev", "sdso_ba_get_accumulators", "sdso_ba_get_point_terms", "sdso_ba_solve",
+    "sdso_ba_accum_dev", "sdso_ba_get_accumulators", "sdso_ba_set_accumulators", "sdso_ba_get_point_terms", "sdso_ba_solve",
     "sdso_ba_get_point_steps", "sdso_ba_optimize", "sdso_ba_marginalize_points", "sdso_ba_get_tables",
     "sdso_ba_keep_projections", "sdso_ba_batch_create", "sdso_ba_batch_accumulate", "sdso_ba_batch_solve",
     "sdso_ba_batch_accum_dev", "sdso_ba_batch_get_x", "sdso_ba_batch_set_materialize",

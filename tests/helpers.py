@@ -82,3 +82,60 @@ def permuted_window(win, seed):
     w2["res_point"] = np.array(rp, np.int32)
     w2["res_target"] = np.array(rt, np.int32)
     return w2, order
+
+
+def smoke_ba(ctx, orc):
+    """One GN iteration of the windowed BA (linearize, applyRes, accumulate, solve) on a small window, vs the oracle."""
+    from sdso_amd import synth
+    win = synth.ba_window(w=320, h=240, nf=4, pts_per_kf=60, seed=3031)
+    nf, nr, n = win["nf"], win["nr"], 8 * win["nf"] + 4
+    for f in range(nf):
+        ctx.upload_pyramid(40 + f, win["pyrs"][f][:1])
+    W, keep = abi.make_ba_window(win, frame_slots=[40 + f for f in range(nf)], dI_list=[p[0] for p in win["pyrs"]])
+    ctx.check(ctx.L.sdso_ba_upload_window(ctx.h, 3, C.byref(W)))
+    h = orc.orc_ba_create(C.byref(W))
+    eo, eg = C.c_double(0), C.c_double(0)
+    orc.orc_ba_linearize(h, C.byref(eo))
+    ctx.check(ctx.L.sdso_ba_linearize(ctx.h, 3, C.byref(eg)))
+    Jo, Jg = np.zeros((nr, 74), np.float32), np.zeros((nr, 74), np.float32)
+    so, sg = np.zeros(nr, np.uint8), np.zeros(nr, np.uint8)
+    orc.orc_ba_get_linearization(h, abi.fp(Jo), abi.bp(so), None, None, None, None)
+    ctx.check(ctx.L.sdso_ba_get_linearization(ctx.h, 3, abi.fp(Jg), abi.bp(sg), None, None, None, None))
+    assert np.array_equal(so, sg) and np.array_equal(Jo[so != 1], Jg[so != 1])
+    orc.orc_ba_apply_res(h)
+    ctx.check(ctx.L.sdso_ba_apply_res(ctx.h, 3))
+    orc.orc_ba_accumulate(h)
+    ctx.check(ctx.L.sdso_ba_accumulate(ctx.h, 3))
+    xo, Ho, xg = np.zeros(n), np.zeros((n, n)), np.zeros(n)
+    orc.orc_ba_solve(h, 0, 0.1, abi.dp(xo), abi.dp(Ho), None, None, None)
+    ctx.check(ctx.L.sdso_ba_solve(ctx.h, 3, 0, 0.1, abi.dp(xg), None, None, None, None))
+    d = np.sqrt(np.abs(np.diag(Ho))) + 1e-30
+    err = np.abs((xg - xo) * d).max() / max(1.0, np.abs(xo * d).max())
+    assert err <= 2e-4, err
+    orc.orc_ba_destroy(h)
+    ctx.check(ctx.L.sdso_ba_release_window(ctx.h, 3))
+    print("smoke BA ok: residuals", nr, "J bit-exact, whitened |dx|", err)
+
+
+def smoke_stereo(ctx, orc):
+    """ImmaturePoint ctor + traceStereo on a small stereo pair, bit-exact vs the oracle."""
+    from sdso_amd import synth
+    pr = synth.stereo_problem(w=320, h=240, npts=400, seed=4031)
+    left = np.ascontiguousarray(pr["pyr_l"][0]); right = np.ascontiguousarray(pr["pyr_r"][0])
+    ctx.upload_pyramid(80, [left]); ctx.upload_pyramid(81, [right])
+    n = len(pr["u"])
+    co, wo, go, eo = np.zeros((n, 8), np.float32), np.zeros((n, 8), np.float32), np.zeros((n, 4), np.float32), np.zeros(n, np.float32)
+    cg, wg, gg, eg = np.zeros_like(co), np.zeros_like(wo), np.zeros_like(go), np.zeros_like(eo)
+    orc.orc_immature_init_batch(abi.fp(left), pr["w"], pr["h"], n, abi.fp(pr["u"]), abi.fp(pr["v"]), abi.fp(co), abi.fp(wo), abi.fp(go), abi.fp(eo))
+    ctx.check(ctx.L.sdso_immature_init_batch(ctx.h, 80, n, abi.fp(pr["u"]), abi.fp(pr["v"]), abi.fp(cg), abi.fp(wg), abi.fp(gg), abi.fp(eg)))
+    assert np.array_equal(co, cg) and np.array_equal(eo, eg)
+    K = np.array(pr["K"], np.float32); bl = float(pr["calib"]["baseline"])
+    Po, do = abi.make_trace_points(n, pr["u"], pr["v"], co, wo, go, eo)
+    Pg, dg = abi.make_trace_points(n, pr["u"], pr["v"], co, wo, go, eo)
+    so, sg = np.zeros(n, np.uint8), np.zeros(n, np.uint8)
+    orc.orc_trace_stereo_batch(abi.fp(right), pr["w"], pr["h"], abi.fp(K), bl, 1, C.byref(Po), abi.bp(so))
+    ctx.check(ctx.L.sdso_trace_stereo_batch(ctx.h, 81, abi.fp(K), bl, 1, C.byref(Pg), abi.bp(sg)))
+    assert np.array_equal(so, sg)
+    for k in ("idepth_min_stereo", "idepth_max_stereo", "idepth_stereo", "lastTraceUV"):
+        assert np.array_equal(do[k], dg[k], equal_nan=True), k
+    print("smoke stereo ok: good", int((sg == 0).sum()), "of", n)

@@ -1,0 +1,87 @@
+"""N>1 path on CPU: two gloo ranks shard the points of one BA window, each accumulates its shard
+(oracle arithmetic, CPU), ONE all-reduce(sum) of the packed accumulator block follows, and the
+result must equal the unsharded accumulation — the same partition / packing / collective the
+GPU path uses with RCCL (bench.py --gpus N, tests/test_dist_gpu.py)."""
+import ctypes as C
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, outdir):
+    import torch
+    import torch.distributed as dist
+    sys.path[:0] = [os.path.join(ROOT, "stereo-dso-g2o_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
+    import pyoracle
+    from sdso_amd import abi, synth, dist as sdist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    L = pyoracle.load()
+    win = synth.ba_window(w=320, h=240, nf=4, pts_per_kf=60, seed=3021)
+    sub, (first, last), res_idx = sdist.shard_window(win, rank, world)
+    W, keep = abi.make_ba_window(sub, frame_slots=list(range(win["nf"])), dI_list=[p[0] for p in win["pyrs"]])
+    h = L.orc_ba_create(C.byref(W))
+    L.orc_ba_linearize(h, None)
+    L.orc_ba_apply_res(h)
+    L.orc_ba_accumulate(h)
+    na = abi.accum_floats(win["nf"])
+    acc = np.zeros(na, np.float32)
+    L.orc_ba_get_accumulators(h, abi.fp(acc))
+    t = sdist.allreduce_accumulators(acc)      # ONE collective per iteration
+    # per-point quantities stay rank-local
+    hdi = np.zeros(sub["np"], np.float32)
+    L.orc_ba_get_point_terms(h, abi.fp(hdi), None, None, None, None)
+    np.save(os.path.join(outdir, "acc_%d.npy" % rank), t.numpy())
+    np.save(os.path.join(outdir, "hdi_%d.npy" % rank), hdi)
+    np.save(os.path.join(outdir, "range_%d.npy" % rank), np.array([first, last, sub["nr"]]))
+    L.orc_ba_destroy(h)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_accumulation_equals_unsharded(oracle, tmp_path, world):
+    sys.path[:0] = [os.path.join(ROOT, "stereo-dso-g2o_amd")]
+    from sdso_amd import abi, synth, dist as sdist
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    win = synth.ba_window(w=320, h=240, nf=4, pts_per_kf=60, seed=3021)
+    W, keep = abi.make_ba_window(win, frame_slots=list(range(win["nf"])), dI_list=[p[0] for p in win["pyrs"]])
+    h = oracle.orc_ba_create(C.byref(W))
+    oracle.orc_ba_linearize(h, None)
+    oracle.orc_ba_apply_res(h)
+    oracle.orc_ba_accumulate(h)
+    na = abi.accum_floats(win["nf"])
+    full = np.zeros(na, np.float32)
+    oracle.orc_ba_get_accumulators(h, abi.fp(full))
+    hdi_full = np.zeros(win["np"], np.float32)
+    oracle.orc_ba_get_point_terms(h, abi.fp(hdi_full), None, None, None, None)
+    oracle.orc_ba_destroy(h)
+    accs = [np.load(tmp_path / ("acc_%d.npy" % r)) for r in range(world)]
+    for r in range(1, world):
+        assert np.array_equal(accs[0], accs[r])                 # every rank holds the same reduced block
+    scale = np.abs(full).max()
+    assert np.abs(accs[0] - full).max() <= 2e-6 * scale        # float sums in a different association
+    assert accs[0][-2] == full[-2]                             # nresA: exact count
+    ranges = [np.load(tmp_path / ("range_%d.npy" % r)) for r in range(world)]
+    assert ranges[0][0] == 0 and ranges[-1][1] == win["np"] and sum(int(x[2]) for x in ranges) == win["nr"]
+    for r in range(world):
+        f, l = int(ranges[r][0]), int(ranges[r][1])
+        assert np.array_equal(np.load(tmp_path / ("hdi_%d.npy" % r)), hdi_full[f:l])   # bit-exact, rank-local
+        if r:
+            assert f == int(ranges[r - 1][1])
+    assert sdist.shard_ranges(10, 3) == [(0, 3), (3, 6), (6, 10)]

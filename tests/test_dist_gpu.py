@@ -1,0 +1,75 @@
+"""Sharded BA on the GPU: two processes share cuda:0, each owns half of the points of one window,
+accumulates with libsdso_hip.so, the packed accumulators are summed with ONE collective (gloo here,
+because two ranks cannot open RCCL on one device; bench.py --gpus N uses backend nccl == RCCL on
+the same buffer), then both ranks stitch + solve and must obtain the x of the unsharded window."""
+import ctypes as C
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _solve(ctx, abi, win, wid, slot0, reduce_fn=None):
+    for f in range(win["nf"]):
+        ctx.upload_pyramid(slot0 + f, win["pyrs"][f][:1])
+    W, keep = abi.make_ba_window(win, frame_slots=[slot0 + f for f in range(win["nf"])])
+    ctx.check(ctx.L.sdso_ba_upload_window(ctx.h, wid, C.byref(W)))
+    ctx.check(ctx.L.sdso_ba_linearize(ctx.h, wid, None))
+    ctx.check(ctx.L.sdso_ba_apply_res(ctx.h, wid))
+    ctx.check(ctx.L.sdso_ba_accumulate(ctx.h, wid))
+    if reduce_fn is not None:
+        acc = np.zeros(abi.accum_floats(win["nf"]), np.float32)
+        ctx.check(ctx.L.sdso_ba_get_accumulators(ctx.h, wid, abi.fp(acc)))
+        acc = reduce_fn(acc)
+        ctx.check(ctx.L.sdso_ba_set_accumulators(ctx.h, wid, abi.fp(np.ascontiguousarray(acc))))
+    n = 8 * win["nf"] + 4
+    x, H = np.zeros(n), np.zeros((n, n))
+    ctx.check(ctx.L.sdso_ba_solve(ctx.h, wid, 0, 0.1, abi.dp(x), abi.dp(H), None, None, None))
+    step = np.zeros(win["np"], np.float32)
+    ctx.check(ctx.L.sdso_ba_get_point_steps(ctx.h, wid, abi.fp(step)))
+    return x, H, step
+
+
+def _worker(rank, world, port, outdir):
+    import torch.distributed as dist
+    sys.path[:0] = [os.path.join(ROOT, "stereo-dso-g2o_amd")]
+    from sdso_amd import abi, synth, dist as sdist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ctx = abi.Context(0)
+    win = synth.ba_window(w=640, h=480, nf=5, pts_per_kf=100, seed=3031)
+    sub, (first, last), _ = sdist.shard_window(win, rank, world)
+    x, H, step = _solve(ctx, abi, sub, 1, 10, reduce_fn=lambda a: sdist.allreduce_accumulators(a).numpy())
+    np.save(os.path.join(outdir, "x_%d.npy" % rank), x)
+    np.save(os.path.join(outdir, "step_%d.npy" % rank), step)
+    ctx.close()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_solve_matches_single(gpu_ctx, tmp_path):
+    from sdso_amd import abi, synth, dist as sdist
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    win = synth.ba_window(w=640, h=480, nf=5, pts_per_kf=100, seed=3031)
+    x, H, step = _solve(gpu_ctx, abi, win, 31, 90)
+    xs = [np.load(tmp_path / ("x_%d.npy" % r)) for r in range(world)]
+    assert np.array_equal(xs[0], xs[1])                         # identical reduced input -> identical solve on every rank
+    d = np.sqrt(np.abs(np.diag(H))) + 1e-30
+    assert np.abs((xs[0] - x) * d).max() <= 2e-4 * max(1.0, np.abs(x * d).max())
+    steps = np.concatenate([np.load(tmp_path / ("step_%d.npy" % r)) for r in range(world)])
+    assert np.abs(steps - step).max() <= 2e-4 * max(np.abs(step).max(), 1e-6)
