@@ -31,20 +31,21 @@ class BAWorkload:
         from sdso_amd import abi, synth
         self.ctx, self.abi, self.world, self.torch = ctx, abi, world, torch
         t0 = time.time()
-        nwin = args.batch or 24
+        nwin = args.batch or 128   # enough independent windows that the working set is >> the 256 MB MALL
         win = synth.ba_window(w=1232, h=368, nf=8, pts_per_kf=250, seed=3001, point_seed=(3001 + 131 * rank) if world > 1 else None)
         self.win = win
         nf = win["nf"]
         rs = np.random.RandomState(11)
         ids = []
+        shared = os.environ.get("SDSO_BA_SHARED_IMAGES") == "1"   # experiment: all windows read the same 8 pyramids (cache-resident)
         for k in range(nwin):
             # distinct HBM-resident pyramids per window (content: the rendered keyframes + a little noise)
-            for f in range(nf):
+            for f in range(nf if (k == 0 or not shared) else 0):
                 img = win["pyrs"][f][0][..., 0]
                 if k:
                     img = np.clip(img + rs.uniform(-0.5, 0.5, img.shape).astype(np.float32), 0, 255).astype(np.float32)
                 ctx.check(ctx.L.sdso_make_pyramid(ctx.h, 1000 + k * nf + f, 1232, 368, abi.fp(np.ascontiguousarray(img, np.float32))))
-            W, keep = abi.make_ba_window(win, frame_slots=[1000 + k * nf + f for f in range(nf)])
+            W, keep = abi.make_ba_window(win, frame_slots=[1000 + (0 if shared else k) * nf + f for f in range(nf)])
             ctx.check(ctx.L.sdso_ba_upload_window(ctx.h, 100 + k, C.byref(W)))
             ids.append(100 + k)
         self.ids = np.array(ids, np.int32)

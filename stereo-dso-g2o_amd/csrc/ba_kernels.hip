@@ -297,44 +297,72 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_reset_all(const BaDev* __restri
 }
 
 // ------------------------------------------------------------------ top accumulation
-// Block reduction of the 55 + 30 + 6 AccumulatorApprox sums (+ residual count) of one chunk -> top_part[chunk]
+// Block reduction of the 55 + 30 + 6 AccumulatorApprox sums (+ residual count) of one chunk -> top_part[chunk].
+//
+// The sums over the residuals of a chunk are  D = sum_i  u0_i (x) v0_i + u1_i (x) v1_i  with
+//   u0 = [Jpdc0|Jpdxi0] (10), u1 = [Jpdc1|Jpdxi1] (10),
+//   v0 = [a*u0 + b*u1 (10) | JabJIdx col 0 (2), JI_r0 | Jab2_00, Jab2_01, Jab_r0],
+//   v1 = [b*u0 + c*u1 (10) | JabJIdx col 1 (2), JI_r1 | Jab2_11, Jab_r1, rr],
+// plus a constant-1 row per half that turns the last three columns into plain sums: a 12 x 16 x (2*64) product
+// per wave.  Summing 92 values over 64 lanes with shuffles costs ~1100 issue slots per residual; instead every
+// lane parks its 26 values per half in a wave-private LDS panel (row stride 68 floats: conflict-free for the
+// lane-contiguous writes and for the (row = lane%16, k = lane/16) reads) and 2 x 16 v_mfma_f32_16x16x4_f32
+// (full fp32) do the reduction.  Only the ORDER of the cross-residual float sums differs from the CPU path.
+constexpr int TE_STRIDE = 68;
+constexpr int TE_ROWS = 26;
+constexpr int TE_WAVE_FLOATS = TE_ROWS * TE_STRIDE;
+constexpr int TE_LDS_FLOATS = (BA_BLOCK / 64) * TE_WAVE_FLOATS;
+typedef float te_f4 __attribute__((ext_vector_type(4)));
+
 __device__ __forceinline__ void top_emit(const BaDev& B, const float* x, const float* y, float a, float b, float c, float TR00, float TR10, float TR01,
-                                         float TR11, float TR02, float TR12, const float* br, bool on, float (*red)[92]) {
+                                         float TR11, float TR02, float TR12, const float* br, bool on, float* stage) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  // 55 + 30 + 6 sums (AccumulatorApprox::update / updateTopRight / updateBotRight) + residual count
-  int idx = 0;
+  float* S = stage + wv * TE_WAVE_FLOATS;
+  const int m = lane & 15, kq = lane >> 4;
+  const int mu = m < 10 ? m : 9;
+  te_f4 acc = {0.f, 0.f, 0.f, 0.f};
+  const unsigned long long onmask = __ballot(on);
 #pragma unroll
-  for (int r = 0; r < 10; r++) {
+  for (int ph = 0; ph < 2; ph++) {
+    const float* u = ph ? y : x;
 #pragma unroll
-    for (int cc = r; cc < 10; cc++) {
-      const float val = a * x[cc] * x[r] + c * y[cc] * y[r] + b * (x[cc] * y[r] + y[cc] * x[r]);
-      const float s = wave_sum(val);
-      if (lane == 0) red[wv][idx] = s;
-      idx++;
+    for (int r = 0; r < 10; r++) S[r * TE_STRIDE + lane] = u[r];
+#pragma unroll
+    for (int cc = 0; cc < 10; cc++) S[(10 + cc) * TE_STRIDE + lane] = ph ? (b * x[cc] + c * y[cc]) : (a * x[cc] + b * y[cc]);
+    S[20 * TE_STRIDE + lane] = ph ? TR10 : TR00;
+    S[21 * TE_STRIDE + lane] = ph ? TR11 : TR01;
+    S[22 * TE_STRIDE + lane] = ph ? TR12 : TR02;
+#pragma unroll
+    for (int q = 0; q < 3; q++) S[(23 + q) * TE_STRIDE + lane] = br[3 * ph + q];
+    __syncthreads();
+    const float one = (m == 10 + ph) ? 1.f : 0.f;
+#pragma unroll
+    for (int s4 = 0; s4 < 16; s4++) {
+      float av = S[mu * TE_STRIDE + 4 * s4 + kq];
+      av = m < 10 ? av : one;
+      const float bv = S[(10 + m) * TE_STRIDE + 4 * s4 + kq];
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
     }
+    __syncthreads();
   }
+  // D[i][j]: i = 4*(lane/16) + v, j = lane%16
+  float* R = stage;
 #pragma unroll
-  for (int r = 0; r < 10; r++) {
-    const float s0 = wave_sum(x[r] * TR00 + y[r] * TR10);
-    const float s1 = wave_sum(x[r] * TR01 + y[r] * TR11);
-    const float s2 = wave_sum(x[r] * TR02 + y[r] * TR12);
-    if (lane == 0) { red[wv][55 + 3 * r] = s0; red[wv][55 + 3 * r + 1] = s1; red[wv][55 + 3 * r + 2] = s2; }
-  }
-#pragma unroll
-  for (int k = 0; k < 6; k++) {
-    const float s = wave_sum(br[k]);
-    if (lane == 0) red[wv][85 + k] = s;
-  }
-  {
-    const float s = wave_sum(on ? 1.f : 0.f);
-    if (lane == 0) red[wv][91] = s;
-  }
+  for (int v = 0; v < 4; v++) R[wv * 256 + (4 * kq + v) * 16 + m] = acc[v];
+  if (lane == 0) R[(BA_BLOCK / 64) * 256 + wv] = (float)__popcll(onmask);
   __syncthreads();
   if (threadIdx.x < 92) {
-    float s = red[0][threadIdx.x];
+    const int t = threadIdx.x;
+    int off;
+    if (t < 55) { int r = 0, rem = t; while (rem >= 10 - r) { rem -= 10 - r; r++; } off = r * 16 + r + rem; }
+    else if (t < 85) off = ((t - 55) / 3) * 16 + 10 + (t - 55) % 3;
+    else if (t < 88) off = 10 * 16 + 13 + (t - 85);
+    else if (t < 91) off = 11 * 16 + 13 + (t - 88);
+    else off = (BA_BLOCK / 64) * 256;   // count slots follow the tiles
+    float s = R[off];
 #pragma unroll
-    for (int w = 1; w < BA_BLOCK / 64; w++) s += red[w][threadIdx.x];
-    B.top_part[(size_t)blockIdx.x * 92 + threadIdx.x] = s;
+    for (int w = 1; w < BA_BLOCK / 64; w++) s += R[off + (t < 91 ? w * 256 : w)];
+    B.top_part[(size_t)blockIdx.x * 92 + t] = s;
   }
 }
 
@@ -352,8 +380,7 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_accum_top(const BaDev* __restri
     else if (mode == 1) on = lin && act;
     else on = act && pflag[B.r_point[i]];
   }
-  __shared__ float red[BA_BLOCK / 64][92];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  __shared__ float red[TE_LDS_FLOATS];
   float x[10], y[10], a = 0, b = 0, c = 0;
   float TR00 = 0, TR10 = 0, TR01 = 0, TR11 = 0, TR02 = 0, TR12 = 0;
   float br[6] = {0, 0, 0, 0, 0, 0};
@@ -435,7 +462,7 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_lin_fused(const BaDev* __restri
   if ((int)blockIdx.x >= B.nchunks) return;
   const int4 ch = B.chunks[blockIdx.x];
   const int i = ch.y + threadIdx.x;
-  __shared__ float red[BA_BLOCK / 64][92];
+  __shared__ float red[TE_LDS_FLOATS];
   __shared__ double lds[BA_BLOCK / 64];
   float x[10], y[10], a = 0, b = 0, c = 0;
   float TR00 = 0, TR10 = 0, TR01 = 0, TR11 = 0, TR02 = 0, TR12 = 0;
