@@ -226,7 +226,7 @@ extern "C" int sdso_ba_upload_window(sdso_ctx* ctx, int win, const sdso_ba_windo
     pair_beg[nf * nf] = (int)chunks.size();
   }
   // SC items per host (tunable for experiments: SDSO_SC_PTS in [1,64])
-  int sc_pts = BA_SC_PTS;
+  int sc_pts = getenv("SDSO_SC_REG") ? BA_SC_PTS : 64;
   if (const char* e = getenv("SDSO_SC_PTS")) sc_pts = std::max(1, std::min(64, atoi(e)));
   std::vector<int4> items;
   std::vector<int> host_beg(nf + 1, 0);
@@ -367,11 +367,16 @@ static void launch_sc_and_folds(sdso_ctx* ctx, const BaLaunch& L, const uint8_t*
     ProfScope ps(ctx, "k_ba_sc");
     const dim3 grid((L.max_items + BA_BLOCK / 64 - 1) / (BA_BLOCK / 64), L.nwin), blk(BA_BLOCK);
     const int shift = marg ? 0 : 1, mm = marg ? 1 : 0;
-    switch (nf) {
+    static const bool use_reg = getenv("SDSO_SC_REG") != nullptr;   // experiment: the VALU register-tile variant
+    if (!use_reg) {
+      hipLaunchKernelGGL(k_ba_sc_mfma, grid, blk, 0, ctx->stream, L.d_arr, pflag, shift, mm);
+    } else {
+      switch (nf) {
 #define SC_CASE(N) case N: hipLaunchKernelGGL(k_ba_sc_reg<N>, grid, blk, 0, ctx->stream, L.d_arr, pflag, shift, mm); break;
-      SC_CASE(1) SC_CASE(2) SC_CASE(3) SC_CASE(4) SC_CASE(5) SC_CASE(6) SC_CASE(7) SC_CASE(8)
+        SC_CASE(1) SC_CASE(2) SC_CASE(3) SC_CASE(4) SC_CASE(5) SC_CASE(6) SC_CASE(7) SC_CASE(8)
 #undef SC_CASE
-      default: break;   // nf <= 8 is enforced at upload
+        default: break;   // nf <= 8 is enforced at upload
+      }
     }
   }
   hipLaunchKernelGGL(k_ba_fold_sc, dim3(nf * nf * nf + nf * nf + 1, L.nwin), dim3(64), 0, ctx->stream, L.d_arr);

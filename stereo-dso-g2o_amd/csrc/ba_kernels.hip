@@ -686,4 +686,131 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_sc_reg(const BaDev* __restrict_
   if (lane < 4) out[per_wave + 16 + lane] = bcv;
 }
 
+
+// ------------------------------------------------------------------ per-point Schur accumulation on the matrix cores
+// All Schur sums of a host are ONE symmetric product over its points,
+//     D' = Z^T diag(HdiF) Z,   Z[p] = [ JpJdF of target 0..7 (64) | Hcd (4) | bdSumF (1) ]  (69 columns, padded to 80):
+//     accD[t1][t2] = D'[8t1.., 8t2..],  accE[t1] = D'[8t1.., 64..67],  accEB[t1] = D'[8t1.., 68],  accHcc = D'[64..67, 64..67],
+//     accbc = D'[64..67, 68]                                                     (AccumulatedSCHessian.cpp:75-101).
+// One wave per item (<= 64 consecutive points of one host).  Phase 1, lane = point: the per-point terms
+// (Hdd/bd/Hcd sums in target-slot order, HdiF, bdSumF — unchanged arithmetic, bit-exact with the CPU path) go to
+// p_out and to a small LDS table.  Phase 2, 4 points per step: lane (i, k) = (lane%16, lane/16) loads column
+// 16*tt+i of point 4g+k for the 5 column tiles and 21 v_mfma_f32_16x16x4_f32 accumulate the 4x5 (+1) output tiles
+// in 84 VGPRs.  Absent / inactive residuals enter as exact zeros.  Only the order of the cross-point float sums
+// differs from the CPU path (and the product HdiF*J1*J2 is fused in the MFMA: one rounding less).
+__global__ __launch_bounds__(BA_BLOCK) void k_ba_sc_mfma(const BaDev* __restrict__ wins, const uint8_t* __restrict__ pflag, int shiftPriorToZero, int margMode) {
+  const BaDev& B = wins[blockIdx.y];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int item = blockIdx.x * (BA_BLOCK / 64) + wv;
+  __shared__ float pt_all[BA_BLOCK / 64][64][8];   // HdiF, bdSumF, Hcd[4], mask bits, -
+  if (item >= B.nitems) return;                    // (no block-level barrier below: waves are independent)
+  float (*pt)[8] = pt_all[wv];
+  const int4 it = B.items[item];
+  const int nf = B.nf, npts = it.z - it.y;
+  // ---- phase 1: per-point terms
+  {
+    float HdiF = 0.f, bdSumF = 0.f, Hcd[4] = {0.f, 0.f, 0.f, 0.f};
+    int mbits = 0;
+    if (lane < npts) {
+      const int p = it.y + lane;
+      const float prior = B.p_prior[p], delta = B.p_delta[p];
+      const float onf = (pflag ? (int)pflag[p] : 1) ? 1.f : 0.f;
+      const float* base = B.r_rec + (size_t)p * nf * 16;
+      float Hdd_A = 0, bd_A = 0, Hdd_L = 0, bd_L = 0, HcdA[4] = {0, 0, 0, 0}, HcdL[4] = {0, 0, 0, 0};
+      float ngood = 0;
+      for (int t = 0; t < nf; t++) {
+        const float4 q0 = *(const float4*)(base + t * 16 + 8);    // bd, Hdd, Hcd0, Hcd1
+        const float4 q1 = *(const float4*)(base + t * 16 + 12);   // Hcd2, Hcd3, flags, target
+        const int fl = (int)q1.z;
+        const float m = ((fl & 1) ? 1.f : 0.f) * onf;                          // residual present and active
+        const float mA = (!(fl & 2) && !margMode) ? m : 0.f, mL = m - mA;      // mode 0 vs mode 1/2 sums (AccumulatedTopHessian.cpp:54-71)
+        const float rh[4] = {q0.z, q0.w, q1.x, q1.y};
+        ngood += m;
+        if (m != 0.f) mbits |= 1 << t;
+        bd_A += mA != 0.f ? q0.x : 0.f; Hdd_A += mA != 0.f ? q0.y : 0.f;
+        bd_L += mL != 0.f ? q0.x : 0.f; Hdd_L += mL != 0.f ? q0.y : 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { HcdA[k] += mA != 0.f ? rh[k] : 0.f; HcdL[k] += mL != 0.f ? rh[k] : 0.f; }
+      }
+      float H = Hdd_A + Hdd_L + prior;
+      if (H < 1e-10) H = 1e-10;
+      const float hdi = 1.0 / H;
+      float bds = bd_A + bd_L;
+      if (shiftPriorToZero) bds += prior * delta;
+      const bool any = ngood > 0.f;
+      HdiF = any ? hdi : 0.f; bdSumF = any ? bds : 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; k++) Hcd[k] = any ? HcdA[k] + HcdL[k] : 0.f;
+      if (onf != 0.f) {
+        float* po = B.p_out + (size_t)p * 16;
+        *(float4*)(po + 0) = make_float4(Hdd_A, bd_A, HcdA[0], HcdA[1]);
+        *(float4*)(po + 4) = make_float4(HcdA[2], HcdA[3], Hdd_L, bd_L);
+        *(float4*)(po + 8) = make_float4(HcdL[0], HcdL[1], HcdL[2], HcdL[3]);
+        po[PO_HDI] = HdiF; po[PO_BDSUM] = bdSumF;
+      }
+    }
+    *(float4*)(&pt[lane][0]) = make_float4(HdiF, bdSumF, Hcd[0], Hcd[1]);
+    *(float4*)(&pt[lane][4]) = make_float4(Hcd[2], Hcd[3], __int_as_float(mbits), 0.f);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  // ---- phase 2: D' += Z^T diag(HdiF) Z, four points per step
+  te_f4 acc[4][5], acc44 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int a = 0; a < 4; a++)
+#pragma unroll
+    for (int b = 0; b < 5; b++) acc[a][b] = (te_f4){0.f, 0.f, 0.f, 0.f};
+  const int ci = lane & 15, kq = lane >> 4;
+  const int tsub = ci >> 3, asub = ci & 7;
+  for (int g = 0; g < npts; g += 4) {
+    const int q = g + kq;                      // q < 64 always: rows of points >= npts hold zeros (HdiF = 0, mask = 0)
+    const float4 h0 = *(const float4*)(&pt[q][0]);
+    const float4 h1 = *(const float4*)(&pt[q][4]);
+    const int mb = __float_as_int(h1.z);
+    const float* base = B.r_rec + (size_t)(it.y + (q < npts ? q : 0)) * nf * 16 + asub;
+    float z[5], za[5];
+#pragma unroll
+    for (int tt = 0; tt < 4; tt++) {
+      const int t = 2 * tt + tsub;
+      z[tt] = ((mb >> t) & 1) ? base[t * 16] : 0.f;
+    }
+    z[4] = ci == 0 ? h0.z : ci == 1 ? h0.w : ci == 2 ? h1.x : ci == 3 ? h1.y : ci == 4 ? h0.y : 0.f;
+#pragma unroll
+    for (int tt = 0; tt < 5; tt++) za[tt] = h0.x * z[tt];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+      for (int b = 0; b < 5; b++) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(za[a], z[b], acc[a][b], 0, 0, 0);
+    acc44 = __builtin_amdgcn_mfma_f32_16x16x4f32(za[4], z[4], acc44, 0, 0, 0);
+  }
+  // ---- phase 3: tiles -> the partial layout k_ba_fold_sc expects.  acc[a][b][v] = D'[16a + 4*kq + v][16b + ci]
+  float* out = B.sc_part + (size_t)item * sc_part_floats(nf);
+  const int nf2 = nf * nf;
+#pragma unroll
+  for (int a = 0; a < 4; a++) {
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+      const int R = 16 * a + 4 * kq + v, t1 = R >> 3, ra = R & 7;
+      if (t1 < nf) {
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+          const int C = 16 * b + ci, t2 = C >> 3, cc = C & 7;
+          if (t2 < nf) out[(t1 * nf + t2) * 64 + ra * 8 + cc] = acc[a][b][v];
+        }
+        if (ci < 4) out[nf2 * 64 + t1 * 32 + ra * 4 + ci] = acc[a][4][v];
+        if (ci == 4) out[nf2 * 64 + nf * 32 + t1 * 8 + ra] = acc[a][4][v];
+      }
+    }
+  }
+  const int per_wave = nf2 * 64 + nf * 32 + nf * 8;
+  if (kq == 0) {
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+      if (ci < 4) out[per_wave + v * 4 + ci] = acc44[v];
+      if (ci == 4) out[per_wave + 16 + v] = acc44[v];
+    }
+  }
+}
+
 }  // namespace sdso
