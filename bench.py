@@ -30,6 +30,19 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "stereo-dso-g2o_amd"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_traffic.json")   # PMC passes of this same command (tools/profile_round.sh + tools/make_traffic.py)
+
+
+def pmc_traffic(workload, config):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes; None when the passes were
+    taken on another configuration (a counter pass cannot run inside the timed region)."""
+    try:
+        rec = json.load(open(TRAFFIC_FILE)).get(workload)
+    except (OSError, ValueError):
+        return None
+    if not rec or rec.get("config") != config:
+        return None
+    return rec["traffic_bytes_per_launch"]
 
 
 def log(*a):
@@ -202,25 +215,31 @@ def main():
     wl = WORKLOADS[args.workload](ctx, args, rank) if args.workload != "ba" else None
     if wl is None:
         from bench_ba import BAWorkload
-        wl = BAWorkload(ctx, args, rank, world)
+        wl = BAWorkload(ctx, args, rank, world, device=local_rank)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         ctx.sync()
+        if hasattr(wl, "sync"):
+            wl.sync()
 
     for _ in range(args.warmup):
         wl.step()
     barrier()
-    ctx.check(ctx.L.sdso_prof_reset(ctx.h))
-    ctx.check(ctx.L.sdso_prof_enable(ctx.h, 1))
+    prof_reset = getattr(wl, "prof_reset", lambda: ctx.check(ctx.L.sdso_prof_reset(ctx.h)))
+    prof_enable = getattr(wl, "prof_enable", lambda on: ctx.check(ctx.L.sdso_prof_enable(ctx.h, int(on))))
+    prof_read = getattr(wl, "prof_read", ctx.prof_read)
+    prof_reset()
+    prof_enable(1)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         wl.step()
+    t_enq = time.perf_counter() - t0     # host time to enqueue the timed steps (the device runs behind)
     barrier()
     dt = time.perf_counter() - t0
-    ctx.check(ctx.L.sdso_prof_enable(ctx.h, 0))
+    prof_enable(0)
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -230,12 +249,12 @@ def main():
         units_per_step = float(units.item())
     else:
         units_per_step = float(wl.units_per_step)
-    kms, klaunch = ctx.prof_read(wl.kernel)
+    kms, klaunch = prof_read(wl.kernel)
     extra = wl.verify()
 
     if rank == 0:
         value = units_per_step * args.steps / dt
-        per_launch_units = wl.units_per_step * args.steps / max(klaunch, 1)
+        per_launch_units = wl.units_per_step * args.steps / max(klaunch, 1)   # a group launch covers its share of the windows
         avg_ms = kms / max(klaunch, 1)
         achieved = per_launch_units * wl.bytes_per_unit / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         out = {
@@ -245,16 +264,19 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": wl.config,
             "roofline": {"bound": "hbm", "kernel": wl.kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.workload, wl.config),
                          "kernel_avg_ms": avg_ms, "launches": klaunch, "algorithmic_bytes_per_unit": wl.bytes_per_unit},
             "extra": extra,
         }
+        out["extra"]["host_enqueue_ms_per_step"] = t_enq / args.steps * 1e3
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = wl.cpu_baseline()
             out["extra"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
         if args.workload == "ba":
             out["extra"]["ba_window_iters_per_s"] = wl.nwin * args.steps / dt   # sharded ranks work on the SAME windows
         print(json.dumps(out), flush=True)
+    if hasattr(wl, "close"):
+        wl.close()
     ctx.close()
     if world > 1:
         dist.destroy_process_group()

@@ -4,7 +4,13 @@ One step = one DSO-native Gauss-Newton iteration of EnergyFunctional for `batch`
 8-keyframe windows: linearizeAll + applyRes + accumulateAF/LF/SCF (+ RCCL all-reduce of the packed
 accumulators when the points of every window are sharded over N ranks) + stitch + solveSystemF +
 resubstituteF.  Per-GPU work is fixed (2000 points ~ 12.5k point-residuals per window and rank), so
-the global window grows with N (weak scaling); the all-reduce payload is batch x 161 KiB."""
+the global window grows with N (weak scaling); the all-reduce payload is batch x 184 KiB.
+
+The batch is split into two groups, each on its own sdso_ctx (= its own HIP stream).  The
+bandwidth-bound accumulate phases of the two groups are chained by events (A, B, A, B, ...), so the
+latency-bound tail of one group (fold, stitch, 68x68 solve, back-substitution, and the all-reduce at
+N>1) runs underneath the accumulate phase of the other group instead of leaving the chip idle.
+SDSO_BA_GROUPS=1 gives the plain single-stream order."""
 import ctypes as C
 import os
 import sys
@@ -20,70 +26,120 @@ class _DevBlob:
         self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False), "version": 3}
 
 
+class _Group:
+    pass
+
+
 class BAWorkload:
     name = "windowed_ba_8kf_2kpts_per_gpu_kitti1232x368"
     kernel = "k_ba_lin_fused"
     unit = "point-residuals/s"
     bytes_per_unit = 760.0  # 80 B point + 8x4 taps x 12 B + 296 B RawResidualJacobian written
 
-    def __init__(self, ctx, args, rank, world):
+    def __init__(self, ctx, args, rank, world, device=0):
         import torch
         from sdso_amd import abi, synth
         self.ctx, self.abi, self.world, self.torch = ctx, abi, world, torch
         t0 = time.time()
         nwin = args.batch or 128   # enough independent windows that the working set is >> the 256 MB MALL
+        ngroups = max(1, min(int(os.environ.get("SDSO_BA_GROUPS", "2")), nwin))
         win = synth.ba_window(w=1232, h=368, nf=8, pts_per_kf=250, seed=3001, point_seed=(3001 + 131 * rank) if world > 1 else None)
         self.win = win
         nf = win["nf"]
         rs = np.random.RandomState(11)
-        ids = []
-        shared = os.environ.get("SDSO_BA_SHARED_IMAGES") == "1"   # experiment: all windows read the same 8 pyramids (cache-resident)
-        for k in range(nwin):
-            # distinct HBM-resident pyramids per window (content: the rendered keyframes + a little noise)
-            for f in range(nf if (k == 0 or not shared) else 0):
-                img = win["pyrs"][f][0][..., 0]
-                if k:
-                    img = np.clip(img + rs.uniform(-0.5, 0.5, img.shape).astype(np.float32), 0, 255).astype(np.float32)
-                ctx.check(ctx.L.sdso_make_pyramid(ctx.h, 1000 + k * nf + f, 1232, 368, abi.fp(np.ascontiguousarray(img, np.float32))))
-            W, keep = abi.make_ba_window(win, frame_slots=[1000 + (0 if shared else k) * nf + f for f in range(nf)])
-            ctx.check(ctx.L.sdso_ba_upload_window(ctx.h, 100 + k, C.byref(W)))
-            ids.append(100 + k)
-        self.ids = np.array(ids, np.int32)
-        ctx.check(ctx.L.sdso_ba_batch_create(ctx.h, nwin, abi.ip(self.ids)))
-        self.nwin = nwin
         self.materialize = 0 if os.environ.get("SDSO_BA_NO_J") == "1" else 1
-        ctx.check(ctx.L.sdso_ba_batch_set_materialize(ctx.h, self.materialize))
         if not self.materialize:
             self.bytes_per_unit = 464.0  # SURVEY §8d figure without the Jacobian record
+        shared = os.environ.get("SDSO_BA_SHARED_IMAGES") == "1"   # experiment: all windows read the same 8 pyramids (cache-resident)
+        self.groups = []
+        nfl_total = 0
+        for g in range(ngroups):
+            G = _Group()
+            G.ctx = ctx if g == 0 else abi.Context(device)
+            lo, hi = g * nwin // ngroups, (g + 1) * nwin // ngroups
+            ids = []
+            for k in range(lo, hi):
+                # distinct HBM-resident pyramids per window (content: the rendered keyframes + a little noise)
+                first = (k == lo)
+                for f in range(nf if (first or not shared) else 0):
+                    img = win["pyrs"][f][0][..., 0]
+                    if k:
+                        img = np.clip(img + rs.uniform(-0.5, 0.5, img.shape).astype(np.float32), 0, 255).astype(np.float32)
+                    G.ctx.check(G.ctx.L.sdso_make_pyramid(G.ctx.h, 1000 + k * nf + f, 1232, 368, abi.fp(np.ascontiguousarray(img, np.float32))))
+                W, keep = abi.make_ba_window(win, frame_slots=[1000 + (lo if shared else k) * nf + f for f in range(nf)])
+                G.ctx.check(G.ctx.L.sdso_ba_upload_window(G.ctx.h, 100 + k, C.byref(W)))
+                ids.append(100 + k)
+            G.ids = np.array(ids, np.int32)
+            G.nwin = len(ids)
+            G.ctx.check(G.ctx.L.sdso_ba_batch_create(G.ctx.h, G.nwin, abi.ip(G.ids)))
+            G.ctx.check(G.ctx.L.sdso_ba_batch_set_materialize(G.ctx.h, self.materialize))
+            ptr, nfl = C.c_void_p(), C.c_long(0)
+            G.ctx.check(G.ctx.L.sdso_ba_batch_accum_dev(G.ctx.h, C.byref(ptr), C.byref(nfl)))
+            nfl_total += int(nfl.value)
+            G.stream = torch.cuda.ExternalStream(G.ctx.L.sdso_ctx_stream(G.ctx.h))
+            G.accum = torch.as_tensor(_DevBlob(ptr.value, nfl.value), device="cuda") if world > 1 else None
+            G.ev = torch.cuda.Event()
+            self.groups.append(G)
+        self.nwin = nwin
         self.units_per_step = nwin * win["nr"]
-        ptr, nfl = C.c_void_p(), C.c_long(0)
-        ctx.check(ctx.L.sdso_ba_batch_accum_dev(ctx.h, C.byref(ptr), C.byref(nfl)))
-        self.accum = None
-        if world > 1:
-            self.accum = torch.as_tensor(_DevBlob(ptr.value, nfl.value), device="cuda")
-            self.stream = torch.cuda.ExternalStream(ctx.L.sdso_ctx_stream(ctx.h))
         self.config = {"workload": self.name, "windows_per_step": nwin, "keyframes": nf, "points_per_window_per_gpu": win["np"],
-                       "residuals_per_window_per_gpu": win["nr"], "jacobians_materialized": bool(self.materialize), "allreduce_floats": int(nfl.value) if world > 1 else 0,
-                       "parallelism": ("points sharded over %d ranks, 1 RCCL all-reduce of the packed accumulators per iteration" % world) if world > 1 else "single GPU"}
-        print("[rank %d] BA setup %.1fs: %d windows x %d residuals" % (rank, time.time() - t0, nwin, win["nr"]), file=sys.stderr, flush=True)
+                       "residuals_per_window_per_gpu": win["nr"], "jacobians_materialized": bool(self.materialize), "stream_groups": ngroups,
+                       "allreduce_floats": nfl_total if world > 1 else 0,
+                       "parallelism": ("points sharded over %d ranks, 1 RCCL all-reduce of the packed accumulators per group and iteration" % world) if world > 1 else "single GPU"}
+        print("[rank %d] BA setup %.1fs: %d windows x %d residuals in %d stream group(s)" % (rank, time.time() - t0, nwin, win["nr"], ngroups), file=sys.stderr, flush=True)
+
+    # bench.py drives profiling / synchronisation through these so that every group's ctx is covered
+    def prof_reset(self):
+        for G in self.groups:
+            G.ctx.check(G.ctx.L.sdso_prof_reset(G.ctx.h))
+
+    def prof_enable(self, on):
+        for G in self.groups:
+            G.ctx.check(G.ctx.L.sdso_prof_enable(G.ctx.h, int(on)))
+
+    def prof_read(self, kernel):
+        ms, n = 0.0, 0
+        for G in self.groups:
+            a, b = G.ctx.prof_read(kernel)
+            ms += a; n += b
+        return ms, n
+
+    def sync(self):
+        for G in self.groups:
+            G.ctx.sync()
+
+    def close(self):
+        for G in self.groups[1:]:
+            G.ctx.close()
 
     def step(self):
-        ctx = self.ctx
-        ctx.check(ctx.L.sdso_ba_batch_accumulate(ctx.h))
-        if self.accum is not None:
-            import torch.distributed as dist
-            with self.torch.cuda.stream(self.stream):
-                dist.all_reduce(self.accum, op=dist.ReduceOp.SUM)
-        ctx.check(ctx.L.sdso_ba_batch_solve(ctx.h, 1e-5, 0))
+        gs = self.groups
+        prev = gs[-1]
+        chain = len(gs) > 1 and os.environ.get("SDSO_BA_NOCHAIN") != "1"
+        for G in gs:
+            if chain:
+                G.stream.wait_event(prev.ev)          # accumulate phases run one after the other ...
+            G.ctx.check(G.ctx.L.sdso_ba_batch_accumulate(G.ctx.h))
+            if chain:
+                G.ev.record(G.stream)                 # ... and everything enqueued below overlaps the next group's accumulate
+            if G.accum is not None:
+                import torch.distributed as dist
+                with self.torch.cuda.stream(G.stream):
+                    dist.all_reduce(G.accum, op=dist.ReduceOp.SUM)
+            G.ctx.check(G.ctx.L.sdso_ba_batch_solve(G.ctx.h, 1e-5, 0))
+            prev = G
 
     def verify(self):
-        x = np.zeros((self.nwin, 68))
-        self.ctx.check(self.ctx.L.sdso_ba_batch_get_x(self.ctx.h, self.abi.dp(x)))
-        assert np.isfinite(x).all() and np.abs(x).max() > 0
-        out = {"ba_window_iters_per_s_per_gpu": None, "max_abs_x": float(np.abs(x).max())}
-        out["jacobians_materialized"] = bool(self.materialize)
+        out = {"jacobians_materialized": bool(self.materialize)}
+        mx = 0.0
+        for G in self.groups:
+            x = np.zeros((G.nwin, 68))
+            G.ctx.check(G.ctx.L.sdso_ba_batch_get_x(G.ctx.h, self.abi.dp(x)))
+            assert np.isfinite(x).all() and np.abs(x).max() > 0
+            mx = max(mx, float(np.abs(x).max()))
+        out["max_abs_x"] = mx
         for k in ("k_ba_lin_fused", "k_ba_sc"):
-            ms, n = self.ctx.prof_read(k)
+            ms, n = self.prof_read(k)
             out[k + "_avg_ms"] = ms / max(n, 1)
         return out
 

@@ -47,28 +47,30 @@ __host__ __device__ constexpr int jdev(int f) {
 #define JV(f) jl[jdev(f)]
 
 // ------------------------------------------------------------------ linearize
-// STORE: write the RawResidualJacobian groups to HBM (PointFrameResidual::J);  KEEP: leave them in jl[76]
-// (device layout) for the caller.  ns_out = state_NewState.
+// STORE: write the RawResidualJacobian groups to HBM (PointFrameResidual::J);  KEEP 1: leave them in jl[76]
+// (device layout) for the caller;  KEEP 2: leave only the geometric groups and the 2x2 blocks in jl and return the
+// five per-pixel sums of AccumulatedTopHessianSSE::addPoint<0> (resApprox = resF: JI_r[2], Jab_r[2], rr; same
+// k = 0..7 order as AccumulatedTopHessian.cpp:119-128) in rs[5] — 35 fewer live registers.  ns_out = state_NewState.
 #define SETQ(g, a, b, c, d)                                                              \
   do {                                                                                   \
     const float4 _q = make_float4(a, b, c, d);                                           \
     if (STORE) JQ(J, S, i, g) = _q;                                                      \
-    if (KEEP) { jl[4 * (g)] = _q.x; jl[4 * (g) + 1] = _q.y; jl[4 * (g) + 2] = _q.z; jl[4 * (g) + 3] = _q.w; } \
+    if (KEEP == 1 || (KEEP == 2 && ((g) < 6 || (g) > 15))) { jl[4 * (g)] = _q.x; jl[4 * (g) + 1] = _q.y; jl[4 * (g) + 2] = _q.z; jl[4 * (g) + 3] = _q.w; } \
   } while (0)
-template <bool STORE, bool KEEP>
-__device__ __forceinline__ double linearize_one(const BaDev& B, int i, float* jl, int& ns_out) {
+template <bool STORE, int KEEP>
+__device__ __forceinline__ double linearize_one(const BaDev& B, int i, int h, int t, float* jl, int& ns_out, float* rs = nullptr) {
   B.r_newEnergyWO[i] = -1.f;
   ns_out = 1;
   const uint8_t st = B.r_state[i];
   if (st == 1) { B.r_newState[i] = 1; return (double)B.r_energy[i]; }
-  const int pt = B.r_point[i], h = B.r_host[i], t = B.r_target[i];
+  const int pt = B.r_point[i];
   const float* __restrict__ pre = B.t_precalc + (size_t)(h * B.nf + t) * 27;
   const float* KRKi = pre; const float* Kt = pre + 9; const float* R0 = pre + 12; const float* t0 = pre + 21;
   const float affLL0 = pre[24], affLL1 = pre[25], b0 = pre[26];
   const float4 g = B.p_geo[pt];
   const float pu = g.x, pv = g.y, idepth_scaled = g.z, idepth_zero_scaled = g.w;
   const float4* __restrict__ dIl = B.t_img[t];
-  float* __restrict__ J = B.J[1 - B.r_jsel[i]];
+  float* __restrict__ J = STORE ? (B.r_jsel[i] ? B.J[0] : B.J[1]) : nullptr;
   const int S = B.nrp;
   const float fxl = B.fxl, fyl = B.fyl, cxl = B.cxl, cyl = B.cyl, fxli = B.fxli, fyli = B.fyli;
 
@@ -142,15 +144,19 @@ __device__ __forceinline__ double linearize_one(const BaDev& B, int i, float* jl
     if (!(Kus[idx] > 1.1f && Kvs[idx] > 1.1f && Kus[idx] < B.wM3 && Kvs[idx] < B.hM3)) oob = true;
   }
   if (oob) { B.r_newState[i] = 1; return (double)B.r_energy[i]; }
-  float3 hits[8];
-#pragma unroll
-  for (int idx = 0; idx < 8; idx++) hits[idx] = interp33(dIl, Kus[idx], Kvs[idx], B.w);
   float jab1[8];
+  // the taps are fetched in two groups of 4 pattern pixels (16 gathers in flight per lane): half the registers
+  // of one group of 32
 #pragma unroll
-  for (int idx = 0; idx < 8; idx++) {
+  for (int hb = 0; hb < 8; hb += 4) {
+  float3 hits[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) hits[k] = interp33(dIl, Kus[hb + k], Kvs[hb + k], B.w);
+#pragma unroll
+  for (int idx = hb; idx < hb + 4; idx++) {
     const float Ku = Kus[idx], Kv = Kvs[idx];
     if (B.r_proj) { B.r_proj[(size_t)i * 19 + idx * 2] = Ku; B.r_proj[(size_t)i * 19 + idx * 2 + 1] = Kv; }
-    float3 hit = hits[idx];
+    float3 hit = hits[idx - hb];
     if (!isfinite(hit.x)) oob = true;
     const float residual = hit.x - (affLL0 * color[idx] + affLL1);
     const float drdA = (color[idx] - b0);
@@ -164,6 +170,12 @@ __device__ __forceinline__ double linearize_one(const BaDev& B, int i, float* jl
     hit.z *= hw;
     SETQ(6 + idx, residual * hw, hit.y, hit.z, B.affA_fixed ? 0.f : drdA * hw);   // resF, JIdx[0], JIdx[1], JabF[0]
     jab1[idx] = B.affB_fixed ? 0.f : hw;
+    if (KEEP == 2) {
+      const float ra = residual * hw;
+      rs[0] += ra * hit.y; rs[1] += ra * hit.z;
+      rs[2] += ra * (B.affA_fixed ? 0.f : drdA * hw); rs[3] += ra * jab1[idx];
+      rs[4] += ra * ra;
+    }
     JIdxJIdx_00 += hit.y * hit.y;
     JIdxJIdx_11 += hit.z * hit.z;
     JIdxJIdx_10 += hit.y * hit.z;
@@ -175,6 +187,8 @@ __device__ __forceinline__ double linearize_one(const BaDev& B, int i, float* jl
     JabJab_01 += drdA * hw * hw;
     JabJab_11 += hw * hw;
     wJI2_sum += hw * hw * (hit.y * hit.y + hit.z * hit.z);
+  }
+  __builtin_amdgcn_sched_barrier(0);   // keep the second group's gathers behind the first group's arithmetic
   }
   if (oob) { B.r_newState[i] = 1; return (double)B.r_energy[i]; }
   SETQ(14, jab1[0], jab1[1], jab1[2], jab1[3]);
@@ -200,7 +214,7 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_linearize(const BaDev* __restri
   const int i = blockIdx.x * BA_BLOCK + threadIdx.x;
   double e = 0;
   int ns;
-  if (i < B.nr && !B.r_lin[i]) e = linearize_one<true, false>(B, i, nullptr, ns);
+  if (i < B.nr && !B.r_lin[i]) e = linearize_one<true, 0>(B, i, B.r_host[i], B.r_target[i], nullptr, ns);
   e = block_sum_d(e, lds);
   if (threadIdx.x == 0) B.e_part[blockIdx.x] = e;
 }
@@ -458,9 +472,12 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_accum_top(const BaDev* __restri
 // Linearized residuals are untouched (their accumulation is the separate mode-1 pass).
 template <bool MATERIALIZE>
 __global__ __launch_bounds__(BA_BLOCK) void k_ba_lin_fused(const BaDev* __restrict__ wins) {
-  const BaDev& B = wins[blockIdx.y];
+  // by-value copy first: every pointer of the descriptor is read before the kernel's first store, so the
+  // compiler can prove them global (global_load / s_load instead of flat_load) and keep them in SGPRs
+  const BaDev B = wins[blockIdx.y];
   if ((int)blockIdx.x >= B.nchunks) return;
   const int4 ch = B.chunks[blockIdx.x];
+  const int pair = __builtin_amdgcn_readfirstlane(ch.x);   // one (host,target) per workgroup: precalc, image, thresholds are wave-uniform
   const int i = ch.y + threadIdx.x;
   __shared__ float red[TE_LDS_FLOATS];
   __shared__ double lds[BA_BLOCK / 64];
@@ -473,11 +490,12 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_lin_fused(const BaDev* __restri
   double e = 0;
   if ((int)threadIdx.x < ch.z && !B.r_lin[i]) {
     float jl[76];
+    float rs5[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
     int ns;
     const uint8_t st = B.r_state[i];
-    e = linearize_one<MATERIALIZE, true>(B, i, jl, ns);
+    e = linearize_one<MATERIALIZE, 2>(B, i, pair % B.nf, pair / B.nf, jl, ns, rs5);
     const int pt = B.r_point[i];
-    float* rec = B.r_rec + ((size_t)pt * B.nf + ch.x / B.nf) * 16;
+    float* rec = B.r_rec + ((size_t)pt * B.nf + pair / B.nf) * 16;
     if (st != 1) {  // applyRes(true): OOB is sticky
       uint8_t act = 0;
       if (ns == 0) {
@@ -503,16 +521,7 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_lin_fused(const BaDev* __restri
       on = B.r_act[i] != 0;   // (an OOB residual is never active)
     }
     if (on) {   // AccumulatedTopHessianSSE::addPoint<0>, resApprox = resF
-      float JI_r0 = 0, JI_r1 = 0, Jab_r0 = 0, Jab_r1 = 0, rr = 0;
-#pragma unroll
-      for (int k = 0; k < 8; k++) {
-        const float ra = JV(J_RESF + k);
-        JI_r0 += ra * JV(J_IDX0 + k);
-        JI_r1 += ra * JV(J_IDX1 + k);
-        Jab_r0 += ra * JV(J_AB0 + k);
-        Jab_r1 += ra * JV(J_AB1 + k);
-        rr += ra * ra;
-      }
+      const float JI_r0 = rs5[0], JI_r1 = rs5[1], Jab_r0 = rs5[2], Jab_r1 = rs5[3], rr = rs5[4];
 #pragma unroll
       for (int k = 0; k < 4; k++) { x[k] = JV(J_C0 + k); y[k] = JV(J_C1 + k); }
 #pragma unroll

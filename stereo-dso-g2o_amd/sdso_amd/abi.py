@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libsdso_hip.so")
+LIB_PATH = os.environ.get("SDSO_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "csrc", "libsdso_hip.so")   # override: A/B experiments only
 
 c_float_p = C.POINTER(C.c_float)
 c_double_p = C.POINTER(C.c_double)

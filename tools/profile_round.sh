@@ -13,3 +13,4 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/prof_${tag
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/prof_${tag}_write -- python3 $root/bench.py $args > $out/prof_${tag}_write.log 2>&1
 python3 $root/tools/prof_summary.py $out/prof_${tag}_stats $out/prof_${tag}_fetch $out/prof_${tag}_write > $out/prof_${tag}_summary.txt
 grep '^{' $out/prof_${tag}_stats.log > $out/prof_${tag}_bench_under_rocprof.json || true
+cp $out/prof_${tag}_stats/*/*_kernel_stats.csv $out/prof_${tag}_kernel_stats.csv 2>/dev/null || true
