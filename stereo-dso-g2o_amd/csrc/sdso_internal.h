@@ -142,4 +142,39 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+
+// Sum N (multiple of 4) per-lane values over the 64 lanes of a wave with gfx950's half/row swaps instead of one
+// 6-step butterfly per value: v_permlane32_swap exchanges the upper half of one register with the lower half of
+// another, so one swap + one add finishes the 32-lane step for TWO values; v_permlane16_swap does the same for the
+// 16-lane rows.  N values -> N/4 registers, each then folded inside its rows by four DPP row rotations:
+// 2.5 instructions per value instead of 12.  emit(k, sum) is called by one lane per value.
+template <int N, class Emit>
+__device__ __forceinline__ void wave_reduce_rows(const float* v, Emit emit) {
+  static_assert(N % 4 == 0, "N must be a multiple of 4");
+  const int lane = threadIdx.x & 63;
+  float z[N / 4];
+#pragma unroll
+  for (int m = 0; m < N / 4; m++) {
+    float x[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[4 * m + 2 * h]), __float_as_uint(v[4 * m + 2 * h + 1]), false, false);
+      x[h] = __uint_as_float(r[0]) + __uint_as_float(r[1]);   // rows 0,1: v[4m+2h] (32-lane partials), rows 2,3: v[4m+2h+1]
+    }
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x[0]), __float_as_uint(x[1]), false, false);
+    float t = __uint_as_float(r[0]) + __uint_as_float(r[1]);  // rows: v[4m], v[4m+2], v[4m+1], v[4m+3] (16-lane partials)
+    t += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(t), 0x128, 0xf, 0xf, false));   // row_ror:8
+    t += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(t), 0x124, 0xf, 0xf, false));   // row_ror:4
+    t += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(t), 0x122, 0xf, 0xf, false));   // row_ror:2
+    t += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(t), 0x121, 0xf, 0xf, false));   // row_ror:1
+    z[m] = t;
+  }
+  if ((lane & 15) == 0) {
+    const int row = lane >> 4;
+    const int sub = row == 0 ? 0 : row == 1 ? 2 : row == 2 ? 1 : 3;
+#pragma unroll
+    for (int m = 0; m < N / 4; m++) emit(4 * m + sub, z[m]);
+  }
+}
+
 }  // namespace sdso

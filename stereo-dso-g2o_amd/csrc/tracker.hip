@@ -30,6 +30,7 @@ using namespace sdso;
 namespace sdso {
 
 constexpr int TRK_BLOCK = 256;
+constexpr int TRK_UNROLL = 4;  // template points per lane and loop trip (16 gathers in flight)
 constexpr int TRK_NF = 48;  // float partials: 45 H + E + shiftT + shiftRT
 constexpr int TRK_NI = 4;   // int partials: numTermsInE, numSaturated, numWarped, shiftNum
 
@@ -86,6 +87,7 @@ __global__ __launch_bounds__(TRK_BLOCK) void k_track_eval(const TrackProb* __res
   if (p >= nprob) return;
   const TrackProb& P = probs[p];
   const int n = P.n;
+  if (bx > 0 && bx * TRK_BLOCK >= n) return;   // no points for this workgroup (k_track_finalize skips its partial)
   const int lvl = P.ev.lvl, wl = P.ev.w, hl = P.ev.h;
   const float fxl = P.ev.fx, fyl = P.ev.fy, cxl = P.ev.cx, cyl = P.ev.cy;
   const float affLL0 = P.ev.affLL[0], affLL1 = P.ev.affLL[1];
@@ -106,42 +108,64 @@ __global__ __launch_bounds__(TRK_BLOCK) void k_track_eval(const TrackProb* __res
   float E = 0.f, sT = 0.f, sRT = 0.f;
   int nE = 0, nSat = 0, nWarp = 0, nShift = 0;
 
-  for (int i = bx * TRK_BLOCK + threadIdx.x; i < n; i += gx * TRK_BLOCK) {
-    const float4 q = pc[i];
-    const float x = q.x, y = q.y, id = q.z, refColor = q.w;
-    float pt[3];
+  // TRK_UNROLL template points per lane and trip, in three straight-line stages so that the memory system sees
+  // all of a trip's requests at once: (1) the pc loads, (2) projection + bounds test + the 4 bilinear taps of every
+  // point (an out-of-bounds point reads pixel (2,2) instead of branching around its loads), (3) residual, Huber,
+  // the 45 products — in point order, so the per-lane sums are those of the one-point-per-trip loop.
+  const int stride = gx * TRK_BLOCK;
+  for (int i0 = bx * TRK_BLOCK + threadIdx.x; i0 < n; i0 += TRK_UNROLL * stride) {
+    float4 q[TRK_UNROLL];
 #pragma unroll
-    for (int r = 0; r < 3; r++) pt[r] = ((RKi[r * 3 + 0] * x + RKi[r * 3 + 1] * y) + RKi[r * 3 + 2]) + t[r] * id;
-    const float u = pt[0] / pt[2];
-    const float v = pt[1] / pt[2];
-    const float Ku = fxl * u + cxl;
-    const float Kv = fyl * v + cyl;
-    const float new_idepth = id / pt[2];
-
-    if (lvl == 0 && (i & 31) == 0) {  // CoarseTracker.cpp:662-693 flow indicators
-      float ptT[3], ptT2[3], pt3[3];
-#pragma unroll
-      for (int r = 0; r < 3; r++) {
-        const float kp = (Ki[r * 3 + 0] * x + Ki[r * 3 + 1] * y) + Ki[r * 3 + 2];
-        const float rp = (RKi[r * 3 + 0] * x + RKi[r * 3 + 1] * y) + RKi[r * 3 + 2];
-        ptT[r] = kp + t[r] * id;
-        ptT2[r] = kp - t[r] * id;
-        pt3[r] = rp - t[r] * id;
-      }
-      const float KuT = fxl * (ptT[0] / ptT[2]) + cxl, KvT = fyl * (ptT[1] / ptT[2]) + cyl;
-      const float KuT2 = fxl * (ptT2[0] / ptT2[2]) + cxl, KvT2 = fyl * (ptT2[1] / ptT2[2]) + cyl;
-      const float Ku3 = fxl * (pt3[0] / pt3[2]) + cxl, Kv3 = fyl * (pt3[1] / pt3[2]) + cyl;
-      sT += (KuT - x) * (KuT - x) + (KvT - y) * (KvT - y);
-      sT += (KuT2 - x) * (KuT2 - x) + (KvT2 - y) * (KvT2 - y);
-      sRT += (Ku - x) * (Ku - x) + (Kv - y) * (Kv - y);
-      sRT += (Ku3 - x) * (Ku3 - x) + (Kv3 - y) * (Kv3 - y);
-      nShift += 2;
+    for (int s = 0; s < TRK_UNROLL; s++) {
+      const int i = i0 + s * stride;
+      q[s] = pc[i < n ? i : i0];
     }
+    float us[TRK_UNROLL], vs[TRK_UNROLL], nid[TRK_UNROLL];
+    bool ok[TRK_UNROLL];
+    float3 hits[TRK_UNROLL];
+#pragma unroll
+    for (int s = 0; s < TRK_UNROLL; s++) {
+      const int i = i0 + s * stride;
+      const float x = q[s].x, y = q[s].y, id = q[s].z;
+      float pt[3];
+#pragma unroll
+      for (int r = 0; r < 3; r++) pt[r] = ((RKi[r * 3 + 0] * x + RKi[r * 3 + 1] * y) + RKi[r * 3 + 2]) + t[r] * id;
+      const float u = pt[0] / pt[2];
+      const float v = pt[1] / pt[2];
+      const float Ku = fxl * u + cxl;
+      const float Kv = fyl * v + cyl;
+      const float new_idepth = id / pt[2];
+      us[s] = u; vs[s] = v; nid[s] = new_idepth;
 
-    bool inl = false;
-    if (Ku > 2 && Kv > 2 && Ku < wlm3 && Kv < hlm3 && new_idepth > 0) {  // :696
-      const float3 hit = interp33(img, Ku, Kv, wl);
-      if (isfinite(hit.x)) {
+      if (lvl == 0 && (i & 31) == 0 && i < n) {  // CoarseTracker.cpp:662-693 flow indicators
+        float ptT[3], ptT2[3], pt3[3];
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+          const float kp = (Ki[r * 3 + 0] * x + Ki[r * 3 + 1] * y) + Ki[r * 3 + 2];
+          const float rp = (RKi[r * 3 + 0] * x + RKi[r * 3 + 1] * y) + RKi[r * 3 + 2];
+          ptT[r] = kp + t[r] * id;
+          ptT2[r] = kp - t[r] * id;
+          pt3[r] = rp - t[r] * id;
+        }
+        const float KuT = fxl * (ptT[0] / ptT[2]) + cxl, KvT = fyl * (ptT[1] / ptT[2]) + cyl;
+        const float KuT2 = fxl * (ptT2[0] / ptT2[2]) + cxl, KvT2 = fyl * (ptT2[1] / ptT2[2]) + cyl;
+        const float Ku3 = fxl * (pt3[0] / pt3[2]) + cxl, Kv3 = fyl * (pt3[1] / pt3[2]) + cyl;
+        sT += (KuT - x) * (KuT - x) + (KvT - y) * (KvT - y);
+        sT += (KuT2 - x) * (KuT2 - x) + (KvT2 - y) * (KvT2 - y);
+        sRT += (Ku - x) * (Ku - x) + (Kv - y) * (Kv - y);
+        sRT += (Ku3 - x) * (Ku3 - x) + (Kv3 - y) * (Kv3 - y);
+        nShift += 2;
+      }
+      ok[s] = i < n && Ku > 2 && Kv > 2 && Ku < wlm3 && Kv < hlm3 && new_idepth > 0;  // :696
+      hits[s] = interp33(img, ok[s] ? Ku : 2.5f, ok[s] ? Kv : 2.5f, wl);
+    }
+#pragma unroll
+    for (int s = 0; s < TRK_UNROLL; s++) {
+      const int i = i0 + s * stride;
+      const float u = us[s], v = vs[s], new_idepth = nid[s], refColor = q[s].w;
+      const float3 hit = hits[s];
+      bool inl = false;
+      if (ok[s] && isfinite(hit.x)) {
         const float residual = hit.x - (affLL0 * refColor + affLL1);
         const float ar = fabsf(residual);
         const float hw = ar < huberTH ? 1.f : huberTH / ar;
@@ -175,27 +199,28 @@ __global__ __launch_bounds__(TRK_BLOCK) void k_track_eval(const TrackProb* __res
           }
         }
       }
+      if (MASK && i < n) mask[i] = inl ? 1 : 0;
     }
-    if (MASK) mask[i] = inl ? 1 : 0;
   }
 
   // ---- workgroup reduction: 64-lane butterfly, then 4 waves through LDS
   __shared__ float sF[TRK_BLOCK / 64][TRK_NF];
   __shared__ int sI[TRK_BLOCK / 64][TRK_NI];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  {
+    float v48[TRK_NF];
 #pragma unroll
-  for (int k = 0; k < 45; k++) {
-    const float s = wave_sum(acc[k]);
-    if (lane == 0) sF[wv][k] = s;
+    for (int k = 0; k < 45; k++) v48[k] = acc[k];
+    v48[45] = E; v48[46] = sT; v48[47] = sRT;
+    wave_reduce_rows<TRK_NF>(v48, [&](int k, float s) { sF[wv][k] = s; });
   }
   {
-    const float e = wave_sum(E), a = wave_sum(sT), b = wave_sum(sRT);
     int i0 = nE, i1 = nSat, i2 = nWarp, i3 = nShift;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       i0 += __shfl_xor(i0, o, 64); i1 += __shfl_xor(i1, o, 64); i2 += __shfl_xor(i2, o, 64); i3 += __shfl_xor(i3, o, 64);
     }
-    if (lane == 0) { sF[wv][45] = e; sF[wv][46] = a; sF[wv][47] = b; sI[wv][0] = i0; sI[wv][1] = i1; sI[wv][2] = i2; sI[wv][3] = i3; }
+    if (lane == 0) { sI[wv][0] = i0; sI[wv][1] = i1; sI[wv][2] = i2; sI[wv][3] = i3; }
   }
   __syncthreads();
   const size_t rec = (size_t)p * gx + bx;
@@ -215,19 +240,20 @@ __global__ __launch_bounds__(TRK_BLOCK) void k_track_eval(const TrackProb* __res
 
 // Fold the per-workgroup partials of each problem (fixed order) and finish like calcGSSSE :580-595
 // and calcRes :783-789.
-__global__ __launch_bounds__(64) void k_track_finalize(const float* __restrict__ partF, const int* __restrict__ partI, int gx,
-                                                       TrackOut* __restrict__ out) {
+__global__ __launch_bounds__(64) void k_track_finalize(const TrackProb* __restrict__ probs, const float* __restrict__ partF,
+                                                       const int* __restrict__ partI, int gx, TrackOut* __restrict__ out) {
   const int p = blockIdx.x;
+  const int nb = min(gx, max(1, (probs[p].n + TRK_BLOCK - 1) / TRK_BLOCK));   // workgroups that had points
   __shared__ float F[TRK_NF];
   __shared__ int I[TRK_NI];
   const int tid = threadIdx.x;
   if (tid < TRK_NF) {
     float s = 0.f;
-    for (int b = 0; b < gx; b++) s += partF[((size_t)p * gx + b) * TRK_NF + tid];
+    for (int b = 0; b < nb; b++) s += partF[((size_t)p * gx + b) * TRK_NF + tid];
     F[tid] = s;
   } else if (tid < TRK_NF + TRK_NI) {
     int s = 0;
-    for (int b = 0; b < gx; b++) s += partI[((size_t)p * gx + b) * TRK_NI + tid - TRK_NF];
+    for (int b = 0; b < nb; b++) s += partI[((size_t)p * gx + b) * TRK_NI + tid - TRK_NF];
     I[tid - TRK_NF] = s;
   }
   __syncthreads();
@@ -349,13 +375,15 @@ static int batch_reserve(sdso_ctx* ctx, int nprob, int gx) {
   return SDSO_OK;
 }
 
-// workgroups per problem: enough to fill the chip when few problems are in flight, otherwise one
-// pass of 256 threads x ~8 points.
+// workgroups per problem: enough to fill the chip when few problems are in flight.
 static int choose_gx(const sdso_ctx* ctx, int nprob, int maxn) {
   if (maxn <= 0) return 1;
   int by_points = (maxn + TRK_BLOCK - 1) / TRK_BLOCK;          // 1 point / thread
   int target = (ctx->n_cu * 8 + nprob - 1) / nprob;            // ~8 workgroups per CU over the batch
+  // few, fat workgroups: the per-workgroup epilogue (48-value reduction, partial stores) is amortised over several
+  // loop trips (measured on 640 problems: gx 10 -> 65 us, 4 -> 62 us, 1 -> 71 us)
   int gx = std::max(1, std::min(by_points, target));
+  if (const char* e = getenv("SDSO_TRK_GX")) gx = std::max(1, std::min(by_points, atoi(e)));   // experiment
   return gx;
 }
 
@@ -388,7 +416,7 @@ extern "C" int sdso_track_batch_enqueue(sdso_ctx* ctx) {
     ProfScope ps(ctx, "k_track_eval");
     hipLaunchKernelGGL(k_track_eval<false>, dim3(nblk), dim3(TRK_BLOCK), 0, ctx->stream, tb->d_probs, tb->nprob, tb->gx, tb->d_partF, tb->d_partI, (uint8_t*)nullptr);
   }
-  hipLaunchKernelGGL(k_track_finalize, dim3(tb->nprob), dim3(64), 0, ctx->stream, tb->d_partF, tb->d_partI, tb->gx, tb->d_out);
+  hipLaunchKernelGGL(k_track_finalize, dim3(tb->nprob), dim3(64), 0, ctx->stream, tb->d_probs, tb->d_partF, tb->d_partI, tb->gx, tb->d_out);
   SDSO_HIP(ctx, hipGetLastError());
   return SDSO_OK;
 }
@@ -439,7 +467,7 @@ static int eval_one(sdso_ctx* ctx, const TrackProb& P, uint8_t* mask_host) {
     hipLaunchKernelGGL(k_track_eval<true>, dim3(8 * gx), dim3(TRK_BLOCK), 0, ctx->stream, tb->d_probs, 1, gx, tb->d_partF, tb->d_partI, d_mask);
   else
     hipLaunchKernelGGL(k_track_eval<false>, dim3(8 * gx), dim3(TRK_BLOCK), 0, ctx->stream, tb->d_probs, 1, gx, tb->d_partF, tb->d_partI, (uint8_t*)nullptr);
-  hipLaunchKernelGGL(k_track_finalize, dim3(1), dim3(64), 0, ctx->stream, tb->d_partF, tb->d_partI, gx, tb->d_out);
+  hipLaunchKernelGGL(k_track_finalize, dim3(1), dim3(64), 0, ctx->stream, tb->d_probs, tb->d_partF, tb->d_partI, gx, tb->d_out);
   SDSO_HIP(ctx, hipGetLastError());
   SDSO_HIP(ctx, hipMemcpyAsync(ctx->pinned, tb->d_out, sizeof(TrackOut), hipMemcpyDeviceToHost, ctx->stream));
   if (d_mask) SDSO_HIP(ctx, hipMemcpyAsync(mask_host, d_mask, (size_t)P.n, hipMemcpyDeviceToHost, ctx->stream));
