@@ -645,10 +645,41 @@ extern "C" int sdso_ba_get_tables(sdso_ctx* ctx, int win, float* precalc, double
   return SDSO_OK;
 }
 
+// EnergyFunctional::calcLEnergyF_MT (EnergyFunctional.cpp:420-442) and calcMEnergyF (:344-351); both are 0 under
+// setting_forceAceptStep (FullSystemOptimize.cpp:374-376, :1056)
+static int calc_energies(sdso_ctx* ctx, BaWindowDev* W, double* EL, double* EM) {
+  *EL = 0; *EM = 0;
+  if (W->forceAccept) return SDSO_OK;
+  const int nf = W->d.nf, n = W->d.n;
+  const int nblk = W->d.nchunks + W->nblk_pts;
+  double E = 0;
+  for (const HostFrame& f : W->frames) for (int i = 0; i < 8; i++) E += f.delta_prior[i] * f.prior[i] * f.delta_prior[i];
+  { float s = 0; for (int i = 0; i < 4; i++) s += W->tab.cDeltaF[i] * (float)W->tab.cPrior[i] * W->tab.cDeltaF[i]; E += s; }
+  if (nblk > 0) {
+    int rc = ensure_scratch(ctx, sizeof(float) * nblk);
+    if (rc) return rc;
+    BaLaunch L = single(W);
+    hipLaunchKernelGGL(k_ba_lenergy, dim3(nblk, 1), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr, (float*)ctx->scratch);
+    std::vector<float> part(nblk);
+    SDSO_HIP(ctx, hipMemcpyAsync(part.data(), ctx->scratch, sizeof(float) * nblk, hipMemcpyDeviceToHost, ctx->stream));
+    SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    float Ept = 0;
+    for (int b = 0; b < nblk; b++) Ept += part[b];
+    E += Ept;
+  }
+  *EL = E;
+  std::vector<double> delta(n);                               // getStitchedDeltaF (:1021-1032)
+  for (int i = 0; i < 4; i++) delta[i] = W->calib.value_minus_value_zero[i];
+  for (int f = 0; f < nf; f++) for (int i = 0; i < 8; i++) delta[4 + 8 * f + i] = W->frames[f].delta[i];
+  double em = 0;
+  for (int i = 0; i < n; i++) { double s = 0; for (int k = 0; k < n; k++) s += W->HM[(size_t)i * n + k] * delta[k]; em += delta[i] * (2 * W->bM[i] + s); }
+  *EM = em;
+  return SDSO_OK;
+}
+
 // FullSystem::optimize, DSO-native GN loop (FullSystemOptimize.cpp:871-1041)
 extern "C" int sdso_ba_optimize(sdso_ctx* ctx, int win, int mnumOptIts, double* state_out, float* idepth_out, uint8_t* res_state_out, sdso_ba_opt_result_t* out) {
   GET_WIN();
-  SDSO_REQUIRE(ctx, W->forceAccept, "forceAcceptStep=0 (energy-gated steps, calcLEnergy/calcMEnergy) is not on the device path yet");
   const int nf = W->d.nf, np = W->d.np, nr = W->d.nr;
   sdso_ba_opt_result_t res{0, 0, 0, 0};
   BaLaunch L = single(W);
@@ -658,6 +689,9 @@ extern "C" int sdso_ba_optimize(sdso_ctx* ctx, int win, int mnumOptIts, double* 
     hipLaunchKernelGGL(k_ba_reset_all, dim3(L.max_nblk_res, 1), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr);
     double lastEnergy = 0;
     int rc = linearize_all(ctx, W, false, &lastEnergy);
+    if (rc) return rc;
+    double lastEnergyL = 0, lastEnergyM = 0;
+    rc = calc_energies(ctx, W, &lastEnergyL, &lastEnergyM);
     if (rc) return rc;
     launch_apply(ctx, L);
     double lambda = 1e-1;
@@ -705,9 +739,26 @@ extern "C" int sdso_ba_optimize(sdso_ctx* ctx, int win, int mnumOptIts, double* 
       double newEnergy = 0;
       rc = linearize_all(ctx, W, false, &newEnergy);
       if (rc) return rc;
-      launch_apply(ctx, L);  // setting_forceAceptStep
-      lastEnergy = newEnergy;
-      lambda *= 0.25;
+      double newEnergyL = 0, newEnergyM = 0;
+      rc = calc_energies(ctx, W, &newEnergyL, &newEnergyM);
+      if (rc) return rc;
+      if (W->forceAccept || (newEnergy + newEnergyL + newEnergyM < lastEnergy + lastEnergyL + lastEnergyM)) {   // :978
+        launch_apply(ctx, L);
+        lastEnergy = newEnergy; lastEnergyL = newEnergyL; lastEnergyM = newEnergyM;
+        lambda *= 0.25;
+      } else {
+        // loadSateBackup (:355-370), then re-linearize at the restored state
+        W->calib.setValue(W->calib.value_backup);
+        for (HostFrame& fh : W->frames) { double bs[10]; for (int i = 0; i < 10; i++) bs[i] = fh.state_backup[i]; fh.setState(bs); }
+        if (L.max_nblk_pts) hipLaunchKernelGGL(k_ba_points_op, dim3(L.max_nblk_pts, 1), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr, 2, 0.f, (float*)nullptr);
+        rc = upload_tables(ctx, W, false);
+        if (rc) return rc;
+        rc = linearize_all(ctx, W, false, &lastEnergy);
+        if (rc) return rc;
+        rc = calc_energies(ctx, W, &lastEnergyL, &lastEnergyM);
+        if (rc) return rc;
+        lambda *= 1e2;
+      }
       if (canbreak && iteration >= 1) break;
     }
     double nsz[10] = {0};

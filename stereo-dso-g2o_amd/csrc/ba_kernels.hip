@@ -544,6 +544,51 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_lin_fused(const BaDev* __restri
   top_emit(B, x, y, a, b, c, TR00, TR10, TR01, TR11, TR02, TR12, br, on, red);
 }
 
+// ------------------------------------------------------------------ linearised energy (EnergyFunctional::calcLEnergyPt, EnergyFunctional.cpp:354-417)
+// sum over linearized & active residuals of (2*res_toZeroF + J*delta) * J*delta, plus deltaF^2 * priorF per point.
+// grid.x = nchunks (one (host,target) pair each: adHTdeltaF is uniform) + point blocks; one float partial per workgroup.
+__global__ __launch_bounds__(BA_BLOCK) void k_ba_lenergy(const BaDev* __restrict__ wins, float* __restrict__ out) {
+  const BaDev& B = wins[blockIdx.y];
+  float e = 0.f;
+  if ((int)blockIdx.x < B.nchunks) {
+    const int4 ch = B.chunks[blockIdx.x];
+    const int i = ch.y + threadIdx.x;
+    if ((int)threadIdx.x < ch.z && (B.r_lin[i] & 1) && B.r_act[i]) {
+      float jl[76];
+      load_J(B.r_jsel[i] ? B.J[1] : B.J[0], B.nrp, i, jl);
+      const float* dp = B.t_adHTdelta + (size_t)ch.x * 8;
+      const float* dc = B.t_cdelta;
+      const float dd = B.p_delta[B.r_point[i]];
+      float sx = 0, sy = 0, cx = 0, cy = 0;
+#pragma unroll
+      for (int k = 0; k < 6; k++) { sx += JV(J_XI0 + k) * dp[k]; sy += JV(J_XI1 + k) * dp[k]; }
+#pragma unroll
+      for (int k = 0; k < 4; k++) { cx += JV(J_C0 + k) * dc[k]; cy += JV(J_C1 + k) * dc[k]; }
+      const float dx = sx + cx + JV(J_DD + 0) * dd;
+      const float dy = sy + cy + JV(J_DD + 1) * dd;
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        float Jdelta = JV(J_IDX0 + k) * dx;
+        Jdelta = Jdelta + JV(J_IDX1 + k) * dy;
+        Jdelta = Jdelta + JV(J_AB0 + k) * dp[6];
+        Jdelta = Jdelta + JV(J_AB1 + k) * dp[7];
+        float r0 = B.r_toZero[k * B.nrp + i];
+        r0 = r0 + r0;
+        r0 = r0 + Jdelta;
+        e += Jdelta * r0;
+      }
+    }
+  } else {
+    const int p = ((int)blockIdx.x - B.nchunks) * BA_BLOCK + threadIdx.x;
+    if (p < B.np) { const float d = B.p_delta[p]; e = d * d * B.p_prior[p]; }
+  }
+  __shared__ float red[BA_BLOCK / 64];
+  e = wave_sum(e);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = e;
+  __syncthreads();
+  if (threadIdx.x == 0) { float s = 0; for (int w = 0; w < BA_BLOCK / 64; w++) s += red[w]; out[blockIdx.x] = s; }
+}
+
 // fold chunk partials per pair (fixed order) into the packed accumulator; grid.x = nf*nf
 __global__ __launch_bounds__(128) void k_ba_fold_top(const BaDev* __restrict__ wins, int which /*0 = A, 1 = L*/) {
   const BaDev& B = wins[blockIdx.y];

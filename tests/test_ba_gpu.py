@@ -200,6 +200,35 @@ def test_optimize_full_gn_loop(gpu_ctx, oracle, win_small, win_c3, which):
     oracle.orc_ba_destroy(h)
 
 
+@pytest.mark.parametrize("noise", [dict(), dict(idepth_noise=0.3, state_noise=1e-2)])
+def test_optimize_energy_gated_steps(gpu_ctx, oracle, noise):
+    """setting_forceAceptStep = false: calcLEnergyF_MT / calcMEnergyF gate every step (FullSystemOptimize.cpp:978),
+    rejected steps restore the backup and multiply lambda by 100.  Both windows below reject steps on the CPU path
+    (their final energy differs from the forced-accept run); the device path must take the same decisions."""
+    win = dict(synth.ba_window(w=640, h=480, nf=5, pts_per_kf=120, seed=3001, **noise))
+    nf, npts, nr = win["nf"], win["np"], win["nr"]
+    n = 8 * nf + 4
+    rs = np.random.RandomState(5)
+    A = rs.normal(0, 1, (n, n))
+    win["HM"] = (A @ A.T) * 1e3                  # a marginalisation prior, so that calcMEnergyF is not trivially zero
+    win["bM"] = rs.normal(0, 1e2, n)
+    forced = dict(win)
+    win["forceAcceptStep"] = 0
+    res = {}
+    for name, w in (("gated", win), ("forced", forced)):
+        W, keep, h = _both(gpu_ctx, oracle, w)
+        so, io, ro, oo = np.zeros((nf, 10)), np.zeros(npts, np.float32), np.zeros(nr, np.uint8), abi.BAOptResult()
+        sg, ig, rg, og = np.zeros((nf, 10)), np.zeros(npts, np.float32), np.zeros(nr, np.uint8), abi.BAOptResult()
+        oracle.orc_ba_optimize(h, 6, abi.dp(so), abi.fp(io), abi.bp(ro), C.byref(oo))
+        gpu_ctx.check(gpu_ctx.L.sdso_ba_optimize(gpu_ctx.h, 3, 6, abi.dp(sg), abi.fp(ig), abi.bp(rg), C.byref(og)))
+        oracle.orc_ba_destroy(h)
+        res[name] = (so, oo.lastEnergy)
+        assert og.iterations == oo.iterations
+        assert abs(og.lastEnergy - oo.lastEnergy) <= 1e-3 * oo.lastEnergy
+        assert np.abs(sg - so).max() <= 2e-4 and np.abs(ig - io).max() <= 2e-4     # same accept / reject sequence, float-order spread only
+    assert abs(res["gated"][1] - res["forced"][1]) > 1e-3 * res["forced"][1]         # the gate really rejected something
+
+
 def test_marginalize_points(gpu_ctx, oracle, win_small):
     win = win_small
     W, keep, h = _both(gpu_ctx, oracle, win)
