@@ -313,6 +313,25 @@ int sdso_trace_stereo_prepare(sdso_ctx* ctx, int frame_slot, const float K[4], f
 int sdso_trace_stereo_enqueue(sdso_ctx* ctx);
 int sdso_trace_stereo_fetch(sdso_ctx* ctx, sdso_trace_points_t* pts, uint8_t* status);
 
+/* Left-right-left matching as every caller of traceStereo performs it (FullSystem::stereoMatch FullSystem.cpp:581-613,
+ * traceNewCoarseNonKey :667-725, CoarseTracker::makeCoarseDepthL0 CoarseTracker.cpp:295-347):
+ *   forward: ImmaturePoint(u, v, frame A) traced into frame B   (interval idepth_min/max_stereo, NULL = fresh 0 / NaN)
+ *   back   : where the forward trace is IPS_GOOD, ImmaturePoint(lastTraceUV, frame B) traced into frame A
+ * The accept rule differs per caller (|u - back_uv[0]| < 1 and a depth bound), so it is left to the caller.
+ * status_back is 255 where the back trace did not run.  Any output pointer may be NULL. */
+typedef struct {
+  int n;
+  const float* u; const float* v;
+  const float* idepth_min_stereo; const float* idepth_max_stereo;
+  const float* back_idepth_min_stereo; const float* back_idepth_max_stereo;
+  uint8_t* status_fwd; uint8_t* status_back;
+  float* idepth_stereo; float* idepth_min_out; float* idepth_max_out;   /* of the forward trace */
+  float* fwd_uv;   /* n*2 lastTraceUV of the forward trace */
+  float* back_uv;  /* n*2 lastTraceUV of the back trace */
+} sdso_stereo_match_t;
+int sdso_stereo_match_batch(sdso_ctx* ctx, int slot_a, int slot_b, const float K[4], float baseline,
+                            int mode_right_first, sdso_stereo_match_t* m);
+
 #ifdef __cplusplus
 }
 #endif

@@ -81,6 +81,7 @@ namespace sdso {
 void release_all_windows(sdso_ctx* ctx);
 void release_track_batch(sdso_ctx* ctx);
 void release_trace(sdso_ctx* ctx);
+void release_match(sdso_ctx* ctx);
 }
 
 extern "C" void sdso_ctx_destroy(sdso_ctx* ctx) {
@@ -94,6 +95,7 @@ extern "C" void sdso_ctx_destroy(sdso_ctx* ctx) {
   release_all_windows(ctx);
   release_track_batch(ctx);
   release_trace(ctx);
+  release_match(ctx);
   if (ctx->scratch) hipFree(ctx->scratch);
   if (ctx->pinned) hipHostFree(ctx->pinned);
   hipStreamDestroy(ctx->stream);

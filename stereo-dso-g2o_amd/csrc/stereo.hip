@@ -35,6 +35,7 @@ struct TraceDev {
   const float *color, *weights, *gradH, *energyTH;
   float* quality; uint8_t* lastTraceStatus; float* lastTraceUV; float* lastTracePixelInterval;
   uint8_t* status;
+  const uint8_t* skip;   // optional: 1 = leave the point alone (status 255)
 };
 
 // getInterpolatedElement33BiLin (src/util/globalFuncs.h:160-184)
@@ -76,6 +77,7 @@ __global__ __launch_bounds__(256) void k_trace_stereo(TraceDev T) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int i = blockIdx.x * 4 + wv;
   if (i >= T.n) return;
+  if (T.skip && T.skip[i]) { if (lane == 0 && T.status) T.status[i] = 255; return; }
   __shared__ float s_err[4][128];
   volatile float* errors = s_err[wv];
   const float4* __restrict__ dI = T.img;
@@ -334,7 +336,7 @@ static void trace_bind(TraceBatch& B, int n) {
   T.u_stereo = f; T.v_stereo = f + N; T.idepth_min = f + 2 * N; T.idepth_min_stereo = f + 3 * N; T.idepth_max_stereo = f + 4 * N; T.quality = f + 5 * N;
   T.idepth_stereo = f + 6 * N; T.color = f + 7 * N; T.weights = f + 15 * N; T.gradH = f + 23 * N; T.energyTH = f + 27 * N;
   T.lastTraceUV = f + 28 * N; T.lastTracePixelInterval = f + 30 * N;
-  T.lastTraceStatus = B.bytes; T.status = B.bytes + N;
+  T.lastTraceStatus = B.bytes; T.status = B.bytes + N; T.skip = nullptr;
 }
 void release_trace(sdso_ctx* ctx) {
   auto it = g_trace.find(ctx);
@@ -409,4 +411,114 @@ extern "C" int sdso_trace_stereo_batch(sdso_ctx* ctx, int frame_slot, const floa
   rc = sdso_trace_stereo_enqueue(ctx);
   if (rc) return rc;
   return sdso_trace_stereo_fetch(ctx, pts, status);
+}
+
+
+// ------------------------------------------------------------------ left-right-left matching (S4)
+// The callers of traceStereo all run the same three steps per point (FullSystem::stereoMatch FullSystem.cpp:581-613,
+// traceNewCoarseNonKey :667-725, CoarseTracker::makeCoarseDepthL0 CoarseTracker.cpp:295-347):
+//   ImmaturePoint(u, v, frameA) -> traceStereo(frameB)                       [forward]
+//   if GOOD: ImmaturePoint(lastTraceUV, frameB) -> traceStereo(frameA)        [back]
+// and then compare u with the back trace's lastTraceUV(0).  Everything stays on the device between the steps.
+__global__ __launch_bounds__(256) void k_match_prepare(int n, const float* __restrict__ u, const float* __restrict__ v, const float* __restrict__ imin,
+                                                       const float* __restrict__ imax, TraceDev T) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  T.u_stereo[p] = u[p]; T.v_stereo[p] = v[p];
+  T.idepth_min[p] = 0.f;
+  T.idepth_min_stereo[p] = imin ? imin[p] : 0.f;
+  T.idepth_max_stereo[p] = imax ? imax[p] : NAN;
+  T.idepth_stereo[p] = 0.f; T.quality[p] = 10000.f; T.lastTraceStatus[p] = IPS_UNINITIALIZED;   // ImmaturePoint.cpp:34-38
+  T.lastTraceUV[2 * p] = 0.f; T.lastTraceUV[2 * p + 1] = 0.f; T.lastTracePixelInterval[p] = 0.f;
+}
+// back points at the forward trace's lastTraceUV; points whose forward trace was not GOOD are skipped (and parked on a
+// harmless pixel so that the constructor kernel reads valid memory)
+__global__ __launch_bounds__(256) void k_match_back_points(int n, TraceDev F, TraceDev Bk, uint8_t* __restrict__ skip, const float* __restrict__ bmin,
+                                                           const float* __restrict__ bmax) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const bool good = F.status[p] == IPS_GOOD;
+  skip[p] = good ? 0 : 1;
+  Bk.u_stereo[p] = good ? F.lastTraceUV[2 * p] : 8.f;
+  Bk.v_stereo[p] = good ? F.lastTraceUV[2 * p + 1] : 8.f;
+  Bk.idepth_min[p] = 0.f;
+  Bk.idepth_min_stereo[p] = bmin ? bmin[p] : 0.f;
+  Bk.idepth_max_stereo[p] = bmax ? bmax[p] : NAN;
+  Bk.idepth_stereo[p] = 0.f; Bk.quality[p] = 10000.f; Bk.lastTraceStatus[p] = IPS_UNINITIALIZED;
+  Bk.lastTraceUV[2 * p] = 0.f; Bk.lastTraceUV[2 * p + 1] = 0.f; Bk.lastTracePixelInterval[p] = 0.f;
+}
+
+namespace sdso {
+static std::map<sdso_ctx*, TraceBatch> g_match[2];
+void release_match(sdso_ctx* ctx) {
+  for (int k = 0; k < 2; k++) {
+    auto it = g_match[k].find(ctx);
+    if (it == g_match[k].end()) continue;
+    if (it->second.blob) hipFree(it->second.blob);
+    if (it->second.bytes) hipFree(it->second.bytes);
+    g_match[k].erase(it);
+  }
+}
+}  // namespace sdso
+
+extern "C" int sdso_stereo_match_batch(sdso_ctx* ctx, int slot_a, int slot_b, const float K[4], float baseline, int mode_right_first,
+                                       sdso_stereo_match_t* M) {
+  if (!ctx) return SDSO_ERR_STATE;
+  SDSO_HIP(ctx, hipSetDevice(ctx->device));
+  SDSO_REQUIRE(ctx, K && M && M->n >= 0, "null argument");
+  auto ia = ctx->pyr.find(slot_a), ib = ctx->pyr.find(slot_b);
+  SDSO_REQUIRE(ctx, ia != ctx->pyr.end() && ib != ctx->pyr.end(), "unknown frame slot");
+  SDSO_REQUIRE(ctx, ia->second.w[0] == ib->second.w[0] && ia->second.h[0] == ib->second.h[0], "the two frames differ in size");
+  const int n = M->n, w = ia->second.w[0], h = ia->second.h[0];
+  if (n == 0) return SDSO_OK;
+  SDSO_REQUIRE(ctx, M->u && M->v, "null point arrays");
+  for (int i = 0; i < n; i++)
+    SDSO_REQUIRE(ctx, M->u[i] >= 2 && M->v[i] >= 2 && M->u[i] < w - 3 && M->v[i] < h - 3, "immature point too close to the image border");
+  TraceBatch& A = g_match[0][ctx];
+  TraceBatch& Bk = g_match[1][ctx];
+  int rc = trace_reserve(ctx, A, n);
+  if (rc) return rc;
+  rc = trace_reserve(ctx, Bk, n);
+  if (rc) return rc;
+  trace_bind(A, n); trace_bind(Bk, n);
+  auto geom = [&](TraceDev& T, const float4* img, int mode_right) {
+    T.w = w; T.h = h; T.mode_right = mode_right; T.img = img;
+    T.fx = K[0]; T.fy = K[1]; T.cx = K[2]; T.cy = K[3]; T.baseline = baseline;
+  };
+  geom(A.T, ib->second.d[0], mode_right_first ? 1 : 0);       // forward: points of frame A searched in frame B
+  geom(Bk.T, ia->second.d[0], mode_right_first ? 0 : 1);      // back: points of frame B searched in frame A
+  // host inputs -> device (the unused tail of the back batch's float blob is the staging area: 32N..36N)
+  float* stage = Bk.blob + 32 * (size_t)Bk.n;
+  const float* d_in[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  const float* h_in[6] = {M->u, M->v, M->idepth_min_stereo, M->idepth_max_stereo, M->back_idepth_min_stereo, M->back_idepth_max_stereo};
+  rc = ensure_scratch(ctx, sizeof(float) * 6 * (size_t)n);
+  if (rc) return rc;
+  (void)stage;
+  for (int k = 0; k < 6; k++)
+    if (h_in[k]) {
+      float* d = (float*)ctx->scratch + (size_t)k * n;
+      SDSO_HIP(ctx, hipMemcpyAsync(d, h_in[k], sizeof(float) * n, hipMemcpyHostToDevice, ctx->stream));
+      d_in[k] = d;
+    }
+  const dim3 g1((n + 255) / 256), b1(256), gw((n + 3) / 4);
+  uint8_t* skip = Bk.bytes + 2 * (size_t)Bk.n;
+  hipLaunchKernelGGL(k_match_prepare, g1, b1, 0, ctx->stream, n, d_in[0], d_in[1], d_in[2], d_in[3], A.T);
+  hipLaunchKernelGGL(k_immature_init, g1, b1, 0, ctx->stream, ia->second.d[0], w, n, (const float*)A.T.u_stereo, (const float*)A.T.v_stereo,
+                     (float*)A.T.color, (float*)A.T.weights, (float*)A.T.gradH, (float*)A.T.energyTH);
+  hipLaunchKernelGGL(k_trace_stereo, gw, b1, 0, ctx->stream, A.T);
+  hipLaunchKernelGGL(k_match_back_points, g1, b1, 0, ctx->stream, n, A.T, Bk.T, skip, d_in[4], d_in[5]);
+  hipLaunchKernelGGL(k_immature_init, g1, b1, 0, ctx->stream, ib->second.d[0], w, n, (const float*)Bk.T.u_stereo, (const float*)Bk.T.v_stereo,
+                     (float*)Bk.T.color, (float*)Bk.T.weights, (float*)Bk.T.gradH, (float*)Bk.T.energyTH);
+  TraceDev Tb = Bk.T;
+  Tb.skip = skip;
+  hipLaunchKernelGGL(k_trace_stereo, gw, b1, 0, ctx->stream, Tb);
+  SDSO_HIP(ctx, hipGetLastError());
+#define DN(dst, src, cnt) if (dst) SDSO_HIP(ctx, hipMemcpyAsync((dst), (src), sizeof(float) * (size_t)(cnt), hipMemcpyDeviceToHost, ctx->stream))
+  DN(M->idepth_stereo, A.T.idepth_stereo, n); DN(M->idepth_min_out, A.T.idepth_min_stereo, n); DN(M->idepth_max_out, A.T.idepth_max_stereo, n);
+  DN(M->fwd_uv, A.T.lastTraceUV, 2 * n); DN(M->back_uv, Bk.T.lastTraceUV, 2 * n);
+#undef DN
+  if (M->status_fwd) SDSO_HIP(ctx, hipMemcpyAsync(M->status_fwd, A.T.status, n, hipMemcpyDeviceToHost, ctx->stream));
+  if (M->status_back) SDSO_HIP(ctx, hipMemcpyAsync(M->status_back, Bk.T.status, n, hipMemcpyDeviceToHost, ctx->stream));
+  SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SDSO_OK;
 }

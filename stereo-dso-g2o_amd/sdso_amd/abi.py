@@ -82,6 +82,13 @@ class TracePoints(C.Structure):
                 ("lastTracePixelInterval", c_float_p)]
 
 
+class StereoMatch(C.Structure):
+    _fields_ = [("n", C.c_int), ("u", c_float_p), ("v", c_float_p), ("idepth_min_stereo", c_float_p), ("idepth_max_stereo", c_float_p),
+                ("back_idepth_min_stereo", c_float_p), ("back_idepth_max_stereo", c_float_p), ("status_fwd", c_u8_p), ("status_back", c_u8_p),
+                ("idepth_stereo", c_float_p), ("idepth_min_out", c_float_p), ("idepth_max_out", c_float_p), ("fwd_uv", c_float_p),
+                ("back_uv", c_float_p)]
+
+
 def fp(a):
     return a.ctypes.data_as(c_float_p)
 
@@ -234,6 +241,7 @@ def load():
     L.sdso_trace_stereo_prepare.argtypes = [vp, C.c_int, c_float_p, C.c_float, C.c_int, C.POINTER(TracePoints)]
     L.sdso_trace_stereo_enqueue.argtypes = [vp]
     L.sdso_trace_stereo_fetch.argtypes = [vp, C.POINTER(TracePoints), c_u8_p]
+    L.sdso_stereo_match_batch.argtypes = [vp, C.c_int, C.c_int, c_float_p, C.c_float, C.c_int, C.POINTER(StereoMatch)]
     _lib = L
     return L
 
@@ -252,7 +260,7 @@ EXPORTED_SYMBOLS = [
     "sdso_ba_keep_projections", "sdso_ba_batch_create", "sdso_ba_batch_accumulate", "sdso_ba_batch_solve",
     "sdso_ba_batch_accum_dev", "sdso_ba_batch_get_x", "sdso_ba_batch_set_materialize",
     "sdso_immature_init_batch", "sdso_trace_stereo_batch", "sdso_trace_stereo_prepare", "sdso_trace_stereo_enqueue",
-    "sdso_trace_stereo_fetch",
+    "sdso_trace_stereo_fetch", "sdso_stereo_match_batch",
 ]
 
 

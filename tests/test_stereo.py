@@ -123,3 +123,47 @@ def test_gpu_trace_edge_cases(gpu_ctx, oracle, pair):
     P0, d0 = abi.make_trace_points(0, u[:0], v[:0], col[:0], wgt[:0], gH[:0], eth[:0])
     gpu_ctx.check(gpu_ctx.L.sdso_trace_stereo_batch(gpu_ctx.h, 81, abi.fp(K), bl, 1, C.byref(P0), None))
     assert gpu_ctx.L.sdso_trace_stereo_batch(gpu_ctx.h, 999, abi.fp(K), bl, 1, C.byref(P0), None) == -1
+
+
+@pytest.mark.gpu
+def test_gpu_stereo_match_left_right_left(gpu_ctx, oracle, pair):
+    """sdso_stereo_match_batch = the L->R->L pattern of FullSystem::stereoMatch / makeCoarseDepthL0 in one call; every
+    intermediate stays on the device.  Must equal the four oracle steps (ctor, trace, ctor at lastTraceUV, trace back)."""
+    pr = pair
+    left = np.ascontiguousarray(pr["pyr_l"][0]); right = np.ascontiguousarray(pr["pyr_r"][0])
+    gpu_ctx.upload_pyramid(80, [left]); gpu_ctx.upload_pyramid(81, [right])
+    n = len(pr["u"])
+    K = np.array(pr["K"], np.float32); bl = float(pr["calib"]["baseline"])
+    for interval in (False, True):     # fresh points (stereoMatch) / prior interval 0.1..1.9 x idepth (makeCoarseDepthL0)
+        imin = (pr["idepth_true"] * 0.1).astype(np.float32) if interval else None
+        imax = (pr["idepth_true"] * 1.9).astype(np.float32) if interval else None
+        # oracle, step by step
+        co, wo, go, eo = _oracle_init(oracle, pr, left, pr["u"], pr["v"])
+        Po, do = abi.make_trace_points(n, pr["u"], pr["v"], co, wo, go, eo, imin, imax)
+        sf = _oracle_trace(oracle, pr, right, Po, 1)
+        good = np.nonzero(sf == 0)[0]
+        ub, vb = do["lastTraceUV"][good, 0].copy(), do["lastTraceUV"][good, 1].copy()
+        c2, w2, g2, e2 = _oracle_init(oracle, pr, right, ub, vb)
+        Pb, db = abi.make_trace_points(len(good), ub, vb, c2, w2, g2, e2, None if imin is None else imin[good], None if imax is None else imax[good])
+        sb = _oracle_trace(oracle, pr, left, Pb, 0)
+        # device, one call
+        M = abi.StereoMatch()
+        out = dict(status_fwd=np.zeros(n, np.uint8), status_back=np.zeros(n, np.uint8), idepth_stereo=np.zeros(n, np.float32),
+                   idepth_min_out=np.zeros(n, np.float32), idepth_max_out=np.zeros(n, np.float32), fwd_uv=np.zeros((n, 2), np.float32),
+                   back_uv=np.zeros((n, 2), np.float32))
+        M.n = n; M.u = abi.fp(pr["u"]); M.v = abi.fp(pr["v"])
+        if interval:
+            M.idepth_min_stereo = abi.fp(imin); M.idepth_max_stereo = abi.fp(imax)
+            M.back_idepth_min_stereo = abi.fp(imin); M.back_idepth_max_stereo = abi.fp(imax)
+        for k, a in out.items():
+            setattr(M, k, abi.bp(a) if a.dtype == np.uint8 else abi.fp(a))
+        gpu_ctx.check(gpu_ctx.L.sdso_stereo_match_batch(gpu_ctx.h, 80, 81, abi.fp(K), bl, 1, C.byref(M)))
+        assert np.array_equal(out["status_fwd"], sf)
+        assert np.array_equal(out["idepth_stereo"][good], do["idepth_stereo"][good])
+        assert np.array_equal(out["idepth_min_out"][good], do["idepth_min_stereo"][good]) and np.array_equal(out["idepth_max_out"][good], do["idepth_max_stereo"][good])
+        assert np.array_equal(out["fwd_uv"], do["lastTraceUV"])
+        assert (out["status_back"][sf != 0] == 255).all() and np.array_equal(out["status_back"][good], sb)
+        assert np.array_equal(out["back_uv"][good], db["lastTraceUV"])
+        # the caller's accept rule (FullSystem.cpp:598-601) keeps most points and the kept ones are consistent by construction
+        ok = (sb == 0) & (np.abs(pr["u"][good] - db["lastTraceUV"][:, 0]) < 1) & (1.0 / do["idepth_stereo"][good] > 0) & (1.0 / do["idepth_stereo"][good] < 70)
+        assert ok.mean() > 0.5
