@@ -92,6 +92,18 @@ int sdso_track_set_ref(sdso_ctx* ctx, int ref_slot, int lvl, int n, const float*
                        const float* pc_v, const float* pc_idepth, const float* pc_color);
 int sdso_track_release_ref(sdso_ctx* ctx, int ref_slot);
 
+/* CoarseTracker::makeCoarseDepthL0 (CoarseTracker.cpp:352-534) on the device: STEP1 splat of n weighted inverse depths at
+ * integer pixels (u,v) of the newest keyframe `frame_slot` (= lastRef), STEP2 2x2 pyramid sums, STEP3/4 dilation, STEP5
+ * normalisation + compaction in raster order, for every level of that pyramid.  The result is installed as tracking
+ * reference `ref_slot` exactly as sdso_track_set_ref would; pc_n_out[levels] receives pc_n[lvl].
+ * (new_idepth / weight are what STEP1 computes per active point: the stereo-refined idepth — sdso_stereo_match_batch —
+ * and sqrtf(1e-3 / (HdiF + 1e-12)), :350.) */
+int sdso_track_make_ref(sdso_ctx* ctx, int ref_slot, int frame_slot, int n, const int* u, const int* v,
+                        const float* new_idepth, const float* weight, int* pc_n_out);
+/* read a template level back (tests); n_out = pc_n[lvl]; arrays may be NULL */
+int sdso_track_get_ref(sdso_ctx* ctx, int ref_slot, int lvl, int* n_out, float* pc_u, float* pc_v,
+                       float* pc_idepth, float* pc_color);
+
 /* Host-only helper (no GPU work): fill the evaluation parameters for (level, pose, affine) the way
  * CoarseTracker::makeK (:108-136) and calcRes (:617-621) derive them; cutoffTH =
  * prm->coarseCutoffTH * levelCutoffRepeat. Declared after sdso_track_params_t below. */

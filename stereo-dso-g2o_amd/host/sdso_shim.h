@@ -111,6 +111,17 @@ class CoarseTracker {
     refFrameID = refFrameID_;
     firstCoarseRMSE = -1;
   }
+  // makeCoarseDepthL0 (CoarseTracker.cpp:275-534) from STEP1's per-point results: integer pixel (u,v) on lastRef, the
+  // (stereo-refined) new_idepth and weight = sqrtf(1e-3 / (HdiF + 1e-12)).  Splat, pyramid, dilation, normalisation and
+  // the raster-order compaction run on the device; pc_n[lvl] comes back for the reference's bookkeeping.
+  void makeCoarseDepthL0(int lastRef_slot, int n, const int* u, const int* v, const float* new_idepth, const float* weight, int* pc_n,
+                         float lastRef_ab_exposure, const AffLightT& lastRef_aff_g2l_, int refFrameID_) {
+    dev_.check(sdso_track_make_ref(dev_.ctx(), ref_slot_, lastRef_slot, n, u, v, new_idepth, weight, pc_n), "sdso_track_make_ref");
+    prm_.ref_exposure = lastRef_ab_exposure;
+    prm_.ref_aff_g2l.a = lastRef_aff_g2l_.a; prm_.ref_aff_g2l.b = lastRef_aff_g2l_.b;
+    refFrameID = refFrameID_;
+    firstCoarseRMSE = -1;
+  }
   // bool trackNewestCoarse(FrameHessian* newFrameHessian, SE3& lastToNew_out, AffLight& aff_g2l_out, int coarsestLvl, Vec5 minResForAbort)
   template <class Vec5T>
   bool trackNewestCoarse(int newFrame_slot, float newFrame_ab_exposure, SE3T& lastToNew_out, AffLightT& aff_g2l_out, int coarsestLvl,

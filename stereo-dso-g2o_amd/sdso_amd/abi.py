@@ -241,6 +241,8 @@ def load():
     L.sdso_trace_stereo_prepare.argtypes = [vp, C.c_int, c_float_p, C.c_float, C.c_int, C.POINTER(TracePoints)]
     L.sdso_trace_stereo_enqueue.argtypes = [vp]
     L.sdso_trace_stereo_fetch.argtypes = [vp, C.POINTER(TracePoints), c_u8_p]
+    L.sdso_track_make_ref.argtypes = [vp, C.c_int, C.c_int, C.c_int, c_int_p, c_int_p, c_float_p, c_float_p, c_int_p]
+    L.sdso_track_get_ref.argtypes = [vp, C.c_int, C.c_int, c_int_p, c_float_p, c_float_p, c_float_p, c_float_p]
     L.sdso_stereo_match_batch.argtypes = [vp, C.c_int, C.c_int, c_float_p, C.c_float, C.c_int, C.POINTER(StereoMatch)]
     _lib = L
     return L
@@ -260,7 +262,7 @@ EXPORTED_SYMBOLS = [
     "sdso_ba_keep_projections", "sdso_ba_batch_create", "sdso_ba_batch_accumulate", "sdso_ba_batch_solve",
     "sdso_ba_batch_accum_dev", "sdso_ba_batch_get_x", "sdso_ba_batch_set_materialize",
     "sdso_immature_init_batch", "sdso_trace_stereo_batch", "sdso_trace_stereo_prepare", "sdso_trace_stereo_enqueue",
-    "sdso_trace_stereo_fetch", "sdso_stereo_match_batch",
+    "sdso_trace_stereo_fetch", "sdso_stereo_match_batch", "sdso_track_make_ref", "sdso_track_get_ref",
 ]
 
 

@@ -179,3 +179,46 @@ def test_make_pyramid_bit_exact(gpu_ctx, oracle, prob_kitti):
     out = np.zeros_like(prob_kitti["pyr_ref"][2])
     gpu_ctx.check(gpu_ctx.L.sdso_download_pyramid_level(gpu_ctx.h, 12, 2, abi.fp(out)))
     assert np.array_equal(out, prob_kitti["pyr_ref"][2])
+
+
+def test_make_ref_bit_exact_bookkeeping(gpu_ctx):
+    """CoarseTracker::makeCoarseDepthL0 STEP1-5 on the device (sdso_track_make_ref) against the numpy restatement
+    (synth.make_pc, CoarseTracker.cpp:352-534): pc_n of every level, the ORDER of the template points and every float
+    must be identical — this is the tracker's point-index bookkeeping.  The input has pixels hit by 2, 3 and 5 points
+    with different weights (the splat must add them in point order)."""
+    prob = synth.tracker_problem(w=640, h=480, npts=1500, seed=2031)
+    u, v, idp = prob["points"]
+    rs = np.random.RandomState(3)
+    u = u.astype(np.int32).copy(); v = v.astype(np.int32).copy(); idp = idp.astype(np.float32).copy()
+    for dst, src in ((10, 500), (11, 500), (12, 500), (13, 500), (20, 700), (21, 700), (30, 900), (1400, 3), (1401, 3)):
+        u[dst], v[dst] = u[src], v[src]                       # collisions, also across the 256-thread / 2048-tile boundaries
+    wgt = rs.uniform(0.2, 3.0, len(u)).astype(np.float32)
+    idp = (idp * rs.uniform(0.9, 1.1, len(u))).astype(np.float32)
+    exp = synth.make_pc(u, v, idp, wgt, prob["pyr_ref"])
+    gpu_ctx.upload_pyramid(21, prob["pyr_ref"])
+    L = prob["levels"]
+    pcn = np.zeros(8, np.int32)
+    gpu_ctx.check(gpu_ctx.L.sdso_track_make_ref(gpu_ctx.h, 31, 21, len(u), abi.ip(u), abi.ip(v), abi.fp(idp), abi.fp(wgt), abi.ip(pcn)))
+    for l in range(L):
+        n = len(exp[l]["u"])
+        assert pcn[l] == n and n > 0
+        got = [np.zeros(n, np.float32) for _ in range(4)]
+        nn = C.c_int(0)
+        gpu_ctx.check(gpu_ctx.L.sdso_track_get_ref(gpu_ctx.h, 31, l, C.byref(nn), *[abi.fp(a) for a in got]))
+        assert nn.value == n
+        for a, k in zip(got, ("u", "v", "idepth", "color")):
+            assert np.array_equal(a, exp[l][k]), (l, k)
+    # the installed reference tracks like one set with sdso_track_set_ref
+    gpu_ctx.upload_pyramid(22, prob["pyr_new"])
+    p2 = dict(prob); p2["pc"] = exp
+    gpu_ctx.set_ref(32, exp)
+    prm = helpers.track_params(p2)
+    res = []
+    for ref in (31, 32):
+        T = abi.SE3.from_Rt(np.eye(3), np.zeros(3)); aff = abi.Aff(0, 0); out = abi.TrackResult()
+        gpu_ctx.check(gpu_ctx.L.sdso_track_newest_coarse(gpu_ctx.h, ref, 22, C.byref(prm), C.byref(T), C.byref(aff), C.byref(out)))
+        res.append((T.Rt(), aff.a, aff.b, out.good))
+    assert np.array_equal(res[0][0][0], res[1][0][0]) and np.array_equal(res[0][0][1], res[1][0][1]) and res[0][1:] == res[1][1:]
+    # empty input: every level empty, nothing faults
+    gpu_ctx.check(gpu_ctx.L.sdso_track_make_ref(gpu_ctx.h, 33, 21, 0, None, None, None, None, abi.ip(pcn)))
+    assert (pcn[:L] == 0).all()
