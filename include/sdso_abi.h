@@ -325,6 +325,15 @@ int sdso_trace_stereo_prepare(sdso_ctx* ctx, int frame_slot, const float K[4], f
 int sdso_trace_stereo_enqueue(sdso_ctx* ctx);
 int sdso_trace_stereo_fetch(sdso_ctx* ctx, sdso_trace_points_t* pts, uint8_t* status);
 
+/* ImmaturePoint::traceOn (ImmaturePoint.cpp:459-828): the temporal epipolar search of every immature point of every host
+ * keyframe in the newest frame (FullSystem::traceNewCoarseKey / NonKey, FullSystem.cpp:632-790).  geom[g] is the
+ * hostToFrame geometry of host g (:654-665): KRKi = K R K^-1, Kt = K t, aff = AffLight::fromToVecExposure(...) as floats;
+ * point_geom[i] selects it.  pts uses the traceStereo layout with u_stereo/v_stereo = u/v and idepth_min_stereo /
+ * idepth_max_stereo = idepth_min / idepth_max (in/out); idepth_min and idepth_stereo are not used. */
+typedef struct { float KRKi[9]; float Kt[3]; float aff[2]; } sdso_trace_geom_t;
+int sdso_trace_on_batch(sdso_ctx* ctx, int frame_slot, int ngeom, const sdso_trace_geom_t* geom, const int* point_geom,
+                        sdso_trace_points_t* pts, uint8_t* status);
+
 /* Left-right-left matching as every caller of traceStereo performs it (FullSystem::stereoMatch FullSystem.cpp:581-613,
  * traceNewCoarseNonKey :667-725, CoarseTracker::makeCoarseDepthL0 CoarseTracker.cpp:295-347):
  *   forward: ImmaturePoint(u, v, frame A) traced into frame B   (interval idepth_min/max_stereo, NULL = fresh 0 / NaN)

@@ -167,6 +167,11 @@ int orc_ba_get_tables(orc_ba* h, float* precalc, double* adHost, double* adTarge
 /* ---- static stereo */
 int orc_immature_init_batch(const float* dI, int w, int h, int n, const float* u, const float* v,
                             float* color, float* weights, float* gradH, float* energyTH);
+/* hostToFrame geometry of traceOn (FullSystem.cpp:654-665, :760-766) */
+typedef struct { float KRKi[9]; float Kt[3]; float aff[2]; } orc_trace_geom_t;
+/* ImmaturePoint::traceOn (ImmaturePoint.cpp:459-828); pts->u_stereo/v_stereo = u/v, idepth_min_stereo/idepth_max_stereo = idepth_min/idepth_max */
+int orc_trace_on_batch(const float* dI, int w, int h, int ngeom, const orc_trace_geom_t* geom, const int* point_geom,
+                       orc_trace_points_t* pts, uint8_t* status);
 int orc_trace_stereo_batch(const float* dI, int w, int h, const float K[4], float baseline,
                            int mode_right, orc_trace_points_t* pts, uint8_t* status);
 

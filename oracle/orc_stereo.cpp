@@ -241,7 +241,182 @@ int traceStereoOne(const float* dI, int wG0, int hG0, const float* K4, float bas
   P->idepth_stereo[i] = (u_stereo - bestU) / bf;
   return lastTraceStatus = IPS_GOOD;
 }
+// ImmaturePoint::traceOn (src/FullSystem/ImmaturePoint.cpp:459-828), DSO-native sub-pixel GN (:707-769).
+// P->u_stereo / v_stereo carry u / v, P->idepth_min_stereo / idepth_max_stereo carry idepth_min / idepth_max (in/out).
+int traceOnOne(const float* dI, int wG0, int hG0, const orc_trace_geom_t* G, orc_trace_points_t* P, int i) {
+  float& u_stereo = P->u_stereo[i]; float& v_stereo = P->v_stereo[i];
+  float& idepth_min_stereo = P->idepth_min_stereo[i]; float& idepth_max_stereo = P->idepth_max_stereo[i];
+  const float* color = P->color + i * 8; const float* weights = P->weights + i * 8; const float* gradH = P->gradH + i * 4;
+  float* lastTraceUV = P->lastTraceUV + i * 2;
+  float& lastTracePixelInterval = P->lastTracePixelInterval[i];
+  uint8_t& lastTraceStatus = P->lastTraceStatus[i];
+  const float energyTH = P->energyTH[i];
+  float& quality = P->quality[i];
+  if (lastTraceStatus == IPS_OOB) return lastTraceStatus;                               // :466-468
+  const float idepth_min = idepth_min_stereo;
+  const float* KRKi = G->KRKi; const float* Kt = G->Kt;
+  const float aff0 = G->aff[0], aff1 = G->aff[1];
+  float pr[3];
+  for (int r = 0; r < 3; r++) pr[r] = (KRKi[r * 3 + 0] * u_stereo + KRKi[r * 3 + 1] * v_stereo) + KRKi[r * 3 + 2] * 1.0f;
+  float ptpMin[3];
+  for (int k = 0; k < 3; k++) ptpMin[k] = pr[k] + Kt[k] * idepth_min_stereo;
+  float uMin = ptpMin[0] / ptpMin[2];
+  float vMin = ptpMin[1] / ptpMin[2];
+  auto oob = [&]() { lastTraceUV[0] = -1; lastTraceUV[1] = -1; lastTracePixelInterval = 0; return (int)(lastTraceStatus = IPS_OOB); };
+  if (!(uMin > 4 && vMin > 4 && uMin < wG0 - 5 && vMin < hG0 - 5)) return oob();
+
+  float dist, uMax, vMax, ptpMax[3];
+  float maxPixSearch = (wG0 + hG0) * setting_maxPixSearch;
+  if (std::isfinite(idepth_max_stereo)) {
+    for (int k = 0; k < 3; k++) ptpMax[k] = pr[k] + Kt[k] * idepth_max_stereo;
+    uMax = ptpMax[0] / ptpMax[2];
+    vMax = ptpMax[1] / ptpMax[2];
+    if (!(uMax > 4 && vMax > 4 && uMax < wG0 - 5 && vMax < hG0 - 5)) return oob();
+    dist = (uMin - uMax) * (uMin - uMax) + (vMin - vMax) * (vMin - vMax);
+    dist = sqrtf(dist);
+    if (dist < setting_trace_slackInterval) {                                            // :525-531
+      lastTraceUV[0] = (uMax + uMin) * 0.5f; lastTraceUV[1] = (vMax + vMin) * 0.5f;
+      lastTracePixelInterval = dist;
+      return lastTraceStatus = IPS_SKIPPED;
+    }
+  } else {
+    dist = maxPixSearch;
+    for (int k = 0; k < 3; k++) ptpMax[k] = pr[k] + Kt[k] * 0.01f;
+    uMax = ptpMax[0] / ptpMax[2];
+    vMax = ptpMax[1] / ptpMax[2];
+    float dx = uMax - uMin;
+    float dy = vMax - vMin;
+    float d = 1.0f / sqrtf(dx * dx + dy * dy);
+    uMax = uMin + dist * dx * d;
+    vMax = vMin + dist * dy * d;
+    if (!(uMax > 4 && vMax > 4 && uMax < wG0 - 5 && vMax < hG0 - 5)) return oob();
+  }
+  if (!(idepth_min < 0 || (ptpMin[2] > 0.75 && ptpMin[2] < 1.5))) return oob();
+
+  float dx = setting_trace_stepsize * (uMax - uMin);
+  float dy = setting_trace_stepsize * (vMax - vMin);
+  // Vec2f(dx,dy)^T * gradH * Vec2f(dx,dy): (row * matrix) then * vector
+  float a = (dx * gradH[0] + dy * gradH[2]) * dx + (dx * gradH[1] + dy * gradH[3]) * dy;
+  float b = (dy * gradH[0] + (-dx) * gradH[2]) * dy + (dy * gradH[1] + (-dx) * gradH[3]) * (-dx);
+  float errorInPixel = 0.2f + 0.2f * (a + b) / a;
+  if (errorInPixel * setting_trace_minImprovementFactor > dist && std::isfinite(idepth_max_stereo)) {   // :596-603
+    lastTraceUV[0] = (uMax + uMin) * 0.5f; lastTraceUV[1] = (vMax + vMin) * 0.5f;
+    lastTracePixelInterval = dist;
+    return lastTraceStatus = IPS_BADCONDITION;
+  }
+  if (errorInPixel > 10) errorInPixel = 10;
+
+  dx /= dist;
+  dy /= dist;
+  if (dist > maxPixSearch) {
+    uMax = uMin + maxPixSearch * dx;
+    vMax = vMin + maxPixSearch * dy;
+    dist = maxPixSearch;
+  }
+  int numSteps = 1.9999f + dist / setting_trace_stepsize;
+  float randShift = uMin * 1000 - floorf(uMin * 1000);
+  float ptx = uMin - randShift * dx;
+  float pty = vMin - randShift * dy;
+  float rotatetPattern[8][2];
+  for (int idx = 0; idx < patternNum; idx++) {  // Rplane = KRKi.topLeftCorner<2,2>()  (:628, :636-637)
+    rotatetPattern[idx][0] = KRKi[0] * patternP[idx][0] + KRKi[1] * patternP[idx][1];
+    rotatetPattern[idx][1] = KRKi[3] * patternP[idx][0] + KRKi[4] * patternP[idx][1];
+  }
+  if (!std::isfinite(dx) || !std::isfinite(dy)) return oob();
+
+  float errors[100];
+  float bestU = 0, bestV = 0, bestEnergy = 1e10;
+  int bestIdx = -1;
+  if (numSteps >= 100) numSteps = 99;
+  for (int s = 0; s < numSteps; s++) {
+    float energy = 0;
+    for (int idx = 0; idx < patternNum; idx++) {
+      float hitColor = interp31(dI, (float)(ptx + rotatetPattern[idx][0]), (float)(pty + rotatetPattern[idx][1]), wG0);
+      if (!std::isfinite(hitColor)) { energy += 1e5; continue; }
+      float residual = hitColor - (float)(aff0 * color[idx] + aff1);
+      float hw = fabs(residual) < setting_huberTH ? 1 : setting_huberTH / fabs(residual);
+      energy += hw * residual * residual * (2 - hw);
+    }
+    errors[s] = energy;
+    if (energy < bestEnergy) { bestU = ptx; bestV = pty; bestEnergy = energy; bestIdx = s; }
+    ptx += dx;
+    pty += dy;
+  }
+  float secondBest = 1e10;
+  for (int s = 0; s < numSteps; s++)
+    if ((s < bestIdx - setting_minTraceTestRadius || s > bestIdx + setting_minTraceTestRadius) && errors[s] < secondBest) secondBest = errors[s];
+  float newQuality = secondBest / bestEnergy;
+  if (newQuality < quality || numSteps > 10) quality = newQuality;
+
+  // DSO-native GN (ImmaturePoint.cpp:707-769)
+  float uBak = bestU, vBak = bestV, gnstepsize = 1, stepBack = 0;
+  if (setting_trace_GNIterations > 0) bestEnergy = 1e5;
+  for (int it = 0; it < setting_trace_GNIterations; it++) {
+    float H = 1, bb = 0, energy = 0;
+    for (int idx = 0; idx < patternNum; idx++) {
+      float hitColor[3];
+      interp33(dI, (float)(bestU + rotatetPattern[idx][0]), (float)(bestV + rotatetPattern[idx][1]), wG0, hitColor);
+      if (!std::isfinite((float)hitColor[0])) { energy += 1e5; continue; }
+      float residual = hitColor[0] - (aff0 * color[idx] + aff1);
+      float dResdDist = dx * hitColor[1] + dy * hitColor[2];
+      float hw = fabs(residual) < setting_huberTH ? 1 : setting_huberTH / fabs(residual);
+      H += hw * dResdDist * dResdDist;
+      bb += hw * residual * dResdDist;
+      energy += weights[idx] * weights[idx] * hw * residual * residual * (2 - hw);
+    }
+    if (energy > bestEnergy) {
+      stepBack *= 0.5;
+      bestU = uBak + stepBack * dx;
+      bestV = vBak + stepBack * dy;
+    } else {
+      float step = -gnstepsize * bb / H;
+      if (step < -0.5) step = -0.5;
+      else if (step > 0.5) step = 0.5;
+      if (!std::isfinite(step)) step = 0;
+      uBak = bestU;
+      vBak = bestV;
+      stepBack = step;
+      bestU += step * dx;
+      bestV += step * dy;
+      bestEnergy = energy;
+    }
+    if (fabsf(stepBack) < setting_trace_GNThreshold) break;
+  }
+
+  if (!(bestEnergy < energyTH * setting_trace_extraSlackOnTH)) {
+    lastTracePixelInterval = 0;
+    lastTraceUV[0] = -1; lastTraceUV[1] = -1;
+    if (lastTraceStatus == IPS_OUTLIER) return lastTraceStatus = IPS_OOB;
+    else return lastTraceStatus = IPS_OUTLIER;
+  }
+  if (dx * dx > dy * dy) {
+    idepth_min_stereo = (pr[2] * (bestU - errorInPixel * dx) - pr[0]) / (Kt[0] - Kt[2] * (bestU - errorInPixel * dx));
+    idepth_max_stereo = (pr[2] * (bestU + errorInPixel * dx) - pr[0]) / (Kt[0] - Kt[2] * (bestU + errorInPixel * dx));
+  } else {
+    idepth_min_stereo = (pr[2] * (bestV - errorInPixel * dy) - pr[1]) / (Kt[1] - Kt[2] * (bestV - errorInPixel * dy));
+    idepth_max_stereo = (pr[2] * (bestV + errorInPixel * dy) - pr[1]) / (Kt[1] - Kt[2] * (bestV + errorInPixel * dy));
+  }
+  if (idepth_min_stereo > idepth_max_stereo) std::swap(idepth_min_stereo, idepth_max_stereo);
+  if (!std::isfinite(idepth_min_stereo) || !std::isfinite(idepth_max_stereo) || (idepth_max_stereo < 0)) {
+    lastTracePixelInterval = 0;
+    lastTraceUV[0] = -1; lastTraceUV[1] = -1;
+    return lastTraceStatus = IPS_OUTLIER;
+  }
+  lastTracePixelInterval = 2 * errorInPixel;
+  lastTraceUV[0] = bestU; lastTraceUV[1] = bestV;
+  return lastTraceStatus = IPS_GOOD;
+}
 }  // namespace
+
+extern "C" int orc_trace_on_batch(const float* dI, int w, int h, int ngeom, const orc_trace_geom_t* geom, const int* point_geom,
+                                  orc_trace_points_t* pts, uint8_t* status) {
+  for (int i = 0; i < pts->n; i++) {
+    if (point_geom[i] < 0 || point_geom[i] >= ngeom) return -1;
+    int s = traceOnOne(dI, w, h, geom + point_geom[i], pts, i);
+    if (status) status[i] = (uint8_t)s;
+  }
+  return 0;
+}
 
 extern "C" int orc_trace_stereo_batch(const float* dI, int w, int h, const float K[4], float baseline, int mode_right,
                                       orc_trace_points_t* pts, uint8_t* status) {

@@ -278,6 +278,215 @@ __global__ __launch_bounds__(256) void k_trace_stereo(TraceDev T) {
   finish(IPS_GOOD, bestU, bestV, 2 * errorInPixel, true);
 }
 
+// ImmaturePoint::traceOn (ImmaturePoint.cpp:459-828): the same search along a general epipolar line.  geom[pgeom[i]] is the
+// hostToFrame geometry of the point's host; T.idepth_min_stereo / idepth_max_stereo hold idepth_min / idepth_max.
+__global__ __launch_bounds__(256) void k_trace_on(TraceDev T, const sdso_trace_geom_t* __restrict__ geom, const int* __restrict__ pgeom) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int i = blockIdx.x * 4 + wv;
+  if (i >= T.n) return;
+  if (T.skip && T.skip[i]) { if (lane == 0 && T.status) T.status[i] = 255; return; }
+  __shared__ float s_err[4][128];
+  volatile float* errors = s_err[wv];
+  const float4* __restrict__ dI = T.img;
+  const int wG0 = T.w, hG0 = T.h;
+  const float u_stereo = T.u_stereo[i], v_stereo = T.v_stereo[i];
+  float idepth_min_stereo = T.idepth_min_stereo[i], idepth_max_stereo = T.idepth_max_stereo[i];
+  const float* color = T.color + (size_t)i * 8;
+  const float* weights = T.weights + (size_t)i * 8;
+  const float* gradH = T.gradH + (size_t)i * 4;
+  const float idepth_min = idepth_min_stereo, energyTH = T.energyTH[i];
+  float quality = T.quality[i];
+  const uint8_t prevStatus = T.lastTraceStatus[i];
+  if (prevStatus == IPS_OOB) { if (lane == 0 && T.status) T.status[i] = IPS_OOB; return; }   // :466-468
+  const sdso_trace_geom_t G = geom[pgeom[i]];
+
+  auto finish = [&](int st, float uvx, float uvy, float interval, bool writeUV) {
+    if (lane == 0) {
+      T.lastTraceStatus[i] = (uint8_t)st;
+      if (T.status) T.status[i] = (uint8_t)st;
+      if (writeUV) { T.lastTraceUV[i * 2] = uvx; T.lastTraceUV[i * 2 + 1] = uvy; T.lastTracePixelInterval[i] = interval; }
+      T.quality[i] = quality;
+    }
+  };
+
+  float Kt[3] = {G.Kt[0], G.Kt[1], G.Kt[2]};
+  float pr[3];
+#pragma unroll
+  for (int r = 0; r < 3; r++) pr[r] = (G.KRKi[r * 3 + 0] * u_stereo + G.KRKi[r * 3 + 1] * v_stereo) + G.KRKi[r * 3 + 2] * 1.0f;
+  const float aff0 = G.aff[0], aff1 = G.aff[1];
+  float rot[8][2];
+#pragma unroll
+  for (int idx = 0; idx < 8; idx++) {   // Rplane * patternP  (:628, :636-637)
+    rot[idx][0] = G.KRKi[0] * (float)c_pat[idx][0] + G.KRKi[1] * (float)c_pat[idx][1];
+    rot[idx][1] = G.KRKi[3] * (float)c_pat[idx][0] + G.KRKi[4] * (float)c_pat[idx][1];
+  }
+  float ptpMin[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) ptpMin[k] = pr[k] + Kt[k] * idepth_min_stereo;
+  const float uMin = ptpMin[0] / ptpMin[2];
+  const float vMin = ptpMin[1] / ptpMin[2];
+  if (!(uMin > 4 && vMin > 4 && uMin < wG0 - 5 && vMin < hG0 - 5)) { finish(IPS_OOB, -1, -1, 0, true); return; }
+
+  float dist, uMax, vMax, ptpMax[3];
+  const float maxPixSearch = (wG0 + hG0) * kMaxPixSearch;
+  const bool finiteMax = isfinite(idepth_max_stereo);
+  if (finiteMax) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) ptpMax[k] = pr[k] + Kt[k] * idepth_max_stereo;
+    uMax = ptpMax[0] / ptpMax[2];
+    vMax = ptpMax[1] / ptpMax[2];
+    if (!(uMax > 4 && vMax > 4 && uMax < wG0 - 5 && vMax < hG0 - 5)) { finish(IPS_OOB, -1, -1, 0, true); return; }
+    dist = (uMin - uMax) * (uMin - uMax) + (vMin - vMax) * (vMin - vMax);
+    dist = sqrtf(dist);
+    if (dist < kTraceSlackInterval) { finish(IPS_SKIPPED, (uMax + uMin) * 0.5f, (vMax + vMin) * 0.5f, dist, true); return; }   // :525-531
+  } else {
+    dist = maxPixSearch;
+#pragma unroll
+    for (int k = 0; k < 3; k++) ptpMax[k] = pr[k] + Kt[k] * 0.01f;
+    uMax = ptpMax[0] / ptpMax[2];
+    vMax = ptpMax[1] / ptpMax[2];
+    const float ddx = uMax - uMin;
+    const float ddy = vMax - vMin;
+    const float d = 1.0f / sqrtf(ddx * ddx + ddy * ddy);
+    uMax = uMin + dist * ddx * d;
+    vMax = vMin + dist * ddy * d;
+    if (!(uMax > 4 && vMax > 4 && uMax < wG0 - 5 && vMax < hG0 - 5)) { finish(IPS_OOB, -1, -1, 0, true); return; }
+  }
+  if (!(idepth_min < 0 || (ptpMin[2] > 0.75 && ptpMin[2] < 1.5))) { finish(IPS_OOB, -1, -1, 0, true); return; }
+
+  float dx = kTraceStepsize * (uMax - uMin);
+  float dy = kTraceStepsize * (vMax - vMin);
+  const float a = (dx * gradH[0] + dy * gradH[2]) * dx + (dx * gradH[1] + dy * gradH[3]) * dy;
+  const float b = (dy * gradH[0] + (-dx) * gradH[2]) * dy + (dy * gradH[1] + (-dx) * gradH[3]) * (-dx);
+  float errorInPixel = 0.2f + 0.2f * (a + b) / a;
+  if (errorInPixel * kTraceMinImprovement > dist && finiteMax) { finish(IPS_BADCONDITION, (uMax + uMin) * 0.5f, (vMax + vMin) * 0.5f, dist, true); return; }   // :596-603
+  if (errorInPixel > 10) errorInPixel = 10;
+  dx /= dist;
+  dy /= dist;
+  if (dist > maxPixSearch) {
+    uMax = uMin + maxPixSearch * dx;
+    vMax = vMin + maxPixSearch * dy;
+    dist = maxPixSearch;
+  }
+  int numSteps = 1.9999f + dist / kTraceStepsize;
+  const float randShift = uMin * 1000 - floorf(uMin * 1000);
+  const float ptx0 = uMin - randShift * dx;
+  const float pty0 = vMin - randShift * dy;
+  if (!isfinite(dx) || !isfinite(dy)) { finish(IPS_OOB, -1, -1, 0, true); return; }
+  if (numSteps >= 100) numSteps = 99;
+
+  // ---- discrete search: lane = step (ptx is the reference's running sum ptx += dx)
+  float myE[2] = {1e30f, 1e30f}, myX[2] = {0, 0}, myY[2] = {0, 0};
+#pragma unroll
+  for (int pass = 0; pass < 2; pass++) {
+    const int s = pass * 64 + lane;
+    if (s < numSteps) {
+      float ptx = ptx0, pty = pty0;
+      for (int k = 0; k < s; k++) { ptx += dx; pty += dy; }
+      float energy = 0;
+#pragma unroll
+      for (int idx = 0; idx < 8; idx++) {
+        const float hitColor = interp31(dI, (float)(ptx + rot[idx][0]), (float)(pty + rot[idx][1]), wG0);
+        if (!isfinite(hitColor)) { energy += 1e5; continue; }
+        const float residual = hitColor - (float)(aff0 * color[idx] + aff1);
+        const float hw = fabsf(residual) < kHuberTH ? 1 : kHuberTH / fabsf(residual);
+        energy += hw * residual * residual * (2 - hw);
+      }
+      errors[s] = energy;
+      myE[pass] = energy; myX[pass] = ptx; myY[pass] = pty;
+    }
+  }
+  // first minimum (the reference takes strictly smaller energies only, in step order)
+  float bE = 1e10f; int bI = -1; float bX = 0, bY = 0;
+#pragma unroll
+  for (int pass = 0; pass < 2; pass++) {
+    const int s = pass * 64 + lane;
+    if (s < numSteps && myE[pass] < bE) { bE = myE[pass]; bI = s; bX = myX[pass]; bY = myY[pass]; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float oE = __shfl_xor(bE, o, 64); const int oI = __shfl_xor(bI, o, 64);
+    const float oX = __shfl_xor(bX, o, 64), oY = __shfl_xor(bY, o, 64);
+    const bool take = (oI >= 0) && (bI < 0 || oE < bE || (oE == bE && oI < bI));
+    if (take) { bE = oE; bI = oI; bX = oX; bY = oY; }
+  }
+  float bestU = bX, bestV = bY, bestEnergy = bE;
+  const int bestIdx = bI;
+  if (bestIdx < 0) { bestU = 0; bestV = 0; bestEnergy = 1e10f; }
+  float secondBest = 1e10f;
+#pragma unroll
+  for (int pass = 0; pass < 2; pass++) {
+    const int s = pass * 64 + lane;
+    if (s < numSteps && (s < bestIdx - kMinTraceTestRadius || s > bestIdx + kMinTraceTestRadius) && myE[pass] < secondBest) secondBest = myE[pass];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) secondBest = fminf(secondBest, __shfl_xor(secondBest, o, 64));
+  const float newQuality = secondBest / bestEnergy;
+  if (newQuality < quality || numSteps > 10) quality = newQuality;
+
+  // ---- DSO-native GN (ImmaturePoint.cpp:707-769): pattern pixel idx on lane idx, summed in order
+  float uBak = bestU, vBak = bestV, stepBack = 0;
+  const float gnstepsize = 1;
+  if (kTraceGNIterations > 0) bestEnergy = 1e5;
+  for (int it = 0; it < kTraceGNIterations; it++) {
+    float tH = 0, tb = 0, te = 0;
+    bool nan = false;
+    if (lane < 8) {
+      const float3 hit = interp33(dI, (float)(bestU + rot[lane][0]), (float)(bestV + rot[lane][1]), wG0);
+      if (!isfinite(hit.x)) nan = true;
+      else {
+        const float residual = hit.x - (aff0 * color[lane] + aff1);
+        const float dResdDist = dx * hit.y + dy * hit.z;
+        const float hw = fabsf(residual) < kHuberTH ? 1 : kHuberTH / fabsf(residual);
+        tH = hw * dResdDist * dResdDist;
+        tb = hw * residual * dResdDist;
+        te = weights[lane] * weights[lane] * hw * residual * residual * (2 - hw);
+      }
+    }
+    float H = 1, bb = 0, energy = 0;
+#pragma unroll
+    for (int idx = 0; idx < 8; idx++) {
+      const float h_ = __shfl(tH, idx, 64), b_ = __shfl(tb, idx, 64), e_ = __shfl(te, idx, 64);
+      const int nn = __shfl((int)nan, idx, 64);
+      if (nn) { energy += 1e5; continue; }
+      H += h_; bb += b_; energy += e_;
+    }
+    if (energy > bestEnergy) {
+      stepBack *= 0.5;
+      bestU = uBak + stepBack * dx;
+      bestV = vBak + stepBack * dy;
+    } else {
+      float step = -gnstepsize * bb / H;
+      if (step < -0.5) step = -0.5;
+      else if (step > 0.5) step = 0.5;
+      if (!isfinite(step)) step = 0;
+      uBak = bestU;
+      vBak = bestV;
+      stepBack = step;
+      bestU += step * dx;
+      bestV += step * dy;
+      bestEnergy = energy;
+    }
+    if (fabsf(stepBack) < kTraceGNThreshold) break;
+  }
+
+  if (!(bestEnergy < energyTH * kTraceExtraSlack)) {
+    finish(prevStatus == IPS_OUTLIER ? IPS_OOB : IPS_OUTLIER, -1, -1, 0, true);
+    return;
+  }
+  if (dx * dx > dy * dy) {
+    idepth_min_stereo = (pr[2] * (bestU - errorInPixel * dx) - pr[0]) / (Kt[0] - Kt[2] * (bestU - errorInPixel * dx));
+    idepth_max_stereo = (pr[2] * (bestU + errorInPixel * dx) - pr[0]) / (Kt[0] - Kt[2] * (bestU + errorInPixel * dx));
+  } else {
+    idepth_min_stereo = (pr[2] * (bestV - errorInPixel * dy) - pr[1]) / (Kt[1] - Kt[2] * (bestV - errorInPixel * dy));
+    idepth_max_stereo = (pr[2] * (bestV + errorInPixel * dy) - pr[1]) / (Kt[1] - Kt[2] * (bestV + errorInPixel * dy));
+  }
+  if (idepth_min_stereo > idepth_max_stereo) { const float t = idepth_min_stereo; idepth_min_stereo = idepth_max_stereo; idepth_max_stereo = t; }
+  if (lane == 0) { T.idepth_min_stereo[i] = idepth_min_stereo; T.idepth_max_stereo[i] = idepth_max_stereo; }
+  if (!isfinite(idepth_min_stereo) || !isfinite(idepth_max_stereo) || (idepth_max_stereo < 0)) { finish(IPS_OUTLIER, -1, -1, 0, true); return; }
+  finish(IPS_GOOD, bestU, bestV, 2 * errorInPixel, true);
+}
+
 // ------------------------------------------------------------------ API
 extern "C" int sdso_immature_init_batch(sdso_ctx* ctx, int frame_slot, int n, const float* u, const float* v, float* color, float* weights,
                                         float* gradH, float* energyTH) {
@@ -403,6 +612,37 @@ extern "C" int sdso_trace_stereo_fetch(sdso_ctx* ctx, sdso_trace_points_t* P, ui
   if (n && status) SDSO_HIP(ctx, hipMemcpyAsync(status, T.status, n, hipMemcpyDeviceToHost, ctx->stream));
   SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return SDSO_OK;
+}
+
+extern "C" int sdso_trace_on_batch(sdso_ctx* ctx, int frame_slot, int ngeom, const sdso_trace_geom_t* geom, const int* point_geom,
+                                   sdso_trace_points_t* pts, uint8_t* status) {
+  if (!ctx) return SDSO_ERR_STATE;
+  SDSO_HIP(ctx, hipSetDevice(ctx->device));
+  SDSO_REQUIRE(ctx, pts && pts->n >= 0 && ngeom >= 0, "null argument");
+  const int n = pts->n;
+  if (n == 0) return SDSO_OK;
+  SDSO_REQUIRE(ctx, geom && point_geom && ngeom > 0, "null geometry");
+  for (int i = 0; i < n; i++) SDSO_REQUIRE(ctx, point_geom[i] >= 0 && point_geom[i] < ngeom, "point_geom out of range");
+  const float K0[4] = {1, 1, 0, 0};
+  if (!pts->idepth_min) pts->idepth_min = pts->idepth_min_stereo;       // not used by traceOn; the upload needs a valid pointer
+  if (!pts->idepth_stereo) pts->idepth_stereo = pts->idepth_min_stereo;
+  int rc = sdso_trace_stereo_prepare(ctx, frame_slot, K0, 0.f, 1, pts);   // uploads the point state into the ctx's trace batch
+  if (rc) return rc;
+  TraceBatch& B = g_trace[ctx];
+  rc = ensure_scratch(ctx, sizeof(sdso_trace_geom_t) * (size_t)ngeom + sizeof(int) * (size_t)n);
+  if (rc) return rc;
+  sdso_trace_geom_t* d_geom = (sdso_trace_geom_t*)ctx->scratch;
+  int* d_pg = (int*)(d_geom + ngeom);
+  SDSO_HIP(ctx, hipMemcpyAsync(d_geom, geom, sizeof(sdso_trace_geom_t) * ngeom, hipMemcpyHostToDevice, ctx->stream));
+  SDSO_HIP(ctx, hipMemcpyAsync(d_pg, point_geom, sizeof(int) * n, hipMemcpyHostToDevice, ctx->stream));
+  {
+    ProfScope ps(ctx, "k_trace_on");
+    hipLaunchKernelGGL(k_trace_on, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, B.T, (const sdso_trace_geom_t*)d_geom, (const int*)d_pg);
+  }
+  SDSO_HIP(ctx, hipGetLastError());
+  sdso_trace_points_t out = *pts;
+  out.idepth_stereo = nullptr;
+  return sdso_trace_stereo_fetch(ctx, &out, status);
 }
 
 extern "C" int sdso_trace_stereo_batch(sdso_ctx* ctx, int frame_slot, const float K[4], float baseline, int mode_right, sdso_trace_points_t* pts, uint8_t* status) {

@@ -82,6 +82,10 @@ class TracePoints(C.Structure):
                 ("lastTracePixelInterval", c_float_p)]
 
 
+class TraceGeom(C.Structure):
+    _fields_ = [("KRKi", C.c_float * 9), ("Kt", C.c_float * 3), ("aff", C.c_float * 2)]
+
+
 class StereoMatch(C.Structure):
     _fields_ = [("n", C.c_int), ("u", c_float_p), ("v", c_float_p), ("idepth_min_stereo", c_float_p), ("idepth_max_stereo", c_float_p),
                 ("back_idepth_min_stereo", c_float_p), ("back_idepth_max_stereo", c_float_p), ("status_fwd", c_u8_p), ("status_back", c_u8_p),
@@ -243,6 +247,7 @@ def load():
     L.sdso_trace_stereo_fetch.argtypes = [vp, C.POINTER(TracePoints), c_u8_p]
     L.sdso_track_make_ref.argtypes = [vp, C.c_int, C.c_int, C.c_int, c_int_p, c_int_p, c_float_p, c_float_p, c_int_p]
     L.sdso_track_get_ref.argtypes = [vp, C.c_int, C.c_int, c_int_p, c_float_p, c_float_p, c_float_p, c_float_p]
+    L.sdso_trace_on_batch.argtypes = [vp, C.c_int, C.c_int, C.POINTER(TraceGeom), c_int_p, C.POINTER(TracePoints), c_u8_p]
     L.sdso_stereo_match_batch.argtypes = [vp, C.c_int, C.c_int, c_float_p, C.c_float, C.c_int, C.POINTER(StereoMatch)]
     _lib = L
     return L
@@ -262,7 +267,7 @@ EXPORTED_SYMBOLS = [
     "sdso_ba_keep_projections", "sdso_ba_batch_create", "sdso_ba_batch_accumulate", "sdso_ba_batch_solve",
     "sdso_ba_batch_accum_dev", "sdso_ba_batch_get_x", "sdso_ba_batch_set_materialize",
     "sdso_immature_init_batch", "sdso_trace_stereo_batch", "sdso_trace_stereo_prepare", "sdso_trace_stereo_enqueue",
-    "sdso_trace_stereo_fetch", "sdso_stereo_match_batch", "sdso_track_make_ref", "sdso_track_get_ref",
+    "sdso_trace_stereo_fetch", "sdso_stereo_match_batch", "sdso_trace_on_batch", "sdso_track_make_ref", "sdso_track_get_ref",
 ]
 
 

@@ -167,3 +167,74 @@ def test_gpu_stereo_match_left_right_left(gpu_ctx, oracle, pair):
         # the caller's accept rule (FullSystem.cpp:598-601) keeps most points and the kept ones are consistent by construction
         ok = (sb == 0) & (np.abs(pr["u"][good] - db["lastTraceUV"][:, 0]) < 1) & (1.0 / do["idepth_stereo"][good] > 0) & (1.0 / do["idepth_stereo"][good] < 70)
         assert ok.mean() > 0.5
+
+
+def _trace_on_case(n=3000, seed=2041):
+    """A host keyframe, the newest frame displaced by a general motion (rotation + translation, so the epipolar lines are
+    neither horizontal nor parallel), immature points on the host."""
+    prob = synth.tracker_problem(w=640, h=480, npts=n, seed=seed, motion=(0.25, -0.06, 0.10, 0.006, -0.01, 0.012), aff=(0.02, 1.5))
+    u, v, idp = prob["points"]
+    R, t = prob["refToNew_true"]
+    fx, fy, cx, cy = [np.float32(x) for x in prob["K"]]
+    K = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1]], np.float32)
+    Ki = np.linalg.inv(K.astype(np.float64)).astype(np.float32)
+    G = abi.TraceGeom()
+    KRKi = (K @ R.astype(np.float32) @ Ki).astype(np.float32)
+    Kt = (K @ t.astype(np.float32)).astype(np.float32)
+    G.KRKi[:] = list(KRKi.ravel()); G.Kt[:] = list(Kt); G.aff[:] = [float(np.exp(np.float32(0.02))), 1.5]
+    return prob, u.astype(np.float32), v.astype(np.float32), idp.astype(np.float32), G
+
+
+def test_oracle_trace_on_brackets_true_depth(oracle):
+    prob, u, v, idp, G = _trace_on_case()
+    host = np.ascontiguousarray(prob["pyr_ref"][0]); new = np.ascontiguousarray(prob["pyr_new"][0])
+    pr = dict(w=640, h=480)
+    col, wgt, gH, eth = _oracle_init(oracle, pr, host, u, v)
+    P, d = abi.make_trace_points(len(u), u, v, col, wgt, gH, eth)
+    st = np.zeros(len(u), np.uint8)
+    pg = np.zeros(len(u), np.int32)
+    assert oracle.orc_trace_on_batch(abi.fp(new), 640, 480, 1, C.byref(G), abi.ip(pg), C.byref(P), abi.bp(st)) == 0
+    good = st == 0
+    assert good.mean() > 0.4
+    mid = 0.5 * (d["idepth_min_stereo"][good] + d["idepth_max_stereo"][good])
+    assert np.median(np.abs(mid - idp[good]) / idp[good]) < 0.08     # sub-pixel match along a general epipolar line
+    inside = (d["idepth_min_stereo"][good] <= idp[good] * 1.1) & (d["idepth_max_stereo"][good] >= idp[good] * 0.9)
+    assert inside.mean() > 0.7                                      # the new interval brackets the true inverse depth
+    assert set(np.unique(st)) <= {0, 1, 2, 3, 4}
+
+
+@pytest.mark.gpu
+def test_gpu_trace_on_bit_exact(gpu_ctx, oracle):
+    prob, u, v, idp, G = _trace_on_case()
+    host = np.ascontiguousarray(prob["pyr_ref"][0]); new = np.ascontiguousarray(prob["pyr_new"][0])
+    gpu_ctx.upload_pyramid(85, [new])
+    pr = dict(w=640, h=480)
+    n = len(u)
+    col, wgt, gH, eth = _oracle_init(oracle, pr, host, u, v)
+    # two geometries (the second with a different affine pair) and three kinds of prior state: fresh, a finite interval around
+    # the truth (SKIPPED / BADCONDITION paths write the interval midpoint), and points that were OOB / OUTLIER before
+    G2 = abi.TraceGeom(); G2.KRKi[:] = list(G.KRKi); G2.Kt[:] = list(G.Kt); G2.aff[:] = [1.0, 0.0]
+    geoms = (abi.TraceGeom * 2)(G, G2)
+    pg = (np.arange(n) % 7 == 0).astype(np.int32)
+    imin = np.zeros(n, np.float32); imax = np.full(n, np.nan, np.float32)
+    sel = np.arange(n) % 3 == 1
+    imin[sel] = idp[sel] * 0.6; imax[sel] = idp[sel] * 1.5
+    sel2 = np.arange(n) % 11 == 2
+    imin[sel2] = idp[sel2] * 0.99; imax[sel2] = idp[sel2] * 1.01
+    prev = np.full(n, 5, np.uint8); prev[np.arange(n) % 13 == 3] = 1; prev[np.arange(n) % 13 == 4] = 2
+    outs = []
+    for which in ("oracle", "gpu"):
+        P, d = abi.make_trace_points(n, u, v, col, wgt, gH, eth, imin, imax)
+        d["lastTraceStatus"][:] = prev
+        st = np.zeros(n, np.uint8)
+        if which == "oracle":
+            assert oracle.orc_trace_on_batch(abi.fp(new), 640, 480, 2, geoms, abi.ip(pg), C.byref(P), abi.bp(st)) == 0
+        else:
+            gpu_ctx.check(gpu_ctx.L.sdso_trace_on_batch(gpu_ctx.h, 85, 2, geoms, abi.ip(pg), C.byref(P), abi.bp(st)))
+        outs.append((st, d))
+    (so, do), (sg, dg) = outs
+    assert np.array_equal(so, sg)
+    for k in ("idepth_min_stereo", "idepth_max_stereo", "quality", "lastTraceStatus", "lastTraceUV", "lastTracePixelInterval"):
+        assert np.array_equal(do[k], dg[k], equal_nan=True), k
+    assert {0, 1, 2, 3}.issubset(set(np.unique(so)))               # GOOD, OOB (incl. already-OOB), OUTLIER, SKIPPED all occur
+    assert gpu_ctx.L.sdso_trace_on_batch(gpu_ctx.h, 85, 1, geoms, abi.ip(pg), C.byref(P), abi.bp(st)) == -1   # point_geom out of range
