@@ -334,6 +334,24 @@ typedef struct { float KRKi[9]; float Kt[3]; float aff[2]; } sdso_trace_geom_t;
 int sdso_trace_on_batch(sdso_ctx* ctx, int frame_slot, int ngeom, const sdso_trace_geom_t* geom, const int* point_geom,
                         sdso_trace_points_t* pts, uint8_t* status);
 
+/* FullSystem::optimizeImmaturePoint (FullSystemOptPoint.cpp:52-238) with ImmaturePoint::linearizeResidual
+ * (ImmaturePoint.cpp:886-985), the DSO-native idepth-only Gauss-Newton, for n candidate points at once
+ * (FullSystem::activatePointsMT, FullSystem.cpp:796-958).  pair_* are the FrameFramePrecalc members the reference reads
+ * (host->targetPrecalc[target->idx]: PRE_RTll, PRE_tTll, PRE_aff_mode), indexed host*nf+target.
+ *   status[n]      : 1 activated, 0 not well-constrained (the reference returns 0), -1 outlier (returns (PointHessian*)-1)
+ *   idepth_out[n]  : currentIdepth at exit
+ *   res_state[n*nf]: final ResState per target frame (255 for the host itself / not evaluated) */
+typedef struct {
+  int nf, w, h, n, minObs;
+  float K[4];                              /* fxl fyl cxl cyl */
+  const float* pair_R; const float* pair_t; const float* pair_aff;
+  const int* frame_slot;                   /* nf pyramid slots */
+  const float* const* dI;                  /* unused by the library (layout shared with the test oracle) */
+  const int* host; const float* u; const float* v; const float* idepth_min; const float* idepth_max;
+  const float* color; const float* weights; const float* energyTH;
+} sdso_activate_t;
+int sdso_activate_points_batch(sdso_ctx* ctx, const sdso_activate_t* A, int8_t* status, float* idepth_out, uint8_t* res_state);
+
 /* Left-right-left matching as every caller of traceStereo performs it (FullSystem::stereoMatch FullSystem.cpp:581-613,
  * traceNewCoarseNonKey :667-725, CoarseTracker::makeCoarseDepthL0 CoarseTracker.cpp:295-347):
  *   forward: ImmaturePoint(u, v, frame A) traced into frame B   (interval idepth_min/max_stereo, NULL = fresh 0 / NaN)

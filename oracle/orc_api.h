@@ -167,6 +167,18 @@ int orc_ba_get_tables(orc_ba* h, float* precalc, double* adHost, double* adTarge
 /* ---- static stereo */
 int orc_immature_init_batch(const float* dI, int w, int h, int n, const float* u, const float* v,
                             float* color, float* weights, float* gradH, float* energyTH);
+/* FullSystem::optimizeImmaturePoint (FullSystemOptPoint.cpp:52-238), DSO-native; same layout as sdso_activate_t + host images */
+typedef struct {
+  int nf, w, h, n, minObs;
+  float K[4];
+  const float* pair_R; const float* pair_t; const float* pair_aff;   /* [host*nf+target] PRE_RTll 9, PRE_tTll 3, PRE_aff_mode 2 */
+  const int* frame_slot;            /* product only */
+  const float* const* dI;           /* oracle only: nf level-0 images, AoS float3 */
+  const int* host; const float* u; const float* v; const float* idepth_min; const float* idepth_max;
+  const float* color; const float* weights; const float* energyTH;
+} orc_activate_t;
+int orc_activate_points(const orc_activate_t* A, int8_t* status, float* idepth_out, uint8_t* res_state);
+
 /* hostToFrame geometry of traceOn (FullSystem.cpp:654-665, :760-766) */
 typedef struct { float KRKi[9]; float Kt[3]; float aff[2]; } orc_trace_geom_t;
 /* ImmaturePoint::traceOn (ImmaturePoint.cpp:459-828); pts->u_stereo/v_stereo = u/v, idepth_min_stereo/idepth_max_stereo = idepth_min/idepth_max */

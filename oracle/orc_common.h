@@ -49,6 +49,8 @@ static const int setting_minOptIterations = 1;
 static const float setting_maxPixSearch = 0.027;
 static const float setting_trace_stepsize = 1.0;
 static const int setting_trace_GNIterations = 3;
+static const float setting_minIdepthH_act = 100;        // settings.cpp:56
+static const int setting_GNItsOnPointActivation = 3;    // settings.cpp:114
 static const float setting_trace_GNThreshold = 0.1;
 static const float setting_trace_extraSlackOnTH = 1.2;
 static const float setting_trace_slackInterval = 1.5;

@@ -427,6 +427,103 @@ extern "C" int orc_trace_stereo_batch(const float* dI, int w, int h, const float
   return 0;
 }
 
+
+// ------------------------------------------------------------------ point activation
+// FullSystem::optimizeImmaturePoint (src/FullSystem/FullSystemOptPoint.cpp:52-238) with ImmaturePoint::linearizeResidual
+// (src/FullSystem/ImmaturePoint.cpp:886-985): the DSO-native idepth-only Gauss-Newton that the fork keeps as comments
+// (FullSystemOptPoint.cpp:104-110, :124-169; ImmaturePoint.cpp:940-968), including the two "not well-constrained" exits.
+namespace {
+struct ActFrameGeom { const float* R; const float* t; const float* aff; };
+// returns energy; accumulates Hdd / bd exactly like the reference (contributions of the pixels before an OOB pixel stay in)
+static double linearizeResidualOne(const orc_activate_t* A, int p, int tgt, float outlierTHSlack, uint8_t state_state, float state_energy,
+                                   uint8_t* newState, float* newEnergy, float& Hdd, float& bd, float idepth) {
+  if (state_state == 1) { *newState = 1; return state_energy; }                       // :893-895
+  const int host = A->host[p], nf = A->nf;
+  const float* R = A->pair_R + (size_t)(host * nf + tgt) * 9;
+  const float* t = A->pair_t + (size_t)(host * nf + tgt) * 3;
+  const float* affLL = A->pair_aff + (size_t)(host * nf + tgt) * 2;
+  const float* dIl = A->dI[tgt];
+  const float fxl = A->K[0], fyl = A->K[1], cxl = A->K[2], cyl = A->K[3];
+  const float fxli = 1.0f / fxl, fyli = 1.0f / fyl;
+  const float wM3G = A->w - 3, hM3G = A->h - 3;
+  const float* color = A->color + (size_t)p * 8; const float* weights = A->weights + (size_t)p * 8;
+  const float energyTH = A->energyTH[p];
+  float energyLeft = 0;
+  for (int idx = 0; idx < patternNum; idx++) {
+    int dx = patternP[idx][0], dy = patternP[idx][1];
+    // projectPoint (ResidualProjections.h:64-96)
+    float KliP[3] = {(A->u[p] + dx - cxl) * fxli, (A->v[p] + dy - cyl) * fyli, 1};
+    float ptp[3];
+    for (int r = 0; r < 3; r++) ptp[r] = ((R[r * 3 + 0] * KliP[0] + R[r * 3 + 1] * KliP[1]) + R[r * 3 + 2] * KliP[2]) + t[r] * idepth;
+    float drescale = 1.0f / ptp[2];
+    if (!(drescale > 0)) { *newState = 1; return state_energy; }
+    float u = ptp[0] * drescale, v = ptp[1] * drescale;
+    float Ku = u * fxl + cxl, Kv = v * fyl + cyl;
+    if (!(Ku > 1.1f && Kv > 1.1f && Ku < wM3G && Kv < hM3G)) { *newState = 1; return state_energy; }
+    float hitColor[3];
+    interp33(dIl, Ku, Kv, A->w, hitColor);
+    if (!std::isfinite((float)hitColor[0])) { *newState = 1; return state_energy; }
+    float residual = hitColor[0] - (affLL[0] * color[idx] + affLL[1]);
+    float hw = fabsf(residual) < setting_huberTH ? 1 : setting_huberTH / fabsf(residual);
+    energyLeft += weights[idx] * weights[idx] * hw * residual * residual * (2 - hw);
+    float dxInterp = hitColor[1] * fxl, dyInterp = hitColor[2] * fyl;
+    float d_idepth = (dxInterp * drescale * (t[0] - t[2] * u) + dyInterp * drescale * (t[1] - t[2] * v)) * SCALE_IDEPTH;   // derive_idepth
+    hw *= weights[idx] * weights[idx];
+    Hdd += (hw * d_idepth) * d_idepth;
+    bd += (hw * residual) * d_idepth;
+  }
+  if (energyLeft > energyTH * outlierTHSlack) { energyLeft = energyTH * outlierTHSlack; *newState = 2; }
+  else *newState = 0;
+  *newEnergy = energyLeft;
+  return energyLeft;
+}
+}  // namespace
+
+extern "C" int orc_activate_points(const orc_activate_t* A, int8_t* status, float* idepth_out, uint8_t* res_state) {
+  const int nf = A->nf;
+  for (int p = 0; p < A->n; p++) {
+    uint8_t st[8], nst[8]; float en[8], nen[8]; int tg[8];
+    int nres = 0;
+    for (int f = 0; f < nf; f++) if (f != A->host[p]) { st[nres] = 0; nst[nres] = 2; en[nres] = 0; nen[nres] = 0; tg[nres] = f; nres++; }
+    for (int f = 0; f < nf; f++) res_state[(size_t)p * nf + f] = 255;
+    float lastEnergy = 0, lastHdd = 0, lastbd = 0;
+    float currentIdepth = (A->idepth_max[p] + A->idepth_min[p]) * 0.5f;
+    for (int i = 0; i < nres; i++) {
+      lastEnergy += linearizeResidualOne(A, p, tg[i], 1000, st[i], en[i], &nst[i], &nen[i], lastHdd, lastbd, currentIdepth);
+      st[i] = nst[i]; en[i] = nen[i];
+    }
+    idepth_out[p] = currentIdepth;
+    if (!std::isfinite(lastEnergy) || lastHdd < setting_minIdepthH_act) { status[p] = 0; continue; }       // :104-110
+    float lambda = 0.1;
+    bool skip = false;
+    for (int iteration = 0; iteration < setting_GNItsOnPointActivation; iteration++) {
+      float H = lastHdd;
+      H *= 1 + lambda;
+      float step = (1.0 / H) * lastbd;
+      float newIdepth = currentIdepth - step;
+      float newHdd = 0, newbd = 0, newEnergy = 0;
+      for (int i = 0; i < nres; i++) newEnergy += linearizeResidualOne(A, p, tg[i], 1, st[i], en[i], &nst[i], &nen[i], newHdd, newbd, newIdepth);
+      if (!std::isfinite(lastEnergy) || newHdd < setting_minIdepthH_act) { skip = true; break; }            // :134-141
+      if (newEnergy < lastEnergy) {
+        currentIdepth = newIdepth; lastHdd = newHdd; lastbd = newbd; lastEnergy = newEnergy;
+        for (int i = 0; i < nres; i++) { st[i] = nst[i]; en[i] = nen[i]; }
+        lambda *= 0.5;
+      } else lambda *= 5;
+      if (fabsf(step) < 0.0001 * currentIdepth) break;
+    }
+    idepth_out[p] = currentIdepth;
+    if (skip) { status[p] = 0; continue; }
+    if (!std::isfinite(currentIdepth)) { status[p] = -1; continue; }
+    int numGoodRes = 0;
+    for (int i = 0; i < nres; i++) if (st[i] == 0) numGoodRes++;
+    for (int i = 0; i < nres; i++) res_state[(size_t)p * nf + tg[i]] = st[i];
+    if (numGoodRes < A->minObs) { status[p] = -1; continue; }
+    if (!std::isfinite(A->energyTH[p])) { status[p] = -1; continue; }                                       // :199-202
+    status[p] = 1;
+  }
+  return 0;
+}
+
 // ---- math wrappers
 static SE3 toSE3(const orc_se3_t* T) { SE3 S; std::memcpy(S.R, T->R, 72); std::memcpy(S.t, T->t, 24); return S; }
 static void fromSE3(const SE3& S, orc_se3_t* T) { std::memcpy(T->R, S.R, 72); std::memcpy(T->t, S.t, 24); }

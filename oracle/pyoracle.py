@@ -11,7 +11,7 @@ import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(os.path.dirname(_HERE), "stereo-dso-g2o_amd"))
-from sdso_amd.abi import (TraceGeom, TrackEval, SE3, Aff, TrackParams, TrackResult, BAWindow, BAOptResult, TracePoints,  # noqa: E402
+from sdso_amd.abi import (Activate, TraceGeom, TrackEval, SE3, Aff, TrackParams, TrackResult, BAWindow, BAOptResult, TracePoints,  # noqa: E402
                           c_float_p, c_double_p, c_int_p, c_u8_p)
 
 _libs = {}
@@ -70,6 +70,7 @@ def load(fast=False):
     L.orc_ba_marginalize_points.argtypes = [vp, c_u8_p, c_double_p, c_double_p]
     L.orc_ba_get_tables.argtypes = [vp, c_float_p, c_double_p, c_double_p, c_float_p]
     L.orc_immature_init_batch.argtypes = [c_float_p, C.c_int, C.c_int, C.c_int, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p]
+    L.orc_activate_points.argtypes = [C.POINTER(Activate), C.POINTER(C.c_int8), c_float_p, c_u8_p]
     L.orc_trace_on_batch.argtypes = [c_float_p, C.c_int, C.c_int, C.c_int, C.POINTER(TraceGeom), c_int_p, C.POINTER(TracePoints), c_u8_p]
     L.orc_trace_stereo_batch.argtypes = [c_float_p, C.c_int, C.c_int, c_float_p, C.c_float, C.c_int, C.POINTER(TracePoints), c_u8_p]
     _libs[name] = L

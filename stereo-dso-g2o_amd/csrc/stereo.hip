@@ -762,3 +762,198 @@ extern "C" int sdso_stereo_match_batch(sdso_ctx* ctx, int slot_a, int slot_b, co
   SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return SDSO_OK;
 }
+
+// ------------------------------------------------------------------ point activation (N3)
+// FullSystem::optimizeImmaturePoint (src/FullSystem/FullSystemOptPoint.cpp:52-238) + ImmaturePoint::linearizeResidual
+// (src/FullSystem/ImmaturePoint.cpp:886-985), the DSO-native idepth-only Gauss-Newton (kept as comments in the fork).
+// One wave per immature point: lane (r, idx) = (lane>>3, lane&7) evaluates pattern pixel idx of the residual to the r-th
+// other keyframe (<= 7 residuals x 8 pixels = 56 lanes) — projection, bilinear sample, Huber weight, d(res)/d(idepth) —
+// and the reference's running sums (energy per residual; Hdd and bd across ALL residuals and pixels, including the pixels
+// that precede an out-of-bounds pixel of the same residual) are rebuilt in its exact order from the 56 lane values.
+namespace sdso {
+struct ActDev {
+  int nf, w, h, n, minObs;
+  float fx, fy, cx, cy;
+  const float* pair_R; const float* pair_t; const float* pair_aff;
+  const float4* const* img;
+  const int* host; const float* u; const float* v; const float* idepth_min; const float* idepth_max;
+  const float* color; const float* weights; const float* energyTH;
+  int8_t* status; float* idepth_out; uint8_t* res_state;
+};
+constexpr float kMinIdepthH_act = 100.f;
+constexpr int kGNItsOnPointActivation = 3;
+}  // namespace sdso
+
+__global__ __launch_bounds__(256) void k_activate_points(ActDev A) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int p = blockIdx.x * 4 + wv;
+  if (p >= A.n) return;
+  const int nf = A.nf, host = A.host[p];
+  const int r = lane >> 3, idx = lane & 7;
+  const int nres = nf - 1;
+  const int tgt = r < host ? r : r + 1;                  // r-th frame != host, in frame order
+  const bool live = r < nres;
+  const int pairi = host * nf + (live ? tgt : (host == 0 ? 1 % nf : 0));
+  float R[9], t[3];
+#pragma unroll
+  for (int k = 0; k < 9; k++) R[k] = A.pair_R[(size_t)pairi * 9 + k];
+#pragma unroll
+  for (int k = 0; k < 3; k++) t[k] = A.pair_t[(size_t)pairi * 3 + k];
+  const float aff0 = A.pair_aff[(size_t)pairi * 2], aff1 = A.pair_aff[(size_t)pairi * 2 + 1];
+  const float4* __restrict__ dIl = A.img[live ? tgt : host];
+  const float fxl = A.fx, fyl = A.fy, cxl = A.cx, cyl = A.cy;
+  const float fxli = 1.0f / fxl, fyli = 1.0f / fyl;
+  const float wM3G = A.w - 3, hM3G = A.h - 3;
+  const float pu = A.u[p], pv = A.v[p];
+  const float color = A.color[(size_t)p * 8 + idx], wgt = A.weights[(size_t)p * 8 + idx];
+  const float energyTH = A.energyTH[p];
+  const int pdx = c_pat[idx][0], pdy = c_pat[idx][1];
+
+  // per-lane terms of one linearizeResidual pass at `idepth`
+  auto eval = [&](float idepth, bool& fail, float& e, float& hh, float& bb) {
+    fail = false; e = 0; hh = 0; bb = 0;
+    const float KliP0 = (pu + pdx - cxl) * fxli, KliP1 = (pv + pdy - cyl) * fyli, KliP2 = 1;
+    float ptp[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) ptp[k] = ((R[k * 3 + 0] * KliP0 + R[k * 3 + 1] * KliP1) + R[k * 3 + 2] * KliP2) + t[k] * idepth;
+    const float drescale = 1.0f / ptp[2];
+    if (!(drescale > 0)) { fail = true; return; }
+    const float u = ptp[0] * drescale, v = ptp[1] * drescale;
+    const float Ku = u * fxl + cxl, Kv = v * fyl + cyl;
+    if (!(Ku > 1.1f && Kv > 1.1f && Ku < wM3G && Kv < hM3G)) { fail = true; return; }
+    const float3 hit = interp33(dIl, Ku, Kv, A.w);
+    if (!isfinite(hit.x)) { fail = true; return; }
+    const float residual = hit.x - (aff0 * color + aff1);
+    float hw = fabsf(residual) < kHuberTH ? 1 : kHuberTH / fabsf(residual);
+    e = wgt * wgt * hw * residual * residual * (2 - hw);
+    const float dxInterp = hit.y * fxl, dyInterp = hit.z * fyl;
+    const float d_idepth = (dxInterp * drescale * (t[0] - t[2] * u) + dyInterp * drescale * (t[1] - t[2] * v)) * SCALE_IDEPTH;
+    hw *= wgt * wgt;
+    hh = (hw * d_idepth) * d_idepth;
+    bb = (hw * residual) * d_idepth;
+  };
+
+  int st[7], nst[7];
+  float en[7], nen[7];
+#pragma unroll
+  for (int i = 0; i < 7; i++) { st[i] = 0; nst[i] = 2; en[i] = 0; nen[i] = 0; }
+
+  // one pass over all residuals in the reference's order; every lane ends with the same (uniform) results
+  auto pass = [&](float idepth, float slack, float& Hdd, float& bd) -> float {
+    bool f; float e, hh, bb;
+    if (live) eval(idepth, f, e, hh, bb); else { f = false; e = 0; hh = 0; bb = 0; }
+    float total = 0;
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+      if (i >= nres) continue;
+      if (st[i] == 1) { nst[i] = 1; total += en[i]; continue; }          // ImmaturePoint.cpp:893-895
+      float energyLeft = 0;
+      bool alive = true;
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const int src = i * 8 + k;
+        const bool fk = __shfl((int)f, src, 64) != 0;
+        const float ek = __shfl(e, src, 64), hk = __shfl(hh, src, 64), bk = __shfl(bb, src, 64);
+        if (alive && fk) alive = false;
+        if (alive) { energyLeft += ek; Hdd += hk; bd += bk; }
+      }
+      if (!alive) { nst[i] = 1; total += en[i]; continue; }               // OOB: returns the old state_energy
+      if (energyLeft > energyTH * slack) { energyLeft = energyTH * slack; nst[i] = 2; }
+      else nst[i] = 0;
+      nen[i] = energyLeft;
+      total += energyLeft;
+    }
+    return total;
+  };
+
+  float lastHdd = 0, lastbd = 0;
+  float currentIdepth = (A.idepth_max[p] + A.idepth_min[p]) * 0.5f;
+  float lastEnergy = pass(currentIdepth, 1000.f, lastHdd, lastbd);
+#pragma unroll
+  for (int i = 0; i < 7; i++) { st[i] = nst[i]; en[i] = nen[i]; }
+  int8_t status = 1;
+  bool done = false;
+  if (!isfinite(lastEnergy) || lastHdd < kMinIdepthH_act) { status = 0; done = true; }     // FullSystemOptPoint.cpp:104-110
+  float lambda = 0.1f;
+  if (!done) {
+    for (int iteration = 0; iteration < kGNItsOnPointActivation; iteration++) {
+      float H = lastHdd;
+      H *= 1 + lambda;
+      const float step = (1.0 / H) * lastbd;
+      const float newIdepth = currentIdepth - step;
+      float newHdd = 0, newbd = 0;
+      const float newEnergy = pass(newIdepth, 1.f, newHdd, newbd);
+      if (!isfinite(lastEnergy) || newHdd < kMinIdepthH_act) { status = 0; done = true; break; }   // :134-141
+      if (newEnergy < lastEnergy) {
+        currentIdepth = newIdepth; lastHdd = newHdd; lastbd = newbd; lastEnergy = newEnergy;
+#pragma unroll
+        for (int i = 0; i < 7; i++) { st[i] = nst[i]; en[i] = nen[i]; }
+        lambda *= 0.5;
+      } else lambda *= 5;
+      if (fabsf(step) < 0.0001 * currentIdepth) break;
+    }
+  }
+  if (lane == 0) {
+    for (int f = 0; f < nf; f++) A.res_state[(size_t)p * nf + f] = 255;
+    A.idepth_out[p] = currentIdepth;
+    if (!done) {
+      if (!isfinite(currentIdepth)) status = -1;
+      else {
+        int good = 0;
+#pragma unroll
+        for (int i = 0; i < 7; i++) if (i < nres) { good += st[i] == 0; A.res_state[(size_t)p * nf + (i < host ? i : i + 1)] = (uint8_t)st[i]; }
+        if (good < A.minObs || !isfinite(energyTH)) status = -1;
+      }
+    }
+    A.status[p] = status;
+  }
+}
+
+extern "C" int sdso_activate_points_batch(sdso_ctx* ctx, const sdso_activate_t* A, int8_t* status, float* idepth_out, uint8_t* res_state) {
+  if (!ctx) return SDSO_ERR_STATE;
+  SDSO_HIP(ctx, hipSetDevice(ctx->device));
+  SDSO_REQUIRE(ctx, A && status && idepth_out && res_state, "null argument");
+  const int nf = A->nf, n = A->n;
+  SDSO_REQUIRE(ctx, nf >= 2 && nf <= 8 && n >= 0, "2 <= nf <= 8 keyframes");
+  if (n == 0) return SDSO_OK;
+  SDSO_REQUIRE(ctx, A->pair_R && A->pair_t && A->pair_aff && A->frame_slot && A->host && A->u && A->v && A->idepth_min && A->idepth_max && A->color &&
+                        A->weights && A->energyTH, "null array");
+  std::vector<const float4*> imgs(nf);
+  for (int f = 0; f < nf; f++) {
+    auto ip = ctx->pyr.find(A->frame_slot[f]);
+    SDSO_REQUIRE(ctx, ip != ctx->pyr.end(), "unknown frame slot");
+    SDSO_REQUIRE(ctx, ip->second.w[0] == A->w && ip->second.h[0] == A->h, "pyramid size differs from w/h");
+    imgs[f] = ip->second.d[0];
+  }
+  for (int i = 0; i < n; i++) SDSO_REQUIRE(ctx, A->host[i] >= 0 && A->host[i] < nf, "host out of range");
+  // one scratch blob: tables, images, point arrays, outputs
+  const size_t fl = (size_t)nf * nf * 14 + (size_t)n * 21;
+  const size_t bytes = sizeof(float) * fl + sizeof(void*) * nf + sizeof(int) * n + sizeof(float) * n + (size_t)n * (1 + nf) + 64;
+  int rc = ensure_scratch(ctx, bytes);
+  if (rc) return rc;
+  float* f0 = (float*)ctx->scratch;
+  ActDev D;
+  D.nf = nf; D.w = A->w; D.h = A->h; D.n = n; D.minObs = A->minObs;
+  D.fx = A->K[0]; D.fy = A->K[1]; D.cx = A->K[2]; D.cy = A->K[3];
+  float* q = f0;
+  auto upf = [&](const float* src, size_t cnt) { float* d = q; q += cnt; hipMemcpyAsync(d, src, sizeof(float) * cnt, hipMemcpyHostToDevice, ctx->stream); return (const float*)d; };
+  D.pair_R = upf(A->pair_R, (size_t)nf * nf * 9); D.pair_t = upf(A->pair_t, (size_t)nf * nf * 3); D.pair_aff = upf(A->pair_aff, (size_t)nf * nf * 2);
+  D.u = upf(A->u, n); D.v = upf(A->v, n); D.idepth_min = upf(A->idepth_min, n); D.idepth_max = upf(A->idepth_max, n);
+  D.color = upf(A->color, (size_t)n * 8); D.weights = upf(A->weights, (size_t)n * 8); D.energyTH = upf(A->energyTH, n);
+  D.idepth_out = q; q += n;
+  const float4** d_img = (const float4**)(((uintptr_t)q + 15) & ~(uintptr_t)15);
+  SDSO_HIP(ctx, hipMemcpyAsync(d_img, imgs.data(), sizeof(void*) * nf, hipMemcpyHostToDevice, ctx->stream));
+  D.img = d_img;
+  int* d_host = (int*)(d_img + nf);
+  SDSO_HIP(ctx, hipMemcpyAsync(d_host, A->host, sizeof(int) * n, hipMemcpyHostToDevice, ctx->stream));
+  D.host = d_host;
+  D.status = (int8_t*)(d_host + n);
+  D.res_state = (uint8_t*)(D.status + n);
+  hipLaunchKernelGGL(k_activate_points, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, D);
+  SDSO_HIP(ctx, hipGetLastError());
+  SDSO_HIP(ctx, hipMemcpyAsync(status, D.status, n, hipMemcpyDeviceToHost, ctx->stream));
+  SDSO_HIP(ctx, hipMemcpyAsync(res_state, D.res_state, (size_t)n * nf, hipMemcpyDeviceToHost, ctx->stream));
+  SDSO_HIP(ctx, hipMemcpyAsync(idepth_out, D.idepth_out, sizeof(float) * n, hipMemcpyDeviceToHost, ctx->stream));
+  SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SDSO_OK;
+}

@@ -86,6 +86,13 @@ class TraceGeom(C.Structure):
     _fields_ = [("KRKi", C.c_float * 9), ("Kt", C.c_float * 3), ("aff", C.c_float * 2)]
 
 
+class Activate(C.Structure):
+    _fields_ = [("nf", C.c_int), ("w", C.c_int), ("h", C.c_int), ("n", C.c_int), ("minObs", C.c_int), ("K", C.c_float * 4),
+                ("pair_R", c_float_p), ("pair_t", c_float_p), ("pair_aff", c_float_p), ("frame_slot", c_int_p), ("dI", C.POINTER(c_float_p)),
+                ("host", c_int_p), ("u", c_float_p), ("v", c_float_p), ("idepth_min", c_float_p), ("idepth_max", c_float_p),
+                ("color", c_float_p), ("weights", c_float_p), ("energyTH", c_float_p)]
+
+
 class StereoMatch(C.Structure):
     _fields_ = [("n", C.c_int), ("u", c_float_p), ("v", c_float_p), ("idepth_min_stereo", c_float_p), ("idepth_max_stereo", c_float_p),
                 ("back_idepth_min_stereo", c_float_p), ("back_idepth_max_stereo", c_float_p), ("status_fwd", c_u8_p), ("status_back", c_u8_p),
@@ -248,6 +255,7 @@ def load():
     L.sdso_track_make_ref.argtypes = [vp, C.c_int, C.c_int, C.c_int, c_int_p, c_int_p, c_float_p, c_float_p, c_int_p]
     L.sdso_track_get_ref.argtypes = [vp, C.c_int, C.c_int, c_int_p, c_float_p, c_float_p, c_float_p, c_float_p]
     L.sdso_trace_on_batch.argtypes = [vp, C.c_int, C.c_int, C.POINTER(TraceGeom), c_int_p, C.POINTER(TracePoints), c_u8_p]
+    L.sdso_activate_points_batch.argtypes = [vp, C.POINTER(Activate), C.POINTER(C.c_int8), c_float_p, c_u8_p]
     L.sdso_stereo_match_batch.argtypes = [vp, C.c_int, C.c_int, c_float_p, C.c_float, C.c_int, C.POINTER(StereoMatch)]
     _lib = L
     return L
@@ -267,7 +275,7 @@ EXPORTED_SYMBOLS = [
     "sdso_ba_keep_projections", "sdso_ba_batch_create", "sdso_ba_batch_accumulate", "sdso_ba_batch_solve",
     "sdso_ba_batch_accum_dev", "sdso_ba_batch_get_x", "sdso_ba_batch_set_materialize",
     "sdso_immature_init_batch", "sdso_trace_stereo_batch", "sdso_trace_stereo_prepare", "sdso_trace_stereo_enqueue",
-    "sdso_trace_stereo_fetch", "sdso_stereo_match_batch", "sdso_trace_on_batch", "sdso_track_make_ref", "sdso_track_get_ref",
+    "sdso_trace_stereo_fetch", "sdso_stereo_match_batch", "sdso_activate_points_batch", "sdso_trace_on_batch", "sdso_track_make_ref", "sdso_track_get_ref",
 ]
 
 

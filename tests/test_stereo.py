@@ -238,3 +238,84 @@ def test_gpu_trace_on_bit_exact(gpu_ctx, oracle):
         assert np.array_equal(do[k], dg[k], equal_nan=True), k
     assert {0, 1, 2, 3}.issubset(set(np.unique(so)))               # GOOD, OOB (incl. already-OOB), OUTLIER, SKIPPED all occur
     assert gpu_ctx.L.sdso_trace_on_batch(gpu_ctx.h, 85, 1, geoms, abi.ip(pg), C.byref(P), abi.bp(st)) == -1   # point_geom out of range
+
+
+def _activation_case(oracle, nf=5, per_host=150, seed=3051):
+    """nf keyframes of a synthetic window; `per_host` immature points on every host with an idepth interval around the truth."""
+    win = synth.ba_window(w=640, h=480, nf=nf, pts_per_kf=4, seed=seed)
+    K = win["K"]
+    rs = np.random.RandomState(seed)
+    pair_R = np.zeros((nf * nf, 9), np.float32); pair_t = np.zeros((nf * nf, 3), np.float32); pair_aff = np.zeros((nf * nf, 2), np.float32)
+    for h in range(nf):
+        for t in range(nf):
+            T = synth.se3_mul(win["poses"][t], synth.se3_inv(win["poses"][h]))           # leftToLeft = target.worldToCam * host.camToWorld
+            pair_R[h * nf + t] = T[0].astype(np.float32).ravel(); pair_t[h * nf + t] = T[1].astype(np.float32)
+            a = np.exp(win["affs"][t][0] - win["affs"][h][0])                             # AffLight::fromToVecExposure, exposures 1
+            pair_aff[h * nf + t] = (a, win["affs"][t][1] - a * win["affs"][h][1])
+    hosts, us, vs, imin, imax, cols, wgts, eths, truth = [], [], [], [], [], [], [], [], []
+    cal = dict(w=640, h=480)
+    scene = synth.Scene(1001)
+    for h in range(nf):
+        img = np.ascontiguousarray(win["pyrs"][h][0])
+        _, idmap = scene.render(640, 480, K, win["poses"][h])
+        u, v = synth.select_points(win["pyrs"][h][0], per_host, seed + 17 * h, margin=8, idepth=idmap, min_idepth=0.0075)
+        u = u.astype(np.float32); v = v.astype(np.float32)
+        c, w_, g, e = _oracle_init(oracle, cal, img, u, v)
+        idt = idmap[v.astype(int), u.astype(int)].astype(np.float32)
+        lo = idt * rs.uniform(0.6, 1.0, len(u)).astype(np.float32); hi = idt * rs.uniform(1.0, 1.6, len(u)).astype(np.float32)
+        hosts.append(np.full(len(u), h, np.int32)); us.append(u); vs.append(v); imin.append(lo); imax.append(hi)
+        cols.append(c); wgts.append(w_); eths.append(e); truth.append(idt)
+    cat = lambda xs: np.ascontiguousarray(np.concatenate(xs))
+    d = dict(nf=nf, win=win, pair_R=pair_R, pair_t=pair_t, pair_aff=pair_aff, host=cat(hosts), u=cat(us), v=cat(vs), idepth_min=cat(imin),
+             idepth_max=cat(imax), color=cat(cols), weights=cat(wgts), energyTH=cat(eths), truth=cat(truth))
+    return d
+
+
+def _activate_struct(d, frame_slots=None, dI=None, minObs=2):
+    A = abi.Activate()
+    keep = []
+    A.nf, A.w, A.h, A.n, A.minObs = d["nf"], 640, 480, len(d["u"]), minObs
+    A.K[:] = [float(x) for x in d["win"]["K"]]
+    for k in ("pair_R", "pair_t", "pair_aff", "u", "v", "idepth_min", "idepth_max", "color", "weights", "energyTH"):
+        a = np.ascontiguousarray(d[k], np.float32); keep.append(a); setattr(A, k, abi.fp(a))
+    A.host = abi.ip(d["host"])
+    if frame_slots is not None:
+        fs = np.ascontiguousarray(frame_slots, np.int32); keep.append(fs); A.frame_slot = abi.ip(fs)
+    if dI is not None:
+        ptrs = (abi.c_float_p * len(dI))()
+        for i, a in enumerate(dI):
+            a = np.ascontiguousarray(a, np.float32); keep.append(a); ptrs[i] = abi.fp(a)
+        keep.append(ptrs); A.dI = C.cast(ptrs, C.POINTER(abi.c_float_p))
+    return A, keep
+
+
+def test_oracle_activation_converges_to_true_idepth(oracle):
+    d = _activation_case(oracle)
+    A, keep = _activate_struct(d, dI=[p[0] for p in d["win"]["pyrs"]])
+    n = A.n
+    st = np.zeros(n, np.int8); idp = np.zeros(n, np.float32); rs_ = np.zeros((n, d["nf"]), np.uint8)
+    assert oracle.orc_activate_points(C.byref(A), st.ctypes.data_as(C.POINTER(C.c_int8)), abi.fp(idp), abi.bp(rs_)) == 0
+    act = st == 1
+    assert act.mean() > 0.5 and (st == -1).sum() > 0                      # most points activate, some are rejected
+    rel = np.abs(idp[act] - d["truth"][act]) / d["truth"][act]
+    start = np.abs(0.5 * (d["idepth_min"][act] + d["idepth_max"][act]) - d["truth"][act]) / d["truth"][act]
+    assert np.median(rel) < 0.02 and np.median(rel) < 0.3 * np.median(start)   # the 3 GN steps pull the interval midpoint onto the surface
+
+
+@pytest.mark.gpu
+def test_gpu_activation_bit_exact(gpu_ctx, oracle):
+    d = _activation_case(oracle)
+    nf = d["nf"]
+    for f in range(nf):
+        gpu_ctx.upload_pyramid(60 + f, d["win"]["pyrs"][f][:1])
+    # degrade some inputs: huge interval (diverging first step), interval far from the truth (outliers), NaN energyTH
+    d["idepth_max"][::17] *= 6; d["idepth_min"][5::23] *= 0.05; d["idepth_max"][5::23] *= 0.1; d["energyTH"][9::41] = np.nan
+    A, keep = _activate_struct(d, frame_slots=[60 + f for f in range(nf)], dI=[p[0] for p in d["win"]["pyrs"]])
+    n = A.n
+    so = np.zeros(n, np.int8); io = np.zeros(n, np.float32); ro = np.zeros((n, nf), np.uint8)
+    sg = np.zeros(n, np.int8); ig = np.zeros(n, np.float32); rg = np.zeros((n, nf), np.uint8)
+    assert oracle.orc_activate_points(C.byref(A), so.ctypes.data_as(C.POINTER(C.c_int8)), abi.fp(io), abi.bp(ro)) == 0
+    gpu_ctx.check(gpu_ctx.L.sdso_activate_points_batch(gpu_ctx.h, C.byref(A), sg.ctypes.data_as(C.POINTER(C.c_int8)), abi.fp(ig), abi.bp(rg)))
+    assert np.array_equal(so, sg) and np.array_equal(ro, rg)
+    assert np.array_equal(io, ig, equal_nan=True)                          # same float operations in the same order: bit-exact
+    assert set(np.unique(so)) == {-1, 0, 1}
