@@ -263,6 +263,12 @@ int sdso_ba_optimize(sdso_ctx* ctx, int win, int mnumOptIts, double* state_out /
 int sdso_ba_marginalize_points(sdso_ctx* ctx, int win, const uint8_t* marg_flag, double* HM_out,
                                double* bM_out);
 
+/* EnergyFunctional::marginalizeFrame (EnergyFunctional.cpp:554-660): remove keyframe `idx` (EFFrame::idx) from the
+ * marginalisation prior.  prior8 / delta_prior8 are EFFrame::prior / delta_prior.  HM_in (8nf+4)^2, bM_in 8nf+4 ->
+ * HM_out (8(nf-1)+4)^2, bM_out.  ~70x70 double algebra once per keyframe: runs on the host, needs no ctx. */
+int sdso_ba_marginalize_frame(int nf, int idx, const double* prior8, const double* delta_prior8,
+                              const double* HM_in, const double* bM_in, double* HM_out, double* bM_out);
+
 /* keep projectedTo / centerProjectedTo of PointFrameResidual (Residuals.h:96-99) for
  * sdso_ba_get_linearization; off by default (76 B of extra stores per residual). */
 int sdso_ba_keep_projections(sdso_ctx* ctx, int win, int on);

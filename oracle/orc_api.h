@@ -167,6 +167,10 @@ int orc_ba_get_tables(orc_ba* h, float* precalc, double* adHost, double* adTarge
 /* ---- static stereo */
 int orc_immature_init_batch(const float* dI, int w, int h, int n, const float* u, const float* v,
                             float* color, float* weights, float* gradH, float* energyTH);
+/* EnergyFunctional::marginalizeFrame (EnergyFunctional.cpp:554-660) */
+int orc_marginalize_frame(int nf, int idx, const double* prior8, const double* delta_prior8, const double* HM_in, const double* bM_in,
+                          double* HM_out, double* bM_out);
+
 /* FullSystem::optimizeImmaturePoint (FullSystemOptPoint.cpp:52-238), DSO-native; same layout as sdso_activate_t + host images */
 typedef struct {
   int nf, w, h, n, minObs;

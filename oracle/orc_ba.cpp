@@ -1235,3 +1235,46 @@ extern "C" int orc_ba_get_tables(orc_ba* h, float* precalc, double* adHost, doub
   if (adHTdeltaF) std::memcpy(adHTdeltaF, h->adHTdeltaF.data(), h->adHTdeltaF.size() * 4);
   return 0;
 }
+
+// EnergyFunctional::marginalizeFrame (EnergyFunctional.cpp:554-660) on plain arrays
+extern "C" int orc_marginalize_frame(int nf, int idx, const double* prior8, const double* delta_prior8, const double* HM_in, const double* bM_in,
+                                     double* HM_out, double* bM_out) {
+  const int odim = nf * 8 + 4, ndim = odim - 8;
+  MatX HM(odim, odim); VecX bM(odim);
+  for (int i = 0; i < odim; i++) { bM[i] = bM_in[i]; for (int j = 0; j < odim; j++) HM(i, j) = HM_in[(size_t)i * odim + j]; }
+  if (idx != nf - 1) {                                  // [step 1] :569-591
+    const int io = idx * 8 + 4, ntail = 8 * (nf - idx - 1);
+    VecX b2 = bM;
+    for (int i = 0; i < ntail; i++) b2[io + i] = bM[io + 8 + i];
+    for (int i = 0; i < 8; i++) b2[odim - 8 + i] = bM[io + i];
+    bM = b2;
+    MatX H2 = HM;
+    for (int r = 0; r < odim; r++) { for (int i = 0; i < ntail; i++) H2(r, io + i) = HM(r, io + 8 + i); for (int i = 0; i < 8; i++) H2(r, odim - 8 + i) = HM(r, io + i); }
+    MatX H3 = H2;
+    for (int c = 0; c < odim; c++) { for (int i = 0; i < ntail; i++) H3(io + i, c) = H2(io + 8 + i, c); for (int i = 0; i < 8; i++) H3(odim - 8 + i, c) = H2(io + i, c); }
+    HM = H3;
+  }
+  for (int i = 0; i < 8; i++) { HM(ndim + i, ndim + i) += prior8[i]; bM[ndim + i] += prior8[i] * delta_prior8[i]; }   // [step 2] :596-597
+  VecX SVec(odim), SVecI(odim);                         // [step 3] :601-632
+  for (int i = 0; i < odim; i++) { SVec[i] = std::sqrt(std::fabs(HM(i, i)) + 10); SVecI[i] = 1.0 / SVec[i]; }
+  MatX HS(odim, odim); VecX bS(odim);
+  for (int i = 0; i < odim; i++) { bS[i] = SVecI[i] * bM[i]; for (int j = 0; j < odim; j++) HS(i, j) = SVecI[i] * HM(i, j) * SVecI[j]; }
+  MatX hpi(8, 8), hinv;
+  for (int i = 0; i < 8; i++) for (int j = 0; j < 8; j++) hpi(i, j) = 0.5f * (HS(ndim + i, ndim + j) + HS(ndim + i, ndim + j));
+  mat_inverse(hpi, hinv);
+  for (int i = 0; i < 8; i++) for (int j = 0; j < 8; j++) hinv(i, j) = 0.5f * (hinv(i, j) + hinv(i, j));
+  MatX bli(ndim, 8);
+  for (int r = 0; r < ndim; r++) for (int c = 0; c < 8; c++) { double s = 0; for (int k = 0; k < 8; k++) s += HS(ndim + k, r) * hinv(k, c); bli(r, c) = s; }
+  MatX HT = HS; VecX bT = bS;
+  for (int r = 0; r < ndim; r++) {
+    for (int c = 0; c < ndim; c++) { double s = 0; for (int k = 0; k < 8; k++) s += bli(r, k) * HS(ndim + k, c); HT(r, c) = HS(r, c) - s; }
+    double s = 0;
+    for (int k = 0; k < 8; k++) s += bli(r, k) * bS[ndim + k];
+    bT[r] = bS[r] - s;
+  }
+  for (int r = 0; r < ndim; r++) {
+    bM_out[r] = SVec[r] * bT[r];
+    for (int c = 0; c < ndim; c++) HM_out[(size_t)r * ndim + c] = 0.5 * (SVec[r] * HT(r, c) * SVec[c] + SVec[c] * HT(c, r) * SVec[r]);
+  }
+  return 0;
+}

@@ -910,3 +910,51 @@ extern "C" int sdso_ba_batch_get_x(sdso_ctx* ctx, double* x /* nwin * (8nf+4) */
   }
   return SDSO_OK;
 }
+
+// EnergyFunctional::marginalizeFrame (EnergyFunctional.cpp:554-660): drop frame `idx` from the marginalisation prior
+// HM / bM by a scaled Schur complement.  ~70x70 doubles once per keyframe: host algebra, no device work.
+extern "C" int sdso_ba_marginalize_frame(int nf, int idx, const double* prior8, const double* delta_prior8, const double* HM_in,
+                                         const double* bM_in, double* HM_out, double* bM_out) {
+  if (nf < 1 || idx < 0 || idx >= nf || !prior8 || !delta_prior8 || !HM_in || !bM_in || !HM_out || !bM_out) return SDSO_ERR_ARG;
+  const int odim = nf * 8 + 4, ndim = odim - 8;
+  // step 1: move the frame's 8 rows / columns to the end (order of the others unchanged)
+  std::vector<int> ord;
+  for (int i = 0; i < odim; i++) if (i < idx * 8 + 4 || i >= idx * 8 + 12) ord.push_back(i);
+  for (int i = 0; i < 8; i++) ord.push_back(idx * 8 + 4 + i);
+  std::vector<double> H((size_t)odim * odim), b(odim);
+  for (int i = 0; i < odim; i++) { b[i] = bM_in[ord[i]]; for (int j = 0; j < odim; j++) H[(size_t)i * odim + j] = HM_in[(size_t)ord[i] * odim + ord[j]]; }
+  // step 2: the frame's prior
+  for (int i = 0; i < 8; i++) { H[(size_t)(ndim + i) * odim + ndim + i] += prior8[i]; b[ndim + i] += prior8[i] * delta_prior8[i]; }
+  // step 3: scale, invert the 8x8 corner, Schur complement, unscale
+  std::vector<double> S(odim), Si(odim);
+  for (int i = 0; i < odim; i++) { S[i] = std::sqrt(std::fabs(H[(size_t)i * odim + i]) + 10); Si[i] = 1.0 / S[i]; }
+  for (int i = 0; i < odim; i++) { b[i] = Si[i] * b[i]; for (int j = 0; j < odim; j++) H[(size_t)i * odim + j] = Si[i] * H[(size_t)i * odim + j] * Si[j]; }
+  double A[8][8], inv[8][8];
+  for (int i = 0; i < 8; i++) for (int j = 0; j < 8; j++) { const double v = H[(size_t)(ndim + i) * odim + ndim + j]; A[i][j] = 0.5f * (v + v); inv[i][j] = i == j; }
+  for (int k = 0; k < 8; k++) {   // Gauss-Jordan, partial pivoting (Eigen's fixed-size inverse() is PartialPivLU)
+    int pv = k;
+    for (int i = k + 1; i < 8; i++) if (std::fabs(A[i][k]) > std::fabs(A[pv][k])) pv = i;
+    if (pv != k) for (int j = 0; j < 8; j++) { std::swap(A[k][j], A[pv][j]); std::swap(inv[k][j], inv[pv][j]); }
+    const double d = A[k][k];
+    for (int j = 0; j < 8; j++) { A[k][j] /= d; inv[k][j] /= d; }
+    for (int i = 0; i < 8; i++) {
+      if (i == k) continue;
+      const double f = A[i][k];
+      if (f == 0) continue;
+      for (int j = 0; j < 8; j++) { A[i][j] -= f * A[k][j]; inv[i][j] -= f * inv[k][j]; }
+    }
+  }
+  for (int i = 0; i < 8; i++) for (int j = 0; j < 8; j++) inv[i][j] = 0.5f * (inv[i][j] + inv[i][j]);
+  std::vector<double> bli((size_t)ndim * 8);   // bottomLeft^T * hpi
+  for (int r = 0; r < ndim; r++)
+    for (int c = 0; c < 8; c++) { double s = 0; for (int k = 0; k < 8; k++) s += H[(size_t)(ndim + k) * odim + r] * inv[k][c]; bli[(size_t)r * 8 + c] = s; }
+  for (int r = 0; r < ndim; r++) {
+    for (int c = 0; c < ndim; c++) { double s = 0; for (int k = 0; k < 8; k++) s += bli[(size_t)r * 8 + k] * H[(size_t)(ndim + k) * odim + c]; H[(size_t)r * odim + c] -= s; }
+    double s = 0;
+    for (int k = 0; k < 8; k++) s += bli[(size_t)r * 8 + k] * b[ndim + k];
+    b[r] -= s;
+  }
+  for (int i = 0; i < odim; i++) { b[i] = S[i] * b[i]; for (int j = 0; j < odim; j++) H[(size_t)i * odim + j] = S[i] * H[(size_t)i * odim + j] * S[j]; }
+  for (int r = 0; r < ndim; r++) { bM_out[r] = b[r]; for (int c = 0; c < ndim; c++) HM_out[(size_t)r * ndim + c] = 0.5 * (H[(size_t)r * odim + c] + H[(size_t)c * odim + r]); }
+  return SDSO_OK;
+}

@@ -60,3 +60,35 @@ def test_make_eval_matches_oracle_bitwise(oracle):
         oracle.orc_track_make_eval(C.byref(prm), lvl, C.byref(T), C.byref(aff), 2.0, C.byref(b))
         assert bytes(a) == bytes(b)
         assert a.cutoffTH == 40.0 and a.w == 1232 >> lvl
+
+
+def test_marginalize_frame_host_algebra(oracle):
+    """EnergyFunctional::marginalizeFrame (EnergyFunctional.cpp:554-660) is ~70x70 double algebra that needs no GPU: the library
+    function against the oracle and against the textbook Schur complement of the re-ordered system."""
+    import numpy as np
+    from sdso_amd import abi
+    L = abi.load()
+    rs = np.random.RandomState(7)
+    for nf, idx in ((8, 0), (8, 3), (8, 7), (3, 1), (1, 0)):
+        n = 8 * nf + 4
+        A = rs.normal(0, 1, (n, 2 * n))
+        scale = 10.0 ** rs.uniform(0, 6, n)                       # entries spanning many decades, like the real prior
+        HM = (A @ A.T) * np.outer(scale, scale)
+        bM = rs.normal(0, 1, n) * scale
+        prior = np.where(rs.rand(8) < 0.5, 10.0 ** rs.uniform(2, 10, 8), 0.0)
+        dprior = rs.normal(0, 1e-2, 8)
+        m = n - 8
+        Ho, bo, Hg, bg = np.zeros((m, m)), np.zeros(m), np.zeros((m, m)), np.zeros(m)
+        assert oracle.orc_marginalize_frame(nf, idx, abi.dp(prior), abi.dp(dprior), abi.dp(HM), abi.dp(bM), abi.dp(Ho), abi.dp(bo)) == 0
+        assert L.sdso_ba_marginalize_frame(nf, idx, abi.dp(prior), abi.dp(dprior), abi.dp(HM), abi.dp(bM), abi.dp(Hg), abi.dp(bg)) == 0
+        d = np.sqrt(np.abs(np.diag(Ho))) + 1e-300
+        assert np.abs((Hg - Ho) / np.outer(d, d)).max() <= 1e-9 and np.abs((bg - bo) / d).max() <= 1e-9 * max(1.0, np.abs(bo / d).max())
+        keep = [i for i in range(n) if not (4 + 8 * idx <= i < 12 + 8 * idx)]
+        drop = list(range(4 + 8 * idx, 12 + 8 * idx))
+        D = HM[np.ix_(drop, drop)] + np.diag(prior)
+        B = HM[np.ix_(keep, drop)]
+        Href = HM[np.ix_(keep, keep)] - B @ np.linalg.solve(D, B.T)
+        bref = bM[keep] - B @ np.linalg.solve(D, bM[drop] + prior * dprior)
+        assert np.abs((Hg - Href) / np.outer(d, d)).max() <= 1e-6 and np.allclose(Hg, Hg.T)
+        assert np.abs((bg - bref) / d).max() <= 1e-6 * max(1.0, np.abs(bref / d).max())
+    assert L.sdso_ba_marginalize_frame(2, 5, abi.dp(prior), abi.dp(dprior), abi.dp(HM), abi.dp(bM), abi.dp(Hg), abi.dp(bg)) == -1
