@@ -402,7 +402,7 @@ static void launch_fused(sdso_ctx* ctx, const BaLaunch& L, bool materialize) {
 }
 static void launch_solve(sdso_ctx* ctx, const BaLaunch& L, double lambda, int orth) {
   const int nf = L.nf, n = L.n;
-  hipLaunchKernelGGL(k_ba_stitch, dim3(3 * (nf * nf + nf + 1), L.nwin), dim3(64), 0, ctx->stream, L.d_arr);
+  hipLaunchKernelGGL(k_ba_stitch, dim3(3 * (nf * nf + nf + 1), L.nwin), dim3(256), 0, ctx->stream, L.d_arr);
   const size_t lds = sizeof(double) * ((size_t)n * (n + 1) + 5 * n) + sizeof(int) * n;
   hipLaunchKernelGGL(k_ba_solve, dim3(1, L.nwin), dim3(BA_BLOCK), lds, ctx->stream, L.d_arr, lambda, orth);
   if (L.max_nblk_pts > 0) hipLaunchKernelGGL(k_ba_resub, dim3(L.max_nblk_pts, L.nwin), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr);
@@ -806,7 +806,7 @@ extern "C" int sdso_ba_marginalize_points(sdso_ctx* ctx, int win, const uint8_t*
   for (int p = 0; p < np; p++) if (marg_flag[p]) W->h_prior[p] *= 600.f * 600.f;   // setting_idepthFixPriorMargFac (:674)
   H2D(W->d.p_prior, W->h_prior.data(), sizeof(float) * np);
   launch_accumulate(ctx, L, W->d_pflag, true);
-  hipLaunchKernelGGL(k_ba_stitch, dim3(3 * (nf * nf + nf + 1), 1), dim3(64), 0, ctx->stream, L.d_arr);
+  hipLaunchKernelGGL(k_ba_stitch, dim3(3 * (nf * nf + nf + 1), 1), dim3(256), 0, ctx->stream, L.d_arr);
   SDSO_HIP(ctx, hipGetLastError());
   const size_t blk = (size_t)n * n + n;
   std::vector<double> MA(blk), MS(blk);

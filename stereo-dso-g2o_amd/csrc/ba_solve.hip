@@ -61,23 +61,33 @@ __device__ __forceinline__ double acc13(const float* __restrict__ p, int r, int 
 struct TileWork {
   double* Ls; double* Xs; double* Rs; double* Ts;  // 64 doubles each (LDS)
 };
+// LDS hand-off between the lanes of ONE wave (each wave of the stitch kernel owns its tile buffers)
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 __device__ __forceinline__ double lxr(const TileWork& W, int a, int c) {
   double t = 0;
 #pragma unroll
   for (int m = 0; m < 8; m++) t += W.Ls[a * 8 + m] * W.Xs[m * 8 + c];
   W.Ts[a * 8 + c] = t;
-  __syncthreads();
+  wave_sync();
   double o = 0;
 #pragma unroll
   for (int n = 0; n < 8; n++) o += W.Ts[a * 8 + n] * W.Rs[c * 8 + n];
-  __syncthreads();
+  wave_sync();
   return o;
 }
 
 // grid.x = 3 * (nf*nf + nf + 1) tiles: matrix m in {0: top A, 1: top L (with priors), 2: SC};
 // tile kinds: frame-frame (x,y) 8x8; frame-calib x: 8x4 + b(8); calib: 4x4 + b(4).
 // sol layout: [H_A n*n | b_A n | H_L n*n | b_L n | H_sc n*n | b_sc n | ...]
-__global__ __launch_bounds__(64) void k_ba_stitch(const BaDev* __restrict__ wins) {
+// A workgroup = 4 waves per output tile: the 8x8x8 triple products of a tile (up to nf^2 + 3nf of them for a diagonal
+// Schur tile) are dealt round-robin to the waves, each with its own LDS operands, and the four partial tiles are added
+// in wave order at the end (fixed order: reproducible).  Tile kinds without a product chain run on wave 0 alone.
+constexpr int ST_WAVES = 4;
+__global__ __launch_bounds__(64 * ST_WAVES) void k_ba_stitch(const BaDev* __restrict__ wins) {
   const BaDev& B = wins[blockIdx.y];
   const int nf = B.nf, nf2 = nf * nf, n = B.n;
   const int per = nf2 + nf + 1;
@@ -86,9 +96,21 @@ __global__ __launch_bounds__(64) void k_ba_stitch(const BaDev* __restrict__ wins
   if (m >= 3) return;
   double* H = B.sol + (size_t)m * ((size_t)n * n + n);
   double* bvec = H + (size_t)n * n;
-  const int lane = threadIdx.x, a = lane >> 3, c = lane & 7;
-  __shared__ double sL[64], sX[64], sR[64], sT[64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, a = lane >> 3, c = lane & 7;
+  __shared__ double sLb[ST_WAVES][64], sXb[ST_WAVES][64], sRb[ST_WAVES][64], sTb[ST_WAVES][64];
+  double* sL = sLb[wv]; double* sX = sXb[wv]; double* sR = sRb[wv]; double* sT = sTb[wv];
   TileWork W{sL, sX, sR, sT};
+  int turn = 0;
+  auto mine = [&]() { return ((turn++) % ST_WAVES) == wv; };
+  // sum of the waves' partial tiles, in wave order; returns the total on wave 0
+  auto fold = [&](double part) {
+    sTb[wv][lane] = part;
+    __syncthreads();
+    double s = sTb[0][lane];
+#pragma unroll
+    for (int w = 1; w < ST_WAVES; w++) s += sTb[w][lane];
+    return s;
+  };
   const double* adH = B.t_adHost;
   const double* adT = B.t_adTarget;
 
@@ -102,15 +124,18 @@ __global__ __launch_bounds__(64) void k_ba_stitch(const BaDev* __restrict__ wins
         sL[lane] = Lm[(size_t)aidx * 64 + lane];
         sR[lane] = Rm[(size_t)aidx * 64 + lane];
         sX[lane] = acc13(acc + (size_t)aidx * 91, 4 + a, 4 + c);
-        __syncthreads();
+        wave_sync();
         return lxr(W, a, c);
       };
       if (x == y) {
-        for (int t = 0; t < nf; t++) out += pairprod(x, t, adH, adH);   // H[h,h] += AH A AH^T
-        for (int h = 0; h < nf; h++) out += pairprod(h, x, adT, adT);   // H[t,t] += AT A AT^T
-        out += pairprod(x, x, adH, adT);                                // H[h,t] with h==t
+        for (int t = 0; t < nf; t++) if (mine()) out += pairprod(x, t, adH, adH);   // H[h,h] += AH A AH^T
+        for (int h = 0; h < nf; h++) if (mine()) out += pairprod(h, x, adT, adT);   // H[t,t] += AT A AT^T
+        if (mine()) out += pairprod(x, x, adH, adT);                                // H[h,t] with h==t
+        out = fold(out);
+        if (wv != 0) return;
         if (m == 1 && a == c) out += B.t_prior[x * 8 + a];
       } else {
+        if (wv != 0) return;
         // after the symmetrisation of AccumulatedTopHessian.h:133-147: for lo<hi
         //   H[lo,hi] = M(lo,hi) + M(hi,lo)^T ;  H[hi,lo] = H[lo,hi]^T,  M(h,t) = AH_ht A_ht AT_ht^T
         const int lo = x < y ? x : y, hi = x < y ? y : x;
@@ -118,16 +143,17 @@ __global__ __launch_bounds__(64) void k_ba_stitch(const BaDev* __restrict__ wins
         const double m2 = pairprod(hi, lo, adH, adT);   // element (a,c) of M(hi,lo)
         // need m1[a][c] + m2[c][a] for tile (lo,hi); transpose through LDS
         sT[a * 8 + c] = m2;
-        __syncthreads();
+        wave_sync();
         const double up = m1 + sT[c * 8 + a];           // (lo,hi)[a][c]
-        __syncthreads();
+        wave_sync();
         if (x < y) out = up;
-        else { sT[a * 8 + c] = up; __syncthreads(); out = sT[c * 8 + a]; __syncthreads(); }
+        else { sT[a * 8 + c] = up; wave_sync(); out = sT[c * 8 + a]; wave_sync(); }
       }
       H[(size_t)(4 + x * 8 + a) * n + (4 + y * 8 + c)] = out;
       return;
     }
     tile -= nf2;
+    if (wv != 0) return;
     if (tile < nf) {
       // frame-calib column block and b segment of frame x
       const int x = tile;
@@ -181,19 +207,21 @@ __global__ __launch_bounds__(64) void k_ba_stitch(const BaDev* __restrict__ wins
       sL[lane] = Lm[(size_t)(li + nf * lj) * 64 + lane];
       sR[lane] = Rm[(size_t)(ri + nf * rj) * 64 + lane];
       sX[lane] = (double)accD[(size_t)(di + nf * dj + nf2 * dk) * 64 + lane];
-      __syncthreads();
+      wave_sync();
       return lxr(W, a, c);
     };
     if (x == y)
       for (int j = 0; j < nf; j++)
-        for (int k = 0; k < nf; k++) out += prod(adH, x, j, x, j, k, adH, x, k);      // H[i,i] += AH_ij D_ijk AH_ik^T
-    for (int i = 0; i < nf; i++) out += prod(adT, i, x, i, x, y, adT, i, y);          // H[j,k] += AT_ij D_ijk AT_ik^T  (j=x,k=y)
-    for (int k = 0; k < nf; k++) out += prod(adT, y, x, y, x, k, adH, y, k);          // H[j,i] += AT_ij D_ijk AH_ik^T  (j=x,i=y)
-    for (int j = 0; j < nf; j++) out += prod(adH, x, j, x, j, y, adT, x, y);          // H[i,k] += AH_ij D_ijk AT_ik^T  (i=x,k=y)
-    H[(size_t)(4 + x * 8 + a) * n + (4 + y * 8 + c)] = out;
+        for (int k = 0; k < nf; k++) if (mine()) out += prod(adH, x, j, x, j, k, adH, x, k);      // H[i,i] += AH_ij D_ijk AH_ik^T
+    for (int i = 0; i < nf; i++) if (mine()) out += prod(adT, i, x, i, x, y, adT, i, y);          // H[j,k] += AT_ij D_ijk AT_ik^T  (j=x,k=y)
+    for (int k = 0; k < nf; k++) if (mine()) out += prod(adT, y, x, y, x, k, adH, y, k);          // H[j,i] += AT_ij D_ijk AH_ik^T  (j=x,i=y)
+    for (int j = 0; j < nf; j++) if (mine()) out += prod(adH, x, j, x, j, y, adT, x, y);          // H[i,k] += AH_ij D_ijk AT_ik^T  (i=x,k=y)
+    out = fold(out);
+    if (wv == 0) H[(size_t)(4 + x * 8 + a) * n + (4 + y * 8 + c)] = out;
     return;
   }
   tile -= nf2;
+  if (wv != 0) return;
   if (tile < nf) {
     const int x = tile;
     double hv = 0;
