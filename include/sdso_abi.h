@@ -331,6 +331,16 @@ int sdso_trace_stereo_prepare(sdso_ctx* ctx, int frame_slot, const float K[4], f
 int sdso_trace_stereo_enqueue(sdso_ctx* ctx);
 int sdso_trace_stereo_fetch(sdso_ctx* ctx, sdso_trace_points_t* pts, uint8_t* status);
 
+/* PixelSelector::makeMaps (src/FullSystem/PixelSelector2.cpp:193-300, with makeHists :84-189 and select :330-540): candidate
+ * pixels of the keyframe in `frame_slot` (needs pyramid levels 0..2; absSquaredGrad = dx*dx + dy*dy, identity response).
+ *   potential : PixelSelector::currentPotential, in/out (3 after construction)
+ *   map_out   : w*h floats, 0 / 1 / 2 / 4 = not selected / selected at level 0 / 1 / 2   (may be NULL)
+ *   num_out   : the value makeMaps returns (points left after the random thinning)
+ * The random pattern is glibc's rand() & 0xFF after srand(3141592) (:43-44), reproduced inside the library. */
+int sdso_pixel_select(sdso_ctx* ctx, int frame_slot, float density, int recursionsLeft, float thFactor,
+                      int* potential, float* map_out, int* num_out);
+int sdso_pixel_selector_pattern(int n, unsigned char* out); /* host only: first n pattern bytes */
+
 /* ImmaturePoint::traceOn (ImmaturePoint.cpp:459-828): the temporal epipolar search of every immature point of every host
  * keyframe in the newest frame (FullSystem::traceNewCoarseKey / NonKey, FullSystem.cpp:632-790).  geom[g] is the
  * hostToFrame geometry of host g (:654-665): KRKi = K R K^-1, Kt = K t, aff = AffLight::fromToVecExposure(...) as floats;

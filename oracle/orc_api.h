@@ -167,6 +167,11 @@ int orc_ba_get_tables(orc_ba* h, float* precalc, double* adHost, double* adTarge
 /* ---- static stereo */
 int orc_immature_init_batch(const float* dI, int w, int h, int n, const float* u, const float* v,
                             float* color, float* weights, float* gradH, float* energyTH);
+/* PixelSelector::makeMaps (PixelSelector2.cpp:193-300) with makeHists / select; dIp = levels 0..2 (AoS float3) */
+int orc_pixel_select(const float* const* dIp, int w, int h, float density, int recursionsLeft, float thFactor, int* potential,
+                     float* map_out);
+void orc_selector_random_pattern(int n, unsigned char* out);
+
 /* EnergyFunctional::marginalizeFrame (EnergyFunctional.cpp:554-660) */
 int orc_marginalize_frame(int nf, int idx, const double* prior8, const double* delta_prior8, const double* HM_in, const double* bM_in,
                           double* HM_out, double* bM_out);

@@ -25,10 +25,10 @@ int ensure_pinned(sdso_ctx* ctx, size_t bytes) {
 }  // namespace sdso
 
 // ------------------------------------------------------------------ kernels
-// AoS float3 {I,dx,dy} -> float4 {I,dx,dy,0}
+// AoS float3 {I,dx,dy} -> float4 {I,dx,dy,absSquaredGrad}  (absSquaredGrad = dx*dx+dy*dy, HessianBlocks.cpp:192)
 __global__ void k_expand3to4(const float* __restrict__ src, float4* __restrict__ dst, int npix) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < npix) dst[i] = make_float4(src[3 * i], src[3 * i + 1], src[3 * i + 2], 0.f);
+  if (i < npix) { const float dx = src[3 * i + 1], dy = src[3 * i + 2]; dst[i] = make_float4(src[3 * i], dx, dy, dx * dx + dy * dy); }
 }
 __global__ void k_pack4to3(const float4* __restrict__ src, float* __restrict__ dst, int npix) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -58,6 +58,7 @@ __global__ void k_gradients(float4* __restrict__ img, int wl, int hl) {
   if (!isfinite(dy)) dy = 0;
   img[idx].y = dx;
   img[idx].z = dy;
+  img[idx].w = dx * dx + dy * dy;   // absSquaredGrad (:192); the response-gradient weight of :194-198 is 1 for the identity response
 }
 
 // ------------------------------------------------------------------ API
@@ -82,6 +83,7 @@ void release_all_windows(sdso_ctx* ctx);
 void release_track_batch(sdso_ctx* ctx);
 void release_trace(sdso_ctx* ctx);
 void release_match(sdso_ctx* ctx);
+void release_selector(sdso_ctx* ctx);
 }
 
 extern "C" void sdso_ctx_destroy(sdso_ctx* ctx) {
@@ -96,6 +98,7 @@ extern "C" void sdso_ctx_destroy(sdso_ctx* ctx) {
   release_track_batch(ctx);
   release_trace(ctx);
   release_match(ctx);
+  release_selector(ctx);
   if (ctx->scratch) hipFree(ctx->scratch);
   if (ctx->pinned) hipHostFree(ctx->pinned);
   hipStreamDestroy(ctx->stream);

@@ -92,3 +92,16 @@ def test_marginalize_frame_host_algebra(oracle):
         assert np.abs((Hg - Href) / np.outer(d, d)).max() <= 1e-6 and np.allclose(Hg, Hg.T)
         assert np.abs((bg - bref) / d).max() <= 1e-6 * max(1.0, np.abs(bref / d).max())
     assert L.sdso_ba_marginalize_frame(2, 5, abi.dp(prior), abi.dp(dprior), abi.dp(HM), abi.dp(bM), abi.dp(Hg), abi.dp(bg)) == -1
+
+
+def test_selector_random_pattern_is_glibc_rand(oracle):
+    """PixelSelector's randomPattern is rand() & 0xFF after srand(3141592) (PixelSelector2.cpp:43-44).  The library carries its
+    own copy of glibc's generator (it must not reseed the process-wide one); the oracle calls srand/rand."""
+    import numpy as np
+    from sdso_amd import abi
+    L = abi.load()
+    n = 640 * 480
+    a = np.zeros(n, np.uint8); b = np.zeros(n, np.uint8)
+    oracle.orc_selector_random_pattern(n, abi.bp(a))
+    assert L.sdso_pixel_selector_pattern(n, abi.bp(b)) == 0
+    assert np.array_equal(a, b) and len(np.unique(a)) == 256
