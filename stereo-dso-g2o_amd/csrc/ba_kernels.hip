@@ -45,6 +45,7 @@ __host__ __device__ constexpr int jdev(int f) {
        : f < 66 ? 64 + (f - 62) : f < 70 ? 68 + (f - 66) : 72 + (f - 70);
 }
 #define JV(f) jl[jdev(f)]
+typedef float te_f4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------ linearize
 // STORE: write the RawResidualJacobian groups to HBM (PointFrameResidual::J);  KEEP 1: leave them in jl[76]
@@ -54,7 +55,7 @@ __host__ __device__ constexpr int jdev(int f) {
 #define SETQ(g, a, b, c, d)                                                              \
   do {                                                                                   \
     const float4 _q = make_float4(a, b, c, d);                                           \
-    if (STORE) JQ(J, S, i, g) = _q;                                                      \
+    if (STORE) __builtin_nontemporal_store((te_f4){_q.x, _q.y, _q.z, _q.w}, (te_f4*)&JQ(J, S, i, g)); /* streamed, not re-read this iteration */ \
     if (KEEP == 1 || (KEEP == 2 && ((g) < 6 || (g) > 15))) { jl[4 * (g)] = _q.x; jl[4 * (g) + 1] = _q.y; jl[4 * (g) + 2] = _q.z; jl[4 * (g) + 3] = _q.w; } \
   } while (0)
 template <bool STORE, int KEEP>
@@ -326,7 +327,6 @@ constexpr int TE_STRIDE = 68;
 constexpr int TE_ROWS = 26;
 constexpr int TE_WAVE_FLOATS = TE_ROWS * TE_STRIDE;
 constexpr int TE_LDS_FLOATS = (BA_BLOCK / 64) * TE_WAVE_FLOATS;
-typedef float te_f4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void top_emit(const BaDev& B, const float* x, const float* y, float a, float b, float c, float TR00, float TR10, float TR01,
                                          float TR11, float TR02, float TR12, const float* br, bool on, float* stage) {
