@@ -64,6 +64,7 @@ static void free_window(BaWindowDev* W) {
 struct BaLaunch {
   const BaDev* d_arr; int nwin; int max_nblk_res, max_nblk_pts, max_chunks, max_items, nf, n;
   bool any_lin;   // some window holds linearized residuals -> the mode-1 accumulation has work to do
+  bool tiled;     // the windows' t_img are 4x2-tiled level-0 images (same for every window of a launch)
 };
 struct BaBatch {
   std::vector<int> wins;
@@ -149,6 +150,7 @@ extern "C" int sdso_ba_upload_window(sdso_ctx* ctx, int win, const sdso_ba_windo
   SDSO_REQUIRE(ctx, (Win->solverMode & unsupported) == 0, "solverMode bit not supported on the device path (only the reference default FIX_LAMBDA|ORTHOGONALIZE_X_LATER family)");
   int rc = sdso_ba_release_window(ctx, win);
   if (rc) return rc;
+  const bool use_tiled = getenv("SDSO_BA_ROWMAJOR") == nullptr;   // 4x2-tiled level-0 images for the linearisation (default)
 
   BaWindowDev* W = new BaWindowDev();
   ctx->wins[win] = W;
@@ -177,7 +179,11 @@ extern "C" int sdso_ba_upload_window(sdso_ctx* ctx, int win, const sdso_ba_windo
     auto ip = ctx->pyr.find(F.frame_slot);
     SDSO_REQUIRE(ctx, ip != ctx->pyr.end(), "window references a frame slot without an uploaded pyramid");
     SDSO_REQUIRE(ctx, ip->second.w[0] == Win->w && ip->second.h[0] == Win->h, "pyramid level-0 size differs from the window's w/h");
-    imgs[f] = ip->second.d[0];
+    if (use_tiled) {
+      int rc = ensure_tiled0(ctx, ip->second);
+      if (rc) return rc;
+      imgs[f] = ip->second.tiled0;
+    } else imgs[f] = ip->second.d[0];
   }
   W->HM.assign((size_t)n * n, 0.0); W->bM.assign(n, 0.0);
   if (Win->HM) std::memcpy(W->HM.data(), Win->HM, sizeof(double) * n * n);
@@ -271,6 +277,7 @@ extern "C" int sdso_ba_upload_window(sdso_ctx* ctx, int win, const sdso_ba_windo
   d.p_geo = p_geo; d.p_color = p_color; d.p_weights = p_weights; d.p_host = p_host; d.p_prior = p_prior; d.p_delta = p_delta;
   d.p_rbeg = p_rbeg; d.p_rcnt = p_rcnt; d.p_rlist = p_rlist; d.p_out = p_out;
   d.r_point = r_point; d.r_orig = r_orig; d.r_host = r_host; d.r_target = r_target;
+  d.tiledT = use_tiled ? (Win->w + 3) / 4 : 0;
   d.t_precalc = W->dt_precalc; d.t_adHTdelta = W->dt_adHTdelta; d.t_cdelta = W->dt_cdelta; d.t_frameTH = W->dt_frameTH; d.t_img = d_img;
   d.t_adHost = W->dt_adHost; d.t_adTarget = W->dt_adTarget; d.t_xAd = W->dt_xAd; d.t_prior = W->dt_prior; d.t_HM = W->dt_HM; d.t_bM = W->dt_bM; d.t_P = W->dt_P;
   d.chunks = d_chunks; d.pair_chunk_beg = d_pair_beg; d.items = d_items; d.host_item_beg = d_host_beg;
@@ -335,7 +342,8 @@ extern "C" int sdso_ba_keep_projections(sdso_ctx* ctx, int win, int on) {
 namespace sdso {
 static void launch_linearize(sdso_ctx* ctx, const BaLaunch& L) {
   ProfScope ps(ctx, "k_ba_linearize");
-  hipLaunchKernelGGL(k_ba_linearize, dim3(L.max_nblk_res, L.nwin), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr);
+  if (L.tiled) hipLaunchKernelGGL(k_ba_linearize<true>, dim3(L.max_nblk_res, L.nwin), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr);
+  else hipLaunchKernelGGL(k_ba_linearize<false>, dim3(L.max_nblk_res, L.nwin), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr);
 }
 static void launch_apply(sdso_ctx* ctx, const BaLaunch& L) {
   hipLaunchKernelGGL(k_ba_apply, dim3(L.max_nblk_res, L.nwin), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr);
@@ -387,8 +395,9 @@ static void launch_fused(sdso_ctx* ctx, const BaLaunch& L, bool materialize) {
   if (L.max_chunks > 0) {
     {
       ProfScope ps(ctx, "k_ba_lin_fused");
-      if (materialize) hipLaunchKernelGGL(k_ba_lin_fused<true>, dim3(L.max_chunks, L.nwin), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr);
-      else hipLaunchKernelGGL(k_ba_lin_fused<false>, dim3(L.max_chunks, L.nwin), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr);
+      const dim3 g(L.max_chunks, L.nwin), b(BA_BLOCK);
+      if (materialize) { if (L.tiled) hipLaunchKernelGGL((k_ba_lin_fused<true, true>), g, b, 0, ctx->stream, L.d_arr); else hipLaunchKernelGGL((k_ba_lin_fused<true, false>), g, b, 0, ctx->stream, L.d_arr); }
+      else { if (L.tiled) hipLaunchKernelGGL((k_ba_lin_fused<false, true>), g, b, 0, ctx->stream, L.d_arr); else hipLaunchKernelGGL((k_ba_lin_fused<false, false>), g, b, 0, ctx->stream, L.d_arr); }
     }
     hipLaunchKernelGGL(k_ba_fold_top, dim3(nf * nf, L.nwin), dim3(128), 0, ctx->stream, L.d_arr, 0);
     if (L.any_lin) {
@@ -412,6 +421,7 @@ static BaLaunch single(BaWindowDev* W) {
   L.d_arr = W->d_self; L.nwin = 1; L.max_nblk_res = std::max(W->nblk_res, 1); L.max_nblk_pts = W->nblk_pts;
   L.max_chunks = W->d.nchunks; L.max_items = W->d.nitems; L.nf = W->d.nf; L.n = W->d.n;
   L.any_lin = std::any_of(W->h_lin.begin(), W->h_lin.end(), [](uint8_t v) { return v != 0; });
+  L.tiled = W->d.tiledT > 0;
   return L;
 }
 
@@ -799,7 +809,8 @@ extern "C" int sdso_ba_marginalize_points(sdso_ctx* ctx, int win, const uint8_t*
   BaLaunch L = single(W);
   H2D(W->d_pflag, marg_flag, np);
   hipLaunchKernelGGL(k_ba_reset_flagged, dim3(L.max_nblk_res, 1), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr, W->d_pflag);
-  hipLaunchKernelGGL(k_ba_linearize, dim3(L.max_nblk_res, 1), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr);
+  if (L.tiled) hipLaunchKernelGGL(k_ba_linearize<true>, dim3(L.max_nblk_res, 1), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr);
+  else hipLaunchKernelGGL(k_ba_linearize<false>, dim3(L.max_nblk_res, 1), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr);
   launch_apply(ctx, L);
   hipLaunchKernelGGL(k_ba_unmask, dim3(L.max_nblk_res, 1), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr);
   hipLaunchKernelGGL(k_ba_fixlin, dim3(L.max_nblk_res, 1), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr, W->d_pflag);
@@ -847,10 +858,11 @@ extern "C" int sdso_ba_batch_create(sdso_ctx* ctx, int nwin, const int* wins) {
   SDSO_HIP(ctx, hipMemsetAsync(Bt->d_accum, 0, sizeof(float) * af * nwin, ctx->stream));
   std::vector<BaDev> h(nwin);
   BaLaunch L{};
-  L.nwin = nwin; L.nf = nf; L.n = W0->d.n;
+  L.nwin = nwin; L.nf = nf; L.n = W0->d.n; L.tiled = W0->d.tiledT > 0;
   for (int i = 0; i < nwin; i++) {
     BaWindowDev* W = find_win(ctx, wins[i]);
     SDSO_REQUIRE(ctx, W && W->d.nf == nf, "batch windows must exist and share nf");
+    SDSO_REQUIRE(ctx, (W->d.tiledT > 0) == L.tiled, "batch windows must share the image layout");
     W->d.accum = Bt->d_accum + af * i;   // contiguous accumulators: ONE all-reduce covers the batch
     W->own_accum = false;
     h[i] = W->d;

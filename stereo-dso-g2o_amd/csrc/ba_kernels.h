@@ -28,6 +28,7 @@ constexpr int RR_BD = 8, RR_HDD = 9, RR_HCD = 10, RR_FLAGS = 14, RR_TARGET = 15;
 
 struct BaDev {
   int nf, np, nr, nrp, w, h, nchunks, nitems, n;
+  int tiledT;               // > 0: t_img are 4x2-tiled level-0 images with tiledT tiles per row; 0: row-major
   float wM3, hM3, fxl, fyl, cxl, cyl, fxli, fyli;
   int affA_fixed, affB_fixed;
   // points

@@ -61,6 +61,22 @@ __global__ void k_gradients(float4* __restrict__ img, int wl, int hl) {
   img[idx].w = dx * dx + dy * dy;   // absSquaredGrad (:192); the response-gradient weight of :194-198 is 1 for the identity response
 }
 
+__global__ void k_tile0(const float4* __restrict__ src, float4* __restrict__ dst, int w, int h, int T) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x < w && y < h) dst[tiled_index(x, y, T)] = src[x + y * w];
+}
+namespace sdso {
+int ensure_tiled0(sdso_ctx* ctx, PyramidDev& P) {
+  if (P.tiled_ok) return SDSO_OK;
+  const int w = P.w[0], h = P.h[0], T = (w + 3) / 4, Th = (h + 1) / 2;
+  if (!P.tiled0) SDSO_HIP(ctx, hipMalloc(&P.tiled0, sizeof(float4) * 8 * (size_t)T * Th));
+  hipLaunchKernelGGL(k_tile0, dim3((w + 255) / 256, h), dim3(256), 0, ctx->stream, (const float4*)P.d[0], P.tiled0, w, h, T);
+  SDSO_HIP(ctx, hipGetLastError());
+  P.tiled_ok = true;
+  return SDSO_OK;
+}
+}  // namespace sdso
+
 // ------------------------------------------------------------------ API
 extern "C" int sdso_ctx_create(int device_ordinal, sdso_ctx** out) {
   if (!out) return SDSO_ERR_ARG;
@@ -154,6 +170,7 @@ extern "C" int sdso_release_pyramid(sdso_ctx* ctx, int frame_slot) {
   if (it == ctx->pyr.end()) return SDSO_OK;
   SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
   for (int l = 0; l < it->second.levels; l++) hipFree(it->second.d[l]);
+  if (it->second.tiled0) hipFree(it->second.tiled0);
   ctx->pyr.erase(it);
   return SDSO_OK;
 }
@@ -164,7 +181,7 @@ static int alloc_pyramid(sdso_ctx* ctx, int frame_slot, int levels, const int* w
   if (it != ctx->pyr.end()) {
     bool same = it->second.levels == levels;
     for (int l = 0; same && l < levels; l++) same = it->second.w[l] == w[l] && it->second.h[l] == h[l];
-    if (same) return SDSO_OK;
+    if (same) { it->second.tiled_ok = false; return SDSO_OK; }   // new content arrives in the same buffers
     int rc = sdso_release_pyramid(ctx, frame_slot);
     if (rc) return rc;
   }

@@ -26,6 +26,9 @@ struct PyramidDev {
   int levels = 0;
   int w[SDSO_PYR_LEVELS] = {0}, h[SDSO_PYR_LEVELS] = {0};
   float4* d[SDSO_PYR_LEVELS] = {nullptr};
+  // level 0 once more in 4x2-pixel tiles (one 128-B line per tile) for the BA linearisation, built on first use
+  float4* tiled0 = nullptr;
+  bool tiled_ok = false;
 };
 // pc_* of one reference keyframe: one float4 {u, v, idepth, color} per template point.
 struct RefDev {
@@ -100,6 +103,9 @@ struct ProfScope {
   }
 };
 int ensure_pinned(sdso_ctx* ctx, size_t bytes);
+int ensure_tiled0(sdso_ctx* ctx, PyramidDev& P);   // ctx.hip
+// pixel (x, y) of a 4x2-tiled level-0 image with T tiles per row
+__host__ __device__ inline int tiled_index(int x, int y, int T) { return (((y >> 1) * T + (x >> 2)) << 3) + ((y & 1) << 2) + (x & 3); }
 
 // ------------------------------------------------------------------ device helpers
 // getInterpolatedElement33 (src/util/globalFuncs.h:73-86) on the float4 image.
