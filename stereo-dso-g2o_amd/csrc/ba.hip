@@ -348,7 +348,7 @@ static void launch_linearize(sdso_ctx* ctx, const BaLaunch& L) {
 static void launch_apply(sdso_ctx* ctx, const BaLaunch& L) {
   hipLaunchKernelGGL(k_ba_apply, dim3(L.max_nblk_res, L.nwin), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr);
 }
-static void launch_sc_and_folds(sdso_ctx* ctx, const BaLaunch& L, const uint8_t* pflag, bool marg);
+static void launch_sc_and_folds(sdso_ctx* ctx, const BaLaunch& L, const uint8_t* pflag, bool marg, bool fold_top_too = false);
 static void launch_accumulate(sdso_ctx* ctx, const BaLaunch& L, const uint8_t* pflag, bool marg) {
   const int nf = L.nf;
   if (L.max_chunks > 0) {
@@ -369,7 +369,7 @@ static void launch_accumulate(sdso_ctx* ctx, const BaLaunch& L, const uint8_t* p
   }
   launch_sc_and_folds(ctx, L, pflag, marg);
 }
-static void launch_sc_and_folds(sdso_ctx* ctx, const BaLaunch& L, const uint8_t* pflag, bool marg) {
+static void launch_sc_and_folds(sdso_ctx* ctx, const BaLaunch& L, const uint8_t* pflag, bool marg, bool fold_top_too) {
   const int nf = L.nf;
   if (L.max_items > 0) {
     ProfScope ps(ctx, "k_ba_sc");
@@ -387,7 +387,8 @@ static void launch_sc_and_folds(sdso_ctx* ctx, const BaLaunch& L, const uint8_t*
       }
     }
   }
-  hipLaunchKernelGGL(k_ba_fold_sc, dim3(nf * nf * nf + nf * nf + 1, L.nwin), dim3(64), 0, ctx->stream, L.d_arr);
+  if (fold_top_too) hipLaunchKernelGGL(k_ba_fold_all, dim3(nf * nf * nf + 3 * nf * nf + 1, L.nwin), dim3(128), 0, ctx->stream, L.d_arr);
+  else hipLaunchKernelGGL(k_ba_fold_sc, dim3(nf * nf * nf + nf * nf + 1, L.nwin), dim3(64), 0, ctx->stream, L.d_arr);
 }
 // linearizeAll + applyRes + accumulateAF in one kernel, then the (normally empty) linearized pass and the Schur part
 static void launch_fused(sdso_ctx* ctx, const BaLaunch& L, bool materialize) {
@@ -399,15 +400,14 @@ static void launch_fused(sdso_ctx* ctx, const BaLaunch& L, bool materialize) {
       if (materialize) { if (L.tiled) hipLaunchKernelGGL((k_ba_lin_fused<true, true>), g, b, 0, ctx->stream, L.d_arr); else hipLaunchKernelGGL((k_ba_lin_fused<true, false>), g, b, 0, ctx->stream, L.d_arr); }
       else { if (L.tiled) hipLaunchKernelGGL((k_ba_lin_fused<false, true>), g, b, 0, ctx->stream, L.d_arr); else hipLaunchKernelGGL((k_ba_lin_fused<false, false>), g, b, 0, ctx->stream, L.d_arr); }
     }
-    hipLaunchKernelGGL(k_ba_fold_top, dim3(nf * nf, L.nwin), dim3(128), 0, ctx->stream, L.d_arr, 0);
     if (L.any_lin) {
+      hipLaunchKernelGGL(k_ba_fold_top, dim3(nf * nf, L.nwin), dim3(128), 0, ctx->stream, L.d_arr, 0);
       hipLaunchKernelGGL(k_ba_accum_top, dim3(L.max_chunks, L.nwin), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr, 1, (const uint8_t*)nullptr);
       hipLaunchKernelGGL(k_ba_fold_top, dim3(nf * nf, L.nwin), dim3(128), 0, ctx->stream, L.d_arr, 1);
-    } else {
-      hipLaunchKernelGGL(k_ba_zero_topL, dim3(nf * nf, L.nwin), dim3(128), 0, ctx->stream, L.d_arr);
     }
   }
-  launch_sc_and_folds(ctx, L, nullptr, false);
+  // without linearized residuals the top partials are folded together with the Schur partials, after the Schur kernel
+  launch_sc_and_folds(ctx, L, nullptr, false, L.max_chunks > 0 && !L.any_lin);
 }
 static void launch_solve(sdso_ctx* ctx, const BaLaunch& L, double lambda, int orth) {
   const int nf = L.nf, n = L.n;

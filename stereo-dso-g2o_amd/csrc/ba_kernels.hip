@@ -609,32 +609,29 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_lenergy(const BaDev* __restrict
   if (threadIdx.x == 0) { float s = 0; for (int w = 0; w < BA_BLOCK / 64; w++) s += red[w]; out[blockIdx.x] = s; }
 }
 
-// fold chunk partials per pair (fixed order) into the packed accumulator; grid.x = nf*nf
-__global__ __launch_bounds__(128) void k_ba_fold_top(const BaDev* __restrict__ wins, int which /*0 = A, 1 = L*/) {
-  const BaDev& B = wins[blockIdx.y];
-  const int pair = blockIdx.x;
+// fold chunk partials per pair (fixed order) into the packed accumulator; one 128-thread workgroup per pair
+__device__ __forceinline__ void fold_top_body(const BaDev& B, int pair, int which /*0 = A, 1 = L*/, int tid) {
   if (pair >= B.nf * B.nf) return;
   const int cb = B.pair_chunk_beg[pair], ce = B.pair_chunk_beg[pair + 1];
   float* out = B.accum + (which ? acc_off_topL(B.nf) : acc_off_topA(B.nf)) + (size_t)pair * 91;
-  if (threadIdx.x < 91) {
+  if (tid < 91) {
     float s = 0;
-    for (int ck = cb; ck < ce; ck++) s += B.top_part[(size_t)ck * 92 + threadIdx.x];
-    out[threadIdx.x] = s;
+    for (int ck = cb; ck < ce; ck++) s += B.top_part[(size_t)ck * 92 + tid];
+    out[tid] = s;
   }
-  if (pair == 0 && threadIdx.x == 127) {
+  if (pair == 0 && tid == 127) {
     float s = 0;
     for (int ck = 0; ck < B.nchunks; ck++) s += B.top_part[(size_t)ck * 92 + 91];
     B.accum[acc_off_nres(B.nf) + which] = s;
   }
 }
-
-__global__ __launch_bounds__(128) void k_ba_zero_topL(const BaDev* __restrict__ wins) {
-  const BaDev& B = wins[blockIdx.y];
-  const int pair = blockIdx.x;
+__device__ __forceinline__ void zero_topL_body(const BaDev& B, int pair, int tid) {
   if (pair >= B.nf * B.nf) return;
-  if (threadIdx.x < 91) B.accum[acc_off_topL(B.nf) + (size_t)pair * 91 + threadIdx.x] = 0.f;
-  if (pair == 0 && threadIdx.x == 127) B.accum[acc_off_nres(B.nf) + 1] = 0.f;
+  if (tid < 91) B.accum[acc_off_topL(B.nf) + (size_t)pair * 91 + tid] = 0.f;
+  if (pair == 0 && tid == 127) B.accum[acc_off_nres(B.nf) + 1] = 0.f;
 }
+__global__ __launch_bounds__(128) void k_ba_fold_top(const BaDev* __restrict__ wins, int which) { fold_top_body(wins[blockIdx.y], blockIdx.x, which, threadIdx.x); }
+__global__ __launch_bounds__(128) void k_ba_zero_topL(const BaDev* __restrict__ wins) { zero_topL_body(wins[blockIdx.y], blockIdx.x, threadIdx.x); }
 
 // ------------------------------------------------------------------ per-point Schur accumulation
 // AccumulatedSCHessianSSE::addPoint for nf <= 8 (template NF).  One wave per item (<= 64 consecutive

@@ -13,12 +13,9 @@ namespace sdso {
 
 // ------------------------------------------------------------------ fold of the Schur partials
 // grid.x = nf^3 (D bins, 64 threads each) + nf^2 (E/EB per pair) + 1 (Hcc, bc)
-__global__ __launch_bounds__(64) void k_ba_fold_sc(const BaDev* __restrict__ wins) {
-  const BaDev& B = wins[blockIdx.y];
+__device__ __forceinline__ void fold_sc_body(const BaDev& B, int b, int lane) {
   const int nf = B.nf, nf2 = nf * nf, nf3 = nf2 * nf;
   const int pf = sc_part_floats(nf);
-  const int lane = threadIdx.x;
-  int b = blockIdx.x;
   if (b < nf3) {
     // accD[h + t1*nf + t2*nf^2] <- items of host h, tile (t1,t2)
     const int h = b % nf, t1 = (b / nf) % nf, t2 = b / nf2;
@@ -45,6 +42,18 @@ __global__ __launch_bounds__(64) void k_ba_fold_sc(const BaDev* __restrict__ win
     for (int it = 0; it < B.nitems; it++) s += B.sc_part[(size_t)it * pf + off];
     B.accum[acc_off_Hcc(nf) + lane] = s;  // Hcc 16 then bc 4 are contiguous
   }
+}
+
+__global__ __launch_bounds__(64) void k_ba_fold_sc(const BaDev* __restrict__ wins) { fold_sc_body(wins[blockIdx.y], blockIdx.x, threadIdx.x); }
+// every fold of one accumulate phase in ONE launch (the usual case: no linearized residuals, topL is just cleared):
+// grid.x = [nf^3 + nf^2 + 1 Schur bins | nf^2 top-A pairs | nf^2 top-L pairs], 128 threads
+__global__ __launch_bounds__(128) void k_ba_fold_all(const BaDev* __restrict__ wins) {
+  const BaDev& B = wins[blockIdx.y];
+  const int nf = B.nf, nf2 = nf * nf, nsc = nf2 * nf + nf2 + 1;
+  const int b = blockIdx.x;
+  if (b < nsc) { if (threadIdx.x < 64) fold_sc_body(B, b, threadIdx.x); }
+  else if (b < nsc + nf2) fold_top_body(B, b - nsc, 0, threadIdx.x);
+  else zero_topL_body(B, b - nsc - nf2, threadIdx.x);
 }
 
 // ------------------------------------------------------------------ stitch
