@@ -274,3 +274,78 @@ def test_batch_equals_single(gpu_ctx, oracle, win_small):
     gpu_ctx.check(gpu_ctx.L.sdso_ba_batch_get_x(gpu_ctx.h, abi.dp(xb)))
     for i in range(2):
         assert np.array_equal(xb[i], xs[i])             # deterministic kernels: identical bits
+
+
+def test_ragged_and_degenerate_windows(gpu_ctx, oracle):
+    """Edge cases of the window shape: two keyframes only, hosts without points, points without residuals, residual lists of very
+    different length in one batch launch.  Everything must agree with the oracle (x in the whitened metric) and nothing may fault."""
+    cases = []
+    w2 = synth.ba_window(w=320, h=240, nf=2, pts_per_kf=40, seed=3071)                       # minimum window
+    cases.append(("nf2", w2))
+    w3 = dict(synth.ba_window(w=320, h=240, nf=4, pts_per_kf=30, seed=3072))
+    keep_pts = w3["host"] != 1                                                                # a keyframe that hosts no point
+    idx = np.nonzero(keep_pts)[0]
+    remap = -np.ones(w3["np"], np.int64); remap[idx] = np.arange(len(idx))
+    rk = keep_pts[w3["res_point"]]
+    for k in ("u", "v", "idepth", "idepth_zero", "color", "weights", "host", "hasDepthPrior"):
+        w3[k] = w3[k][idx]
+    w3["res_point"] = remap[w3["res_point"][rk]].astype(np.int32); w3["res_target"] = w3["res_target"][rk]; w3["res_state"] = w3["res_state"][rk]
+    w3["np"], w3["nr"] = len(idx), int(rk.sum())
+    cases.append(("empty_host", w3))
+    w4 = dict(synth.ba_window(w=320, h=240, nf=4, pts_per_kf=30, seed=3073))
+    drop = np.isin(w4["res_point"], np.arange(0, w4["np"], 3))                                # every third point loses all its residuals
+    w4["res_point"] = w4["res_point"][~drop]; w4["res_target"] = w4["res_target"][~drop]; w4["res_state"] = w4["res_state"][~drop]
+    w4["nr"] = int((~drop).sum())
+    cases.append(("points_without_residuals", w4))
+    xs = {}
+    for i, (name, win) in enumerate(cases):
+        nf, n = win["nf"], 8 * win["nf"] + 4
+        for f in range(nf):
+            gpu_ctx.upload_pyramid(200 + 10 * i + f, win["pyrs"][f][:1])
+        W, keep = abi.make_ba_window(win, frame_slots=[200 + 10 * i + f for f in range(nf)], dI_list=[p[0] for p in win["pyrs"]])
+        gpu_ctx.check(gpu_ctx.L.sdso_ba_upload_window(gpu_ctx.h, 20 + i, C.byref(W)))
+        h = oracle.orc_ba_create(C.byref(W))
+        oracle.orc_ba_linearize(h, None); oracle.orc_ba_apply_res(h); oracle.orc_ba_accumulate(h)
+        xo, Ho = np.zeros(n), np.zeros((n, n))
+        oracle.orc_ba_solve(h, 0, 0.1, abi.dp(xo), abi.dp(Ho), None, None, None)
+        oracle.orc_ba_destroy(h)
+        gpu_ctx.check(gpu_ctx.L.sdso_ba_linearize(gpu_ctx.h, 20 + i, None))
+        gpu_ctx.check(gpu_ctx.L.sdso_ba_apply_res(gpu_ctx.h, 20 + i))
+        gpu_ctx.check(gpu_ctx.L.sdso_ba_accumulate(gpu_ctx.h, 20 + i))
+        xg = np.zeros(n)
+        gpu_ctx.check(gpu_ctx.L.sdso_ba_solve(gpu_ctx.h, 20 + i, 0, 0.1, abi.dp(xg), None, None, None, None))
+        d = np.sqrt(np.abs(np.diag(Ho))) + 1e-30
+        assert np.abs((xg - xo) * d).max() <= 2e-4 * max(1.0, np.abs(xo * d).max()), name
+        xs[name] = xg
+    # the two nf = 4 windows (different point / residual counts) in ONE batch launch give the same x as alone
+    ids = np.array([21, 22], np.int32)
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_upload_window(gpu_ctx.h, 21, C.byref(abi.make_ba_window(cases[1][1], frame_slots=[210 + f for f in range(4)])[0])))
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_upload_window(gpu_ctx.h, 22, C.byref(abi.make_ba_window(cases[2][1], frame_slots=[220 + f for f in range(4)])[0])))
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_batch_create(gpu_ctx.h, 2, abi.ip(ids)))
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_batch_accumulate(gpu_ctx.h))
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_batch_solve(gpu_ctx.h, 1e-5, 0))      # sdso_ba_solve applies SOLVER_FIX_LAMBDA (lambda := 1e-5) itself
+    xb = np.zeros((2, 36))
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_batch_get_x(gpu_ctx.h, abi.dp(xb)))
+    for k, name in enumerate(("empty_host", "points_without_residuals")):
+        dd = np.abs(xb[k] - xs[name]).max()
+        assert dd <= 1e-9 * max(1.0, np.abs(xs[name]).max()), (name, dd)
+    # a window with no points at all is accepted and solves to the prior-only system
+    w0 = dict(cases[0][1])
+    for k in ("u", "v", "idepth", "idepth_zero", "host", "hasDepthPrior"):
+        w0[k] = w0[k][:0]
+    w0["color"] = w0["color"][:0]; w0["weights"] = w0["weights"][:0]
+    w0["res_point"] = w0["res_point"][:0]; w0["res_target"] = w0["res_target"][:0]; w0["res_state"] = w0["res_state"][:0]
+    w0["np"] = w0["nr"] = 0
+    W0, k0 = abi.make_ba_window(w0, frame_slots=[200, 201], dI_list=[p[0] for p in w0["pyrs"]])
+    h0 = oracle.orc_ba_create(C.byref(W0))
+    oracle.orc_ba_linearize(h0, None); oracle.orc_ba_apply_res(h0); oracle.orc_ba_accumulate(h0)
+    xo0 = np.zeros(20)
+    oracle.orc_ba_solve(h0, 0, 0.1, abi.dp(xo0), None, None, None, None)
+    oracle.orc_ba_destroy(h0)
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_upload_window(gpu_ctx.h, 25, C.byref(W0)))
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_linearize(gpu_ctx.h, 25, None))
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_apply_res(gpu_ctx.h, 25))
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_accumulate(gpu_ctx.h, 25))
+    x0 = np.ones(20)
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_solve(gpu_ctx.h, 25, 0, 0.1, abi.dp(x0), None, None, None, None))
+    assert np.isfinite(x0).all() and np.allclose(x0, xo0, rtol=1e-9, atol=1e-12)     # priors only: pure double algebra on both sides
