@@ -73,3 +73,37 @@ def test_two_rank_sharded_solve_matches_single(gpu_ctx, tmp_path):
     assert np.abs((xs[0] - x) * d).max() <= 2e-4 * max(1.0, np.abs(x * d).max())
     steps = np.concatenate([np.load(tmp_path / ("step_%d.npy" % r)) for r in range(world)])
     assert np.abs(steps - step).max() <= 2e-4 * max(np.abs(step).max(), 1e-6)
+
+
+@pytest.mark.gpu
+def test_accumulator_block_is_aliased_by_torch(gpu_ctx):
+    """bench.py all-reduces the packed accumulators IN PLACE through a torch tensor built on the library's device pointer
+    (__cuda_array_interface__) on the ctx stream.  The tensor must alias the block, not copy it."""
+    import torch
+    from sdso_amd import abi, synth
+    win = synth.ba_window(w=320, h=240, nf=4, pts_per_kf=40, seed=3091)
+    nf = win["nf"]
+    for f in range(nf):
+        gpu_ctx.upload_pyramid(300 + f, win["pyrs"][f][:1])
+    W, keep = abi.make_ba_window(win, frame_slots=[300 + f for f in range(nf)])
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_upload_window(gpu_ctx.h, 30, C.byref(W)))
+    ids = np.array([30], np.int32)
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_batch_create(gpu_ctx.h, 1, abi.ip(ids)))
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_batch_accumulate(gpu_ctx.h))
+    ptr, nfl = C.c_void_p(), C.c_long(0)
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_batch_accum_dev(gpu_ctx.h, C.byref(ptr), C.byref(nfl)))
+    assert nfl.value == abi.accum_floats(nf)
+
+    class Blob:
+        __cuda_array_interface__ = {"shape": (nfl.value,), "typestr": "<f4", "data": (ptr.value, False), "version": 3}
+    t = torch.as_tensor(Blob(), device="cuda")
+    assert t.data_ptr() == ptr.value                                   # same memory
+    stream = torch.cuda.ExternalStream(gpu_ctx.L.sdso_ctx_stream(gpu_ctx.h))
+    before = np.zeros(nfl.value, np.float32)
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_get_accumulators(gpu_ctx.h, 30, abi.fp(before)))
+    assert np.abs(before).max() > 0
+    with torch.cuda.stream(stream):
+        t.mul_(2.0)                                                    # stands in for the all-reduce of two equal shards
+    after = np.zeros(nfl.value, np.float32)
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_get_accumulators(gpu_ctx.h, 30, abi.fp(after)))   # ctx stream: ordered after the torch op
+    assert np.array_equal(after, 2.0 * before)
