@@ -65,7 +65,20 @@ __global__ void k_tile0(const float4* __restrict__ src, float4* __restrict__ dst
   const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
   if (x < w && y < h) dst[tiled_index(x, y, T)] = src[x + y * w];
 }
+__global__ void k_plane0(const float4* __restrict__ src, float* __restrict__ dst, int npix) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < npix) dst[i] = src[i].x;
+}
 namespace sdso {
+int ensure_plane0(sdso_ctx* ctx, PyramidDev& P) {
+  if (P.plane_ok) return SDSO_OK;
+  const int npix = P.w[0] * P.h[0];
+  if (!P.plane0) SDSO_HIP(ctx, hipMalloc(&P.plane0, sizeof(float) * (size_t)npix));
+  hipLaunchKernelGGL(k_plane0, dim3((npix + 255) / 256), dim3(256), 0, ctx->stream, (const float4*)P.d[0], P.plane0, npix);
+  SDSO_HIP(ctx, hipGetLastError());
+  P.plane_ok = true;
+  return SDSO_OK;
+}
 int ensure_tiled0(sdso_ctx* ctx, PyramidDev& P) {
   if (P.tiled_ok) return SDSO_OK;
   const int w = P.w[0], h = P.h[0], T = (w + 3) / 4, Th = (h + 1) / 2;
@@ -171,6 +184,7 @@ extern "C" int sdso_release_pyramid(sdso_ctx* ctx, int frame_slot) {
   SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
   for (int l = 0; l < it->second.levels; l++) hipFree(it->second.d[l]);
   if (it->second.tiled0) hipFree(it->second.tiled0);
+  if (it->second.plane0) hipFree(it->second.plane0);
   ctx->pyr.erase(it);
   return SDSO_OK;
 }
@@ -181,7 +195,7 @@ static int alloc_pyramid(sdso_ctx* ctx, int frame_slot, int levels, const int* w
   if (it != ctx->pyr.end()) {
     bool same = it->second.levels == levels;
     for (int l = 0; same && l < levels; l++) same = it->second.w[l] == w[l] && it->second.h[l] == h[l];
-    if (same) { it->second.tiled_ok = false; return SDSO_OK; }   // new content arrives in the same buffers
+    if (same) { it->second.tiled_ok = false; it->second.plane_ok = false; return SDSO_OK; }   // new content arrives in the same buffers
     int rc = sdso_release_pyramid(ctx, frame_slot);
     if (rc) return rc;
   }

@@ -29,6 +29,9 @@ struct PyramidDev {
   // level 0 once more in 4x2-pixel tiles (one 128-B line per tile) for the BA linearisation, built on first use
   float4* tiled0 = nullptr;
   bool tiled_ok = false;
+  // level-0 intensities alone (4 B per pixel) for the discrete epipolar search, which samples I only; built on first use
+  float* plane0 = nullptr;
+  bool plane_ok = false;
 };
 // pc_* of one reference keyframe: one float4 {u, v, idepth, color} per template point.
 struct RefDev {
@@ -104,6 +107,7 @@ struct ProfScope {
 };
 int ensure_pinned(sdso_ctx* ctx, size_t bytes);
 int ensure_tiled0(sdso_ctx* ctx, PyramidDev& P);   // ctx.hip
+int ensure_plane0(sdso_ctx* ctx, PyramidDev& P);   // ctx.hip
 // pixel (x, y) of a 4x2-tiled level-0 image with T tiles per row
 __host__ __device__ inline int tiled_index(int x, int y, int T) { return (((y >> 1) * T + (x >> 2)) << 3) + ((y & 1) << 2) + (x & 3); }
 
@@ -134,6 +138,17 @@ __device__ __forceinline__ float interp31(const float4* __restrict__ img, float 
   const float dxdy = dx * dy;
   const float4* bp = img + ix + iy * width;
   return dxdy * bp[1 + width].x + (dy - dxdy) * bp[width].x + (dx - dxdy) * bp[1].x + (1 - dx - dy + dxdy) * bp[0].x;
+}
+
+// getInterpolatedElement31 on the intensity plane (same expression, a quarter of the bytes per tap)
+__device__ __forceinline__ float interp31_plane(const float* __restrict__ I, float x, float y, int width) {
+  const int ix = (int)x;
+  const int iy = (int)y;
+  const float dx = x - ix;
+  const float dy = y - iy;
+  const float dxdy = dx * dy;
+  const float* bp = I + ix + iy * width;
+  return dxdy * bp[1 + width] + (dy - dxdy) * bp[width] + (dx - dxdy) * bp[1] + (1 - dx - dy + dxdy) * bp[0];
 }
 
 // 64-lane butterfly sum

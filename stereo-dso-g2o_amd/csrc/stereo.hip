@@ -31,6 +31,7 @@ struct TraceDev {
   int n, w, h, mode_right;
   float fx, fy, cx, cy, baseline;
   const float4* img;
+  const float* plane;   // level-0 intensities only (discrete search)
   float *u_stereo, *v_stereo, *idepth_min, *idepth_min_stereo, *idepth_max_stereo, *idepth_stereo;
   const float *color, *weights, *gradH, *energyTH;
   float* quality; uint8_t* lastTraceStatus; float* lastTraceUV; float* lastTracePixelInterval;
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(256) void k_trace_stereo(TraceDev T) {
       float energy = 0;
 #pragma unroll
       for (int idx = 0; idx < 8; idx++) {
-        const float hitColor = interp31(dI, (float)(ptx + (float)c_pat[idx][0]), (float)(pty + (float)c_pat[idx][1]), wG0);
+        const float hitColor = interp31_plane(T.plane, (float)(ptx + (float)c_pat[idx][0]), (float)(pty + (float)c_pat[idx][1]), wG0);
         if (!isfinite(hitColor)) { energy += 1e5; continue; }
         const float residual = hitColor - (float)(1.0f * color[idx] + 0.0f);
         const float hw = fabsf(residual) < kHuberTH ? 1 : kHuberTH / fabsf(residual);
@@ -386,7 +387,7 @@ __global__ __launch_bounds__(256) void k_trace_on(TraceDev T, const sdso_trace_g
       float energy = 0;
 #pragma unroll
       for (int idx = 0; idx < 8; idx++) {
-        const float hitColor = interp31(dI, (float)(ptx + rot[idx][0]), (float)(pty + rot[idx][1]), wG0);
+        const float hitColor = interp31_plane(T.plane, (float)(ptx + rot[idx][0]), (float)(pty + rot[idx][1]), wG0);
         if (!isfinite(hitColor)) { energy += 1e5; continue; }
         const float residual = hitColor - (float)(aff0 * color[idx] + aff1);
         const float hw = fabsf(residual) < kHuberTH ? 1 : kHuberTH / fabsf(residual);
@@ -569,7 +570,9 @@ extern "C" int sdso_trace_stereo_prepare(sdso_ctx* ctx, int frame_slot, const fl
   if (rc) return rc;
   trace_bind(B, n);
   TraceDev& T = B.T;
-  T.w = ip->second.w[0]; T.h = ip->second.h[0]; T.mode_right = mode_right; T.img = ip->second.d[0];
+  rc = ensure_plane0(ctx, ip->second);
+  if (rc) return rc;
+  T.w = ip->second.w[0]; T.h = ip->second.h[0]; T.mode_right = mode_right; T.img = ip->second.d[0]; T.plane = ip->second.plane0;
   T.fx = K[0]; T.fy = K[1]; T.cx = K[2]; T.cy = K[3]; T.baseline = baseline;
 #define UP(dst, src, cnt) if (n) SDSO_HIP(ctx, hipMemcpyAsync((void*)(dst), (src), sizeof(float) * (size_t)(cnt), hipMemcpyHostToDevice, ctx->stream))
   UP(T.u_stereo, P->u_stereo, n); UP(T.v_stereo, P->v_stereo, n); UP(T.idepth_min, P->idepth_min, n);
@@ -721,12 +724,16 @@ extern "C" int sdso_stereo_match_batch(sdso_ctx* ctx, int slot_a, int slot_b, co
   rc = trace_reserve(ctx, Bk, n);
   if (rc) return rc;
   trace_bind(A, n); trace_bind(Bk, n);
-  auto geom = [&](TraceDev& T, const float4* img, int mode_right) {
-    T.w = w; T.h = h; T.mode_right = mode_right; T.img = img;
+  rc = ensure_plane0(ctx, ia->second);
+  if (rc) return rc;
+  rc = ensure_plane0(ctx, ib->second);
+  if (rc) return rc;
+  auto geom = [&](TraceDev& T, const float4* img, const float* plane, int mode_right) {
+    T.w = w; T.h = h; T.mode_right = mode_right; T.img = img; T.plane = plane;
     T.fx = K[0]; T.fy = K[1]; T.cx = K[2]; T.cy = K[3]; T.baseline = baseline;
   };
-  geom(A.T, ib->second.d[0], mode_right_first ? 1 : 0);       // forward: points of frame A searched in frame B
-  geom(Bk.T, ia->second.d[0], mode_right_first ? 0 : 1);      // back: points of frame B searched in frame A
+  geom(A.T, ib->second.d[0], ib->second.plane0, mode_right_first ? 1 : 0);       // forward: points of frame A searched in frame B
+  geom(Bk.T, ia->second.d[0], ia->second.plane0, mode_right_first ? 0 : 1);      // back: points of frame B searched in frame A
   // host inputs -> device (the unused tail of the back batch's float blob is the staging area: 32N..36N)
   float* stage = Bk.blob + 32 * (size_t)Bk.n;
   const float* d_in[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
