@@ -151,6 +151,10 @@ __device__ __forceinline__ float interp31_plane(const float* __restrict__ I, flo
   return dxdy * bp[1 + width] + (dy - dxdy) * bp[width] + (dx - dxdy) * bp[1] + (1 - dx - dy + dxdy) * bp[0];
 }
 
+// value of a compile-time-constant lane in every lane (v_readlane_b32: scalar broadcast, no LDS crossbar trip)
+__device__ __forceinline__ float lane_bcast(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
+__device__ __forceinline__ int lane_bcast(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+
 // 64-lane butterfly sum
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

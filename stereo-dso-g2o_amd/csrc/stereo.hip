@@ -237,8 +237,8 @@ __global__ __launch_bounds__(256) void k_trace_stereo(TraceDev T) {
     float H = 1, bb = 0, energy = 0;
 #pragma unroll
     for (int idx = 0; idx < 8; idx++) {
-      const float h_ = __shfl(tH, idx, 64), b_ = __shfl(tb, idx, 64), e_ = __shfl(te, idx, 64);
-      const int nn = __shfl((int)nan, idx, 64);
+      const float h_ = lane_bcast(tH, idx), b_ = lane_bcast(tb, idx), e_ = lane_bcast(te, idx);
+      const int nn = lane_bcast((int)nan, idx);
       if (nn) { energy += 1e5; continue; }
       H += h_; bb += b_; energy += e_;
     }
@@ -447,8 +447,8 @@ __global__ __launch_bounds__(256) void k_trace_on(TraceDev T, const sdso_trace_g
     float H = 1, bb = 0, energy = 0;
 #pragma unroll
     for (int idx = 0; idx < 8; idx++) {
-      const float h_ = __shfl(tH, idx, 64), b_ = __shfl(tb, idx, 64), e_ = __shfl(te, idx, 64);
-      const int nn = __shfl((int)nan, idx, 64);
+      const float h_ = lane_bcast(tH, idx), b_ = lane_bcast(tb, idx), e_ = lane_bcast(te, idx);
+      const int nn = lane_bcast((int)nan, idx);
       if (nn) { energy += 1e5; continue; }
       H += h_; bb += b_; energy += e_;
     }
@@ -859,8 +859,8 @@ __global__ __launch_bounds__(256) void k_activate_points(ActDev A) {
 #pragma unroll
       for (int k = 0; k < 8; k++) {
         const int src = i * 8 + k;
-        const bool fk = __shfl((int)f, src, 64) != 0;
-        const float ek = __shfl(e, src, 64), hk = __shfl(hh, src, 64), bk = __shfl(bb, src, 64);
+        const bool fk = lane_bcast((int)f, src) != 0;
+        const float ek = lane_bcast(e, src), hk = lane_bcast(hh, src), bk = lane_bcast(bb, src);
         if (alive && fk) alive = false;
         if (alive) { energyLeft += ek; Hdd += hk; bd += bk; }
       }
