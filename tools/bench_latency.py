@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Single-problem latencies of the drop-in calls (what one FullSystem call costs): trackNewestCoarse and optimize, GPU vs oracle."""
+import ctypes as C, json, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in ("stereo-dso-g2o_amd", "oracle", "tests"):
+    sys.path.insert(0, os.path.join(ROOT, p))
+from sdso_amd import abi, synth
+import pyoracle, helpers
+
+orc = pyoracle.load(fast=True)
+ctx = abi.Context(0)
+out = {}
+prob = synth.tracker_problem(w=1232, h=368, npts=2000, seed=2002)
+ctx.upload_pyramid(2, prob["pyr_new"]); ctx.set_ref(1, prob["pc"])
+prm = helpers.track_params(prob)
+def trk():
+    T = abi.SE3.from_Rt(np.eye(3), np.zeros(3)); aff = abi.Aff(0, 0); o = abi.TrackResult()
+    ctx.check(ctx.L.sdso_track_newest_coarse(ctx.h, 1, 2, C.byref(prm), C.byref(T), C.byref(aff), C.byref(o)))
+    return o
+trk(); t0 = time.perf_counter()
+for _ in range(10): o = trk()
+g = (time.perf_counter() - t0) / 10 * 1e3
+t0 = time.perf_counter(); helpers.oracle_track(orc, prob, prm, (np.eye(3), np.zeros(3)), (0.0, 0.0)); c = (time.perf_counter() - t0) * 1e3
+out["trackNewestCoarse_1232x368_2000pts"] = {"gpu_ms": g, "cpu_oracle_ms": c, "evaluations": o.evaluations, "point_evals": o.point_evals}
+win = synth.ba_window(w=1232, h=368, nf=8, pts_per_kf=250, seed=3001)
+nf, npts, nr = win["nf"], win["np"], win["nr"]
+for f in range(nf): ctx.upload_pyramid(40 + f, win["pyrs"][f][:1])
+W, keep = abi.make_ba_window(win, frame_slots=[40 + f for f in range(nf)], dI_list=[p[0] for p in win["pyrs"]])
+st, idp, rs, oo = np.zeros((nf, 10)), np.zeros(npts, np.float32), np.zeros(nr, np.uint8), abi.BAOptResult()
+def opt():
+    ctx.check(ctx.L.sdso_ba_upload_window(ctx.h, 3, C.byref(W)))
+    ctx.check(ctx.L.sdso_ba_optimize(ctx.h, 3, 6, abi.dp(st), abi.fp(idp), abi.bp(rs), C.byref(oo)))
+opt(); t0 = time.perf_counter()
+for _ in range(5): opt()
+g = (time.perf_counter() - t0) / 5 * 1e3
+h = orc.orc_ba_create(C.byref(W)); t0 = time.perf_counter(); orc.orc_ba_optimize(h, 6, abi.dp(st), abi.fp(idp), abi.bp(rs), C.byref(oo)); c = (time.perf_counter() - t0) * 1e3; orc.orc_ba_destroy(h)
+out["optimize_8kf_2000pts_%dres_upload_plus_%dits" % (nr, oo.iterations)] = {"gpu_ms": g, "cpu_oracle_ms": c}
+ctx.close()
+print(json.dumps(out, indent=1))
