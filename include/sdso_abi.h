@@ -163,6 +163,13 @@ void sdso_track_make_eval(const sdso_track_params_t* prm, int lvl, const sdso_se
 int sdso_track_newest_coarse(sdso_ctx* ctx, int ref_slot, int frame_slot,
                              const sdso_track_params_t* prm, sdso_se3_t* lastToNew,
                              sdso_aff_t* aff_g2l, sdso_track_result_t* out);
+/* The same for `nhyp` independent (reference, frame, initial pose) hypotheses in lock-step: every round evaluates the pending
+ * calcRes+calcGSSSE of all unfinished hypotheses in one launch (FullSystem::trackNewCoarse tries up to 53 initial motions one
+ * after the other, FullSystem.cpp:305-441).  Every hypothesis follows exactly the evaluation sequence of the single call.
+ * prms / lastToNew / aff_g2l / outs are arrays of nhyp entries (in/out like the single call). */
+int sdso_track_newest_coarse_batch(sdso_ctx* ctx, int nhyp, const int* ref_slots, const int* frame_slots,
+                                   const sdso_track_params_t* prms, sdso_se3_t* lastToNew, sdso_aff_t* aff_g2l,
+                                   sdso_track_result_t* outs);
 
 /* ------------------------------------------------------------------ windowed bundle adjustment
  * One "window" mirrors an EnergyFunctional (src/OptimizationBackend/EnergyFunctional.h:49-150) with

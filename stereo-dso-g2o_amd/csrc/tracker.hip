@@ -494,138 +494,210 @@ extern "C" int sdso_track_calc_res_gs(sdso_ctx* ctx, int ref_slot, int frame_slo
 }
 
 // CoarseTracker::trackNewestCoarse, DSO-native LM.
+// ------------------------------------------------------------------ trackNewestCoarse for many hypotheses in lock-step
+// CoarseTracker::trackNewestCoarse (CoarseTracker.cpp:827-1069, DSO-native LM :908-1024) is a chain of calcRes+calcGSSSE
+// evaluations with a little 8x8 algebra in between.  Each hypothesis is a small state machine that always has exactly one
+// evaluation pending (first evaluation of a level, repeat with a doubled cutoff, or the trial step of an LM iteration); all
+// pending evaluations of a round go to the device in ONE launch.  The sequence of evaluations — and therefore every number —
+// of a hypothesis is the one the sequential loop produces.
+namespace sdso {
+struct LmState {
+  int ref_slot = 0, frame_slot = 0;
+  sdso_track_params_t p;
+  sdso_track_result_t* out = nullptr;
+  sdso_se3_t* T_io = nullptr;
+  sdso_aff_t* aff_io = nullptr;
+  Se3 cur, Tnew;
+  sdso_aff_t affCur, affNew;
+  bool haveRepeated = false, done = false;
+  int lvl = 0, iteration = 0, phase = 0;   // phase 0: first / repeated evaluation of a level, 1: trial step
+  float levelCutoffRepeat = 1, lambda = 0.01f;
+  TrackOut oldO;
+  double H[64], b[8];
+  std::vector<double> inc;
+  // the evaluation this hypothesis waits for
+  Se3 reqT; sdso_aff_t reqAff;
+
+  void request(const Se3& T, const sdso_aff_t& a) { reqT = T; reqAff = a; }
+  void start_level() { levelCutoffRepeat = 1; phase = 0; request(cur, affCur); }
+  void finish() {   // :1044-1068
+    done = true;
+    std::memcpy(T_io->R, cur.R.data(), 72);
+    std::memcpy(T_io->t, cur.t.data(), 24);
+    *aff_io = affCur;
+    if ((p.affineOptModeA != 0 && (fabsf((float)aff_io->a) > 1.2)) || (p.affineOptModeB != 0 && (fabsf((float)aff_io->b) > 200))) return;
+    double rel[2];
+    affFromTo(p.ref_exposure, p.new_exposure, p.ref_aff_g2l.a, p.ref_aff_g2l.b, aff_io->a, aff_io->b, rel);
+    const float r0 = (float)rel[0], r1 = (float)rel[1];
+    if ((p.affineOptModeA == 0 && (fabsf(logf(r0)) > 1.5)) || (p.affineOptModeB == 0 && (fabsf(r1) > 200))) return;
+    if (p.affineOptModeA < 0) aff_io->a = 0;
+    if (p.affineOptModeB < 0) aff_io->b = 0;
+    out->good = 1;
+  }
+  void finish_level() {
+    out->lastResiduals[lvl] = sqrtf((float)(oldO.res[0] / oldO.res[1]));
+    out->lastFlowIndicators[0] = oldO.res[2]; out->lastFlowIndicators[1] = oldO.res[3]; out->lastFlowIndicators[2] = oldO.res[4];
+    if (out->lastResiduals[lvl] > 1.5 * p.minResForAbort[lvl]) { done = true; return; }  // :1032 (good stays 0, pose untouched)
+    if (levelCutoffRepeat > 1 && !haveRepeated) { lvl++; haveRepeated = true; }
+    lvl--;
+    if (lvl < 0) finish(); else start_level();
+  }
+  void propose() {   // one LM step from (H, b, lambda): :931-1000
+    const float lambdaExtrapolationLimit = 0.001f;
+    if (iteration >= p.maxIterations[lvl]) { finish_level(); return; }
+    out->iterations[lvl]++;
+    Dense Hl(8);
+    for (int i = 0; i < 8; i++) for (int j = 0; j < 8; j++) Hl(i, j) = H[i * 8 + j];
+    for (int i = 0; i < 8; i++) Hl(i, i) *= (1 + lambda);
+    std::vector<double> nb(8);
+    for (int i = 0; i < 8; i++) nb[i] = -b[i];
+    solveLdlt(Hl, nb, inc);
+    auto sub = [&](const Dense& Hs, const double* bs, int m, std::vector<double>& xs) {
+      Dense Hm(m);
+      std::vector<double> bm(m);
+      for (int i = 0; i < m; i++) { bm[i] = -bs[i]; for (int j = 0; j < m; j++) Hm(i, j) = Hs(i, j); }
+      solveLdlt(Hm, bm, xs);
+    };
+    if (p.affineOptModeA < 0 && p.affineOptModeB < 0) {  // fix a, b (:937-940)
+      std::vector<double> x6; sub(Hl, b, 6, x6);
+      for (int i = 0; i < 6; i++) inc[i] = x6[i];
+      inc[6] = inc[7] = 0;
+    }
+    if (!(p.affineOptModeA < 0) && p.affineOptModeB < 0) {  // fix b (:943-946)
+      std::vector<double> x7; sub(Hl, b, 7, x7);
+      for (int i = 0; i < 7; i++) inc[i] = x7[i];
+      inc[7] = 0;
+    }
+    if (p.affineOptModeA < 0 && !(p.affineOptModeB < 0)) {  // fix a (:949-964)
+      Dense Hs = Hl;
+      double bs[8];
+      std::memcpy(bs, b, sizeof(bs));
+      for (int i = 0; i < 8; i++) Hs(i, 6) = Hs(i, 7);
+      for (int j = 0; j < 8; j++) Hs(6, j) = Hs(7, j);
+      bs[6] = bs[7];
+      std::vector<double> x7; sub(Hs, bs, 7, x7);
+      for (int i = 0; i < 8; i++) inc[i] = 0;
+      for (int i = 0; i < 6; i++) inc[i] = x7[i];
+      inc[7] = x7[6];
+    }
+    float extrapFac = 1;
+    if (lambda < lambdaExtrapolationLimit) extrapFac = sqrt(sqrt(lambdaExtrapolationLimit / lambda));
+    for (int i = 0; i < 8; i++) inc[i] *= extrapFac;
+    double incScaled[8];
+    for (int i = 0; i < 8; i++) incScaled[i] = inc[i];
+    for (int i = 0; i < 3; i++) incScaled[i] *= SCALE_XI_ROT;
+    for (int i = 3; i < 6; i++) incScaled[i] *= SCALE_XI_TRANS;
+    incScaled[6] *= SCALE_A;
+    incScaled[7] *= SCALE_B;
+    double sum = 0;
+    for (int i = 0; i < 8; i++) sum += incScaled[i];
+    if (!std::isfinite(sum)) for (int i = 0; i < 8; i++) incScaled[i] = 0;
+    Tnew = expSe3(incScaled) * cur;
+    affNew = affCur;
+    affNew.a += incScaled[6];
+    affNew.b += incScaled[7];
+    phase = 1;
+    request(Tnew, affNew);
+  }
+  void consume(const TrackOut& O) {
+    const float lambdaExtrapolationLimit = 0.001f;
+    if (phase == 0) {
+      oldO = O;
+      if (oldO.res[5] > 0.6 && levelCutoffRepeat < 50) { levelCutoffRepeat *= 2; request(cur, affCur); return; }   // :897-904
+      std::memcpy(H, oldO.H, sizeof(H));
+      std::memcpy(b, oldO.b, sizeof(b));
+      lambda = 0.01f;
+      iteration = 0;
+      propose();
+      return;
+    }
+    const bool accept = (O.res[0] / O.res[1]) < (oldO.res[0] / oldO.res[1]);
+    if (accept) {
+      std::memcpy(H, O.H, sizeof(H));
+      std::memcpy(b, O.b, sizeof(b));
+      oldO = O;
+      affCur = affNew;
+      cur = Tnew;
+      lambda *= 0.5;
+    } else {
+      lambda *= 4;
+      if (lambda < lambdaExtrapolationLimit) lambda = lambdaExtrapolationLimit;
+    }
+    double nrm = 0;
+    for (int i = 0; i < 8; i++) nrm += inc[i] * inc[i];
+    if (!(std::sqrt(nrm) > 1e-3)) { finish_level(); return; }
+    iteration++;
+    propose();
+  }
+};
+}  // namespace sdso
+
+extern "C" int sdso_track_newest_coarse_batch(sdso_ctx* ctx, int nhyp, const int* ref_slots, const int* frame_slots, const sdso_track_params_t* prms,
+                                              sdso_se3_t* lastToNew, sdso_aff_t* aff_g2l, sdso_track_result_t* outs) {
+  if (!ctx) return SDSO_ERR_STATE;
+  SDSO_HIP(ctx, hipSetDevice(ctx->device));
+  SDSO_REQUIRE(ctx, nhyp > 0 && ref_slots && frame_slots && prms && lastToNew && aff_g2l && outs, "null argument");
+  std::vector<LmState> S(nhyp);
+  for (int k = 0; k < nhyp; k++) {
+    LmState& s = S[k];
+    s.p = prms[k];
+    SDSO_REQUIRE(ctx, s.p.coarsestLvl >= 0 && s.p.coarsestLvl < 5 && s.p.coarsestLvl < s.p.levels, "coarsestLvl out of range");  // assert :853
+    s.ref_slot = ref_slots[k]; s.frame_slot = frame_slots[k];
+    s.out = &outs[k]; s.T_io = &lastToNew[k]; s.aff_io = &aff_g2l[k];
+    for (int i = 0; i < 5; i++) { s.out->lastResiduals[i] = NAN; s.out->iterations[i] = 0; }
+    for (int i = 0; i < 3; i++) s.out->lastFlowIndicators[i] = 1000;
+    s.out->evaluations = 0; s.out->point_evals = 0; s.out->good = 0;
+    std::memcpy(s.cur.R.data(), lastToNew[k].R, 72);
+    std::memcpy(s.cur.t.data(), lastToNew[k].t, 24);
+    s.affCur = aff_g2l[k];
+    s.lvl = s.p.coarsestLvl;
+    s.start_level();
+  }
+  std::vector<TrackProb> probs;
+  std::vector<int> who;
+  for (;;) {
+    probs.clear(); who.clear();
+    for (int k = 0; k < nhyp; k++) {
+      LmState& s = S[k];
+      if (s.done) continue;
+      sdso_track_eval_t ev;
+      fill_eval(s.p, s.lvl, s.reqT, s.reqAff, s.p.coarseCutoffTH * s.levelCutoffRepeat, ev);
+      TrackProb P;
+      int rc = resolve_prob(ctx, s.ref_slot, s.frame_slot, ev, P);
+      if (rc) return rc;
+      probs.push_back(P); who.push_back(k);
+      s.out->evaluations++;
+      s.out->point_evals += P.n;
+    }
+    if (probs.empty()) break;
+    const int np = (int)probs.size();
+    int maxn = 0;
+    for (const TrackProb& P : probs) maxn = std::max(maxn, P.n);
+    const int gx = choose_gx(ctx, np, maxn);
+    int rc = batch_reserve(ctx, np, gx);
+    if (rc) return rc;
+    TrackBatch* tb = ctx->tb;
+    tb->nprob = 0;  // invalidates any prepared batch
+    rc = ensure_pinned(ctx, (sizeof(TrackOut) + sizeof(TrackProb)) * (size_t)np);
+    if (rc) return rc;
+    TrackProb* hp = (TrackProb*)((char*)ctx->pinned + sizeof(TrackOut) * (size_t)np);
+    std::memcpy(hp, probs.data(), sizeof(TrackProb) * np);
+    SDSO_HIP(ctx, hipMemcpyAsync(tb->d_probs, hp, sizeof(TrackProb) * np, hipMemcpyHostToDevice, ctx->stream));
+    const int groups = (np + 7) / 8;
+    hipLaunchKernelGGL(k_track_eval<false>, dim3(groups * 8 * gx), dim3(TRK_BLOCK), 0, ctx->stream, tb->d_probs, np, gx, tb->d_partF, tb->d_partI, (uint8_t*)nullptr);
+    hipLaunchKernelGGL(k_track_finalize, dim3(np), dim3(64), 0, ctx->stream, tb->d_probs, tb->d_partF, tb->d_partI, gx, tb->d_out);
+    SDSO_HIP(ctx, hipGetLastError());
+    SDSO_HIP(ctx, hipMemcpyAsync(ctx->pinned, tb->d_out, sizeof(TrackOut) * np, hipMemcpyDeviceToHost, ctx->stream));
+    SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const TrackOut* O = (const TrackOut*)ctx->pinned;
+    for (int j = 0; j < np; j++) S[who[j]].consume(O[j]);
+  }
+  return SDSO_OK;
+}
+
 extern "C" int sdso_track_newest_coarse(sdso_ctx* ctx, int ref_slot, int frame_slot, const sdso_track_params_t* prm,
                                         sdso_se3_t* lastToNew, sdso_aff_t* aff_g2l, sdso_track_result_t* out) {
   if (!ctx) return SDSO_ERR_STATE;
-  SDSO_HIP(ctx, hipSetDevice(ctx->device));
   SDSO_REQUIRE(ctx, prm && lastToNew && aff_g2l && out, "null argument");
-  const sdso_track_params_t& p = *prm;
-  SDSO_REQUIRE(ctx, p.coarsestLvl >= 0 && p.coarsestLvl < 5 && p.coarsestLvl < p.levels, "coarsestLvl out of range");  // assert :853
-  for (int i = 0; i < 5; i++) { out->lastResiduals[i] = NAN; out->iterations[i] = 0; }
-  for (int i = 0; i < 3; i++) out->lastFlowIndicators[i] = 1000;
-  out->evaluations = 0; out->point_evals = 0; out->good = 0;
-  const float lambdaExtrapolationLimit = 0.001f;
-
-  Se3 cur;
-  std::memcpy(cur.R.data(), lastToNew->R, 72);
-  std::memcpy(cur.t.data(), lastToNew->t, 24);
-  sdso_aff_t affCur = *aff_g2l;
-  bool haveRepeated = false;
-
-  for (int lvl = p.coarsestLvl; lvl >= 0; lvl--) {
-    float levelCutoffRepeat = 1;
-    TrackOut oldO, newO;
-    auto eval = [&](const Se3& T, const sdso_aff_t& a, TrackOut& O) -> int {
-      sdso_track_eval_t ev;
-      fill_eval(p, lvl, T, a, p.coarseCutoffTH * levelCutoffRepeat, ev);
-      TrackProb P;
-      int rc = resolve_prob(ctx, ref_slot, frame_slot, ev, P);
-      if (rc) return rc;
-      rc = eval_one(ctx, P, nullptr);
-      if (rc) return rc;
-      O = *(const TrackOut*)ctx->pinned;
-      out->evaluations++;
-      out->point_evals += P.n;
-      return SDSO_OK;
-    };
-    int rc = eval(cur, affCur, oldO);
-    if (rc) return rc;
-    while (oldO.res[5] > 0.6 && levelCutoffRepeat < 50) {  // :897-904
-      levelCutoffRepeat *= 2;
-      rc = eval(cur, affCur, oldO);
-      if (rc) return rc;
-    }
-    double H[64], b[8];
-    std::memcpy(H, oldO.H, sizeof(H));
-    std::memcpy(b, oldO.b, sizeof(b));
-    float lambda = 0.01f;
-
-    for (int iteration = 0; iteration < p.maxIterations[lvl]; iteration++) {
-      out->iterations[lvl]++;
-      Dense Hl(8);
-      for (int i = 0; i < 8; i++) for (int j = 0; j < 8; j++) Hl(i, j) = H[i * 8 + j];
-      for (int i = 0; i < 8; i++) Hl(i, i) *= (1 + lambda);
-      std::vector<double> nb(8), inc;
-      for (int i = 0; i < 8; i++) nb[i] = -b[i];
-      solveLdlt(Hl, nb, inc);
-      auto sub = [&](const Dense& Hs, const double* bs, int m, std::vector<double>& xs) {
-        Dense Hm(m);
-        std::vector<double> bm(m);
-        for (int i = 0; i < m; i++) { bm[i] = -bs[i]; for (int j = 0; j < m; j++) Hm(i, j) = Hs(i, j); }
-        solveLdlt(Hm, bm, xs);
-      };
-      if (p.affineOptModeA < 0 && p.affineOptModeB < 0) {  // fix a, b (:937-940)
-        std::vector<double> x6; sub(Hl, b, 6, x6);
-        for (int i = 0; i < 6; i++) inc[i] = x6[i];
-        inc[6] = inc[7] = 0;
-      }
-      if (!(p.affineOptModeA < 0) && p.affineOptModeB < 0) {  // fix b (:943-946)
-        std::vector<double> x7; sub(Hl, b, 7, x7);
-        for (int i = 0; i < 7; i++) inc[i] = x7[i];
-        inc[7] = 0;
-      }
-      if (p.affineOptModeA < 0 && !(p.affineOptModeB < 0)) {  // fix a (:949-964)
-        Dense Hs = Hl;
-        double bs[8];
-        std::memcpy(bs, b, sizeof(bs));
-        for (int i = 0; i < 8; i++) Hs(i, 6) = Hs(i, 7);
-        for (int j = 0; j < 8; j++) Hs(6, j) = Hs(7, j);
-        bs[6] = bs[7];
-        std::vector<double> x7; sub(Hs, bs, 7, x7);
-        for (int i = 0; i < 8; i++) inc[i] = 0;
-        for (int i = 0; i < 6; i++) inc[i] = x7[i];
-        inc[7] = x7[6];
-      }
-      float extrapFac = 1;
-      if (lambda < lambdaExtrapolationLimit) extrapFac = sqrt(sqrt(lambdaExtrapolationLimit / lambda));
-      for (int i = 0; i < 8; i++) inc[i] *= extrapFac;
-      double incScaled[8];
-      for (int i = 0; i < 8; i++) incScaled[i] = inc[i];
-      for (int i = 0; i < 3; i++) incScaled[i] *= SCALE_XI_ROT;
-      for (int i = 3; i < 6; i++) incScaled[i] *= SCALE_XI_TRANS;
-      incScaled[6] *= SCALE_A;
-      incScaled[7] *= SCALE_B;
-      double s = 0;
-      for (int i = 0; i < 8; i++) s += incScaled[i];
-      if (!std::isfinite(s)) for (int i = 0; i < 8; i++) incScaled[i] = 0;
-
-      const Se3 Tnew = expSe3(incScaled) * cur;
-      sdso_aff_t affNew = affCur;
-      affNew.a += incScaled[6];
-      affNew.b += incScaled[7];
-      rc = eval(Tnew, affNew, newO);
-      if (rc) return rc;
-      const bool accept = (newO.res[0] / newO.res[1]) < (oldO.res[0] / oldO.res[1]);
-      if (accept) {
-        std::memcpy(H, newO.H, sizeof(H));
-        std::memcpy(b, newO.b, sizeof(b));
-        oldO = newO;
-        affCur = affNew;
-        cur = Tnew;
-        lambda *= 0.5;
-      } else {
-        lambda *= 4;
-        if (lambda < lambdaExtrapolationLimit) lambda = lambdaExtrapolationLimit;
-      }
-      double nrm = 0;
-      for (int i = 0; i < 8; i++) nrm += inc[i] * inc[i];
-      if (!(std::sqrt(nrm) > 1e-3)) break;
-    }
-    out->lastResiduals[lvl] = sqrtf((float)(oldO.res[0] / oldO.res[1]));
-    out->lastFlowIndicators[0] = oldO.res[2]; out->lastFlowIndicators[1] = oldO.res[3]; out->lastFlowIndicators[2] = oldO.res[4];
-    if (out->lastResiduals[lvl] > 1.5 * p.minResForAbort[lvl]) return SDSO_OK;  // :1032 (good stays 0)
-    if (levelCutoffRepeat > 1 && !haveRepeated) { lvl++; haveRepeated = true; }
-  }
-  std::memcpy(lastToNew->R, cur.R.data(), 72);
-  std::memcpy(lastToNew->t, cur.t.data(), 24);
-  *aff_g2l = affCur;
-  if ((p.affineOptModeA != 0 && (fabsf((float)aff_g2l->a) > 1.2)) || (p.affineOptModeB != 0 && (fabsf((float)aff_g2l->b) > 200))) return SDSO_OK;
-  double rel[2];
-  affFromTo(p.ref_exposure, p.new_exposure, p.ref_aff_g2l.a, p.ref_aff_g2l.b, aff_g2l->a, aff_g2l->b, rel);
-  const float r0 = (float)rel[0], r1 = (float)rel[1];
-  if ((p.affineOptModeA == 0 && (fabsf(logf(r0)) > 1.5)) || (p.affineOptModeB == 0 && (fabsf(r1) > 200))) return SDSO_OK;
-  if (p.affineOptModeA < 0) aff_g2l->a = 0;
-  if (p.affineOptModeB < 0) aff_g2l->b = 0;
-  out->good = 1;
-  return SDSO_OK;
+  return sdso_track_newest_coarse_batch(ctx, 1, &ref_slot, &frame_slot, prm, lastToNew, aff_g2l, out);
 }

@@ -252,6 +252,7 @@ def load():
     L.sdso_trace_stereo_prepare.argtypes = [vp, C.c_int, c_float_p, C.c_float, C.c_int, C.POINTER(TracePoints)]
     L.sdso_trace_stereo_enqueue.argtypes = [vp]
     L.sdso_trace_stereo_fetch.argtypes = [vp, C.POINTER(TracePoints), c_u8_p]
+    L.sdso_track_newest_coarse_batch.argtypes = [vp, C.c_int, c_int_p, c_int_p, C.POINTER(TrackParams), C.POINTER(SE3), C.POINTER(Aff), C.POINTER(TrackResult)]
     L.sdso_track_make_ref.argtypes = [vp, C.c_int, C.c_int, C.c_int, c_int_p, c_int_p, c_float_p, c_float_p, c_int_p]
     L.sdso_track_get_ref.argtypes = [vp, C.c_int, C.c_int, c_int_p, c_float_p, c_float_p, c_float_p, c_float_p]
     L.sdso_trace_on_batch.argtypes = [vp, C.c_int, C.c_int, C.POINTER(TraceGeom), c_int_p, C.POINTER(TracePoints), c_u8_p]
@@ -278,7 +279,7 @@ EXPORTED_SYMBOLS = [
     "sdso_ba_keep_projections", "sdso_ba_batch_create", "sdso_ba_batch_accumulate", "sdso_ba_batch_solve",
     "sdso_ba_batch_accum_dev", "sdso_ba_batch_get_x", "sdso_ba_batch_set_materialize",
     "sdso_immature_init_batch", "sdso_trace_stereo_batch", "sdso_trace_stereo_prepare", "sdso_trace_stereo_enqueue",
-    "sdso_trace_stereo_fetch", "sdso_stereo_match_batch", "sdso_activate_points_batch", "sdso_ba_marginalize_frame", "sdso_pixel_select", "sdso_pixel_selector_pattern", "sdso_trace_on_batch", "sdso_track_make_ref", "sdso_track_get_ref",
+    "sdso_trace_stereo_fetch", "sdso_stereo_match_batch", "sdso_activate_points_batch", "sdso_ba_marginalize_frame", "sdso_pixel_select", "sdso_pixel_selector_pattern", "sdso_trace_on_batch", "sdso_track_make_ref", "sdso_track_newest_coarse_batch", "sdso_track_get_ref",
 ]
 
 

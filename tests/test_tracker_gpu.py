@@ -222,3 +222,41 @@ def test_make_ref_bit_exact_bookkeeping(gpu_ctx):
     # empty input: every level empty, nothing faults
     gpu_ctx.check(gpu_ctx.L.sdso_track_make_ref(gpu_ctx.h, 33, 21, 0, None, None, None, None, abi.ip(pcn)))
     assert (pcn[:L] == 0).all()
+
+
+def test_track_hypotheses_in_lock_step(gpu_ctx, oracle, prob_small, prob_kitti):
+    """sdso_track_newest_coarse_batch: the motion hypotheses FullSystem::trackNewCoarse tries one after the other
+    (FullSystem.cpp:305-441), all advanced together.  Each hypothesis must end where the sequential oracle ends."""
+    _setup(gpu_ctx, prob_small, 1, 2)
+    _setup(gpu_ctx, prob_kitti, 3, 4)
+    rs = np.random.RandomState(17)
+    hyps = []
+    for k in range(9):
+        prob, r, f = (prob_small, 1, 2) if k % 3 else (prob_kitti, 3, 4)
+        xi = np.zeros(6) if k < 2 else rs.normal(0, [0.02, 0.02, 0.1, 0.003, 0.003, 0.003])
+        if k == 8:
+            xi = np.array([3.0, 0, 0, 0, 0.5, 0])            # a hopeless start: must come back not good without disturbing the others
+        hyps.append((prob, r, f, synth.se3_exp(xi)))
+    n = len(hyps)
+    prms = (abi.TrackParams * n)(*[helpers.track_params(h[0]) for h in hyps])
+    for k in range(n):
+        for i in range(5):
+            prms[k].minResForAbort[i] = 1e3 if k != 4 else 0.01   # hypothesis 4 aborts on its first level
+    Ts = (abi.SE3 * n)(*[abi.SE3.from_Rt(*h[3]) for h in hyps])
+    affs = (abi.Aff * n)(*[abi.Aff(0, 0) for _ in hyps])
+    outs = (abi.TrackResult * n)()
+    refs = np.array([h[1] for h in hyps], np.int32); frames = np.array([h[2] for h in hyps], np.int32)
+    gpu_ctx.check(gpu_ctx.L.sdso_track_newest_coarse_batch(gpu_ctx.h, n, abi.ip(refs), abi.ip(frames), prms, Ts, affs, outs))
+    ngood = 0
+    for k, (prob, r, f, T0) in enumerate(hyps):
+        To, affo, outo = helpers.oracle_track(oracle, prob, prms[k], T0, (0.0, 0.0))
+        assert outs[k].good == outo.good, k
+        if k == 8:          # almost no inliers: the 8x8 system is near-singular and amplifies the order of the float sums; only the verdict is compared
+            continue
+        assert list(outs[k].iterations) == list(outo.iterations) and outs[k].evaluations == outo.evaluations, k
+        R, t = Ts[k].Rt(); Ro, to = To.Rt()
+        assert np.abs(t - to).max() <= 1e-5 and np.abs(R - Ro).max() <= 1e-5, k
+        assert abs(affs[k].a - affo.a) <= 1e-5 and abs(affs[k].b - affo.b) <= 1e-3, k
+        ngood += outs[k].good
+    assert outs[4].good == 0 and np.array_equal(Ts[4].Rt()[0], hyps[4][3][0])      # aborted: pose untouched
+    assert ngood >= 6
