@@ -23,6 +23,20 @@ for _ in range(10): o = trk()
 g = (time.perf_counter() - t0) / 10 * 1e3
 t0 = time.perf_counter(); helpers.oracle_track(orc, prob, prm, (np.eye(3), np.zeros(3)), (0.0, 0.0)); c = (time.perf_counter() - t0) * 1e3
 out["trackNewestCoarse_1232x368_2000pts"] = {"gpu_ms": g, "cpu_oracle_ms": c, "evaluations": o.evaluations, "point_evals": o.point_evals}
+for nh in (8, 64):
+    rs = np.random.RandomState(3)
+    prms = (abi.TrackParams * nh)(*[prm for _ in range(nh)])
+    def many():
+        Ts = (abi.SE3 * nh)(*[abi.SE3.from_Rt(*synth.se3_exp(rs.normal(0, [0.01, 0.01, 0.05, 0.002, 0.002, 0.002]))) for _ in range(nh)])
+        affs = (abi.Aff * nh)(*[abi.Aff(0, 0) for _ in range(nh)])
+        outs = (abi.TrackResult * nh)()
+        refs = np.full(nh, 1, np.int32); frames = np.full(nh, 2, np.int32)
+        t0 = time.perf_counter()
+        ctx.check(ctx.L.sdso_track_newest_coarse_batch(ctx.h, nh, abi.ip(refs), abi.ip(frames), prms, Ts, affs, outs))
+        return (time.perf_counter() - t0) * 1e3, sum(o.point_evals for o in outs), sum(o.good for o in outs)
+    many(); r = [many() for _ in range(5)]
+    g = float(np.mean([x[0] for x in r]))
+    out["trackNewestCoarse_%d_hypotheses_lockstep" % nh] = {"gpu_ms": g, "gpu_ms_per_hypothesis": g / nh, "point_evals": int(r[0][1]), "good": int(r[0][2])}
 win = synth.ba_window(w=1232, h=368, nf=8, pts_per_kf=250, seed=3001)
 nf, npts, nr = win["nf"], win["np"], win["nr"]
 for f in range(nf): ctx.upload_pyramid(40 + f, win["pyrs"][f][:1])
