@@ -17,7 +17,7 @@ struct BaBatch;
 struct BaWindowDev {
   BaDev d;                 // host copy of the device descriptor
   BaDev* d_self = nullptr; // device copy (array of 1)
-  std::vector<void*> allocs;
+  std::vector<std::pair<void*, size_t>> allocs;
   // host mirror
   HostCalib calib;
   std::vector<HostFrame> frames;
@@ -42,10 +42,20 @@ struct BaWindowDev {
   bool accumulated = false;
 };
 
+// zeroed device buffer for a window: reuse a pooled buffer of a released window when one of a similar size exists
+// (hipMalloc / hipFree of ~40 buffers cost more than the whole upload otherwise)
 static int dmalloc(sdso_ctx* ctx, BaWindowDev* W, void** p, size_t bytes) {
-  SDSO_HIP(ctx, hipMalloc(p, bytes ? bytes : 16));
-  SDSO_HIP(ctx, hipMemsetAsync(*p, 0, bytes ? bytes : 16, ctx->stream));
-  W->allocs.push_back(*p);
+  const size_t want = ((bytes ? bytes : 16) + 255) & ~(size_t)255;
+  int best = -1;
+  for (int i = 0; i < (int)ctx->ba_pool.size(); i++) {
+    const size_t have = ctx->ba_pool[i].second;
+    if (have >= want && have <= 2 * want + 4096 && (best < 0 || have < ctx->ba_pool[best].second)) best = i;
+  }
+  size_t got = want;
+  if (best >= 0) { *p = ctx->ba_pool[best].first; got = ctx->ba_pool[best].second; ctx->ba_pool.erase(ctx->ba_pool.begin() + best); }
+  else SDSO_HIP(ctx, hipMalloc(p, want));
+  SDSO_HIP(ctx, hipMemsetAsync(*p, 0, want, ctx->stream));
+  W->allocs.emplace_back(*p, got);
   return SDSO_OK;
 }
 #define DM(ptr, T, count)                                                   \
@@ -57,8 +67,10 @@ static int dmalloc(sdso_ctx* ctx, BaWindowDev* W, void** p, size_t bytes) {
   } while (0)
 #define H2D(dst, src, bytes) SDSO_HIP(ctx, hipMemcpyAsync((void*)(dst), (src), (bytes), hipMemcpyHostToDevice, ctx->stream))
 
-static void free_window(BaWindowDev* W) {
-  for (void* p : W->allocs) hipFree(p);
+static void free_window(sdso_ctx* ctx, BaWindowDev* W) {
+  for (auto& a : W->allocs) {
+    if (ctx->ba_pool.size() < 4096) ctx->ba_pool.push_back(a); else hipFree(a.first);
+  }
   delete W;
 }
 struct BaLaunch {
@@ -75,14 +87,13 @@ struct BaBatch {
 };
 static std::map<sdso_ctx*, BaBatch*> g_batches;
 static void free_batch(sdso_ctx* ctx) {
-  auto it = g_batches.find(ctx);
-  if (it == g_batches.end() || !it->second) return;
-  hipFree(it->second->d_arr); hipFree(it->second->d_accum);
-  delete it->second;
-  g_batches.erase(it);
+  BaBatch* taken = nullptr;
+  if (!reg_take(g_batches, ctx, taken) || !taken) return;
+  hipFree(taken->d_arr); hipFree(taken->d_accum);
+  delete taken;
 }
 void release_all_windows(sdso_ctx* ctx) {
-  for (auto& kv : ctx->wins) free_window(kv.second);
+  for (auto& kv : ctx->wins) free_window(ctx, kv.second);
   ctx->wins.clear();
   free_batch(ctx);
 }
@@ -132,7 +143,7 @@ extern "C" int sdso_ba_release_window(sdso_ctx* ctx, int win) {
   auto it = ctx->wins.find(win);
   if (it == ctx->wins.end()) return SDSO_OK;
   SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  free_window(it->second);
+  free_window(ctx, it->second);
   ctx->wins.erase(it);
   return SDSO_OK;
 }
@@ -848,7 +859,7 @@ extern "C" int sdso_ba_batch_create(sdso_ctx* ctx, int nwin, const int* wins) {
   SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
   free_batch(ctx);
   BaBatch* Bt = new BaBatch();
-  g_batches[ctx] = Bt;
+  reg_get(g_batches, ctx) = Bt;
   BaWindowDev* W0 = find_win(ctx, wins[0]);
   SDSO_REQUIRE(ctx, W0, "unknown window in batch");
   const int nf = W0->d.nf;
@@ -881,8 +892,8 @@ extern "C" int sdso_ba_batch_create(sdso_ctx* ctx, int nwin, const int* wins) {
 }
 // phase 1 of one GN iteration for every window of the batch: linearize + applyRes + accumulate A/L/SC (enqueue only)
 extern "C" int sdso_ba_batch_accumulate(sdso_ctx* ctx) {
-  if (!ctx || !g_batches.count(ctx) || !g_batches[ctx]) return sdso::fail(ctx, SDSO_ERR_STATE, "no batch");
-  BaBatch* Bt = g_batches[ctx];
+  BaBatch* Bt = ctx && reg_has(g_batches, ctx) ? reg_get(g_batches, ctx) : nullptr;
+  if (!Bt) return sdso::fail(ctx, SDSO_ERR_STATE, "no batch");
   launch_fused(ctx, Bt->L, Bt->materialize);
   SDSO_HIP(ctx, hipGetLastError());
   return SDSO_OK;
@@ -891,29 +902,30 @@ extern "C" int sdso_ba_batch_accumulate(sdso_ctx* ctx) {
 // (what PointFrameResidual::J holds in the reference); 0: they stay in registers (the solver never
 // re-reads them) — 296 B less store traffic per point-residual.
 extern "C" int sdso_ba_batch_set_materialize(sdso_ctx* ctx, int materialize) {
-  if (!ctx || !g_batches.count(ctx) || !g_batches[ctx]) return sdso::fail(ctx, SDSO_ERR_STATE, "no batch");
-  g_batches[ctx]->materialize = materialize != 0;
+  BaBatch* Bt = ctx && reg_has(g_batches, ctx) ? reg_get(g_batches, ctx) : nullptr;
+  if (!Bt) return sdso::fail(ctx, SDSO_ERR_STATE, "no batch");
+  Bt->materialize = materialize != 0;
   return SDSO_OK;
 }
 // phase 2: stitch + solve + resubstitute (enqueue only). Between the phases the caller may all-reduce
 // the packed accumulators (sdso_ba_batch_accum_dev) across ranks.
 extern "C" int sdso_ba_batch_solve(sdso_ctx* ctx, double lambda, int orthogonalize_x) {
-  if (!ctx || !g_batches.count(ctx) || !g_batches[ctx]) return sdso::fail(ctx, SDSO_ERR_STATE, "no batch");
-  BaBatch* Bt = g_batches[ctx];
+  BaBatch* Bt = ctx && reg_has(g_batches, ctx) ? reg_get(g_batches, ctx) : nullptr;
+  if (!Bt) return sdso::fail(ctx, SDSO_ERR_STATE, "no batch");
   launch_solve(ctx, Bt->L, lambda, orthogonalize_x);
   SDSO_HIP(ctx, hipGetLastError());
   return SDSO_OK;
 }
 extern "C" int sdso_ba_batch_accum_dev(sdso_ctx* ctx, void** dev_ptr, long* nfloats) {
-  if (!ctx || !g_batches.count(ctx) || !g_batches[ctx]) return sdso::fail(ctx, SDSO_ERR_STATE, "no batch");
-  BaBatch* Bt = g_batches[ctx];
+  BaBatch* Bt = ctx && reg_has(g_batches, ctx) ? reg_get(g_batches, ctx) : nullptr;
+  if (!Bt) return sdso::fail(ctx, SDSO_ERR_STATE, "no batch");
   if (dev_ptr) *dev_ptr = Bt->d_accum;
   if (nfloats) *nfloats = (long)(acc_floats(Bt->L.nf) * Bt->wins.size());
   return SDSO_OK;
 }
 extern "C" int sdso_ba_batch_get_x(sdso_ctx* ctx, double* x /* nwin * (8nf+4) */) {
-  if (!ctx || !g_batches.count(ctx) || !g_batches[ctx]) return sdso::fail(ctx, SDSO_ERR_STATE, "no batch");
-  BaBatch* Bt = g_batches[ctx];
+  BaBatch* Bt = ctx && reg_has(g_batches, ctx) ? reg_get(g_batches, ctx) : nullptr;
+  if (!Bt) return sdso::fail(ctx, SDSO_ERR_STATE, "no batch");
   SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
   const int n = Bt->L.n;
   for (size_t i = 0; i < Bt->wins.size(); i++) {

@@ -120,10 +120,11 @@ extern "C" void sdso_ctx_destroy(sdso_ctx* ctx) {
   hipSetDevice(ctx->device);
   hipStreamSynchronize(ctx->stream);
   for (auto& kv : ctx->pyr)
-    for (int l = 0; l < kv.second.levels; l++) hipFree(kv.second.d[l]);
+    { for (int l = 0; l < kv.second.levels; l++) hipFree(kv.second.d[l]); if (kv.second.tiled0) hipFree(kv.second.tiled0); if (kv.second.plane0) hipFree(kv.second.plane0); }
   for (auto& kv : ctx->refs)
     for (int l = 0; l < SDSO_PYR_LEVELS; l++) if (kv.second.pc[l]) hipFree(kv.second.pc[l]);
   release_all_windows(ctx);
+  for (auto& b : ctx->ba_pool) hipFree(b.first);
   release_track_batch(ctx);
   release_trace(ctx);
   release_match(ctx);

@@ -4,6 +4,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 #include "../../include/sdso_abi.h"
@@ -64,12 +65,29 @@ struct sdso_ctx {
   void* pinned = nullptr;
   size_t pinned_bytes = 0;
   int n_cu = 256;
+  // device buffers of released BA windows, kept for the next upload (a window is re-uploaded for every keyframe)
+  std::vector<std::pair<void*, size_t>> ba_pool;
   // optional in-library kernel timing (HIP events on ctx->stream), see sdso_prof_*
   bool prof_on = false;
   std::map<std::string, sdso::ProfEntry> prof;
 };
 
 namespace sdso {
+
+// Per-context state kept outside sdso_ctx lives in file-local registries keyed by the ctx.  A ctx is used by one thread at a
+// time, but different contexts may be driven from different threads (tracking / mapping), so the registries themselves are
+// guarded; the mapped objects are only touched by their ctx's thread (std::map nodes are stable).
+inline std::mutex& registry_mutex() { static std::mutex m; return m; }
+template <class V> inline V& reg_get(std::map<sdso_ctx*, V>& m, sdso_ctx* ctx) { std::lock_guard<std::mutex> g(registry_mutex()); return m[ctx]; }
+template <class V> inline bool reg_has(std::map<sdso_ctx*, V>& m, sdso_ctx* ctx) { std::lock_guard<std::mutex> g(registry_mutex()); return m.count(ctx) != 0; }
+template <class V> inline bool reg_take(std::map<sdso_ctx*, V>& m, sdso_ctx* ctx, V& out) {
+  std::lock_guard<std::mutex> g(registry_mutex());
+  auto it = m.find(ctx);
+  if (it == m.end()) return false;
+  out = it->second;
+  m.erase(it);
+  return true;
+}
 
 inline int fail(sdso_ctx* ctx, int code, const std::string& msg) {
   if (ctx) ctx->err = msg;

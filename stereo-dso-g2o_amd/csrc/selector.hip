@@ -221,10 +221,9 @@ static std::map<sdso_ctx*, SelState> g_sel;
 
 namespace sdso {
 void release_selector(sdso_ctx* ctx) {
-  auto it = g_sel.find(ctx);
-  if (it == g_sel.end()) return;
-  if (it->second.d_rnd) hipFree(it->second.d_rnd);
-  g_sel.erase(it);
+  SelState st;
+  if (!reg_take(g_sel, ctx, st)) return;
+  if (st.d_rnd) hipFree(st.d_rnd);
 }
 }  // namespace sdso
 
@@ -248,7 +247,7 @@ extern "C" int sdso_pixel_select(sdso_ctx* ctx, int frame_slot, float density, i
   SDSO_REQUIRE(ctx, P.levels >= 3, "the selector reads absSquaredGrad of levels 0..2");
   const int w = P.w[0], h = P.h[0], w32 = w / 32, h32 = h / 32;
   SDSO_REQUIRE(ctx, w32 > 0 && h32 > 0, "image smaller than one 32x32 cell");
-  SelState& S = g_sel[ctx];
+  SelState& S = reg_get(g_sel, ctx);
   if (S.w != w || S.h != h) {
     if (S.d_rnd) { SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream)); hipFree(S.d_rnd); S.d_rnd = nullptr; }
     glibc_rand_bytes(3141592u, (size_t)w * h, S.h_rnd);

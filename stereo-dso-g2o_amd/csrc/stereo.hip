@@ -549,11 +549,10 @@ static void trace_bind(TraceBatch& B, int n) {
   T.lastTraceStatus = B.bytes; T.status = B.bytes + N; T.skip = nullptr;
 }
 void release_trace(sdso_ctx* ctx) {
-  auto it = g_trace.find(ctx);
-  if (it == g_trace.end()) return;
-  if (it->second.blob) hipFree(it->second.blob);
-  if (it->second.bytes) hipFree(it->second.bytes);
-  g_trace.erase(it);
+  TraceBatch tb;
+  if (!reg_take(g_trace, ctx, tb)) return;
+  if (tb.blob) hipFree(tb.blob);
+  if (tb.bytes) hipFree(tb.bytes);
 }
 }  // namespace sdso
 
@@ -565,7 +564,7 @@ extern "C" int sdso_trace_stereo_prepare(sdso_ctx* ctx, int frame_slot, const fl
   auto ip = ctx->pyr.find(frame_slot);
   SDSO_REQUIRE(ctx, ip != ctx->pyr.end(), "unknown frame slot");
   const int n = P->n;
-  TraceBatch& B = g_trace[ctx];
+  TraceBatch& B = reg_get(g_trace, ctx);
   int rc = trace_reserve(ctx, B, std::max(n, 1));
   if (rc) return rc;
   trace_bind(B, n);
@@ -588,8 +587,8 @@ extern "C" int sdso_trace_stereo_prepare(sdso_ctx* ctx, int frame_slot, const fl
   return SDSO_OK;
 }
 extern "C" int sdso_trace_stereo_enqueue(sdso_ctx* ctx) {
-  if (!ctx || !g_trace.count(ctx)) return sdso::fail(ctx, SDSO_ERR_STATE, "no prepared trace batch");
-  TraceBatch& B = g_trace[ctx];
+  if (!ctx || !reg_has(g_trace, ctx)) return sdso::fail(ctx, SDSO_ERR_STATE, "no prepared trace batch");
+  TraceBatch& B = reg_get(g_trace, ctx);
   if (B.T.n == 0) return SDSO_OK;
   SDSO_HIP(ctx, hipMemcpyAsync(B.blob + 3 * (size_t)B.n, B.blob + 32 * (size_t)B.n, sizeof(float) * 3 * (size_t)B.n, hipMemcpyDeviceToDevice, ctx->stream));
   SDSO_HIP(ctx, hipMemcpyAsync(B.bytes, B.bytes + 2 * (size_t)B.n, (size_t)B.n, hipMemcpyDeviceToDevice, ctx->stream));
@@ -601,8 +600,8 @@ extern "C" int sdso_trace_stereo_enqueue(sdso_ctx* ctx) {
   return SDSO_OK;
 }
 extern "C" int sdso_trace_stereo_fetch(sdso_ctx* ctx, sdso_trace_points_t* P, uint8_t* status) {
-  if (!ctx || !g_trace.count(ctx)) return sdso::fail(ctx, SDSO_ERR_STATE, "no prepared trace batch");
-  TraceBatch& B = g_trace[ctx];
+  if (!ctx || !reg_has(g_trace, ctx)) return sdso::fail(ctx, SDSO_ERR_STATE, "no prepared trace batch");
+  TraceBatch& B = reg_get(g_trace, ctx);
   const int n = B.T.n;
   TraceDev& T = B.T;
 #define DN(dst, src, cnt) if (n && dst) SDSO_HIP(ctx, hipMemcpyAsync((dst), (src), sizeof(float) * (size_t)(cnt), hipMemcpyDeviceToHost, ctx->stream))
@@ -631,7 +630,7 @@ extern "C" int sdso_trace_on_batch(sdso_ctx* ctx, int frame_slot, int ngeom, con
   if (!pts->idepth_stereo) pts->idepth_stereo = pts->idepth_min_stereo;
   int rc = sdso_trace_stereo_prepare(ctx, frame_slot, K0, 0.f, 1, pts);   // uploads the point state into the ctx's trace batch
   if (rc) return rc;
-  TraceBatch& B = g_trace[ctx];
+  TraceBatch& B = reg_get(g_trace, ctx);
   rc = ensure_scratch(ctx, sizeof(sdso_trace_geom_t) * (size_t)ngeom + sizeof(int) * (size_t)n);
   if (rc) return rc;
   sdso_trace_geom_t* d_geom = (sdso_trace_geom_t*)ctx->scratch;
@@ -695,11 +694,10 @@ namespace sdso {
 static std::map<sdso_ctx*, TraceBatch> g_match[2];
 void release_match(sdso_ctx* ctx) {
   for (int k = 0; k < 2; k++) {
-    auto it = g_match[k].find(ctx);
-    if (it == g_match[k].end()) continue;
-    if (it->second.blob) hipFree(it->second.blob);
-    if (it->second.bytes) hipFree(it->second.bytes);
-    g_match[k].erase(it);
+    TraceBatch tb;
+    if (!reg_take(g_match[k], ctx, tb)) continue;
+    if (tb.blob) hipFree(tb.blob);
+    if (tb.bytes) hipFree(tb.bytes);
   }
 }
 }  // namespace sdso
@@ -717,8 +715,8 @@ extern "C" int sdso_stereo_match_batch(sdso_ctx* ctx, int slot_a, int slot_b, co
   SDSO_REQUIRE(ctx, M->u && M->v, "null point arrays");
   for (int i = 0; i < n; i++)
     SDSO_REQUIRE(ctx, M->u[i] >= 2 && M->v[i] >= 2 && M->u[i] < w - 3 && M->v[i] < h - 3, "immature point too close to the image border");
-  TraceBatch& A = g_match[0][ctx];
-  TraceBatch& Bk = g_match[1][ctx];
+  TraceBatch& A = reg_get(g_match[0], ctx);
+  TraceBatch& Bk = reg_get(g_match[1], ctx);
   int rc = trace_reserve(ctx, A, n);
   if (rc) return rc;
   rc = trace_reserve(ctx, Bk, n);
