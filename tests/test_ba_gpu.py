@@ -349,3 +349,30 @@ def test_ragged_and_degenerate_windows(gpu_ctx, oracle):
     x0 = np.ones(20)
     gpu_ctx.check(gpu_ctx.L.sdso_ba_solve(gpu_ctx.h, 25, 0, 0.1, abi.dp(x0), None, None, None, None))
     assert np.isfinite(x0).all() and np.allclose(x0, xo0, rtol=1e-9, atol=1e-12)     # priors only: pure double algebra on both sides
+
+
+@pytest.mark.parametrize("modes", [(-1.0, -1.0), (0.0, 0.0)])
+def test_affine_modes_in_the_window(gpu_ctx, oracle, modes):
+    """setting_affineOptModeA/B < 0 fixes the affine brightness parameters: JabF columns are zeroed in linearize (Residuals.cpp:262-263)
+    and the frame priors change (HessianBlocks.h:239-265); = 0 removes the affine prior."""
+    win = dict(synth.ba_window(w=640, h=480, nf=4, pts_per_kf=80, seed=3081))
+    win["affineOptModeA"], win["affineOptModeB"] = modes
+    W, keep, h = _both(gpu_ctx, oracle, win)
+    eo, eg, o, g = _lin_both(gpu_ctx, oracle, win, h, 3)
+    _check_lin(eo, eg, o, g)
+    if modes[0] < 0:
+        live = o["ns"] == 0
+        assert not g["J"][live][:, 46:54].any() and not g["J"][live][:, 54:62].any()      # JabF[0], JabF[1]
+    nf, npts, nr = win["nf"], win["np"], win["nr"]
+    so, io, ro, oo = np.zeros((nf, 10)), np.zeros(npts, np.float32), np.zeros(nr, np.uint8), abi.BAOptResult()
+    sg, ig, rg, og = np.zeros((nf, 10)), np.zeros(npts, np.float32), np.zeros(nr, np.uint8), abi.BAOptResult()
+    oracle.orc_ba_destroy(h)
+    W, keep, h = _both(gpu_ctx, oracle, win)
+    oracle.orc_ba_optimize(h, 4, abi.dp(so), abi.fp(io), abi.bp(ro), C.byref(oo))
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_optimize(gpu_ctx.h, 3, 4, abi.dp(sg), abi.fp(ig), abi.bp(rg), C.byref(og)))
+    oracle.orc_ba_destroy(h)
+    assert og.iterations == oo.iterations
+    # order-of-summation spread after 4 GN iterations (cf. test_optimize_full_gn_loop); states are O(1e-2)
+    assert np.abs(sg - so).max() <= 5e-4 and np.abs(ig - io).max() <= 5e-4
+    if modes[0] < 0:
+        assert np.abs(sg[:, 6:8]).max() < 1e-6 and np.allclose(sg[:, 6:8], so[:, 6:8], rtol=1e-2, atol=1e-12)   # held by the 1e14 prior

@@ -260,3 +260,25 @@ def test_track_hypotheses_in_lock_step(gpu_ctx, oracle, prob_small, prob_kitti):
         ngood += outs[k].good
     assert outs[4].good == 0 and np.array_equal(Ts[4].Rt()[0], hyps[4][3][0])      # aborted: pose untouched
     assert ngood >= 6
+
+
+@pytest.mark.parametrize("modes", [(-1.0, -1.0), (0.0, 0.0), (-1.0, 1e8), (1e12, -1.0)])
+def test_track_affine_modes(gpu_ctx, oracle, prob_small, modes):
+    """setting_affineOptModeA/B variants (main_dso_pangolin.cpp:315-338: mode 1 sets both 0, mode 2 sets both -1): the LM solves the
+    reduced 6 / 7-parameter systems (CoarseTracker.cpp:937-964) and the final affine sanity checks differ (:1050-1066)."""
+    prob = prob_small
+    _setup(gpu_ctx, prob, 1, 2)
+    prm = helpers.track_params(prob)
+    prm.affineOptModeA, prm.affineOptModeB = modes
+    To, affo, outo = helpers.oracle_track(oracle, prob, prm, (np.eye(3), np.zeros(3)), (0.0, 0.0))
+    T = abi.SE3.from_Rt(np.eye(3), np.zeros(3)); aff = abi.Aff(0, 0); out = abi.TrackResult()
+    gpu_ctx.check(gpu_ctx.L.sdso_track_newest_coarse(gpu_ctx.h, 1, 2, C.byref(prm), C.byref(T), C.byref(aff), C.byref(out)))
+    assert out.good == outo.good
+    assert list(out.iterations) == list(outo.iterations) and out.evaluations == outo.evaluations
+    R, t = T.Rt(); Ro, to = To.Rt()
+    assert np.abs(t - to).max() <= 1e-5 and np.abs(R - Ro).max() <= 1e-5
+    assert abs(aff.a - affo.a) <= 1e-5 and abs(aff.b - affo.b) <= 1e-3
+    if modes[0] < 0:
+        assert aff.a == 0.0
+    if modes[1] < 0:
+        assert aff.b == 0.0
