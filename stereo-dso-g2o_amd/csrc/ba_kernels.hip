@@ -516,24 +516,22 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_lin_fused(const BaDev* __restri
     e = linearize_one<MATERIALIZE, 2, TILED>(B, i, pair % B.nf, pair / B.nf, jl, ns, rs5);
     const int pt = B.r_point[i];
     float* rec = B.r_rec + ((size_t)pt * B.nf + pair / B.nf) * 16;
+    // the 64-byte record of this (point, target): written once, whole, at the end (four 16-byte stores of one line)
+    float o8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, rbd = 0.f, rhdd = 0.f, rhcd[4] = {0.f, 0.f, 0.f, 0.f};
+    uint8_t act = 0;
     if (st != 1) {  // applyRes(true): OOB is sticky
-      uint8_t act = 0;
       if (ns == 0) {
         act = 1;
         if (MATERIALIZE) B.r_jsel[i] ^= 1;
         const float jdd0 = JV(J_DD + 0), jdd1 = JV(J_DD + 1);
         const float v0 = JV(J_IDX2 + 0) * jdd0 + JV(J_IDX2 + 1) * jdd1;
         const float v1 = JV(J_IDX2 + 2) * jdd0 + JV(J_IDX2 + 3) * jdd1;
-        float o8[8];
 #pragma unroll
         for (int k = 0; k < 6; k++) o8[k] = JV(J_XI0 + k) * v0 + JV(J_XI1 + k) * v1;
         o8[6] = JV(J_ABIDX + 0) * jdd0 + JV(J_ABIDX + 1) * jdd1;
         o8[7] = JV(J_ABIDX + 2) * jdd0 + JV(J_ABIDX + 3) * jdd1;
-        *(float4*)(rec) = make_float4(o8[0], o8[1], o8[2], o8[3]);
-        *(float4*)(rec + 4) = make_float4(o8[4], o8[5], o8[6], o8[7]);
       }
       B.r_act[i] = act;
-      rec[RR_FLAGS] = (float)act;
       B.r_state[i] = (uint8_t)ns;
       B.r_energy[i] = B.r_newEnergy[i];
       on = act != 0;
@@ -553,10 +551,16 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_lin_fused(const BaDev* __restri
       const float jdd0 = JV(J_DD + 0), jdd1 = JV(J_DD + 1);
       const float q0 = a * jdd0 + b * jdd1;
       const float q1 = JV(J_IDX2 + 2) * jdd0 + c * jdd1;
-      rec[RR_BD] = JI_r0 * jdd0 + JI_r1 * jdd1;
-      rec[RR_HDD] = q0 * jdd0 + q1 * jdd1;
+      rbd = JI_r0 * jdd0 + JI_r1 * jdd1;
+      rhdd = q0 * jdd0 + q1 * jdd1;
 #pragma unroll
-      for (int k = 0; k < 4; k++) rec[RR_HCD + k] = x[k] * q0 + y[k] * q1;
+      for (int k = 0; k < 4; k++) rhcd[k] = x[k] * q0 + y[k] * q1;
+    }
+    if (st != 1) {   // (a sticky-OOB residual keeps the record its last applyRes wrote: flags 0)
+      *(float4*)(rec) = make_float4(o8[0], o8[1], o8[2], o8[3]);
+      *(float4*)(rec + 4) = make_float4(o8[4], o8[5], o8[6], o8[7]);
+      *(float4*)(rec + 8) = make_float4(rbd, rhdd, rhcd[0], rhcd[1]);
+      *(float4*)(rec + 12) = make_float4(rhcd[2], rhcd[3], (float)act, (float)(pair / B.nf));
     }
   }
   e = block_sum_d(e, lds);
