@@ -179,6 +179,30 @@ class TraceWorkload:
 WORKLOADS = {"tracker": TrackerWorkload, "trace": TraceWorkload}
 
 
+def side_run(cls, ctx, args, rank, steps=30, warmup=5):
+    import torch
+
+    class A:
+        batch = 0
+    wl = cls(ctx, A, rank)
+    for _ in range(warmup):
+        wl.step()
+    torch.cuda.synchronize(); ctx.sync()
+    ctx.check(ctx.L.sdso_prof_reset(ctx.h)); ctx.check(ctx.L.sdso_prof_enable(ctx.h, 1))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        wl.step()
+    torch.cuda.synchronize(); ctx.sync()
+    dt = time.perf_counter() - t0
+    ctx.check(ctx.L.sdso_prof_enable(ctx.h, 0))
+    kms, kl = ctx.prof_read(wl.kernel)
+    wl.verify()
+    avg = kms / max(kl, 1)
+    ach = wl.units_per_step * steps / max(kl, 1) * wl.bytes_per_unit / (avg * 1e-3) / 1e9 if avg > 0 else 0.0
+    return {"workload": wl.config["workload"], "value": wl.units_per_step * steps / dt, "unit": wl.unit, "ms_per_step": dt / steps * 1e3,
+            "kernel": wl.kernel, "kernel_avg_ms": avg, "roofline_frac_hbm": ach / HBM_PEAK_GBS}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -272,6 +296,10 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = wl.cpu_baseline()
             out["extra"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        if args.workload == "ba" and world == 1 and not args.no_cpu_baseline and os.environ.get("SDSO_BENCH_SKIP_OTHERS") != "1":
+            # the two other units of BASELINE.json's metric family, measured the same way in short runs (informational; the
+            # headline `value` / `roofline` above are the BA workload's)
+            out["extra"]["other_workloads"] = {name: side_run(cls, ctx, args, rank) for name, cls in WORKLOADS.items()}
         if args.workload == "ba":
             out["extra"]["ba_window_iters_per_s"] = wl.nwin * args.steps / dt   # sharded ranks work on the SAME windows
         print(json.dumps(out), flush=True)
