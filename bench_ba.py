@@ -122,6 +122,8 @@ class BAWorkload:
             G.ctx.check(G.ctx.L.sdso_ba_batch_accumulate(G.ctx.h))
             if chain:
                 G.ev.record(G.stream)                 # ... and everything enqueued below overlaps the next group's accumulate
+                # (recording already after the linearisation, with the Schur kernel in the overlapped tail, was measured
+                # slower: 0.97 vs 0.91 ms — the Schur kernel competes for HBM with the other group's linearisation)
             if G.accum is not None:
                 import torch.distributed as dist
                 with self.torch.cuda.stream(G.stream):

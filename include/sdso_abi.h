@@ -290,6 +290,10 @@ int sdso_ba_keep_projections(sdso_ctx* ctx, int win, int on);
  *   sdso_ba_batch_get_x      : lastX of every window (synchronises)                          */
 int sdso_ba_batch_create(sdso_ctx* ctx, int nwin, const int* wins);
 int sdso_ba_batch_accumulate(sdso_ctx* ctx);
+/* = sdso_ba_batch_linearize (linearizeAll + applyRes + accumulateAF) followed by sdso_ba_batch_schur (accumulateLF/SCF + folds),
+ * available separately for callers that interleave several batches on several contexts / streams */
+int sdso_ba_batch_linearize(sdso_ctx* ctx);
+int sdso_ba_batch_schur(sdso_ctx* ctx);
 /* 1 (default): every linearization writes the RawResidualJacobian records to HBM like
  * PointFrameResidual::J; 0: they stay in registers of the fused linearize+accumulate kernel. */
 int sdso_ba_batch_set_materialize(sdso_ctx* ctx, int materialize);

@@ -402,9 +402,9 @@ static void launch_sc_and_folds(sdso_ctx* ctx, const BaLaunch& L, const uint8_t*
   else hipLaunchKernelGGL(k_ba_fold_sc, dim3(nf * nf * nf + nf * nf + 1, L.nwin), dim3(64), 0, ctx->stream, L.d_arr);
 }
 // linearizeAll + applyRes + accumulateAF in one kernel, then the (normally empty) linearized pass and the Schur part
-static void launch_fused(sdso_ctx* ctx, const BaLaunch& L, bool materialize) {
+static void launch_fused(sdso_ctx* ctx, const BaLaunch& L, bool materialize, int part = 3 /* bit 0: linearize+top, bit 1: Schur+folds */) {
   const int nf = L.nf;
-  if (L.max_chunks > 0) {
+  if ((part & 1) && L.max_chunks > 0) {
     {
       ProfScope ps(ctx, "k_ba_lin_fused");
       const dim3 g(L.max_chunks, L.nwin), b(BA_BLOCK);
@@ -418,7 +418,7 @@ static void launch_fused(sdso_ctx* ctx, const BaLaunch& L, bool materialize) {
     }
   }
   // without linearized residuals the top partials are folded together with the Schur partials, after the Schur kernel
-  launch_sc_and_folds(ctx, L, nullptr, false, L.max_chunks > 0 && !L.any_lin);
+  if (part & 2) launch_sc_and_folds(ctx, L, nullptr, false, L.max_chunks > 0 && !L.any_lin);
 }
 static void launch_solve(sdso_ctx* ctx, const BaLaunch& L, double lambda, int orth) {
   const int nf = L.nf, n = L.n;
@@ -895,6 +895,23 @@ extern "C" int sdso_ba_batch_accumulate(sdso_ctx* ctx) {
   BaBatch* Bt = ctx && reg_has(g_batches, ctx) ? reg_get(g_batches, ctx) : nullptr;
   if (!Bt) return sdso::fail(ctx, SDSO_ERR_STATE, "no batch");
   launch_fused(ctx, Bt->L, Bt->materialize);
+  SDSO_HIP(ctx, hipGetLastError());
+  return SDSO_OK;
+}
+// the two halves of sdso_ba_batch_accumulate as separate enqueues, for callers that overlap batches on several streams: the
+// bandwidth-bound linearisation of one batch is best followed immediately by the linearisation of the next one, with the Schur
+// accumulation and the folds of the first running underneath it
+extern "C" int sdso_ba_batch_linearize(sdso_ctx* ctx) {
+  BaBatch* Bt = ctx && reg_has(g_batches, ctx) ? reg_get(g_batches, ctx) : nullptr;
+  if (!Bt) return sdso::fail(ctx, SDSO_ERR_STATE, "no batch");
+  launch_fused(ctx, Bt->L, Bt->materialize, 1);
+  SDSO_HIP(ctx, hipGetLastError());
+  return SDSO_OK;
+}
+extern "C" int sdso_ba_batch_schur(sdso_ctx* ctx) {
+  BaBatch* Bt = ctx && reg_has(g_batches, ctx) ? reg_get(g_batches, ctx) : nullptr;
+  if (!Bt) return sdso::fail(ctx, SDSO_ERR_STATE, "no batch");
+  launch_fused(ctx, Bt->L, Bt->materialize, 2);
   SDSO_HIP(ctx, hipGetLastError());
   return SDSO_OK;
 }

@@ -243,6 +243,8 @@ def load():
     L.sdso_ba_keep_projections.argtypes = [vp, C.c_int, C.c_int]
     L.sdso_ba_batch_create.argtypes = [vp, C.c_int, c_int_p]
     L.sdso_ba_batch_accumulate.argtypes = [vp]
+    L.sdso_ba_batch_linearize.argtypes = [vp]
+    L.sdso_ba_batch_schur.argtypes = [vp]
     L.sdso_ba_batch_set_materialize.argtypes = [vp, C.c_int]
     L.sdso_ba_batch_solve.argtypes = [vp, C.c_double, C.c_int]
     L.sdso_ba_batch_accum_dev.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_long)]
@@ -279,7 +281,7 @@ EXPORTED_SYMBOLS = [
     "sdso_ba_keep_projections", "sdso_ba_batch_create", "sdso_ba_batch_accumulate", "sdso_ba_batch_solve",
     "sdso_ba_batch_accum_dev", "sdso_ba_batch_get_x", "sdso_ba_batch_set_materialize",
     "sdso_immature_init_batch", "sdso_trace_stereo_batch", "sdso_trace_stereo_prepare", "sdso_trace_stereo_enqueue",
-    "sdso_trace_stereo_fetch", "sdso_stereo_match_batch", "sdso_activate_points_batch", "sdso_ba_marginalize_frame", "sdso_pixel_select", "sdso_pixel_selector_pattern", "sdso_trace_on_batch", "sdso_track_make_ref", "sdso_track_newest_coarse_batch", "sdso_track_get_ref",
+    "sdso_trace_stereo_fetch", "sdso_stereo_match_batch", "sdso_activate_points_batch", "sdso_ba_marginalize_frame", "sdso_ba_batch_linearize", "sdso_ba_batch_schur", "sdso_pixel_select", "sdso_pixel_selector_pattern", "sdso_trace_on_batch", "sdso_track_make_ref", "sdso_track_newest_coarse_batch", "sdso_track_get_ref",
 ]
 
 
