@@ -279,7 +279,7 @@ extern "C" int sdso_ba_upload_window(sdso_ctx* ctx, int win, const sdso_ba_windo
   const float4** d_img; DM(d_img, const float4*, nf);
   int4* d_chunks; int* d_pair_beg; int4* d_items; int* d_host_beg;
   DM(d_chunks, int4, chunks.size()); DM(d_pair_beg, int, nf * nf + 1); DM(d_items, int4, items.size()); DM(d_host_beg, int, nf + 1);
-  DM(d.top_part, float, (size_t)d.nchunks * 92); DM(d.sc_part, float, (size_t)d.nitems * sc_part_floats(nf)); DM(d.e_part, double, std::max(W->nblk_res, d.nchunks) + 1);
+  DM(d.top_part, float, (size_t)d.nchunks * 92); DM(d.sc_part, float, std::max((size_t)d.nitems * sc_part_floats(nf), (size_t)nf * 20)); DM(d.e_part, double, std::max(W->nblk_res, d.nchunks) + 1);
   DM(d.accum, float, acc_floats(nf));
   DM(d.sol, double, 4 * ((size_t)n * n + n) + n);
   DM(W->d_pflag, uint8_t, np); DM(W->d_sums, float, 2 * (W->nblk_pts + 1));
@@ -382,12 +382,21 @@ static void launch_accumulate(sdso_ctx* ctx, const BaLaunch& L, const uint8_t* p
 }
 static void launch_sc_and_folds(sdso_ctx* ctx, const BaLaunch& L, const uint8_t* pflag, bool marg, bool fold_top_too) {
   const int nf = L.nf;
+  const int shift = marg ? 0 : 1, mm = marg ? 1 : 0;
+  static const int sc_variant = getenv("SDSO_SC_REG") ? 2 : getenv("SDSO_SC_ITEMS") ? 1 : 0;   // 0: one workgroup per host (default); 1: per-item MFMA; 2: VALU register tiles
+  if (sc_variant == 0) {
+    {
+      ProfScope ps(ctx, "k_ba_sc");
+      hipLaunchKernelGGL(k_ba_sc_host, dim3(nf, L.nwin), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr, pflag, shift, mm);
+    }
+    if (fold_top_too) hipLaunchKernelGGL(k_ba_fold_all, dim3(1 + 2 * nf * nf, L.nwin), dim3(128), 0, ctx->stream, L.d_arr, 1);
+    else hipLaunchKernelGGL(k_ba_fold_hcc, dim3(1, L.nwin), dim3(64), 0, ctx->stream, L.d_arr);
+    return;
+  }
   if (L.max_items > 0) {
     ProfScope ps(ctx, "k_ba_sc");
     const dim3 grid((L.max_items + BA_BLOCK / 64 - 1) / (BA_BLOCK / 64), L.nwin), blk(BA_BLOCK);
-    const int shift = marg ? 0 : 1, mm = marg ? 1 : 0;
-    static const bool use_reg = getenv("SDSO_SC_REG") != nullptr;   // experiment: the VALU register-tile variant
-    if (!use_reg) {
+    if (sc_variant == 1) {
       hipLaunchKernelGGL(k_ba_sc_mfma, grid, blk, 0, ctx->stream, L.d_arr, pflag, shift, mm);
     } else {
       switch (nf) {
@@ -398,7 +407,7 @@ static void launch_sc_and_folds(sdso_ctx* ctx, const BaLaunch& L, const uint8_t*
       }
     }
   }
-  if (fold_top_too) hipLaunchKernelGGL(k_ba_fold_all, dim3(nf * nf * nf + 3 * nf * nf + 1, L.nwin), dim3(128), 0, ctx->stream, L.d_arr);
+  if (fold_top_too) hipLaunchKernelGGL(k_ba_fold_all, dim3(nf * nf * nf + 3 * nf * nf + 1, L.nwin), dim3(128), 0, ctx->stream, L.d_arr, 0);
   else hipLaunchKernelGGL(k_ba_fold_sc, dim3(nf * nf * nf + nf * nf + 1, L.nwin), dim3(64), 0, ctx->stream, L.d_arr);
 }
 // linearizeAll + applyRes + accumulateAF in one kernel, then the (normally empty) linearized pass and the Schur part

@@ -888,4 +888,160 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_sc_mfma(const BaDev* __restrict
   }
 }
 
+
+// ------------------------------------------------------------------ Schur accumulation, one workgroup per host frame
+// Same arithmetic as k_ba_sc_mfma (phase 1 per-point terms, phase 2 Z^T diag(HdiF) Z on the matrix cores), but the four waves
+// of a workgroup share ALL points of one host (64-point slices dealt round-robin), add their 21 accumulator tiles through LDS
+// in a fixed order (3+2 -> 1+0 -> 0) and wave 0 writes the host's accD / accE / accEB bins straight into the packed accumulator
+// block: no per-item partials in HBM and no fold pass.  Only Hcc / bc (sums over ALL hosts) leave a 20-float partial per host.
+__global__ __launch_bounds__(BA_BLOCK) void k_ba_sc_host(const BaDev* __restrict__ wins, const uint8_t* __restrict__ pflag, int shiftPriorToZero, int margMode) {
+  const BaDev& B = wins[blockIdx.y];
+  const int nf = B.nf, h = blockIdx.x;
+  if (h >= nf) return;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  __shared__ float pt_all[BA_BLOCK / 64][64][8];
+  __shared__ float tiles[2][21 * 256];                  // two waves' worth of accumulator tiles
+  float (*pt)[8] = pt_all[wv];
+  const int ib = B.host_item_beg[h], ie = B.host_item_beg[h + 1];
+  const int pb = ib < ie ? B.items[ib].y : 0, pe = ib < ie ? B.items[ie - 1].z : 0;
+  te_f4 acc[4][5], acc44 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int a = 0; a < 4; a++)
+#pragma unroll
+    for (int b = 0; b < 5; b++) acc[a][b] = (te_f4){0.f, 0.f, 0.f, 0.f};
+  const int ci = lane & 15, kq = lane >> 4;
+  const int tsub = ci >> 3, asub = ci & 7;
+  for (int p0 = pb + 64 * wv; p0 < pe; p0 += 64 * (BA_BLOCK / 64)) {
+    const int npts = min(64, pe - p0);
+    {  // phase 1: per-point terms, lane = point (identical to k_ba_sc_mfma)
+      float HdiF = 0.f, bdSumF = 0.f, Hcd[4] = {0.f, 0.f, 0.f, 0.f};
+      int mbits = 0;
+      if (lane < npts) {
+        const int p = p0 + lane;
+        const float prior = B.p_prior[p], delta = B.p_delta[p];
+        const float onf = (pflag ? (int)pflag[p] : 1) ? 1.f : 0.f;
+        const float* base = B.r_rec + (size_t)p * nf * 16;
+        float Hdd_A = 0, bd_A = 0, Hdd_L = 0, bd_L = 0, HcdA[4] = {0, 0, 0, 0}, HcdL[4] = {0, 0, 0, 0};
+        float ngood = 0;
+        for (int t = 0; t < nf; t++) {
+          const float4 q0 = *(const float4*)(base + t * 16 + 8);
+          const float4 q1 = *(const float4*)(base + t * 16 + 12);
+          const int fl = (int)q1.z;
+          const float m = ((fl & 1) ? 1.f : 0.f) * onf;
+          const float mA = (!(fl & 2) && !margMode) ? m : 0.f, mL = m - mA;
+          const float rh[4] = {q0.z, q0.w, q1.x, q1.y};
+          ngood += m;
+          if (m != 0.f) mbits |= 1 << t;
+          bd_A += mA != 0.f ? q0.x : 0.f; Hdd_A += mA != 0.f ? q0.y : 0.f;
+          bd_L += mL != 0.f ? q0.x : 0.f; Hdd_L += mL != 0.f ? q0.y : 0.f;
+#pragma unroll
+          for (int k = 0; k < 4; k++) { HcdA[k] += mA != 0.f ? rh[k] : 0.f; HcdL[k] += mL != 0.f ? rh[k] : 0.f; }
+        }
+        float H = Hdd_A + Hdd_L + prior;
+        if (H < 1e-10) H = 1e-10;
+        const float hdi = 1.0 / H;
+        float bds = bd_A + bd_L;
+        if (shiftPriorToZero) bds += prior * delta;
+        const bool any = ngood > 0.f;
+        HdiF = any ? hdi : 0.f; bdSumF = any ? bds : 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; k++) Hcd[k] = any ? HcdA[k] + HcdL[k] : 0.f;
+        if (onf != 0.f) {
+          float* po = B.p_out + (size_t)p * 16;
+          *(float4*)(po + 0) = make_float4(Hdd_A, bd_A, HcdA[0], HcdA[1]);
+          *(float4*)(po + 4) = make_float4(HcdA[2], HcdA[3], Hdd_L, bd_L);
+          *(float4*)(po + 8) = make_float4(HcdL[0], HcdL[1], HcdL[2], HcdL[3]);
+          po[PO_HDI] = HdiF; po[PO_BDSUM] = bdSumF;
+        }
+      }
+      *(float4*)(&pt[lane][0]) = make_float4(HdiF, bdSumF, Hcd[0], Hcd[1]);
+      *(float4*)(&pt[lane][4]) = make_float4(Hcd[2], Hcd[3], __int_as_float(mbits), 0.f);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int g = 0; g < npts; g += 4) {   // phase 2
+      const int q = g + kq;
+      const float4 h0 = *(const float4*)(&pt[q][0]);
+      const float4 h1 = *(const float4*)(&pt[q][4]);
+      const int mb = __float_as_int(h1.z);
+      const float* base = B.r_rec + (size_t)(p0 + (q < npts ? q : 0)) * nf * 16 + asub;
+      float z[5], za[5];
+#pragma unroll
+      for (int tt = 0; tt < 4; tt++) {
+        const int t = 2 * tt + tsub;
+        z[tt] = ((mb >> t) & 1) ? base[t * 16] : 0.f;
+      }
+      z[4] = ci == 0 ? h0.z : ci == 1 ? h0.w : ci == 2 ? h1.x : ci == 3 ? h1.y : ci == 4 ? h0.y : 0.f;
+#pragma unroll
+      for (int tt = 0; tt < 5; tt++) za[tt] = h0.x * z[tt];
+#pragma unroll
+      for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 5; b++) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(za[a], z[b], acc[a][b], 0, 0, 0);
+      acc44 = __builtin_amdgcn_mfma_f32_16x16x4f32(za[4], z[4], acc44, 0, 0, 0);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();          // the next slice overwrites pt[]
+  }
+  // ---- fixed-order tree over the four waves: (3 -> 1, 2 -> 0), then (1 -> 0)
+  auto put = [&](float* dst) {
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+      for (int b = 0; b < 5; b++)
+#pragma unroll
+        for (int v = 0; v < 4; v++) dst[((a * 5 + b) * 4 + v) * 64 + lane] = acc[a][b][v];
+#pragma unroll
+    for (int v = 0; v < 4; v++) dst[(80 + v) * 64 + lane] = acc44[v];
+  };
+  auto add = [&](const float* src) {
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+      for (int b = 0; b < 5; b++)
+#pragma unroll
+        for (int v = 0; v < 4; v++) acc[a][b][v] += src[((a * 5 + b) * 4 + v) * 64 + lane];
+#pragma unroll
+    for (int v = 0; v < 4; v++) acc44[v] += src[(80 + v) * 64 + lane];
+  };
+  if (wv >= 2) put(tiles[wv - 2]);
+  __syncthreads();
+  if (wv < 2) add(tiles[wv]);
+  __syncthreads();
+  if (wv == 1) put(tiles[0]);
+  __syncthreads();
+  if (wv != 0) return;
+  add(tiles[0]);
+  // ---- wave 0: the host's bins.  acc[a][b][v] = D'[16a + 4*kq + v][16b + ci]
+  const int nf2 = nf * nf;
+  float* accD = B.accum + acc_off_D(nf);
+  float* accE = B.accum + acc_off_E(nf);
+  float* accEB = B.accum + acc_off_EB(nf);
+#pragma unroll
+  for (int a = 0; a < 4; a++) {
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+      const int Rr = 16 * a + 4 * kq + v, t1 = Rr >> 3, ra = Rr & 7;
+      if (t1 < nf) {
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+          const int Cc = 16 * b + ci, t2 = Cc >> 3, cc = Cc & 7;
+          if (t2 < nf) accD[(size_t)(h + t1 * nf + t2 * nf2) * 64 + ra * 8 + cc] = acc[a][b][v];
+        }
+        if (ci < 4) accE[(size_t)(h + t1 * nf) * 32 + ra * 4 + ci] = acc[a][4][v];
+        if (ci == 4) accEB[(size_t)(h + t1 * nf) * 8 + ra] = acc[a][4][v];
+      }
+    }
+  }
+  float* hp = B.sc_part + (size_t)h * 20;      // Hcc (16) and bc (4) of this host; k_ba_fold_all adds the hosts
+  if (kq == 0) {
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+      if (ci < 4) hp[v * 4 + ci] = acc44[v];
+      if (ci == 4) hp[16 + v] = acc44[v];
+    }
+  }
+}
+
 }  // namespace sdso

@@ -45,13 +45,23 @@ __device__ __forceinline__ void fold_sc_body(const BaDev& B, int b, int lane) {
 }
 
 __global__ __launch_bounds__(64) void k_ba_fold_sc(const BaDev* __restrict__ wins) { fold_sc_body(wins[blockIdx.y], blockIdx.x, threadIdx.x); }
+// Hcc / bc after k_ba_sc_host: nf per-host partials of 20 floats
+__device__ __forceinline__ void fold_hcc_hosts(const BaDev& B, int lane) {
+  if (lane < 20) {
+    float s = 0;
+    for (int h = 0; h < B.nf; h++) s += B.sc_part[(size_t)h * 20 + lane];
+    B.accum[acc_off_Hcc(B.nf) + lane] = s;
+  }
+}
+__global__ __launch_bounds__(64) void k_ba_fold_hcc(const BaDev* __restrict__ wins) { fold_hcc_hosts(wins[blockIdx.y], threadIdx.x); }
 // every fold of one accumulate phase in ONE launch (the usual case: no linearized residuals, topL is just cleared):
 // grid.x = [nf^3 + nf^2 + 1 Schur bins | nf^2 top-A pairs | nf^2 top-L pairs], 128 threads
-__global__ __launch_bounds__(128) void k_ba_fold_all(const BaDev* __restrict__ wins) {
+// host_sc != 0: the Schur bins were written by k_ba_sc_host, only Hcc / bc remain (grid.x = 1 + 2 nf^2)
+__global__ __launch_bounds__(128) void k_ba_fold_all(const BaDev* __restrict__ wins, int host_sc) {
   const BaDev& B = wins[blockIdx.y];
-  const int nf = B.nf, nf2 = nf * nf, nsc = nf2 * nf + nf2 + 1;
+  const int nf = B.nf, nf2 = nf * nf, nsc = host_sc ? 1 : nf2 * nf + nf2 + 1;
   const int b = blockIdx.x;
-  if (b < nsc) { if (threadIdx.x < 64) fold_sc_body(B, b, threadIdx.x); }
+  if (b < nsc) { if (host_sc) fold_hcc_hosts(B, threadIdx.x); else if (threadIdx.x < 64) fold_sc_body(B, b, threadIdx.x); }
   else if (b < nsc + nf2) fold_top_body(B, b - nsc, 0, threadIdx.x);
   else zero_topL_body(B, b - nsc - nf2, threadIdx.x);
 }
