@@ -148,7 +148,7 @@ extern "C" int sdso_ba_release_window(sdso_ctx* ctx, int win) {
   return SDSO_OK;
 }
 
-extern "C" int sdso_ba_upload_window(sdso_ctx* ctx, int win, const sdso_ba_window_t* Win) {
+static int upload_window_impl(sdso_ctx* ctx, int win, const sdso_ba_window_t* Win) {
   if (!ctx) return SDSO_ERR_STATE;
   SDSO_HIP(ctx, hipSetDevice(ctx->device));
   SDSO_REQUIRE(ctx, Win, "null window");
@@ -335,6 +335,16 @@ extern "C" int sdso_ba_upload_window(sdso_ctx* ctx, int win, const sdso_ba_windo
   }
   SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return upload_tables(ctx, W, true);
+}
+// a window that failed half-way through its upload must not stay registered (later calls would launch on null arrays)
+extern "C" int sdso_ba_upload_window(sdso_ctx* ctx, int win, const sdso_ba_window_t* Win) {
+  const int rc = upload_window_impl(ctx, win, Win);
+  if (rc && ctx) {
+    const std::string why = ctx->err;
+    sdso_ba_release_window(ctx, win);
+    ctx->err = why;
+  }
+  return rc;
 }
 
 // optional: keep projectedTo / centerProjectedTo (tests); costs 76 B of stores per residual

@@ -162,6 +162,7 @@ def test_solve_requires_accumulate_and_arg_errors(gpu_ctx, oracle, win_small):
     bad["host"] = win_small["host"][::-1].copy()      # not in allPoints order
     Wb, kb = abi.make_ba_window(bad, frame_slots=[40 + f for f in range(bad["nf"])])
     assert gpu_ctx.L.sdso_ba_upload_window(gpu_ctx.h, 6, C.byref(Wb)) == -1
+    assert gpu_ctx.L.sdso_ba_linearize(gpu_ctx.h, 6, None) == -1          # a refused upload leaves no half-built window behind
     gpu_ctx.check(gpu_ctx.L.sdso_ba_release_window(gpu_ctx.h, 5))
 
 
@@ -376,3 +377,48 @@ def test_affine_modes_in_the_window(gpu_ctx, oracle, modes):
     assert np.abs(sg - so).max() <= 5e-4 and np.abs(ig - io).max() <= 5e-4
     if modes[0] < 0:
         assert np.abs(sg[:, 6:8]).max() < 1e-6 and np.allclose(sg[:, 6:8], so[:, 6:8], rtol=1e-2, atol=1e-12)   # held by the 1e14 prior
+
+
+def test_full_size_window_properties(gpu_ctx):
+    """BASELINE configs[4] size (8 keyframes x ~8000 points, ~50k residuals), checked through size-independent properties instead of
+    the oracle: (1) the packed accumulators of two half-windows (contiguous point ranges, as on two ranks) add up to those of the whole window —
+    the invariant the multi-GPU sharding rests on; (2) solving from the summed shards gives the x of the whole window; (3) the
+    stitched system is symmetric and its Schur part shrinks the top part (H - Hsc stays positive on the diagonal)."""
+    from sdso_amd import dist as sd
+    win = synth.ba_window(w=1232, h=368, nf=8, pts_per_kf=1000, seed=3101)
+    nf, n = win["nf"], 68
+    assert win["np"] == 8000 and win["nr"] > 45000
+    for f in range(nf):
+        gpu_ctx.upload_pyramid(400 + f, win["pyrs"][f][:1])
+    slots = [400 + f for f in range(nf)]
+    na = abi.accum_floats(nf)
+
+    def run(w, wid):
+        W, keep = abi.make_ba_window(w, frame_slots=slots)
+        gpu_ctx.check(gpu_ctx.L.sdso_ba_upload_window(gpu_ctx.h, wid, C.byref(W)))
+        gpu_ctx.check(gpu_ctx.L.sdso_ba_linearize(gpu_ctx.h, wid, None))
+        gpu_ctx.check(gpu_ctx.L.sdso_ba_apply_res(gpu_ctx.h, wid))
+        gpu_ctx.check(gpu_ctx.L.sdso_ba_accumulate(gpu_ctx.h, wid))
+        a = np.zeros(na, np.float32)
+        gpu_ctx.check(gpu_ctx.L.sdso_ba_get_accumulators(gpu_ctx.h, wid, abi.fp(a)))
+        return a
+
+    whole = run(win, 50)
+    x = np.zeros(n); H = np.zeros((n, n)); b = np.zeros(n)
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_solve(gpu_ctx.h, 50, 0, 0.1, abi.dp(x), abi.dp(H), abi.dp(b), None, None))
+    parts = [run(sd.shard_window(win, r, 2)[0], 51 + r) for r in range(2)]
+    ssum = parts[0] + parts[1]
+    scale = np.maximum(np.abs(whole), 1e-30)
+    blocks = [(0, nf * nf * 91 * 2, 91), (nf * nf * 91 * 2, nf * nf * 91 * 2 + nf ** 3 * 64, 64)]
+    for lo, hi, wdt in blocks:                                                 # per accumulator block, relative to its largest entry
+        A = whole[lo:hi].reshape(-1, wdt); S = ssum[lo:hi].reshape(-1, wdt)
+        m = np.abs(A).max(axis=1, keepdims=True)
+        assert np.array_equal(m == 0, np.abs(S).max(axis=1, keepdims=True) == 0)
+        assert (np.abs(A - S) / np.maximum(m, 1e-30)).max() <= 5e-5
+    assert np.array_equal(whole[-2:], ssum[-2:])                               # residual counts are exact
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_set_accumulators(gpu_ctx.h, 51, abi.fp(ssum)))
+    xs = np.zeros(n)
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_solve(gpu_ctx.h, 51, 0, 0.1, abi.dp(xs), None, None, None, None))
+    d = np.sqrt(np.abs(np.diag(H))) + 1e-30
+    assert np.abs((xs - x) * d).max() <= 2e-4 * max(1.0, np.abs(x * d).max())
+    assert np.abs(H - H.T).max() <= 1e-9 * np.abs(H).max() and (np.diag(H) > 0).all() and np.isfinite(x).all()

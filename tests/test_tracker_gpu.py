@@ -282,3 +282,33 @@ def test_track_affine_modes(gpu_ctx, oracle, prob_small, modes):
         assert aff.a == 0.0
     if modes[1] < 0:
         assert aff.b == 0.0
+
+
+def test_full_size_linearity(gpu_ctx, prob_kitti):
+    """configs[1] size, a size-independent property: calcRes+calcGSSSE is a sum over template points, so the un-normalised Hessian
+    n*H, n*b and the energy of a template equal the sums over its two halves (even / odd points), and the inlier counts add."""
+    prob = prob_kitti
+    gpu_ctx.upload_pyramid(4, prob["pyr_new"])
+    prm = helpers.track_params(prob)
+    T = synth.se3_exp(np.array(prob_motion()))
+    for lvl in (0, 2):
+        pc = prob["pc"][lvl]
+        halves = [{k: v[i::2] for k, v in pc.items()} for i in range(2)]
+        res = []
+        for slot, sub in ((70, pc), (71, halves[0]), (72, halves[1])):
+            pcs = [dict(u=np.zeros(0, np.float32), v=np.zeros(0, np.float32), idepth=np.zeros(0, np.float32), color=np.zeros(0, np.float32))] * prob["levels"]
+            pcs = list(pcs); pcs[lvl] = sub
+            gpu_ctx.set_ref(slot, pcs)
+            ev = abi.TrackEval()
+            gpu_ctx.L.sdso_track_make_eval(C.byref(prm), lvl, C.byref(abi.SE3.from_Rt(*T)), C.byref(abi.Aff(0.02, 1.0)), 1.0, C.byref(ev))
+            H = np.zeros(64); b = np.zeros(8); r = np.zeros(6); nw = C.c_int(0); mask = np.zeros(len(sub["u"]), np.uint8)
+            gpu_ctx.check(gpu_ctx.L.sdso_track_calc_res_gs(gpu_ctx.h, slot, 4, C.byref(ev), abi.dp(H), abi.dp(b), abi.dp(r), C.byref(nw), abi.bp(mask)))
+            n_in = int(mask.sum())
+            res.append((H * n_in, b * n_in, r[0], r[1], n_in, mask))
+        (Hf, bf, Ef, nf_, cf, mf), (Ha, ba, Ea, na, ca, ma), (Hb, bb, Eb, nb, cb, mb) = res
+        assert cf == ca + cb and nf_ == na + nb
+        assert np.array_equal(mf[0::2], ma) and np.array_equal(mf[1::2], mb)                 # the same points are inliers
+        assert abs(Ef - (Ea + Eb)) <= 2e-5 * Ef
+        assert np.abs(Hf - (Ha + Hb)).max() <= 5e-5 * np.abs(Hf).max()
+        d = np.sqrt(np.abs(np.diag(Hf.reshape(8, 8)))) + 1e-30
+        assert np.abs((bf - (ba + bb)) / d).max() <= 5e-5 * max(1.0, np.abs(bf / d).max())
