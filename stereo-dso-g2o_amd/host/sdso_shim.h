@@ -297,4 +297,58 @@ inline void traceStereoAll(Device& dev, std::vector<ImmaturePointT*>& pts, int f
   }
 }
 
+
+// =================================================================================== per-keyframe steps
+// PixelSelector (src/FullSystem/PixelSelector2.h): int makeMaps(const FrameHessian* fh, float* map_out, float density,
+// int recursionsLeft = 1, bool plot = false, float thFactor = 1); currentPotential is the public member the callers reset.
+class PixelSelector {
+ public:
+  explicit PixelSelector(Device& dev) : dev_(dev) {}
+  int currentPotential = 3;
+  int makeMaps(int frame_slot, float* map_out, float density, int recursionsLeft = 1, bool /*plot*/ = false, float thFactor = 1) {
+    int n = 0;
+    dev_.check(sdso_pixel_select(dev_.ctx(), frame_slot, density, recursionsLeft, thFactor, &currentPotential, map_out, &n), "sdso_pixel_select");
+    return n;
+  }
+
+ private:
+  Device& dev_;
+};
+
+// ImmaturePoint::traceOn for all immature points of all host keyframes in the newest frame (FullSystem::traceNewCoarseKey / NonKey,
+// FullSystem.cpp:632-790).  geom[h] = {KRKi, Kt, aff} of host h as computed at :654-665; host_of[i] selects it.
+template <class ImmaturePointT>
+inline void traceOnAll(Device& dev, std::vector<ImmaturePointT*>& pts, const std::vector<int>& host_of, const std::vector<sdso_trace_geom_t>& geom,
+                       int frame_slot, std::vector<uint8_t>& status_out) {
+  const int n = (int)pts.size();
+  std::vector<float> us(n), vs(n), imin(n), imax(n), col(n * 8), wgt(n * 8), gH(n * 4), eth(n), q(n), uv(n * 2), itv(n);
+  std::vector<uint8_t> lts(n);
+  for (int i = 0; i < n; i++) {
+    const ImmaturePointT* p = pts[i];
+    us[i] = p->u; vs[i] = p->v; imin[i] = p->idepth_min; imax[i] = p->idepth_max; eth[i] = p->energyTH; q[i] = p->quality;
+    lts[i] = (uint8_t)p->lastTraceStatus; uv[2 * i] = p->lastTraceUV[0]; uv[2 * i + 1] = p->lastTraceUV[1]; itv[i] = p->lastTracePixelInterval;
+    for (int k = 0; k < 8; k++) { col[i * 8 + k] = p->color[k]; wgt[i * 8 + k] = p->weights[k]; }
+    gH[i * 4 + 0] = p->gradH(0, 0); gH[i * 4 + 1] = p->gradH(0, 1); gH[i * 4 + 2] = p->gradH(1, 0); gH[i * 4 + 3] = p->gradH(1, 1);
+  }
+  sdso_trace_points_t P{n, us.data(), vs.data(), nullptr, imin.data(), imax.data(), nullptr, col.data(), wgt.data(), gH.data(), eth.data(),
+                        q.data(), lts.data(), uv.data(), itv.data()};
+  status_out.assign(n, 0);
+  dev.check(sdso_trace_on_batch(dev.ctx(), frame_slot, (int)geom.size(), geom.data(), host_of.data(), &P, status_out.data()), "sdso_trace_on_batch");
+  for (int i = 0; i < n; i++) {
+    ImmaturePointT* p = pts[i];
+    p->idepth_min = imin[i]; p->idepth_max = imax[i]; p->quality = q[i];
+    p->lastTraceStatus = static_cast<decltype(p->lastTraceStatus)>(lts[i]);
+    p->lastTraceUV[0] = uv[2 * i]; p->lastTraceUV[1] = uv[2 * i + 1]; p->lastTracePixelInterval = itv[i];
+  }
+}
+
+// EnergyFunctional::marginalizeFrame's algebra (EnergyFunctional.cpp:554-660) on plain row-major arrays
+inline void marginalizeFrame(int nFrames, int idx, const double* prior8, const double* delta_prior8, std::vector<double>& HM, std::vector<double>& bM) {
+  const int m = 8 * (nFrames - 1) + 4;
+  std::vector<double> Ho((size_t)m * m), bo(m);
+  if (sdso_ba_marginalize_frame(nFrames, idx, prior8, delta_prior8, HM.data(), bM.data(), Ho.data(), bo.data()) != SDSO_OK)
+    throw Error("sdso_ba_marginalize_frame: bad arguments");
+  HM.swap(Ho); bM.swap(bo);
+}
+
 }  // namespace sdso_shim

@@ -3,7 +3,7 @@
 // writes a problem as raw arrays into a directory, runs this program on the GPU box and compares
 // what it prints with the same problem pushed through the C-ABI from Python.
 //
-//   test_shim <dir> tracker|stereo|ba
+//   test_shim <dir> tracker|stereo|ba|selector
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -61,10 +61,14 @@ struct DynMat {
 };
 struct EnergyFunctional { std::vector<EFFrame*> frames; DynMat HM; std::vector<double> bM; };
 struct ImmaturePoint {
+  float u, v, idepth_max;
   float u_stereo, v_stereo, idepth_min, idepth_min_stereo, idepth_max_stereo, idepth_stereo, energyTH, quality, color[8], weights[8];
   Mat22f gradH; int lastTraceStatus; float lastTraceUV[2]; float lastTracePixelInterval;
 };
 struct Vec5 { double v[5]; double operator[](int i) const { return v[i]; } };
+// compile the temporal-trace wrapper against the stand-in as well (it is exercised through the C-ABI in tests/test_stereo.py)
+template void sdso_shim::traceOnAll<ImmaturePoint>(sdso_shim::Device&, std::vector<ImmaturePoint*>&, const std::vector<int>&, const std::vector<sdso_trace_geom_t>&, int,
+                                                   std::vector<uint8_t>&);
 
 static void load_pyramid(const std::string& dir, const char* prefix, FrameHessian& fh, int levels) {
   fh.store.resize(levels);
@@ -204,6 +208,30 @@ static int run_ba(const std::string& dir) {
   return 0;
 }
 
+static int run_selector(const std::string& dir) {
+  auto meta = load<int>(dir, "meta");             // w, h, levels, potential, recursions
+  auto par = load<float>(dir, "par");             // density, thFactor
+  FrameHessian fr; load_pyramid(dir, "img", fr, meta[2]);
+  sdso_shim::Device dev(0);
+  int w[SDSO_PYR_LEVELS], h[SDSO_PYR_LEVELS];
+  for (int l = 0; l < meta[2]; l++) { w[l] = meta[0] >> l; h[l] = meta[1] >> l; }
+  dev.uploadFrame(7, &fr, meta[2], w, h);
+  sdso_shim::PixelSelector sel(dev);
+  sel.currentPotential = meta[3];
+  std::vector<float> map((size_t)meta[0] * meta[1]);
+  const int n = sel.makeMaps(7, map.data(), par[0], meta[4], false, par[1]);
+  unsigned long long sum = 0; long cnt[5] = {0, 0, 0, 0, 0};
+  for (size_t i = 0; i < map.size(); i++) { const int v = (int)map[i]; cnt[v]++; sum = sum * 1000003ull + (unsigned long long)(v * 7 + 1) * (i + 1); }
+  std::printf("n %d potential %d c1 %ld c2 %ld c4 %ld hash %llu\n", n, sel.currentPotential, cnt[1], cnt[2], cnt[4], sum);
+  // marginalizeFrame through the shim on a small SPD prior
+  std::vector<double> HM(20 * 20, 0.0), bM(20);
+  for (int i = 0; i < 20; i++) { bM[i] = 0.1 * (i + 1); for (int j = 0; j < 20; j++) HM[i * 20 + j] = (i == j ? 50.0 + i : 1.0 / (1 + i + j)); }
+  const double prior[8] = {1e3, 0, 1e3, 0, 1e2, 0, 1e6, 1e6}, dprior[8] = {1e-3, 0, -2e-3, 0, 1e-3, 0, 1e-4, -1e-4};
+  sdso_shim::marginalizeFrame(2, 0, prior, dprior, HM, bM);
+  std::printf("marg %zu %zu %.17g %.17g\n", HM.size(), bM.size(), HM[0], bM[11]);
+  return 0;
+}
+
 int main(int argc, char** argv) {
   if (argc < 3) { std::fprintf(stderr, "usage: test_shim <dir> tracker|stereo|ba\n"); return 2; }
   try {
@@ -211,6 +239,7 @@ int main(int argc, char** argv) {
     if (what == "tracker") return run_tracker(argv[1]);
     if (what == "stereo") return run_stereo(argv[1]);
     if (what == "ba") return run_ba(argv[1]);
+    if (what == "selector") return run_selector(argv[1]);
   } catch (const std::exception& e) { std::fprintf(stderr, "error: %s\n", e.what()); return 1; }
   return 2;
 }

@@ -120,3 +120,32 @@ def test_shim_windowed_ba(gpu_ctx, tmp_path):
     assert np.array_equal(st, sg)
     assert np.array_equal(np.array(lines[1 + nf].split()[1:], np.float32), ig)
     assert np.array_equal(np.array(lines[2 + nf].split()[1:], np.uint8), rg)
+
+
+@pytest.mark.gpu
+def test_shim_selector_and_marginalize_frame(gpu_ctx, tmp_path):
+    prob = synth.tracker_problem(w=640, h=480, npts=50, seed=7)
+    pyr = prob["pyr_ref"]
+    gpu_ctx.upload_pyramid(91, pyr)
+    m = np.zeros((480, 640), np.float32); p = C.c_int(3); n = C.c_int(0)
+    gpu_ctx.check(gpu_ctx.L.sdso_pixel_select(gpu_ctx.h, 91, 1500.0, 1, 1.0, C.byref(p), abi.fp(m), C.byref(n)))
+    arrays = dict(meta=np.array([640, 480, prob["levels"], 3, 1], np.int32), par=np.array([1500.0, 1.0], np.float32))
+    for l in range(prob["levels"]):
+        arrays["img_l%d" % l] = pyr[l]
+    _dump(tmp_path, **arrays)
+    lines = _run(tmp_path, "selector")
+    f = lines[0].split()
+    assert int(f[1]) == n.value and int(f[3]) == p.value
+    assert [int(f[5]), int(f[7]), int(f[9])] == [int((m == 1).sum()), int((m == 2).sum()), int((m == 4).sum())]
+    h = 0
+    for i, v in enumerate(m.ravel().astype(np.int64)):
+        if v or True:
+            h = (h * 1000003 + (int(v) * 7 + 1) * (i + 1)) % (1 << 64)
+    assert int(f[11]) == h
+    HM = np.array([[50.0 + i if i == j else 1.0 / (1 + i + j) for j in range(20)] for i in range(20)])
+    bM = 0.1 * (np.arange(20) + 1)
+    prior = np.array([1e3, 0, 1e3, 0, 1e2, 0, 1e6, 1e6]); dprior = np.array([1e-3, 0, -2e-3, 0, 1e-3, 0, 1e-4, -1e-4])
+    Ho = np.zeros((12, 12)); bo = np.zeros(12)
+    assert gpu_ctx.L.sdso_ba_marginalize_frame(2, 0, abi.dp(prior), abi.dp(dprior), abi.dp(HM), abi.dp(bM), abi.dp(Ho), abi.dp(bo)) == 0
+    g = lines[1].split()
+    assert int(g[1]) == 144 and int(g[2]) == 12 and float(g[3]) == Ho[0, 0] and float(g[4]) == bo[11]
