@@ -398,6 +398,74 @@ typedef struct {
 int sdso_stereo_match_batch(sdso_ctx* ctx, int slot_a, int slot_b, const float K[4], float baseline,
                             int mode_right_first, sdso_stereo_match_t* m);
 
+/* ------------------------------------------------------------------ the fork's live g2o factors
+ * gyubeomim/stereo-dso-g2o routes tracking, window optimisation and the sub-pixel trace refinement through g2o edges
+ * (src/FullSystem/dso_g2o_edge.cpp, dso_g2o_vertex.cpp).  The edges' own arithmetic is specified by the reference tree and
+ * is reproduced here exactly; g2o itself (robust kernel, quadratic form, Levenberg-Marquardt / Gauss-Newton control) is
+ * neither vendored nor version-pinned (CMakeLists.txt:47-58) and is restated from its published algorithm — "parity
+ * unpinned" for everything g2o decides.  `SE3 * Vec3` is evaluated as R*X + t with R = rotationMatrix(). */
+
+/* S3: sub-pixel refinement used by every later traceStereo launch of this ctx (sdso_trace_stereo_*, sdso_stereo_match_batch):
+ *   0  DSO-native GN, ImmaturePoint.cpp:707-769 (default)
+ *   1  fork-live: VertexUVDSO + 8 EdgeTracePointUVDSO (dso_g2o_edge.cpp:571-619, dso_g2o_vertex.cpp:65-88), Huber(9),
+ *      one g2o Gauss-Newton iteration per pass, 3 passes (ImmaturePoint.cpp:309-412) */
+int sdso_trace_set_gn_mode(sdso_ctx* ctx, int mode);
+
+/* T5: EdgeSE3PosePhotoDSO (dso_g2o_edge.cpp:395-500) at one evaluation point. */
+typedef struct {
+  int lvl, w, h;
+  float fx, fy, cx, cy;      /* KG[level] (Matrix3f, globalCalib.cpp:90-107) = CoarseTracker fx[lvl]..cy[lvl] */
+  float Ki[9];               /* Ki[lvl]                                              CoarseTracker.cpp:130  */
+  float RKi[9], t_cull[3];   /* calcRes :617-618 from the pose calcRes is CALLED with (the fork always passes the
+                                initial lastToNew_out, :890) — used for the border cull and the flow indicators only */
+  double R[9], t[3];         /* VertexSE3PoseDSO::estimate(): rotationMatrix(), translation() */
+  float ab[2];               /* AffLight::fromToVecExposure(ref_exposure, new_exposure, a0b0, VertexPhotometricDSO::estimate()).cast<float>() */
+  double b0;                 /* a0b0_.b = lastRef_aff_g2l.b */
+  float cutoffTH, huberTH;   /* setting_coarseCutoffTH (edges with error > 10*cutoffTH are dropped, :724), setting_huberTH */
+} sdso_g2o_track_eval_t;
+/* CoarseTracker::calcRes, fork-live body (CoarseTracker.cpp:600-792) for level ev->lvl of reference `ref_slot` against frame
+ * `frame_slot`: culls the pc points, creates the edges, evaluates them at the vertices' estimates and keeps those that are
+ * not saturated.  The edge set {mask, Xref, measurement} stays on the device, keyed by (ref_slot, level).
+ *   res6     : the Vec6 calcRes returns (:783-789; E is never accumulated by the live body -> 0)
+ *   n_edges  : numTermsInE;  edge_mask[pc_n], Xref[3*pc_n] optional copies (tests) */
+int sdso_g2o_track_add_edges(sdso_ctx* ctx, int ref_slot, int frame_slot, const sdso_g2o_track_eval_t* ev, double* res6,
+                             int* n_edges, uint8_t* edge_mask, float* Xref);
+/* computeActiveErrors + linearizeOplus + g2o's robustified quadratic form over that edge set at the vertex estimates in ev:
+ *   H[64] row-major over [pose 6 | photometric 2], b[8], chi2 = {sum e^2, sum rho0 (activeRobustChi2)};
+ *   err[pc_n], J[8*pc_n] optional per-edge values (0 where the point carries no edge). */
+int sdso_g2o_track_linearize(sdso_ctx* ctx, int ref_slot, int frame_slot, const sdso_g2o_track_eval_t* ev, double* H, double* b,
+                             double* chi2, double* err, double* J);
+/* CoarseTracker::trackNewestCoarse as the fork runs it (CoarseTracker.cpp:827-1069): per level add_edges, then g2o's
+ * Levenberg-Marquardt (lambda0 0.01, 2 iterations, gain threshold 1e-3) on the 8-parameter system.  Same in/out convention
+ * as sdso_track_newest_coarse; prm->maxIterations is ignored (the fork hard-codes {2,2,2,2,2}, :861). */
+int sdso_g2o_track_newest_coarse(sdso_ctx* ctx, int ref_slot, int frame_slot, const sdso_track_params_t* prm,
+                                 sdso_se3_t* lastToNew, sdso_aff_t* aff_g2l, sdso_track_result_t* out);
+
+/* B13: EdgeLBASE3PosePhotoIdepthCamDSO (dso_g2o_edge.cpp:5-282) for the nr active residuals of a window, laid out as
+ * FullSystem::optimize builds the graph (FullSystemOptimize.cpp:455-542): one pose + one photometric vertex per HOST frame,
+ * one idepth vertex per RESIDUAL, one camera vertex; the target pose is a constant (PRE_worldToCam). */
+typedef struct {
+  int nf, nr, w, h;
+  const int* frame_slot;         /* nf level-0 images */
+  const float* const* dI;        /* unused by the library (kept so that the layout equals the test oracle's) */
+  const float* pair_R;           /* [host*nf+target] 9: (Ttw * Twh).rotationMatrix().cast<float>()   :27-30 */
+  const float* pair_t;           /* [host*nf+target] 3: translation */
+  const float* pair_ab;          /* [host*nf+target] 2: fromToVecExposure(host, target, a0b0 = host vertex, a1b1 = target aff).cast<float>() :85-91 */
+  const double* host_b0;         /* nf: b0_ (SetB, FullSystemOptimize.cpp:527-528) */
+  const float* frameEnergyTH;    /* nf */
+  double cam[4];                 /* VertexCamDSO::estimate(): fx fy cx cy */
+  const int* host; const int* target;        /* nr */
+  const float* u; const float* v;            /* nr: r->point->u, v */
+  const double* idepth;          /* nr: VertexInverseDepthDSO::estimate() */
+  const float* color; const float* weights;  /* nr*8: r->point->color (= measurement), weights */
+} sdso_g2o_lba_t;
+/* computeError + linearizeOplus for every residual:
+ *   error[nr*8] (double), J[nr*8*13] rows = [xi 6 | photometric 2 | idepth 1 | camera 4] (zero where linearizeOplus returns early),
+ *   state[nr] (0 IN, 1 OOB, 2 OUTLIER), energy[nr*2] = {state_NewEnergy, state_NewEnergyWithOutlier},
+ *   centerProjectedTo[nr*3] ((2,2,0) if the centre pixel was not reached), idepth_hessian[nr], edge_level[nr] (1 = setLevel(1), :60-65) */
+int sdso_g2o_lba_eval(sdso_ctx* ctx, const sdso_g2o_lba_t* L, double* error, double* J, uint8_t* state, float* energy,
+                      float* centerProjectedTo, float* idepth_hessian, uint8_t* edge_level);
+
 #ifdef __cplusplus
 }
 #endif

@@ -196,6 +196,46 @@ int orc_trace_on_batch(const float* dI, int w, int h, int ngeom, const orc_trace
 int orc_trace_stereo_batch(const float* dI, int w, int h, const float K[4], float baseline,
                            int mode_right, orc_trace_points_t* pts, uint8_t* status);
 
+int orc_trace_stereo_batch_gn(const float* dI, int w, int h, const float K[4], float baseline,
+                              int mode_right, orc_trace_points_t* pts, uint8_t* status, int gn_mode);
+
+/* ---- the fork's live g2o factors (orc_g2o.cpp) */
+typedef struct {
+  int lvl, w, h;
+  float fx, fy, cx, cy;      /* KG[level] (float, globalCalib.cpp:90-107) */
+  float Ki[9];               /* Ki[lvl] */
+  float RKi[9], t_cull[3];   /* calcRes :617-618, from the pose calcRes is called with */
+  double R[9], t[3];         /* VertexSE3PoseDSO::estimate() */
+  float ab[2];               /* fromToVecExposure(ref, new, a0b0, VertexPhotometricDSO::estimate()).cast<float>() */
+  double b0;                 /* a0b0_.b = lastRef_aff_g2l.b */
+  float cutoffTH, huberTH;
+} orc_g2o_track_eval_t;
+int orc_g2o_track_add_edges(int n, const float* pc_u, const float* pc_v, const float* pc_idepth, const float* pc_color,
+                            const float* dI, const orc_g2o_track_eval_t* ev, double* res6, uint8_t* edge_mask, float* Xref);
+int orc_g2o_track_linearize(int n, const uint8_t* edge_mask, const float* Xref, const float* pc_color, const float* dI,
+                            const orc_g2o_track_eval_t* ev, double* H, double* b, double* chi2, double* err, double* J);
+int orc_g2o_track_newest_coarse(const int* pc_n, const float* const* pc_u, const float* const* pc_v,
+                                const float* const* pc_idepth, const float* const* pc_color,
+                                const float* const* dIp, const orc_track_params_t* prm,
+                                orc_se3_t* lastToNew, orc_aff_t* aff_g2l, orc_track_result_t* out);
+typedef struct {
+  int nf, nr, w, h;
+  const int* frame_slot;         /* product only */
+  const float* const* dI;        /* oracle only: nf level-0 images, AoS float3 */
+  const float* pair_R;           /* [host*nf+target] (Ttw * Twh).rotationMatrix().cast<float>() */
+  const float* pair_t;           /* [host*nf+target] translation */
+  const float* pair_ab;          /* [host*nf+target] fromToVecExposure(host, target, a0b0, a1b1).cast<float>() */
+  const double* host_b0;         /* nf: b0_ (EdgeLBA...::SetB, FullSystemOptimize.cpp:527-528) */
+  const float* frameEnergyTH;    /* nf */
+  double cam[4];                 /* VertexCamDSO::estimate() fx fy cx cy */
+  const int* host; const int* target;
+  const float* u; const float* v;
+  const double* idepth;          /* VertexInverseDepthDSO::estimate(), one vertex per residual */
+  const float* color; const float* weights;
+} orc_g2o_lba_t;
+int orc_g2o_lba_eval(const orc_g2o_lba_t* L, double* error, double* J, uint8_t* state, float* energy,
+                     float* centerProjectedTo, float* idepth_hessian, uint8_t* edge_level);
+
 #ifdef __cplusplus
 }
 #endif

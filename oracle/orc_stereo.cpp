@@ -76,7 +76,7 @@ extern "C" int orc_immature_init_batch(const float* dI, int w, int h, int n, con
 namespace {
 // One point of ImmaturePoint::traceStereo.  Returns the new lastTraceStatus.
 int traceStereoOne(const float* dI, int wG0, int hG0, const float* K4, float baseline, bool mode_right,
-                   orc_trace_points_t* P, int i) {
+                   orc_trace_points_t* P, int i, int gn_mode = 0) {
   float& u_stereo = P->u_stereo[i]; float& v_stereo = P->v_stereo[i];
   float& idepth_min_stereo = P->idepth_min_stereo[i]; float& idepth_max_stereo = P->idepth_max_stereo[i];
   const float* color = P->color + i * 8; const float* weights = P->weights + i * 8; const float* gradH = P->gradH + i * 4;
@@ -182,6 +182,47 @@ int traceStereoOne(const float* dI, int wG0, int hG0, const float* K4, float bas
   float newQuality = secondBest / bestEnergy;
   if (newQuality < quality || numSteps > 10) quality = newQuality;
 
+  if (gn_mode == 1) {
+    // fork-live GN (ImmaturePoint.cpp:309-412): a VertexUVDSO at (bestU, bestV), per pass 8 NEW EdgeTracePointUVDSO
+    // (dso_g2o_edge.cpp:571-619) with Huber(9) and one g2o Gauss-Newton iteration over all edges added so far.  The
+    // duplicates of earlier passes scale H and b alike, so the step is b/H of the 8 current edges (restated g2o: unpinned).
+    double U = bestU, V = bestV;
+    const double ddx = dx, ddy = dy;
+    if (setting_trace_GNIterations > 0) bestEnergy = 1e5;
+    for (int it = 0; it < setting_trace_GNIterations; it++) {
+      float energy = 0;
+      double Hs = 0, bs = 0;
+      for (int idx = 0; idx < patternNum; idx++) {
+        double e = 0, J = 0;
+        if (!((U - 2) < 0 || (U + 3) > (wG0 - 3) || (V - 2) < 0 || (V + 3) > (hG0 - 3))) {   // util::CheckBoundary(bestU, bestV, wG[0]-3, hG[0]-3)
+          float hit[3];
+          interp33(dI, (float)(U + rotatetPattern[idx][0]), (float)(V + rotatetPattern[idx][1]), wG0, hit);
+          if (std::isfinite(hit[0])) {
+            e = hit[0] - (aff0 * (double)color[idx] + aff1);
+            J = ddx * hit[1] + ddy * hit[2];
+          }
+        }
+        const float residual = e;
+        const float hw = fabs(residual) < setting_huberTH ? 1 : setting_huberTH / fabs(residual);
+        energy += weights[idx] * weights[idx] * hw * residual * residual * (2 - hw);
+        const double e2 = e * e, dsqr = (double)setting_huberTH * setting_huberTH;
+        const double rho1 = e2 <= dsqr ? 1. : setting_huberTH / std::sqrt(e2);
+        bs -= rho1 * J * e;
+        Hs += J * rho1 * J;
+      }
+      if (Hs != 0) {                                       // LDLT of a zero 1x1 system fails -> no update
+        double update = bs / Hs;                           // VertexUVDSO::oplusImpl (dso_g2o_vertex.cpp:73-88)
+        if (update < -0.5) update = -0.5;
+        else if (update > 0.5) update = 0.5;
+        else if (!std::isfinite(update)) update = 0;
+        U += update * ddx;
+        V += update * ddy;
+      }
+      if (!(energy > bestEnergy)) bestEnergy = energy;     // :381-407 (no step back in the live code)
+    }
+    bestU = U;
+    bestV = V;
+  } else {
   // DSO-native GN (ImmaturePoint.cpp:707-769)
   float uBak = bestU, vBak = bestV, gnstepsize = 1, stepBack = 0;
   if (setting_trace_GNIterations > 0) bestEnergy = 1e5;
@@ -215,6 +256,7 @@ int traceStereoOne(const float* dI, int wG0, int hG0, const float* K4, float bas
       bestEnergy = energy;
     }
     if (fabsf(stepBack) < setting_trace_GNThreshold) break;
+  }
   }
 
   if (!(bestEnergy < energyTH * setting_trace_extraSlackOnTH)) {
@@ -421,12 +463,22 @@ extern "C" int orc_trace_on_batch(const float* dI, int w, int h, int ngeom, cons
 extern "C" int orc_trace_stereo_batch(const float* dI, int w, int h, const float K[4], float baseline, int mode_right,
                                       orc_trace_points_t* pts, uint8_t* status) {
   for (int i = 0; i < pts->n; i++) {
-    int s = traceStereoOne(dI, w, h, K, baseline, mode_right != 0, pts, i);
+    int s = traceStereoOne(dI, w, h, K, baseline, mode_right != 0, pts, i, 0);
     if (status) status[i] = (uint8_t)s;
   }
   return 0;
 }
 
+
+// the same with the fork-live sub-pixel refinement (gn_mode 1: g2o Gauss-Newton on EdgeTracePointUVDSO, ImmaturePoint.cpp:309-412)
+extern "C" int orc_trace_stereo_batch_gn(const float* dI, int w, int h, const float K[4], float baseline, int mode_right,
+                                         orc_trace_points_t* pts, uint8_t* status, int gn_mode) {
+  for (int i = 0; i < pts->n; i++) {
+    int s = traceStereoOne(dI, w, h, K, baseline, mode_right != 0, pts, i, gn_mode);
+    if (status) status[i] = (uint8_t)s;
+  }
+  return 0;
+}
 
 // ------------------------------------------------------------------ point activation
 // FullSystem::optimizeImmaturePoint (src/FullSystem/FullSystemOptPoint.cpp:52-238) with ImmaturePoint::linearizeResidual

@@ -11,7 +11,7 @@ import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(os.path.dirname(_HERE), "stereo-dso-g2o_amd"))
-from sdso_amd.abi import (Activate, TraceGeom, TrackEval, SE3, Aff, TrackParams, TrackResult, BAWindow, BAOptResult, TracePoints,  # noqa: E402
+from sdso_amd.abi import (G2oTrackEval, G2oLba, Activate, TraceGeom, TrackEval, SE3, Aff, TrackParams, TrackResult, BAWindow, BAOptResult, TracePoints,  # noqa: E402
                           c_float_p, c_double_p, c_int_p, c_u8_p)
 
 _libs = {}
@@ -77,5 +77,12 @@ def load(fast=False):
     L.orc_activate_points.argtypes = [C.POINTER(Activate), C.POINTER(C.c_int8), c_float_p, c_u8_p]
     L.orc_trace_on_batch.argtypes = [c_float_p, C.c_int, C.c_int, C.c_int, C.POINTER(TraceGeom), c_int_p, C.POINTER(TracePoints), c_u8_p]
     L.orc_trace_stereo_batch.argtypes = [c_float_p, C.c_int, C.c_int, c_float_p, C.c_float, C.c_int, C.POINTER(TracePoints), c_u8_p]
+    L.orc_trace_stereo_batch_gn.argtypes = [c_float_p, C.c_int, C.c_int, c_float_p, C.c_float, C.c_int, C.POINTER(TracePoints), c_u8_p, C.c_int]
+    L.orc_g2o_track_add_edges.argtypes = [C.c_int, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, C.POINTER(G2oTrackEval), c_double_p, c_u8_p, c_float_p]
+    L.orc_g2o_track_linearize.argtypes = [C.c_int, c_u8_p, c_float_p, c_float_p, c_float_p, C.POINTER(G2oTrackEval), c_double_p, c_double_p, c_double_p,
+                                          c_double_p, c_double_p]
+    L.orc_g2o_track_newest_coarse.argtypes = [c_int_p, C.POINTER(c_float_p), C.POINTER(c_float_p), C.POINTER(c_float_p), C.POINTER(c_float_p),
+                                              C.POINTER(c_float_p), C.POINTER(TrackParams), C.POINTER(SE3), C.POINTER(Aff), C.POINTER(TrackResult)]
+    L.orc_g2o_lba_eval.argtypes = [C.POINTER(G2oLba), c_double_p, c_double_p, c_u8_p, c_float_p, c_float_p, c_float_p, c_u8_p]
     _libs[name] = L
     return L

@@ -113,6 +113,7 @@ void release_track_batch(sdso_ctx* ctx);
 void release_trace(sdso_ctx* ctx);
 void release_match(sdso_ctx* ctx);
 void release_selector(sdso_ctx* ctx);
+void release_g2o(sdso_ctx* ctx);
 }
 
 extern "C" void sdso_ctx_destroy(sdso_ctx* ctx) {
@@ -129,6 +130,7 @@ extern "C" void sdso_ctx_destroy(sdso_ctx* ctx) {
   release_trace(ctx);
   release_match(ctx);
   release_selector(ctx);
+  release_g2o(ctx);
   if (ctx->scratch) hipFree(ctx->scratch);
   if (ctx->pinned) hipHostFree(ctx->pinned);
   hipStreamDestroy(ctx->stream);

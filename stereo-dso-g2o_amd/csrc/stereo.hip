@@ -74,6 +74,7 @@ __global__ __launch_bounds__(256) void k_immature_init(const float4* __restrict_
   energyTH[p] = bad ? NAN : e;
 }
 
+template <int GN_MODE>
 __global__ __launch_bounds__(256) void k_trace_stereo(TraceDev T) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int i = blockIdx.x * 4 + wv;
@@ -215,6 +216,52 @@ __global__ __launch_bounds__(256) void k_trace_stereo(TraceDev T) {
   const float newQuality = secondBest / bestEnergy;
   if (newQuality < quality || numSteps > 10) quality = newQuality;
 
+  if constexpr (GN_MODE == 1) {
+    // ---- fork-live refinement (ImmaturePoint.cpp:309-412): VertexUVDSO at (bestU, bestV) in double, 8 EdgeTracePointUVDSO
+    // (dso_g2o_edge.cpp:571-619) with Huber(9), one undamped g2o Gauss-Newton step per pass, update clamped by
+    // VertexUVDSO::oplusImpl (dso_g2o_vertex.cpp:73-88).  Pattern pixel idx on lane idx, summed in order.
+    double U = bestU, V = bestV;
+    const double ddx = dx, ddy = dy;
+    if (kTraceGNIterations > 0) bestEnergy = 1e5;
+    for (int it = 0; it < kTraceGNIterations; it++) {
+      double e = 0, J = 0;
+      float te = 0;
+      if (lane < 8) {
+        if (!((U - 2) < 0 || (U + 3) > (wG0 - 3) || (V - 2) < 0 || (V + 3) > (hG0 - 3))) {
+          const float3 hit = interp33(dI, (float)(U + (float)c_pat[lane][0]), (float)(V + (float)c_pat[lane][1]), wG0);
+          if (isfinite(hit.x)) {
+            e = hit.x - (1.0f * (double)color[lane] + 0.0f);
+            J = ddx * hit.y + ddy * hit.z;
+          }
+        }
+        const float residual = e;
+        const float hw = fabsf(residual) < kHuberTH ? 1 : kHuberTH / fabsf(residual);
+        te = weights[lane] * weights[lane] * hw * residual * residual * (2 - hw);
+      }
+      const double e2 = e * e;
+      const double rho1 = e2 <= (double)kHuberTH * kHuberTH ? 1. : kHuberTH / sqrt(e2);
+      const double tb = rho1 * J * e, tH = J * rho1 * J;
+      float energy = 0;
+      double Hs = 0, bs = 0;
+#pragma unroll
+      for (int idx = 0; idx < 8; idx++) {
+        energy += lane_bcast(te, idx);
+        bs -= __shfl(tb, idx, 64);
+        Hs += __shfl(tH, idx, 64);
+      }
+      if (Hs != 0) {
+        double update = bs / Hs;
+        if (update < -0.5) update = -0.5;
+        else if (update > 0.5) update = 0.5;
+        else if (!isfinite(update)) update = 0;
+        U += update * ddx;
+        V += update * ddy;
+      }
+      if (!(energy > bestEnergy)) bestEnergy = energy;
+    }
+    bestU = U;
+    bestV = V;
+  } else {
   // ---- DSO-native GN (ImmaturePoint.cpp:707-769): pattern pixel idx on lane idx, summed in order
   float uBak = bestU, vBak = bestV, stepBack = 0;
   const float gnstepsize = 1;
@@ -259,6 +306,7 @@ __global__ __launch_bounds__(256) void k_trace_stereo(TraceDev T) {
       bestEnergy = energy;
     }
     if (fabsf(stepBack) < kTraceGNThreshold) break;
+  }
   }
 
   if (!(bestEnergy < energyTH * kTraceExtraSlack)) {
@@ -594,7 +642,8 @@ extern "C" int sdso_trace_stereo_enqueue(sdso_ctx* ctx) {
   SDSO_HIP(ctx, hipMemcpyAsync(B.bytes, B.bytes + 2 * (size_t)B.n, (size_t)B.n, hipMemcpyDeviceToDevice, ctx->stream));
   {
     ProfScope ps(ctx, "k_trace_stereo");
-    hipLaunchKernelGGL(k_trace_stereo, dim3((B.T.n + 3) / 4), dim3(256), 0, ctx->stream, B.T);
+    if (ctx->gn_mode == 1) hipLaunchKernelGGL(k_trace_stereo<1>, dim3((B.T.n + 3) / 4), dim3(256), 0, ctx->stream, B.T);
+    else hipLaunchKernelGGL(k_trace_stereo<0>, dim3((B.T.n + 3) / 4), dim3(256), 0, ctx->stream, B.T);
   }
   SDSO_HIP(ctx, hipGetLastError());
   return SDSO_OK;
@@ -645,6 +694,15 @@ extern "C" int sdso_trace_on_batch(sdso_ctx* ctx, int frame_slot, int ngeom, con
   sdso_trace_points_t out = *pts;
   out.idepth_stereo = nullptr;
   return sdso_trace_stereo_fetch(ctx, &out, status);
+}
+
+// 0: DSO-native sub-pixel refinement (ImmaturePoint.cpp:707-769); 1: the fork's live g2o Gauss-Newton on
+// EdgeTracePointUVDSO (ImmaturePoint.cpp:309-412).  Applies to every later traceStereo launch of this ctx.
+extern "C" int sdso_trace_set_gn_mode(sdso_ctx* ctx, int mode) {
+  if (!ctx) return SDSO_ERR_STATE;
+  SDSO_REQUIRE(ctx, mode == 0 || mode == 1, "gn mode must be 0 (DSO-native) or 1 (g2o fork)");
+  ctx->gn_mode = mode;
+  return SDSO_OK;
 }
 
 extern "C" int sdso_trace_stereo_batch(sdso_ctx* ctx, int frame_slot, const float K[4], float baseline, int mode_right, sdso_trace_points_t* pts, uint8_t* status) {
@@ -750,13 +808,15 @@ extern "C" int sdso_stereo_match_batch(sdso_ctx* ctx, int slot_a, int slot_b, co
   hipLaunchKernelGGL(k_match_prepare, g1, b1, 0, ctx->stream, n, d_in[0], d_in[1], d_in[2], d_in[3], A.T);
   hipLaunchKernelGGL(k_immature_init, g1, b1, 0, ctx->stream, ia->second.d[0], w, n, (const float*)A.T.u_stereo, (const float*)A.T.v_stereo,
                      (float*)A.T.color, (float*)A.T.weights, (float*)A.T.gradH, (float*)A.T.energyTH);
-  hipLaunchKernelGGL(k_trace_stereo, gw, b1, 0, ctx->stream, A.T);
+  if (ctx->gn_mode == 1) hipLaunchKernelGGL(k_trace_stereo<1>, gw, b1, 0, ctx->stream, A.T);
+  else hipLaunchKernelGGL(k_trace_stereo<0>, gw, b1, 0, ctx->stream, A.T);
   hipLaunchKernelGGL(k_match_back_points, g1, b1, 0, ctx->stream, n, A.T, Bk.T, skip, d_in[4], d_in[5]);
   hipLaunchKernelGGL(k_immature_init, g1, b1, 0, ctx->stream, ib->second.d[0], w, n, (const float*)Bk.T.u_stereo, (const float*)Bk.T.v_stereo,
                      (float*)Bk.T.color, (float*)Bk.T.weights, (float*)Bk.T.gradH, (float*)Bk.T.energyTH);
   TraceDev Tb = Bk.T;
   Tb.skip = skip;
-  hipLaunchKernelGGL(k_trace_stereo, gw, b1, 0, ctx->stream, Tb);
+  if (ctx->gn_mode == 1) hipLaunchKernelGGL(k_trace_stereo<1>, gw, b1, 0, ctx->stream, Tb);
+  else hipLaunchKernelGGL(k_trace_stereo<0>, gw, b1, 0, ctx->stream, Tb);
   SDSO_HIP(ctx, hipGetLastError());
 #define DN(dst, src, cnt) if (dst) SDSO_HIP(ctx, hipMemcpyAsync((dst), (src), sizeof(float) * (size_t)(cnt), hipMemcpyDeviceToHost, ctx->stream))
   DN(M->idepth_stereo, A.T.idepth_stereo, n); DN(M->idepth_min_out, A.T.idepth_min_stereo, n); DN(M->idepth_max_out, A.T.idepth_max_stereo, n);

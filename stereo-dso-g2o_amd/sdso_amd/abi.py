@@ -100,6 +100,24 @@ class StereoMatch(C.Structure):
                 ("back_uv", c_float_p)]
 
 
+class G2oTrackEval(C.Structure):
+    """sdso_g2o_track_eval_t: one EdgeSE3PosePhotoDSO evaluation point (fork-live tracker, dso_g2o_edge.cpp:395-500)."""
+    _fields_ = [("lvl", C.c_int), ("w", C.c_int), ("h", C.c_int),
+                ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+                ("Ki", C.c_float * 9), ("RKi", C.c_float * 9), ("t_cull", C.c_float * 3),
+                ("R", C.c_double * 9), ("t", C.c_double * 3), ("ab", C.c_float * 2), ("b0", C.c_double),
+                ("cutoffTH", C.c_float), ("huberTH", C.c_float)]
+
+
+class G2oLba(C.Structure):
+    """sdso_g2o_lba_t: EdgeLBASE3PosePhotoIdepthCamDSO batch (dso_g2o_edge.cpp:5-282)."""
+    _fields_ = [("nf", C.c_int), ("nr", C.c_int), ("w", C.c_int), ("h", C.c_int),
+                ("frame_slot", c_int_p), ("dI", C.POINTER(c_float_p)),
+                ("pair_R", c_float_p), ("pair_t", c_float_p), ("pair_ab", c_float_p), ("host_b0", c_double_p),
+                ("frameEnergyTH", c_float_p), ("cam", C.c_double * 4), ("host", c_int_p), ("target", c_int_p),
+                ("u", c_float_p), ("v", c_float_p), ("idepth", c_double_p), ("color", c_float_p), ("weights", c_float_p)]
+
+
 def fp(a):
     return a.ctypes.data_as(c_float_p)
 
@@ -263,6 +281,11 @@ def load():
     L.sdso_ba_marginalize_frame.argtypes = [C.c_int, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]
     L.sdso_activate_points_batch.argtypes = [vp, C.POINTER(Activate), C.POINTER(C.c_int8), c_float_p, c_u8_p]
     L.sdso_stereo_match_batch.argtypes = [vp, C.c_int, C.c_int, c_float_p, C.c_float, C.c_int, C.POINTER(StereoMatch)]
+    L.sdso_g2o_track_add_edges.argtypes = [vp, C.c_int, C.c_int, C.POINTER(G2oTrackEval), c_double_p, c_int_p, c_u8_p, c_float_p]
+    L.sdso_g2o_track_linearize.argtypes = [vp, C.c_int, C.c_int, C.POINTER(G2oTrackEval), c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]
+    L.sdso_g2o_track_newest_coarse.argtypes = [vp, C.c_int, C.c_int, C.POINTER(TrackParams), C.POINTER(SE3), C.POINTER(Aff), C.POINTER(TrackResult)]
+    L.sdso_g2o_lba_eval.argtypes = [vp, C.POINTER(G2oLba), c_double_p, c_double_p, c_u8_p, c_float_p, c_float_p, c_float_p, c_u8_p]
+    L.sdso_trace_set_gn_mode.argtypes = [vp, C.c_int]
     _lib = L
     return L
 
@@ -282,6 +305,7 @@ EXPORTED_SYMBOLS = [
     "sdso_ba_batch_accum_dev", "sdso_ba_batch_get_x", "sdso_ba_batch_set_materialize",
     "sdso_immature_init_batch", "sdso_trace_stereo_batch", "sdso_trace_stereo_prepare", "sdso_trace_stereo_enqueue",
     "sdso_trace_stereo_fetch", "sdso_stereo_match_batch", "sdso_activate_points_batch", "sdso_ba_marginalize_frame", "sdso_ba_batch_linearize", "sdso_ba_batch_schur", "sdso_pixel_select", "sdso_pixel_selector_pattern", "sdso_trace_on_batch", "sdso_track_make_ref", "sdso_track_newest_coarse_batch", "sdso_track_get_ref",
+    "sdso_g2o_track_add_edges", "sdso_g2o_track_linearize", "sdso_g2o_track_newest_coarse", "sdso_g2o_lba_eval", "sdso_trace_set_gn_mode",
 ]
 
 

@@ -27,7 +27,7 @@ def track_params(prob, coarsest=None, ref_aff=(0.0, 0.0), exposure=(1.0, 1.0), m
     return p
 
 
-def oracle_track(L, prob, prm, T0, aff0):
+def oracle_track(L, prob, prm, T0, aff0, fn="orc_track_newest_coarse"):
     n = prob["levels"]
     pc = prob["pc"]
     keep = []
@@ -49,7 +49,7 @@ def oracle_track(L, prob, prm, T0, aff0):
     T = abi.SE3.from_Rt(*T0)
     aff = abi.Aff(*aff0)
     out = abi.TrackResult()
-    L.orc_track_newest_coarse(pcn, ptrs("u"), ptrs("v"), ptrs("idepth"), ptrs("color"), dI, C.byref(prm), C.byref(T), C.byref(aff), C.byref(out))
+    getattr(L, fn)(pcn, ptrs("u"), ptrs("v"), ptrs("idepth"), ptrs("color"), dI, C.byref(prm), C.byref(T), C.byref(aff), C.byref(out))
     return T, aff, out
 
 
