@@ -52,6 +52,9 @@ class Device {
     check(sdso_upload_pyramid(ctx_, slot, levels, w, h, p.data()), "sdso_upload_pyramid");
   }
   void releaseFrame(int slot) { sdso_release_pyramid(ctx_, slot); }
+  // traceStereo's sub-pixel refinement: false = DSO-native GN (ImmaturePoint.cpp:707-769), true = the fork's g2o GN on
+  // EdgeTracePointUVDSO (ImmaturePoint.cpp:309-412)
+  void setForkLiveTraceRefinement(bool on) { check(sdso_trace_set_gn_mode(ctx_, on ? 1 : 0), "sdso_trace_set_gn_mode"); }
 
  private:
   sdso_ctx* ctx_ = nullptr;
@@ -132,7 +135,8 @@ class CoarseTracker {
     sdso_se3_t T = toAbi(lastToNew_out);
     sdso_aff_t aff{aff_g2l_out.a, aff_g2l_out.b};
     sdso_track_result_t out;
-    dev_.check(sdso_track_newest_coarse(dev_.ctx(), ref_slot_, newFrame_slot, &prm_, &T, &aff, &out), "sdso_track_newest_coarse");
+    if (forkLive) dev_.check(sdso_g2o_track_newest_coarse(dev_.ctx(), ref_slot_, newFrame_slot, &prm_, &T, &aff, &out), "sdso_g2o_track_newest_coarse");
+    else dev_.check(sdso_track_newest_coarse(dev_.ctx(), ref_slot_, newFrame_slot, &prm_, &T, &aff, &out), "sdso_track_newest_coarse");
     for (int i = 0; i < 5; i++) lastResiduals[i] = out.lastResiduals[i];
     for (int i = 0; i < 3; i++) lastFlowIndicators[i] = out.lastFlowIndicators[i];
     lastToNew_out = fromAbi<SE3T, Mat33T, Vec3T>(T);
@@ -151,6 +155,9 @@ class CoarseTracker {
     dev_.check(sdso_track_calc_res_gs(dev_.ctx(), ref_slot_, newFrame_slot, &ev, H_out, b_out, res6, buf_warped_n, nullptr), "sdso_track_calc_res_gs");
   }
 
+  // false: DSO-native LM (the body kept as comments at CoarseTracker.cpp:908-1024).  true: the fork's live body — one
+  // EdgeSE3PosePhotoDSO per point and g2o's Levenberg-Marquardt, 2 iterations per level (CoarseTracker.cpp:834-1047).
+  bool forkLive = false;
   // public outputs of the reference (CoarseTracker.h:98-113)
   double lastResiduals[5];
   double lastFlowIndicators[3];

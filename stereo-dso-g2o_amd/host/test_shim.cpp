@@ -3,7 +3,7 @@
 // writes a problem as raw arrays into a directory, runs this program on the GPU box and compares
 // what it prints with the same problem pushed through the C-ABI from Python.
 //
-//   test_shim <dir> tracker|stereo|ba|selector
+//   test_shim <dir> tracker|tracker_g2o|stereo|stereo_g2o|ba|selector
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -79,7 +79,7 @@ static void load_pyramid(const std::string& dir, const char* prefix, FrameHessia
   }
 }
 
-static int run_tracker(const std::string& dir) {
+static int run_tracker(const std::string& dir, bool fork_live) {
   auto meta = load<int>(dir, "meta");             // levels, w0, h0, coarsestLvl
   auto calib = load<double>(dir, "calib");        // fx fy cx cy
   auto misc = load<double>(dir, "misc");          // ref_exposure new_exposure ref_a ref_b, T0 (12), aff0 (2), minResForAbort (5)
@@ -93,6 +93,7 @@ static int run_tracker(const std::string& dir) {
   CalibHessian HC; for (int i = 0; i < 4; i++) HC.value_scaled[i] = HC.value_zero[i] = calib[i];
   sdso_shim::CoarseTracker<SE3, AffLight, Mat33, Vec3> tracker(dev, 0);
   tracker.makeK(&HC, levels, w0, h0);
+  tracker.forkLive = fork_live;
   AffLight refAff; refAff.a = misc[2]; refAff.b = misc[3];
   for (int l = 0; l < levels; l++) {
     char nm[32];
@@ -117,7 +118,7 @@ static int run_tracker(const std::string& dir) {
   return 0;
 }
 
-static int run_stereo(const std::string& dir) {
+static int run_stereo(const std::string& dir, bool fork_live) {
   auto meta = load<int>(dir, "meta");             // w, h, n, mode_right
   auto kf = load<float>(dir, "K");                // fx fy cx cy baseline
   FrameHessian fr; load_pyramid(dir, "right", fr, 1);
@@ -140,6 +141,7 @@ static int run_stereo(const std::string& dir) {
   }
   Mat33f K{{kf[0], 0, kf[2], 0, kf[1], kf[3], 0, 0, 1}};
   std::vector<uint8_t> status;
+  dev.setForkLiveTraceRefinement(fork_live);
   sdso_shim::traceStereoAll(dev, pts, 3, K, kf[4], meta[3] != 0, status);
   for (int i = 0; i < n; i++)
     std::printf("%d %d %.9g %.9g %.9g %.9g %.9g %.9g %.9g\n", (int)status[i], store[i].lastTraceStatus, store[i].idepth_min_stereo, store[i].idepth_max_stereo,
@@ -236,8 +238,10 @@ int main(int argc, char** argv) {
   if (argc < 3) { std::fprintf(stderr, "usage: test_shim <dir> tracker|stereo|ba\n"); return 2; }
   try {
     const std::string what = argv[2];
-    if (what == "tracker") return run_tracker(argv[1]);
-    if (what == "stereo") return run_stereo(argv[1]);
+    if (what == "tracker") return run_tracker(argv[1], false);
+    if (what == "tracker_g2o") return run_tracker(argv[1], true);
+    if (what == "stereo") return run_stereo(argv[1], false);
+    if (what == "stereo_g2o") return run_stereo(argv[1], true);
     if (what == "ba") return run_ba(argv[1]);
     if (what == "selector") return run_selector(argv[1]);
   } catch (const std::exception& e) { std::fprintf(stderr, "error: %s\n", e.what()); return 1; }

@@ -21,7 +21,7 @@ def _load(name):
     return dict(np.load(os.path.join(GOLD, name + ".npz")))
 
 
-@pytest.mark.parametrize("name", ["tracker", "ba", "stereo"])
+@pytest.mark.parametrize("name", ["tracker", "ba", "stereo", "g2o"])
 def test_oracle_reproduces_golden(oracle, name):
     exp = _load(name)
     got = cases.CASES[name](oracle)
@@ -104,3 +104,64 @@ def test_gpu_stereo_matches_golden(gpu_ctx):
     assert np.array_equal(st, exp["status"])
     for k in ("idepth_min_stereo", "idepth_max_stereo", "idepth_stereo", "quality", "lastTraceStatus", "lastTraceUV", "lastTracePixelInterval"):
         assert np.array_equal(d[k], exp[k], equal_nan=True), k          # every traceStereo output: bit-exact
+
+
+@pytest.mark.gpu
+def test_gpu_g2o_factors_match_golden(gpu_ctx):
+    """The fork's live factors against the frozen oracle outputs: per-edge doubles bit-exact, sums over edges to 1e-12."""
+    from sdso_amd import synth
+    exp = _load("g2o")
+    prob, prm, _ = cases.tracker_case()
+    assert np.array_equal(exp["input_digest"], cases.digest(prob["pyr_new"][0], prob["pc"][0]["u"], prob["pc"][0]["idepth"]))
+    gpu_ctx.upload_pyramid(12, prob["pyr_new"]); gpu_ctx.set_ref(11, prob["pc"])
+    Tc, Tv = synth.se3_exp(cases.G2O_CULL), synth.se3_exp(cases.G2O_VERTEX)
+    for lvl in range(prob["levels"]):
+        ev = cases.g2o_eval(gpu_ctx.L, "sdso_", prm, lvl, Tc, Tv, (0.01, 1.0))
+        n = len(prob["pc"][lvl]["u"])
+        res = np.zeros(6); ne = C.c_int(0); mask = np.zeros(n, np.uint8); X = np.zeros((n, 3), np.float32)
+        gpu_ctx.check(gpu_ctx.L.sdso_g2o_track_add_edges(gpu_ctx.h, 11, 12, C.byref(ev), abi.dp(res), C.byref(ne), abi.bp(mask), abi.fp(X)))
+        assert np.array_equal(np.packbits(mask), exp["mask%d" % lvl]) and np.array_equal(X[::cases.G2O_STRIDE], exp["Xref%d" % lvl])
+        assert np.allclose(res, exp["res%d" % lvl], rtol=1e-6, equal_nan=True) and res[1] == exp["res%d" % lvl][1]
+        H = np.zeros(64); b = np.zeros(8); chi = np.zeros(2); err = np.zeros(n); J = np.zeros((n, 8))
+        gpu_ctx.check(gpu_ctx.L.sdso_g2o_track_linearize(gpu_ctx.h, 11, 12, C.byref(ev), abi.dp(H), abi.dp(b), abi.dp(chi), abi.dp(err), abi.dp(J)))
+        sd = cases.G2O_STRIDE
+        assert np.allclose(err[::sd], exp["err%d" % lvl], rtol=1e-12, atol=1e-12) and np.allclose(J[::sd], exp["J%d" % lvl], rtol=1e-12, atol=1e-12)
+        Ho = exp["H%d" % lvl]
+        d = np.sqrt(np.diag(Ho)) + 1e-300
+        assert np.abs((H.reshape(8, 8) - Ho) / np.outer(d, d)).max() < 1e-11
+        assert np.allclose(chi, exp["chi%d" % lvl], rtol=1e-11)
+    T = abi.SE3.from_Rt(np.eye(3), np.zeros(3)); aff = abi.Aff(0, 0); out = abi.TrackResult()
+    gpu_ctx.check(gpu_ctx.L.sdso_g2o_track_newest_coarse(gpu_ctx.h, 11, 12, C.byref(prm), C.byref(T), C.byref(aff), C.byref(out)))
+    R, t = T.Rt()
+    assert np.abs(R - exp["track_R"]).max() <= 1e-8 and np.abs(t - exp["track_t"]).max() <= 1e-8
+    assert np.array_equal(np.array(list(out.iterations), np.int32), exp["track_iterations"]) and out.evaluations == int(exp["track_evaluations"])
+    # window edge
+    d = cases.g2o_lba_case()
+    nf, nr = d["nf"], d["nr"]
+    for f in range(nf):
+        gpu_ctx.upload_pyramid(20 + f, d["win"]["pyrs"][f][:1])
+    S, keep = cases.g2o_lba_struct(d, frame_slots=[20 + f for f in range(nf)])
+    e = np.zeros((nr, 8)); Jl = np.zeros((nr, 8, 13)); st = np.zeros(nr, np.uint8); en = np.zeros((nr, 2), np.float32)
+    cpt = np.zeros((nr, 3), np.float32); ih = np.zeros(nr, np.float32); lv = np.zeros(nr, np.uint8)
+    gpu_ctx.check(gpu_ctx.L.sdso_g2o_lba_eval(gpu_ctx.h, C.byref(S), abi.dp(e), abi.dp(Jl), abi.bp(st), abi.fp(en), abi.fp(cpt), abi.fp(ih), abi.bp(lv)))
+    assert np.array_equal(st, exp["lba_state"]) and np.array_equal(lv, exp["lba_level"])
+    for got, key in ((e, "lba_error"), (Jl[::cases.G2O_STRIDE], "lba_J"), (en, "lba_energy"), (cpt, "lba_cpt"), (ih, "lba_idepth_hessian")):
+        assert np.allclose(got, exp[key], rtol=1e-6, atol=1e-9), key      # the fixture may come from another host's libm; live comparison is bit-exact
+    # trace refinement, g2o mode
+    pr = cases.stereo_case()
+    left = np.ascontiguousarray(pr["pyr_l"][0]); right = np.ascontiguousarray(pr["pyr_r"][0])
+    gpu_ctx.upload_pyramid(30, [left]); gpu_ctx.upload_pyramid(31, [right])
+    n = len(pr["u"])
+    col, wgt, gH, eth = np.zeros((n, 8), np.float32), np.zeros((n, 8), np.float32), np.zeros((n, 4), np.float32), np.zeros(n, np.float32)
+    gpu_ctx.check(gpu_ctx.L.sdso_immature_init_batch(gpu_ctx.h, 30, n, abi.fp(pr["u"]), abi.fp(pr["v"]), abi.fp(col), abi.fp(wgt), abi.fp(gH), abi.fp(eth)))
+    P, dd = abi.make_trace_points(n, pr["u"], pr["v"], col, wgt, gH, eth)
+    stt = np.zeros(n, np.uint8)
+    K = np.array(pr["K"], np.float32)
+    gpu_ctx.check(gpu_ctx.L.sdso_trace_set_gn_mode(gpu_ctx.h, 1))
+    try:
+        gpu_ctx.check(gpu_ctx.L.sdso_trace_stereo_batch(gpu_ctx.h, 31, abi.fp(K), float(pr["calib"]["baseline"]), 1, C.byref(P), abi.bp(stt)))
+    finally:
+        gpu_ctx.check(gpu_ctx.L.sdso_trace_set_gn_mode(gpu_ctx.h, 0))
+    assert np.array_equal(stt, exp["trace_status"])
+    for k in ("idepth_min_stereo", "idepth_max_stereo", "idepth_stereo", "lastTraceUV", "lastTracePixelInterval"):
+        assert np.array_equal(dd[k], exp["trace_" + k], equal_nan=True), k

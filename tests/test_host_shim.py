@@ -65,6 +65,33 @@ def test_shim_tracker(gpu_ctx, tmp_path):
 
 
 @pytest.mark.gpu
+def test_shim_fork_live_modes(gpu_ctx, tmp_path):
+    """CoarseTracker::forkLive and Device::setForkLiveTraceRefinement select the fork's g2o factors (sdso_g2o_*)."""
+    prob = synth.tracker_problem(w=640, h=480, npts=1500, seed=2011)
+    L = prob["levels"]
+    prm = helpers.track_params(prob)
+    gpu_ctx.upload_pyramid(2, prob["pyr_new"]); gpu_ctx.set_ref(1, prob["pc"])
+    T = abi.SE3.from_Rt(np.eye(3), np.zeros(3)); aff = abi.Aff(0, 0); out = abi.TrackResult()
+    gpu_ctx.check(gpu_ctx.L.sdso_g2o_track_newest_coarse(gpu_ctx.h, 1, 2, C.byref(prm), C.byref(T), C.byref(aff), C.byref(out)))
+    arrays = dict(meta=np.array([L, 640, 480, prm.coarsestLvl], np.int32), calib=np.array(prob["K"], np.float64),
+                  misc=np.array([1.0, 1.0, 0.0, 0.0] + list(np.eye(3).ravel()) + [0, 0, 0] + [0.0, 0.0] + [np.nan] * 5, np.float64))
+    for l in range(L):
+        arrays["ref_l%d" % l] = prob["pyr_ref"][l]; arrays["new_l%d" % l] = prob["pyr_new"][l]
+        for k in ("u", "v", "idepth", "color"):
+            arrays["pc_%s_l%d" % (k, l)] = prob["pc"][l][k]
+    _dump(tmp_path, **arrays)
+    lines = _run(tmp_path, "tracker_g2o")
+    assert lines[0] == "good 1" and out.good == 1
+    Tc = np.array(lines[1].split()[1:], np.float64)
+    R, t = T.Rt()
+    assert np.array_equal(Tc[:9].reshape(3, 3), R) and np.array_equal(Tc[9:], t)       # same library, same calls: identical
+    resc = np.array(lines[3].split()[1:], np.float64)
+    assert np.array_equal(resc, np.array(list(out.lastResiduals)), equal_nan=True)
+    native = _run(tmp_path, "tracker")
+    assert native[0] == "good 1" and native[1] != lines[1]                               # and it is not the native LM
+
+
+@pytest.mark.gpu
 def test_shim_trace_stereo(gpu_ctx, tmp_path):
     pr = synth.stereo_problem(w=640, h=480, npts=1200, seed=4011)
     left = np.ascontiguousarray(pr["pyr_l"][0]); right = np.ascontiguousarray(pr["pyr_r"][0])
