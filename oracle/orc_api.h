@@ -235,12 +235,7 @@ typedef struct {
 } orc_g2o_lba_t;
 int orc_g2o_lba_eval(const orc_g2o_lba_t* L, double* error, double* J, uint8_t* state, float* energy,
                      float* centerProjectedTo, float* idepth_hessian, uint8_t* edge_level);
-/* FullSystem::optimize, fork-live (FullSystemOptimize.cpp:403-600): g2o LM with Schur complement over the idepth vertices.
- * Twh / Ttw: nf * 12 doubles (R row-major 9 | t 3) = PRE_camToWorld / PRE_worldToCam; aff: nf * 2; exposure: nf.
- * info[4] = {iterations run, first chi2, last chi2, last lambda}.  L->pair_* / host_b0 are ignored (derived inside). */
-int orc_g2o_lba_optimize(const orc_g2o_lba_t* L, const double* Twh, const double* Ttw, const double* aff, const float* exposure, int its,
-                         double* Twh_out, double* aff_out, double* cam_out, double* idepth_out, uint8_t* state, float* energy,
-                         float* centerProjectedTo, float* idepth_hessian, uint8_t* edge_level, double* info);
+
 
 #ifdef __cplusplus
 }

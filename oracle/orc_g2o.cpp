@@ -413,213 +413,3 @@ extern "C" int orc_g2o_lba_eval(const orc_g2o_lba_t* L, double* error, double* J
   }
   return 0;
 }
-
-// ---------------------------------------------------------------------------------------------------------------
-// FullSystem::optimize as the fork runs it (FullSystemOptimize.cpp:403-600): graph of one camera vertex, a pose and a
-// photometric vertex per HOST frame, one marginalised idepth vertex per residual; g2o Levenberg-Marquardt (lambda0 0.1,
-// Schur complement on the idepths, gain threshold 1e-3) for its = 10 / 7 / 3 iterations.  Restated g2o: unpinned.
-//   frames: Twh[nf*12] (PRE_camToWorld: R row-major 9 | t 3), Ttw[nf*12] (PRE_worldToCam), aff[nf*2], exposure[nf]
-//   per residual: as orc_g2o_lba_t (pair tables are derived here and ignored on input)
-// Output: Twh_out[nf*12], aff_out[nf*2] (frames that host no active edge keep their input), cam_out[4], idepth_out[nr],
-//   state/energy/centerProjectedTo/idepth_hessian/edge_level as left by the last calls, info = {iterations, chi2_first, chi2_last, lambda_last}
-extern "C" int orc_g2o_lba_optimize(const orc_g2o_lba_t* L0, const double* Twh_in, const double* Ttw, const double* aff_in, const float* exposure, int its,
-                                    double* Twh_out, double* aff_out, double* cam_out, double* idepth_out, uint8_t* state, float* energy,
-                                    float* centerProjectedTo, float* idepth_hessian, uint8_t* edge_level, double* info) {
-  const int nf = L0->nf, nr = L0->nr;
-  orc_g2o_lba_t L = *L0;
-  std::vector<SE3> Twh(nf), Tt(nf);
-  std::vector<double> aff(aff_in, aff_in + 2 * nf), idepth(L0->idepth, L0->idepth + nr);
-  double cam[4] = {L0->cam[0], L0->cam[1], L0->cam[2], L0->cam[3]};
-  for (int f = 0; f < nf; f++) {
-    std::memcpy(Twh[f].R, Twh_in + f * 12, 72); std::memcpy(Twh[f].t, Twh_in + f * 12 + 9, 24);
-    std::memcpy(Tt[f].R, Ttw + f * 12, 72); std::memcpy(Tt[f].t, Ttw + f * 12 + 9, 24);
-  }
-  std::vector<double> b0(nf);
-  for (int f = 0; f < nf; f++) b0[f] = aff_in[f * 2 + 1];          // SetB(a0b0.b) at graph build, never refreshed
-  std::vector<float> pR((size_t)nf * nf * 9), pt((size_t)nf * nf * 3), pab((size_t)nf * nf * 2);
-  auto tables = [&](const std::vector<SE3>& Th, const std::vector<double>& a) {
-    for (int h = 0; h < nf; h++)
-      for (int t = 0; t < nf; t++) {
-        const SE3 T = se3_mul(Tt[t], Th[h]);                        // Tth = Ttw * Twh (dso_g2o_edge.cpp:25-27)
-        for (int k = 0; k < 9; k++) pR[(size_t)(h * nf + t) * 9 + k] = (float)T.R[k];
-        for (int k = 0; k < 3; k++) pt[(size_t)(h * nf + t) * 3 + k] = (float)T.t[k];
-        double ab[2];
-        fromToVecExposure(exposure[h], exposure[t], a[h * 2], a[h * 2 + 1], aff_in[t * 2], aff_in[t * 2 + 1], ab);   // a1b1 = target->aff_g2l(): constant
-        pab[(size_t)(h * nf + t) * 2] = (float)ab[0]; pab[(size_t)(h * nf + t) * 2 + 1] = (float)ab[1];
-      }
-  };
-  std::vector<LbaEdge> E(nr);
-  auto pairOf = [&](int ri) {
-    const int h = L.host[ri], tg = L.target[ri];
-    return LbaPair{pR.data() + (size_t)(h * nf + tg) * 9, pt.data() + (size_t)(h * nf + tg) * 3, pab.data() + (size_t)(h * nf + tg) * 2};
-  };
-  // graph build: every edge evaluates itself once (FullSystemOptimize.cpp:530-533)
-  tables(Twh, aff);
-  for (int ri = 0; ri < nr; ri++) { E[ri].init(); lbaComputeError(&L, ri, pairOf(ri), cam, idepth[ri], E[ri]); }
-  std::vector<uint8_t> active(nr);
-  std::vector<int> hostUsed(nf, 0);
-  for (int ri = 0; ri < nr; ri++) { active[ri] = E[ri].level == 0; hostUsed[L.host[ri]] = 1; }   // vertices exist for every host of activeResiduals
-  // variable layout: [cam 4 | frame f: pose 6, photometric 2]; frames without vertices are left out of the solve
-  const int np = 4 + 8 * nf;
-  std::vector<int> var;                    // indices of live variables
-  for (int k = 0; k < 4; k++) var.push_back(k);
-  for (int f = 0; f < nf; f++) if (hostUsed[f]) for (int k = 0; k < 8; k++) var.push_back(4 + 8 * f + k);
-  const int nv = (int)var.size();
-
-  auto computeErrors = [&]() {
-    double chi = 0;
-    for (int ri = 0; ri < nr; ri++) {
-      if (!active[ri]) continue;
-      lbaComputeError(&L, ri, pairOf(ri), cam, idepth[ri], E[ri]);
-      double e2 = 0;
-      for (int k = 0; k < 8; k++) e2 += E[ri].e[k] * E[ri].e[k];
-      double rho[2];
-      huber(e2, setting_huberTH, rho);
-      chi += rho[0];
-    }
-    return chi;
-  };
-  // per edge: w, Hpl (12), Hll, bl with the 12 local variables [cam 4 | pose 6 | photometric 2]
-  auto edgeTerms = [&](int ri, double* w, double* g, double* Hll, double* bl, double Jp[8][12]) {
-    const LbaEdge& S = E[ri];
-    double e2 = 0;
-    for (int k = 0; k < 8; k++) e2 += S.e[k] * S.e[k];
-    double rho[2];
-    huber(e2, setting_huberTH, rho);
-    *w = rho[1];
-    for (int k = 0; k < 8; k++) {
-      const double* row = S.J + k * 13;
-      for (int c = 0; c < 4; c++) Jp[k][c] = row[9 + c];
-      for (int c = 0; c < 8; c++) Jp[k][4 + c] = row[c];
-    }
-    *Hll = 0; *bl = 0;
-    for (int k = 0; k < 8; k++) { const double jd = S.J[k * 13 + 8]; *Hll += jd * rho[1] * jd; *bl -= rho[1] * jd * S.e[k]; }
-    for (int c = 0; c < 12; c++) { g[c] = 0; for (int k = 0; k < 8; k++) g[c] += Jp[k][c] * rho[1] * S.J[k * 13 + 8]; }
-  };
-
-  double lambda = 0, ni = 2, lastChi = 0, chiFirst = 0, chiLast = 0;
-  bool stop = false, ok = true;
-  int done = 0;
-  for (int it = 0; it < its && !stop && ok; it++) {
-    double currentChi = computeErrors();
-    if (it == 0) chiFirst = currentChi;
-    for (int ri = 0; ri < nr; ri++) if (active[ri]) lbaLinearize(&L, ri, pairOf(ri), cam, idepth[ri], b0[L.host[ri]], E[ri]);
-    if (it == 0) { lambda = 0.1; ni = 2; }                           // setUserLambdaInit(0.1), :424
-    // Hpp, bp without lambda (sums in edge order)
-    MatX Hpp(np, np); VecX bp(np);
-    for (int i = 0; i < np; i++) { bp[i] = 0; for (int j = 0; j < np; j++) Hpp(i, j) = 0; }
-    for (int ri = 0; ri < nr; ri++) {
-      if (!active[ri]) continue;
-      double w, g[12], Hll, bl, Jp[8][12];
-      edgeTerms(ri, &w, g, &Hll, &bl, Jp);
-      const int h = L.host[ri];
-      int gi[12];
-      for (int c = 0; c < 4; c++) gi[c] = c;
-      for (int c = 0; c < 8; c++) gi[4 + c] = 4 + 8 * h + c;
-      for (int r = 0; r < 12; r++) {
-        double br = 0;
-        for (int k = 0; k < 8; k++) br -= w * Jp[k][r] * E[ri].e[k];
-        bp[gi[r]] += br;
-        for (int c = 0; c < 12; c++) { double v = 0; for (int k = 0; k < 8; k++) v += Jp[k][r] * w * Jp[k][c]; Hpp(gi[r], gi[c]) += v; }
-      }
-    }
-    double rho = 0;
-    int qmax = 0;
-    do {
-      // Schur complement with the current lambda on both diagonals
-      MatX A(nv, nv); VecX rhs(nv), xs(nv);
-      std::vector<double> S(np * np, 0.0), bs(np, 0.0);
-      for (int i = 0; i < np; i++) { bs[i] = bp[i]; for (int j = 0; j < np; j++) S[i * np + j] = Hpp(i, j); S[i * np + i] += lambda; }
-      for (int ri = 0; ri < nr; ri++) {
-        if (!active[ri]) continue;
-        double w, g[12], Hll, bl, Jp[8][12];
-        edgeTerms(ri, &w, g, &Hll, &bl, Jp);
-        const double inv = 1.0 / (Hll + lambda);
-        const int h = L.host[ri];
-        int gi[12];
-        for (int c = 0; c < 4; c++) gi[c] = c;
-        for (int c = 0; c < 8; c++) gi[4 + c] = 4 + 8 * h + c;
-        for (int r = 0; r < 12; r++) {
-          bs[gi[r]] -= g[r] * inv * bl;
-          for (int c = 0; c < 12; c++) S[gi[r] * np + gi[c]] -= g[r] * inv * g[c];
-        }
-      }
-      for (int i = 0; i < nv; i++) { rhs[i] = bs[var[i]]; for (int j = 0; j < nv; j++) A(i, j) = S[var[i] * np + var[j]]; }
-      const bool ok2 = ldlt_solve(A, rhs, xs);
-      std::vector<double> xp(np, 0.0), xl(nr, 0.0);
-      if (ok2) for (int i = 0; i < nv; i++) xp[var[i]] = xs[i];
-      // landmarks and the LM scale over ALL increments
-      double scale = 0;
-      for (int i = 0; i < nv; i++) scale += xp[var[i]] * (lambda * xp[var[i]] + bp[var[i]]);
-      std::vector<SE3> Tn = Twh;
-      std::vector<double> affN = aff, idN = idepth;
-      double camN[4] = {cam[0], cam[1], cam[2], cam[3]};
-      for (int ri = 0; ri < nr && ok2; ri++) {
-        if (!active[ri]) continue;
-        double w, g[12], Hll, bl, Jp[8][12];
-        edgeTerms(ri, &w, g, &Hll, &bl, Jp);
-        const int h = L.host[ri];
-        double c = bl;
-        for (int r = 0; r < 4; r++) c -= g[r] * xp[r];
-        for (int r = 0; r < 8; r++) c -= g[4 + r] * xp[4 + 8 * h + r];
-        xl[ri] = c / (Hll + lambda);
-        scale += xl[ri] * (lambda * xl[ri] + bl);
-        idN[ri] = idepth[ri] + xl[ri];                                 // VertexInverseDepthDSO::oplusImpl
-      }
-      if (ok2) {
-        for (int k = 0; k < 4; k++) camN[k] += xp[k];                  // VertexCamDSO::oplusImpl
-        for (int f = 0; f < nf; f++) {
-          if (!hostUsed[f]) continue;
-          Tn[f] = se3_mul(se3_exp(&xp[4 + 8 * f]), Twh[f]);           // VertexSE3PoseDSO::oplusImpl
-          affN[f * 2] += xp[4 + 8 * f + 6]; affN[f * 2 + 1] += xp[4 + 8 * f + 7];
-        }
-      }
-      // trial
-      std::swap(Twh, Tn); std::swap(aff, affN); std::swap(idepth, idN);
-      double camB[4]; for (int k = 0; k < 4; k++) { camB[k] = cam[k]; cam[k] = camN[k]; }
-      tables(Twh, aff);
-      double tempChi = computeErrors();
-      if (!ok2) tempChi = 1.7976931348623157e308;
-      rho = (currentChi - tempChi) / (scale + 1e-3);
-      if (rho > 0 && std::isfinite(tempChi)) {
-        double alpha = 1. - std::pow((2 * rho - 1), 3);
-        alpha = std::min(alpha, 2. / 3.);
-        lambda *= std::max(1. / 3., alpha);
-        ni = 2;
-        currentChi = tempChi;
-      } else {
-        lambda *= ni;
-        ni *= 2;
-        std::swap(Twh, Tn); std::swap(aff, affN); std::swap(idepth, idN);   // pop(): estimates only, the edges keep what the trial wrote
-        for (int k = 0; k < 4; k++) cam[k] = camB[k];
-        tables(Twh, aff);
-        if (!std::isfinite(lambda)) break;
-      }
-      qmax++;
-    } while (rho < 0 && qmax < 10);
-    done++;
-    if (qmax == 10 || rho == 0 || !std::isfinite(lambda)) ok = false;
-    const double chiNow = computeErrors();                              // terminate action: computeActiveErrors at the kept estimate
-    chiLast = chiNow;
-    if (it == 0) lastChi = chiNow;
-    else {
-      const double gain = (lastChi - chiNow) / chiNow;
-      lastChi = chiNow;
-      if (gain >= 0 && gain < 1e-3) stop = true;
-    }
-  }
-  for (int f = 0; f < nf; f++) {
-    std::memcpy(Twh_out + f * 12, Twh[f].R, 72); std::memcpy(Twh_out + f * 12 + 9, Twh[f].t, 24);
-    aff_out[f * 2] = aff[f * 2]; aff_out[f * 2 + 1] = aff[f * 2 + 1];
-  }
-  for (int k = 0; k < 4; k++) cam_out[k] = cam[k];
-  for (int ri = 0; ri < nr; ri++) {
-    idepth_out[ri] = idepth[ri];
-    state[ri] = E[ri].state; edge_level[ri] = E[ri].level;
-    energy[ri * 2] = E[ri].energy[0]; energy[ri * 2 + 1] = E[ri].energy[1];
-    for (int k = 0; k < 3; k++) centerProjectedTo[ri * 3 + k] = E[ri].cpt[k];
-    idepth_hessian[ri] = E[ri].ih;
-  }
-  info[0] = done; info[1] = chiFirst; info[2] = chiLast; info[3] = lambda;
-  return 0;
-}

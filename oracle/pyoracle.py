@@ -84,7 +84,5 @@ def load(fast=False):
     L.orc_g2o_track_newest_coarse.argtypes = [c_int_p, C.POINTER(c_float_p), C.POINTER(c_float_p), C.POINTER(c_float_p), C.POINTER(c_float_p),
                                               C.POINTER(c_float_p), C.POINTER(TrackParams), C.POINTER(SE3), C.POINTER(Aff), C.POINTER(TrackResult)]
     L.orc_g2o_lba_eval.argtypes = [C.POINTER(G2oLba), c_double_p, c_double_p, c_u8_p, c_float_p, c_float_p, c_float_p, c_u8_p]
-    L.orc_g2o_lba_optimize.argtypes = [C.POINTER(G2oLba), c_double_p, c_double_p, c_double_p, c_float_p, C.c_int, c_double_p, c_double_p, c_double_p,
-                                       c_double_p, c_u8_p, c_float_p, c_float_p, c_float_p, c_u8_p, c_double_p]
     _libs[name] = L
     return L

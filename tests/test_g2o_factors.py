@@ -260,6 +260,35 @@ def test_oracle_lba_edge_idepth_jacobian_and_energy(oracle):
     sc = np.abs(ana[ok]).max()
     bad = np.abs(ana[ok] - num[ok]) > 0.03 * sc + 0.1 * np.abs(ana[ok])
     assert bad.mean() < 0.03
+    # the 8x6 pose block is the derivative under a LEFT perturbation of Tth = Ttw * Twh (the target-frame convention of
+    # Residuals.cpp:173-185).  (The fork attaches it to a vertex that perturbs Twh, and its photometric block keeps the
+    # tracker's sign although the vertex here is the HOST's (a, b): the window optimiser built on these edges is steered by
+    # g2o's accept / reject logic, which is one more reason it is not a parity target — DESIGN.md section 1.)
+    win, nf = d["win"], d["nf"]
+
+    def tables(delta):
+        pR = np.zeros((nf * nf, 9), np.float32); pt = np.zeros((nf * nf, 3), np.float32)
+        for h in range(nf):
+            for t in range(nf):
+                T = synth.se3_mul(synth.se3_exp(delta), synth.se3_mul(win["poses"][t], synth.se3_inv(win["poses"][h])))
+                pR[h * nf + t] = T[0].astype(np.float32).ravel(); pt[h * nf + t] = T[1].astype(np.float32)
+        return pR, pt
+    num6 = np.zeros((d["nr"], 8, 6))
+    ok6 = ok.copy()
+    for k in range(6):
+        es = []
+        for s in (+1, -1):
+            d2 = dict(d); v = np.zeros(6); v[k] = s * eps
+            d2["pair_R"], d2["pair_t"] = tables(v)
+            S2, k2 = _lba_struct(d2, dI=smooth)
+            o2 = _lba_out(d["nr"])
+            oracle.orc_g2o_lba_eval(C.byref(S2), *_lba_args(o2))
+            es.append(o2)
+            ok6 &= o2["state"] != 1
+        num6[:, :, k] = (es[0]["error"] - es[1]["error"]) / (2 * eps)
+    a6 = outs[0]["J"][:, :, :6][ok6].reshape(-1, 6); n6 = num6[ok6].reshape(-1, 6)
+    for k in range(6):
+        assert np.corrcoef(a6[:, k], n6[:, k])[0, 1] > 0.999 and abs(np.polyfit(a6[:, k], n6[:, k], 1)[0] - 1) < 0.01, k
     assert np.all(o["J"][inl][:, :, 7] == -1.0)
     # centre pixel projection is inside the target image
     assert np.all(o["cpt"][inl][:, 0] > 2) and np.all(o["cpt"][inl][:, 0] < 640 - 3)
