@@ -206,7 +206,9 @@ typedef struct {
   const double* HM;                /* (8nf+4)^2 */
   const double* bM;                /* 8nf+4 */
   /* settings */
-  int solverMode;                  /* setting_solverMode (settings.h:32-43) */
+  int solverMode;                  /* setting_solverMode (settings.h:32-43): every bit solveSystemF reads is honoured (SVD, SVD_CUT7,
+                                      ORTHOGONALIZE_SYSTEM, REMOVE_POSEPRIOR, USE_GN, FIX_LAMBDA, ORTHOGONALIZE_X[_LATER]); SVD and
+                                      ORTHOGONALIZE_SYSTEM windows are solved per window (not in sdso_ba_batch_*) */
   double affineOptModeA, affineOptModeB;
   int forceAcceptStep;             /* setting_forceAceptStep */
 } sdso_ba_window_t;

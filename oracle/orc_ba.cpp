@@ -875,7 +875,38 @@ struct orc_ba {
       for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) HFinal_top(i, j) -= H_sc(i, j) * f;
     }
     VecX x;
-    {  // LDLT branch (:966-977); the SVD branch (:924-965) is not restated (SOLVER_SVD is off by default)
+    if (solverMode & SOLVER_SVD) {  // :924-965.  JacobiSVD of the symmetric scaled system = its eigen-decomposition: S = |w| sorted
+      VecX SVecI(n);                // decreasing, U_i = sign(w_i) V_i (Eigen is external and unpinned: restated, not copied)
+      for (int i = 0; i < n; i++) SVecI[i] = 1.0 / std::sqrt(HFinal_top(i, i));
+      MatX HFinalScaled(n, n);
+      VecX bs(n);
+      for (int i = 0; i < n; i++) { for (int j = 0; j < n; j++) HFinalScaled(i, j) = SVecI[i] * HFinal_top(i, j) * SVecI[j]; bs[i] = SVecI[i] * bFinal_top[i]; }
+      VecX w; MatX V;
+      sym_eigen(HFinalScaled, w, V);
+      std::vector<int> ord(n);
+      for (int i = 0; i < n; i++) ord[i] = i;
+      std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return std::fabs(w[a]) > std::fabs(w[b]); });
+      double maxSv = 0;
+      for (int i = 0; i < n; i++) maxSv = std::max(maxSv, std::fabs(w[i]));
+      VecX Ub(n, 0.0);
+      for (int i = 0; i < n; i++) {
+        const int c = ord[i];
+        const double S = std::fabs(w[c]);
+        double ub = 0;
+        for (int k = 0; k < n; k++) ub += V(k, c) * bs[k];
+        if (w[c] < 0) ub = -ub;
+        if (S < setting_solverModeDelta * maxSv) ub = 0;
+        if ((solverMode & SOLVER_SVD_CUT7) && (i >= n - 7)) ub = 0;
+        else ub /= S;
+        Ub[i] = ub;
+      }
+      x.assign(n, 0.0);
+      for (int i = 0; i < n; i++) {
+        const int c = ord[i];
+        for (int k = 0; k < n; k++) x[k] += V(k, c) * Ub[i];
+      }
+      for (int k = 0; k < n; k++) x[k] *= SVecI[k];
+    } else {  // LDLT branch (:966-977)
       VecX SVecI(n);
       for (int i = 0; i < n; i++) SVecI[i] = 1.0 / std::sqrt(HFinal_top(i, i) + 10);
       MatX HFinalScaled(n, n);

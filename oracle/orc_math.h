@@ -370,4 +370,32 @@ inline void span_projector(const MatX& N, double delta, MatX& P) {
   }
 }
 
+// Eigen-decomposition of a symmetric matrix by cyclic Jacobi rotations: A = V diag(w) V^T (columns of V).  Stands in for
+// Eigen::JacobiSVD on the symmetric system matrix of EnergyFunctional.cpp:931 (singular values = |w|, U = V sign(w)).
+inline void sym_eigen(const MatX& Ain, VecX& w, MatX& V) {
+  const int n = Ain.r;
+  MatX G = Ain;
+  V = MatX(n, n);
+  for (int i = 0; i < n; i++) V(i, i) = 1;
+  double nrm = 0;
+  for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) nrm += G(i, j) * G(i, j);
+  for (int sweep = 0; sweep < 100; sweep++) {
+    double off = 0;
+    for (int i = 0; i < n; i++) for (int j = i + 1; j < n; j++) off += G(i, j) * G(i, j);
+    if (off <= 1e-30 * nrm) break;
+    for (int p = 0; p < n; p++)
+      for (int q = p + 1; q < n; q++) {
+        if (G(p, q) == 0.0) continue;
+        const double tau = (G(q, q) - G(p, p)) / (2 * G(p, q));
+        const double t = (tau >= 0 ? 1.0 : -1.0) / (std::fabs(tau) + std::sqrt(1 + tau * tau));
+        const double c = 1 / std::sqrt(1 + t * t), sn = t * c;
+        for (int k = 0; k < n; k++) { const double a = G(k, p), b = G(k, q); G(k, p) = c * a - sn * b; G(k, q) = sn * a + c * b; }
+        for (int k = 0; k < n; k++) { const double a = G(p, k), b = G(q, k); G(p, k) = c * a - sn * b; G(q, k) = sn * a + c * b; }
+        for (int k = 0; k < n; k++) { const double a = V(k, p), b = V(k, q); V(k, p) = c * a - sn * b; V(k, q) = sn * a + c * b; }
+      }
+  }
+  w.assign(n, 0.0);
+  for (int i = 0; i < n; i++) w[i] = G(i, i);
+}
+
 }  // namespace orc

@@ -157,8 +157,9 @@ static int upload_window_impl(sdso_ctx* ctx, int win, const sdso_ba_window_t* Wi
   SDSO_REQUIRE(ctx, Win->evalPT && Win->state && Win->state_zero && Win->ab_exposure && Win->frameEnergyTH && Win->frameID && Win->frame_slot, "null frame arrays");
   SDSO_REQUIRE(ctx, np == 0 || (Win->u && Win->v && Win->idepth && Win->idepth_zero && Win->color && Win->weights && Win->host && Win->hasDepthPrior), "null point arrays");
   SDSO_REQUIRE(ctx, nr == 0 || (Win->res_point && Win->res_target && Win->res_state), "null residual arrays");
-  const int unsupported = SOLVER_SVD | SOLVER_ORTHOGONALIZE_SYSTEM | SOLVER_ORTHOGONALIZE_POINTMARG | SOLVER_ORTHOGONALIZE_FULL | SOLVER_MOMENTUM | SOLVER_STEPMOMENTUM;
-  SDSO_REQUIRE(ctx, (Win->solverMode & unsupported) == 0, "solverMode bit not supported on the device path (only the reference default FIX_LAMBDA|ORTHOGONALIZE_X_LATER family)");
+  // bits solveSystemF never reads (ORTHOGONALIZE_POINTMARG / _FULL, MOMENTUM) or that only the un-compiled driver uses (STEPMOMENTUM)
+  const int unsupported = SOLVER_ORTHOGONALIZE_POINTMARG | SOLVER_ORTHOGONALIZE_FULL | SOLVER_MOMENTUM | SOLVER_STEPMOMENTUM;
+  SDSO_REQUIRE(ctx, (Win->solverMode & unsupported) == 0, "solverMode bit not supported (ORTHOGONALIZE_POINTMARG / ORTHOGONALIZE_FULL / MOMENTUM / STEPMOMENTUM)");
   int rc = sdso_ba_release_window(ctx, win);
   if (rc) return rc;
   const bool use_tiled = getenv("SDSO_BA_ROWMAJOR") == nullptr;   // 4x2-tiled level-0 images for the linearisation (default)
@@ -625,9 +626,115 @@ extern "C" int sdso_ba_get_point_terms(sdso_ctx* ctx, int win, float* HdiF, floa
 }
 
 namespace sdso {
+// solveSystemF's non-default branches (EnergyFunctional.cpp:876-900 SOLVER_ORTHOGONALIZE_SYSTEM, :924-965 SOLVER_SVD [_CUT7]):
+// the stitched 68x68 blocks come back from the device, the assembly and the solve run on the host in double (a Jacobi
+// eigen-decomposition stands in for Eigen::JacobiSVD of the symmetric matrix), x / lastHS / lastbS go back for the
+// back-substitution kernel.  Single-window path only; the batch entry points keep the default branch.
+static int solve_system_host(sdso_ctx* ctx, BaWindowDev* W, int iteration, double lambda) {
+  const BaLaunch L = single(W);
+  const int nf = L.nf, n = L.n;
+  hipLaunchKernelGGL(k_ba_stitch, dim3(3 * (nf * nf + nf + 1), 1), dim3(256), 0, ctx->stream, L.d_arr);
+  SDSO_HIP(ctx, hipGetLastError());
+  const size_t blk = (size_t)n * n + n;
+  std::vector<double> st(3 * blk);
+  SDSO_HIP(ctx, hipMemcpyAsync(st.data(), W->d.sol, sizeof(double) * st.size(), hipMemcpyDeviceToHost, ctx->stream));
+  SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const double *HA = st.data(), *bA = HA + (size_t)n * n, *HL = st.data() + blk, *bL = HL + (size_t)n * n, *HS = st.data() + 2 * blk, *bS = HS + (size_t)n * n;
+  std::vector<double> delta(n), bM_top(n);
+  for (int i = 0; i < 4; i++) delta[i] = (double)W->tab.cDeltaF[i];
+  for (int f = 0; f < nf; f++) for (int i = 0; i < 8; i++) delta[4 + 8 * f + i] = W->frames[f].delta[i];
+  for (int i = 0; i < n; i++) { double s = 0; for (int k = 0; k < n; k++) s += W->HM[(size_t)i * n + k] * delta[k]; bM_top[i] = W->bM[i] + s; }
+  Dense Hf(n);
+  std::vector<double> bf(n), lastHS((size_t)n * n), lastbS(n);
+  auto orthogonalize = [&](std::vector<double>* b, Dense* H) {   // EnergyFunctional.cpp:775-835 with the window's projector
+    const Dense& P = W->P;
+    if (b) { std::vector<double> Pb(n, 0.0); for (int i = 0; i < n; i++) { double s = 0; for (int k = 0; k < n; k++) s += P(i, k) * (*b)[k]; Pb[i] = s; } for (int i = 0; i < n; i++) (*b)[i] -= Pb[i]; }
+    if (H) {
+      Dense PH(n), PHP(n);
+      for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) { double s = 0; for (int k = 0; k < n; k++) s += P(i, k) * (*H)(k, j); PH(i, j) = s; }
+      for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) { double s = 0; for (int k = 0; k < n; k++) s += PH(i, k) * P(k, j); PHP(i, j) = s; }
+      for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) (*H)(i, j) -= PHP(i, j);
+    }
+  };
+  if (W->solverMode & SOLVER_ORTHOGONALIZE_SYSTEM) {
+    bool haveFirstFrame = false;
+    for (const HostFrame& f : W->frames) if (f.frameID == 0) haveFirstFrame = true;
+    Dense HT(n);
+    std::vector<double> bT(n);
+    for (int i = 0; i < n; i++) { for (int j = 0; j < n; j++) HT(i, j) = HL[(size_t)i * n + j] + HA[(size_t)i * n + j] - HS[(size_t)i * n + j]; bT[i] = bL[i] + bA[i] - bS[i]; }
+    if (!haveFirstFrame) orthogonalize(&bT, &HT);
+    for (int i = 0; i < n; i++) { for (int j = 0; j < n; j++) Hf(i, j) = HT(i, j) + W->HM[(size_t)i * n + j]; bf[i] = bT[i] + bM_top[i]; }
+    for (int i = 0; i < n; i++) { for (int j = 0; j < n; j++) lastHS[(size_t)i * n + j] = Hf(i, j); lastbS[i] = bf[i]; }
+    for (int i = 0; i < n; i++) Hf(i, i) *= (1 + lambda);
+  } else {
+    for (int i = 0; i < n; i++) {
+      for (int j = 0; j < n; j++) Hf(i, j) = HL[(size_t)i * n + j] + W->HM[(size_t)i * n + j] + HA[(size_t)i * n + j];
+      bf[i] = bL[i] + bM_top[i] + bA[i] - bS[i];
+    }
+    for (int i = 0; i < n; i++) { for (int j = 0; j < n; j++) lastHS[(size_t)i * n + j] = Hf(i, j) - HS[(size_t)i * n + j]; lastbS[i] = bf[i]; }
+    for (int i = 0; i < n; i++) Hf(i, i) *= (1 + lambda);
+    const double f = (double)(1.0f / (1 + lambda));
+    for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) Hf(i, j) -= HS[(size_t)i * n + j] * f;
+  }
+  std::vector<double> x(n, 0.0);
+  if (W->solverMode & SOLVER_SVD) {
+    std::vector<double> sv(n), bs(n), w;
+    for (int i = 0; i < n; i++) sv[i] = 1.0 / std::sqrt(Hf(i, i));
+    Dense Hs(n), V;
+    for (int i = 0; i < n; i++) { for (int j = 0; j < n; j++) Hs(i, j) = sv[i] * Hf(i, j) * sv[j]; bs[i] = sv[i] * bf[i]; }
+    symEigen(Hs, w, V);
+    std::vector<int> ord(n);
+    for (int i = 0; i < n; i++) ord[i] = i;
+    std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return std::fabs(w[a]) > std::fabs(w[b]); });
+    double maxSv = 0;
+    for (int i = 0; i < n; i++) maxSv = std::max(maxSv, std::fabs(w[i]));
+    for (int i = 0; i < n; i++) {
+      const int c = ord[i];
+      const double S = std::fabs(w[c]);
+      double ub = 0;
+      for (int k = 0; k < n; k++) ub += V(k, c) * bs[k];
+      if (w[c] < 0) ub = -ub;
+      if (S < kSolverModeDelta * maxSv) ub = 0;                            // setting_solverModeDelta, settings.cpp:52
+      if ((W->solverMode & SOLVER_SVD_CUT7) && (i >= n - 7)) ub = 0;
+      else ub /= S;
+      for (int k = 0; k < n; k++) x[k] += V(k, c) * ub;
+    }
+    for (int k = 0; k < n; k++) x[k] *= sv[k];
+  } else {
+    std::vector<double> sv(n), bs(n), y;
+    for (int i = 0; i < n; i++) sv[i] = 1.0 / std::sqrt(Hf(i, i) + 10);
+    Dense Hs(n);
+    for (int i = 0; i < n; i++) { for (int j = 0; j < n; j++) Hs(i, j) = sv[i] * Hf(i, j) * sv[j]; bs[i] = sv[i] * bf[i]; }
+    solveLdlt(Hs, bs, y);
+    for (int i = 0; i < n; i++) x[i] = sv[i] * y[i];
+  }
+  if ((W->solverMode & SOLVER_ORTHOGONALIZE_X) || (iteration >= 2 && (W->solverMode & SOLVER_ORTHOGONALIZE_X_LATER))) orthogonalize(&x, nullptr);
+  double* xout = W->d.sol + 3 * blk;
+  SDSO_HIP(ctx, hipMemcpyAsync(xout, x.data(), sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
+  SDSO_HIP(ctx, hipMemcpyAsync(xout + n, lastHS.data(), sizeof(double) * n * n, hipMemcpyHostToDevice, ctx->stream));
+  SDSO_HIP(ctx, hipMemcpyAsync(xout + n + (size_t)n * n, lastbS.data(), sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
+  // xAd[nf*h+t] = xF(h)^T adHostF[h+nf*t] + xF(t)^T adTargetF[h+nf*t]  (EnergyFunctional.cpp:289-291), as k_ba_solve leaves it
+  std::vector<float> xAd((size_t)nf * nf * 8);
+  for (int h = 0; h < nf; h++)
+    for (int t = 0; t < nf; t++)
+      for (int j = 0; j < 8; j++) {
+        float sh = 0, stt = 0;
+        for (int i = 0; i < 8; i++) {
+          sh += (float)x[4 + 8 * h + i] * (float)W->tab.adHost[(size_t)(h + nf * t) * 64 + i * 8 + j];
+          stt += (float)x[4 + 8 * t + i] * (float)W->tab.adTarget[(size_t)(h + nf * t) * 64 + i * 8 + j];
+        }
+        xAd[(size_t)(nf * h + t) * 8 + j] = sh + stt;
+      }
+  SDSO_HIP(ctx, hipMemcpyAsync(W->dt_xAd, xAd.data(), sizeof(float) * xAd.size(), hipMemcpyHostToDevice, ctx->stream));
+  if (L.max_nblk_pts > 0) hipLaunchKernelGGL(k_ba_resub, dim3(L.max_nblk_pts, 1), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr);
+  SDSO_HIP(ctx, hipGetLastError());
+  SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));   // x / lastHS / lastbS / xAd are stack-local
+  return SDSO_OK;
+}
 static int solve_system(sdso_ctx* ctx, BaWindowDev* W, int iteration, double lambda) {
   if (W->solverMode & SOLVER_USE_GN) lambda = 0;
   if (W->solverMode & SOLVER_FIX_LAMBDA) lambda = 1e-5;
+  if (W->solverMode & (SOLVER_SVD | SOLVER_ORTHOGONALIZE_SYSTEM)) return solve_system_host(ctx, W, iteration, lambda);
   const int orth = (W->solverMode & SOLVER_ORTHOGONALIZE_X) || (iteration >= 2 && (W->solverMode & SOLVER_ORTHOGONALIZE_X_LATER));
   launch_solve(ctx, single(W), lambda, orth ? 1 : 0);
   SDSO_HIP(ctx, hipGetLastError());
@@ -893,6 +1000,7 @@ extern "C" int sdso_ba_batch_create(sdso_ctx* ctx, int nwin, const int* wins) {
     BaWindowDev* W = find_win(ctx, wins[i]);
     SDSO_REQUIRE(ctx, W && W->d.nf == nf, "batch windows must exist and share nf");
     SDSO_REQUIRE(ctx, (W->d.tiledT > 0) == L.tiled, "batch windows must share the image layout");
+    SDSO_REQUIRE(ctx, (W->solverMode & (SOLVER_SVD | SOLVER_ORTHOGONALIZE_SYSTEM)) == 0, "SOLVER_SVD / SOLVER_ORTHOGONALIZE_SYSTEM windows are solved through sdso_ba_solve / sdso_ba_optimize, not in a batch");
     W->d.accum = Bt->d_accum + af * i;   // contiguous accumulators: ONE all-reduce covers the batch
     W->own_accum = false;
     h[i] = W->d;

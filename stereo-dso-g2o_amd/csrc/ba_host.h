@@ -14,6 +14,7 @@ namespace sdso {
 constexpr float kInitialRotPrior = 1e11f, kInitialTransPrior = 1e10f, kInitialAffBPrior = 1e14f, kInitialAffAPrior = 1e14f;
 constexpr float kInitialCalibHessian = 5e9f;
 constexpr double kSolverModeDelta = 0.00001;
+constexpr int SOLVER_SVD_CUT7 = 16;
 constexpr int SOLVER_SVD = 1, SOLVER_ORTHOGONALIZE_SYSTEM = 2, SOLVER_ORTHOGONALIZE_POINTMARG = 4, SOLVER_ORTHOGONALIZE_FULL = 8,
               SOLVER_REMOVE_POSEPRIOR = 32, SOLVER_USE_GN = 64, SOLVER_FIX_LAMBDA = 128, SOLVER_ORTHOGONALIZE_X = 256,
               SOLVER_MOMENTUM = 512, SOLVER_STEPMOMENTUM = 1024, SOLVER_ORTHOGONALIZE_X_LATER = 2048;

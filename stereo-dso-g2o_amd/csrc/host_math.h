@@ -245,6 +245,33 @@ inline bool solveLdlt(Dense A, const std::vector<double>& rhs, std::vector<doubl
   return ok;
 }
 
+// A = V diag(w) V^T for symmetric A by cyclic Jacobi rotations (columns of V).  Used where the reference calls
+// Eigen::JacobiSVD on the symmetric system matrix (EnergyFunctional.cpp:931): singular values |w|, U = V sign(w).
+inline void symEigen(Dense G, std::vector<double>& w, Dense& V) {
+  const int n = G.n;
+  V = Dense(n);
+  for (int i = 0; i < n; ++i) V(i, i) = 1;
+  double nrm = 0;
+  for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) nrm += G(i, j) * G(i, j);
+  for (int sweep = 0; sweep < 100; ++sweep) {
+    double off = 0;
+    for (int i = 0; i < n; ++i) for (int j = i + 1; j < n; ++j) off += G(i, j) * G(i, j);
+    if (off <= 1e-30 * nrm) break;
+    for (int p = 0; p < n; ++p)
+      for (int q = p + 1; q < n; ++q) {
+        if (G(p, q) == 0.0) continue;
+        const double tau = (G(q, q) - G(p, p)) / (2 * G(p, q));
+        const double t = (tau >= 0 ? 1.0 : -1.0) / (std::fabs(tau) + std::sqrt(1 + tau * tau));
+        const double c = 1 / std::sqrt(1 + t * t), sn = t * c;
+        for (int k = 0; k < n; ++k) { const double a = G(k, p), b = G(k, q); G(k, p) = c * a - sn * b; G(k, q) = sn * a + c * b; }
+        for (int k = 0; k < n; ++k) { const double a = G(p, k), b = G(q, k); G(p, k) = c * a - sn * b; G(q, k) = sn * a + c * b; }
+        for (int k = 0; k < n; ++k) { const double a = V(k, p), b = V(k, q); V(k, p) = c * a - sn * b; V(k, q) = sn * a + c * b; }
+      }
+  }
+  w.assign(n, 0.0);
+  for (int i = 0; i < n; ++i) w[i] = G(i, i);
+}
+
 // Projector onto span of the (normalised) columns of N (dim x m, row-major), directions with
 // singular value <= delta*max dropped.  = N*pinv(N) (EnergyFunctional.cpp:791-820).
 inline Dense spanProjector(const std::vector<double>& N, int dim, int m, double delta) {
