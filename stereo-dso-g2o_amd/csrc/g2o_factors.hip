@@ -41,6 +41,19 @@ void release_g2o(sdso_ctx* ctx) {
   if (st.d_flow) hipFree(st.d_flow);
 }
 
+// sdso_track_release_ref: the edge sets built on a released template go with it
+void release_g2o_ref(sdso_ctx* ctx, int ref_slot) {
+  if (!reg_has(g_g2o, ctx)) return;
+  G2oState& st = reg_get(g_g2o, ctx);
+  for (auto it = st.sets.begin(); it != st.sets.end();) {
+    if (it->first.first == ref_slot) {
+      if (it->second.mask) hipFree(it->second.mask);
+      if (it->second.xref) hipFree(it->second.xref);
+      it = st.sets.erase(it);
+    } else ++it;
+  }
+}
+
 constexpr int kSysDoubles = 36 + 8 + 2;   // upper triangle of H, b, {chi2, robust chi2}
 constexpr int kMaxLinBlocks = 128;
 

@@ -325,11 +325,13 @@ extern "C" int sdso_track_set_ref(sdso_ctx* ctx, int ref_slot, int lvl, int n, c
   return SDSO_OK;
 }
 
+namespace sdso { void release_g2o_ref(sdso_ctx* ctx, int ref_slot); }   // g2o_factors.hip
 extern "C" int sdso_track_release_ref(sdso_ctx* ctx, int ref_slot) {
   if (!ctx) return SDSO_ERR_STATE;
   auto it = ctx->refs.find(ref_slot);
   if (it == ctx->refs.end()) return SDSO_OK;
   SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  sdso::release_g2o_ref(ctx, ref_slot);
   for (int l = 0; l < SDSO_PYR_LEVELS; l++) if (it->second.pc[l]) hipFree(it->second.pc[l]);
   ctx->refs.erase(it);
   return SDSO_OK;
