@@ -428,8 +428,11 @@ static void launch_fused(sdso_ctx* ctx, const BaLaunch& L, bool materialize, int
     {
       ProfScope ps(ctx, "k_ba_lin_fused");
       const dim3 g(L.max_chunks, L.nwin), b(BA_BLOCK);
-      if (materialize) { if (L.tiled) hipLaunchKernelGGL((k_ba_lin_fused<true, true>), g, b, 0, ctx->stream, L.d_arr); else hipLaunchKernelGGL((k_ba_lin_fused<true, false>), g, b, 0, ctx->stream, L.d_arr); }
-      else { if (L.tiled) hipLaunchKernelGGL((k_ba_lin_fused<false, true>), g, b, 0, ctx->stream, L.d_arr); else hipLaunchKernelGGL((k_ba_lin_fused<false, false>), g, b, 0, ctx->stream, L.d_arr); }
+      static const bool direct = getenv("SDSO_BA_DIRECT_TAPS") != nullptr;   // A/B: one residual's 32 taps on one lane (the first design)
+#define LF(M, T) do { if (direct) hipLaunchKernelGGL((k_ba_lin_fused<M, T, false>), g, b, 0, ctx->stream, L.d_arr); else hipLaunchKernelGGL((k_ba_lin_fused<M, T, true>), g, b, 0, ctx->stream, L.d_arr); } while (0)
+      if (materialize) { if (L.tiled) LF(true, true); else LF(true, false); }
+      else { if (L.tiled) LF(false, true); else LF(false, false); }
+#undef LF
     }
     if (L.any_lin) {
       hipLaunchKernelGGL(k_ba_fold_top, dim3(nf * nf, L.nwin), dim3(128), 0, ctx->stream, L.d_arr, 0);

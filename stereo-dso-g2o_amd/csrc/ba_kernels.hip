@@ -225,6 +225,241 @@ __device__ __forceinline__ double linearize_one(const BaDev& B, int i, int h, in
   B.r_newEnergy[i] = energyLeft;
   return (double)energyLeft;
 }
+// The same function for the fused kernel, with the 32 bilinear taps of every residual fetched COOPERATIVELY: the taps of one
+// residual sit on 32 neighbouring lanes of ONE load instruction (pixel-major, the four corners of a pixel adjacent), so an
+// instruction touches ~16 distinct 128-B lines instead of 64 and no line is asked for twice.  On gfx950 a divergent 16-byte load costs per distinct line, not
+// per byte: with one residual per lane the 32 taps run at 105 G lane-taps/s whatever HBM could deliver (tools/mix_bw.hip);
+// spread over lanes the same taps run at the HBM rate.  The interpolated samples travel through a wave-private LDS stage back
+// to the residual's own lane, which then does exactly the arithmetic of linearize_one — every per-residual result stays
+// bit-identical.  Must be called by ALL lanes of the wave
+// (`live` = this lane has a residual to linearise); early exits of linearize_one become the `dead` flag.
+// Stage of one wave: the 8 pattern-pixel coordinates of its 64 residuals (float2 each), and the interpolated {I, dx, dy}
+// of every pattern pixel in rows of 65 floats ([pixel*3 + channel][residual]).
+constexpr int CG_COORD_FLOATS = 64 * 8 * 2, CG_ROW = 65, CG_HIT_FLOATS = 8 * 3 * CG_ROW, CG_WAVE_FLOATS = CG_COORD_FLOATS + CG_HIT_FLOATS;
+constexpr int CG_BATCH = 8;                                   // loads in flight per lane
+__device__ __forceinline__ void cg_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// value of lane (quad base + k) of the caller's quad (v_mov_b32 with DPP quad_perm broadcast)
+template <int K>
+__device__ __forceinline__ float quad_bcast(float v) {
+  return __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(v), K * 0x55, 0xf, 0xf, true));
+}
+// All 32 bilinear taps of a residual in ONE load instruction: round r serves residuals 2r and 2r+1 of the wave, lane = (residual,
+// pattern pixel, corner).  The four corner lanes of a pixel exchange their samples inside the quad and evaluate
+// getInterpolatedElement33 (same expression, same order: bit-identical to interp33); the corner-0 lane parks the result for the
+// residual's own lane.  A residual's image lines are touched by exactly one instruction, so they are fetched once.
+template <bool TILED>
+__device__ __forceinline__ void coop_gather_hits(const float4* __restrict__ img, int Tw, bool dead, const float* Ku, const float* Kv, float* wstage) {
+  const int lane = threadIdx.x & 63;
+  float2* coords = (float2*)wstage;
+  float* hits = wstage + CG_COORD_FLOATS;
+#pragma unroll
+  for (int k = 0; k < 8; k++) coords[lane * 8 + k] = dead ? make_float2(-1.f, -1.f) : make_float2(Ku[k], Kv[k]);
+  cg_wave_sync();
+  struct __attribute__((packed, aligned(4))) px3 { float x, y, z; };
+  const int sub = lane >> 5, px = (lane >> 2) & 7, c = lane & 3;
+#pragma unroll
+  for (int r0 = 0; r0 < 32; r0 += CG_BATCH) {
+    px3 q[CG_BATCH];
+    float2 cx[CG_BATCH];
+#pragma unroll
+    for (int r = 0; r < CG_BATCH; r++) {
+      const int unit = (r0 + r) * 2 + sub;
+      cx[r] = coords[unit * 8 + px];
+      q[r].x = 0; q[r].y = 0; q[r].z = 0;
+      if (cx[r].x >= 0) {
+        const int x = (int)cx[r].x + (c & 1), y = (int)cx[r].y + (c >> 1);
+        q[r] = *(const px3*)(img + (TILED ? tiled_index(x, y, Tw) : x + y * Tw));
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < CG_BATCH; r++) {
+      const int unit = (r0 + r) * 2 + sub;
+      const float x = cx[r].x, y = cx[r].y;
+      const int ix = (int)x;
+      const int iy = (int)y;
+      const float dx = x - ix;
+      const float dy = y - iy;
+      const float dxdy = dx * dy;
+      // corners: lane c = 0 -> p00 (x, y), 1 -> p10 (x+1, y), 2 -> p01 (x, y+1), 3 -> p11.  Every corner lane scales its own
+      // sample by its own weight; lane 0 adds the four products in the order of interp33: ((w11 p11 + w01 p01) + w10 p10) + w00 p00
+      const float w11 = dxdy, w01 = dy - dxdy, w10 = dx - dxdy, w00 = 1 - dx - dy + dxdy;
+      const float wa = (c & 1) ? w11 : w01, wb = (c & 1) ? w10 : w00;
+      const float wc = (c & 2) ? wa : wb;
+      const float tx = wc * q[r].x, ty = wc * q[r].y, tz = wc * q[r].z;
+      const float hx = ((quad_bcast<3>(tx) + quad_bcast<2>(tx)) + quad_bcast<1>(tx)) + tx;
+      const float hy = ((quad_bcast<3>(ty) + quad_bcast<2>(ty)) + quad_bcast<1>(ty)) + ty;
+      const float hz = ((quad_bcast<3>(tz) + quad_bcast<2>(tz)) + quad_bcast<1>(tz)) + tz;
+      if (c == 0) {
+        hits[(px * 3 + 0) * CG_ROW + unit] = hx;
+        hits[(px * 3 + 1) * CG_ROW + unit] = hy;
+        hits[(px * 3 + 2) * CG_ROW + unit] = hz;
+      }
+    }
+  }
+  cg_wave_sync();
+}
+template <bool STORE, int KEEP, bool TILED>
+__device__ __forceinline__ double linearize_coop(const BaDev& B, int i, bool live, int h, int t, float* jl, int& ns_out, float* rs, float* wstage) {
+  ns_out = 1;
+  bool dead = !live;
+  double ret = 0;
+  float Kus[8], Kvs[8], color[8], weights[8], jab1[8];
+  bool oob = false;
+  float g_u = 0, g_v = 0, g_dr = 0, g_nid = 0, g_k0 = 0, g_k1 = 0;
+  float JIdxJIdx_00 = 0, JIdxJIdx_11 = 0, JIdxJIdx_10 = 0;
+  float JabJIdx_00 = 0, JabJIdx_01 = 0, JabJIdx_10 = 0, JabJIdx_11 = 0;
+  float JabJab_00 = 0, JabJab_01 = 0, JabJab_11 = 0;
+  float wJI2_sum = 0, energyLeft = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) { Kus[k] = 0; Kvs[k] = 0; color[k] = 0; weights[k] = 0; jab1[k] = 0; }
+  const float* __restrict__ pre = B.t_precalc + (size_t)(h * B.nf + t) * 27;
+  const float affLL0 = pre[24], affLL1 = pre[25], b0 = pre[26];
+  const float4* __restrict__ dIl = B.t_img[t];
+  const int S = B.nrp;
+  float* __restrict__ J = nullptr;
+  if (!dead) do {
+  B.r_newEnergyWO[i] = -1.f;
+  const uint8_t st = B.r_state[i];
+  if (st == 1) { B.r_newState[i] = 1; ret = (double)B.r_energy[i]; dead = true; break; }
+  const int pt = B.r_point[i];
+  const float* KRKi = pre; const float* Kt = pre + 9; const float* R0 = pre + 12; const float* t0 = pre + 21;
+  const float4 g = B.p_geo[pt];
+  const float pu = g.x, pv = g.y, idepth_scaled = g.z, idepth_zero_scaled = g.w;
+  J = STORE ? (B.r_jsel[i] ? B.J[0] : B.J[1]) : nullptr;
+  const float fxl = B.fxl, fyl = B.fyl, cxl = B.cxl, cyl = B.cyl, fxli = B.fxli, fyli = B.fyli;
+
+  // projectPoint (ResidualProjections.h:64-96) at the FEJ point
+  float KliP[3];
+  KliP[0] = (pu + 0 - cxl) * fxli;
+  KliP[1] = (pv + 0 - cyl) * fyli;
+  KliP[2] = 1;
+  float ptp[3];
+#pragma unroll
+  for (int r = 0; r < 3; r++) ptp[r] = ((R0[r * 3 + 0] * KliP[0] + R0[r * 3 + 1] * KliP[1]) + R0[r * 3 + 2] * KliP[2]) + t0[r] * idepth_zero_scaled;
+  const float drescale = 1.0f / ptp[2];
+  const float new_idepth = idepth_zero_scaled * drescale;
+  if (!(drescale > 0)) { B.r_newState[i] = 1; ret = (double)B.r_energy[i]; dead = true; break; }
+  const float u = ptp[0] * drescale;
+  const float v = ptp[1] * drescale;
+  const float Ku0 = u * fxl + cxl;
+  const float Kv0 = v * fyl + cyl;
+  if (!(Ku0 > 1.1f && Kv0 > 1.1f && Ku0 < B.wM3 && Kv0 < B.hM3)) { B.r_newState[i] = 1; ret = (double)B.r_energy[i]; dead = true; break; }
+  if (B.r_proj) { float* pj = B.r_proj + (size_t)i * 19; pj[16] = Ku0; pj[17] = Kv0; pj[18] = new_idepth; }
+
+  g_u = u; g_v = v; g_dr = drescale; g_nid = new_idepth; g_k0 = KliP[0]; g_k1 = KliP[1];   // the geometric Jacobians are built after the taps (fewer live registers during the gathers)
+
+  const float4 c0 = *(const float4*)(B.p_color + (size_t)pt * 8), c1 = *(const float4*)(B.p_color + (size_t)pt * 8 + 4);
+  const float4 w0 = *(const float4*)(B.p_weights + (size_t)pt * 8), w1 = *(const float4*)(B.p_weights + (size_t)pt * 8 + 4);
+  color[0] = c0.x; color[1] = c0.y; color[2] = c0.z; color[3] = c0.w; color[4] = c1.x; color[5] = c1.y; color[6] = c1.z; color[7] = c1.w;
+  weights[0] = w0.x; weights[1] = w0.y; weights[2] = w0.z; weights[3] = w0.w; weights[4] = w1.x; weights[5] = w1.y; weights[6] = w1.z; weights[7] = w1.w;
+  // Pass 1 (no memory traffic): project the 8 pattern pixels; the residual is OOB as soon as one leaves
+  // the image (Residuals.cpp:215-225).  Doing this first removes the early exit from the sampling loop, so
+  // the 32 bilinear taps below are independent loads the hardware can keep in flight together.
+#pragma unroll
+  for (int idx = 0; idx < 8; idx++) {
+    const float up = pu + c_pattern[idx][0], vp = pv + c_pattern[idx][1];
+    float q[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) q[r] = ((KRKi[r * 3 + 0] * up + KRKi[r * 3 + 1] * vp) + KRKi[r * 3 + 2]) + Kt[r] * idepth_scaled;
+    Kus[idx] = q[0] / q[2];
+    Kvs[idx] = q[1] / q[2];
+    if (!(Kus[idx] > 1.1f && Kvs[idx] > 1.1f && Kus[idx] < B.wM3 && Kvs[idx] < B.hM3)) oob = true;
+  }
+  if (oob) { B.r_newState[i] = 1; ret = (double)B.r_energy[i]; dead = true; break; }
+  } while (0);
+  coop_gather_hits<TILED>(dIl, TILED ? B.tiledT : B.w, dead, Kus, Kvs, wstage);
+  {
+  if (!dead) {
+  const float* hstage = wstage + CG_COORD_FLOATS + (threadIdx.x & 63);
+#pragma unroll
+  for (int idx = 0; idx < 8; idx++) {
+    const float Ku = Kus[idx], Kv = Kvs[idx];
+    if (B.r_proj) { B.r_proj[(size_t)i * 19 + idx * 2] = Ku; B.r_proj[(size_t)i * 19 + idx * 2 + 1] = Kv; }
+    float3 hit = make_float3(hstage[(idx * 3 + 0) * CG_ROW], hstage[(idx * 3 + 1) * CG_ROW], hstage[(idx * 3 + 2) * CG_ROW]);
+    if (!isfinite(hit.x)) oob = true;
+    const float residual = hit.x - (affLL0 * color[idx] + affLL1);
+    const float drdA = (color[idx] - b0);
+    float wgt = sqrtf(kOutlierTHSumComponent / (kOutlierTHSumComponent + (hit.y * hit.y + hit.z * hit.z)));
+    wgt = 0.5f * (wgt + weights[idx]);
+    float hw = fabsf(residual) < kHuberTH ? 1 : kHuberTH / fabsf(residual);
+    energyLeft += wgt * wgt * hw * residual * residual * (2 - hw);
+    if (hw < 1) hw = sqrtf(hw);
+    hw = hw * wgt;
+    hit.y *= hw;
+    hit.z *= hw;
+    SETQ(6 + idx, residual * hw, hit.y, hit.z, B.affA_fixed ? 0.f : drdA * hw);   // resF, JIdx[0], JIdx[1], JabF[0]
+    jab1[idx] = B.affB_fixed ? 0.f : hw;
+    if (KEEP == 2) {
+      const float ra = residual * hw;
+      rs[0] += ra * hit.y; rs[1] += ra * hit.z;
+      rs[2] += ra * (B.affA_fixed ? 0.f : drdA * hw); rs[3] += ra * jab1[idx];
+      rs[4] += ra * ra;
+    }
+    JIdxJIdx_00 += hit.y * hit.y;
+    JIdxJIdx_11 += hit.z * hit.z;
+    JIdxJIdx_10 += hit.y * hit.z;
+    JabJIdx_00 += drdA * hw * hit.y;
+    JabJIdx_01 += drdA * hw * hit.z;
+    JabJIdx_10 += hw * hit.y;
+    JabJIdx_11 += hw * hit.z;
+    JabJab_00 += drdA * drdA * hw * hw;
+    JabJab_01 += drdA * hw * hw;
+    JabJab_11 += hw * hw;
+    wJI2_sum += hw * hw * (hit.y * hit.y + hit.z * hit.z);
+  }
+  }
+  }
+  if (dead) return ret;
+  if (oob) { B.r_newState[i] = 1; return (double)B.r_energy[i]; }
+  {  // Residuals.cpp:135-185
+    const float* R0 = pre + 12; const float* t0 = pre + 21;
+    const float u = g_u, v = g_v, drescale = g_dr, new_idepth = g_nid;
+    const float KliP[2] = {g_k0, g_k1};
+    const float fxl = B.fxl, fyl = B.fyl, fxli = B.fxli, fyli = B.fyli;
+    float d_C_x[4], d_C_y[4];
+    const float d_d_x = drescale * (t0[0] - t0[2] * u) * SCALE_IDEPTH * fxl;
+    const float d_d_y = drescale * (t0[1] - t0[2] * v) * SCALE_IDEPTH * fyl;
+    d_C_x[2] = drescale * (R0[6] * u - R0[0]);
+    d_C_x[3] = fxl * drescale * (R0[7] * u - R0[1]) * fyli;
+    d_C_x[0] = KliP[0] * d_C_x[2];
+    d_C_x[1] = KliP[1] * d_C_x[3];
+    d_C_y[2] = fyl * drescale * (R0[6] * v - R0[3]) * fxli;
+    d_C_y[3] = drescale * (R0[7] * v - R0[4]);
+    d_C_y[0] = KliP[0] * d_C_y[2];
+    d_C_y[1] = KliP[1] * d_C_y[3];
+    d_C_x[0] = (d_C_x[0] + u) * SCALE_F;
+    d_C_x[1] *= SCALE_F;
+    d_C_x[2] = (d_C_x[2] + 1) * SCALE_C;
+    d_C_x[3] *= SCALE_C;
+    d_C_y[0] *= SCALE_F;
+    d_C_y[1] = (d_C_y[1] + v) * SCALE_F;
+    d_C_y[2] *= SCALE_C;
+    d_C_y[3] = (d_C_y[3] + 1) * SCALE_C;
+    SETQ(0, new_idepth * fxl, 0, -new_idepth * u * fxl, -u * v * fxl);                       // Jpdxi[0][0..3]
+    SETQ(1, (1 + u * u) * fxl, -v * fxl, 0, new_idepth * fyl);                                // Jpdxi[0][4..5], Jpdxi[1][0..1]
+    SETQ(2, -new_idepth * v * fyl, -(1 + v * v) * fyl, u * v * fyl, u * fyl);                 // Jpdxi[1][2..5]
+    SETQ(3, d_C_x[0], d_C_x[1], d_C_x[2], d_C_x[3]);
+    SETQ(4, d_C_y[0], d_C_y[1], d_C_y[2], d_C_y[3]);
+    SETQ(5, d_d_x, d_d_y, 0.f, 0.f);
+  }
+  SETQ(14, jab1[0], jab1[1], jab1[2], jab1[3]);
+  SETQ(15, jab1[4], jab1[5], jab1[6], jab1[7]);
+  SETQ(16, JIdxJIdx_00, JIdxJIdx_10, JIdxJIdx_10, JIdxJIdx_11);
+  SETQ(17, JabJIdx_00, JabJIdx_01, JabJIdx_10, JabJIdx_11);
+  SETQ(18, JabJab_00, JabJab_01, JabJab_01, JabJab_11);
+
+  B.r_newEnergyWO[i] = energyLeft;
+  const float th = fmaxf(B.t_frameTH[h], B.t_frameTH[t]);
+  if (energyLeft > th || wJI2_sum < 2) { energyLeft = th; ns_out = 2; }
+  else ns_out = 0;
+  B.r_newState[i] = (uint8_t)ns_out;
+  B.r_newEnergy[i] = energyLeft;
+  return (double)energyLeft;
+}
 #undef SETQ
 
 template <bool TILED>
@@ -490,7 +725,7 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_accum_top(const BaDev* __restri
 // one workgroup per chunk of one (host,target) pair, J is written to HBM only when MATERIALIZE
 // (the reference API keeps RawResidualJacobian; the solver itself never reads it again).
 // Linearized residuals are untouched (their accumulation is the separate mode-1 pass).
-template <bool MATERIALIZE, bool TILED>
+template <bool MATERIALIZE, bool TILED, bool COOP = true>
 __global__ __launch_bounds__(BA_BLOCK) void k_ba_lin_fused(const BaDev* __restrict__ wins) {
   // by-value copy first: every pointer of the descriptor is read before the kernel's first store, so the
   // compiler can prove them global (global_load / s_load instead of flat_load) and keep them in SGPRs
@@ -499,7 +734,8 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_lin_fused(const BaDev* __restri
   const int4 ch = B.chunks[blockIdx.x];
   const int pair = __builtin_amdgcn_readfirstlane(ch.x);   // one (host,target) per workgroup: precalc, image, thresholds are wave-uniform
   const int i = ch.y + threadIdx.x;
-  __shared__ float red[TE_LDS_FLOATS];
+  constexpr int RED_FLOATS = COOP ? (TE_LDS_FLOATS > (BA_BLOCK / 64) * CG_WAVE_FLOATS ? TE_LDS_FLOATS : (BA_BLOCK / 64) * CG_WAVE_FLOATS) : TE_LDS_FLOATS;
+  __shared__ float red[RED_FLOATS];    // the gather stage of the linearisation, then the MFMA panels of the reduction
   __shared__ double lds[BA_BLOCK / 64];
   float x[10], y[10], a = 0, b = 0, c = 0;
   float TR00 = 0, TR10 = 0, TR01 = 0, TR11 = 0, TR02 = 0, TR12 = 0;
@@ -508,12 +744,21 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_lin_fused(const BaDev* __restri
   for (int k = 0; k < 10; k++) { x[k] = 0; y[k] = 0; }
   bool on = false;
   double e = 0;
-  if ((int)threadIdx.x < ch.z && !B.r_lin[i]) {
-    float jl[76];
-    float rs5[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-    int ns;
-    const uint8_t st = B.r_state[i];
-    e = linearize_one<MATERIALIZE, 2, TILED>(B, i, pair % B.nf, pair / B.nf, jl, ns, rs5);
+  const bool live = (int)threadIdx.x < ch.z && !B.r_lin[i];
+  float jl[76];
+  float rs5[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  int ns = 1;
+  uint8_t st = 1;
+  if (COOP) {
+    if (live) st = B.r_state[i];
+    e = linearize_coop<MATERIALIZE, 2, TILED>(B, i, live, pair % B.nf, pair / B.nf, jl, ns, rs5, red + (threadIdx.x >> 6) * CG_WAVE_FLOATS);
+    __syncthreads();   // the reduction below reuses the stage of all waves
+  }
+  if (live) {
+    if (!COOP) {
+      st = B.r_state[i];
+      e = linearize_one<MATERIALIZE, 2, TILED>(B, i, pair % B.nf, pair / B.nf, jl, ns, rs5);
+    }
     const int pt = B.r_point[i];
     float* rec = B.r_rec + ((size_t)pt * B.nf + pair / B.nf) * 16;
     // the 64-byte record of this (point, target): written once, whole, at the end (four 16-byte stores of one line)
