@@ -235,7 +235,7 @@ __device__ __forceinline__ double linearize_one(const BaDev& B, int i, int h, in
 // (`live` = this lane has a residual to linearise); early exits of linearize_one become the `dead` flag.
 // Stage of one wave: the 8 pattern-pixel coordinates of its 64 residuals (float2 each), and the interpolated {I, dx, dy}
 // of every pattern pixel in rows of 65 floats ([pixel*3 + channel][residual]).
-constexpr int CG_COORD_FLOATS = 64 * 8 * 2, CG_ROW = 65, CG_HIT_FLOATS = 8 * 3 * CG_ROW, CG_WAVE_FLOATS = CG_COORD_FLOATS + CG_HIT_FLOATS;
+constexpr int CG_COORD_FLOATS = 64 * 8 * 2, CG_ROW = 64, CG_HIT_FLOATS = 8 * 3 * CG_ROW, CG_WAVE_FLOATS = CG_COORD_FLOATS + CG_HIT_FLOATS;
 constexpr int CG_BATCH = 8;                                   // loads in flight per lane
 __device__ __forceinline__ void cg_wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -725,8 +725,10 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_accum_top(const BaDev* __restri
 // one workgroup per chunk of one (host,target) pair, J is written to HBM only when MATERIALIZE
 // (the reference API keeps RawResidualJacobian; the solver itself never reads it again).
 // Linearized residuals are untouched (their accumulation is the separate mode-1 pass).
+// Workgroups per CU: four without the Jacobian stores (124 VGPRs, 40 KB of LDS each); with them the kernel needs 152 VGPRs
+// (capping it at 128 spills 22-38 of them and loses more than the fourth wave per SIMD gains), so three.
 template <bool MATERIALIZE, bool TILED, bool COOP = true>
-__global__ __launch_bounds__(BA_BLOCK) void k_ba_lin_fused(const BaDev* __restrict__ wins) {
+__global__ __launch_bounds__(BA_BLOCK, (MATERIALIZE ? 3 : 4)) void k_ba_lin_fused(const BaDev* __restrict__ wins) {
   // by-value copy first: every pointer of the descriptor is read before the kernel's first store, so the
   // compiler can prove them global (global_load / s_load instead of flat_load) and keep them in SGPRs
   const BaDev B = wins[blockIdx.y];
@@ -736,7 +738,7 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_lin_fused(const BaDev* __restri
   const int i = ch.y + threadIdx.x;
   constexpr int RED_FLOATS = COOP ? (TE_LDS_FLOATS > (BA_BLOCK / 64) * CG_WAVE_FLOATS ? TE_LDS_FLOATS : (BA_BLOCK / 64) * CG_WAVE_FLOATS) : TE_LDS_FLOATS;
   __shared__ float red[RED_FLOATS];    // the gather stage of the linearisation, then the MFMA panels of the reduction
-  __shared__ double lds[BA_BLOCK / 64];
+  double* const lds = (double*)red;    // (the energy reduction runs between the two uses; 40 KB in all = four workgroups per CU)
   float x[10], y[10], a = 0, b = 0, c = 0;
   float TR00 = 0, TR10 = 0, TR01 = 0, TR11 = 0, TR02 = 0, TR12 = 0;
   float br[6] = {0, 0, 0, 0, 0, 0};
@@ -810,6 +812,7 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_lin_fused(const BaDev* __restri
   }
   e = block_sum_d(e, lds);
   if (threadIdx.x == 0) B.e_part[blockIdx.x] = e;
+  __syncthreads();
   top_emit(B, x, y, a, b, c, TR00, TR10, TR01, TR11, TR02, TR12, br, on, red);
 }
 
