@@ -1142,7 +1142,7 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_sc_mfma(const BaDev* __restrict
 // of a workgroup share ALL points of one host (64-point slices dealt round-robin), add their 21 accumulator tiles through LDS
 // in a fixed order (3+2 -> 1+0 -> 0) and wave 0 writes the host's accD / accE / accEB bins straight into the packed accumulator
 // block: no per-item partials in HBM and no fold pass.  Only Hcc / bc (sums over ALL hosts) leave a 20-float partial per host.
-__global__ __launch_bounds__(BA_BLOCK) void k_ba_sc_host(const BaDev* __restrict__ wins, const uint8_t* __restrict__ pflag, int shiftPriorToZero, int margMode) {
+__global__ __launch_bounds__(BA_BLOCK, 2) void k_ba_sc_host(const BaDev* __restrict__ wins, const uint8_t* __restrict__ pflag, int shiftPriorToZero, int margMode) {
   const BaDev& B = wins[blockIdx.y];
   const int nf = B.nf, h = blockIdx.x;
   if (h >= nf) return;
@@ -1208,26 +1208,37 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_sc_host(const BaDev* __restrict
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    for (int g = 0; g < npts; g += 4) {   // phase 2
-      const int q = g + kq;
-      const float4 h0 = *(const float4*)(&pt[q][0]);
-      const float4 h1 = *(const float4*)(&pt[q][4]);
-      const int mb = __float_as_int(h1.z);
-      const float* base = B.r_rec + (size_t)(p0 + (q < npts ? q : 0)) * nf * 16 + asub;
-      float z[5], za[5];
+    // phase 2, four point-groups per trip: the 16 record loads of a trip are issued before its first MFMA (one trip used to be a
+    // load -> wait -> 21 MFMAs chain, sixteen times per slice; the workgroups of a launch are all resident at once, so the kernel
+    // took as long as that chain).  Groups past npts read the zero rows lanes >= npts wrote into pt[]: exact no-ops.
+    for (int g0 = 0; g0 < npts; g0 += 16) {
+      float zz[4][5], hx[4];
 #pragma unroll
-      for (int tt = 0; tt < 4; tt++) {
-        const int t = 2 * tt + tsub;
-        z[tt] = ((mb >> t) & 1) ? base[t * 16] : 0.f;
+      for (int u = 0; u < 4; u++) {
+        const int q = g0 + 4 * u + kq;
+        const float4 h0 = *(const float4*)(&pt[q][0]);
+        const float4 h1 = *(const float4*)(&pt[q][4]);
+        const int mb = __float_as_int(h1.z);
+        const float* base = B.r_rec + (size_t)(p0 + (q < npts ? q : 0)) * nf * 16 + asub;
+#pragma unroll
+        for (int tt = 0; tt < 4; tt++) {
+          const int t = 2 * tt + tsub;
+          zz[u][tt] = ((mb >> t) & 1) ? base[t * 16] : 0.f;
+        }
+        zz[u][4] = ci == 0 ? h0.z : ci == 1 ? h0.w : ci == 2 ? h1.x : ci == 3 ? h1.y : ci == 4 ? h0.y : 0.f;
+        hx[u] = h0.x;
       }
-      z[4] = ci == 0 ? h0.z : ci == 1 ? h0.w : ci == 2 ? h1.x : ci == 3 ? h1.y : ci == 4 ? h0.y : 0.f;
 #pragma unroll
-      for (int tt = 0; tt < 5; tt++) za[tt] = h0.x * z[tt];
+      for (int u = 0; u < 4; u++) {
+        float za[5];
 #pragma unroll
-      for (int a = 0; a < 4; a++)
+        for (int tt = 0; tt < 5; tt++) za[tt] = hx[u] * zz[u][tt];
 #pragma unroll
-        for (int b = 0; b < 5; b++) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(za[a], z[b], acc[a][b], 0, 0, 0);
-      acc44 = __builtin_amdgcn_mfma_f32_16x16x4f32(za[4], z[4], acc44, 0, 0, 0);
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+          for (int b = 0; b < 5; b++) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(za[a], zz[u][b], acc[a][b], 0, 0, 0);
+        acc44 = __builtin_amdgcn_mfma_f32_16x16x4f32(za[4], zz[u][4], acc44, 0, 0, 0);
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();          // the next slice overwrites pt[]
