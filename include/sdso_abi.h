@@ -231,6 +231,9 @@ int sdso_ba_get_linearization(sdso_ctx* ctx, int win, float* J, uint8_t* newStat
 int sdso_ba_apply_res(sdso_ctx* ctx, int win);
 int sdso_ba_get_residual_state(sdso_ctx* ctx, int win, uint8_t* state, uint8_t* isActive,
                                float* JpJdF /* nr*8 */);
+/* EFResidual::J (the record takeDataF swapped in, EnergyFunctionalStructs.cpp:39) of every residual, J[nr*74] in the field order of
+ * sdso_ba_get_linearization; rows of residuals that never became active are unspecified. */
+int sdso_ba_get_ef_jacobians(sdso_ctx* ctx, int win, float* J);
 
 /* accumulateAF_MT + accumulateLF_MT + accumulateSCF_MT up to (not including) the stitch
  * (EnergyFunctional.cpp:212-269; AccumulatedTopHessian.cpp:36-198; AccumulatedSCHessian.cpp:34-103). */

@@ -9,6 +9,12 @@
 
 namespace orc {
 
+// TRUTH MODE (not in the reference): when on, the windowed-BA accumulators below also keep every sum in double, with
+// double products of the same float inputs, and their readers (h() / a()) return those instead of the float tiers.
+// The float path is unchanged; the mode exists so that tests can measure how far the float summation order of the CPU
+// path and of the device path each sit from an order-independent value.
+inline int& acc64_mode() { static int on = 0; return on; }
+
 // MatrixAccumulators.h:907-1277 (Accumulator9).  Variable order [J0..J7, J8=r].
 struct Accumulator9 {
   float H[9][9];
@@ -68,8 +74,11 @@ struct AccumulatorApprox {
   float TR[32], TR1k[32], TR1m[32];
   float BR[8], BR1k[8], BR1m[8];
   float numIn1, numIn1k, numIn1m;
+  double Dd[60], TRd[32], BRd[8], Hd[13][13];   // truth mode
+  double h(int r, int c) const { return acc64_mode() ? Hd[r][c] : (double)H[r][c]; }
 
   void initialize() {
+    std::memset(Dd, 0, sizeof(Dd)); std::memset(TRd, 0, sizeof(TRd)); std::memset(BRd, 0, sizeof(BRd));
     std::memset(Data, 0, sizeof(Data)); std::memset(Data1k, 0, sizeof(Data)); std::memset(Data1m, 0, sizeof(Data));
     std::memset(TR, 0, sizeof(TR)); std::memset(TR1k, 0, sizeof(TR)); std::memset(TR1m, 0, sizeof(TR));
     std::memset(BR, 0, sizeof(BR)); std::memset(BR1k, 0, sizeof(BR)); std::memset(BR1m, 0, sizeof(BR));
@@ -101,6 +110,7 @@ struct AccumulatorApprox {
       for (int cc = r; cc < 10; cc++) {
         // Data[idx] += a*x[cc]*x[r] + c*y[cc]*y[r] + b*(x[cc]*y[r] + y[cc]*x[r]);
         Data[idx] += a * x[cc] * x[r] + c * y[cc] * y[r] + b * (x[cc] * y[r] + y[cc] * x[r]);
+        Dd[idx] += (double)a * x[cc] * x[r] + (double)c * y[cc] * y[r] + (double)b * ((double)x[cc] * y[r] + (double)y[cc] * x[r]);
         idx++;
       }
     num++; numIn1++;
@@ -116,11 +126,15 @@ struct AccumulatorApprox {
       TR[3 * r + 0] += x[r] * TR00 + y[r] * TR10;
       TR[3 * r + 1] += x[r] * TR01 + y[r] * TR11;
       TR[3 * r + 2] += x[r] * TR02 + y[r] * TR12;
+      TRd[3 * r + 0] += (double)x[r] * TR00 + (double)y[r] * TR10;
+      TRd[3 * r + 1] += (double)x[r] * TR01 + (double)y[r] * TR11;
+      TRd[3 * r + 2] += (double)x[r] * TR02 + (double)y[r] * TR12;
     }
   }
   // :842-855
   void updateBotRight(float a00, float a01, float a02, float a11, float a12, float a22) {
     BR[0] += a00; BR[1] += a01; BR[2] += a02; BR[3] += a11; BR[4] += a12; BR[5] += a22;
+    BRd[0] += a00; BRd[1] += a01; BRd[2] += a02; BRd[3] += a11; BRd[4] += a12; BRd[5] += a22;
   }
   void finish() {  // :589-618
     std::memset(H, 0, sizeof(H));
@@ -138,6 +152,15 @@ struct AccumulatorApprox {
     H[11][12] = H[12][11] = BR1m[4];
     H[12][12] = BR1m[5];
     num = (size_t)(numIn1 + numIn1k + numIn1m);
+    std::memset(Hd, 0, sizeof(Hd));
+    idx = 0;
+    for (int r = 0; r < 10; r++)
+      for (int c = r; c < 10; c++) { Hd[r][c] = Hd[c][r] = Dd[idx]; idx++; }
+    idx = 0;
+    for (int r = 0; r < 10; r++)
+      for (int c = 0; c < 3; c++) { Hd[r][c + 10] = Hd[c + 10][r] = TRd[idx]; idx++; }
+    Hd[10][10] = BRd[0]; Hd[10][11] = Hd[11][10] = BRd[1]; Hd[10][12] = Hd[12][10] = BRd[2];
+    Hd[11][11] = BRd[3]; Hd[11][12] = Hd[12][11] = BRd[4]; Hd[12][12] = BRd[5];
   }
 };
 
@@ -147,7 +170,10 @@ struct AccumulatorXX {
   float A[I][J], A1k[I][J], A1m[I][J];
   size_t num;
   float numIn1, numIn1k, numIn1m;
+  double Ad[I][J];   // truth mode
+  double a(int i, int j) const { return acc64_mode() ? Ad[i][j] : (double)A1m[i][j]; }
   void initialize() {
+    std::memset(Ad, 0, sizeof(Ad));
     std::memset(A, 0, sizeof(A)); std::memset(A1k, 0, sizeof(A)); std::memset(A1m, 0, sizeof(A));
     num = 0; numIn1 = numIn1k = numIn1m = 0;
   }
@@ -164,7 +190,7 @@ struct AccumulatorXX {
   void update(const float* L, const float* R, float w) {  // A += w*L*R^T  ((w*L)*R^T in Eigen)
     for (int i = 0; i < I; i++) {
       float wl = w * L[i];
-      for (int j = 0; j < J; j++) A[i][j] += wl * R[j];
+      for (int j = 0; j < J; j++) { A[i][j] += wl * R[j]; Ad[i][j] += (double)w * L[i] * R[j]; }
     }
     numIn1++;
     shiftUp(false);
@@ -176,7 +202,10 @@ struct AccumulatorX {
   float A[I], A1k[I], A1m[I];
   size_t num;
   float numIn1, numIn1k, numIn1m;
+  double Ad[I];   // truth mode
+  double a(int i) const { return acc64_mode() ? Ad[i] : (double)A1m[i]; }
   void initialize() {
+    std::memset(Ad, 0, sizeof(Ad));
     std::memset(A, 0, sizeof(A)); std::memset(A1k, 0, sizeof(A)); std::memset(A1m, 0, sizeof(A));
     num = 0; numIn1 = numIn1k = numIn1m = 0;
   }
@@ -191,7 +220,7 @@ struct AccumulatorX {
     }
   }
   void update(const float* L, float w) {
-    for (int i = 0; i < I; i++) A[i] += w * L[i];
+    for (int i = 0; i < I; i++) { A[i] += w * L[i]; Ad[i] += (double)w * L[i]; }
     numIn1++;
     shiftUp(false);
   }

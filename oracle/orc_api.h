@@ -148,10 +148,16 @@ int orc_ba_get_linearization(orc_ba* h, float* J, uint8_t* newState, float* newE
                              float* newEnergyWithOutlier, float* projectedTo,
                              float* centerProjectedTo);
 int orc_ba_apply_res(orc_ba* h);
+int orc_ba_get_ef_jacobians(orc_ba* h, float* J /* nr*74: EFResidual::J */);
 int orc_ba_get_residual_state(orc_ba* h, uint8_t* state, uint8_t* isActive, float* JpJdF);
 int orc_ba_accumulate(orc_ba* h);
 int orc_ba_accum_floats(int nf);
 int orc_ba_get_accumulators(orc_ba* h, float* packed);
+/* TRUTH MODE (not in the reference): orc_set_acc64(1) makes every later stitch read the BA accumulators' double shadow sums
+ * (double products of the same float Jacobian entries, double accumulation) instead of the float 3-tier sums; the float path
+ * itself is unchanged.  orc_ba_get_accumulators_f64 returns the packed block in double (shadow sums when the mode is on). */
+void orc_set_acc64(int on);
+int orc_ba_get_accumulators_f64(orc_ba* h, double* packed);
 int orc_ba_get_point_terms(orc_ba* h, float* HdiF, float* bdSumF, float* Hdd_accAF, float* bd_accAF,
                            float* Hcd_accAF);
 int orc_ba_solve(orc_ba* h, int iteration, double lambda, double* x, double* HS, double* bS,

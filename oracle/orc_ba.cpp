@@ -649,7 +649,7 @@ struct orc_ba {
       for (int i = 0; i < 13; i++) for (int j = 0; j < 13; j++) accH[i][j] = 0;
       acc[aidx].finish();
       if (acc[aidx].num != 0)
-        for (int i = 0; i < 13; i++) for (int j = 0; j < 13; j++) accH[i][j] += (double)acc[aidx].H[i][j];
+        for (int i = 0; i < 13; i++) for (int j = 0; j < 13; j++) accH[i][j] += acc[aidx].h(i, j);
       const double* AH = &adHost[(size_t)aidx * 64];
       const double* AT = &adTarget[(size_t)aidx * 64];
       double A88[64], tmp[64], out[64];
@@ -708,13 +708,13 @@ struct orc_ba {
       for (int a = 0; a < 8; a++)
         for (int c = 0; c < 4; c++) {
           double sh = 0, st = 0;
-          for (int kk = 0; kk < 8; kk++) { sh += AHij[a * 8 + kk] * (double)accE[ijIdx].A1m[kk][c]; st += ATij[a * 8 + kk] * (double)accE[ijIdx].A1m[kk][c]; }
+          for (int kk = 0; kk < 8; kk++) { sh += AHij[a * 8 + kk] * accE[ijIdx].a(kk, c); st += ATij[a * 8 + kk] * accE[ijIdx].a(kk, c); }
           H(iIdx + a, c) += sh;
           H(jIdx + a, c) += st;
         }
       for (int a = 0; a < 8; a++) {
         double sh = 0, st = 0;
-        for (int kk = 0; kk < 8; kk++) { sh += AHij[a * 8 + kk] * (double)accEB[ijIdx].A1m[kk]; st += ATij[a * 8 + kk] * (double)accEB[ijIdx].A1m[kk]; }
+        for (int kk = 0; kk < 8; kk++) { sh += AHij[a * 8 + kk] * accEB[ijIdx].a(kk); st += ATij[a * 8 + kk] * accEB[ijIdx].a(kk); }
         b[iIdx + a] += sh;
         b[jIdx + a] += st;
       }
@@ -723,7 +723,7 @@ struct orc_ba {
         accD[ijkIdx].finish();
         if (accD[ijkIdx].num == 0) continue;
         double D[64], tmp[64], out[64];
-        for (int a = 0; a < 8; a++) for (int c = 0; c < 8; c++) D[a * 8 + c] = (double)accD[ijkIdx].A1m[a][c];
+        for (int a = 0; a < 8; a++) for (int c = 0; c < 8; c++) D[a * 8 + c] = accD[ijkIdx].a(a, c);
         const double* AHik = &adHost[(size_t)ikIdx * 64];
         const double* ATik = &adTarget[(size_t)ikIdx * 64];
         mul88(AHij, D, tmp, false); mul88(tmp, AHik, out, true);
@@ -737,7 +737,7 @@ struct orc_ba {
       }
     }
     accHcc.finish(); accbc.finish();
-    for (int a = 0; a < 4; a++) { for (int c = 0; c < 4; c++) H(a, c) += (double)accHcc.A1m[a][c]; b[a] += (double)accbc.A1m[a]; }
+    for (int a = 0; a < 4; a++) { for (int c = 0; c < 4; c++) H(a, c) += accHcc.a(a, c); b[a] += accbc.a(a); }
     for (int h = 0; h < nf; h++) {
       int hIdx = 4 + h * 8;
       for (int a = 0; a < 8; a++) for (int c = 0; c < 4; c++) H(c, hIdx + a) = H(hIdx + a, c);
@@ -1180,6 +1180,10 @@ extern "C" int orc_ba_get_linearization(orc_ba* h, float* J, uint8_t* newState, 
   }
   return 0;
 }
+extern "C" int orc_ba_get_ef_jacobians(orc_ba* h, float* J) {   // EFResidual::J
+  for (int i = 0; i < h->nr; i++) std::memcpy(J + (size_t)i * 74, &h->res[i].Jef, sizeof(RawJ));
+  return 0;
+}
 extern "C" int orc_ba_apply_res(orc_ba* h) { h->applyAll(); return 0; }
 extern "C" int orc_ba_get_residual_state(orc_ba* h, uint8_t* state, uint8_t* isActive, float* JpJdF) {
   for (int i = 0; i < h->nr; i++) {
@@ -1212,6 +1216,28 @@ extern "C" int orc_ba_get_accumulators(orc_ba* h, float* packed) {
   for (int a = 0; a < 4; a++) for (int c = 0; c < 4; c++) *p++ = h->accHcc.A1m[a][c];
   for (int a = 0; a < 4; a++) *p++ = h->accbc.A1m[a];
   *p++ = (float)h->nresA; *p++ = (float)h->nresL;
+  return 0;
+}
+// truth mode (orc_acc.h): the same packed layout in double, read through the accumulators' h() / a()
+extern "C" void orc_set_acc64(int on) { acc64_mode() = on; }
+extern "C" int orc_ba_get_accumulators_f64(orc_ba* h, double* packed) {
+  int nf = h->nf;
+  double* p = packed;
+  for (int which = 0; which < 2; which++)
+    for (int i = 0; i < nf * nf; i++) {
+      AccumulatorApprox& a = which ? h->accTopL[i] : h->accTopA[i];
+      a.finish();
+      for (int r = 0; r < 10; r++) for (int c = r; c < 10; c++) *p++ = a.h(r, c);
+      for (int r = 0; r < 10; r++) for (int c = 0; c < 3; c++) *p++ = a.h(r, 10 + c);
+      *p++ = a.h(10, 10); *p++ = a.h(10, 11); *p++ = a.h(10, 12); *p++ = a.h(11, 11); *p++ = a.h(11, 12); *p++ = a.h(12, 12);
+    }
+  for (int i = 0; i < nf * nf * nf; i++) { h->accD[i].finish(); for (int a = 0; a < 8; a++) for (int c = 0; c < 8; c++) *p++ = h->accD[i].a(a, c); }
+  for (int i = 0; i < nf * nf; i++) { h->accE[i].finish(); for (int a = 0; a < 8; a++) for (int c = 0; c < 4; c++) *p++ = h->accE[i].a(a, c); }
+  for (int i = 0; i < nf * nf; i++) { h->accEB[i].finish(); for (int a = 0; a < 8; a++) *p++ = h->accEB[i].a(a); }
+  h->accHcc.finish(); h->accbc.finish();
+  for (int a = 0; a < 4; a++) for (int c = 0; c < 4; c++) *p++ = h->accHcc.a(a, c);
+  for (int a = 0; a < 4; a++) *p++ = h->accbc.a(a);
+  *p++ = (double)h->nresA; *p++ = (double)h->nresL;
   return 0;
 }
 extern "C" int orc_ba_get_point_terms(orc_ba* h, float* HdiF, float* bdSumF, float* Hdd_accAF, float* bd_accAF, float* Hcd_accAF) {

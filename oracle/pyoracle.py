@@ -59,10 +59,14 @@ def load(fast=False):
     L.orc_ba_linearize.argtypes = [vp, c_double_p]
     L.orc_ba_get_linearization.argtypes = [vp, c_float_p, c_u8_p, c_float_p, c_float_p, c_float_p, c_float_p]
     L.orc_ba_apply_res.argtypes = [vp]
+    L.orc_ba_get_ef_jacobians.argtypes = [vp, c_float_p]
     L.orc_ba_get_residual_state.argtypes = [vp, c_u8_p, c_u8_p, c_float_p]
     L.orc_ba_accumulate.argtypes = [vp]
     L.orc_ba_accum_floats.argtypes = [C.c_int]
     L.orc_ba_get_accumulators.argtypes = [vp, c_float_p]
+    L.orc_set_acc64.argtypes = [C.c_int]
+    L.orc_set_acc64.restype = None
+    L.orc_ba_get_accumulators_f64.argtypes = [vp, c_double_p]
     L.orc_ba_get_point_terms.argtypes = [vp, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p]
     L.orc_ba_solve.argtypes = [vp, C.c_int, C.c_double, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]
     L.orc_ba_get_point_steps.argtypes = [vp, c_float_p]

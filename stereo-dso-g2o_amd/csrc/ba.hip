@@ -38,8 +38,10 @@ struct BaWindowDev {
   float* dt_xAd = nullptr;
   uint8_t* d_pflag = nullptr;
   float* d_sums = nullptr;
-  bool own_accum = true;
+  float* accum_own = nullptr;   // the window's own packed accumulator block (d.accum points into the batch block while batched)
+  bool in_batch = false;
   bool accumulated = false;
+  bool has_lin_cached = false;  // some residual of the window is linearized (updated wherever h_lin changes)
 };
 
 // zeroed device buffer for a window: reuse a pooled buffer of a released window when one of a similar size exists
@@ -80,22 +82,34 @@ struct BaLaunch {
 };
 struct BaBatch {
   std::vector<int> wins;
+  std::vector<BaWindowDev*> W;   // valid while the batch lives: releasing / re-uploading a member frees the batch first
   BaDev* d_arr = nullptr;
   float* d_accum = nullptr;
   BaLaunch L;
   bool materialize = true;
+  bool direct_taps = false;      // A/B: one residual's 32 taps on one lane (SDSO_BA_DIRECT_TAPS at batch_create)
 };
 static std::map<sdso_ctx*, BaBatch*> g_batches;
+// Dissolve the ctx's batch: every member window gets its own accumulator block back (host descriptor and its device copy),
+// so later per-window calls never touch the freed batch block.
 static void free_batch(sdso_ctx* ctx) {
   BaBatch* taken = nullptr;
   if (!reg_take(g_batches, ctx, taken) || !taken) return;
+  hipStreamSynchronize(ctx->stream);
+  for (BaWindowDev* W : taken->W) {
+    W->d.accum = W->accum_own;
+    W->in_batch = false;
+    W->accumulated = false;
+    hipMemcpyAsync(W->d_self, &W->d, sizeof(BaDev), hipMemcpyHostToDevice, ctx->stream);
+  }
+  hipStreamSynchronize(ctx->stream);
   hipFree(taken->d_arr); hipFree(taken->d_accum);
   delete taken;
 }
 void release_all_windows(sdso_ctx* ctx) {
+  free_batch(ctx);
   for (auto& kv : ctx->wins) free_window(ctx, kv.second);
   ctx->wins.clear();
-  free_batch(ctx);
 }
 
 static int upload_tables(sdso_ctx* ctx, BaWindowDev* W, bool adjoints) {
@@ -143,6 +157,7 @@ extern "C" int sdso_ba_release_window(sdso_ctx* ctx, int win) {
   auto it = ctx->wins.find(win);
   if (it == ctx->wins.end()) return SDSO_OK;
   SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (it->second->in_batch) free_batch(ctx);   // the batch holds a snapshot of this window's buffers
   free_window(ctx, it->second);
   ctx->wins.erase(it);
   return SDSO_OK;
@@ -215,6 +230,14 @@ static int upload_window_impl(sdso_ctx* ctx, int win, const sdso_ba_window_t* Wi
     rcnt[p]++;
     SDSO_REQUIRE(ctx, rcnt[p] <= SDSO_MAX_RES, "more than MAX_RES_PER_POINT residuals on a point");
   }
+  {  // every validation runs before the first H2D copy: the staging vectors below must outlive the copies
+    std::vector<uint8_t> seen((size_t)np * nf, 0);
+    for (int o = 0; o < nr; o++) {
+      const size_t slot = (size_t)Win->res_point[o] * nf + Win->res_target[o];
+      SDSO_REQUIRE(ctx, !seen[slot], "two residuals of one point observe the same target frame");
+      seen[slot] = 1;
+    }
+  }
   W->perm.resize(nr); W->inv.resize(nr);
   std::iota(W->perm.begin(), W->perm.end(), 0);
   std::stable_sort(W->perm.begin(), W->perm.end(), [&](int a, int b) {
@@ -230,6 +253,7 @@ static int upload_window_impl(sdso_ctx* ctx, int win, const sdso_ba_window_t* Wi
   W->h_target = s_target;
   W->h_point = s_point;
   W->h_lin.assign(nr, 0);
+  W->has_lin_cached = false;
   // chunks per pair
   std::vector<int4> chunks;
   std::vector<int> pair_beg(nf * nf + 1, 0);
@@ -282,6 +306,7 @@ static int upload_window_impl(sdso_ctx* ctx, int win, const sdso_ba_window_t* Wi
   DM(d_chunks, int4, chunks.size()); DM(d_pair_beg, int, nf * nf + 1); DM(d_items, int4, items.size()); DM(d_host_beg, int, nf + 1);
   DM(d.top_part, float, (size_t)d.nchunks * 92); DM(d.sc_part, float, std::max((size_t)d.nitems * sc_part_floats(nf), (size_t)nf * 20)); DM(d.e_part, double, std::max(W->nblk_res, d.nchunks) + 1);
   DM(d.accum, float, acc_floats(nf));
+  W->accum_own = d.accum;
   DM(d.sol, double, 4 * ((size_t)n * n + n) + n);
   DM(W->d_pflag, uint8_t, np); DM(W->d_sums, float, 2 * (W->nblk_pts + 1));
   DM(W->d_self, BaDev, 1);
@@ -320,11 +345,8 @@ static int upload_window_impl(sdso_ctx* ctx, int win, const sdso_ba_window_t* Wi
   // per-residual record: target in slot 15, newState OUTLIER, newEnergyWO -1
   {
     std::vector<float> rec((size_t)np * nf * 16, 0.f);
-    std::vector<uint8_t> seen((size_t)np * nf, 0);
     for (int o = 0; o < nr; o++) {
       const size_t slot = (size_t)Win->res_point[o] * nf + Win->res_target[o];
-      SDSO_REQUIRE(ctx, !seen[slot], "two residuals of one point observe the same target frame");
-      seen[slot] = 1;
       rec[slot * 16 + RR_TARGET] = (float)Win->res_target[o];
     }
     H2D(d.r_rec, rec.data(), sizeof(float) * rec.size());
@@ -373,21 +395,20 @@ static void launch_apply(sdso_ctx* ctx, const BaLaunch& L) {
 static void launch_sc_and_folds(sdso_ctx* ctx, const BaLaunch& L, const uint8_t* pflag, bool marg, bool fold_top_too = false);
 static void launch_accumulate(sdso_ctx* ctx, const BaLaunch& L, const uint8_t* pflag, bool marg) {
   const int nf = L.nf;
-  if (L.max_chunks > 0) {
-    if (!marg) {
-      { ProfScope ps(ctx, "k_ba_accum_top"); hipLaunchKernelGGL(k_ba_accum_top, dim3(L.max_chunks, L.nwin), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr, 0, (const uint8_t*)nullptr); }
-      hipLaunchKernelGGL(k_ba_fold_top, dim3(nf * nf, L.nwin), dim3(128), 0, ctx->stream, L.d_arr, 0);
-      if (L.any_lin) {
-        hipLaunchKernelGGL(k_ba_accum_top, dim3(L.max_chunks, L.nwin), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr, 1, (const uint8_t*)nullptr);
-        hipLaunchKernelGGL(k_ba_fold_top, dim3(nf * nf, L.nwin), dim3(128), 0, ctx->stream, L.d_arr, 1);
-      } else {
-        // accumulateLF_MT over zero linearized residuals: only the priors survive (added in the stitch)
-        hipLaunchKernelGGL(k_ba_zero_topL, dim3(nf * nf, L.nwin), dim3(128), 0, ctx->stream, L.d_arr);
-      }
+  // the folds run even without a single chunk: they are what clears the top bins of the previous call
+  if (!marg) {
+    if (L.max_chunks > 0) { ProfScope ps(ctx, "k_ba_accum_top"); hipLaunchKernelGGL(k_ba_accum_top, dim3(L.max_chunks, L.nwin), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr, 0, (const uint8_t*)nullptr); }
+    hipLaunchKernelGGL(k_ba_fold_top, dim3(nf * nf, L.nwin), dim3(128), 0, ctx->stream, L.d_arr, 0);
+    if (L.any_lin && L.max_chunks > 0) {
+      hipLaunchKernelGGL(k_ba_accum_top, dim3(L.max_chunks, L.nwin), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr, 1, (const uint8_t*)nullptr);
+      hipLaunchKernelGGL(k_ba_fold_top, dim3(nf * nf, L.nwin), dim3(128), 0, ctx->stream, L.d_arr, 1);
     } else {
-      hipLaunchKernelGGL(k_ba_accum_top, dim3(L.max_chunks, L.nwin), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr, 2, pflag);
-      hipLaunchKernelGGL(k_ba_fold_top, dim3(nf * nf, L.nwin), dim3(128), 0, ctx->stream, L.d_arr, 0);
+      // accumulateLF_MT over zero linearized residuals: only the priors survive (added in the stitch)
+      hipLaunchKernelGGL(k_ba_zero_topL, dim3(nf * nf, L.nwin), dim3(128), 0, ctx->stream, L.d_arr);
     }
+  } else {
+    if (L.max_chunks > 0) hipLaunchKernelGGL(k_ba_accum_top, dim3(L.max_chunks, L.nwin), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr, 2, pflag);
+    hipLaunchKernelGGL(k_ba_fold_top, dim3(nf * nf, L.nwin), dim3(128), 0, ctx->stream, L.d_arr, 0);
   }
   launch_sc_and_folds(ctx, L, pflag, marg);
 }
@@ -422,13 +443,12 @@ static void launch_sc_and_folds(sdso_ctx* ctx, const BaLaunch& L, const uint8_t*
   else hipLaunchKernelGGL(k_ba_fold_sc, dim3(nf * nf * nf + nf * nf + 1, L.nwin), dim3(64), 0, ctx->stream, L.d_arr);
 }
 // linearizeAll + applyRes + accumulateAF in one kernel, then the (normally empty) linearized pass and the Schur part
-static void launch_fused(sdso_ctx* ctx, const BaLaunch& L, bool materialize, int part = 3 /* bit 0: linearize+top, bit 1: Schur+folds */) {
+static void launch_fused(sdso_ctx* ctx, const BaLaunch& L, bool materialize, bool direct, int part = 3 /* bit 0: linearize+top, bit 1: Schur+folds */) {
   const int nf = L.nf;
   if ((part & 1) && L.max_chunks > 0) {
     {
       ProfScope ps(ctx, "k_ba_lin_fused");
       const dim3 g(L.max_chunks, L.nwin), b(BA_BLOCK);
-      static const bool direct = getenv("SDSO_BA_DIRECT_TAPS") != nullptr;   // A/B: one residual's 32 taps on one lane (the first design)
 #define LF(M, T) do { if (direct) hipLaunchKernelGGL((k_ba_lin_fused<M, T, false>), g, b, 0, ctx->stream, L.d_arr); else hipLaunchKernelGGL((k_ba_lin_fused<M, T, true>), g, b, 0, ctx->stream, L.d_arr); } while (0)
       if (materialize) { if (L.tiled) LF(true, true); else LF(true, false); }
       else { if (L.tiled) LF(false, true); else LF(false, false); }
@@ -441,7 +461,7 @@ static void launch_fused(sdso_ctx* ctx, const BaLaunch& L, bool materialize, int
     }
   }
   // without linearized residuals the top partials are folded together with the Schur partials, after the Schur kernel
-  if (part & 2) launch_sc_and_folds(ctx, L, nullptr, false, L.max_chunks > 0 && !L.any_lin);
+  if (part & 2) launch_sc_and_folds(ctx, L, nullptr, false, !L.any_lin);
 }
 static void launch_solve(sdso_ctx* ctx, const BaLaunch& L, double lambda, int orth) {
   const int nf = L.nf, n = L.n;
@@ -454,7 +474,7 @@ static BaLaunch single(BaWindowDev* W) {
   BaLaunch L;
   L.d_arr = W->d_self; L.nwin = 1; L.max_nblk_res = std::max(W->nblk_res, 1); L.max_nblk_pts = W->nblk_pts;
   L.max_chunks = W->d.nchunks; L.max_items = W->d.nitems; L.nf = W->d.nf; L.n = W->d.n;
-  L.any_lin = std::any_of(W->h_lin.begin(), W->h_lin.end(), [](uint8_t v) { return v != 0; });
+  L.any_lin = W->has_lin_cached;
   L.tiled = W->d.tiledT > 0;
   return L;
 }
@@ -515,23 +535,38 @@ extern "C" int sdso_ba_linearize(sdso_ctx* ctx, int win, double* energy) {
   return linearize_all(ctx, W, false, energy);
 }
 
+namespace sdso {
+// RawResidualJacobian records in the ABI's field order; ef = false: PointFrameResidual::J (= J[1 - jsel], what linearize wrote
+// last), ef = true: EFResidual::J (= J[jsel], what takeDataF swapped in)
+static int fetch_jacobians(sdso_ctx* ctx, BaWindowDev* W, bool ef, float* J) {
+  const int nr = W->d.nr, S = W->d.nrp;
+  std::vector<float> j0((size_t)76 * S), j1((size_t)76 * S);
+  std::vector<uint8_t> sel(nr);
+  SDSO_HIP(ctx, hipMemcpy(j0.data(), W->d.J[0], sizeof(float) * j0.size(), hipMemcpyDeviceToHost));
+  SDSO_HIP(ctx, hipMemcpy(j1.data(), W->d.J[1], sizeof(float) * j1.size(), hipMemcpyDeviceToHost));
+  if (nr) SDSO_HIP(ctx, hipMemcpy(sel.data(), W->d.r_jsel, nr, hipMemcpyDeviceToHost));
+  for (int j = 0; j < nr; j++) {
+    const std::vector<float>& src = ((sel[j] != 0) != ef) ? j0 : j1;
+    float* o = J + (size_t)W->perm[j] * 74;
+    for (int f = 0; f < 74; f++) { const int dv = jdev(f); o[f] = src[(size_t)(dv >> 2) * 4 * S + 4 * (size_t)j + (dv & 3)]; }
+  }
+  return SDSO_OK;
+}
+}  // namespace sdso
+
+extern "C" int sdso_ba_get_ef_jacobians(sdso_ctx* ctx, int win, float* J) {
+  GET_WIN();
+  SDSO_REQUIRE(ctx, J, "null buffer");
+  SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return fetch_jacobians(ctx, W, true, J);
+}
+
 extern "C" int sdso_ba_get_linearization(sdso_ctx* ctx, int win, float* J, uint8_t* newState, float* newEnergy, float* newEnergyWithOutlier,
                                          float* projectedTo, float* centerProjectedTo) {
   GET_WIN();
-  const int nr = W->d.nr, S = W->d.nrp;
+  const int nr = W->d.nr;
   SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  if (J) {
-    std::vector<float> j0((size_t)76 * S), j1((size_t)76 * S);
-    std::vector<uint8_t> sel(nr);
-    SDSO_HIP(ctx, hipMemcpy(j0.data(), W->d.J[0], sizeof(float) * j0.size(), hipMemcpyDeviceToHost));
-    SDSO_HIP(ctx, hipMemcpy(j1.data(), W->d.J[1], sizeof(float) * j1.size(), hipMemcpyDeviceToHost));
-    if (nr) SDSO_HIP(ctx, hipMemcpy(sel.data(), W->d.r_jsel, nr, hipMemcpyDeviceToHost));
-    for (int j = 0; j < nr; j++) {
-      const std::vector<float>& src = sel[j] ? j0 : j1;  // PointFrameResidual::J = J[1 - jsel]
-      float* o = J + (size_t)W->perm[j] * 74;
-      for (int f = 0; f < 74; f++) { const int dv = jdev(f); o[f] = src[(size_t)(dv >> 2) * 4 * S + 4 * (size_t)j + (dv & 3)]; }
-    }
-  }
+  if (J) { const int rcj = fetch_jacobians(ctx, W, false, J); if (rcj) return rcj; }
   auto fetch = [&](auto* dst, const auto* dsrc, int width) -> int {
     using T = std::remove_pointer_t<decltype(dst)>;
     std::vector<T> tmp((size_t)nr * width);
@@ -967,6 +1002,7 @@ extern "C" int sdso_ba_marginalize_points(sdso_ctx* ctx, int win, const uint8_t*
   if (nr) SDSO_HIP(ctx, hipMemcpyAsync(lin.data(), W->d.r_lin, nr, hipMemcpyDeviceToHost, ctx->stream));
   SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
   W->h_lin = lin;
+  W->has_lin_cached = std::any_of(lin.begin(), lin.end(), [](uint8_t v) { return v != 0; });
   const float fac = 0.5f * 0.5f;  // setting_margWeightFac
   for (size_t i = 0; i < (size_t)n * n; i++) W->HM[i] += fac * (MA[i] - MS[i]);
   for (int i = 0; i < n; i++) W->bM[i] += fac * (MA[(size_t)n * n + i] - MS[(size_t)n * n + i]);
@@ -987,44 +1023,61 @@ extern "C" int sdso_ba_batch_create(sdso_ctx* ctx, int nwin, const int* wins) {
   SDSO_REQUIRE(ctx, nwin > 0 && wins, "bad batch");
   SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
   free_batch(ctx);
-  BaBatch* Bt = new BaBatch();
-  reg_get(g_batches, ctx) = Bt;
-  BaWindowDev* W0 = find_win(ctx, wins[0]);
-  SDSO_REQUIRE(ctx, W0, "unknown window in batch");
-  const int nf = W0->d.nf;
+  // validate every member before anything is registered or rebound
+  std::vector<BaWindowDev*> Ws(nwin);
+  for (int i = 0; i < nwin; i++) {
+    Ws[i] = find_win(ctx, wins[i]);
+    SDSO_REQUIRE(ctx, Ws[i], "unknown window in batch");
+    SDSO_REQUIRE(ctx, Ws[i]->d.nf == Ws[0]->d.nf, "batch windows must share nf");
+    SDSO_REQUIRE(ctx, (Ws[i]->d.tiledT > 0) == (Ws[0]->d.tiledT > 0), "batch windows must share the image layout");
+    SDSO_REQUIRE(ctx, (Ws[i]->solverMode & (SOLVER_SVD | SOLVER_ORTHOGONALIZE_SYSTEM)) == 0, "SOLVER_SVD / SOLVER_ORTHOGONALIZE_SYSTEM windows are solved through sdso_ba_solve / sdso_ba_optimize, not in a batch");
+    for (int k = 0; k < i; k++) SDSO_REQUIRE(ctx, Ws[k] != Ws[i], "a window may appear only once in a batch");
+  }
+  const int nf = Ws[0]->d.nf;
   const size_t af = acc_floats(nf);
-  SDSO_HIP(ctx, hipMalloc(&Bt->d_arr, sizeof(BaDev) * nwin));
-  SDSO_HIP(ctx, hipMalloc(&Bt->d_accum, sizeof(float) * af * nwin));
-  SDSO_HIP(ctx, hipMemsetAsync(Bt->d_accum, 0, sizeof(float) * af * nwin, ctx->stream));
+  BaDev* d_arr = nullptr; float* d_accum = nullptr;
+  SDSO_HIP(ctx, hipMalloc(&d_arr, sizeof(BaDev) * nwin));
+  if (hipMalloc(&d_accum, sizeof(float) * af * nwin) != hipSuccess) { hipFree(d_arr); return sdso::fail(ctx, SDSO_ERR_HIP, "hipMalloc of the batch accumulator block failed"); }
+  BaBatch* Bt = new BaBatch();
+  Bt->d_arr = d_arr; Bt->d_accum = d_accum; Bt->W = Ws;
+  Bt->wins.assign(wins, wins + nwin);
+  Bt->direct_taps = getenv("SDSO_BA_DIRECT_TAPS") != nullptr;
+  reg_get(g_batches, ctx) = Bt;
+  hipMemsetAsync(Bt->d_accum, 0, sizeof(float) * af * nwin, ctx->stream);
   std::vector<BaDev> h(nwin);
   BaLaunch L{};
-  L.nwin = nwin; L.nf = nf; L.n = W0->d.n; L.tiled = W0->d.tiledT > 0;
+  L.nwin = nwin; L.nf = nf; L.n = Ws[0]->d.n; L.tiled = Ws[0]->d.tiledT > 0;
   for (int i = 0; i < nwin; i++) {
-    BaWindowDev* W = find_win(ctx, wins[i]);
-    SDSO_REQUIRE(ctx, W && W->d.nf == nf, "batch windows must exist and share nf");
-    SDSO_REQUIRE(ctx, (W->d.tiledT > 0) == L.tiled, "batch windows must share the image layout");
-    SDSO_REQUIRE(ctx, (W->solverMode & (SOLVER_SVD | SOLVER_ORTHOGONALIZE_SYSTEM)) == 0, "SOLVER_SVD / SOLVER_ORTHOGONALIZE_SYSTEM windows are solved through sdso_ba_solve / sdso_ba_optimize, not in a batch");
+    BaWindowDev* W = Ws[i];
     W->d.accum = Bt->d_accum + af * i;   // contiguous accumulators: ONE all-reduce covers the batch
-    W->own_accum = false;
+    W->in_batch = true;
     h[i] = W->d;
-    SDSO_HIP(ctx, hipMemcpyAsync(W->d_self, &W->d, sizeof(BaDev), hipMemcpyHostToDevice, ctx->stream));
+    hipMemcpyAsync(W->d_self, &W->d, sizeof(BaDev), hipMemcpyHostToDevice, ctx->stream);
     L.max_nblk_res = std::max(L.max_nblk_res, std::max(W->nblk_res, 1)); L.max_nblk_pts = std::max(L.max_nblk_pts, W->nblk_pts);
     L.max_chunks = std::max(L.max_chunks, W->d.nchunks); L.max_items = std::max(L.max_items, W->d.nitems);
-    L.any_lin = L.any_lin || std::any_of(W->h_lin.begin(), W->h_lin.end(), [](uint8_t v) { return v != 0; });
     W->accumulated = true;
   }
-  SDSO_HIP(ctx, hipMemcpyAsync(Bt->d_arr, h.data(), sizeof(BaDev) * nwin, hipMemcpyHostToDevice, ctx->stream));
-  SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  hipMemcpyAsync(Bt->d_arr, h.data(), sizeof(BaDev) * nwin, hipMemcpyHostToDevice, ctx->stream);
   L.d_arr = Bt->d_arr;
+  L.any_lin = false;   // recomputed at every launch (marginalisation may linearize residuals of a member later)
   Bt->L = L;
-  Bt->wins.assign(wins, wins + nwin);
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess) { free_batch(ctx); return sdso::fail(ctx, SDSO_ERR_HIP, "batch descriptor upload failed"); }
   return SDSO_OK;
 }
+namespace sdso {
+static BaBatch* get_batch(sdso_ctx* ctx) { return ctx && reg_has(g_batches, ctx) ? reg_get(g_batches, ctx) : nullptr; }
+// launch descriptor of the batch with the state-dependent flags refreshed
+static const BaLaunch& batch_launch(BaBatch* Bt) {
+  Bt->L.any_lin = false;
+  for (BaWindowDev* W : Bt->W) if (W->has_lin_cached) { Bt->L.any_lin = true; break; }
+  return Bt->L;
+}
+}  // namespace sdso
 // phase 1 of one GN iteration for every window of the batch: linearize + applyRes + accumulate A/L/SC (enqueue only)
 extern "C" int sdso_ba_batch_accumulate(sdso_ctx* ctx) {
-  BaBatch* Bt = ctx && reg_has(g_batches, ctx) ? reg_get(g_batches, ctx) : nullptr;
+  BaBatch* Bt = get_batch(ctx);
   if (!Bt) return sdso::fail(ctx, SDSO_ERR_STATE, "no batch");
-  launch_fused(ctx, Bt->L, Bt->materialize);
+  launch_fused(ctx, batch_launch(Bt), Bt->materialize, Bt->direct_taps);
   SDSO_HIP(ctx, hipGetLastError());
   return SDSO_OK;
 }
@@ -1032,16 +1085,16 @@ extern "C" int sdso_ba_batch_accumulate(sdso_ctx* ctx) {
 // bandwidth-bound linearisation of one batch is best followed immediately by the linearisation of the next one, with the Schur
 // accumulation and the folds of the first running underneath it
 extern "C" int sdso_ba_batch_linearize(sdso_ctx* ctx) {
-  BaBatch* Bt = ctx && reg_has(g_batches, ctx) ? reg_get(g_batches, ctx) : nullptr;
+  BaBatch* Bt = get_batch(ctx);
   if (!Bt) return sdso::fail(ctx, SDSO_ERR_STATE, "no batch");
-  launch_fused(ctx, Bt->L, Bt->materialize, 1);
+  launch_fused(ctx, batch_launch(Bt), Bt->materialize, Bt->direct_taps, 1);
   SDSO_HIP(ctx, hipGetLastError());
   return SDSO_OK;
 }
 extern "C" int sdso_ba_batch_schur(sdso_ctx* ctx) {
-  BaBatch* Bt = ctx && reg_has(g_batches, ctx) ? reg_get(g_batches, ctx) : nullptr;
+  BaBatch* Bt = get_batch(ctx);
   if (!Bt) return sdso::fail(ctx, SDSO_ERR_STATE, "no batch");
-  launch_fused(ctx, Bt->L, Bt->materialize, 2);
+  launch_fused(ctx, batch_launch(Bt), Bt->materialize, Bt->direct_taps, 2);
   SDSO_HIP(ctx, hipGetLastError());
   return SDSO_OK;
 }
@@ -1049,7 +1102,7 @@ extern "C" int sdso_ba_batch_schur(sdso_ctx* ctx) {
 // (what PointFrameResidual::J holds in the reference); 0: they stay in registers (the solver never
 // re-reads them) — 296 B less store traffic per point-residual.
 extern "C" int sdso_ba_batch_set_materialize(sdso_ctx* ctx, int materialize) {
-  BaBatch* Bt = ctx && reg_has(g_batches, ctx) ? reg_get(g_batches, ctx) : nullptr;
+  BaBatch* Bt = get_batch(ctx);
   if (!Bt) return sdso::fail(ctx, SDSO_ERR_STATE, "no batch");
   Bt->materialize = materialize != 0;
   return SDSO_OK;
@@ -1057,21 +1110,21 @@ extern "C" int sdso_ba_batch_set_materialize(sdso_ctx* ctx, int materialize) {
 // phase 2: stitch + solve + resubstitute (enqueue only). Between the phases the caller may all-reduce
 // the packed accumulators (sdso_ba_batch_accum_dev) across ranks.
 extern "C" int sdso_ba_batch_solve(sdso_ctx* ctx, double lambda, int orthogonalize_x) {
-  BaBatch* Bt = ctx && reg_has(g_batches, ctx) ? reg_get(g_batches, ctx) : nullptr;
+  BaBatch* Bt = get_batch(ctx);
   if (!Bt) return sdso::fail(ctx, SDSO_ERR_STATE, "no batch");
   launch_solve(ctx, Bt->L, lambda, orthogonalize_x);
   SDSO_HIP(ctx, hipGetLastError());
   return SDSO_OK;
 }
 extern "C" int sdso_ba_batch_accum_dev(sdso_ctx* ctx, void** dev_ptr, long* nfloats) {
-  BaBatch* Bt = ctx && reg_has(g_batches, ctx) ? reg_get(g_batches, ctx) : nullptr;
+  BaBatch* Bt = get_batch(ctx);
   if (!Bt) return sdso::fail(ctx, SDSO_ERR_STATE, "no batch");
   if (dev_ptr) *dev_ptr = Bt->d_accum;
   if (nfloats) *nfloats = (long)(acc_floats(Bt->L.nf) * Bt->wins.size());
   return SDSO_OK;
 }
 extern "C" int sdso_ba_batch_get_x(sdso_ctx* ctx, double* x /* nwin * (8nf+4) */) {
-  BaBatch* Bt = ctx && reg_has(g_batches, ctx) ? reg_get(g_batches, ctx) : nullptr;
+  BaBatch* Bt = get_batch(ctx);
   if (!Bt) return sdso::fail(ctx, SDSO_ERR_STATE, "no batch");
   SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
   const int n = Bt->L.n;

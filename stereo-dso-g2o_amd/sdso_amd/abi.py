@@ -247,6 +247,7 @@ def load():
     L.sdso_ba_get_linearization.argtypes = [vp, C.c_int, c_float_p, c_u8_p, c_float_p, c_float_p, c_float_p, c_float_p]
     L.sdso_ba_apply_res.argtypes = [vp, C.c_int]
     L.sdso_ba_get_residual_state.argtypes = [vp, C.c_int, c_u8_p, c_u8_p, c_float_p]
+    L.sdso_ba_get_ef_jacobians.argtypes = [vp, C.c_int, c_float_p]
     L.sdso_ba_accumulate.argtypes = [vp, C.c_int]
     L.sdso_ba_accum_floats.argtypes = [C.c_int]
     L.sdso_ba_accum_dev.argtypes = [vp, C.c_int, C.POINTER(vp)]
@@ -298,7 +299,7 @@ EXPORTED_SYMBOLS = [
     "sdso_track_calc_res_gs", "sdso_track_calc_res_gs_batch", "sdso_track_batch_prepare",
     "sdso_track_batch_enqueue", "sdso_track_batch_fetch", "sdso_track_newest_coarse",
     "sdso_ba_upload_window", "sdso_ba_release_window", "sdso_ba_linearize", "sdso_ba_get_linearization",
-    "sdso_ba_apply_res", "sdso_ba_get_residual_state", "sdso_ba_accumulate", "sdso_ba_accum_floats",
+    "sdso_ba_apply_res", "sdso_ba_get_residual_state", "sdso_ba_get_ef_jacobians", "sdso_ba_accumulate", "sdso_ba_accum_floats",
     "sdso_ba_accum_dev", "sdso_ba_get_accumulators", "sdso_ba_set_accumulators", "sdso_ba_get_point_terms", "sdso_ba_solve",
     "sdso_ba_get_point_steps", "sdso_ba_optimize", "sdso_ba_marginalize_points", "sdso_ba_get_tables",
     "sdso_ba_keep_projections", "sdso_ba_batch_create", "sdso_ba_batch_accumulate", "sdso_ba_batch_solve",
