@@ -145,23 +145,49 @@ class BAWorkload:
             out[k + "_avg_ms"] = ms / max(n, 1)
         return out
 
-    def cpu_baseline(self, budget_s=15.0):
+    def cpu_baseline(self, warmup=5, reps=50):
+        """SURVEY §8d protocol: the oracle port (-O3 -march=native) on one window, 5 warm-up + 50 timed GN iterations per leg,
+        median / p10 / p90; legs = 1 thread, 6 threads (the reference's NUM_THREADS, util/NumType.h:38; IndexThreadReduce work
+        stealing with chunks of 50 points and per-thread accumulator copies, EnergyFunctional.cpp:212-269) and all host cores.
+        `value` is the fastest leg's median rate, `cores` the threads that leg used."""
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import pyoracle  # cpu_baseline leg only
         abi = self.abi
         orc = pyoracle.load(fast=True)
         win = self.win
         W, keep = abi.make_ba_window(win, frame_slots=list(range(win["nf"])), dI_list=[p[0] for p in win["pyrs"]])
-        h = orc.orc_ba_create(C.byref(W))
-        x = np.zeros(68)
-        t0, its = time.perf_counter(), 0
-        while time.perf_counter() - t0 < budget_s:
-            orc.orc_ba_linearize(h, None)
-            orc.orc_ba_apply_res(h)
-            orc.orc_ba_solve(h, 0, 1e-5, abi.dp(x), None, None, None, None)
-            its += 1
-        dt = time.perf_counter() - t0
-        orc.orc_ba_destroy(h)
-        return {"value": its * win["nr"] / dt, "unit": self.unit, "cores": 1, "kind": "port",
-                "sample": "%d GN iterations of one 8KF/2000-point window (%d residuals) in %.1f s, oracle -O3 -march=native, 1 thread"
-                          % (its, win["nr"], dt), "ba_iters_per_s": its / dt}
+        nproc = os.cpu_count() or 1
+        try:
+            nproc = len(os.sched_getaffinity(0))
+        except (AttributeError, OSError):
+            pass
+        model = "unknown"
+        try:
+            for line in open("/proc/cpuinfo"):
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+        except OSError:
+            pass
+        legs = []
+        for nt in sorted({1, 6, nproc}):
+            h = orc.orc_ba_create(C.byref(W))
+            orc.orc_ba_set_threads(h, nt)
+            x = np.zeros(68)
+            ts = []
+            for it in range(warmup + reps):
+                t0 = time.perf_counter()
+                orc.orc_ba_linearize(h, None)
+                orc.orc_ba_apply_res(h)
+                orc.orc_ba_solve(h, 0, 1e-5, abi.dp(x), None, None, None, None)
+                ts.append(time.perf_counter() - t0)
+            orc.orc_ba_destroy(h)
+            t = np.array(ts[warmup:])
+            legs.append({"threads": nt, "median_ms": float(np.median(t) * 1e3), "p10_ms": float(np.percentile(t, 10) * 1e3),
+                         "p90_ms": float(np.percentile(t, 90) * 1e3), "point_residuals_per_s": float(win["nr"] / np.median(t)),
+                         "ba_iters_per_s": float(1.0 / np.median(t))})
+        best = max(legs, key=lambda l: l["point_residuals_per_s"])
+        return {"value": best["point_residuals_per_s"], "unit": self.unit, "cores": best["threads"], "kind": "port",
+                "sample": "%d warm-up + %d timed GN iterations (linearizeAll + applyRes + accumulate A/L/SC + stitch + solve + resubstitute) of one "
+                          "8KF/2000-point window (%d residuals) per leg, oracle -O3 -march=native; median of the fastest leg" % (warmup, reps, win["nr"]),
+                "cpu_model": model, "nproc": nproc, "legs": legs, "ba_iters_per_s": best["ba_iters_per_s"]}

@@ -110,9 +110,16 @@ struct AccumulatorApprox {
       for (int cc = r; cc < 10; cc++) {
         // Data[idx] += a*x[cc]*x[r] + c*y[cc]*y[r] + b*(x[cc]*y[r] + y[cc]*x[r]);
         Data[idx] += a * x[cc] * x[r] + c * y[cc] * y[r] + b * (x[cc] * y[r] + y[cc] * x[r]);
-        Dd[idx] += (double)a * x[cc] * x[r] + (double)c * y[cc] * y[r] + (double)b * ((double)x[cc] * y[r] + (double)y[cc] * x[r]);
         idx++;
       }
+    if (acc64_mode()) {   // truth mode only: the timed CPU baseline must not pay for it
+      idx = 0;
+      for (int r = 0; r < 10; r++)
+        for (int cc = r; cc < 10; cc++) {
+          Dd[idx] += (double)a * x[cc] * x[r] + (double)c * y[cc] * y[r] + (double)b * ((double)x[cc] * y[r] + (double)y[cc] * x[r]);
+          idx++;
+        }
+    }
     num++; numIn1++;
     shiftUp(false);
   }
@@ -126,15 +133,18 @@ struct AccumulatorApprox {
       TR[3 * r + 0] += x[r] * TR00 + y[r] * TR10;
       TR[3 * r + 1] += x[r] * TR01 + y[r] * TR11;
       TR[3 * r + 2] += x[r] * TR02 + y[r] * TR12;
-      TRd[3 * r + 0] += (double)x[r] * TR00 + (double)y[r] * TR10;
-      TRd[3 * r + 1] += (double)x[r] * TR01 + (double)y[r] * TR11;
-      TRd[3 * r + 2] += (double)x[r] * TR02 + (double)y[r] * TR12;
     }
+    if (acc64_mode())
+      for (int r = 0; r < 10; r++) {
+        TRd[3 * r + 0] += (double)x[r] * TR00 + (double)y[r] * TR10;
+        TRd[3 * r + 1] += (double)x[r] * TR01 + (double)y[r] * TR11;
+        TRd[3 * r + 2] += (double)x[r] * TR02 + (double)y[r] * TR12;
+      }
   }
   // :842-855
   void updateBotRight(float a00, float a01, float a02, float a11, float a12, float a22) {
     BR[0] += a00; BR[1] += a01; BR[2] += a02; BR[3] += a11; BR[4] += a12; BR[5] += a22;
-    BRd[0] += a00; BRd[1] += a01; BRd[2] += a02; BRd[3] += a11; BRd[4] += a12; BRd[5] += a22;
+    if (acc64_mode()) { BRd[0] += a00; BRd[1] += a01; BRd[2] += a02; BRd[3] += a11; BRd[4] += a12; BRd[5] += a22; }
   }
   void finish() {  // :589-618
     std::memset(H, 0, sizeof(H));
@@ -190,8 +200,10 @@ struct AccumulatorXX {
   void update(const float* L, const float* R, float w) {  // A += w*L*R^T  ((w*L)*R^T in Eigen)
     for (int i = 0; i < I; i++) {
       float wl = w * L[i];
-      for (int j = 0; j < J; j++) { A[i][j] += wl * R[j]; Ad[i][j] += (double)w * L[i] * R[j]; }
+      for (int j = 0; j < J; j++) A[i][j] += wl * R[j];
     }
+    if (acc64_mode())
+      for (int i = 0; i < I; i++) for (int j = 0; j < J; j++) Ad[i][j] += (double)w * L[i] * R[j];
     numIn1++;
     shiftUp(false);
   }
@@ -220,7 +232,8 @@ struct AccumulatorX {
     }
   }
   void update(const float* L, float w) {
-    for (int i = 0; i < I; i++) { A[i] += w * L[i]; Ad[i] += (double)w * L[i]; }
+    for (int i = 0; i < I; i++) A[i] += w * L[i];
+    if (acc64_mode()) for (int i = 0; i < I; i++) Ad[i] += (double)w * L[i];
     numIn1++;
     shiftUp(false);
   }

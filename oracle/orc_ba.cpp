@@ -17,12 +17,100 @@
 #include <cstdio>
 #include <vector>
 #include <algorithm>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
 
 using namespace orc;
 
 namespace {
 
 enum ResState { RS_IN = 0, RS_OOB = 1, RS_OUTLIER = 2 };
+
+// src/util/IndexThreadReduce.h:34-196 with the number of workers a run-time value (the reference fixes NUM_THREADS = 6,
+// util/NumType.h:38): persistent workers take index chunks of `stepSize` from a shared counter under one mutex (stepSize 0 =
+// ceil(n / workers)); a worker that got no chunk is still called once with (0, 0) so that per-thread state is initialised
+// everywhere (:179-187); the caller sleeps on a condition variable until every worker reports done.  Used by the timed CPU
+// baseline only (orc_ba_set_threads); the parity path of the tests stays single-threaded (tid 0).
+class Reducer {
+ public:
+  typedef std::function<void(int, int, double*, int)> Fn;
+  explicit Reducer(int n) : nthreads(n), isDone(n, 0), gotOne(n, 1) {
+    for (int i = 0; i < n; i++) workers.emplace_back(&Reducer::workerLoop, this, i);
+  }
+  ~Reducer() {
+    { std::unique_lock<std::mutex> lock(exMutex); running = false; todo_signal.notify_all(); }
+    for (auto& t : workers) t.join();
+  }
+  double reduce(const Fn& f, int first, int end, int step = 0) {
+    if (step == 0) step = ((end - first) + nthreads - 1) / nthreads;
+    std::unique_lock<std::mutex> lock(exMutex);
+    stats = 0;
+    callPerIndex = f; nextIndex = first; maxIndex = end; stepSize = step;
+    for (int i = 0; i < nthreads; i++) { isDone[i] = 0; gotOne[i] = 0; }
+    todo_signal.notify_all();
+    while (true) {
+      done_signal.wait(lock);
+      bool allDone = true;
+      for (int i = 0; i < nthreads; i++) allDone = allDone && isDone[i];
+      if (allDone) break;
+    }
+    nextIndex = 0; maxIndex = 0;
+    return stats;
+  }
+  const int nthreads;
+
+ private:
+  void workerLoop(int idx) {
+    std::unique_lock<std::mutex> lock(exMutex);
+    while (running) {
+      int todo = 0;
+      bool gotSomething = false;
+      if (nextIndex < maxIndex) { todo = nextIndex; nextIndex += stepSize; gotSomething = true; }
+      if (gotSomething) {
+        const int hi = std::min(todo + stepSize, maxIndex);
+        lock.unlock();
+        double sres = 0;
+        callPerIndex(todo, hi, &sres, idx);
+        lock.lock();
+        gotOne[idx] = 1;
+        stats += sres;
+      } else {
+        if (!gotOne[idx]) {
+          lock.unlock();
+          double sres = 0;
+          callPerIndex(0, 0, &sres, idx);
+          lock.lock();
+          gotOne[idx] = 1;
+          stats += sres;
+        }
+        isDone[idx] = 1;
+        done_signal.notify_all();
+        todo_signal.wait(lock);
+      }
+    }
+  }
+  std::vector<std::thread> workers;
+  std::vector<char> isDone, gotOne;
+  std::mutex exMutex;
+  std::condition_variable todo_signal, done_signal;
+  int nextIndex = 0, maxIndex = 0, stepSize = 1;
+  bool running = true;
+  double stats = 0;
+  Fn callPerIndex;
+};
+
+// one thread's private accumulators (AccumulatedTopHessianSSE::acc[tid], AccumulatedSCHessianSSE::accD/E/EB/Hcc/bc[tid])
+struct AccSet {
+  std::vector<AccumulatorApprox> topA, topL;
+  std::vector<AccumulatorXX<8, 8>> D;
+  std::vector<AccumulatorXX<8, 4>> E;
+  std::vector<AccumulatorX<8>> EB;
+  AccumulatorXX<4, 4> Hcc;
+  AccumulatorX<4> bc;
+  int nresA = 0, nresL = 0;
+};
 
 struct RawJ {  // RawResidualJacobian.h:32-65, flattened in the ABI's field order (74 floats)
   float resF[8];
@@ -202,14 +290,11 @@ struct orc_ba {
   int solverMode;
   double affineOptModeA, affineOptModeB;
   bool forceAcceptStep;
-  // accumulators
-  std::vector<AccumulatorApprox> accTopA, accTopL;
-  std::vector<AccumulatorXX<8, 8>> accD;
-  std::vector<AccumulatorXX<8, 4>> accE;
-  std::vector<AccumulatorX<8>> accEB;
-  AccumulatorXX<4, 4> accHcc;
-  AccumulatorX<4> accbc;
+  // accumulators: T[tid]; T[0] alone on the single-thread (parity) path
+  std::vector<AccSet> T = std::vector<AccSet>(1);
+  Reducer* red = nullptr;   // null: everything runs on the calling thread
   int nresA, nresL, resInM;
+  ~orc_ba() { delete red; }
   MatX lastHS;
   VecX lastbS, lastX;
   std::vector<VecX> lastNullspaces_pose, lastNullspaces_scale;
@@ -512,10 +597,21 @@ struct orc_ba {
   // FullSystemOptimize.cpp:142-203 (activeResiduals = residuals that are not linearized)
   double linearizeAll(bool fixLinearization) {
     double lastEnergyP = 0;
-    for (Residual& r : res) {
-      if (r.isLinearized) continue;
-      lastEnergyP += linearize(r);
-      if (fixLinearization) applyRes(r);
+    if (red) {  // treadReduce.reduce(linearizeAll_Reductor, 0, activeResiduals.size(), 0)  (:142-160)
+      lastEnergyP = red->reduce([&](int lo, int hi, double* stats, int) {
+        for (int k = lo; k < hi; k++) {
+          Residual& r = res[k];
+          if (r.isLinearized) continue;
+          *stats += linearize(r);
+          if (fixLinearization) applyRes(r);
+        }
+      }, 0, nr, 0);
+    } else {
+      for (Residual& r : res) {
+        if (r.isLinearized) continue;
+        lastEnergyP += linearize(r);
+        if (fixLinearization) applyRes(r);
+      }
     }
     setNewFrameEnergyTH();
     return lastEnergyP;
@@ -584,7 +680,7 @@ struct orc_ba {
       p.Hdd_accAF = 0; p.bd_accAF = 0;
     }
   }
-  void addPointSC(Point& p, bool shiftPriorToZero) {  // AccumulatedSCHessian.cpp:34-103
+  void addPointSC(Point& p, bool shiftPriorToZero, AccSet& A) {  // AccumulatedSCHessian.cpp:34-103
     int ngoodres = 0;
     for (int ri = p.rbeg; ri < p.rend; ri++) if (res[ri].isActive) ngoodres++;
     if (ngoodres == 0) { p.HdiF = 0; p.bdSumF = 0; p.idepth_hessian = 0; return; }
@@ -596,8 +692,8 @@ struct orc_ba {
     if (shiftPriorToZero) p.bdSumF += p.priorF * p.deltaF;
     float Hcd[4];
     for (int i = 0; i < 4; i++) Hcd[i] = p.Hcd_accAF[i] + p.Hcd_accLF[i];
-    accHcc.update(Hcd, Hcd, p.HdiF);
-    accbc.update(Hcd, p.bdSumF * p.HdiF);
+    A.Hcc.update(Hcd, Hcd, p.HdiF);
+    A.bc.update(Hcd, p.bdSumF * p.HdiF);
     int nFrames2 = nf * nf;
     for (int r1i = p.rbeg; r1i < p.rend; r1i++) {
       Residual& r1 = res[r1i];
@@ -606,27 +702,42 @@ struct orc_ba {
       for (int r2i = p.rbeg; r2i < p.rend; r2i++) {
         Residual& r2 = res[r2i];
         if (!r2.isActive) continue;
-        accD[r1ht + r2.target * nFrames2].update(r1.JpJdF, r2.JpJdF, p.HdiF);
+        A.D[r1ht + r2.target * nFrames2].update(r1.JpJdF, r2.JpJdF, p.HdiF);
       }
-      accE[r1ht].update(r1.JpJdF, Hcd, p.HdiF);
-      accEB[r1ht].update(r1.JpJdF, p.HdiF * p.bdSumF);
+      A.E[r1ht].update(r1.JpJdF, Hcd, p.HdiF);
+      A.EB[r1ht].update(r1.JpJdF, p.HdiF * p.bdSumF);
     }
   }
   void zeroTop(std::vector<AccumulatorApprox>& a) { a.resize((size_t)nf * nf); for (auto& x : a) x.initialize(); }
-  void zeroSC() {
-    accD.resize((size_t)nf * nf * nf); accE.resize((size_t)nf * nf); accEB.resize((size_t)nf * nf);
-    for (auto& x : accD) x.initialize();
-    for (auto& x : accE) x.initialize();
-    for (auto& x : accEB) x.initialize();
-    accHcc.initialize(); accbc.initialize();
+  void zeroSC(AccSet& A) {
+    A.D.resize((size_t)nf * nf * nf); A.E.resize((size_t)nf * nf); A.EB.resize((size_t)nf * nf);
+    for (auto& x : A.D) x.initialize();
+    for (auto& x : A.E) x.initialize();
+    for (auto& x : A.EB) x.initialize();
+    A.Hcc.initialize(); A.bc.initialize();
   }
-  void accumulateAll() {  // the addPoint loops of EnergyFunctional.cpp:212-269 (single accumulator copy, tid 0)
-    zeroTop(accTopA); nresA = 0;
-    for (Point& p : points) addPointTop<0>(p, accTopA, nresA);
-    zeroTop(accTopL); nresL = 0;
-    for (Point& p : points) addPointTop<1>(p, accTopL, nresL);
-    zeroSC();
-    for (Point& p : points) addPointSC(p, true);
+  void zeroAll() { for (AccSet& A : T) { zeroTop(A.topA); zeroTop(A.topL); zeroSC(A); A.nresA = A.nresL = 0; } }
+  void accumulateAll() {  // EnergyFunctional.cpp:212-269
+    if (red) {
+      // setZero on every worker (reduce over an empty range), then addPointsInternal in chunks of 50 points with acc[tid]
+      red->reduce([&](int, int, double*, int tid) { zeroTop(T[tid].topA); T[tid].nresA = 0; }, 0, 0, 0);
+      red->reduce([&](int lo, int hi, double*, int tid) { for (int i = lo; i < hi; i++) addPointTop<0>(points[i], T[tid].topA, T[tid].nresA); }, 0, np, 50);
+      red->reduce([&](int, int, double*, int tid) { zeroTop(T[tid].topL); T[tid].nresL = 0; }, 0, 0, 0);
+      red->reduce([&](int lo, int hi, double*, int tid) { for (int i = lo; i < hi; i++) addPointTop<1>(points[i], T[tid].topL, T[tid].nresL); }, 0, np, 50);
+      red->reduce([&](int, int, double*, int tid) { zeroSC(T[tid]); }, 0, 0, 0);
+      red->reduce([&](int lo, int hi, double*, int tid) { for (int i = lo; i < hi; i++) addPointSC(points[i], true, T[tid]); }, 0, np, 50);
+      nresA = nresL = 0;
+      for (AccSet& A : T) { nresA += A.nresA; nresL += A.nresL; }
+      return;
+    }
+    // single accumulator copy, tid 0
+    AccSet& A = T[0];
+    zeroTop(A.topA); nresA = 0;
+    for (Point& p : points) addPointTop<0>(p, A.topA, nresA);
+    zeroTop(A.topL); nresL = 0;
+    for (Point& p : points) addPointTop<1>(p, A.topL, nresL);
+    zeroSC(A);
+    for (Point& p : points) addPointSC(p, true, A);
   }
 
   // ---------------------------------------------------------------- stitch
@@ -638,18 +749,19 @@ struct orc_ba {
         C[i * 8 + j] = s;
       }
   }
-  // AccumulatedTopHessian.cpp:265-337 + the symmetrisation of AccumulatedTopHessian.h:133-147
-  void stitchTop(std::vector<AccumulatorApprox>& acc, MatX& H, VecX& b, bool usePrior) {
-    int n = nf * 8 + 4;
-    H = MatX(n, n); b.assign(n, 0.0);
-    for (int k = 0; k < nf * nf; k++) {
+  // AccumulatedTopHessian.cpp:265-337 (stitchDoubleInternal for pairs [kmin, kmax)) — the copies of all threads are summed in double (:299-308)
+  void stitchTopBlocks(bool linearized, MatX& H, VecX& b, int kmin, int kmax) {
+    for (int k = kmin; k < kmax; k++) {
       int h = k % nf, t = k / nf;
       int hIdx = 4 + h * 8, tIdx = 4 + t * 8, aidx = h + nf * t;
       double accH[13][13];
       for (int i = 0; i < 13; i++) for (int j = 0; j < 13; j++) accH[i][j] = 0;
-      acc[aidx].finish();
-      if (acc[aidx].num != 0)
-        for (int i = 0; i < 13; i++) for (int j = 0; j < 13; j++) accH[i][j] += acc[aidx].h(i, j);
+      for (AccSet& A : T) {
+        AccumulatorApprox& acc = linearized ? A.topL[aidx] : A.topA[aidx];
+        acc.finish();
+        if (acc.num == 0) continue;
+        for (int i = 0; i < 13; i++) for (int j = 0; j < 13; j++) accH[i][j] += acc.h(i, j);
+      }
       const double* AH = &adHost[(size_t)aidx * 64];
       const double* AT = &adTarget[(size_t)aidx * 64];
       double A88[64], tmp[64], out[64];
@@ -676,6 +788,23 @@ struct orc_ba {
       }
       for (int i = 0; i < 4; i++) b[i] += accH[i][12];
     }
+  }
+  // stitchDoubleMT (AccumulatedTopHessian.h:95-148): pairs split over the workers into private H/b copies that are then added, or
+  // one pass on the calling thread; priors (:324-336) and the symmetrisation (:133-147) afterwards
+  void stitchTop(bool linearized, MatX& H, VecX& b, bool usePrior) {
+    int n = nf * 8 + 4;
+    H = MatX(n, n); b.assign(n, 0.0);
+    if (red) {
+      std::vector<MatX> Hs(red->nthreads, MatX(n, n));
+      std::vector<VecX> bs(red->nthreads, VecX(n, 0.0));
+      red->reduce([&](int lo, int hi, double*, int tid) { stitchTopBlocks(linearized, Hs[tid], bs[tid], lo, hi); }, 0, nf * nf, 0);
+      for (int t = 0; t < red->nthreads; t++) {
+        for (size_t i = 0; i < H.d.size(); i++) H.d[i] += Hs[t].d[i];
+        for (int i = 0; i < n; i++) b[i] += bs[t][i];
+      }
+    } else {
+      stitchTopBlocks(linearized, H, b, 0, nf * nf);
+    }
     if (usePrior) {
       for (int i = 0; i < 4; i++) { H(i, i) += cPrior[i]; b[i] += cPrior[i] * (double)cDeltaF[i]; }
       for (int h = 0; h < nf; h++)
@@ -694,36 +823,45 @@ struct orc_ba {
       }
     }
   }
-  // AccumulatedSCHessian.cpp:106-195 + AccumulatedSCHessian.h:129-134
-  void stitchSC(MatX& H, VecX& b) {
-    int n = nf * 8 + 4;
-    H = MatX(n, n); b.assign(n, 0.0);
+  // AccumulatedSCHessian.cpp:106-195 (stitchDoubleInternal for pairs [kmin, kmax)); thread copies summed in double (:136-141, :158-164)
+  void stitchSCBlocks(MatX& H, VecX& b, int kmin, int kmax) {
     int nframes2 = nf * nf;
-    for (int k0 = 0; k0 < nf * nf; k0++) {
+    for (int k0 = kmin; k0 < kmax; k0++) {
       int i = k0 % nf, j = k0 / nf;
       int iIdx = 4 + i * 8, jIdx = 4 + j * 8, ijIdx = i + nf * j;
-      accE[ijIdx].finish(); accEB[ijIdx].finish();
+      double Hpc[8][4], bp[8];
+      for (int a = 0; a < 8; a++) { bp[a] = 0; for (int c = 0; c < 4; c++) Hpc[a][c] = 0; }
+      for (AccSet& A : T) {
+        A.E[ijIdx].finish(); A.EB[ijIdx].finish();
+        for (int a = 0; a < 8; a++) { bp[a] += A.EB[ijIdx].a(a); for (int c = 0; c < 4; c++) Hpc[a][c] += A.E[ijIdx].a(a, c); }
+      }
       const double* AHij = &adHost[(size_t)ijIdx * 64];
       const double* ATij = &adTarget[(size_t)ijIdx * 64];
       for (int a = 0; a < 8; a++)
         for (int c = 0; c < 4; c++) {
           double sh = 0, st = 0;
-          for (int kk = 0; kk < 8; kk++) { sh += AHij[a * 8 + kk] * accE[ijIdx].a(kk, c); st += ATij[a * 8 + kk] * accE[ijIdx].a(kk, c); }
+          for (int kk = 0; kk < 8; kk++) { sh += AHij[a * 8 + kk] * Hpc[kk][c]; st += ATij[a * 8 + kk] * Hpc[kk][c]; }
           H(iIdx + a, c) += sh;
           H(jIdx + a, c) += st;
         }
       for (int a = 0; a < 8; a++) {
         double sh = 0, st = 0;
-        for (int kk = 0; kk < 8; kk++) { sh += AHij[a * 8 + kk] * accEB[ijIdx].a(kk); st += ATij[a * 8 + kk] * accEB[ijIdx].a(kk); }
+        for (int kk = 0; kk < 8; kk++) { sh += AHij[a * 8 + kk] * bp[kk]; st += ATij[a * 8 + kk] * bp[kk]; }
         b[iIdx + a] += sh;
         b[jIdx + a] += st;
       }
       for (int k = 0; k < nf; k++) {
         int kIdx = 4 + k * 8, ijkIdx = ijIdx + k * nframes2, ikIdx = i + nf * k;
-        accD[ijkIdx].finish();
-        if (accD[ijkIdx].num == 0) continue;
         double D[64], tmp[64], out[64];
-        for (int a = 0; a < 8; a++) for (int c = 0; c < 8; c++) D[a * 8 + c] = accD[ijkIdx].a(a, c);
+        for (int a = 0; a < 64; a++) D[a] = 0;
+        bool any = false;
+        for (AccSet& A : T) {
+          A.D[ijkIdx].finish();
+          if (A.D[ijkIdx].num == 0) continue;
+          any = true;
+          for (int a = 0; a < 8; a++) for (int c = 0; c < 8; c++) D[a * 8 + c] += A.D[ijkIdx].a(a, c);
+        }
+        if (!any) continue;   // (the reference multiplies the zero block through: same result)
         const double* AHik = &adHost[(size_t)ikIdx * 64];
         const double* ATik = &adTarget[(size_t)ikIdx * 64];
         mul88(AHij, D, tmp, false); mul88(tmp, AHik, out, true);
@@ -736,8 +874,28 @@ struct orc_ba {
         for (int a = 0; a < 8; a++) for (int c = 0; c < 8; c++) H(iIdx + a, kIdx + c) += out[a * 8 + c];
       }
     }
-    accHcc.finish(); accbc.finish();
-    for (int a = 0; a < 4; a++) { for (int c = 0; c < 4; c++) H(a, c) += accHcc.a(a, c); b[a] += accbc.a(a); }
+    if (kmin == 0 && kmax > 0) {
+      for (AccSet& A : T) {
+        A.Hcc.finish(); A.bc.finish();
+        for (int a = 0; a < 4; a++) { for (int c = 0; c < 4; c++) H(a, c) += A.Hcc.a(a, c); b[a] += A.bc.a(a); }
+      }
+    }
+  }
+  // stitchDoubleMT (AccumulatedSCHessian.h:96-135)
+  void stitchSC(MatX& H, VecX& b) {
+    int n = nf * 8 + 4;
+    H = MatX(n, n); b.assign(n, 0.0);
+    if (red) {
+      std::vector<MatX> Hs(red->nthreads, MatX(n, n));
+      std::vector<VecX> bs(red->nthreads, VecX(n, 0.0));
+      red->reduce([&](int lo, int hi, double*, int tid) { stitchSCBlocks(Hs[tid], bs[tid], lo, hi); }, 0, nf * nf, 0);
+      for (int t = 0; t < red->nthreads; t++) {
+        for (size_t i = 0; i < H.d.size(); i++) H.d[i] += Hs[t].d[i];
+        for (int i = 0; i < n; i++) b[i] += bs[t][i];
+      }
+    } else {
+      stitchSCBlocks(H, b, 0, nf * nf);
+    }
     for (int h = 0; h < nf; h++) {
       int hIdx = 4 + h * 8;
       for (int a = 0; a < 8; a++) for (int c = 0; c < 4; c++) H(c, hIdx + a) = H(hIdx + a, c);
@@ -818,7 +976,8 @@ struct orc_ba {
         }
     }
     const float* xc = xF.data();
-    for (Point& p : points) {
+    auto perPoint = [&](int lo, int hi, double*, int) { for (int pi = lo; pi < hi; pi++) {
+      Point& p = points[pi];
       int ngoodres = 0;
       for (int ri = p.rbeg; ri < p.rend; ri++) if (res[ri].isActive) ngoodres++;
       if (ngoodres == 0) { p.step = 0; continue; }
@@ -835,7 +994,9 @@ struct orc_ba {
         b -= s;
       }
       p.step = -b * p.HdiF;
-    }
+    } };
+    if (red) red->reduce(perPoint, 0, np, 50);   // resubstituteF_MT (:294-295)
+    else perPoint(0, np, nullptr, 0);
   }
   // EnergyFunctional.cpp:838-995
   void solveSystemF(int iteration, double lambda) {
@@ -845,8 +1006,8 @@ struct orc_ba {
     accumulateAll();
     MatX HL_top, HA_top, H_sc;
     VecX bL_top, bA_top, b_sc;
-    stitchTop(accTopA, HA_top, bA_top, false);
-    stitchTop(accTopL, HL_top, bL_top, true);
+    stitchTop(false, HA_top, bA_top, false);
+    stitchTop(true, HL_top, bL_top, true);
     stitchSC(H_sc, b_sc);
     VecX delta = getStitchedDeltaF();
     VecX bM_top(n);
@@ -1007,7 +1168,10 @@ struct orc_ba {
   }
   double calcLEnergy() { return forceAcceptStep ? 0 : calcLEnergyF(); }
   double calcMEnergy() { return forceAcceptStep ? 0 : calcMEnergyF(); }
-  void applyAll() { for (Residual& r : res) if (!r.isLinearized) applyRes(r); }
+  void applyAll() {   // applyRes_Reductor (FullSystemOptimize.cpp:90-96), chunks of 50
+    auto f = [&](int lo, int hi, double*, int) { for (int k = lo; k < hi; k++) if (!res[k].isLinearized) applyRes(res[k]); };
+    if (red) red->reduce(f, 0, nr, 50); else f(0, nr, nullptr, 0);
+  }
 
   float optimize(int mnumOptIts, orc_ba_opt_result_t* out) {  // :871-1041
     out->iterations = 0; out->lastEnergy = 0; out->rmse = 0; out->resInA = 0;
@@ -1071,19 +1235,19 @@ struct orc_ba {
         if (r.isActive) fixLinearizationF(r);
       }
     }
-    zeroSC(); zeroTop(accTopA); nresA = 0;
+    zeroAll(); nresA = 0;
     for (int pi = 0; pi < np; pi++) {
       if (!marg_flag[pi]) continue;
       Point& p = points[pi];
       p.priorF *= setting_idepthFixPriorMargFac;
-      addPointTop<2>(p, accTopA, nresA);
-      addPointSC(p, false);
+      addPointTop<2>(p, T[0].topA, nresA);
+      addPointSC(p, false, T[0]);
     }
     // stitchDouble (single-thread variants, AccumulatedTopHessian.cpp:201-262 / AccumulatedSCHessian.cpp:198-256):
     // identical block arithmetic to stitchTop/stitchSC above with usePrior=false; the SC variant
     // assigns (not adds) Hcc/bc, which is the same on a zeroed matrix.
     MatX M, Msc; VecX Mb, Mbsc;
-    stitchTop(accTopA, M, Mb, false);
+    stitchTop(false, M, Mb, false);
     stitchSC(Msc, Mbsc);
     resInM += nresA;
     int n = 4 + nf * 8;
@@ -1161,11 +1325,21 @@ extern "C" orc_ba* orc_ba_create(const orc_ba_window_t* W) {
   h->setAdjointsF();
   h->setPrecalcValues();
   h->nresA = h->nresL = h->resInM = 0;
-  h->zeroTop(h->accTopA); h->zeroTop(h->accTopL); h->zeroSC();
+  h->zeroAll();
   h->getNullspaces();
   return h;
 }
 extern "C" void orc_ba_destroy(orc_ba* h) { delete h; }
+// CPU-baseline threading (IndexThreadReduce model): n <= 1 restores the single-thread path.  The packed-accumulator getters read
+// thread 0's copy only, so they are meaningful on the single-thread path (the one the parity tests use).
+extern "C" int orc_ba_set_threads(orc_ba* h, int n) {
+  delete h->red;
+  h->red = nullptr;
+  h->T.assign(n > 1 ? n : 1, AccSet());
+  h->zeroAll();
+  if (n > 1) h->red = new Reducer(n);
+  return 0;
+}
 extern "C" int orc_ba_linearize(orc_ba* h, double* energy) { double e = h->linearizeAll(false); if (energy) *energy = e; return 0; }
 extern "C" int orc_ba_get_linearization(orc_ba* h, float* J, uint8_t* newState, float* newEnergy, float* newEnergyWithOutlier,
                                         float* projectedTo, float* centerProjectedTo) {
@@ -1207,14 +1381,14 @@ static void packTop(AccumulatorApprox& a, float* out) {
 extern "C" int orc_ba_get_accumulators(orc_ba* h, float* packed) {
   int nf = h->nf;
   float* p = packed;
-  for (int i = 0; i < nf * nf; i++, p += 91) packTop(h->accTopA[i], p);
-  for (int i = 0; i < nf * nf; i++, p += 91) packTop(h->accTopL[i], p);
-  for (int i = 0; i < nf * nf * nf; i++) { h->accD[i].finish(); for (int a = 0; a < 8; a++) for (int c = 0; c < 8; c++) *p++ = h->accD[i].A1m[a][c]; }
-  for (int i = 0; i < nf * nf; i++) { h->accE[i].finish(); for (int a = 0; a < 8; a++) for (int c = 0; c < 4; c++) *p++ = h->accE[i].A1m[a][c]; }
-  for (int i = 0; i < nf * nf; i++) { h->accEB[i].finish(); for (int a = 0; a < 8; a++) *p++ = h->accEB[i].A1m[a]; }
-  h->accHcc.finish(); h->accbc.finish();
-  for (int a = 0; a < 4; a++) for (int c = 0; c < 4; c++) *p++ = h->accHcc.A1m[a][c];
-  for (int a = 0; a < 4; a++) *p++ = h->accbc.A1m[a];
+  for (int i = 0; i < nf * nf; i++, p += 91) packTop(h->T[0].topA[i], p);
+  for (int i = 0; i < nf * nf; i++, p += 91) packTop(h->T[0].topL[i], p);
+  for (int i = 0; i < nf * nf * nf; i++) { h->T[0].D[i].finish(); for (int a = 0; a < 8; a++) for (int c = 0; c < 8; c++) *p++ = h->T[0].D[i].A1m[a][c]; }
+  for (int i = 0; i < nf * nf; i++) { h->T[0].E[i].finish(); for (int a = 0; a < 8; a++) for (int c = 0; c < 4; c++) *p++ = h->T[0].E[i].A1m[a][c]; }
+  for (int i = 0; i < nf * nf; i++) { h->T[0].EB[i].finish(); for (int a = 0; a < 8; a++) *p++ = h->T[0].EB[i].A1m[a]; }
+  h->T[0].Hcc.finish(); h->T[0].bc.finish();
+  for (int a = 0; a < 4; a++) for (int c = 0; c < 4; c++) *p++ = h->T[0].Hcc.A1m[a][c];
+  for (int a = 0; a < 4; a++) *p++ = h->T[0].bc.A1m[a];
   *p++ = (float)h->nresA; *p++ = (float)h->nresL;
   return 0;
 }
@@ -1225,18 +1399,18 @@ extern "C" int orc_ba_get_accumulators_f64(orc_ba* h, double* packed) {
   double* p = packed;
   for (int which = 0; which < 2; which++)
     for (int i = 0; i < nf * nf; i++) {
-      AccumulatorApprox& a = which ? h->accTopL[i] : h->accTopA[i];
+      AccumulatorApprox& a = which ? h->T[0].topL[i] : h->T[0].topA[i];
       a.finish();
       for (int r = 0; r < 10; r++) for (int c = r; c < 10; c++) *p++ = a.h(r, c);
       for (int r = 0; r < 10; r++) for (int c = 0; c < 3; c++) *p++ = a.h(r, 10 + c);
       *p++ = a.h(10, 10); *p++ = a.h(10, 11); *p++ = a.h(10, 12); *p++ = a.h(11, 11); *p++ = a.h(11, 12); *p++ = a.h(12, 12);
     }
-  for (int i = 0; i < nf * nf * nf; i++) { h->accD[i].finish(); for (int a = 0; a < 8; a++) for (int c = 0; c < 8; c++) *p++ = h->accD[i].a(a, c); }
-  for (int i = 0; i < nf * nf; i++) { h->accE[i].finish(); for (int a = 0; a < 8; a++) for (int c = 0; c < 4; c++) *p++ = h->accE[i].a(a, c); }
-  for (int i = 0; i < nf * nf; i++) { h->accEB[i].finish(); for (int a = 0; a < 8; a++) *p++ = h->accEB[i].a(a); }
-  h->accHcc.finish(); h->accbc.finish();
-  for (int a = 0; a < 4; a++) for (int c = 0; c < 4; c++) *p++ = h->accHcc.a(a, c);
-  for (int a = 0; a < 4; a++) *p++ = h->accbc.a(a);
+  for (int i = 0; i < nf * nf * nf; i++) { h->T[0].D[i].finish(); for (int a = 0; a < 8; a++) for (int c = 0; c < 8; c++) *p++ = h->T[0].D[i].a(a, c); }
+  for (int i = 0; i < nf * nf; i++) { h->T[0].E[i].finish(); for (int a = 0; a < 8; a++) for (int c = 0; c < 4; c++) *p++ = h->T[0].E[i].a(a, c); }
+  for (int i = 0; i < nf * nf; i++) { h->T[0].EB[i].finish(); for (int a = 0; a < 8; a++) *p++ = h->T[0].EB[i].a(a); }
+  h->T[0].Hcc.finish(); h->T[0].bc.finish();
+  for (int a = 0; a < 4; a++) for (int c = 0; c < 4; c++) *p++ = h->T[0].Hcc.a(a, c);
+  for (int a = 0; a < 4; a++) *p++ = h->T[0].bc.a(a);
   *p++ = (double)h->nresA; *p++ = (double)h->nresL;
   return 0;
 }

@@ -56,6 +56,7 @@ def load(fast=False):
     L.orc_ba_create.restype = vp
     L.orc_ba_destroy.argtypes = [vp]
     L.orc_ba_destroy.restype = None
+    L.orc_ba_set_threads.argtypes = [vp, C.c_int]
     L.orc_ba_linearize.argtypes = [vp, c_double_p]
     L.orc_ba_get_linearization.argtypes = [vp, c_float_p, c_u8_p, c_float_p, c_float_p, c_float_p, c_float_p]
     L.orc_ba_apply_res.argtypes = [vp]

@@ -321,7 +321,7 @@ def ba_window(w=1232, h=368, nf=8, pts_per_kf=250, seed=3001, scene_seed=1001, s
     fx, fy, cx, cy = [np.float64(x) for x in K]
     Kmat = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1]])
     Ki = np.linalg.inv(Kmat)
-    us, vs, ids, hosts, colors, weights = [], [], [], [], [], []
+    us, vs, ids, hosts, colors, weights, ids_true = [], [], [], [], [], [], []
     res_point, res_target = [], []
     c2 = np.float32(50 * 50)
     for k in range(nf):
@@ -339,7 +339,7 @@ def ba_window(w=1232, h=368, nf=8, pts_per_kf=250, seed=3001, scene_seed=1001, s
             gx = np.array([dI[v[i] + PATTERN[j, 1], u[i] + PATTERN[j, 0], 1] for j in range(8)], np.float32)
             gy = np.array([dI[v[i] + PATTERN[j, 1], u[i] + PATTERN[j, 0], 2] for j in range(8)], np.float32)
             wgt = np.sqrt(c2 / (c2 + (gx * gx + gy * gy))).astype(np.float32)
-            us.append(np.float32(u[i])); vs.append(np.float32(v[i])); ids.append(idp[i]); hosts.append(k)
+            us.append(np.float32(u[i])); vs.append(np.float32(v[i])); ids.append(idp[i]); hosts.append(k); ids_true.append(idp_true[i])
             colors.append(col); weights.append(wgt)
             # residuals to the other keyframes where the pattern stays inside
             P_h = Ki @ np.array([u[i], v[i], 1.0]) / idp_true[i]
@@ -366,7 +366,7 @@ def ba_window(w=1232, h=368, nf=8, pts_per_kf=250, seed=3001, scene_seed=1001, s
         ab_exposure=np.ones(nf, np.float32), frameEnergyTH=np.full(nf, 8 * 8 * 8, np.float32),
         frameID=np.arange(nf, dtype=np.int32),
         u=np.array(us, np.float32), v=np.array(vs, np.float32), idepth=np.array(ids, np.float32),
-        idepth_zero=np.array(ids, np.float32), color=np.array(colors, np.float32).reshape(np_, 8),
+        idepth_true=np.array(ids_true, np.float64), idepth_zero=np.array(ids, np.float32), color=np.array(colors, np.float32).reshape(np_, 8),
         weights=np.array(weights, np.float32).reshape(np_, 8), host=np.array(hosts, np.int32),
         hasDepthPrior=np.zeros(np_, np.uint8),
         res_point=np.array(res_point, np.int32), res_target=np.array(res_target, np.int32),
