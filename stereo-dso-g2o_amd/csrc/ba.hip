@@ -87,7 +87,7 @@ struct BaBatch {
   float* d_accum = nullptr;
   BaLaunch L;
   bool materialize = true;
-  bool direct_taps = false;      // A/B: one residual's 32 taps on one lane (SDSO_BA_DIRECT_TAPS at batch_create)
+  int gather = 1;                // tap gather of the fused kernel: 1 cooperative quads (default), 2 LDS-DMA rounds, 0 direct (SDSO_BA_GATHER / SDSO_BA_DIRECT_TAPS at batch_create)
 };
 static std::map<sdso_ctx*, BaBatch*> g_batches;
 // Dissolve the ctx's batch: every member window gets its own accumulator block back (host descriptor and its device copy),
@@ -443,14 +443,17 @@ static void launch_sc_and_folds(sdso_ctx* ctx, const BaLaunch& L, const uint8_t*
   else hipLaunchKernelGGL(k_ba_fold_sc, dim3(nf * nf * nf + nf * nf + 1, L.nwin), dim3(64), 0, ctx->stream, L.d_arr);
 }
 // linearizeAll + applyRes + accumulateAF in one kernel, then the (normally empty) linearized pass and the Schur part
-static void launch_fused(sdso_ctx* ctx, const BaLaunch& L, bool materialize, bool direct, int part = 3 /* bit 0: linearize+top, bit 1: Schur+folds */) {
+static void launch_fused(sdso_ctx* ctx, const BaLaunch& L, bool materialize, int gather, int part = 3 /* bit 0: linearize+top, bit 1: Schur+folds */) {
   const int nf = L.nf;
   if ((part & 1) && L.max_chunks > 0) {
     {
       ProfScope ps(ctx, "k_ba_lin_fused");
       const dim3 g(L.max_chunks, L.nwin), b(BA_BLOCK);
-#define LF(M, T) do { if (direct) hipLaunchKernelGGL((k_ba_lin_fused<M, T, false>), g, b, 0, ctx->stream, L.d_arr); else hipLaunchKernelGGL((k_ba_lin_fused<M, T, true>), g, b, 0, ctx->stream, L.d_arr); } while (0)
-      if (materialize) { if (L.tiled) LF(true, true); else LF(true, false); }
+      // gather: 0 one residual's 32 taps on one lane, 1 cooperative quad gather, 2 LDS-DMA rounds (tiled images)
+      const int gm = (gather == 2 && !L.tiled) ? 1 : gather;
+#define LF(M, T) do { if (gm == 0) hipLaunchKernelGGL((k_ba_lin_fused<M, T, 0>), g, b, 0, ctx->stream, L.d_arr); else hipLaunchKernelGGL((k_ba_lin_fused<M, T, 1>), g, b, 0, ctx->stream, L.d_arr); } while (0)
+      if (gm == 2) { if (materialize) hipLaunchKernelGGL((k_ba_lin_dma<true>), g, b, 0, ctx->stream, L.d_arr); else hipLaunchKernelGGL((k_ba_lin_dma<false>), g, b, 0, ctx->stream, L.d_arr); }
+      else if (materialize) { if (L.tiled) LF(true, true); else LF(true, false); }
       else { if (L.tiled) LF(false, true); else LF(false, false); }
 #undef LF
     }
@@ -1041,7 +1044,8 @@ extern "C" int sdso_ba_batch_create(sdso_ctx* ctx, int nwin, const int* wins) {
   BaBatch* Bt = new BaBatch();
   Bt->d_arr = d_arr; Bt->d_accum = d_accum; Bt->W = Ws;
   Bt->wins.assign(wins, wins + nwin);
-  Bt->direct_taps = getenv("SDSO_BA_DIRECT_TAPS") != nullptr;
+  if (const char* e = getenv("SDSO_BA_GATHER")) Bt->gather = std::max(0, std::min(2, atoi(e)));
+  if (getenv("SDSO_BA_DIRECT_TAPS")) Bt->gather = 0;
   reg_get(g_batches, ctx) = Bt;
   hipMemsetAsync(Bt->d_accum, 0, sizeof(float) * af * nwin, ctx->stream);
   std::vector<BaDev> h(nwin);
@@ -1077,7 +1081,7 @@ static const BaLaunch& batch_launch(BaBatch* Bt) {
 extern "C" int sdso_ba_batch_accumulate(sdso_ctx* ctx) {
   BaBatch* Bt = get_batch(ctx);
   if (!Bt) return sdso::fail(ctx, SDSO_ERR_STATE, "no batch");
-  launch_fused(ctx, batch_launch(Bt), Bt->materialize, Bt->direct_taps);
+  launch_fused(ctx, batch_launch(Bt), Bt->materialize, Bt->gather);
   SDSO_HIP(ctx, hipGetLastError());
   return SDSO_OK;
 }
@@ -1087,14 +1091,14 @@ extern "C" int sdso_ba_batch_accumulate(sdso_ctx* ctx) {
 extern "C" int sdso_ba_batch_linearize(sdso_ctx* ctx) {
   BaBatch* Bt = get_batch(ctx);
   if (!Bt) return sdso::fail(ctx, SDSO_ERR_STATE, "no batch");
-  launch_fused(ctx, batch_launch(Bt), Bt->materialize, Bt->direct_taps, 1);
+  launch_fused(ctx, batch_launch(Bt), Bt->materialize, Bt->gather, 1);
   SDSO_HIP(ctx, hipGetLastError());
   return SDSO_OK;
 }
 extern "C" int sdso_ba_batch_schur(sdso_ctx* ctx) {
   BaBatch* Bt = get_batch(ctx);
   if (!Bt) return sdso::fail(ctx, SDSO_ERR_STATE, "no batch");
-  launch_fused(ctx, batch_launch(Bt), Bt->materialize, Bt->direct_taps, 2);
+  launch_fused(ctx, batch_launch(Bt), Bt->materialize, Bt->gather, 2);
   SDSO_HIP(ctx, hipGetLastError());
   return SDSO_OK;
 }

@@ -14,14 +14,22 @@ namespace sdso {
 
 __constant__ int c_pattern[8][2] = {{0, -2}, {-1, -1}, {1, -1}, {-2, 0}, {0, 0}, {2, 0}, {-1, 1}, {0, 2}};
 
+// Workgroup barrier for exchanges that go through LDS only: waits for this wave's LDS traffic, not for its outstanding global
+// stores (`__syncthreads()` drains vmcnt too — microseconds per barrier while a wave still has Jacobian records in flight).
+template <bool LDS_ONLY>
+__device__ __forceinline__ void wg_barrier() {
+  if (LDS_ONLY) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  else __syncthreads();
+}
+template <bool LDS_ONLY = false>
 __device__ __forceinline__ double block_sum_d(double v, double* lds) {
   v = wave_sum(v);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   if (lane == 0) lds[wv] = v;
-  __syncthreads();
+  wg_barrier<LDS_ONLY>();
   double s = 0;
   for (int w = 0; w < (int)(blockDim.x >> 6); w++) s += lds[w];
-  __syncthreads();
+  wg_barrier<LDS_ONLY>();
   return s;
 }
 
@@ -348,8 +356,6 @@ __device__ __forceinline__ double linearize_coop(const BaDev& B, int i, bool liv
   const float Ku0 = u * fxl + cxl;
   const float Kv0 = v * fyl + cyl;
   if (!(Ku0 > 1.1f && Kv0 > 1.1f && Ku0 < B.wM3 && Kv0 < B.hM3)) { B.r_newState[i] = 1; ret = (double)B.r_energy[i]; dead = true; break; }
-  if (B.r_proj) { float* pj = B.r_proj + (size_t)i * 19; pj[16] = Ku0; pj[17] = Kv0; pj[18] = new_idepth; }
-
   g_u = u; g_v = v; g_dr = drescale; g_nid = new_idepth; g_k0 = KliP[0]; g_k1 = KliP[1];   // the geometric Jacobians are built after the taps (fewer live registers during the gathers)
 
   const float4 c0 = *(const float4*)(B.p_color + (size_t)pt * 8), c1 = *(const float4*)(B.p_color + (size_t)pt * 8 + 4);
@@ -377,8 +383,6 @@ __device__ __forceinline__ double linearize_coop(const BaDev& B, int i, bool liv
   const float* hstage = wstage + CG_COORD_FLOATS + (threadIdx.x & 63);
 #pragma unroll
   for (int idx = 0; idx < 8; idx++) {
-    const float Ku = Kus[idx], Kv = Kvs[idx];
-    if (B.r_proj) { B.r_proj[(size_t)i * 19 + idx * 2] = Ku; B.r_proj[(size_t)i * 19 + idx * 2 + 1] = Kv; }
     float3 hit = make_float3(hstage[(idx * 3 + 0) * CG_ROW], hstage[(idx * 3 + 1) * CG_ROW], hstage[(idx * 3 + 2) * CG_ROW]);
     if (!isfinite(hit.x)) oob = true;
     const float residual = hit.x - (affLL0 * color[idx] + affLL1);
@@ -459,6 +463,42 @@ __device__ __forceinline__ double linearize_coop(const BaDev& B, int i, bool liv
   B.r_newState[i] = (uint8_t)ns_out;
   B.r_newEnergy[i] = energyLeft;
   return (double)energyLeft;
+}
+// ------------------------------------------------------------------ linearize with the taps brought in by LDS-DMA
+// Third gather scheme (GATHER = 2, 4x2-tiled images): the 32 taps of a residual are fetched by `global_load_lds_dwordx4`
+// (one 16-byte pixel per lane, written by the memory pipeline straight into LDS — no destination VGPRs, nothing to wait for at
+// issue).  A ROUND is one pattern pixel of all 64 residuals of the wave: 4 instructions, lane = (residual % 16, corner) so that the
+// four corners of a bilinear sample sit on neighbouring lanes (one or two 128-byte lines per quad, as in the cooperative gather),
+// 4 KiB of LDS.  DM_DEPTH rounds are in flight per wave; while they travel the wave interpolates and does the per-pixel arithmetic
+// of the round that has landed ON THE RESIDUAL'S OWN LANE (four ds_read_b128 of its 64 contiguous bytes, then exactly
+// interp33's expression) and stores that pixel's Jacobian group: no coordinate / sample stage, no quad shuffles, and a third
+// fewer vector instructions than the cooperative scheme (which spends 32 x ~40 instructions per wave on redundant weights).
+// The compiler cannot track the LDS dependency of the DMA finer than `s_waitcnt vmcnt(0)`, so the ring is read with inline
+// assembly behind a counted wait: vector-memory operations complete in issue order, hence `vmcnt(4 x rounds issued later)` is a
+// sufficient wait for round p whatever stores were issued in between (they only make the wait earlier than necessary).
+constexpr int DM_DEPTH = 3;
+constexpr int DM_ROUND_FLOATS = 4 * 64 * 4;
+constexpr int DM_WAVE_FLOATS = DM_DEPTH * DM_ROUND_FLOATS;     // 12 KiB per wave
+template <int N>
+__device__ __forceinline__ void dm_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// one round: xy = (int)Ku | (int)Kv << 16 of THIS lane's residual for the round's pattern pixel (0 for a dead lane: pixel (0,0))
+__device__ __forceinline__ void dm_issue_round(const float4* __restrict__ img, int Tw, int xy, float* slot) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int v = __shfl(xy, 16 * q + (lane >> 2), 64);
+    const int x = (v & 0xffff) + (lane & 1), y = (v >> 16) + ((lane >> 1) & 1);
+    const float4* a = img + tiled_index(x, y, Tw);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)a, (__attribute__((address_space(3))) void*)(slot + q * 256), 16, 0, 0);
+  }
+}
+// the four corner pixels of this lane's sample: 64 contiguous bytes at slot + 16 * lane floats (instruction lane/16, its lanes 4*(lane%16)..+3)
+__device__ __forceinline__ void dm_read_taps(const float* slot_lane, te_f4& p00, te_f4& p10, te_f4& p01, te_f4& p11) {
+  const unsigned addr = (unsigned)(unsigned long)(const __attribute__((address_space(3))) float*)slot_lane;
+  asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:32\n\tds_read_b128 %3, %4 offset:48\n\ts_waitcnt lgkmcnt(0)"
+               : "=&v"(p00), "=&v"(p10), "=&v"(p01), "=&v"(p11)
+               : "v"(addr)
+               : "memory");
 }
 #undef SETQ
 
@@ -583,6 +623,7 @@ constexpr int TE_ROWS = 26;
 constexpr int TE_WAVE_FLOATS = TE_ROWS * TE_STRIDE;
 constexpr int TE_LDS_FLOATS = (BA_BLOCK / 64) * TE_WAVE_FLOATS;
 
+template <bool LDS_ONLY = false>
 __device__ __forceinline__ void top_emit(const BaDev& B, const float* x, const float* y, float a, float b, float c, float TR00, float TR10, float TR01,
                                          float TR11, float TR02, float TR12, const float* br, bool on, float* stage) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -603,7 +644,7 @@ __device__ __forceinline__ void top_emit(const BaDev& B, const float* x, const f
     S[22 * TE_STRIDE + lane] = ph ? TR12 : TR02;
 #pragma unroll
     for (int q = 0; q < 3; q++) S[(23 + q) * TE_STRIDE + lane] = br[3 * ph + q];
-    __syncthreads();
+    wg_barrier<LDS_ONLY>();
     const float one = (m == 10 + ph) ? 1.f : 0.f;
 #pragma unroll
     for (int s4 = 0; s4 < 16; s4++) {
@@ -612,14 +653,14 @@ __device__ __forceinline__ void top_emit(const BaDev& B, const float* x, const f
       const float bv = S[(10 + m) * TE_STRIDE + 4 * s4 + kq];
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
     }
-    __syncthreads();
+    wg_barrier<LDS_ONLY>();
   }
   // D[i][j]: i = 4*(lane/16) + v, j = lane%16
   float* R = stage;
 #pragma unroll
   for (int v = 0; v < 4; v++) R[wv * 256 + (4 * kq + v) * 16 + m] = acc[v];
   if (lane == 0) R[(BA_BLOCK / 64) * 256 + wv] = (float)__popcll(onmask);
-  __syncthreads();
+  wg_barrier<LDS_ONLY>();
   if (threadIdx.x < 92) {
     const int t = threadIdx.x;
     int off;
@@ -727,8 +768,11 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_accum_top(const BaDev* __restri
 // Linearized residuals are untouched (their accumulation is the separate mode-1 pass).
 // Workgroups per CU: four without the Jacobian stores (124 VGPRs, 40 KB of LDS each); with them the kernel needs 152 VGPRs
 // (capping it at 128 spills 22-38 of them and loses more than the fourth wave per SIMD gains), so three.
-template <bool MATERIALIZE, bool TILED, bool COOP = true>
+// GATHER: 0 = every lane fetches the 32 taps of its own residual; 1 = cooperative quad gather (linearize_coop).  The default path
+// of the library is k_ba_lin_dma below (LDS-DMA rounds, tiled images); these two stay for row-major images and for A/B runs.
+template <bool MATERIALIZE, bool TILED, int GATHER = 1>
 __global__ __launch_bounds__(BA_BLOCK, (MATERIALIZE ? 3 : 4)) void k_ba_lin_fused(const BaDev* __restrict__ wins) {
+  constexpr bool COOP = GATHER == 1;
   // by-value copy first: every pointer of the descriptor is read before the kernel's first store, so the
   // compiler can prove them global (global_load / s_load instead of flat_load) and keep them in SGPRs
   const BaDev B = wins[blockIdx.y];
@@ -736,7 +780,8 @@ __global__ __launch_bounds__(BA_BLOCK, (MATERIALIZE ? 3 : 4)) void k_ba_lin_fuse
   const int4 ch = B.chunks[blockIdx.x];
   const int pair = __builtin_amdgcn_readfirstlane(ch.x);   // one (host,target) per workgroup: precalc, image, thresholds are wave-uniform
   const int i = ch.y + threadIdx.x;
-  constexpr int RED_FLOATS = COOP ? (TE_LDS_FLOATS > (BA_BLOCK / 64) * CG_WAVE_FLOATS ? TE_LDS_FLOATS : (BA_BLOCK / 64) * CG_WAVE_FLOATS) : TE_LDS_FLOATS;
+  constexpr int STAGE_FLOATS = (BA_BLOCK / 64) * (COOP ? CG_WAVE_FLOATS : 0);
+  constexpr int RED_FLOATS = TE_LDS_FLOATS > STAGE_FLOATS ? TE_LDS_FLOATS : STAGE_FLOATS;
   __shared__ float red[RED_FLOATS];    // the gather stage of the linearisation, then the MFMA panels of the reduction
   double* const lds = (double*)red;    // (the energy reduction runs between the two uses; 40 KB in all = four workgroups per CU)
   float x[10], y[10], a = 0, b = 0, c = 0;
@@ -757,7 +802,7 @@ __global__ __launch_bounds__(BA_BLOCK, (MATERIALIZE ? 3 : 4)) void k_ba_lin_fuse
     __syncthreads();   // the reduction below reuses the stage of all waves
   }
   if (live) {
-    if (!COOP) {
+    if (GATHER == 0) {
       st = B.r_state[i];
       e = linearize_one<MATERIALIZE, 2, TILED>(B, i, pair % B.nf, pair / B.nf, jl, ns, rs5);
     }
@@ -814,6 +859,270 @@ __global__ __launch_bounds__(BA_BLOCK, (MATERIALIZE ? 3 : 4)) void k_ba_lin_fuse
   if (threadIdx.x == 0) B.e_part[blockIdx.x] = e;
   __syncthreads();
   top_emit(B, x, y, a, b, c, TR00, TR10, TR01, TR11, TR02, TR12, br, on, red);
+}
+
+// ------------------------------------------------------------------ fused linearize + applyRes + accumulateAF, taps by LDS-DMA
+// The library's default BA kernel (4x2-tiled level-0 images).  Same work per workgroup as k_ba_lin_fused — one chunk of <= 256
+// residuals of ONE (host,target) pair — organised around what the profile of its predecessor showed: a workgroup lived ~60 us for
+// ~3.5 k instructions per wave, i.e. it sat in a chain of a dozen DEPENDENT memory round trips at three waves per SIMD.
+//   * prologue: every per-residual input is fetched by two batches of independent, unconditional loads (indices / states, then the
+//     point), lanes past the end of the chunk read the chunk's first residual; the OOB / sticky-state decisions become flags;
+//   * taps: LDS-DMA rounds (see dm_issue_round above), DM_DEPTH pixel rounds in flight per wave, interpolation and the per-pixel
+//     arithmetic on the residual's own lane while the next rounds travel; `s_waitcnt vmcnt(N)` with N = exactly the younger
+//     vector-memory operations (later rounds + the record stores issued since), given through the builtin so that the compiler's
+//     own scoreboard knows when the last DMA has landed and does not drain the record stores before the reduction;
+//   * the record stores are `global_store ... nt` straight from the registers of the pixel just finished (one live quad);
+//   * workgroup barriers wait for LDS traffic only (wg_barrier<true>): the Jacobian records keep streaming out underneath the
+//     energy sum and the MFMA reduction of the 91 top sums.
+// Per-residual arithmetic is expression for expression that of linearize_one: every output stays bit-identical.
+template <int VM>
+__device__ __forceinline__ void dm_wait_builtin() {
+  static_assert(VM >= 0 && VM < 64, "vmcnt is a 6-bit field");
+  __builtin_amdgcn_s_waitcnt(0x0F70 | (VM & 15) | ((VM >> 4) << 14));   // vmcnt(VM), expcnt / lgkmcnt untouched
+}
+template <bool MATERIALIZE>
+__global__ __launch_bounds__(BA_BLOCK, 3) void k_ba_lin_dma(const BaDev* __restrict__ wins) {
+  // explicit address spaces: global_* instead of flat_* (flat operations complete out of order, so every use of a flat load
+  // would force `s_waitcnt vmcnt(0)` and drain the record stores), s_load for the wave-uniform tables
+#define GP(T, p) ((__attribute__((address_space(1))) T*)(p))
+#define CP(T, p) ((const __attribute__((address_space(4))) T*)(p))
+  const BaDev B = wins[blockIdx.y];
+  if ((int)blockIdx.x >= B.nchunks) return;
+  typedef int te_i4 __attribute__((ext_vector_type(4)));
+  const te_i4 ch = CP(te_i4, B.chunks)[blockIdx.x];          // {pair, start, count, -}
+  const int pair = __builtin_amdgcn_readfirstlane(ch.x);
+  const int nf = B.nf, h = pair % nf, t = pair / nf;
+  constexpr int STAGE_FLOATS = (BA_BLOCK / 64) * DM_WAVE_FLOATS;
+  constexpr int RED_FLOATS = TE_LDS_FLOATS > STAGE_FLOATS ? TE_LDS_FLOATS : STAGE_FLOATS;
+  __shared__ float red[RED_FLOATS];     // the DMA rings of the four waves, then the MFMA panels of the reduction
+  double* const lds = (double*)red;
+  float* const ring = red + (threadIdx.x >> 6) * DM_WAVE_FLOATS;
+  const bool inb = (int)threadIdx.x < ch.z;
+  const int i = ch.y + (inb ? (int)threadIdx.x : 0);
+  // ---- batch 1: indices and states (independent loads)
+  const uint8_t lin = GP(const uint8_t, B.r_lin)[i], st = GP(const uint8_t, B.r_state)[i], jsel = GP(const uint8_t, B.r_jsel)[i];
+  const int pt = GP(const int, B.r_point)[i];
+  const float e_old = GP(const float, B.r_energy)[i], ne_old = GP(const float, B.r_newEnergy)[i];
+  const __attribute__((address_space(4))) float* pre = CP(float, B.t_precalc) + (size_t)(h * nf + t) * 27;   // wave-uniform: SGPRs
+  const float affLL0 = pre[24], affLL1 = pre[25], b0 = pre[26];
+  const float4* __restrict__ dIl = (const float4*)CP(unsigned long long, B.t_img)[t];
+  const float th = fmaxf(GP(const float, B.t_frameTH)[h], GP(const float, B.t_frameTH)[t]);
+  // ---- batch 2: the point
+  const te_f4 g = GP(const te_f4, B.p_geo)[pt];
+  const te_f4 c0 = GP(const te_f4, B.p_color)[2 * (size_t)pt], c1 = GP(const te_f4, B.p_color)[2 * (size_t)pt + 1];
+  const te_f4 w0 = GP(const te_f4, B.p_weights)[2 * (size_t)pt], w1 = GP(const te_f4, B.p_weights)[2 * (size_t)pt + 1];
+  const bool live = inb && !lin;                     // linearizeAll skips linearized residuals (FullSystemOptimize.cpp:52-87)
+  const float color[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+  const float weights[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+  const float pu = g.x, pv = g.y, idepth_scaled = g.z, idepth_zero_scaled = g.w;
+  const float fxl = B.fxl, fyl = B.fyl, cxl = B.cxl, cyl = B.cyl, fxli = B.fxli, fyli = B.fyli;
+  const auto KRKi = pre; const auto Kt = pre + 9; const auto R0 = pre + 12; const auto t0 = pre + 21;
+  // projectPoint (ResidualProjections.h:64-96) at the FEJ point
+  float KliP[3];
+  KliP[0] = (pu + 0 - cxl) * fxli;
+  KliP[1] = (pv + 0 - cyl) * fyli;
+  KliP[2] = 1;
+  float ptp[3];
+#pragma unroll
+  for (int r = 0; r < 3; r++) ptp[r] = ((R0[r * 3 + 0] * KliP[0] + R0[r * 3 + 1] * KliP[1]) + R0[r * 3 + 2] * KliP[2]) + t0[r] * idepth_zero_scaled;
+  const float drescale = 1.0f / ptp[2];
+  const float new_idepth = idepth_zero_scaled * drescale;
+  const float u = ptp[0] * drescale;
+  const float v = ptp[1] * drescale;
+  const float Ku0 = u * fxl + cxl;
+  const float Kv0 = v * fyl + cyl;
+  // a residual is sampled when it is live, not sticky-OOB (Residuals.cpp:88-91), its centre projects into the image (:96-100) and
+  // so do all 8 pattern pixels (:215-225)
+  bool comp = live && st != 1 && (drescale > 0) && (Ku0 > 1.1f && Kv0 > 1.1f && Ku0 < B.wM3 && Kv0 < B.hM3);
+  float Kus[8], Kvs[8];
+#pragma unroll
+  for (int idx = 0; idx < 8; idx++) {
+    const float up = pu + c_pattern[idx][0], vp = pv + c_pattern[idx][1];
+    float q[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) q[r] = ((KRKi[r * 3 + 0] * up + KRKi[r * 3 + 1] * vp) + KRKi[r * 3 + 2]) + Kt[r] * idepth_scaled;
+    Kus[idx] = q[0] / q[2];
+    Kvs[idx] = q[1] / q[2];
+    if (!(Kus[idx] > 1.1f && Kvs[idx] > 1.1f && Kus[idx] < B.wM3 && Kvs[idx] < B.hM3)) comp = false;
+  }
+  __attribute__((address_space(1))) float* const J = MATERIALIZE ? (__attribute__((address_space(1))) float*)(jsel ? B.J[0] : B.J[1]) : nullptr;
+  const int S = B.nrp;
+#define JSTORE(grp, a, b, c, d)                                                                                                      \
+  do {                                                                                                                               \
+    if (MATERIALIZE) __builtin_nontemporal_store((te_f4){a, b, c, d}, (__attribute__((address_space(1))) te_f4*)(J + (size_t)(grp) * 4 * S + 4 * (size_t)i)); \
+  } while (0)
+  float JIdxJIdx_00 = 0, JIdxJIdx_11 = 0, JIdxJIdx_10 = 0;
+  float JabJIdx_00 = 0, JabJIdx_01 = 0, JabJIdx_10 = 0, JabJIdx_11 = 0;
+  float JabJab_00 = 0, JabJab_01 = 0, JabJab_11 = 0;
+  float wJI2_sum = 0, energyLeft = 0;
+  float JI_r0 = 0, JI_r1 = 0, Jab_r0 = 0, Jab_r1 = 0, rr = 0;      // addPoint<0>'s per-pixel sums with resApprox = resF (AccumulatedTopHessian.cpp:119-128)
+  float jab1[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  bool nonfinite = false;
+  if (__ballot(comp) != 0ull) {      // (wave-uniform)
+    int xy[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) xy[k] = comp ? ((int)Kus[k] | ((int)Kvs[k] << 16)) : 0;
+    const int Tw = B.tiledT;
+    const float* my = ring + 16 * (threadIdx.x & 63);
+#pragma unroll
+    for (int p = 0; p < DM_DEPTH; p++) dm_issue_round(dIl, Tw, xy[p], ring + p * DM_ROUND_FLOATS);
+#pragma unroll
+    for (int idx = 0; idx < 8; idx++) {
+      // vector-memory operations younger than round idx: the rounds issued after it, and (when the records are materialised) the
+      // record stores issued since it was issued — exec is non-zero here (some lane samples), so each of those was one instruction
+      constexpr int D1 = DM_DEPTH - 1;
+      const int later = (7 - idx < D1 ? 7 - idx : D1);
+      const int stores = MATERIALIZE ? (idx < DM_DEPTH ? idx : DM_DEPTH) : 0;
+      switch (4 * later + stores) {
+#define DMW(N) case N: dm_wait_builtin<N>(); break;
+        DMW(0) DMW(1) DMW(2) DMW(3) DMW(4) DMW(5) DMW(6) DMW(7) DMW(8) DMW(9) DMW(10) DMW(11) DMW(12) DMW(13) DMW(14) DMW(15)
+#undef DMW
+        default: dm_wait_builtin<0>(); break;
+      }
+      te_f4 p00, p10, p01, p11;
+      dm_read_taps(my + (idx % DM_DEPTH) * DM_ROUND_FLOATS, p00, p10, p01, p11);
+      if (idx + DM_DEPTH < 8) dm_issue_round(dIl, Tw, xy[idx + DM_DEPTH], ring + (idx % DM_DEPTH) * DM_ROUND_FLOATS);   // the slot has just been read
+      // getInterpolatedElement33 (same expression and order as interp33)
+      const float x = Kus[idx], y = Kvs[idx];
+      const int ix = (int)x;
+      const int iy = (int)y;
+      const float dx = x - ix;
+      const float dy = y - iy;
+      const float dxdy = dx * dy;
+      const float w11 = dxdy, w01 = dy - dxdy, w10 = dx - dxdy, w00 = 1 - dx - dy + dxdy;
+      float3 hit;
+      hit.x = w11 * p11.x + w01 * p01.x + w10 * p10.x + w00 * p00.x;
+      hit.y = w11 * p11.y + w01 * p01.y + w10 * p10.y + w00 * p00.y;
+      hit.z = w11 * p11.z + w01 * p01.z + w10 * p10.z + w00 * p00.z;
+      if (!isfinite(hit.x)) nonfinite = true;
+      const float residual = hit.x - (affLL0 * color[idx] + affLL1);
+      const float drdA = (color[idx] - b0);
+      float wgt = sqrtf(kOutlierTHSumComponent / (kOutlierTHSumComponent + (hit.y * hit.y + hit.z * hit.z)));
+      wgt = 0.5f * (wgt + weights[idx]);
+      float hw = fabsf(residual) < kHuberTH ? 1 : kHuberTH / fabsf(residual);
+      energyLeft += wgt * wgt * hw * residual * residual * (2 - hw);
+      if (hw < 1) hw = sqrtf(hw);
+      hw = hw * wgt;
+      hit.y *= hw;
+      hit.z *= hw;
+      const float ra = residual * hw, ja0 = B.affA_fixed ? 0.f : drdA * hw;
+      jab1[idx] = B.affB_fixed ? 0.f : hw;
+      if (comp) JSTORE(6 + idx, ra, hit.y, hit.z, ja0);        // resF, JIdx[0], JIdx[1], JabF[0]
+      JI_r0 += ra * hit.y; JI_r1 += ra * hit.z;
+      Jab_r0 += ra * ja0; Jab_r1 += ra * jab1[idx];
+      rr += ra * ra;
+      JIdxJIdx_00 += hit.y * hit.y;
+      JIdxJIdx_11 += hit.z * hit.z;
+      JIdxJIdx_10 += hit.y * hit.z;
+      JabJIdx_00 += drdA * hw * hit.y;
+      JabJIdx_01 += drdA * hw * hit.z;
+      JabJIdx_10 += hw * hit.y;
+      JabJIdx_11 += hw * hit.z;
+      JabJab_00 += drdA * drdA * hw * hw;
+      JabJab_01 += drdA * hw * hw;
+      JabJab_11 += hw * hw;
+      wJI2_sum += hw * hw * (hit.y * hit.y + hit.z * hit.z);
+    }
+  }
+  const bool done = comp && !nonfinite;             // linearize ran to its end (Residuals.cpp:302-336)
+  // ---- geometric Jacobians at the FEJ point (Residuals.cpp:135-185) and the rest of the record
+  float xv[10], yv[10], jdd0 = 0.f, jdd1 = 0.f;
+#pragma unroll
+  for (int k = 0; k < 10; k++) { xv[k] = 0.f; yv[k] = 0.f; }
+  int ns = 1;
+  if (done) {
+    float d_C_x[4], d_C_y[4];
+    const float d_d_x = drescale * (t0[0] - t0[2] * u) * SCALE_IDEPTH * fxl;
+    const float d_d_y = drescale * (t0[1] - t0[2] * v) * SCALE_IDEPTH * fyl;
+    d_C_x[2] = drescale * (R0[6] * u - R0[0]);
+    d_C_x[3] = fxl * drescale * (R0[7] * u - R0[1]) * fyli;
+    d_C_x[0] = KliP[0] * d_C_x[2];
+    d_C_x[1] = KliP[1] * d_C_x[3];
+    d_C_y[2] = fyl * drescale * (R0[6] * v - R0[3]) * fxli;
+    d_C_y[3] = drescale * (R0[7] * v - R0[4]);
+    d_C_y[0] = KliP[0] * d_C_y[2];
+    d_C_y[1] = KliP[1] * d_C_y[3];
+    d_C_x[0] = (d_C_x[0] + u) * SCALE_F;
+    d_C_x[1] *= SCALE_F;
+    d_C_x[2] = (d_C_x[2] + 1) * SCALE_C;
+    d_C_x[3] *= SCALE_C;
+    d_C_y[0] *= SCALE_F;
+    d_C_y[1] = (d_C_y[1] + v) * SCALE_F;
+    d_C_y[2] *= SCALE_C;
+    d_C_y[3] = (d_C_y[3] + 1) * SCALE_C;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { xv[k] = d_C_x[k]; yv[k] = d_C_y[k]; }
+    xv[4] = new_idepth * fxl; xv[5] = 0; xv[6] = -new_idepth * u * fxl; xv[7] = -u * v * fxl; xv[8] = (1 + u * u) * fxl; xv[9] = -v * fxl;
+    yv[4] = 0; yv[5] = new_idepth * fyl; yv[6] = -new_idepth * v * fyl; yv[7] = -(1 + v * v) * fyl; yv[8] = u * v * fyl; yv[9] = u * fyl;
+    jdd0 = d_d_x; jdd1 = d_d_y;
+    JSTORE(0, xv[4], xv[5], xv[6], xv[7]);                    // Jpdxi[0][0..3]
+    JSTORE(1, xv[8], xv[9], yv[4], yv[5]);                    // Jpdxi[0][4..5], Jpdxi[1][0..1]
+    JSTORE(2, yv[6], yv[7], yv[8], yv[9]);                    // Jpdxi[1][2..5]
+    JSTORE(3, xv[0], xv[1], xv[2], xv[3]);
+    JSTORE(4, yv[0], yv[1], yv[2], yv[3]);
+    JSTORE(5, jdd0, jdd1, 0.f, 0.f);
+    JSTORE(14, jab1[0], jab1[1], jab1[2], jab1[3]);
+    JSTORE(15, jab1[4], jab1[5], jab1[6], jab1[7]);
+    JSTORE(16, JIdxJIdx_00, JIdxJIdx_10, JIdxJIdx_10, JIdxJIdx_11);
+    JSTORE(17, JabJIdx_00, JabJIdx_01, JabJIdx_10, JabJIdx_11);
+    JSTORE(18, JabJab_00, JabJab_01, JabJab_01, JabJab_11);
+    ns = (energyLeft > th || wJI2_sum < 2) ? 2 : 0;           // OUTLIER / IN (Residuals.cpp:325-332)
+  }
+#undef JSTORE
+  const float e_new = ns == 2 ? th : energyLeft;              // state_NewEnergy when linearize ran through
+  double e = 0;
+  bool on = false;
+  float a = 0, b = 0, c = 0, TR00 = 0, TR10 = 0, TR01 = 0, TR11 = 0, TR02 = 0, TR12 = 0;
+  float br[6] = {0, 0, 0, 0, 0, 0};
+  if (live) {
+    GP(float, B.r_newEnergyWO)[i] = done ? energyLeft : -1.f;
+    GP(uint8_t, B.r_newState)[i] = (uint8_t)ns;
+    if (done) GP(float, B.r_newEnergy)[i] = e_new;
+    e = done ? (double)e_new : (double)e_old;
+    if (st != 1) {                                            // applyRes(true): OOB is sticky (Residuals.cpp:367-385)
+      __attribute__((address_space(1))) te_f4* rec = GP(te_f4, B.r_rec) + ((size_t)pt * nf + t) * 4;
+      float o8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, rbd = 0.f, rhdd = 0.f, rhcd[4] = {0.f, 0.f, 0.f, 0.f};
+      const uint8_t act = ns == 0;
+      if (act) {                                              // takeDataF (EnergyFunctionalStructs.cpp:37-51), then addPoint<0>
+        if (MATERIALIZE) GP(uint8_t, B.r_jsel)[i] = jsel ^ 1;
+        const float v0 = JIdxJIdx_00 * jdd0 + JIdxJIdx_10 * jdd1;
+        const float v1 = JIdxJIdx_10 * jdd0 + JIdxJIdx_11 * jdd1;
+#pragma unroll
+        for (int k = 0; k < 6; k++) o8[k] = xv[4 + k] * v0 + yv[4 + k] * v1;
+        o8[6] = JabJIdx_00 * jdd0 + JabJIdx_01 * jdd1;
+        o8[7] = JabJIdx_10 * jdd0 + JabJIdx_11 * jdd1;
+        on = true;
+        a = JIdxJIdx_00; b = JIdxJIdx_10; c = JIdxJIdx_11;
+        TR00 = JabJIdx_00; TR10 = JabJIdx_01; TR01 = JabJIdx_10; TR11 = JabJIdx_11;
+        TR02 = JI_r0; TR12 = JI_r1;
+        br[0] = JabJab_00; br[1] = JabJab_01; br[2] = Jab_r0; br[3] = JabJab_11; br[4] = Jab_r1; br[5] = rr;
+        const float q0 = a * jdd0 + b * jdd1;
+        const float q1 = JIdxJIdx_10 * jdd0 + c * jdd1;
+        rbd = JI_r0 * jdd0 + JI_r1 * jdd1;
+        rhdd = q0 * jdd0 + q1 * jdd1;
+#pragma unroll
+        for (int k = 0; k < 4; k++) rhcd[k] = xv[k] * q0 + yv[k] * q1;
+      }
+      GP(uint8_t, B.r_act)[i] = act;
+      GP(uint8_t, B.r_state)[i] = (uint8_t)ns;
+      GP(float, B.r_energy)[i] = done ? e_new : ne_old;        // state_energy = state_NewEnergy
+      rec[0] = (te_f4){o8[0], o8[1], o8[2], o8[3]};
+      rec[1] = (te_f4){o8[4], o8[5], o8[6], o8[7]};
+      rec[2] = (te_f4){rbd, rhdd, rhcd[0], rhcd[1]};
+      rec[3] = (te_f4){rhcd[2], rhcd[3], (float)act, (float)t};
+    }
+  }
+  if (!on) {
+#pragma unroll
+    for (int k = 0; k < 10; k++) { xv[k] = 0.f; yv[k] = 0.f; }
+  }
+  wg_barrier<true>();     // every wave is done with its ring: the reductions reuse the space
+  e = block_sum_d<true>(e, lds);
+  if (threadIdx.x == 0) GP(double, B.e_part)[blockIdx.x] = e;
+  wg_barrier<true>();
+#undef GP
+#undef CP
+  top_emit<true>(B, xv, yv, a, b, c, TR00, TR10, TR01, TR11, TR02, TR12, br, on, red);
 }
 
 // ------------------------------------------------------------------ linearised energy (EnergyFunctional::calcLEnergyPt, EnergyFunctional.cpp:354-417)
