@@ -307,7 +307,7 @@ static int upload_window_impl(sdso_ctx* ctx, int win, const sdso_ba_window_t* Wi
   DM(d.top_part, float, (size_t)d.nchunks * 92); DM(d.sc_part, float, std::max((size_t)d.nitems * sc_part_floats(nf), (size_t)nf * 20)); DM(d.e_part, double, std::max(W->nblk_res, d.nchunks) + 1);
   DM(d.accum, float, acc_floats(nf));
   W->accum_own = d.accum;
-  DM(d.sol, double, 4 * ((size_t)n * n + n) + n);
+  DM(d.sol, double, sol_doubles(n, nf));
   DM(W->d_pflag, uint8_t, np); DM(W->d_sums, float, 2 * (W->nblk_pts + 1));
   DM(W->d_self, BaDev, 1);
 
@@ -466,10 +466,17 @@ static void launch_fused(sdso_ctx* ctx, const BaLaunch& L, bool materialize, int
   // without linearized residuals the top partials are folded together with the Schur partials, after the Schur kernel
   if (part & 2) launch_sc_and_folds(ctx, L, nullptr, false, !L.any_lin);
 }
+// stitchDouble of the three accumulator groups: the Schur pre-products, then one wave per output tile
+static void launch_stitch(sdso_ctx* ctx, const BaLaunch& L) {
+  const int nf = L.nf;
+  hipLaunchKernelGGL(k_ba_stitch_pre, dim3((2 * nf * nf + 3) / 4, L.nwin), dim3(256), 0, ctx->stream, L.d_arr);
+  hipLaunchKernelGGL(k_ba_stitch, dim3((3 * (nf * nf + nf + 1) + ST_WAVES - 1) / ST_WAVES, L.nwin), dim3(64 * ST_WAVES), 0, ctx->stream, L.d_arr);
+}
+// stitch + solveSystemF (default branch) + resubstitute
 static void launch_solve(sdso_ctx* ctx, const BaLaunch& L, double lambda, int orth) {
-  const int nf = L.nf, n = L.n;
-  hipLaunchKernelGGL(k_ba_stitch, dim3(3 * (nf * nf + nf + 1), L.nwin), dim3(256), 0, ctx->stream, L.d_arr);
-  const size_t lds = sizeof(double) * ((size_t)n * (n + 1) + 5 * n) + sizeof(int) * n;
+  const int n = L.n;
+  launch_stitch(ctx, L);
+  const size_t lds = sizeof(double) * ((size_t)n * ((n + 2) & ~1) + 6 * n + 8) + sizeof(int) * n;   // matrix, six vectors (+8 pad), perm
   hipLaunchKernelGGL(k_ba_solve, dim3(1, L.nwin), dim3(BA_BLOCK), lds, ctx->stream, L.d_arr, lambda, orth);
   if (L.max_nblk_pts > 0) hipLaunchKernelGGL(k_ba_resub, dim3(L.max_nblk_pts, L.nwin), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr);
 }
@@ -674,7 +681,7 @@ namespace sdso {
 static int solve_system_host(sdso_ctx* ctx, BaWindowDev* W, int iteration, double lambda) {
   const BaLaunch L = single(W);
   const int nf = L.nf, n = L.n;
-  hipLaunchKernelGGL(k_ba_stitch, dim3(3 * (nf * nf + nf + 1), 1), dim3(256), 0, ctx->stream, L.d_arr);
+  launch_stitch(ctx, L);
   SDSO_HIP(ctx, hipGetLastError());
   const size_t blk = (size_t)n * n + n;
   std::vector<double> st(3 * blk);
@@ -983,7 +990,7 @@ extern "C" int sdso_ba_optimize(sdso_ctx* ctx, int win, int mnumOptIts, double* 
 extern "C" int sdso_ba_marginalize_points(sdso_ctx* ctx, int win, const uint8_t* marg_flag, double* HM_out, double* bM_out) {
   GET_WIN();
   SDSO_REQUIRE(ctx, marg_flag, "null flags");
-  const int np = W->d.np, nr = W->d.nr, nf = W->d.nf, n = W->d.n;
+  const int np = W->d.np, nr = W->d.nr, n = W->d.n;
   BaLaunch L = single(W);
   H2D(W->d_pflag, marg_flag, np);
   hipLaunchKernelGGL(k_ba_reset_flagged, dim3(L.max_nblk_res, 1), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr, W->d_pflag);
@@ -995,7 +1002,7 @@ extern "C" int sdso_ba_marginalize_points(sdso_ctx* ctx, int win, const uint8_t*
   for (int p = 0; p < np; p++) if (marg_flag[p]) W->h_prior[p] *= 600.f * 600.f;   // setting_idepthFixPriorMargFac (:674)
   H2D(W->d.p_prior, W->h_prior.data(), sizeof(float) * np);
   launch_accumulate(ctx, L, W->d_pflag, true);
-  hipLaunchKernelGGL(k_ba_stitch, dim3(3 * (nf * nf + nf + 1), 1), dim3(256), 0, ctx->stream, L.d_arr);
+  launch_stitch(ctx, L);
   SDSO_HIP(ctx, hipGetLastError());
   const size_t blk = (size_t)n * n + n;
   std::vector<double> MA(blk), MS(blk);
