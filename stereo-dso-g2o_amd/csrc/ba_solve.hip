@@ -413,6 +413,7 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_solve(const BaDev* __restrict__
     };
     for (int k = 0; k < n; k++) {
       unsigned long long tq = TNOW();
+      (void)tq;
       // ---- pivot: first position with the largest |d|, position >= k
       const unsigned long long k0 = (has0 && r0 >= k) ? (unsigned long long)__double_as_longlong(fabs(d0)) : 0ull;
       const unsigned long long k1 = (has1 && r1 >= k) ? (unsigned long long)__double_as_longlong(fabs(d1)) : 0ull;

@@ -1,5 +1,5 @@
-// Host-side (CPU, double precision) small math of libsdso_hip.so: SE(3), tiny dense algebra,
-// pivoted LDL^T and the nullspace projector.  This is the product's own implementation of what
+// Small double-precision math of libsdso_hip.so: SE(3), tiny dense algebra, pivoted LDL^T and the nullspace projector.  Host code
+// uses all of it; the functions marked SDSO_HD also run on the device (the Levenberg-Marquardt step of the resident tracker).  This is the product's own implementation of what
 // the reference gets from Sophus / Eigen:
 //   thirdparty/Sophus/sophus/se3.hpp:131-140 (Adj), :406-428 (exp), :560-600 (log)
 //   thirdparty/Sophus/sophus/so3.hpp:343-370, :491-531
@@ -9,6 +9,8 @@
 #include <cmath>
 #include <cstring>
 #include <vector>
+
+#define SDSO_HD __host__ __device__
 
 namespace sdso {
 
@@ -20,27 +22,27 @@ struct Se3 {
   V3 t{{0, 0, 0}};
 };
 
-inline M3 mul(const M3& a, const M3& b) {
+SDSO_HD inline M3 mul(const M3& a, const M3& b) {
   M3 c;
   for (int i = 0; i < 3; ++i)
     for (int j = 0; j < 3; ++j) c[i * 3 + j] = a[i * 3] * b[j] + a[i * 3 + 1] * b[3 + j] + a[i * 3 + 2] * b[6 + j];
   return c;
 }
-inline V3 mul(const M3& a, const V3& x) {
+SDSO_HD inline V3 mul(const M3& a, const V3& x) {
   return V3{{a[0] * x[0] + a[1] * x[1] + a[2] * x[2], a[3] * x[0] + a[4] * x[1] + a[5] * x[2],
              a[6] * x[0] + a[7] * x[1] + a[8] * x[2]}};
 }
-inline M3 transpose(const M3& a) { return M3{{a[0], a[3], a[6], a[1], a[4], a[7], a[2], a[5], a[8]}}; }
-inline M3 skew(const V3& w) { return M3{{0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0}}; }
+SDSO_HD inline M3 transpose(const M3& a) { return M3{{a[0], a[3], a[6], a[1], a[4], a[7], a[2], a[5], a[8]}}; }
+SDSO_HD inline M3 skew(const V3& w) { return M3{{0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0}}; }
 
-inline Se3 operator*(const Se3& A, const Se3& B) {
+SDSO_HD inline Se3 operator*(const Se3& A, const Se3& B) {
   Se3 C;
   C.R = mul(A.R, B.R);
   V3 rt = mul(A.R, B.t);
   for (int i = 0; i < 3; ++i) C.t[i] = rt[i] + A.t[i];
   return C;
 }
-inline Se3 inverse(const Se3& A) {
+SDSO_HD inline Se3 inverse(const Se3& A) {
   Se3 C;
   C.R = transpose(A.R);
   V3 v = mul(C.R, A.t);
@@ -49,7 +51,7 @@ inline Se3 inverse(const Se3& A) {
 }
 
 // unit quaternion {w,x,y,z} <-> rotation
-inline M3 rotationFromQuat(double w, double x, double y, double z) {
+SDSO_HD inline M3 rotationFromQuat(double w, double x, double y, double z) {
   const double n = std::sqrt(w * w + x * x + y * y + z * z);
   w /= n; x /= n; y /= n; z /= n;
   return M3{{1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
@@ -77,7 +79,7 @@ inline std::array<double, 4> quatFromRotation(const M3& R) {
 
 constexpr double kSophusEps = 1e-10;
 
-inline M3 expSo3(const V3& om, double* theta_out) {
+SDSO_HD inline M3 expSo3(const V3& om, double* theta_out) {
   const double th2 = om[0] * om[0] + om[1] * om[1] + om[2] * om[2];
   const double th = std::sqrt(th2);
   double im, re;
@@ -105,7 +107,7 @@ inline V3 logSo3(const M3& R, double* theta_out) {
   return V3{{f * q[1], f * q[2], f * q[3]}};
 }
 // tangent = [upsilon | omega] (translation first, Sophus order)
-inline Se3 expSe3(const double* xi) {
+SDSO_HD inline Se3 expSe3(const double* xi) {
   const V3 om{{xi[3], xi[4], xi[5]}};
   Se3 T;
   double th;
@@ -150,7 +152,7 @@ inline void adjoint(const Se3& T, double* A) {
 }
 
 // float 3x3: cofactor inverse (Eigen's fixed 3x3 inverse order), product, mat-vec
-inline void inv3f(const float* m, float* o) {
+SDSO_HD inline void inv3f(const float* m, float* o) {
   const float c00 = m[4] * m[8] - m[5] * m[7];
   const float c10 = m[5] * m[6] - m[3] * m[8];
   const float c20 = m[3] * m[7] - m[4] * m[6];
@@ -164,9 +166,9 @@ inline void inv3f(const float* m, float* o) {
   r[2] = (m[1] * m[5] - m[2] * m[4]) * id;
   r[5] = (m[2] * m[3] - m[0] * m[5]) * id;
   r[8] = (m[0] * m[4] - m[1] * m[3]) * id;
-  std::memcpy(o, r, sizeof(r));
+  for (int i = 0; i < 9; ++i) o[i] = r[i];
 }
-inline void mul3f(const float* a, const float* b, float* c) {
+SDSO_HD inline void mul3f(const float* a, const float* b, float* c) {
   float r[9];
   for (int i = 0; i < 3; ++i)
     for (int j = 0; j < 3; ++j) {
@@ -175,7 +177,7 @@ inline void mul3f(const float* a, const float* b, float* c) {
       s = s + a[i * 3 + 2] * b[6 + j];
       r[i * 3 + j] = s;
     }
-  std::memcpy(c, r, sizeof(r));
+  for (int i = 0; i < 9; ++i) c[i] = r[i];
 }
 inline void mulv3f(const float* a, const float* x, float* y) {
   float r[3];
@@ -189,7 +191,7 @@ inline void mulv3f(const float* a, const float* x, float* y) {
 }
 
 // AffLight::fromToVecExposure (src/util/NumType.h:159-170)
-inline void affFromTo(float expF, float expT, double aF, double bF, double aT, double bT, double* out) {
+SDSO_HD inline void affFromTo(float expF, float expT, double aF, double bF, double aT, double bT, double* out) {
   if (expF == 0 || expT == 0) expT = expF = 1;
   const double a = std::exp(aT - aF) * expT / expF;
   out[0] = a;
@@ -241,6 +243,45 @@ inline bool solveLdlt(Dense A, const std::vector<double>& rhs, std::vector<doubl
   for (int i = 0; i < n; ++i) y[i] = D[i] != 0.0 ? y[i] / D[i] : 0.0;
   for (int i = n - 1; i >= 0; --i) { double s = y[i]; for (int j = i + 1; j < n; ++j) s -= A(j, i) * y[j]; y[i] = s; }
   x.assign(n, 0.0);
+  for (int i = 0; i < n; ++i) x[p[i]] = y[i];
+  return ok;
+}
+
+// The same algorithm on plain arrays for n <= 8 (row-major A with row stride lda; A is copied): host and device.
+// `work` = 80 doubles (the copy of A, D, y), `p` = 8 ints: the caller's storage, so that a device caller can keep them in LDS (dynamically
+// indexed locals would live in scratch memory).
+SDSO_HD inline bool solveLdltSmall(const double* Ain, int lda, int n, const double* rhs, double* x, double* work, int* p) {
+  double* A = work;
+  double* D = work + 64;
+  double* y = work + 72;
+  for (int i = 0; i < n; ++i) { p[i] = i; D[i] = 0.0; for (int j = 0; j < n; ++j) A[i * 8 + j] = Ain[i * lda + j]; }
+  bool ok = true;
+  for (int k = 0; k < n; ++k) {
+    int piv = k;
+    double best = fabs(A[k * 8 + k]);
+    for (int i = k + 1; i < n; ++i)
+      if (fabs(A[i * 8 + i]) > best) { best = fabs(A[i * 8 + i]); piv = i; }
+    if (piv != k) {
+      for (int j = 0; j < n; ++j) { const double t = A[k * 8 + j]; A[k * 8 + j] = A[piv * 8 + j]; A[piv * 8 + j] = t; }
+      for (int i = 0; i < n; ++i) { const double t = A[i * 8 + k]; A[i * 8 + k] = A[i * 8 + piv]; A[i * 8 + piv] = t; }
+      const int t = p[k]; p[k] = p[piv]; p[piv] = t;
+    }
+    const double d = A[k * 8 + k];
+    D[k] = d;
+    if (d == 0.0) { ok = false; for (int i = k + 1; i < n; ++i) A[i * 8 + k] = 0; continue; }
+    for (int i = k + 1; i < n; ++i) A[i * 8 + k] /= d;
+    for (int i = k + 1; i < n; ++i) {
+      const double l = A[i * 8 + k];
+      if (l == 0.0) continue;
+      for (int j = k + 1; j <= i; ++j) A[i * 8 + j] -= l * d * A[j * 8 + k];
+    }
+    for (int i = k + 1; i < n; ++i)
+      for (int j = i + 1; j < n; ++j) A[i * 8 + j] = A[j * 8 + i];
+  }
+  for (int i = 0; i < n; ++i) y[i] = rhs[p[i]];
+  for (int i = 0; i < n; ++i) { double s = y[i]; for (int j = 0; j < i; ++j) s -= A[i * 8 + j] * y[j]; y[i] = s; }
+  for (int i = 0; i < n; ++i) y[i] = D[i] != 0.0 ? y[i] / D[i] : 0.0;
+  for (int i = n - 1; i >= 0; --i) { double s = y[i]; for (int j = i + 1; j < n; ++j) s -= A[j * 8 + i] * y[j]; y[i] = s; }
   for (int i = 0; i < n; ++i) x[p[i]] = y[i];
   return ok;
 }

@@ -73,36 +73,28 @@ void release_track_batch(sdso_ctx* ctx) {
 }  // namespace sdso
 
 // ------------------------------------------------------------------ kernels
+// Per-lane sums of calcRes + calcGSSSE over the points first, first + stride, ... of one problem (TRK_UNROLL points per trip):
+// the 45 upper-triangle products, E, the flow-indicator sums and the four counters.
+struct TrackLaneSums {
+  float acc[45];
+  float E, sT, sRT;
+  int nE, nSat, nWarp, nShift;
+};
 template <bool MASK>
-__global__ __launch_bounds__(TRK_BLOCK) void k_track_eval(const TrackProb* __restrict__ probs, int nprob, int gx,
-                                                          float* __restrict__ partF, int* __restrict__ partI,
-                                                          uint8_t* __restrict__ mask) {
-  // XCD-aware mapping: linear workgroup id L runs on XCD (L % 8); give every chunk of problem p
-  // the same residue so one L2 serves the problem's image.  Speed only; any placement is correct.
-  const int L = blockIdx.x;
-  const int xcd = L & 7;
-  const int j = L >> 3;
-  const int p = (j / gx) * 8 + xcd;
-  const int bx = j % gx;
-  if (p >= nprob) return;
-  const TrackProb& P = probs[p];
-  const int n = P.n;
-  if (bx > 0 && bx * TRK_BLOCK >= n) return;   // no points for this workgroup (k_track_finalize skips its partial)
-  const int lvl = P.ev.lvl, wl = P.ev.w, hl = P.ev.h;
-  const float fxl = P.ev.fx, fyl = P.ev.fy, cxl = P.ev.cx, cyl = P.ev.cy;
-  const float affLL0 = P.ev.affLL[0], affLL1 = P.ev.affLL[1];
-  const float b0 = P.ev.ref_b0, cutoffTH = P.ev.cutoffTH, huberTH = P.ev.huberTH;
+__device__ __forceinline__ void track_accumulate(const sdso_track_eval_t& EV, const float4* __restrict__ pc, const float4* __restrict__ img, int n,
+                                                 int first, int stride, uint8_t* __restrict__ mask, TrackLaneSums& S) {
+  const int lvl = EV.lvl, wl = EV.w, hl = EV.h;
+  const float fxl = EV.fx, fyl = EV.fy, cxl = EV.cx, cyl = EV.cy;
+  const float affLL0 = EV.affLL[0], affLL1 = EV.affLL[1];
+  const float b0 = EV.ref_b0, cutoffTH = EV.cutoffTH, huberTH = EV.huberTH;
   const float maxEnergy = 2 * huberTH * cutoffTH - huberTH * huberTH;
-  const float4* __restrict__ pc = P.pc;
-  const float4* __restrict__ img = P.img;
   float RKi[9], Ki[9], t[3];
 #pragma unroll
-  for (int k = 0; k < 9; k++) { RKi[k] = P.ev.RKi[k]; Ki[k] = P.ev.Ki[k]; }
+  for (int k = 0; k < 9; k++) { RKi[k] = EV.RKi[k]; Ki[k] = EV.Ki[k]; }
 #pragma unroll
-  for (int k = 0; k < 3; k++) t[k] = P.ev.t[k];
+  for (int k = 0; k < 3; k++) t[k] = EV.t[k];
   const float wlm3 = (float)(wl - 3), hlm3 = (float)(hl - 3);
-
-  float acc[45];
+  float* acc = S.acc;
 #pragma unroll
   for (int k = 0; k < 45; k++) acc[k] = 0.f;
   float E = 0.f, sT = 0.f, sRT = 0.f;
@@ -112,8 +104,7 @@ __global__ __launch_bounds__(TRK_BLOCK) void k_track_eval(const TrackProb* __res
   // all of a trip's requests at once: (1) the pc loads, (2) projection + bounds test + the 4 bilinear taps of every
   // point (an out-of-bounds point reads pixel (2,2) instead of branching around its loads), (3) residual, Huber,
   // the 45 products — in point order, so the per-lane sums are those of the one-point-per-trip loop.
-  const int stride = gx * TRK_BLOCK;
-  for (int i0 = bx * TRK_BLOCK + threadIdx.x; i0 < n; i0 += TRK_UNROLL * stride) {
+  for (int i0 = first; i0 < n; i0 += TRK_UNROLL * stride) {
     float4 q[TRK_UNROLL];
 #pragma unroll
     for (int s = 0; s < TRK_UNROLL; s++) {
@@ -202,6 +193,29 @@ __global__ __launch_bounds__(TRK_BLOCK) void k_track_eval(const TrackProb* __res
       if (MASK && i < n) mask[i] = inl ? 1 : 0;
     }
   }
+  S.E = E; S.sT = sT; S.sRT = sRT; S.nE = nE; S.nSat = nSat; S.nWarp = nWarp; S.nShift = nShift;
+}
+
+template <bool MASK>
+__global__ __launch_bounds__(TRK_BLOCK) void k_track_eval(const TrackProb* __restrict__ probs, int nprob, int gx,
+                                                          float* __restrict__ partF, int* __restrict__ partI,
+                                                          uint8_t* __restrict__ mask) {
+  // XCD-aware mapping: linear workgroup id L runs on XCD (L % 8); give every chunk of problem p
+  // the same residue so one L2 serves the problem's image.  Speed only; any placement is correct.
+  const int L = blockIdx.x;
+  const int xcd = L & 7;
+  const int j = L >> 3;
+  const int p = (j / gx) * 8 + xcd;
+  const int bx = j % gx;
+  if (p >= nprob) return;
+  const TrackProb& P = probs[p];
+  const int n = P.n;
+  if (bx > 0 && bx * TRK_BLOCK >= n) return;   // no points for this workgroup (k_track_finalize skips its partial)
+  TrackLaneSums S;
+  track_accumulate<MASK>(P.ev, P.pc, P.img, n, bx * TRK_BLOCK + threadIdx.x, gx * TRK_BLOCK, mask, S);
+  float* acc = S.acc;
+  const float E = S.E, sT = S.sT, sRT = S.sRT;
+  const int nE = S.nE, nSat = S.nSat, nWarp = S.nWarp, nShift = S.nShift;
 
   // ---- workgroup reduction: 64-lane butterfly, then 4 waves through LDS
   __shared__ float sF[TRK_BLOCK / 64][TRK_NF];
@@ -283,7 +297,7 @@ __global__ __launch_bounds__(64) void k_track_finalize(const TrackProb* __restri
 }
 
 // ------------------------------------------------------------------ host side
-static void fill_eval(const sdso_track_params_t& p, int lvl, const Se3& T, const sdso_aff_t& aff, float cutoff, sdso_track_eval_t& ev) {
+SDSO_HD static void fill_eval(const sdso_track_params_t& p, int lvl, const Se3& T, const sdso_aff_t& aff, float cutoff, sdso_track_eval_t& ev) {
   ev.lvl = lvl; ev.w = p.w[lvl]; ev.h = p.h[lvl];
   ev.fx = p.fx[lvl]; ev.fy = p.fy[lvl]; ev.cx = p.cx[lvl]; ev.cy = p.cy[lvl];
   const float K[9] = {ev.fx, 0, ev.cx, 0, ev.fy, ev.cy, 0, 0, 1};
@@ -495,95 +509,143 @@ extern "C" int sdso_track_calc_res_gs(sdso_ctx* ctx, int ref_slot, int frame_slo
   return SDSO_OK;
 }
 
-// CoarseTracker::trackNewestCoarse, DSO-native LM.
-// ------------------------------------------------------------------ trackNewestCoarse for many hypotheses in lock-step
+// ------------------------------------------------------------------ trackNewestCoarse
 // CoarseTracker::trackNewestCoarse (CoarseTracker.cpp:827-1069, DSO-native LM :908-1024) is a chain of calcRes+calcGSSSE
-// evaluations with a little 8x8 algebra in between.  Each hypothesis is a small state machine that always has exactly one
-// evaluation pending (first evaluation of a level, repeat with a doubled cutoff, or the trial step of an LM iteration); all
-// pending evaluations of a round go to the device in ONE launch.  The sequence of evaluations — and therefore every number —
-// of a hypothesis is the one the sequential loop produces.
+// evaluations with a little 8x8 algebra in between: LmCore is that state machine, written once for host and device.  It always
+// has exactly one evaluation pending (first evaluation of a level, repeat with a doubled cutoff, or the trial step of an LM
+// iteration).  Two drivers:
+//   * k_track_lm (default): ONE launch runs the whole call — one 512-thread workgroup per motion hypothesis (FullSystem::
+//     trackNewCoarse tries up to 53 of them, FullSystem.cpp:305-441; they run side by side on different CUs), all threads evaluate the
+//     pending calcRes+calcGSSSE over the level's points, thread 0 solves the 8x8 system, applies SE3::exp and takes the accept / reject
+//     and level decisions.  No host round trip per evaluation (it cost 25 us of launch + synchronisation each, 28 times per call).
+//   * the lock-step host loop (SDSO_TRK_HOST_LM=1): every round evaluates the pending requests of all hypotheses in one k_track_eval
+//     launch.  Same LmCore, same sequence of evaluations.
 namespace sdso {
-struct LmState {
-  int ref_slot = 0, frame_slot = 0;
+struct LmCore {
   sdso_track_params_t p;
-  sdso_track_result_t* out = nullptr;
-  sdso_se3_t* T_io = nullptr;
-  sdso_aff_t* aff_io = nullptr;
+  sdso_track_result_t out;
   Se3 cur, Tnew;
   sdso_aff_t affCur, affNew;
-  bool haveRepeated = false, done = false;
-  int lvl = 0, iteration = 0, phase = 0;   // phase 0: first / repeated evaluation of a level, 1: trial step
-  float levelCutoffRepeat = 1, lambda = 0.01f;
-  TrackOut oldO;
-  double H[64], b[8];
-  std::vector<double> inc;
-  // the evaluation this hypothesis waits for
-  Se3 reqT; sdso_aff_t reqAff;
+  sdso_se3_t T_final; sdso_aff_t aff_final;     // what lastToNew / aff_g2l receive (only when the call reaches its end)
+  bool wrote_final, haveRepeated, done;
+  int lvl, iteration, phase;                    // phase 0: first / repeated evaluation of a level, 1: trial step
+  float levelCutoffRepeat, lambda;
+  double oldres[6];                             // calcRes' Vec6 of the accepted state
+  double H[64], b[8], inc[8];
+  Se3 reqT; sdso_aff_t reqAff;                  // the evaluation this hypothesis waits for
+  double wHl[64], wHs[64], wnb[8], wbs[8], wx[8], wwork[80];   // work space of solve_inc() (members: in LDS on the device)
+  int wperm[8];
 
-  void request(const Se3& T, const sdso_aff_t& a) { reqT = T; reqAff = a; }
-  void start_level() { levelCutoffRepeat = 1; phase = 0; request(cur, affCur); }
-  void finish() {   // :1044-1068
+  SDSO_HD void init(const sdso_track_params_t& prm, const sdso_se3_t& T0, const sdso_aff_t& aff0) {
+    p = prm;
+    for (int i = 0; i < 5; i++) { out.lastResiduals[i] = NAN; out.iterations[i] = 0; }
+    for (int i = 0; i < 3; i++) out.lastFlowIndicators[i] = 1000;
+    out.evaluations = 0; out.point_evals = 0; out.good = 0;
+    for (int i = 0; i < 9; i++) cur.R[i] = T0.R[i];
+    for (int i = 0; i < 3; i++) cur.t[i] = T0.t[i];
+    affCur = aff0;
+    T_final = T0; aff_final = aff0; wrote_final = false;
+    haveRepeated = false; done = false;
+    iteration = 0; lambda = 0.01f;
+    lvl = p.coarsestLvl;
+    for (int i = 0; i < 8; i++) inc[i] = 0;
+    for (int i = 0; i < 6; i++) oldres[i] = 0;
+    start_level();
+  }
+  SDSO_HD void request(const Se3& T, const sdso_aff_t& a) { reqT = T; reqAff = a; }
+  SDSO_HD void start_level() { levelCutoffRepeat = 1; phase = 0; request(cur, affCur); }
+  SDSO_HD void finish() {   // :1044-1068
     done = true;
-    std::memcpy(T_io->R, cur.R.data(), 72);
-    std::memcpy(T_io->t, cur.t.data(), 24);
-    *aff_io = affCur;
-    if ((p.affineOptModeA != 0 && (fabsf((float)aff_io->a) > 1.2)) || (p.affineOptModeB != 0 && (fabsf((float)aff_io->b) > 200))) return;
+    wrote_final = true;
+    for (int i = 0; i < 9; i++) T_final.R[i] = cur.R[i];
+    for (int i = 0; i < 3; i++) T_final.t[i] = cur.t[i];
+    aff_final = affCur;
+    if ((p.affineOptModeA != 0 && (fabsf((float)aff_final.a) > 1.2)) || (p.affineOptModeB != 0 && (fabsf((float)aff_final.b) > 200))) return;
     double rel[2];
-    affFromTo(p.ref_exposure, p.new_exposure, p.ref_aff_g2l.a, p.ref_aff_g2l.b, aff_io->a, aff_io->b, rel);
+    affFromTo(p.ref_exposure, p.new_exposure, p.ref_aff_g2l.a, p.ref_aff_g2l.b, aff_final.a, aff_final.b, rel);
     const float r0 = (float)rel[0], r1 = (float)rel[1];
     if ((p.affineOptModeA == 0 && (fabsf(logf(r0)) > 1.5)) || (p.affineOptModeB == 0 && (fabsf(r1) > 200))) return;
-    if (p.affineOptModeA < 0) aff_io->a = 0;
-    if (p.affineOptModeB < 0) aff_io->b = 0;
-    out->good = 1;
+    if (p.affineOptModeA < 0) aff_final.a = 0;
+    if (p.affineOptModeB < 0) aff_final.b = 0;
+    out.good = 1;
   }
-  void finish_level() {
-    out->lastResiduals[lvl] = sqrtf((float)(oldO.res[0] / oldO.res[1]));
-    out->lastFlowIndicators[0] = oldO.res[2]; out->lastFlowIndicators[1] = oldO.res[3]; out->lastFlowIndicators[2] = oldO.res[4];
-    if (out->lastResiduals[lvl] > 1.5 * p.minResForAbort[lvl]) { done = true; return; }  // :1032 (good stays 0, pose untouched)
+  SDSO_HD void finish_level() {
+    out.lastResiduals[lvl] = sqrtf((float)(oldres[0] / oldres[1]));
+    out.lastFlowIndicators[0] = oldres[2]; out.lastFlowIndicators[1] = oldres[3]; out.lastFlowIndicators[2] = oldres[4];
+    if (out.lastResiduals[lvl] > 1.5 * p.minResForAbort[lvl]) { done = true; return; }  // :1032 (good stays 0, pose untouched)
     if (levelCutoffRepeat > 1 && !haveRepeated) { lvl++; haveRepeated = true; }
     lvl--;
     if (lvl < 0) finish(); else start_level();
   }
-  void propose() {   // one LM step from (H, b, lambda): :931-1000
+  // Stage 1 of consuming an evaluation: the scalar decisions (:897-904, :1004-1023).  Returns 1 when an LM step has to be proposed
+  // (then: if take_Hb copy H, b from the evaluation, solve_inc, propose_post); 0 when the next request (or `done`) is already set.
+  SDSO_HD int consume_pre(const double* res, bool& take_Hb) {
     const float lambdaExtrapolationLimit = 0.001f;
-    if (iteration >= p.maxIterations[lvl]) { finish_level(); return; }
-    out->iterations[lvl]++;
-    Dense Hl(8);
-    for (int i = 0; i < 8; i++) for (int j = 0; j < 8; j++) Hl(i, j) = H[i * 8 + j];
-    for (int i = 0; i < 8; i++) Hl(i, i) *= (1 + lambda);
-    std::vector<double> nb(8);
+    take_Hb = false;
+    if (phase == 0) {
+      for (int i = 0; i < 6; i++) oldres[i] = res[i];
+      if (oldres[5] > 0.6 && levelCutoffRepeat < 50) { levelCutoffRepeat *= 2; request(cur, affCur); return 0; }   // :897-904
+      take_Hb = true;
+      lambda = 0.01f;
+      iteration = 0;
+    } else {
+      const bool accept = (res[0] / res[1]) < (oldres[0] / oldres[1]);
+      if (accept) {
+        take_Hb = true;
+        for (int i = 0; i < 6; i++) oldres[i] = res[i];
+        affCur = affNew;
+        cur = Tnew;
+        lambda *= 0.5;
+      } else {
+        lambda *= 4;
+        if (lambda < lambdaExtrapolationLimit) lambda = lambdaExtrapolationLimit;
+      }
+      double nrm = 0;
+      for (int i = 0; i < 8; i++) nrm += inc[i] * inc[i];
+      if (!(std::sqrt(nrm) > 1e-3)) { finish_level(); return 0; }
+      iteration++;
+    }
+    if (iteration >= p.maxIterations[lvl]) { finish_level(); return 0; }
+    out.iterations[lvl]++;
+    return 1;
+  }
+  // Stage 2 (host form): inc from (H, b, lambda) and the affine modes (:931-964)
+  SDSO_HD void solve_inc() {
+    double* Hl = wHl; double* nb = wnb;
+    for (int i = 0; i < 64; i++) Hl[i] = H[i];
+    for (int i = 0; i < 8; i++) Hl[i * 8 + i] *= (1 + lambda);
     for (int i = 0; i < 8; i++) nb[i] = -b[i];
-    solveLdlt(Hl, nb, inc);
-    auto sub = [&](const Dense& Hs, const double* bs, int m, std::vector<double>& xs) {
-      Dense Hm(m);
-      std::vector<double> bm(m);
-      for (int i = 0; i < m; i++) { bm[i] = -bs[i]; for (int j = 0; j < m; j++) Hm(i, j) = Hs(i, j); }
-      solveLdlt(Hm, bm, xs);
-    };
+    solveLdltSmall(Hl, 8, 8, nb, inc, wwork, wperm);
     if (p.affineOptModeA < 0 && p.affineOptModeB < 0) {  // fix a, b (:937-940)
-      std::vector<double> x6; sub(Hl, b, 6, x6);
+      double* x6 = wx;
+      solveLdltSmall(Hl, 8, 6, nb, x6, wwork, wperm);
       for (int i = 0; i < 6; i++) inc[i] = x6[i];
       inc[6] = inc[7] = 0;
     }
     if (!(p.affineOptModeA < 0) && p.affineOptModeB < 0) {  // fix b (:943-946)
-      std::vector<double> x7; sub(Hl, b, 7, x7);
+      double* x7 = wx;
+      solveLdltSmall(Hl, 8, 7, nb, x7, wwork, wperm);
       for (int i = 0; i < 7; i++) inc[i] = x7[i];
       inc[7] = 0;
     }
     if (p.affineOptModeA < 0 && !(p.affineOptModeB < 0)) {  // fix a (:949-964)
-      Dense Hs = Hl;
-      double bs[8];
-      std::memcpy(bs, b, sizeof(bs));
-      for (int i = 0; i < 8; i++) Hs(i, 6) = Hs(i, 7);
-      for (int j = 0; j < 8; j++) Hs(6, j) = Hs(7, j);
+      double* Hs = wHs; double* bs = wbs; double* x7 = wx;
+      for (int i = 0; i < 64; i++) Hs[i] = Hl[i];
+      for (int i = 0; i < 8; i++) bs[i] = -b[i];
+      for (int i = 0; i < 8; i++) Hs[i * 8 + 6] = Hs[i * 8 + 7];
+      for (int j = 0; j < 8; j++) Hs[6 * 8 + j] = Hs[7 * 8 + j];
       bs[6] = bs[7];
-      std::vector<double> x7; sub(Hs, bs, 7, x7);
+      solveLdltSmall(Hs, 8, 7, bs, x7, wwork, wperm);
       for (int i = 0; i < 8; i++) inc[i] = 0;
       for (int i = 0; i < 6; i++) inc[i] = x7[i];
       inc[7] = x7[6];
     }
+  }
+  // Stage 3: extrapolation, scaling, SE3::exp and the request of the trial evaluation (:966-1000)
+  SDSO_HD void propose_post() {
+    const float lambdaExtrapolationLimit = 0.001f;
     float extrapFac = 1;
-    if (lambda < lambdaExtrapolationLimit) extrapFac = sqrt(sqrt(lambdaExtrapolationLimit / lambda));
+    if (lambda < lambdaExtrapolationLimit) extrapFac = sqrtf(sqrtf(lambdaExtrapolationLimit / lambda));
     for (int i = 0; i < 8; i++) inc[i] *= extrapFac;
     double incScaled[8];
     for (int i = 0; i < 8; i++) incScaled[i] = inc[i];
@@ -601,75 +663,294 @@ struct LmState {
     phase = 1;
     request(Tnew, affNew);
   }
+  // host form of the whole consumption of one evaluation
   void consume(const TrackOut& O) {
-    const float lambdaExtrapolationLimit = 0.001f;
-    if (phase == 0) {
-      oldO = O;
-      if (oldO.res[5] > 0.6 && levelCutoffRepeat < 50) { levelCutoffRepeat *= 2; request(cur, affCur); return; }   // :897-904
-      std::memcpy(H, oldO.H, sizeof(H));
-      std::memcpy(b, oldO.b, sizeof(b));
-      lambda = 0.01f;
-      iteration = 0;
-      propose();
-      return;
-    }
-    const bool accept = (O.res[0] / O.res[1]) < (oldO.res[0] / oldO.res[1]);
-    if (accept) {
-      std::memcpy(H, O.H, sizeof(H));
-      std::memcpy(b, O.b, sizeof(b));
-      oldO = O;
-      affCur = affNew;
-      cur = Tnew;
-      lambda *= 0.5;
-    } else {
-      lambda *= 4;
-      if (lambda < lambdaExtrapolationLimit) lambda = lambdaExtrapolationLimit;
-    }
-    double nrm = 0;
-    for (int i = 0; i < 8; i++) nrm += inc[i] * inc[i];
-    if (!(std::sqrt(nrm) > 1e-3)) { finish_level(); return; }
-    iteration++;
-    propose();
+    bool take = false;
+    if (!consume_pre(O.res, take)) return;
+    if (take) { for (int i = 0; i < 64; i++) H[i] = O.H[i]; for (int i = 0; i < 8; i++) b[i] = O.b[i]; }
+    solve_inc();
+    propose_post();
   }
 };
+
+// one hypothesis of the resident driver
+struct LmJob {
+  sdso_track_params_t p;
+  const float4* pc[SDSO_PYR_LEVELS];
+  const float4* img[SDSO_PYR_LEVELS];
+  int n[SDSO_PYR_LEVELS];
+  sdso_se3_t T;            // in: initial lastToNew; out: the call's result (unchanged when the call aborts, like the reference's references)
+  sdso_aff_t aff;
+  sdso_track_result_t out;
+};
+constexpr int LM_BLOCK = 512;    // 8 waves: the evaluation body wants ~200 VGPRs (two waves per SIMD)
 }  // namespace sdso
 
-extern "C" int sdso_track_newest_coarse_batch(sdso_ctx* ctx, int nhyp, const int* ref_slots, const int* frame_slots, const sdso_track_params_t* prms,
-                                              sdso_se3_t* lastToNew, sdso_aff_t* aff_g2l, sdso_track_result_t* outs) {
-  if (!ctx) return SDSO_ERR_STATE;
-  SDSO_HIP(ctx, hipSetDevice(ctx->device));
-  SDSO_REQUIRE(ctx, nhyp > 0 && ref_slots && frame_slots && prms && lastToNew && aff_g2l && outs, "null argument");
-  std::vector<LmState> S(nhyp);
-  for (int k = 0; k < nhyp; k++) {
-    LmState& s = S[k];
-    s.p = prms[k];
-    SDSO_REQUIRE(ctx, s.p.coarsestLvl >= 0 && s.p.coarsestLvl < 5 && s.p.coarsestLvl < s.p.levels, "coarsestLvl out of range");  // assert :853
-    s.ref_slot = ref_slots[k]; s.frame_slot = frame_slots[k];
-    s.out = &outs[k]; s.T_io = &lastToNew[k]; s.aff_io = &aff_g2l[k];
-    for (int i = 0; i < 5; i++) { s.out->lastResiduals[i] = NAN; s.out->iterations[i] = 0; }
-    for (int i = 0; i < 3; i++) s.out->lastFlowIndicators[i] = 1000;
-    s.out->evaluations = 0; s.out->point_evals = 0; s.out->good = 0;
-    std::memcpy(s.cur.R.data(), lastToNew[k].R, 72);
-    std::memcpy(s.cur.t.data(), lastToNew[k].t, 24);
-    s.affCur = aff_g2l[k];
-    s.lvl = s.p.coarsestLvl;
-    s.start_level();
+// ---- the LM step of the resident driver, by the 64 lanes of wave 0 ------------------------------------------------------------
+__device__ __forceinline__ double lm_readlane(double v, int src) {
+  const unsigned long long u = __double_as_longlong(v);
+  const unsigned lo = __builtin_amdgcn_readlane((unsigned)u, src), hi = __builtin_amdgcn_readlane((unsigned)(u >> 32), src);
+  return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+// x = A^-1 rhs for the leading n x n block (n <= 8) of a symmetric A: the algorithm of solveLdltSmall / Eigen::LDLT (symmetric pivoting
+// on the largest remaining |diagonal|, first index wins), with the matrix spread over the wave — lane 8i + j holds A(i,j), lanes
+// 8i hold rhs(i) — and every element updated by the expression the sequential code uses (the upper triangle mirrors the lower one:
+// its lanes evaluate the lower element's expression with the roles swapped).  A single lane walking these 64 doubles through LDS
+// took ~19 us per solve; here a step is a handful of cross-lane moves.  All lanes return with the same x[0..7].
+__device__ __forceinline__ void lm_wave_ldlt(double a, double rhs, int n, double* x) {
+  const int lane = threadIdx.x & 63, i = lane >> 3, j = lane & 7;
+  double y = rhs;
+  int pi = i;
+  for (int k = 0; k < n; k++) {
+    double best = fabs(lm_readlane(a, k * 9));
+    int p = k;
+    for (int m = k + 1; m < n; m++) {
+      const double v = fabs(lm_readlane(a, m * 9));
+      if (v > best) { best = v; p = m; }
+    }
+    if (p != k) {
+      const int si = i == k ? p : (i == p ? k : i), sj = j == k ? p : (j == p ? k : j);
+      a = __shfl(a, si * 8 + sj, 64);
+      y = __shfl(y, si * 8, 64);
+      pi = __shfl(pi, si * 8 + j, 64);
+    }
+    const double dk = lm_readlane(a, k * 9);
+    if (dk == 0.0) {
+      if (j == k && i > k) a = 0;
+      continue;
+    }
+    const double l = a / dk;                      // column k below the diagonal: L(i,k)
+    const double lik = __shfl(l, i * 8 + k, 64), ljk = __shfl(l, j * 8 + k, 64);
+    if (i > k && j > k && i < n && j < n) {
+      if (i >= j) a = a - (lik * dk) * ljk;       // A(i,j) -= l_ik d_k A(j,k)
+      else a = a - (ljk * dk) * lik;              // mirror of the lower element (j,i)
+    }
+    if (j == k && i > k) a = l;
   }
+  // triangular solves, every lane redundantly (values by v_readlane at fixed lanes): same summation order as the sequential code
+  double yv[8];
+#pragma unroll
+  for (int r = 0; r < 8; r++) yv[r] = lm_readlane(y, r * 8);
+#pragma unroll
+  for (int r = 0; r < 8; r++) {
+    if (r < n) {
+      double sacc = yv[r];
+#pragma unroll
+      for (int c = 0; c < 8; c++) if (c < r) sacc -= lm_readlane(a, r * 8 + c) * yv[c];
+      yv[r] = sacc;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 8; r++) { const double d = lm_readlane(a, r * 9); if (r < n) yv[r] = d != 0.0 ? yv[r] / d : 0.0; }
+#pragma unroll
+  for (int r = 7; r >= 0; r--) {
+    if (r < n) {
+      double sacc = yv[r];
+#pragma unroll
+      for (int c = 0; c < 8; c++) if (c > r && c < n) sacc -= lm_readlane(a, c * 8 + r) * yv[c];
+      yv[r] = sacc;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 8; r++) x[r] = 0.0;
+#pragma unroll
+  for (int r = 0; r < 8; r++) {
+    const int pr = __builtin_amdgcn_readlane(pi, r * 8);
+    if (r < n) {
+#pragma unroll
+      for (int c = 0; c < 8; c++) if (pr == c) x[c] = yv[r];
+    }
+  }
+}
+
+// wave 0 of k_track_lm: finalise the evaluation (calcGSSSE :580-595, calcRes :783-789, the expressions of k_track_finalize), take
+// the LM decisions (lane 0, LmCore::consume_pre), copy H / b, solve for the increment (wave), propose the trial pose (lane 0)
+__device__ __forceinline__ void lm_wave_step(LmCore& core, const float* F, const int* I, TrackOut& O, int* s_flags) {
+  const int lane = threadIdx.x & 63;
+  const int nE = I[0], nSat = I[1], nWarp = I[2], nShift = I[3];
+  const int npad = (nWarp + 3) & ~3;
+  {
+    const double SC[8] = {SCALE_XI_ROT, SCALE_XI_ROT, SCALE_XI_ROT, SCALE_XI_TRANS, SCALE_XI_TRANS, SCALE_XI_TRANS, SCALE_A, SCALE_B};
+    const float inv_n = 1.0f / npad;
+    for (int e = lane; e < 72; e += 64) {
+      const int r = e / 9, c = e % 9;
+      const int lo = r < c ? r : c, hi = r < c ? c : r;
+      const int idx = lo * 9 - lo * (lo - 1) / 2 + (hi - lo);
+      double v = npad > 0 ? (double)F[idx] * (double)inv_n : 0.0;
+      if (c < 8) { v *= SC[c]; v *= SC[r]; O.H[r * 8 + c] = v; }
+      else { v *= SC[r]; O.b[r] = v; }
+    }
+    if (lane == 0) {
+      O.res[0] = (double)F[45];
+      O.res[1] = (double)nE;
+      O.res[2] = (double)F[46] / ((double)(float)nShift + 0.1);
+      O.res[3] = 0;
+      O.res[4] = (double)F[47] / ((double)(float)nShift + 0.1);
+      O.res[5] = (double)((float)nSat / (float)nE);
+      O.n_warped = npad;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  if (lane == 0) {
+    bool take = false;
+    const int act = core.consume_pre(O.res, take);
+    s_flags[0] = act; s_flags[1] = take ? 1 : 0;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  if (s_flags[0]) {
+    if (s_flags[1]) { core.H[lane] = O.H[lane]; if (lane < 8) core.b[lane] = O.b[lane]; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // LmCore::solve_inc on the wave
+    const int i = lane >> 3, j = lane & 7;
+    const double lam1 = 1 + core.lambda;
+    double a = core.H[lane];
+    if (i == j) a *= lam1;
+    const double nb = -core.b[i];
+    const bool fixA = core.p.affineOptModeA < 0, fixB = core.p.affineOptModeB < 0;
+    double x[8];
+    lm_wave_ldlt(a, nb, 8, x);
+    double incv[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) incv[r] = x[r];
+    if (fixA && fixB) {
+      lm_wave_ldlt(a, nb, 6, x);
+#pragma unroll
+      for (int r = 0; r < 6; r++) incv[r] = x[r];
+      incv[6] = incv[7] = 0;
+    }
+    if (!fixA && fixB) {
+      lm_wave_ldlt(a, nb, 7, x);
+#pragma unroll
+      for (int r = 0; r < 7; r++) incv[r] = x[r];
+      incv[7] = 0;
+    }
+    if (fixA && !fixB) {   // rows / columns 6 <- 7 of the damped matrix, b likewise (:949-964)
+      const int si = i == 6 ? 7 : i, sj = j == 6 ? 7 : j;
+      const double as = __shfl(a, si * 8 + sj, 64);
+      const double bs = -core.b[si];
+      lm_wave_ldlt(as, bs, 7, x);
+#pragma unroll
+      for (int r = 0; r < 8; r++) incv[r] = 0;
+#pragma unroll
+      for (int r = 0; r < 6; r++) incv[r] = x[r];
+      incv[7] = x[6];
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int r = 0; r < 8; r++) core.inc[r] = incv[r];
+      core.propose_post();
+    }
+  }
+  if (lane == 0) s_flags[2] = core.done ? 1 : 0;
+}
+
+__global__ __launch_bounds__(LM_BLOCK) void k_track_lm(LmJob* __restrict__ jobs) {
+  LmJob& J = jobs[blockIdx.x];
+  __shared__ __align__(16) unsigned char core_raw[sizeof(LmCore)];     // (LmCore has member initialisers: raw storage, init() sets every field it reads)
+  LmCore& core = *reinterpret_cast<LmCore*>(core_raw);
+  __shared__ sdso_track_eval_t ev;
+  __shared__ float sF[LM_BLOCK / 64][TRK_NF + TRK_NI];
+  __shared__ float F[TRK_NF];
+  __shared__ int I[TRK_NI];
+  __shared__ int s_lvl, s_flags[3];
+  __shared__ TrackOut O;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (tid == 0) {
+    core.init(J.p, J.T, J.aff);
+    s_flags[2] = 0;
+  }
+  __syncthreads();
+  // every trip is one evaluation; the loop ends for all threads together (the done flag is read behind a barrier)
+#ifdef SDSO_LM_STAMPS
+  unsigned long long t_fill = 0, t_eval = 0, t_red = 0, t_step = 0, t0s = 0;
+#define LMT(acc) do { if (tid == 0) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); acc += tn - t0s; t0s = tn; } } while (0)
+  if (tid == 0) t0s = __builtin_amdgcn_s_memtime();
+#else
+#define LMT(acc) do { } while (0)
+#endif
+  for (int guard = 0; guard < 1024; guard++) {
+    if (tid == 0) {
+      fill_eval(core.p, core.lvl, core.reqT, core.reqAff, core.p.coarseCutoffTH * core.levelCutoffRepeat, ev);
+      s_lvl = core.lvl;
+      core.out.evaluations++;
+      core.out.point_evals += J.n[core.lvl];
+    }
+    __syncthreads();
+    LMT(t_fill);
+    const int lvl = s_lvl, n = J.n[lvl];
+    TrackLaneSums S;
+    track_accumulate<false>(ev, J.pc[lvl], J.img[lvl], n, tid, LM_BLOCK, nullptr, S);
+    LMT(t_eval);
+    {   // the four counters ride along as floats (exact: they stay far below 2^24), so one 52-value row reduction covers everything
+      float v52[TRK_NF + TRK_NI];
+#pragma unroll
+      for (int k = 0; k < 45; k++) v52[k] = S.acc[k];
+      v52[45] = S.E; v52[46] = S.sT; v52[47] = S.sRT;
+      v52[48] = (float)S.nE; v52[49] = (float)S.nSat; v52[50] = (float)S.nWarp; v52[51] = (float)S.nShift;
+      wave_reduce_rows<TRK_NF + TRK_NI>(v52, [&](int k, float sum) { sF[wv][k] = sum; });
+    }
+    __syncthreads();
+    if (tid < TRK_NF + TRK_NI) {        // fixed order over the waves: run-to-run reproducible
+      float sum = sF[0][tid];
+#pragma unroll
+      for (int w = 1; w < LM_BLOCK / 64; w++) sum += sF[w][tid];
+      if (tid < TRK_NF) F[tid] = sum; else I[tid - TRK_NF] = (int)sum;
+    }
+    __syncthreads();
+    LMT(t_red);
+    if (wv == 0) lm_wave_step(core, F, I, O, s_flags);
+    __syncthreads();
+    LMT(t_step);
+    if (s_flags[2]) break;
+  }
+#ifdef SDSO_LM_STAMPS
+  if (tid == 0) { core.out.lastFlowIndicators[0] = (double)t_fill; core.out.lastFlowIndicators[1] = (double)t_eval; core.out.lastFlowIndicators[2] = (double)t_red; core.out.lastResiduals[4] = (double)t_step; }
+#endif
+#undef LMT
+  if (tid == 0) {
+    J.out = core.out;
+    if (core.wrote_final) { J.T = core.T_final; J.aff = core.aff_final; }
+  }
+}
+
+namespace sdso {
+static int resolve_job(sdso_ctx* ctx, int ref_slot, int frame_slot, const sdso_track_params_t& p, LmJob& J) {
+  auto ir = ctx->refs.find(ref_slot);
+  SDSO_REQUIRE(ctx, ir != ctx->refs.end(), "unknown ref slot");
+  auto ip = ctx->pyr.find(frame_slot);
+  SDSO_REQUIRE(ctx, ip != ctx->pyr.end(), "unknown frame slot");
+  SDSO_REQUIRE(ctx, p.coarsestLvl < ip->second.levels, "level not in pyramid");
+  for (int l = 0; l < SDSO_PYR_LEVELS; l++) { J.pc[l] = nullptr; J.img[l] = nullptr; J.n[l] = 0; }
+  for (int l = 0; l <= p.coarsestLvl; l++) {
+    // the kernel indexes the image with (w,h) of the params: they must be the uploaded level's size
+    SDSO_REQUIRE(ctx, p.w[l] == ip->second.w[l] && p.h[l] == ip->second.h[l], "params w/h do not match the uploaded pyramid level");
+    J.pc[l] = ir->second.pc[l]; J.img[l] = ip->second.d[l]; J.n[l] = ir->second.n[l];
+  }
+  J.p = p;
+  return SDSO_OK;
+}
+}  // namespace sdso
+
+// the lock-step host driver (A/B and fallback for SDSO_TRK_HOST_LM=1)
+static int track_newest_coarse_host(sdso_ctx* ctx, int nhyp, const int* ref_slots, const int* frame_slots, const sdso_track_params_t* prms,
+                                    sdso_se3_t* lastToNew, sdso_aff_t* aff_g2l, sdso_track_result_t* outs) {
+  std::vector<LmCore> S(nhyp);
+  for (int k = 0; k < nhyp; k++) S[k].init(prms[k], lastToNew[k], aff_g2l[k]);
   std::vector<TrackProb> probs;
   std::vector<int> who;
   for (;;) {
     probs.clear(); who.clear();
     for (int k = 0; k < nhyp; k++) {
-      LmState& s = S[k];
+      LmCore& s = S[k];
       if (s.done) continue;
       sdso_track_eval_t ev;
       fill_eval(s.p, s.lvl, s.reqT, s.reqAff, s.p.coarseCutoffTH * s.levelCutoffRepeat, ev);
       TrackProb P;
-      int rc = resolve_prob(ctx, s.ref_slot, s.frame_slot, ev, P);
+      int rc = resolve_prob(ctx, ref_slots[k], frame_slots[k], ev, P);
       if (rc) return rc;
       probs.push_back(P); who.push_back(k);
-      s.out->evaluations++;
-      s.out->point_evals += P.n;
+      s.out.evaluations++;
+      s.out.point_evals += P.n;
     }
     if (probs.empty()) break;
     const int np = (int)probs.size();
@@ -694,6 +975,44 @@ extern "C" int sdso_track_newest_coarse_batch(sdso_ctx* ctx, int nhyp, const int
     const TrackOut* O = (const TrackOut*)ctx->pinned;
     for (int j = 0; j < np; j++) S[who[j]].consume(O[j]);
   }
+  for (int k = 0; k < nhyp; k++) {
+    outs[k] = S[k].out;
+    if (S[k].wrote_final) { lastToNew[k] = S[k].T_final; aff_g2l[k] = S[k].aff_final; }
+  }
+  return SDSO_OK;
+}
+
+extern "C" int sdso_track_newest_coarse_batch(sdso_ctx* ctx, int nhyp, const int* ref_slots, const int* frame_slots, const sdso_track_params_t* prms,
+                                              sdso_se3_t* lastToNew, sdso_aff_t* aff_g2l, sdso_track_result_t* outs) {
+  if (!ctx) return SDSO_ERR_STATE;
+  SDSO_HIP(ctx, hipSetDevice(ctx->device));
+  SDSO_REQUIRE(ctx, nhyp > 0 && ref_slots && frame_slots && prms && lastToNew && aff_g2l && outs, "null argument");
+  for (int k = 0; k < nhyp; k++)
+    SDSO_REQUIRE(ctx, prms[k].coarsestLvl >= 0 && prms[k].coarsestLvl < 5 && prms[k].coarsestLvl < prms[k].levels, "coarsestLvl out of range");  // assert :853
+  static const bool host_lm = getenv("SDSO_TRK_HOST_LM") != nullptr;
+  if (host_lm) return track_newest_coarse_host(ctx, nhyp, ref_slots, frame_slots, prms, lastToNew, aff_g2l, outs);
+  // resident driver: jobs through pinned memory, one launch, one synchronisation
+  int rc = ensure_pinned(ctx, sizeof(LmJob) * (size_t)nhyp);
+  if (rc) return rc;
+  rc = ensure_scratch(ctx, sizeof(LmJob) * (size_t)nhyp);
+  if (rc) return rc;
+  LmJob* hj = (LmJob*)ctx->pinned;
+  for (int k = 0; k < nhyp; k++) {
+    rc = resolve_job(ctx, ref_slots[k], frame_slots[k], prms[k], hj[k]);
+    if (rc) return rc;
+    hj[k].T = lastToNew[k]; hj[k].aff = aff_g2l[k];
+  }
+  if (ctx->tb) ctx->tb->nprob = 0;   // (a prepared evaluation batch keeps its own buffers; nothing shared)
+  LmJob* dj = (LmJob*)ctx->scratch;
+  SDSO_HIP(ctx, hipMemcpyAsync(dj, hj, sizeof(LmJob) * nhyp, hipMemcpyHostToDevice, ctx->stream));
+  {
+    ProfScope ps(ctx, "k_track_lm");
+    hipLaunchKernelGGL(k_track_lm, dim3(nhyp), dim3(LM_BLOCK), 0, ctx->stream, dj);
+  }
+  SDSO_HIP(ctx, hipGetLastError());
+  SDSO_HIP(ctx, hipMemcpyAsync(hj, dj, sizeof(LmJob) * nhyp, hipMemcpyDeviceToHost, ctx->stream));
+  SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (int k = 0; k < nhyp; k++) { outs[k] = hj[k].out; lastToNew[k] = hj[k].T; aff_g2l[k] = hj[k].aff; }
   return SDSO_OK;
 }
 
