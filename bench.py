@@ -211,6 +211,8 @@ def main():
     ap.add_argument("--workload", default=os.environ.get("SDSO_BENCH_WORKLOAD", "ba"), choices=["ba", "tracker", "trace"])
     ap.add_argument("--batch", type=int, default=0, help="independent problems (frames / windows / pairs) per step and GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scaling", default=os.environ.get("SDSO_BENCH_SCALING", "weak"), choices=["weak", "strong"],
+                    help="BA at --gpus N: weak = 2000 points per window and rank (default); strong = BASELINE configs[4], 8000 points per window cut N ways")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -284,7 +286,7 @@ def main():
         out = {
             "metric": "point-residuals/sec (8-pix patches) per GN iter; windowed-BA iters/sec, 8KF window",
             "value": value, "unit": wl.unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": getattr(wl, "scaling", "weak"),
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": wl.config,
             "roofline": {"bound": "hbm", "kernel": wl.kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -1,10 +1,18 @@
-"""Windowed-BA workload of bench.py (BASELINE configs[2] at N=1, configs[4]-style sharding at N>1).
+"""Windowed-BA workload of bench.py (BASELINE configs[2] at N=1, configs[4] sharding at N>1).
 
 One step = one DSO-native Gauss-Newton iteration of EnergyFunctional for `batch` independent
-8-keyframe windows: linearizeAll + applyRes + accumulateAF/LF/SCF (+ RCCL all-reduce of the packed
-accumulators when the points of every window are sharded over N ranks) + stitch + solveSystemF +
-resubstituteF.  Per-GPU work is fixed (2000 points ~ 12.5k point-residuals per window and rank), so
-the global window grows with N (weak scaling); the all-reduce payload is batch x 184 KiB.
+8-keyframe windows: linearizeAll + applyRes + accumulateAF/LF/SCF (+ ONE RCCL all-reduce of the packed
+accumulators, issued by the library itself: sdso_ba_allreduce, when the points of every window are
+sharded over N ranks) + stitch + solveSystemF + resubstituteF.
+
+Multi-GPU: every window of the batch is ONE global window whose allPoints are cut into N contiguous
+ranges (sdso_amd/dist.py), so after the all-reduce every rank solves the system of the unsharded
+window; rank 0 checks that against a single-GPU, un-fused solve of the same global window
+(`extra.sharded_x_whitened_err`).
+  --scaling weak  (default) 2000 points per window AND RANK: the global window has 2000 N points
+                  (BASELINE configs[2] at N=1), per-GPU work fixed;
+  --scaling strong          BASELINE configs[4]: 8 keyframes x 8000 points in total, cut 1/2/4/8 ways.
+The all-reduce payload is batch x 184 KiB.
 
 The batch is split into two groups, each on its own sdso_ctx (= its own HIP stream).  The
 bandwidth-bound accumulate phases of the two groups are chained by events (A, B, A, B, ...), so the
@@ -41,10 +49,18 @@ class BAWorkload:
         from sdso_amd import abi, synth
         self.ctx, self.abi, self.world, self.torch = ctx, abi, world, torch
         t0 = time.time()
-        nwin = args.batch or 128   # enough independent windows that the working set is >> the 256 MB MALL
+        from sdso_amd import dist as sdist
+        self.scaling = getattr(args, "scaling", "weak")
+        strong = self.scaling == "strong"
+        nwin = args.batch or (32 if strong else 128)   # enough independent windows that the working set is >> the 256 MB MALL
         ngroups = max(1, min(int(os.environ.get("SDSO_BA_GROUPS", "2")), nwin))
-        win = synth.ba_window(w=1232, h=368, nf=8, pts_per_kf=250, seed=3001, point_seed=(3001 + 131 * rank) if world > 1 else None)
+        if strong:
+            self.name = "windowed_ba_8kf_8kpts_sharded"
+        # the GLOBAL window (identical on every rank) and this rank's contiguous share of its points
+        self.win_global = synth.ba_window(w=1232, h=368, nf=8, pts_per_kf=1000 if strong else 250 * world, seed=3001)
+        win = self.win_global if world == 1 else sdist.shard_window(self.win_global, rank, world)[0]
         self.win = win
+        self.rank = rank
         nf = win["nf"]
         rs = np.random.RandomState(11)
         self.materialize = 0 if os.environ.get("SDSO_BA_NO_J") == "1" else 1
@@ -77,15 +93,37 @@ class BAWorkload:
             G.ctx.check(G.ctx.L.sdso_ba_batch_accum_dev(G.ctx.h, C.byref(ptr), C.byref(nfl)))
             nfl_total += int(nfl.value)
             G.stream = torch.cuda.ExternalStream(G.ctx.L.sdso_ctx_stream(G.ctx.h))
-            G.accum = torch.as_tensor(_DevBlob(ptr.value, nfl.value), device="cuda") if world > 1 else None
+            G.accum = None
             G.ev = torch.cuda.Event()
             self.groups.append(G)
+        # communicator: RCCL inside the library (backend nccl).  With SDSO_DIST_BACKEND=gloo (rehearsal of the multi-rank path on a
+        # box with fewer GPUs than ranks: RCCL refuses two ranks on one device) the block is all-reduced through torch instead.
+        self.lib_comm = world > 1 and os.environ.get("SDSO_DIST_BACKEND", "nccl") == "nccl"
+        if world > 1:
+            import torch.distributed as dist
+            if self.lib_comm:
+                uid = np.zeros(128, np.uint8)
+                if rank == 0:
+                    ctx.check(ctx.L.sdso_comm_unique_id(uid.ctypes.data_as(C.c_void_p)))
+                t = torch.from_numpy(uid).cuda()
+                dist.broadcast(t, src=0)
+                uid = t.cpu().numpy().copy()
+                g0 = self.groups[0]
+                g0.ctx.check(g0.ctx.L.sdso_comm_init(g0.ctx.h, world, rank, uid.ctypes.data_as(C.c_void_p)))
+                for G in self.groups[1:]:
+                    G.ctx.check(G.ctx.L.sdso_comm_attach(G.ctx.h, g0.ctx.h))
+            else:
+                for G in self.groups:
+                    ptr, nfl = C.c_void_p(), C.c_long(0)
+                    G.ctx.check(G.ctx.L.sdso_ba_batch_accum_dev(G.ctx.h, C.byref(ptr), C.byref(nfl)))
+                    G.accum = torch.as_tensor(_DevBlob(ptr.value, nfl.value), device="cuda")
         self.nwin = nwin
         self.units_per_step = nwin * win["nr"]
         self.config = {"workload": self.name, "windows_per_step": nwin, "keyframes": nf, "points_per_window_per_gpu": win["np"],
-                       "residuals_per_window_per_gpu": win["nr"], "jacobians_materialized": bool(self.materialize), "stream_groups": ngroups,
+                       "residuals_per_window_per_gpu": win["nr"], "points_per_global_window": self.win_global["np"],
+                       "jacobians_materialized": bool(self.materialize), "stream_groups": ngroups,
                        "allreduce_floats": nfl_total if world > 1 else 0,
-                       "parallelism": ("points sharded over %d ranks, 1 RCCL all-reduce of the packed accumulators per group and iteration" % world) if world > 1 else "single GPU"}
+                       "parallelism": ("allPoints of every window cut into %d contiguous ranges, 1 RCCL all-reduce (sdso_ba_allreduce) of the packed accumulators per group and iteration" % world) if world > 1 else "single GPU"}
         print("[rank %d] BA setup %.1fs: %d windows x %d residuals in %d stream group(s)" % (rank, time.time() - t0, nwin, win["nr"], ngroups), file=sys.stderr, flush=True)
 
     # bench.py drives profiling / synchronisation through these so that every group's ctx is covered
@@ -124,7 +162,9 @@ class BAWorkload:
                 G.ev.record(G.stream)                 # ... and everything enqueued below overlaps the next group's accumulate
                 # (recording already after the linearisation, with the Schur kernel in the overlapped tail, was measured
                 # slower: 0.97 vs 0.91 ms — the Schur kernel competes for HBM with the other group's linearisation)
-            if G.accum is not None:
+            if self.lib_comm:
+                G.ctx.check(G.ctx.L.sdso_ba_allreduce(G.ctx.h))        # RCCL over xGMI, enqueued on the ctx stream by the library
+            elif G.accum is not None:
                 import torch.distributed as dist
                 with self.torch.cuda.stream(G.stream):
                     dist.all_reduce(G.accum, op=dist.ReduceOp.SUM)
@@ -132,14 +172,34 @@ class BAWorkload:
             prev = G
 
     def verify(self):
+        """x of every window is finite; window 0's x (fused batch path, summed over the ranks when sharded) equals the x of the
+        UNSHARDED global window solved through the un-fused single-window entry points on this GPU (2e-4 in the whitened metric,
+        the bar of tests/test_ba_gpu.py)."""
+        abi = self.abi
         out = {"jacobians_materialized": bool(self.materialize)}
-        mx = 0.0
+        mx, x0 = 0.0, None
         for G in self.groups:
             x = np.zeros((G.nwin, 68))
-            G.ctx.check(G.ctx.L.sdso_ba_batch_get_x(G.ctx.h, self.abi.dp(x)))
+            G.ctx.check(G.ctx.L.sdso_ba_batch_get_x(G.ctx.h, abi.dp(x)))
             assert np.isfinite(x).all() and np.abs(x).max() > 0
             mx = max(mx, float(np.abs(x).max()))
+            if x0 is None:
+                x0 = x[0].copy()
         out["max_abs_x"] = mx
+        if self.rank == 0:
+            g0, wg, nf = self.groups[0], self.win_global, self.win_global["nf"]
+            W, keep = abi.make_ba_window(wg, frame_slots=[1000 + f for f in range(nf)])          # the pyramids of window 0
+            g0.ctx.check(g0.ctx.L.sdso_ba_upload_window(g0.ctx.h, 9000, C.byref(W)))
+            g0.ctx.check(g0.ctx.L.sdso_ba_linearize(g0.ctx.h, 9000, None))
+            g0.ctx.check(g0.ctx.L.sdso_ba_apply_res(g0.ctx.h, 9000))
+            g0.ctx.check(g0.ctx.L.sdso_ba_accumulate(g0.ctx.h, 9000))
+            xr, Hr = np.zeros(68), np.zeros((68, 68))
+            g0.ctx.check(g0.ctx.L.sdso_ba_solve(g0.ctx.h, 9000, 0, 1e-5, abi.dp(xr), abi.dp(Hr), None, None, None))
+            g0.ctx.check(g0.ctx.L.sdso_ba_release_window(g0.ctx.h, 9000))
+            d = np.sqrt(np.abs(np.diag(Hr))) + 1e-30
+            err = float(np.abs((x0 - xr) * d).max() / max(1.0, np.abs(xr * d).max()))
+            out["sharded_x_whitened_err" if self.world > 1 else "fused_vs_unfused_x_whitened_err"] = err
+            assert err <= 2e-4, "x of window 0 differs from the unsharded / un-fused reference solve: %g" % err
         for k in ("k_ba_lin_fused", "k_ba_sc"):
             ms, n = self.prof_read(k)
             out[k + "_avg_ms"] = ms / max(n, 1)
@@ -148,7 +208,8 @@ class BAWorkload:
     def cpu_baseline(self, warmup=5, reps=50):
         """SURVEY §8d protocol: the oracle port (-O3 -march=native) on one window, 5 warm-up + 50 timed GN iterations per leg,
         median / p10 / p90; legs = 1 thread, 6 threads (the reference's NUM_THREADS, util/NumType.h:38; IndexThreadReduce work
-        stealing with chunks of 50 points and per-thread accumulator copies, EnergyFunctional.cpp:212-269) and all host cores.
+        stealing with chunks of 50 points and per-thread accumulator copies, EnergyFunctional.cpp:212-269), 16, 64 and all host cores
+        (the reference's condition-variable pool stops scaling long before a 256-thread host is full; the legs show where).
         `value` is the fastest leg's median rate, `cores` the threads that leg used."""
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import pyoracle  # cpu_baseline leg only
@@ -170,7 +231,7 @@ class BAWorkload:
         except OSError:
             pass
         legs = []
-        for nt in sorted({1, 6, nproc}):
+        for nt in sorted({1, 6, min(16, nproc), min(64, nproc), nproc}):
             h = orc.orc_ba_create(C.byref(W))
             orc.orc_ba_set_threads(h, nt)
             x = np.zeros(68)
@@ -189,5 +250,6 @@ class BAWorkload:
         best = max(legs, key=lambda l: l["point_residuals_per_s"])
         return {"value": best["point_residuals_per_s"], "unit": self.unit, "cores": best["threads"], "kind": "port",
                 "sample": "%d warm-up + %d timed GN iterations (linearizeAll + applyRes + accumulate A/L/SC + stitch + solve + resubstitute) of one "
-                          "8KF/2000-point window (%d residuals) per leg, oracle -O3 -march=native; median of the fastest leg" % (warmup, reps, win["nr"]),
+                          "%dKF/%d-point window (%d residuals) per leg, oracle -O3 -march=native; median of the fastest leg"
+                          % (warmup, reps, win["nf"], win["np"], win["nr"]),
                 "cpu_model": model, "nproc": nproc, "legs": legs, "ba_iters_per_s": best["ba_iters_per_s"]}

@@ -306,6 +306,29 @@ int sdso_ba_batch_solve(sdso_ctx* ctx, double lambda, int orthogonalize_x);
 int sdso_ba_batch_accum_dev(sdso_ctx* ctx, void** dev_ptr, long* nfloats);
 int sdso_ba_batch_get_x(sdso_ctx* ctx, double* x /* nwin*(8nf+4) */);
 
+/* ------------------------------------------------------------------ multi-GPU exchange
+ * The points of every window are sharded over the ranks (one process per GPU, contiguous allPoints ranges, every rank holds all
+ * pyramids and frame states); the packed accumulators are plain sums over points — the reference adds the per-thread copies the same
+ * way before it stitches (AccumulatedTopHessian.cpp:299-308, AccumulatedSCHessian.cpp:136-185) — so ONE all-reduce(sum, float32) per
+ * Gauss-Newton iteration over RCCL / xGMI makes every rank stitch and solve the same system:
+ *     sdso_ba_batch_accumulate -> sdso_ba_allreduce -> sdso_ba_batch_solve           (all three only enqueue on the ctx stream)
+ * RCCL is loaded (dlopen) by the first of these calls; single-GPU users never need it.
+ *   sdso_comm_unique_id : rank 0 creates the 128-byte ncclUniqueId; the caller ships it to the other ranks (MPI, sockets, a file ...)
+ *   sdso_comm_init      : collective over the nranks processes; binds the communicator to ctx (its device, its stream)
+ *   sdso_comm_attach    : a second ctx of the same process / device uses the communicator of `owner`
+ *   sdso_ba_allreduce   : in-place sum of the batch's contiguous block (sdso_ba_batch_accum_dev) over the ranks
+ *   sdso_ba_allreduce_window : the same for one window's block (sdso_ba_accum_dev), between sdso_ba_accumulate and sdso_ba_solve
+ * A single-iteration exchange sums everything solveSystemF needs.  The energy threshold of the newest frame (setNewFrameEnergyTH,
+ * FullSystemOptimize.cpp:98-139: a 70 % quantile over its residuals) is NOT additive: a multi-iteration loop over sharded points has to
+ * gather those energies as well (not provided; sdso_ba_optimize is a single-rank call). */
+int sdso_comm_unique_id(void* id128);
+int sdso_comm_init(sdso_ctx* ctx, int nranks, int rank, const void* id128);
+int sdso_comm_attach(sdso_ctx* ctx, sdso_ctx* owner);
+int sdso_comm_info(sdso_ctx* ctx, int* nranks, int* rank);   /* nranks = 0 without a communicator */
+int sdso_comm_destroy(sdso_ctx* ctx);
+int sdso_ba_allreduce(sdso_ctx* ctx);
+int sdso_ba_allreduce_window(sdso_ctx* ctx, int win);
+
 /* host tables derived from the frame states (tests): precalc nf*nf*27 floats per (host*nf+target)
  * {PRE_KRKiTll 9, PRE_KtTll 3, PRE_RTll_0 9, PRE_tTll_0 3, PRE_aff_mode 2, PRE_b0_mode 1}
  * (FrameFramePrecalc::set, HessianBlocks.cpp:206-242); adHost/adTarget nf*nf*64 doubles and

@@ -1084,6 +1084,22 @@ static const BaLaunch& batch_launch(BaBatch* Bt) {
   return Bt->L;
 }
 }  // namespace sdso
+namespace sdso {
+// comm.hip: the blocks the RCCL all-reduce sums in place
+void* ba_batch_accum_block(sdso_ctx* ctx, size_t* nfloats) {
+  BaBatch* Bt = get_batch(ctx);
+  if (!Bt) return nullptr;
+  *nfloats = acc_floats(Bt->L.nf) * Bt->wins.size();
+  return Bt->d_accum;
+}
+void* ba_window_accum_block(sdso_ctx* ctx, int win, size_t* nfloats) {
+  BaWindowDev* W = find_win(ctx, win);
+  if (!W) return nullptr;
+  *nfloats = acc_floats(W->d.nf);
+  W->accumulated = true;
+  return W->d.accum;
+}
+}  // namespace sdso
 // phase 1 of one GN iteration for every window of the batch: linearize + applyRes + accumulate A/L/SC (enqueue only)
 extern "C" int sdso_ba_batch_accumulate(sdso_ctx* ctx) {
   BaBatch* Bt = get_batch(ctx);

@@ -1,0 +1,160 @@
+// Multi-GPU exchange step of the windowed BA inside the library.
+//
+// Every accumulator of the window is a plain sum over points, and the reference sums per-thread partial copies before it
+// stitches (src/OptimizationBackend/AccumulatedTopHessian.cpp:299-308, AccumulatedSCHessian.cpp:136-185).  With the points of a
+// window sharded over ranks the same sum runs across GPUs: ONE ncclAllReduce(sum, float32) over xGMI of the packed accumulator
+// block [topA | topL | accD | accE | accEB | Hcc | bc | nres] of every window of the batch (contiguous: one collective however many
+// windows), enqueued on the context's stream between sdso_ba_batch_accumulate and sdso_ba_batch_solve; every rank then stitches and
+// solves the same system.  A C++ FullSystem needs nothing but these entry points — no Python, no torch.
+//
+// RCCL is resolved with dlopen at sdso_comm_init (librccl.so.1; a process that already carries an RCCL, e.g. through
+// torch.distributed, gets that copy): libsdso_hip.so itself has no link-time dependency on it and single-GPU users never load it.
+#include "sdso_internal.h"
+#include <dlfcn.h>
+#include <cstring>
+#include <rccl/rccl.h>
+#include <map>
+#include <memory>
+
+namespace sdso {
+void* ba_batch_accum_block(sdso_ctx* ctx, size_t* nfloats);            // ba.hip
+void* ba_window_accum_block(sdso_ctx* ctx, int win, size_t* nfloats);  // ba.hip
+
+struct RcclApi {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+static RcclApi* rccl_api(std::string* why) {
+  static RcclApi api;
+  static bool tried = false;
+  static std::string err;
+  if (!tried) {
+    tried = true;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (api.lib) break;
+    }
+    if (!api.lib) err = std::string("RCCL not found: ") + (dlerror() ? dlerror() : "dlopen failed");
+    else {
+      api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.lib, "ncclGetUniqueId");
+      api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.lib, "ncclCommInitRank");
+      api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.lib, "ncclCommDestroy");
+      api.AllReduce = (decltype(api.AllReduce))dlsym(api.lib, "ncclAllReduce");
+      api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.lib, "ncclGetErrorString");
+      if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllReduce) { err = "RCCL symbols missing"; api.lib = nullptr; }
+    }
+  }
+  if (!api.lib) { if (why) *why = err; return nullptr; }
+  return &api;
+}
+
+// one communicator may serve several contexts of a process (e.g. the two stream groups of bench.py): collectives on one
+// communicator are issued in the same order on every rank, whatever stream they run on
+struct Comm {
+  ncclComm_t comm = nullptr;
+  int nranks = 1, rank = 0, device = 0;
+  ~Comm() { if (comm) { RcclApi* a = rccl_api(nullptr); if (a) a->CommDestroy(comm); } }
+};
+static std::map<sdso_ctx*, std::shared_ptr<Comm>> g_comms;
+void release_comm(sdso_ctx* ctx) {
+  std::lock_guard<std::mutex> g(registry_mutex());
+  g_comms.erase(ctx);
+}
+static std::shared_ptr<Comm> comm_of(sdso_ctx* ctx) {
+  std::lock_guard<std::mutex> g(registry_mutex());
+  auto it = g_comms.find(ctx);
+  return it == g_comms.end() ? nullptr : it->second;
+}
+}  // namespace sdso
+
+using namespace sdso;
+
+#define SDSO_NCCL(ctx, api, expr)                                                                                              \
+  do {                                                                                                                         \
+    ncclResult_t _r = (expr);                                                                                                  \
+    if (_r != ncclSuccess) return sdso::fail(ctx, SDSO_ERR_HIP, std::string(#expr) + ": " + ((api)->GetErrorString ? (api)->GetErrorString(_r) : "RCCL error")); \
+  } while (0)
+
+extern "C" int sdso_comm_unique_id(void* id128) {
+  if (!id128) return SDSO_ERR_ARG;
+  RcclApi* a = rccl_api(nullptr);
+  if (!a) return SDSO_ERR_STATE;
+  ncclUniqueId id;
+  if (a->GetUniqueId(&id) != ncclSuccess) return SDSO_ERR_HIP;
+  static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
+  std::memcpy(id128, &id, sizeof(id));
+  return SDSO_OK;
+}
+
+extern "C" int sdso_comm_init(sdso_ctx* ctx, int nranks, int rank, const void* id128) {
+  if (!ctx) return SDSO_ERR_STATE;
+  SDSO_REQUIRE(ctx, nranks >= 1 && rank >= 0 && rank < nranks && id128, "bad communicator arguments");
+  SDSO_HIP(ctx, hipSetDevice(ctx->device));
+  std::string why;
+  RcclApi* a = rccl_api(&why);
+  if (!a) return sdso::fail(ctx, SDSO_ERR_STATE, why);
+  release_comm(ctx);
+  auto c = std::make_shared<Comm>();
+  c->nranks = nranks; c->rank = rank; c->device = ctx->device;
+  ncclUniqueId id;
+  std::memcpy(&id, id128, sizeof(id));
+  SDSO_NCCL(ctx, a, a->CommInitRank(&c->comm, nranks, id, rank));
+  std::lock_guard<std::mutex> g(registry_mutex());
+  g_comms[ctx] = c;
+  return SDSO_OK;
+}
+
+extern "C" int sdso_comm_attach(sdso_ctx* ctx, sdso_ctx* owner) {
+  if (!ctx || !owner) return SDSO_ERR_STATE;
+  auto c = comm_of(owner);
+  SDSO_REQUIRE(ctx, c, "the owner context has no communicator");
+  SDSO_REQUIRE(ctx, c->device == ctx->device, "contexts that share a communicator must sit on the same device");
+  std::lock_guard<std::mutex> g(registry_mutex());
+  g_comms[ctx] = c;
+  return SDSO_OK;
+}
+
+extern "C" int sdso_comm_info(sdso_ctx* ctx, int* nranks, int* rank) {
+  if (!ctx) return SDSO_ERR_STATE;
+  auto c = comm_of(ctx);
+  if (nranks) *nranks = c ? c->nranks : 0;
+  if (rank) *rank = c ? c->rank : -1;
+  return SDSO_OK;
+}
+
+extern "C" int sdso_comm_destroy(sdso_ctx* ctx) {
+  if (!ctx) return SDSO_ERR_STATE;
+  hipStreamSynchronize(ctx->stream);
+  release_comm(ctx);
+  return SDSO_OK;
+}
+
+static int allreduce_block(sdso_ctx* ctx, void* ptr, size_t nfloats) {
+  auto c = comm_of(ctx);
+  SDSO_REQUIRE(ctx, c, "no communicator: call sdso_comm_init (or sdso_comm_attach) first");
+  SDSO_REQUIRE(ctx, ptr && nfloats > 0, "nothing to reduce");
+  RcclApi* a = rccl_api(nullptr);
+  SDSO_HIP(ctx, hipSetDevice(ctx->device));
+  SDSO_NCCL(ctx, a, a->AllReduce(ptr, ptr, nfloats, ncclFloat32, ncclSum, c->comm, ctx->stream));
+  return SDSO_OK;
+}
+
+extern "C" int sdso_ba_allreduce(sdso_ctx* ctx) {
+  if (!ctx) return SDSO_ERR_STATE;
+  size_t n = 0;
+  void* p = ba_batch_accum_block(ctx, &n);
+  SDSO_REQUIRE(ctx, p, "no batch: sdso_ba_batch_create first");
+  return allreduce_block(ctx, p, n);
+}
+
+extern "C" int sdso_ba_allreduce_window(sdso_ctx* ctx, int win) {
+  if (!ctx) return SDSO_ERR_STATE;
+  size_t n = 0;
+  void* p = ba_window_accum_block(ctx, win, &n);
+  SDSO_REQUIRE(ctx, p, "unknown window");
+  return allreduce_block(ctx, p, n);
+}

@@ -114,6 +114,7 @@ void release_trace(sdso_ctx* ctx);
 void release_match(sdso_ctx* ctx);
 void release_selector(sdso_ctx* ctx);
 void release_g2o(sdso_ctx* ctx);
+void release_comm(sdso_ctx* ctx);
 }
 
 extern "C" void sdso_ctx_destroy(sdso_ctx* ctx) {
@@ -131,6 +132,7 @@ extern "C" void sdso_ctx_destroy(sdso_ctx* ctx) {
   release_match(ctx);
   release_selector(ctx);
   release_g2o(ctx);
+  release_comm(ctx);
   if (ctx->scratch) hipFree(ctx->scratch);
   if (ctx->pinned) hipHostFree(ctx->pinned);
   hipStreamDestroy(ctx->stream);

@@ -54,6 +54,12 @@ class Device {
   void releaseFrame(int slot) { sdso_release_pyramid(ctx_, slot); }
   // traceStereo's sub-pixel refinement: false = DSO-native GN (ImmaturePoint.cpp:707-769), true = the fork's g2o GN on
   // EdgeTracePointUVDSO (ImmaturePoint.cpp:309-412)
+  // Multi-GPU: one process per GPU; rank 0 makes the id (static uniqueId()), the caller ships the 128 bytes to the other ranks,
+  // then every rank calls commInit (collective).  RCCL is resolved at run time; a missing librccl is an error, not a fallback.
+  static void uniqueId(unsigned char id[128]) {
+    if (sdso_comm_unique_id(id) != SDSO_OK) throw Error("sdso_comm_unique_id failed (librccl.so.1 not loadable?)");
+  }
+  void commInit(int nranks, int rank, const unsigned char id[128]) { check(sdso_comm_init(ctx_, nranks, rank, id), "sdso_comm_init"); }
   void setForkLiveTraceRefinement(bool on) { check(sdso_trace_set_gn_mode(ctx_, on ? 1 : 0), "sdso_trace_set_gn_mode"); }
 
  private:
@@ -232,10 +238,19 @@ class WindowedBA {
   // applyRes_Reductor(true, ...)
   void applyRes() { dev_.check(sdso_ba_apply_res(dev_.ctx(), win_), "sdso_ba_apply_res"); }
   // EnergyFunctional::solveSystemF(iteration, lambda, HCalib): fills lastX; frame / calib / point steps are fetched below
+  // Multi-GPU: when this process holds only a contiguous range of allPoints, sum the packed accumulators over the
+  // ranks before the stitch — what stitchDoubleMT does with the per-thread copies (AccumulatedTopHessian.cpp:299-308), across GPUs.
+  // Device::commInit must have been called (sdso_comm_unique_id / sdso_comm_init); a no-op without a communicator.
+  void allreduce() {
+    int nranks = 0;
+    dev_.check(sdso_comm_info(dev_.ctx(), &nranks, nullptr), "sdso_comm_info");
+    if (nranks > 1) dev_.check(sdso_ba_allreduce_window(dev_.ctx(), win_), "sdso_ba_allreduce_window");
+  }
   void solveSystemF(int iteration, double lambda, std::vector<double>& lastX, std::vector<double>& frame_step, double calib_step[4]) {
     const int n = 8 * nf_ + 4;
     lastX.assign(n, 0); frame_step.assign(nf_ * 8, 0);
     dev_.check(sdso_ba_accumulate(dev_.ctx(), win_), "sdso_ba_accumulate");
+    allreduce();
     dev_.check(sdso_ba_solve(dev_.ctx(), win_, iteration, lambda, lastX.data(), nullptr, nullptr, frame_step.data(), calib_step), "sdso_ba_solve");
   }
   // float FullSystem::optimize(int mnumOptIts): writes states / idepths / residual states back into the reference objects

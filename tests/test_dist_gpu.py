@@ -107,3 +107,70 @@ def test_accumulator_block_is_aliased_by_torch(gpu_ctx):
     after = np.zeros(nfl.value, np.float32)
     gpu_ctx.check(gpu_ctx.L.sdso_ba_get_accumulators(gpu_ctx.h, 30, abi.fp(after)))   # ctx stream: ordered after the torch op
     assert np.array_equal(after, 2.0 * before)
+
+
+@pytest.mark.gpu
+def test_library_allreduce_one_rank_is_identity():
+    """The RCCL exchange inside the library (sdso_comm_* / sdso_ba_allreduce, csrc/comm.hip): a 1-rank communicator's sum is the
+    identity, bit for bit, on the batch block and on one window's block; a second ctx of the process attaches to the same
+    communicator; without a communicator the call is refused (SDSO_ERR_STATE), never silently skipped."""
+    from sdso_amd import abi, synth
+    ctx, ctx2 = abi.Context(0), abi.Context(0)
+    try:
+        L = ctx.L
+        win = synth.ba_window(w=320, h=240, nf=4, pts_per_kf=40, seed=3093)
+        nf = win["nf"]
+        for c in (ctx, ctx2):
+            for f in range(nf):
+                c.upload_pyramid(320 + f, win["pyrs"][f][:1])
+        W, keep = abi.make_ba_window(win, frame_slots=[320 + f for f in range(nf)])
+        ids = np.array([33], np.int32)
+        for c in (ctx, ctx2):
+            c.check(L.sdso_ba_upload_window(c.h, 33, C.byref(W)))
+            c.check(L.sdso_ba_batch_create(c.h, 1, abi.ip(ids)))
+            c.check(L.sdso_ba_batch_accumulate(c.h))
+        assert L.sdso_ba_allreduce(ctx.h) != 0                # no communicator yet: an error, not a no-op
+        nr, rk = C.c_int(-5), C.c_int(-5)
+        ctx.check(L.sdso_comm_info(ctx.h, C.byref(nr), C.byref(rk)))
+        assert (nr.value, rk.value) == (0, -1)
+        uid = (C.c_ubyte * 128)()
+        assert L.sdso_comm_unique_id(uid) == 0
+        assert any(uid)
+        ctx.check(L.sdso_comm_init(ctx.h, 1, 0, uid))
+        ctx2.check(L.sdso_comm_attach(ctx2.h, ctx.h))
+        for c in (ctx, ctx2):
+            c.check(L.sdso_comm_info(c.h, C.byref(nr), C.byref(rk)))
+            assert (nr.value, rk.value) == (1, 0)
+        n = 8 * nf + 4
+        xs = []
+        for c in (ctx, ctx2):
+            before, after = np.zeros(abi.accum_floats(nf), np.float32), np.zeros(abi.accum_floats(nf), np.float32)
+            c.check(L.sdso_ba_get_accumulators(c.h, 33, abi.fp(before)))
+            assert np.abs(before).max() > 0
+            c.check(L.sdso_ba_allreduce(c.h))
+            c.check(L.sdso_ba_get_accumulators(c.h, 33, abi.fp(after)))
+            assert np.array_equal(before, after)
+            c.check(L.sdso_ba_batch_solve(c.h, 0.1, 0))
+            x = np.zeros(n)
+            c.check(L.sdso_ba_batch_get_x(c.h, abi.dp(x)))
+            xs.append(x)
+        assert np.array_equal(xs[0], xs[1]) and np.abs(xs[0]).max() > 0
+        # the per-window form, between sdso_ba_accumulate and sdso_ba_solve (the shim's WindowedBA::allreduce)
+        ctx.check(L.sdso_ba_upload_window(ctx.h, 34, C.byref(W)))
+        ctx.check(L.sdso_ba_linearize(ctx.h, 34, None))
+        ctx.check(L.sdso_ba_apply_res(ctx.h, 34))
+        ctx.check(L.sdso_ba_accumulate(ctx.h, 34))
+        before, after = np.zeros(abi.accum_floats(nf), np.float32), np.zeros(abi.accum_floats(nf), np.float32)
+        ctx.check(L.sdso_ba_get_accumulators(ctx.h, 34, abi.fp(before)))
+        assert np.abs(before).max() > 0
+        ctx.check(L.sdso_ba_allreduce_window(ctx.h, 34))
+        ctx.check(L.sdso_ba_get_accumulators(ctx.h, 34, abi.fp(after)))
+        assert np.array_equal(before, after)
+        # destroying the owner's handle keeps the communicator alive for the attached ctx
+        ctx.check(L.sdso_comm_destroy(ctx.h))
+        ctx2.check(L.sdso_ba_allreduce(ctx2.h))
+        ctx2.check(L.sdso_comm_destroy(ctx2.h))
+        assert L.sdso_ba_allreduce(ctx2.h) != 0
+    finally:
+        ctx2.close()
+        ctx.close()
