@@ -101,18 +101,40 @@ class BAWorkload:
         self.lib_comm = world > 1 and os.environ.get("SDSO_DIST_BACKEND", "nccl") == "nccl"
         if world > 1:
             import torch.distributed as dist
+            self.exchange = "torch.distributed all_reduce on the library's device block (SDSO_DIST_BACKEND != nccl)"
             if self.lib_comm:
-                uid = np.zeros(128, np.uint8)
-                if rank == 0:
-                    ctx.check(ctx.L.sdso_comm_unique_id(uid.ctypes.data_as(C.c_void_p)))
+                # any rank that cannot open the library communicator (librccl not loadable ...) sends every rank to the torch
+                # collective on the same block: the line is then still measured, and says so in config.exchange
+                ok, why = 1, ""
+                try:
+                    uid = np.zeros(128, np.uint8)
+                    if rank == 0:
+                        ctx.check(ctx.L.sdso_comm_unique_id(uid.ctypes.data_as(C.c_void_p)))
+                except RuntimeError as e:
+                    ok, why = 0, str(e)
                 t = torch.from_numpy(uid).cuda()
                 dist.broadcast(t, src=0)
                 uid = t.cpu().numpy().copy()
                 g0 = self.groups[0]
-                g0.ctx.check(g0.ctx.L.sdso_comm_init(g0.ctx.h, world, rank, uid.ctypes.data_as(C.c_void_p)))
-                for G in self.groups[1:]:
-                    G.ctx.check(G.ctx.L.sdso_comm_attach(G.ctx.h, g0.ctx.h))
-            else:
+                if ok:
+                    try:
+                        g0.ctx.check(g0.ctx.L.sdso_comm_init(g0.ctx.h, world, rank, uid.ctypes.data_as(C.c_void_p)))
+                        for G in self.groups[1:]:
+                            G.ctx.check(G.ctx.L.sdso_comm_attach(G.ctx.h, g0.ctx.h))
+                    except RuntimeError as e:
+                        ok, why = 0, str(e)
+                flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if int(flag.item()) == 1:
+                    self.exchange = "sdso_ba_allreduce (RCCL communicator owned by libsdso_hip.so)"
+                else:
+                    print("[rank %d] library communicator unavailable (%s): torch.distributed all_reduce on the same block" % (rank, why or "another rank failed"),
+                          file=sys.stderr, flush=True)
+                    for G in self.groups:
+                        G.ctx.L.sdso_comm_destroy(G.ctx.h)
+                    self.lib_comm = False
+                    self.exchange = "torch.distributed all_reduce (RCCL) on the library's device block; library communicator failed: " + (why or "on another rank")
+            if not self.lib_comm:
                 for G in self.groups:
                     ptr, nfl = C.c_void_p(), C.c_long(0)
                     G.ctx.check(G.ctx.L.sdso_ba_batch_accum_dev(G.ctx.h, C.byref(ptr), C.byref(nfl)))
@@ -122,7 +144,7 @@ class BAWorkload:
         self.config = {"workload": self.name, "windows_per_step": nwin, "keyframes": nf, "points_per_window_per_gpu": win["np"],
                        "residuals_per_window_per_gpu": win["nr"], "points_per_global_window": self.win_global["np"],
                        "jacobians_materialized": bool(self.materialize), "stream_groups": ngroups,
-                       "allreduce_floats": nfl_total if world > 1 else 0,
+                       "allreduce_floats": nfl_total if world > 1 else 0, "exchange": getattr(self, "exchange", None),
                        "parallelism": ("allPoints of every window cut into %d contiguous ranges, 1 RCCL all-reduce (sdso_ba_allreduce) of the packed accumulators per group and iteration" % world) if world > 1 else "single GPU"}
         print("[rank %d] BA setup %.1fs: %d windows x %d residuals in %d stream group(s)" % (rank, time.time() - t0, nwin, win["nr"], ngroups), file=sys.stderr, flush=True)
 

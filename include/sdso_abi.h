@@ -302,6 +302,8 @@ int sdso_ba_batch_schur(sdso_ctx* ctx);
 /* 1 (default): every linearization writes the RawResidualJacobian records to HBM like
  * PointFrameResidual::J; 0: they stay in registers of the fused linearize+accumulate kernel. */
 int sdso_ba_batch_set_materialize(sdso_ctx* ctx, int materialize);
+/* lambda is subject to the windows' solverMode exactly as in solveSystemF (SOLVER_USE_GN -> 0, SOLVER_FIX_LAMBDA -> 1e-5,
+ * EnergyFunctional.cpp:840-846); the members of a batch must share one solverMode. */
 int sdso_ba_batch_solve(sdso_ctx* ctx, double lambda, int orthogonalize_x);
 int sdso_ba_batch_accum_dev(sdso_ctx* ctx, void** dev_ptr, long* nfloats);
 int sdso_ba_batch_get_x(sdso_ctx* ctx, double* x /* nwin*(8nf+4) */);

@@ -1040,6 +1040,7 @@ extern "C" int sdso_ba_batch_create(sdso_ctx* ctx, int nwin, const int* wins) {
     SDSO_REQUIRE(ctx, Ws[i], "unknown window in batch");
     SDSO_REQUIRE(ctx, Ws[i]->d.nf == Ws[0]->d.nf, "batch windows must share nf");
     SDSO_REQUIRE(ctx, (Ws[i]->d.tiledT > 0) == (Ws[0]->d.tiledT > 0), "batch windows must share the image layout");
+    SDSO_REQUIRE(ctx, Ws[i]->solverMode == Ws[0]->solverMode, "batch windows must share solverMode (one lambda per launch)");
     SDSO_REQUIRE(ctx, (Ws[i]->solverMode & (SOLVER_SVD | SOLVER_ORTHOGONALIZE_SYSTEM)) == 0, "SOLVER_SVD / SOLVER_ORTHOGONALIZE_SYSTEM windows are solved through sdso_ba_solve / sdso_ba_optimize, not in a batch");
     for (int k = 0; k < i; k++) SDSO_REQUIRE(ctx, Ws[k] != Ws[i], "a window may appear only once in a batch");
   }
@@ -1139,7 +1140,10 @@ extern "C" int sdso_ba_batch_set_materialize(sdso_ctx* ctx, int materialize) {
 extern "C" int sdso_ba_batch_solve(sdso_ctx* ctx, double lambda, int orthogonalize_x) {
   BaBatch* Bt = get_batch(ctx);
   if (!Bt) return sdso::fail(ctx, SDSO_ERR_STATE, "no batch");
-  launch_solve(ctx, Bt->L, lambda, orthogonalize_x);
+  // solveSystem's overrides of lambda (EnergyFunctional.cpp:840-846), as in the single-window call
+  if (Bt->W[0]->solverMode & SOLVER_USE_GN) lambda = 0;
+  if (Bt->W[0]->solverMode & SOLVER_FIX_LAMBDA) lambda = 1e-5;
+  launch_solve(ctx, batch_launch(Bt), lambda, orthogonalize_x);
   SDSO_HIP(ctx, hipGetLastError());
   return SDSO_OK;
 }
