@@ -308,6 +308,26 @@ int sdso_ba_batch_solve(sdso_ctx* ctx, double lambda, int orthogonalize_x);
 int sdso_ba_batch_accum_dev(sdso_ctx* ctx, void** dev_ptr, long* nfloats);
 int sdso_ba_batch_get_x(sdso_ctx* ctx, double* x /* nwin*(8nf+4) */);
 
+/* FullSystem::optimize (FullSystemOptimize.cpp:871-1041, DSO-native loop) for EVERY window of the batch, device-resident: the host
+ * logic between the kernel phases — backupState / doStepFromBackup (:207-351), FrameHessian::setState, setPrecalcValues
+ * (HessianBlocks.cpp:206-242), setDeltaF (EnergyFunctional.cpp:173-207), setNewFrameEnergyTH (:98-139), the break test — runs in one
+ * workgroup per window (k_ba_opt_step), so a whole loop is enqueued without a host round trip.  This is the accepted-step flow
+ * (setting_forceAceptStep = true, the reference's default, settings.cpp:53); windows with forceAcceptStep = 0 are refused here and go
+ * through sdso_ba_optimize's host loop.
+ *   sdso_ba_batch_optimize       : the whole loop with the reference's lambda (1e-1 * 0.25^it, subject to solverMode) and
+ *                                  orthogonalisation schedule; out[nwin].  With a communicator on ctx (points sharded over ranks) every
+ *                                  iteration all-reduces the accumulators and all-gathers the newest-frame energies / break-test sums, so
+ *                                  every rank takes the decisions of the unsharded window.
+ *   ..._begin / sdso_ba_batch_step / ..._end : the same in pieces, for callers that drive the iterations themselves:
+ *       begin ; per iteration { sdso_ba_batch_accumulate ; [sdso_ba_allreduce] ; sdso_ba_batch_solve ; sdso_ba_batch_step } ; end
+ *     stop_on_convergence = 0 keeps every window iterating (benchmarks).
+ *   sdso_ba_get_state            : states / idepths / residual states of one window as they stand (synchronises). */
+int sdso_ba_batch_optimize(sdso_ctx* ctx, int mnumOptIts, sdso_ba_opt_result_t* out /* nwin */);
+int sdso_ba_batch_optimize_begin(sdso_ctx* ctx, int stop_on_convergence);
+int sdso_ba_batch_step(sdso_ctx* ctx);
+int sdso_ba_batch_optimize_end(sdso_ctx* ctx, sdso_ba_opt_result_t* out /* nwin, may be NULL */);
+int sdso_ba_get_state(sdso_ctx* ctx, int win, double* state_out /* nf*10 */, float* idepth_out /* np */, uint8_t* res_state_out /* nr */);
+
 /* ------------------------------------------------------------------ multi-GPU exchange
  * The points of every window are sharded over the ranks (one process per GPU, contiguous allPoints ranges, every rank holds all
  * pyramids and frame states); the packed accumulators are plain sums over points — the reference adds the per-thread copies the same
@@ -322,7 +342,8 @@ int sdso_ba_batch_get_x(sdso_ctx* ctx, double* x /* nwin*(8nf+4) */);
  *   sdso_ba_allreduce_window : the same for one window's block (sdso_ba_accum_dev), between sdso_ba_accumulate and sdso_ba_solve
  * A single-iteration exchange sums everything solveSystemF needs.  The energy threshold of the newest frame (setNewFrameEnergyTH,
  * FullSystemOptimize.cpp:98-139: a 70 % quantile over its residuals) is NOT additive: a multi-iteration loop over sharded points has to
- * gather those energies as well (not provided; sdso_ba_optimize is a single-rank call). */
+ * gather those energies as well — sdso_ba_batch_optimize / sdso_ba_batch_step do (one all-gather per iteration); sdso_ba_optimize is a
+ * single-rank call. */
 int sdso_comm_unique_id(void* id128);
 int sdso_comm_init(sdso_ctx* ctx, int nranks, int rank, const void* id128);
 int sdso_comm_attach(sdso_ctx* ctx, sdso_ctx* owner);

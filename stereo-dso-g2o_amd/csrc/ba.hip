@@ -4,6 +4,7 @@
 // (ba_kernels.h).  Call-surface mapping: see include/sdso_abi.h and INTEGRATION.md.
 #include "ba_kernels.hip"   // single translation unit: kernels + host API
 #include "ba_solve.hip"
+#include "ba_opt.hip"
 #include "ba_host.h"
 #include <algorithm>
 #include <cmath>
@@ -38,6 +39,10 @@ struct BaWindowDev {
   float* dt_xAd = nullptr;
   uint8_t* d_pflag = nullptr;
   float* d_sums = nullptr;
+  BaOptDev* d_opt = nullptr;    // resident GN loop state (ba_opt.hip)
+  BaOptDev h_opt;               // staging of its upload
+  std::vector<double> h_prstage;  // staging of the dt_prior upload (upload_tables)
+  int newest_first = 0;         // first pair-sorted residual whose target is the newest frame
   float* accum_own = nullptr;   // the window's own packed accumulator block (d.accum points into the batch block while batched)
   bool in_batch = false;
   bool accumulated = false;
@@ -90,10 +95,14 @@ struct BaBatch {
   int gather = 1;                // tap gather of the fused kernel: 1 cooperative quads (default), 2 LDS-DMA rounds, 0 direct (SDSO_BA_GATHER / SDSO_BA_DIRECT_TAPS at batch_create)
 };
 static std::map<sdso_ctx*, BaBatch*> g_batches;
+void free_optrun(sdso_ctx* ctx);    // the resident GN loop's bookkeeping (end of this file)
+void free_optbufs(sdso_ctx* ctx);
+int optimize_resident_single(sdso_ctx* ctx, BaWindowDev* W, int mnumOptIts, sdso_ba_opt_result_t* res);
 // Dissolve the ctx's batch: every member window gets its own accumulator block back (host descriptor and its device copy),
 // so later per-window calls never touch the freed batch block.
 static void free_batch(sdso_ctx* ctx) {
   BaBatch* taken = nullptr;
+  free_optrun(ctx);   // a resident loop over the batch ends with it
   if (!reg_take(g_batches, ctx, taken) || !taken) return;
   hipStreamSynchronize(ctx->stream);
   for (BaWindowDev* W : taken->W) {
@@ -108,11 +117,12 @@ static void free_batch(sdso_ctx* ctx) {
 }
 void release_all_windows(sdso_ctx* ctx) {
   free_batch(ctx);
+  free_optbufs(ctx);
   for (auto& kv : ctx->wins) free_window(ctx, kv.second);
   ctx->wins.clear();
 }
 
-static int upload_tables(sdso_ctx* ctx, BaWindowDev* W, bool adjoints) {
+static int upload_tables(sdso_ctx* ctx, BaWindowDev* W, bool adjoints, bool sync = true) {
   const int nf = W->d.nf, n = W->d.n;
   buildPrecalc(W->calib, W->frames, W->tab);
   if (adjoints) { buildAdjoints(W->frames, W->tab); W->P = buildNullspaceProjector(W->frames); }
@@ -125,7 +135,8 @@ static int upload_tables(sdso_ctx* ctx, BaWindowDev* W, bool adjoints) {
     H2D(W->dt_adTarget, W->tab.adTarget.data(), sizeof(double) * nf * nf * 64);
     H2D(W->dt_P, W->P.a.data(), sizeof(double) * n * n);
   }
-  std::vector<double> pr((size_t)nf * 16 + 4 + n);
+  std::vector<double>& pr = W->h_prstage;   // member: the copy may still be in flight when this returns (sync == false)
+  pr.assign((size_t)nf * 16 + 4 + n, 0.0);
   for (int f = 0; f < nf; f++)
     for (int i = 0; i < 8; i++) { pr[f * 8 + i] = W->frames[f].prior[i]; pr[nf * 8 + f * 8 + i] = W->frames[f].delta_prior[i]; }
   for (int i = 0; i < 4; i++) pr[nf * 16 + i] = W->tab.cPrior[i];
@@ -137,7 +148,7 @@ static int upload_tables(sdso_ctx* ctx, BaWindowDev* W, bool adjoints) {
   W->d.cxl = W->calib.value_scaledf[2]; W->d.cyl = W->calib.value_scaledf[3];
   W->d.fxli = W->calib.value_scaledi[0]; W->d.fyli = W->calib.value_scaledi[1];
   H2D(W->d_self, &W->d, sizeof(BaDev));
-  SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));  // host staging vectors go out of scope
+  if (sync) SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the tables in W->tab are rebuilt by the next call
   return SDSO_OK;
 }
 
@@ -252,6 +263,8 @@ static int upload_window_impl(sdso_ctx* ctx, int win, const sdso_ba_window_t* Wi
   }
   W->h_target = s_target;
   W->h_point = s_point;
+  W->newest_first = nr;
+  for (int j = 0; j < nr; j++) if (s_target[j] == nf - 1) { W->newest_first = j; break; }
   W->h_lin.assign(nr, 0);
   W->has_lin_cached = false;
   // chunks per pair
@@ -310,6 +323,8 @@ static int upload_window_impl(sdso_ctx* ctx, int win, const sdso_ba_window_t* Wi
   DM(d.sol, double, sol_doubles(n, nf));
   DM(W->d_pflag, uint8_t, np); DM(W->d_sums, float, 2 * (W->nblk_pts + 1));
   DM(W->d_self, BaDev, 1);
+  DM(W->d_opt, BaOptDev, 1);
+  d.opt = W->d_opt; d.finished = 0;
 
   d.p_geo = p_geo; d.p_color = p_color; d.p_weights = p_weights; d.p_host = p_host; d.p_prior = p_prior; d.p_delta = p_delta;
   d.p_rbeg = p_rbeg; d.p_rcnt = p_rcnt; d.p_rlist = p_rlist; d.p_out = p_out;
@@ -878,7 +893,13 @@ extern "C" int sdso_ba_optimize(sdso_ctx* ctx, int win, int mnumOptIts, double* 
   const int nf = W->d.nf, np = W->d.np, nr = W->d.nr;
   sdso_ba_opt_result_t res{0, 0, 0, 0};
   BaLaunch L = single(W);
-  if (nf >= 2) {
+  // setting_forceAceptStep (the reference's default): every step is taken, the whole loop runs on the device (ba_opt.hip) without a
+  // host round trip; the energy-gated flow keeps the host loop below.  SDSO_BA_HOST_LOOP=1 forces the host loop (A/B).
+  const bool host_loop = getenv("SDSO_BA_HOST_LOOP") != nullptr;   // read per call: tests flip it
+  if (nf >= 2 && W->forceAccept && !host_loop && (W->solverMode & (SOLVER_SVD | SOLVER_ORTHOGONALIZE_SYSTEM)) == 0) {
+    int rc = optimize_resident_single(ctx, W, mnumOptIts, &res);
+    if (rc) return rc;
+  } else if (nf >= 2) {
     if (nf < 3) mnumOptIts = 20;
     if (nf < 4) mnumOptIts = 15;
     hipLaunchKernelGGL(k_ba_reset_all, dim3(L.max_nblk_res, 1), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr);
@@ -1211,5 +1232,277 @@ extern "C" int sdso_ba_marginalize_frame(int nf, int idx, const double* prior8, 
   }
   for (int i = 0; i < odim; i++) { b[i] = S[i] * b[i]; for (int j = 0; j < odim; j++) H[(size_t)i * odim + j] = S[i] * H[(size_t)i * odim + j] * S[j]; }
   for (int r = 0; r < ndim; r++) { bM_out[r] = b[r]; for (int c = 0; c < ndim; c++) HM_out[(size_t)r * ndim + c] = 0.5 * (H[(size_t)r * odim + c] + H[(size_t)c * odim + r]); }
+  return SDSO_OK;
+}
+
+// ------------------------------------------------------------------ device-resident Gauss-Newton loop (ba_opt.hip)
+namespace sdso {
+int comm_nranks(sdso_ctx* ctx);                                                            // comm.hip
+int comm_allgather_floats(sdso_ctx* ctx, const float* send, float* recv, size_t nfloats);  // comm.hip
+int comm_max_int(sdso_ctx* ctx, int* value);                                               // comm.hip
+
+// scratch of the resident loop, one set per ctx (grown on demand, freed with the ctx's windows)
+struct OptBufs {
+  float* d_sums = nullptr; size_t sums_cap = 0;
+  float* d_pack = nullptr; size_t pack_cap = 0;
+  float* d_gather = nullptr; size_t gather_cap = 0;
+  BaOptOut* d_out = nullptr; BaOptOut* h_out = nullptr; size_t out_cap = 0;
+};
+static std::map<sdso_ctx*, OptBufs*> g_optbufs;
+void free_optbufs(sdso_ctx* ctx) {
+  OptBufs* b = nullptr;
+  if (!reg_take(g_optbufs, ctx, b) || !b) return;
+  hipFree(b->d_sums); hipFree(b->d_pack); hipFree(b->d_gather); hipFree(b->d_out);
+  if (b->h_out) hipHostFree(b->h_out);
+  delete b;
+}
+template <class T> static int grow(sdso_ctx* ctx, T*& p, size_t& cap, size_t want) {
+  if (want <= cap) return SDSO_OK;
+  SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  hipFree(p); p = nullptr; cap = 0;
+  SDSO_HIP(ctx, hipMalloc(&p, sizeof(T) * want));
+  cap = want;
+  return SDSO_OK;
+}
+
+// one resident loop on a ctx: a batch (sdso_ba_batch_optimize*) or a single window (sdso_ba_optimize)
+struct OptRun {
+  BaLaunch L{};
+  std::vector<BaWindowDev*> W;
+  bool materialize = true; int gather = 1;
+  int cap = 0, nranks = 1, sums_stride = 0, iteration = 0, stop = 1;
+  bool active = false;
+  OptBufs* B = nullptr;
+};
+
+static int opt_begin(sdso_ctx* ctx, OptRun& R, int stop_on_convergence) {
+  const int nwin = (int)R.W.size(), nf = R.L.nf;
+  SDSO_REQUIRE(ctx, nf >= 2, "the Gauss-Newton loop needs at least two keyframes (FullSystemOptimize.cpp:873)");
+  int cap = 1;
+  for (BaWindowDev* W : R.W) {
+    SDSO_REQUIRE(ctx, W->forceAccept, "the device-resident loop is the accepted-step flow (setting_forceAceptStep); energy-gated windows go through sdso_ba_optimize");
+    SDSO_REQUIRE(ctx, (W->solverMode & (SOLVER_SVD | SOLVER_ORTHOGONALIZE_SYSTEM)) == 0, "SOLVER_SVD / SOLVER_ORTHOGONALIZE_SYSTEM windows are optimised through the host loop");
+    cap = std::max(cap, W->d.nr - W->newest_first);
+  }
+  R.nranks = comm_nranks(ctx);
+  if (R.nranks > 1) { int rc = comm_max_int(ctx, &cap); if (rc) return rc; }
+  R.cap = cap;
+  R.sums_stride = 2 * (R.L.max_nblk_pts + 1);
+  if (!reg_has(g_optbufs, ctx)) reg_get(g_optbufs, ctx) = new OptBufs();
+  OptBufs* B = reg_get(g_optbufs, ctx);
+  R.B = B;
+  const size_t pf = opt_pack_floats(cap);
+  int rc;
+  if ((rc = grow(ctx, B->d_sums, B->sums_cap, (size_t)nwin * R.sums_stride))) return rc;
+  if ((rc = grow(ctx, B->d_pack, B->pack_cap, (size_t)nwin * pf))) return rc;
+  if (R.nranks > 1 && (rc = grow(ctx, B->d_gather, B->gather_cap, (size_t)R.nranks * nwin * pf))) return rc;
+  if ((size_t)nwin > B->out_cap) {
+    SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    hipFree(B->d_out); if (B->h_out) hipHostFree(B->h_out);
+    B->d_out = nullptr; B->h_out = nullptr; B->out_cap = 0;
+    SDSO_HIP(ctx, hipMalloc(&B->d_out, sizeof(BaOptOut) * nwin));
+    SDSO_HIP(ctx, hipHostMalloc(&B->h_out, sizeof(BaOptOut) * nwin));
+    B->out_cap = nwin;
+  }
+  for (BaWindowDev* W : R.W) {
+    BaOptDev& O = W->h_opt;
+    std::memset(&O, 0, sizeof(O));
+    for (int f = 0; f < nf; f++) {
+      const HostFrame& F = W->frames[f];
+      for (int i = 0; i < 10; i++) { O.state[f][i] = F.state[i]; O.state_backup[f][i] = F.state[i]; O.state_zero[f][i] = F.state_zero[i]; }
+      for (int i = 0; i < 9; i++) O.evalPT[f][i] = F.evalPT.R[i];
+      for (int i = 0; i < 3; i++) O.evalPT[f][9 + i] = F.evalPT.t[i];
+      O.ab_exposure[f] = F.ab_exposure;
+    }
+    for (int i = 0; i < 4; i++) { O.calib_value[i] = W->calib.value[i]; O.calib_backup[i] = W->calib.value[i]; O.calib_zero[i] = W->calib.value_zero[i]; }
+    O.newest_first = W->newest_first;
+    H2D(W->d_opt, &W->h_opt, sizeof(BaOptDev));
+  }
+  hipLaunchKernelGGL(k_ba_reset_all, dim3(R.L.max_nblk_res, nwin), dim3(BA_BLOCK), 0, ctx->stream, R.L.d_arr);
+  SDSO_HIP(ctx, hipGetLastError());
+  R.iteration = 0; R.stop = stop_on_convergence; R.active = true;
+  return SDSO_OK;
+}
+
+// pack -> [all-gather] -> k_ba_opt_step.  unfused: the energies come from k_ba_linearize's workgroups, not from the fused kernel's chunks
+static int opt_consume(sdso_ctx* ctx, OptRun& R, int last, bool unfused, bool with_sums) {
+  const int nwin = (int)R.W.size();
+  OptBufs* B = R.B;
+  hipLaunchKernelGGL(k_ba_opt_pack, dim3(1, nwin), dim3(256), 0, ctx->stream, R.L.d_arr, B->d_pack, R.cap, unfused ? 1 : 0, with_sums ? B->d_sums : (const float*)nullptr, R.sums_stride);
+  const float* gathered = B->d_pack;
+  if (R.nranks > 1) {
+    int rc = comm_allgather_floats(ctx, B->d_pack, B->d_gather, (size_t)nwin * opt_pack_floats(R.cap));
+    if (rc) return rc;
+    gathered = B->d_gather;
+  }
+  hipLaunchKernelGGL(k_ba_opt_step, dim3(1, nwin), dim3(256), 0, ctx->stream, R.L.d_arr, gathered, R.nranks, R.cap, R.iteration, last, R.stop, 1.0f);
+  SDSO_HIP(ctx, hipGetLastError());
+  return SDSO_OK;
+}
+
+// after the solve of one iteration: doStepFromBackup for points, frames and calibration, tables, break test
+static int opt_step(sdso_ctx* ctx, OptRun& R) {
+  const int nwin = (int)R.W.size();
+  if (R.L.max_nblk_pts) hipLaunchKernelGGL(k_ba_points_op, dim3(R.L.max_nblk_pts, nwin), dim3(BA_BLOCK), 0, ctx->stream, R.L.d_arr, 3, 1.0f, R.B->d_sums, R.sums_stride);
+  int rc = opt_consume(ctx, R, 0, false, R.L.max_nblk_pts > 0);
+  R.iteration++;
+  return rc;
+}
+
+static int opt_collect(sdso_ctx* ctx, OptRun& R) {
+  const int nwin = (int)R.W.size();
+  hipLaunchKernelGGL(k_ba_opt_release, dim3(nwin), dim3(128), 0, ctx->stream, R.L.d_arr, R.B->d_out);
+  SDSO_HIP(ctx, hipMemcpyAsync(R.B->h_out, R.B->d_out, sizeof(BaOptOut) * nwin, hipMemcpyDeviceToHost, ctx->stream));
+  SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SDSO_OK;
+}
+
+// the end of FullSystem::optimize (FullSystemOptimize.cpp:993-1041): consume the linearisation at the final state, bring the host
+// mirrors up to date, newest frame's setEvalPT, linearizeAll(true)
+static int opt_finish(sdso_ctx* ctx, OptRun& R, sdso_ba_opt_result_t* out) {
+  const int nwin = (int)R.W.size(), nf = R.L.nf;
+  launch_fused(ctx, R.L, R.materialize, R.gather, 1);
+  int rc = opt_consume(ctx, R, 1, false, false);
+  if (rc) return rc;
+  if ((rc = opt_collect(ctx, R))) return rc;
+  std::vector<int> its(nwin), resInA(nwin);
+  for (int w = 0; w < nwin; w++) {
+    BaWindowDev* W = R.W[w];
+    const BaOptOut& o = R.B->h_out[w];
+    its[w] = o.iterations; resInA[w] = o.resInA;
+    W->calib.setValue(o.calib_value);
+    for (int f = 0; f < nf; f++) W->frames[f].setState(o.state[f]);
+    W->frames[nf - 1].frameEnergyTH = o.frameTH_new;
+    double nsz[10] = {0};
+    nsz[6] = W->frames[nf - 1].state[6];
+    nsz[7] = W->frames[nf - 1].state[7];
+    W->frames[nf - 1].setEvalPT(W->frames[nf - 1].PRE_worldToCam, nsz);
+    if ((rc = upload_tables(ctx, W, true, false))) return rc;
+    if (W->in_batch) H2D(const_cast<BaDev*>(R.L.d_arr) + w, &W->d, sizeof(BaDev));   // the batch's descriptor copy carries the calibration scalars too
+    W->accumulated = false;
+  }
+  if (R.L.tiled) hipLaunchKernelGGL(k_ba_linearize<true>, dim3(R.L.max_nblk_res, nwin), dim3(BA_BLOCK), 0, ctx->stream, R.L.d_arr);
+  else hipLaunchKernelGGL(k_ba_linearize<false>, dim3(R.L.max_nblk_res, nwin), dim3(BA_BLOCK), 0, ctx->stream, R.L.d_arr);
+  hipLaunchKernelGGL(k_ba_apply, dim3(R.L.max_nblk_res, nwin), dim3(BA_BLOCK), 0, ctx->stream, R.L.d_arr);
+  if ((rc = opt_consume(ctx, R, 1, true, false))) return rc;
+  if ((rc = opt_collect(ctx, R))) return rc;
+  for (int w = 0; w < nwin; w++) {
+    BaWindowDev* W = R.W[w];
+    const BaOptOut& o = R.B->h_out[w];
+    W->frames[nf - 1].frameEnergyTH = o.frameTH_new;
+    if (out) {
+      out[w].iterations = its[w];
+      out[w].lastEnergy = o.lastEnergy;
+      out[w].resInA = resInA[w];
+      out[w].rmse = sqrtf((float)(o.lastEnergy / (8 * resInA[w])));
+    }
+  }
+  R.active = false;
+  return SDSO_OK;
+}
+
+static double opt_lambda(int iteration) { double l = 1e-1; for (int i = 0; i < iteration; i++) l *= 0.25; return l; }
+static int opt_iterations(int nf, int mnumOptIts) {
+  if (nf < 3) mnumOptIts = 20;
+  if (nf < 4) mnumOptIts = 15;
+  return mnumOptIts;
+}
+// accumulate (fused linearisation + Schur part) -> [all-reduce] -> solve of iteration `it`
+static int opt_solve_phase(sdso_ctx* ctx, OptRun& R, int it) {
+  launch_fused(ctx, R.L, R.materialize, R.gather);
+  if (R.nranks > 1) {
+    int rc = R.W[0]->in_batch ? sdso_ba_allreduce(ctx) : SDSO_ERR_STATE;
+    if (rc) return rc;
+  }
+  const int sm = R.W[0]->solverMode;
+  double lambda = opt_lambda(it);
+  if (sm & SOLVER_USE_GN) lambda = 0;
+  if (sm & SOLVER_FIX_LAMBDA) lambda = 1e-5;
+  const int orth = (sm & SOLVER_ORTHOGONALIZE_X) || (it >= 2 && (sm & SOLVER_ORTHOGONALIZE_X_LATER));
+  launch_solve(ctx, R.L, lambda, orth ? 1 : 0);
+  SDSO_HIP(ctx, hipGetLastError());
+  return SDSO_OK;
+}
+
+int optimize_resident_single(sdso_ctx* ctx, BaWindowDev* W, int mnumOptIts, sdso_ba_opt_result_t* res) {
+  OptRun R;
+  R.L = single(W); R.W = {W};
+  R.materialize = true; R.gather = 1;
+  int rc = opt_begin(ctx, R, 1);
+  if (rc) return rc;
+  if (R.nranks > 1) return sdso::fail(ctx, SDSO_ERR_STATE, "sdso_ba_optimize is a single-rank call; sharded windows use sdso_ba_batch_optimize");
+  const int N = opt_iterations(W->d.nf, mnumOptIts);
+  for (int it = 0; it < N; it++) {
+    if ((rc = opt_solve_phase(ctx, R, it))) return rc;
+    if ((rc = opt_step(ctx, R))) return rc;
+  }
+  return opt_finish(ctx, R, res);
+}
+static std::map<sdso_ctx*, OptRun*> g_optruns;   // the batch loop in flight between sdso_ba_batch_optimize_begin and _end
+void free_optrun(sdso_ctx* ctx) {
+  OptRun* r = nullptr;
+  if (reg_take(g_optruns, ctx, r) && r) delete r;
+}
+}  // namespace sdso
+
+// FullSystem::optimize for every window of the batch, device-resident (no host round trip inside the loop):
+//   begin : backupState's initial copy of the states on the device, resetOOB of every residual
+//   then per iteration  sdso_ba_batch_accumulate -> [sdso_ba_allreduce] -> sdso_ba_batch_solve -> sdso_ba_batch_step
+//   end   : the linearisation at the final state, setEvalPT of the newest frame, linearizeAll(true); results per window
+// sdso_ba_batch_optimize runs the whole sequence with the reference's lambda / orthogonalisation schedule.
+extern "C" int sdso_ba_batch_optimize_begin(sdso_ctx* ctx, int stop_on_convergence) {
+  BaBatch* Bt = get_batch(ctx);
+  if (!Bt) return sdso::fail(ctx, SDSO_ERR_STATE, "no batch");
+  SDSO_HIP(ctx, hipSetDevice(ctx->device));
+  free_optrun(ctx);
+  OptRun* R = new OptRun();
+  R->L = batch_launch(Bt); R->W = Bt->W; R->materialize = Bt->materialize; R->gather = Bt->gather;
+  int rc = opt_begin(ctx, *R, stop_on_convergence);
+  if (rc) { delete R; return rc; }
+  reg_get(g_optruns, ctx) = R;
+  return SDSO_OK;
+}
+extern "C" int sdso_ba_batch_step(sdso_ctx* ctx) {
+  if (!ctx || !reg_has(g_optruns, ctx)) return sdso::fail(ctx, SDSO_ERR_STATE, "sdso_ba_batch_optimize_begin first");
+  OptRun* R = reg_get(g_optruns, ctx);
+  SDSO_REQUIRE(ctx, get_batch(ctx) && get_batch(ctx)->W == R->W, "the batch changed since sdso_ba_batch_optimize_begin");
+  return opt_step(ctx, *R);
+}
+extern "C" int sdso_ba_batch_optimize_end(sdso_ctx* ctx, sdso_ba_opt_result_t* out) {
+  if (!ctx || !reg_has(g_optruns, ctx)) return sdso::fail(ctx, SDSO_ERR_STATE, "sdso_ba_batch_optimize_begin first");
+  OptRun* R = reg_get(g_optruns, ctx);
+  SDSO_REQUIRE(ctx, get_batch(ctx) && get_batch(ctx)->W == R->W, "the batch changed since sdso_ba_batch_optimize_begin");
+  R->L = batch_launch(get_batch(ctx));
+  const int rc = opt_finish(ctx, *R, out);
+  free_optrun(ctx);
+  return rc;
+}
+extern "C" int sdso_ba_batch_optimize(sdso_ctx* ctx, int mnumOptIts, sdso_ba_opt_result_t* out) {
+  int rc = sdso_ba_batch_optimize_begin(ctx, 1);
+  if (rc) return rc;
+  OptRun* R = reg_get(g_optruns, ctx);
+  const int N = opt_iterations(R->L.nf, mnumOptIts);
+  for (int it = 0; it < N; it++) {
+    if ((rc = opt_solve_phase(ctx, *R, it)) || (rc = opt_step(ctx, *R))) { free_optrun(ctx); return rc; }
+  }
+  return sdso_ba_batch_optimize_end(ctx, out);
+}
+// FrameHessian::state, PointHessian::idepth and the residual states of one window as they stand (after sdso_ba_optimize /
+// sdso_ba_batch_optimize); synchronises
+extern "C" int sdso_ba_get_state(sdso_ctx* ctx, int win, double* state_out /* nf*10 */, float* idepth_out /* np */, uint8_t* res_state_out /* nr */) {
+  GET_WIN();
+  const int nf = W->d.nf, np = W->d.np, nr = W->d.nr;
+  SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (state_out) for (int f = 0; f < nf; f++) for (int i = 0; i < 10; i++) state_out[f * 10 + i] = W->frames[f].state[i];
+  if (idepth_out && np) {
+    std::vector<float4> geo(np);
+    SDSO_HIP(ctx, hipMemcpy(geo.data(), W->d.p_geo, sizeof(float4) * np, hipMemcpyDeviceToHost));
+    for (int p = 0; p < np; p++) idepth_out[p] = geo[p].z;
+  }
+  if (res_state_out && nr) {
+    std::vector<uint8_t> t(nr);
+    SDSO_HIP(ctx, hipMemcpy(t.data(), W->d.r_state, nr, hipMemcpyDeviceToHost));
+    for (int j = 0; j < nr; j++) res_state_out[W->perm[j]] = t[j];
+  }
   return SDSO_OK;
 }

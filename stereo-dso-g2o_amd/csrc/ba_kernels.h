@@ -26,6 +26,22 @@ constexpr int PO_HDD_A = 0, PO_BD_A = 1, PO_HCD_A = 2, PO_HDD_L = 6, PO_BD_L = 7
 // r_rec record (16 floats per residual): JpJdF[8], bd, Hdd, Hcd[4], flags, target
 constexpr int RR_BD = 8, RR_HDD = 9, RR_HCD = 10, RR_FLAGS = 14, RR_TARGET = 15;
 
+// Device-resident state of FullSystem::optimize's Gauss-Newton loop for one window (ba_opt.hip): what the reference keeps in
+// FrameHessian (state / state_backup / state_zero / worldToCam_evalPT / PRE_worldToCam, HessianBlocks.h:120-190) and
+// CalibHessian (value / value_backup / value_zero, :276-349), plus the loop's own scalars.
+struct BaOptDev {
+  double state[8][10], state_backup[8][10], state_zero[8][10];
+  double evalPT[8][12];          // worldToCam_evalPT: R (9, row-major) then t (3)
+  double calib_value[4], calib_backup[4], calib_zero[4];
+  float ab_exposure[8];
+  double lastEnergy;             // energy of the latest linearizeAll
+  float frameTH_new;             // frameEnergyTH of the newest frame after the latest setNewFrameEnergyTH
+  int iterations;                // GN iterations run
+  int phase;                     // 0 running; 1 the break test fired: the linearisation at the final state is still to be consumed; 2 finished
+  int resInA;                    // nres[0] of the latest accumulate
+  int newest_first;              // first (pair-sorted) residual whose target is the newest frame; they run to nr
+};
+
 struct BaDev {
   int nf, np, nr, nrp, w, h, nchunks, nitems, n;
   int tiledT;               // > 0: t_img are 4x2-tiled level-0 images with tiledT tiles per row; 0: row-major
@@ -74,7 +90,13 @@ struct BaDev {
   double* e_part;           // energy partials of linearize (per workgroup)
   float* accum;             // packed accumulators (see sdso_ba_accum_floats)
   double* sol;              // Htop_A n*n | btop_A n | Htop_L n*n | btop_L n | Hsc n*n | bsc n | x n | HS n*n | bS n
+  BaOptDev* opt;            // resident optimizer state (ba_opt.hip)
+  int finished;             // resident GN loop (k_ba_opt_step): 1 the break test fired (only the linearisation at the final state is
+                            // still wanted), 2 the loop has ended; cleared by k_ba_opt_release
 };
+// the remaining iterations of a batch skip a window whose resident GN loop has ended
+__device__ __forceinline__ bool ba_finished(const BaDev& B) { return B.finished >= 1; }       // accumulate / solve / step kernels
+__device__ __forceinline__ bool ba_finished_lin(const BaDev& B) { return B.finished >= 2; }   // the linearisation runs once more
 
 __host__ __device__ inline int sc_part_floats(int nf) { return nf * nf * 64 + nf * 32 + nf * 8 + 16 + 4; }
 __host__ __device__ inline size_t acc_off_topA(int nf) { return 0; }

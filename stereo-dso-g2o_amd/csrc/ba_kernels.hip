@@ -679,6 +679,7 @@ __device__ __forceinline__ void top_emit(const BaDev& B, const float* x, const f
 // One workgroup per chunk of <=256 residuals of ONE (host,target) pair.  mode: 0 active, 1 linearized, 2 marginalise.
 __global__ __launch_bounds__(BA_BLOCK) void k_ba_accum_top(const BaDev* __restrict__ wins, int mode, const uint8_t* __restrict__ pflag) {
   const BaDev& B = wins[blockIdx.y];
+  if (ba_finished(B)) return;
   if ((int)blockIdx.x >= B.nchunks) return;
   const int4 ch = B.chunks[blockIdx.x];
   const int i = ch.y + threadIdx.x;
@@ -776,6 +777,7 @@ __global__ __launch_bounds__(BA_BLOCK, (MATERIALIZE ? 3 : 4)) void k_ba_lin_fuse
   // by-value copy first: every pointer of the descriptor is read before the kernel's first store, so the
   // compiler can prove them global (global_load / s_load instead of flat_load) and keep them in SGPRs
   const BaDev B = wins[blockIdx.y];
+  if (ba_finished_lin(B)) return;
   if ((int)blockIdx.x >= B.nchunks) return;
   const int4 ch = B.chunks[blockIdx.x];
   const int pair = __builtin_amdgcn_readfirstlane(ch.x);   // one (host,target) per workgroup: precalc, image, thresholds are wave-uniform
@@ -887,6 +889,7 @@ __global__ __launch_bounds__(BA_BLOCK, 3) void k_ba_lin_dma(const BaDev* __restr
 #define GP(T, p) ((__attribute__((address_space(1))) T*)(p))
 #define CP(T, p) ((const __attribute__((address_space(4))) T*)(p))
   const BaDev B = wins[blockIdx.y];
+  if (ba_finished_lin(B)) return;
   if ((int)blockIdx.x >= B.nchunks) return;
   typedef int te_i4 __attribute__((ext_vector_type(4)));
   const te_i4 ch = CP(te_i4, B.chunks)[blockIdx.x];          // {pair, start, count, -}
@@ -1191,8 +1194,8 @@ __device__ __forceinline__ void zero_topL_body(const BaDev& B, int pair, int tid
   if (tid < 91) B.accum[acc_off_topL(B.nf) + (size_t)pair * 91 + tid] = 0.f;
   if (pair == 0 && tid == 127) B.accum[acc_off_nres(B.nf) + 1] = 0.f;
 }
-__global__ __launch_bounds__(128) void k_ba_fold_top(const BaDev* __restrict__ wins, int which) { fold_top_body(wins[blockIdx.y], blockIdx.x, which, threadIdx.x); }
-__global__ __launch_bounds__(128) void k_ba_zero_topL(const BaDev* __restrict__ wins) { zero_topL_body(wins[blockIdx.y], blockIdx.x, threadIdx.x); }
+__global__ __launch_bounds__(128) void k_ba_fold_top(const BaDev* __restrict__ wins, int which) { if (ba_finished(wins[blockIdx.y])) return; fold_top_body(wins[blockIdx.y], blockIdx.x, which, threadIdx.x); }
+__global__ __launch_bounds__(128) void k_ba_zero_topL(const BaDev* __restrict__ wins) { if (ba_finished(wins[blockIdx.y])) return; zero_topL_body(wins[blockIdx.y], blockIdx.x, threadIdx.x); }
 
 // ------------------------------------------------------------------ per-point Schur accumulation
 // AccumulatedSCHessianSSE::addPoint for nf <= 8 (template NF).  One wave per item (<= 64 consecutive
@@ -1206,6 +1209,7 @@ __global__ __launch_bounds__(128) void k_ba_zero_topL(const BaDev* __restrict__ 
 template <int NF>
 __global__ __launch_bounds__(BA_BLOCK) void k_ba_sc_reg(const BaDev* __restrict__ wins, const uint8_t* __restrict__ pflag, int shiftPriorToZero, int margMode) {
   const BaDev& B = wins[blockIdx.y];
+  if (ba_finished(B)) return;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int item = blockIdx.x * (BA_BLOCK / 64) + wv;
   if (item >= B.nitems) return;
@@ -1332,6 +1336,7 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_sc_reg(const BaDev* __restrict_
 // differs from the CPU path (and the product HdiF*J1*J2 is fused in the MFMA: one rounding less).
 __global__ __launch_bounds__(BA_BLOCK) void k_ba_sc_mfma(const BaDev* __restrict__ wins, const uint8_t* __restrict__ pflag, int shiftPriorToZero, int margMode) {
   const BaDev& B = wins[blockIdx.y];
+  if (ba_finished(B)) return;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int item = blockIdx.x * (BA_BLOCK / 64) + wv;
   __shared__ float pt_all[BA_BLOCK / 64][64][8];   // HdiF, bdSumF, Hcd[4], mask bits, -
@@ -1453,6 +1458,7 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_sc_mfma(const BaDev* __restrict
 // block: no per-item partials in HBM and no fold pass.  Only Hcc / bc (sums over ALL hosts) leave a 20-float partial per host.
 __global__ __launch_bounds__(BA_BLOCK, 2) void k_ba_sc_host(const BaDev* __restrict__ wins, const uint8_t* __restrict__ pflag, int shiftPriorToZero, int margMode) {
   const BaDev& B = wins[blockIdx.y];
+  if (ba_finished(B)) return;
   const int nf = B.nf, h = blockIdx.x;
   if (h >= nf) return;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;

@@ -1,0 +1,259 @@
+// The host logic of FullSystem::optimize's Gauss-Newton loop between the kernel phases, on the device — one 256-thread workgroup
+// per window, so that a whole loop (any number of windows) is enqueued without a single host round trip.
+// Reference (paths under /root/reference):
+//   FullSystem::optimize loop body                                   src/FullSystem/FullSystemOptimize.cpp:927-991
+//   FullSystem::backupState / doStepFromBackup (break test)          FullSystemOptimize.cpp:309-351, :207-305
+//   FullSystem::setNewFrameEnergyTH (70 % quantile, newest frame)    FullSystemOptimize.cpp:98-139
+//   FrameHessian::setState -> PRE_worldToCam                         src/FullSystem/HessianBlocks.h:197-214
+//   FrameFramePrecalc::set (setPrecalcValues)                        src/FullSystem/HessianBlocks.cpp:206-242
+//   EnergyFunctional::setDeltaF                                      src/OptimizationBackend/EnergyFunctional.cpp:173-207
+//   CalibHessian::setValue                                           HessianBlocks.h:318-333
+// This path is the accepted-step flow (setting_forceAceptStep = true, the reference's default, settings.cpp:53): every step is
+// taken, so linearizeAll + applyRes + the next accumulate collapse into the fused kernel.  The energy-gated loop stays on the host
+// (sdso_ba_optimize).  Sharded windows (one rank per GPU): the quantile and the break test need every rank's residuals / points, so
+// each rank packs them (k_ba_opt_pack) and ONE all-gather per iteration feeds the same k_ba_opt_step everywhere.
+#include "ba_kernels.h"
+#include "host_math.h"
+
+namespace sdso {
+
+// floats of one window's packed record: [0,cap) newEnergyWithOutlier of the residuals that enter the quantile (-1 = none),
+// then the energy of the linearisation (a double in two float slots), sum |idepth backup|, number of points
+constexpr int OPT_PACK_TAIL = 4;
+__host__ __device__ inline int opt_pack_floats(int cap) { return cap + OPT_PACK_TAIL; }
+
+// after the points' step: this rank's contribution to setNewFrameEnergyTH and to the break test
+__global__ __launch_bounds__(256) void k_ba_opt_pack(const BaDev* __restrict__ wins, float* __restrict__ out, int cap, int nparts /* energy partials: 0 -> nchunks (fused), else ceil(nr/256) */,
+                                                     const float* __restrict__ sums, int sums_stride) {
+  const BaDev& B = wins[blockIdx.y];
+  if (ba_finished_lin(B)) return;
+  float* o = out + (size_t)blockIdx.y * opt_pack_floats(cap);
+  const int first = B.opt->newest_first, nf = B.nf;
+  for (int k = threadIdx.x; k < cap; k += 256) {
+    const int i = first + k;
+    float e = -1.f;
+    if (i < B.nr && B.r_target[i] == nf - 1 && !B.r_lin[i]) e = B.r_newEnergyWO[i];
+    o[k] = e;
+  }
+  if (threadIdx.x == 0) {
+    double s = 0;
+    const int np_ = nparts ? (B.nr + BA_BLOCK - 1) / BA_BLOCK : B.nchunks;
+    for (int b = 0; b < np_; b++) s += B.e_part[b];
+    __builtin_memcpy(o + cap, &s, 8);
+    float sumNID = 0;
+    if (sums) {
+      const float* sm = sums + (size_t)blockIdx.y * sums_stride;
+      for (int b = 0; b < (B.np + BA_BLOCK - 1) / BA_BLOCK; b++) sumNID += sm[2 * b + 1];
+    }
+    o[cap + 2] = sumNID;
+    o[cap + 3] = (float)B.np;
+  }
+}
+
+// the k-th smallest (0-based) of the non-negative floats v[r * rstride + 0..cap) over r < nranks: 4 radix passes over the bit patterns
+__device__ inline float opt_select(const float* __restrict__ v, int nranks, size_t rstride, int cap, int k, unsigned* hist /* LDS 256 */, unsigned* sh /* LDS 2 */) {
+  unsigned prefix = 0, mask = 0;
+  for (int shift = 24; shift >= 0; shift -= 8) {
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (int r = 0; r < nranks; r++)
+      for (int j = threadIdx.x; j < cap; j += 256) {
+        const float e = v[r * rstride + j];
+        if (!(e >= 0)) continue;
+        const unsigned key = __float_as_uint(e);
+        if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255], 1u);
+      }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned cum = 0, b = 0;
+      for (; b < 256; b++) { if (cum + hist[b] > (unsigned)k) break; cum += hist[b]; }
+      sh[0] = b; sh[1] = cum;
+    }
+    __syncthreads();
+    prefix |= sh[0] << shift;
+    mask |= 255u << shift;
+    k -= (int)sh[1];
+    __syncthreads();
+  }
+  return __uint_as_float(prefix);
+}
+
+// One GN iteration's host part for every window.  gathered: [nranks][nwin][opt_pack_floats(cap)] (nranks = 1: the local pack).
+//   last == 0:  consume the energies of the linearisation at the current state (lastEnergy, setNewFrameEnergyTH), take the step the
+//               solver left in sol (backupState + doStepFromBackup for frames and calibration; the points were stepped by
+//               k_ba_points_op), rebuild the tables (setPrecalcValues + setDeltaF), evaluate the break test.
+//   last != 0 or the break test fired in the previous call: consume the energies only, then mark the window finished.
+__global__ __launch_bounds__(256) void k_ba_opt_step(const BaDev* __restrict__ wins, const float* __restrict__ gathered, int nranks, int cap, int iteration, int last,
+                                                     int stop_on_convergence, float stepsize) {
+  BaDev& B = const_cast<BaDev&>(wins[blockIdx.y]);
+  if (ba_finished_lin(B)) return;
+  BaOptDev& O = *B.opt;
+  const int tid = threadIdx.x, nf = B.nf, nwin = gridDim.y;
+  const int pf = opt_pack_floats(cap);
+  const size_t rstride = (size_t)nwin * pf;
+  const float* g = gathered + (size_t)blockIdx.y * pf;
+  __shared__ unsigned hist[256], sh[2];
+  __shared__ int s_cnt[4];
+  __shared__ double s_w2c[8][12], s_c2w[8][12], s_step[8][8];
+  __shared__ float s_K[9], s_Ki[9];
+  const int phase = O.phase;
+
+  // ---- setNewFrameEnergyTH over every rank's residuals into the newest frame
+  int cnt = 0;
+  for (int r = 0; r < nranks; r++)
+    for (int j = tid; j < cap; j += 256) cnt += g[r * rstride + j] >= 0 ? 1 : 0;
+  cnt = (int)wave_sum((float)cnt);                       // <= nranks * cap < 2^24: exact in float
+  if ((tid & 63) == 0) s_cnt[tid >> 6] = cnt;
+  __syncthreads();
+  const int M = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+  float th = 12 * 12 * 8;
+  if (M > 0) {
+    const int nth = (int)(0.7f * M);
+    const float q = opt_select(g, nranks, rstride, cap, nth, hist, sh);
+    const float nthElement = sqrtf(q);
+    th = nthElement * 1.5f;
+    th = 26.0f * 0.5f + th * (1 - 0.5f);
+    th = th * th;
+    th *= 1.0f * 1.0f;
+  }
+  if (tid == 0) {
+    B.t_frameTH[nf - 1] = th;
+    O.frameTH_new = th;
+    double e = 0;
+    for (int r = 0; r < nranks; r++) { double er; __builtin_memcpy(&er, g + r * rstride + cap, 8); e += er; }
+    O.lastEnergy = e;
+  }
+  if (phase == 1 || last) {
+    if (tid == 0) { O.phase = 2; B.finished = 2; }
+    return;
+  }
+
+  // ---- backupState + doStepFromBackup: frames on threads 0..nf-1, the calibration on thread 64
+  const double* x = B.sol + 3 * ((size_t)B.n * B.n + B.n);
+  double* tp = const_cast<double*>(B.t_prior);
+  if (tid < nf) {
+    const int f = tid;
+    double ns[10], sc[10];
+    for (int i = 0; i < 10; i++) {
+      const double st = i < 8 ? -x[4 + 8 * f + i] : 0.0;       // step = -x (EnergyFunctional.cpp:978-985)
+      if (i < 8) s_step[f][i] = st;
+      O.state_backup[f][i] = O.state[f][i];
+      ns[i] = O.state[f][i] + (double)stepsize * st;
+      O.state[f][i] = ns[i];
+    }
+    for (int i = 0; i < 3; i++) sc[i] = SCALE_XI_TRANS * ns[i];
+    for (int i = 3; i < 6; i++) sc[i] = SCALE_XI_ROT * ns[i];
+    sc[6] = SCALE_A * ns[6]; sc[7] = SCALE_B * ns[7]; sc[8] = SCALE_A * ns[8]; sc[9] = SCALE_B * ns[9];
+    Se3 E;
+    for (int i = 0; i < 9; i++) E.R[i] = O.evalPT[f][i];
+    for (int i = 0; i < 3; i++) E.t[i] = O.evalPT[f][9 + i];
+    const Se3 Wc = expSe3(sc) * E;                             // PRE_worldToCam = SE3::exp(w2c_leftEps()) * worldToCam_evalPT
+    const Se3 Cw = inverse(Wc);
+    for (int i = 0; i < 9; i++) { s_w2c[f][i] = Wc.R[i]; s_c2w[f][i] = Cw.R[i]; }
+    for (int i = 0; i < 3; i++) { s_w2c[f][9 + i] = Wc.t[i]; s_c2w[f][9 + i] = Cw.t[i]; }
+    // setDeltaF: delta_prior = state, delta = state - state_zero
+    for (int i = 0; i < 8; i++) {
+      tp[nf * 8 + f * 8 + i] = ns[i];
+      tp[nf * 16 + 8 + f * 8 + i] = ns[i] - O.state_zero[f][i];
+    }
+  }
+  if (tid == 64) {
+    double v[4], vs[4];
+    float vsf[4];
+    for (int i = 0; i < 4; i++) {
+      O.calib_backup[i] = O.calib_value[i];
+      v[i] = O.calib_value[i] + stepsize * -x[i];
+      O.calib_value[i] = v[i];
+    }
+    vs[0] = SCALE_F * v[0]; vs[1] = SCALE_F * v[1]; vs[2] = SCALE_C * v[2]; vs[3] = SCALE_C * v[3];
+    for (int i = 0; i < 4; i++) vsf[i] = (float)vs[i];
+    B.fxl = vsf[0]; B.fyl = vsf[1]; B.cxl = vsf[2]; B.cyl = vsf[3];
+    B.fxli = 1.0f / vsf[0]; B.fyli = 1.0f / vsf[1];
+    const float K[9] = {vsf[0], 0, vsf[2], 0, vsf[1], vsf[3], 0, 0, 1};
+    float Ki[9];
+    inv3f(K, Ki);
+    for (int i = 0; i < 9; i++) { s_K[i] = K[i]; s_Ki[i] = Ki[i]; }
+    float* cd = const_cast<float*>(B.t_cdelta);
+    for (int i = 0; i < 4; i++) {
+      const float c = (float)(v[i] - O.calib_zero[i]);
+      cd[i] = c;
+      tp[nf * 16 + 4 + i] = (double)c;
+    }
+  }
+  __syncthreads();
+
+  // ---- setPrecalcValues: one (host, target) pair per thread; the evalPT parts (PRE_RTll_0, PRE_tTll_0) do not change in the loop
+  if (tid < nf * nf) {
+    const int h = tid / nf, t = tid % nf;
+    float* o = const_cast<float*>(B.t_precalc) + (size_t)(h * nf + t) * 27;
+    Se3 Tw, Ch;
+    for (int i = 0; i < 9; i++) { Tw.R[i] = s_w2c[t][i]; Ch.R[i] = s_c2w[h][i]; }
+    for (int i = 0; i < 3; i++) { Tw.t[i] = s_w2c[t][9 + i]; Ch.t[i] = s_c2w[h][9 + i]; }
+    const Se3 l = Tw * Ch;
+    float R[9], tt[3], KR[9], K[9], Ki[9];
+    for (int i = 0; i < 9; i++) { R[i] = (float)l.R[i]; K[i] = s_K[i]; Ki[i] = s_Ki[i]; }
+    for (int i = 0; i < 3; i++) tt[i] = (float)l.t[i];
+    mul3f(K, R, KR);
+    mul3f(KR, Ki, o);          // PRE_KRKiTll
+    mulv3f(K, tt, o + 9);      // PRE_KtTll
+    double a2[2];
+    affFromTo(O.ab_exposure[h], O.ab_exposure[t], SCALE_A * O.state[h][6], SCALE_B * O.state[h][7], SCALE_A * O.state[t][6], SCALE_B * O.state[t][7], a2);
+    o[24] = (float)a2[0]; o[25] = (float)a2[1];
+    o[26] = (float)(O.state_zero[h][7] * SCALE_B);
+  }
+  // adHTdeltaF[h + t*nf] = delta_h^T adHostF + delta_t^T adTargetF  (float arithmetic)
+  for (int e = tid; e < nf * nf * 8; e += 256) {
+    const int idx = e >> 3, j = e & 7, h = idx % nf, t = idx / nf;
+    float shh = 0, stt = 0;
+    for (int i = 0; i < 8; i++) {
+      const float dh = (float)(O.state[h][i] - O.state_zero[h][i]), dt = (float)(O.state[t][i] - O.state_zero[t][i]);
+      shh += dh * (float)B.t_adHost[(size_t)idx * 64 + i * 8 + j];
+      stt += dt * (float)B.t_adTarget[(size_t)idx * 64 + i * 8 + j];
+    }
+    const_cast<float*>(B.t_adHTdelta)[e] = shh + stt;
+  }
+
+  // ---- the loop's break test (doStepFromBackup's return value) and bookkeeping
+  if (tid == 0) {
+    float sumA = 0, sumB = 0, sumT = 0, sumR = 0;
+    for (int f = 0; f < nf; f++) {
+      const double* st = s_step[f];
+      sumA += st[6] * st[6];
+      sumB += st[7] * st[7];
+      sumT += st[0] * st[0] + st[1] * st[1] + st[2] * st[2];
+      sumR += st[3] * st[3] + st[4] * st[4] + st[5] * st[5];
+    }
+    float sumNID = 0, numID = 0;
+    for (int r = 0; r < nranks; r++) { sumNID += g[r * rstride + cap + 2]; numID += g[r * rstride + cap + 3]; }
+    sumA /= nf; sumB /= nf; sumR /= nf; sumT /= nf;
+    sumNID /= numID;
+    const bool canbreak = sqrtf(sumA) < 0.0005 * 1.2f && sqrtf(sumB) < 0.00005 * 1.2f && sqrtf(sumR) < 0.00005 * 1.2f && sqrtf(sumT) * sumNID < 0.00005 * 1.2f;
+    O.iterations = O.iterations + 1;
+    O.resInA = (int)B.accum[acc_off_nres(nf)];
+    if (stop_on_convergence && canbreak && iteration >= 1) { O.phase = 1; B.finished = 1; }
+  }
+}
+
+// what the host needs back from a resident loop, one record per window (one D2H copy per batch)
+struct BaOptOut {
+  double state[8][10];
+  double calib_value[4];
+  double lastEnergy;
+  float frameTH_new;
+  int iterations, resInA, pad;
+};
+__global__ __launch_bounds__(128) void k_ba_opt_release(const BaDev* __restrict__ wins, BaOptOut* __restrict__ out) {
+  BaDev& B = const_cast<BaDev&>(wins[blockIdx.x]);
+  BaOptDev& O = *B.opt;
+  BaOptOut& R = out[blockIdx.x];
+  const int tid = threadIdx.x;
+  if (tid < 80) R.state[tid / 10][tid % 10] = O.state[tid / 10][tid % 10];
+  if (tid >= 96 && tid < 100) R.calib_value[tid - 96] = O.calib_value[tid - 96];
+  if (tid == 127) {
+    R.lastEnergy = O.lastEnergy; R.frameTH_new = O.frameTH_new; R.iterations = O.iterations; R.resInA = O.resInA; R.pad = 0;
+    O.phase = 0;
+    B.finished = 0;
+  }
+}
+
+}  // namespace sdso

@@ -44,7 +44,7 @@ __device__ __forceinline__ void fold_sc_body(const BaDev& B, int b, int lane) {
   }
 }
 
-__global__ __launch_bounds__(64) void k_ba_fold_sc(const BaDev* __restrict__ wins) { fold_sc_body(wins[blockIdx.y], blockIdx.x, threadIdx.x); }
+__global__ __launch_bounds__(64) void k_ba_fold_sc(const BaDev* __restrict__ wins) { if (ba_finished(wins[blockIdx.y])) return; fold_sc_body(wins[blockIdx.y], blockIdx.x, threadIdx.x); }
 // Hcc / bc after k_ba_sc_host: nf per-host partials of 20 floats
 __device__ __forceinline__ void fold_hcc_hosts(const BaDev& B, int lane) {
   if (lane < 20) {
@@ -53,12 +53,13 @@ __device__ __forceinline__ void fold_hcc_hosts(const BaDev& B, int lane) {
     B.accum[acc_off_Hcc(B.nf) + lane] = s;
   }
 }
-__global__ __launch_bounds__(64) void k_ba_fold_hcc(const BaDev* __restrict__ wins) { fold_hcc_hosts(wins[blockIdx.y], threadIdx.x); }
+__global__ __launch_bounds__(64) void k_ba_fold_hcc(const BaDev* __restrict__ wins) { if (ba_finished(wins[blockIdx.y])) return; fold_hcc_hosts(wins[blockIdx.y], threadIdx.x); }
 // every fold of one accumulate phase in ONE launch (the usual case: no linearized residuals, topL is just cleared):
 // grid.x = [nf^3 + nf^2 + 1 Schur bins | nf^2 top-A pairs | nf^2 top-L pairs], 128 threads
 // host_sc != 0: the Schur bins were written by k_ba_sc_host, only Hcc / bc remain (grid.x = 1 + 2 nf^2)
 __global__ __launch_bounds__(128) void k_ba_fold_all(const BaDev* __restrict__ wins, int host_sc) {
   const BaDev& B = wins[blockIdx.y];
+  if (ba_finished(B)) return;
   const int nf = B.nf, nf2 = nf * nf, nsc = host_sc ? 1 : nf2 * nf + nf2 + 1;
   const int b = blockIdx.x;
   if (b < nsc) { if (host_sc) fold_hcc_hosts(B, threadIdx.x); else if (threadIdx.x < 64) fold_sc_body(B, b, threadIdx.x); }
@@ -107,6 +108,7 @@ __host__ __device__ inline size_t sol_doubles(int n, int nf) { return sol_off_pr
 // grid.x = ceil(2 nf^2 / 4) blocks of 4 waves, one wave per S1 / S2 tile
 __global__ __launch_bounds__(256) void k_ba_stitch_pre(const BaDev* __restrict__ wins) {
   const BaDev& B = wins[blockIdx.y];
+  if (ba_finished(B)) return;
   const int nf = B.nf, nf2 = nf * nf;
   const int job = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (job >= 2 * nf2) return;
@@ -141,6 +143,7 @@ __global__ __launch_bounds__(256) void k_ba_stitch_pre(const BaDev* __restrict__
 constexpr int ST_WAVES = 4;
 __global__ __launch_bounds__(64 * ST_WAVES) void k_ba_stitch(const BaDev* __restrict__ wins) {
   const BaDev& B = wins[blockIdx.y];
+  if (ba_finished(B)) return;
   const int nf = B.nf, nf2 = nf * nf, n = B.n;
   const int per = nf2 + nf + 1;
   const int job = blockIdx.x * ST_WAVES + (threadIdx.x >> 6);
@@ -336,6 +339,7 @@ __global__ __launch_bounds__(64 * ST_WAVES) void k_ba_stitch(const BaDev* __rest
 #endif
 __global__ __launch_bounds__(BA_BLOCK) void k_ba_solve(const BaDev* __restrict__ wins, double lambda, int orthogonalize_x) {
   const BaDev& B = wins[blockIdx.y];
+  if (ba_finished(B)) return;
 #ifdef SDSO_SOLVE_STAMPS
   unsigned long long stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0}, acc_t[6] = {0, 0, 0, 0, 0, 0};
 #endif
@@ -580,6 +584,7 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_solve(const BaDev* __restrict__
 // ------------------------------------------------------------------ back-substitution, one lane per point
 __global__ __launch_bounds__(BA_BLOCK) void k_ba_resub(const BaDev* __restrict__ wins) {
   const BaDev& B = wins[blockIdx.y];
+  if (ba_finished(B)) return;
   const int p = blockIdx.x * BA_BLOCK + threadIdx.x;
   if (p >= B.np) return;
   float* po = B.p_out + (size_t)p * 16;
@@ -608,16 +613,20 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_resub(const BaDev* __restrict__
 }
 
 // FullSystem::backupState / doStepFromBackup / loadSateBackup for the points.  op: 0 backup, 1 step, 2 restore
-__global__ __launch_bounds__(BA_BLOCK) void k_ba_points_op(const BaDev* __restrict__ wins, int op, float stepfacD, float* __restrict__ sums /* per block: sumID, sumNID */) {
+// op 3 = backup + step in one pass (the resident loop never restores)
+__global__ __launch_bounds__(BA_BLOCK) void k_ba_points_op(const BaDev* __restrict__ wins, int op, float stepfacD, float* __restrict__ sums /* per block: sumID, sumNID */,
+                                                           int sums_stride = 0 /* floats between the windows' sums */) {
   const BaDev& B = wins[blockIdx.y];
+  if (ba_finished(B)) return;
   const int p = blockIdx.x * BA_BLOCK + threadIdx.x;
   float sID = 0, sNID = 0;
   if (p < B.np) {
     float* po = B.p_out + (size_t)p * 16;
     float4 g = B.p_geo[p];
     if (op == 0) po[PO_BACKUP] = g.z;
-    else if (op == 1) {
-      const float st = po[PO_STEP], bk = po[PO_BACKUP];
+    else if (op == 1 || op == 3) {
+      if (op == 3) po[PO_BACKUP] = g.z;
+      const float st = po[PO_STEP], bk = op == 3 ? g.z : po[PO_BACKUP];
       const float nid = bk + stepfacD * st;
       g.z = nid; g.w = nid;     // setIdepth + setIdepthZero
       B.p_geo[p] = g;
@@ -638,7 +647,8 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_points_op(const BaDev* __restri
     if (threadIdx.x == 0) {
       float s0 = 0, s1 = 0;
       for (int w = 0; w < BA_BLOCK / 64; w++) { s0 += r0[w]; s1 += r1[w]; }
-      sums[blockIdx.x * 2] = s0; sums[blockIdx.x * 2 + 1] = s1;
+      float* so = sums + (size_t)blockIdx.y * sums_stride;
+      so[blockIdx.x * 2] = s0; so[blockIdx.x * 2 + 1] = s1;
     }
   }
 }

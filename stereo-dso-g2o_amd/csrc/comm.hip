@@ -26,6 +26,7 @@ struct RcclApi {
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 static RcclApi* rccl_api(std::string* why) {
@@ -44,8 +45,9 @@ static RcclApi* rccl_api(std::string* why) {
       api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.lib, "ncclCommInitRank");
       api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.lib, "ncclCommDestroy");
       api.AllReduce = (decltype(api.AllReduce))dlsym(api.lib, "ncclAllReduce");
+      api.AllGather = (decltype(api.AllGather))dlsym(api.lib, "ncclAllGather");
       api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.lib, "ncclGetErrorString");
-      if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllReduce) { err = "RCCL symbols missing"; api.lib = nullptr; }
+      if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllReduce || !api.AllGather) { err = "RCCL symbols missing"; api.lib = nullptr; }
     }
   }
   if (!api.lib) { if (why) *why = err; return nullptr; }
@@ -72,6 +74,34 @@ static std::shared_ptr<Comm> comm_of(sdso_ctx* ctx) {
 }  // namespace sdso
 
 using namespace sdso;
+
+namespace sdso {
+// used by the resident GN loop (ba.hip): ranks of ctx's communicator (1 without one), the all-gather of the per-rank energy / break-test
+// records, and the max over ranks of a host int (collective, synchronises the ctx stream)
+int comm_nranks(sdso_ctx* ctx) { auto c = comm_of(ctx); return c ? c->nranks : 1; }
+int comm_allgather_floats(sdso_ctx* ctx, const float* send, float* recv, size_t nfloats) {
+  auto c = comm_of(ctx);
+  if (!c) return sdso::fail(ctx, SDSO_ERR_STATE, "no communicator");
+  RcclApi* a = rccl_api(nullptr);
+  const ncclResult_t r = a->AllGather(send, recv, nfloats, ncclFloat32, c->comm, ctx->stream);
+  if (r != ncclSuccess) return sdso::fail(ctx, SDSO_ERR_HIP, std::string("ncclAllGather: ") + (a->GetErrorString ? a->GetErrorString(r) : "RCCL error"));
+  return SDSO_OK;
+}
+int comm_max_int(sdso_ctx* ctx, int* value) {
+  auto c = comm_of(ctx);
+  if (!c) return SDSO_OK;
+  RcclApi* a = rccl_api(nullptr);
+  int* d = nullptr;
+  if (hipMalloc(&d, sizeof(int)) != hipSuccess) return sdso::fail(ctx, SDSO_ERR_HIP, "hipMalloc");
+  hipMemcpyAsync(d, value, sizeof(int), hipMemcpyHostToDevice, ctx->stream);
+  const ncclResult_t r = a->AllReduce(d, d, 1, ncclInt32, ncclMax, c->comm, ctx->stream);
+  hipMemcpyAsync(value, d, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+  const hipError_t e = hipStreamSynchronize(ctx->stream);
+  hipFree(d);
+  if (r != ncclSuccess || e != hipSuccess) return sdso::fail(ctx, SDSO_ERR_HIP, "all-reduce(max) of the pack capacity failed");
+  return SDSO_OK;
+}
+}  // namespace sdso
 
 #define SDSO_NCCL(ctx, api, expr)                                                                                              \
   do {                                                                                                                         \

@@ -179,7 +179,7 @@ SDSO_HD inline void mul3f(const float* a, const float* b, float* c) {
     }
   for (int i = 0; i < 9; ++i) c[i] = r[i];
 }
-inline void mulv3f(const float* a, const float* x, float* y) {
+SDSO_HD inline void mulv3f(const float* a, const float* x, float* y) {
   float r[3];
   for (int i = 0; i < 3; ++i) {
     float s = a[i * 3] * x[0];

@@ -1,0 +1,179 @@
+"""The device-resident Gauss-Newton loop (csrc/ba_opt.hip: sdso_ba_optimize's accepted-step path, sdso_ba_batch_optimize,
+sdso_ba_batch_optimize_begin / sdso_ba_batch_step / _end) against the oracle's FullSystem::optimize and against the library's own host
+loop (SDSO_BA_HOST_LOOP=1, see test_resident_equals_host_loop).
+
+Bars: iteration counts, resInA and the residual states equal; states / idepths within 1e-5 + twice the oracle's own order-of-summation
+spread (cf. tests/test_ba_gpu.py::test_optimize_full_gn_loop); setNewFrameEnergyTH's quantile is an order statistic, so the device radix
+select must reproduce nth_element exactly — checked through the residual states (IN / OUTLIER decisions) and lastEnergy."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from sdso_amd import abi, synth
+import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_opt(oracle, win, its):
+    nf, npts, nr = win["nf"], win["np"], win["nr"]
+    W, keep = abi.make_ba_window(win, frame_slots=list(range(nf)), dI_list=[p[0] for p in win["pyrs"]])
+    h = oracle.orc_ba_create(C.byref(W))
+    s, i, r, o = np.zeros((nf, 10)), np.zeros(npts, np.float32), np.zeros(nr, np.uint8), abi.BAOptResult()
+    oracle.orc_ba_optimize(h, its, abi.dp(s), abi.fp(i), abi.bp(r), C.byref(o))
+    oracle.orc_ba_destroy(h)
+    return s, i, r, o
+
+
+def _spread(oracle, win, its, so, io):
+    ss, si = 0.0, 0.0
+    for seed in (1, 3):
+        w2, order = helpers.permuted_window(win, seed)
+        sp, ip, rp, op = _oracle_opt(oracle, w2, its)
+        ss = max(ss, np.abs(sp - so).max())
+        si = max(si, np.abs(ip - io[order]).max())
+    return ss, si
+
+
+def _check(win, got, ref, spread):
+    sg, ig, rg, og = got
+    so, io, ro, oo = ref
+    assert og.iterations == oo.iterations
+    assert np.abs(sg - so).max() <= 1e-5 + 2.0 * spread[0], (np.abs(sg - so).max(), spread)
+    assert np.abs(ig - io).max() <= 1e-5 + 2.0 * spread[1], (np.abs(ig - io).max(), spread)
+    mism = int((rg != ro).sum())
+    assert mism <= max(2, win["nr"] // 2000)                  # IN / OUTLIER flips only where an energy sits on the threshold
+    assert og.resInA == oo.resInA or mism > 0
+    assert abs(og.lastEnergy - oo.lastEnergy) <= 1e-4 * oo.lastEnergy
+    assert abs(og.rmse - oo.rmse) <= 1e-4 * oo.rmse
+
+
+WINS = {
+    "small": dict(w=640, h=480, nf=5, pts_per_kf=120, seed=3001),
+    "c3": dict(w=1232, h=368, nf=8, pts_per_kf=250, seed=3001),
+    "noisy": dict(w=640, h=480, nf=6, pts_per_kf=150, seed=3017, idepth_noise=0.3, state_noise=1e-2),   # larger steps, no early break
+    "three_kf": dict(w=640, h=480, nf=3, pts_per_kf=150, seed=3019),                                     # nf < 4: 15 iterations
+}
+
+
+@pytest.mark.parametrize("which", list(WINS))
+def test_single_window_resident_loop(gpu_ctx, oracle, which):
+    """sdso_ba_optimize with forceAcceptStep (the default): the whole loop runs on the device."""
+    win = synth.ba_window(**WINS[which])
+    nf, npts, nr = win["nf"], win["np"], win["nr"]
+    assert win.get("forceAcceptStep", 1)
+    ref = _oracle_opt(oracle, win, 6)
+    for f in range(nf):
+        gpu_ctx.upload_pyramid(500 + f, win["pyrs"][f][:1])
+    W, keep = abi.make_ba_window(win, frame_slots=[500 + f for f in range(nf)])
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_upload_window(gpu_ctx.h, 50, C.byref(W)))
+    sg, ig, rg, og = np.zeros((nf, 10)), np.zeros(npts, np.float32), np.zeros(nr, np.uint8), abi.BAOptResult()
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_optimize(gpu_ctx.h, 50, 6, abi.dp(sg), abi.fp(ig), abi.bp(rg), C.byref(og)))
+    _check(win, (sg, ig, rg, og), ref, _spread(oracle, win, 6, ref[0], ref[1]))
+    # the window stays usable through the per-window entry points afterwards (finished flag cleared, tables at the final state)
+    e = C.c_double(0)
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_linearize(gpu_ctx.h, 50, C.byref(e)))
+    assert abs(e.value - og.lastEnergy) <= 1e-6 * og.lastEnergy
+    s2 = np.zeros((nf, 10))
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_get_state(gpu_ctx.h, 50, abi.dp(s2), None, None))
+    assert np.array_equal(s2, sg)
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_release_window(gpu_ctx.h, 50))
+
+
+def test_resident_equals_host_loop(gpu_ctx, oracle, monkeypatch):
+    """Device loop vs the library's own host loop (SDSO_BA_HOST_LOOP=1, read per call) on the same windows: same decisions, states equal
+    up to what libm's sin / cos on host vs device and the fused vs un-fused summation order allow."""
+    for spec, mode in ((WINS["small"], 128 | 2048), (WINS["noisy"], 0)):       # default solverMode; and the decaying-lambda schedule
+        out = {}
+        for host in (0, 1):
+            win = dict(synth.ba_window(**spec))
+            win["solverMode"] = mode
+            nf, npts, nr = win["nf"], win["np"], win["nr"]
+            for f in range(nf):
+                gpu_ctx.upload_pyramid(510 + f, win["pyrs"][f][:1])
+            W, keep = abi.make_ba_window(win, frame_slots=[510 + f for f in range(nf)])
+            gpu_ctx.check(gpu_ctx.L.sdso_ba_upload_window(gpu_ctx.h, 51, C.byref(W)))
+            if host:
+                monkeypatch.setenv("SDSO_BA_HOST_LOOP", "1")
+            else:
+                monkeypatch.delenv("SDSO_BA_HOST_LOOP", raising=False)
+            s, i, r, o = np.zeros((nf, 10)), np.zeros(npts, np.float32), np.zeros(nr, np.uint8), abi.BAOptResult()
+            gpu_ctx.check(gpu_ctx.L.sdso_ba_optimize(gpu_ctx.h, 51, 6, abi.dp(s), abi.fp(i), abi.bp(r), C.byref(o)))
+            out[host] = (s, i, r, o)
+            gpu_ctx.check(gpu_ctx.L.sdso_ba_release_window(gpu_ctx.h, 51))
+        monkeypatch.delenv("SDSO_BA_HOST_LOOP", raising=False)
+        (s1, i1, r1, o1), (s0, i0, r0, o0) = out[0], out[1]
+        assert o1.iterations == o0.iterations and o1.resInA == o0.resInA
+        assert np.array_equal(r1, r0)
+        assert np.abs(s1 - s0).max() <= 2e-6 and np.abs(i1 - i0).max() <= 2e-5, (np.abs(s1 - s0).max(), np.abs(i1 - i0).max())
+        assert abs(o1.lastEnergy - o0.lastEnergy) <= 1e-5 * o0.lastEnergy
+
+
+def test_batch_resident_loop(gpu_ctx, oracle):
+    """sdso_ba_batch_optimize over windows that stop at different iterations: each window must match its own oracle run; then the same
+    batch through begin / accumulate / solve / step / end."""
+    specs = [dict(w=1232, h=368, nf=8, pts_per_kf=250, seed=3001),
+             dict(w=1232, h=368, nf=8, pts_per_kf=250, seed=3008, idepth_noise=0.3, state_noise=1e-2),
+             dict(w=1232, h=368, nf=8, pts_per_kf=120, seed=3015)]
+    wins = [synth.ba_window(**s) for s in specs]
+    nf = 8
+    refs = [_oracle_opt(oracle, w, 6) for w in wins]
+    assert len({r[3].iterations for r in refs}) >= 2, "the batch should mix early and late finishers"
+    spreads = [_spread(oracle, w, 6, r[0], r[1]) for w, r in zip(wins, refs)]
+    keepalive = []
+
+    def upload():
+        for k, win in enumerate(wins):
+            for f in range(nf):
+                gpu_ctx.upload_pyramid(520 + k * nf + f, win["pyrs"][f][:1])
+            W, keep = abi.make_ba_window(win, frame_slots=[520 + k * nf + f for f in range(nf)])
+            keepalive.append((W, keep))
+            gpu_ctx.check(gpu_ctx.L.sdso_ba_upload_window(gpu_ctx.h, 60 + k, C.byref(W)))
+        ids = np.array([60 + k for k in range(len(wins))], np.int32)
+        gpu_ctx.check(gpu_ctx.L.sdso_ba_batch_create(gpu_ctx.h, len(wins), abi.ip(ids)))
+
+    def readback(k, res):
+        win = wins[k]
+        s, i, r = np.zeros((nf, 10)), np.zeros(win["np"], np.float32), np.zeros(win["nr"], np.uint8)
+        gpu_ctx.check(gpu_ctx.L.sdso_ba_get_state(gpu_ctx.h, 60 + k, abi.dp(s), abi.fp(i), abi.bp(r)))
+        return s, i, r, res[k]
+
+    upload()
+    res = (abi.BAOptResult * len(wins))()
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_batch_optimize(gpu_ctx.h, 6, res))
+    for k in range(len(wins)):
+        _check(wins[k], readback(k, res), refs[k], spreads[k])
+    first = [readback(k, res) for k in range(len(wins))]
+
+    upload()                                                   # fresh states; the same loop in pieces, Jacobians kept in registers
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_batch_set_materialize(gpu_ctx.h, 0))
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_batch_optimize_begin(gpu_ctx.h, 1))
+    for it in range(6):
+        gpu_ctx.check(gpu_ctx.L.sdso_ba_batch_accumulate(gpu_ctx.h))
+        orth = 1 if it >= 2 else 0                             # SOLVER_ORTHOGONALIZE_X_LATER of the default solverMode
+        gpu_ctx.check(gpu_ctx.L.sdso_ba_batch_solve(gpu_ctx.h, 0.1 * 0.25 ** it, orth))
+        gpu_ctx.check(gpu_ctx.L.sdso_ba_batch_step(gpu_ctx.h))
+    res2 = (abi.BAOptResult * len(wins))()
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_batch_optimize_end(gpu_ctx.h, res2))
+    for k in range(len(wins)):
+        s, i, r, o = readback(k, res2)
+        assert o.iterations == first[k][3].iterations and o.resInA == first[k][3].resInA
+        assert np.array_equal(s, first[k][0]) and np.array_equal(i, first[k][1]) and np.array_equal(r, first[k][2])
+    assert gpu_ctx.L.sdso_ba_batch_step(gpu_ctx.h) != 0        # no loop in flight any more
+    for k in range(len(wins)):
+        gpu_ctx.check(gpu_ctx.L.sdso_ba_release_window(gpu_ctx.h, 60 + k))
+
+
+def test_resident_loop_refuses_gated_windows(gpu_ctx):
+    win = dict(synth.ba_window(w=320, h=240, nf=4, pts_per_kf=40, seed=3093))
+    win["forceAcceptStep"] = 0
+    for f in range(4):
+        gpu_ctx.upload_pyramid(560 + f, win["pyrs"][f][:1])
+    W, keep = abi.make_ba_window(win, frame_slots=[560 + f for f in range(4)])
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_upload_window(gpu_ctx.h, 70, C.byref(W)))
+    ids = np.array([70], np.int32)
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_batch_create(gpu_ctx.h, 1, abi.ip(ids)))
+    assert gpu_ctx.L.sdso_ba_batch_optimize_begin(gpu_ctx.h, 1) != 0
+    assert b"forceAceptStep" in gpu_ctx.L.sdso_last_error(gpu_ctx.h)
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_release_window(gpu_ctx.h, 70))
