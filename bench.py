@@ -158,7 +158,12 @@ class TraceWorkload:
     def verify(self):
         st = np.zeros(self.P.n, np.uint8)
         self.ctx.check(self.ctx.L.sdso_trace_stereo_fetch(self.ctx.h, C.byref(self.P), self.abi.bp(st)))
-        return {"good_fraction": float((st == 0).mean())}
+        # taps of one launch: a point that reaches the discrete search (status GOOD or OUTLIER; OOB / SKIPPED / BADCONDITION leave before
+        # it) samples numSteps x 8 pattern pixels x 4 bilinear taps of the 4-byte plane, then <= 3 GN passes x 8 x 4 taps.  Fresh
+        # immature points search the full maxPixSearch = 0.027 (w + h) = 43.2 px -> numSteps = 45 (ImmaturePoint.cpp:238-258).
+        searched = int(((st == 0) | (st == 2)).sum())
+        self.taps_per_step = searched * (45 * 32 + 3 * 32)
+        return {"good_fraction": float((st == 0).mean()), "searched_points": searched, "taps_per_launch": self.taps_per_step}
 
     def cpu_baseline(self, budget_s=10.0):
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -199,8 +204,15 @@ def side_run(cls, ctx, args, rank, steps=30, warmup=5):
     wl.verify()
     avg = kms / max(kl, 1)
     ach = wl.units_per_step * steps / max(kl, 1) * wl.bytes_per_unit / (avg * 1e-3) / 1e9 if avg > 0 else 0.0
-    return {"workload": wl.config["workload"], "value": wl.units_per_step * steps / dt, "unit": wl.unit, "ms_per_step": dt / steps * 1e3,
-            "kernel": wl.kernel, "kernel_avg_ms": avg, "roofline_frac_hbm": ach / HBM_PEAK_GBS}
+    out = {"workload": wl.config["workload"], "value": wl.units_per_step * steps / dt, "unit": wl.unit, "ms_per_step": dt / steps * 1e3,
+           "kernel": wl.kernel, "kernel_avg_ms": avg, "roofline_frac_hbm": ach / HBM_PEAK_GBS}
+    if getattr(wl, "taps_per_step", 0) and avg > 0:
+        # on-chip roofline of the tap gathers (MI355X_MICROARCH.md: L2 ~34.5 TB/s aggregate; LDS ds_read_b32 ~75 TB/s aggregate):
+        # 4-byte taps per second against what the cache hierarchy / the LDS array could deliver
+        taps = wl.taps_per_step / (avg * 1e-3)
+        out["onchip"] = {"taps_per_s": taps, "tap_bytes_GBps": taps * 4 / 1e9, "frac_of_l2_rate": taps * 4 / 34.5e12, "frac_of_lds_b32_rate": taps * 4 / 75e12,
+                         "lds_band_variant": os.environ.get("SDSO_TRACE_BAND") is not None}
+    return out
 
 
 def main():

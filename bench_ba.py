@@ -105,24 +105,26 @@ class BAWorkload:
             if self.lib_comm:
                 # any rank that cannot open the library communicator (librccl not loadable ...) sends every rank to the torch
                 # collective on the same block: the line is then still measured, and says so in config.exchange
+                # one communicator PER stream group: the groups' collectives run on different streams and interleave, and each group
+                # issues its own sequence (all-reduce, all-gather) in program order on every rank
                 ok, why = 1, ""
-                try:
+                for G in self.groups:
                     uid = np.zeros(128, np.uint8)
-                    if rank == 0:
-                        ctx.check(ctx.L.sdso_comm_unique_id(uid.ctypes.data_as(C.c_void_p)))
-                except RuntimeError as e:
-                    ok, why = 0, str(e)
-                t = torch.from_numpy(uid).cuda()
-                dist.broadcast(t, src=0)
-                uid = t.cpu().numpy().copy()
-                g0 = self.groups[0]
-                if ok:
                     try:
-                        g0.ctx.check(g0.ctx.L.sdso_comm_init(g0.ctx.h, world, rank, uid.ctypes.data_as(C.c_void_p)))
-                        for G in self.groups[1:]:
-                            G.ctx.check(G.ctx.L.sdso_comm_attach(G.ctx.h, g0.ctx.h))
+                        if rank == 0 and ok:
+                            G.ctx.check(G.ctx.L.sdso_comm_unique_id(uid.ctypes.data_as(C.c_void_p)))
                     except RuntimeError as e:
                         ok, why = 0, str(e)
+                    t = torch.from_numpy(uid).cuda()
+                    dist.broadcast(t, src=0)
+                    uid = t.cpu().numpy().copy()
+                    if not uid.any():
+                        ok, why = 0, why or "rank 0 could not create a communicator id"
+                    if ok:
+                        try:
+                            G.ctx.check(G.ctx.L.sdso_comm_init(G.ctx.h, world, rank, uid.ctypes.data_as(C.c_void_p)))
+                        except RuntimeError as e:
+                            ok, why = 0, str(e)
                 flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
                 if int(flag.item()) == 1:
@@ -146,6 +148,17 @@ class BAWorkload:
                        "jacobians_materialized": bool(self.materialize), "stream_groups": ngroups,
                        "allreduce_floats": nfl_total if world > 1 else 0, "exchange": getattr(self, "exchange", None),
                        "parallelism": ("allPoints of every window cut into %d contiguous ranges, 1 RCCL all-reduce (sdso_ba_allreduce) of the packed accumulators per group and iteration" % world) if world > 1 else "single GPU"}
+        # correctness at the initial state (one iteration, before the timed loop moves the states): see _verify_initial
+        self.initial_check = self._verify_initial()
+        # the timed step advances REAL state: the device-resident GN loop (sdso_ba_batch_optimize_begin / sdso_ba_batch_step) takes the step
+        # the solver produced, rebuilds the tables and moves the newest frame's energy threshold, every step, on every window.
+        # SDSO_BA_BENCH_STATIC=1: the round-1 behaviour (re-linearise the same state every step).
+        self.advance = os.environ.get("SDSO_BA_BENCH_STATIC") != "1" and (world == 1 or self.lib_comm)
+        if self.advance:
+            for G in self.groups:
+                G.ctx.check(G.ctx.L.sdso_ba_batch_optimize_begin(G.ctx.h, 0))
+        self.config["state_advances"] = bool(self.advance)
+        self.max_abs_x_steps = []
         print("[rank %d] BA setup %.1fs: %d windows x %d residuals in %d stream group(s)" % (rank, time.time() - t0, nwin, win["nr"], ngroups), file=sys.stderr, flush=True)
 
     # bench.py drives profiling / synchronisation through these so that every group's ctx is covered
@@ -191,14 +204,29 @@ class BAWorkload:
                 with self.torch.cuda.stream(G.stream):
                     dist.all_reduce(G.accum, op=dist.ReduceOp.SUM)
             G.ctx.check(G.ctx.L.sdso_ba_batch_solve(G.ctx.h, 1e-5, 0))
+            if self.advance:
+                G.ctx.check(G.ctx.L.sdso_ba_batch_step(G.ctx.h))      # doStepFromBackup + tables + setNewFrameEnergyTH on the device (+ all-gather when sharded)
             prev = G
 
-    def verify(self):
-        """x of every window is finite; window 0's x (fused batch path, summed over the ranks when sharded) equals the x of the
-        UNSHARDED global window solved through the un-fused single-window entry points on this GPU (2e-4 in the whitened metric,
-        the bar of tests/test_ba_gpu.py)."""
+    def _one_iteration(self):
+        gs = self.groups
+        for G in gs:
+            G.ctx.check(G.ctx.L.sdso_ba_batch_accumulate(G.ctx.h))
+            if self.lib_comm:
+                G.ctx.check(G.ctx.L.sdso_ba_allreduce(G.ctx.h))
+            elif G.accum is not None:
+                import torch.distributed as dist
+                with self.torch.cuda.stream(G.stream):
+                    dist.all_reduce(G.accum, op=dist.ReduceOp.SUM)
+            G.ctx.check(G.ctx.L.sdso_ba_batch_solve(G.ctx.h, 1e-5, 0))
+
+    def _verify_initial(self):
+        """One GN iteration at the uploaded state: x of every window is finite; window 0's x (fused batch path, summed over the ranks
+        when sharded) equals the x of the UNSHARDED global window solved through the un-fused single-window entry points on this GPU
+        (2e-4 in the whitened metric, the bar of tests/test_ba_gpu.py)."""
         abi = self.abi
-        out = {"jacobians_materialized": bool(self.materialize)}
+        self._one_iteration()
+        out = {}
         mx, x0 = 0.0, None
         for G in self.groups:
             x = np.zeros((G.nwin, 68))
@@ -207,7 +235,7 @@ class BAWorkload:
             mx = max(mx, float(np.abs(x).max()))
             if x0 is None:
                 x0 = x[0].copy()
-        out["max_abs_x"] = mx
+        out["max_abs_x_initial"] = mx
         if self.rank == 0:
             g0, wg, nf = self.groups[0], self.win_global, self.win_global["nf"]
             W, keep = abi.make_ba_window(wg, frame_slots=[1000 + f for f in range(nf)])          # the pyramids of window 0
@@ -222,6 +250,23 @@ class BAWorkload:
             err = float(np.abs((x0 - xr) * d).max() / max(1.0, np.abs(xr * d).max()))
             out["sharded_x_whitened_err" if self.world > 1 else "fused_vs_unfused_x_whitened_err"] = err
             assert err <= 2e-4, "x of window 0 differs from the unsharded / un-fused reference solve: %g" % err
+        return out
+
+    def verify(self):
+        """After the timed steps: x of every window still finite; with state_advances the Gauss-Newton steps must have shrunk
+        (max |x| of the last step against the first iteration's) — the loop really moved the states towards the optimum."""
+        abi = self.abi
+        out = {"jacobians_materialized": bool(self.materialize)}
+        out.update(self.initial_check)
+        mx = 0.0
+        for G in self.groups:
+            x = np.zeros((G.nwin, 68))
+            G.ctx.check(G.ctx.L.sdso_ba_batch_get_x(G.ctx.h, abi.dp(x)))
+            assert np.isfinite(x).all()
+            mx = max(mx, float(np.abs(x).max()))
+        out["max_abs_x"] = mx
+        if self.advance:
+            assert mx < out["max_abs_x_initial"], "the GN steps did not shrink: %g -> %g" % (out["max_abs_x_initial"], mx)
         for k in ("k_ba_lin_fused", "k_ba_sc"):
             ms, n = self.prof_read(k)
             out[k + "_avg_ms"] = ms / max(n, 1)

@@ -22,6 +22,7 @@
 #ifndef SDSO_ABI_H
 #define SDSO_ABI_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -347,6 +348,12 @@ int sdso_ba_get_state(sdso_ctx* ctx, int win, double* state_out /* nf*10 */, flo
 int sdso_comm_unique_id(void* id128);
 int sdso_comm_init(sdso_ctx* ctx, int nranks, int rank, const void* id128);
 int sdso_comm_attach(sdso_ctx* ctx, sdso_ctx* owner);
+/* The same communicator over a transport of the caller's (MPI, sockets, a test harness) instead of RCCL: the library stages each
+ * collective through host memory and calls allreduce (in-place sum of n floats) / allgather (n floats per rank, rank-major into recv);
+ * both return 0 on success.  Slow path by construction (it synchronises the ctx stream around every collective). */
+typedef int (*sdso_host_allreduce_fn)(void* user, float* buf, size_t n);
+typedef int (*sdso_host_allgather_fn)(void* user, const float* send, float* recv, size_t n);
+int sdso_comm_init_host(sdso_ctx* ctx, int nranks, int rank, sdso_host_allreduce_fn allreduce, sdso_host_allgather_fn allgather, void* user);
 int sdso_comm_info(sdso_ctx* ctx, int* nranks, int* rank);   /* nranks = 0 without a communicator */
 int sdso_comm_destroy(sdso_ctx* ctx);
 int sdso_ba_allreduce(sdso_ctx* ctx);

@@ -10,6 +10,8 @@
 #include <cmath>
 #include <cstring>
 #include <numeric>
+#include <atomic>
+#include <thread>
 
 namespace sdso {
 
@@ -122,11 +124,28 @@ void release_all_windows(sdso_ctx* ctx) {
   ctx->wins.clear();
 }
 
-static int upload_tables(sdso_ctx* ctx, BaWindowDev* W, bool adjoints, bool sync = true) {
+// the CPU half of upload_tables: everything derived from the frame states / calibration, into the window's own staging members
+// (no HIP call: safe to run for several windows on several host threads)
+static void build_tables(BaWindowDev* W, bool adjoints) {
   const int nf = W->d.nf, n = W->d.n;
   buildPrecalc(W->calib, W->frames, W->tab);
   if (adjoints) { buildAdjoints(W->frames, W->tab); W->P = buildNullspaceProjector(W->frames); }
   buildDelta(W->calib, W->frames, W->tab);
+  std::vector<double>& pr = W->h_prstage;   // member: the copy may still be in flight when upload_tables returns (sync == false)
+  pr.assign((size_t)nf * 16 + 4 + n, 0.0);
+  for (int f = 0; f < nf; f++)
+    for (int i = 0; i < 8; i++) { pr[f * 8 + i] = W->frames[f].prior[i]; pr[nf * 8 + f * 8 + i] = W->frames[f].delta_prior[i]; }
+  for (int i = 0; i < 4; i++) pr[nf * 16 + i] = W->tab.cPrior[i];
+  for (int i = 0; i < 4; i++) pr[nf * 16 + 4 + i] = (double)W->tab.cDeltaF[i];
+  for (int f = 0; f < nf; f++) for (int i = 0; i < 8; i++) pr[nf * 16 + 4 + 4 + f * 8 + i] = W->frames[f].delta[i];
+  // calibration scalars live in the descriptor
+  W->d.fxl = W->calib.value_scaledf[0]; W->d.fyl = W->calib.value_scaledf[1];
+  W->d.cxl = W->calib.value_scaledf[2]; W->d.cyl = W->calib.value_scaledf[3];
+  W->d.fxli = W->calib.value_scaledi[0]; W->d.fyli = W->calib.value_scaledi[1];
+}
+static int upload_tables(sdso_ctx* ctx, BaWindowDev* W, bool adjoints, bool sync = true, bool built = false) {
+  const int nf = W->d.nf, n = W->d.n;
+  if (!built) build_tables(W, adjoints);
   H2D(W->dt_precalc, W->tab.precalc.data(), sizeof(float) * nf * nf * 27);
   H2D(W->dt_adHTdelta, W->tab.adHTdeltaF.data(), sizeof(float) * nf * nf * 8);
   H2D(W->dt_cdelta, W->tab.cDeltaF, sizeof(float) * 4);
@@ -135,18 +154,8 @@ static int upload_tables(sdso_ctx* ctx, BaWindowDev* W, bool adjoints, bool sync
     H2D(W->dt_adTarget, W->tab.adTarget.data(), sizeof(double) * nf * nf * 64);
     H2D(W->dt_P, W->P.a.data(), sizeof(double) * n * n);
   }
-  std::vector<double>& pr = W->h_prstage;   // member: the copy may still be in flight when this returns (sync == false)
-  pr.assign((size_t)nf * 16 + 4 + n, 0.0);
-  for (int f = 0; f < nf; f++)
-    for (int i = 0; i < 8; i++) { pr[f * 8 + i] = W->frames[f].prior[i]; pr[nf * 8 + f * 8 + i] = W->frames[f].delta_prior[i]; }
-  for (int i = 0; i < 4; i++) pr[nf * 16 + i] = W->tab.cPrior[i];
-  for (int i = 0; i < 4; i++) pr[nf * 16 + 4 + i] = (double)W->tab.cDeltaF[i];
-  for (int f = 0; f < nf; f++) for (int i = 0; i < 8; i++) pr[nf * 16 + 4 + 4 + f * 8 + i] = W->frames[f].delta[i];
+  std::vector<double>& pr = W->h_prstage;
   H2D(W->dt_prior, pr.data(), sizeof(double) * pr.size());
-  // calibration scalars live in the descriptor
-  W->d.fxl = W->calib.value_scaledf[0]; W->d.fyl = W->calib.value_scaledf[1];
-  W->d.cxl = W->calib.value_scaledf[2]; W->d.cyl = W->calib.value_scaledf[3];
-  W->d.fxli = W->calib.value_scaledi[0]; W->d.fyli = W->calib.value_scaledi[1];
   H2D(W->d_self, &W->d, sizeof(BaDev));
   if (sync) SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the tables in W->tab are rebuilt by the next call
   return SDSO_OK;
@@ -1238,6 +1247,7 @@ extern "C" int sdso_ba_marginalize_frame(int nf, int idx, const double* prior8, 
 // ------------------------------------------------------------------ device-resident Gauss-Newton loop (ba_opt.hip)
 namespace sdso {
 int comm_nranks(sdso_ctx* ctx);                                                            // comm.hip
+bool comm_present(sdso_ctx* ctx);                                                          // comm.hip
 int comm_allgather_floats(sdso_ctx* ctx, const float* send, float* recv, size_t nfloats);  // comm.hip
 int comm_max_int(sdso_ctx* ctx, int* value);                                               // comm.hip
 
@@ -1271,6 +1281,7 @@ struct OptRun {
   std::vector<BaWindowDev*> W;
   bool materialize = true; int gather = 1;
   int cap = 0, nranks = 1, sums_stride = 0, iteration = 0, stop = 1;
+  bool exchange = false;   // pack + all-gather between the ranks (always when nranks > 1)
   bool active = false;
   OptBufs* B = nullptr;
 };
@@ -1285,7 +1296,9 @@ static int opt_begin(sdso_ctx* ctx, OptRun& R, int stop_on_convergence) {
     cap = std::max(cap, W->d.nr - W->newest_first);
   }
   R.nranks = comm_nranks(ctx);
-  if (R.nranks > 1) { int rc = comm_max_int(ctx, &cap); if (rc) return rc; }
+  // SDSO_OPT_FORCE_EXCHANGE: take the pack / all-gather path on a 1-rank communicator too (tests: the collectives of a 1-GPU box)
+  R.exchange = R.nranks > 1 || (comm_present(ctx) && getenv("SDSO_OPT_FORCE_EXCHANGE") != nullptr);
+  if (R.exchange) { int rc = comm_max_int(ctx, &cap); if (rc) return rc; }
   R.cap = cap;
   R.sums_stride = 2 * (R.L.max_nblk_pts + 1);
   if (!reg_has(g_optbufs, ctx)) reg_get(g_optbufs, ctx) = new OptBufs();
@@ -1295,7 +1308,7 @@ static int opt_begin(sdso_ctx* ctx, OptRun& R, int stop_on_convergence) {
   int rc;
   if ((rc = grow(ctx, B->d_sums, B->sums_cap, (size_t)nwin * R.sums_stride))) return rc;
   if ((rc = grow(ctx, B->d_pack, B->pack_cap, (size_t)nwin * pf))) return rc;
-  if (R.nranks > 1 && (rc = grow(ctx, B->d_gather, B->gather_cap, (size_t)R.nranks * nwin * pf))) return rc;
+  if (R.exchange && (rc = grow(ctx, B->d_gather, B->gather_cap, (size_t)R.nranks * nwin * pf))) return rc;
   if ((size_t)nwin > B->out_cap) {
     SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
     hipFree(B->d_out); if (B->h_out) hipHostFree(B->h_out);
@@ -1328,14 +1341,15 @@ static int opt_begin(sdso_ctx* ctx, OptRun& R, int stop_on_convergence) {
 static int opt_consume(sdso_ctx* ctx, OptRun& R, int last, bool unfused, bool with_sums) {
   const int nwin = (int)R.W.size();
   OptBufs* B = R.B;
-  hipLaunchKernelGGL(k_ba_opt_pack, dim3(1, nwin), dim3(256), 0, ctx->stream, R.L.d_arr, B->d_pack, R.cap, unfused ? 1 : 0, with_sums ? B->d_sums : (const float*)nullptr, R.sums_stride);
-  const float* gathered = B->d_pack;
-  if (R.nranks > 1) {
+  const float* gathered = nullptr;     // single rank: k_ba_opt_step reads the energies where the kernels left them
+  const float* sums = with_sums ? B->d_sums : (const float*)nullptr;
+  if (R.exchange) {
+    hipLaunchKernelGGL(k_ba_opt_pack, dim3(1, nwin), dim3(256), 0, ctx->stream, R.L.d_arr, B->d_pack, R.cap, unfused ? 1 : 0, sums, R.sums_stride);
     int rc = comm_allgather_floats(ctx, B->d_pack, B->d_gather, (size_t)nwin * opt_pack_floats(R.cap));
     if (rc) return rc;
     gathered = B->d_gather;
   }
-  hipLaunchKernelGGL(k_ba_opt_step, dim3(1, nwin), dim3(256), 0, ctx->stream, R.L.d_arr, gathered, R.nranks, R.cap, R.iteration, last, R.stop, 1.0f);
+  hipLaunchKernelGGL(k_ba_opt_step, dim3(1, nwin), dim3(256), 0, ctx->stream, R.L.d_arr, gathered, R.nranks, R.cap, R.iteration, last, R.stop, 1.0f, unfused ? 1 : 0, sums, R.sums_stride);
   SDSO_HIP(ctx, hipGetLastError());
   return SDSO_OK;
 }
@@ -1366,7 +1380,9 @@ static int opt_finish(sdso_ctx* ctx, OptRun& R, sdso_ba_opt_result_t* out) {
   if (rc) return rc;
   if ((rc = opt_collect(ctx, R))) return rc;
   std::vector<int> its(nwin), resInA(nwin);
-  for (int w = 0; w < nwin; w++) {
+  // host mirrors + the tables at the final state: CPU-only per window (numeric nullspaces, adjoints, the gauge projector), spread
+  // over host threads for a batch; the H2D enqueues follow on this thread
+  auto finalize = [&](int w) {
     BaWindowDev* W = R.W[w];
     const BaOptOut& o = R.B->h_out[w];
     its[w] = o.iterations; resInA[w] = o.resInA;
@@ -1377,7 +1393,19 @@ static int opt_finish(sdso_ctx* ctx, OptRun& R, sdso_ba_opt_result_t* out) {
     nsz[6] = W->frames[nf - 1].state[6];
     nsz[7] = W->frames[nf - 1].state[7];
     W->frames[nf - 1].setEvalPT(W->frames[nf - 1].PRE_worldToCam, nsz);
-    if ((rc = upload_tables(ctx, W, true, false))) return rc;
+    build_tables(W, true);
+  };
+  const int nthreads = std::max(1, std::min({nwin / 4, 16, (int)std::thread::hardware_concurrency()}));
+  if (nthreads <= 1) for (int w = 0; w < nwin; w++) finalize(w);
+  else {
+    std::atomic<int> next{0};
+    std::vector<std::thread> pool;
+    for (int t = 0; t < nthreads; t++) pool.emplace_back([&] { for (int w; (w = next.fetch_add(1)) < nwin;) finalize(w); });
+    for (std::thread& t : pool) t.join();
+  }
+  for (int w = 0; w < nwin; w++) {
+    BaWindowDev* W = R.W[w];
+    if ((rc = upload_tables(ctx, W, true, false, true))) return rc;
     if (W->in_batch) H2D(const_cast<BaDev*>(R.L.d_arr) + w, &W->d, sizeof(BaDev));   // the batch's descriptor copy carries the calibration scalars too
     W->accumulated = false;
   }
@@ -1410,7 +1438,7 @@ static int opt_iterations(int nf, int mnumOptIts) {
 // accumulate (fused linearisation + Schur part) -> [all-reduce] -> solve of iteration `it`
 static int opt_solve_phase(sdso_ctx* ctx, OptRun& R, int it) {
   launch_fused(ctx, R.L, R.materialize, R.gather);
-  if (R.nranks > 1) {
+  if (R.exchange) {
     int rc = R.W[0]->in_batch ? sdso_ba_allreduce(ctx) : SDSO_ERR_STATE;
     if (rc) return rc;
   }
@@ -1431,6 +1459,7 @@ int optimize_resident_single(sdso_ctx* ctx, BaWindowDev* W, int mnumOptIts, sdso
   int rc = opt_begin(ctx, R, 1);
   if (rc) return rc;
   if (R.nranks > 1) return sdso::fail(ctx, SDSO_ERR_STATE, "sdso_ba_optimize is a single-rank call; sharded windows use sdso_ba_batch_optimize");
+  R.exchange = false;
   const int N = opt_iterations(W->d.nf, mnumOptIts);
   for (int it = 0; it < N; it++) {
     if ((rc = opt_solve_phase(ctx, R, it))) return rc;

@@ -50,15 +50,27 @@ __global__ __launch_bounds__(256) void k_ba_opt_pack(const BaDev* __restrict__ w
   }
 }
 
-// the k-th smallest (0-based) of the non-negative floats v[r * rstride + 0..cap) over r < nranks: 4 radix passes over the bit patterns
-__device__ inline float opt_select(const float* __restrict__ v, int nranks, size_t rstride, int cap, int k, unsigned* hist /* LDS 256 */, unsigned* sh /* LDS 2 */) {
+// the energies that enter setNewFrameEnergyTH: the all-gathered records of every rank, or (single rank) the window's own residuals
+struct OptEnergies {
+  const float* g; size_t rstride; int nranks, cap;       // gathered records
+  const BaDev* B; int first;                             // local residuals (g == nullptr)
+  __device__ __forceinline__ int ranks() const { return g ? nranks : 1; }
+  __device__ __forceinline__ float at(int r, int j) const {
+    if (g) return g[r * rstride + j];
+    const int i = first + j;
+    return (i < B->nr && B->r_target[i] == B->nf - 1 && !B->r_lin[i]) ? B->r_newEnergyWO[i] : -1.f;
+  }
+};
+// the k-th smallest (0-based) of the non-negative values: 4 radix passes over the bit patterns
+__device__ inline float opt_select(const OptEnergies& v, int k, unsigned* hist /* LDS 256 */, unsigned* sh /* LDS 2 */) {
+  const int nranks = v.ranks(), cap = v.cap;
   unsigned prefix = 0, mask = 0;
   for (int shift = 24; shift >= 0; shift -= 8) {
     hist[threadIdx.x] = 0;
     __syncthreads();
     for (int r = 0; r < nranks; r++)
       for (int j = threadIdx.x; j < cap; j += 256) {
-        const float e = v[r * rstride + j];
+        const float e = v.at(r, j);
         if (!(e >= 0)) continue;
         const unsigned key = __float_as_uint(e);
         if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255], 1u);
@@ -78,20 +90,23 @@ __device__ inline float opt_select(const float* __restrict__ v, int nranks, size
   return __uint_as_float(prefix);
 }
 
-// One GN iteration's host part for every window.  gathered: [nranks][nwin][opt_pack_floats(cap)] (nranks = 1: the local pack).
+// One GN iteration's host part for every window.  gathered: [nranks][nwin][opt_pack_floats(cap)]; nullptr on a single rank: the
+// energies, energy partials and point sums are read where the kernels left them (no pack launch).
 //   last == 0:  consume the energies of the linearisation at the current state (lastEnergy, setNewFrameEnergyTH), take the step the
 //               solver left in sol (backupState + doStepFromBackup for frames and calibration; the points were stepped by
 //               k_ba_points_op), rebuild the tables (setPrecalcValues + setDeltaF), evaluate the break test.
 //   last != 0 or the break test fired in the previous call: consume the energies only, then mark the window finished.
 __global__ __launch_bounds__(256) void k_ba_opt_step(const BaDev* __restrict__ wins, const float* __restrict__ gathered, int nranks, int cap, int iteration, int last,
-                                                     int stop_on_convergence, float stepsize) {
+                                                     int stop_on_convergence, float stepsize, int unfused_parts, const float* __restrict__ sums, int sums_stride) {
   BaDev& B = const_cast<BaDev&>(wins[blockIdx.y]);
   if (ba_finished_lin(B)) return;
   BaOptDev& O = *B.opt;
   const int tid = threadIdx.x, nf = B.nf, nwin = gridDim.y;
   const int pf = opt_pack_floats(cap);
   const size_t rstride = (size_t)nwin * pf;
-  const float* g = gathered + (size_t)blockIdx.y * pf;
+  const float* g = gathered ? gathered + (size_t)blockIdx.y * pf : nullptr;
+  OptEnergies en{g, rstride, nranks, cap, &B, O.newest_first};
+  if (!g) { nranks = 1; en.cap = cap = max(B.nr - O.newest_first, 0); }
   __shared__ unsigned hist[256], sh[2];
   __shared__ int s_cnt[4];
   __shared__ double s_w2c[8][12], s_c2w[8][12], s_step[8][8];
@@ -101,7 +116,7 @@ __global__ __launch_bounds__(256) void k_ba_opt_step(const BaDev* __restrict__ w
   // ---- setNewFrameEnergyTH over every rank's residuals into the newest frame
   int cnt = 0;
   for (int r = 0; r < nranks; r++)
-    for (int j = tid; j < cap; j += 256) cnt += g[r * rstride + j] >= 0 ? 1 : 0;
+    for (int j = tid; j < cap; j += 256) cnt += en.at(r, j) >= 0 ? 1 : 0;
   cnt = (int)wave_sum((float)cnt);                       // <= nranks * cap < 2^24: exact in float
   if ((tid & 63) == 0) s_cnt[tid >> 6] = cnt;
   __syncthreads();
@@ -109,7 +124,7 @@ __global__ __launch_bounds__(256) void k_ba_opt_step(const BaDev* __restrict__ w
   float th = 12 * 12 * 8;
   if (M > 0) {
     const int nth = (int)(0.7f * M);
-    const float q = opt_select(g, nranks, rstride, cap, nth, hist, sh);
+    const float q = opt_select(en, nth, hist, sh);
     const float nthElement = sqrtf(q);
     th = nthElement * 1.5f;
     th = 26.0f * 0.5f + th * (1 - 0.5f);
@@ -120,7 +135,11 @@ __global__ __launch_bounds__(256) void k_ba_opt_step(const BaDev* __restrict__ w
     B.t_frameTH[nf - 1] = th;
     O.frameTH_new = th;
     double e = 0;
-    for (int r = 0; r < nranks; r++) { double er; __builtin_memcpy(&er, g + r * rstride + cap, 8); e += er; }
+    if (g) for (int r = 0; r < nranks; r++) { double er; __builtin_memcpy(&er, g + r * rstride + cap, 8); e += er; }
+    else {
+      const int np_ = unfused_parts ? (B.nr + BA_BLOCK - 1) / BA_BLOCK : B.nchunks;
+      for (int b = 0; b < np_; b++) e += B.e_part[b];
+    }
     O.lastEnergy = e;
   }
   if (phase == 1 || last) {
@@ -224,7 +243,14 @@ __global__ __launch_bounds__(256) void k_ba_opt_step(const BaDev* __restrict__ w
       sumR += st[3] * st[3] + st[4] * st[4] + st[5] * st[5];
     }
     float sumNID = 0, numID = 0;
-    for (int r = 0; r < nranks; r++) { sumNID += g[r * rstride + cap + 2]; numID += g[r * rstride + cap + 3]; }
+    if (g) for (int r = 0; r < nranks; r++) { sumNID += g[r * rstride + cap + 2]; numID += g[r * rstride + cap + 3]; }
+    else {
+      if (sums) {
+        const float* sm = sums + (size_t)blockIdx.y * sums_stride;
+        for (int b = 0; b < (B.np + BA_BLOCK - 1) / BA_BLOCK; b++) sumNID += sm[2 * b + 1];
+      }
+      numID = (float)B.np;
+    }
     sumA /= nf; sumB /= nf; sumR /= nf; sumT /= nf;
     sumNID /= numID;
     const bool canbreak = sqrtf(sumA) < 0.0005 * 1.2f && sqrtf(sumB) < 0.00005 * 1.2f && sqrtf(sumR) < 0.00005 * 1.2f && sqrtf(sumT) * sumNID < 0.00005 * 1.2f;

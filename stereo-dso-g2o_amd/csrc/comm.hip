@@ -15,6 +15,8 @@
 #include <rccl/rccl.h>
 #include <map>
 #include <memory>
+#include <vector>
+#include <algorithm>
 
 namespace sdso {
 void* ba_batch_accum_block(sdso_ctx* ctx, size_t* nfloats);            // ba.hip
@@ -59,6 +61,12 @@ static RcclApi* rccl_api(std::string* why) {
 struct Comm {
   ncclComm_t comm = nullptr;
   int nranks = 1, rank = 0, device = 0;
+  // host transport (sdso_comm_init_host): the collectives are staged through host memory and handed to the caller's functions
+  sdso_host_allreduce_fn h_allreduce = nullptr;
+  sdso_host_allgather_fn h_allgather = nullptr;
+  void* h_user = nullptr;
+  std::vector<float> h_send, h_recv;
+  bool host() const { return h_allreduce != nullptr; }
   ~Comm() { if (comm) { RcclApi* a = rccl_api(nullptr); if (a) a->CommDestroy(comm); } }
 };
 static std::map<sdso_ctx*, std::shared_ptr<Comm>> g_comms;
@@ -79,9 +87,19 @@ namespace sdso {
 // used by the resident GN loop (ba.hip): ranks of ctx's communicator (1 without one), the all-gather of the per-rank energy / break-test
 // records, and the max over ranks of a host int (collective, synchronises the ctx stream)
 int comm_nranks(sdso_ctx* ctx) { auto c = comm_of(ctx); return c ? c->nranks : 1; }
+bool comm_present(sdso_ctx* ctx) { return comm_of(ctx) != nullptr; }
 int comm_allgather_floats(sdso_ctx* ctx, const float* send, float* recv, size_t nfloats) {
   auto c = comm_of(ctx);
   if (!c) return sdso::fail(ctx, SDSO_ERR_STATE, "no communicator");
+  if (c->host()) {
+    c->h_send.resize(nfloats); c->h_recv.resize(nfloats * c->nranks);
+    SDSO_HIP(ctx, hipMemcpyAsync(c->h_send.data(), send, sizeof(float) * nfloats, hipMemcpyDeviceToHost, ctx->stream));
+    SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (c->h_allgather(c->h_user, c->h_send.data(), c->h_recv.data(), nfloats)) return sdso::fail(ctx, SDSO_ERR_STATE, "the host transport's all-gather failed");
+    SDSO_HIP(ctx, hipMemcpyAsync(recv, c->h_recv.data(), sizeof(float) * nfloats * c->nranks, hipMemcpyHostToDevice, ctx->stream));
+    SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SDSO_OK;
+  }
   RcclApi* a = rccl_api(nullptr);
   const ncclResult_t r = a->AllGather(send, recv, nfloats, ncclFloat32, c->comm, ctx->stream);
   if (r != ncclSuccess) return sdso::fail(ctx, SDSO_ERR_HIP, std::string("ncclAllGather: ") + (a->GetErrorString ? a->GetErrorString(r) : "RCCL error"));
@@ -90,6 +108,13 @@ int comm_allgather_floats(sdso_ctx* ctx, const float* send, float* recv, size_t 
 int comm_max_int(sdso_ctx* ctx, int* value) {
   auto c = comm_of(ctx);
   if (!c) return SDSO_OK;
+  if (c->host()) {
+    const float mine = (float)*value;                       // capacities are far below 2^24: exact
+    std::vector<float> all(c->nranks);
+    if (c->h_allgather(c->h_user, &mine, all.data(), 1)) return sdso::fail(ctx, SDSO_ERR_STATE, "the host transport's all-gather failed");
+    for (float v : all) *value = std::max(*value, (int)v);
+    return SDSO_OK;
+  }
   RcclApi* a = rccl_api(nullptr);
   int* d = nullptr;
   if (hipMalloc(&d, sizeof(int)) != hipSuccess) return sdso::fail(ctx, SDSO_ERR_HIP, "hipMalloc");
@@ -138,6 +163,21 @@ extern "C" int sdso_comm_init(sdso_ctx* ctx, int nranks, int rank, const void* i
   return SDSO_OK;
 }
 
+// Bring-your-own transport (MPI, sockets, a test harness): the same collectives, staged through host memory and carried out by the
+// caller's functions.  Every library path that talks to the communicator (sdso_ba_allreduce*, the resident loop's all-gather) works on
+// top of it; it synchronises the ctx stream around each collective, so it is the slow path by construction.
+extern "C" int sdso_comm_init_host(sdso_ctx* ctx, int nranks, int rank, sdso_host_allreduce_fn allreduce, sdso_host_allgather_fn allgather, void* user) {
+  if (!ctx) return SDSO_ERR_STATE;
+  SDSO_REQUIRE(ctx, nranks >= 1 && rank >= 0 && rank < nranks && allreduce && allgather, "bad communicator arguments");
+  release_comm(ctx);
+  auto c = std::make_shared<Comm>();
+  c->nranks = nranks; c->rank = rank; c->device = ctx->device;
+  c->h_allreduce = allreduce; c->h_allgather = allgather; c->h_user = user;
+  std::lock_guard<std::mutex> g(registry_mutex());
+  g_comms[ctx] = c;
+  return SDSO_OK;
+}
+
 extern "C" int sdso_comm_attach(sdso_ctx* ctx, sdso_ctx* owner) {
   if (!ctx || !owner) return SDSO_ERR_STATE;
   auto c = comm_of(owner);
@@ -167,8 +207,17 @@ static int allreduce_block(sdso_ctx* ctx, void* ptr, size_t nfloats) {
   auto c = comm_of(ctx);
   SDSO_REQUIRE(ctx, c, "no communicator: call sdso_comm_init (or sdso_comm_attach) first");
   SDSO_REQUIRE(ctx, ptr && nfloats > 0, "nothing to reduce");
-  RcclApi* a = rccl_api(nullptr);
   SDSO_HIP(ctx, hipSetDevice(ctx->device));
+  if (c->host()) {
+    c->h_send.resize(nfloats);
+    SDSO_HIP(ctx, hipMemcpyAsync(c->h_send.data(), ptr, sizeof(float) * nfloats, hipMemcpyDeviceToHost, ctx->stream));
+    SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (c->h_allreduce(c->h_user, c->h_send.data(), nfloats)) return sdso::fail(ctx, SDSO_ERR_STATE, "the host transport's all-reduce failed");
+    SDSO_HIP(ctx, hipMemcpyAsync(ptr, c->h_send.data(), sizeof(float) * nfloats, hipMemcpyHostToDevice, ctx->stream));
+    SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SDSO_OK;
+  }
+  RcclApi* a = rccl_api(nullptr);
   SDSO_NCCL(ctx, a, a->AllReduce(ptr, ptr, nfloats, ncclFloat32, ncclSum, c->comm, ctx->stream));
   return SDSO_OK;
 }

@@ -74,13 +74,29 @@ __global__ __launch_bounds__(256) void k_immature_init(const float4* __restrict_
   energyTH[p] = bad ? NAN : e;
 }
 
-template <int GN_MODE>
-__global__ __launch_bounds__(256) void k_trace_stereo(TraceDev T) {
+// BAND (A/B variant, SDSO_TRACE_BAND=1): the survey's design — the wave first stages the (numSteps + 6) x 6 band of the intensity plane
+// that its search touches in LDS (12 coalesced row-segment loads instead of 32 gathers per lane) and takes the 8 x 4 taps of every step
+// from there.  Same floats, same expression: bit-identical outputs.  Measured equal to the L1-served gathers: the kernel
+// is bound by the latency chain of a wave, not by the tap rate of either path.
+constexpr int kBandW = 112, kBandH = 6;
+// getInterpolatedElement31 (interp31_plane's expression) on the LDS band
+__device__ __forceinline__ float interp31_band(const float* band, int off, float x, float y) {
+  const int ix = (int)x;
+  const int iy = (int)y;
+  const float dx = x - ix;
+  const float dy = y - iy;
+  const float dxdy = dx * dy;
+  const float* bp = band + (ix + iy * kBandW - off);
+  return dxdy * bp[1 + kBandW] + (dy - dxdy) * bp[kBandW] + (dx - dxdy) * bp[1] + (1 - dx - dy + dxdy) * bp[0];
+}
+template <int GN_MODE, bool BAND = false, int MINB = 1>
+__global__ __launch_bounds__(256, MINB) void k_trace_stereo(TraceDev T) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int i = blockIdx.x * 4 + wv;
   if (i >= T.n) return;
   if (T.skip && T.skip[i]) { if (lane == 0 && T.status) T.status[i] = 255; return; }
   __shared__ float s_err[4][128];
+  __shared__ float s_band[BAND ? 4 : 1][BAND ? kBandH * kBandW : 1];
   volatile float* errors = s_err[wv];
   const float4* __restrict__ dI = T.img;
   const int wG0 = T.w, hG0 = T.h;
@@ -175,17 +191,59 @@ __global__ __launch_bounds__(256) void k_trace_stereo(TraceDev T) {
     if (s < numSteps) {
       float ptx = ptx0, pty = pty0;
       for (int k = 0; k < s; k++) { ptx += dx; pty += dy; }
+      myX[pass] = ptx; myY[pass] = pty;
+    }
+  }
+  // BAND: bounding box of every tap of the wave (wave-uniform); staged only when it fits the LDS band (always for rectified stereo:
+  // dy == 0 and numSteps <= 99), otherwise the wave falls back to the gathers
+  bool banded = false;
+  int bandOff = 0;
+  if constexpr (BAND) {
+    int xlo = 1 << 30, xhi = -(1 << 30), ylo = 1 << 30, yhi = -(1 << 30);
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+      const int s = pass * 64 + lane;
+      if (s < numSteps) {
+        xlo = min(xlo, (int)(myX[pass] + (float)-2)); xhi = max(xhi, (int)(myX[pass] + (float)2) + 1);
+        ylo = min(ylo, (int)(myY[pass] + (float)-2)); yhi = max(yhi, (int)(myY[pass] + (float)2) + 1);
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      xlo = min(xlo, __shfl_xor(xlo, o, 64)); xhi = max(xhi, __shfl_xor(xhi, o, 64));
+      ylo = min(ylo, __shfl_xor(ylo, o, 64)); yhi = max(yhi, __shfl_xor(yhi, o, 64));
+    }
+    const int bw = xhi - xlo + 1, bh = yhi - ylo + 1;
+    banded = bw >= 1 && bw <= kBandW && bh >= 1 && bh <= kBandH && xlo >= 0 && ylo >= 0 && xhi < wG0 && yhi < hG0;
+    if (banded) {
+      float* band = s_band[wv];
+      for (int r = 0; r < bh; r++)
+        for (int c = lane; c < bw; c += 64) band[r * kBandW + c] = T.plane[(size_t)(ylo + r) * wG0 + xlo + c];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      bandOff = ylo * kBandW + xlo;            // the tap of pixel (ix, iy) sits at band[ix + iy * kBandW - bandOff]
+    }
+  }
+#pragma unroll
+  for (int pass = 0; pass < 2; pass++) {
+    const int s = pass * 64 + lane;
+    if (s < numSteps) {
+      const float ptx = myX[pass], pty = myY[pass];
       float energy = 0;
 #pragma unroll
       for (int idx = 0; idx < 8; idx++) {
-        const float hitColor = interp31_plane(T.plane, (float)(ptx + (float)c_pat[idx][0]), (float)(pty + (float)c_pat[idx][1]), wG0);
+        const float tx = (float)(ptx + (float)c_pat[idx][0]), ty = (float)(pty + (float)c_pat[idx][1]);
+        float hitColor;
+        if (BAND && banded) hitColor = interp31_band(s_band[wv], bandOff, tx, ty);
+        else hitColor = interp31_plane(T.plane, tx, ty, wG0);
         if (!isfinite(hitColor)) { energy += 1e5; continue; }
         const float residual = hitColor - (float)(1.0f * color[idx] + 0.0f);
         const float hw = fabsf(residual) < kHuberTH ? 1 : kHuberTH / fabsf(residual);
         energy += hw * residual * residual * (2 - hw);
       }
       errors[s] = energy;
-      myE[pass] = energy; myX[pass] = ptx; myY[pass] = pty;
+      myE[pass] = energy;
     }
   }
   // first minimum (the reference takes strictly smaller energies only, in step order)
@@ -634,6 +692,14 @@ extern "C" int sdso_trace_stereo_prepare(sdso_ctx* ctx, int frame_slot, const fl
   SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return SDSO_OK;
 }
+// k_trace_stereo in the ctx's refinement mode; SDSO_TRACE_BAND=1 selects the LDS-band A/B variant (read per launch)
+static void launch_trace_stereo(sdso_ctx* ctx, const TraceDev& T) {
+  const dim3 g((T.n + 3) / 4), b(256);
+  const bool band = getenv("SDSO_TRACE_BAND") != nullptr;
+  if (getenv("SDSO_TRACE_OCC") && ctx->gn_mode == 0 && !band) { hipLaunchKernelGGL((k_trace_stereo<0, false, 8>), g, b, 0, ctx->stream, T); return; }
+  if (ctx->gn_mode == 1) { if (band) hipLaunchKernelGGL((k_trace_stereo<1, true>), g, b, 0, ctx->stream, T); else hipLaunchKernelGGL((k_trace_stereo<1, false>), g, b, 0, ctx->stream, T); }
+  else { if (band) hipLaunchKernelGGL((k_trace_stereo<0, true>), g, b, 0, ctx->stream, T); else hipLaunchKernelGGL((k_trace_stereo<0, false>), g, b, 0, ctx->stream, T); }
+}
 extern "C" int sdso_trace_stereo_enqueue(sdso_ctx* ctx) {
   if (!ctx || !reg_has(g_trace, ctx)) return sdso::fail(ctx, SDSO_ERR_STATE, "no prepared trace batch");
   TraceBatch& B = reg_get(g_trace, ctx);
@@ -642,8 +708,7 @@ extern "C" int sdso_trace_stereo_enqueue(sdso_ctx* ctx) {
   SDSO_HIP(ctx, hipMemcpyAsync(B.bytes, B.bytes + 2 * (size_t)B.n, (size_t)B.n, hipMemcpyDeviceToDevice, ctx->stream));
   {
     ProfScope ps(ctx, "k_trace_stereo");
-    if (ctx->gn_mode == 1) hipLaunchKernelGGL(k_trace_stereo<1>, dim3((B.T.n + 3) / 4), dim3(256), 0, ctx->stream, B.T);
-    else hipLaunchKernelGGL(k_trace_stereo<0>, dim3((B.T.n + 3) / 4), dim3(256), 0, ctx->stream, B.T);
+    launch_trace_stereo(ctx, B.T);
   }
   SDSO_HIP(ctx, hipGetLastError());
   return SDSO_OK;
@@ -808,15 +873,13 @@ extern "C" int sdso_stereo_match_batch(sdso_ctx* ctx, int slot_a, int slot_b, co
   hipLaunchKernelGGL(k_match_prepare, g1, b1, 0, ctx->stream, n, d_in[0], d_in[1], d_in[2], d_in[3], A.T);
   hipLaunchKernelGGL(k_immature_init, g1, b1, 0, ctx->stream, ia->second.d[0], w, n, (const float*)A.T.u_stereo, (const float*)A.T.v_stereo,
                      (float*)A.T.color, (float*)A.T.weights, (float*)A.T.gradH, (float*)A.T.energyTH);
-  if (ctx->gn_mode == 1) hipLaunchKernelGGL(k_trace_stereo<1>, gw, b1, 0, ctx->stream, A.T);
-  else hipLaunchKernelGGL(k_trace_stereo<0>, gw, b1, 0, ctx->stream, A.T);
+  launch_trace_stereo(ctx, A.T);
   hipLaunchKernelGGL(k_match_back_points, g1, b1, 0, ctx->stream, n, A.T, Bk.T, skip, d_in[4], d_in[5]);
   hipLaunchKernelGGL(k_immature_init, g1, b1, 0, ctx->stream, ib->second.d[0], w, n, (const float*)Bk.T.u_stereo, (const float*)Bk.T.v_stereo,
                      (float*)Bk.T.color, (float*)Bk.T.weights, (float*)Bk.T.gradH, (float*)Bk.T.energyTH);
   TraceDev Tb = Bk.T;
   Tb.skip = skip;
-  if (ctx->gn_mode == 1) hipLaunchKernelGGL(k_trace_stereo<1>, gw, b1, 0, ctx->stream, Tb);
-  else hipLaunchKernelGGL(k_trace_stereo<0>, gw, b1, 0, ctx->stream, Tb);
+  launch_trace_stereo(ctx, Tb);
   SDSO_HIP(ctx, hipGetLastError());
 #define DN(dst, src, cnt) if (dst) SDSO_HIP(ctx, hipMemcpyAsync((dst), (src), sizeof(float) * (size_t)(cnt), hipMemcpyDeviceToHost, ctx->stream))
   DN(M->idepth_stereo, A.T.idepth_stereo, n); DN(M->idepth_min_out, A.T.idepth_min_stereo, n); DN(M->idepth_max_out, A.T.idepth_max_stereo, n);

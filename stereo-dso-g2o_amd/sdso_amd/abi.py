@@ -70,6 +70,11 @@ class BAWindow(C.Structure):
                 ("forceAcceptStep", C.c_int)]
 
 
+# sdso_comm_init_host's transport callbacks (include/sdso_abi.h)
+HOST_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_float), C.c_size_t)
+HOST_ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_size_t)
+
+
 class BAOptResult(C.Structure):
     _fields_ = [("iterations", C.c_int), ("lastEnergy", C.c_double), ("rmse", C.c_double), ("resInA", C.c_int)]
 
@@ -276,6 +281,7 @@ def load():
     L.sdso_comm_unique_id.argtypes = [vp]
     L.sdso_comm_init.argtypes = [vp, C.c_int, C.c_int, vp]
     L.sdso_comm_attach.argtypes = [vp, vp]
+    L.sdso_comm_init_host.argtypes = [vp, C.c_int, C.c_int, HOST_ALLREDUCE_FN, HOST_ALLGATHER_FN, vp]
     L.sdso_comm_info.argtypes = [vp, c_int_p, c_int_p]
     L.sdso_comm_destroy.argtypes = [vp]
     L.sdso_ba_allreduce.argtypes = [vp]
@@ -319,7 +325,7 @@ EXPORTED_SYMBOLS = [
     "sdso_immature_init_batch", "sdso_trace_stereo_batch", "sdso_trace_stereo_prepare", "sdso_trace_stereo_enqueue",
     "sdso_trace_stereo_fetch", "sdso_stereo_match_batch", "sdso_activate_points_batch", "sdso_ba_marginalize_frame", "sdso_ba_batch_linearize", "sdso_ba_batch_schur", "sdso_pixel_select", "sdso_pixel_selector_pattern", "sdso_trace_on_batch", "sdso_track_make_ref", "sdso_track_newest_coarse_batch", "sdso_track_get_ref",
     "sdso_ba_batch_optimize", "sdso_ba_batch_optimize_begin", "sdso_ba_batch_step", "sdso_ba_batch_optimize_end", "sdso_ba_get_state",
-    "sdso_comm_unique_id", "sdso_comm_init", "sdso_comm_attach", "sdso_comm_info", "sdso_comm_destroy", "sdso_ba_allreduce", "sdso_ba_allreduce_window",
+    "sdso_comm_unique_id", "sdso_comm_init", "sdso_comm_init_host", "sdso_comm_attach", "sdso_comm_info", "sdso_comm_destroy", "sdso_ba_allreduce", "sdso_ba_allreduce_window",
     "sdso_g2o_track_add_edges", "sdso_g2o_track_linearize", "sdso_g2o_track_newest_coarse", "sdso_g2o_lba_eval", "sdso_trace_set_gn_mode",
 ]
 

@@ -174,3 +174,140 @@ def test_library_allreduce_one_rank_is_identity():
     finally:
         ctx2.close()
         ctx.close()
+
+
+def _host_transport(dist, torch, world):
+    """sdso_comm_init_host callbacks over torch.distributed (gloo) — two ranks cannot open RCCL on one device, and the library's
+    collectives (all-reduce of the accumulators, all-gather of the resident loop's energy records) are transport-agnostic."""
+    from sdso_amd import abi
+
+    def allreduce(user, buf, n):
+        t = torch.from_numpy(np.ctypeslib.as_array(buf, shape=(n,)))
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return 0
+
+    def allgather(user, send, recv, n):
+        s = torch.from_numpy(np.ctypeslib.as_array(send, shape=(n,)).copy())
+        out = [torch.empty(n, dtype=torch.float32) for _ in range(world)]
+        dist.all_gather(out, s)
+        r = np.ctypeslib.as_array(recv, shape=(n * world,))
+        for k, o in enumerate(out):
+            r[k * n:(k + 1) * n] = o.numpy()
+        return 0
+    return abi.HOST_ALLREDUCE_FN(allreduce), abi.HOST_ALLGATHER_FN(allgather)
+
+
+_OPT_SPECS = [dict(w=1232, h=368, nf=8, pts_per_kf=120, seed=3041), dict(w=640, h=480, nf=8, pts_per_kf=100, seed=3043, idepth_noise=0.3, state_noise=1e-2)]
+
+
+def _batch_optimize(ctx, abi, wins, wid0, slot0):
+    nf = wins[0]["nf"]
+    keep = []
+    for k, win in enumerate(wins):
+        for f in range(nf):
+            ctx.upload_pyramid(slot0 + k * nf + f, win["pyrs"][f][:1])
+        W, kp = abi.make_ba_window(win, frame_slots=[slot0 + k * nf + f for f in range(nf)])
+        keep.append((W, kp))
+        ctx.check(ctx.L.sdso_ba_upload_window(ctx.h, wid0 + k, C.byref(W)))
+    ids = np.array([wid0 + k for k in range(len(wins))], np.int32)
+    ctx.check(ctx.L.sdso_ba_batch_create(ctx.h, len(wins), abi.ip(ids)))
+    res = (abi.BAOptResult * len(wins))()
+    ctx.check(ctx.L.sdso_ba_batch_optimize(ctx.h, 6, res))
+    out = []
+    for k, win in enumerate(wins):
+        s, i, r = np.zeros((nf, 10)), np.zeros(win["np"], np.float32), np.zeros(win["nr"], np.uint8)
+        ctx.check(ctx.L.sdso_ba_get_state(ctx.h, wid0 + k, abi.dp(s), abi.fp(i), abi.bp(r)))
+        out.append((s, i, r, res[k].iterations, res[k].resInA, res[k].lastEnergy))
+    return out
+
+
+def _opt_worker(rank, world, port, outdir):
+    import torch
+    import torch.distributed as dist
+    sys.path[:0] = [os.path.join(ROOT, "stereo-dso-g2o_amd")]
+    from sdso_amd import abi, synth, dist as sdist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ctx = abi.Context(0)
+    cbs = _host_transport(dist, torch, world)
+    ctx.check(ctx.L.sdso_comm_init_host(ctx.h, world, rank, cbs[0], cbs[1], None))
+    subs = [sdist.shard_window(synth.ba_window(**s), rank, world)[0] for s in _OPT_SPECS]
+    out = _batch_optimize(ctx, abi, subs, 1, 10)
+    for k, (s, i, r, its, resInA, e) in enumerate(out):
+        np.savez(os.path.join(outdir, "opt_%d_%d.npz" % (rank, k)), s=s, i=i, r=r, its=its, resInA=resInA, e=e)
+    ctx.close()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_gn_loop_matches_single(gpu_ctx, oracle, tmp_path):
+    """The whole Gauss-Newton loop over sharded windows (sdso_ba_batch_optimize on 2 ranks: per iteration one all-reduce of the packed
+    accumulators and one all-gather of the newest-frame energies / break-test sums) takes the decisions of the unsharded window on every
+    rank: same iteration count, same quantile thresholds (through the residual states), states / idepths within 1e-5 + twice the
+    oracle's own order-of-summation spread."""
+    from sdso_amd import abi, synth
+    import helpers
+    world = 2
+    mp.spawn(_opt_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    wins = [synth.ba_window(**s) for s in _OPT_SPECS]
+    single = _batch_optimize(gpu_ctx, abi, wins, 41, 600)
+    for k, win in enumerate(wins):
+        nf, npts, nr = win["nf"], win["np"], win["nr"]
+        sh = [np.load(tmp_path / ("opt_%d_%d.npz" % (r, k))) for r in range(world)]
+        s1, i1, r1, its1, resInA1, e1 = single[k]
+        assert int(sh[0]["its"]) == int(sh[1]["its"]) == its1
+        assert np.array_equal(sh[0]["s"], sh[1]["s"])                        # identical reduced systems -> identical states on every rank
+        assert int(sh[0]["resInA"]) == int(sh[1]["resInA"])
+        # order-of-summation spread of the CPU arithmetic on this window
+        W, keep = abi.make_ba_window(win, frame_slots=list(range(nf)), dI_list=[p[0] for p in win["pyrs"]])
+        h = oracle.orc_ba_create(C.byref(W))
+        so, io, ro, oo = np.zeros((nf, 10)), np.zeros(npts, np.float32), np.zeros(nr, np.uint8), abi.BAOptResult()
+        oracle.orc_ba_optimize(h, 6, abi.dp(so), abi.fp(io), abi.bp(ro), C.byref(oo))
+        oracle.orc_ba_destroy(h)
+        ss, si = 0.0, 0.0
+        for seed in (1, 3):
+            w2, order = helpers.permuted_window(win, seed)
+            W2, keep2 = abi.make_ba_window(w2, frame_slots=list(range(nf)), dI_list=[p[0] for p in win["pyrs"]])
+            h2 = oracle.orc_ba_create(C.byref(W2))
+            sp, ip, rp, op = np.zeros((nf, 10)), np.zeros(npts, np.float32), np.zeros(nr, np.uint8), abi.BAOptResult()
+            oracle.orc_ba_optimize(h2, 6, abi.dp(sp), abi.fp(ip), abi.bp(rp), C.byref(op))
+            oracle.orc_ba_destroy(h2)
+            ss, si = max(ss, np.abs(sp - so).max()), max(si, np.abs(ip - io[order]).max())
+        idep = np.concatenate([sh[r]["i"] for r in range(world)])
+        rst = np.concatenate([sh[r]["r"] for r in range(world)])
+        assert np.abs(sh[0]["s"] - s1).max() <= 1e-5 + 2.0 * ss, (np.abs(sh[0]["s"] - s1).max(), ss)
+        assert np.abs(idep - i1).max() <= 1e-5 + 2.0 * si, (np.abs(idep - i1).max(), si)
+        assert (rst != r1).sum() <= max(2, nr // 2000)
+        assert int(sh[0]["resInA"]) == resInA1 or (rst != r1).sum() > 0
+        esum = float(sh[0]["e"])
+        assert abs(esum - e1) <= 1e-4 * e1                                   # lastEnergy is the all-gathered sum on every rank
+    for k in range(len(wins)):
+        gpu_ctx.check(gpu_ctx.L.sdso_ba_release_window(gpu_ctx.h, 41 + k))
+
+
+@pytest.mark.gpu
+def test_resident_loop_through_rccl_one_rank(monkeypatch):
+    """The RCCL collectives of the resident loop on the one GPU this box has: with a 1-rank communicator and SDSO_OPT_FORCE_EXCHANGE=1
+    sdso_ba_batch_optimize takes the multi-rank path — ncclAllReduce(max) of the pack capacity, per iteration ncclAllReduce of the
+    accumulators, k_ba_opt_pack and ncclAllGather of the energy records — and must reproduce the plain single-rank run bit for bit."""
+    from sdso_amd import abi, synth
+    wins = [synth.ba_window(**s) for s in _OPT_SPECS]
+    outs = {}
+    for mode in ("plain", "rccl"):
+        ctx = abi.Context(0)
+        try:
+            if mode == "rccl":
+                uid = (C.c_ubyte * 128)()
+                assert ctx.L.sdso_comm_unique_id(uid) == 0
+                ctx.check(ctx.L.sdso_comm_init(ctx.h, 1, 0, uid))
+                monkeypatch.setenv("SDSO_OPT_FORCE_EXCHANGE", "1")
+            else:
+                monkeypatch.delenv("SDSO_OPT_FORCE_EXCHANGE", raising=False)
+            outs[mode] = _batch_optimize(ctx, abi, wins, 1, 10)
+        finally:
+            monkeypatch.delenv("SDSO_OPT_FORCE_EXCHANGE", raising=False)
+            ctx.close()
+    for a, b in zip(outs["plain"], outs["rccl"]):
+        assert a[3] == b[3] and a[4] == b[4]
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+        assert a[5] == b[5]
