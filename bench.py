@@ -19,6 +19,7 @@ per-GPU work fixed, windows scale with N); tracker / trace are replicas (no coll
 """
 import argparse
 import ctypes as C
+import glob
 import json
 import os
 import sys
@@ -30,7 +31,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "stereo-dso-g2o_amd"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_traffic.json")   # PMC passes of this same command (tools/profile_round.sh + tools/make_traffic.py)
+# PMC passes of this same command (tools/profile_round.sh + tools/make_traffic.py); the latest round's file
+TRAFFIC_FILE = (sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_traffic.json"))) or [os.path.join(ROOT, "profiles", "r01_traffic.json")])[-1]
+TRAFFIC_KEYS = ("workload", "windows_per_step", "keyframes", "points_per_window_per_gpu", "residuals_per_window_per_gpu", "jacobians_materialized",
+                "stream_groups", "state_advances", "points", "problems", "levels")
 
 
 def pmc_traffic(workload, config):
@@ -40,7 +44,8 @@ def pmc_traffic(workload, config):
         rec = json.load(open(TRAFFIC_FILE)).get(workload)
     except (OSError, ValueError):
         return None
-    if not rec or rec.get("config") != config:
+    rc = (rec or {}).get("config") or {}
+    if not rec or any(rc.get(k) != config.get(k) for k in TRAFFIC_KEYS if k in config or k in rc):
         return None
     return rec["traffic_bytes_per_launch"]
 

@@ -494,13 +494,15 @@ static void launch_fused(sdso_ctx* ctx, const BaLaunch& L, bool materialize, int
 static void launch_stitch(sdso_ctx* ctx, const BaLaunch& L) {
   const int nf = L.nf;
   hipLaunchKernelGGL(k_ba_stitch_pre, dim3((2 * nf * nf + 3) / 4, L.nwin), dim3(256), 0, ctx->stream, L.d_arr);
-  hipLaunchKernelGGL(k_ba_stitch, dim3((3 * (nf * nf + nf + 1) + ST_WAVES - 1) / ST_WAVES, L.nwin), dim3(64 * ST_WAVES), 0, ctx->stream, L.d_arr);
+  const dim3 sg((3 * (nf * nf + nf + 1) + ST_WAVES - 1) / ST_WAVES, L.nwin), sb(64 * ST_WAVES);
+  // NF = 0 (runtime nf): the fully unrolled NF = 8 instantiation was measured 2x slower (register pressure: 259 vs 127 us per 64 windows)
+  hipLaunchKernelGGL(k_ba_stitch<0>, sg, sb, 0, ctx->stream, L.d_arr);
 }
 // stitch + solveSystemF (default branch) + resubstitute
 static void launch_solve(sdso_ctx* ctx, const BaLaunch& L, double lambda, int orth) {
   const int n = L.n;
   launch_stitch(ctx, L);
-  const size_t lds = sizeof(double) * ((size_t)n * ((n + 2) & ~1) + 6 * n + 8) + sizeof(int) * n;   // matrix, six vectors (+8 pad), perm
+  const size_t lds = sizeof(double) * ((size_t)n * ((n + 2) & ~1) + 6 * n + 16) + sizeof(int) * n;   // matrix, six vectors (+16 pad), perm
   hipLaunchKernelGGL(k_ba_solve, dim3(1, L.nwin), dim3(BA_BLOCK), lds, ctx->stream, L.d_arr, lambda, orth);
   if (L.max_nblk_pts > 0) hipLaunchKernelGGL(k_ba_resub, dim3(L.max_nblk_pts, L.nwin), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr);
 }

@@ -62,7 +62,7 @@ struct OptEnergies {
   }
 };
 // the k-th smallest (0-based) of the non-negative values: 4 radix passes over the bit patterns
-__device__ inline float opt_select(const OptEnergies& v, int k, unsigned* hist /* LDS 256 */, unsigned* sh /* LDS 2 */) {
+__device__ inline float opt_select(const OptEnergies& v, int k, unsigned* hist /* LDS 256 */, unsigned* sh /* LDS 6 */) {
   const int nranks = v.ranks(), cap = v.cap;
   unsigned prefix = 0, mask = 0;
   for (int shift = 24; shift >= 0; shift -= 8) {
@@ -76,10 +76,18 @@ __device__ inline float opt_select(const OptEnergies& v, int k, unsigned* hist /
         if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255], 1u);
       }
     __syncthreads();
-    if (threadIdx.x == 0) {
-      unsigned cum = 0, b = 0;
-      for (; b < 256; b++) { if (cum + hist[b] > (unsigned)k) break; cum += hist[b]; }
-      sh[0] = b; sh[1] = cum;
+    {
+      // bin b with  cum(b) <= k < cum(b) + hist[b]  (cum = exclusive prefix sum): thread b owns bin b; wave-level scan + the wave totals
+      const unsigned hb = hist[threadIdx.x];
+      unsigned inc = hb;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const unsigned up = __shfl_up(inc, o, 64); if ((int)(threadIdx.x & 63) >= o) inc += up; }
+      if ((threadIdx.x & 63) == 63) sh[2 + (threadIdx.x >> 6)] = inc;
+      __syncthreads();
+      unsigned base = 0;
+      for (int w = 0; w < (int)(threadIdx.x >> 6); w++) base += sh[2 + w];
+      const unsigned excl = base + inc - hb;
+      if (hb > 0 && excl <= (unsigned)k && (unsigned)k < excl + hb) { sh[0] = threadIdx.x; sh[1] = excl; }
     }
     __syncthreads();
     prefix |= sh[0] << shift;
@@ -98,7 +106,8 @@ __device__ inline float opt_select(const OptEnergies& v, int k, unsigned* hist /
 //   last != 0 or the break test fired in the previous call: consume the energies only, then mark the window finished.
 __global__ __launch_bounds__(256) void k_ba_opt_step(const BaDev* __restrict__ wins, const float* __restrict__ gathered, int nranks, int cap, int iteration, int last,
                                                      int stop_on_convergence, float stepsize, int unfused_parts, const float* __restrict__ sums, int sums_stride) {
-  BaDev& B = const_cast<BaDev&>(wins[blockIdx.y]);
+  BaDev& Bw = const_cast<BaDev&>(wins[blockIdx.y]);   // written: calibration scalars, finished
+  const BaDev B = Bw;                                   // read once: later loads need not be repeated after the stores below
   if (ba_finished_lin(B)) return;
   BaOptDev& O = *B.opt;
   const int tid = threadIdx.x, nf = B.nf, nwin = gridDim.y;
@@ -107,16 +116,69 @@ __global__ __launch_bounds__(256) void k_ba_opt_step(const BaDev* __restrict__ w
   const float* g = gathered ? gathered + (size_t)blockIdx.y * pf : nullptr;
   OptEnergies en{g, rstride, nranks, cap, &B, O.newest_first};
   if (!g) { nranks = 1; en.cap = cap = max(B.nr - O.newest_first, 0); }
-  __shared__ unsigned hist[256], sh[2];
+  __shared__ unsigned hist[256], sh[6];
   __shared__ int s_cnt[4];
+  __shared__ double s_esum[4];
+  __shared__ float s_nid[4];
+  constexpr int kStage = 8192;                          // energies staged in LDS for the radix passes (32 KiB); larger sets re-read global
+  __shared__ float s_en[kStage];
   __shared__ double s_w2c[8][12], s_c2w[8][12], s_step[8][8];
   __shared__ float s_K[9], s_Ki[9];
+  __shared__ float s_dlt[8][8], s_zb[8];
   const int phase = O.phase;
 
+  // ---- every global input of the step below is requested here, before the quantile (LDS work) — the kernel is a chain of memory round
+  // trips otherwise, and each of them stretches several-fold while another batch's linearisation saturates HBM
+  const double* x = B.sol + 3 * ((size_t)B.n * B.n + B.n);
+  double p_x[8], p_st[10], p_zero[8], p_ev[12];
+  float p_ah[2][8], p_at[2][8], p_exp_h = 1, p_exp_t = 1;
+  if (tid < nf) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) { p_x[i] = x[4 + 8 * tid + i]; p_zero[i] = O.state_zero[tid][i]; }
+#pragma unroll
+    for (int i = 0; i < 10; i++) p_st[i] = O.state[tid][i];
+#pragma unroll
+    for (int i = 0; i < 12; i++) p_ev[i] = O.evalPT[tid][i];
+  } else if (tid == 64) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) { p_x[i] = x[i]; p_st[i] = O.calib_value[i]; p_zero[i] = O.calib_zero[i]; }
+  }
+  if (tid < nf * nf) { p_exp_h = O.ab_exposure[tid / nf]; p_exp_t = O.ab_exposure[tid % nf]; }
+#pragma unroll
+  for (int u = 0; u < 2; u++) {
+    const int e = tid + 256 * u;
+    if (e < nf * nf * 8) {
+      const int idx = e >> 3, j = e & 7;
+#pragma unroll
+      for (int i = 0; i < 8; i++) { p_ah[u][i] = (float)B.t_adHost[(size_t)idx * 64 + i * 8 + j]; p_at[u][i] = (float)B.t_adTarget[(size_t)idx * 64 + i * 8 + j]; }
+    }
+  }
+  const float p_nres = B.accum[acc_off_nres(nf)];
+  const int p_its = O.iterations;
+
   // ---- setNewFrameEnergyTH over every rank's residuals into the newest frame
+  // one pass over global memory: the energies go to LDS (all loads of a thread in flight together), the radix passes read LDS
+  const bool staged = nranks * cap <= kStage;
   int cnt = 0;
   for (int r = 0; r < nranks; r++)
-    for (int j = tid; j < cap; j += 256) cnt += en.at(r, j) >= 0 ? 1 : 0;
+    for (int j = tid; j < cap; j += 256) {
+      const float e = en.at(r, j);
+      if (staged) s_en[r * cap + j] = e;
+      cnt += e >= 0 ? 1 : 0;
+    }
+  // the energy partials and the points' |idepth| sums of this rank (single-rank path), summed by all threads
+  double esum = 0; float nidsum = 0;
+  if (!g) {
+    const int np_ = unfused_parts ? (B.nr + BA_BLOCK - 1) / BA_BLOCK : B.nchunks;
+    for (int b = tid; b < np_; b += 256) esum += B.e_part[b];
+    if (sums) {
+      const float* sm = sums + (size_t)blockIdx.y * sums_stride;
+      for (int b = tid; b < (B.np + BA_BLOCK - 1) / BA_BLOCK; b += 256) nidsum += sm[2 * b + 1];
+    }
+    esum = wave_sum(esum); nidsum = wave_sum(nidsum);
+    if ((tid & 63) == 0) { s_esum[tid >> 6] = esum; s_nid[tid >> 6] = nidsum; }
+  }
+  if (staged) { en.g = s_en; en.rstride = cap; en.nranks = nranks; en.cap = cap; }
   cnt = (int)wave_sum((float)cnt);                       // <= nranks * cap < 2^24: exact in float
   if ((tid & 63) == 0) s_cnt[tid >> 6] = cnt;
   __syncthreads();
@@ -136,65 +198,68 @@ __global__ __launch_bounds__(256) void k_ba_opt_step(const BaDev* __restrict__ w
     O.frameTH_new = th;
     double e = 0;
     if (g) for (int r = 0; r < nranks; r++) { double er; __builtin_memcpy(&er, g + r * rstride + cap, 8); e += er; }
-    else {
-      const int np_ = unfused_parts ? (B.nr + BA_BLOCK - 1) / BA_BLOCK : B.nchunks;
-      for (int b = 0; b < np_; b++) e += B.e_part[b];
-    }
+    else e = (s_esum[0] + s_esum[1]) + (s_esum[2] + s_esum[3]);
     O.lastEnergy = e;
   }
   if (phase == 1 || last) {
-    if (tid == 0) { O.phase = 2; B.finished = 2; }
+    if (tid == 0) { O.phase = 2; Bw.finished = 2; }
     return;
   }
 
   // ---- backupState + doStepFromBackup: frames on threads 0..nf-1, the calibration on thread 64
-  const double* x = B.sol + 3 * ((size_t)B.n * B.n + B.n);
   double* tp = const_cast<double*>(B.t_prior);
   if (tid < nf) {
     const int f = tid;
     double ns[10], sc[10];
+#pragma unroll
     for (int i = 0; i < 10; i++) {
-      const double st = i < 8 ? -x[4 + 8 * f + i] : 0.0;       // step = -x (EnergyFunctional.cpp:978-985)
+      const double st = i < 8 ? -p_x[i < 8 ? i : 0] : 0.0;     // step = -x (EnergyFunctional.cpp:978-985)
       if (i < 8) s_step[f][i] = st;
-      O.state_backup[f][i] = O.state[f][i];
-      ns[i] = O.state[f][i] + (double)stepsize * st;
-      O.state[f][i] = ns[i];
+      ns[i] = p_st[i] + (double)stepsize * st;
     }
+#pragma unroll
+    for (int i = 0; i < 10; i++) { O.state_backup[f][i] = p_st[i]; O.state[f][i] = ns[i]; }
     for (int i = 0; i < 3; i++) sc[i] = SCALE_XI_TRANS * ns[i];
     for (int i = 3; i < 6; i++) sc[i] = SCALE_XI_ROT * ns[i];
     sc[6] = SCALE_A * ns[6]; sc[7] = SCALE_B * ns[7]; sc[8] = SCALE_A * ns[8]; sc[9] = SCALE_B * ns[9];
     Se3 E;
-    for (int i = 0; i < 9; i++) E.R[i] = O.evalPT[f][i];
-    for (int i = 0; i < 3; i++) E.t[i] = O.evalPT[f][9 + i];
+    for (int i = 0; i < 9; i++) E.R[i] = p_ev[i];
+    for (int i = 0; i < 3; i++) E.t[i] = p_ev[9 + i];
     const Se3 Wc = expSe3(sc) * E;                             // PRE_worldToCam = SE3::exp(w2c_leftEps()) * worldToCam_evalPT
     const Se3 Cw = inverse(Wc);
     for (int i = 0; i < 9; i++) { s_w2c[f][i] = Wc.R[i]; s_c2w[f][i] = Cw.R[i]; }
     for (int i = 0; i < 3; i++) { s_w2c[f][9 + i] = Wc.t[i]; s_c2w[f][9 + i] = Cw.t[i]; }
     // setDeltaF: delta_prior = state, delta = state - state_zero
+#pragma unroll
     for (int i = 0; i < 8; i++) {
       tp[nf * 8 + f * 8 + i] = ns[i];
-      tp[nf * 16 + 8 + f * 8 + i] = ns[i] - O.state_zero[f][i];
+      const double dl = ns[i] - p_zero[i];
+      tp[nf * 16 + 8 + f * 8 + i] = dl;
+      s_dlt[f][i] = (float)dl;
     }
+    s_zb[f] = (float)(p_zero[7] * SCALE_B);
   }
+  __shared__ double s_affd[8][2];
+  if (tid < nf) { s_affd[tid][0] = SCALE_A * (p_st[6] + (double)stepsize * -p_x[6]); s_affd[tid][1] = SCALE_B * (p_st[7] + (double)stepsize * -p_x[7]); }
   if (tid == 64) {
     double v[4], vs[4];
     float vsf[4];
-    for (int i = 0; i < 4; i++) {
-      O.calib_backup[i] = O.calib_value[i];
-      v[i] = O.calib_value[i] + stepsize * -x[i];
-      O.calib_value[i] = v[i];
-    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) v[i] = p_st[i] + stepsize * -p_x[i];
+#pragma unroll
+    for (int i = 0; i < 4; i++) { O.calib_backup[i] = p_st[i]; O.calib_value[i] = v[i]; }
     vs[0] = SCALE_F * v[0]; vs[1] = SCALE_F * v[1]; vs[2] = SCALE_C * v[2]; vs[3] = SCALE_C * v[3];
     for (int i = 0; i < 4; i++) vsf[i] = (float)vs[i];
-    B.fxl = vsf[0]; B.fyl = vsf[1]; B.cxl = vsf[2]; B.cyl = vsf[3];
-    B.fxli = 1.0f / vsf[0]; B.fyli = 1.0f / vsf[1];
+    Bw.fxl = vsf[0]; Bw.fyl = vsf[1]; Bw.cxl = vsf[2]; Bw.cyl = vsf[3];
+    Bw.fxli = 1.0f / vsf[0]; Bw.fyli = 1.0f / vsf[1];
     const float K[9] = {vsf[0], 0, vsf[2], 0, vsf[1], vsf[3], 0, 0, 1};
     float Ki[9];
     inv3f(K, Ki);
     for (int i = 0; i < 9; i++) { s_K[i] = K[i]; s_Ki[i] = Ki[i]; }
     float* cd = const_cast<float*>(B.t_cdelta);
+#pragma unroll
     for (int i = 0; i < 4; i++) {
-      const float c = (float)(v[i] - O.calib_zero[i]);
+      const float c = (float)(v[i] - p_zero[i]);
       cd[i] = c;
       tp[nf * 16 + 4 + i] = (double)c;
     }
@@ -209,27 +274,33 @@ __global__ __launch_bounds__(256) void k_ba_opt_step(const BaDev* __restrict__ w
     for (int i = 0; i < 9; i++) { Tw.R[i] = s_w2c[t][i]; Ch.R[i] = s_c2w[h][i]; }
     for (int i = 0; i < 3; i++) { Tw.t[i] = s_w2c[t][9 + i]; Ch.t[i] = s_c2w[h][9 + i]; }
     const Se3 l = Tw * Ch;
-    float R[9], tt[3], KR[9], K[9], Ki[9];
+    float R[9], tt[3], KR[9], K[9], Ki[9], o9[9], o3[3];
     for (int i = 0; i < 9; i++) { R[i] = (float)l.R[i]; K[i] = s_K[i]; Ki[i] = s_Ki[i]; }
     for (int i = 0; i < 3; i++) tt[i] = (float)l.t[i];
     mul3f(K, R, KR);
-    mul3f(KR, Ki, o);          // PRE_KRKiTll
-    mulv3f(K, tt, o + 9);      // PRE_KtTll
+    mul3f(KR, Ki, o9);         // PRE_KRKiTll
+    mulv3f(K, tt, o3);         // PRE_KtTll
     double a2[2];
-    affFromTo(O.ab_exposure[h], O.ab_exposure[t], SCALE_A * O.state[h][6], SCALE_B * O.state[h][7], SCALE_A * O.state[t][6], SCALE_B * O.state[t][7], a2);
+    affFromTo(p_exp_h, p_exp_t, s_affd[h][0], s_affd[h][1], s_affd[t][0], s_affd[t][1], a2);
+    for (int i = 0; i < 9; i++) o[i] = o9[i];
+    for (int i = 0; i < 3; i++) o[9 + i] = o3[i];
     o[24] = (float)a2[0]; o[25] = (float)a2[1];
-    o[26] = (float)(O.state_zero[h][7] * SCALE_B);
+    o[26] = s_zb[h];
   }
   // adHTdeltaF[h + t*nf] = delta_h^T adHostF + delta_t^T adTargetF  (float arithmetic)
-  for (int e = tid; e < nf * nf * 8; e += 256) {
-    const int idx = e >> 3, j = e & 7, h = idx % nf, t = idx / nf;
-    float shh = 0, stt = 0;
-    for (int i = 0; i < 8; i++) {
-      const float dh = (float)(O.state[h][i] - O.state_zero[h][i]), dt = (float)(O.state[t][i] - O.state_zero[t][i]);
-      shh += dh * (float)B.t_adHost[(size_t)idx * 64 + i * 8 + j];
-      stt += dt * (float)B.t_adTarget[(size_t)idx * 64 + i * 8 + j];
+#pragma unroll
+  for (int u = 0; u < 2; u++) {
+    const int e = tid + 256 * u;
+    if (e < nf * nf * 8) {
+      const int idx = e >> 3, h = idx % nf, t = idx / nf;
+      float shh = 0, stt = 0;
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        shh += s_dlt[h][i] * p_ah[u][i];
+        stt += s_dlt[t][i] * p_at[u][i];
+      }
+      const_cast<float*>(B.t_adHTdelta)[e] = shh + stt;
     }
-    const_cast<float*>(B.t_adHTdelta)[e] = shh + stt;
   }
 
   // ---- the loop's break test (doStepFromBackup's return value) and bookkeeping
@@ -245,18 +316,15 @@ __global__ __launch_bounds__(256) void k_ba_opt_step(const BaDev* __restrict__ w
     float sumNID = 0, numID = 0;
     if (g) for (int r = 0; r < nranks; r++) { sumNID += g[r * rstride + cap + 2]; numID += g[r * rstride + cap + 3]; }
     else {
-      if (sums) {
-        const float* sm = sums + (size_t)blockIdx.y * sums_stride;
-        for (int b = 0; b < (B.np + BA_BLOCK - 1) / BA_BLOCK; b++) sumNID += sm[2 * b + 1];
-      }
+      sumNID = (s_nid[0] + s_nid[1]) + (s_nid[2] + s_nid[3]);
       numID = (float)B.np;
     }
     sumA /= nf; sumB /= nf; sumR /= nf; sumT /= nf;
     sumNID /= numID;
     const bool canbreak = sqrtf(sumA) < 0.0005 * 1.2f && sqrtf(sumB) < 0.00005 * 1.2f && sqrtf(sumR) < 0.00005 * 1.2f && sqrtf(sumT) * sumNID < 0.00005 * 1.2f;
-    O.iterations = O.iterations + 1;
-    O.resInA = (int)B.accum[acc_off_nres(nf)];
-    if (stop_on_convergence && canbreak && iteration >= 1) { O.phase = 1; B.finished = 1; }
+    O.iterations = p_its + 1;
+    O.resInA = (int)p_nres;
+    if (stop_on_convergence && canbreak && iteration >= 1) { O.phase = 1; Bw.finished = 1; }
   }
 }
 

@@ -141,10 +141,14 @@ __global__ __launch_bounds__(256) void k_ba_stitch_pre(const BaDev* __restrict__
 // grid.x = ceil(3 (nf^2 + nf + 1) / 4) blocks of 4 waves; job -> (matrix m in {0: top A, 1: top L with priors, 2: Schur}, tile);
 // tile kinds: frame-frame (x,y) 8x8; frame-calib x: 8x4 + b(8); calib: 4x4 + b(4).
 constexpr int ST_WAVES = 4;
+// The loops over hosts / targets are partially unrolled so that the loads of several iterations are in flight together: the kernel is
+// a chain of memory round trips otherwise, which stretches 2-3x when the linearisation of another batch saturates HBM next to it.
+// NF > 0 fixes the keyframe count at compile time (full unrolling at NF = 8 was measured 2x slower: register pressure); NF = 0: runtime nf.
+template <int NF>
 __global__ __launch_bounds__(64 * ST_WAVES) void k_ba_stitch(const BaDev* __restrict__ wins) {
   const BaDev& B = wins[blockIdx.y];
   if (ba_finished(B)) return;
-  const int nf = B.nf, nf2 = nf * nf, n = B.n;
+  const int nf = NF ? NF : B.nf, nf2 = nf * nf, n = B.n;
   const int per = nf2 + nf + 1;
   const int job = blockIdx.x * ST_WAVES + (threadIdx.x >> 6);
   if (job >= 3 * per) return;
@@ -163,6 +167,7 @@ __global__ __launch_bounds__(64 * ST_WAVES) void k_ba_stitch(const BaDev* __rest
       const int x = tile % nf, y = tile / nf;  // block row x, block col y
       double out = 0;
       if (x == y) {
+#pragma unroll 2
         for (int t = 0; t < nf; t++) {                     // H[h,h] += AH A AH^T over the targets of host x
           const int aidx = x + nf * t;
           const double* AH = adH + (size_t)aidx * 64;
@@ -188,6 +193,7 @@ __global__ __launch_bounds__(64 * ST_WAVES) void k_ba_stitch(const BaDev* __rest
           }
           out += s;
         }
+#pragma unroll 4
         for (int h = 0; h < nf; h++)                       // H[t,t] += AT A AT^T over the hosts of target x
           out += at(h, x, a) * acc13(acc + (size_t)(h + nf * x) * 91, 4 + a, 4 + c) * at(h, x, c);
         {                                                  // H[h,t] += AH A AT^T of the pair (x,x)
@@ -222,6 +228,7 @@ __global__ __launch_bounds__(64 * ST_WAVES) void k_ba_stitch(const BaDev* __rest
       const int x = tile;
       // lane -> (a, c4) for c4 < 4 : H[x-rows, calib cols]; lanes with c in 4..7: c==4 -> b
       double hv = 0;
+#pragma unroll 4
       for (int k = 0; k < 2 * nf; k++) {
         const int h = k < nf ? x : k - nf, t = k < nf ? k : x;
         const double* Am = (k < nf ? adH : adT) + (size_t)(h + nf * t) * 64;
@@ -269,9 +276,11 @@ __global__ __launch_bounds__(64 * ST_WAVES) void k_ba_stitch(const BaDev* __rest
     const int x = tile % nf, y = tile / nf;
     double out = S1[(size_t)(x + nf * y) * 64 + lane] * at(x, y, c);          // H[i,k] += AH(i,j) D AT(i,k)^T     (i = x, k = y)
     out += at(y, x, a) * S2[(size_t)(y + nf * x) * 64 + lane];               // H[j,i] += AT(i,j) D AH(i,k)^T     (j = x, i = y)
+#pragma unroll 4
     for (int i = 0; i < nf; i++)                                              // H[j,k] += AT(i,j) D AT(i,k)^T     (j = x, k = y)
       out += at(i, x, a) * (double)accD[(size_t)(i + nf * x + nf2 * y) * 64 + lane] * at(i, y, c);
     if (x == y)                                                               // H[i,i] += AH(i,j) D AH(i,k)^T     (i = x)
+#pragma unroll 4
       for (int k = 0; k < nf; k++) {
         const double* s1 = S1 + (size_t)(x + nf * k) * 64 + a * 8;
         const double* R = adH + (size_t)(x + nf * k) * 64 + c * 8;
@@ -287,6 +296,7 @@ __global__ __launch_bounds__(64 * ST_WAVES) void k_ba_stitch(const BaDev* __rest
   if (tile < nf) {
     const int x = tile;
     double hv = 0;
+#pragma unroll 4
     for (int k = 0; k < 2 * nf; k++) {
       const int i = k < nf ? x : k - nf, j = k < nf ? k : x;   // pair (i host, j target); frame x is host (AH) or target (AT)
       const int ij = i + nf * j;
@@ -353,8 +363,8 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_solve(const BaDev* __restrict__
   double* yv = sv + n;            // n
   double* Dg = yv + n;            // n
   double* xv = Dg + n;            // n
-  double* wq = xv + n;            // n  d_q L_kq of the current pivot row (+ padding to a multiple of 8)
-  int* perm = (int*)(wq + n + 8); // n
+  double* wq = xv + n;            // n  d_q L_kq of the current pivot row (+ 16 zeros: the dot products run in trips of 16)
+  int* perm = (int*)(wq + n + 16); // n
   const size_t blk = (size_t)n * n + n;
   const double* HA = B.sol; const double* bA = HA + (size_t)n * n;
   const double* HL = B.sol + blk; const double* bL = HL + (size_t)n * n;
@@ -399,7 +409,7 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_solve(const BaDev* __restrict__
   __syncthreads();
   for (int e = tid; e < n * n; e += BA_BLOCK) { const int i = e / n, j = e - i * n; A[i * ld + j] = sv[i] * A[i * ld + j] * sv[j]; }
   for (int i = tid; i < n; i += BA_BLOCK) { bF[i] = sv[i] * bF[i]; perm[i] = i; }
-  for (int i = tid; i < n + 8; i += BA_BLOCK) wq[i] = 0.0;
+  for (int i = tid; i < n + 16; i += BA_BLOCK) wq[i] = 0.0;
   __syncthreads();
   STAMP(1);
 
@@ -471,18 +481,19 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_solve(const BaDev* __restrict__
       const double* row0 = Lm + q0c * ld;
       const double* row1 = Lm + q1c * ld;
       const bool any1 = n > 64;                    // (wave-uniform) rows past the 64th exist
-      for (int q = 0; q < k; q += 8) {             // eight terms per trip; beyond k the products are exact zeros (w is zero there)
-        double lv[8], wv8[8];
+      for (int q = 0; q < k; q += 16) {            // sixteen terms per trip (one exposed LDS latency per 16); beyond k the products are exact zeros (w is zero there)
+        double lv[16], wv8[16];
 #pragma unroll
-        for (int u = 0; u < 8; u++) { lv[u] = row0[q + u]; wv8[u] = wq[q + u]; }
-#pragma unroll
-        for (int u = 0; u < 8; u++) c0 = __builtin_fma(-lv[u], wv8[u], c0);
+        for (int u = 0; u < 16; u++) { lv[u] = row0[q + u]; wv8[u] = wq[q + u]; }
         if (any1) {
-          double l2[8];
+          double l2[16];
 #pragma unroll
-          for (int u = 0; u < 8; u++) l2[u] = row1[q + u];
+          for (int u = 0; u < 16; u++) l2[u] = row1[q + u];
 #pragma unroll
-          for (int u = 0; u < 8; u++) c1 = __builtin_fma(-l2[u], wv8[u], c1);
+          for (int u = 0; u < 16; u++) { c0 = __builtin_fma(-lv[u], wv8[u], c0); c1 = __builtin_fma(-l2[u], wv8[u], c1); }
+        } else {
+#pragma unroll
+          for (int u = 0; u < 16; u++) c0 = __builtin_fma(-lv[u], wv8[u], c0);
         }
       }
       ACCUM(3, tq); tq = TNOW();
@@ -591,25 +602,47 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_resub(const BaDev* __restrict__
   const double* x = B.sol + 3 * ((size_t)B.n * B.n + B.n);
   const int nf = B.nf;
   const float* recs = B.r_rec + (size_t)p * nf * 16;
-  int ngood = 0;
-  for (int t = 0; t < nf; t++) if (((int)recs[t * 16 + RR_FLAGS]) & 1) ngood++;
-  if (ngood == 0) { po[PO_STEP] = 0; return; }
-  float b = po[PO_BDSUM];
-  float d = 0;
-#pragma unroll
-  for (int k = 0; k < 4; k++) d += (float)x[k] * (po[PO_HCD_A + k] + po[PO_HCD_L + k]);
-  b -= d;
   const int h = B.p_host[p];
-  for (int t = 0; t < nf; t++) {       // residuals in target order
-    const float* rec = recs + t * 16;
-    if (!(((int)rec[RR_FLAGS]) & 1)) continue;
-    const float* xa = B.t_xAd + (size_t)(h * nf + t) * 8;
-    float sacc = 0;
+  // every load of the point is issued before the first one is consumed (the loop over the targets is unrolled to the 8 frames a
+  // window can hold and predicated): one memory round trip instead of one per target
+  float4 j0[8], j1[8];
+  float4 xa0[8], xa1[8];
+  bool good[8];
 #pragma unroll
-    for (int k = 0; k < 8; k++) sacc += xa[k] * rec[k];
+  for (int t = 0; t < 8; t++) {
+    good[t] = false;
+    if (t < nf) {
+      const float* rec = recs + t * 16;
+      good[t] = (((int)rec[RR_FLAGS]) & 1) != 0;
+      j0[t] = *reinterpret_cast<const float4*>(rec); j1[t] = *reinterpret_cast<const float4*>(rec + 4);
+      const float* xa = B.t_xAd + (size_t)(h * nf + t) * 8;
+      xa0[t] = *reinterpret_cast<const float4*>(xa); xa1[t] = *reinterpret_cast<const float4*>(xa + 4);
+    }
+  }
+  float hA[4] = {po[PO_HCD_A], po[PO_HCD_A + 1], po[PO_HCD_A + 2], po[PO_HCD_A + 3]};
+  float hL[4] = {po[PO_HCD_L], po[PO_HCD_L + 1], po[PO_HCD_L + 2], po[PO_HCD_L + 3]};
+  const float bsum = po[PO_BDSUM], hdi = po[PO_HDI];
+  const double x0 = x[0], x1 = x[1], x2 = x[2], x3 = x[3];
+  int ngood = 0;
+#pragma unroll
+  for (int t = 0; t < 8; t++) ngood += good[t] ? 1 : 0;
+  if (ngood == 0) { po[PO_STEP] = 0; return; }
+  float b = bsum;
+  float d = 0;
+  d += (float)x0 * (hA[0] + hL[0]);
+  d += (float)x1 * (hA[1] + hL[1]);
+  d += (float)x2 * (hA[2] + hL[2]);
+  d += (float)x3 * (hA[3] + hL[3]);
+  b -= d;
+#pragma unroll
+  for (int t = 0; t < 8; t++) {       // residuals in target order
+    if (!good[t]) continue;
+    float sacc = 0;
+    sacc += xa0[t].x * j0[t].x; sacc += xa0[t].y * j0[t].y; sacc += xa0[t].z * j0[t].z; sacc += xa0[t].w * j0[t].w;
+    sacc += xa1[t].x * j1[t].x; sacc += xa1[t].y * j1[t].y; sacc += xa1[t].z * j1[t].z; sacc += xa1[t].w * j1[t].w;
     b -= sacc;
   }
-  po[PO_STEP] = -b * po[PO_HDI];
+  po[PO_STEP] = -b * hdi;
 }
 
 // FullSystem::backupState / doStepFromBackup / loadSateBackup for the points.  op: 0 backup, 1 step, 2 restore
