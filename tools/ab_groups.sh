@@ -1,7 +1,7 @@
 #!/bin/bash
 # step time of the default BA bench against the number of stream groups / the chaining of their accumulate phases
 mkdir -p gpurun_out
-for g in 1 2 3 4; do
+for g in ${GROUPS_LIST:-1 2 3 4}; do
   for nc in 0 1; do
     if [ $g = 1 ] && [ $nc = 1 ]; then continue; fi
     if [ $nc = 1 ]; then export SDSO_BA_NOCHAIN=1; else unset SDSO_BA_NOCHAIN; fi

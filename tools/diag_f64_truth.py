@@ -37,12 +37,17 @@ for name, (win, its) in cases.items():
     W, keep = abi.make_ba_window(win, frame_slots=[40 + f for f in range(nf)], dI_list=[p[0] for p in win["pyrs"]])
     # (1) accumulators
     na = abi.accum_floats(nf)
-    h = orc.orc_ba_create(C.byref(W))
-    orc.orc_ba_linearize(h, None); orc.orc_ba_apply_res(h); orc.orc_ba_accumulate(h)
     a32, a64 = np.zeros(na, np.float32), np.zeros(na)
-    orc.orc_ba_get_accumulators(h, abi.fp(a32))
-    orc.orc_set_acc64(1); orc.orc_ba_get_accumulators_f64(h, abi.dp(a64)); orc.orc_set_acc64(0)
-    orc.orc_ba_destroy(h)
+    for mode in (0, 1):                      # the f64 shadow sums are built only while the mode is on
+        orc.orc_set_acc64(mode)
+        h = orc.orc_ba_create(C.byref(W))
+        orc.orc_ba_linearize(h, None); orc.orc_ba_apply_res(h); orc.orc_ba_accumulate(h)
+        if mode:
+            orc.orc_ba_get_accumulators_f64(h, abi.dp(a64))
+        else:
+            orc.orc_ba_get_accumulators(h, abi.fp(a32))
+        orc.orc_ba_destroy(h)
+    orc.orc_set_acc64(0)
     ctx.check(ctx.L.sdso_ba_upload_window(ctx.h, 3, C.byref(W)))
     ctx.check(ctx.L.sdso_ba_linearize(ctx.h, 3, None)); ctx.check(ctx.L.sdso_ba_apply_res(ctx.h, 3)); ctx.check(ctx.L.sdso_ba_accumulate(ctx.h, 3))
     ag = np.zeros(na, np.float32)
