@@ -410,6 +410,10 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_solve(const BaDev* __restrict__
   for (int e = tid; e < n * n; e += BA_BLOCK) { const int i = e / n, j = e - i * n; A[i * ld + j] = sv[i] * A[i * ld + j] * sv[j]; }
   for (int i = tid; i < n; i += BA_BLOCK) { bF[i] = sv[i] * bF[i]; perm[i] = i; }
   for (int i = tid; i < n + 16; i += BA_BLOCK) wq[i] = 0.0;
+  // the dot products of the factorisation run in trips of 16 and read past column n-1 of a row (times an exact zero of w): the
+  // padding columns of every row and the vectors behind the matrix must hold finite values, not whatever the last kernel left in LDS
+  for (int i = tid; i < n * (ld - n); i += BA_BLOCK) A[(i / (ld - n)) * ld + n + i % (ld - n)] = 0.0;
+  for (int i = tid; i < n; i += BA_BLOCK) { yv[i] = 0.0; Dg[i] = 0.0; xv[i] = 0.0; }
   __syncthreads();
   STAMP(1);
 
