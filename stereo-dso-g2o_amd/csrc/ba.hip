@@ -10,6 +10,8 @@
 #include <cmath>
 #include <cstring>
 #include <numeric>
+#include <functional>
+#include <chrono>
 #include <atomic>
 #include <thread>
 
@@ -45,6 +47,8 @@ struct BaWindowDev {
   BaOptDev h_opt;               // staging of its upload
   std::vector<double> h_prstage;  // staging of the dt_prior upload (upload_tables)
   int newest_first = 0;         // first pair-sorted residual whose target is the newest frame
+  char* tbl_first = nullptr;    // the tables upload_tables refreshes are one contiguous block of the window's slab:
+  size_t tbl_bytes = 0;         //   [precalc | adHTdelta | cdelta | adHost | adTarget | P | prior | BaDev], 256-byte aligned each
   float* accum_own = nullptr;   // the window's own packed accumulator block (d.accum points into the batch block while batched)
   bool in_batch = false;
   bool accumulated = false;
@@ -53,7 +57,7 @@ struct BaWindowDev {
 
 // zeroed device buffer for a window: reuse a pooled buffer of a released window when one of a similar size exists
 // (hipMalloc / hipFree of ~40 buffers cost more than the whole upload otherwise)
-static int dmalloc(sdso_ctx* ctx, BaWindowDev* W, void** p, size_t bytes) {
+static int dmalloc(sdso_ctx* ctx, BaWindowDev* W, void** p, size_t bytes, bool zero = true) {
   const size_t want = ((bytes ? bytes : 16) + 255) & ~(size_t)255;
   int best = -1;
   for (int i = 0; i < (int)ctx->ba_pool.size(); i++) {
@@ -63,9 +67,30 @@ static int dmalloc(sdso_ctx* ctx, BaWindowDev* W, void** p, size_t bytes) {
   size_t got = want;
   if (best >= 0) { *p = ctx->ba_pool[best].first; got = ctx->ba_pool[best].second; ctx->ba_pool.erase(ctx->ba_pool.begin() + best); }
   else SDSO_HIP(ctx, hipMalloc(p, want));
-  SDSO_HIP(ctx, hipMemsetAsync(*p, 0, want, ctx->stream));
+  if (zero) SDSO_HIP(ctx, hipMemsetAsync(*p, 0, want, ctx->stream));
   W->allocs.emplace_back(*p, got);
   return SDSO_OK;
+}
+// pinned host staging of the ctx (window uploads, table refreshes): grown on demand, released with the ctx's windows.  The caller
+// synchronises the stream before the next reservation is written.
+struct StageBuf { char* p = nullptr; size_t cap = 0; };
+static std::map<sdso_ctx*, StageBuf> g_stage;
+static int stage_reserve(sdso_ctx* ctx, size_t bytes, char** out) {
+  StageBuf& b = reg_get(g_stage, ctx);
+  if (bytes > b.cap) {
+    SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (b.p) hipHostFree(b.p);
+    b.p = nullptr; b.cap = 0;
+    const size_t want = (bytes * 3 / 2 + 4095) & ~(size_t)4095;
+    SDSO_HIP(ctx, hipHostMalloc((void**)&b.p, want));
+    b.cap = want;
+  }
+  *out = b.p;
+  return SDSO_OK;
+}
+static void stage_free(sdso_ctx* ctx) {
+  StageBuf b;
+  if (reg_take(g_stage, ctx, b) && b.p) hipHostFree(b.p);
 }
 #define DM(ptr, T, count)                                                   \
   do {                                                                      \
@@ -120,6 +145,7 @@ static void free_batch(sdso_ctx* ctx) {
 void release_all_windows(sdso_ctx* ctx) {
   free_batch(ctx);
   free_optbufs(ctx);
+  stage_free(ctx);
   for (auto& kv : ctx->wins) free_window(ctx, kv.second);
   ctx->wins.clear();
 }
@@ -143,21 +169,28 @@ static void build_tables(BaWindowDev* W, bool adjoints) {
   W->d.cxl = W->calib.value_scaledf[2]; W->d.cyl = W->calib.value_scaledf[3];
   W->d.fxli = W->calib.value_scaledi[0]; W->d.fyli = W->calib.value_scaledi[1];
 }
-static int upload_tables(sdso_ctx* ctx, BaWindowDev* W, bool adjoints, bool sync = true, bool built = false) {
+// tables -> device.  The block is contiguous in the window's slab, so it travels as ONE copy from a pinned staging area: `stage`
+// (tbl_bytes of the caller's reservation; it must stay untouched until the stream has passed the copy), or the ctx staging buffer,
+// in which case the call synchronises.
+static int upload_tables(sdso_ctx* ctx, BaWindowDev* W, bool adjoints, bool sync = true, bool built = false, char* stage = nullptr) {
   const int nf = W->d.nf, n = W->d.n;
   if (!built) build_tables(W, adjoints);
-  H2D(W->dt_precalc, W->tab.precalc.data(), sizeof(float) * nf * nf * 27);
-  H2D(W->dt_adHTdelta, W->tab.adHTdeltaF.data(), sizeof(float) * nf * nf * 8);
-  H2D(W->dt_cdelta, W->tab.cDeltaF, sizeof(float) * 4);
-  if (adjoints) {
-    H2D(W->dt_adHost, W->tab.adHost.data(), sizeof(double) * nf * nf * 64);
-    H2D(W->dt_adTarget, W->tab.adTarget.data(), sizeof(double) * nf * nf * 64);
-    H2D(W->dt_P, W->P.a.data(), sizeof(double) * n * n);
+  if (!stage) {
+    int rc = stage_reserve(ctx, W->tbl_bytes, &stage);
+    if (rc) return rc;
+    sync = true;
   }
-  std::vector<double>& pr = W->h_prstage;
-  H2D(W->dt_prior, pr.data(), sizeof(double) * pr.size());
-  H2D(W->d_self, &W->d, sizeof(BaDev));
-  if (sync) SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the tables in W->tab are rebuilt by the next call
+  auto put = [&](const void* dst, const void* src, size_t bytes) { std::memcpy(stage + ((const char*)dst - W->tbl_first), src, bytes); };
+  put(W->dt_precalc, W->tab.precalc.data(), sizeof(float) * nf * nf * 27);
+  put(W->dt_adHTdelta, W->tab.adHTdeltaF.data(), sizeof(float) * nf * nf * 8);
+  put(W->dt_cdelta, W->tab.cDeltaF, sizeof(float) * 4);
+  put(W->dt_adHost, W->tab.adHost.data(), sizeof(double) * nf * nf * 64);       // unchanged unless `adjoints`: the host copies persist
+  put(W->dt_adTarget, W->tab.adTarget.data(), sizeof(double) * nf * nf * 64);
+  put(W->dt_P, W->P.a.data(), sizeof(double) * n * n);
+  put(W->dt_prior, W->h_prstage.data(), sizeof(double) * W->h_prstage.size());
+  put(W->d_self, &W->d, sizeof(BaDev));
+  SDSO_HIP(ctx, hipMemcpyAsync(W->tbl_first, stage, W->tbl_bytes, hipMemcpyHostToDevice, ctx->stream));
+  if (sync) SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return SDSO_OK;
 }
 
@@ -195,8 +228,17 @@ static int upload_window_impl(sdso_ctx* ctx, int win, const sdso_ba_window_t* Wi
   // bits solveSystemF never reads (ORTHOGONALIZE_POINTMARG / _FULL, MOMENTUM) or that only the un-compiled driver uses (STEPMOMENTUM)
   const int unsupported = SOLVER_ORTHOGONALIZE_POINTMARG | SOLVER_ORTHOGONALIZE_FULL | SOLVER_MOMENTUM | SOLVER_STEPMOMENTUM;
   SDSO_REQUIRE(ctx, (Win->solverMode & unsupported) == 0, "solverMode bit not supported (ORTHOGONALIZE_POINTMARG / ORTHOGONALIZE_FULL / MOMENTUM / STEPMOMENTUM)");
+  const bool timing = getenv("SDSO_BA_UPLOAD_TIMING") != nullptr;   // phase times of the upload on stderr (diagnostic)
+  auto t_prev = std::chrono::steady_clock::now();
+  auto mark = [&](const char* what) {
+    if (!timing) return;
+    const auto t = std::chrono::steady_clock::now();
+    fprintf(stderr, "[sdso_ba_upload_window] %-28s %7.1f us\n", what, std::chrono::duration<double, std::micro>(t - t_prev).count());
+    t_prev = t;
+  };
   int rc = sdso_ba_release_window(ctx, win);
   if (rc) return rc;
+  mark("release of the old window");
   const bool use_tiled = getenv("SDSO_BA_ROWMAJOR") == nullptr;   // 4x2-tiled level-0 images for the linearisation (default)
 
   BaWindowDev* W = new BaWindowDev();
@@ -236,6 +278,7 @@ static int upload_window_impl(sdso_ctx* ctx, int win, const sdso_ba_window_t* Wi
   if (Win->HM) std::memcpy(W->HM.data(), Win->HM, sizeof(double) * n * n);
   if (Win->bM) std::memcpy(W->bM.data(), Win->bM, sizeof(double) * n);
 
+  mark("host mirror of the frames");
   // ---- validate + sort residuals by (host,target) pair, stable
   std::vector<int> rhost(nr);
   for (int p = 1; p < np; p++) SDSO_REQUIRE(ctx, Win->host[p] >= Win->host[p - 1], "points must be in allPoints order (host index non-decreasing)");
@@ -259,10 +302,12 @@ static int upload_window_impl(sdso_ctx* ctx, int win, const sdso_ba_window_t* Wi
     }
   }
   W->perm.resize(nr); W->inv.resize(nr);
-  std::iota(W->perm.begin(), W->perm.end(), 0);
-  std::stable_sort(W->perm.begin(), W->perm.end(), [&](int a, int b) {
-    return rhost[a] + Win->res_target[a] * nf < rhost[b] + Win->res_target[b] * nf;
-  });
+  {  // stable counting sort by htIDX = host + target * nf (nf^2 <= 64 keys)
+    std::vector<int> cnt(nf * nf + 1, 0);
+    for (int i = 0; i < nr; i++) cnt[rhost[i] + Win->res_target[i] * nf + 1]++;
+    for (int k = 0; k < nf * nf; k++) cnt[k + 1] += cnt[k];
+    for (int i = 0; i < nr; i++) W->perm[cnt[rhost[i] + Win->res_target[i] * nf]++] = i;
+  }
   for (int j = 0; j < nr; j++) W->inv[W->perm[j]] = j;
   std::vector<int> s_point(nr);
   std::vector<uint8_t> s_host(nr), s_target(nr), s_state(nr);
@@ -309,31 +354,64 @@ static int upload_window_impl(sdso_ctx* ctx, int win, const sdso_ba_window_t* Wi
   W->nblk_res = (nr + BA_BLOCK - 1) / BA_BLOCK;
   W->nblk_pts = (np + BA_BLOCK - 1) / BA_BLOCK;
 
-  // ---- device allocations
+  mark("validation, sort, work lists");
+  // ---- device memory: ONE slab per window.  Segments whose content comes from the host sit at its front and are filled by one staged
+  // H2D copy (a pinned staging buffer of the ctx, same layout); everything behind them is cleared by one memset.  (~60 separate buffers
+  // with a memset each and ~40 small pageable copies cost 0.7 of the 0.96 ms an upload took.)
+  struct Seg { size_t bytes; bool init; std::function<void(char*)> set; size_t off; };
+  std::vector<Seg> segs;
+#define PL(ptr, T, count, init) segs.push_back(Seg{sizeof(T) * (size_t)(count), (init), [&](char* b) { ptr = (T*)b; }, 0})
   float4* p_geo; float *p_color, *p_weights, *p_prior, *p_delta, *p_out; int *p_host, *p_rbeg, *p_rcnt, *p_rlist;
-  DM(p_geo, float4, np); DM(p_color, float, np * 8); DM(p_weights, float, np * 8); DM(p_host, int, np);
-  DM(p_prior, float, np); DM(p_delta, float, np); DM(p_rbeg, int, np); DM(p_rcnt, int, np); DM(p_rlist, int, nr); DM(p_out, float, (size_t)np * 16);
+  PL(p_geo, float4, np, true); PL(p_color, float, np * 8, true); PL(p_weights, float, np * 8, true); PL(p_host, int, np, true);
+  PL(p_prior, float, np, true); PL(p_delta, float, np, true); PL(p_rbeg, int, np, true); PL(p_rcnt, int, np, true); PL(p_rlist, int, nr, true);
+  PL(p_out, float, (size_t)np * 16, false);
   int* r_point; int* r_orig; uint8_t *r_host, *r_target;
-  DM(r_point, int, nr); DM(r_orig, int, nr); DM(r_host, uint8_t, nr); DM(r_target, uint8_t, nr);
-  DM(d.r_state, uint8_t, nr); DM(d.r_newState, uint8_t, nr); DM(d.r_lin, uint8_t, nr); DM(d.r_act, uint8_t, nr); DM(d.r_jsel, uint8_t, nr);
-  DM(d.r_energy, float, nr); DM(d.r_newEnergy, float, nr); DM(d.r_newEnergyWO, float, nr);
-  DM(d.J[0], float, (size_t)76 * d.nrp); DM(d.J[1], float, (size_t)76 * d.nrp); DM(d.r_toZero, float, (size_t)8 * d.nrp);
-  DM(d.r_rec, float, (size_t)np * nf * 16);   // dense [point][target] records
+  PL(r_point, int, nr, true); PL(r_orig, int, nr, true); PL(r_host, uint8_t, nr, true); PL(r_target, uint8_t, nr, true);
+  PL(d.r_state, uint8_t, nr, true); PL(d.r_newState, uint8_t, nr, false); PL(d.r_lin, uint8_t, nr, false); PL(d.r_act, uint8_t, nr, false); PL(d.r_jsel, uint8_t, nr, false);
+  PL(d.r_energy, float, nr, false); PL(d.r_newEnergy, float, nr, false); PL(d.r_newEnergyWO, float, nr, false);
+  PL(d.J[0], float, (size_t)76 * d.nrp, false); PL(d.J[1], float, (size_t)76 * d.nrp, false); PL(d.r_toZero, float, (size_t)8 * d.nrp, false);
+  PL(d.r_rec, float, (size_t)np * nf * 16, false);   // dense [point][target] records
   d.r_proj = nullptr;
-  DM(W->dt_precalc, float, nf * nf * 27); DM(W->dt_adHTdelta, float, nf * nf * 8); DM(W->dt_cdelta, float, 4); DM(W->dt_frameTH, float, nf);
-  DM(W->dt_adHost, double, nf * nf * 64); DM(W->dt_adTarget, double, nf * nf * 64); DM(W->dt_prior, double, nf * 16 + 4 + n);
-  DM(W->dt_HM, double, (size_t)n * n); DM(W->dt_bM, double, n); DM(W->dt_P, double, (size_t)n * n); DM(W->dt_xAd, float, nf * nf * 8);
-  const float4** d_img; DM(d_img, const float4*, nf);
+  // the tables upload_tables refreshes: contiguous, in this order (one staged copy there too)
+  PL(W->dt_precalc, float, nf * nf * 27, true); PL(W->dt_adHTdelta, float, nf * nf * 8, true); PL(W->dt_cdelta, float, 4, true);
+  PL(W->dt_adHost, double, nf * nf * 64, true); PL(W->dt_adTarget, double, nf * nf * 64, true); PL(W->dt_P, double, (size_t)n * n, true);
+  PL(W->dt_prior, double, nf * 16 + 4 + n, true); PL(W->d_self, BaDev, 1, true);
+  PL(W->dt_frameTH, float, nf, true);
+  PL(W->dt_HM, double, (size_t)n * n, true); PL(W->dt_bM, double, n, true); PL(W->dt_xAd, float, nf * nf * 8, false);
+  const float4** d_img; PL(d_img, const float4*, nf, true);
   int4* d_chunks; int* d_pair_beg; int4* d_items; int* d_host_beg;
-  DM(d_chunks, int4, chunks.size()); DM(d_pair_beg, int, nf * nf + 1); DM(d_items, int4, items.size()); DM(d_host_beg, int, nf + 1);
-  DM(d.top_part, float, (size_t)d.nchunks * 92); DM(d.sc_part, float, std::max((size_t)d.nitems * sc_part_floats(nf), (size_t)nf * 20)); DM(d.e_part, double, std::max(W->nblk_res, d.nchunks) + 1);
-  DM(d.accum, float, acc_floats(nf));
+  PL(d_chunks, int4, chunks.size(), true); PL(d_pair_beg, int, nf * nf + 1, true); PL(d_items, int4, items.size(), true); PL(d_host_beg, int, nf + 1, true);
+  PL(d.top_part, float, (size_t)d.nchunks * 92, false); PL(d.sc_part, float, std::max((size_t)d.nitems * sc_part_floats(nf), (size_t)nf * 20), false);
+  PL(d.e_part, double, std::max(W->nblk_res, d.nchunks) + 1, false);
+  PL(d.accum, float, acc_floats(nf), false);
+  PL(d.sol, double, sol_doubles(n, nf), false);
+  PL(W->d_pflag, uint8_t, np, false); PL(W->d_sums, float, 2 * (W->nblk_pts + 1), false);
+  PL(W->d_opt, BaOptDev, 1, false);
+#undef PL
+  size_t init_bytes = 0, total = 0;
+  for (int pass = 0; pass < 2; pass++) {
+    for (Seg& sg : segs)
+      if (sg.init == (pass == 0)) { sg.off = total; total += ((sg.bytes ? sg.bytes : 16) + 255) & ~(size_t)255; }
+    if (pass == 0) init_bytes = total;
+  }
+  char* slab = nullptr;
+  {
+    void* sp = nullptr;
+    int rc2 = dmalloc(ctx, W, &sp, total, false);
+    if (rc2) return rc2;
+    slab = (char*)sp;
+  }
+  for (Seg& sg : segs) sg.set(slab + sg.off);
   W->accum_own = d.accum;
-  DM(d.sol, double, sol_doubles(n, nf));
-  DM(W->d_pflag, uint8_t, np); DM(W->d_sums, float, 2 * (W->nblk_pts + 1));
-  DM(W->d_self, BaDev, 1);
-  DM(W->d_opt, BaOptDev, 1);
   d.opt = W->d_opt; d.finished = 0;
+  W->tbl_first = (char*)W->dt_precalc; W->tbl_bytes = (size_t)((char*)W->d_self + sizeof(BaDev) - (char*)W->dt_precalc);
+  char* stage = nullptr;
+  {
+    int rc2 = stage_reserve(ctx, init_bytes, &stage);
+    if (rc2) return rc2;
+    std::memset(stage, 0, init_bytes);
+  }
+#define STG(dst, src, bytes) std::memcpy(stage + ((const char*)(dst) - slab), (src), (bytes))
 
   d.p_geo = p_geo; d.p_color = p_color; d.p_weights = p_weights; d.p_host = p_host; d.p_prior = p_prior; d.p_delta = p_delta;
   d.p_rbeg = p_rbeg; d.p_rcnt = p_rcnt; d.p_rlist = p_rlist; d.p_out = p_out;
@@ -343,6 +421,7 @@ static int upload_window_impl(sdso_ctx* ctx, int win, const sdso_ba_window_t* Wi
   d.t_adHost = W->dt_adHost; d.t_adTarget = W->dt_adTarget; d.t_xAd = W->dt_xAd; d.t_prior = W->dt_prior; d.t_HM = W->dt_HM; d.t_bM = W->dt_bM; d.t_P = W->dt_P;
   d.chunks = d_chunks; d.pair_chunk_beg = d_pair_beg; d.items = d_items; d.host_item_beg = d_host_beg;
 
+  mark("slab + staging reservation");
   // ---- uploads
   std::vector<float4> geo(np);
   W->h_prior.resize(np);
@@ -358,30 +437,35 @@ static int upload_window_impl(sdso_ctx* ctx, int win, const sdso_ba_window_t* Wi
   for (int i = 0; i < nr; i++) rlist[i] = W->inv[i];   // slot order == original order (grouped by point)
   std::vector<float> frameTH(nf);
   for (int f = 0; f < nf; f++) frameTH[f] = W->frames[f].frameEnergyTH;
-  H2D(p_geo, geo.data(), sizeof(float4) * np); H2D(p_color, Win->color, sizeof(float) * np * 8); H2D(p_weights, Win->weights, sizeof(float) * np * 8);
-  H2D(p_host, Win->host, sizeof(int) * np); H2D(p_prior, W->h_prior.data(), sizeof(float) * np); H2D(p_delta, delta.data(), sizeof(float) * np);
-  H2D(p_rbeg, rbeg.data(), sizeof(int) * np); H2D(p_rcnt, rcnt.data(), sizeof(int) * np); H2D(p_rlist, rlist.data(), sizeof(int) * nr);
-  H2D(r_point, s_point.data(), sizeof(int) * nr); H2D(r_orig, W->perm.data(), sizeof(int) * nr); H2D(r_host, s_host.data(), nr); H2D(r_target, s_target.data(), nr); H2D(d.r_state, s_state.data(), nr);
-  H2D(W->dt_frameTH, frameTH.data(), sizeof(float) * nf); H2D(d_img, imgs.data(), sizeof(float4*) * nf);
-  H2D(d_chunks, chunks.data(), sizeof(int4) * chunks.size()); H2D(d_pair_beg, pair_beg.data(), sizeof(int) * (nf * nf + 1));
-  H2D(d_items, items.data(), sizeof(int4) * items.size()); H2D(d_host_beg, host_beg.data(), sizeof(int) * (nf + 1));
-  H2D(W->dt_HM, W->HM.data(), sizeof(double) * n * n); H2D(W->dt_bM, W->bM.data(), sizeof(double) * n);
+  STG(p_geo, geo.data(), sizeof(float4) * np); STG(p_color, Win->color, sizeof(float) * np * 8); STG(p_weights, Win->weights, sizeof(float) * np * 8);
+  STG(p_host, Win->host, sizeof(int) * np); STG(p_prior, W->h_prior.data(), sizeof(float) * np); STG(p_delta, delta.data(), sizeof(float) * np);
+  STG(p_rbeg, rbeg.data(), sizeof(int) * np); STG(p_rcnt, rcnt.data(), sizeof(int) * np); STG(p_rlist, rlist.data(), sizeof(int) * nr);
+  STG(r_point, s_point.data(), sizeof(int) * nr); STG(r_orig, W->perm.data(), sizeof(int) * nr); STG(r_host, s_host.data(), nr); STG(r_target, s_target.data(), nr); STG(d.r_state, s_state.data(), nr);
+  STG(W->dt_frameTH, frameTH.data(), sizeof(float) * nf); STG(d_img, imgs.data(), sizeof(float4*) * nf);
+  STG(d_chunks, chunks.data(), sizeof(int4) * chunks.size()); STG(d_pair_beg, pair_beg.data(), sizeof(int) * (nf * nf + 1));
+  STG(d_items, items.data(), sizeof(int4) * items.size()); STG(d_host_beg, host_beg.data(), sizeof(int) * (nf + 1));
+  STG(W->dt_HM, W->HM.data(), sizeof(double) * n * n); STG(W->dt_bM, W->bM.data(), sizeof(double) * n);
+  mark("staging of points / residuals");
+  // the tables at the uploaded state, staged with everything else
+  build_tables(W, true);
+  STG(W->dt_precalc, W->tab.precalc.data(), sizeof(float) * nf * nf * 27);
+  STG(W->dt_adHTdelta, W->tab.adHTdeltaF.data(), sizeof(float) * nf * nf * 8);
+  STG(W->dt_cdelta, W->tab.cDeltaF, sizeof(float) * 4);
+  STG(W->dt_adHost, W->tab.adHost.data(), sizeof(double) * nf * nf * 64);
+  STG(W->dt_adTarget, W->tab.adTarget.data(), sizeof(double) * nf * nf * 64);
+  STG(W->dt_P, W->P.a.data(), sizeof(double) * n * n);
+  STG(W->dt_prior, W->h_prstage.data(), sizeof(double) * W->h_prstage.size());
+  STG(W->d_self, &W->d, sizeof(BaDev));
+#undef STG
+  mark("tables (adjoints, projector)");
+  SDSO_HIP(ctx, hipMemcpyAsync(slab, stage, init_bytes, hipMemcpyHostToDevice, ctx->stream));
+  if (total > init_bytes) SDSO_HIP(ctx, hipMemsetAsync(slab + init_bytes, 0, total - init_bytes, ctx->stream));
   // per-residual record: target in slot 15, newState OUTLIER, newEnergyWO -1
-  {
-    std::vector<float> rec((size_t)np * nf * 16, 0.f);
-    for (int o = 0; o < nr; o++) {
-      const size_t slot = (size_t)Win->res_point[o] * nf + Win->res_target[o];
-      rec[slot * 16 + RR_TARGET] = (float)Win->res_target[o];
-    }
-    H2D(d.r_rec, rec.data(), sizeof(float) * rec.size());
-    std::vector<uint8_t> ns(nr, 2);
-    H2D(d.r_newState, ns.data(), nr);
-    std::vector<float> m1(nr, -1.f);
-    H2D(d.r_newEnergyWO, m1.data(), sizeof(float) * nr);
-    SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  }
-  SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  return upload_tables(ctx, W, true);
+  if (nr) hipLaunchKernelGGL(k_ba_init_res, dim3(W->nblk_res), dim3(BA_BLOCK), 0, ctx->stream, W->d_self);
+  SDSO_HIP(ctx, hipGetLastError());
+  SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the staging buffer is the ctx's: free for the next upload
+  mark("copy + clear + init kernel");
+  return SDSO_OK;
 }
 // a window that failed half-way through its upload must not stay registered (later calls would launch on null arrays)
 extern "C" int sdso_ba_upload_window(sdso_ctx* ctx, int win, const sdso_ba_window_t* Win) {
@@ -1405,9 +1489,13 @@ static int opt_finish(sdso_ctx* ctx, OptRun& R, sdso_ba_opt_result_t* out) {
     for (int t = 0; t < nthreads; t++) pool.emplace_back([&] { for (int w; (w = next.fetch_add(1)) < nwin;) finalize(w); });
     for (std::thread& t : pool) t.join();
   }
+  size_t tb = 0;
+  for (BaWindowDev* W : R.W) tb = std::max(tb, (W->tbl_bytes + 255) & ~(size_t)255);
+  char* tstage = nullptr;
+  if ((rc = stage_reserve(ctx, tb * nwin, &tstage))) return rc;      // released for reuse by the synchronisation of opt_collect below
   for (int w = 0; w < nwin; w++) {
     BaWindowDev* W = R.W[w];
-    if ((rc = upload_tables(ctx, W, true, false, true))) return rc;
+    if ((rc = upload_tables(ctx, W, true, false, true, tstage + tb * w))) return rc;
     if (W->in_batch) H2D(const_cast<BaDev*>(R.L.d_arr) + w, &W->d, sizeof(BaDev));   // the batch's descriptor copy carries the calibration scalars too
     W->accumulated = false;
   }

@@ -598,6 +598,17 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_unmask(const BaDev* __restrict_
   const int i = blockIdx.x * BA_BLOCK + threadIdx.x;
   if (i < B.nr) B.r_lin[i] &= 1;
 }
+// upload: state_NewState = OUTLIER, state_NewEnergyWithOutlier = -1 (Residuals.cpp:40-52), and the target of every existing
+// (point, target) slot of the dense per-point records
+__global__ __launch_bounds__(BA_BLOCK) void k_ba_init_res(const BaDev* __restrict__ wins) {
+  const BaDev& B = wins[blockIdx.y];
+  const int i = blockIdx.x * BA_BLOCK + threadIdx.x;
+  if (i >= B.nr) return;
+  B.r_newState[i] = 2;
+  B.r_newEnergyWO[i] = -1.f;
+  const int t = B.r_target[i];
+  B.r_rec[((size_t)B.r_point[i] * B.nf + t) * 16 + RR_TARGET] = (float)t;
+}
 // resetOOB for every non-linearized residual (FullSystemOptimize.cpp:886-892)
 __global__ __launch_bounds__(BA_BLOCK) void k_ba_reset_all(const BaDev* __restrict__ wins) {
   const BaDev& B = wins[blockIdx.y];
