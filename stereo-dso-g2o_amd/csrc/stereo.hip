@@ -385,6 +385,279 @@ __global__ __launch_bounds__(256, MINB) void k_trace_stereo(TraceDev T) {
   finish(IPS_GOOD, bestU, bestV, 2 * errorInPixel, true);
 }
 
+// ImmaturePoint::traceStereo, block organisation (default): a 256-thread workgroup owns 64 points.
+//   phase 1  thread t < 64 : the search geometry of point t, one LANE per point (the reference's scalar code; every early exit of
+//                            ImmaturePoint.cpp:118-238 is a per-lane exit) -> numSteps, start, direction in LDS
+//   phase 2  wave w        : the discrete searches of points 16w .. 16w+15, one after the other, lanes = steps (as in the per-wave kernel)
+//   phase 3  thread t < 64 : sub-pixel refinement of point t with the 8 pattern pixels in a serial loop (the reference's order by
+//                            construction), interval update, outputs
+// The per-wave kernel above spends every instruction of the geometry at 1 / 64 and of the refinement at 8 / 64 lanes and is VALU-issue
+// bound (1 350 VALU instructions per point); here those parts run 64 points per instruction: ~750 per point.  Same expressions, same
+// operation order: bit-identical outputs.
+template <int GN_MODE, int PTS>   // PTS points per 256-thread workgroup (PTS / 4 searches per wave)
+__global__ __launch_bounds__(256) void k_trace_stereo_blk(TraceDev T) {
+  __shared__ float s_ptx0[PTS], s_pty0[PTS], s_dx[PTS], s_dy[PTS];
+  __shared__ int s_steps[PTS];                                   // 0: the point does not reach the search
+  __shared__ float s_bE[PTS], s_bX[PTS], s_bY[PTS], s_second[PTS];
+  __shared__ int s_bI[PTS];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int i = blockIdx.x * PTS + t;
+  const float4* __restrict__ dI = T.img;
+  const int wG0 = T.w, hG0 = T.h;
+  bool live = false;                                            // the point goes on to the search and the refinement
+  // per-lane state that survives the barriers (thread t of phase 1 is thread t of phase 3)
+  float u_stereo = 0, v_stereo = 0, idepth_min_stereo = 0, idepth_max_stereo = 0, energyTH = 0, quality = 0, errorInPixel = 0, dx = 0, dy = 0, bf = 0;
+  float Kt[3] = {0, 0, 0}, pr[3] = {0, 0, 0};
+  int numSteps = 0;
+  uint8_t prevStatus = 0;
+  auto finish = [&](int st, float uvx, float uvy, float interval, bool writeUV) {
+    T.lastTraceStatus[i] = (uint8_t)st;
+    if (T.status) T.status[i] = (uint8_t)st;
+    if (writeUV) { T.lastTraceUV[i * 2] = uvx; T.lastTraceUV[i * 2 + 1] = uvy; T.lastTracePixelInterval[i] = interval; }
+    T.quality[i] = quality;
+  };
+  if (t < PTS) {
+    s_steps[t] = 0;
+    if (i < T.n) {
+      if (T.skip && T.skip[i]) { if (T.status) T.status[i] = 255; }
+      else do {
+        u_stereo = T.u_stereo[i]; v_stereo = T.v_stereo[i];
+        idepth_min_stereo = T.idepth_min_stereo[i]; idepth_max_stereo = T.idepth_max_stereo[i];
+        const float* gradH = T.gradH + (size_t)i * 4;
+        const float idepth_min = T.idepth_min[i];
+        energyTH = T.energyTH[i];
+        quality = T.quality[i];
+        prevStatus = T.lastTraceStatus[i];
+        const float bl0 = T.mode_right ? -T.baseline : T.baseline;
+        Kt[0] = (T.fx * bl0 + 0.0f * 0.0f) + T.cx * 0.0f;
+        Kt[1] = (0.0f * bl0 + T.fy * 0.0f) + T.cy * 0.0f;
+        Kt[2] = (0.0f * bl0 + 0.0f * 0.0f) + 1.0f * 0.0f;
+        bf = -T.fx * bl0;
+        pr[0] = (1.0f * u_stereo + 0.0f * v_stereo) + 0.0f * 1.0f;
+        pr[1] = (0.0f * u_stereo + 1.0f * v_stereo) + 0.0f * 1.0f;
+        pr[2] = (0.0f * u_stereo + 0.0f * v_stereo) + 1.0f * 1.0f;
+        float ptpMin[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) ptpMin[k] = pr[k] + Kt[k] * idepth_min_stereo;
+        const float uMin = ptpMin[0] / ptpMin[2];
+        const float vMin = ptpMin[1] / ptpMin[2];
+        if (!(uMin > 4 && vMin > 4 && uMin < wG0 - 5 && vMin < hG0 - 5)) { finish(IPS_OOB, -1, -1, 0, true); break; }
+        float dist, uMax, vMax, ptpMax[3];
+        const float maxPixSearch = (wG0 + hG0) * kMaxPixSearch;
+        const bool finiteMax = isfinite(idepth_max_stereo);
+        if (finiteMax) {
+#pragma unroll
+          for (int k = 0; k < 3; k++) ptpMax[k] = pr[k] + Kt[k] * idepth_max_stereo;
+          uMax = ptpMax[0] / ptpMax[2];
+          vMax = ptpMax[1] / ptpMax[2];
+          if (!(uMax > 4 && vMax > 4 && uMax < wG0 - 5 && vMax < hG0 - 5)) { finish(IPS_OOB, -1, -1, 0, true); break; }
+          dist = (uMin - uMax) * (uMin - uMax) + (vMin - vMax) * (vMin - vMax);
+          dist = sqrtf(dist);
+          if (dist < kTraceSlackInterval) { finish(IPS_SKIPPED, 0, 0, 0, false); break; }
+        } else {
+          dist = maxPixSearch;
+#pragma unroll
+          for (int k = 0; k < 3; k++) ptpMax[k] = pr[k] + Kt[k] * 0.01f;
+          uMax = ptpMax[0] / ptpMax[2];
+          vMax = ptpMax[1] / ptpMax[2];
+          const float ddx = uMax - uMin;
+          const float ddy = vMax - vMin;
+          const float d = 1.0f / sqrtf(ddx * ddx + ddy * ddy);
+          uMax = uMin + dist * ddx * d;
+          vMax = vMin + dist * ddy * d;
+          if (!(uMax > 4 && vMax > 4 && uMax < wG0 - 5 && vMax < hG0 - 5)) { finish(IPS_OOB, -1, -1, 0, true); break; }
+        }
+        if (!(idepth_min < 0 || (ptpMin[2] > 0.75 && ptpMin[2] < 1.5))) { finish(IPS_OOB, -1, -1, 0, true); break; }
+        dx = kTraceStepsize * (uMax - uMin);
+        dy = kTraceStepsize * (vMax - vMin);
+        const float a = (dx * gradH[0] + dy * gradH[2]) * dx + (dx * gradH[1] + dy * gradH[3]) * dy;
+        const float b = (dy * gradH[0] + (-dx) * gradH[2]) * dy + (dy * gradH[1] + (-dx) * gradH[3]) * (-dx);
+        errorInPixel = 0.2f + 0.2f * (a + b) / a;
+        if (errorInPixel * kTraceMinImprovement > dist && finiteMax) { finish(IPS_BADCONDITION, 0, 0, 0, false); break; }
+        if (errorInPixel > 10) errorInPixel = 10;
+        dx /= dist;
+        dy /= dist;
+        if (dist > maxPixSearch) {
+          uMax = uMin + maxPixSearch * dx;
+          vMax = vMin + maxPixSearch * dy;
+          dist = maxPixSearch;
+        }
+        numSteps = 1.9999f + dist / kTraceStepsize;
+        const float randShift = uMin * 1000 - floorf(uMin * 1000);
+        const float ptx0 = uMin - randShift * dx;
+        const float pty0 = vMin - randShift * dy;
+        if (!isfinite(dx) || !isfinite(dy)) { finish(IPS_OOB, -1, -1, 0, true); break; }
+        if (numSteps >= 100) numSteps = 99;
+        s_ptx0[t] = ptx0; s_pty0[t] = pty0; s_dx[t] = dx; s_dy[t] = dy;
+        s_steps[t] = numSteps > 0 ? numSteps : 0;
+        live = true;
+      } while (false);
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 2: discrete search, one wave per point, lane = step (ptx is the reference's running sum ptx += dx)
+  // (unrolled over the wave's points, no branch around a point that does not search — its lanes are simply inactive — so that the
+  // taps of the next point are in flight while the minimum of the current one is reduced)
+#pragma unroll
+  for (int pp = 0; pp < PTS / 4; pp++) {
+    const int pt = wv * (PTS / 4) + pp;
+    const int nsteps = s_steps[pt];
+    const float sdx = s_dx[pt], sdy = s_dy[pt], x0 = s_ptx0[pt], y0 = s_pty0[pt];
+    const float* color = T.color + (size_t)(blockIdx.x * PTS + pt) * 8;
+    float myE[2] = {1e30f, 1e30f}, myX[2] = {0, 0}, myY[2] = {0, 0};
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+      const int s = pass * 64 + lane;
+      if (s < nsteps) {
+        float ptx = x0, pty = y0;
+        for (int k = 0; k < s; k++) { ptx += sdx; pty += sdy; }
+        float energy = 0;
+#pragma unroll
+        for (int idx = 0; idx < 8; idx++) {
+          const float hitColor = interp31_plane(T.plane, (float)(ptx + (float)c_pat[idx][0]), (float)(pty + (float)c_pat[idx][1]), wG0);
+          if (!isfinite(hitColor)) { energy += 1e5; continue; }
+          const float residual = hitColor - (float)(1.0f * color[idx] + 0.0f);
+          const float hw = fabsf(residual) < kHuberTH ? 1 : kHuberTH / fabsf(residual);
+          energy += hw * residual * residual * (2 - hw);
+        }
+        myE[pass] = energy; myX[pass] = ptx; myY[pass] = pty;
+      }
+    }
+    // first minimum (the reference takes strictly smaller energies only, in step order)
+    float bE = 1e10f; int bI = -1; float bX = 0, bY = 0;
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+      const int s = pass * 64 + lane;
+      if (s < nsteps && myE[pass] < bE) { bE = myE[pass]; bI = s; bX = myX[pass]; bY = myY[pass]; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float oE = __shfl_xor(bE, o, 64); const int oI = __shfl_xor(bI, o, 64);
+      const float oX = __shfl_xor(bX, o, 64), oY = __shfl_xor(bY, o, 64);
+      const bool take = (oI >= 0) && (bI < 0 || oE < bE || (oE == bE && oI < bI));
+      if (take) { bE = oE; bI = oI; bX = oX; bY = oY; }
+    }
+    const int bestIdx = bI;
+    float secondBest = 1e10f;
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+      const int s = pass * 64 + lane;
+      if (s < nsteps && (s < bestIdx - kMinTraceTestRadius || s > bestIdx + kMinTraceTestRadius) && myE[pass] < secondBest) secondBest = myE[pass];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) secondBest = fminf(secondBest, __shfl_xor(secondBest, o, 64));
+    if (lane == 0 && nsteps > 0) { s_bE[pt] = bE; s_bI[pt] = bI; s_bX[pt] = bX; s_bY[pt] = bY; s_second[pt] = secondBest; }
+  }
+  __syncthreads();
+
+  // ---- phase 3: refinement and outputs, one lane per point
+  if (!live) return;
+  const float* color = T.color + (size_t)i * 8;
+  const float* weights = T.weights + (size_t)i * 8;
+  float bestU = s_bX[t], bestV = s_bY[t], bestEnergy = s_bE[t];
+  const int bestIdx = s_bI[t];
+  if (bestIdx < 0) { bestU = 0; bestV = 0; bestEnergy = 1e10f; }
+  const float secondBest = s_second[t];
+  const float newQuality = secondBest / bestEnergy;
+  if (newQuality < quality || numSteps > 10) quality = newQuality;
+
+  if constexpr (GN_MODE == 1) {
+    // fork-live refinement (ImmaturePoint.cpp:309-412): VertexUVDSO in double, 8 EdgeTracePointUVDSO (dso_g2o_edge.cpp:571-619) with
+    // Huber(9), one undamped g2o Gauss-Newton step per pass, update clamped by VertexUVDSO::oplusImpl (dso_g2o_vertex.cpp:73-88)
+    double U = bestU, V = bestV;
+    const double ddx = dx, ddy = dy;
+    if (kTraceGNIterations > 0) bestEnergy = 1e5;
+    for (int it = 0; it < kTraceGNIterations; it++) {
+      float energy = 0;
+      double Hs = 0, bs = 0;
+      const bool inside = !((U - 2) < 0 || (U + 3) > (wG0 - 3) || (V - 2) < 0 || (V + 3) > (hG0 - 3));
+      for (int idx = 0; idx < 8; idx++) {
+        double e = 0, J = 0;
+        if (inside) {
+          const float3 hit = interp33(dI, (float)(U + (float)c_pat[idx][0]), (float)(V + (float)c_pat[idx][1]), wG0);
+          if (isfinite(hit.x)) {
+            e = hit.x - (1.0f * (double)color[idx] + 0.0f);
+            J = ddx * hit.y + ddy * hit.z;
+          }
+        }
+        const float residual = e;
+        const float hw = fabsf(residual) < kHuberTH ? 1 : kHuberTH / fabsf(residual);
+        const float te = weights[idx] * weights[idx] * hw * residual * residual * (2 - hw);
+        const double e2 = e * e;
+        const double rho1 = e2 <= (double)kHuberTH * kHuberTH ? 1. : kHuberTH / sqrt(e2);
+        const double tb = rho1 * J * e, tH = J * rho1 * J;
+        energy += te;
+        bs -= tb;
+        Hs += tH;
+      }
+      if (Hs != 0) {
+        double update = bs / Hs;
+        if (update < -0.5) update = -0.5;
+        else if (update > 0.5) update = 0.5;
+        else if (!isfinite(update)) update = 0;
+        U += update * ddx;
+        V += update * ddy;
+      }
+      if (!(energy > bestEnergy)) bestEnergy = energy;
+    }
+    bestU = U;
+    bestV = V;
+  } else {
+    // DSO-native GN (ImmaturePoint.cpp:707-769)
+    float uBak = bestU, vBak = bestV, stepBack = 0;
+    const float gnstepsize = 1;
+    if (kTraceGNIterations > 0) bestEnergy = 1e5;
+    for (int it = 0; it < kTraceGNIterations; it++) {
+      float H = 1, bb = 0, energy = 0;
+      for (int idx = 0; idx < 8; idx++) {
+        const float3 hit = interp33(dI, (float)(bestU + (float)c_pat[idx][0]), (float)(bestV + (float)c_pat[idx][1]), wG0);
+        if (!isfinite(hit.x)) { energy += 1e5; continue; }
+        const float residual = hit.x - (1.0f * color[idx] + 0.0f);
+        const float dResdDist = dx * hit.y + dy * hit.z;
+        const float hw = fabsf(residual) < kHuberTH ? 1 : kHuberTH / fabsf(residual);
+        H += hw * dResdDist * dResdDist;
+        bb += hw * residual * dResdDist;
+        energy += weights[idx] * weights[idx] * hw * residual * residual * (2 - hw);
+      }
+      if (energy > bestEnergy) {
+        stepBack *= 0.5;
+        bestU = uBak + stepBack * dx;
+        bestV = vBak + stepBack * dy;
+      } else {
+        float step = -gnstepsize * bb / H;
+        if (step < -0.5) step = -0.5;
+        else if (step > 0.5) step = 0.5;
+        if (!isfinite(step)) step = 0;
+        uBak = bestU;
+        vBak = bestV;
+        stepBack = step;
+        bestU += step * dx;
+        bestV += step * dy;
+        bestEnergy = energy;
+      }
+      if (fabsf(stepBack) < kTraceGNThreshold) break;
+    }
+  }
+
+  if (!(bestEnergy < energyTH * kTraceExtraSlack)) {
+    finish(prevStatus == IPS_OUTLIER ? IPS_OOB : IPS_OUTLIER, -1, -1, 0, true);
+    return;
+  }
+  if (dx * dx > dy * dy) {
+    idepth_min_stereo = (pr[2] * (bestU - errorInPixel * dx) - pr[0]) / (Kt[0] - Kt[2] * (bestU - errorInPixel * dx));
+    idepth_max_stereo = (pr[2] * (bestU + errorInPixel * dx) - pr[0]) / (Kt[0] - Kt[2] * (bestU + errorInPixel * dx));
+  } else {
+    idepth_min_stereo = (pr[2] * (bestV - errorInPixel * dy) - pr[1]) / (Kt[1] - Kt[2] * (bestV - errorInPixel * dy));
+    idepth_max_stereo = (pr[2] * (bestV + errorInPixel * dy) - pr[1]) / (Kt[1] - Kt[2] * (bestV + errorInPixel * dy));
+  }
+  if (idepth_min_stereo > idepth_max_stereo) { const float tmp = idepth_min_stereo; idepth_min_stereo = idepth_max_stereo; idepth_max_stereo = tmp; }
+  T.idepth_min_stereo[i] = idepth_min_stereo; T.idepth_max_stereo[i] = idepth_max_stereo;
+  if (!isfinite(idepth_min_stereo) || !isfinite(idepth_max_stereo) || (idepth_max_stereo < 0)) { finish(IPS_OUTLIER, -1, -1, 0, true); return; }
+  T.idepth_stereo[i] = (u_stereo - bestU) / bf;
+  finish(IPS_GOOD, bestU, bestV, 2 * errorInPixel, true);
+}
+
 // ImmaturePoint::traceOn (ImmaturePoint.cpp:459-828): the same search along a general epipolar line.  geom[pgeom[i]] is the
 // hostToFrame geometry of the point's host; T.idepth_min_stereo / idepth_max_stereo hold idepth_min / idepth_max.
 __global__ __launch_bounds__(256) void k_trace_on(TraceDev T, const sdso_trace_geom_t* __restrict__ geom, const int* __restrict__ pgeom) {
@@ -696,6 +969,17 @@ extern "C" int sdso_trace_stereo_prepare(sdso_ctx* ctx, int frame_slot, const fl
 static void launch_trace_stereo(sdso_ctx* ctx, const TraceDev& T) {
   const dim3 g((T.n + 3) / 4), b(256);
   const bool band = getenv("SDSO_TRACE_BAND") != nullptr;
+  // default: the block organisation (64 points per workgroup); SDSO_TRACE_WAVE=1 (or one of the A/B variants below) selects the
+  // one-wave-per-point kernel
+  if (!band && !getenv("SDSO_TRACE_OCC") && !getenv("SDSO_TRACE_WAVE")) {
+    const char* e = getenv("SDSO_TRACE_PTS");
+    const int pts = e ? atoi(e) : 16;
+#define TB(G, P) hipLaunchKernelGGL((k_trace_stereo_blk<G, P>), dim3((T.n + P - 1) / P), b, 0, ctx->stream, T)
+    if (ctx->gn_mode == 1) { if (pts == 64) TB(1, 64); else if (pts == 32) TB(1, 32); else if (pts == 8) TB(1, 8); else TB(1, 16); }
+    else { if (pts == 64) TB(0, 64); else if (pts == 32) TB(0, 32); else if (pts == 8) TB(0, 8); else TB(0, 16); }
+#undef TB
+    return;
+  }
   if (getenv("SDSO_TRACE_OCC") && ctx->gn_mode == 0 && !band) { hipLaunchKernelGGL((k_trace_stereo<0, false, 8>), g, b, 0, ctx->stream, T); return; }
   if (ctx->gn_mode == 1) { if (band) hipLaunchKernelGGL((k_trace_stereo<1, true>), g, b, 0, ctx->stream, T); else hipLaunchKernelGGL((k_trace_stereo<1, false>), g, b, 0, ctx->stream, T); }
   else { if (band) hipLaunchKernelGGL((k_trace_stereo<0, true>), g, b, 0, ctx->stream, T); else hipLaunchKernelGGL((k_trace_stereo<0, false>), g, b, 0, ctx->stream, T); }
