@@ -254,7 +254,8 @@ __global__ __launch_bounds__(64 * ST_WAVES) void k_ba_stitch(const BaDev* __rest
     if (lane < 20) {
       const int r = lane < 16 ? lane >> 2 : lane - 16, col = lane < 16 ? (lane & 3) : 12;
       double s = 0;
-      for (int p = 0; p < nf2; p++) s += acc13(acc + (size_t)p * 91, r, col);
+#pragma unroll 16
+      for (int p = 0; p < nf2; p++) s += acc13(acc + (size_t)p * 91, r, col);      // (64 dependent round trips when not unrolled: the longest job of the kernel)
       if (lane < 16) {
         if (m == 1 && r == col) s += B.t_prior[nf * 16 + r];
         H[(size_t)r * n + col] = s;
