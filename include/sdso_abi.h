@@ -68,8 +68,16 @@ int sdso_upload_pyramid(sdso_ctx* ctx, int frame_slot, int levels, const int* w,
                         const float* const* dIp /* [levels] AoS float3, w*h*3 floats each */);
 /* FrameHessian::makeImages on the device from the level-0 irradiance image (w*h floats). */
 int sdso_make_pyramid(sdso_ctx* ctx, int frame_slot, int w, int h, const float* color);
+/* Photometric calibration for the pixel selection (setting_gammaWeightsPixelSelect == 1): absSquaredGrad of every pyramid built or
+ * uploaded after the call is multiplied by CalibHessian::getBGradOnly(I)^2 (HessianBlocks.cpp:194-198, HessianBlocks.h:356-362).
+ * B = CalibHessian::B (256 floats); NULL = identity response (weight exactly 1, the default).
+ * sdso_gamma_from_binv = FullSystem::setGammaFunction (FullSystem.cpp:210-234): B from the inverse response table. */
+int sdso_set_gamma(sdso_ctx* ctx, const float* B /* 256 or NULL */);
+int sdso_gamma_from_binv(const float* BInv /* 256 */, float* B /* 256 */);
 /* copy level `lvl` back as AoS float3 (tests) */
 int sdso_download_pyramid_level(sdso_ctx* ctx, int frame_slot, int lvl, float* dI_out);
+/* FrameHessian::absSquaredGrad[lvl] (HessianBlocks.h:109) as the device holds it: w_l*h_l floats */
+int sdso_download_abs_grad(sdso_ctx* ctx, int frame_slot, int lvl, float* out);
 int sdso_release_pyramid(sdso_ctx* ctx, int frame_slot);
 
 /* ------------------------------------------------------------------ coarse tracker

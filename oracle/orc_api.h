@@ -182,6 +182,9 @@ int orc_immature_init_batch(const float* dI, int w, int h, int n, const float* u
 int orc_pixel_select(const float* const* dIp, int w, int h, float density, int recursionsLeft, float thFactor, int* potential,
                      float* map_out);
 void orc_selector_random_pattern(int n, unsigned char* out);
+/* CalibHessian::B (256 floats) for the gamma-weighted absSquaredGrad of orc_pixel_select (HessianBlocks.cpp:194-198); NULL = identity */
+void orc_set_gamma(const float* B);
+void orc_gamma_from_binv(const float* BInv, float* B);
 
 /* EnergyFunctional::marginalizeFrame (EnergyFunctional.cpp:554-660) */
 int orc_marginalize_frame(int nf, int idx, const double* prior8, const double* delta_prior8, const double* HM_in, const double* bM_in,

@@ -170,6 +170,23 @@ struct Selector {
 }  // namespace
 
 // dIp[0..2]: AoS float3 levels 0..2 (sizes w>>l x h>>l).  potential: PixelSelector::currentPotential, in/out.
+static const float* g_gammaB = nullptr;
+static float g_gammaB_store[256];
+// CalibHessian::B for the gamma-weighted absSquaredGrad (setting_gammaWeightsPixelSelect == 1); NULL = identity response
+extern "C" void orc_set_gamma(const float* B) {
+  if (!B) { g_gammaB = nullptr; return; }
+  for (int i = 0; i < 256; i++) g_gammaB_store[i] = B[i];
+  g_gammaB = g_gammaB_store;
+}
+// FullSystem::setGammaFunction (FullSystem.cpp:210-234)
+extern "C" void orc_gamma_from_binv(const float* BInv, float* B) {
+  for (int i = 0; i < 256; i++) B[i] = 0;
+  for (int i = 1; i < 255; i++)
+    for (int s = 1; s < 255; s++)
+      if (BInv[s] <= i && BInv[s + 1] >= i) { B[i] = s + (i - BInv[s]) / (BInv[s + 1] - BInv[s]); break; }
+  B[0] = 0;
+  B[255] = 255;
+}
 extern "C" int orc_pixel_select(const float* const* dIp, int w, int h, float density, int recursionsLeft, float thFactor, int* potential,
                                 float* map_out) {
   Selector S;
@@ -182,7 +199,18 @@ extern "C" int orc_pixel_select(const float* const* dIp, int w, int h, float den
   for (int l = 0; l < 3; l++) {
     const int wl = w >> l, hl = h >> l;
     ab[l]->assign((size_t)wl * hl, 0.f);
-    for (int i = 0; i < wl * hl; i++) { const float dx = dIp[l][i * 3 + 1], dy = dIp[l][i * 3 + 2]; (*ab[l])[i] = dx * dx + dy * dy; }
+    for (int i = 0; i < wl * hl; i++) {
+      const float dx = dIp[l][i * 3 + 1], dy = dIp[l][i * 3 + 2];
+      float a = dx * dx + dy * dy;                                  // HessianBlocks.cpp:192
+      if (g_gammaB) {                                               // :194-198 with CalibHessian::getBGradOnly (HessianBlocks.h:356-362)
+        int c = dIp[l][i * 3] + 0.5f;
+        if (c < 5) c = 5;
+        if (c > 250) c = 250;
+        const float gw = g_gammaB[c + 1] - g_gammaB[c];
+        a *= gw * gw;
+      }
+      (*ab[l])[i] = a;
+    }
   }
   S.currentPotential = *potential;
   S.makeHists();

@@ -76,6 +76,10 @@ def load(fast=False):
     L.orc_ba_get_tables.argtypes = [vp, c_float_p, c_double_p, c_double_p, c_float_p]
     L.orc_immature_init_batch.argtypes = [c_float_p, C.c_int, C.c_int, C.c_int, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p]
     L.orc_pixel_select.argtypes = [C.POINTER(c_float_p), C.c_int, C.c_int, C.c_float, C.c_int, C.c_float, c_int_p, c_float_p]
+    L.orc_set_gamma.argtypes = [c_float_p]
+    L.orc_set_gamma.restype = None
+    L.orc_gamma_from_binv.argtypes = [c_float_p, c_float_p]
+    L.orc_gamma_from_binv.restype = None
     L.orc_selector_random_pattern.argtypes = [C.c_int, c_u8_p]
     L.orc_selector_random_pattern.restype = None
     L.orc_marginalize_frame.argtypes = [C.c_int, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]

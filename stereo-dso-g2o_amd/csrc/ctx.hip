@@ -25,10 +25,23 @@ int ensure_pinned(sdso_ctx* ctx, size_t bytes) {
 }  // namespace sdso
 
 // ------------------------------------------------------------------ kernels
-// AoS float3 {I,dx,dy} -> float4 {I,dx,dy,absSquaredGrad}  (absSquaredGrad = dx*dx+dy*dy, HessianBlocks.cpp:192)
-__global__ void k_expand3to4(const float* __restrict__ src, float4* __restrict__ dst, int npix) {
+// CalibHessian::getBGradOnly (HessianBlocks.h:356-362) squared: the weight of absSquaredGrad when setting_gammaWeightsPixelSelect == 1
+// (HessianBlocks.cpp:194-198).  B == nullptr: identity response, weight 1.
+__device__ __forceinline__ float abs_grad(float color, float dx, float dy, const float* __restrict__ B) {
+  float a = dx * dx + dy * dy;
+  if (B) {
+    int c = color + 0.5f;
+    if (c < 5) c = 5;
+    if (c > 250) c = 250;
+    const float gw = B[c + 1] - B[c];
+    a *= gw * gw;
+  }
+  return a;
+}
+// AoS float3 {I,dx,dy} -> float4 {I,dx,dy,absSquaredGrad}  (HessianBlocks.cpp:192-198)
+__global__ void k_expand3to4(const float* __restrict__ src, float4* __restrict__ dst, int npix, const float* __restrict__ B) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < npix) { const float dx = src[3 * i + 1], dy = src[3 * i + 2]; dst[i] = make_float4(src[3 * i], dx, dy, dx * dx + dy * dy); }
+  if (i < npix) { const float dx = src[3 * i + 1], dy = src[3 * i + 2]; dst[i] = make_float4(src[3 * i], dx, dy, abs_grad(src[3 * i], dx, dy, B)); }
 }
 __global__ void k_pack4to3(const float4* __restrict__ src, float* __restrict__ dst, int npix) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -49,7 +62,7 @@ __global__ void k_downsample(const float4* __restrict__ src, int wsrc, float4* _
   dst[x + y * wl] = make_float4(v, 0.f, 0.f, 0.f);
 }
 // HessianBlocks.cpp:182-192 — central differences on rows 1..h-2 (linear index wl .. wl*(hl-1)-1)
-__global__ void k_gradients(float4* __restrict__ img, int wl, int hl) {
+__global__ void k_gradients(float4* __restrict__ img, int wl, int hl, const float* __restrict__ B) {
   int idx = blockIdx.x * blockDim.x + threadIdx.x + wl;
   if (idx >= wl * (hl - 1)) return;
   float dx = 0.5f * (img[idx + 1].x - img[idx - 1].x);
@@ -58,7 +71,7 @@ __global__ void k_gradients(float4* __restrict__ img, int wl, int hl) {
   if (!isfinite(dy)) dy = 0;
   img[idx].y = dx;
   img[idx].z = dy;
-  img[idx].w = dx * dx + dy * dy;   // absSquaredGrad (:192); the response-gradient weight of :194-198 is 1 for the identity response
+  img[idx].w = abs_grad(img[idx].x, dx, dy, B);   // absSquaredGrad (:192) times the squared response gradient (:194-198)
 }
 
 __global__ void k_tile0(const float4* __restrict__ src, float4* __restrict__ dst, int w, int h, int T) {
@@ -133,6 +146,7 @@ extern "C" void sdso_ctx_destroy(sdso_ctx* ctx) {
   release_selector(ctx);
   release_g2o(ctx);
   release_comm(ctx);
+  if (ctx->gammaB) hipFree(ctx->gammaB);
   if (ctx->scratch) hipFree(ctx->scratch);
   if (ctx->pinned) hipHostFree(ctx->pinned);
   hipStreamDestroy(ctx->stream);
@@ -215,6 +229,29 @@ static int alloc_pyramid(sdso_ctx* ctx, int frame_slot, int levels, const int* w
   return SDSO_OK;
 }
 
+// FullSystem::setGammaFunction (FullSystem.cpp:210-234): B from the inverse response Binv (host, 256 entries each)
+extern "C" int sdso_gamma_from_binv(const float* BInv, float* B) {
+  if (!BInv || !B) return SDSO_ERR_ARG;
+  for (int i = 0; i < 256; i++) B[i] = 0;
+  for (int i = 1; i < 255; i++)
+    for (int s = 1; s < 255; s++)
+      if (BInv[s] <= i && BInv[s + 1] >= i) { B[i] = s + (i - BInv[s]) / (BInv[s + 1] - BInv[s]); break; }
+  B[0] = 0;
+  B[255] = 255;
+  return SDSO_OK;
+}
+// CalibHessian::B for the pyramids built or uploaded from now on (setting_gammaWeightsPixelSelect == 1, HessianBlocks.cpp:194-198);
+// B == NULL: identity response (the weight is exactly 1)
+extern "C" int sdso_set_gamma(sdso_ctx* ctx, const float* B) {
+  if (!ctx) return SDSO_ERR_STATE;
+  SDSO_HIP(ctx, hipSetDevice(ctx->device));
+  SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (!B) { if (ctx->gammaB) hipFree(ctx->gammaB); ctx->gammaB = nullptr; return SDSO_OK; }
+  if (!ctx->gammaB) SDSO_HIP(ctx, hipMalloc(&ctx->gammaB, 256 * sizeof(float)));
+  SDSO_HIP(ctx, hipMemcpy(ctx->gammaB, B, 256 * sizeof(float), hipMemcpyHostToDevice));
+  return SDSO_OK;
+}
+
 extern "C" int sdso_upload_pyramid(sdso_ctx* ctx, int frame_slot, int levels, const int* w, const int* h, const float* const* dIp) {
   if (!ctx) return SDSO_ERR_STATE;
   SDSO_HIP(ctx, hipSetDevice(ctx->device));
@@ -229,10 +266,29 @@ extern "C" int sdso_upload_pyramid(sdso_ctx* ctx, int frame_slot, int levels, co
   for (int l = 0; l < levels; l++) {
     int npix = w[l] * h[l];
     SDSO_HIP(ctx, hipMemcpyAsync(ctx->scratch, dIp[l], (size_t)npix * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_expand3to4, dim3((npix + 255) / 256), dim3(256), 0, ctx->stream, (const float*)ctx->scratch, P.d[l], npix);
+    hipLaunchKernelGGL(k_expand3to4, dim3((npix + 255) / 256), dim3(256), 0, ctx->stream, (const float*)ctx->scratch, P.d[l], npix, (const float*)ctx->gammaB);
     SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));  // scratch is reused by the next level / caller buffer may go away
   }
   SDSO_HIP(ctx, hipGetLastError());
+  return SDSO_OK;
+}
+
+__global__ void k_pack_w(const float4* __restrict__ src, float* __restrict__ dst, int npix) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < npix) dst[i] = src[i].w;
+}
+// FrameHessian::absSquaredGrad[lvl] as the device holds it (w_l * h_l floats)
+extern "C" int sdso_download_abs_grad(sdso_ctx* ctx, int frame_slot, int lvl, float* out) {
+  if (!ctx) return SDSO_ERR_STATE;
+  SDSO_HIP(ctx, hipSetDevice(ctx->device));
+  auto it = ctx->pyr.find(frame_slot);
+  SDSO_REQUIRE(ctx, it != ctx->pyr.end() && out && lvl >= 0 && lvl < it->second.levels, "unknown pyramid slot / level");
+  const int npix = it->second.w[lvl] * it->second.h[lvl];
+  int rc = ensure_scratch(ctx, (size_t)npix * sizeof(float));
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_pack_w, dim3((npix + 255) / 256), dim3(256), 0, ctx->stream, (const float4*)it->second.d[lvl], (float*)ctx->scratch, npix);
+  SDSO_HIP(ctx, hipMemcpyAsync(out, ctx->scratch, (size_t)npix * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return SDSO_OK;
 }
 
@@ -253,7 +309,7 @@ extern "C" int sdso_make_pyramid(sdso_ctx* ctx, int frame_slot, int w, int h, co
   for (int l = 0; l < levels; l++) {
     if (l > 0) hipLaunchKernelGGL(k_downsample, dim3((ws[l] + 255) / 256, hs[l]), dim3(256), 0, ctx->stream, P.d[l - 1], ws[l - 1], P.d[l], ws[l], hs[l]);
     int ng = ws[l] * (hs[l] - 2);
-    hipLaunchKernelGGL(k_gradients, dim3((ng + 255) / 256), dim3(256), 0, ctx->stream, P.d[l], ws[l], hs[l]);
+    hipLaunchKernelGGL(k_gradients, dim3((ng + 255) / 256), dim3(256), 0, ctx->stream, P.d[l], ws[l], hs[l], (const float*)ctx->gammaB);
   }
   SDSO_HIP(ctx, hipGetLastError());
   SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));

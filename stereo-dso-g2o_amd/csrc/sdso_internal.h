@@ -66,6 +66,7 @@ struct sdso_ctx {
   size_t pinned_bytes = 0;
   int n_cu = 256;
   int gn_mode = 0;   // traceStereo refinement: 0 DSO-native, 1 fork-live g2o GN (sdso_trace_set_gn_mode)
+  float* gammaB = nullptr;   // device copy of CalibHessian::B (256 floats) for the gamma-weighted absSquaredGrad; null = identity response
   // device buffers of released BA windows, kept for the next upload (a window is re-uploaded for every keyframe)
   std::vector<std::pair<void*, size_t>> ba_pool;
   // optional in-library kernel timing (HIP events on ctx->stream), see sdso_prof_*

@@ -235,7 +235,10 @@ def load():
     L.sdso_pyramid_levels.argtypes = [C.c_int, C.c_int]
     L.sdso_upload_pyramid.argtypes = [vp, C.c_int, C.c_int, c_int_p, c_int_p, C.POINTER(c_float_p)]
     L.sdso_make_pyramid.argtypes = [vp, C.c_int, C.c_int, C.c_int, c_float_p]
+    L.sdso_set_gamma.argtypes = [vp, c_float_p]
+    L.sdso_gamma_from_binv.argtypes = [c_float_p, c_float_p]
     L.sdso_download_pyramid_level.argtypes = [vp, C.c_int, C.c_int, c_float_p]
+    L.sdso_download_abs_grad.argtypes = [vp, C.c_int, C.c_int, c_float_p]
     L.sdso_release_pyramid.argtypes = [vp, C.c_int]
     L.sdso_track_set_ref.argtypes = [vp, C.c_int, C.c_int, C.c_int, c_float_p, c_float_p, c_float_p, c_float_p]
     L.sdso_track_release_ref.argtypes = [vp, C.c_int]
@@ -312,7 +315,7 @@ def load():
 EXPORTED_SYMBOLS = [
     "sdso_ctx_create", "sdso_ctx_destroy", "sdso_last_error", "sdso_ctx_stream", "sdso_ctx_sync",
     "sdso_prof_enable", "sdso_prof_reset", "sdso_prof_read",
-    "sdso_pyramid_levels", "sdso_upload_pyramid", "sdso_make_pyramid", "sdso_download_pyramid_level",
+    "sdso_pyramid_levels", "sdso_upload_pyramid", "sdso_make_pyramid", "sdso_set_gamma", "sdso_gamma_from_binv", "sdso_download_pyramid_level", "sdso_download_abs_grad",
     "sdso_release_pyramid", "sdso_track_set_ref", "sdso_track_release_ref", "sdso_track_make_eval",
     "sdso_track_calc_res_gs", "sdso_track_calc_res_gs_batch", "sdso_track_batch_prepare",
     "sdso_track_batch_enqueue", "sdso_track_batch_fetch", "sdso_track_newest_coarse",

@@ -136,6 +136,31 @@ class Scene:
 
 
 # ------------------------------------------------------------------ pyramid (makeImages rule)
+def abs_squared_grad(d, B=None):
+    """absSquaredGrad of one level d = [h, w, 3] {I, dx, dy} (HessianBlocks.cpp:192), times CalibHessian::getBGradOnly(I)^2 when a
+    response table B (256 floats) is given (:194-198, HessianBlocks.h:356-362).  float32 arithmetic in the reference's order."""
+    a = (d[..., 1] * d[..., 1] + d[..., 2] * d[..., 2]).astype(np.float32)
+    if B is not None:
+        B = np.asarray(B, np.float32)
+        c = np.clip((d[..., 0] + np.float32(0.5)).astype(np.int32), 5, 250)
+        gw = (B[c + 1] - B[c]).astype(np.float32)
+        a = (a * (gw * gw).astype(np.float32)).astype(np.float32)
+    return a
+
+
+def gamma_from_binv(BInv):
+    """FullSystem::setGammaFunction (FullSystem.cpp:210-234): CalibHessian::B from the inverse response, float32 like the reference."""
+    BInv = np.asarray(BInv, np.float32)
+    B = np.zeros(256, np.float32)
+    for i in range(1, 255):
+        for s in range(1, 255):
+            if BInv[s] <= i and BInv[s + 1] >= i:
+                B[i] = np.float32(s) + (np.float32(i) - BInv[s]) / (BInv[s + 1] - BInv[s])
+                break
+    B[0], B[255] = 0, 255
+    return B
+
+
 def make_pyramid(color, levels=None):
     """color: float32 [h,w].  Returns list of AoS arrays [h_l, w_l, 3] float32 = {I, dx, dy}."""
     h, w = color.shape
