@@ -856,7 +856,7 @@ __global__ __launch_bounds__(LM_BLOCK) void k_track_lm(LmJob* __restrict__ jobs)
   __shared__ int I[TRK_NI];
   __shared__ int s_lvl, s_flags[3];
   __shared__ TrackOut O;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int tid = threadIdx.x, wv = tid >> 6;
   if (tid == 0) {
     core.init(J.p, J.T, J.aff);
     s_flags[2] = 0;
