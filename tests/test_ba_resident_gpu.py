@@ -177,3 +177,60 @@ def test_resident_loop_refuses_gated_windows(gpu_ctx):
     assert gpu_ctx.L.sdso_ba_batch_optimize_begin(gpu_ctx.h, 1) != 0
     assert b"forceAceptStep" in gpu_ctx.L.sdso_last_error(gpu_ctx.h)
     gpu_ctx.check(gpu_ctx.L.sdso_ba_release_window(gpu_ctx.h, 70))
+
+
+def test_resident_loop_degenerate_windows(gpu_ctx, oracle, monkeypatch):
+    """Window shapes at the edge — two keyframes (mnumOptIts becomes 15), a keyframe that hosts no point, points without residuals, no
+    points at all (the quantile falls back to 12*12*8, the break test divides 0 by 0 like the reference) — through the device loop:
+    same iteration counts as the oracle and as the library's host loop, nothing faults."""
+    def strip(win, keep_pts=None, drop_res=None, empty=False):
+        win = dict(win)
+        if keep_pts is not None:
+            idx = np.nonzero(keep_pts)[0]
+            remap = -np.ones(win["np"], np.int64); remap[idx] = np.arange(len(idx))
+            rk = keep_pts[win["res_point"]]
+            for k in ("u", "v", "idepth", "idepth_zero", "color", "weights", "host", "hasDepthPrior"):
+                win[k] = win[k][idx]
+            win["res_point"] = remap[win["res_point"][rk]].astype(np.int32); win["res_target"] = win["res_target"][rk]; win["res_state"] = win["res_state"][rk]
+            win["np"], win["nr"] = len(idx), int(rk.sum())
+        if drop_res is not None:
+            for k in ("res_point", "res_target", "res_state"):
+                win[k] = win[k][~drop_res]
+            win["nr"] = int((~drop_res).sum())
+        if empty:
+            for k in ("u", "v", "idepth", "idepth_zero", "host", "hasDepthPrior", "color", "weights", "res_point", "res_target", "res_state"):
+                win[k] = win[k][:0]
+            win["np"] = win["nr"] = 0
+        return win
+    w2 = synth.ba_window(w=320, h=240, nf=2, pts_per_kf=40, seed=3071)
+    w3 = synth.ba_window(w=320, h=240, nf=4, pts_per_kf=30, seed=3072)
+    w4 = synth.ba_window(w=320, h=240, nf=4, pts_per_kf=30, seed=3073)
+    cases = [("nf2", w2), ("empty_host", strip(w3, keep_pts=w3["host"] != 1)),
+             ("points_without_residuals", strip(w4, drop_res=np.isin(w4["res_point"], np.arange(0, w4["np"], 3)))),
+             ("no_points", strip(w2, empty=True))]
+    for k, (name, win) in enumerate(cases):
+        nf, npts, nr = win["nf"], win["np"], win["nr"]
+        so, io, ro, oo = _oracle_opt(oracle, win, 6)
+        for f in range(nf):
+            gpu_ctx.upload_pyramid(580 + f, win["pyrs"][f][:1])
+        W, keep = abi.make_ba_window(win, frame_slots=[580 + f for f in range(nf)])
+        res = {}
+        for host in (0, 1):
+            if host:
+                monkeypatch.setenv("SDSO_BA_HOST_LOOP", "1")
+            else:
+                monkeypatch.delenv("SDSO_BA_HOST_LOOP", raising=False)
+            gpu_ctx.check(gpu_ctx.L.sdso_ba_upload_window(gpu_ctx.h, 75, C.byref(W)))
+            s, i, r, o = np.zeros((nf, 10)), np.zeros(max(npts, 1), np.float32), np.zeros(max(nr, 1), np.uint8), abi.BAOptResult()
+            gpu_ctx.check(gpu_ctx.L.sdso_ba_optimize(gpu_ctx.h, 75, 6, abi.dp(s), abi.fp(i), abi.bp(r), C.byref(o)))
+            res[host] = (s, i[:npts], r[:nr], o.iterations, o.resInA)
+        monkeypatch.delenv("SDSO_BA_HOST_LOOP", raising=False)
+        gpu_ctx.check(gpu_ctx.L.sdso_ba_release_window(gpu_ctx.h, 75))
+        assert res[0][3] == res[1][3] == oo.iterations, name
+        assert res[0][4] == res[1][4] == oo.resInA, name
+        assert np.isfinite(res[0][0]).all() and np.abs(res[0][0] - res[1][0]).max() <= 2e-6, name
+        assert np.abs(res[0][0] - so).max() <= 2e-4, name
+        if npts:
+            assert np.abs(res[0][1] - res[1][1]).max() <= 2e-5 and np.abs(res[0][1] - io).max() <= 2e-4, name
+        if nr:
+            assert (res[0][2] != ro).sum() <= 2, name
