@@ -320,9 +320,11 @@ int sdso_ba_batch_get_x(sdso_ctx* ctx, double* x /* nwin*(8nf+4) */);
 /* FullSystem::optimize (FullSystemOptimize.cpp:871-1041, DSO-native loop) for EVERY window of the batch, device-resident: the host
  * logic between the kernel phases — backupState / doStepFromBackup (:207-351), FrameHessian::setState, setPrecalcValues
  * (HessianBlocks.cpp:206-242), setDeltaF (EnergyFunctional.cpp:173-207), setNewFrameEnergyTH (:98-139), the break test — runs in one
- * workgroup per window (k_ba_opt_step), so a whole loop is enqueued without a host round trip.  This is the accepted-step flow
- * (setting_forceAceptStep = true, the reference's default, settings.cpp:53); windows with forceAcceptStep = 0 are refused here and go
- * through sdso_ba_optimize's host loop.
+ * workgroup per window (k_ba_opt_step), so a whole loop is enqueued without a host round trip.  The accepted-step flow
+ * (setting_forceAceptStep = true, the reference's default, settings.cpp:53) runs through the fused linearise+accumulate kernel; with
+ * forceAcceptStep = 0 the energy gate of :961-990 (calcLEnergy, calcMEnergy, accept or loadSateBackup + re-linearisation, lambda * 0.25 /
+ * * 100) is taken on the device too (k_ba_opt_gate; single rank, sdso_ba_batch_optimize only).  The members of a batch share
+ * forceAcceptStep.
  *   sdso_ba_batch_optimize       : the whole loop with the reference's lambda (1e-1 * 0.25^it, subject to solverMode) and
  *                                  orthogonalisation schedule; out[nwin].  With a communicator on ctx (points sharded over ranks) every
  *                                  iteration all-reduces the accumulators and all-gathers the newest-frame energies / break-test sums, so

@@ -988,10 +988,11 @@ extern "C" int sdso_ba_optimize(sdso_ctx* ctx, int win, int mnumOptIts, double* 
   const int nf = W->d.nf, np = W->d.np, nr = W->d.nr;
   sdso_ba_opt_result_t res{0, 0, 0, 0};
   BaLaunch L = single(W);
-  // setting_forceAceptStep (the reference's default): every step is taken, the whole loop runs on the device (ba_opt.hip) without a
-  // host round trip; the energy-gated flow keeps the host loop below.  SDSO_BA_HOST_LOOP=1 forces the host loop (A/B).
+  // The whole loop runs on the device (ba_opt.hip) without a host round trip: the accepted-step flow (setting_forceAceptStep, the
+  // reference's default) through the fused kernel, the energy-gated flow through the un-fused ones with the decision taken by
+  // k_ba_opt_gate.  The SVD / orthogonalised-system solver modes and SDSO_BA_HOST_LOOP=1 (A/B) take the host loop below.
   const bool host_loop = getenv("SDSO_BA_HOST_LOOP") != nullptr;   // read per call: tests flip it
-  if (nf >= 2 && W->forceAccept && !host_loop && (W->solverMode & (SOLVER_SVD | SOLVER_ORTHOGONALIZE_SYSTEM)) == 0) {
+  if (nf >= 2 && !host_loop && (W->solverMode & (SOLVER_SVD | SOLVER_ORTHOGONALIZE_SYSTEM)) == 0) {
     int rc = optimize_resident_single(ctx, W, mnumOptIts, &res);
     if (rc) return rc;
   } else if (nf >= 2) {
@@ -1343,12 +1344,13 @@ struct OptBufs {
   float* d_pack = nullptr; size_t pack_cap = 0;
   float* d_gather = nullptr; size_t gather_cap = 0;
   BaOptOut* d_out = nullptr; BaOptOut* h_out = nullptr; size_t out_cap = 0;
+  float* d_lpart = nullptr; size_t lpart_cap = 0;
 };
 static std::map<sdso_ctx*, OptBufs*> g_optbufs;
 void free_optbufs(sdso_ctx* ctx) {
   OptBufs* b = nullptr;
   if (!reg_take(g_optbufs, ctx, b) || !b) return;
-  hipFree(b->d_sums); hipFree(b->d_pack); hipFree(b->d_gather); hipFree(b->d_out);
+  hipFree(b->d_sums); hipFree(b->d_pack); hipFree(b->d_gather); hipFree(b->d_out); hipFree(b->d_lpart);
   if (b->h_out) hipHostFree(b->h_out);
   delete b;
 }
@@ -1368,6 +1370,8 @@ struct OptRun {
   bool materialize = true; int gather = 1;
   int cap = 0, nranks = 1, sums_stride = 0, iteration = 0, stop = 1;
   bool exchange = false;   // pack + all-gather between the ranks (always when nranks > 1)
+  bool gated = false;      // energy-gated flow (setting_forceAceptStep = false): un-fused kernels + k_ba_opt_gate
+  int lstride = 0;         // floats between the windows' calcLEnergy partials
   bool active = false;
   OptBufs* B = nullptr;
 };
@@ -1377,13 +1381,15 @@ static int opt_begin(sdso_ctx* ctx, OptRun& R, int stop_on_convergence) {
   SDSO_REQUIRE(ctx, nf >= 2, "the Gauss-Newton loop needs at least two keyframes (FullSystemOptimize.cpp:873)");
   int cap = 1;
   for (BaWindowDev* W : R.W) {
-    SDSO_REQUIRE(ctx, W->forceAccept, "the device-resident loop is the accepted-step flow (setting_forceAceptStep); energy-gated windows go through sdso_ba_optimize");
+    SDSO_REQUIRE(ctx, (W->forceAccept != 0) == (R.W[0]->forceAccept != 0), "the windows of a resident loop must share setting_forceAceptStep");
     SDSO_REQUIRE(ctx, (W->solverMode & (SOLVER_SVD | SOLVER_ORTHOGONALIZE_SYSTEM)) == 0, "SOLVER_SVD / SOLVER_ORTHOGONALIZE_SYSTEM windows are optimised through the host loop");
     cap = std::max(cap, W->d.nr - W->newest_first);
   }
   R.nranks = comm_nranks(ctx);
   // SDSO_OPT_FORCE_EXCHANGE: take the pack / all-gather path on a 1-rank communicator too (tests: the collectives of a 1-GPU box)
   R.exchange = R.nranks > 1 || (comm_present(ctx) && getenv("SDSO_OPT_FORCE_EXCHANGE") != nullptr);
+  R.gated = !R.W[0]->forceAccept;
+  SDSO_REQUIRE(ctx, !(R.gated && R.exchange), "the energy-gated loop over sharded windows is not provided (forceAceptStep = true is; the energies would need one more exchange)");
   if (R.exchange) { int rc = comm_max_int(ctx, &cap); if (rc) return rc; }
   R.cap = cap;
   R.sums_stride = 2 * (R.L.max_nblk_pts + 1);
@@ -1395,6 +1401,8 @@ static int opt_begin(sdso_ctx* ctx, OptRun& R, int stop_on_convergence) {
   if ((rc = grow(ctx, B->d_sums, B->sums_cap, (size_t)nwin * R.sums_stride))) return rc;
   if ((rc = grow(ctx, B->d_pack, B->pack_cap, (size_t)nwin * pf))) return rc;
   if (R.exchange && (rc = grow(ctx, B->d_gather, B->gather_cap, (size_t)R.nranks * nwin * pf))) return rc;
+  R.lstride = R.L.max_chunks + R.L.max_nblk_pts + 1;
+  if (R.gated && (rc = grow(ctx, B->d_lpart, B->lpart_cap, (size_t)nwin * R.lstride))) return rc;
   if ((size_t)nwin > B->out_cap) {
     SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
     hipFree(B->d_out); if (B->h_out) hipHostFree(B->h_out);
@@ -1415,6 +1423,7 @@ static int opt_begin(sdso_ctx* ctx, OptRun& R, int stop_on_convergence) {
     }
     for (int i = 0; i < 4; i++) { O.calib_value[i] = W->calib.value[i]; O.calib_backup[i] = W->calib.value[i]; O.calib_zero[i] = W->calib.value_zero[i]; }
     O.newest_first = W->newest_first;
+    O.lambda = 1e-1;
     H2D(W->d_opt, &W->h_opt, sizeof(BaOptDev));
   }
   hipLaunchKernelGGL(k_ba_reset_all, dim3(R.L.max_nblk_res, nwin), dim3(BA_BLOCK), 0, ctx->stream, R.L.d_arr);
@@ -1449,6 +1458,48 @@ static int opt_step(sdso_ctx* ctx, OptRun& R) {
   return rc;
 }
 
+// ---- energy-gated flow (setting_forceAceptStep = false): the un-fused kernels, with the decision taken by k_ba_opt_gate on the device and
+// the kernels of the two branches (applyRes / loadSateBackup + re-linearisation) launched unconditionally, each looking at the decision
+static void gated_linearize(sdso_ctx* ctx, OptRun& R, int cond, int which) {
+  const int nwin = (int)R.W.size();
+  const dim3 g(R.L.max_nblk_res, nwin), b(BA_BLOCK);
+  if (R.L.tiled) hipLaunchKernelGGL(k_ba_linearize<true>, g, b, 0, ctx->stream, R.L.d_arr, cond);
+  else hipLaunchKernelGGL(k_ba_linearize<false>, g, b, 0, ctx->stream, R.L.d_arr, cond);
+  const int nblk = R.L.max_chunks + R.L.max_nblk_pts;
+  if (nblk > 0) hipLaunchKernelGGL(k_ba_lenergy, dim3(nblk, nwin), b, 0, ctx->stream, R.L.d_arr, R.B->d_lpart, R.lstride, cond);
+  hipLaunchKernelGGL(k_ba_opt_gate, dim3(1, nwin), dim3(256), 0, ctx->stream, R.L.d_arr, (const float*)R.B->d_lpart, R.lstride, which, R.stop);
+}
+static int opt_gated_start(sdso_ctx* ctx, OptRun& R) {   // linearizeAll(false) + the energies of the uploaded state + applyRes (:894-908)
+  const int nwin = (int)R.W.size();
+  gated_linearize(ctx, R, 0, 0);
+  hipLaunchKernelGGL(k_ba_apply, dim3(R.L.max_nblk_res, nwin), dim3(BA_BLOCK), 0, ctx->stream, R.L.d_arr, 0);
+  SDSO_HIP(ctx, hipGetLastError());
+  return SDSO_OK;
+}
+static int opt_gated_iteration(sdso_ctx* ctx, OptRun& R, int it) {
+  const int nwin = (int)R.W.size();
+  const dim3 gp(std::max(R.L.max_nblk_pts, 1), nwin), b(BA_BLOCK);
+  if (R.L.max_nblk_pts) hipLaunchKernelGGL(k_ba_points_op, gp, b, 0, ctx->stream, R.L.d_arr, 0, 0.f, (float*)nullptr, 0, 0);   // backupState
+  launch_accumulate(ctx, R.L, nullptr, false);
+  const int sm = R.W[0]->solverMode;
+  double lambda = 0;
+  int flags = ((sm & SOLVER_ORTHOGONALIZE_X) || (it >= 2 && (sm & SOLVER_ORTHOGONALIZE_X_LATER))) ? 1 : 0;
+  if (sm & SOLVER_FIX_LAMBDA) lambda = 1e-5;
+  else if (sm & SOLVER_USE_GN) lambda = 0;
+  else flags |= 2;                                             // the loop's own lambda, kept on the device (it depends on the decisions)
+  launch_solve(ctx, R.L, lambda, flags);
+  if (R.L.max_nblk_pts) hipLaunchKernelGGL(k_ba_points_op, gp, b, 0, ctx->stream, R.L.d_arr, 1, 1.0f, R.B->d_sums, R.sums_stride, 0);
+  hipLaunchKernelGGL(k_ba_opt_step, dim3(1, nwin), dim3(256), 0, ctx->stream, R.L.d_arr, (const float*)nullptr, 1, R.cap, it, 2, R.stop, 1.0f, 1,
+                     R.L.max_nblk_pts ? (const float*)R.B->d_sums : (const float*)nullptr, R.sums_stride);
+  gated_linearize(ctx, R, 0, 1);                               // trial linearisation, energies, decision
+  hipLaunchKernelGGL(k_ba_apply, dim3(R.L.max_nblk_res, nwin), b, 0, ctx->stream, R.L.d_arr, 1);                                  // accepted: applyRes
+  if (R.L.max_nblk_pts) hipLaunchKernelGGL(k_ba_points_op, gp, b, 0, ctx->stream, R.L.d_arr, 2, 0.f, (float*)nullptr, 0, 2);   // rejected: the points go back,
+  gated_linearize(ctx, R, 2, 2);                               //           the restored state is linearised again and its energies kept
+  SDSO_HIP(ctx, hipGetLastError());
+  R.iteration++;
+  return SDSO_OK;
+}
+
 static int opt_collect(sdso_ctx* ctx, OptRun& R) {
   const int nwin = (int)R.W.size();
   hipLaunchKernelGGL(k_ba_opt_release, dim3(nwin), dim3(128), 0, ctx->stream, R.L.d_arr, R.B->d_out);
@@ -1461,9 +1512,11 @@ static int opt_collect(sdso_ctx* ctx, OptRun& R) {
 // mirrors up to date, newest frame's setEvalPT, linearizeAll(true)
 static int opt_finish(sdso_ctx* ctx, OptRun& R, sdso_ba_opt_result_t* out) {
   const int nwin = (int)R.W.size(), nf = R.L.nf;
-  launch_fused(ctx, R.L, R.materialize, R.gather, 1);
-  int rc = opt_consume(ctx, R, 1, false, false);
-  if (rc) return rc;
+  int rc = SDSO_OK;
+  if (!R.gated) {   // (the gated loop leaves every window linearised at its final state)
+    launch_fused(ctx, R.L, R.materialize, R.gather, 1);
+    if ((rc = opt_consume(ctx, R, 1, false, false))) return rc;
+  }
   if ((rc = opt_collect(ctx, R))) return rc;
   std::vector<int> its(nwin), resInA(nwin);
   // host mirrors + the tables at the final state: CPU-only per window (numeric nullspaces, adjoints, the gauge projector), spread
@@ -1551,6 +1604,11 @@ int optimize_resident_single(sdso_ctx* ctx, BaWindowDev* W, int mnumOptIts, sdso
   if (R.nranks > 1) return sdso::fail(ctx, SDSO_ERR_STATE, "sdso_ba_optimize is a single-rank call; sharded windows use sdso_ba_batch_optimize");
   R.exchange = false;
   const int N = opt_iterations(W->d.nf, mnumOptIts);
+  if (R.gated) {
+    if ((rc = opt_gated_start(ctx, R))) return rc;
+    for (int it = 0; it < N; it++) if ((rc = opt_gated_iteration(ctx, R, it))) return rc;
+    return opt_finish(ctx, R, res);
+  }
   for (int it = 0; it < N; it++) {
     if ((rc = opt_solve_phase(ctx, R, it))) return rc;
     if ((rc = opt_step(ctx, R))) return rc;
@@ -1585,6 +1643,7 @@ extern "C" int sdso_ba_batch_step(sdso_ctx* ctx) {
   if (!ctx || !reg_has(g_optruns, ctx)) return sdso::fail(ctx, SDSO_ERR_STATE, "sdso_ba_batch_optimize_begin first");
   OptRun* R = reg_get(g_optruns, ctx);
   SDSO_REQUIRE(ctx, get_batch(ctx) && get_batch(ctx)->W == R->W, "the batch changed since sdso_ba_batch_optimize_begin");
+  SDSO_REQUIRE(ctx, !R->gated, "sdso_ba_batch_step drives the accepted-step flow; energy-gated windows run through sdso_ba_batch_optimize");
   return opt_step(ctx, *R);
 }
 extern "C" int sdso_ba_batch_optimize_end(sdso_ctx* ctx, sdso_ba_opt_result_t* out) {
@@ -1601,6 +1660,11 @@ extern "C" int sdso_ba_batch_optimize(sdso_ctx* ctx, int mnumOptIts, sdso_ba_opt
   if (rc) return rc;
   OptRun* R = reg_get(g_optruns, ctx);
   const int N = opt_iterations(R->L.nf, mnumOptIts);
+  if (R->gated) {
+    if ((rc = opt_gated_start(ctx, *R))) { free_optrun(ctx); return rc; }
+    for (int it = 0; it < N; it++) if ((rc = opt_gated_iteration(ctx, *R, it))) { free_optrun(ctx); return rc; }
+    return sdso_ba_batch_optimize_end(ctx, out);
+  }
   for (int it = 0; it < N; it++) {
     if ((rc = opt_solve_phase(ctx, *R, it)) || (rc = opt_step(ctx, *R))) { free_optrun(ctx); return rc; }
   }

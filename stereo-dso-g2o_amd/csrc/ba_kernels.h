@@ -40,6 +40,14 @@ struct BaOptDev {
   int phase;                     // 0 running; 1 the break test fired: the linearisation at the final state is still to be consumed; 2 finished
   int resInA;                    // nres[0] of the latest accumulate
   int newest_first;              // first (pair-sorted) residual whose target is the newest frame; they run to nr
+  // ---- energy-gated flow (setting_forceAceptStep = false, FullSystemOptimize.cpp:969-990)
+  double lastEnergyL, lastEnergyM;   // calcLEnergy / calcMEnergy of the accepted state
+  double lambda;                     // the loop's lambda: *0.25 on an accepted step, *100 on a rejected one
+  int gate;                          // decision of the current iteration (k_ba_opt_gate): 1 accepted, 2 rejected; read by the conditional kernels
+  int canbreak;                      // doStepFromBackup's return value of the current iteration
+  // what loadSateBackup + setPrecalcValues restore on a rejected step
+  float bk_precalc[64 * 27], bk_adHTdelta[64 * 8], bk_cdelta[4], bk_calib[6];
+  double bk_prior[8 * 16 + 4 + 8 * 8 + 4];
 };
 
 struct BaDev {
@@ -97,6 +105,8 @@ struct BaDev {
 // the remaining iterations of a batch skip a window whose resident GN loop has ended
 __device__ __forceinline__ bool ba_finished(const BaDev& B) { return B.finished >= 1; }       // accumulate / solve / step kernels
 __device__ __forceinline__ bool ba_finished_lin(const BaDev& B) { return B.finished >= 2; }   // the linearisation runs once more
+// conditional kernels of the energy-gated loop: cond = 0 always, 1 only when the step was accepted, 2 only when it was rejected
+__device__ __forceinline__ bool ba_gate_skip(const BaDev& B, int cond) { return cond != 0 && (ba_finished_lin(B) || B.opt->gate != cond); }
 
 __host__ __device__ inline int sc_part_floats(int nf) { return nf * nf * 64 + nf * 32 + nf * 8 + 16 + 4; }
 __host__ __device__ inline size_t acc_off_topA(int nf) { return 0; }

@@ -503,8 +503,9 @@ __device__ __forceinline__ void dm_read_taps(const float* slot_lane, te_f4& p00,
 #undef SETQ
 
 template <bool TILED>
-__global__ __launch_bounds__(BA_BLOCK) void k_ba_linearize(const BaDev* __restrict__ wins) {
+__global__ __launch_bounds__(BA_BLOCK) void k_ba_linearize(const BaDev* __restrict__ wins, int cond = 0) {
   const BaDev& B = wins[blockIdx.y];
+  if (ba_finished_lin(B) || ba_gate_skip(B, cond)) return;   // (a window whose resident loop has ended is left alone)
   if ((int)(blockIdx.x * BA_BLOCK) >= B.nr) return;
   __shared__ double lds[BA_BLOCK / 64];
   const int i = blockIdx.x * BA_BLOCK + threadIdx.x;
@@ -517,8 +518,9 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_linearize(const BaDev* __restri
 
 // ------------------------------------------------------------------ applyRes(true) + takeDataF
 // only_points: when non-null, restrict to residuals of flagged points (flagPointsForRemoval path)
-__global__ __launch_bounds__(BA_BLOCK) void k_ba_apply(const BaDev* __restrict__ wins) {
+__global__ __launch_bounds__(BA_BLOCK) void k_ba_apply(const BaDev* __restrict__ wins, int cond = 0) {
   const BaDev& B = wins[blockIdx.y];
+  if (ba_gate_skip(B, cond)) return;
   const int i = blockIdx.x * BA_BLOCK + threadIdx.x;
   if (i >= B.nr) return;
   float* rec = B.r_rec + ((size_t)B.r_point[i] * B.nf + B.r_target[i]) * 16;
@@ -1142,8 +1144,12 @@ __global__ __launch_bounds__(BA_BLOCK, 3) void k_ba_lin_dma(const BaDev* __restr
 // ------------------------------------------------------------------ linearised energy (EnergyFunctional::calcLEnergyPt, EnergyFunctional.cpp:354-417)
 // sum over linearized & active residuals of (2*res_toZeroF + J*delta) * J*delta, plus deltaF^2 * priorF per point.
 // grid.x = nchunks (one (host,target) pair each: adHTdeltaF is uniform) + point blocks; one float partial per workgroup.
-__global__ __launch_bounds__(BA_BLOCK) void k_ba_lenergy(const BaDev* __restrict__ wins, float* __restrict__ out) {
+__global__ __launch_bounds__(BA_BLOCK) void k_ba_lenergy(const BaDev* __restrict__ wins, float* __restrict__ out, int out_stride = 0 /* floats between the windows' partials */,
+                                                         int cond = 0) {
   const BaDev& B = wins[blockIdx.y];
+  if (ba_finished_lin(B) || ba_gate_skip(B, cond)) return;
+  if ((int)blockIdx.x >= B.nchunks + (B.np + BA_BLOCK - 1) / BA_BLOCK) return;
+  out += (size_t)blockIdx.y * out_stride;
   float e = 0.f;
   if ((int)blockIdx.x < B.nchunks) {
     const int4 ch = B.chunks[blockIdx.x];

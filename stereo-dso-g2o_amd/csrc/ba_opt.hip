@@ -103,7 +103,9 @@ __device__ inline float opt_select(const OptEnergies& v, int k, unsigned* hist /
 //   last == 0:  consume the energies of the linearisation at the current state (lastEnergy, setNewFrameEnergyTH), take the step the
 //               solver left in sol (backupState + doStepFromBackup for frames and calibration; the points were stepped by
 //               k_ba_points_op), rebuild the tables (setPrecalcValues + setDeltaF), evaluate the break test.
-//   last != 0 or the break test fired in the previous call: consume the energies only, then mark the window finished.
+//   last == 1 or the break test fired in the previous call: consume the energies only, then mark the window finished.
+//   last == 2 (energy-gated flow): the step only — the energies of the trial linearisation are consumed by k_ba_opt_gate afterwards;
+//               the tables and calibration scalars of the current state are kept for loadSateBackup, the break test is only recorded.
 __global__ __launch_bounds__(256) void k_ba_opt_step(const BaDev* __restrict__ wins, const float* __restrict__ gathered, int nranks, int cap, int iteration, int last,
                                                      int stop_on_convergence, float stepsize, int unfused_parts, const float* __restrict__ sums, int sums_stride) {
   BaDev& Bw = const_cast<BaDev&>(wins[blockIdx.y]);   // written: calibration scalars, finished
@@ -193,7 +195,8 @@ __global__ __launch_bounds__(256) void k_ba_opt_step(const BaDev* __restrict__ w
     th = th * th;
     th *= 1.0f * 1.0f;
   }
-  if (tid == 0) {
+  const bool gated = last == 2;
+  if (tid == 0 && !gated) {
     B.t_frameTH[nf - 1] = th;
     O.frameTH_new = th;
     double e = 0;
@@ -201,9 +204,17 @@ __global__ __launch_bounds__(256) void k_ba_opt_step(const BaDev* __restrict__ w
     else e = (s_esum[0] + s_esum[1]) + (s_esum[2] + s_esum[3]);
     O.lastEnergy = e;
   }
-  if (phase == 1 || last) {
+  if (!gated && (phase == 1 || last)) {
     if (tid == 0) { O.phase = 2; Bw.finished = 2; }
     return;
+  }
+  if (gated) {   // what a rejected step puts back (loadSateBackup + setPrecalcValues, FullSystemOptimize.cpp:355-370)
+    for (int e = tid; e < nf * nf * 27; e += 256) O.bk_precalc[e] = B.t_precalc[e];
+    for (int e = tid; e < nf * nf * 8; e += 256) O.bk_adHTdelta[e] = B.t_adHTdelta[e];
+    for (int e = tid; e < nf * 16 + 8 + nf * 8; e += 256) O.bk_prior[e] = B.t_prior[e];
+    if (tid < 4) O.bk_cdelta[tid] = B.t_cdelta[tid];
+    if (tid == 0) { O.bk_calib[0] = B.fxl; O.bk_calib[1] = B.fyl; O.bk_calib[2] = B.cxl; O.bk_calib[3] = B.cyl; O.bk_calib[4] = B.fxli; O.bk_calib[5] = B.fyli; }
+    __syncthreads();
   }
 
   // ---- backupState + doStepFromBackup: frames on threads 0..nf-1, the calibration on thread 64
@@ -324,8 +335,100 @@ __global__ __launch_bounds__(256) void k_ba_opt_step(const BaDev* __restrict__ w
     const bool canbreak = sqrtf(sumA) < 0.0005 * 1.2f && sqrtf(sumB) < 0.00005 * 1.2f && sqrtf(sumR) < 0.00005 * 1.2f && sqrtf(sumT) * sumNID < 0.00005 * 1.2f;
     O.iterations = p_its + 1;
     O.resInA = (int)p_nres;
-    if (stop_on_convergence && canbreak && iteration >= 1) { O.phase = 1; Bw.finished = 1; }
+    if (gated) O.canbreak = (stop_on_convergence && canbreak && iteration >= 1) ? 1 : 0;
+    else if (stop_on_convergence && canbreak && iteration >= 1) { O.phase = 1; Bw.finished = 1; }
   }
+}
+
+
+// The energy gate of one GN iteration (FullSystemOptimize.cpp:961-990) for every window, after the trial linearisation:
+//   which 0: the loop's start — lastEnergy, setNewFrameEnergyTH, lastEnergyL, lastEnergyM of the uploaded state (:895-906)
+//   which 1: newEnergy (+ threshold), newEnergyL, newEnergyM; accepted when their sum is below the last one: the new values become the
+//            last ones, lambda *= 0.25, gate = 1 (applyRes follows); otherwise loadSateBackup — states, calibration and tables go back —,
+//            lambda *= 1e2, gate = 2 (the points are restored and the state re-linearised by the conditional kernels that follow)
+//   which 2: (rejected windows only) the energies of the re-linearisation at the restored state become the last ones (:983-985)
+// After which 1 (accepted) / which 2 the recorded break test ends the window's loop.  lpart: k_ba_lenergy's per-workgroup partials.
+__global__ __launch_bounds__(256) void k_ba_opt_gate(const BaDev* __restrict__ wins, const float* __restrict__ lpart, int lstride, int which, int stop_on_convergence) {
+  BaDev& Bw = const_cast<BaDev&>(wins[blockIdx.y]);
+  const BaDev B = Bw;
+  if (ba_finished_lin(B)) return;
+  BaOptDev& O = *B.opt;
+  if (which == 2 && O.gate != 2) return;
+  const int tid = threadIdx.x, nf = B.nf, n = B.n;
+  __shared__ unsigned hist[256], sh[6];
+  __shared__ int s_cnt[4];
+  __shared__ double s_esum[4], s_term[72], s_delta[72];
+  __shared__ float s_lp[1024];
+  constexpr int kStage = 8192;
+  __shared__ float s_en[kStage];
+  // ---- energy of the linearisation (k_ba_linearize: one partial per 256 residuals) and the newest frame's threshold
+  OptEnergies en{nullptr, 0, 1, max(B.nr - O.newest_first, 0), &B, O.newest_first};
+  const int cap = en.cap;
+  const bool staged = cap <= kStage;
+  int cnt = 0;
+  for (int j = tid; j < cap; j += 256) { const float e = en.at(0, j); if (staged) s_en[j] = e; cnt += e >= 0 ? 1 : 0; }
+  double esum = 0;
+  for (int b = tid; b < (B.nr + BA_BLOCK - 1) / BA_BLOCK; b += 256) esum += B.e_part[b];
+  esum = wave_sum(esum);
+  cnt = (int)wave_sum((float)cnt);
+  if ((tid & 63) == 0) { s_esum[tid >> 6] = esum; s_cnt[tid >> 6] = cnt; }
+  // calcLEnergy's partials and the operands of calcMEnergy (EnergyFunctional.cpp:344-442), fetched before the quantile
+  const int nlp = B.nchunks + (B.np + BA_BLOCK - 1) / BA_BLOCK;
+  const float* lp = lpart + (size_t)blockIdx.y * lstride;
+  for (int b = tid; b < nlp && b < 1024; b += 256) s_lp[b] = lp[b];
+  if (tid < n) s_delta[tid] = tid < 4 ? O.calib_value[tid] - O.calib_zero[tid] : B.t_prior[nf * 16 + 8 + (tid - 4)];   // getStitchedDeltaF (:1021-1032)
+  __syncthreads();
+  if (staged) { en.g = s_en; en.rstride = cap; en.nranks = 1; en.cap = cap; }
+  const int M = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+  float th = 12 * 12 * 8;
+  if (M > 0) {
+    const int nth = (int)(0.7f * M);
+    const float q = opt_select(en, nth, hist, sh);
+    const float nthElement = sqrtf(q);
+    th = nthElement * 1.5f;
+    th = 26.0f * 0.5f + th * (1 - 0.5f);
+    th = th * th;
+    th *= 1.0f * 1.0f;
+  }
+  if (tid < n) {                                              // delta^T (2 bM + HM delta), row by row like the host loop
+    double s2 = 0;
+    for (int k = 0; k < n; k++) s2 += B.t_HM[(size_t)tid * n + k] * s_delta[k];
+    s_term[tid] = s_delta[tid] * (2 * B.t_bM[tid] + s2);
+  }
+  __syncthreads();
+  if (tid != 0) return;
+  const double newE = (s_esum[0] + s_esum[1]) + (s_esum[2] + s_esum[3]);
+  Bw.t_frameTH[nf - 1] = th;
+  O.frameTH_new = th;
+  double EL = 0;
+  for (int f = 0; f < nf; f++) for (int i = 0; i < 8; i++) { const double dp = B.t_prior[nf * 8 + f * 8 + i]; EL += dp * B.t_prior[f * 8 + i] * dp; }
+  { float s = 0; for (int i = 0; i < 4; i++) { const float cd = B.t_cdelta[i]; s += cd * (float)B.t_prior[nf * 16 + i] * cd; } EL += s; }
+  { float Ept = 0; for (int b = 0; b < nlp; b++) Ept += b < 1024 ? s_lp[b] : lp[b]; EL += Ept; }
+  double EM = 0;
+  for (int i = 0; i < n; i++) EM += s_term[i];
+  if (which != 1) {                                           // the loop's start, or the state a rejected step went back to
+    O.lastEnergy = newE; O.lastEnergyL = EL; O.lastEnergyM = EM;
+    if (which == 0) { O.gate = 0; return; }
+  } else if (newE + EL + EM < O.lastEnergy + O.lastEnergyL + O.lastEnergyM) {      // :969
+    O.lastEnergy = newE; O.lastEnergyL = EL; O.lastEnergyM = EM;
+    O.lambda *= 0.25;
+    O.gate = 1;
+  } else {
+    O.lambda *= 1e2;
+    O.gate = 2;
+    // loadSateBackup: frames, calibration, and everything setPrecalcValues / setDeltaF derived from them
+    for (int f = 0; f < nf; f++) for (int i = 0; i < 10; i++) O.state[f][i] = O.state_backup[f][i];
+    for (int i = 0; i < 4; i++) O.calib_value[i] = O.calib_backup[i];
+    float* pc = const_cast<float*>(B.t_precalc); float* ad = const_cast<float*>(B.t_adHTdelta); float* cd = const_cast<float*>(B.t_cdelta);
+    double* tp = const_cast<double*>(B.t_prior);
+    for (int e = 0; e < nf * nf * 27; e++) pc[e] = O.bk_precalc[e];
+    for (int e = 0; e < nf * nf * 8; e++) ad[e] = O.bk_adHTdelta[e];
+    for (int e = 0; e < nf * 16 + 8 + nf * 8; e++) tp[e] = O.bk_prior[e];
+    for (int e = 0; e < 4; e++) cd[e] = O.bk_cdelta[e];
+    Bw.fxl = O.bk_calib[0]; Bw.fyl = O.bk_calib[1]; Bw.cxl = O.bk_calib[2]; Bw.cyl = O.bk_calib[3]; Bw.fxli = O.bk_calib[4]; Bw.fyli = O.bk_calib[5];
+    return;                                                   // the break test waits for the re-linearisation (which 2)
+  }
+  if (O.canbreak) { O.phase = 2; Bw.finished = 2; }           // :990 `if(canbreak && iteration >= setting_minOptIterations) break;`
 }
 
 // what the host needs back from a resident loop, one record per window (one D2H copy per batch)

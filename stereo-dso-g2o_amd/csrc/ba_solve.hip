@@ -348,9 +348,12 @@ __global__ __launch_bounds__(64 * ST_WAVES) void k_ba_stitch(const BaDev* __rest
 #define ACCUM(i, t0v) do { } while (0)
 #define TNOW() 0ull
 #endif
+// orthogonalize_x bit 1: lambda of the window's resident GN loop (BaOptDev::lambda, energy-gated flow) instead of the argument
 __global__ __launch_bounds__(BA_BLOCK) void k_ba_solve(const BaDev* __restrict__ wins, double lambda, int orthogonalize_x) {
   const BaDev& B = wins[blockIdx.y];
   if (ba_finished(B)) return;
+  if (orthogonalize_x & 2) lambda = B.opt->lambda;
+  orthogonalize_x &= 1;
 #ifdef SDSO_SOLVE_STAMPS
   unsigned long long stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0}, acc_t[6] = {0, 0, 0, 0, 0, 0};
 #endif
@@ -653,9 +656,10 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_resub(const BaDev* __restrict__
 // FullSystem::backupState / doStepFromBackup / loadSateBackup for the points.  op: 0 backup, 1 step, 2 restore
 // op 3 = backup + step in one pass (the resident loop never restores)
 __global__ __launch_bounds__(BA_BLOCK) void k_ba_points_op(const BaDev* __restrict__ wins, int op, float stepfacD, float* __restrict__ sums /* per block: sumID, sumNID */,
-                                                           int sums_stride = 0 /* floats between the windows' sums */) {
+                                                           int sums_stride = 0 /* floats between the windows' sums */, int cond = 0) {
   const BaDev& B = wins[blockIdx.y];
   if (ba_finished(B)) return;
+  if (ba_gate_skip(B, cond)) return;
   const int p = blockIdx.x * BA_BLOCK + threadIdx.x;
   float sID = 0, sNID = 0;
   if (p < B.np) {

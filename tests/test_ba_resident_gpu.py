@@ -165,18 +165,56 @@ def test_batch_resident_loop(gpu_ctx, oracle):
         gpu_ctx.check(gpu_ctx.L.sdso_ba_release_window(gpu_ctx.h, 60 + k))
 
 
-def test_resident_loop_refuses_gated_windows(gpu_ctx):
-    win = dict(synth.ba_window(w=320, h=240, nf=4, pts_per_kf=40, seed=3093))
+@pytest.mark.parametrize("noise", [dict(), dict(idepth_noise=0.3, state_noise=1e-2)])
+@pytest.mark.parametrize("mode", [128 | 2048, 0])
+def test_gated_loop_on_the_device(gpu_ctx, oracle, monkeypatch, noise, mode):
+    """setting_forceAceptStep = false: the energy gate (FullSystemOptimize.cpp:961-990) is taken on the device (k_ba_opt_gate) — against
+    the library's host loop the decisions, iteration counts and states must agree (a marginalisation prior makes calcMEnergyF non-trivial;
+    solverMode 0 exercises the loop's own lambda, which depends on the decisions), and against the oracle as
+    tests/test_ba_gpu.py::test_optimize_energy_gated_steps demands."""
+    win = dict(synth.ba_window(w=640, h=480, nf=5, pts_per_kf=120, seed=3001, **noise))
+    nf, npts, nr, n = win["nf"], win["np"], win["nr"], 8 * win["nf"] + 4
+    A = np.random.RandomState(4).normal(size=(n, 5))
+    win["HM"] = (A @ A.T) * 1e3
+    win["bM"] = np.random.RandomState(5).normal(size=n) * 5
     win["forceAcceptStep"] = 0
-    for f in range(4):
+    win["solverMode"] = mode
+    so, io, ro, oo = _oracle_opt(oracle, win, 6)
+    for f in range(nf):
         gpu_ctx.upload_pyramid(560 + f, win["pyrs"][f][:1])
-    W, keep = abi.make_ba_window(win, frame_slots=[560 + f for f in range(4)])
+    W, keep = abi.make_ba_window(win, frame_slots=[560 + f for f in range(nf)])
+    out = {}
+    for host in (0, 1):
+        if host:
+            monkeypatch.setenv("SDSO_BA_HOST_LOOP", "1")
+        else:
+            monkeypatch.delenv("SDSO_BA_HOST_LOOP", raising=False)
+        gpu_ctx.check(gpu_ctx.L.sdso_ba_upload_window(gpu_ctx.h, 70, C.byref(W)))
+        s, i, r, o = np.zeros((nf, 10)), np.zeros(npts, np.float32), np.zeros(nr, np.uint8), abi.BAOptResult()
+        gpu_ctx.check(gpu_ctx.L.sdso_ba_optimize(gpu_ctx.h, 70, 6, abi.dp(s), abi.fp(i), abi.bp(r), C.byref(o)))
+        out[host] = (s, i, r, o)
+    monkeypatch.delenv("SDSO_BA_HOST_LOOP", raising=False)
+    (s1, i1, r1, o1), (s0, i0, r0, o0) = out[0], out[1]
+    assert o1.iterations == o0.iterations == oo.iterations and o1.resInA == o0.resInA
+    assert np.array_equal(r1, r0)
+    assert np.abs(s1 - s0).max() <= 2e-6 and np.abs(i1 - i0).max() <= 2e-5, (np.abs(s1 - s0).max(), np.abs(i1 - i0).max())
+    assert abs(o1.lastEnergy - o0.lastEnergy) <= 1e-5 * o0.lastEnergy
+    assert np.abs(s1 - so).max() <= 2e-4 and np.abs(i1 - io).max() <= 2e-4          # same accept / reject sequence as the oracle
+    # the same window twice in a batch: sdso_ba_batch_optimize takes the gated flow for every member
     gpu_ctx.check(gpu_ctx.L.sdso_ba_upload_window(gpu_ctx.h, 70, C.byref(W)))
-    ids = np.array([70], np.int32)
-    gpu_ctx.check(gpu_ctx.L.sdso_ba_batch_create(gpu_ctx.h, 1, abi.ip(ids)))
-    assert gpu_ctx.L.sdso_ba_batch_optimize_begin(gpu_ctx.h, 1) != 0
-    assert b"forceAceptStep" in gpu_ctx.L.sdso_last_error(gpu_ctx.h)
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_upload_window(gpu_ctx.h, 71, C.byref(W)))
+    ids = np.array([70, 71], np.int32)
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_batch_create(gpu_ctx.h, 2, abi.ip(ids)))
+    res = (abi.BAOptResult * 2)()
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_batch_optimize(gpu_ctx.h, 6, res))
+    for k in range(2):
+        s = np.zeros((nf, 10))
+        gpu_ctx.check(gpu_ctx.L.sdso_ba_get_state(gpu_ctx.h, 70 + k, abi.dp(s), None, None))
+        assert res[k].iterations == o1.iterations and np.array_equal(s, s1)
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_batch_optimize_begin(gpu_ctx.h, 1))
+    assert gpu_ctx.L.sdso_ba_batch_step(gpu_ctx.h) != 0                              # the piecewise driver is the accepted-step flow only
     gpu_ctx.check(gpu_ctx.L.sdso_ba_release_window(gpu_ctx.h, 70))
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_release_window(gpu_ctx.h, 71))
 
 
 def test_resident_loop_degenerate_windows(gpu_ctx, oracle, monkeypatch):
