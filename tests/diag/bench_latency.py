@@ -2,7 +2,7 @@
 """Single-problem latencies of the drop-in calls (what one FullSystem call costs): trackNewestCoarse and optimize, GPU vs oracle."""
 import ctypes as C, json, os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in ("stereo-dso-g2o_amd", "oracle", "tests"):
     sys.path.insert(0, os.path.join(ROOT, p))
 from sdso_amd import abi, synth

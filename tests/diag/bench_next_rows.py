@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Wall-clock of the widened rows through the host-buffer C-ABI calls, next to the oracle on one host core.
 These calls include the H2D/D2H copies of their arguments (they run once per keyframe, not in the GN inner loop), so the numbers
-are call latencies, not kernel roofline figures.  Usage on the GPU box:  python3 tools/bench_next_rows.py > gpurun_out/next_rows.json"""
+are call latencies, not kernel roofline figures.  Usage on the GPU box:  python3 tests/diag/bench_next_rows.py > gpurun_out/next_rows.json"""
 import ctypes as C
 import json
 import os
@@ -10,7 +10,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in ("stereo-dso-g2o_amd", "oracle", "tests"):
     sys.path.insert(0, os.path.join(ROOT, p))
 from sdso_amd import abi, synth  # noqa: E402

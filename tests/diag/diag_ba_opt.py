@@ -2,7 +2,7 @@
 sensitivity to the order of its float sums (points permuted inside each host group)."""
 import ctypes as C, os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [os.path.join(ROOT, "stereo-dso-g2o_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
 from sdso_amd import abi, synth
 import pyoracle

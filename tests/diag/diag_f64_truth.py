@@ -2,7 +2,7 @@
 (1) packed accumulators after one linearize+apply+accumulate, (2) states / idepths after the GN loop, raw and modulo the scale gauge."""
 import ctypes as C, os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in ("stereo-dso-g2o_amd", "oracle", "tests"):
     sys.path.insert(0, os.path.join(ROOT, p))
 import pyoracle

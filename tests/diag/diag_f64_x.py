@@ -1,7 +1,7 @@
 """Diagnostic (GPU box): one GN iteration's x (device, float oracle) against the f64-accumulator oracle, whitened by the f64 system."""
 import ctypes as C, os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in ("stereo-dso-g2o_amd", "oracle", "tests"):
     sys.path.insert(0, os.path.join(ROOT, p))
 import pyoracle

@@ -10,7 +10,7 @@ SDSO_BA_NO_J=1 SDSO_BENCH_SKIP_OTHERS=1 timeout -k 10 300 python bench.py --step
 timeout -k 10 300 python bench.py --workload tracker --steps 50 2>/dev/null | tail -1 > gpurun_out/r02_bench_tracker.json
 timeout -k 10 300 python bench.py --workload trace --steps 50 2>/dev/null | tail -1 > gpurun_out/r02_bench_trace.json
 echo bench done
-timeout -k 10 300 python tools/bench_latency.py > gpurun_out/r02_latency.json 2>gpurun_out/r02_latency.err
+timeout -k 10 300 python tests/diag/bench_latency.py > gpurun_out/r02_latency.json 2>gpurun_out/r02_latency.err
 timeout -k 10 200 python tools/time_optimize.py > gpurun_out/r02_optimize_times.txt 2>&1
 echo latency done
 bash tools/profile_r02.sh > gpurun_out/profile_r02.log 2>&1
