@@ -782,8 +782,8 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_accum_top(const BaDev* __restri
 // Linearized residuals are untouched (their accumulation is the separate mode-1 pass).
 // Workgroups per CU: four without the Jacobian stores (124 VGPRs, 40 KB of LDS each); with them the kernel needs 152 VGPRs
 // (capping it at 128 spills 22-38 of them and loses more than the fourth wave per SIMD gains), so three.
-// GATHER: 0 = every lane fetches the 32 taps of its own residual; 1 = cooperative quad gather (linearize_coop).  The default path
-// of the library is k_ba_lin_dma below (LDS-DMA rounds, tiled images); these two stay for row-major images and for A/B runs.
+// GATHER: 0 = every lane fetches the 32 taps of its own residual (A/B: SDSO_BA_DIRECT_TAPS); 1 = cooperative quad gather
+// (linearize_coop), the library's default.  k_ba_lin_dma below (LDS-DMA rounds, tiled images) is a third, equally fast variant.
 template <bool MATERIALIZE, bool TILED, int GATHER = 1>
 __global__ __launch_bounds__(BA_BLOCK, (MATERIALIZE ? 3 : 4)) void k_ba_lin_fused(const BaDev* __restrict__ wins) {
   constexpr bool COOP = GATHER == 1;
@@ -877,7 +877,8 @@ __global__ __launch_bounds__(BA_BLOCK, (MATERIALIZE ? 3 : 4)) void k_ba_lin_fuse
 }
 
 // ------------------------------------------------------------------ fused linearize + applyRes + accumulateAF, taps by LDS-DMA
-// The library's default BA kernel (4x2-tiled level-0 images).  Same work per workgroup as k_ba_lin_fused — one chunk of <= 256
+// A/B variant of the fused kernel (SDSO_BA_GATHER=2, 4x2-tiled level-0 images; measured equal to the cooperative gather of
+// k_ba_lin_fused<.,.,1>, which stays the default).  Same work per workgroup as k_ba_lin_fused — one chunk of <= 256
 // residuals of ONE (host,target) pair — organised around what the profile of its predecessor showed: a workgroup lived ~60 us for
 // ~3.5 k instructions per wave, i.e. it sat in a chain of a dozen DEPENDENT memory round trips at three waves per SIMD.
 //   * prologue: every per-residual input is fetched by two batches of independent, unconditional loads (indices / states, then the
