@@ -265,7 +265,7 @@ def main():
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
-            dist.init_process_group(backend=backend)
+            dist.init_process_group(backend="gloo" if backend == "gloo_lib" else backend)   # gloo_lib: gloo under the library's host transport
 
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from sdso_amd import abi

@@ -98,8 +98,31 @@ class BAWorkload:
             self.groups.append(G)
         # communicator: RCCL inside the library (backend nccl).  With SDSO_DIST_BACKEND=gloo (rehearsal of the multi-rank path on a
         # box with fewer GPUs than ranks: RCCL refuses two ranks on one device) the block is all-reduced through torch instead.
-        self.lib_comm = world > 1 and os.environ.get("SDSO_DIST_BACKEND", "nccl") == "nccl"
-        if world > 1:
+        backend = os.environ.get("SDSO_DIST_BACKEND", "nccl")
+        self.lib_comm = world > 1 and backend in ("nccl", "gloo_lib")
+        if world > 1 and backend == "gloo_lib":
+            # rehearsal of the WHOLE multi-rank step (library all-reduce + the resident loop's all-gather) on a box with fewer GPUs than
+            # ranks: the library communicator over its host transport (sdso_comm_init_host), gloo underneath
+            import torch.distributed as dist
+
+            def _ar(user, buf, n):
+                t = torch.from_numpy(np.ctypeslib.as_array(buf, shape=(n,)))
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                return 0
+
+            def _ag(user, send, recv, n):
+                sd = torch.from_numpy(np.ctypeslib.as_array(send, shape=(n,)).copy())
+                outl = [torch.empty(n, dtype=torch.float32) for _ in range(world)]
+                dist.all_gather(outl, sd)
+                r = np.ctypeslib.as_array(recv, shape=(n * world,))
+                for k, o in enumerate(outl):
+                    r[k * n:(k + 1) * n] = o.numpy()
+                return 0
+            self._cbs = (abi.HOST_ALLREDUCE_FN(_ar), abi.HOST_ALLGATHER_FN(_ag))
+            for G in self.groups:
+                G.ctx.check(G.ctx.L.sdso_comm_init_host(G.ctx.h, world, rank, self._cbs[0], self._cbs[1], None))
+            self.exchange = "sdso_ba_allreduce over the library's host transport (gloo; rehearsal)"
+        elif world > 1:
             import torch.distributed as dist
             self.exchange = "torch.distributed all_reduce on the library's device block (SDSO_DIST_BACKEND != nccl)"
             if self.lib_comm:
