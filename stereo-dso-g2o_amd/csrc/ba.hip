@@ -586,8 +586,14 @@ static void launch_stitch(sdso_ctx* ctx, const BaLaunch& L) {
 static void launch_solve(sdso_ctx* ctx, const BaLaunch& L, double lambda, int orth) {
   const int n = L.n;
   launch_stitch(ctx, L);
-  const size_t lds = sizeof(double) * ((size_t)n * ((n + 2) & ~1) + 6 * n + 16) + sizeof(int) * n;   // matrix, six vectors (+16 pad), perm
-  hipLaunchKernelGGL(k_ba_solve, dim3(1, L.nwin), dim3(BA_BLOCK), lds, ctx->stream, L.d_arr, lambda, orth);
+  static const int solve_ver = getenv("SDSO_BA_SOLVE") ? atoi(getenv("SDSO_BA_SOLVE")) : 1;   // 2: lane = original row, nothing exchanged (A/B)
+  if (solve_ver == 2) {
+    const size_t lds2 = sizeof(double) * ((size_t)n * ((n + 2) & ~1) + 6 * n + 32 + (n * (n + 1)) / 2 + 2) + sizeof(int) * n;   // factor, vectors, packed system, pivot rows
+    hipLaunchKernelGGL(k_ba_solve<2>, dim3(1, L.nwin), dim3(BA_BLOCK), lds2, ctx->stream, L.d_arr, lambda, orth);
+  } else {
+    const size_t lds = sizeof(double) * ((size_t)n * ((n + 2) & ~1) + 6 * n + 16) + sizeof(int) * n;   // matrix, six vectors (+16 pad), perm
+    hipLaunchKernelGGL(k_ba_solve<1>, dim3(1, L.nwin), dim3(BA_BLOCK), lds, ctx->stream, L.d_arr, lambda, orth);
+  }
   if (L.max_nblk_pts > 0) hipLaunchKernelGGL(k_ba_resub, dim3(L.max_nblk_pts, L.nwin), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr);
 }
 static BaLaunch single(BaWindowDev* W) {
