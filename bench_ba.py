@@ -89,9 +89,9 @@ class BAWorkload:
             G.nwin = len(ids)
             G.ctx.check(G.ctx.L.sdso_ba_batch_create(G.ctx.h, G.nwin, abi.ip(G.ids)))
             G.ctx.check(G.ctx.L.sdso_ba_batch_set_materialize(G.ctx.h, self.materialize))
-            ptr, nfl = C.c_void_p(), C.c_long(0)
-            G.ctx.check(G.ctx.L.sdso_ba_batch_accum_dev(G.ctx.h, C.byref(ptr), C.byref(nfl)))
-            nfl_total += int(nfl.value)
+            # (the all-reduce payload; sdso_ba_batch_accum_dev is NOT called here: handing the block's address out makes every
+            #  accumulate fold eagerly, and the single-rank step leaves the folds to the fused tail kernel)
+            nfl_total += int(G.ctx.L.sdso_ba_accum_floats(nf)) * G.nwin
             G.stream = torch.cuda.ExternalStream(G.ctx.L.sdso_ctx_stream(G.ctx.h))
             G.accum = None
             G.ev = torch.cuda.Event()
@@ -226,9 +226,12 @@ class BAWorkload:
                 import torch.distributed as dist
                 with self.torch.cuda.stream(G.stream):
                     dist.all_reduce(G.accum, op=dist.ReduceOp.SUM)
-            G.ctx.check(G.ctx.L.sdso_ba_batch_solve(G.ctx.h, 1e-5, 0))
             if self.advance:
-                G.ctx.check(G.ctx.L.sdso_ba_batch_step(G.ctx.h))      # doStepFromBackup + tables + setNewFrameEnergyTH on the device (+ all-gather when sharded)
+                # solveSystemF + resubstitute + doStepFromBackup + tables + setNewFrameEnergyTH: ONE launch of the fused tail kernel per group
+                # (+ pack / all-gather / k_ba_opt_step when sharded)
+                G.ctx.check(G.ctx.L.sdso_ba_batch_solve_step(G.ctx.h, 1e-5, 0))
+            else:
+                G.ctx.check(G.ctx.L.sdso_ba_batch_solve(G.ctx.h, 1e-5, 0))
             prev = G
 
     def _one_iteration(self):
@@ -290,7 +293,7 @@ class BAWorkload:
         out["max_abs_x"] = mx
         if self.advance:
             assert mx < out["max_abs_x_initial"], "the GN steps did not shrink: %g -> %g" % (out["max_abs_x_initial"], mx)
-        for k in ("k_ba_lin_fused", "k_ba_sc"):
+        for k in ("k_ba_lin_fused", "k_ba_sc", "k_ba_tail"):
             ms, n = self.prof_read(k)
             out[k + "_avg_ms"] = ms / max(n, 1)
         return out

@@ -332,10 +332,15 @@ int sdso_ba_batch_get_x(sdso_ctx* ctx, double* x /* nwin*(8nf+4) */);
  *   ..._begin / sdso_ba_batch_step / ..._end : the same in pieces, for callers that drive the iterations themselves:
  *       begin ; per iteration { sdso_ba_batch_accumulate ; [sdso_ba_allreduce] ; sdso_ba_batch_solve ; sdso_ba_batch_step } ; end
  *     stop_on_convergence = 0 keeps every window iterating (benchmarks).
+ *   sdso_ba_batch_solve_step     : sdso_ba_batch_solve + sdso_ba_batch_step as ONE enqueue — EnergyFunctional::solveSystemF (:838-995),
+ *                                  resubstituteF (:272-341), doStepFromBackup, setPrecalcValues, setDeltaF, setNewFrameEnergyTH and the
+ *                                  break test in one launch of the fused tail kernel (k_ba_tail: a persistent workgroup per window;
+ *                                  the stitched system never leaves the CU).  lambda / orthogonalize_x as in sdso_ba_batch_solve.
  *   sdso_ba_get_state            : states / idepths / residual states of one window as they stand (synchronises). */
 int sdso_ba_batch_optimize(sdso_ctx* ctx, int mnumOptIts, sdso_ba_opt_result_t* out /* nwin */);
 int sdso_ba_batch_optimize_begin(sdso_ctx* ctx, int stop_on_convergence);
 int sdso_ba_batch_step(sdso_ctx* ctx);
+int sdso_ba_batch_solve_step(sdso_ctx* ctx, double lambda, int orthogonalize_x);
 int sdso_ba_batch_optimize_end(sdso_ctx* ctx, sdso_ba_opt_result_t* out /* nwin, may be NULL */);
 int sdso_ba_get_state(sdso_ctx* ctx, int win, double* state_out /* nf*10 */, float* idepth_out /* np */, uint8_t* res_state_out /* nr */);
 

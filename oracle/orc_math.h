@@ -232,53 +232,65 @@ struct MatX {
 };
 typedef std::vector<double> VecX;
 
-// Solve A x = rhs for symmetric A (n x n) with LDL^T and symmetric pivoting on the largest
-// remaining |diagonal| (the strategy of Eigen::LDLT, used at EnergyFunctional.cpp:976 and
-// CoarseTracker.cpp:934).  Returns false if a zero pivot blocks the factorisation.
+// Solve A x = rhs for symmetric A (n x n) with Eigen's LDLT (`A.ldlt().solve(rhs)`, used at EnergyFunctional.cpp:976 and
+// CoarseTracker.cpp:934).  Eigen is an external, un-pinned dependency of the reference (absent from /root/reference); what follows
+// restates its published unblocked algorithm, `internal::ldlt_inplace<Lower>::unblocked` (Eigen/src/Cholesky/LDLT.h, 3.2 .. 3.4):
+//   for k = 0 .. n-1
+//     p = index of the FIRST largest |mat(i,i)|, i >= k            (`mat.diagonal().tail(size-k).cwiseAbs().maxCoeff(&idx)`)
+//     exchange positions k and p symmetrically (only the lower triangle is ever read)
+//     temp(q) = D(q) * L(k,q), q < k;   mat(k,k) -= L(k,:) . temp;   mat(i,k) -= L(i,:) . temp  for i > k      (left-looking)
+//     if |mat(k,k)| > 0:  mat(i,k) /= mat(k,k)  for i > k         (a zero pivot leaves its column as it is)
+// The trailing block is NOT updated before its turn, so the diagonal the pivot search sees at positions > k is the ORIGINAL one:
+// the permutation depends on the input diagonal only.  The solve (`LDLT::_solve_impl`): P b, L^-1, D^-1 with 0 for a zero D
+// (Eigen's tolerance there is the smallest positive double), L^-T, P^T.
+// Returns false if a zero pivot was met.
 inline bool ldlt_solve(const MatX& Ain, const VecX& rhs, VecX& x) {
-  int n = Ain.r;
-  MatX A = Ain;
+  const int n = Ain.r;
   std::vector<int> perm(n);
   for (int i = 0; i < n; i++) perm[i] = i;
-  std::vector<double> D(n, 0.0);
+  MatX L(n, n);                        // unit lower factor by POSITION (strict lower part)
+  std::vector<double> D(n, 0.0), temp(n, 0.0);
+  auto a = [&](int pi, int pj) {       // element of the permuted input, read from the lower triangle of the original
+    const int i = perm[pi], j = perm[pj];
+    return i >= j ? Ain(i, j) : Ain(j, i);
+  };
   bool ok = true;
   for (int k = 0; k < n; k++) {
-    // pivot
     int p = k;
-    double best = std::fabs(A(k, k));
-    for (int i = k + 1; i < n; i++)
-      if (std::fabs(A(i, i)) > best) { best = std::fabs(A(i, i)); p = i; }
-    if (p != k) {
-      for (int j = 0; j < n; j++) std::swap(A(k, j), A(p, j));
-      for (int i = 0; i < n; i++) std::swap(A(i, k), A(i, p));
-      std::swap(perm[k], perm[p]);
-    }
-    double dk = A(k, k);
-    D[k] = dk;
-    if (dk == 0.0) { ok = false; for (int i = k + 1; i < n; i++) A(i, k) = 0; continue; }
-    for (int i = k + 1; i < n; i++) A(i, k) = A(i, k) / dk;
+    double best = std::fabs(Ain(perm[k], perm[k]));
     for (int i = k + 1; i < n; i++) {
-      double lik = A(i, k);
-      if (lik == 0.0) continue;
-      for (int j = k + 1; j <= i; j++) {
-        A(i, j) -= lik * dk * A(j, k);
-      }
+      const double v = std::fabs(Ain(perm[i], perm[i]));
+      if (v > best) { best = v; p = i; }
     }
-    for (int i = k + 1; i < n; i++)
-      for (int j = i + 1; j < n; j++) A(i, j) = A(j, i);
+    if (p != k) {
+      std::swap(perm[k], perm[p]);
+      for (int q = 0; q < k; q++) std::swap(L(k, q), L(p, q));
+    }
+    for (int q = 0; q < k; q++) temp[q] = D[q] * L(k, q);
+    double dk = a(k, k);
+    { double s = 0; for (int q = 0; q < k; q++) s += L(k, q) * temp[q]; dk -= s; }
+    D[k] = dk;
+    const bool valid = std::fabs(dk) > 0.0;
+    if (!valid) ok = false;
+    for (int i = k + 1; i < n; i++) {
+      double c = a(i, k);
+      double s = 0;
+      for (int q = 0; q < k; q++) s += L(i, q) * temp[q];
+      c -= s;
+      L(i, k) = valid ? c / dk : c;
+    }
   }
-  // solve: P A P^T = L D L^T
   VecX y(n);
   for (int i = 0; i < n; i++) y[i] = rhs[perm[i]];
   for (int i = 0; i < n; i++) {
     double s = y[i];
-    for (int j = 0; j < i; j++) s -= A(i, j) * y[j];
+    for (int j = 0; j < i; j++) s -= L(i, j) * y[j];
     y[i] = s;
   }
   for (int i = 0; i < n; i++) y[i] = (D[i] != 0.0) ? y[i] / D[i] : 0.0;
   for (int i = n - 1; i >= 0; i--) {
     double s = y[i];
-    for (int j = i + 1; j < n; j++) s -= A(j, i) * y[j];
+    for (int j = i + 1; j < n; j++) s -= L(j, i) * y[j];
     y[i] = s;
   }
   x.assign(n, 0.0);

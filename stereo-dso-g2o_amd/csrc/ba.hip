@@ -5,6 +5,7 @@
 #include "ba_kernels.hip"   // single translation unit: kernels + host API
 #include "ba_solve.hip"
 #include "ba_opt.hip"
+#include "ba_tail.hip"
 #include "ba_host.h"
 #include <algorithm>
 #include <cmath>
@@ -119,6 +120,9 @@ struct BaBatch {
   float* d_accum = nullptr;
   BaLaunch L;
   bool materialize = true;
+  bool eager_fold = false;       // sdso_ba_batch_accum_dev handed the block's address out: never defer the folds
+  bool folded = true;            // the packed accumulator block holds the folded sums of the latest accumulate (false: the top partials and the
+                                 // per-host Hcc / bc are still unfolded — the fused tail kernel folds them itself; ensure_folded() for anyone else)
   int gather = 1;                // tap gather of the fused kernel: 1 cooperative quads (default), 2 LDS-DMA rounds, 0 direct (SDSO_BA_GATHER / SDSO_BA_DIRECT_TAPS at batch_create)
 };
 static std::map<sdso_ctx*, BaBatch*> g_batches;
@@ -500,7 +504,7 @@ static void launch_linearize(sdso_ctx* ctx, const BaLaunch& L) {
 static void launch_apply(sdso_ctx* ctx, const BaLaunch& L) {
   hipLaunchKernelGGL(k_ba_apply, dim3(L.max_nblk_res, L.nwin), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr);
 }
-static void launch_sc_and_folds(sdso_ctx* ctx, const BaLaunch& L, const uint8_t* pflag, bool marg, bool fold_top_too = false);
+static bool launch_sc_and_folds(sdso_ctx* ctx, const BaLaunch& L, const uint8_t* pflag, bool marg, bool fold_top_too = false, bool defer_fold = false);
 static void launch_accumulate(sdso_ctx* ctx, const BaLaunch& L, const uint8_t* pflag, bool marg) {
   const int nf = L.nf;
   // the folds run even without a single chunk: they are what clears the top bins of the previous call
@@ -520,7 +524,8 @@ static void launch_accumulate(sdso_ctx* ctx, const BaLaunch& L, const uint8_t* p
   }
   launch_sc_and_folds(ctx, L, pflag, marg);
 }
-static void launch_sc_and_folds(sdso_ctx* ctx, const BaLaunch& L, const uint8_t* pflag, bool marg, bool fold_top_too) {
+// returns false when the folds were left to the fused tail kernel (defer_fold: only the default Schur kernel, only together with the top fold)
+static bool launch_sc_and_folds(sdso_ctx* ctx, const BaLaunch& L, const uint8_t* pflag, bool marg, bool fold_top_too, bool defer_fold) {
   const int nf = L.nf;
   const int shift = marg ? 0 : 1, mm = marg ? 1 : 0;
   static const int sc_variant = getenv("SDSO_SC_REG") ? 2 : getenv("SDSO_SC_ITEMS") ? 1 : 0;   // 0: one workgroup per host (default); 1: per-item MFMA; 2: VALU register tiles
@@ -529,9 +534,10 @@ static void launch_sc_and_folds(sdso_ctx* ctx, const BaLaunch& L, const uint8_t*
       ProfScope ps(ctx, "k_ba_sc");
       hipLaunchKernelGGL(k_ba_sc_host, dim3(nf, L.nwin), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr, pflag, shift, mm);
     }
+    if (fold_top_too && defer_fold) return false;
     if (fold_top_too) hipLaunchKernelGGL(k_ba_fold_all, dim3(1 + 2 * nf * nf, L.nwin), dim3(128), 0, ctx->stream, L.d_arr, 1);
     else hipLaunchKernelGGL(k_ba_fold_hcc, dim3(1, L.nwin), dim3(64), 0, ctx->stream, L.d_arr);
-    return;
+    return true;
   }
   if (L.max_items > 0) {
     ProfScope ps(ctx, "k_ba_sc");
@@ -549,9 +555,11 @@ static void launch_sc_and_folds(sdso_ctx* ctx, const BaLaunch& L, const uint8_t*
   }
   if (fold_top_too) hipLaunchKernelGGL(k_ba_fold_all, dim3(nf * nf * nf + 3 * nf * nf + 1, L.nwin), dim3(128), 0, ctx->stream, L.d_arr, 0);
   else hipLaunchKernelGGL(k_ba_fold_sc, dim3(nf * nf * nf + nf * nf + 1, L.nwin), dim3(64), 0, ctx->stream, L.d_arr);
+  return true;
 }
 // linearizeAll + applyRes + accumulateAF in one kernel, then the (normally empty) linearized pass and the Schur part
-static void launch_fused(sdso_ctx* ctx, const BaLaunch& L, bool materialize, int gather, int part = 3 /* bit 0: linearize+top, bit 1: Schur+folds */) {
+// returns false when the folds were deferred to the tail kernel (defer_fold)
+static bool launch_fused(sdso_ctx* ctx, const BaLaunch& L, bool materialize, int gather, int part = 3 /* bit 0: linearize+top, bit 1: Schur+folds */, bool defer_fold = false) {
   const int nf = L.nf;
   if ((part & 1) && L.max_chunks > 0) {
     {
@@ -572,7 +580,8 @@ static void launch_fused(sdso_ctx* ctx, const BaLaunch& L, bool materialize, int
     }
   }
   // without linearized residuals the top partials are folded together with the Schur partials, after the Schur kernel
-  if (part & 2) launch_sc_and_folds(ctx, L, nullptr, false, !L.any_lin);
+  if (part & 2) return launch_sc_and_folds(ctx, L, nullptr, false, !L.any_lin, defer_fold);
+  return true;
 }
 // stitchDouble of the three accumulator groups: the Schur pre-products, then one wave per output tile
 static void launch_stitch(sdso_ctx* ctx, const BaLaunch& L) {
@@ -582,9 +591,27 @@ static void launch_stitch(sdso_ctx* ctx, const BaLaunch& L) {
   // NF = 0 (runtime nf): the fully unrolled NF = 8 instantiation was measured 2x slower (register pressure: 259 vs 127 us per 64 windows)
   hipLaunchKernelGGL(k_ba_stitch<0>, sg, sb, 0, ctx->stream, L.d_arr);
 }
-// stitch + solveSystemF (default branch) + resubstitute
-static void launch_solve(sdso_ctx* ctx, const BaLaunch& L, double lambda, int orth) {
+// the fused tail kernel (ba_tail.hip); SDSO_BA_TAIL=0 keeps the chain of separate kernels (A/B)
+static bool tail_enabled() { static const bool on = !(getenv("SDSO_BA_TAIL") && atoi(getenv("SDSO_BA_TAIL")) == 0); return on; }
+static void launch_tail(sdso_ctx* ctx, const BaLaunch& L, double lambda, int flags, int iteration = 0, int last = 0, int stop = 0) {
+  ProfScope ps(ctx, "k_ba_tail");
+  if (L.nf == 8) hipLaunchKernelGGL(k_ba_tail<8>, dim3(L.nwin), dim3(TAIL_NT), 0, ctx->stream, L.d_arr, lambda, flags, iteration, last, stop);
+  else hipLaunchKernelGGL(k_ba_tail<0>, dim3(L.nwin), dim3(TAIL_NT), 0, ctx->stream, L.d_arr, lambda, flags, iteration, last, stop);
+}
+static void launch_fold_deferred(sdso_ctx* ctx, const BaLaunch& L) {   // what launch_fused left out under defer_fold
+  hipLaunchKernelGGL(k_ba_fold_all, dim3(1 + 2 * L.nf * L.nf, L.nwin), dim3(128), 0, ctx->stream, L.d_arr, 1);
+}
+// stitch + solveSystemF (default branch) + resubstitute.  orth bit 0: x -= P x; bit 1: lambda of the window's resident loop.
+// folded = false: the accumulate left the folds to the tail kernel (launch_fused with defer_fold)
+static void launch_solve(sdso_ctx* ctx, const BaLaunch& L, double lambda, int orth, bool folded = true) {
   const int n = L.n;
+  if (tail_enabled()) {
+    const int flags = TAIL_HS | ((orth & 1) ? TAIL_ORTH : 0) | ((orth & 2) ? TAIL_LAMBDA_DEV : 0) | (L.any_lin ? TAIL_TOPL : 0) | (folded ? 0 : TAIL_FOLD);
+    launch_tail(ctx, L, lambda, flags);
+    if (L.max_nblk_pts > 0) hipLaunchKernelGGL(k_ba_resub, dim3(L.max_nblk_pts, L.nwin), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr);
+    return;
+  }
+  if (!folded) launch_fold_deferred(ctx, L);
   launch_stitch(ctx, L);
   static const int solve_ver = getenv("SDSO_BA_SOLVE") ? atoi(getenv("SDSO_BA_SOLVE")) : 1;   // 2: lane = original row, nothing exchanged (A/B)
   if (solve_ver == 2) {
@@ -596,6 +623,13 @@ static void launch_solve(sdso_ctx* ctx, const BaLaunch& L, double lambda, int or
   }
   if (L.max_nblk_pts > 0) hipLaunchKernelGGL(k_ba_resub, dim3(L.max_nblk_pts, L.nwin), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr);
 }
+// the packed block of a batch whose latest accumulate deferred its folds: fold now (anyone but the tail kernel reads folded sums)
+static void ensure_folded(sdso_ctx* ctx, BaBatch* Bt) {
+  if (!Bt || Bt->folded) return;
+  launch_fold_deferred(ctx, Bt->L);
+  Bt->folded = true;
+}
+static void ensure_folded_win(sdso_ctx* ctx, BaWindowDev* W) { if (W->in_batch && reg_has(g_batches, ctx)) ensure_folded(ctx, reg_get(g_batches, ctx)); }
 static BaLaunch single(BaWindowDev* W) {
   BaLaunch L;
   L.d_arr = W->d_self; L.nwin = 1; L.max_nblk_res = std::max(W->nblk_res, 1); L.max_nblk_pts = W->nblk_pts;
@@ -750,6 +784,7 @@ extern "C" int sdso_ba_accumulate(sdso_ctx* ctx, int win) {
 extern "C" int sdso_ba_accum_dev(sdso_ctx* ctx, int win, void** dev_ptr) {
   GET_WIN();
   SDSO_REQUIRE(ctx, dev_ptr, "null out pointer");
+  ensure_folded_win(ctx, W);
   *dev_ptr = W->d.accum;
   return SDSO_OK;
 }
@@ -757,6 +792,8 @@ extern "C" int sdso_ba_accum_dev(sdso_ctx* ctx, int win, void** dev_ptr) {
 extern "C" int sdso_ba_get_accumulators(sdso_ctx* ctx, int win, float* packed) {
   GET_WIN();
   SDSO_REQUIRE(ctx, packed, "null buffer");
+  SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ensure_folded_win(ctx, W);
   SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
   SDSO_HIP(ctx, hipMemcpy(packed, W->d.accum, sizeof(float) * acc_floats(W->d.nf), hipMemcpyDeviceToHost));
   return SDSO_OK;
@@ -766,6 +803,7 @@ extern "C" int sdso_ba_get_accumulators(sdso_ctx* ctx, int win, float* packed) {
 extern "C" int sdso_ba_set_accumulators(sdso_ctx* ctx, int win, const float* packed) {
   GET_WIN();
   SDSO_REQUIRE(ctx, packed, "null buffer");
+  ensure_folded_win(ctx, W);
   SDSO_HIP(ctx, hipMemcpyAsync(W->d.accum, packed, sizeof(float) * acc_floats(W->d.nf), hipMemcpyHostToDevice, ctx->stream));
   SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
   W->accumulated = true;
@@ -1214,6 +1252,7 @@ void* ba_batch_accum_block(sdso_ctx* ctx, size_t* nfloats) {
   BaBatch* Bt = get_batch(ctx);
   if (!Bt) return nullptr;
   *nfloats = acc_floats(Bt->L.nf) * Bt->wins.size();
+  ensure_folded(ctx, Bt);
   return Bt->d_accum;
 }
 void* ba_window_accum_block(sdso_ctx* ctx, int win, size_t* nfloats) {
@@ -1221,14 +1260,21 @@ void* ba_window_accum_block(sdso_ctx* ctx, int win, size_t* nfloats) {
   if (!W) return nullptr;
   *nfloats = acc_floats(W->d.nf);
   W->accumulated = true;
+  ensure_folded_win(ctx, W);
   return W->d.accum;
 }
 }  // namespace sdso
-// phase 1 of one GN iteration for every window of the batch: linearize + applyRes + accumulate A/L/SC (enqueue only)
+namespace sdso {
+struct OptRun;
+static bool batch_defers_fold(sdso_ctx* ctx, BaBatch* Bt);   // below, next to the resident loop
+}
+// phase 1 of one GN iteration for every window of the batch: linearize + applyRes + accumulate A/L/SC (enqueue only).
+// Inside a single-rank resident loop (sdso_ba_batch_optimize_begin) the folds of the partial sums are left to the fused tail kernel of
+// sdso_ba_batch_solve / sdso_ba_batch_solve_step; whoever else looks at the packed block gets it folded first (ensure_folded).
 extern "C" int sdso_ba_batch_accumulate(sdso_ctx* ctx) {
   BaBatch* Bt = get_batch(ctx);
   if (!Bt) return sdso::fail(ctx, SDSO_ERR_STATE, "no batch");
-  launch_fused(ctx, batch_launch(Bt), Bt->materialize, Bt->gather);
+  Bt->folded = launch_fused(ctx, batch_launch(Bt), Bt->materialize, Bt->gather, 3, batch_defers_fold(ctx, Bt));
   SDSO_HIP(ctx, hipGetLastError());
   return SDSO_OK;
 }
@@ -1245,7 +1291,7 @@ extern "C" int sdso_ba_batch_linearize(sdso_ctx* ctx) {
 extern "C" int sdso_ba_batch_schur(sdso_ctx* ctx) {
   BaBatch* Bt = get_batch(ctx);
   if (!Bt) return sdso::fail(ctx, SDSO_ERR_STATE, "no batch");
-  launch_fused(ctx, batch_launch(Bt), Bt->materialize, Bt->gather, 2);
+  Bt->folded = launch_fused(ctx, batch_launch(Bt), Bt->materialize, Bt->gather, 2, batch_defers_fold(ctx, Bt));
   SDSO_HIP(ctx, hipGetLastError());
   return SDSO_OK;
 }
@@ -1266,13 +1312,16 @@ extern "C" int sdso_ba_batch_solve(sdso_ctx* ctx, double lambda, int orthogonali
   // solveSystem's overrides of lambda (EnergyFunctional.cpp:840-846), as in the single-window call
   if (Bt->W[0]->solverMode & SOLVER_USE_GN) lambda = 0;
   if (Bt->W[0]->solverMode & SOLVER_FIX_LAMBDA) lambda = 1e-5;
-  launch_solve(ctx, batch_launch(Bt), lambda, orthogonalize_x);
+  launch_solve(ctx, batch_launch(Bt), lambda, orthogonalize_x, Bt->folded);   // (the tail kernel folds for itself: the block stays as it is)
+  if (!tail_enabled()) Bt->folded = true;
   SDSO_HIP(ctx, hipGetLastError());
   return SDSO_OK;
 }
 extern "C" int sdso_ba_batch_accum_dev(sdso_ctx* ctx, void** dev_ptr, long* nfloats) {
   BaBatch* Bt = get_batch(ctx);
   if (!Bt) return sdso::fail(ctx, SDSO_ERR_STATE, "no batch");
+  ensure_folded(ctx, Bt);
+  Bt->eager_fold = true;          // the caller holds the address: every later accumulate leaves folded sums there
   if (dev_ptr) *dev_ptr = Bt->d_accum;
   if (nfloats) *nfloats = (long)(acc_floats(Bt->L.nf) * Bt->wins.size());
   return SDSO_OK;
@@ -1379,6 +1428,7 @@ struct OptRun {
   bool gated = false;      // energy-gated flow (setting_forceAceptStep = false): un-fused kernels + k_ba_opt_gate
   int lstride = 0;         // floats between the windows' calcLEnergy partials
   bool active = false;
+  bool local_only = false; // single-window call: never a collective, whatever communicator the ctx carries
   OptBufs* B = nullptr;
 };
 
@@ -1393,7 +1443,7 @@ static int opt_begin(sdso_ctx* ctx, OptRun& R, int stop_on_convergence) {
   }
   R.nranks = comm_nranks(ctx);
   // SDSO_OPT_FORCE_EXCHANGE: take the pack / all-gather path on a 1-rank communicator too (tests: the collectives of a 1-GPU box)
-  R.exchange = R.nranks > 1 || (comm_present(ctx) && getenv("SDSO_OPT_FORCE_EXCHANGE") != nullptr);
+  R.exchange = !R.local_only && (R.nranks > 1 || (comm_present(ctx) && getenv("SDSO_OPT_FORCE_EXCHANGE") != nullptr));
   R.gated = !R.W[0]->forceAccept;
   SDSO_REQUIRE(ctx, !(R.gated && R.exchange), "the energy-gated loop over sharded windows is not provided (forceAceptStep = true is; the energies would need one more exchange)");
   if (R.exchange) { int rc = comm_max_int(ctx, &cap); if (rc) return rc; }
@@ -1584,41 +1634,67 @@ static int opt_iterations(int nf, int mnumOptIts) {
   if (nf < 4) mnumOptIts = 15;
   return mnumOptIts;
 }
-// accumulate (fused linearisation + Schur part) -> [all-reduce] -> solve of iteration `it`
-static int opt_solve_phase(sdso_ctx* ctx, OptRun& R, int it) {
-  launch_fused(ctx, R.L, R.materialize, R.gather);
+static bool batch_defers_fold(sdso_ctx* ctx, BaBatch* Bt) { (void)ctx; return tail_enabled() && !Bt->eager_fold; }
+
+// solveSystem + doStepFromBackup + the loop's host part of iteration R.iteration.  Single rank: ONE launch of the fused tail kernel.
+// Sharded windows: tail kernel (stitch, solve, resubstitute, points' step) -> pack -> all-gather -> k_ba_opt_step, as before.
+static int opt_solve_step(sdso_ctx* ctx, OptRun& R, double lambda, int orth, bool folded) {
+  if (!tail_enabled()) {
+    launch_solve(ctx, R.L, lambda, orth, folded);
+    SDSO_HIP(ctx, hipGetLastError());
+    return opt_step(ctx, R);
+  }
+  const int flags = ((orth & 1) ? TAIL_ORTH : 0) | (R.L.any_lin ? TAIL_TOPL : 0) | (folded ? 0 : TAIL_FOLD);
+  const int nwin = (int)R.W.size();
+  const dim3 gp(std::max(R.L.max_nblk_pts, 1), nwin);
+  if (!R.exchange) {
+    launch_tail(ctx, R.L, lambda, flags | TAIL_STEP, R.iteration, 0, R.stop);
+    if (R.L.max_nblk_pts) hipLaunchKernelGGL(k_ba_resub_step, gp, dim3(BA_BLOCK), 0, ctx->stream, R.L.d_arr, R.iteration + 1, (float*)nullptr, 0);
+    SDSO_HIP(ctx, hipGetLastError());
+    R.iteration++;
+    return SDSO_OK;
+  }
+  launch_tail(ctx, R.L, lambda, flags);
+  if (R.L.max_nblk_pts) hipLaunchKernelGGL(k_ba_resub_step, gp, dim3(BA_BLOCK), 0, ctx->stream, R.L.d_arr, -1, R.B->d_sums, R.sums_stride);
+  const int rc = opt_consume(ctx, R, 0, false, R.L.max_nblk_pts > 0);
+  R.iteration++;
+  return rc;
+}
+// one whole GN iteration: accumulate (fused linearisation + Schur part) -> [all-reduce] -> solve + step
+static int opt_iteration(sdso_ctx* ctx, OptRun& R, int it) {
+  BaBatch* Bt = R.W[0]->in_batch ? get_batch(ctx) : nullptr;
+  const bool defer = tail_enabled() && !R.exchange && !(Bt && Bt->eager_fold);
+  bool folded = launch_fused(ctx, R.L, R.materialize, R.gather, 3, defer);
+  if (Bt) Bt->folded = folded;
   if (R.exchange) {
-    int rc = R.W[0]->in_batch ? sdso_ba_allreduce(ctx) : SDSO_ERR_STATE;
+    int rc = Bt ? sdso_ba_allreduce(ctx) : SDSO_ERR_STATE;
     if (rc) return rc;
+    folded = true;
   }
   const int sm = R.W[0]->solverMode;
   double lambda = opt_lambda(it);
   if (sm & SOLVER_USE_GN) lambda = 0;
   if (sm & SOLVER_FIX_LAMBDA) lambda = 1e-5;
   const int orth = (sm & SOLVER_ORTHOGONALIZE_X) || (it >= 2 && (sm & SOLVER_ORTHOGONALIZE_X_LATER));
-  launch_solve(ctx, R.L, lambda, orth ? 1 : 0);
-  SDSO_HIP(ctx, hipGetLastError());
-  return SDSO_OK;
+  return opt_solve_step(ctx, R, lambda, orth ? 1 : 0, folded);
 }
 
 int optimize_resident_single(sdso_ctx* ctx, BaWindowDev* W, int mnumOptIts, sdso_ba_opt_result_t* res) {
   OptRun R;
   R.L = single(W); R.W = {W};
   R.materialize = true; R.gather = 1;
+  // refused before anything is touched: opt_begin would already issue a collective and reset the window's residuals
+  if (comm_nranks(ctx) > 1) return sdso::fail(ctx, SDSO_ERR_STATE, "sdso_ba_optimize is a single-rank call; sharded windows use sdso_ba_batch_optimize");
+  R.local_only = true;
   int rc = opt_begin(ctx, R, 1);
   if (rc) return rc;
-  if (R.nranks > 1) return sdso::fail(ctx, SDSO_ERR_STATE, "sdso_ba_optimize is a single-rank call; sharded windows use sdso_ba_batch_optimize");
-  R.exchange = false;
   const int N = opt_iterations(W->d.nf, mnumOptIts);
   if (R.gated) {
     if ((rc = opt_gated_start(ctx, R))) return rc;
     for (int it = 0; it < N; it++) if ((rc = opt_gated_iteration(ctx, R, it))) return rc;
     return opt_finish(ctx, R, res);
   }
-  for (int it = 0; it < N; it++) {
-    if ((rc = opt_solve_phase(ctx, R, it))) return rc;
-    if ((rc = opt_step(ctx, R))) return rc;
-  }
+  for (int it = 0; it < N; it++) if ((rc = opt_iteration(ctx, R, it))) return rc;
   return opt_finish(ctx, R, res);
 }
 static std::map<sdso_ctx*, OptRun*> g_optruns;   // the batch loop in flight between sdso_ba_batch_optimize_begin and _end
@@ -1652,6 +1728,19 @@ extern "C" int sdso_ba_batch_step(sdso_ctx* ctx) {
   SDSO_REQUIRE(ctx, !R->gated, "sdso_ba_batch_step drives the accepted-step flow; energy-gated windows run through sdso_ba_batch_optimize");
   return opt_step(ctx, *R);
 }
+// sdso_ba_batch_solve + sdso_ba_batch_step as ONE enqueue: solveSystemF, resubstituteF, doStepFromBackup, setPrecalcValues / setDeltaF /
+// setNewFrameEnergyTH and the break test of the batch's resident loop run in one launch of the fused tail kernel (ba_tail.hip)
+extern "C" int sdso_ba_batch_solve_step(sdso_ctx* ctx, double lambda, int orthogonalize_x) {
+  if (!ctx || !reg_has(g_optruns, ctx)) return sdso::fail(ctx, SDSO_ERR_STATE, "sdso_ba_batch_optimize_begin first");
+  OptRun* R = reg_get(g_optruns, ctx);
+  BaBatch* Bt = get_batch(ctx);
+  SDSO_REQUIRE(ctx, Bt && Bt->W == R->W, "the batch changed since sdso_ba_batch_optimize_begin");
+  SDSO_REQUIRE(ctx, !R->gated, "sdso_ba_batch_solve_step drives the accepted-step flow; energy-gated windows run through sdso_ba_batch_optimize");
+  if (Bt->W[0]->solverMode & SOLVER_USE_GN) lambda = 0;
+  if (Bt->W[0]->solverMode & SOLVER_FIX_LAMBDA) lambda = 1e-5;
+  R->L = batch_launch(Bt);
+  return opt_solve_step(ctx, *R, lambda, orthogonalize_x ? 1 : 0, Bt->folded);
+}
 extern "C" int sdso_ba_batch_optimize_end(sdso_ctx* ctx, sdso_ba_opt_result_t* out) {
   if (!ctx || !reg_has(g_optruns, ctx)) return sdso::fail(ctx, SDSO_ERR_STATE, "sdso_ba_batch_optimize_begin first");
   OptRun* R = reg_get(g_optruns, ctx);
@@ -1672,7 +1761,7 @@ extern "C" int sdso_ba_batch_optimize(sdso_ctx* ctx, int mnumOptIts, sdso_ba_opt
     return sdso_ba_batch_optimize_end(ctx, out);
   }
   for (int it = 0; it < N; it++) {
-    if ((rc = opt_solve_phase(ctx, *R, it)) || (rc = opt_step(ctx, *R))) { free_optrun(ctx); return rc; }
+    if ((rc = opt_iteration(ctx, *R, it))) { free_optrun(ctx); return rc; }
   }
   return sdso_ba_batch_optimize_end(ctx, out);
 }

@@ -61,33 +61,39 @@ struct OptEnergies {
     return (i < B->nr && B->r_target[i] == B->nf - 1 && !B->r_lin[i]) ? B->r_newEnergyWO[i] : -1.f;
   }
 };
-// the k-th smallest (0-based) of the non-negative values: 4 radix passes over the bit patterns
+// the k-th smallest (0-based) of the non-negative values: 4 radix passes over the bit patterns.  NT threads call it together
+// (NT = 256 or 512); the 256 bins are owned by the first 256 threads.
+template <int NT>
 __device__ inline float opt_select(const OptEnergies& v, int k, unsigned* hist /* LDS 256 */, unsigned* sh /* LDS 6 */) {
   const int nranks = v.ranks(), cap = v.cap;
+  const int tid = threadIdx.x;
   unsigned prefix = 0, mask = 0;
   for (int shift = 24; shift >= 0; shift -= 8) {
-    hist[threadIdx.x] = 0;
+    if (tid < 256) hist[tid] = 0;
     __syncthreads();
     for (int r = 0; r < nranks; r++)
-      for (int j = threadIdx.x; j < cap; j += 256) {
+      for (int j = tid; j < cap; j += NT) {
         const float e = v.at(r, j);
         if (!(e >= 0)) continue;
         const unsigned key = __float_as_uint(e);
         if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255], 1u);
       }
     __syncthreads();
-    {
-      // bin b with  cum(b) <= k < cum(b) + hist[b]  (cum = exclusive prefix sum): thread b owns bin b; wave-level scan + the wave totals
-      const unsigned hb = hist[threadIdx.x];
-      unsigned inc = hb;
+    // bin b with  cum(b) <= k < cum(b) + hist[b]  (cum = exclusive prefix sum): thread b owns bin b; wave-level scan + the wave totals
+    unsigned hb = 0, inc = 0;
+    if (tid < 256) {
+      hb = hist[tid];
+      inc = hb;
 #pragma unroll
-      for (int o = 1; o < 64; o <<= 1) { const unsigned up = __shfl_up(inc, o, 64); if ((int)(threadIdx.x & 63) >= o) inc += up; }
-      if ((threadIdx.x & 63) == 63) sh[2 + (threadIdx.x >> 6)] = inc;
-      __syncthreads();
+      for (int o = 1; o < 64; o <<= 1) { const unsigned up = __shfl_up(inc, o, 64); if ((int)(tid & 63) >= o) inc += up; }
+      if ((tid & 63) == 63) sh[2 + (tid >> 6)] = inc;
+    }
+    __syncthreads();
+    if (tid < 256) {
       unsigned base = 0;
-      for (int w = 0; w < (int)(threadIdx.x >> 6); w++) base += sh[2 + w];
+      for (int w = 0; w < (int)(tid >> 6); w++) base += sh[2 + w];
       const unsigned excl = base + inc - hb;
-      if (hb > 0 && excl <= (unsigned)k && (unsigned)k < excl + hb) { sh[0] = threadIdx.x; sh[1] = excl; }
+      if (hb > 0 && excl <= (unsigned)k && (unsigned)k < excl + hb) { sh[0] = tid; sh[1] = excl; }
     }
     __syncthreads();
     prefix |= sh[0] << shift;
@@ -98,6 +104,18 @@ __device__ inline float opt_select(const OptEnergies& v, int k, unsigned* hist /
   return __uint_as_float(prefix);
 }
 
+// LDS of opt_step_body (the caller provides it: a kernel of its own declares one, the fused tail kernel aliases it onto dead buffers)
+struct OptStepSmem {
+  static constexpr int kStage = 8192;                   // energies staged for the radix passes (32 KiB); larger sets re-read global
+  float en[kStage];
+  unsigned hist[256], sh[8];
+  int cnt[8];
+  double esum[8];
+  float nid[8];
+  double w2c[8][12], c2w[8][12], step[8][8], affd[8][2];
+  float K[9], Ki[9], dlt[8][8], zb[8];
+};
+
 // One GN iteration's host part for every window.  gathered: [nranks][nwin][opt_pack_floats(cap)]; nullptr on a single rank: the
 // energies, energy partials and point sums are read where the kernels left them (no pack launch).
 //   last == 0:  consume the energies of the linearisation at the current state (lastEnergy, setNewFrameEnergyTH), take the step the
@@ -106,34 +124,26 @@ __device__ inline float opt_select(const OptEnergies& v, int k, unsigned* hist /
 //   last == 1 or the break test fired in the previous call: consume the energies only, then mark the window finished.
 //   last == 2 (energy-gated flow): the step only — the energies of the trial linearisation are consumed by k_ba_opt_gate afterwards;
 //               the tables and calibration scalars of the current state are kept for loadSateBackup, the break test is only recorded.
-__global__ __launch_bounds__(256) void k_ba_opt_step(const BaDev* __restrict__ wins, const float* __restrict__ gathered, int nranks, int cap, int iteration, int last,
-                                                     int stop_on_convergence, float stepsize, int unfused_parts, const float* __restrict__ sums, int sums_stride) {
-  BaDev& Bw = const_cast<BaDev&>(wins[blockIdx.y]);   // written: calibration scalars, finished
-  const BaDev B = Bw;                                   // read once: later loads need not be repeated after the stores below
-  if (ba_finished_lin(B)) return;
+// xsol: the solver's x of this iteration (global B.sol segment, or the fused tail kernel's copy in LDS); nres_f: nres[0] of the
+// accumulate (read from the packed block by the caller); wsums: this window's per-block point sums (sumID, sumNID pairs; nwsums pairs)
+template <int NT>
+__device__ __forceinline__ void opt_step_body(BaDev& Bw, const BaDev& B, OptStepSmem& S, const float* __restrict__ gathered, int nranks, int cap, int iteration, int last,
+                                              int stop_on_convergence, float stepsize, int unfused_parts, const float* __restrict__ wsums, int nwsums,
+                                              const double* __restrict__ x, float p_nres, int win, int nwin) {
   BaOptDev& O = *B.opt;
-  const int tid = threadIdx.x, nf = B.nf, nwin = gridDim.y;
+  const int tid = threadIdx.x, nf = B.nf;
   const int pf = opt_pack_floats(cap);
   const size_t rstride = (size_t)nwin * pf;
-  const float* g = gathered ? gathered + (size_t)blockIdx.y * pf : nullptr;
+  const float* g = gathered ? gathered + (size_t)win * pf : nullptr;
   OptEnergies en{g, rstride, nranks, cap, &B, O.newest_first};
   if (!g) { nranks = 1; en.cap = cap = max(B.nr - O.newest_first, 0); }
-  __shared__ unsigned hist[256], sh[6];
-  __shared__ int s_cnt[4];
-  __shared__ double s_esum[4];
-  __shared__ float s_nid[4];
-  constexpr int kStage = 8192;                          // energies staged in LDS for the radix passes (32 KiB); larger sets re-read global
-  __shared__ float s_en[kStage];
-  __shared__ double s_w2c[8][12], s_c2w[8][12], s_step[8][8];
-  __shared__ float s_K[9], s_Ki[9];
-  __shared__ float s_dlt[8][8], s_zb[8];
   const int phase = O.phase;
 
   // ---- every global input of the step below is requested here, before the quantile (LDS work) — the kernel is a chain of memory round
   // trips otherwise, and each of them stretches several-fold while another batch's linearisation saturates HBM
-  const double* x = B.sol + 3 * ((size_t)B.n * B.n + B.n);
   double p_x[8], p_st[10], p_zero[8], p_ev[12];
-  float p_ah[2][8], p_at[2][8], p_exp_h = 1, p_exp_t = 1;
+  constexpr int U = 512 / NT;                            // nf^2 * 8 <= 512 adjoint columns over NT threads
+  float p_ah[U][8], p_at[U][8], p_exp_h = 1, p_exp_t = 1;
   if (tid < nf) {
 #pragma unroll
     for (int i = 0; i < 8; i++) { p_x[i] = x[4 + 8 * tid + i]; p_zero[i] = O.state_zero[tid][i]; }
@@ -147,48 +157,46 @@ __global__ __launch_bounds__(256) void k_ba_opt_step(const BaDev* __restrict__ w
   }
   if (tid < nf * nf) { p_exp_h = O.ab_exposure[tid / nf]; p_exp_t = O.ab_exposure[tid % nf]; }
 #pragma unroll
-  for (int u = 0; u < 2; u++) {
-    const int e = tid + 256 * u;
+  for (int u = 0; u < U; u++) {
+    const int e = tid + NT * u;
     if (e < nf * nf * 8) {
       const int idx = e >> 3, j = e & 7;
 #pragma unroll
       for (int i = 0; i < 8; i++) { p_ah[u][i] = (float)B.t_adHost[(size_t)idx * 64 + i * 8 + j]; p_at[u][i] = (float)B.t_adTarget[(size_t)idx * 64 + i * 8 + j]; }
     }
   }
-  const float p_nres = B.accum[acc_off_nres(nf)];
   const int p_its = O.iterations;
 
   // ---- setNewFrameEnergyTH over every rank's residuals into the newest frame
   // one pass over global memory: the energies go to LDS (all loads of a thread in flight together), the radix passes read LDS
-  const bool staged = nranks * cap <= kStage;
+  const bool staged = nranks * cap <= OptStepSmem::kStage;
   int cnt = 0;
   for (int r = 0; r < nranks; r++)
-    for (int j = tid; j < cap; j += 256) {
+    for (int j = tid; j < cap; j += NT) {
       const float e = en.at(r, j);
-      if (staged) s_en[r * cap + j] = e;
+      if (staged) S.en[r * cap + j] = e;
       cnt += e >= 0 ? 1 : 0;
     }
   // the energy partials and the points' |idepth| sums of this rank (single-rank path), summed by all threads
   double esum = 0; float nidsum = 0;
   if (!g) {
     const int np_ = unfused_parts ? (B.nr + BA_BLOCK - 1) / BA_BLOCK : B.nchunks;
-    for (int b = tid; b < np_; b += 256) esum += B.e_part[b];
-    if (sums) {
-      const float* sm = sums + (size_t)blockIdx.y * sums_stride;
-      for (int b = tid; b < (B.np + BA_BLOCK - 1) / BA_BLOCK; b += 256) nidsum += sm[2 * b + 1];
-    }
+    for (int b = tid; b < np_; b += NT) esum += B.e_part[b];
+    if (wsums) for (int b = tid; b < nwsums; b += NT) nidsum += wsums[2 * b + 1];
     esum = wave_sum(esum); nidsum = wave_sum(nidsum);
-    if ((tid & 63) == 0) { s_esum[tid >> 6] = esum; s_nid[tid >> 6] = nidsum; }
+    if ((tid & 63) == 0) { S.esum[tid >> 6] = esum; S.nid[tid >> 6] = nidsum; }
   }
-  if (staged) { en.g = s_en; en.rstride = cap; en.nranks = nranks; en.cap = cap; }
+  if (staged) { en.g = S.en; en.rstride = cap; en.nranks = nranks; en.cap = cap; }
   cnt = (int)wave_sum((float)cnt);                       // <= nranks * cap < 2^24: exact in float
-  if ((tid & 63) == 0) s_cnt[tid >> 6] = cnt;
+  if ((tid & 63) == 0) S.cnt[tid >> 6] = cnt;
   __syncthreads();
-  const int M = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+  int M = 0;
+#pragma unroll
+  for (int w = 0; w < NT / 64; w++) M += S.cnt[w];
   float th = 12 * 12 * 8;
   if (M > 0) {
     const int nth = (int)(0.7f * M);
-    const float q = opt_select(en, nth, hist, sh);
+    const float q = opt_select<NT>(en, nth, S.hist, S.sh);
     const float nthElement = sqrtf(q);
     th = nthElement * 1.5f;
     th = 26.0f * 0.5f + th * (1 - 0.5f);
@@ -201,7 +209,7 @@ __global__ __launch_bounds__(256) void k_ba_opt_step(const BaDev* __restrict__ w
     O.frameTH_new = th;
     double e = 0;
     if (g) for (int r = 0; r < nranks; r++) { double er; __builtin_memcpy(&er, g + r * rstride + cap, 8); e += er; }
-    else e = (s_esum[0] + s_esum[1]) + (s_esum[2] + s_esum[3]);
+    else { e = (S.esum[0] + S.esum[1]) + (S.esum[2] + S.esum[3]); if (NT > 256) e += (S.esum[4] + S.esum[5]) + (S.esum[6] + S.esum[7]); }
     O.lastEnergy = e;
   }
   if (!gated && (phase == 1 || last)) {
@@ -209,9 +217,9 @@ __global__ __launch_bounds__(256) void k_ba_opt_step(const BaDev* __restrict__ w
     return;
   }
   if (gated) {   // what a rejected step puts back (loadSateBackup + setPrecalcValues, FullSystemOptimize.cpp:355-370)
-    for (int e = tid; e < nf * nf * 27; e += 256) O.bk_precalc[e] = B.t_precalc[e];
-    for (int e = tid; e < nf * nf * 8; e += 256) O.bk_adHTdelta[e] = B.t_adHTdelta[e];
-    for (int e = tid; e < nf * 16 + 8 + nf * 8; e += 256) O.bk_prior[e] = B.t_prior[e];
+    for (int e = tid; e < nf * nf * 27; e += NT) O.bk_precalc[e] = B.t_precalc[e];
+    for (int e = tid; e < nf * nf * 8; e += NT) O.bk_adHTdelta[e] = B.t_adHTdelta[e];
+    for (int e = tid; e < nf * 16 + 8 + nf * 8; e += NT) O.bk_prior[e] = B.t_prior[e];
     if (tid < 4) O.bk_cdelta[tid] = B.t_cdelta[tid];
     if (tid == 0) { O.bk_calib[0] = B.fxl; O.bk_calib[1] = B.fyl; O.bk_calib[2] = B.cxl; O.bk_calib[3] = B.cyl; O.bk_calib[4] = B.fxli; O.bk_calib[5] = B.fyli; }
     __syncthreads();
@@ -225,7 +233,7 @@ __global__ __launch_bounds__(256) void k_ba_opt_step(const BaDev* __restrict__ w
 #pragma unroll
     for (int i = 0; i < 10; i++) {
       const double st = i < 8 ? -p_x[i < 8 ? i : 0] : 0.0;     // step = -x (EnergyFunctional.cpp:978-985)
-      if (i < 8) s_step[f][i] = st;
+      if (i < 8) S.step[f][i] = st;
       ns[i] = p_st[i] + (double)stepsize * st;
     }
 #pragma unroll
@@ -238,20 +246,19 @@ __global__ __launch_bounds__(256) void k_ba_opt_step(const BaDev* __restrict__ w
     for (int i = 0; i < 3; i++) E.t[i] = p_ev[9 + i];
     const Se3 Wc = expSe3(sc) * E;                             // PRE_worldToCam = SE3::exp(w2c_leftEps()) * worldToCam_evalPT
     const Se3 Cw = inverse(Wc);
-    for (int i = 0; i < 9; i++) { s_w2c[f][i] = Wc.R[i]; s_c2w[f][i] = Cw.R[i]; }
-    for (int i = 0; i < 3; i++) { s_w2c[f][9 + i] = Wc.t[i]; s_c2w[f][9 + i] = Cw.t[i]; }
+    for (int i = 0; i < 9; i++) { S.w2c[f][i] = Wc.R[i]; S.c2w[f][i] = Cw.R[i]; }
+    for (int i = 0; i < 3; i++) { S.w2c[f][9 + i] = Wc.t[i]; S.c2w[f][9 + i] = Cw.t[i]; }
     // setDeltaF: delta_prior = state, delta = state - state_zero
 #pragma unroll
     for (int i = 0; i < 8; i++) {
       tp[nf * 8 + f * 8 + i] = ns[i];
       const double dl = ns[i] - p_zero[i];
       tp[nf * 16 + 8 + f * 8 + i] = dl;
-      s_dlt[f][i] = (float)dl;
+      S.dlt[f][i] = (float)dl;
     }
-    s_zb[f] = (float)(p_zero[7] * SCALE_B);
+    S.zb[f] = (float)(p_zero[7] * SCALE_B);
   }
-  __shared__ double s_affd[8][2];
-  if (tid < nf) { s_affd[tid][0] = SCALE_A * (p_st[6] + (double)stepsize * -p_x[6]); s_affd[tid][1] = SCALE_B * (p_st[7] + (double)stepsize * -p_x[7]); }
+  if (tid < nf) { S.affd[tid][0] = SCALE_A * (p_st[6] + (double)stepsize * -p_x[6]); S.affd[tid][1] = SCALE_B * (p_st[7] + (double)stepsize * -p_x[7]); }
   if (tid == 64) {
     double v[4], vs[4];
     float vsf[4];
@@ -266,7 +273,7 @@ __global__ __launch_bounds__(256) void k_ba_opt_step(const BaDev* __restrict__ w
     const float K[9] = {vsf[0], 0, vsf[2], 0, vsf[1], vsf[3], 0, 0, 1};
     float Ki[9];
     inv3f(K, Ki);
-    for (int i = 0; i < 9; i++) { s_K[i] = K[i]; s_Ki[i] = Ki[i]; }
+    for (int i = 0; i < 9; i++) { S.K[i] = K[i]; S.Ki[i] = Ki[i]; }
     float* cd = const_cast<float*>(B.t_cdelta);
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -282,33 +289,33 @@ __global__ __launch_bounds__(256) void k_ba_opt_step(const BaDev* __restrict__ w
     const int h = tid / nf, t = tid % nf;
     float* o = const_cast<float*>(B.t_precalc) + (size_t)(h * nf + t) * 27;
     Se3 Tw, Ch;
-    for (int i = 0; i < 9; i++) { Tw.R[i] = s_w2c[t][i]; Ch.R[i] = s_c2w[h][i]; }
-    for (int i = 0; i < 3; i++) { Tw.t[i] = s_w2c[t][9 + i]; Ch.t[i] = s_c2w[h][9 + i]; }
+    for (int i = 0; i < 9; i++) { Tw.R[i] = S.w2c[t][i]; Ch.R[i] = S.c2w[h][i]; }
+    for (int i = 0; i < 3; i++) { Tw.t[i] = S.w2c[t][9 + i]; Ch.t[i] = S.c2w[h][9 + i]; }
     const Se3 l = Tw * Ch;
     float R[9], tt[3], KR[9], K[9], Ki[9], o9[9], o3[3];
-    for (int i = 0; i < 9; i++) { R[i] = (float)l.R[i]; K[i] = s_K[i]; Ki[i] = s_Ki[i]; }
+    for (int i = 0; i < 9; i++) { R[i] = (float)l.R[i]; K[i] = S.K[i]; Ki[i] = S.Ki[i]; }
     for (int i = 0; i < 3; i++) tt[i] = (float)l.t[i];
     mul3f(K, R, KR);
     mul3f(KR, Ki, o9);         // PRE_KRKiTll
     mulv3f(K, tt, o3);         // PRE_KtTll
     double a2[2];
-    affFromTo(p_exp_h, p_exp_t, s_affd[h][0], s_affd[h][1], s_affd[t][0], s_affd[t][1], a2);
+    affFromTo(p_exp_h, p_exp_t, S.affd[h][0], S.affd[h][1], S.affd[t][0], S.affd[t][1], a2);
     for (int i = 0; i < 9; i++) o[i] = o9[i];
     for (int i = 0; i < 3; i++) o[9 + i] = o3[i];
     o[24] = (float)a2[0]; o[25] = (float)a2[1];
-    o[26] = s_zb[h];
+    o[26] = S.zb[h];
   }
   // adHTdeltaF[h + t*nf] = delta_h^T adHostF + delta_t^T adTargetF  (float arithmetic)
 #pragma unroll
-  for (int u = 0; u < 2; u++) {
-    const int e = tid + 256 * u;
+  for (int u = 0; u < U; u++) {
+    const int e = tid + NT * u;
     if (e < nf * nf * 8) {
       const int idx = e >> 3, h = idx % nf, t = idx / nf;
       float shh = 0, stt = 0;
 #pragma unroll
       for (int i = 0; i < 8; i++) {
-        shh += s_dlt[h][i] * p_ah[u][i];
-        stt += s_dlt[t][i] * p_at[u][i];
+        shh += S.dlt[h][i] * p_ah[u][i];
+        stt += S.dlt[t][i] * p_at[u][i];
       }
       const_cast<float*>(B.t_adHTdelta)[e] = shh + stt;
     }
@@ -318,7 +325,7 @@ __global__ __launch_bounds__(256) void k_ba_opt_step(const BaDev* __restrict__ w
   if (tid == 0) {
     float sumA = 0, sumB = 0, sumT = 0, sumR = 0;
     for (int f = 0; f < nf; f++) {
-      const double* st = s_step[f];
+      const double* st = S.step[f];
       sumA += st[6] * st[6];
       sumB += st[7] * st[7];
       sumT += st[0] * st[0] + st[1] * st[1] + st[2] * st[2];
@@ -327,7 +334,8 @@ __global__ __launch_bounds__(256) void k_ba_opt_step(const BaDev* __restrict__ w
     float sumNID = 0, numID = 0;
     if (g) for (int r = 0; r < nranks; r++) { sumNID += g[r * rstride + cap + 2]; numID += g[r * rstride + cap + 3]; }
     else {
-      sumNID = (s_nid[0] + s_nid[1]) + (s_nid[2] + s_nid[3]);
+      sumNID = (S.nid[0] + S.nid[1]) + (S.nid[2] + S.nid[3]);
+      if (NT > 256) sumNID += (S.nid[4] + S.nid[5]) + (S.nid[6] + S.nid[7]);
       numID = (float)B.np;
     }
     sumA /= nf; sumB /= nf; sumR /= nf; sumT /= nf;
@@ -340,6 +348,18 @@ __global__ __launch_bounds__(256) void k_ba_opt_step(const BaDev* __restrict__ w
   }
 }
 
+
+
+__global__ __launch_bounds__(256) void k_ba_opt_step(const BaDev* __restrict__ wins, const float* __restrict__ gathered, int nranks, int cap, int iteration, int last,
+                                                     int stop_on_convergence, float stepsize, int unfused_parts, const float* __restrict__ sums, int sums_stride) {
+  BaDev& Bw = const_cast<BaDev&>(wins[blockIdx.y]);   // written: calibration scalars, finished
+  const BaDev B = Bw;                                   // read once: later loads need not be repeated after the stores below
+  if (ba_finished_lin(B)) return;
+  __shared__ OptStepSmem S;
+  opt_step_body<256>(Bw, B, S, gathered, nranks, cap, iteration, last, stop_on_convergence, stepsize, unfused_parts,
+                     sums ? sums + (size_t)blockIdx.y * sums_stride : nullptr, (B.np + BA_BLOCK - 1) / BA_BLOCK,
+                     B.sol + 3 * ((size_t)B.n * B.n + B.n), B.accum[acc_off_nres(B.nf)], blockIdx.y, gridDim.y);
+}
 
 // The energy gate of one GN iteration (FullSystemOptimize.cpp:961-990) for every window, after the trial linearisation:
 //   which 0: the loop's start — lastEnergy, setNewFrameEnergyTH, lastEnergyL, lastEnergyM of the uploaded state (:895-906)
@@ -383,7 +403,7 @@ __global__ __launch_bounds__(256) void k_ba_opt_gate(const BaDev* __restrict__ w
   float th = 12 * 12 * 8;
   if (M > 0) {
     const int nth = (int)(0.7f * M);
-    const float q = opt_select(en, nth, hist, sh);
+    const float q = opt_select<256>(en, nth, hist, sh);
     const float nthElement = sqrtf(q);
     th = nthElement * 1.5f;
     th = 26.0f * 0.5f + th * (1 - 0.5f);

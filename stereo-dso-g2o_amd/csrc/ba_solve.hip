@@ -865,6 +865,82 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_resub(const BaDev* __restrict__
   po[PO_STEP] = -b * hdi;
 }
 
+// resubstituteFPt + backupState + doStepFromBackup (stepfacD = 1) of the points in ONE pass over the point data (k_ba_resub followed
+// by k_ba_points_op op 3), after the fused tail kernel of the resident loop.  expect_iterations >= 0: the window takes part iff its
+// loop has taken exactly that many steps — the tail kernel that just ran may have set `finished` for the NEXT iteration (the break
+// test fires after the step it belongs to); < 0: the plain `finished` test (sharded windows: k_ba_opt_step has not run yet).
+__global__ __launch_bounds__(BA_BLOCK) void k_ba_resub_step(const BaDev* __restrict__ wins, int expect_iterations, float* __restrict__ sums, int sums_stride) {
+  const BaDev& B = wins[blockIdx.y];
+  if (expect_iterations >= 0 ? (ba_finished_lin(B) || B.opt->iterations != expect_iterations) : ba_finished(B)) return;
+  const int p = blockIdx.x * BA_BLOCK + threadIdx.x;
+  float sID = 0, sNID = 0;
+  if (p < B.np) {
+    float* po = B.p_out + (size_t)p * 16;
+    const double* x = B.sol + 3 * ((size_t)B.n * B.n + B.n);
+    const int nf = B.nf;
+    const float* recs = B.r_rec + (size_t)p * nf * 16;
+    const int h = B.p_host[p];
+    float4 j0[8], j1[8], xa0[8], xa1[8];
+    bool good[8];
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+      good[t] = false;
+      if (t < nf) {
+        const float* rec = recs + t * 16;
+        good[t] = (((int)rec[RR_FLAGS]) & 1) != 0;
+        j0[t] = *reinterpret_cast<const float4*>(rec); j1[t] = *reinterpret_cast<const float4*>(rec + 4);
+        const float* xa = B.t_xAd + (size_t)(h * nf + t) * 8;
+        xa0[t] = *reinterpret_cast<const float4*>(xa); xa1[t] = *reinterpret_cast<const float4*>(xa + 4);
+      }
+    }
+    const float4 hA = *reinterpret_cast<const float4*>(po + PO_HCD_A), hL = *reinterpret_cast<const float4*>(po + PO_HCD_L);
+    const float bsum = po[PO_BDSUM], hdi = po[PO_HDI];
+    const double x0 = x[0], x1 = x[1], x2 = x[2], x3 = x[3];
+    float4 g = B.p_geo[p];
+    int ngood = 0;
+#pragma unroll
+    for (int t = 0; t < 8; t++) ngood += good[t] ? 1 : 0;
+    float st = 0.f;
+    if (ngood != 0) {
+      float b = bsum;
+      float d = 0;
+      d += (float)x0 * (hA.x + hL.x);
+      d += (float)x1 * (hA.y + hL.y);
+      d += (float)x2 * (hA.z + hL.z);
+      d += (float)x3 * (hA.w + hL.w);
+      b -= d;
+#pragma unroll
+      for (int t = 0; t < 8; t++) {       // residuals in target order
+        if (!good[t]) continue;
+        float sacc = 0;
+        sacc += xa0[t].x * j0[t].x; sacc += xa0[t].y * j0[t].y; sacc += xa0[t].z * j0[t].z; sacc += xa0[t].w * j0[t].w;
+        sacc += xa1[t].x * j1[t].x; sacc += xa1[t].y * j1[t].y; sacc += xa1[t].z * j1[t].z; sacc += xa1[t].w * j1[t].w;
+        b -= sacc;
+      }
+      st = -b * hdi;
+    }
+    po[PO_STEP] = st;
+    po[PO_BACKUP] = g.z;
+    const float bk = g.z, nid = bk + 1.0f * st;
+    g.z = nid; g.w = nid;     // setIdepth + setIdepthZero
+    B.p_geo[p] = g;
+    B.p_delta[p] = nid - nid;
+    sID = st * st; sNID = fabsf(bk);
+  }
+  if (sums) {
+    __shared__ float r0[BA_BLOCK / 64], r1[BA_BLOCK / 64];
+    const float a = wave_sum(sID), b = wave_sum(sNID);
+    if ((threadIdx.x & 63) == 0) { r0[threadIdx.x >> 6] = a; r1[threadIdx.x >> 6] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float s0 = 0, s1 = 0;
+      for (int w = 0; w < BA_BLOCK / 64; w++) { s0 += r0[w]; s1 += r1[w]; }
+      float* so = sums + (size_t)blockIdx.y * sums_stride;
+      so[blockIdx.x * 2] = s0; so[blockIdx.x * 2 + 1] = s1;
+    }
+  }
+}
+
 // FullSystem::backupState / doStepFromBackup / loadSateBackup for the points.  op: 0 backup, 1 step, 2 restore
 // op 3 = backup + step in one pass (the resident loop never restores)
 __global__ __launch_bounds__(BA_BLOCK) void k_ba_points_op(const BaDev* __restrict__ wins, int op, float stepfacD, float* __restrict__ sums /* per block: sumID, sumNID */,

@@ -1,0 +1,450 @@
+// The tail of one windowed-BA Gauss-Newton iteration as ONE kernel: a persistent 512-thread workgroup per window folds the
+// accumulator partials, stitches the (8 nf + 4)^2 system straight into LDS, factorises it in registers, solves and runs the
+// loop's host part — nothing between these phases leaves the CU.  It replaces the launches
+//   k_ba_fold_all, k_ba_stitch_pre, k_ba_stitch, k_ba_solve, k_ba_opt_step       (k_ba_resub + k_ba_points_op become k_ba_resub_step)
+// (seven dependent launches whose intermediate results — three stitched 68x68 blocks, the Schur pre-products, x — round-tripped
+// through global memory; profiles/r02_*: 0.45 ms of a 0.83 ms step).  Reference (paths under /root/reference/src):
+//   AccumulatedTopHessianSSE::stitchDoubleInternal / stitchDoubleMT   OptimizationBackend/AccumulatedTopHessian.cpp:265-337, .h:95-148
+//   AccumulatedSCHessianSSE::stitchDoubleInternal / stitchDoubleMT    OptimizationBackend/AccumulatedSCHessian.cpp:106-195, .h:96-135
+//   EnergyFunctional::solveSystemF (default LDLT branch)              OptimizationBackend/EnergyFunctional.cpp:838-995
+//   EnergyFunctional::resubstituteF_MT / resubstituteFPt              OptimizationBackend/EnergyFunctional.cpp:272-341
+//   FullSystem::backupState / doStepFromBackup (points)               FullSystem/FullSystemOptimize.cpp:207-351
+//   the loop's host part: see ba_opt.hip (opt_step_body)
+// Phases (B = workgroup barrier):
+//   P1  all threads: fold the per-chunk top partials per (host,target) pair into LDS (fixed order), Hcc / bc over the hosts, the
+//       diagonals of adTarget, bM + HM delta; then wave h: the Schur pre-products of host h, S1(h,y) = sum_j adHost(h,j) D(h,j,y)
+//       (lane = column, eight running sums per lane, adHost rows through the scalar cache)                                   B
+//   P2  one wave per output tile (8x8 frame-frame, frame-calibration, calibration): top-A + top-L (+ priors) + marginalisation
+//       prior - Schur complement / (1 + lambda), written as ONE finished element into the LDS matrix M                       B
+//   P3  SVecI, Eigen's pivot order from the scaled diagonal (ba_ldlt.h)                                                       B
+//   P4  the scaled, permuted system As (mirrored from the lower triangle, like Eigen reads it)                               B
+//   P5  wave 0: register-resident LDL^T + both substitutions (ba_ldlt.h)                                                      B
+//   P6  x = SVecI * y back in original order, nullspace projection, x and the adjoint products xAd                           B
+//   P7  opt_step_body: setNewFrameEnergyTH, frames / calibration step, SE3::exp, precalc + delta tables, break test
+// The back-substitution and the points' step stay a kernel of their own over the points (k_ba_resub_step): they stream 0.6 KB per
+// point (1.2 MB per window), which ONE CU pulls at ~50 GB/s — 24 us — while a grid over the points takes a few; and the break test
+// does not wait for them: doStepFromBackup's sumNID is the sum of the BACKUP idepths, known before the step (summed in P1).
+// S2(y,x) of the previous kernels is S1(y,x)^T here: D(i,j,k) = D(i,k,j)^T holds exactly in the reference (the same products in
+// the same order) and up to float rounding in the MFMA accumulation, so the transposed pre-product stands in for the second one.
+#include "ba_ldlt.h"
+
+namespace sdso {
+
+constexpr int TAIL_NT = 512;
+constexpr int TAIL_FOLD = 1;        // fold the top partials / per-host Hcc here (else: the packed block holds folded, possibly all-reduced sums)
+constexpr int TAIL_HS = 2;          // write lastHS / lastbS (sdso_ba_solve's HS, bS outputs)
+constexpr int TAIL_STEP = 16;       // the loop's host part (opt_step_body), single rank
+constexpr int TAIL_ORTH = 32;       // x -= P x
+constexpr int TAIL_LAMBDA_DEV = 64; // lambda of the window's resident loop (energy-gated flow)
+constexpr int TAIL_TOPL = 128;      // the linearised (L) top sums are not zero: read them from the packed block
+
+// LDS layout (bytes); the big regions are reused by phases that do not overlap
+struct TailLds {
+  static constexpr int kCol = 0;                                  // 64 d   column exchange of the factorisation (low address: immediate offsets)
+  static constexpr int kVec = kCol + 64 * 8;                      // 8 vectors of 72 d: bF sv bp xp xv bMt dg tmp
+  static constexpr int kPos = kVec + 8 * 72 * 8;                  // 72 i pos, 72 i perm
+  static constexpr int kKeys = kPos + 2 * 72 * 4;                 // 72 u64
+  static constexpr int kAtd = kKeys + 72 * 8;                     // 64 pairs x 8 d: diagonals of adTarget
+  static constexpr int kXad = kAtd + 64 * 8 * 8;                  // 512 f
+  static constexpr int kMisc = kXad + 512 * 4;                    // 64 f: Hcc 16, bc 4, nres 2, sums 2, flags
+  static constexpr int kM = kMisc + 64 * 4;                       // 68 x 70 d: the finished system (then L^T of the factorisation)
+  static constexpr int kR1 = kM + LDLT_NMAX * LDLT_LD * 8;        // union: {accA 64 x 92 f | S1 64 x 64 d}, As 68 x 70 d, OptStepSmem
+  static constexpr int kAccA = kR1;
+  static constexpr int kS1 = kAccA + 64 * 92 * 4;
+  static constexpr int kG = kS1 + 64 * 64 * 8;                    // 64 pairs x 64 d: adHost, staged once (lives until the end of P6)
+  static constexpr int kE = kG + 64 * 64 * 8;                     // 64 pairs x (32 + 8) f: the Schur frame-calibration sums accE, accEB
+  static constexpr int kEnd1 = kE + 64 * 40 * 4;
+  static constexpr int kEnd2 = kR1 + LDLT_NMAX * LDLT_LD * 8;
+  static constexpr int kEnd3 = kR1 + (int)sizeof(OptStepSmem) + 16;
+  static_assert(kEnd2 <= kG && kEnd3 <= kG, "As / OptStepSmem must not reach the adHost stage");
+  static constexpr int kBytes = kEnd1 > kEnd2 ? (kEnd1 > kEnd3 ? kEnd1 : kEnd3) : (kEnd2 > kEnd3 ? kEnd2 : kEnd3);
+};
+
+#ifdef SDSO_TAIL_STAMPS   // diagnostic build only (make EXTRA=-DSDSO_TAIL_STAMPS, tools/dbg_tail_stamps.py): x[0..] carry cycle counts of the phases
+#define TSTAMP(i) do { if (threadIdx.x == 0) tstamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TSTAMP(i) do { } while (0)
+#endif
+typedef const double __attribute__((address_space(4)))* tail_cdptr;   // uniform read-only data through the scalar cache
+
+// element (r,c) of the 13x13 AccumulatorApprox matrix from its 91 packed sums, any address space
+template <class P> __device__ __forceinline__ double tail_acc13(P p, int r, int c) { return (double)p[acc13_index(r, c)]; }
+
+// NFT > 0 fixes the keyframe count at compile time (the full window of 8: every loop over hosts / targets unrolls, so the loads of all
+// its trips are in flight together and independent dependency chains interleave); NFT = 0: runtime nf.
+template <int NFT>
+__global__ __launch_bounds__(TAIL_NT) void k_ba_tail(const BaDev* __restrict__ wins, double lambda, int flags, int iteration, int last,
+                                                     int stop_on_convergence) {
+  BaDev& Bw = const_cast<BaDev&>(wins[blockIdx.x]);
+  const BaDev B = Bw;
+  if (ba_finished_lin(B)) return;
+  __shared__ __attribute__((aligned(16))) char tail_smem[TailLds::kBytes];
+  double* col = (double*)(tail_smem + TailLds::kCol);
+  double* vec = (double*)(tail_smem + TailLds::kVec);
+  double *bF = vec, *sv = vec + 72, *bp = vec + 144, *xp = vec + 216, *xv = vec + 288, *bMt = vec + 360, *dg = vec + 432, *tmpv = vec + 504;
+  int* pos = (int*)(tail_smem + TailLds::kPos);
+  int* perm = pos + 72;
+  unsigned long long* keys = (unsigned long long*)(tail_smem + TailLds::kKeys);
+  double* atd = (double*)(tail_smem + TailLds::kAtd);
+  float* xAd_s = (float*)(tail_smem + TailLds::kXad);
+  float* misc = (float*)(tail_smem + TailLds::kMisc);
+  double* M = (double*)(tail_smem + TailLds::kM);
+  float* accA = (float*)(tail_smem + TailLds::kAccA);
+  double* S1 = (double*)(tail_smem + TailLds::kS1);
+  double* G = (double*)(tail_smem + TailLds::kG);
+  float* Es = (float*)(tail_smem + TailLds::kE);
+  double* As = (double*)(tail_smem + TailLds::kR1);
+  OptStepSmem& OS = *(OptStepSmem*)(tail_smem + ((TailLds::kR1 + 15) & ~15));
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nf = NFT ? NFT : B.nf, nf2 = nf * nf, n = NFT ? 8 * NFT + 4 : B.n;
+  float nres_f = 0.f;
+#ifdef SDSO_TAIL_STAMPS
+  unsigned long long tstamps[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  TSTAMP(0);
+
+  if (!ba_finished(B)) {     // (a window whose break test fired only consumes the energies of its final linearisation: P8)
+  if (flags & TAIL_LAMBDA_DEV) lambda = B.opt->lambda;
+  const double f = (double)1.0f / (1 + lambda);
+  const double* adH = B.t_adHost;
+  const double* adT = B.t_adTarget;
+  const float* accum = B.accum;
+  // ------------------------------------------------------------------ P1
+  {
+    const bool fold = (flags & TAIL_FOLD) != 0;
+    for (int e = tid; e < nf2 * 92; e += TAIL_NT) {
+      const int pair = e / 92, k = e - pair * 92;
+      float s = 0.f;
+      if (fold) {
+        const int cb = B.pair_chunk_beg[pair], ce = B.pair_chunk_beg[pair + 1];
+        for (int ck = cb; ck < ce; ck++) s += B.top_part[(size_t)ck * 92 + k];
+      } else if (k < 91) s = accum[acc_off_topA(nf) + (size_t)pair * 91 + k];
+      accA[e] = s;
+    }
+    if (tid < 20) {
+      float s = 0.f;
+      if (fold) for (int h = 0; h < nf; h++) s += B.sc_part[(size_t)h * 20 + tid];
+      else s = accum[acc_off_Hcc(nf) + tid];
+      misc[tid] = s;
+    }
+    for (int e = tid; e < nf2 * 8; e += TAIL_NT) atd[e] = adT[(size_t)(e >> 3) * 64 + (e & 7) * 9];
+    for (int e = tid; e < nf2 * 64; e += TAIL_NT) G[e] = adH[e];
+    for (int e = tid; e < nf2 * 40; e += TAIL_NT) Es[e] = accum[acc_off_E(nf) + e];      // accE (nf2 x 32) and accEB (nf2 x 8) are contiguous
+    float nid = 0.f;                          // sum |idepth| of the points as they stand: the break test's sumNID (doStepFromBackup sums the
+    if (flags & TAIL_STEP)                    //   BACKUP values, FullSystemOptimize.cpp:262 — known before the step is taken)
+      for (int p = tid; p < B.np; p += TAIL_NT) nid += fabsf(B.p_geo[p].z);
+    if (tid >= 64 && tid < 64 + 4 * 72) {     // bM_top = bM + HM * delta   (EnergyFunctional.cpp:870): four threads per row, every load of a
+      const int i = (tid - 64) >> 2, q = tid & 3;   //   thread in flight together; their partial sums are added in a fixed order
+      const double* delta = B.t_prior + nf * 16 + 4;
+      double part = 0;
+      if (i < n) {
+        const double* hm = B.t_HM + (size_t)i * n;
+        double hv[17], dl[17];
+#pragma unroll
+        for (int u = 0; u < 17; u++) { const int k = q + 4 * u; hv[u] = k < n ? hm[k] : 0.0; dl[u] = k < n ? delta[k] : 0.0; }
+#pragma unroll
+        for (int u = 0; u < 17; u++) part += hv[u] * dl[u];
+      }
+      const double p1 = __shfl_xor(part, 1, 64);
+      part += p1;
+      const double p2 = __shfl_xor(part, 2, 64);
+      part += p2;
+      if (i < n && q == 0) bMt[i] = B.t_bM[i] + part;
+    }
+    nid = wave_sum(nid);
+    if (lane == 0) misc[24 + wv] = nid;
+    __syncthreads();
+    TSTAMP(1);
+    // S1(h,y)[a][c], h = this wave, lane = (y,c): eight sums per lane, j outer / m inner like k_ba_stitch_pre.  The rows of adHost(h,j)
+    // are wave-uniform LDS reads (broadcast); the eight D values of a (j, lane) are requested before the FMAs of the previous j finish.
+    for (int h = wv; h < nf; h += TAIL_NT / 64) {
+      const int y = lane >> 3;
+      double w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      const float* accD = accum + acc_off_D(nf);
+      const float* Dbase = accD + (size_t)(h + nf2 * (y < nf ? y : 0)) * 64 + (lane & 7);
+      float d[8], dn[8];
+#pragma unroll
+      for (int m = 0; m < 8; m++) d[m] = Dbase[m * 8];
+      for (int j = 0; j < nf; j++) {
+        if (j + 1 < nf) {
+          const float* Dp = Dbase + (size_t)nf * (j + 1) * 64;
+#pragma unroll
+          for (int m = 0; m < 8; m++) dn[m] = Dp[m * 8];
+        }
+        const double* L = G + (size_t)(h + nf * j) * 64;
+#pragma unroll
+        for (int a = 0; a < 8; a++) {
+#pragma unroll
+          for (int m = 0; m < 8; m++) w[a] = __builtin_fma(L[a * 8 + m], (double)d[m], w[a]);
+        }
+#pragma unroll
+        for (int m = 0; m < 8; m++) d[m] = dn[m];
+      }
+      if (y < nf) {
+#pragma unroll
+        for (int a = 0; a < 8; a++) S1[(size_t)(h + nf * y) * 64 + a * 8 + (lane & 7)] = w[a];
+      }
+    }
+  }
+  __syncthreads();
+  TSTAMP(2);
+  if (flags & TAIL_FOLD) {                  // nres[0] (the packed block's slot too: sdso_ba_optimize reports it), nres[1] = 0
+    if (tid == 0) {
+      float s = 0.f;
+      for (int p = 0; p < nf2; p++) s += accA[p * 92 + 91];
+      misc[20] = s; misc[21] = 0.f;
+      B.accum[acc_off_nres(nf)] = s; B.accum[acc_off_nres(nf) + 1] = 0.f;
+    }
+  } else if (tid == 0) { misc[20] = accum[acc_off_nres(nf)]; misc[21] = accum[acc_off_nres(nf) + 1]; }
+
+  // ------------------------------------------------------------------ P2: one wave per output tile
+  {
+    const int a = lane >> 3, c = lane & 7;
+    const bool topL = (flags & TAIL_TOPL) != 0;
+    const float* accL = accum + acc_off_topL(nf);
+    const float* accD = accum + acc_off_D(nf);
+    const float* accE = Es;
+    const float* accEB = Es + nf2 * 32;
+    const double* prior = B.t_prior;
+    const size_t blk = (size_t)n * n + n;
+    double* lastHS = B.sol + 3 * blk + n;
+    double* lastbS = lastHS + (size_t)n * n;
+    const bool wr_hs = (flags & TAIL_HS) != 0;
+    auto at = [&](int p, int q, int d) { return atd[(p + nf * q) * 8 + d]; };
+    const double* adHs = G;                             // adHost from its LDS stage
+    int idxA[8];                                       // packed index of A8[a][nn], nn = 0..7 (row a of the frame block)
+#pragma unroll
+    for (int nn = 0; nn < 8; nn++) idxA[nn] = acc13_index(4 + a, 4 + nn);
+    // element (i, j) of the finished system from its three parts
+    auto finish = [&](int i, int j, double oA, double oL, double oS, double hm) {
+      double v = oL + hm + oA;                              // HFinal_top = HL + HM + HA        (:906)
+      if (wr_hs) lastHS[(size_t)i * n + j] = v - oS;       // :909
+      if (i == j) v *= (1 + lambda);                        // :914-916
+      v -= oS * f;                                          // :918
+      M[i * LDLT_LD + j] = v;
+    };
+    // top part of a frame-frame tile from 91-sum blocks `acc` (LDS or global): the expressions of k_ba_stitch
+    auto top_ff = [&](auto acc, int x, int y, bool isL) -> double {
+      double out = 0;
+      if (x == y) {
+#pragma unroll
+        for (int t = 0; t < nf; t++) {                      // H[h,h] += AH A AH^T over the targets of host x
+          const int aidx = x + nf * t;
+          const double* AH = adHs + (size_t)aidx * 64;
+          auto ap = acc + (size_t)aidx * (isL ? 91 : 92);
+          double ra[8], rc[8];
+#pragma unroll
+          for (int q = 0; q < 8; q++) { ra[q] = AH[a * 8 + q]; rc[q] = AH[c * 8 + q]; }
+          double tv = 0;                                    // T[a][c] = sum_nn A8[a][nn] AH[c][nn]: this lane's element of A AH^T
+#pragma unroll
+          for (int nn = 0; nn < 8; nn++) tv += (double)ap[idxA[nn]] * rc[nn];
+          double s = 0;                                     // (AH T)[a][c]: column c of T sits on the lanes (mm, c)
+#pragma unroll
+          for (int mm = 0; mm < 8; mm++) s += ra[mm] * __shfl(tv, mm * 8 + c, 64);
+          out += s;
+        }
+#pragma unroll
+        for (int h = 0; h < nf; h++)                        // H[t,t] += AT A AT^T over the hosts of target x
+          out += at(h, x, a) * tail_acc13(acc + (size_t)(h + nf * x) * (isL ? 91 : 92), 4 + a, 4 + c) * at(h, x, c);
+        {                                                   // H[h,t] += AH A AT^T of the pair (x,x)
+          const double* AH = adHs + (size_t)(x + nf * x) * 64;
+          auto ap = acc + (size_t)(x + nf * x) * (isL ? 91 : 92);
+          double s = 0;
+#pragma unroll
+          for (int mm = 0; mm < 8; mm++) s += AH[a * 8 + mm] * tail_acc13(ap, 4 + mm, 4 + c);
+          out += s * at(x, x, c);
+        }
+      } else {
+        const double* AH1 = adHs + (size_t)(x + nf * y) * 64;
+        auto ap1 = acc + (size_t)(x + nf * y) * (isL ? 91 : 92);
+        const double* AH2 = adHs + (size_t)(y + nf * x) * 64;
+        auto ap2 = acc + (size_t)(y + nf * x) * (isL ? 91 : 92);
+        double s1 = 0, s2 = 0;
+#pragma unroll
+        for (int mm = 0; mm < 8; mm++) { s1 += AH1[a * 8 + mm] * tail_acc13(ap1, 4 + mm, 4 + c); s2 += AH2[c * 8 + mm] * tail_acc13(ap2, 4 + mm, 4 + a); }
+        const double m_lo = x < y ? s1 * at(x, y, c) : s2 * at(y, x, a);      // M(lo,hi) first, then M(hi,lo)^T: the order the CPU adds them in
+        const double m_hi = x < y ? s2 * at(y, x, a) : s1 * at(x, y, c);
+        out = m_lo + m_hi;
+      }
+      return out;
+    };
+    auto top_fc = [&](auto acc, int x, bool isL) -> double {   // lanes (a, c < 4): H[frame x row a][calib c]; c == 4: b
+      double hv = 0;
+      if (c < 5) {
+        const int colx = c < 4 ? c : 12;
+#pragma unroll
+        for (int k = 0; k < 2 * nf; k++) {
+          const int h = k < nf ? x : k - nf, t = k < nf ? k : x;
+          auto ap = acc + (size_t)(h + nf * t) * (isL ? 91 : 92);
+          double s = 0;
+          if (k < nf) {
+            const double* Am = adHs + (size_t)(h + nf * t) * 64;
+#pragma unroll
+            for (int kk = 0; kk < 8; kk++) s += Am[a * 8 + kk] * tail_acc13(ap, 4 + kk, colx);
+          } else s = at(h, t, a) * tail_acc13(ap, 4 + a, colx);      // adTarget is diagonal
+          hv += s;
+        }
+      }
+      return hv;
+    };
+    const int njobs = nf2 + nf + 1;
+    // diagonal tiles first (they are the long ones: one per wave), then the rest round-robin
+    for (int jj = wv; jj < njobs; jj += TAIL_NT / 64) {
+      int tile;
+      if (jj < nf) tile = jj * (nf + 1);                       // (x, x)
+      else if (jj < nf2) { const int o = jj - nf; const int x = o / (nf - 1), r = o % (nf - 1); const int y = r < x ? r : r + 1; tile = x + nf * y; }
+      else tile = jj;
+      if (tile < nf2) {
+        const int x = tile % nf, y = tile / nf;
+        const double hm = B.t_HM[(size_t)(4 + x * 8 + a) * n + (4 + y * 8 + c)];      // requested first, consumed last
+        double dv[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) dv[i] = i < nf ? (double)accD[(size_t)(i + nf * x + nf2 * y) * 64 + lane] : 0.0;
+        const double oA = top_ff(accA, x, y, false);
+        double oL = topL ? top_ff(accL, x, y, true) : 0.0;
+        if (x == y && a == c) oL += prior[x * 8 + a];
+        // Schur complement (AccumulatedSCHessian.cpp:151-171, factored as in k_ba_stitch)
+        double oS = S1[(size_t)(x + nf * y) * 64 + lane] * at(x, y, c);
+        oS += at(y, x, a) * S1[(size_t)(y + nf * x) * 64 + c * 8 + a];
+#pragma unroll
+        for (int i = 0; i < 8; i++) if (i < nf) oS += at(i, x, a) * dv[i] * at(i, y, c);
+        if (x == y)
+#pragma unroll
+          for (int k = 0; k < nf; k++) {
+            const double* s1 = S1 + (size_t)(x + nf * k) * 64 + a * 8;
+            const double* R = adHs + (size_t)(x + nf * k) * 64 + c * 8;
+            double s = 0;
+#pragma unroll
+            for (int nn = 0; nn < 8; nn++) s += s1[nn] * R[nn];
+            oS += s;
+          }
+        finish(4 + x * 8 + a, 4 + y * 8 + c, oA, oL, oS, hm);
+      } else if (tile < nf2 + nf) {
+        const int x = tile - nf2;
+        const double hA = top_fc(accA, x, false);
+        double hL = topL ? top_fc(accL, x, true) : 0.0;
+        double hS = 0;
+        if (c < 5) {
+#pragma unroll
+          for (int k = 0; k < 2 * nf; k++) {
+            const int i = k < nf ? x : k - nf, j = k < nf ? k : x;   // pair (i host, j target); frame x is host (AH) or target (AT)
+            const int ij = i + nf * j;
+            double s = 0;
+            if (k < nf) {
+              const double* Am = adHs + (size_t)ij * 64;
+#pragma unroll
+              for (int kk = 0; kk < 8; kk++) s += Am[a * 8 + kk] * (double)(c < 4 ? accE[(size_t)ij * 32 + kk * 4 + c] : accEB[(size_t)ij * 8 + kk]);
+            } else s = at(i, j, a) * (double)(c < 4 ? accE[(size_t)ij * 32 + a * 4 + c] : accEB[(size_t)ij * 8 + a]);
+            hS += s;
+          }
+        }
+        const int i = 4 + x * 8 + a;
+        if (c < 4) {
+          double v = hL + B.t_HM[(size_t)i * n + c] + hA;
+          if (wr_hs) { lastHS[(size_t)i * n + c] = v - hS; lastHS[(size_t)c * n + i] = (hL + B.t_HM[(size_t)c * n + i] + hA) - hS; }
+          v -= hS * f;
+          M[i * LDLT_LD + c] = v;
+          M[c * LDLT_LD + i] = (hL + B.t_HM[(size_t)c * n + i] + hA) - hS * f;
+        } else if (c == 4) {
+          hL += prior[x * 8 + a] * prior[nf * 8 + x * 8 + a];
+          const double v = hL + bMt[i] + hA - hS;            // bFinal = bL + bM_top + bA - b_sc      (:907)
+          bF[i] = v;
+          if (wr_hs) lastbS[i] = v;
+        }
+      } else if (lane < 20) {                                  // calibration block and its b
+        const int r = lane < 16 ? lane >> 2 : lane - 16, colx = lane < 16 ? (lane & 3) : 12;
+        double sA = 0, sL = 0;
+#pragma unroll 16
+        for (int p = 0; p < nf2; p++) sA += tail_acc13(accA + p * 92, r, colx);
+        if (topL) for (int p = 0; p < nf2; p++) sL += tail_acc13(accL + (size_t)p * 91, r, colx);
+        const double sS = (double)misc[lane];                  // Hcc (16) then bc (4)
+        if (lane < 16) {
+          if (r == colx) sL += prior[nf * 16 + r];
+          finish(r, colx, sA, sL, sS, B.t_HM[(size_t)r * n + colx]);
+        } else {
+          sL += prior[nf * 16 + r] * (double)B.t_cdelta[r];
+          const double v = sL + bMt[r] + sA - sS;
+          bF[r] = v;
+          if (wr_hs) lastbS[r] = v;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  TSTAMP(3);
+  // ------------------------------------------------------------------ P3: SVecI (:967) and Eigen's pivot order of the scaled system
+  if (tid < 72) {
+    double s = 0, d = 0;
+    if (tid < n) { const double mii = M[tid * LDLT_LD + tid]; s = 1.0 / sqrt(mii + 10); d = s * mii * s; }
+    sv[tid] = s; dg[tid] = d; bp[tid] = 0.0;
+  }
+  for (int e = tid; e < LDLT_NMAX * LDLT_LD; e += TAIL_NT) As[e] = 0.0;     // (accA / S1 are dead: P2 is behind a barrier)
+  __syncthreads();
+  ldlt_pivot_rank(dg, n, pos, keys);
+  TSTAMP(4);
+  // ------------------------------------------------------------------ P4: As = SVecI H SVecI, permuted; the lower triangle mirrored
+  for (int e = tid; e < n * n; e += TAIL_NT) {
+    const int i = e / n, j = e - i * n;
+    if (i >= j) {
+      const double v = sv[i] * M[i * LDLT_LD + j] * sv[j];
+      const int pi = pos[i], pj = pos[j];
+      As[pi * LDLT_LD + pj] = v;
+      As[pj * LDLT_LD + pi] = v;
+    }
+  }
+  if (tid < n) bp[pos[tid]] = sv[tid] * bF[tid];
+  __syncthreads();
+  TSTAMP(5);
+  // ------------------------------------------------------------------ P5
+  if (wv == 0) ldlt_solve_regs(As, bp, M /* L^T */, col, xp, n);
+  __syncthreads();
+  TSTAMP(6);
+  // ------------------------------------------------------------------ P6: x = SVecI * solve(...) (:976), x -= P x (:980-984, :824-826)
+  if (tid < n) xv[tid] = sv[tid] * xp[pos[tid]];
+  __syncthreads();
+  if (flags & TAIL_ORTH) {
+    if (tid < n) {
+      double s = 0;
+      const double* pr = B.t_P + (size_t)tid * n;
+      for (int k = 0; k < n; k++) s += pr[k] * xv[k];
+      tmpv[tid] = xv[tid] - s;
+    }
+    __syncthreads();
+    if (tid < n) xv[tid] = tmpv[tid];
+    __syncthreads();
+  }
+  {
+    double* xout = B.sol + 3 * ((size_t)n * n + n);
+    if (tid < n) xout[tid] = xv[tid];
+    // xAd[nf*h+t] = xF(h)^T adHostF[h+nf*t] + xF(t)^T adTargetF[h+nf*t]   (:289-291), float arithmetic
+    float* xAd = const_cast<float*>(B.t_xAd);
+    for (int e = tid; e < nf2 * 8; e += TAIL_NT) {
+      const int j = e & 7, ht = e >> 3, h = ht / nf, t = ht % nf;
+      const double* AH = G + (size_t)(h + nf * t) * 64;
+      float sh = 0, st = 0;                  // (adTarget is diagonal: its column j has one entry; the other products are exact zeros)
+      for (int i = 0; i < 8; i++) { sh += (float)xv[4 + 8 * h + i] * (float)AH[i * 8 + j]; st += (float)xv[4 + 8 * t + i] * (i == j ? (float)atd[(h + nf * t) * 8 + j] : 0.f); }
+      const float v = sh + st;
+      xAd[e] = v; xAd_s[e] = v;
+    }
+  }
+  __syncthreads();
+  TSTAMP(7);
+  nres_f = misc[20];
+  if (tid == 0) { float t = 0.f; for (int w = 0; w < TAIL_NT / 64; w++) t += misc[24 + w]; misc[22] = 0.f; misc[23] = t; }
+  TSTAMP(8);
+#ifdef SDSO_TAIL_STAMPS
+  __syncthreads();
+  if (threadIdx.x == 0 && !(flags & TAIL_STEP)) {
+    double* xo = B.sol + 3 * ((size_t)n * n + n);
+    for (int i = 0; i < 8; i++) xo[i] = (double)(tstamps[i + 1] - tstamps[i]);   // stage | S1 | tiles | SVecI+order | assemble | factor+solve | x, xAd | resub
+  }
+#endif
+  }  // !ba_finished
+  // ------------------------------------------------------------------ P7
+  if (flags & TAIL_STEP) {
+    __syncthreads();
+    opt_step_body<TAIL_NT>(Bw, B, OS, nullptr, 1, 0, iteration, last, stop_on_convergence, 1.0f, 0, misc + 22, 1, xv, nres_f, blockIdx.x, gridDim.x);
+  }
+}
+
+}  // namespace sdso

@@ -17,6 +17,9 @@
 #include <memory>
 #include <vector>
 #include <algorithm>
+#include <mutex>
+#include <string>
+#include <cstdlib>
 
 namespace sdso {
 void* ba_batch_accum_block(sdso_ctx* ctx, size_t* nfloats);            // ba.hip
@@ -31,17 +34,24 @@ struct RcclApi {
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
+// SDSO_RCCL_LIB overrides the library name (a deployment with its own RCCL build; tests force the "not loadable" path with it)
 static RcclApi* rccl_api(std::string* why) {
   static RcclApi api;
-  static bool tried = false;
+  static std::once_flag once;
   static std::string err;
-  if (!tried) {
-    tried = true;
-    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+  std::call_once(once, [] {
+    const char* forced = getenv("SDSO_RCCL_LIB");
+    std::vector<const char*> names;
+    if (forced && *forced) names = {forced};
+    else names = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    std::string last;
+    for (const char* name : names) {
       api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
       if (api.lib) break;
+      const char* e = dlerror();            // (one call: dlerror clears the message it returns)
+      last = e ? e : "dlopen failed";
     }
-    if (!api.lib) err = std::string("RCCL not found: ") + (dlerror() ? dlerror() : "dlopen failed");
+    if (!api.lib) err = std::string("RCCL not found: ") + last;
     else {
       api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.lib, "ncclGetUniqueId");
       api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.lib, "ncclCommInitRank");
@@ -51,7 +61,7 @@ static RcclApi* rccl_api(std::string* why) {
       api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.lib, "ncclGetErrorString");
       if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllReduce || !api.AllGather) { err = "RCCL symbols missing"; api.lib = nullptr; }
     }
-  }
+  });
   if (!api.lib) { if (why) *why = err; return nullptr; }
   return &api;
 }
@@ -66,13 +76,18 @@ struct Comm {
   sdso_host_allgather_fn h_allgather = nullptr;
   void* h_user = nullptr;
   std::vector<float> h_send, h_recv;
+  std::mutex h_mutex;       // the staging vectors are shared by every ctx attached to this communicator
   bool host() const { return h_allreduce != nullptr; }
   ~Comm() { if (comm) { RcclApi* a = rccl_api(nullptr); if (a) a->CommDestroy(comm); } }
 };
 static std::map<sdso_ctx*, std::shared_ptr<Comm>> g_comms;
 void release_comm(sdso_ctx* ctx) {
-  std::lock_guard<std::mutex> g(registry_mutex());
-  g_comms.erase(ctx);
+  std::shared_ptr<Comm> dying;     // destroyed (ncclCommDestroy may block) after the registry lock is released
+  {
+    std::lock_guard<std::mutex> g(registry_mutex());
+    auto it = g_comms.find(ctx);
+    if (it != g_comms.end()) { dying = std::move(it->second); g_comms.erase(it); }
+  }
 }
 static std::shared_ptr<Comm> comm_of(sdso_ctx* ctx) {
   std::lock_guard<std::mutex> g(registry_mutex());
@@ -92,6 +107,7 @@ int comm_allgather_floats(sdso_ctx* ctx, const float* send, float* recv, size_t 
   auto c = comm_of(ctx);
   if (!c) return sdso::fail(ctx, SDSO_ERR_STATE, "no communicator");
   if (c->host()) {
+    std::lock_guard<std::mutex> hg(c->h_mutex);
     c->h_send.resize(nfloats); c->h_recv.resize(nfloats * c->nranks);
     SDSO_HIP(ctx, hipMemcpyAsync(c->h_send.data(), send, sizeof(float) * nfloats, hipMemcpyDeviceToHost, ctx->stream));
     SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -209,6 +225,7 @@ static int allreduce_block(sdso_ctx* ctx, void* ptr, size_t nfloats) {
   SDSO_REQUIRE(ctx, ptr && nfloats > 0, "nothing to reduce");
   SDSO_HIP(ctx, hipSetDevice(ctx->device));
   if (c->host()) {
+    std::lock_guard<std::mutex> hg(c->h_mutex);
     c->h_send.resize(nfloats);
     SDSO_HIP(ctx, hipMemcpyAsync(c->h_send.data(), ptr, sizeof(float) * nfloats, hipMemcpyDeviceToHost, ctx->stream));
     SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));

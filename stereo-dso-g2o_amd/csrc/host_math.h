@@ -208,26 +208,30 @@ struct Dense {
   double operator()(int i, int j) const { return a[(size_t)i * n + j]; }
 };
 
-// x = A^-1 rhs, A symmetric; LDL^T with symmetric pivoting on the largest remaining |diagonal|.
+// x = A^-1 rhs, A symmetric; LDL^T with Eigen's symmetric pivoting: the first largest |diagonal| among the positions not yet
+// eliminated, where that diagonal is the ORIGINAL one — Eigen's unblocked LDLT is left-looking and touches a diagonal element only
+// at its own step (ba_ldlt.h) — so `d0` carries the input diagonal through the exchanges.  A zero pivot leaves its column undivided.
 inline bool solveLdlt(Dense A, const std::vector<double>& rhs, std::vector<double>& x) {
   const int n = A.n;
   std::vector<int> p(n);
   for (int i = 0; i < n; ++i) p[i] = i;
-  std::vector<double> D(n, 0.0);
+  std::vector<double> D(n, 0.0), d0(n);
+  for (int i = 0; i < n; ++i) d0[i] = A(i, i);
   bool ok = true;
   for (int k = 0; k < n; ++k) {
     int piv = k;
-    double best = std::fabs(A(k, k));
+    double best = std::fabs(d0[k]);
     for (int i = k + 1; i < n; ++i)
-      if (std::fabs(A(i, i)) > best) { best = std::fabs(A(i, i)); piv = i; }
+      if (std::fabs(d0[i]) > best) { best = std::fabs(d0[i]); piv = i; }
     if (piv != k) {
       for (int j = 0; j < n; ++j) std::swap(A(k, j), A(piv, j));
       for (int i = 0; i < n; ++i) std::swap(A(i, k), A(i, piv));
       std::swap(p[k], p[piv]);
+      std::swap(d0[k], d0[piv]);
     }
     const double d = A(k, k);
     D[k] = d;
-    if (d == 0.0) { ok = false; for (int i = k + 1; i < n; ++i) A(i, k) = 0; continue; }
+    if (d == 0.0) { ok = false; continue; }
     for (int i = k + 1; i < n; ++i) A(i, k) /= d;
     for (int i = k + 1; i < n; ++i) {
       const double l = A(i, k);
@@ -253,22 +257,23 @@ inline bool solveLdlt(Dense A, const std::vector<double>& rhs, std::vector<doubl
 SDSO_HD inline bool solveLdltSmall(const double* Ain, int lda, int n, const double* rhs, double* x, double* work, int* p) {
   double* A = work;
   double* D = work + 64;
-  double* y = work + 72;
-  for (int i = 0; i < n; ++i) { p[i] = i; D[i] = 0.0; for (int j = 0; j < n; ++j) A[i * 8 + j] = Ain[i * lda + j]; }
+  double* y = work + 72;          // (also the input diagonal during the factorisation: the pivot search reads it, see solveLdlt)
+  for (int i = 0; i < n; ++i) { p[i] = i; D[i] = 0.0; for (int j = 0; j < n; ++j) A[i * 8 + j] = Ain[i * lda + j]; y[i] = Ain[i * lda + i]; }
   bool ok = true;
   for (int k = 0; k < n; ++k) {
     int piv = k;
-    double best = fabs(A[k * 8 + k]);
+    double best = fabs(y[k]);
     for (int i = k + 1; i < n; ++i)
-      if (fabs(A[i * 8 + i]) > best) { best = fabs(A[i * 8 + i]); piv = i; }
+      if (fabs(y[i]) > best) { best = fabs(y[i]); piv = i; }
     if (piv != k) {
       for (int j = 0; j < n; ++j) { const double t = A[k * 8 + j]; A[k * 8 + j] = A[piv * 8 + j]; A[piv * 8 + j] = t; }
       for (int i = 0; i < n; ++i) { const double t = A[i * 8 + k]; A[i * 8 + k] = A[i * 8 + piv]; A[i * 8 + piv] = t; }
       const int t = p[k]; p[k] = p[piv]; p[piv] = t;
+      const double td = y[k]; y[k] = y[piv]; y[piv] = td;
     }
     const double d = A[k * 8 + k];
     D[k] = d;
-    if (d == 0.0) { ok = false; for (int i = k + 1; i < n; ++i) A[i * 8 + k] = 0; continue; }
+    if (d == 0.0) { ok = false; continue; }
     for (int i = k + 1; i < n; ++i) A[i * 8 + k] /= d;
     for (int i = k + 1; i < n; ++i) {
       const double l = A[i * 8 + k];

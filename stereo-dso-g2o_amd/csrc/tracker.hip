@@ -695,32 +695,31 @@ __device__ __forceinline__ double lm_readlane(double v, int src) {
   return __longlong_as_double(((unsigned long long)hi << 32) | lo);
 }
 // x = A^-1 rhs for the leading n x n block (n <= 8) of a symmetric A: the algorithm of solveLdltSmall / Eigen::LDLT (symmetric pivoting
-// on the largest remaining |diagonal|, first index wins), with the matrix spread over the wave — lane 8i + j holds A(i,j), lanes
+// on the first largest |diagonal| of the not yet eliminated positions, read from the INPUT matrix as Eigen's left-looking loop does), with the matrix spread over the wave — lane 8i + j holds A(i,j), lanes
 // 8i hold rhs(i) — and every element updated by the expression the sequential code uses (the upper triangle mirrors the lower one:
 // its lanes evaluate the lower element's expression with the roles swapped).  A single lane walking these 64 doubles through LDS
 // took ~19 us per solve; here a step is a handful of cross-lane moves.  All lanes return with the same x[0..7].
 __device__ __forceinline__ void lm_wave_ldlt(double a, double rhs, int n, double* x) {
   const int lane = threadIdx.x & 63, i = lane >> 3, j = lane & 7;
   double y = rhs;
+  double a0 = a;                                  // the input matrix, exchanged along: the pivot search reads ITS diagonal (solveLdlt, ba_ldlt.h)
   int pi = i;
   for (int k = 0; k < n; k++) {
-    double best = fabs(lm_readlane(a, k * 9));
+    double best = fabs(lm_readlane(a0, k * 9));
     int p = k;
     for (int m = k + 1; m < n; m++) {
-      const double v = fabs(lm_readlane(a, m * 9));
+      const double v = fabs(lm_readlane(a0, m * 9));
       if (v > best) { best = v; p = m; }
     }
     if (p != k) {
       const int si = i == k ? p : (i == p ? k : i), sj = j == k ? p : (j == p ? k : j);
       a = __shfl(a, si * 8 + sj, 64);
+      a0 = __shfl(a0, si * 8 + sj, 64);
       y = __shfl(y, si * 8, 64);
       pi = __shfl(pi, si * 8 + j, 64);
     }
     const double dk = lm_readlane(a, k * 9);
-    if (dk == 0.0) {
-      if (j == k && i > k) a = 0;
-      continue;
-    }
+    if (dk == 0.0) continue;                      // a zero pivot leaves its column as it is
     const double l = a / dk;                      // column k below the diagonal: L(i,k)
     const double lik = __shfl(l, i * 8 + k, 64), ljk = __shfl(l, j * 8 + k, 64);
     if (i > k && j > k && i < n && j < n) {

@@ -16,6 +16,8 @@ import pytest
 from sdso_amd import abi, synth
 from test_ba_gpu import _check_accum
 
+SDSO_ERR_STATE = -4   # include/sdso_abi.h:36
+
 pytestmark = pytest.mark.gpu
 
 NWIN = 3
@@ -156,7 +158,7 @@ def test_batch_lifetime(gpu_ctx, oracle):
     assert np.array_equal(x, ref)
     # releasing a member dissolves the batch instead of leaving a stale snapshot behind
     ctx.check(ctx.L.sdso_ba_release_window(ctx.h, 81))
-    assert ctx.L.sdso_ba_batch_accumulate(ctx.h) == -4 or ctx.L.sdso_ba_batch_accumulate(ctx.h) != 0
+    assert ctx.L.sdso_ba_batch_accumulate(ctx.h) == SDSO_ERR_STATE                # "no batch"
     assert np.array_equal(single(80), ref)
     # a batch naming an unknown window is refused and registers nothing
     assert ctx.L.sdso_ba_batch_create(ctx.h, 2, abi.ip(np.array([80, 999], np.int32))) != 0
