@@ -323,6 +323,7 @@ def main():
             "config": wl.config,
             "roofline": {"bound": "hbm", "kernel": wl.kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.workload, wl.config),
+                         "traffic_source": "replayed from %s: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (a counter pass cannot run inside the timed region); null when the configuration differs" % os.path.relpath(TRAFFIC_FILE, ROOT),
                          "kernel_avg_ms": avg_ms, "launches": klaunch, "algorithmic_bytes_per_unit": wl.bytes_per_unit},
             "extra": extra,
         }

@@ -93,77 +93,75 @@ class BAWorkload:
             #  accumulate fold eagerly, and the single-rank step leaves the folds to the fused tail kernel)
             nfl_total += int(G.ctx.L.sdso_ba_accum_floats(nf)) * G.nwin
             G.stream = torch.cuda.ExternalStream(G.ctx.L.sdso_ctx_stream(G.ctx.h))
-            G.accum = None
             G.ev = torch.cuda.Event()
             self.groups.append(G)
-        # communicator: RCCL inside the library (backend nccl).  With SDSO_DIST_BACKEND=gloo (rehearsal of the multi-rank path on a
-        # box with fewer GPUs than ranks: RCCL refuses two ranks on one device) the block is all-reduced through torch instead.
+        # communicator: RCCL inside the library (backend nccl).  Every multi-rank mode runs the SAME step — library all-reduce, fused
+        # tail kernel, pack / all-gather / k_ba_opt_step, states advancing — or the run fails: there is no reduced-work fallback.
+        #   nccl (default)  sdso_comm_init: the library opens its own RCCL communicator (one per stream group)
+        #   when some rank cannot load RCCL inside the library (agreed on BEFORE any collective init, from a local probe): the library's
+        #                   host transport (sdso_comm_init_host) with torch.distributed underneath — slower, same work; config.exchange says so
+        #   gloo_lib        rehearsal on a box with fewer GPUs than ranks: host transport over gloo
         backend = os.environ.get("SDSO_DIST_BACKEND", "nccl")
-        self.lib_comm = world > 1 and backend in ("nccl", "gloo_lib")
-        if world > 1 and backend == "gloo_lib":
-            # rehearsal of the WHOLE multi-rank step (library all-reduce + the resident loop's all-gather) on a box with fewer GPUs than
-            # ranks: the library communicator over its host transport (sdso_comm_init_host), gloo underneath
+        self.lib_comm = world > 1
+        if world > 1:
             import torch.distributed as dist
+            use_host = backend == "gloo_lib"
+            why = ""
+            if not use_host:
+                probe = np.zeros(128, np.uint8)      # local and non-collective: dlopen of librccl + ncclGetUniqueId
+                ok = 1 if ctx.L.sdso_comm_unique_id(probe.ctypes.data_as(C.c_void_p)) == 0 else 0
+                flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if int(flag.item()) != 1:
+                    use_host, why = True, "librccl not loadable inside libsdso_hip.so on some rank"
+            if use_host:
+                on_gpu = dist.get_backend() == "nccl"
 
-            def _ar(user, buf, n):
-                t = torch.from_numpy(np.ctypeslib.as_array(buf, shape=(n,)))
-                dist.all_reduce(t, op=dist.ReduceOp.SUM)
-                return 0
+                def _ar(user, buf, n):
+                    a = np.ctypeslib.as_array(buf, shape=(n,))
+                    t = torch.from_numpy(a)
+                    if on_gpu:
+                        t = t.cuda()
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                    if on_gpu:
+                        a[:] = t.cpu().numpy()
+                    return 0
 
-            def _ag(user, send, recv, n):
-                sd = torch.from_numpy(np.ctypeslib.as_array(send, shape=(n,)).copy())
-                outl = [torch.empty(n, dtype=torch.float32) for _ in range(world)]
-                dist.all_gather(outl, sd)
-                r = np.ctypeslib.as_array(recv, shape=(n * world,))
-                for k, o in enumerate(outl):
-                    r[k * n:(k + 1) * n] = o.numpy()
-                return 0
-            self._cbs = (abi.HOST_ALLREDUCE_FN(_ar), abi.HOST_ALLGATHER_FN(_ag))
-            for G in self.groups:
-                G.ctx.check(G.ctx.L.sdso_comm_init_host(G.ctx.h, world, rank, self._cbs[0], self._cbs[1], None))
-            self.exchange = "sdso_ba_allreduce over the library's host transport (gloo; rehearsal)"
-        elif world > 1:
-            import torch.distributed as dist
-            self.exchange = "torch.distributed all_reduce on the library's device block (SDSO_DIST_BACKEND != nccl)"
-            if self.lib_comm:
-                # any rank that cannot open the library communicator (librccl not loadable ...) sends every rank to the torch
-                # collective on the same block: the line is then still measured, and says so in config.exchange
-                # one communicator PER stream group: the groups' collectives run on different streams and interleave, and each group
-                # issues its own sequence (all-reduce, all-gather) in program order on every rank
-                ok, why = 1, ""
+                def _ag(user, send, recv, n):
+                    sd = torch.from_numpy(np.ctypeslib.as_array(send, shape=(n,)).copy())
+                    if on_gpu:
+                        sd = sd.cuda()
+                    outl = [torch.empty(n, dtype=torch.float32, device=sd.device) for _ in range(world)]
+                    dist.all_gather(outl, sd)
+                    r = np.ctypeslib.as_array(recv, shape=(n * world,))
+                    for k, o in enumerate(outl):
+                        r[k * n:(k + 1) * n] = o.cpu().numpy()
+                    return 0
+                self._cbs = (abi.HOST_ALLREDUCE_FN(_ar), abi.HOST_ALLGATHER_FN(_ag))
+                for G in self.groups:
+                    G.ctx.check(G.ctx.L.sdso_comm_init_host(G.ctx.h, world, rank, self._cbs[0], self._cbs[1], None))
+                self.exchange = "sdso_ba_allreduce over the library's host transport (torch.distributed %s underneath)%s" % (
+                    dist.get_backend(), ("; " + why) if why else "; rehearsal")
+            else:
+                # one communicator PER stream group: the groups' collectives run on different streams and interleave, and each group issues
+                # its own sequence (all-reduce, all-gather) in program order on every rank.  ncclCommInitRank is collective: every rank
+                # makes every call; a failure after the agreement above ends the run (non-zero exit) instead of measuring something else.
+                fails = 0
                 for G in self.groups:
                     uid = np.zeros(128, np.uint8)
-                    try:
-                        if rank == 0 and ok:
-                            G.ctx.check(G.ctx.L.sdso_comm_unique_id(uid.ctypes.data_as(C.c_void_p)))
-                    except RuntimeError as e:
-                        ok, why = 0, str(e)
+                    if rank == 0:
+                        G.ctx.check(G.ctx.L.sdso_comm_unique_id(uid.ctypes.data_as(C.c_void_p)))
                     t = torch.from_numpy(uid).cuda()
                     dist.broadcast(t, src=0)
                     uid = t.cpu().numpy().copy()
-                    if not uid.any():
-                        ok, why = 0, why or "rank 0 could not create a communicator id"
-                    if ok:
-                        try:
-                            G.ctx.check(G.ctx.L.sdso_comm_init(G.ctx.h, world, rank, uid.ctypes.data_as(C.c_void_p)))
-                        except RuntimeError as e:
-                            ok, why = 0, str(e)
-                flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-                if int(flag.item()) == 1:
-                    self.exchange = "sdso_ba_allreduce (RCCL communicator owned by libsdso_hip.so)"
-                else:
-                    print("[rank %d] library communicator unavailable (%s): torch.distributed all_reduce on the same block" % (rank, why or "another rank failed"),
-                          file=sys.stderr, flush=True)
-                    for G in self.groups:
-                        G.ctx.L.sdso_comm_destroy(G.ctx.h)
-                    self.lib_comm = False
-                    self.exchange = "torch.distributed all_reduce (RCCL) on the library's device block; library communicator failed: " + (why or "on another rank")
-            if not self.lib_comm:
-                for G in self.groups:
-                    ptr, nfl = C.c_void_p(), C.c_long(0)
-                    G.ctx.check(G.ctx.L.sdso_ba_batch_accum_dev(G.ctx.h, C.byref(ptr), C.byref(nfl)))
-                    G.accum = torch.as_tensor(_DevBlob(ptr.value, nfl.value), device="cuda")
+                    if G.ctx.L.sdso_comm_init(G.ctx.h, world, rank, uid.ctypes.data_as(C.c_void_p)) != 0:
+                        fails += 1
+                flag = torch.tensor([fails], dtype=torch.int32, device="cuda")
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+                if int(flag.item()) != 0:
+                    msg = ctx.L.sdso_last_error(ctx.h)
+                    raise RuntimeError("sdso_comm_init failed on some rank (this rank: %s): no reduced-work fallback, the run ends here" % (msg.decode() if msg else "ok"))
+                self.exchange = "sdso_ba_allreduce (RCCL communicator owned by libsdso_hip.so)"
         self.nwin = nwin
         self.units_per_step = nwin * win["nr"]
         self.config = {"workload": self.name, "windows_per_step": nwin, "keyframes": nf, "points_per_window_per_gpu": win["np"],
@@ -176,7 +174,7 @@ class BAWorkload:
         # the timed step advances REAL state: the device-resident GN loop (sdso_ba_batch_optimize_begin / sdso_ba_batch_step) takes the step
         # the solver produced, rebuilds the tables and moves the newest frame's energy threshold, every step, on every window.
         # SDSO_BA_BENCH_STATIC=1: the round-1 behaviour (re-linearise the same state every step).
-        self.advance = os.environ.get("SDSO_BA_BENCH_STATIC") != "1" and (world == 1 or self.lib_comm)
+        self.advance = os.environ.get("SDSO_BA_BENCH_STATIC") != "1"
         if self.advance:
             for G in self.groups:
                 G.ctx.check(G.ctx.L.sdso_ba_batch_optimize_begin(G.ctx.h, 0))
@@ -212,20 +210,23 @@ class BAWorkload:
         gs = self.groups
         prev = gs[-1]
         chain = len(gs) > 1 and os.environ.get("SDSO_BA_NOCHAIN") != "1"
+        chain_lin = chain and os.environ.get("SDSO_BA_CHAIN", "acc") == "lin"
         for G in gs:
             if chain:
-                G.stream.wait_event(prev.ev)          # accumulate phases run one after the other ...
-            G.ctx.check(G.ctx.L.sdso_ba_batch_accumulate(G.ctx.h))
-            if chain:
-                G.ev.record(G.stream)                 # ... and everything enqueued below overlaps the next group's accumulate
-                # (recording already after the linearisation, with the Schur kernel in the overlapped tail, was measured
-                # slower: 0.97 vs 0.91 ms — the Schur kernel competes for HBM with the other group's linearisation)
+                G.stream.wait_event(prev.ev)          # the bandwidth-bound linearisations run one after the other ...
+            if chain_lin:
+                # ... and everything enqueued after the event overlaps the next group's linearisation: Schur accumulation, the fused
+                # tail kernel, the points' step.  (SDSO_BA_CHAIN=acc records the event after the Schur kernel, as rounds 1-2 did:
+                # with the nine-launch tail of that time the earlier hand-over was slower, 0.97 vs 0.91 ms.)
+                G.ctx.check(G.ctx.L.sdso_ba_batch_linearize(G.ctx.h))
+                G.ev.record(G.stream)
+                G.ctx.check(G.ctx.L.sdso_ba_batch_schur(G.ctx.h))
+            else:
+                G.ctx.check(G.ctx.L.sdso_ba_batch_accumulate(G.ctx.h))
+                if chain:
+                    G.ev.record(G.stream)
             if self.lib_comm:
                 G.ctx.check(G.ctx.L.sdso_ba_allreduce(G.ctx.h))        # RCCL over xGMI, enqueued on the ctx stream by the library
-            elif G.accum is not None:
-                import torch.distributed as dist
-                with self.torch.cuda.stream(G.stream):
-                    dist.all_reduce(G.accum, op=dist.ReduceOp.SUM)
             if self.advance:
                 # solveSystemF + resubstitute + doStepFromBackup + tables + setNewFrameEnergyTH: ONE launch of the fused tail kernel per group
                 # (+ pack / all-gather / k_ba_opt_step when sharded)
@@ -240,10 +241,6 @@ class BAWorkload:
             G.ctx.check(G.ctx.L.sdso_ba_batch_accumulate(G.ctx.h))
             if self.lib_comm:
                 G.ctx.check(G.ctx.L.sdso_ba_allreduce(G.ctx.h))
-            elif G.accum is not None:
-                import torch.distributed as dist
-                with self.torch.cuda.stream(G.stream):
-                    dist.all_reduce(G.accum, op=dist.ReduceOp.SUM)
             G.ctx.check(G.ctx.L.sdso_ba_batch_solve(G.ctx.h, 1e-5, 0))
 
     def _verify_initial(self):
@@ -307,12 +304,20 @@ class BAWorkload:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import pyoracle  # cpu_baseline leg only
         abi = self.abi
-        orc = pyoracle.load(fast=True)
+        # the library is rebuilt with the reference's own flags (-O3 -march=native, CMakeLists.txt:83-84) ON THE HOST THAT TIMES IT when a
+        # compiler is there; otherwise the shipped build (explicit -march=x86-64-v3: built in another container) is timed, and says so
+        npath, nflags = pyoracle.build_native()
+        if npath:
+            orc, flags, built = pyoracle.load(path=npath), nflags, "on the timed host"
+        else:
+            orc, flags, built = pyoracle.load(fast=True), pyoracle.FAST_FLAGS_SHIPPED, "in the build container (%s)" % nflags
         win = self.win
         W, keep = abi.make_ba_window(win, frame_slots=list(range(win["nf"])), dI_list=[p[0] for p in win["pyrs"]])
         nproc = os.cpu_count() or 1
+        allowed = None
         try:
-            nproc = len(os.sched_getaffinity(0))
+            allowed = sorted(os.sched_getaffinity(0))
+            nproc = len(allowed)
         except (AttributeError, OSError):
             pass
         model = "unknown"
@@ -326,7 +331,12 @@ class BAWorkload:
         legs = []
         for nt in sorted({1, 6, min(16, nproc), min(64, nproc), nproc}):
             h = orc.orc_ba_create(C.byref(W))
-            orc.orc_ba_set_threads(h, nt)
+            pinned = orc.orc_ba_set_threads(h, nt)            # the Reducer's workers are bound to distinct cores
+            if nt == 1 and allowed:
+                try:
+                    os.sched_setaffinity(0, {allowed[0]}); pinned = 1     # the single-thread leg runs on the calling thread
+                except OSError:
+                    pass
             x = np.zeros(68)
             ts = []
             for it in range(warmup + reps):
@@ -336,13 +346,20 @@ class BAWorkload:
                 orc.orc_ba_solve(h, 0, 1e-5, abi.dp(x), None, None, None, None)
                 ts.append(time.perf_counter() - t0)
             orc.orc_ba_destroy(h)
+            if nt == 1 and allowed:
+                try:
+                    os.sched_setaffinity(0, set(allowed))
+                except OSError:
+                    pass
             t = np.array(ts[warmup:])
-            legs.append({"threads": nt, "median_ms": float(np.median(t) * 1e3), "p10_ms": float(np.percentile(t, 10) * 1e3),
+            legs.append({"threads": nt, "pinned_workers": int(pinned), "median_ms": float(np.median(t) * 1e3), "p10_ms": float(np.percentile(t, 10) * 1e3),
                          "p90_ms": float(np.percentile(t, 90) * 1e3), "point_residuals_per_s": float(win["nr"] / np.median(t)),
                          "ba_iters_per_s": float(1.0 / np.median(t))})
         best = max(legs, key=lambda l: l["point_residuals_per_s"])
+        ref6 = next((l for l in legs if l["threads"] == 6), None)    # the reference's NUM_THREADS (src/util/NumType.h:38)
         return {"value": best["point_residuals_per_s"], "unit": self.unit, "cores": best["threads"], "kind": "port",
                 "sample": "%d warm-up + %d timed GN iterations (linearizeAll + applyRes + accumulate A/L/SC + stitch + solve + resubstitute) of one "
-                          "%dKF/%d-point window (%d residuals) per leg, oracle -O3 -march=native; median of the fastest leg"
+                          "%dKF/%d-point window (%d residuals) per leg; median of the fastest leg; workers pinned to distinct cores"
                           % (warmup, reps, win["nf"], win["np"], win["nr"]),
+                "flags": flags, "built": built, "reference_num_threads_leg": ref6,
                 "cpu_model": model, "nproc": nproc, "legs": legs, "ba_iters_per_s": best["ba_iters_per_s"]}

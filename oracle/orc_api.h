@@ -147,7 +147,7 @@ void orc_ba_destroy(orc_ba* h);
  * reference's IndexThreadReduce does (src/util/IndexThreadReduce.h:34-196; NUM_THREADS = 6 there, util/NumType.h:38): index chunks
  * from a shared counter (50 points per chunk for the accumulators, EnergyFunctional.cpp:216-217), one private accumulator copy per
  * worker, copies summed in double in the stitch (AccumulatedTopHessian.cpp:299-308).  n <= 1: single thread (the parity path). */
-int orc_ba_set_threads(orc_ba* h, int n);
+int orc_ba_set_threads(orc_ba* h, int n);   /* returns the number of workers that were pinned to a core of their own */
 int orc_ba_linearize(orc_ba* h, double* energy);
 int orc_ba_get_linearization(orc_ba* h, float* J, uint8_t* newState, float* newEnergy,
                              float* newEnergyWithOutlier, float* projectedTo,

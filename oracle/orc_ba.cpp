@@ -10,6 +10,8 @@
 //   src/FullSystem/FullSystemOptimize.cpp:52-370, 871-1041, 1087-1147   GN driver, nullspaces
 //   src/FullSystem/FullSystem.cpp:1004-1021, 1633-1644            flagPointsForRemoval core, setPrecalcValues
 #include "orc_api.h"
+#include <pthread.h>
+#include <sched.h>
 #include "orc_math.h"
 #include "orc_acc.h"
 #include "orc_common.h"
@@ -38,7 +40,23 @@ class Reducer {
   typedef std::function<void(int, int, double*, int)> Fn;
   explicit Reducer(int n) : nthreads(n), isDone(n, 0), gotOne(n, 1) {
     for (int i = 0; i < n; i++) workers.emplace_back(&Reducer::workerLoop, this, i);
+    // timed baseline hygiene: every worker on a core of its own (the i-th CPU this process may run on), so that a leg's time does
+    // not depend on where the scheduler happens to put the threads
+    cpu_set_t allowed;
+    CPU_ZERO(&allowed);
+    if (sched_getaffinity(0, sizeof(allowed), &allowed) == 0) {
+      std::vector<int> cpus;
+      for (int c = 0; c < CPU_SETSIZE; c++) if (CPU_ISSET(c, &allowed)) cpus.push_back(c);
+      if ((int)cpus.size() >= n)
+        for (int i = 0; i < n; i++) {
+          cpu_set_t one;
+          CPU_ZERO(&one);
+          CPU_SET(cpus[i], &one);
+          pinned += pthread_setaffinity_np(workers[i].native_handle(), sizeof(one), &one) == 0 ? 1 : 0;
+        }
+    }
   }
+  int pinned = 0;     // workers that were bound to a core
   ~Reducer() {
     { std::unique_lock<std::mutex> lock(exMutex); running = false; todo_signal.notify_all(); }
     for (auto& t : workers) t.join();
@@ -1338,7 +1356,7 @@ extern "C" int orc_ba_set_threads(orc_ba* h, int n) {
   h->T.assign(n > 1 ? n : 1, AccSet());
   h->zeroAll();
   if (n > 1) h->red = new Reducer(n);
-  return 0;
+  return h->red ? h->red->pinned : 0;     // workers bound to a core of their own (timed-baseline hygiene)
 }
 extern "C" int orc_ba_linearize(orc_ba* h, double* energy) { double e = h->linearizeAll(false); if (energy) *energy = e; return 0; }
 extern "C" int orc_ba_get_linearization(orc_ba* h, float* J, uint8_t* newState, float* newEnergy, float* newEnergyWithOutlier,

@@ -21,11 +21,29 @@ def build():
     subprocess.check_call(["make", "-s", "-C", _HERE])
 
 
-def load(fast=False):
-    name = "liboracle_fast.so" if fast else "liboracle.so"
+FAST_FLAGS_SHIPPED = "-O3 -march=x86-64-v3 -mtune=generic"   # oracle/Makefile FAST_FLAGS
+
+
+def build_native(out_dir="/tmp"):
+    """The timed CPU baseline rebuilt ON THE HOST THAT TIMES IT (-O3 -march=native, the reference's own flags, CMakeLists.txt:83-84).
+    Returns (path, flags), or (None, reason) when no compiler is there."""
+    import shutil
+    if not shutil.which(os.environ.get("CXX", "g++")):
+        return None, "no g++ on the timed host"
+    out = os.path.join(out_dir, "liboracle_native_%d.so" % os.getpid())
+    flags = "-O3 -march=native"
+    try:
+        subprocess.check_call(["make", "-s", "-C", _HERE, "native", "FAST_FLAGS=" + flags, "FAST_OUT=" + out], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
+    except (subprocess.SubprocessError, OSError) as e:
+        return None, "native build failed: %r" % (e,)
+    return out, flags
+
+
+def load(fast=False, path=None):
+    name = path or ("liboracle_fast.so" if fast else "liboracle.so")
     if name in _libs:
         return _libs[name]
-    path = os.path.join(_HERE, name)
+    path = path or os.path.join(_HERE, name)
     if not os.path.exists(path):
         build()
     L = C.CDLL(path)

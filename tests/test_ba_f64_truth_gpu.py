@@ -114,27 +114,64 @@ def test_one_iteration_against_f64_truth(gpu_ctx, oracle, which, path):
     assert np.abs(sg - st64).max() <= 2e-4 * max(np.abs(st64).max(), 1e-6)
 
 
-@pytest.mark.parametrize("which", ["small", "c3", "aff_fixed"])
+def _gauge_free(win, ds):
+    """The component of a frame-state difference ds (nf x 10) outside the span of the window's seven gauge directions (global rigid
+    motion + monocular scale; tests/test_oracle_ba.py::gauge_vectors, the vectors FrameHessian::setStateZero differentiates,
+    HessianBlocks.cpp:78-123 / EnergyFunctional.cpp:775-835), least-squares projection in state coordinates."""
+    from test_oracle_ba import gauge_vectors
+    nf = win["nf"]
+    N = gauge_vectors(win)                                   # (4 + 8 nf) x 7, calibration rows zero
+    v = np.zeros(4 + 8 * nf)
+    for f in range(nf):
+        v[4 + 8 * f:12 + 8 * f] = ds[f, :8]
+    c, *_ = np.linalg.lstsq(N, v, rcond=None)
+    return v - N @ c, N @ c
+
+
+@pytest.mark.parametrize("which", list(CASES))
 def test_gn_loop_against_f64_truth(gpu_ctx, oracle, which):
+    """All five windows.  The frame states after the loop sit within 1e-4 of the f64-accumulator truth, the idepths within 5e-5.
+    Round 2 attributed the excess over north_star's 1e-5 to the near-singular gauge directions; round 3 measured it
+    (tests/diag/gauge_probe.py, profiles/r03_gauge_probe.txt) and that is NOT where it lives: with frame 0's pose prior only the scale
+    direction is near-singular (one whitened eigenvalue below 1e-4), and the difference projected onto the well-determined subspace is as
+    large as the raw one (device 0.2 .. 8.7e-5 depending on the window, the CPU float path 1.3 .. 2.4e-5, the previous device kernels
+    1.2 .. 4.9e-5: samples of the same float-accumulator noise, whose x-error the 6 iterations carry along).  So the bar stays the
+    absolute one, the CPU float path is held to it too (test_one_iteration...), and what is asserted about the gauge is only that
+    removing it does not make the difference larger.  Every residual whose final state differs from the truth sits at its threshold:
+    the energy one side keeps is within 1e-3 of the value the other side clamps to."""
     win = CASES[which]
     nf, npts, nr = win["nf"], win["np"], win["nr"]
     for f in range(nf):
         gpu_ctx.upload_pyramid(40 + f, win["pyrs"][f][:1])
     W, keep = abi.make_ba_window(win, frame_slots=[40 + f for f in range(nf)], dI_list=[p[0] for p in win["pyrs"]])
+    ns64, ne64, nw64 = np.zeros(nr, np.uint8), np.zeros(nr, np.float32), np.zeros(nr, np.float32)
     oracle.orc_set_acc64(1)
     try:
         h = oracle.orc_ba_create(C.byref(W))
         s64, i64, r64, o64 = np.zeros((nf, 10)), np.zeros(npts, np.float32), np.zeros(nr, np.uint8), abi.BAOptResult()
         oracle.orc_ba_optimize(h, 6, abi.dp(s64), abi.fp(i64), abi.bp(r64), C.byref(o64))
+        oracle.orc_ba_get_linearization(h, None, abi.bp(ns64), abi.fp(ne64), abi.fp(nw64), None, None)     # of the final linearizeAll(true)
         oracle.orc_ba_destroy(h)
     finally:
         oracle.orc_set_acc64(0)
     gpu_ctx.check(gpu_ctx.L.sdso_ba_upload_window(gpu_ctx.h, 3, C.byref(W)))
     s, i, r, o = np.zeros((nf, 10)), np.zeros(npts, np.float32), np.zeros(nr, np.uint8), abi.BAOptResult()
     gpu_ctx.check(gpu_ctx.L.sdso_ba_optimize(gpu_ctx.h, 3, 6, abi.dp(s), abi.fp(i), abi.bp(r), C.byref(o)))
+    ns, ne, nw = np.zeros(nr, np.uint8), np.zeros(nr, np.float32), np.zeros(nr, np.float32)
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_get_linearization(gpu_ctx.h, 3, None, abi.bp(ns), abi.fp(ne), abi.fp(nw), None, None))
     gpu_ctx.check(gpu_ctx.L.sdso_ba_release_window(gpu_ctx.h, 3))
     assert o.iterations == o64.iterations
-    assert np.abs(s - s64).max() <= 1e-4, np.abs(s - s64).max()
+    raw = np.abs(s - s64).max()
+    assert raw <= 1e-4, raw
+    free, gauge = _gauge_free(win, s - s64)
+    assert np.abs(free).max() <= raw * (1 + 1e-9) + 1e-12, (np.abs(free).max(), np.abs(gauge).max(), raw)
+    assert np.abs(s[:, 8:] - s64[:, 8:]).max() <= 1e-5
     assert np.abs(i.astype(np.float64) - i64).max() <= 5e-5, np.abs(i.astype(np.float64) - i64).max()
-    assert (r != r64).sum() <= max(2, nr // 2000)
+    flipped = np.nonzero(r != r64)[0]
+    assert len(flipped) <= max(2, nr // 2000)
+    for j in flipped:
+        # IN on one side, OUTLIER on the other (the energy test of Residuals.cpp:303-311): the kept energy against the clamp value
+        if {int(r[j]), int(r64[j])} == {0, 2}:
+            e_in, th = (nw[j], ne64[j]) if r[j] == 0 else (nw64[j], ne[j])
+            assert abs(float(e_in) - float(th)) <= 1e-3 * float(th), (j, e_in, th)
     assert abs(o.lastEnergy - o64.lastEnergy) <= 1e-4 * o64.lastEnergy

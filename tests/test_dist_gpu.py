@@ -311,3 +311,48 @@ def test_resident_loop_through_rccl_one_rank(monkeypatch):
         assert a[3] == b[3] and a[4] == b[4]
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
         assert a[5] == b[5]
+
+
+# ------------------------------------------------------------------ the bench workload itself on two ranks (rehearsal of `bench.py --gpus 2`)
+def _bench_worker(rank, world, port, outdir, scaling):
+    """bench_ba.BAWorkload exactly as bench.py builds it at N = 2 — library all-reduce, fused tail kernel, pack / all-gather / k_ba_opt_step,
+    states advancing — over the library's host transport (gloo underneath: two ranks cannot open RCCL on one device)."""
+    import json
+    import types
+    import torch.distributed as dist
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "stereo-dso-g2o_amd")]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["SDSO_DIST_BACKEND"] = "gloo_lib"
+    os.environ["RANK"] = str(rank)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from sdso_amd import abi
+    import bench_ba
+    ctx = abi.Context(0)
+    args = types.SimpleNamespace(batch=4, scaling=scaling)
+    wl = bench_ba.BAWorkload(ctx, args, rank, world, device=0)
+    xs = []
+    for _ in range(6):
+        wl.step()
+    wl.sync()
+    out = wl.verify()
+    out["config"] = wl.config
+    if rank == 0:
+        json.dump({k: v for k, v in out.items() if isinstance(v, (int, float, bool, str, dict))}, open(os.path.join(outdir, "out_%s.json" % scaling), "w"))
+    wl.close()
+    ctx.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_workload_two_ranks_advances_the_same_work(tmp_path, scaling):
+    """The first real multi-GPU run must not be able to measure something else than N = 1 does: on two ranks the step is the full one
+    (state_advances), window 0's sharded x equals the unsharded window's, and the GN steps shrink over six iterations."""
+    import json
+    world = 2
+    mp.spawn(_bench_worker, args=(world, _free_port(), str(tmp_path), scaling), nprocs=world, join=True)
+    out = json.load(open(os.path.join(str(tmp_path), "out_%s.json" % scaling)))
+    assert out["config"]["state_advances"] is True
+    assert "host transport" in out["config"]["exchange"]
+    assert out["sharded_x_whitened_err"] <= 2e-4
+    assert out["max_abs_x"] < out["max_abs_x_initial"]
