@@ -290,9 +290,22 @@ class BAWorkload:
         out["max_abs_x"] = mx
         if self.advance:
             assert mx < out["max_abs_x_initial"], "the GN steps did not shrink: %g -> %g" % (out["max_abs_x_initial"], mx)
-        for k in ("k_ba_lin_fused", "k_ba_sc", "k_ba_tail"):
-            ms, n = self.prof_read(k)
-            out[k + "_avg_ms"] = ms / max(n, 1)
+        # the secondary kernels, bracketed in a few extra steps AFTER the timed loop (level-2 profiling: the timed steps bracket the
+        # dominant kernel only — two event records per bracket and stream are queue time the step would otherwise pay for nothing)
+        ms, n = self.prof_read("k_ba_lin_fused")
+        out["k_ba_lin_fused_avg_ms"] = ms / max(n, 1)
+        if os.environ.get("SDSO_BENCH_SECONDARY", "1") == "1":
+            for G in self.groups:
+                G.ctx.check(G.ctx.L.sdso_prof_enable(G.ctx.h, 2))
+            base = {k: self.prof_read(k) for k in ("k_ba_sc", "k_ba_tail")}
+            for _ in range(5):
+                self.step()
+            self.sync()
+            for k in ("k_ba_sc", "k_ba_tail"):
+                ms, n = self.prof_read(k)
+                out[k + "_avg_ms"] = (ms - base[k][0]) / max(n - base[k][1], 1)
+            for G in self.groups:
+                G.ctx.check(G.ctx.L.sdso_prof_enable(G.ctx.h, 0))
         return out
 
     def cpu_baseline(self, warmup=5, reps=50):

@@ -52,8 +52,10 @@ const char* sdso_last_error(const sdso_ctx* ctx);
 void* sdso_ctx_stream(sdso_ctx* ctx);
 int sdso_ctx_sync(sdso_ctx* ctx);
 
-/* Optional kernel timing with HIP events recorded on the ctx stream around the launches of the
- * dominant kernels ("k_track_eval", "k_ba_lin_fused", "k_ba_linearize", "k_ba_accum_top", "k_ba_sc", "k_trace_stereo").
+/* Optional kernel timing with HIP events recorded on the ctx stream around launches.  on = 1: the dominant kernel of each workload
+ * ("k_track_eval", "k_track_lm", "k_ba_lin_fused", "k_ba_linearize", "k_trace_stereo", ...); on = 2: also the secondary ones
+ * ("k_ba_sc", "k_ba_tail", "k_ba_accum_top") — every bracket costs two event records on the stream, which a timed loop should only
+ * pay for the kernel it reports; on = 0: off.
  * sdso_prof_read synchronises the stream and returns the accumulated milliseconds / launch count. */
 int sdso_prof_enable(sdso_ctx* ctx, int on);
 int sdso_prof_reset(sdso_ctx* ctx);
@@ -228,7 +230,10 @@ int sdso_ba_release_window(sdso_ctx* ctx, int win);
 /* FullSystem::linearizeAll(false) over every residual (FullSystemOptimize.cpp:142-203) =
  * PointFrameResidual::linearize (Residuals.cpp:83-336).  Returns the summed energy (stats[0]). */
 int sdso_ba_linearize(sdso_ctx* ctx, int win, double* energy);
-/* fetch what linearize produced (any pointer may be NULL):
+/* fetch what the latest linearisation produced (any pointer may be NULL).  After the FUSED linearise + applyRes + accumulate kernel
+ * (sdso_ba_batch_accumulate, the resident loop) the records were written straight into EFResidual::J's slot — the swap of
+ * takeDataF (EnergyFunctionalStructs.cpp:39) is skipped because the swapped-out copy is dead in the accepted-step flow — and are
+ * returned from there, for applied (IN) and not applied (OUTLIER) residuals alike.
  *   J[nr*74] in RawResidualJacobian field order: resF8 Jpdxi0(6) Jpdxi1(6) Jpdc0(4) Jpdc1(4) Jpdd(2)
  *            JIdx0(8) JIdx1(8) JabF0(8) JabF1(8) JIdx2(4) JabJIdx(4) Jab2(4)
  *   newState[nr], newEnergy[nr], newEnergyWithOutlier[nr], projectedTo[nr*16], centerProjectedTo[nr*3] */
@@ -241,7 +246,8 @@ int sdso_ba_apply_res(sdso_ctx* ctx, int win);
 int sdso_ba_get_residual_state(sdso_ctx* ctx, int win, uint8_t* state, uint8_t* isActive,
                                float* JpJdF /* nr*8 */);
 /* EFResidual::J (the record takeDataF swapped in, EnergyFunctionalStructs.cpp:39) of every residual, J[nr*74] in the field order of
- * sdso_ba_get_linearization; rows of residuals that never became active are unspecified. */
+ * sdso_ba_get_linearization; rows of residuals that are not active are unspecified (the reference never reads them either:
+ * AccumulatedTopHessian.cpp:49 / EnergyFunctional.cpp:675 skip !isActive()). */
 int sdso_ba_get_ef_jacobians(sdso_ctx* ctx, int win, float* J);
 
 /* accumulateAF_MT + accumulateLF_MT + accumulateSCF_MT up to (not including) the stitch

@@ -54,6 +54,8 @@ struct BaWindowDev {
   bool in_batch = false;
   bool accumulated = false;
   bool has_lin_cached = false;  // some residual of the window is linearized (updated wherever h_lin changes)
+  bool j_inplace_last = false;  // the latest linearisation was the fused kernel's, written IN PLACE into EFResidual::J's slot (BaDev::jfix):
+                                // sdso_ba_get_linearization reads the records from there
 };
 
 // zeroed device buffer for a window: reuse a pooled buffer of a released window when one of a similar size exists
@@ -252,6 +254,7 @@ static int upload_window_impl(sdso_ctx* ctx, int win, const sdso_ba_window_t* Wi
   d.nf = nf; d.np = np; d.nr = nr; d.nrp = (nr + 63) & ~63; d.w = Win->w; d.h = Win->h; d.n = 8 * nf + 4;
   d.wM3 = (float)(Win->w - 3); d.hM3 = (float)(Win->h - 3);
   d.affA_fixed = Win->affineOptModeA < 0; d.affB_fixed = Win->affineOptModeB < 0;
+  d.jfix = getenv("SDSO_BA_JSWAP") && atoi(getenv("SDSO_BA_JSWAP")) ? 0 : 1;
   W->solverMode = Win->solverMode; W->forceAccept = Win->forceAcceptStep; W->affA = Win->affineOptModeA; W->affB = Win->affineOptModeB;
   const int n = d.n;
 
@@ -509,7 +512,7 @@ static void launch_accumulate(sdso_ctx* ctx, const BaLaunch& L, const uint8_t* p
   const int nf = L.nf;
   // the folds run even without a single chunk: they are what clears the top bins of the previous call
   if (!marg) {
-    if (L.max_chunks > 0) { ProfScope ps(ctx, "k_ba_accum_top"); hipLaunchKernelGGL(k_ba_accum_top, dim3(L.max_chunks, L.nwin), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr, 0, (const uint8_t*)nullptr); }
+    if (L.max_chunks > 0) { ProfScope ps(ctx, "k_ba_accum_top", 2); hipLaunchKernelGGL(k_ba_accum_top, dim3(L.max_chunks, L.nwin), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr, 0, (const uint8_t*)nullptr); }
     hipLaunchKernelGGL(k_ba_fold_top, dim3(nf * nf, L.nwin), dim3(128), 0, ctx->stream, L.d_arr, 0);
     if (L.any_lin && L.max_chunks > 0) {
       hipLaunchKernelGGL(k_ba_accum_top, dim3(L.max_chunks, L.nwin), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr, 1, (const uint8_t*)nullptr);
@@ -531,7 +534,7 @@ static bool launch_sc_and_folds(sdso_ctx* ctx, const BaLaunch& L, const uint8_t*
   static const int sc_variant = getenv("SDSO_SC_REG") ? 2 : getenv("SDSO_SC_ITEMS") ? 1 : 0;   // 0: one workgroup per host (default); 1: per-item MFMA; 2: VALU register tiles
   if (sc_variant == 0) {
     {
-      ProfScope ps(ctx, "k_ba_sc");
+      ProfScope ps(ctx, "k_ba_sc", 2);
       hipLaunchKernelGGL(k_ba_sc_host, dim3(nf, L.nwin), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr, pflag, shift, mm);
     }
     if (fold_top_too && defer_fold) return false;
@@ -540,7 +543,7 @@ static bool launch_sc_and_folds(sdso_ctx* ctx, const BaLaunch& L, const uint8_t*
     return true;
   }
   if (L.max_items > 0) {
-    ProfScope ps(ctx, "k_ba_sc");
+    ProfScope ps(ctx, "k_ba_sc", 2);
     const dim3 grid((L.max_items + BA_BLOCK / 64 - 1) / (BA_BLOCK / 64), L.nwin), blk(BA_BLOCK);
     if (sc_variant == 1) {
       hipLaunchKernelGGL(k_ba_sc_mfma, grid, blk, 0, ctx->stream, L.d_arr, pflag, shift, mm);
@@ -594,7 +597,7 @@ static void launch_stitch(sdso_ctx* ctx, const BaLaunch& L) {
 // the fused tail kernel (ba_tail.hip); SDSO_BA_TAIL=0 keeps the chain of separate kernels (A/B)
 static bool tail_enabled() { static const bool on = !(getenv("SDSO_BA_TAIL") && atoi(getenv("SDSO_BA_TAIL")) == 0); return on; }
 static void launch_tail(sdso_ctx* ctx, const BaLaunch& L, double lambda, int flags, int iteration = 0, int last = 0, int stop = 0) {
-  ProfScope ps(ctx, "k_ba_tail");
+  ProfScope ps(ctx, "k_ba_tail", 2);
   if (L.nf == 8) hipLaunchKernelGGL(k_ba_tail<8>, dim3(L.nwin), dim3(TAIL_NT), 0, ctx->stream, L.d_arr, lambda, flags, iteration, last, stop);
   else hipLaunchKernelGGL(k_ba_tail<0>, dim3(L.nwin), dim3(TAIL_NT), 0, ctx->stream, L.d_arr, lambda, flags, iteration, last, stop);
 }
@@ -630,6 +633,10 @@ static void ensure_folded(sdso_ctx* ctx, BaBatch* Bt) {
   Bt->folded = true;
 }
 static void ensure_folded_win(sdso_ctx* ctx, BaWindowDev* W) { if (W->in_batch && reg_has(g_batches, ctx)) ensure_folded(ctx, reg_get(g_batches, ctx)); }
+// bookkeeping for sdso_ba_get_linearization: where the latest linearisation's records are (fetch_jacobians)
+static void mark_linearized(const std::vector<BaWindowDev*>& Ws, bool fused_materialized) {
+  for (BaWindowDev* W : Ws) W->j_inplace_last = fused_materialized && W->d.jfix != 0;
+}
 static BaLaunch single(BaWindowDev* W) {
   BaLaunch L;
   L.d_arr = W->d_self; L.nwin = 1; L.max_nblk_res = std::max(W->nblk_res, 1); L.max_nblk_pts = W->nblk_pts;
@@ -670,6 +677,7 @@ static int update_frame_energy_th(sdso_ctx* ctx, BaWindowDev* W) {
 static int linearize_all(sdso_ctx* ctx, BaWindowDev* W, bool fix, double* energy) {
   BaLaunch L = single(W);
   launch_linearize(ctx, L);
+  W->j_inplace_last = false;
   if (fix) launch_apply(ctx, L);
   SDSO_HIP(ctx, hipGetLastError());
   std::vector<double> ep(W->nblk_res);
@@ -697,7 +705,7 @@ extern "C" int sdso_ba_linearize(sdso_ctx* ctx, int win, double* energy) {
 
 namespace sdso {
 // RawResidualJacobian records in the ABI's field order; ef = false: PointFrameResidual::J (= J[1 - jsel], what linearize wrote
-// last), ef = true: EFResidual::J (= J[jsel], what takeDataF swapped in)
+// last — or J[jsel] when that was the fused kernel refreshing the record in place), ef = true: EFResidual::J (= J[jsel], what takeDataF swapped in)
 static int fetch_jacobians(sdso_ctx* ctx, BaWindowDev* W, bool ef, float* J) {
   const int nr = W->d.nr, S = W->d.nrp;
   std::vector<float> j0((size_t)76 * S), j1((size_t)76 * S);
@@ -705,8 +713,9 @@ static int fetch_jacobians(sdso_ctx* ctx, BaWindowDev* W, bool ef, float* J) {
   SDSO_HIP(ctx, hipMemcpy(j0.data(), W->d.J[0], sizeof(float) * j0.size(), hipMemcpyDeviceToHost));
   SDSO_HIP(ctx, hipMemcpy(j1.data(), W->d.J[1], sizeof(float) * j1.size(), hipMemcpyDeviceToHost));
   if (nr) SDSO_HIP(ctx, hipMemcpy(sel.data(), W->d.r_jsel, nr, hipMemcpyDeviceToHost));
+  const bool both_ef = W->j_inplace_last;     // fused kernel, in place: "what linearize wrote last" sits in the EF slot too
   for (int j = 0; j < nr; j++) {
-    const std::vector<float>& src = ((sel[j] != 0) != ef) ? j0 : j1;
+    const std::vector<float>& src = ((sel[j] != 0) != (ef || both_ef)) ? j0 : j1;
     float* o = J + (size_t)W->perm[j] * 74;
     for (int f = 0; f < 74; f++) { const int dv = jdev(f); o[f] = src[(size_t)(dv >> 2) * 4 * S + 4 * (size_t)j + (dv & 3)]; }
   }
@@ -1157,6 +1166,7 @@ extern "C" int sdso_ba_marginalize_points(sdso_ctx* ctx, int win, const uint8_t*
   hipLaunchKernelGGL(k_ba_reset_flagged, dim3(L.max_nblk_res, 1), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr, W->d_pflag);
   if (L.tiled) hipLaunchKernelGGL(k_ba_linearize<true>, dim3(L.max_nblk_res, 1), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr);
   else hipLaunchKernelGGL(k_ba_linearize<false>, dim3(L.max_nblk_res, 1), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr);
+  W->j_inplace_last = false;
   launch_apply(ctx, L);
   hipLaunchKernelGGL(k_ba_unmask, dim3(L.max_nblk_res, 1), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr);
   hipLaunchKernelGGL(k_ba_fixlin, dim3(L.max_nblk_res, 1), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr, W->d_pflag);
@@ -1275,6 +1285,7 @@ extern "C" int sdso_ba_batch_accumulate(sdso_ctx* ctx) {
   BaBatch* Bt = get_batch(ctx);
   if (!Bt) return sdso::fail(ctx, SDSO_ERR_STATE, "no batch");
   Bt->folded = launch_fused(ctx, batch_launch(Bt), Bt->materialize, Bt->gather, 3, batch_defers_fold(ctx, Bt));
+  mark_linearized(Bt->W, Bt->materialize);
   SDSO_HIP(ctx, hipGetLastError());
   return SDSO_OK;
 }
@@ -1285,6 +1296,7 @@ extern "C" int sdso_ba_batch_linearize(sdso_ctx* ctx) {
   BaBatch* Bt = get_batch(ctx);
   if (!Bt) return sdso::fail(ctx, SDSO_ERR_STATE, "no batch");
   launch_fused(ctx, batch_launch(Bt), Bt->materialize, Bt->gather, 1);
+  mark_linearized(Bt->W, Bt->materialize);
   SDSO_HIP(ctx, hipGetLastError());
   return SDSO_OK;
 }
@@ -1521,6 +1533,7 @@ static void gated_linearize(sdso_ctx* ctx, OptRun& R, int cond, int which) {
   const dim3 g(R.L.max_nblk_res, nwin), b(BA_BLOCK);
   if (R.L.tiled) hipLaunchKernelGGL(k_ba_linearize<true>, g, b, 0, ctx->stream, R.L.d_arr, cond);
   else hipLaunchKernelGGL(k_ba_linearize<false>, g, b, 0, ctx->stream, R.L.d_arr, cond);
+  mark_linearized(R.W, false);
   const int nblk = R.L.max_chunks + R.L.max_nblk_pts;
   if (nblk > 0) hipLaunchKernelGGL(k_ba_lenergy, dim3(nblk, nwin), b, 0, ctx->stream, R.L.d_arr, R.B->d_lpart, R.lstride, cond);
   hipLaunchKernelGGL(k_ba_opt_gate, dim3(1, nwin), dim3(256), 0, ctx->stream, R.L.d_arr, (const float*)R.B->d_lpart, R.lstride, which, R.stop);
@@ -1571,6 +1584,7 @@ static int opt_finish(sdso_ctx* ctx, OptRun& R, sdso_ba_opt_result_t* out) {
   int rc = SDSO_OK;
   if (!R.gated) {   // (the gated loop leaves every window linearised at its final state)
     launch_fused(ctx, R.L, R.materialize, R.gather, 1);
+    mark_linearized(R.W, R.materialize);
     if ((rc = opt_consume(ctx, R, 1, false, false))) return rc;
   }
   if ((rc = opt_collect(ctx, R))) return rc;
@@ -1610,6 +1624,7 @@ static int opt_finish(sdso_ctx* ctx, OptRun& R, sdso_ba_opt_result_t* out) {
   }
   if (R.L.tiled) hipLaunchKernelGGL(k_ba_linearize<true>, dim3(R.L.max_nblk_res, nwin), dim3(BA_BLOCK), 0, ctx->stream, R.L.d_arr);
   else hipLaunchKernelGGL(k_ba_linearize<false>, dim3(R.L.max_nblk_res, nwin), dim3(BA_BLOCK), 0, ctx->stream, R.L.d_arr);
+  mark_linearized(R.W, false);
   hipLaunchKernelGGL(k_ba_apply, dim3(R.L.max_nblk_res, nwin), dim3(BA_BLOCK), 0, ctx->stream, R.L.d_arr);
   if ((rc = opt_consume(ctx, R, 1, true, false))) return rc;
   if ((rc = opt_collect(ctx, R))) return rc;
@@ -1665,6 +1680,7 @@ static int opt_iteration(sdso_ctx* ctx, OptRun& R, int it) {
   BaBatch* Bt = R.W[0]->in_batch ? get_batch(ctx) : nullptr;
   const bool defer = tail_enabled() && !R.exchange && !(Bt && Bt->eager_fold);
   bool folded = launch_fused(ctx, R.L, R.materialize, R.gather, 3, defer);
+  mark_linearized(R.W, R.materialize);
   if (Bt) Bt->folded = folded;
   if (R.exchange) {
     int rc = Bt ? sdso_ba_allreduce(ctx) : SDSO_ERR_STATE;

@@ -55,6 +55,11 @@ struct BaDev {
   int tiledT;               // > 0: t_img are 4x2-tiled level-0 images with tiledT tiles per row; 0: row-major
   float wM3, hM3, fxl, fyl, cxl, cyl, fxli, fyli;
   int affA_fixed, affB_fixed;
+  int jfix;                 // 1 (default): the fused kernel refreshes EFResidual::J IN PLACE (J[jsel]) instead of writing the other buffer and
+                            // swapping the roles like PointFrameResidual::applyRes (Residuals.cpp:367-385) — in the accepted-step flow the
+                            // swapped-out copy is dead until the next linearize overwrites it, and alternating between two 4 MB record buffers
+                            // per window costs the kernel 5-15 % (measured: every other step 255 vs 305 us, 235 us in place; profiles/).
+                            // 0: swap (SDSO_BA_JSWAP=1)
   // points
   float4* p_geo;            // u, v, idepth, idepth_zero
   const float* p_color;     // np*8

@@ -86,7 +86,7 @@ __device__ __forceinline__ float3 interp33_tiled(const float4* __restrict__ img,
     if (KEEP == 1 || (KEEP == 2 && ((g) < 6 || (g) > 15))) { jl[4 * (g)] = _q.x; jl[4 * (g) + 1] = _q.y; jl[4 * (g) + 2] = _q.z; jl[4 * (g) + 3] = _q.w; } \
   } while (0)
 template <bool STORE, int KEEP, bool TILED>
-__device__ __forceinline__ double linearize_one(const BaDev& B, int i, int h, int t, float* jl, int& ns_out, float* rs = nullptr) {
+__device__ __forceinline__ double linearize_one(const BaDev& B, int i, int h, int t, float* jl, int& ns_out, float* rs = nullptr, bool inplace = false /* fused kernel with BaDev::jfix */) {
   B.r_newEnergyWO[i] = -1.f;
   ns_out = 1;
   const uint8_t st = B.r_state[i];
@@ -98,7 +98,7 @@ __device__ __forceinline__ double linearize_one(const BaDev& B, int i, int h, in
   const float4 g = B.p_geo[pt];
   const float pu = g.x, pv = g.y, idepth_scaled = g.z, idepth_zero_scaled = g.w;
   const float4* __restrict__ dIl = B.t_img[t];
-  float* __restrict__ J = STORE ? (B.r_jsel[i] ? B.J[0] : B.J[1]) : nullptr;
+  float* __restrict__ J = STORE ? ((B.r_jsel[i] != 0) != inplace ? B.J[0] : B.J[1]) : nullptr;
   const int S = B.nrp;
   const float fxl = B.fxl, fyl = B.fyl, cxl = B.cxl, cyl = B.cyl, fxli = B.fxli, fyli = B.fyli;
 
@@ -337,7 +337,7 @@ __device__ __forceinline__ double linearize_coop(const BaDev& B, int i, bool liv
   const float* KRKi = pre; const float* Kt = pre + 9; const float* R0 = pre + 12; const float* t0 = pre + 21;
   const float4 g = B.p_geo[pt];
   const float pu = g.x, pv = g.y, idepth_scaled = g.z, idepth_zero_scaled = g.w;
-  J = STORE ? (B.r_jsel[i] ? B.J[0] : B.J[1]) : nullptr;
+  J = STORE ? ((B.r_jsel[i] != 0) != (B.jfix != 0) ? B.J[0] : B.J[1]) : nullptr;   // jfix: EFResidual::J refreshed in place (ba_kernels.h)
   const float fxl = B.fxl, fyl = B.fyl, cxl = B.cxl, cyl = B.cyl, fxli = B.fxli, fyli = B.fyli;
 
   // projectPoint (ResidualProjections.h:64-96) at the FEJ point
@@ -819,7 +819,7 @@ __global__ __launch_bounds__(BA_BLOCK, (MATERIALIZE ? 3 : 4)) void k_ba_lin_fuse
   if (live) {
     if (GATHER == 0) {
       st = B.r_state[i];
-      e = linearize_one<MATERIALIZE, 2, TILED>(B, i, pair % B.nf, pair / B.nf, jl, ns, rs5);
+      e = linearize_one<MATERIALIZE, 2, TILED>(B, i, pair % B.nf, pair / B.nf, jl, ns, rs5, B.jfix == 1);
     }
     const int pt = B.r_point[i];
     float* rec = B.r_rec + ((size_t)pt * B.nf + pair / B.nf) * 16;
@@ -829,7 +829,7 @@ __global__ __launch_bounds__(BA_BLOCK, (MATERIALIZE ? 3 : 4)) void k_ba_lin_fuse
     if (st != 1) {  // applyRes(true): OOB is sticky
       if (ns == 0) {
         act = 1;
-        if (MATERIALIZE) B.r_jsel[i] ^= 1;
+        if (MATERIALIZE && !B.jfix) B.r_jsel[i] ^= 1;
         const float jdd0 = JV(J_DD + 0), jdd1 = JV(J_DD + 1);
         const float v0 = JV(J_IDX2 + 0) * jdd0 + JV(J_IDX2 + 1) * jdd1;
         const float v1 = JV(J_IDX2 + 2) * jdd0 + JV(J_IDX2 + 3) * jdd1;
@@ -962,7 +962,7 @@ __global__ __launch_bounds__(BA_BLOCK, 3) void k_ba_lin_dma(const BaDev* __restr
     Kvs[idx] = q[1] / q[2];
     if (!(Kus[idx] > 1.1f && Kvs[idx] > 1.1f && Kus[idx] < B.wM3 && Kvs[idx] < B.hM3)) comp = false;
   }
-  __attribute__((address_space(1))) float* const J = MATERIALIZE ? (__attribute__((address_space(1))) float*)(jsel ? B.J[0] : B.J[1]) : nullptr;
+  __attribute__((address_space(1))) float* const J = MATERIALIZE ? (__attribute__((address_space(1))) float*)((jsel != 0) != (B.jfix != 0) ? B.J[0] : B.J[1]) : nullptr;   // (jfix: in place, see ba_kernels.h)
   const int S = B.nrp;
 #define JSTORE(grp, a, b, c, d)                                                                                                      \
   do {                                                                                                                               \
@@ -1101,7 +1101,7 @@ __global__ __launch_bounds__(BA_BLOCK, 3) void k_ba_lin_dma(const BaDev* __restr
       float o8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, rbd = 0.f, rhdd = 0.f, rhcd[4] = {0.f, 0.f, 0.f, 0.f};
       const uint8_t act = ns == 0;
       if (act) {                                              // takeDataF (EnergyFunctionalStructs.cpp:37-51), then addPoint<0>
-        if (MATERIALIZE) GP(uint8_t, B.r_jsel)[i] = jsel ^ 1;
+        if (MATERIALIZE && !B.jfix) GP(uint8_t, B.r_jsel)[i] = jsel ^ 1;
         const float v0 = JIdxJIdx_00 * jdd0 + JIdxJIdx_10 * jdd1;
         const float v1 = JIdxJIdx_10 * jdd0 + JIdxJIdx_11 * jdd1;
 #pragma unroll

@@ -107,6 +107,130 @@ __device__ __forceinline__ void ldlt_back_steps(std::integer_sequence<int, Ks...
   (ldlt_back_step<63 - Ks>(A, xv, n), ...);      // k = 63 .. 1
 }
 
+// packed layouts of the slim variant (ldlt_solve_regs_packed): the unpermuted, UNSCALED lower triangle with diagonal, M(i,j), i >= j, at
+// i (i+1)/2 + j; the strict lower triangle of the 64 x 64 part of L by rows, L(i,k), i > k, at i (i-1)/2 + k
+__host__ __device__ constexpr int ldlt_mtri(int i, int j) { return i * (i + 1) / 2 + j; }
+__host__ __device__ constexpr int ldlt_ltri(int i, int k) { return i * (i - 1) / 2 + k; }
+constexpr int LDLT_M_PACKED = LDLT_NMAX * (LDLT_NMAX + 1) / 2;   // 2346 doubles
+constexpr int LDLT_L_PACKED = 64 * 63 / 2;                        // 2016 doubles
+
+// (the pivot row comes from lane K's registers by v_readlane pairs: SGPRs instead of a VGPR batch and no LDS round trip to wait for —
+//  the slim variant has 160 registers, and a batch small enough to fit exposes the read latency every four terms: 91 k against 60 k cycles)
+template <int K, int BATCH>
+__device__ __forceinline__ void ldlt_step_p(double (&A)[LDLT_NMAX], double& y, double& dmine, double* __restrict__ Lp, double* __restrict__ col, int lane, int n) {
+  if (K >= n) return;                              // (wave-uniform)
+  const double dk = ldlt_rl(A[K], K);
+  const double yk = ldlt_rl(y, K);
+  dmine = lane == K ? dk : dmine;
+  double l = A[K];
+  if (dk != 0.0) l = l / dk;
+  l = lane > K ? l : 0.0;
+  if (lane > K) Lp[ldlt_ltri(lane, K)] = l;
+  y = __builtin_fma(-l, yk, y);
+#pragma unroll
+  for (int j0 = K + 1; j0 < LDLT_NMAX; j0 += BATCH) {
+    double sj[BATCH];
+#pragma unroll
+    for (int u = 0; u < BATCH; u++) if (j0 + u < LDLT_NMAX) sj[u] = ldlt_rl(A[j0 + u], K);
+#pragma unroll
+    for (int u = 0; u < BATCH; u++) if (j0 + u < LDLT_NMAX) A[j0 + u] = __builtin_fma(-l, sj[u], A[j0 + u]);
+  }
+}
+template <int BATCH, int... Ks>
+__device__ __forceinline__ void ldlt_steps_p(std::integer_sequence<int, Ks...>, double (&A)[LDLT_NMAX], double& y, double& dmine, double* __restrict__ Lp, double* __restrict__ col, int lane, int n) {
+  (ldlt_step_p<Ks, BATCH>(A, y, dmine, Lp, col, lane, n), ...);
+}
+// The same solve with a third of the LDS and fewer registers, for a kernel that has to fit beside the linearisation's workgroups
+// (ba_tail.hip, slim variant): the lane gathers its permuted, scaled row straight from the packed lower triangle Mp of the unscaled
+// system (perm[p] = original index at position p, sv = SVecI), the factor goes to the packed array Lp, which ALIASES Mp (every row is
+// in registers before the first element of L is written).  bs = SVecI * b by ORIGINAL index; x by position; col: 80 doubles of scratch.
+template <int BATCH>
+__device__ __forceinline__ void ldlt_solve_regs_packed(double* __restrict__ MpLp, const double* __restrict__ sv, const int* __restrict__ perm, const double* __restrict__ bs,
+                                                       double* __restrict__ col, double* __restrict__ x, int n) {
+  const int lane = threadIdx.x & 63;
+  double A[LDLT_NMAX];
+  const int pi = lane < n ? perm[lane] : 0;
+#pragma unroll
+  for (int j = 0; j < LDLT_NMAX; j++) {
+    double v = 0.0;
+    if (j < n) {                                   // (wave-uniform)
+      const int pj = perm[j];
+      const int hi = pi > pj ? pi : pj, lo = pi > pj ? pj : pi;
+      v = sv[hi] * MpLp[ldlt_mtri(hi, lo)] * sv[lo];     // the LOWER element (Eigen reads the lower triangle): both copies of a pair are the same double
+    }
+    A[j] = lane < n ? v : 0.0;
+  }
+  const bool tail = n > 64;
+  // the trailing 4 x 4 block and the last four right-hand sides wait in `col[64..77]` (not in registers) until the lanes are through
+  if (tail && lane < 14) {
+    int r = 0, c = 0;                              // lane -> (r, c <= r) of the block, lanes 10..13 -> rhs r
+    if (lane < 10) { r = lane < 1 ? 0 : lane < 3 ? 1 : lane < 6 ? 2 : 3; c = lane - (r * (r + 1)) / 2; }
+    else r = lane - 10;
+    const int pr = perm[64 + r], pc = perm[64 + c];
+    const int hi = pr > pc ? pr : pc, lo = pr > pc ? pc : pr;
+    col[64 + lane] = lane < 10 ? sv[hi] * MpLp[ldlt_mtri(hi, lo)] * sv[lo] : bs[pr];
+  }
+  double y = lane < n ? bs[pi] : 0.0;
+  double dmine = 0.0;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // Mp is dead from here on
+  ldlt_steps_p<BATCH>(std::make_integer_sequence<int, 64>{}, A, y, dmine, MpLp, col, lane, n);
+  double t[4] = {0, 0, 0, 0}, xt[4] = {0, 0, 0, 0}, dt[4] = {0, 0, 0, 0}, T[4][4], yt[4] = {0, 0, 0, 0};
+  if (tail) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) t[r] = dmine != 0.0 ? A[64 + r] / dmine : A[64 + r];       // L(64 + r, lane)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      yt[r] = col[64 + 10 + r] - ldlt_wave_sum(t[r] * y);
+#pragma unroll
+      for (int c = 0; c <= r; c++) T[r][c] = col[64 + (r * (r + 1)) / 2 + c] - ldlt_wave_sum(t[r] * A[64 + c]);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const double dk = T[k][k];
+      dt[k] = dk;
+      double s[4], l[4];
+#pragma unroll
+      for (int i = k + 1; i < 4; i++) { s[i] = T[i][k]; l[i] = dk != 0.0 ? s[i] / dk : s[i]; T[i][k] = l[i]; }
+#pragma unroll
+      for (int i = k + 1; i < 4; i++) {
+        yt[i] = __builtin_fma(-l[i], yt[k], yt[i]);
+#pragma unroll
+        for (int j = k + 1; j <= i; j++) T[i][j] = __builtin_fma(-l[i], s[j], T[i][j]);
+      }
+    }
+#pragma unroll
+    for (int k = 3; k >= 0; k--) {
+      double v = dt[k] != 0.0 ? yt[k] / dt[k] : 0.0;
+#pragma unroll
+      for (int i = k + 1; i < 4; i++) v = __builtin_fma(-T[i][k], xt[i], v);
+      xt[k] = v;
+    }
+  }
+  double xv = dmine != 0.0 ? y / dmine : 0.0;
+  if (tail) {
+#pragma unroll
+    for (int r = 3; r >= 0; r--) xv = __builtin_fma(-t[r], xt[r], xv);
+  }
+  // L^T x = z: lane i needs L(k, i) for k > i — column i of L, one element per row k (the lanes' addresses are contiguous)
+  constexpr int BT = 16;
+#pragma unroll 1
+  for (int k0 = 63; k0 >= 1; k0 -= BT) {
+    double u[BT];
+#pragma unroll
+    for (int q = 0; q < BT; q++) {
+      const int k = k0 - q;
+      u[q] = (k >= 1 && k > lane) ? MpLp[ldlt_ltri(k, lane)] : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < BT; q++) {
+      const int k = k0 - q;
+      if (k >= 1 && k < n) xv = __builtin_fma(-u[q], ldlt_rl(xv, k), xv);
+    }
+  }
+  x[lane] = xv;
+  if (lane < 4) x[64 + lane] = tail ? (lane == 0 ? xt[0] : lane == 1 ? xt[1] : lane == 2 ? xt[2] : xt[3]) : 0.0;
+}
+
 // Solve As x = b for the PERMUTED, scaled system in LDS.  Called by one full wave (all 64 lanes).
 //   As   : LDLT_NMAX rows x LDLT_LD, symmetric (both triangles filled), zero outside n x n
 //   b    : LDLT_NMAX, zero beyond n                x : LDLT_NMAX out (positions)

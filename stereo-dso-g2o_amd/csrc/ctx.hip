@@ -162,7 +162,7 @@ extern "C" int sdso_ctx_sync(sdso_ctx* ctx) {
 
 extern "C" int sdso_prof_enable(sdso_ctx* ctx, int on) {
   if (!ctx) return SDSO_ERR_STATE;
-  ctx->prof_on = on != 0;
+  ctx->prof_on = on < 0 ? 0 : on;
   return SDSO_OK;
 }
 extern "C" int sdso_prof_reset(sdso_ctx* ctx) {

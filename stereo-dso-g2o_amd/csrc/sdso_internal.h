@@ -70,7 +70,8 @@ struct sdso_ctx {
   // device buffers of released BA windows, kept for the next upload (a window is re-uploaded for every keyframe)
   std::vector<std::pair<void*, size_t>> ba_pool;
   // optional in-library kernel timing (HIP events on ctx->stream), see sdso_prof_*
-  bool prof_on = false;
+  int prof_on = 0;           // 0 off; 1 the dominant kernel of each workload; 2 every bracketed kernel (each bracket is two hipEventRecord on the
+                             //   stream: ~5 us of queue time apiece, which a timed loop should not pay for kernels it does not report)
   std::map<std::string, sdso::ProfEntry> prof;
 };
 
@@ -114,8 +115,8 @@ struct ProfScope {
   sdso_ctx* ctx;
   hipEvent_t a = nullptr, b = nullptr;
   const char* name;
-  ProfScope(sdso_ctx* c, const char* n) : ctx(c), name(n) {
-    if (!ctx->prof_on) return;
+  ProfScope(sdso_ctx* c, const char* n, int level = 1) : ctx(c), name(n) {
+    if (ctx->prof_on < level) return;
     hipEventCreate(&a); hipEventCreate(&b);
     hipEventRecord(a, ctx->stream);
   }

@@ -9,6 +9,7 @@
 #include <random>
 #include <vector>
 #include "../stereo-dso-g2o_amd/csrc/ba_ldlt.h"
+#include "../stereo-dso-g2o_amd/csrc/ba_ldlt4.h"
 using namespace sdso;
 
 __global__ __launch_bounds__(64) void k_ldlt(const double* __restrict__ Ms, const double* __restrict__ bs, double* __restrict__ xs, int n, long long* ticks) {
@@ -23,7 +24,12 @@ __global__ __launch_bounds__(64) void k_ldlt(const double* __restrict__ Ms, cons
   for (int i = lane; i < LDLT_NMAX; i += 64) { bp[i] = 0.0; dg[i] = i < n ? M[i * n + i] : 0.0; }
   __syncthreads();
   const long long t0 = __builtin_amdgcn_s_memtime();
-  ldlt_pivot_order(dg, n, pos, perm, keys);
+  for (int i = lane; i < n; i += 64) {     // (ldlt_pivot_rank wants n threads; this kernel has one wave)
+    int r = 0;
+    for (int j = 0; j < n; j++) r += (fabs(dg[j]) > fabs(dg[i]) || (fabs(dg[j]) == fabs(dg[i]) && j < i)) ? 1 : 0;
+    pos[i] = r;
+  }
+  __syncthreads();
   const long long t1 = __builtin_amdgcn_s_memtime();
   for (int e = lane; e < n * n; e += 64) {
     const int i = e / n, j = e % n;
@@ -37,6 +43,54 @@ __global__ __launch_bounds__(64) void k_ldlt(const double* __restrict__ Ms, cons
   const long long t3 = __builtin_amdgcn_s_memtime();
   for (int i = lane; i < n; i += 64) xs[(size_t)blockIdx.x * n + i] = xp[pos[i]];
   if (ticks && lane == 0) { ticks[blockIdx.x * 3] = t1 - t0; ticks[blockIdx.x * 3 + 1] = t2 - t1; ticks[blockIdx.x * 3 + 2] = t3 - t2; }
+}
+
+// the four-wave panel variant (ba_ldlt4.h): 256 threads, packed lower triangle in, SVecI = 1
+__global__ __launch_bounds__(256, 3) void k_ldlt4(const double* __restrict__ Ms, const double* __restrict__ bs, double* __restrict__ xs, int n, long long* ticks) {
+  __shared__ double Mp[LP_M_DOUBLES], U[LP_U_DOUBLES], Lp[LP_L_DOUBLES + 8], svv[72], bsv[72], xp[72], dg[72];
+  __shared__ LpShared S;
+  __shared__ int pos[72], perm[72];
+  __shared__ unsigned long long keys[72];
+  const double* M = Ms + (size_t)blockIdx.x * n * n;
+  const double* b = bs + (size_t)blockIdx.x * n;
+  const int tid = threadIdx.x;
+  for (int e = tid; e < n * n; e += 256) { const int i = e / n, j = e % n; if (i >= j) Mp[lp_mtri(i, j)] = M[e]; }
+  if (tid < 72) { svv[tid] = 1.0; bsv[tid] = tid < n ? b[tid] : 0.0; dg[tid] = tid < n ? M[tid * n + tid] : 0.0; }
+  __syncthreads();
+  const long long t0 = __builtin_amdgcn_s_memtime();
+  ldlt_pivot_rank(dg, n, pos, keys);
+  if (tid < n) perm[pos[tid]] = tid;
+  __syncthreads();
+  const long long t1 = __builtin_amdgcn_s_memtime();
+  ldlt_solve_panels(Mp, svv, perm, bsv, U, Lp, S, xp, n);
+  __syncthreads();
+  const long long t2 = __builtin_amdgcn_s_memtime();
+  for (int i = tid; i < n; i += 256) xs[(size_t)blockIdx.x * n + i] = xp[pos[i]];
+  if (ticks && tid == 0) { ticks[blockIdx.x * 3] = t1 - t0; ticks[blockIdx.x * 3 + 1] = 0; ticks[blockIdx.x * 3 + 2] = t2 - t1; }
+}
+
+// the slim one-wave variant (ldlt_solve_regs_packed): packed lower triangle in, factor over it, SVecI = 1; 256-thread workgroup
+__global__ __launch_bounds__(256, 3) void k_ldltp(const double* __restrict__ Ms, const double* __restrict__ bs, double* __restrict__ xs, int n, long long* ticks) {
+  __shared__ double Mp[LDLT_M_PACKED], svv[72], bsv[72], xp[72], dg[72];
+  __shared__ __attribute__((aligned(16))) double colb[80];
+  __shared__ int pos[72], perm[72];
+  __shared__ unsigned long long keys[72];
+  const double* M = Ms + (size_t)blockIdx.x * n * n;
+  const double* b = bs + (size_t)blockIdx.x * n;
+  const int tid = threadIdx.x;
+  for (int e = tid; e < n * n; e += 256) { const int i = e / n, j = e % n; if (i >= j) Mp[ldlt_mtri(i, j)] = M[e]; }
+  if (tid < 72) { svv[tid] = 1.0; bsv[tid] = tid < n ? b[tid] : 0.0; dg[tid] = tid < n ? M[tid * n + tid] : 0.0; }
+  __syncthreads();
+  const long long t0 = __builtin_amdgcn_s_memtime();
+  ldlt_pivot_rank(dg, n, pos, keys);
+  if (tid < n) perm[pos[tid]] = tid;
+  __syncthreads();
+  const long long t1 = __builtin_amdgcn_s_memtime();
+  if (tid < 64) ldlt_solve_regs_packed<8>(Mp, svv, perm, bsv, colb, xp, n);
+  __syncthreads();
+  const long long t2 = __builtin_amdgcn_s_memtime();
+  for (int i = tid; i < n; i += 256) xs[(size_t)blockIdx.x * n + i] = xp[pos[i]];
+  if (ticks && tid == 0) { ticks[blockIdx.x * 3] = t1 - t0; ticks[blockIdx.x * 3 + 1] = 0; ticks[blockIdx.x * 3 + 2] = t2 - t1; }
 }
 
 static void host_solve(const std::vector<double>& M, const std::vector<double>& b, int n, std::vector<long double>& x) {
@@ -82,7 +136,10 @@ int main(int argc, char** argv) {
     double *dM, *db, *dx; long long* dt;
     hipMalloc(&dM, M.size() * 8); hipMalloc(&db, b.size() * 8); hipMalloc(&dx, b.size() * 8); hipMalloc(&dt, W * 3 * 8);
     hipMemcpy(dM, M.data(), M.size() * 8, hipMemcpyHostToDevice); hipMemcpy(db, b.data(), b.size() * 8, hipMemcpyHostToDevice);
-    hipLaunchKernelGGL(k_ldlt, dim3(W), dim3(64), 0, 0, dM, db, dx, n, dt);
+    for (int variant = 0; variant < 3; variant++) {
+    if (variant == 0) hipLaunchKernelGGL(k_ldlt, dim3(W), dim3(64), 0, 0, dM, db, dx, n, dt);
+    else if (variant == 1) hipLaunchKernelGGL(k_ldlt4, dim3(W), dim3(256), 0, 0, dM, db, dx, n, dt);
+    else hipLaunchKernelGGL(k_ldltp, dim3(W), dim3(256), 0, 0, dM, db, dx, n, dt);
     if (hipDeviceSynchronize() != hipSuccess) { printf("launch failed\n"); return 2; }
     std::vector<double> x(b.size()); std::vector<long long> tk(W * 3);
     hipMemcpy(x.data(), dx, x.size() * 8, hipMemcpyDeviceToHost); hipMemcpy(tk.data(), dt, tk.size() * 8, hipMemcpyDeviceToHost);
@@ -105,15 +162,19 @@ int main(int argc, char** argv) {
       }
     }
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int i = 0; i < 5; i++) hipLaunchKernelGGL(k_ldlt, dim3(W), dim3(64), 0, 0, dM, db, dx, n, (long long*)nullptr);
-    hipEventRecord(e0, 0);
     const int reps = 50;
-    for (int i = 0; i < reps; i++) hipLaunchKernelGGL(k_ldlt, dim3(W), dim3(64), 0, 0, dM, db, dx, n, (long long*)nullptr);
+    for (int i = 0; i < 5 + reps; i++) {
+      if (i == 5) hipEventRecord(e0, 0);
+      if (variant == 0) hipLaunchKernelGGL(k_ldlt, dim3(W), dim3(64), 0, 0, dM, db, dx, n, (long long*)nullptr);
+      else if (variant == 1) hipLaunchKernelGGL(k_ldlt4, dim3(W), dim3(256), 0, 0, dM, db, dx, n, (long long*)nullptr);
+      else hipLaunchKernelGGL(k_ldltp, dim3(W), dim3(256), 0, 0, dM, db, dx, n, (long long*)nullptr);
+    }
     hipEventRecord(e1, 0); hipEventSynchronize(e1);
     float ms = 0; hipEventElapsedTime(&ms, e0, e1);
-    printf("n %2d: max rel err %.3e %s | launch of %d systems %.1f us | ticks(shader clock) order %lld assemble %lld solve %lld\n", n, worst, worst < 1e-9 ? "ok" : "FAIL", W, ms * 1e3 / reps,
+    printf("%s n %2d: max rel err %.3e %s | launch of %d systems %.1f us | ticks(shader clock) order %lld assemble %lld solve %lld\n", variant == 0 ? "1 wave, registers" : variant == 1 ? "4 waves, panels " : "1 wave, packed   ", n, worst, worst < 1e-9 ? "ok" : "FAIL", W, ms * 1e3 / reps,
            tk[0], tk[1], tk[2]);
     if (!(worst < 1e-9)) rc = 1;
+    }
     hipFree(dM); hipFree(db); hipFree(dx); hipFree(dt);
   }
   return rc;
