@@ -210,14 +210,15 @@ class BAWorkload:
         gs = self.groups
         prev = gs[-1]
         chain = len(gs) > 1 and os.environ.get("SDSO_BA_NOCHAIN") != "1"
-        chain_lin = chain and os.environ.get("SDSO_BA_CHAIN", "acc") == "lin"
+        chain_lin = chain and os.environ.get("SDSO_BA_CHAIN", "lin") == "lin"
         for G in gs:
             if chain:
                 G.stream.wait_event(prev.ev)          # the bandwidth-bound linearisations run one after the other ...
             if chain_lin:
-                # ... and everything enqueued after the event overlaps the next group's linearisation: Schur accumulation, the fused
-                # tail kernel, the points' step.  (SDSO_BA_CHAIN=acc records the event after the Schur kernel, as rounds 1-2 did:
-                # with the nine-launch tail of that time the earlier hand-over was slower, 0.97 vs 0.91 ms.)
+                # ... and everything enqueued after the event overlaps the next group's linearisation: the Schur accumulation (which the
+                # library puts on the ctx's side stream), the fused tail kernel (launched ahead of it on the main stream, so that its
+                # workgroups take CUs before the next linearisation floods the chip, and waiting in-kernel for the Schur kernel's
+                # signal), the points' step.  (SDSO_BA_CHAIN=acc records the event after the Schur kernel, as rounds 1-2 did.)
                 G.ctx.check(G.ctx.L.sdso_ba_batch_linearize(G.ctx.h))
                 G.ev.record(G.stream)
                 G.ctx.check(G.ctx.L.sdso_ba_batch_schur(G.ctx.h))

@@ -122,6 +122,7 @@ struct BaBatch {
   float* d_accum = nullptr;
   BaLaunch L;
   bool materialize = true;
+  bool sc_async = false;         // the Schur kernel of the latest accumulate is on the side stream and has not been consumed by a tail kernel
   bool eager_fold = false;       // sdso_ba_batch_accum_dev handed the block's address out: never defer the folds
   bool folded = true;            // the packed accumulator block holds the folded sums of the latest accumulate (false: the top partials and the
                                  // per-host Hcc / bc are still unfolded — the fused tail kernel folds them itself; ensure_folded() for anyone else)
@@ -134,6 +135,7 @@ int optimize_resident_single(sdso_ctx* ctx, BaWindowDev* W, int mnumOptIts, sdso
 // Dissolve the ctx's batch: every member window gets its own accumulator block back (host descriptor and its device copy),
 // so later per-window calls never touch the freed batch block.
 static void free_batch(sdso_ctx* ctx) {
+  if (ctx->stream2) hipStreamSynchronize(ctx->stream2);
   BaBatch* taken = nullptr;
   free_optrun(ctx);   // a resident loop over the batch ends with it
   if (!reg_take(g_batches, ctx, taken) || !taken) return;
@@ -507,7 +509,7 @@ static void launch_linearize(sdso_ctx* ctx, const BaLaunch& L) {
 static void launch_apply(sdso_ctx* ctx, const BaLaunch& L) {
   hipLaunchKernelGGL(k_ba_apply, dim3(L.max_nblk_res, L.nwin), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr);
 }
-static bool launch_sc_and_folds(sdso_ctx* ctx, const BaLaunch& L, const uint8_t* pflag, bool marg, bool fold_top_too = false, bool defer_fold = false);
+static bool launch_sc_and_folds(sdso_ctx* ctx, const BaLaunch& L, const uint8_t* pflag, bool marg, bool fold_top_too = false, bool defer_fold = false, bool* async_sc = nullptr);
 static void launch_accumulate(sdso_ctx* ctx, const BaLaunch& L, const uint8_t* pflag, bool marg) {
   const int nf = L.nf;
   // the folds run even without a single chunk: they are what clears the top bins of the previous call
@@ -528,14 +530,35 @@ static void launch_accumulate(sdso_ctx* ctx, const BaLaunch& L, const uint8_t* p
   launch_sc_and_folds(ctx, L, pflag, marg);
 }
 // returns false when the folds were left to the fused tail kernel (defer_fold: only the default Schur kernel, only together with the top fold)
-static bool launch_sc_and_folds(sdso_ctx* ctx, const BaLaunch& L, const uint8_t* pflag, bool marg, bool fold_top_too, bool defer_fold) {
+// the side stream of the resident loop (see sdso_ctx::stream2)
+static bool side_stream(sdso_ctx* ctx) {
+  if (ctx->stream2) return true;
+  if (hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess) { ctx->stream2 = nullptr; return false; }
+  if (hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
+    hipStreamDestroy(ctx->stream2); ctx->stream2 = nullptr; return false;
+  }
+  return true;
+}
+// async_sc != nullptr and *async_sc on entry: put the Schur kernel on the side stream (behind an event recorded now on the main stream) with
+// its completion signalled in-kernel — the caller launches the tail kernel with TAIL_WAIT_SC next, on the main stream, so that it is
+// resident before the other batch's linearisation floods the chip.  Only together with a deferred fold; *async_sc says what happened.
+static bool launch_sc_and_folds(sdso_ctx* ctx, const BaLaunch& L, const uint8_t* pflag, bool marg, bool fold_top_too, bool defer_fold, bool* async_sc) {
   const int nf = L.nf;
   const int shift = marg ? 0 : 1, mm = marg ? 1 : 0;
   static const int sc_variant = getenv("SDSO_SC_REG") ? 2 : getenv("SDSO_SC_ITEMS") ? 1 : 0;   // 0: one workgroup per host (default); 1: per-item MFMA; 2: VALU register tiles
   if (sc_variant == 0) {
+    const bool want_async = async_sc && *async_sc && fold_top_too && defer_fold && !marg && side_stream(ctx);
+    if (async_sc) *async_sc = want_async;
+    if (want_async) {
+      hipEventRecord(ctx->ev_fork, ctx->stream);
+      hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0);
+      hipLaunchKernelGGL(k_ba_sc_host, dim3(nf, L.nwin), dim3(BA_BLOCK), 0, ctx->stream2, L.d_arr, pflag, shift, mm, 1);
+      hipEventRecord(ctx->ev_join, ctx->stream2);
+      return false;
+    }
     {
       ProfScope ps(ctx, "k_ba_sc", 2);
-      hipLaunchKernelGGL(k_ba_sc_host, dim3(nf, L.nwin), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr, pflag, shift, mm);
+      hipLaunchKernelGGL(k_ba_sc_host, dim3(nf, L.nwin), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr, pflag, shift, mm, 0);
     }
     if (fold_top_too && defer_fold) return false;
     if (fold_top_too) hipLaunchKernelGGL(k_ba_fold_all, dim3(1 + 2 * nf * nf, L.nwin), dim3(128), 0, ctx->stream, L.d_arr, 1);
@@ -562,7 +585,7 @@ static bool launch_sc_and_folds(sdso_ctx* ctx, const BaLaunch& L, const uint8_t*
 }
 // linearizeAll + applyRes + accumulateAF in one kernel, then the (normally empty) linearized pass and the Schur part
 // returns false when the folds were deferred to the tail kernel (defer_fold)
-static bool launch_fused(sdso_ctx* ctx, const BaLaunch& L, bool materialize, int gather, int part = 3 /* bit 0: linearize+top, bit 1: Schur+folds */, bool defer_fold = false) {
+static bool launch_fused(sdso_ctx* ctx, const BaLaunch& L, bool materialize, int gather, int part = 3 /* bit 0: linearize+top, bit 1: Schur+folds */, bool defer_fold = false, bool* async_sc = nullptr) {
   const int nf = L.nf;
   if ((part & 1) && L.max_chunks > 0) {
     {
@@ -583,7 +606,8 @@ static bool launch_fused(sdso_ctx* ctx, const BaLaunch& L, bool materialize, int
     }
   }
   // without linearized residuals the top partials are folded together with the Schur partials, after the Schur kernel
-  if (part & 2) return launch_sc_and_folds(ctx, L, nullptr, false, !L.any_lin, defer_fold);
+  if (part & 2) return launch_sc_and_folds(ctx, L, nullptr, false, !L.any_lin, defer_fold, async_sc);
+  if (async_sc) *async_sc = false;
   return true;
 }
 // stitchDouble of the three accumulator groups: the Schur pre-products, then one wave per output tile
@@ -606,10 +630,10 @@ static void launch_fold_deferred(sdso_ctx* ctx, const BaLaunch& L) {   // what l
 }
 // stitch + solveSystemF (default branch) + resubstitute.  orth bit 0: x -= P x; bit 1: lambda of the window's resident loop.
 // folded = false: the accumulate left the folds to the tail kernel (launch_fused with defer_fold)
-static void launch_solve(sdso_ctx* ctx, const BaLaunch& L, double lambda, int orth, bool folded = true) {
+static void launch_solve(sdso_ctx* ctx, const BaLaunch& L, double lambda, int orth, bool folded = true, bool wait_sc = false) {
   const int n = L.n;
   if (tail_enabled()) {
-    const int flags = TAIL_HS | ((orth & 1) ? TAIL_ORTH : 0) | ((orth & 2) ? TAIL_LAMBDA_DEV : 0) | (L.any_lin ? TAIL_TOPL : 0) | (folded ? 0 : TAIL_FOLD);
+    const int flags = TAIL_HS | ((orth & 1) ? TAIL_ORTH : 0) | ((orth & 2) ? TAIL_LAMBDA_DEV : 0) | (L.any_lin ? TAIL_TOPL : 0) | (folded ? 0 : TAIL_FOLD) | (wait_sc ? TAIL_WAIT_SC : 0);
     launch_tail(ctx, L, lambda, flags);
     if (L.max_nblk_pts > 0) hipLaunchKernelGGL(k_ba_resub, dim3(L.max_nblk_pts, L.nwin), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr);
     return;
@@ -626,8 +650,17 @@ static void launch_solve(sdso_ctx* ctx, const BaLaunch& L, double lambda, int or
   }
   if (L.max_nblk_pts > 0) hipLaunchKernelGGL(k_ba_resub, dim3(L.max_nblk_pts, L.nwin), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr);
 }
+// a Schur kernel still on the side stream whose consumer is not a waiting tail kernel: join it on the main stream and clear the counters
+__global__ void k_ba_clear_sc_done(const BaDev* __restrict__ wins) { wins[blockIdx.x].opt->sc_done = 0; }
+static void join_sc(sdso_ctx* ctx, BaBatch* Bt) {
+  if (!Bt || !Bt->sc_async) return;
+  hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0);
+  hipLaunchKernelGGL(k_ba_clear_sc_done, dim3(Bt->L.nwin), dim3(1), 0, ctx->stream, Bt->L.d_arr);
+  Bt->sc_async = false;
+}
 // the packed block of a batch whose latest accumulate deferred its folds: fold now (anyone but the tail kernel reads folded sums)
 static void ensure_folded(sdso_ctx* ctx, BaBatch* Bt) {
+  join_sc(ctx, Bt);
   if (!Bt || Bt->folded) return;
   launch_fold_deferred(ctx, Bt->L);
   Bt->folded = true;
@@ -821,6 +854,7 @@ extern "C" int sdso_ba_set_accumulators(sdso_ctx* ctx, int win, const float* pac
 
 extern "C" int sdso_ba_get_point_terms(sdso_ctx* ctx, int win, float* HdiF, float* bdSumF, float* Hdd_accAF, float* bd_accAF, float* Hcd_accAF) {
   GET_WIN();
+  ensure_folded_win(ctx, W);      // (joins a Schur kernel that is still on the side stream)
   const int np = W->d.np;
   std::vector<float> po((size_t)np * 16);
   SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1277,6 +1311,7 @@ void* ba_window_accum_block(sdso_ctx* ctx, int win, size_t* nfloats) {
 namespace sdso {
 struct OptRun;
 static bool batch_defers_fold(sdso_ctx* ctx, BaBatch* Bt);   // below, next to the resident loop
+static bool batch_async_sc(sdso_ctx* ctx, BaBatch* Bt);
 }
 // phase 1 of one GN iteration for every window of the batch: linearize + applyRes + accumulate A/L/SC (enqueue only).
 // Inside a single-rank resident loop (sdso_ba_batch_optimize_begin) the folds of the partial sums are left to the fused tail kernel of
@@ -1284,7 +1319,10 @@ static bool batch_defers_fold(sdso_ctx* ctx, BaBatch* Bt);   // below, next to t
 extern "C" int sdso_ba_batch_accumulate(sdso_ctx* ctx) {
   BaBatch* Bt = get_batch(ctx);
   if (!Bt) return sdso::fail(ctx, SDSO_ERR_STATE, "no batch");
-  Bt->folded = launch_fused(ctx, batch_launch(Bt), Bt->materialize, Bt->gather, 3, batch_defers_fold(ctx, Bt));
+  join_sc(ctx, Bt);
+  bool async = batch_async_sc(ctx, Bt);
+  Bt->folded = launch_fused(ctx, batch_launch(Bt), Bt->materialize, Bt->gather, 3, batch_defers_fold(ctx, Bt), &async);
+  Bt->sc_async = async;
   mark_linearized(Bt->W, Bt->materialize);
   SDSO_HIP(ctx, hipGetLastError());
   return SDSO_OK;
@@ -1303,7 +1341,10 @@ extern "C" int sdso_ba_batch_linearize(sdso_ctx* ctx) {
 extern "C" int sdso_ba_batch_schur(sdso_ctx* ctx) {
   BaBatch* Bt = get_batch(ctx);
   if (!Bt) return sdso::fail(ctx, SDSO_ERR_STATE, "no batch");
-  Bt->folded = launch_fused(ctx, batch_launch(Bt), Bt->materialize, Bt->gather, 2, batch_defers_fold(ctx, Bt));
+  join_sc(ctx, Bt);
+  bool async = batch_async_sc(ctx, Bt);
+  Bt->folded = launch_fused(ctx, batch_launch(Bt), Bt->materialize, Bt->gather, 2, batch_defers_fold(ctx, Bt), &async);
+  Bt->sc_async = async;
   SDSO_HIP(ctx, hipGetLastError());
   return SDSO_OK;
 }
@@ -1324,7 +1365,9 @@ extern "C" int sdso_ba_batch_solve(sdso_ctx* ctx, double lambda, int orthogonali
   // solveSystem's overrides of lambda (EnergyFunctional.cpp:840-846), as in the single-window call
   if (Bt->W[0]->solverMode & SOLVER_USE_GN) lambda = 0;
   if (Bt->W[0]->solverMode & SOLVER_FIX_LAMBDA) lambda = 1e-5;
-  launch_solve(ctx, batch_launch(Bt), lambda, orthogonalize_x, Bt->folded);   // (the tail kernel folds for itself: the block stays as it is)
+  if (!tail_enabled()) join_sc(ctx, Bt);
+  launch_solve(ctx, batch_launch(Bt), lambda, orthogonalize_x, Bt->folded, Bt->sc_async);   // (the tail kernel folds for itself: the block stays as it is)
+  Bt->sc_async = false;
   if (!tail_enabled()) Bt->folded = true;
   SDSO_HIP(ctx, hipGetLastError());
   return SDSO_OK;
@@ -1653,13 +1696,25 @@ static bool batch_defers_fold(sdso_ctx* ctx, BaBatch* Bt) { (void)ctx; return ta
 
 // solveSystem + doStepFromBackup + the loop's host part of iteration R.iteration.  Single rank: ONE launch of the fused tail kernel.
 // Sharded windows: tail kernel (stitch, solve, resubstitute, points' step) -> pack -> all-gather -> k_ba_opt_step, as before.
-static int opt_solve_step(sdso_ctx* ctx, OptRun& R, double lambda, int orth, bool folded) {
+static std::map<sdso_ctx*, OptRun*> g_optruns;   // the batch loop in flight between sdso_ba_batch_optimize_begin and _end
+static bool batch_async_sc(sdso_ctx* ctx, BaBatch* Bt) {
+  // SDSO_BA_SC_ASYNC=1 (experiment, off by default): the Schur kernel goes to the side stream inside a single-rank resident loop, where
+  // the next thing on the main stream is the tail kernel that waits for it in-kernel.  Measured on MI355X (profiles/r03_ab_sc_async.txt):
+  // 0.66-0.69 ms per step against 0.60 in order — the waiting workgroups hold 64 CUs for the event latency + the whole Schur kernel
+  // (tail 278 instead of 120-190 us), which costs the other batch's linearisation more than the earlier start of the tail gains.
+  static const bool on = getenv("SDSO_BA_SC_ASYNC") && atoi(getenv("SDSO_BA_SC_ASYNC")) == 1;
+  // the waiting tail workgroups hold one CU each (150 KB of LDS): they must leave most of the chip to the kernel they wait for
+  if (!on || !tail_enabled() || Bt->eager_fold || !reg_has(g_optruns, ctx) || Bt->L.nwin > ctx->n_cu / 2) return false;
+  OptRun* R = reg_get(g_optruns, ctx);
+  return R && R->active && !R->exchange && !R->gated && R->W == Bt->W;
+}
+static int opt_solve_step(sdso_ctx* ctx, OptRun& R, double lambda, int orth, bool folded, bool wait_sc = false) {
   if (!tail_enabled()) {
     launch_solve(ctx, R.L, lambda, orth, folded);
     SDSO_HIP(ctx, hipGetLastError());
     return opt_step(ctx, R);
   }
-  const int flags = ((orth & 1) ? TAIL_ORTH : 0) | (R.L.any_lin ? TAIL_TOPL : 0) | (folded ? 0 : TAIL_FOLD);
+  const int flags = ((orth & 1) ? TAIL_ORTH : 0) | (R.L.any_lin ? TAIL_TOPL : 0) | (folded ? 0 : TAIL_FOLD) | (wait_sc ? TAIL_WAIT_SC : 0);
   const int nwin = (int)R.W.size();
   const dim3 gp(std::max(R.L.max_nblk_pts, 1), nwin);
   if (!R.exchange) {
@@ -1679,7 +1734,9 @@ static int opt_solve_step(sdso_ctx* ctx, OptRun& R, double lambda, int orth, boo
 static int opt_iteration(sdso_ctx* ctx, OptRun& R, int it) {
   BaBatch* Bt = R.W[0]->in_batch ? get_batch(ctx) : nullptr;
   const bool defer = tail_enabled() && !R.exchange && !(Bt && Bt->eager_fold);
-  bool folded = launch_fused(ctx, R.L, R.materialize, R.gather, 3, defer);
+  if (Bt) join_sc(ctx, Bt);
+  bool async = Bt ? batch_async_sc(ctx, Bt) : false;      // (a single window has nothing to overlap the Schur kernel with)
+  bool folded = launch_fused(ctx, R.L, R.materialize, R.gather, 3, defer, &async);
   mark_linearized(R.W, R.materialize);
   if (Bt) Bt->folded = folded;
   if (R.exchange) {
@@ -1692,7 +1749,7 @@ static int opt_iteration(sdso_ctx* ctx, OptRun& R, int it) {
   if (sm & SOLVER_USE_GN) lambda = 0;
   if (sm & SOLVER_FIX_LAMBDA) lambda = 1e-5;
   const int orth = (sm & SOLVER_ORTHOGONALIZE_X) || (it >= 2 && (sm & SOLVER_ORTHOGONALIZE_X_LATER));
-  return opt_solve_step(ctx, R, lambda, orth ? 1 : 0, folded);
+  return opt_solve_step(ctx, R, lambda, orth ? 1 : 0, folded, async);
 }
 
 int optimize_resident_single(sdso_ctx* ctx, BaWindowDev* W, int mnumOptIts, sdso_ba_opt_result_t* res) {
@@ -1713,7 +1770,6 @@ int optimize_resident_single(sdso_ctx* ctx, BaWindowDev* W, int mnumOptIts, sdso
   for (int it = 0; it < N; it++) if ((rc = opt_iteration(ctx, R, it))) return rc;
   return opt_finish(ctx, R, res);
 }
-static std::map<sdso_ctx*, OptRun*> g_optruns;   // the batch loop in flight between sdso_ba_batch_optimize_begin and _end
 void free_optrun(sdso_ctx* ctx) {
   OptRun* r = nullptr;
   if (reg_take(g_optruns, ctx, r) && r) delete r;
@@ -1755,7 +1811,10 @@ extern "C" int sdso_ba_batch_solve_step(sdso_ctx* ctx, double lambda, int orthog
   if (Bt->W[0]->solverMode & SOLVER_USE_GN) lambda = 0;
   if (Bt->W[0]->solverMode & SOLVER_FIX_LAMBDA) lambda = 1e-5;
   R->L = batch_launch(Bt);
-  return opt_solve_step(ctx, *R, lambda, orthogonalize_x ? 1 : 0, Bt->folded);
+  const bool wait_sc = Bt->sc_async;
+  Bt->sc_async = false;
+  if (wait_sc && (!tail_enabled() || R->exchange)) { Bt->sc_async = true; join_sc(ctx, Bt); return opt_solve_step(ctx, *R, lambda, orthogonalize_x ? 1 : 0, Bt->folded); }
+  return opt_solve_step(ctx, *R, lambda, orthogonalize_x ? 1 : 0, Bt->folded, wait_sc);
 }
 extern "C" int sdso_ba_batch_optimize_end(sdso_ctx* ctx, sdso_ba_opt_result_t* out) {
   if (!ctx || !reg_has(g_optruns, ctx)) return sdso::fail(ctx, SDSO_ERR_STATE, "sdso_ba_batch_optimize_begin first");

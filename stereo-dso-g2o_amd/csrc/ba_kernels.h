@@ -48,6 +48,9 @@ struct BaOptDev {
   // what loadSateBackup + setPrecalcValues restore on a rejected step
   float bk_precalc[64 * 27], bk_adHTdelta[64 * 8], bk_cdelta[4], bk_calib[6];
   double bk_prior[8 * 16 + 4 + 8 * 8 + 4];
+  // hand-off from the Schur kernel on the side stream to the fused tail kernel (ba_tail.hip, TAIL_WAIT_SC): every host workgroup
+  // of k_ba_sc_host adds one when its bins are written; the tail waits for nf of them and clears the word
+  int sc_done;
 };
 
 struct BaDev {

@@ -1474,7 +1474,7 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_sc_mfma(const BaDev* __restrict
 // of a workgroup share ALL points of one host (64-point slices dealt round-robin), add their 21 accumulator tiles through LDS
 // in a fixed order (3+2 -> 1+0 -> 0) and wave 0 writes the host's accD / accE / accEB bins straight into the packed accumulator
 // block: no per-item partials in HBM and no fold pass.  Only Hcc / bc (sums over ALL hosts) leave a 20-float partial per host.
-__global__ __launch_bounds__(BA_BLOCK, 2) void k_ba_sc_host(const BaDev* __restrict__ wins, const uint8_t* __restrict__ pflag, int shiftPriorToZero, int margMode) {
+__global__ __launch_bounds__(BA_BLOCK, 2) void k_ba_sc_host(const BaDev* __restrict__ wins, const uint8_t* __restrict__ pflag, int shiftPriorToZero, int margMode, int signal = 0) {
   const BaDev& B = wins[blockIdx.y];
   if (ba_finished(B)) return;
   const int nf = B.nf, h = blockIdx.x;
@@ -1633,6 +1633,15 @@ __global__ __launch_bounds__(BA_BLOCK, 2) void k_ba_sc_host(const BaDev* __restr
       if (ci < 4) hp[v * 4 + ci] = acc44[v];
       if (ci == 4) hp[16 + v] = acc44[v];
     }
+  }
+  if (signal) {
+    // side-stream launch: tell the tail kernel (already resident, polling) that this host's bins, Hcc partial and per-point terms are
+    // in memory.  The other waves' p_out stores were drained before the workgroup barriers above (__syncthreads waits for vmcnt(0));
+    // this wave drains its own, releases at agent scope (L2 write-back) and only then bumps the counter.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add(&B.opt->sc_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
