@@ -14,11 +14,10 @@ window; rank 0 checks that against a single-GPU, un-fused solve of the same glob
   --scaling strong          BASELINE configs[4]: 8 keyframes x 8000 points in total, cut 1/2/4/8 ways.
 The all-reduce payload is batch x 184 KiB.
 
-The batch is split into two groups, each on its own sdso_ctx (= its own HIP stream).  The
-bandwidth-bound accumulate phases of the two groups are chained by events (A, B, A, B, ...), so the
-latency-bound tail of one group (fold, stitch, 68x68 solve, back-substitution, and the all-reduce at
-N>1) runs underneath the accumulate phase of the other group instead of leaving the chip idle.
-SDSO_BA_GROUPS=1 gives the plain single-stream order."""
+SDSO_BA_GROUPS stream groups, each on its own sdso_ctx (= its own HIP stream); default 1 on one rank (see the
+comment at `ngroups`), 2 on several: the bandwidth-bound linearisations of the groups are chained by events
+(A, B, A, B, ...), so the rest of one group's iteration (Schur accumulation, fused tail kernel, points' step, and the
+all-reduce at N>1) runs underneath the linearisation of the other group."""
 import ctypes as C
 import os
 import sys
@@ -53,7 +52,12 @@ class BAWorkload:
         self.scaling = getattr(args, "scaling", "weak")
         strong = self.scaling == "strong"
         nwin = args.batch or (32 if strong else 128)   # enough independent windows that the working set is >> the 256 MB MALL
-        ngroups = max(1, min(int(os.environ.get("SDSO_BA_GROUPS", "2")), nwin))
+        # stream groups.  One rank: ONE group — every kernel of the step runs alone on the chip (the linearisation at its clean-stream
+        # 0.40 of the HBM peak) and the step is lin + Schur + tail + points in sequence; two chained groups reach the same step time
+        # with the linearisation slowed by the other group's tail (0.35), three unchained groups are 6 % faster but their overlapping
+        # linearisation launches make the per-launch duration meaningless (profiles/r03_ab_groups.txt).  Several ranks: two chained
+        # groups, so that the all-reduce of one group travels under the linearisation of the other.
+        ngroups = max(1, min(int(os.environ.get("SDSO_BA_GROUPS", "1" if world == 1 else "2")), nwin))
         if strong:
             self.name = "windowed_ba_8kf_8kpts_sharded"
         # the GLOBAL window (identical on every rank) and this rank's contiguous share of its points

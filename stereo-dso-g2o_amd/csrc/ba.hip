@@ -750,7 +750,7 @@ static int fetch_jacobians(sdso_ctx* ctx, BaWindowDev* W, bool ef, float* J) {
   for (int j = 0; j < nr; j++) {
     const std::vector<float>& src = ((sel[j] != 0) != (ef || both_ef)) ? j0 : j1;
     float* o = J + (size_t)W->perm[j] * 74;
-    for (int f = 0; f < 74; f++) { const int dv = jdev(f); o[f] = src[(size_t)(dv >> 2) * 4 * S + 4 * (size_t)j + (dv & 3)]; }
+    for (int f = 0; f < 74; f++) { const int dv = jdev(f); o[f] = src[j_off(S, j, dv >> 2) + (dv & 3)]; }
   }
   return SDSO_OK;
 }

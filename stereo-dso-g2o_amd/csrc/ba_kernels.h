@@ -116,6 +116,19 @@ __device__ __forceinline__ bool ba_finished_lin(const BaDev& B) { return B.finis
 // conditional kernels of the energy-gated loop: cond = 0 always, 1 only when the step was accepted, 2 only when it was rejected
 __device__ __forceinline__ bool ba_gate_skip(const BaDev& B, int cond) { return cond != 0 && (ba_finished_lin(B) || B.opt->gate != cond); }
 
+// Float offset of group g (0..18, one float4) of residual i in a RawResidualJacobian buffer of S = nrp residual slots.
+//   blocked (default): the 19 groups of 64 consecutive residuals form ONE contiguous 19 KiB block — a wave of the fused kernel streams
+//                      its records into one stretch of memory instead of into 19 streams 4 S floats apart;
+//   -DSDSO_J_SOA     : group-major over the whole window (rounds 1-2), kept for A/B.
+__host__ __device__ inline size_t j_off(int S, int i, int g) {
+#ifdef SDSO_J_SOA
+  return (size_t)g * 4 * S + 4 * (size_t)i;
+#else
+  (void)S;
+  return ((size_t)(i >> 6) * 19 + g) * 256 + (size_t)(i & 63) * 4;
+#endif
+}
+
 __host__ __device__ inline int sc_part_floats(int nf) { return nf * nf * 64 + nf * 32 + nf * 8 + 16 + 4; }
 __host__ __device__ inline size_t acc_off_topA(int nf) { return 0; }
 __host__ __device__ inline size_t acc_off_topL(int nf) { return (size_t)nf * nf * 91; }

@@ -33,16 +33,16 @@ __device__ __forceinline__ double block_sum_d(double v, double* lds) {
   return s;
 }
 
-// Device layout of one RawResidualJacobian: 19 float4 groups (76 floats, SoA over residuals: group g of
-// residual i at J + g*4*S + 4*i), ordered so that linearize can store every group as soon as it is known:
+// Device layout of one RawResidualJacobian: 19 float4 groups (76 floats; group g of residual i at J + j_off(S, i, g), ba_kernels.h:
+// blocks of 64 residuals x 19 groups), ordered so that linearize can store every group as soon as it is known:
 //   g0..g2 Jpdxi[0][0..5],Jpdxi[1][0..5] | g3 Jpdc[0] | g4 Jpdc[1] | g5 {Jpdd[0],Jpdd[1],-,-}
 //   g6+k {resF[k], JIdx[0][k], JIdx[1][k], JabF[0][k]} k=0..7 | g14,g15 JabF[1][0..7] | g16 JIdx2 | g17 JabJIdx | g18 Jab2
-__device__ __forceinline__ float4& JQ(float* J, int S, int i, int g) { return *(float4*)(J + (size_t)g * 4 * S + 4 * (size_t)i); }
-__device__ __forceinline__ float4 JQ(const float* J, int S, int i, int g) { return *(const float4*)(J + (size_t)g * 4 * S + 4 * (size_t)i); }
+__device__ __forceinline__ float4& JQ(float* J, int S, int i, int g) { return *(float4*)(J + j_off(S, i, g)); }
+__device__ __forceinline__ float4 JQ(const float* J, int S, int i, int g) { return *(const float4*)(J + j_off(S, i, g)); }
 __device__ __forceinline__ void load_J(const float* J, int S, int i, float* jl) {
 #pragma unroll
   for (int g = 0; g < 19; g++) {
-    const float4 q = *(const float4*)(J + (size_t)g * 4 * S + 4 * (size_t)i);
+    const float4 q = *(const float4*)(J + j_off(S, i, g));
     jl[4 * g] = q.x; jl[4 * g + 1] = q.y; jl[4 * g + 2] = q.z; jl[4 * g + 3] = q.w;
   }
 }
@@ -966,7 +966,7 @@ __global__ __launch_bounds__(BA_BLOCK, 3) void k_ba_lin_dma(const BaDev* __restr
   const int S = B.nrp;
 #define JSTORE(grp, a, b, c, d)                                                                                                      \
   do {                                                                                                                               \
-    if (MATERIALIZE) __builtin_nontemporal_store((te_f4){a, b, c, d}, (__attribute__((address_space(1))) te_f4*)(J + (size_t)(grp) * 4 * S + 4 * (size_t)i)); \
+    if (MATERIALIZE) __builtin_nontemporal_store((te_f4){a, b, c, d}, (__attribute__((address_space(1))) te_f4*)(J + j_off(S, i, (grp)))); \
   } while (0)
   float JIdxJIdx_00 = 0, JIdxJIdx_11 = 0, JIdxJIdx_10 = 0;
   float JabJIdx_00 = 0, JabJIdx_01 = 0, JabJIdx_10 = 0, JabJIdx_11 = 0;
@@ -1474,6 +1474,9 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_sc_mfma(const BaDev* __restrict
 // of a workgroup share ALL points of one host (64-point slices dealt round-robin), add their 21 accumulator tiles through LDS
 // in a fixed order (3+2 -> 1+0 -> 0) and wave 0 writes the host's accD / accE / accEB bins straight into the packed accumulator
 // block: no per-item partials in HBM and no fold pass.  Only Hcc / bc (sums over ALL hosts) leave a 20-float partial per host.
+// (Round 3 tried the transposed split — wave a owns tile ROW a for all points of the host: 116 VGPRs and 8 KB of LDS, so all 1024
+//  workgroups of a 128-window launch are resident at once instead of two rounds of 512 — and measured it SLOWER, 91 against 72 us: the
+//  kernel is bound by the per-wave chain load -> MFMA over its point groups, which that split makes four times longer.)
 __global__ __launch_bounds__(BA_BLOCK, 2) void k_ba_sc_host(const BaDev* __restrict__ wins, const uint8_t* __restrict__ pflag, int shiftPriorToZero, int margMode, int signal = 0) {
   const BaDev& B = wins[blockIdx.y];
   if (ba_finished(B)) return;
@@ -1504,9 +1507,17 @@ __global__ __launch_bounds__(BA_BLOCK, 2) void k_ba_sc_host(const BaDev* __restr
         const float* base = B.r_rec + (size_t)p * nf * 16;
         float Hdd_A = 0, bd_A = 0, Hdd_L = 0, bd_L = 0, HcdA[4] = {0, 0, 0, 0}, HcdL[4] = {0, 0, 0, 0};
         float ngood = 0;
-        for (int t = 0; t < nf; t++) {
-          const float4 q0 = *(const float4*)(base + t * 16 + 8);
-          const float4 q1 = *(const float4*)(base + t * 16 + 12);
+        // (all 2 x nf record loads of the point are requested before the first is consumed: the loop over the targets used to be nf
+        //  dependent round trips, a third of this latency-bound kernel's time)
+        float4 q0s[8], q1s[8];
+#pragma unroll
+        for (int t = 0; t < 8; t++)
+          if (t < nf) { q0s[t] = *(const float4*)(base + t * 16 + 8); q1s[t] = *(const float4*)(base + t * 16 + 12); }
+#pragma unroll
+        for (int t = 0; t < 8; t++) {
+          if (t >= nf) break;
+          const float4 q0 = q0s[t];
+          const float4 q1 = q1s[t];
           const int fl = (int)q1.z;
           const float m = ((fl & 1) ? 1.f : 0.f) * onf;
           const float mA = (!(fl & 2) && !margMode) ? m : 0.f, mL = m - mA;
