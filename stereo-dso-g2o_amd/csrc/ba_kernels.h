@@ -37,7 +37,8 @@ struct BaOptDev {
   double lastEnergy;             // energy of the latest linearizeAll
   float frameTH_new;             // frameEnergyTH of the newest frame after the latest setNewFrameEnergyTH
   int iterations;                // GN iterations run
-  int phase;                     // 0 running; 1 the break test fired: the linearisation at the final state is still to be consumed; 2 finished
+  int phase;                     // 0 running; 1 the break test fired: the linearisation at the final state is still to be consumed; 2 finished;
+                                 // 3 (energy-gated flow) an accepted step fired the break test: finished once its applyRes has run
   int resInA;                    // nres[0] of the latest accumulate
   int newest_first;              // first (pair-sorted) residual whose target is the newest frame; they run to nr
   // ---- energy-gated flow (setting_forceAceptStep = false, FullSystemOptimize.cpp:969-990)

@@ -1507,17 +1507,9 @@ __global__ __launch_bounds__(BA_BLOCK, 2) void k_ba_sc_host(const BaDev* __restr
         const float* base = B.r_rec + (size_t)p * nf * 16;
         float Hdd_A = 0, bd_A = 0, Hdd_L = 0, bd_L = 0, HcdA[4] = {0, 0, 0, 0}, HcdL[4] = {0, 0, 0, 0};
         float ngood = 0;
-        // (all 2 x nf record loads of the point are requested before the first is consumed: the loop over the targets used to be nf
-        //  dependent round trips, a third of this latency-bound kernel's time)
-        float4 q0s[8], q1s[8];
-#pragma unroll
-        for (int t = 0; t < 8; t++)
-          if (t < nf) { q0s[t] = *(const float4*)(base + t * 16 + 8); q1s[t] = *(const float4*)(base + t * 16 + 12); }
-#pragma unroll
-        for (int t = 0; t < 8; t++) {
-          if (t >= nf) break;
-          const float4 q0 = q0s[t];
-          const float4 q1 = q1s[t];
+        for (int t = 0; t < nf; t++) {
+          const float4 q0 = *(const float4*)(base + t * 16 + 8);
+          const float4 q1 = *(const float4*)(base + t * 16 + 12);
           const int fl = (int)q1.z;
           const float m = ((fl & 1) ? 1.f : 0.f) * onf;
           const float mA = (!(fl & 2) && !margMode) ? m : 0.f, mL = m - mA;

@@ -373,6 +373,10 @@ __global__ __launch_bounds__(256) void k_ba_opt_gate(const BaDev* __restrict__ w
   const BaDev B = Bw;
   if (ba_finished_lin(B)) return;
   BaOptDev& O = *B.opt;
+  if (which == 2 && O.phase == 3) {                          // an accepted step that also fired the break test: its applyRes (the conditional
+    if (threadIdx.x == 0) { O.phase = 2; Bw.finished = 2; } //   kernel between which 1 and which 2) has run — only now is the window finished
+    return;
+  }
   if (which == 2 && O.gate != 2) return;
   const int tid = threadIdx.x, nf = B.nf, n = B.n;
   __shared__ unsigned hist[256], sh[6];
@@ -448,7 +452,9 @@ __global__ __launch_bounds__(256) void k_ba_opt_gate(const BaDev* __restrict__ w
     Bw.fxl = O.bk_calib[0]; Bw.fyl = O.bk_calib[1]; Bw.cxl = O.bk_calib[2]; Bw.cyl = O.bk_calib[3]; Bw.fxli = O.bk_calib[4]; Bw.fyli = O.bk_calib[5];
     return;                                                   // the break test waits for the re-linearisation (which 2)
   }
-  if (O.canbreak) { O.phase = 2; Bw.finished = 2; }           // :990 `if(canbreak && iteration >= setting_minOptIterations) break;`
+  // :990 `if(canbreak && iteration >= setting_minOptIterations) break;` — after the accepted step's applyRes (:969-981 run before the break):
+  // which 1 only records it (phase 3), the which-2 call that follows the conditional applyRes ends the loop; a rejected step's call (which 2) ends it directly
+  if (O.canbreak) { if (which == 1) O.phase = 3; else { O.phase = 2; Bw.finished = 2; } }
 }
 
 // what the host needs back from a resident loop, one record per window (one D2H copy per batch)
