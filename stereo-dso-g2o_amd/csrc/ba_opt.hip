@@ -116,6 +116,87 @@ struct OptStepSmem {
   float K[9], Ki[9], dlt[8][8], zb[8];
 };
 
+// ---- the part of opt_step_body that does not depend on the solver's x — the energies of the linearisation, their 70 % quantile, the
+// energy sum — by ONE wave without any workgroup barrier, so that the fused tail kernel can run it on an idle wave beside the
+// factorisation.  Same exact order statistic as opt_select (four radix passes over the bit patterns), the energy sum in another order.
+struct OptPreSmem {
+  static constexpr int kStage = 4096;                   // larger sets: the workgroup path of opt_step_body
+  float en[kStage];
+  unsigned hist[256];
+};
+struct OptPre { float valid, th; double esum; };        // valid != 0: th (the new frameEnergyTH of the newest frame) and esum are set
+__device__ __forceinline__ void opt_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ inline float opt_wave_select(const float* v, int n, int k, unsigned* hist) {
+  const int lane = threadIdx.x & 63;
+  unsigned prefix = 0, mask = 0;
+  for (int shift = 24; shift >= 0; shift -= 8) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) hist[64 * q + lane] = 0;
+    opt_wave_sync();
+    for (int j = lane; j < n; j += 64) {
+      const float e = v[j];
+      if (!(e >= 0)) continue;
+      const unsigned key = __float_as_uint(e);
+      if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255], 1u);
+    }
+    opt_wave_sync();
+    // lane owns bins 4 lane .. 4 lane + 3; exclusive prefix over the lanes, then inside the lane
+    unsigned h[4], tot = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) { h[q] = hist[4 * lane + q]; tot += h[q]; }
+    unsigned inc = tot;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const unsigned up = __shfl_up(inc, o, 64); if (lane >= o) inc += up; }
+    unsigned excl = inc - tot;
+    int bin = -1; unsigned bex = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      if (h[q] > 0 && excl <= (unsigned)k && (unsigned)k < excl + h[q]) { bin = 4 * lane + q; bex = excl; }
+      excl += h[q];
+    }
+    const unsigned long long who = __ballot(bin >= 0);
+    const int src = who ? __ffsll((long long)who) - 1 : 0;
+    const int b = __shfl(bin, src, 64);
+    const unsigned be = __shfl(bex, src, 64);
+    prefix |= (unsigned)(b < 0 ? 0 : b) << shift;
+    mask |= 255u << shift;
+    k -= (int)be;
+    opt_wave_sync();
+  }
+  return __uint_as_float(prefix);
+}
+__device__ inline void opt_pre_wave(const BaDev& B, OptPreSmem& P, OptPre* out) {
+  const BaOptDev& O = *B.opt;
+  const int lane = threadIdx.x & 63, nf = B.nf;
+  const int first = O.newest_first, cap = max(B.nr - first, 0);
+  if (cap > OptPreSmem::kStage) { if (lane == 0) out->valid = 0.f; return; }
+  int cnt = 0;
+  for (int j = lane; j < cap; j += 64) {
+    const int i = first + j;
+    const float e = (B.r_target[i] == nf - 1 && !B.r_lin[i]) ? B.r_newEnergyWO[i] : -1.f;
+    P.en[j] = e;
+    cnt += e >= 0 ? 1 : 0;
+  }
+  double esum = 0;
+  for (int b = lane; b < B.nchunks; b += 64) esum += B.e_part[b];     // (the fused kernel's partials: one per chunk)
+  esum = wave_sum(esum);
+  const int M = (int)wave_sum((float)cnt);
+  opt_wave_sync();
+  float th = 12 * 12 * 8;
+  if (M > 0) {
+    const int nth = (int)(0.7f * M);
+    const float q = opt_wave_select(P.en, cap, nth, P.hist);
+    const float nthElement = sqrtf(q);
+    th = nthElement * 1.5f;
+    th = 26.0f * 0.5f + th * (1 - 0.5f);
+    th = th * th;
+    th *= 1.0f * 1.0f;
+  }
+  if (lane == 0) { out->th = th; out->esum = esum; out->valid = 1.f; }
+}
+
 // One GN iteration's host part for every window.  gathered: [nranks][nwin][opt_pack_floats(cap)]; nullptr on a single rank: the
 // energies, energy partials and point sums are read where the kernels left them (no pack launch).
 //   last == 0:  consume the energies of the linearisation at the current state (lastEnergy, setNewFrameEnergyTH), take the step the
@@ -129,7 +210,7 @@ struct OptStepSmem {
 template <int NT>
 __device__ __forceinline__ void opt_step_body(BaDev& Bw, const BaDev& B, OptStepSmem& S, const float* __restrict__ gathered, int nranks, int cap, int iteration, int last,
                                               int stop_on_convergence, float stepsize, int unfused_parts, const float* __restrict__ wsums, int nwsums,
-                                              const double* __restrict__ x, float p_nres, int win, int nwin) {
+                                              const double* __restrict__ x, float p_nres, int win, int nwin, const OptPre* pre = nullptr) {
   BaOptDev& O = *B.opt;
   const int tid = threadIdx.x, nf = B.nf;
   const int pf = opt_pack_floats(cap);
@@ -168,6 +249,17 @@ __device__ __forceinline__ void opt_step_body(BaDev& Bw, const BaDev& B, OptStep
   const int p_its = O.iterations;
 
   // ---- setNewFrameEnergyTH over every rank's residuals into the newest frame
+  // (the fused tail kernel has done this part on an idle wave beside the factorisation: pre)
+  const bool have_pre = pre != nullptr && !g && pre->valid != 0.f;      // (uniform: the barriers below are skipped by every thread)
+  float th = 12 * 12 * 8;
+  float nidsum = 0;
+  if (have_pre) {
+    th = pre->th;
+    if (wsums) for (int b = tid; b < nwsums; b += NT) nidsum += wsums[2 * b + 1];
+    nidsum = wave_sum(nidsum);
+    if ((tid & 63) == 0) { S.esum[tid >> 6] = tid == 0 ? pre->esum : 0.0; S.nid[tid >> 6] = nidsum; }
+    __syncthreads();
+  } else {
   // one pass over global memory: the energies go to LDS (all loads of a thread in flight together), the radix passes read LDS
   const bool staged = nranks * cap <= OptStepSmem::kStage;
   int cnt = 0;
@@ -178,7 +270,7 @@ __device__ __forceinline__ void opt_step_body(BaDev& Bw, const BaDev& B, OptStep
       cnt += e >= 0 ? 1 : 0;
     }
   // the energy partials and the points' |idepth| sums of this rank (single-rank path), summed by all threads
-  double esum = 0; float nidsum = 0;
+  double esum = 0;
   if (!g) {
     const int np_ = unfused_parts ? (B.nr + BA_BLOCK - 1) / BA_BLOCK : B.nchunks;
     for (int b = tid; b < np_; b += NT) esum += B.e_part[b];
@@ -193,7 +285,6 @@ __device__ __forceinline__ void opt_step_body(BaDev& Bw, const BaDev& B, OptStep
   int M = 0;
 #pragma unroll
   for (int w = 0; w < NT / 64; w++) M += S.cnt[w];
-  float th = 12 * 12 * 8;
   if (M > 0) {
     const int nth = (int)(0.7f * M);
     const float q = opt_select<NT>(en, nth, S.hist, S.sh);
@@ -202,6 +293,7 @@ __device__ __forceinline__ void opt_step_body(BaDev& Bw, const BaDev& B, OptStep
     th = 26.0f * 0.5f + th * (1 - 0.5f);
     th = th * th;
     th *= 1.0f * 1.0f;
+  }
   }
   const bool gated = last == 2;
   if (tid == 0 && !gated) {

@@ -44,7 +44,7 @@ struct TailLds {
   static constexpr int kCol = 0;                                  // 64 d   column exchange of the factorisation (low address: immediate offsets)
   static constexpr int kVec = kCol + 64 * 8;                      // 8 vectors of 72 d: bF sv bp xp xv bMt dg tmp
   static constexpr int kPos = kVec + 8 * 72 * 8;                  // 72 i pos, 72 i perm
-  static constexpr int kKeys = kPos + 2 * 72 * 4;                 // 72 u64
+  static constexpr int kKeys = kPos + 2 * 72 * 4;                 // 72 u64 (P1: the nf^2 + 1 chunk offsets of the pairs)
   static constexpr int kAtd = kKeys + 72 * 8;                     // 64 pairs x 8 d: diagonals of adTarget
   static constexpr int kXad = kAtd + 64 * 8 * 8;                  // 512 f
   static constexpr int kMisc = kXad + 512 * 4;                    // 64 f: Hcc 16, bc 4, nres 2, sums 2, flags
@@ -57,6 +57,8 @@ struct TailLds {
   static constexpr int kEnd1 = kE + 64 * 40 * 4;
   static constexpr int kEnd2 = kR1 + LDLT_NMAX * LDLT_LD * 8;
   static constexpr int kEnd3 = kR1 + (int)sizeof(OptStepSmem) + 16;
+  static constexpr int kPre = kEnd2;                              // OptPreSmem: behind As, on the dead tail of S1 (P5 only)
+  static_assert(kPre + (int)sizeof(OptPreSmem) <= kG, "the pre-wave's stage must fit between As and the adHost stage");
   static_assert(kEnd2 <= kG && kEnd3 <= kG, "As / OptStepSmem must not reach the adHost stage");
   static constexpr int kBytes = kEnd1 > kEnd2 ? (kEnd1 > kEnd3 ? kEnd1 : kEnd3) : (kEnd2 > kEnd3 ? kEnd2 : kEnd3);
 };
@@ -128,27 +130,67 @@ __global__ __launch_bounds__(TAIL_NT) void k_ba_tail(const BaDev* __restrict__ w
   // ------------------------------------------------------------------ P1
   {
     const bool fold = (flags & TAIL_FOLD) != 0;
-    for (int e = tid; e < nf2 * 92; e += TAIL_NT) {
-      const int pair = e / 92, k = e - pair * 92;
-      float s = 0.f;
-      if (fold) {
-        const int cb = B.pair_chunk_beg[pair], ce = B.pair_chunk_beg[pair + 1];
-        for (int ck = cb; ck < ce; ck++) s += B.top_part[(size_t)ck * 92 + k];
-      } else if (k < 91) s = accum[acc_off_topA(nf) + (size_t)pair * 91 + k];
-      accA[e] = s;
+    // the fold of the top partials: a thread's trips are independent, but each is two dependent global round trips (chunk range of the
+    // pair, then the partial) — 12 trips in a row were the longest part of this phase.  The chunk ranges go to LDS first, then every
+    // trip's first partial is requested before any is consumed (a pair has one chunk unless it holds more than 256 residuals).
+    int* pcb = (int*)(tail_smem + TailLds::kKeys);            // nf2 + 1 chunk offsets (the keys of the pivot rank are not alive yet)
+    if (fold) for (int e = tid; e <= nf2; e += TAIL_NT) pcb[e] = B.pair_chunk_beg[e];
+    __syncthreads();
+    constexpr int FT = 12;                                   // 64 pairs x 92 sums over 512 threads
+    for (int e0 = tid; e0 < nf2 * 92; e0 += FT * TAIL_NT) {
+      float first[FT];
+      int cbv[FT], cev[FT];
+#pragma unroll
+      for (int u = 0; u < FT; u++) {
+        const int e = e0 + u * TAIL_NT;
+        first[u] = 0.f; cbv[u] = 0; cev[u] = 0;
+        if (e < nf2 * 92) {
+          const int pair = e / 92, k = e - pair * 92;
+          if (fold) {
+            cbv[u] = pcb[pair]; cev[u] = pcb[pair + 1];
+            if (cbv[u] < cev[u]) first[u] = B.top_part[(size_t)cbv[u] * 92 + k];
+          } else if (k < 91) first[u] = accum[acc_off_topA(nf) + (size_t)pair * 91 + k];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < FT; u++) {
+        const int e = e0 + u * TAIL_NT;
+        if (e < nf2 * 92) {
+          float s = first[u];
+          const int k = e % 92;
+          for (int ck = cbv[u] + 1; ck < cev[u]; ck++) s += B.top_part[(size_t)ck * 92 + k];
+          accA[e] = s;
+        }
+      }
     }
+    // the remaining stages as "request everything, then park it": written as separate loops each of them was a round trip of its own
+    // (the LDS store of a loop waits for its load), five in a row
+    constexpr int GT = 8, ET = 5;                              // 4096 adHost doubles / 2560 accE+EB floats over 512 threads
+    double gv[GT]; float ev[ET], hcc = 0.f, hpart[8];
+    double av = 0.0;
+#pragma unroll
+    for (int u = 0; u < GT; u++) { const int e = tid + u * TAIL_NT; gv[u] = e < nf2 * 64 ? adH[e] : 0.0; }
+#pragma unroll
+    for (int u = 0; u < ET; u++) { const int e = tid + u * TAIL_NT; ev[u] = e < nf2 * 40 ? accum[acc_off_E(nf) + e] : 0.f; }   // accE (nf2 x 32) and accEB (nf2 x 8) are contiguous
+    if (tid < nf2 * 8) av = adT[(size_t)(tid >> 3) * 64 + (tid & 7) * 9];
     if (tid < 20) {
-      float s = 0.f;
-      if (fold) for (int h = 0; h < nf; h++) s += B.sc_part[(size_t)h * 20 + tid];
-      else s = accum[acc_off_Hcc(nf) + tid];
-      misc[tid] = s;
+      if (fold) {
+#pragma unroll
+        for (int h = 0; h < 8; h++) hpart[h] = h < nf ? B.sc_part[(size_t)h * 20 + tid] : 0.f;
+      } else hcc = accum[acc_off_Hcc(nf) + tid];
     }
-    for (int e = tid; e < nf2 * 8; e += TAIL_NT) atd[e] = adT[(size_t)(e >> 3) * 64 + (e & 7) * 9];
-    for (int e = tid; e < nf2 * 64; e += TAIL_NT) G[e] = adH[e];
-    for (int e = tid; e < nf2 * 40; e += TAIL_NT) Es[e] = accum[acc_off_E(nf) + e];      // accE (nf2 x 32) and accEB (nf2 x 8) are contiguous
     float nid = 0.f;                          // sum |idepth| of the points as they stand: the break test's sumNID (doStepFromBackup sums the
     if (flags & TAIL_STEP)                    //   BACKUP values, FullSystemOptimize.cpp:262 — known before the step is taken)
       for (int p = tid; p < B.np; p += TAIL_NT) nid += fabsf(B.p_geo[p].z);
+#pragma unroll
+    for (int u = 0; u < GT; u++) { const int e = tid + u * TAIL_NT; if (e < nf2 * 64) G[e] = gv[u]; }
+#pragma unroll
+    for (int u = 0; u < ET; u++) { const int e = tid + u * TAIL_NT; if (e < nf2 * 40) Es[e] = ev[u]; }
+    if (tid < nf2 * 8) atd[tid] = av;
+    if (tid < 20) {
+      if (fold) { hcc = 0.f; for (int h = 0; h < nf; h++) hcc += hpart[h]; }
+      misc[tid] = hcc;
+    }
     if (tid >= 64 && tid < 64 + 4 * 72) {     // bM_top = bM + HM * delta   (EnergyFunctional.cpp:870): four threads per row, every load of a
       const int i = (tid - 64) >> 2, q = tid & 3;   //   thread in flight together; their partial sums are added in a fixed order
       const double* delta = B.t_prior + nf * 16 + 4;
@@ -411,8 +453,11 @@ __global__ __launch_bounds__(TAIL_NT) void k_ba_tail(const BaDev* __restrict__ w
   if (tid < n) bp[pos[tid]] = sv[tid] * bF[tid];
   __syncthreads();
   TSTAMP(5);
-  // ------------------------------------------------------------------ P5
+  // ------------------------------------------------------------------ P5: wave 0 factorises and solves; wave 1 meanwhile does the part of the
+  // loop's host part that does not need x (energies of the linearisation, their 70 % quantile, the energy sum)
+  OptPre* pre = (OptPre*)(misc + 44);
   if (wv == 0) ldlt_solve_regs(As, bp, M /* L^T */, col, xp, n);
+  else if (wv == 1 && (flags & TAIL_STEP)) opt_pre_wave(B, *(OptPreSmem*)(tail_smem + TailLds::kPre), pre);
   __syncthreads();
   TSTAMP(6);
   // ------------------------------------------------------------------ P6: x = SVecI * solve(...) (:976), x -= P x (:980-984, :824-826)
@@ -460,7 +505,7 @@ __global__ __launch_bounds__(TAIL_NT) void k_ba_tail(const BaDev* __restrict__ w
   // ------------------------------------------------------------------ P7
   if (flags & TAIL_STEP) {
     __syncthreads();
-    opt_step_body<TAIL_NT>(Bw, B, OS, nullptr, 1, 0, iteration, last, stop_on_convergence, 1.0f, 0, misc + 22, 1, xv, nres_f, blockIdx.x, gridDim.x);
+    opt_step_body<TAIL_NT>(Bw, B, OS, nullptr, 1, 0, iteration, last, stop_on_convergence, 1.0f, 0, misc + 22, 1, xv, nres_f, blockIdx.x, gridDim.x, ba_finished(B) ? nullptr : (const OptPre*)(misc + 44));
   }
 }
 
