@@ -72,6 +72,18 @@ void release_track_batch(sdso_ctx* ctx) {
 
 }  // namespace sdso
 
+#ifdef SDSO_LM_STAMPS   // diagnostic build (make EXTRA=-DSDSO_LM_STAMPS, tools/dbg_lm_stamps.py): shader-clock cycles of thread 0 per phase of k_track_lm
+__shared__ unsigned long long lm_st_acc[16];
+__shared__ unsigned long long lm_st_last;
+#ifdef SDSO_LM_STAMPS_NOWAIT
+#define LMS_WAIT
+#else
+#define LMS_WAIT asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+#define LMS(i) do { if (threadIdx.x == 0) { LMS_WAIT const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); lm_st_acc[i] += tn_ - lm_st_last; lm_st_last = tn_; } } while (0)
+#else
+#define LMS(i) do { } while (0)
+#endif
 // ------------------------------------------------------------------ kernels
 // Per-lane sums of calcRes + calcGSSSE over the points first, first + stride, ... of one problem (TRK_UNROLL points per trip):
 // the 45 upper-triangle products, E, the flow-indicator sums and the four counters.
@@ -80,9 +92,11 @@ struct TrackLaneSums {
   float E, sT, sRT;
   int nE, nSat, nWarp, nShift;
 };
-template <bool MASK>
+// PRE: the caller hands over the lane's TRK_UNROLL points of the FIRST trip (k_track_lm keeps them in registers while it stays on a
+// level: the template does not move between evaluations); later trips (n > TRK_UNROLL * stride) load theirs.
+template <bool MASK, bool PRE = false, int UNR = TRK_UNROLL>
 __device__ __forceinline__ void track_accumulate(const sdso_track_eval_t& EV, const float4* __restrict__ pc, const float4* __restrict__ img, int n,
-                                                 int first, int stride, uint8_t* __restrict__ mask, TrackLaneSums& Sout) {
+                                                 int first, int stride, uint8_t* __restrict__ mask, TrackLaneSums& Sout, const float4* qpre = nullptr) {
   TrackLaneSums S;   // a local, copied out at the end: accumulating through the reference cost 40 VGPRs (196 instead of 154: 2 waves per SIMD instead of 3)
   const int lvl = EV.lvl, wl = EV.w, hl = EV.h;
   const float fxl = EV.fx, fyl = EV.fy, cxl = EV.cx, cyl = EV.cy;
@@ -101,23 +115,26 @@ __device__ __forceinline__ void track_accumulate(const sdso_track_eval_t& EV, co
   float E = 0.f, sT = 0.f, sRT = 0.f;
   int nE = 0, nSat = 0, nWarp = 0, nShift = 0;
 
-  // TRK_UNROLL template points per lane and trip, in three straight-line stages so that the memory system sees
+  // UNR template points per lane and trip, in three straight-line stages so that the memory system sees
   // all of a trip's requests at once: (1) the pc loads, (2) projection + bounds test + the 4 bilinear taps of every
   // point (an out-of-bounds point reads pixel (2,2) instead of branching around its loads), (3) residual, Huber,
   // the 45 products — in point order, so the per-lane sums are those of the one-point-per-trip loop.
-  for (int i0 = first; i0 < n; i0 += TRK_UNROLL * stride) {
-    float4 q[TRK_UNROLL];
+  for (int i0 = first; i0 < n; i0 += UNR * stride) {
+    float4 q[UNR];
 #pragma unroll
-    for (int s = 0; s < TRK_UNROLL; s++) {
+    for (int s = 0; s < UNR; s++) {
       const int i = i0 + s * stride;
-      q[s] = pc[i < n ? i : i0];
+      if (PRE && i0 == first) q[s] = qpre[s]; else q[s] = pc[i < n ? i : i0];
     }
-    float us[TRK_UNROLL], vs[TRK_UNROLL], nid[TRK_UNROLL];
-    bool ok[TRK_UNROLL];
-    float3 hits[TRK_UNROLL];
+    LMS(1);
+    float us[UNR], vs[UNR], nid[UNR];
+    bool ok[UNR];
+    float3 hits[UNR];
 #pragma unroll
-    for (int s = 0; s < TRK_UNROLL; s++) {
+    for (int s = 0; s < UNR; s++) {
       const int i = i0 + s * stride;
+      ok[s] = false; us[s] = 0.f; vs[s] = 0.f; nid[s] = 0.f; hits[s] = make_float3(0.f, 0.f, 0.f);
+      if (i0 - first + s * stride >= n) continue;            // (uniform over the launch's threads: the whole slot is past the end — the coarse levels have fewer points than threads)
       const float x = q[s].x, y = q[s].y, id = q[s].z;
       float pt[3];
 #pragma unroll
@@ -151,9 +168,11 @@ __device__ __forceinline__ void track_accumulate(const sdso_track_eval_t& EV, co
       ok[s] = i < n && Ku > 2 && Kv > 2 && Ku < wlm3 && Kv < hlm3 && new_idepth > 0;  // :696
       hits[s] = interp33(img, ok[s] ? Ku : 2.5f, ok[s] ? Kv : 2.5f, wl);
     }
+    LMS(2);
 #pragma unroll
-    for (int s = 0; s < TRK_UNROLL; s++) {
+    for (int s = 0; s < UNR; s++) {
       const int i = i0 + s * stride;
+      if (i0 - first + s * stride >= n) continue;
       const float u = us[s], v = vs[s], new_idepth = nid[s], refColor = q[s].w;
       const float3 hit = hits[s];
       bool inl = false;
@@ -685,7 +704,13 @@ struct LmJob {
   sdso_aff_t aff;
   sdso_track_result_t out;
 };
-constexpr int LM_BLOCK = 512;    // 8 waves: the evaluation body wants ~200 VGPRs (two waves per SIMD)
+#ifndef LM_BLOCK_THREADS
+#define LM_BLOCK_THREADS 512
+#endif
+#ifndef LM_UNROLL
+#define LM_UNROLL 4
+#endif
+constexpr int LM_BLOCK = LM_BLOCK_THREADS;    // 512: 8 waves, the evaluation body wants ~200 VGPRs at four points per trip (two waves per SIMD)
 }  // namespace sdso
 
 // ---- the LM step of the resident driver, by the 64 lanes of wave 0 ------------------------------------------------------------
@@ -694,55 +719,80 @@ __device__ __forceinline__ double lm_readlane(double v, int src) {
   const unsigned lo = __builtin_amdgcn_readlane((unsigned)u, src), hi = __builtin_amdgcn_readlane((unsigned)(u >> 32), src);
   return __longlong_as_double(((unsigned long long)hi << 32) | lo);
 }
+// value of lane 8 (lane / 8) + k: ds_swizzle_b32 in bit mode (and 0x18, or k) — a broadcast inside every group of eight lanes, no address register
+template <int K>
+__device__ __forceinline__ double lm_bcast8_c(double v) {
+  const unsigned long long u = __double_as_longlong(v);
+  constexpr int pat = 0x18 | (K << 5);
+  const unsigned lo = (unsigned)__builtin_amdgcn_ds_swizzle((int)(unsigned)u, pat), hi = (unsigned)__builtin_amdgcn_ds_swizzle((int)(unsigned)(u >> 32), pat);
+  return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ double lm_bcast8(double v, int k) {   // k is a constant after unrolling
+  switch (k) {
+    case 0: return lm_bcast8_c<0>(v); case 1: return lm_bcast8_c<1>(v); case 2: return lm_bcast8_c<2>(v); case 3: return lm_bcast8_c<3>(v);
+    case 4: return lm_bcast8_c<4>(v); case 5: return lm_bcast8_c<5>(v); case 6: return lm_bcast8_c<6>(v); default: return lm_bcast8_c<7>(v);
+  }
+}
 // x = A^-1 rhs for the leading n x n block (n <= 8) of a symmetric A: the algorithm of solveLdltSmall / Eigen::LDLT (symmetric pivoting
-// on the first largest |diagonal| of the not yet eliminated positions, read from the INPUT matrix as Eigen's left-looking loop does), with the matrix spread over the wave — lane 8i + j holds A(i,j), lanes
-// 8i hold rhs(i) — and every element updated by the expression the sequential code uses (the upper triangle mirrors the lower one:
-// its lanes evaluate the lower element's expression with the roles swapped).  A single lane walking these 64 doubles through LDS
-// took ~19 us per solve; here a step is a handful of cross-lane moves.  All lanes return with the same x[0..7].
+// on the first largest |diagonal| of the not yet eliminated positions, read from the INPUT matrix as Eigen's left-looking loop does), with
+// the matrix spread over the wave — lane 8i + j holds A(i,j), every lane of row i holds rhs(i) — and every element updated by the
+// expression the sequential code uses (the upper triangle mirrors the lower one: its lanes evaluate the lower element's expression with
+// the roles swapped).  Because the pivot search only ever reads the input diagonal, the whole pivot order is known before the first
+// elimination: every lane replays the eight selections on the eight diagonal values (wave-uniform arithmetic), the matrix is exchanged
+// ONCE, and the eight elimination steps are readlane -> divide -> two broadcasts -> update (the forward substitution rides along: same
+// terms, same order as the sequential loop).  The division by D runs on all rows at once.  All lanes return with the same x[0..7].
+// (History: a single lane walking these 64 doubles through LDS took ~19 us per solve; exchanging per step 4.2 us; this form 2.3 us.)
 __device__ __forceinline__ void lm_wave_ldlt(double a, double rhs, int n, double* x) {
   const int lane = threadIdx.x & 63, i = lane >> 3, j = lane & 7;
-  double y = rhs;
-  double a0 = a;                                  // the input matrix, exchanged along: the pivot search reads ITS diagonal (solveLdlt, ba_ldlt.h)
-  int pi = i;
-  for (int k = 0; k < n; k++) {
-    double best = fabs(lm_readlane(a0, k * 9));
-    int p = k;
-    for (int m = k + 1; m < n; m++) {
-      const double v = fabs(lm_readlane(a0, m * 9));
-      if (v > best) { best = v; p = m; }
+  double dg[8];
+  int perm[8];
+#pragma unroll
+  for (int m = 0; m < 8; m++) { dg[m] = fabs(lm_readlane(a, m * 9)); perm[m] = m; }
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    if (k < n) {
+      double best = dg[k];
+      int p = k;
+#pragma unroll
+      for (int m = k + 1; m < 8; m++) if (m < n && dg[m] > best) { best = dg[m]; p = m; }
+#pragma unroll
+      for (int m = k + 1; m < 8; m++) if (m == p) { dg[m] = dg[k]; const int t = perm[m]; perm[m] = perm[k]; perm[k] = t; }
+      dg[k] = best;
     }
-    if (p != k) {
-      const int si = i == k ? p : (i == p ? k : i), sj = j == k ? p : (j == p ? k : j);
-      a = __shfl(a, si * 8 + sj, 64);
-      a0 = __shfl(a0, si * 8 + sj, 64);
-      y = __shfl(y, si * 8, 64);
-      pi = __shfl(pi, si * 8 + j, 64);
-    }
-    const double dk = lm_readlane(a, k * 9);
-    if (dk == 0.0) continue;                      // a zero pivot leaves its column as it is
-    const double l = a / dk;                      // column k below the diagonal: L(i,k)
-    const double lik = __shfl(l, i * 8 + k, 64), ljk = __shfl(l, j * 8 + k, 64);
-    if (i > k && j > k && i < n && j < n) {
-      if (i >= j) a = a - (lik * dk) * ljk;       // A(i,j) -= l_ik d_k A(j,k)
-      else a = a - (ljk * dk) * lik;              // mirror of the lower element (j,i)
-    }
-    if (j == k && i > k) a = l;
   }
-  // triangular solves, every lane redundantly (values by v_readlane at fixed lanes): same summation order as the sequential code
+  int si = perm[0], sj = perm[0];
+#pragma unroll
+  for (int m = 1; m < 8; m++) { si = i == m ? perm[m] : si; sj = j == m ? perm[m] : sj; }
+  a = __shfl(a, si * 8 + sj, 64);
+  double y = __shfl(rhs, si * 8, 64);
+  const int pi = si;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    if (k < n) {
+      const double dk = lm_readlane(a, k * 9);
+      const double yk = lm_readlane(y, k * 8);
+      const bool nz = dk != 0.0;                    // a zero pivot leaves its column as it is
+      const double l = nz ? a / dk : a;             // column k below the diagonal: L(i,k)
+      const double lik = lm_bcast8(l, k), ljk = __shfl(l, j * 8 + k, 64);
+      if (nz) {
+        if (i > k && j > k && i < n && j < n) {
+          if (i >= j) a = a - (lik * dk) * ljk;     // A(i,j) -= l_ik d_k A(j,k)
+          else a = a - (ljk * dk) * lik;            // mirror of the lower element (j,i)
+        }
+        if (j == k && i > k) a = l;
+      }
+      if (i > k && i < n) y = y - lik * yk;         // L z = rhs, term k of row i
+    }
+  }
+  // D, on every row at once
+  double dmine = lm_readlane(a, 0);
+#pragma unroll
+  for (int m = 1; m < 8; m++) { const double d = lm_readlane(a, m * 9); dmine = i == m ? d : dmine; }
+  const double w = dmine != 0.0 ? y / dmine : 0.0;
+  // L^T x = w, every lane redundantly (values by v_readlane at fixed lanes): same summation order as the sequential code
   double yv[8];
 #pragma unroll
-  for (int r = 0; r < 8; r++) yv[r] = lm_readlane(y, r * 8);
-#pragma unroll
-  for (int r = 0; r < 8; r++) {
-    if (r < n) {
-      double sacc = yv[r];
-#pragma unroll
-      for (int c = 0; c < 8; c++) if (c < r) sacc -= lm_readlane(a, r * 8 + c) * yv[c];
-      yv[r] = sacc;
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < 8; r++) { const double d = lm_readlane(a, r * 9); if (r < n) yv[r] = d != 0.0 ? yv[r] / d : 0.0; }
+  for (int r = 0; r < 8; r++) yv[r] = lm_readlane(w, r * 8);
 #pragma unroll
   for (int r = 7; r >= 0; r--) {
     if (r < n) {
@@ -765,123 +815,219 @@ __device__ __forceinline__ void lm_wave_ldlt(double a, double rhs, int n, double
 }
 
 // wave 0 of k_track_lm: finalise the evaluation (calcGSSSE :580-595, calcRes :783-789, the expressions of k_track_finalize), take
-// the LM decisions (lane 0, LmCore::consume_pre), copy H / b, solve for the increment (wave), propose the trial pose (lane 0)
-__device__ __forceinline__ void lm_wave_step(LmCore& core, const float* F, const int* I, TrackOut& O, int* s_flags) {
+// the LM decisions (lane 0, LmCore::consume_pre), solve for the increment (wave), propose the trial pose (lane 0).  The accepted
+// system lives in the wave's registers — lane 8i + j holds H(i,j) and b(i) — between the evaluations (Hacc / bacc): no copy through LDS.
+// Returns the call's `done`.
+__device__ __forceinline__ bool lm_wave_step(LmCore& core, const float* F, const int* I, double& Hacc, double& bacc) {
   const int lane = threadIdx.x & 63;
+  const int i = lane >> 3, j = lane & 7;
   const int nE = I[0], nSat = I[1], nWarp = I[2], nShift = I[3];
   const int npad = (nWarp + 3) & ~3;
+  double Hnew, bnew;
   {
-    const double SC[8] = {SCALE_XI_ROT, SCALE_XI_ROT, SCALE_XI_ROT, SCALE_XI_TRANS, SCALE_XI_TRANS, SCALE_XI_TRANS, SCALE_A, SCALE_B};
+    auto scale_of = [](int k) -> double { return k < 3 ? (double)SCALE_XI_ROT : k < 6 ? (double)SCALE_XI_TRANS : k == 6 ? (double)SCALE_A : (double)SCALE_B; };
     const float inv_n = 1.0f / npad;
-    for (int e = lane; e < 72; e += 64) {
-      const int r = e / 9, c = e % 9;
-      const int lo = r < c ? r : c, hi = r < c ? c : r;
-      const int idx = lo * 9 - lo * (lo - 1) / 2 + (hi - lo);
-      double v = npad > 0 ? (double)F[idx] * (double)inv_n : 0.0;
-      if (c < 8) { v *= SC[c]; v *= SC[r]; O.H[r * 8 + c] = v; }
-      else { v *= SC[r]; O.b[r] = v; }
-    }
-    if (lane == 0) {
-      O.res[0] = (double)F[45];
-      O.res[1] = (double)nE;
-      O.res[2] = (double)F[46] / ((double)(float)nShift + 0.1);
-      O.res[3] = 0;
-      O.res[4] = (double)F[47] / ((double)(float)nShift + 0.1);
-      O.res[5] = (double)((float)nSat / (float)nE);
-      O.n_warped = npad;
-    }
+    const int lo = i < j ? i : j, hi = i < j ? j : i;
+    const float fh = F[lo * 9 - lo * (lo - 1) / 2 + (hi - lo)], fb = F[i * 9 - i * (i - 1) / 2 + (8 - i)];
+    double v = npad > 0 ? (double)fh * (double)inv_n : 0.0;
+    v *= scale_of(j); v *= scale_of(i);
+    Hnew = v;
+    double u = npad > 0 ? (double)fb * (double)inv_n : 0.0;
+    u *= scale_of(i);
+    bnew = u;
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  LMS(7);
+  int act = 0, take = 0;
   if (lane == 0) {
-    bool take = false;
-    const int act = core.consume_pre(O.res, take);
-    s_flags[0] = act; s_flags[1] = take ? 1 : 0;
+    double res[6];
+    res[0] = (double)F[45];
+    res[1] = (double)nE;
+    res[2] = (double)F[46] / ((double)(float)nShift + 0.1);
+    res[3] = 0;
+    res[4] = (double)F[47] / ((double)(float)nShift + 0.1);
+    res[5] = (double)((float)nSat / (float)nE);
+    bool tk = false;
+    act = core.consume_pre(res, tk);
+    take = tk ? 1 : 0;
   }
+  act = __builtin_amdgcn_readfirstlane(act);
+  take = __builtin_amdgcn_readfirstlane(take);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  if (s_flags[0]) {
-    if (s_flags[1]) { core.H[lane] = O.H[lane]; if (lane < 8) core.b[lane] = O.b[lane]; }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  LMS(8);
+  if (act) {
+    if (take) { Hacc = Hnew; bacc = bnew; }
     // LmCore::solve_inc on the wave
-    const int i = lane >> 3, j = lane & 7;
     const double lam1 = 1 + core.lambda;
-    double a = core.H[lane];
+    double a = Hacc;
     if (i == j) a *= lam1;
-    const double nb = -core.b[i];
+    const double nb = -bacc;
     const bool fixA = core.p.affineOptModeA < 0, fixB = core.p.affineOptModeB < 0;
-    double x[8];
-    lm_wave_ldlt(a, nb, 8, x);
+    // the full solve, then (when an affine parameter is fixed) the reduced one of :937-964 — ONE copy of the factorisation in the code: the
+    // kernel's loop has to stay inside the instruction cache
     double incv[8];
+    const int npass = (fixA || fixB) ? 2 : 1;
+#pragma unroll 1
+    for (int pass = 0; pass < npass; pass++) {
+      double am = a, bm = nb;
+      int n = 8;
+      if (pass == 1) {
+        n = (fixA && fixB) ? 6 : 7;
+        if (fixA && !fixB) {   // rows / columns 6 <- 7 of the damped matrix, b likewise (:949-964)
+          const int si = i == 6 ? 7 : i, sj = j == 6 ? 7 : j;
+          am = __shfl(a, si * 8 + sj, 64);
+          bm = __shfl(nb, si * 8, 64);
+        }
+      }
+      double x[8];
+      lm_wave_ldlt(am, bm, n, x);
+      if (pass == 0) {
 #pragma unroll
-    for (int r = 0; r < 8; r++) incv[r] = x[r];
-    if (fixA && fixB) {
-      lm_wave_ldlt(a, nb, 6, x);
+        for (int r = 0; r < 8; r++) incv[r] = x[r];
+      } else if (fixA && fixB) {
 #pragma unroll
-      for (int r = 0; r < 6; r++) incv[r] = x[r];
-      incv[6] = incv[7] = 0;
+        for (int r = 0; r < 6; r++) incv[r] = x[r];
+        incv[6] = incv[7] = 0;
+      } else if (fixB) {
+#pragma unroll
+        for (int r = 0; r < 7; r++) incv[r] = x[r];
+        incv[7] = 0;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 8; r++) incv[r] = 0;
+#pragma unroll
+        for (int r = 0; r < 6; r++) incv[r] = x[r];
+        incv[7] = x[6];
+      }
     }
-    if (!fixA && fixB) {
-      lm_wave_ldlt(a, nb, 7, x);
-#pragma unroll
-      for (int r = 0; r < 7; r++) incv[r] = x[r];
-      incv[7] = 0;
-    }
-    if (fixA && !fixB) {   // rows / columns 6 <- 7 of the damped matrix, b likewise (:949-964)
-      const int si = i == 6 ? 7 : i, sj = j == 6 ? 7 : j;
-      const double as = __shfl(a, si * 8 + sj, 64);
-      const double bs = -core.b[si];
-      lm_wave_ldlt(as, bs, 7, x);
-#pragma unroll
-      for (int r = 0; r < 8; r++) incv[r] = 0;
-#pragma unroll
-      for (int r = 0; r < 6; r++) incv[r] = x[r];
-      incv[7] = x[6];
-    }
+    LMS(9);
     if (lane == 0) {
 #pragma unroll
       for (int r = 0; r < 8; r++) core.inc[r] = incv[r];
       core.propose_post();
     }
   }
-  if (lane == 0) s_flags[2] = core.done ? 1 : 0;
+  LMS(10);
+  int done = 0;
+  if (lane == 0) done = core.done ? 1 : 0;
+  return __builtin_amdgcn_readfirstlane(done) != 0;
 }
 
-__global__ __launch_bounds__(LM_BLOCK) void k_track_lm(LmJob* __restrict__ jobs) {
-  LmJob& J = jobs[blockIdx.x];
+// ---- a CLUSTER of G workgroups per hypothesis --------------------------------------------------------------------------------------
+// One CU evaluates a 4 000-point level at the rate its L1 is filled (two 128-byte lines per template point at 64 bytes per clock: the
+// point loop of a single workgroup was 55 % of the call).  With G > 1 the hypothesis' points are strided over G workgroups on G CUs (placed
+// on ONE XCD: workgroup L runs on XCD L % 8); member 0 is the LEADER — it owns the LM state machine — and the hand-offs go through an
+// LmCluster record in global memory:
+//   leader -> members : the evaluation request (ev, level, done), every word tagged with the evaluation number;
+//   members -> leader : their 52 partial sums, tagged likewise;
+// the receivers poll the tagged words themselves (≈ 0.7 us per hand-off on one XCD, tools/handoff_bench.hip; a flag + fence + second
+// read protocol cost twice that).  The leader adds the partials in member order: the result does not depend on timing.  Every spin is bounded (a member that never became resident — the device was shared —
+// ends the call with out.evaluations = -1 and the host repeats it with G = 1, which needs no co-residency).
+constexpr int LM_MAXG = 8;
+constexpr int LM_SPIN_LIMIT = 1 << 21;
+constexpr int LM_EV_WORDS = (int)(sizeof(sdso_track_eval_t) / 4);
+static_assert(sizeof(sdso_track_eval_t) % 4 == 0, "eval record is copied word by word");
+constexpr int LM_REQ_WORDS = LM_EV_WORDS + 2;   // + level, done
+static_assert(LM_REQ_WORDS <= 64, "one wave polls the request");
+// Every 32-bit word travels as a 64-bit {word, sequence number} pair written and read by ONE relaxed agent-scope atomic: a reader that
+// sees the tag of evaluation e has that evaluation's word — no flag, no fence, one round trip per hand-off.  (Zeroed before the launch;
+// the first evaluation is number 1.)
+struct LmCluster {
+  unsigned long long req[64];
+  unsigned long long part[LM_MAXG][64];
+};
+__device__ __forceinline__ void lm_put(unsigned long long* slot, unsigned word, int e) {
+  __hip_atomic_store(slot, (unsigned long long)word | ((unsigned long long)(unsigned)e << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long lm_get(const unsigned long long* slot) {
+  return __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// leader, lanes 0 .. LM_REQ_WORDS - 1 of one wave: the request of evaluation e (one store instruction; a single lane writing the 37 words
+// one after the other took 3 300 cycles)
+__device__ __forceinline__ void lm_publish(LmCluster& C, const sdso_track_eval_t& ev, int lvl, int done, int e) {
+  const int k = threadIdx.x;
+  if (k >= LM_REQ_WORDS) return;
+  const unsigned w = k < LM_EV_WORDS ? reinterpret_cast<const unsigned*>(&ev)[k] : k == LM_EV_WORDS ? (unsigned)lvl : (unsigned)done;
+  lm_put(&C.req[k], w, e);
+}
+
+__global__ __launch_bounds__(LM_BLOCK) void k_track_lm(LmJob* __restrict__ jobs, LmCluster* __restrict__ clusters, int nhyp, int G) {
+  // hypothesis c, member g: for G > 1 the members of a cluster share blockIdx % 8 (one XCD, one L2); speed only, any placement is correct
+  int c = blockIdx.x, g = 0;
+  if (G > 1) { const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3; g = j % G; c = (j / G) * 8 + xcd; }
+  if (c >= nhyp) return;
+  LmJob& J = jobs[c];
+  LmCluster& C = clusters[c];
   __shared__ __align__(16) unsigned char core_raw[sizeof(LmCore)];     // (LmCore has member initialisers: raw storage, init() sets every field it reads)
   LmCore& core = *reinterpret_cast<LmCore*>(core_raw);
   __shared__ sdso_track_eval_t ev;
   __shared__ float sF[LM_BLOCK / 64][TRK_NF + TRK_NI];
   __shared__ float F[TRK_NF];
   __shared__ int I[TRK_NI];
-  __shared__ int s_lvl, s_flags[3];
-  __shared__ TrackOut O;
+  __shared__ int s_lvl, s_done, s_abort;
+  __shared__ const float4* s_pc[SDSO_PYR_LEVELS];                      // the job's tables, read once (a global round trip per evaluation otherwise)
+  __shared__ const float4* s_img[SDSO_PYR_LEVELS];
+  __shared__ int s_n[SDSO_PYR_LEVELS];
   const int tid = threadIdx.x, wv = tid >> 6;
+  const bool leader = g == 0;
+  if (tid < SDSO_PYR_LEVELS) { s_pc[tid] = J.pc[tid]; s_img[tid] = J.img[tid]; s_n[tid] = J.n[tid]; }
   if (tid == 0) {
-    core.init(J.p, J.T, J.aff);
-    s_flags[2] = 0;
+    if (leader) core.init(J.p, J.T, J.aff);
+    s_done = 0; s_abort = 0;
   }
   __syncthreads();
-  // every trip is one evaluation; the loop ends for all threads together (the done flag is read behind a barrier)
 #ifdef SDSO_LM_STAMPS
-  unsigned long long t_fill = 0, t_eval = 0, t_red = 0, t_step = 0, t0s = 0;
-#define LMT(acc) do { if (tid == 0) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); acc += tn - t0s; t0s = tn; } } while (0)
-  if (tid == 0) t0s = __builtin_amdgcn_s_memtime();
+  if (tid == 0) { for (int k = 0; k < 16; k++) lm_st_acc[k] = 0; lm_st_last = __builtin_amdgcn_s_memtime(); }
+#define LMSL(i) do { if (leader) LMS(i); } while (0)
 #else
-#define LMT(acc) do { } while (0)
+#define LMSL(i) do { } while (0)
 #endif
-  for (int guard = 0; guard < 1024; guard++) {
-    if (tid == 0) {
-      fill_eval(core.p, core.lvl, core.reqT, core.reqAff, core.p.coarseCutoffTH * core.levelCutoffRepeat, ev);
-      s_lvl = core.lvl;
-      core.out.evaluations++;
-      core.out.point_evals += J.n[core.lvl];
+  double Hacc = 0.0, bacc = 0.0;                // wave 0 of the leader: the accepted system (lm_wave_step)
+  float4 qc[LM_UNROLL];                         // this thread's template points of level qlvl
+  int qlvl = -1;
+#pragma unroll
+  for (int u = 0; u < LM_UNROLL; u++) qc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int first = g * LM_BLOCK + tid, stride = G * LM_BLOCK;
+  // every trip is one evaluation; the loop ends for all threads together (the flags are read behind a barrier)
+  for (int e = 1; e <= 1024; e++) {
+    if (leader) {
+      if (tid == 0) {
+        fill_eval(core.p, core.lvl, core.reqT, core.reqAff, core.p.coarseCutoffTH * core.levelCutoffRepeat, ev);
+        s_lvl = core.lvl;
+        core.out.evaluations++;
+        core.out.point_evals += s_n[core.lvl];
+      }
+      __syncthreads();
+      if (G > 1 && wv == 0) lm_publish(C, ev, s_lvl, 0, e);
+    } else {
+      if (tid < LM_REQ_WORDS) {                 // (one wave) every lane waits for its own word of request e
+        unsigned long long v = 0;
+        int spins = 0;
+        for (;;) {
+          v = lm_get(&C.req[tid]);
+          if ((int)(v >> 32) == e || ++spins >= LM_SPIN_LIMIT) break;
+          __builtin_amdgcn_s_sleep(1);
+        }
+        if ((int)(v >> 32) != e) s_abort = 1;
+        else if (tid < LM_EV_WORDS) reinterpret_cast<unsigned*>(&ev)[tid] = (unsigned)v;
+        else if (tid == LM_EV_WORDS) s_lvl = (int)(unsigned)v;
+        else s_done = (int)(unsigned)v;
+      }
+      __syncthreads();
+      if (s_abort || s_done) return;
     }
-    __syncthreads();
-    LMT(t_fill);
-    const int lvl = s_lvl, n = J.n[lvl];
+    LMSL(0);
+    const int lvl = s_lvl, n = s_n[lvl];
+    if (lvl != qlvl) {                          // (uniform) first evaluation on this level: the points move into registers
+      const float4* __restrict__ pc = s_pc[lvl];
+      if (first < n) {
+#pragma unroll
+        for (int u = 0; u < LM_UNROLL; u++) { const int i = first + u * stride; qc[u] = pc[i < n ? i : first]; }
+      }
+      qlvl = lvl;
+    }
     TrackLaneSums S;
-    track_accumulate<false>(ev, J.pc[lvl], J.img[lvl], n, tid, LM_BLOCK, nullptr, S);
-    LMT(t_eval);
+    track_accumulate<false, true, LM_UNROLL>(ev, s_pc[lvl], s_img[lvl], n, first, stride, nullptr, S, qc);
+    LMSL(3);
     {   // the four counters ride along as floats (exact: they stay far below 2^24), so one 52-value row reduction covers everything
       float v52[TRK_NF + TRK_NI];
 #pragma unroll
@@ -890,27 +1036,57 @@ __global__ __launch_bounds__(LM_BLOCK) void k_track_lm(LmJob* __restrict__ jobs)
       v52[48] = (float)S.nE; v52[49] = (float)S.nSat; v52[50] = (float)S.nWarp; v52[51] = (float)S.nShift;
       wave_reduce_rows<TRK_NF + TRK_NI>(v52, [&](int k, float sum) { sF[wv][k] = sum; });
     }
+    LMSL(4);
     __syncthreads();
-    if (tid < TRK_NF + TRK_NI) {        // fixed order over the waves: run-to-run reproducible
-      float sum = sF[0][tid];
+    LMSL(5);
+    float mine = 0.f;
+    if (tid < TRK_NF + TRK_NI) {                // fixed order over the waves: run-to-run reproducible
+      mine = sF[0][tid];
 #pragma unroll
-      for (int w = 1; w < LM_BLOCK / 64; w++) sum += sF[w][tid];
-      if (tid < TRK_NF) F[tid] = sum; else I[tid - TRK_NF] = (int)sum;
+      for (int w = 1; w < LM_BLOCK / 64; w++) mine += sF[w][tid];
     }
+    if (!leader) {                              // hand the partial over, wait for the next request
+      if (tid < TRK_NF + TRK_NI) lm_put(&C.part[g][tid], __float_as_uint(mine), e);
+      continue;
+    }
+    if (G > 1 && tid < TRK_NF + TRK_NI) {       // the members' partials of evaluation e, added in member order
+      unsigned long long v[LM_MAXG];
+      bool all = false;
+      for (int spins = 0; spins < LM_SPIN_LIMIT && !all; spins++) {
+        all = true;
+#pragma unroll
+        for (int m = 1; m < LM_MAXG; m++)
+          if (m < G) { v[m] = lm_get(&C.part[m][tid]); all = all && (int)(v[m] >> 32) == e; }
+        if (!all) __builtin_amdgcn_s_sleep(1);
+      }
+      if (!all) s_abort = 1;
+#pragma unroll
+      for (int m = 1; m < LM_MAXG; m++) if (m < G) mine += __uint_as_float((unsigned)v[m]);
+    }
+    if (tid < TRK_NF) F[tid] = mine; else if (tid < TRK_NF + TRK_NI) I[tid - TRK_NF] = (int)mine;
     __syncthreads();
-    LMT(t_red);
-    if (wv == 0) lm_wave_step(core, F, I, O, s_flags);
+    if (s_abort) {                              // a member never answered: release the ones that did, give the call back to the host
+      if (wv == 0) lm_publish(C, ev, 0, 1, e + 1);
+      if (tid == 0) { J.out = core.out; J.out.evaluations = -1; }
+      return;
+    }
+    LMSL(6);
+    if (wv == 0) { const bool d = lm_wave_step(core, F, I, Hacc, bacc); if (tid == 0) s_done = d ? 1 : 0; }
     __syncthreads();
-    LMT(t_step);
-    if (s_flags[2]) break;
+    LMSL(11);
+    if (s_done) {
+      if (G > 1 && wv == 0) lm_publish(C, ev, 0, 1, e + 1);
+      break;
+    }
   }
-#ifdef SDSO_LM_STAMPS
-  if (tid == 0) { core.out.lastFlowIndicators[0] = (double)t_fill; core.out.lastFlowIndicators[1] = (double)t_eval; core.out.lastFlowIndicators[2] = (double)t_red; core.out.lastResiduals[4] = (double)t_step; }
-#endif
-#undef LMT
-  if (tid == 0) {
+#undef LMSL
+  if (leader && tid == 0) {
     J.out = core.out;
     if (core.wrote_final) { J.T = core.T_final; J.aff = core.aff_final; }
+#ifdef SDSO_LM_STAMPS
+    for (int k = 0; k < 9; k++) J.T.R[k] = (double)lm_st_acc[k];
+    for (int k = 0; k < 3; k++) J.T.t[k] = (double)lm_st_acc[9 + k];
+#endif
   }
 }
 
@@ -995,24 +1171,41 @@ extern "C" int sdso_track_newest_coarse_batch(sdso_ctx* ctx, int nhyp, const int
   // resident driver: jobs through pinned memory, one launch, one synchronisation
   int rc = ensure_pinned(ctx, sizeof(LmJob) * (size_t)nhyp);
   if (rc) return rc;
-  rc = ensure_scratch(ctx, sizeof(LmJob) * (size_t)nhyp);
+  const size_t jobs_bytes = (sizeof(LmJob) * (size_t)nhyp + 255) & ~(size_t)255;
+  rc = ensure_scratch(ctx, jobs_bytes + sizeof(LmCluster) * (size_t)nhyp);
   if (rc) return rc;
   LmJob* hj = (LmJob*)ctx->pinned;
   for (int k = 0; k < nhyp; k++) {
     rc = resolve_job(ctx, ref_slots[k], frame_slots[k], prms[k], hj[k]);
     if (rc) return rc;
-    hj[k].T = lastToNew[k]; hj[k].aff = aff_g2l[k];
   }
   if (ctx->tb) ctx->tb->nprob = 0;   // (a prepared evaluation batch keeps its own buffers; nothing shared)
   LmJob* dj = (LmJob*)ctx->scratch;
-  SDSO_HIP(ctx, hipMemcpyAsync(dj, hj, sizeof(LmJob) * nhyp, hipMemcpyHostToDevice, ctx->stream));
-  {
-    ProfScope ps(ctx, "k_track_lm");
-    hipLaunchKernelGGL(k_track_lm, dim3(nhyp), dim3(LM_BLOCK), 0, ctx->stream, dj);
+  LmCluster* dc = (LmCluster*)((char*)ctx->scratch + jobs_bytes);
+  // workgroups per hypothesis: as many as keep the whole grid resident at once (the members of a cluster wait for each other; one
+  // 512-thread workgroup of this kernel fills a CU), eight at most.  SDSO_TRK_LM_CLUSTER=1 forces single workgroups.
+  static const int g_env = getenv("SDSO_TRK_LM_CLUSTER") ? atoi(getenv("SDSO_TRK_LM_CLUSTER")) : 0;
+  const int slots8 = 8 * ((nhyp + 7) / 8);
+  int G = std::min(LM_MAXG, (ctx->n_cu * 7 / 8) / slots8);   // (an eighth of the CUs stays free: a grid that needs every CU waits on any straggler)
+  if (g_env > 0) G = std::min(G, g_env);
+  if (G < 2) G = 1;
+  for (int attempt = 0; attempt < 2; attempt++) {
+    for (int k = 0; k < nhyp; k++) { hj[k].T = lastToNew[k]; hj[k].aff = aff_g2l[k]; }
+    SDSO_HIP(ctx, hipMemcpyAsync(dj, hj, sizeof(LmJob) * nhyp, hipMemcpyHostToDevice, ctx->stream));
+    if (G > 1) SDSO_HIP(ctx, hipMemsetAsync(dc, 0, sizeof(LmCluster) * (size_t)nhyp, ctx->stream));
+    {
+      ProfScope ps(ctx, "k_track_lm");
+      hipLaunchKernelGGL(k_track_lm, dim3(G > 1 ? slots8 * G : nhyp), dim3(LM_BLOCK), 0, ctx->stream, dj, dc, nhyp, G);
+    }
+    SDSO_HIP(ctx, hipGetLastError());
+    SDSO_HIP(ctx, hipMemcpyAsync(hj, dj, sizeof(LmJob) * nhyp, hipMemcpyDeviceToHost, ctx->stream));
+    SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    bool gave_up = false;
+    for (int k = 0; k < nhyp; k++) gave_up = gave_up || hj[k].out.evaluations < 0;
+    if (!gave_up) break;
+    SDSO_REQUIRE(ctx, G > 1, "k_track_lm gave up without a cluster");   // (cannot happen: single workgroups wait for nobody)
+    G = 1;                             // a cluster was not co-resident (shared device): the single-workgroup form needs no co-residency
   }
-  SDSO_HIP(ctx, hipGetLastError());
-  SDSO_HIP(ctx, hipMemcpyAsync(hj, dj, sizeof(LmJob) * nhyp, hipMemcpyDeviceToHost, ctx->stream));
-  SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
   for (int k = 0; k < nhyp; k++) { outs[k] = hj[k].out; lastToNew[k] = hj[k].T; aff_g2l[k] = hj[k].aff; }
   return SDSO_OK;
 }

@@ -7,10 +7,13 @@ for p in ("stereo-dso-g2o_amd", "oracle", "tests"):
 from sdso_amd import abi, synth
 import helpers
 ctx = abi.Context(0)
-prob = synth.tracker_problem(w=1232, h=368, npts=2000, seed=2002)
+NP = int(os.environ.get("NPTS", "2000"))
+prob = synth.tracker_problem(w=1232, h=368, npts=NP, seed=2002)
 ctx.upload_pyramid(2, prob["pyr_new"]); ctx.set_ref(1, prob["pc"])
 prm = helpers.track_params(prob)
 for rep in range(3):
     T = abi.SE3.from_Rt(np.eye(3), np.zeros(3)); aff = abi.Aff(0, 0); o = abi.TrackResult()
     ctx.check(ctx.L.sdso_track_newest_coarse(ctx.h, 1, 2, C.byref(prm), C.byref(T), C.byref(aff), C.byref(o)))
-    print("evaluations", o.evaluations, "cycles: fill_eval %d accumulate %d reduce %d step %d" % (o.lastFlowIndicators[0], o.lastFlowIndicators[1], o.lastFlowIndicators[2], o.lastResiduals[4]))
+    names = ["fill_eval+barrier", "acc: EV + pc loads", "acc: project + taps", "acc: products", "wave reduce", "barrier (slowest wave)", "cross-wave sum", "step: finalize H b res", "step: consume_pre", "step: copy + LDLT", "step: propose_post", "closing barrier"]
+    st = [T.R[k] for k in range(9)] + [T.t[k] for k in range(3)]
+    print("evaluations", o.evaluations, "cycles per evaluation: " + "  ".join("%s %d" % (nm, v / o.evaluations) for nm, v in zip(names, st)), " | total per evaluation %d" % (sum(st) / o.evaluations))
