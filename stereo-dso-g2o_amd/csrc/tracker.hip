@@ -742,76 +742,69 @@ __device__ __forceinline__ double lm_bcast8(double v, int k) {   // k is a const
 // ONCE, and the eight elimination steps are readlane -> divide -> two broadcasts -> update (the forward substitution rides along: same
 // terms, same order as the sequential loop).  The division by D runs on all rows at once.  All lanes return with the same x[0..7].
 // (History: a single lane walking these 64 doubles through LDS took ~19 us per solve; exchanging per step 4.2 us; this form 2.3 us.)
-__device__ __forceinline__ void lm_wave_ldlt(double a, double rhs, int n, double* x) {
+__device__ __forceinline__ void lm_wave_ldlt(double a, double rhs, int n, double* __restrict__ xs /* LDS, 8 doubles: x by ORIGINAL index */) {
   const int lane = threadIdx.x & 63, i = lane >> 3, j = lane & 7;
+  // everything outside the leading n x n block is zero: a zero pivot leaves its column alone and contributes nothing anywhere, so the
+  // eight steps below run unconditionally — straight-line code, selects instead of branches (the branchy form was 2 500 instructions)
+  a = (i < n && j < n) ? a : 0.0;
+  rhs = i < n ? rhs : 0.0;
   double dg[8];
   int perm[8];
 #pragma unroll
   for (int m = 0; m < 8; m++) { dg[m] = fabs(lm_readlane(a, m * 9)); perm[m] = m; }
 #pragma unroll
-  for (int k = 0; k < 8; k++) {
-    if (k < n) {
-      double best = dg[k];
-      int p = k;
+  for (int k = 0; k < 7; k++) {
+    double best = dg[k];
+    int p = k;
 #pragma unroll
-      for (int m = k + 1; m < 8; m++) if (m < n && dg[m] > best) { best = dg[m]; p = m; }
+    for (int m = k + 1; m < 8; m++) { const bool gt = dg[m] > best; best = gt ? dg[m] : best; p = gt ? m : p; }
+    const int pk = perm[k];
+    int pp = pk;
 #pragma unroll
-      for (int m = k + 1; m < 8; m++) if (m == p) { dg[m] = dg[k]; const int t = perm[m]; perm[m] = perm[k]; perm[k] = t; }
-      dg[k] = best;
-    }
+    for (int m = k + 1; m < 8; m++) { const bool is = m == p; pp = is ? perm[m] : pp; dg[m] = is ? dg[k] : dg[m]; perm[m] = is ? pk : perm[m]; }
+    perm[k] = pp;
+    dg[k] = best;
   }
   int si = perm[0], sj = perm[0];
 #pragma unroll
   for (int m = 1; m < 8; m++) { si = i == m ? perm[m] : si; sj = j == m ? perm[m] : sj; }
   a = __shfl(a, si * 8 + sj, 64);
   double y = __shfl(rhs, si * 8, 64);
-  const int pi = si;
 #pragma unroll
   for (int k = 0; k < 8; k++) {
-    if (k < n) {
-      const double dk = lm_readlane(a, k * 9);
-      const double yk = lm_readlane(y, k * 8);
-      const bool nz = dk != 0.0;                    // a zero pivot leaves its column as it is
-      const double l = nz ? a / dk : a;             // column k below the diagonal: L(i,k)
-      const double lik = lm_bcast8(l, k), ljk = __shfl(l, j * 8 + k, 64);
-      if (nz) {
-        if (i > k && j > k && i < n && j < n) {
-          if (i >= j) a = a - (lik * dk) * ljk;     // A(i,j) -= l_ik d_k A(j,k)
-          else a = a - (ljk * dk) * lik;            // mirror of the lower element (j,i)
-        }
-        if (j == k && i > k) a = l;
-      }
-      if (i > k && i < n) y = y - lik * yk;         // L z = rhs, term k of row i
-    }
+    const double dk = lm_readlane(a, k * 9);
+    const double yk = lm_readlane(y, k * 8);
+    const bool nz = dk != 0.0;                      // a zero pivot leaves its column as it is
+    const double l = nz ? a / dk : a;               // column k below the diagonal: L(i,k)
+    const double lik = lm_bcast8(l, k), ljk = __shfl(l, j * 8 + k, 64);
+    const bool lower = i >= j;                      // the upper triangle mirrors the lower element (j,i): the same expression with the roles swapped
+    const double an = a - ((lower ? lik : ljk) * dk) * (lower ? ljk : lik);   // A(i,j) -= (l_ik d_k) A(j,k)
+    a = (nz && i > k && j > k) ? an : a;
+    a = (nz && j == k && i > k) ? l : a;
+    y = i > k ? y - lik * yk : y;                   // L z = rhs, term k of row i
   }
   // D, on every row at once
   double dmine = lm_readlane(a, 0);
 #pragma unroll
   for (int m = 1; m < 8; m++) { const double d = lm_readlane(a, m * 9); dmine = i == m ? d : dmine; }
   const double w = dmine != 0.0 ? y / dmine : 0.0;
-  // L^T x = w, every lane redundantly (values by v_readlane at fixed lanes): same summation order as the sequential code
+  // L^T x = w, every lane redundantly (values by v_readlane at fixed lanes): same summation order as the sequential code (the terms past n are 0 * 0)
   double yv[8];
 #pragma unroll
   for (int r = 0; r < 8; r++) yv[r] = lm_readlane(w, r * 8);
 #pragma unroll
-  for (int r = 7; r >= 0; r--) {
-    if (r < n) {
-      double sacc = yv[r];
+  for (int r = 6; r >= 0; r--) {
+    double sacc = yv[r];
 #pragma unroll
-      for (int c = 0; c < 8; c++) if (c > r && c < n) sacc -= lm_readlane(a, c * 8 + r) * yv[c];
-      yv[r] = sacc;
-    }
+    for (int c = r + 1; c < 8; c++) sacc -= lm_readlane(a, c * 8 + r) * yv[c];
+    yv[r] = sacc;
   }
+  // position r holds the unknown of original index perm[r]
+  if (lane == 0) {
 #pragma unroll
-  for (int r = 0; r < 8; r++) x[r] = 0.0;
-#pragma unroll
-  for (int r = 0; r < 8; r++) {
-    const int pr = __builtin_amdgcn_readlane(pi, r * 8);
-    if (r < n) {
-#pragma unroll
-      for (int c = 0; c < 8; c++) if (pr == c) x[c] = yv[r];
-    }
+    for (int r = 0; r < 8; r++) xs[perm[r]] = yv[r];
   }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // wave 0 of k_track_lm: finalise the evaluation (calcGSSSE :580-595, calcRes :783-789, the expressions of k_track_finalize), take
@@ -878,8 +871,10 @@ __device__ __forceinline__ bool lm_wave_step(LmCore& core, const float* F, const
           bm = __shfl(nb, si * 8, 64);
         }
       }
+      lm_wave_ldlt(am, bm, n, core.wx);
       double x[8];
-      lm_wave_ldlt(am, bm, n, x);
+#pragma unroll
+      for (int r = 0; r < 8; r++) x[r] = core.wx[r];
       if (pass == 0) {
 #pragma unroll
         for (int r = 0; r < 8; r++) incv[r] = x[r];
