@@ -396,10 +396,14 @@ __global__ __launch_bounds__(256, MINB) void k_trace_stereo(TraceDev T) {
 // operation order: bit-identical outputs.
 template <int GN_MODE, int PTS>   // PTS points per 256-thread workgroup (PTS / 4 searches per wave)
 __global__ __launch_bounds__(256) void k_trace_stereo_blk(TraceDev T) {
-  __shared__ float s_ptx0[PTS], s_pty0[PTS], s_dx[PTS], s_dy[PTS];
   __shared__ int s_steps[PTS];                                   // 0: the point does not reach the search
   __shared__ float s_bE[PTS], s_bX[PTS], s_bY[PTS], s_second[PTS];
   __shared__ int s_bI[PTS];
+  // the sample positions of every step of every point: ptx is the reference's running sum (ptx += dx, one rounding per step), so step s needs
+  // s dependent additions — run by the point's OWN lane in phase 1 (64 points per instruction) instead of by every step lane of phase 2
+  // (where the 45-trip loop was 40 % of a search's instructions).  Row stride 101: the 16..64 point lanes write distinct banks.
+  constexpr int kStepCap = 100, kStepLd = kStepCap + 1;
+  __shared__ float s_px[PTS * kStepLd], s_py[PTS * kStepLd];
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const int i = blockIdx.x * PTS + t;
   const float4* __restrict__ dI = T.img;
@@ -488,8 +492,11 @@ __global__ __launch_bounds__(256) void k_trace_stereo_blk(TraceDev T) {
         const float pty0 = vMin - randShift * dy;
         if (!isfinite(dx) || !isfinite(dy)) { finish(IPS_OOB, -1, -1, 0, true); break; }
         if (numSteps >= 100) numSteps = 99;
-        s_ptx0[t] = ptx0; s_pty0[t] = pty0; s_dx[t] = dx; s_dy[t] = dy;
         s_steps[t] = numSteps > 0 ? numSteps : 0;
+        {
+          float px = ptx0, py = pty0;
+          for (int k = 0; k < numSteps; k++) { s_px[t * kStepLd + k] = px; s_py[t * kStepLd + k] = py; px += dx; py += dy; }
+        }
         live = true;
       } while (false);
     }
@@ -503,15 +510,13 @@ __global__ __launch_bounds__(256) void k_trace_stereo_blk(TraceDev T) {
   for (int pp = 0; pp < PTS / 4; pp++) {
     const int pt = wv * (PTS / 4) + pp;
     const int nsteps = s_steps[pt];
-    const float sdx = s_dx[pt], sdy = s_dy[pt], x0 = s_ptx0[pt], y0 = s_pty0[pt];
     const float* color = T.color + (size_t)(blockIdx.x * PTS + pt) * 8;
     float myE[2] = {1e30f, 1e30f}, myX[2] = {0, 0}, myY[2] = {0, 0};
 #pragma unroll
     for (int pass = 0; pass < 2; pass++) {
       const int s = pass * 64 + lane;
       if (s < nsteps) {
-        float ptx = x0, pty = y0;
-        for (int k = 0; k < s; k++) { ptx += sdx; pty += sdy; }
+        const float ptx = s_px[pt * kStepLd + s], pty = s_py[pt * kStepLd + s];
         float energy = 0;
 #pragma unroll
         for (int idx = 0; idx < 8; idx++) {
