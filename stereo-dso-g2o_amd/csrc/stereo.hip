@@ -394,11 +394,23 @@ __global__ __launch_bounds__(256, MINB) void k_trace_stereo(TraceDev T) {
 // The per-wave kernel above spends every instruction of the geometry at 1 / 64 and of the refinement at 8 / 64 lanes and is VALU-issue
 // bound (1 350 VALU instructions per point); here those parts run 64 points per instruction: ~750 per point.  Same expressions, same
 // operation order: bit-identical outputs.
+// value of lane 8 (lane / 8) + K of a group of eight lanes (ds_swizzle_b32, bit mode: and 0x18, or K, inside each half of the wave)
+template <int K>
+__device__ __forceinline__ float tr_bcast8(float v) { return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x18 | (K << 5))); }
+template <int K>
+__device__ __forceinline__ int tr_bcast8(int v) { return __builtin_amdgcn_ds_swizzle(v, 0x18 | (K << 5)); }
+template <int K>
+__device__ __forceinline__ double tr_bcast8(double v) {
+  const unsigned long long u = __double_as_longlong(v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_ds_swizzle((int)(unsigned)u, 0x18 | (K << 5)), hi = (unsigned)__builtin_amdgcn_ds_swizzle((int)(unsigned)(u >> 32), 0x18 | (K << 5));
+  return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
 template <int GN_MODE, int PTS>   // PTS points per 256-thread workgroup (PTS / 4 searches per wave)
 __global__ __launch_bounds__(256) void k_trace_stereo_blk(TraceDev T) {
   __shared__ int s_steps[PTS];                                   // 0: the point does not reach the search
   __shared__ float s_bE[PTS], s_bX[PTS], s_bY[PTS], s_second[PTS];
   __shared__ int s_bI[PTS];
+  __shared__ float s_dx[PTS], s_dy[PTS], s_rU[PTS], s_rV[PTS], s_rE[PTS];   // search direction; the refined position and energy (phase 3a -> 3b)
   // the sample positions of every step of every point: ptx is the reference's running sum (ptx += dx, one rounding per step), so step s needs
   // s dependent additions — run by the point's OWN lane in phase 1 (64 points per instruction) instead of by every step lane of phase 2
   // (where the 45-trip loop was 40 % of a search's instructions).  Row stride 101: the 16..64 point lanes write distinct banks.
@@ -493,6 +505,7 @@ __global__ __launch_bounds__(256) void k_trace_stereo_blk(TraceDev T) {
         if (!isfinite(dx) || !isfinite(dy)) { finish(IPS_OOB, -1, -1, 0, true); break; }
         if (numSteps >= 100) numSteps = 99;
         s_steps[t] = numSteps > 0 ? numSteps : 0;
+        s_dx[t] = dx; s_dy[t] = dy;
         {
           float px = ptx0, py = pty0;
           for (int k = 0; k < numSteps; k++) { s_px[t * kStepLd + k] = px; s_py[t * kStepLd + k] = py; px += dx; py += dy; }
@@ -556,94 +569,112 @@ __global__ __launch_bounds__(256) void k_trace_stereo_blk(TraceDev T) {
   }
   __syncthreads();
 
-  // ---- phase 3: refinement and outputs, one lane per point
-  if (!live) return;
-  const float* color = T.color + (size_t)i * 8;
-  const float* weights = T.weights + (size_t)i * 8;
-  float bestU = s_bX[t], bestV = s_bY[t], bestEnergy = s_bE[t];
-  const int bestIdx = s_bI[t];
-  if (bestIdx < 0) { bestU = 0; bestV = 0; bestEnergy = 1e10f; }
-  const float secondBest = s_second[t];
-  const float newQuality = secondBest / bestEnergy;
-  if (newQuality < quality || numSteps > 10) quality = newQuality;
-
-  if constexpr (GN_MODE == 1) {
-    // fork-live refinement (ImmaturePoint.cpp:309-412): VertexUVDSO in double, 8 EdgeTracePointUVDSO (dso_g2o_edge.cpp:571-619) with
-    // Huber(9), one undamped g2o Gauss-Newton step per pass, update clamped by VertexUVDSO::oplusImpl (dso_g2o_vertex.cpp:73-88)
-    double U = bestU, V = bestV;
-    const double ddx = dx, ddy = dy;
-    if (kTraceGNIterations > 0) bestEnergy = 1e5;
-    for (int it = 0; it < kTraceGNIterations; it++) {
-      float energy = 0;
-      double Hs = 0, bs = 0;
-      const bool inside = !((U - 2) < 0 || (U + 3) > (wG0 - 3) || (V - 2) < 0 || (V + 3) > (hG0 - 3));
-      for (int idx = 0; idx < 8; idx++) {
+  // ---- phase 3a: sub-pixel refinement, lane = (point, pattern pixel): the 8 samples of a pass are taken by 8 lanes at once and added in
+  // pattern order on every lane of the group (the reference's sums, term by term); one lane per point walked them one after the other
+  // (840 instructions and 6 dependent round trips per 16 points, with the other three waves of the workgroup idle)
+#define TR_ALL8(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7)
+  for (int q = t; q < PTS * 8; q += 256) {
+    const int pl = q >> 3, idx = q & 7;
+    if (s_steps[pl] <= 0) continue;                             // (all eight lanes of a point alike)
+    const size_t gi = (size_t)blockIdx.x * PTS + pl;
+    const float col = T.color[gi * 8 + idx], wgt = T.weights[gi * 8 + idx];
+    const float dx = s_dx[pl], dy = s_dy[pl];
+    float bestU = s_bX[pl], bestV = s_bY[pl], bestEnergy = s_bE[pl];
+    if (s_bI[pl] < 0) { bestU = 0; bestV = 0; bestEnergy = 1e10f; }
+    const float patx = (float)c_pat[idx][0], paty = (float)c_pat[idx][1];
+    if constexpr (GN_MODE == 1) {
+      // fork-live refinement (ImmaturePoint.cpp:309-412): VertexUVDSO in double, 8 EdgeTracePointUVDSO (dso_g2o_edge.cpp:571-619) with
+      // Huber(9), one undamped g2o Gauss-Newton step per pass, update clamped by VertexUVDSO::oplusImpl (dso_g2o_vertex.cpp:73-88)
+      double U = bestU, V = bestV;
+      const double ddx = dx, ddy = dy;
+      if (kTraceGNIterations > 0) bestEnergy = 1e5;
+      for (int it = 0; it < kTraceGNIterations; it++) {
         double e = 0, J = 0;
-        if (inside) {
-          const float3 hit = interp33(dI, (float)(U + (float)c_pat[idx][0]), (float)(V + (float)c_pat[idx][1]), wG0);
-          if (isfinite(hit.x)) {
-            e = hit.x - (1.0f * (double)color[idx] + 0.0f);
-            J = ddx * hit.y + ddy * hit.z;
-          }
+        const bool inside = !((U - 2) < 0 || (U + 3) > (wG0 - 3) || (V - 2) < 0 || (V + 3) > (hG0 - 3));
+        const float3 hit = interp33(dI, inside ? (float)(U + patx) : 2.5f, inside ? (float)(V + paty) : 2.5f, wG0);   // (outside: pixel (2,2), ignored)
+        if (inside && isfinite(hit.x)) {
+          e = hit.x - (1.0f * (double)col + 0.0f);
+          J = ddx * hit.y + ddy * hit.z;
         }
         const float residual = e;
         const float hw = fabsf(residual) < kHuberTH ? 1 : kHuberTH / fabsf(residual);
-        const float te = weights[idx] * weights[idx] * hw * residual * residual * (2 - hw);
+        const float te = wgt * wgt * hw * residual * residual * (2 - hw);
         const double e2 = e * e;
         const double rho1 = e2 <= (double)kHuberTH * kHuberTH ? 1. : kHuberTH / sqrt(e2);
         const double tb = rho1 * J * e, tH = J * rho1 * J;
-        energy += te;
-        bs -= tb;
-        Hs += tH;
+        float energy = 0;
+        double Hs = 0, bs = 0;
+#define TR_ADD(K) energy += tr_bcast8<K>(te); bs -= tr_bcast8<K>(tb); Hs += tr_bcast8<K>(tH);
+        TR_ALL8(TR_ADD)
+#undef TR_ADD
+        if (Hs != 0) {
+          double update = bs / Hs;
+          if (update < -0.5) update = -0.5;
+          else if (update > 0.5) update = 0.5;
+          else if (!isfinite(update)) update = 0;
+          U += update * ddx;
+          V += update * ddy;
+        }
+        if (!(energy > bestEnergy)) bestEnergy = energy;
       }
-      if (Hs != 0) {
-        double update = bs / Hs;
-        if (update < -0.5) update = -0.5;
-        else if (update > 0.5) update = 0.5;
-        else if (!isfinite(update)) update = 0;
-        U += update * ddx;
-        V += update * ddy;
+      bestU = U;
+      bestV = V;
+    } else {
+      // DSO-native GN (ImmaturePoint.cpp:707-769)
+      float uBak = bestU, vBak = bestV, stepBack = 0;
+      const float gnstepsize = 1;
+      if (kTraceGNIterations > 0) bestEnergy = 1e5;
+      for (int it = 0; it < kTraceGNIterations; it++) {
+        float tH = 0, tb = 0, te = 0;
+        int nan = 0;
+        const float3 hit = interp33(dI, (float)(bestU + patx), (float)(bestV + paty), wG0);
+        if (!isfinite(hit.x)) nan = 1;
+        else {
+          const float residual = hit.x - (1.0f * col + 0.0f);
+          const float dResdDist = dx * hit.y + dy * hit.z;
+          const float hw = fabsf(residual) < kHuberTH ? 1 : kHuberTH / fabsf(residual);
+          tH = hw * dResdDist * dResdDist;
+          tb = hw * residual * dResdDist;
+          te = wgt * wgt * hw * residual * residual * (2 - hw);
+        }
+        float H = 1, bb = 0, energy = 0;
+#define TR_ADD(K) { const float h_ = tr_bcast8<K>(tH), b_ = tr_bcast8<K>(tb), e_ = tr_bcast8<K>(te); const int nn = tr_bcast8<K>(nan); \
+                    if (nn) energy += 1e5; else { H += h_; bb += b_; energy += e_; } }
+        TR_ALL8(TR_ADD)
+#undef TR_ADD
+        if (energy > bestEnergy) {
+          stepBack *= 0.5;
+          bestU = uBak + stepBack * dx;
+          bestV = vBak + stepBack * dy;
+        } else {
+          float step = -gnstepsize * bb / H;
+          if (step < -0.5) step = -0.5;
+          else if (step > 0.5) step = 0.5;
+          if (!isfinite(step)) step = 0;
+          uBak = bestU;
+          vBak = bestV;
+          stepBack = step;
+          bestU += step * dx;
+          bestV += step * dy;
+          bestEnergy = energy;
+        }
+        if (fabsf(stepBack) < kTraceGNThreshold) break;
       }
-      if (!(energy > bestEnergy)) bestEnergy = energy;
     }
-    bestU = U;
-    bestV = V;
-  } else {
-    // DSO-native GN (ImmaturePoint.cpp:707-769)
-    float uBak = bestU, vBak = bestV, stepBack = 0;
-    const float gnstepsize = 1;
-    if (kTraceGNIterations > 0) bestEnergy = 1e5;
-    for (int it = 0; it < kTraceGNIterations; it++) {
-      float H = 1, bb = 0, energy = 0;
-      for (int idx = 0; idx < 8; idx++) {
-        const float3 hit = interp33(dI, (float)(bestU + (float)c_pat[idx][0]), (float)(bestV + (float)c_pat[idx][1]), wG0);
-        if (!isfinite(hit.x)) { energy += 1e5; continue; }
-        const float residual = hit.x - (1.0f * color[idx] + 0.0f);
-        const float dResdDist = dx * hit.y + dy * hit.z;
-        const float hw = fabsf(residual) < kHuberTH ? 1 : kHuberTH / fabsf(residual);
-        H += hw * dResdDist * dResdDist;
-        bb += hw * residual * dResdDist;
-        energy += weights[idx] * weights[idx] * hw * residual * residual * (2 - hw);
-      }
-      if (energy > bestEnergy) {
-        stepBack *= 0.5;
-        bestU = uBak + stepBack * dx;
-        bestV = vBak + stepBack * dy;
-      } else {
-        float step = -gnstepsize * bb / H;
-        if (step < -0.5) step = -0.5;
-        else if (step > 0.5) step = 0.5;
-        if (!isfinite(step)) step = 0;
-        uBak = bestU;
-        vBak = bestV;
-        stepBack = step;
-        bestU += step * dx;
-        bestV += step * dy;
-        bestEnergy = energy;
-      }
-      if (fabsf(stepBack) < kTraceGNThreshold) break;
-    }
+    if (idx == 0) { s_rU[pl] = bestU; s_rV[pl] = bestV; s_rE[pl] = bestEnergy; }
   }
+#undef TR_ALL8
+  __syncthreads();
+
+  // ---- phase 3b: outputs, one lane per point
+  if (!live) return;
+  {
+    float bestEnergy0 = s_bE[t];
+    if (s_bI[t] < 0) bestEnergy0 = 1e10f;
+    const float newQuality = s_second[t] / bestEnergy0;
+    if (newQuality < quality || numSteps > 10) quality = newQuality;
+  }
+  const float bestU = s_rU[t], bestV = s_rV[t], bestEnergy = s_rE[t];
 
   if (!(bestEnergy < energyTH * kTraceExtraSlack)) {
     finish(prevStatus == IPS_OUTLIER ? IPS_OOB : IPS_OUTLIER, -1, -1, 0, true);
