@@ -1483,8 +1483,27 @@ __global__ __launch_bounds__(BA_BLOCK, 2) void k_ba_sc_host(const BaDev* __restr
   const int nf = B.nf, h = blockIdx.x;
   if (h >= nf) return;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  __shared__ float pt_all[BA_BLOCK / 64][64][8];
-  __shared__ float tiles[2][21 * 256];                  // two waves' worth of accumulator tiles
+#ifdef SDSO_SC_STAMPS   // diagnostic build: shader-clock ticks of wave 0 of workgroup (0, 0) per phase, printed
+  unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int stn = 0;
+#define SCS() do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); if (stn < 8) st[stn++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SCS() do { } while (0)
+#endif
+  SCS();
+  __shared__ float pt_all[BA_BLOCK / 64][16][8];
+  // The records of 16 points (16 x nf x 16 floats, contiguous in r_rec) are brought in ONCE by coalesced 16-byte loads and parked in LDS;
+  // both phases read them there.  (Before: phase 1 read floats 8..15 of every record with lane = point and phase 2 floats 0..7 with its
+  // own lane layout, straight from memory — every 128-byte line crossed the memory system twice, and the launch, two rounds of 512
+  // resident workgroups, ran at the rate those 2 x 131 MB stream: the stamps showed each phase at ~16 us per round.)
+  // 160 floats per point: the four point groups of an MFMA operand read (kq) land 32 banks apart.  The accumulator tiles of the final
+  // tree lie over the same memory.
+  constexpr int SC_PSTRIDE = 160;
+  constexpr int SC_STAGE = 16 * SC_PSTRIDE;                  // floats per wave
+  constexpr int SC_LDS = (BA_BLOCK / 64) * SC_STAGE > 2 * 21 * 256 ? (BA_BLOCK / 64) * SC_STAGE : 2 * 21 * 256;
+  __shared__ __align__(16) float stage_all[SC_LDS];
+  float (*tiles)[21 * 256] = reinterpret_cast<float (*)[21 * 256]>(stage_all);   // two waves' worth of accumulator tiles
+  float* stg = stage_all + wv * SC_STAGE;
   float (*pt)[8] = pt_all[wv];
   const int ib = B.host_item_beg[h], ie = B.host_item_beg[h + 1];
   const int pb = ib < ie ? B.items[ib].y : 0, pe = ib < ie ? B.items[ie - 1].z : 0;
@@ -1495,16 +1514,54 @@ __global__ __launch_bounds__(BA_BLOCK, 2) void k_ba_sc_host(const BaDev* __restr
     for (int b = 0; b < 5; b++) acc[a][b] = (te_f4){0.f, 0.f, 0.f, 0.f};
   const int ci = lane & 15, kq = lane >> 4;
   const int tsub = ci >> 3, asub = ci & 7;
-  for (int p0 = pb + 64 * wv; p0 < pe; p0 += 64 * (BA_BLOCK / 64)) {
-    const int npts = min(64, pe - p0);
+  // a wave's 16-point groups: 64-point slices dealt round-robin over the waves (as before), four groups per slice
+  auto group_p0 = [&](int gidx) { return pb + 64 * (wv + (BA_BLOCK / 64) * (gidx >> 2)) + 16 * (gidx & 3); };
+  // the records of group g0: float4 chunk c = lane + 64 k of its (<= 16 nf 4) chunks
+  float pr_next = 0.f, de_next = 0.f;        // prior, delta and the marginalisation flag of the lane's point of the NEXT group: they travel with its records
+  int pf_next = 1;
+  auto request = [&](int p0, float4 (&v)[8]) {
+    const int n16 = min(16, pe - p0);
+    const int nchunks = n16 > 0 ? n16 * nf * 4 : 0;
+    const float* rbase = B.r_rec + (size_t)(n16 > 0 ? p0 : pb) * nf * 16;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int c = lane + 64 * k;
+      v[k] = c < nchunks ? *(const float4*)(rbase + (size_t)c * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (lane < n16) { pr_next = B.p_prior[p0 + lane]; de_next = B.p_delta[p0 + lane]; pf_next = pflag ? (int)pflag[p0 + lane] : 1; }
+  };
+  float4 vnext[8];
+  if (pb == 12345678) SCS();                 // (keeps pb live before the stamp)
+  SCS();
+  request(group_p0(0), vnext);
+  SCS();
+  for (int gidx = 0;; gidx++) {
+    const int p0 = group_p0(gidx);
+    if (p0 >= pe) break;
+    const int npts = min(16, pe - p0);
+    {  // park the group's records: chunk c -> record c / 4 = point * nf + target, floats 4 (c & 3) ..
+      const int nchunks = npts * nf * 4;
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const int c = lane + 64 * k;
+        if (c < nchunks) {
+          const int rec = c >> 2, pl = nf == 8 ? rec >> 3 : rec / nf, t = rec - pl * nf;
+          *(float4*)(stg + pl * SC_PSTRIDE + t * 16 + 4 * (c & 3)) = vnext[k];
+        }
+      }
+    }
+    const float prior = pr_next, delta = de_next;
+    const float onf = pf_next ? 1.f : 0.f;
+    request(group_p0(gidx + 1), vnext);          // the next group's records travel while this one is worked on
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     {  // phase 1: per-point terms, lane = point (identical to k_ba_sc_mfma)
       float HdiF = 0.f, bdSumF = 0.f, Hcd[4] = {0.f, 0.f, 0.f, 0.f};
       int mbits = 0;
       if (lane < npts) {
         const int p = p0 + lane;
-        const float prior = B.p_prior[p], delta = B.p_delta[p];
-        const float onf = (pflag ? (int)pflag[p] : 1) ? 1.f : 0.f;
-        const float* base = B.r_rec + (size_t)p * nf * 16;
+        const float* base = stg + lane * SC_PSTRIDE;
         float Hdd_A = 0, bd_A = 0, Hdd_L = 0, bd_L = 0, HcdA[4] = {0, 0, 0, 0}, HcdL[4] = {0, 0, 0, 0};
         float ngood = 0;
         for (int t = 0; t < nf; t++) {
@@ -1538,28 +1595,29 @@ __global__ __launch_bounds__(BA_BLOCK, 2) void k_ba_sc_host(const BaDev* __restr
           po[PO_HDI] = HdiF; po[PO_BDSUM] = bdSumF;
         }
       }
-      *(float4*)(&pt[lane][0]) = make_float4(HdiF, bdSumF, Hcd[0], Hcd[1]);
-      *(float4*)(&pt[lane][4]) = make_float4(Hcd[2], Hcd[3], __int_as_float(mbits), 0.f);
+      if (lane < 16) {
+        *(float4*)(&pt[lane][0]) = make_float4(HdiF, bdSumF, Hcd[0], Hcd[1]);
+        *(float4*)(&pt[lane][4]) = make_float4(Hcd[2], Hcd[3], __int_as_float(mbits), 0.f);
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // phase 2, four point-groups per trip: the 16 record loads of a trip are issued before its first MFMA (one trip used to be a
-    // load -> wait -> 21 MFMAs chain, sixteen times per slice; the workgroups of a launch are all resident at once, so the kernel
-    // took as long as that chain).  Groups past npts read the zero rows lanes >= npts wrote into pt[]: exact no-ops.
-    for (int g0 = 0; g0 < npts; g0 += 16) {
+    {  // phase 2: the group's four MFMA operand sets (points 4 u + kq), read from the parked records.  Points past npts carry a zero
+       // mask and zero terms in pt[]: exact no-ops.
       float zz[4][5], hx[4];
 #pragma unroll
       for (int u = 0; u < 4; u++) {
-        const int q = g0 + 4 * u + kq;
+        const int q = 4 * u + kq;
         const float4 h0 = *(const float4*)(&pt[q][0]);
         const float4 h1 = *(const float4*)(&pt[q][4]);
         const int mb = __float_as_int(h1.z);
-        const float* base = B.r_rec + (size_t)(p0 + (q < npts ? q : 0)) * nf * 16 + asub;
+        const float* base = stg + q * SC_PSTRIDE + asub;
 #pragma unroll
         for (int tt = 0; tt < 4; tt++) {
           const int t = 2 * tt + tsub;
-          zz[u][tt] = ((mb >> t) & 1) ? base[t * 16] : 0.f;
+          const float r = base[t * 16];             // (rows of masked-off or absent targets are stale LDS: selected away)
+          zz[u][tt] = ((mb >> t) & 1) ? r : 0.f;
         }
         zz[u][4] = ci == 0 ? h0.z : ci == 1 ? h0.w : ci == 2 ? h1.x : ci == 3 ? h1.y : ci == 4 ? h0.y : 0.f;
         hx[u] = h0.x;
@@ -1577,8 +1635,11 @@ __global__ __launch_bounds__(BA_BLOCK, 2) void k_ba_sc_host(const BaDev* __restr
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();          // the next slice overwrites pt[]
+    __builtin_amdgcn_wave_barrier();          // the next group overwrites the stage and pt[]
+    if (gidx == 0) SCS();
   }
+  SCS();
+  __syncthreads();                            // the tiles lie over the other waves' stages
   // ---- fixed-order tree over the four waves: (3 -> 1, 2 -> 0), then (1 -> 0)
   auto put = [&](float* dst) {
 #pragma unroll
@@ -1608,6 +1669,7 @@ __global__ __launch_bounds__(BA_BLOCK, 2) void k_ba_sc_host(const BaDev* __restr
   __syncthreads();
   if (wv != 0) return;
   add(tiles[0]);
+  SCS();
   // ---- wave 0: the host's bins.  acc[a][b][v] = D'[16a + 4*kq + v][16b + ci]
   const int nf2 = nf * nf;
   float* accD = B.accum + acc_off_D(nf);
@@ -1637,6 +1699,12 @@ __global__ __launch_bounds__(BA_BLOCK, 2) void k_ba_sc_host(const BaDev* __restr
       if (ci == 4) hp[16 + v] = acc44[v];
     }
   }
+  SCS();
+#ifdef SDSO_SC_STAMPS
+  if ((blockIdx.x == 0 || blockIdx.x == 5) && (blockIdx.y == 0 || blockIdx.y == 100) && lane == 0)
+    printf("sc_host (%d,%d) ticks: prologue %llu  first records %llu  group 0 %llu  other groups %llu  wave tree %llu  bins %llu | total %llu  (points %d)\n", blockIdx.x, blockIdx.y,
+           st[1] - st[0], st[2] - st[1], st[3] - st[2], st[4] - st[3], st[5] - st[4], st[6] - st[5], st[6] - st[0], pe - pb);
+#endif
   if (signal) {
     // side-stream launch: tell the tail kernel (already resident, polling) that this host's bins, Hcc partial and per-point terms are
     // in memory.  The other waves' p_out stores were drained before the workgroup barriers above (__syncthreads waits for vmcnt(0));
