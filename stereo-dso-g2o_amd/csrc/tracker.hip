@@ -945,11 +945,12 @@ __device__ __forceinline__ void lm_publish(LmCluster& C, const sdso_track_eval_t
   lm_put(&C.req[k], w, e);
 }
 
-__global__ __launch_bounds__(LM_BLOCK) void k_track_lm(LmJob* __restrict__ jobs, LmCluster* __restrict__ clusters, int nhyp, int G) {
+__global__ __launch_bounds__(LM_BLOCK) void k_track_lm(LmJob* __restrict__ jobs, LmCluster* __restrict__ clusters, int nhyp, int G, int spin_limit, int drop_member /* test hook: member G - 1 of every cluster never answers */) {
   // hypothesis c, member g: for G > 1 the members of a cluster share blockIdx % 8 (one XCD, one L2); speed only, any placement is correct
   int c = blockIdx.x, g = 0;
   if (G > 1) { const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3; g = j % G; c = (j / G) * 8 + xcd; }
   if (c >= nhyp) return;
+  if (drop_member && G > 1 && g == G - 1) return;
   LmJob& J = jobs[c];
   LmCluster& C = clusters[c];
   __shared__ __align__(16) unsigned char core_raw[sizeof(LmCore)];     // (LmCore has member initialisers: raw storage, init() sets every field it reads)
@@ -999,7 +1000,7 @@ __global__ __launch_bounds__(LM_BLOCK) void k_track_lm(LmJob* __restrict__ jobs,
         int spins = 0;
         for (;;) {
           v = lm_get(&C.req[tid]);
-          if ((int)(v >> 32) == e || ++spins >= LM_SPIN_LIMIT) break;
+          if ((int)(v >> 32) == e || ++spins >= spin_limit) break;
           __builtin_amdgcn_s_sleep(1);
         }
         if ((int)(v >> 32) != e) s_abort = 1;
@@ -1047,7 +1048,7 @@ __global__ __launch_bounds__(LM_BLOCK) void k_track_lm(LmJob* __restrict__ jobs,
     if (G > 1 && tid < TRK_NF + TRK_NI) {       // the members' partials of evaluation e, added in member order
       unsigned long long v[LM_MAXG];
       bool all = false;
-      for (int spins = 0; spins < LM_SPIN_LIMIT && !all; spins++) {
+      for (int spins = 0; spins < spin_limit && !all; spins++) {
         all = true;
 #pragma unroll
         for (int m = 1; m < LM_MAXG; m++)
@@ -1184,13 +1185,16 @@ extern "C" int sdso_track_newest_coarse_batch(sdso_ctx* ctx, int nhyp, const int
   int G = std::min(LM_MAXG, (ctx->n_cu * 7 / 8) / slots8);   // (an eighth of the CUs stays free: a grid that needs every CU waits on any straggler)
   if (g_env > 0) G = std::min(G, g_env);
   if (G < 2) G = 1;
+  // test hook (tests/test_tracker_gpu.py): the first attempt loses one member of every cluster, with a short spin limit — the call
+  // must come back through the single-workgroup repetition with the single-workgroup result
+  const bool drop = getenv("SDSO_TRK_LM_TEST_DROP_MEMBER") != nullptr;
   for (int attempt = 0; attempt < 2; attempt++) {
     for (int k = 0; k < nhyp; k++) { hj[k].T = lastToNew[k]; hj[k].aff = aff_g2l[k]; }
     SDSO_HIP(ctx, hipMemcpyAsync(dj, hj, sizeof(LmJob) * nhyp, hipMemcpyHostToDevice, ctx->stream));
     if (G > 1) SDSO_HIP(ctx, hipMemsetAsync(dc, 0, sizeof(LmCluster) * (size_t)nhyp, ctx->stream));
     {
       ProfScope ps(ctx, "k_track_lm");
-      hipLaunchKernelGGL(k_track_lm, dim3(G > 1 ? slots8 * G : nhyp), dim3(LM_BLOCK), 0, ctx->stream, dj, dc, nhyp, G);
+      hipLaunchKernelGGL(k_track_lm, dim3(G > 1 ? slots8 * G : nhyp), dim3(LM_BLOCK), 0, ctx->stream, dj, dc, nhyp, G, drop ? 1 << 12 : LM_SPIN_LIMIT, drop && G > 1 ? 1 : 0);
     }
     SDSO_HIP(ctx, hipGetLastError());
     SDSO_HIP(ctx, hipMemcpyAsync(hj, dj, sizeof(LmJob) * nhyp, hipMemcpyDeviceToHost, ctx->stream));
