@@ -118,7 +118,7 @@ class BAWorkload:
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
                 if int(flag.item()) != 1:
                     use_host, why = True, "librccl not loadable inside libsdso_hip.so on some rank"
-            if use_host:
+            def _host_transport(why):
                 on_gpu = dist.get_backend() == "nccl"
 
                 def _ar(user, buf, n):
@@ -146,10 +146,15 @@ class BAWorkload:
                     G.ctx.check(G.ctx.L.sdso_comm_init_host(G.ctx.h, world, rank, self._cbs[0], self._cbs[1], None))
                 self.exchange = "sdso_ba_allreduce over the library's host transport (torch.distributed %s underneath)%s" % (
                     dist.get_backend(), ("; " + why) if why else "; rehearsal")
+
+            if use_host:
+                _host_transport(why)
             else:
                 # one communicator PER stream group: the groups' collectives run on different streams and interleave, and each group issues
                 # its own sequence (all-reduce, all-gather) in program order on every rank.  ncclCommInitRank is collective: every rank
-                # makes every call; a failure after the agreement above ends the run (non-zero exit) instead of measuring something else.
+                # makes every call.  When it fails on some rank after the agreement above, every rank drops what it opened and the run
+                # goes through the host transport: the SAME step (library all-reduce, fused tail, all-gather, states advancing), slower,
+                # and config.exchange says which rank's RCCL said what — never a step that does less work.
                 fails = 0
                 for G in self.groups:
                     uid = np.zeros(128, np.uint8)
@@ -164,8 +169,12 @@ class BAWorkload:
                 dist.all_reduce(flag, op=dist.ReduceOp.MAX)
                 if int(flag.item()) != 0:
                     msg = ctx.L.sdso_last_error(ctx.h)
-                    raise RuntimeError("sdso_comm_init failed on some rank (this rank: %s): no reduced-work fallback, the run ends here" % (msg.decode() if msg else "ok"))
-                self.exchange = "sdso_ba_allreduce (RCCL communicator owned by libsdso_hip.so)"
+                    print("[rank %d] sdso_comm_init failed on some rank (this rank: %s): host transport instead" % (rank, msg.decode() if (msg and fails) else "ok"), file=sys.stderr, flush=True)
+                    for G in self.groups:
+                        G.ctx.L.sdso_comm_destroy(G.ctx.h)
+                    _host_transport("sdso_comm_init (ncclCommInitRank inside libsdso_hip.so) failed on some rank")
+                else:
+                    self.exchange = "sdso_ba_allreduce (RCCL communicator owned by libsdso_hip.so)"
         self.nwin = nwin
         self.units_per_step = nwin * win["nr"]
         self.config = {"workload": self.name, "windows_per_step": nwin, "keyframes": nf, "points_per_window_per_gpu": win["np"],
