@@ -589,15 +589,16 @@ static bool launch_fused(sdso_ctx* ctx, const BaLaunch& L, bool materialize, int
   const int nf = L.nf;
   if ((part & 1) && L.max_chunks > 0) {
     {
-      ProfScope ps(ctx, "k_ba_lin_fused");
       const dim3 g(L.max_chunks, L.nwin), b(BA_BLOCK);
       // gather: 0 one residual's 32 taps on one lane, 1 cooperative quad gather, 2 LDS-DMA rounds (tiled images)
       const int gm = (gather == 2 && !L.tiled) ? 1 : gather;
-#define LF(M, T) do { if (gm == 0) hipLaunchKernelGGL((k_ba_lin_fused<M, T, 0>), g, b, 0, ctx->stream, L.d_arr); else hipLaunchKernelGGL((k_ba_lin_fused<M, T, 1>), g, b, 0, ctx->stream, L.d_arr); } while (0)
-      if (gm == 2) { if (materialize) hipLaunchKernelGGL((k_ba_lin_dma<true>), g, b, 0, ctx->stream, L.d_arr); else hipLaunchKernelGGL((k_ba_lin_dma<false>), g, b, 0, ctx->stream, L.d_arr); }
+#define LT(K) launch_timed(ctx, "k_ba_lin_fused", 1, K, g, b, (const BaDev*)L.d_arr)
+#define LF(M, T) do { if (gm == 0) LT((k_ba_lin_fused<M, T, 0>)); else LT((k_ba_lin_fused<M, T, 1>)); } while (0)
+      if (gm == 2) { if (materialize) LT((k_ba_lin_dma<true>)); else LT((k_ba_lin_dma<false>)); }
       else if (materialize) { if (L.tiled) LF(true, true); else LF(true, false); }
       else { if (L.tiled) LF(false, true); else LF(false, false); }
 #undef LF
+#undef LT
     }
     if (L.any_lin) {
       hipLaunchKernelGGL(k_ba_fold_top, dim3(nf * nf, L.nwin), dim3(128), 0, ctx->stream, L.d_arr, 0);

@@ -1,6 +1,7 @@
 // Internal definitions of libsdso_hip.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <cstdint>
 #include <cstdio>
 #include <map>
@@ -130,6 +131,23 @@ struct ProfScope {
     ctx->prof[name].ev.emplace_back(a, b);
   }
 };
+// ONE kernel launch, timed exactly when profiling is enabled: hipExtLaunchKernelGGL ties the two events to the start and the end of
+// the dispatch itself (the timestamps rocprofv3 reports), where a pair of hipEventRecord calls around the launch also counts the
+// dispatch latency after the first record (≈ 10 us on a 390-us kernel: bench.py's figure sat 2.5 % above rocprofv3's).
+// SDSO_PROF_BRACKET=1: the old record / launch / record bracket.
+template <typename K, typename... A>
+inline void launch_timed(sdso_ctx* ctx, const char* name, int level, K kernel, const dim3& grid, const dim3& block, A... args) {
+  static const bool bracket = getenv("SDSO_PROF_BRACKET") != nullptr;
+  if (ctx->prof_on >= level && !bracket) {
+    hipEvent_t ea = nullptr, eb = nullptr;
+    hipEventCreate(&ea); hipEventCreate(&eb);
+    hipExtLaunchKernelGGL(kernel, grid, block, 0, ctx->stream, ea, eb, 0, args...);
+    ctx->prof[name].ev.emplace_back(ea, eb);
+    return;
+  }
+  ProfScope ps(ctx, name, level);
+  hipLaunchKernelGGL(kernel, grid, block, 0, ctx->stream, args...);
+}
 int ensure_pinned(sdso_ctx* ctx, size_t bytes);
 int ensure_tiled0(sdso_ctx* ctx, PyramidDev& P);   // ctx.hip
 int ensure_plane0(sdso_ctx* ctx, PyramidDev& P);   // ctx.hip

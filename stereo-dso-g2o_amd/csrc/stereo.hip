@@ -1002,7 +1002,7 @@ extern "C" int sdso_trace_stereo_prepare(sdso_ctx* ctx, int frame_slot, const fl
   return SDSO_OK;
 }
 // k_trace_stereo in the ctx's refinement mode; SDSO_TRACE_BAND=1 selects the LDS-band A/B variant (read per launch)
-static void launch_trace_stereo(sdso_ctx* ctx, const TraceDev& T) {
+static void launch_trace_stereo(sdso_ctx* ctx, const TraceDev& T, bool timed = false /* the benchmarked enqueue: the kernel's own duration under the name k_trace_stereo */) {
   const dim3 g((T.n + 3) / 4), b(256);
   const bool band = getenv("SDSO_TRACE_BAND") != nullptr;
   // default: the block organisation (64 points per workgroup); SDSO_TRACE_WAVE=1 (or one of the A/B variants below) selects the
@@ -1010,12 +1010,13 @@ static void launch_trace_stereo(sdso_ctx* ctx, const TraceDev& T) {
   if (!band && !getenv("SDSO_TRACE_OCC") && !getenv("SDSO_TRACE_WAVE")) {
     const char* e = getenv("SDSO_TRACE_PTS");
     const int pts = e ? atoi(e) : 16;
-#define TB(G, P) hipLaunchKernelGGL((k_trace_stereo_blk<G, P>), dim3((T.n + P - 1) / P), b, 0, ctx->stream, T)
+#define TB(G, P) do { if (timed) launch_timed(ctx, "k_trace_stereo", 1, (k_trace_stereo_blk<G, P>), dim3((T.n + P - 1) / P), b, T); else hipLaunchKernelGGL((k_trace_stereo_blk<G, P>), dim3((T.n + P - 1) / P), b, 0, ctx->stream, T); } while (0)
     if (ctx->gn_mode == 1) { if (pts == 64) TB(1, 64); else if (pts == 32) TB(1, 32); else if (pts == 8) TB(1, 8); else TB(1, 16); }
     else { if (pts == 64) TB(0, 64); else if (pts == 32) TB(0, 32); else if (pts == 8) TB(0, 8); else TB(0, 16); }
 #undef TB
     return;
   }
+  ProfScope ps(ctx, "k_trace_stereo", timed ? 1 : 1000);        // (the A/B variants: bracketed)
   if (getenv("SDSO_TRACE_OCC") && ctx->gn_mode == 0 && !band) { hipLaunchKernelGGL((k_trace_stereo<0, false, 8>), g, b, 0, ctx->stream, T); return; }
   if (ctx->gn_mode == 1) { if (band) hipLaunchKernelGGL((k_trace_stereo<1, true>), g, b, 0, ctx->stream, T); else hipLaunchKernelGGL((k_trace_stereo<1, false>), g, b, 0, ctx->stream, T); }
   else { if (band) hipLaunchKernelGGL((k_trace_stereo<0, true>), g, b, 0, ctx->stream, T); else hipLaunchKernelGGL((k_trace_stereo<0, false>), g, b, 0, ctx->stream, T); }
@@ -1026,10 +1027,7 @@ extern "C" int sdso_trace_stereo_enqueue(sdso_ctx* ctx) {
   if (B.T.n == 0) return SDSO_OK;
   SDSO_HIP(ctx, hipMemcpyAsync(B.blob + 3 * (size_t)B.n, B.blob + 32 * (size_t)B.n, sizeof(float) * 3 * (size_t)B.n, hipMemcpyDeviceToDevice, ctx->stream));
   SDSO_HIP(ctx, hipMemcpyAsync(B.bytes, B.bytes + 2 * (size_t)B.n, (size_t)B.n, hipMemcpyDeviceToDevice, ctx->stream));
-  {
-    ProfScope ps(ctx, "k_trace_stereo");
-    launch_trace_stereo(ctx, B.T);
-  }
+  launch_trace_stereo(ctx, B.T, true);
   SDSO_HIP(ctx, hipGetLastError());
   return SDSO_OK;
 }

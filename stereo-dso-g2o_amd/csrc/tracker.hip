@@ -449,10 +449,7 @@ extern "C" int sdso_track_batch_enqueue(sdso_ctx* ctx) {
   TrackBatch* tb = ctx->tb;
   const int groups = (tb->nprob + 7) / 8;
   const int nblk = groups * 8 * tb->gx;
-  {
-    ProfScope ps(ctx, "k_track_eval");
-    hipLaunchKernelGGL(k_track_eval<false>, dim3(nblk), dim3(TRK_BLOCK), 0, ctx->stream, tb->d_probs, tb->nprob, tb->gx, tb->d_partF, tb->d_partI, (uint8_t*)nullptr);
-  }
+  launch_timed(ctx, "k_track_eval", 1, k_track_eval<false>, dim3(nblk), dim3(TRK_BLOCK), (const TrackProb*)tb->d_probs, tb->nprob, tb->gx, tb->d_partF, tb->d_partI, (uint8_t*)nullptr);
   hipLaunchKernelGGL(k_track_finalize, dim3(tb->nprob), dim3(64), 0, ctx->stream, tb->d_probs, tb->d_partF, tb->d_partI, tb->gx, tb->d_out);
   SDSO_HIP(ctx, hipGetLastError());
   return SDSO_OK;
