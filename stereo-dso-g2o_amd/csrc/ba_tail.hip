@@ -103,6 +103,7 @@ __global__ __launch_bounds__(TAIL_NT) void k_ba_tail(const BaDev* __restrict__ w
   float nres_f = 0.f;
 #ifdef SDSO_TAIL_STAMPS
   unsigned long long tstamps[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tjk[4] = {0, 0, 0, 0};        // wave 0's tile jobs by kind
 #endif
   TSTAMP(0);
 
@@ -347,7 +348,13 @@ __global__ __launch_bounds__(TAIL_NT) void k_ba_tail(const BaDev* __restrict__ w
     };
     const int njobs = nf2 + nf + 1;
     // diagonal tiles first (they are the long ones: one per wave), then the rest round-robin
+#ifdef SDSO_TAIL_STAMPS
+    unsigned long long tj[4] = {0, 0, 0, 0}, tj0 = __builtin_amdgcn_s_memtime();   // wave 0's jobs by kind: diagonal tile, off-diagonal, frame-calibration, calibration
+#endif
     for (int jj = wv; jj < njobs; jj += TAIL_NT / 64) {
+#ifdef SDSO_TAIL_STAMPS
+      if (jj != wv) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long tn = __builtin_amdgcn_s_memtime(); const int pj = jj - TAIL_NT / 64; tj[pj < nf ? 0 : pj < nf2 ? 1 : pj < nf2 + nf ? 2 : 3] += tn - tj0; tj0 = tn; }
+#endif
       int tile;
       if (jj < nf) tile = jj * (nf + 1);                       // (x, x)
       else if (jj < nf2) { const int o = jj - nf; const int x = o / (nf - 1), r = o % (nf - 1); const int y = r < x ? r : r + 1; tile = x + nf * y; }
@@ -427,6 +434,14 @@ __global__ __launch_bounds__(TAIL_NT) void k_ba_tail(const BaDev* __restrict__ w
         }
       }
     }
+#ifdef SDSO_TAIL_STAMPS
+    if (threadIdx.x == 0 && !(flags & TAIL_STEP)) {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      const unsigned long long tn = __builtin_amdgcn_s_memtime();
+      tj[3] += tn - tj0;                       // (wave 0's last job is the calibration block)
+      for (int i = 0; i < 4; i++) tjk[i] = tj[i];
+    }
+#endif
   }
   __syncthreads();
   TSTAMP(3);
@@ -499,6 +514,7 @@ __global__ __launch_bounds__(TAIL_NT) void k_ba_tail(const BaDev* __restrict__ w
   if (threadIdx.x == 0 && !(flags & TAIL_STEP)) {
     double* xo = B.sol + 3 * ((size_t)n * n + n);
     for (int i = 0; i < 8; i++) xo[i] = (double)(tstamps[i + 1] - tstamps[i]);   // stage | S1 | tiles | SVecI+order | assemble | factor+solve | x, xAd | resub
+    for (int i = 0; i < 4; i++) xo[8 + i] = (double)tjk[i];
   }
 #endif
   }  // !ba_finished

@@ -24,4 +24,4 @@ for rep in range(4):
     ctx.check(ctx.L.sdso_ba_accumulate(ctx.h, 80))
     x = np.zeros(68)
     ctx.check(ctx.L.sdso_ba_solve(ctx.h, 80, 0, 0.0, abi.dp(x), None, None, None, None))
-    print("s_memtime ticks: " + "  ".join("%s %d" % (nm, v) for nm, v in zip(names, x[:8])) + "  | sum %d" % x[:8].sum())
+    print("s_memtime ticks: " + "  ".join("%s %d" % (nm, v) for nm, v in zip(names, x[:8])) + "  | sum %d" % x[:8].sum() + "  | wave 0's tile jobs: diagonal %d, 7 off-diagonal %d, frame-calibration %d, calibration %d" % tuple(x[8:12]))
