@@ -1485,6 +1485,7 @@ struct OptRun {
   int lstride = 0;         // floats between the windows' calcLEnergy partials
   bool active = false;
   bool local_only = false; // single-window call: never a collective, whatever communicator the ctx carries
+  bool failed = false;     // a collective of the gated flow failed (sdso_last_error says which)
   OptBufs* B = nullptr;
 };
 
@@ -1501,7 +1502,6 @@ static int opt_begin(sdso_ctx* ctx, OptRun& R, int stop_on_convergence) {
   // SDSO_OPT_FORCE_EXCHANGE: take the pack / all-gather path on a 1-rank communicator too (tests: the collectives of a 1-GPU box)
   R.exchange = !R.local_only && (R.nranks > 1 || (comm_present(ctx) && getenv("SDSO_OPT_FORCE_EXCHANGE") != nullptr));
   R.gated = !R.W[0]->forceAccept;
-  SDSO_REQUIRE(ctx, !(R.gated && R.exchange), "the energy-gated loop over sharded windows is not provided (forceAceptStep = true is; the energies would need one more exchange)");
   if (R.exchange) { int rc = comm_max_int(ctx, &cap); if (rc) return rc; }
   R.cap = cap;
   R.sums_stride = 2 * (R.L.max_nblk_pts + 1);
@@ -1580,11 +1580,22 @@ static void gated_linearize(sdso_ctx* ctx, OptRun& R, int cond, int which) {
   mark_linearized(R.W, false);
   const int nblk = R.L.max_chunks + R.L.max_nblk_pts;
   if (nblk > 0) hipLaunchKernelGGL(k_ba_lenergy, dim3(nblk, nwin), b, 0, ctx->stream, R.L.d_arr, R.B->d_lpart, R.lstride, cond);
+  if (R.exchange) {
+    // sharded windows: every rank hands over its newest-frame energies, the energy of its residuals and its part of calcLEnergy; the
+    // gate reads the gathered records rank by rank, so all ranks accept / reject together.  (Unconditional on every rank: a collective.)
+    hipLaunchKernelGGL(k_ba_opt_pack, dim3(1, nwin), dim3(256), 0, ctx->stream, R.L.d_arr, R.B->d_pack, R.cap, 1, (const float*)nullptr, 0,
+                       nblk > 0 ? (const float*)R.B->d_lpart : (const float*)nullptr, R.lstride);
+    if (comm_allgather_floats(ctx, R.B->d_pack, R.B->d_gather, (size_t)nwin * opt_pack_floats(R.cap))) { R.failed = true; return; }
+    hipLaunchKernelGGL(k_ba_opt_gate, dim3(1, nwin), dim3(256), 0, ctx->stream, R.L.d_arr, (const float*)R.B->d_lpart, R.lstride, which, R.stop,
+                       (const float*)R.B->d_gather, R.nranks, R.cap);
+    return;
+  }
   hipLaunchKernelGGL(k_ba_opt_gate, dim3(1, nwin), dim3(256), 0, ctx->stream, R.L.d_arr, (const float*)R.B->d_lpart, R.lstride, which, R.stop);
 }
 static int opt_gated_start(sdso_ctx* ctx, OptRun& R) {   // linearizeAll(false) + the energies of the uploaded state + applyRes (:894-908)
   const int nwin = (int)R.W.size();
   gated_linearize(ctx, R, 0, 0);
+  if (R.failed) return SDSO_ERR_STATE;
   hipLaunchKernelGGL(k_ba_apply, dim3(R.L.max_nblk_res, nwin), dim3(BA_BLOCK), 0, ctx->stream, R.L.d_arr, 0);
   SDSO_HIP(ctx, hipGetLastError());
   return SDSO_OK;
@@ -1594,6 +1605,10 @@ static int opt_gated_iteration(sdso_ctx* ctx, OptRun& R, int it) {
   const dim3 gp(std::max(R.L.max_nblk_pts, 1), nwin), b(BA_BLOCK);
   if (R.L.max_nblk_pts) hipLaunchKernelGGL(k_ba_points_op, gp, b, 0, ctx->stream, R.L.d_arr, 0, 0.f, (float*)nullptr, 0, 0);   // backupState
   launch_accumulate(ctx, R.L, nullptr, false);
+  if (R.exchange) {                                            // sharded windows: the packed accumulators of every rank, summed
+    const int rc = sdso_ba_allreduce(ctx);
+    if (rc) return rc;
+  }
   const int sm = R.W[0]->solverMode;
   double lambda = 0;
   int flags = ((sm & SOLVER_ORTHOGONALIZE_X) || (it >= 2 && (sm & SOLVER_ORTHOGONALIZE_X_LATER))) ? 1 : 0;
@@ -1602,12 +1617,17 @@ static int opt_gated_iteration(sdso_ctx* ctx, OptRun& R, int it) {
   else flags |= 2;                                             // the loop's own lambda, kept on the device (it depends on the decisions)
   launch_solve(ctx, R.L, lambda, flags);
   if (R.L.max_nblk_pts) hipLaunchKernelGGL(k_ba_points_op, gp, b, 0, ctx->stream, R.L.d_arr, 1, 1.0f, R.B->d_sums, R.sums_stride, 0);
-  hipLaunchKernelGGL(k_ba_opt_step, dim3(1, nwin), dim3(256), 0, ctx->stream, R.L.d_arr, (const float*)nullptr, 1, R.cap, it, 2, R.stop, 1.0f, 1,
-                     R.L.max_nblk_pts ? (const float*)R.B->d_sums : (const float*)nullptr, R.sums_stride);
+  if (R.exchange) {                                            // the break-test sums of every rank's points: pack -> all-gather -> step
+    const int rc = opt_consume(ctx, R, 2, true, R.L.max_nblk_pts > 0);
+    if (rc) return rc;
+  } else
+    hipLaunchKernelGGL(k_ba_opt_step, dim3(1, nwin), dim3(256), 0, ctx->stream, R.L.d_arr, (const float*)nullptr, 1, R.cap, it, 2, R.stop, 1.0f, 1,
+                       R.L.max_nblk_pts ? (const float*)R.B->d_sums : (const float*)nullptr, R.sums_stride);
   gated_linearize(ctx, R, 0, 1);                               // trial linearisation, energies, decision
   hipLaunchKernelGGL(k_ba_apply, dim3(R.L.max_nblk_res, nwin), b, 0, ctx->stream, R.L.d_arr, 1);                                  // accepted: applyRes
   if (R.L.max_nblk_pts) hipLaunchKernelGGL(k_ba_points_op, gp, b, 0, ctx->stream, R.L.d_arr, 2, 0.f, (float*)nullptr, 0, 2);   // rejected: the points go back,
   gated_linearize(ctx, R, 2, 2);                               //           the restored state is linearised again and its energies kept
+  if (R.failed) return SDSO_ERR_STATE;
   SDSO_HIP(ctx, hipGetLastError());
   R.iteration++;
   return SDSO_OK;

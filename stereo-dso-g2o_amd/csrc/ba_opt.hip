@@ -18,13 +18,14 @@
 namespace sdso {
 
 // floats of one window's packed record: [0,cap) newEnergyWithOutlier of the residuals that enter the quantile (-1 = none),
-// then the energy of the linearisation (a double in two float slots), sum |idepth backup|, number of points
-constexpr int OPT_PACK_TAIL = 4;
+// then the energy of the linearisation (a double in two float slots), sum |idepth backup|, number of points, and (energy-gated flow)
+// this rank's part of calcLEnergy's point / residual terms
+constexpr int OPT_PACK_TAIL = 5;
 __host__ __device__ inline int opt_pack_floats(int cap) { return cap + OPT_PACK_TAIL; }
 
 // after the points' step: this rank's contribution to setNewFrameEnergyTH and to the break test
 __global__ __launch_bounds__(256) void k_ba_opt_pack(const BaDev* __restrict__ wins, float* __restrict__ out, int cap, int nparts /* energy partials: 0 -> nchunks (fused), else ceil(nr/256) */,
-                                                     const float* __restrict__ sums, int sums_stride) {
+                                                     const float* __restrict__ sums, int sums_stride, const float* __restrict__ lpart = nullptr /* k_ba_lenergy's partials (gated flow) */, int lstride = 0) {
   const BaDev& B = wins[blockIdx.y];
   if (ba_finished_lin(B)) return;
   float* o = out + (size_t)blockIdx.y * opt_pack_floats(cap);
@@ -47,6 +48,13 @@ __global__ __launch_bounds__(256) void k_ba_opt_pack(const BaDev* __restrict__ w
     }
     o[cap + 2] = sumNID;
     o[cap + 3] = (float)B.np;
+    float Ept = 0;
+    if (lpart) {
+      const float* lp = lpart + (size_t)blockIdx.y * lstride;
+      const int nlp = B.nchunks + (B.np + BA_BLOCK - 1) / BA_BLOCK;
+      for (int b = 0; b < nlp; b++) Ept += lp[b];
+    }
+    o[cap + 4] = Ept;
   }
 }
 
@@ -460,7 +468,10 @@ __global__ __launch_bounds__(256) void k_ba_opt_step(const BaDev* __restrict__ w
 //            lambda *= 1e2, gate = 2 (the points are restored and the state re-linearised by the conditional kernels that follow)
 //   which 2: (rejected windows only) the energies of the re-linearisation at the restored state become the last ones (:983-985)
 // After which 1 (accepted) / which 2 the recorded break test ends the window's loop.  lpart: k_ba_lenergy's per-workgroup partials.
-__global__ __launch_bounds__(256) void k_ba_opt_gate(const BaDev* __restrict__ wins, const float* __restrict__ lpart, int lstride, int which, int stop_on_convergence) {
+// Sharded windows: gathered = every rank's k_ba_opt_pack record ([nranks][nwin][opt_pack_floats(pcap)]) — the newest frame's energies, the
+// energy of the linearisation and the point part of calcLEnergy are then taken from there, rank by rank, so every rank takes the same decision.
+__global__ __launch_bounds__(256) void k_ba_opt_gate(const BaDev* __restrict__ wins, const float* __restrict__ lpart, int lstride, int which, int stop_on_convergence,
+                                                     const float* __restrict__ gathered = nullptr, int nranks = 1, int pcap = 0) {
   BaDev& Bw = const_cast<BaDev&>(wins[blockIdx.y]);
   const BaDev B = Bw;
   if (ba_finished_lin(B)) return;
@@ -478,13 +489,17 @@ __global__ __launch_bounds__(256) void k_ba_opt_gate(const BaDev* __restrict__ w
   constexpr int kStage = 8192;
   __shared__ float s_en[kStage];
   // ---- energy of the linearisation (k_ba_linearize: one partial per 256 residuals) and the newest frame's threshold
-  OptEnergies en{nullptr, 0, 1, max(B.nr - O.newest_first, 0), &B, O.newest_first};
-  const int cap = en.cap;
+  const int pf = opt_pack_floats(pcap);
+  const size_t grs = (size_t)gridDim.y * pf;
+  const float* g = gathered ? gathered + (size_t)blockIdx.y * pf : nullptr;
+  OptEnergies en{g, grs, g ? nranks : 1, g ? pcap : max(B.nr - O.newest_first, 0), &B, O.newest_first};
+  const int cap = en.cap * en.ranks();                        // values that enter the quantile, rank after rank
   const bool staged = cap <= kStage;
   int cnt = 0;
-  for (int j = tid; j < cap; j += 256) { const float e = en.at(0, j); if (staged) s_en[j] = e; cnt += e >= 0 ? 1 : 0; }
+  for (int j = tid; j < cap; j += 256) { const float e = en.at(j / en.cap, j % en.cap); if (staged) s_en[j] = e; cnt += e >= 0 ? 1 : 0; }
   double esum = 0;
-  for (int b = tid; b < (B.nr + BA_BLOCK - 1) / BA_BLOCK; b += 256) esum += B.e_part[b];
+  if (g) { if (tid < nranks) { double er; __builtin_memcpy(&er, g + tid * grs + pcap, 8); esum = er; } }
+  else for (int b = tid; b < (B.nr + BA_BLOCK - 1) / BA_BLOCK; b += 256) esum += B.e_part[b];
   esum = wave_sum(esum);
   cnt = (int)wave_sum((float)cnt);
   if ((tid & 63) == 0) { s_esum[tid >> 6] = esum; s_cnt[tid >> 6] = cnt; }
@@ -495,6 +510,7 @@ __global__ __launch_bounds__(256) void k_ba_opt_gate(const BaDev* __restrict__ w
   if (tid < n) s_delta[tid] = tid < 4 ? O.calib_value[tid] - O.calib_zero[tid] : B.t_prior[nf * 16 + 8 + (tid - 4)];   // getStitchedDeltaF (:1021-1032)
   __syncthreads();
   if (staged) { en.g = s_en; en.rstride = cap; en.nranks = 1; en.cap = cap; }
+  else if (g) { /* read in place: opt_select walks the ranks */ }
   const int M = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
   float th = 12 * 12 * 8;
   if (M > 0) {
@@ -519,7 +535,7 @@ __global__ __launch_bounds__(256) void k_ba_opt_gate(const BaDev* __restrict__ w
   double EL = 0;
   for (int f = 0; f < nf; f++) for (int i = 0; i < 8; i++) { const double dp = B.t_prior[nf * 8 + f * 8 + i]; EL += dp * B.t_prior[f * 8 + i] * dp; }
   { float s = 0; for (int i = 0; i < 4; i++) { const float cd = B.t_cdelta[i]; s += cd * (float)B.t_prior[nf * 16 + i] * cd; } EL += s; }
-  { float Ept = 0; for (int b = 0; b < nlp; b++) Ept += b < 1024 ? s_lp[b] : lp[b]; EL += Ept; }
+  { float Ept = 0; if (g) { for (int r = 0; r < nranks; r++) Ept += g[r * grs + pcap + 4]; } else for (int b = 0; b < nlp; b++) Ept += b < 1024 ? s_lp[b] : lp[b]; EL += Ept; }
   double EM = 0;
   for (int i = 0; i < n; i++) EM += s_term[i];
   if (which != 1) {                                           // the loop's start, or the state a rejected step went back to

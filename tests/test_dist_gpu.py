@@ -221,7 +221,7 @@ def _batch_optimize(ctx, abi, wins, wid0, slot0):
     return out
 
 
-def _opt_worker(rank, world, port, outdir):
+def _opt_worker(rank, world, port, outdir, gated=False):
     import torch
     import torch.distributed as dist
     sys.path[:0] = [os.path.join(ROOT, "stereo-dso-g2o_amd")]
@@ -233,6 +233,9 @@ def _opt_worker(rank, world, port, outdir):
     cbs = _host_transport(dist, torch, world)
     ctx.check(ctx.L.sdso_comm_init_host(ctx.h, world, rank, cbs[0], cbs[1], None))
     subs = [sdist.shard_window(synth.ba_window(**s), rank, world)[0] for s in _OPT_SPECS]
+    if gated:
+        for w in subs:
+            w["forceAcceptStep"] = 0
     out = _batch_optimize(ctx, abi, subs, 1, 10)
     for k, (s, i, r, its, resInA, e) in enumerate(out):
         np.savez(os.path.join(outdir, "opt_%d_%d.npz" % (rank, k)), s=s, i=i, r=r, its=its, resInA=resInA, e=e)
@@ -283,6 +286,37 @@ def test_two_rank_sharded_gn_loop_matches_single(gpu_ctx, oracle, tmp_path):
         assert abs(esum - e1) <= 1e-4 * e1                                   # lastEnergy is the all-gathered sum on every rank
     for k in range(len(wins)):
         gpu_ctx.check(gpu_ctx.L.sdso_ba_release_window(gpu_ctx.h, 41 + k))
+
+
+@pytest.mark.gpu
+def test_two_rank_sharded_energy_gated_loop_matches_single(gpu_ctx, tmp_path):
+    """setting_forceAceptStep = false over sharded windows (FullSystemOptimize.cpp:961-990): besides the all-reduce of the accumulators and
+    the all-gather of the break-test sums, every trial linearisation is followed by an all-gather of the ranks' newest-frame energies,
+    residual energies and calcLEnergy parts, and the gate reads them rank by rank — so both ranks take the same accept / reject decisions
+    (identical states on every rank) and they are the decisions of the unsharded window (same iteration count, states / idepths within the
+    sharded accepted-step loop's bars)."""
+    from sdso_amd import abi, synth
+    world = 2
+    mp.spawn(_opt_worker, args=(world, _free_port(), str(tmp_path), True), nprocs=world, join=True)
+    wins = [synth.ba_window(**s) for s in _OPT_SPECS]
+    for w in wins:
+        w["forceAcceptStep"] = 0
+    single = _batch_optimize(gpu_ctx, abi, wins, 51, 700)
+    for k, win in enumerate(wins):
+        nr = win["nr"]
+        sh = [np.load(tmp_path / ("opt_%d_%d.npz" % (r, k))) for r in range(world)]
+        s1, i1, r1, its1, resInA1, e1 = single[k]
+        assert int(sh[0]["its"]) == int(sh[1]["its"]) == its1
+        assert np.array_equal(sh[0]["s"], sh[1]["s"])                        # the same decisions and the same reduced systems on every rank
+        assert int(sh[0]["resInA"]) == int(sh[1]["resInA"])
+        idep = np.concatenate([sh[r]["i"] for r in range(world)])
+        rst = np.concatenate([sh[r]["r"] for r in range(world)])
+        assert np.abs(sh[0]["s"] - s1).max() <= 1e-4, np.abs(sh[0]["s"] - s1).max()
+        assert np.abs(idep - i1).max() <= 2e-4, np.abs(idep - i1).max()
+        assert (rst != r1).sum() <= max(2, nr // 2000)
+        assert abs(float(sh[0]["e"]) - e1) <= 1e-4 * e1
+    for k in range(len(wins)):
+        gpu_ctx.check(gpu_ctx.L.sdso_ba_release_window(gpu_ctx.h, 51 + k))
 
 
 @pytest.mark.gpu
