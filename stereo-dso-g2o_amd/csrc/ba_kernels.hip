@@ -1531,7 +1531,6 @@ __global__ __launch_bounds__(BA_BLOCK, 2) void k_ba_sc_host(const BaDev* __restr
     if (lane < n16) { pr_next = B.p_prior[p0 + lane]; de_next = B.p_delta[p0 + lane]; pf_next = pflag ? (int)pflag[p0 + lane] : 1; }
   };
   float4 vnext[8];
-  if (pb == 12345678) SCS();                 // (keeps pb live before the stamp)
   SCS();
   request(group_p0(0), vnext);
   SCS();

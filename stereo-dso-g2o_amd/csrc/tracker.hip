@@ -907,39 +907,25 @@ __device__ __forceinline__ bool lm_wave_step(LmCore& core, const float* F, const
 // ---- a CLUSTER of G workgroups per hypothesis --------------------------------------------------------------------------------------
 // One CU evaluates a 4 000-point level at the rate its L1 is filled (two 128-byte lines per template point at 64 bytes per clock: the
 // point loop of a single workgroup was 55 % of the call).  With G > 1 the hypothesis' points are strided over G workgroups on G CUs (placed
-// on ONE XCD: workgroup L runs on XCD L % 8); member 0 is the LEADER — it owns the LM state machine — and the hand-offs go through an
-// LmCluster record in global memory:
-//   leader -> members : the evaluation request (ev, level, done), every word tagged with the evaluation number;
-//   members -> leader : their 52 partial sums, tagged likewise;
-// the receivers poll the tagged words themselves (≈ 0.7 us per hand-off on one XCD, tools/handoff_bench.hip; a flag + fence + second
-// read protocol cost twice that).  The leader adds the partials in member order: the result does not depend on timing.  Every spin is bounded (a member that never became resident — the device was shared —
-// ends the call with out.evaluations = -1 and the host repeats it with G = 1, which needs no co-residency).
+// on ONE XCD: workgroup L runs on XCD L % 8).  EVERY member runs the LM state machine: per evaluation a member publishes its 52 partial
+// sums in an LmCluster record in global memory, collects the other members', adds all of them in member order — so every member holds the
+// same sums, bit for bit — and takes the same decisions with the same arithmetic: the next request never has to travel.  ONE hand-off per
+// evaluation (a leader that gathers the partials and publishes the next request needs two: 0.355 against 0.31 ms per call).
+// A partial travels as 64-bit {word, evaluation number} pairs written and polled by single relaxed agent-scope atomics: a reader that sees
+// the tag of evaluation e has that evaluation's word — no flag, no fence, one round trip (≈ 0.7 us on one XCD, tools/handoff_bench.hip).
+// Two buffers alternate: a member can be one evaluation ahead of a slow reader of its previous partial, never two.
+// Every spin is bounded (a member that never became resident — the device was shared — ends the call with out.evaluations = -1 and
+// the host repeats it with G = 1, which needs no co-residency).  Member 0 reports the result.
 constexpr int LM_MAXG = 8;
 constexpr int LM_SPIN_LIMIT = 1 << 21;
-constexpr int LM_EV_WORDS = (int)(sizeof(sdso_track_eval_t) / 4);
-static_assert(sizeof(sdso_track_eval_t) % 4 == 0, "eval record is copied word by word");
-constexpr int LM_REQ_WORDS = LM_EV_WORDS + 2;   // + level, done
-static_assert(LM_REQ_WORDS <= 64, "one wave polls the request");
-// Every 32-bit word travels as a 64-bit {word, sequence number} pair written and read by ONE relaxed agent-scope atomic: a reader that
-// sees the tag of evaluation e has that evaluation's word — no flag, no fence, one round trip per hand-off.  (Zeroed before the launch;
-// the first evaluation is number 1.)
-struct LmCluster {
-  unsigned long long req[64];
-  unsigned long long part[LM_MAXG][64];
+struct LmCluster {                                           // zeroed before the launch; the first evaluation is number 1
+  unsigned long long part[2][LM_MAXG][64];
 };
 __device__ __forceinline__ void lm_put(unsigned long long* slot, unsigned word, int e) {
   __hip_atomic_store(slot, (unsigned long long)word | ((unsigned long long)(unsigned)e << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ unsigned long long lm_get(const unsigned long long* slot) {
   return __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// leader, lanes 0 .. LM_REQ_WORDS - 1 of one wave: the request of evaluation e (one store instruction; a single lane writing the 37 words
-// one after the other took 3 300 cycles)
-__device__ __forceinline__ void lm_publish(LmCluster& C, const sdso_track_eval_t& ev, int lvl, int done, int e) {
-  const int k = threadIdx.x;
-  if (k >= LM_REQ_WORDS) return;
-  const unsigned w = k < LM_EV_WORDS ? reinterpret_cast<const unsigned*>(&ev)[k] : k == LM_EV_WORDS ? (unsigned)lvl : (unsigned)done;
-  lm_put(&C.req[k], w, e);
 }
 
 __global__ __launch_bounds__(LM_BLOCK) void k_track_lm(LmJob* __restrict__ jobs, LmCluster* __restrict__ clusters, int nhyp, int G, int spin_limit, int drop_member /* test hook: member G - 1 of every cluster never answers */) {
@@ -964,7 +950,7 @@ __global__ __launch_bounds__(LM_BLOCK) void k_track_lm(LmJob* __restrict__ jobs,
   const bool leader = g == 0;
   if (tid < SDSO_PYR_LEVELS) { s_pc[tid] = J.pc[tid]; s_img[tid] = J.img[tid]; s_n[tid] = J.n[tid]; }
   if (tid == 0) {
-    if (leader) core.init(J.p, J.T, J.aff);
+    core.init(J.p, J.T, J.aff);                 // every member: the same state machine on the same inputs
     s_done = 0; s_abort = 0;
   }
   __syncthreads();
@@ -974,7 +960,7 @@ __global__ __launch_bounds__(LM_BLOCK) void k_track_lm(LmJob* __restrict__ jobs,
 #else
 #define LMSL(i) do { } while (0)
 #endif
-  double Hacc = 0.0, bacc = 0.0;                // wave 0 of the leader: the accepted system (lm_wave_step)
+  double Hacc = 0.0, bacc = 0.0;                // wave 0: the accepted system (lm_wave_step)
   float4 qc[LM_UNROLL];                         // this thread's template points of level qlvl
   int qlvl = -1;
 #pragma unroll
@@ -982,32 +968,13 @@ __global__ __launch_bounds__(LM_BLOCK) void k_track_lm(LmJob* __restrict__ jobs,
   const int first = g * LM_BLOCK + tid, stride = G * LM_BLOCK;
   // every trip is one evaluation; the loop ends for all threads together (the flags are read behind a barrier)
   for (int e = 1; e <= 1024; e++) {
-    if (leader) {
-      if (tid == 0) {
-        fill_eval(core.p, core.lvl, core.reqT, core.reqAff, core.p.coarseCutoffTH * core.levelCutoffRepeat, ev);
-        s_lvl = core.lvl;
-        core.out.evaluations++;
-        core.out.point_evals += s_n[core.lvl];
-      }
-      __syncthreads();
-      if (G > 1 && wv == 0) lm_publish(C, ev, s_lvl, 0, e);
-    } else {
-      if (tid < LM_REQ_WORDS) {                 // (one wave) every lane waits for its own word of request e
-        unsigned long long v = 0;
-        int spins = 0;
-        for (;;) {
-          v = lm_get(&C.req[tid]);
-          if ((int)(v >> 32) == e || ++spins >= spin_limit) break;
-          __builtin_amdgcn_s_sleep(1);
-        }
-        if ((int)(v >> 32) != e) s_abort = 1;
-        else if (tid < LM_EV_WORDS) reinterpret_cast<unsigned*>(&ev)[tid] = (unsigned)v;
-        else if (tid == LM_EV_WORDS) s_lvl = (int)(unsigned)v;
-        else s_done = (int)(unsigned)v;
-      }
-      __syncthreads();
-      if (s_abort || s_done) return;
+    if (tid == 0) {
+      fill_eval(core.p, core.lvl, core.reqT, core.reqAff, core.p.coarseCutoffTH * core.levelCutoffRepeat, ev);
+      s_lvl = core.lvl;
+      core.out.evaluations++;
+      core.out.point_evals += s_n[core.lvl];
     }
+    __syncthreads();
     LMSL(0);
     const int lvl = s_lvl, n = s_n[lvl];
     if (lvl != qlvl) {                          // (uniform) first evaluation on this level: the points move into registers
@@ -1038,39 +1005,36 @@ __global__ __launch_bounds__(LM_BLOCK) void k_track_lm(LmJob* __restrict__ jobs,
 #pragma unroll
       for (int w = 1; w < LM_BLOCK / 64; w++) mine += sF[w][tid];
     }
-    if (!leader) {                              // hand the partial over, wait for the next request
-      if (tid < TRK_NF + TRK_NI) lm_put(&C.part[g][tid], __float_as_uint(mine), e);
-      continue;
-    }
-    if (G > 1 && tid < TRK_NF + TRK_NI) {       // the members' partials of evaluation e, added in member order
+    if (G > 1 && tid < TRK_NF + TRK_NI) {       // publish this member's partial, collect the others', add all of them in member order
+      unsigned long long (*buf)[64] = C.part[e & 1];
+      const float own = mine;
+      lm_put(&buf[g][tid], __float_as_uint(own), e);
       unsigned long long v[LM_MAXG];
       bool all = false;
       for (int spins = 0; spins < spin_limit && !all; spins++) {
         all = true;
 #pragma unroll
-        for (int m = 1; m < LM_MAXG; m++)
-          if (m < G) { v[m] = lm_get(&C.part[m][tid]); all = all && (int)(v[m] >> 32) == e; }
+        for (int m = 0; m < LM_MAXG; m++)
+          if (m < G && m != g) { v[m] = lm_get(&buf[m][tid]); all = all && (int)(v[m] >> 32) == e; }
         if (!all) __builtin_amdgcn_s_sleep(1);
       }
       if (!all) s_abort = 1;
+      float tot = 0.f;
 #pragma unroll
-      for (int m = 1; m < LM_MAXG; m++) if (m < G) mine += __uint_as_float((unsigned)v[m]);
+      for (int m = 0; m < LM_MAXG; m++) if (m < G) tot = m == 0 ? (g == 0 ? own : __uint_as_float((unsigned)v[0])) : tot + (m == g ? own : __uint_as_float((unsigned)v[m]));
+      mine = tot;
     }
     if (tid < TRK_NF) F[tid] = mine; else if (tid < TRK_NF + TRK_NI) I[tid - TRK_NF] = (int)mine;
     __syncthreads();
-    if (s_abort) {                              // a member never answered: release the ones that did, give the call back to the host
-      if (wv == 0) lm_publish(C, ev, 0, 1, e + 1);
-      if (tid == 0) { J.out = core.out; J.out.evaluations = -1; }
+    if (s_abort) {                              // a member never answered (every member notices): member 0 gives the call back to the host
+      if (leader && tid == 0) { J.out = core.out; J.out.evaluations = -1; }
       return;
     }
     LMSL(6);
     if (wv == 0) { const bool d = lm_wave_step(core, F, I, Hacc, bacc); if (tid == 0) s_done = d ? 1 : 0; }
     __syncthreads();
     LMSL(11);
-    if (s_done) {
-      if (G > 1 && wv == 0) lm_publish(C, ev, 0, 1, e + 1);
-      break;
-    }
+    if (s_done) break;                          // (every member reaches the same verdict)
   }
 #undef LMSL
   if (leader && tid == 0) {
@@ -1186,7 +1150,7 @@ extern "C" int sdso_track_newest_coarse_batch(sdso_ctx* ctx, int nhyp, const int
   // must come back through the single-workgroup repetition with the single-workgroup result
   const bool drop = getenv("SDSO_TRK_LM_TEST_DROP_MEMBER") != nullptr;
   for (int attempt = 0; attempt < 2; attempt++) {
-    for (int k = 0; k < nhyp; k++) { hj[k].T = lastToNew[k]; hj[k].aff = aff_g2l[k]; }
+    for (int k = 0; k < nhyp; k++) { hj[k].T = lastToNew[k]; hj[k].aff = aff_g2l[k]; hj[k].out.evaluations = -1; }   // (-1 until member 0 reports)
     SDSO_HIP(ctx, hipMemcpyAsync(dj, hj, sizeof(LmJob) * nhyp, hipMemcpyHostToDevice, ctx->stream));
     if (G > 1) SDSO_HIP(ctx, hipMemsetAsync(dc, 0, sizeof(LmCluster) * (size_t)nhyp, ctx->stream));
     {
