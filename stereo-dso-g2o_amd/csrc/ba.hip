@@ -1247,7 +1247,6 @@ extern "C" int sdso_ba_batch_create(sdso_ctx* ctx, int nwin, const int* wins) {
     SDSO_REQUIRE(ctx, Ws[i]->d.nf == Ws[0]->d.nf, "batch windows must share nf");
     SDSO_REQUIRE(ctx, (Ws[i]->d.tiledT > 0) == (Ws[0]->d.tiledT > 0), "batch windows must share the image layout");
     SDSO_REQUIRE(ctx, Ws[i]->solverMode == Ws[0]->solverMode, "batch windows must share solverMode (one lambda per launch)");
-    SDSO_REQUIRE(ctx, (Ws[i]->solverMode & (SOLVER_SVD | SOLVER_ORTHOGONALIZE_SYSTEM)) == 0, "SOLVER_SVD / SOLVER_ORTHOGONALIZE_SYSTEM windows are solved through sdso_ba_solve / sdso_ba_optimize, not in a batch");
     for (int k = 0; k < i; k++) SDSO_REQUIRE(ctx, Ws[k] != Ws[i], "a window may appear only once in a batch");
   }
   const int nf = Ws[0]->d.nf;
@@ -1366,6 +1365,19 @@ extern "C" int sdso_ba_batch_solve(sdso_ctx* ctx, double lambda, int orthogonali
   // solveSystem's overrides of lambda (EnergyFunctional.cpp:840-846), as in the single-window call
   if (Bt->W[0]->solverMode & SOLVER_USE_GN) lambda = 0;
   if (Bt->W[0]->solverMode & SOLVER_FIX_LAMBDA) lambda = 1e-5;
+  if (Bt->W[0]->solverMode & (SOLVER_SVD | SOLVER_ORTHOGONALIZE_SYSTEM)) {
+    // solveSystemF's SVD / orthogonalised-system branches (EnergyFunctional.cpp:876-900, 924-965): the batch accumulates in one launch, the
+    // assembly and the eigen-decomposition run on the host window by window (solve_system_host, as for sdso_ba_solve), the back-substitution
+    // on the device.  The host mirrors (deltas, projector) are those of the upload: this is the step-by-step batch API, not the resident loop.
+    join_sc(ctx, Bt);
+    ensure_folded(ctx, Bt);
+    for (BaWindowDev* W : Bt->W) {
+      const int rc = solve_system_host(ctx, W, orthogonalize_x ? 2 : 0, lambda);   // (iteration >= 2 is how the single call spells ORTHOGONALIZE_X_LATER)
+      if (rc) return rc;
+    }
+    Bt->sc_async = false;
+    return SDSO_OK;
+  }
   if (!tail_enabled()) join_sc(ctx, Bt);
   launch_solve(ctx, batch_launch(Bt), lambda, orthogonalize_x, Bt->folded, Bt->sc_async);   // (the tail kernel folds for itself: the block stays as it is)
   Bt->sc_async = false;
@@ -1847,6 +1859,21 @@ extern "C" int sdso_ba_batch_optimize_end(sdso_ctx* ctx, sdso_ba_opt_result_t* o
   return rc;
 }
 extern "C" int sdso_ba_batch_optimize(sdso_ctx* ctx, int mnumOptIts, sdso_ba_opt_result_t* out) {
+  if (BaBatch* Bt = get_batch(ctx)) {
+    if (Bt->W[0]->solverMode & (SOLVER_SVD | SOLVER_ORTHOGONALIZE_SYSTEM)) {
+      // the SVD / orthogonalised-system solver modes are host-driven (one round trip per iteration, solve_system_host): the batch call runs
+      // the single-window loop window by window — the same results as sdso_ba_optimize, no batching gain
+      SDSO_HIP(ctx, hipSetDevice(ctx->device));
+      free_optrun(ctx);
+      join_sc(ctx, Bt);
+      for (size_t i = 0; i < Bt->wins.size(); i++) {
+        const int rc = sdso_ba_optimize(ctx, Bt->wins[i], mnumOptIts, nullptr, nullptr, nullptr, out ? &out[i] : nullptr);
+        if (rc) return rc;
+      }
+      Bt->folded = true; Bt->sc_async = false;
+      return SDSO_OK;
+    }
+  }
   int rc = sdso_ba_batch_optimize_begin(ctx, 1);
   if (rc) return rc;
   OptRun* R = reg_get(g_optruns, ctx);

@@ -200,9 +200,31 @@ def test_solver_mode_variants(gpu_ctx, oracle, win_small, mode, first_id):
         gpu_ctx.check(gpu_ctx.L.sdso_ba_get_point_steps(gpu_ctx.h, 7, abi.fp(sg)))
         assert np.abs(sg - so).max() <= tol * max(np.abs(so).max(), 1e-6)
     oracle.orc_ba_destroy(h)
-    if mode & (SVD | ORTH_SYS):                                             # these windows stay out of the batched device solve
+    if mode & (SVD | ORTH_SYS):
+        # the batch entry points take these windows too (host-driven solve per window behind one batched accumulate): the batch's x is the
+        # single call's x at the same state, and sdso_ba_batch_optimize reproduces sdso_ba_optimize window by window
         ids = np.array([7], np.int32)
-        assert gpu_ctx.L.sdso_ba_batch_create(gpu_ctx.h, 1, abi.ip(ids)) == -1
+        gpu_ctx.check(gpu_ctx.L.sdso_ba_batch_create(gpu_ctx.h, 1, abi.ip(ids)))
+        gpu_ctx.check(gpu_ctx.L.sdso_ba_batch_accumulate(gpu_ctx.h))            # (linearises, applies and accumulates in one kernel)
+        gpu_ctx.check(gpu_ctx.L.sdso_ba_batch_solve(gpu_ctx.h, 0.025, 1))
+        xb = np.zeros(n)
+        gpu_ctx.check(gpu_ctx.L.sdso_ba_batch_get_x(gpu_ctx.h, abi.dp(xb)))
+        xs = np.zeros(n)                                                        # the single call on the state the batch left applied
+        gpu_ctx.check(gpu_ctx.L.sdso_ba_accumulate(gpu_ctx.h, 7))
+        gpu_ctx.check(gpu_ctx.L.sdso_ba_solve(gpu_ctx.h, 7, 2, 0.025, abi.dp(xs), None, None, None, None))
+        d2 = np.sqrt(np.abs(np.diag(Hg))) + 1e-30
+        assert np.abs((xb - xs) * d2).max() <= 1e-6 * max(1.0, np.abs(xs * d2).max())
+        res = (abi.BAOptResult * 1)()
+        gpu_ctx.check(gpu_ctx.L.sdso_ba_upload_window(gpu_ctx.h, 7, C.byref(W)))       # a fresh copy (the calls above moved the newest frame's threshold)
+        gpu_ctx.check(gpu_ctx.L.sdso_ba_batch_create(gpu_ctx.h, 1, abi.ip(ids)))
+        gpu_ctx.check(gpu_ctx.L.sdso_ba_batch_optimize(gpu_ctx.h, 4, res))
+        sb, ib, rb = np.zeros((nf, 10)), np.zeros(npts, np.float32), np.zeros(win["nr"], np.uint8)
+        gpu_ctx.check(gpu_ctx.L.sdso_ba_get_state(gpu_ctx.h, 7, abi.dp(sb), abi.fp(ib), abi.bp(rb)))
+        gpu_ctx.check(gpu_ctx.L.sdso_ba_upload_window(gpu_ctx.h, 7, C.byref(W)))       # the same window again (the upload releases the batch's binding)
+        ss, is_, rs, os_ = np.zeros((nf, 10)), np.zeros(npts, np.float32), np.zeros(win["nr"], np.uint8), abi.BAOptResult()
+        gpu_ctx.check(gpu_ctx.L.sdso_ba_optimize(gpu_ctx.h, 7, 4, abi.dp(ss), abi.fp(is_), abi.bp(rs), C.byref(os_)))
+        assert res[0].iterations == os_.iterations
+        assert np.abs(sb - ss).max() <= 1e-9 and np.abs(ib - is_).max() <= 1e-7 and np.array_equal(rb, rs)
     gpu_ctx.check(gpu_ctx.L.sdso_ba_release_window(gpu_ctx.h, 7))
 
 
