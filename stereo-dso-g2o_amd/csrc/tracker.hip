@@ -532,10 +532,11 @@ extern "C" int sdso_track_calc_res_gs(sdso_ctx* ctx, int ref_slot, int frame_slo
 // evaluations with a little 8x8 algebra in between: LmCore is that state machine, written once for host and device.  It always
 // has exactly one evaluation pending (first evaluation of a level, repeat with a doubled cutoff, or the trial step of an LM
 // iteration).  Two drivers:
-//   * k_track_lm (default): ONE launch runs the whole call — one 512-thread workgroup per motion hypothesis (FullSystem::
-//     trackNewCoarse tries up to 53 of them, FullSystem.cpp:305-441; they run side by side on different CUs), all threads evaluate the
-//     pending calcRes+calcGSSSE over the level's points, thread 0 solves the 8x8 system, applies SE3::exp and takes the accept / reject
-//     and level decisions.  No host round trip per evaluation (it cost 25 us of launch + synchronisation each, 28 times per call).
+//   * k_track_lm (default): ONE launch runs the whole call — a cluster of up to eight 512-thread workgroups per motion hypothesis
+//     (FullSystem::trackNewCoarse tries up to 53 of them, FullSystem.cpp:305-441; the clusters run side by side), all threads evaluate the
+//     pending calcRes+calcGSSSE over the level's points, the members exchange their partial sums once, and every member solves the 8x8
+//     system on one wave, applies SE3::exp and takes the accept / reject and level decisions on the same sums (see the cluster notes at
+//     the kernel).  No host round trip per evaluation (it cost 25 us of launch + synchronisation each, 28 times per call).
 //   * the lock-step host loop (SDSO_TRK_HOST_LM=1): every round evaluates the pending requests of all hypotheses in one k_track_eval
 //     launch.  Same LmCore, same sequence of evaluations.
 namespace sdso {
