@@ -51,7 +51,11 @@ class BAWorkload:
         from sdso_amd import dist as sdist
         self.scaling = getattr(args, "scaling", "weak")
         strong = self.scaling == "strong"
-        nwin = args.batch or (32 if strong else 128)   # enough independent windows that the working set is >> the 256 MB MALL
+        # enough independent windows that the working set is >> the 256 MB MALL.  256 since the end of round 3 (128 before): the
+        # serial kernels behind the linearisation are one workgroup per window (k_ba_tail: 87 us for 128 windows on 256 CUs, 95 us for 256)
+        # or rounds of resident workgroups, so a batch that fills the chip costs 4.2 instead of 4.6-4.7 us per window-iteration; the
+        # linearisation itself scales linearly.  --batch 128 reproduces the earlier rounds' step (profiles/r03_bench_ba_128_windows.json).
+        nwin = args.batch or (32 if strong else 256)
         # stream groups.  One rank: ONE group — every kernel of the step runs alone on the chip (the linearisation at its clean-stream
         # 0.40 of the HBM peak) and the step is lin + Schur + tail + points in sequence; two chained groups reach the same step time
         # with the linearisation slowed by the other group's tail (0.35), three unchained groups are 6 % faster but their overlapping

@@ -4,6 +4,7 @@ root=${GRAFT_REPO_ROOT:-/root/repo}
 cd $root
 mkdir -p gpurun_out
 timeout -k 10 400 python bench.py --steps 20 2>gpurun_out/r03_bench_ba.err | tail -1 > gpurun_out/r03_bench_ba.json
+SDSO_BENCH_SKIP_OTHERS=1 timeout -k 10 300 python bench.py --steps 20 --batch 128 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/r03_bench_ba_128_windows.json
 SDSO_BA_GROUPS=2 SDSO_BENCH_SKIP_OTHERS=1 timeout -k 10 300 python bench.py --steps 20 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/r03_bench_ba_two_groups.json
 SDSO_BA_GROUPS=3 SDSO_BA_NOCHAIN=1 SDSO_BENCH_SKIP_OTHERS=1 timeout -k 10 300 python bench.py --steps 20 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/r03_bench_ba_three_groups_unchained.json
 timeout -k 10 300 python bench.py --steps 20 --scaling strong --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/r03_bench_ba_strong.json
