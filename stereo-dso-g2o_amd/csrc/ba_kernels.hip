@@ -1666,38 +1666,55 @@ __global__ __launch_bounds__(BA_BLOCK, 2) void k_ba_sc_host(const BaDev* __restr
   __syncthreads();
   if (wv == 1) put(tiles[0]);
   __syncthreads();
-  if (wv != 0) return;
-  add(tiles[0]);
-  SCS();
-  // ---- wave 0: the host's bins.  acc[a][b][v] = D'[16a + 4*kq + v][16b + ci]
+  // ---- the host's bins.  acc[a][b][v] = D'[16a + 4*kq + v][16b + ci]: wave 0 lays the finished tiles out in LDS the way the bins lie in
+  // memory (64-float blocks per (t1, t2)), then all four waves write them out, one 256-byte block per store (from the accumulator
+  // layout a store covered eight 32-byte pieces of four blocks, 84 such stores on one wave: 9 k of the kernel's 75 k cycles)
   const int nf2 = nf * nf;
   float* accD = B.accum + acc_off_D(nf);
   float* accE = B.accum + acc_off_E(nf);
   float* accEB = B.accum + acc_off_EB(nf);
+  float* bins = stage_all + 21 * 256;          // the second tile buffer: free since the tree's second barrier
+  constexpr int BIN_E = 64 * 64, BIN_EB = BIN_E + 8 * 32;
+  static_assert(21 * 256 + BIN_EB + 64 <= SC_LDS, "the bins fit behind the first tile buffer");
+  if (wv == 0) {
+    add(tiles[0]);
+    SCS();
 #pragma unroll
-  for (int a = 0; a < 4; a++) {
+    for (int a = 0; a < 4; a++) {
 #pragma unroll
-    for (int v = 0; v < 4; v++) {
-      const int Rr = 16 * a + 4 * kq + v, t1 = Rr >> 3, ra = Rr & 7;
-      if (t1 < nf) {
+      for (int v = 0; v < 4; v++) {
+        const int Rr = 16 * a + 4 * kq + v, t1 = Rr >> 3, ra = Rr & 7;
 #pragma unroll
         for (int b = 0; b < 4; b++) {
           const int Cc = 16 * b + ci, t2 = Cc >> 3, cc = Cc & 7;
-          if (t2 < nf) accD[(size_t)(h + t1 * nf + t2 * nf2) * 64 + ra * 8 + cc] = acc[a][b][v];
+          bins[(t1 * 8 + t2) * 64 + ra * 8 + cc] = acc[a][b][v];
         }
-        if (ci < 4) accE[(size_t)(h + t1 * nf) * 32 + ra * 4 + ci] = acc[a][4][v];
-        if (ci == 4) accEB[(size_t)(h + t1 * nf) * 8 + ra] = acc[a][4][v];
+        if (ci < 4) bins[BIN_E + t1 * 32 + ra * 4 + ci] = acc[a][4][v];
+        if (ci == 4) bins[BIN_EB + t1 * 8 + ra] = acc[a][4][v];
+      }
+    }
+    float* hp = B.sc_part + (size_t)h * 20;      // Hcc (16) and bc (4) of this host; k_ba_fold_all adds the hosts
+    if (kq == 0) {
+#pragma unroll
+      for (int v = 0; v < 4; v++) {
+        if (ci < 4) hp[v * 4 + ci] = acc44[v];
+        if (ci == 4) hp[16 + v] = acc44[v];
       }
     }
   }
-  float* hp = B.sc_part + (size_t)h * 20;      // Hcc (16) and bc (4) of this host; k_ba_fold_all adds the hosts
-  if (kq == 0) {
-#pragma unroll
-    for (int v = 0; v < 4; v++) {
-      if (ci < 4) hp[v * 4 + ci] = acc44[v];
-      if (ci == 4) hp[16 + v] = acc44[v];
-    }
+  __syncthreads();
+#pragma unroll 4
+  for (int blk = wv; blk < 64; blk += BA_BLOCK / 64) {
+    const int t1 = blk >> 3, t2 = blk & 7;
+    if (t1 < nf && t2 < nf) accD[(size_t)(h + t1 * nf + t2 * nf2) * 64 + lane] = bins[blk * 64 + lane];
   }
+  {
+    const int idx = 64 * wv + lane, t1 = idx >> 5;
+    if (t1 < nf) accE[(size_t)(h + t1 * nf) * 32 + (idx & 31)] = bins[BIN_E + idx];
+  }
+  if (wv == 1 && (lane >> 3) < nf) accEB[(size_t)(h + (lane >> 3) * nf) * 8 + (lane & 7)] = bins[BIN_EB + lane];
+  if (signal) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }   // (every wave's stores are out before wave 0 signals)
+  if (wv != 0) return;
   SCS();
 #ifdef SDSO_SC_STAMPS
   if ((blockIdx.x == 0 || blockIdx.x == 5) && (blockIdx.y == 0 || blockIdx.y == 100) && lane == 0)
