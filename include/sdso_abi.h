@@ -222,6 +222,10 @@ typedef struct {
                                       ORTHOGONALIZE_SYSTEM windows are solved per window (not in sdso_ba_batch_*) */
   double affineOptModeA, affineOptModeB;
   int forceAcceptStep;             /* setting_forceAceptStep */
+  /* bookkeeping FullSystem::linearizeAll(true) updates at the end of optimize (FullSystemOptimize.cpp:64-77); each may be NULL */
+  const float* maxRelBaseline;     /* np     PointHessian::maxRelBaseline   (NULL: 0)                              */
+  const int* numGoodResiduals;     /* np     PointHessian::numGoodResiduals (NULL: 0)                              */
+  const uint8_t* res_isNew;        /* nr     PointFrameResidual::isNew      (NULL: 1, what Residuals.cpp:79 sets)  */
 } sdso_ba_window_t;
 
 int sdso_ba_upload_window(sdso_ctx* ctx, int win, const sdso_ba_window_t* W);
@@ -270,6 +274,10 @@ int sdso_ba_get_point_terms(sdso_ctx* ctx, int win, float* HdiF, float* bdSumF, 
  *   frame_step   : nf*8  (FrameHessian::step head<8>), calib_step: 4 */
 int sdso_ba_solve(sdso_ctx* ctx, int win, int iteration, double lambda, double* x, double* HS,
                   double* bS, double* frame_step, double* calib_step);
+/* EnergyFunctional::resubstituteF_MT (EnergyFunctional.cpp:272-341) alone, for a caller-supplied x (8nf+4): frame_step (nf*8) and
+ * calib_step (4) = -x, the points' steps (resubstituteFPt, :305-341) on the device — sdso_ba_get_point_steps reads them.  Needs the
+ * per-point terms of a preceding sdso_ba_accumulate. */
+int sdso_ba_resubstitute(sdso_ctx* ctx, int win, const double* x, double* frame_step, double* calib_step);
 int sdso_ba_get_point_steps(sdso_ctx* ctx, int win, float* step /* np */);
 
 /* FullSystem::optimize, DSO-native GN loop (FullSystemOptimize.cpp:871-1041, the un-compiled #else):
@@ -283,6 +291,55 @@ typedef struct {
 int sdso_ba_optimize(sdso_ctx* ctx, int win, int mnumOptIts, double* state_out /* nf*10 */,
                      float* idepth_out /* np */, uint8_t* res_state_out /* nr */,
                      sdso_ba_opt_result_t* out);
+
+/* Everything FullSystem::optimize leaves behind in the reference's objects and that its callers read afterwards — the state after
+ * the closing `linearizeAll(true)` (FullSystemOptimize.cpp:997-1041 with :52-87 and :142-203) and after the last solveSystemF's
+ * AccumulatedSCHessianSSE::addPoint (AccumulatedSCHessian.cpp:34-60).  Valid after sdso_ba_optimize / sdso_ba_batch_optimize[_end]
+ * of the window (SDSO_ERR_STATE before).  Every pointer may be NULL; arrays are caller-owned, in the window's point / residual order.
+ * Consumers in the reference: CoarseTracker::makeCoarseDepthL0 reads lastResiduals[0].second (= state_state of that residual),
+ * centerProjectedTo and efPoint->HdiF (CoarseTracker.cpp:295-350); FullSystem::flagPointsForRemoval reads residuals.size(),
+ * isInlierNew() (numGoodResiduals), isOOB() (lastResiduals[].second, maxRelBaseline) and idepth_hessian (FullSystem.cpp:997-1040). */
+typedef struct {
+  /* per point [np] */
+  float* idepth;                 /* PointHessian::idepth (== idepth_zero: doStepFromBackup sets both, :268-272)                       */
+  float* step;                   /* PointHessian::step of the last solve                                                              */
+  float* HdiF;                   /* EFPoint::HdiF          (AccumulatedSCHessian.cpp:58; 0 when the point had no active residual :44) */
+  float* bdSumF;                 /* EFPoint::bdSumF        (:61-65)                                                                   */
+  float* idepth_hessian;         /* PointHessian::idepth_hessian (:56; 0 at :46)                                                      */
+  float* maxRelBaseline;         /* PointHessian::maxRelBaseline: reset at AccumulatedSCHessian.cpp:47, raised at FullSystemOptimize.cpp:68-74 */
+  int* numGoodResiduals;         /* PointHessian::numGoodResiduals after :76                                                          */
+  /* per residual [nr] */
+  uint8_t* state_state;          /* PointFrameResidual::state_state after applyRes(true); also lastResiduals[k].second (:165-172)     */
+  uint8_t* isActiveAndIsGoodNEW; /* EFResidual::isActiveAndIsGoodNEW (Residuals.cpp:367-385)                                          */
+  float* state_energy;           /* PointFrameResidual::state_energy                                                                  */
+  float* centerProjectedTo;      /* nr*3, meaningful where isActiveAndIsGoodNEW (the final linearisation reached :130-131); else 0    */
+  float* projectedTo;            /* nr*16, same rule                                                                                  */
+  uint8_t* toRemove;             /* 1: linearizeAll(true) put the residual on toRemove (:80-84) — the caller clears lastResiduals[].first,
+                                    calls ef->dropResidual(r->efResidual) and deleteOut(ph->residuals, k) in this order (:176-195)   */
+  /* frames */
+  double* state;                 /* nf*10  FrameHessian::get_state()                                                                  */
+  double* state_zero;            /* nf*10  (the newest frame's changes: setEvalPT at :1000-1003)                                      */
+  double* evalPT;                /* nf*12  worldToCam_evalPT: R (9, row-major), t (3); the newest frame's is its PRE_worldToCam        */
+  double* PRE_worldToCam;        /* nf*12  (shell->camToWorld = PRE_camToWorld at :1033-1037 is its inverse)                          */
+  double* frame_step;            /* nf*10  FrameHessian::step of the last solve                                                       */
+  float* frameEnergyTH;          /* nf     (the newest frame's: setNewFrameEnergyTH of the closing linearizeAll)                      */
+  /* calibration */
+  double calib_value[4];         /* CalibHessian::value (unscaled)                                                                    */
+  double calib_value_scaled[4];
+  double calib_step[4];
+  /* EnergyFunctional members of the last solveSystemF */
+  double* lastX;                 /* 8nf+4 */
+  double* lastHS;                /* (8nf+4)^2; lastHS / lastbS (log-only in the reference, FullSystem.cpp:1691-1764) are kept by
+                                    sdso_ba_optimize; inside a batch only after sdso_ba_batch_keep_system(ctx, 1): SDSO_ERR_STATE otherwise */
+  double* lastbS;                /* 8nf+4 */
+  int resInA, resInL, resInM;    /* nres of the last accumulateAF / LF; residuals marginalised through this window so far             */
+  int n_toRemove;
+  sdso_ba_opt_result_t result;   /* what the optimize call returned for this window                                                   */
+} sdso_ba_post_state_t;
+int sdso_ba_get_post_state(sdso_ctx* ctx, int win, sdso_ba_post_state_t* out);
+/* EnergyFunctional::resInA / resInL of the latest accumulate (EnergyFunctional.cpp:219, :241) and resInM: the residuals marginalised
+ * through this window by sdso_ba_marginalize_points so far (:704).  Any pointer may be NULL. */
+int sdso_ba_get_counts(sdso_ctx* ctx, int win, int* resInA, int* resInL, int* resInM);
 
 /* EnergyFunctional::marginalizePointsF (EnergyFunctional.cpp:663-736) for the points flagged in
  * marg_flag[np] (after flagPointsForRemoval's linearize + fixLinearizationF, FullSystem.cpp:1012-1021):
@@ -319,6 +376,9 @@ int sdso_ba_batch_schur(sdso_ctx* ctx);
 /* 1 (default): every linearization writes the RawResidualJacobian records to HBM like
  * PointFrameResidual::J; 0: they stay in registers of the fused linearize+accumulate kernel. */
 int sdso_ba_batch_set_materialize(sdso_ctx* ctx, int materialize);
+/* 1: every solve of the batch's resident loop also writes EnergyFunctional::lastHS / lastbS (EnergyFunctional.cpp:909-910; log-only in
+ * the reference) so that sdso_ba_get_post_state can return them; 0 (default): they are not materialised (37 KB per window and iteration). */
+int sdso_ba_batch_keep_system(sdso_ctx* ctx, int on);
 /* lambda is subject to the windows' solverMode exactly as in solveSystemF (SOLVER_USE_GN -> 0, SOLVER_FIX_LAMBDA -> 1e-5,
  * EnergyFunctional.cpp:840-846); the members of a batch must share one solverMode. */
 int sdso_ba_batch_solve(sdso_ctx* ctx, double lambda, int orthogonalize_x);

@@ -88,6 +88,9 @@ typedef struct {
   int solverMode;
   double affineOptModeA, affineOptModeB;
   int forceAcceptStep;
+  const float* maxRelBaseline;     /* np, NULL: 0   PointHessian::maxRelBaseline   */
+  const int* numGoodResiduals;     /* np, NULL: 0   PointHessian::numGoodResiduals */
+  const uint8_t* res_isNew;        /* nr, NULL: 1   PointFrameResidual::isNew      */
 } orc_ba_window_t;
 
 typedef struct {
@@ -96,6 +99,18 @@ typedef struct {
   double rmse;
   int resInA;
 } orc_ba_opt_result_t;
+
+/* what FullSystem::optimize leaves behind (mirror of sdso_ba_post_state_t, include/sdso_abi.h) */
+typedef struct {
+  float* idepth; float* step; float* HdiF; float* bdSumF; float* idepth_hessian; float* maxRelBaseline; int* numGoodResiduals;
+  uint8_t* state_state; uint8_t* isActiveAndIsGoodNEW; float* state_energy; float* centerProjectedTo; float* projectedTo; uint8_t* toRemove;
+  double* state; double* state_zero; double* evalPT; double* PRE_worldToCam; double* frame_step; float* frameEnergyTH;
+  double calib_value[4]; double calib_value_scaled[4]; double calib_step[4];
+  double* lastX; double* lastHS; double* lastbS;
+  int resInA, resInL, resInM;
+  int n_toRemove;
+  orc_ba_opt_result_t result;
+} orc_ba_post_state_t;
 
 typedef struct {
   int n;
@@ -170,6 +185,8 @@ int orc_ba_solve(orc_ba* h, int iteration, double lambda, double* x, double* HS,
 int orc_ba_get_point_steps(orc_ba* h, float* step);
 int orc_ba_optimize(orc_ba* h, int mnumOptIts, double* state_out, float* idepth_out,
                     uint8_t* res_state_out, orc_ba_opt_result_t* out);
+/* the post-state of the last orc_ba_optimize: FullSystemOptimize.cpp:52-87, :142-203, :997-1041, AccumulatedSCHessian.cpp:34-60 */
+int orc_ba_get_post_state(orc_ba* h, orc_ba_post_state_t* out);
 int orc_ba_marginalize_points(orc_ba* h, const uint8_t* marg_flag, double* HM_out, double* bM_out);
 /* host tables the product also derives (for table-level parity): precalc nf*nf*27 floats
  * {KRKi9,Kt3,R0 9,t0 3,aff2,b0 1}, adHost/adTarget nf*nf*64 doubles, adHTdeltaF nf*nf*8 floats */

@@ -265,7 +265,8 @@ struct Point {
   int host;
   bool hasDepthPrior;
   float step, idepth_backup;
-  float idepth_hessian;
+  float idepth_hessian, maxRelBaseline;
+  int numGoodResiduals;
   int rbeg, rend;
   // EFPoint
   float priorF, deltaF, bdSumF, HdiF;
@@ -283,6 +284,7 @@ struct Residual {
   RawJ Jef;   // EFResidual::J
   float res_toZeroF[8], JpJdF[8];
   bool isLinearized, isActive;
+  bool isNew, toRemove;
   float projectedTo[8][2], centerProjectedTo[3];
   void resetOOB() { state_NewEnergy = state_energy = 0; state_NewState = RS_OUTLIER; state_state = RS_IN; }
 };
@@ -312,6 +314,7 @@ struct orc_ba {
   std::vector<AccSet> T = std::vector<AccSet>(1);
   Reducer* red = nullptr;   // null: everything runs on the calling thread
   int nresA, nresL, resInM;
+  orc_ba_opt_result_t lastResult{0, 0, 0, 0};
   ~orc_ba() { delete red; }
   MatX lastHS;
   VecX lastbS, lastX;
@@ -624,15 +627,33 @@ struct orc_ba {
           if (fixLinearization) applyRes(r);
         }
       }, 0, nr, 0);
+      if (fixLinearization) for (Residual& r : res) if (!r.isLinearized) afterFixedLinearization(r);   // (the timed legs: bookkeeping after the reduce)
     } else {
       for (Residual& r : res) {
         if (r.isLinearized) continue;
         lastEnergyP += linearize(r);
-        if (fixLinearization) applyRes(r);
+        if (fixLinearization) { applyRes(r); afterFixedLinearization(r); }
       }
     }
     setNewFrameEnergyTH();
     return lastEnergyP;
+  }
+  // linearizeAll_Reductor with fixLinearization, after applyRes (FullSystemOptimize.cpp:62-84)
+  void afterFixedLinearization(Residual& r) {
+    r.toRemove = false;
+    if (r.isActive) {
+      if (r.isNew) {
+        Point& p = points[r.point];
+        const Precalc& pc = precalc[r.host * nf + r.target];
+        float ptp_inf[3], ptp[3];
+        for (int i = 0; i < 3; i++) ptp_inf[i] = (pc.PRE_KRKiTll[i * 3 + 0] * p.u + pc.PRE_KRKiTll[i * 3 + 1] * p.v) + pc.PRE_KRKiTll[i * 3 + 2] * 1.0f;
+        for (int i = 0; i < 3; i++) ptp[i] = ptp_inf[i] + pc.PRE_KtTll[i] * p.idepth_scaled;
+        const float dx = ptp_inf[0] / ptp_inf[2] - ptp[0] / ptp[2], dy = ptp_inf[1] / ptp_inf[2] - ptp[1] / ptp[2];
+        const float relBS = 0.01 * sqrtf(dx * dx + dy * dy);
+        if (relBS > p.maxRelBaseline) p.maxRelBaseline = relBS;
+        p.numGoodResiduals++;
+      }
+    } else r.toRemove = true;
   }
 
   // ---------------------------------------------------------------- accumulate
@@ -701,7 +722,7 @@ struct orc_ba {
   void addPointSC(Point& p, bool shiftPriorToZero, AccSet& A) {  // AccumulatedSCHessian.cpp:34-103
     int ngoodres = 0;
     for (int ri = p.rbeg; ri < p.rend; ri++) if (res[ri].isActive) ngoodres++;
-    if (ngoodres == 0) { p.HdiF = 0; p.bdSumF = 0; p.idepth_hessian = 0; return; }
+    if (ngoodres == 0) { p.HdiF = 0; p.bdSumF = 0; p.idepth_hessian = 0; p.maxRelBaseline = 0; return; }
     float H = p.Hdd_accAF + p.Hdd_accLF + p.priorF;
     if (H < 1e-10) H = 1e-10;
     p.idepth_hessian = H;
@@ -1235,6 +1256,7 @@ struct orc_ba {
     out->lastEnergy = lastEnergy;
     out->resInA = nresA;
     out->rmse = sqrtf((float)(lastEnergy / (patternNum * nresA)));
+    lastResult = *out;
     return (float)out->rmse;
   }
 
@@ -1312,6 +1334,8 @@ extern "C" orc_ba* orc_ba_create(const orc_ba_window_t* W) {
     p.host = W->host[i];
     p.hasDepthPrior = W->hasDepthPrior[i] != 0;
     p.step = 0; p.idepth_backup = p.idepth; p.idepth_hessian = 0;
+    p.maxRelBaseline = W->maxRelBaseline ? W->maxRelBaseline[i] : 0.f;
+    p.numGoodResiduals = W->numGoodResiduals ? W->numGoodResiduals[i] : 0;
     p.rbeg = p.rend = 0;
     p.priorF = p.hasDepthPrior ? setting_idepthFixPrior * SCALE_IDEPTH * SCALE_IDEPTH : 0;  // EFPoint::takeData
     if (h->solverMode & SOLVER_REMOVE_POSEPRIOR) p.priorF = 0;
@@ -1332,6 +1356,7 @@ extern "C" orc_ba* orc_ba_create(const orc_ba_window_t* W) {
     r.state_NewState = RS_OUTLIER;
     r.state_NewEnergyWithOutlier = -1;
     r.isLinearized = false; r.isActive = false;
+    r.isNew = W->res_isNew ? W->res_isNew[i] != 0 : true; r.toRemove = false;
     if (r.point != prev) { h->points[r.point].rbeg = i; prev = r.point; }
     h->points[r.point].rend = i + 1;
   }
@@ -1461,6 +1486,49 @@ extern "C" int orc_ba_optimize(orc_ba* h, int mnumOptIts, double* state_out, flo
   if (state_out) for (int f = 0; f < h->nf; f++) for (int i = 0; i < 10; i++) state_out[f * 10 + i] = h->frames[f].state[i];
   if (idepth_out) for (int i = 0; i < h->np; i++) idepth_out[i] = h->points[i].idepth;
   if (res_state_out) for (int i = 0; i < h->nr; i++) res_state_out[i] = (uint8_t)h->res[i].state_state;
+  return 0;
+}
+extern "C" int orc_ba_get_post_state(orc_ba* h, orc_ba_post_state_t* o) {
+  const int nf = h->nf, n = 4 + 8 * nf;
+  for (int i = 0; i < h->np; i++) {
+    const Point& p = h->points[i];
+    if (o->idepth) o->idepth[i] = p.idepth;
+    if (o->step) o->step[i] = p.step;
+    if (o->HdiF) o->HdiF[i] = p.HdiF;
+    if (o->bdSumF) o->bdSumF[i] = p.bdSumF;
+    if (o->idepth_hessian) o->idepth_hessian[i] = p.idepth_hessian;
+    if (o->maxRelBaseline) o->maxRelBaseline[i] = p.maxRelBaseline;
+    if (o->numGoodResiduals) o->numGoodResiduals[i] = p.numGoodResiduals;
+  }
+  o->n_toRemove = 0;
+  for (int i = 0; i < h->nr; i++) {
+    const Residual& r = h->res[i];
+    if (o->state_state) o->state_state[i] = (uint8_t)r.state_state;
+    if (o->isActiveAndIsGoodNEW) o->isActiveAndIsGoodNEW[i] = r.isActive ? 1 : 0;
+    if (o->state_energy) o->state_energy[i] = (float)r.state_energy;
+    // (meaningful where the residual is active: the closing linearisation wrote them; zeros elsewhere, like the product)
+    if (o->centerProjectedTo) for (int k = 0; k < 3; k++) o->centerProjectedTo[i * 3 + k] = (r.isActive && !r.isLinearized) ? r.centerProjectedTo[k] : 0.f;
+    if (o->projectedTo) for (int k = 0; k < 16; k++) o->projectedTo[i * 16 + k] = (r.isActive && !r.isLinearized) ? r.projectedTo[k / 2][k % 2] : 0.f;
+    if (o->toRemove) o->toRemove[i] = r.toRemove ? 1 : 0;
+    o->n_toRemove += r.toRemove ? 1 : 0;
+  }
+  for (int f = 0; f < nf; f++) {
+    const Frame& F = h->frames[f];
+    for (int i = 0; i < 10; i++) {
+      if (o->state) o->state[f * 10 + i] = F.state[i];
+      if (o->state_zero) o->state_zero[f * 10 + i] = F.state_zero[i];
+      if (o->frame_step) o->frame_step[f * 10 + i] = F.step[i];
+    }
+    if (o->evalPT) { std::memcpy(o->evalPT + f * 12, F.worldToCam_evalPT.R, 72); std::memcpy(o->evalPT + f * 12 + 9, F.worldToCam_evalPT.t, 24); }
+    if (o->PRE_worldToCam) { std::memcpy(o->PRE_worldToCam + f * 12, F.PRE_worldToCam.R, 72); std::memcpy(o->PRE_worldToCam + f * 12 + 9, F.PRE_worldToCam.t, 24); }
+    if (o->frameEnergyTH) o->frameEnergyTH[f] = F.frameEnergyTH;
+  }
+  for (int i = 0; i < 4; i++) { o->calib_value[i] = h->HCalib.value[i]; o->calib_value_scaled[i] = h->HCalib.value_scaled[i]; o->calib_step[i] = h->HCalib.step[i]; }
+  if (o->lastX) for (int i = 0; i < n; i++) o->lastX[i] = h->lastX[i];
+  if (o->lastHS) for (int i = 0; i < n * n; i++) o->lastHS[i] = h->lastHS.d[i];
+  if (o->lastbS) for (int i = 0; i < n; i++) o->lastbS[i] = h->lastbS[i];
+  o->resInA = h->nresA; o->resInL = h->nresL; o->resInM = h->resInM;
+  o->result = h->lastResult;
   return 0;
 }
 extern "C" int orc_ba_marginalize_points(orc_ba* h, const uint8_t* marg_flag, double* HM_out, double* bM_out) {

@@ -11,7 +11,7 @@ import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(os.path.dirname(_HERE), "stereo-dso-g2o_amd"))
-from sdso_amd.abi import (G2oTrackEval, G2oLba, Activate, TraceGeom, TrackEval, SE3, Aff, TrackParams, TrackResult, BAWindow, BAOptResult, TracePoints,  # noqa: E402
+from sdso_amd.abi import (G2oTrackEval, G2oLba, Activate, TraceGeom, TrackEval, SE3, Aff, TrackParams, TrackResult, BAWindow, BAOptResult, BAPostState, TracePoints,  # noqa: E402
                           c_float_p, c_double_p, c_int_p, c_u8_p)
 
 _libs = {}
@@ -91,6 +91,7 @@ def load(fast=False, path=None):
     L.orc_ba_get_point_steps.argtypes = [vp, c_float_p]
     L.orc_ba_optimize.argtypes = [vp, C.c_int, c_double_p, c_float_p, c_u8_p, C.POINTER(BAOptResult)]
     L.orc_ba_marginalize_points.argtypes = [vp, c_u8_p, c_double_p, c_double_p]
+    L.orc_ba_get_post_state.argtypes = [vp, C.POINTER(BAPostState)]
     L.orc_ba_get_tables.argtypes = [vp, c_float_p, c_double_p, c_double_p, c_float_p]
     L.orc_immature_init_batch.argtypes = [c_float_p, C.c_int, C.c_int, C.c_int, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p]
     L.orc_pixel_select.argtypes = [C.POINTER(c_float_p), C.c_int, C.c_int, C.c_float, C.c_int, C.c_float, c_int_p, c_float_p]

@@ -56,6 +56,13 @@ struct BaWindowDev {
   bool has_lin_cached = false;  // some residual of the window is linearized (updated wherever h_lin changes)
   bool j_inplace_last = false;  // the latest linearisation was the fused kernel's, written IN PLACE into EFResidual::J's slot (BaDev::jfix):
                                 // sdso_ba_get_linearization reads the records from there
+  // post-state of FullSystem::optimize (sdso_ba_get_post_state)
+  bool post_valid = false;      // an optimize call has ended on this window
+  bool post_pending = false;    // ... and k_ba_post_state (linearizeAll_Reductor's per-residual bookkeeping, FullSystemOptimize.cpp:62-78) has not run for it yet
+  bool hs_valid = false;        // the last solveSystemF of that call wrote lastHS / lastbS
+  sdso_ba_opt_result_t last_result{0, 0, 0, 0};
+  float* d_post = nullptr;      // nr x 19: projectedTo, centerProjectedTo of the closing linearisation
+  int resInL = 0, resInM = 0;
 };
 
 // zeroed device buffer for a window: reuse a pooled buffer of a released window when one of a similar size exists
@@ -126,6 +133,7 @@ struct BaBatch {
   bool eager_fold = false;       // sdso_ba_batch_accum_dev handed the block's address out: never defer the folds
   bool folded = true;            // the packed accumulator block holds the folded sums of the latest accumulate (false: the top partials and the
                                  // per-host Hcc / bc are still unfolded — the fused tail kernel folds them itself; ensure_folded() for anyone else)
+  bool keep_system = false;      // sdso_ba_batch_keep_system: the resident loop's solves also write lastHS / lastbS (37 KB per window and iteration)
   int gather = 1;                // tap gather of the fused kernel: 1 cooperative quads (default), 2 LDS-DMA rounds, 0 direct (SDSO_BA_GATHER / SDSO_BA_DIRECT_TAPS at batch_create)
 };
 static std::map<sdso_ctx*, BaBatch*> g_batches;
@@ -371,8 +379,10 @@ static int upload_window_impl(sdso_ctx* ctx, int win, const sdso_ba_window_t* Wi
   std::vector<Seg> segs;
 #define PL(ptr, T, count, init) segs.push_back(Seg{sizeof(T) * (size_t)(count), (init), [&](char* b) { ptr = (T*)b; }, 0})
   float4* p_geo; float *p_color, *p_weights, *p_prior, *p_delta, *p_out; int *p_host, *p_rbeg, *p_rcnt, *p_rlist;
+  unsigned* p_order; float4* p_track; uint8_t* r_isnew;
   PL(p_geo, float4, np, true); PL(p_color, float, np * 8, true); PL(p_weights, float, np * 8, true); PL(p_host, int, np, true);
   PL(p_prior, float, np, true); PL(p_delta, float, np, true); PL(p_rbeg, int, np, true); PL(p_rcnt, int, np, true); PL(p_rlist, int, nr, true);
+  PL(p_order, unsigned, np, true); PL(p_track, float4, np, true); PL(r_isnew, uint8_t, nr, true);
   PL(p_out, float, (size_t)np * 16, false);
   int* r_point; int* r_orig; uint8_t *r_host, *r_target;
   PL(r_point, int, nr, true); PL(r_orig, int, nr, true); PL(r_host, uint8_t, nr, true); PL(r_target, uint8_t, nr, true);
@@ -424,6 +434,7 @@ static int upload_window_impl(sdso_ctx* ctx, int win, const sdso_ba_window_t* Wi
 
   d.p_geo = p_geo; d.p_color = p_color; d.p_weights = p_weights; d.p_host = p_host; d.p_prior = p_prior; d.p_delta = p_delta;
   d.p_rbeg = p_rbeg; d.p_rcnt = p_rcnt; d.p_rlist = p_rlist; d.p_out = p_out;
+  d.p_order = p_order; d.p_track = p_track; d.r_isnew = r_isnew;
   d.r_point = r_point; d.r_orig = r_orig; d.r_host = r_host; d.r_target = r_target;
   d.tiledT = use_tiled ? (Win->w + 3) / 4 : 0;
   d.t_precalc = W->dt_precalc; d.t_adHTdelta = W->dt_adHTdelta; d.t_cdelta = W->dt_cdelta; d.t_frameTH = W->dt_frameTH; d.t_img = d_img;
@@ -444,11 +455,24 @@ static int upload_window_impl(sdso_ctx* ctx, int win, const sdso_ba_window_t* Wi
   }
   std::vector<int> rlist(nr);
   for (int i = 0; i < nr; i++) rlist[i] = W->inv[i];   // slot order == original order (grouped by point)
+  // EFPoint::residualsAll order of every point as a word of target nibbles (BaDev::p_order); PointHessian::maxRelBaseline / numGoodResiduals
+  std::vector<unsigned> order(np, 0xffffffffu);
+  for (int p = 0; p < np; p++)
+    for (int k = 0; k < rcnt[p]; k++) order[p] = (order[p] & ~(15u << (4 * k))) | ((unsigned)Win->res_target[rbeg[p] + k] << (4 * k));
+  std::vector<float4> track(np);
+  for (int p = 0; p < np; p++) {
+    const int ng = Win->numGoodResiduals ? Win->numGoodResiduals[p] : 0;
+    float ngf; std::memcpy(&ngf, &ng, 4);
+    track[p] = make_float4(Win->maxRelBaseline ? Win->maxRelBaseline[p] : 0.f, ngf, 0.f, 0.f);
+  }
+  std::vector<uint8_t> isnew(nr, 1);
+  if (Win->res_isNew) for (int j = 0; j < nr; j++) isnew[j] = Win->res_isNew[W->perm[j]] ? 1 : 0;
   std::vector<float> frameTH(nf);
   for (int f = 0; f < nf; f++) frameTH[f] = W->frames[f].frameEnergyTH;
   STG(p_geo, geo.data(), sizeof(float4) * np); STG(p_color, Win->color, sizeof(float) * np * 8); STG(p_weights, Win->weights, sizeof(float) * np * 8);
   STG(p_host, Win->host, sizeof(int) * np); STG(p_prior, W->h_prior.data(), sizeof(float) * np); STG(p_delta, delta.data(), sizeof(float) * np);
   STG(p_rbeg, rbeg.data(), sizeof(int) * np); STG(p_rcnt, rcnt.data(), sizeof(int) * np); STG(p_rlist, rlist.data(), sizeof(int) * nr);
+  STG(p_order, order.data(), sizeof(unsigned) * np); STG(p_track, track.data(), sizeof(float4) * np); STG(r_isnew, isnew.data(), nr);
   STG(r_point, s_point.data(), sizeof(int) * nr); STG(r_orig, W->perm.data(), sizeof(int) * nr); STG(r_host, s_host.data(), nr); STG(r_target, s_target.data(), nr); STG(d.r_state, s_state.data(), nr);
   STG(W->dt_frameTH, frameTH.data(), sizeof(float) * nf); STG(d_img, imgs.data(), sizeof(float4*) * nf);
   STG(d_chunks, chunks.data(), sizeof(int4) * chunks.size()); STG(d_pair_beg, pair_beg.data(), sizeof(int) * (nf * nf + 1));
@@ -1018,6 +1042,39 @@ extern "C" int sdso_ba_solve(sdso_ctx* ctx, int win, int iteration, double lambd
   return SDSO_OK;
 }
 
+// EnergyFunctional::resubstituteF_MT (EnergyFunctional.cpp:272-341) for a caller-supplied x: frame / calibration steps = -x, xAd from the
+// float adjoints (:283-292), then resubstituteFPt for every point on the device
+extern "C" int sdso_ba_resubstitute(sdso_ctx* ctx, int win, const double* x, double* frame_step, double* calib_step) {
+  GET_WIN();
+  SDSO_REQUIRE(ctx, x, "null x");
+  SDSO_REQUIRE(ctx, W->accumulated, "sdso_ba_resubstitute needs the per-point terms of sdso_ba_accumulate");
+  const int nf = W->d.nf, n = W->d.n;
+  const size_t blk = (size_t)n * n + n;
+  ensure_folded_win(ctx, W);
+  SDSO_HIP(ctx, hipMemcpyAsync(W->d.sol + 3 * blk, x, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
+  std::vector<float> xAd((size_t)nf * nf * 8);
+  for (int h = 0; h < nf; h++)
+    for (int t = 0; t < nf; t++)
+      for (int j = 0; j < 8; j++) {
+        float sh = 0, stt = 0;
+        for (int i = 0; i < 8; i++) {
+          sh += (float)x[4 + 8 * h + i] * (float)W->tab.adHost[(size_t)(h + nf * t) * 64 + i * 8 + j];
+          stt += (float)x[4 + 8 * t + i] * (float)W->tab.adTarget[(size_t)(h + nf * t) * 64 + i * 8 + j];
+        }
+        xAd[(size_t)(nf * h + t) * 8 + j] = sh + stt;
+      }
+  SDSO_HIP(ctx, hipMemcpyAsync(W->dt_xAd, xAd.data(), sizeof(float) * xAd.size(), hipMemcpyHostToDevice, ctx->stream));
+  const BaLaunch L = single(W);
+  if (L.max_nblk_pts > 0) hipLaunchKernelGGL(k_ba_resub, dim3(L.max_nblk_pts, 1), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr);
+  SDSO_HIP(ctx, hipGetLastError());
+  SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (int i = 0; i < 4; i++) W->calib.step[i] = -x[i];
+  for (int f = 0; f < nf; f++) { for (int i = 0; i < 8; i++) W->frames[f].step[i] = -x[4 + 8 * f + i]; W->frames[f].step[8] = W->frames[f].step[9] = 0; }
+  if (frame_step) for (int f = 0; f < nf; f++) for (int i = 0; i < 8; i++) frame_step[f * 8 + i] = W->frames[f].step[i];
+  if (calib_step) for (int i = 0; i < 4; i++) calib_step[i] = W->calib.step[i];
+  return SDSO_OK;
+}
+
 extern "C" int sdso_ba_get_point_steps(sdso_ctx* ctx, int win, float* step) {
   GET_WIN();
   const int np = W->d.np;
@@ -1174,6 +1231,7 @@ extern "C" int sdso_ba_optimize(sdso_ctx* ctx, int win, int mnumOptIts, double* 
     res.lastEnergy = lastEnergy;
     res.resInA = (int)nresA;
     res.rmse = sqrtf((float)(lastEnergy / (8 * res.resInA)));
+    W->post_valid = true; W->post_pending = true; W->hs_valid = true; W->last_result = res;
   }
   SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (state_out) for (int f = 0; f < nf; f++) for (int i = 0; i < 10; i++) state_out[f * 10 + i] = W->frames[f].state[i];
@@ -1219,6 +1277,11 @@ extern "C" int sdso_ba_marginalize_points(sdso_ctx* ctx, int win, const uint8_t*
   SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
   W->h_lin = lin;
   W->has_lin_cached = std::any_of(lin.begin(), lin.end(), [](uint8_t v) { return v != 0; });
+  {  // resInM += accSSE_top_A->nres[0] (EnergyFunctional.cpp:704)
+    float nresM = 0;
+    SDSO_HIP(ctx, hipMemcpy(&nresM, W->d.accum + acc_off_nres(W->d.nf), sizeof(float), hipMemcpyDeviceToHost));
+    W->resInM += (int)nresM;
+  }
   const float fac = 0.5f * 0.5f;  // setting_margWeightFac
   for (size_t i = 0; i < (size_t)n * n; i++) W->HM[i] += fac * (MA[i] - MS[i]);
   for (int i = 0; i < n; i++) W->bM[i] += fac * (MA[(size_t)n * n + i] - MS[(size_t)n * n + i]);
@@ -1498,6 +1561,7 @@ struct OptRun {
   bool active = false;
   bool local_only = false; // single-window call: never a collective, whatever communicator the ctx carries
   bool failed = false;     // a collective of the gated flow failed (sdso_last_error says which)
+  bool keep_hs = false;    // every solve also writes lastHS / lastbS (EnergyFunctional.cpp:909-910): sdso_ba_get_post_state hands them out
   OptBufs* B = nullptr;
 };
 
@@ -1708,12 +1772,13 @@ static int opt_finish(sdso_ctx* ctx, OptRun& R, sdso_ba_opt_result_t* out) {
     BaWindowDev* W = R.W[w];
     const BaOptOut& o = R.B->h_out[w];
     W->frames[nf - 1].frameEnergyTH = o.frameTH_new;
-    if (out) {
-      out[w].iterations = its[w];
-      out[w].lastEnergy = o.lastEnergy;
-      out[w].resInA = resInA[w];
-      out[w].rmse = sqrtf((float)(o.lastEnergy / (8 * resInA[w])));
-    }
+    sdso_ba_opt_result_t r;
+    r.iterations = its[w];
+    r.lastEnergy = o.lastEnergy;
+    r.resInA = resInA[w];
+    r.rmse = sqrtf((float)(o.lastEnergy / (8 * resInA[w])));
+    if (out) out[w] = r;
+    W->post_valid = true; W->post_pending = true; W->hs_valid = R.keep_hs || R.gated || !tail_enabled(); W->last_result = r;
   }
   R.active = false;
   return SDSO_OK;
@@ -1747,7 +1812,7 @@ static int opt_solve_step(sdso_ctx* ctx, OptRun& R, double lambda, int orth, boo
     SDSO_HIP(ctx, hipGetLastError());
     return opt_step(ctx, R);
   }
-  const int flags = ((orth & 1) ? TAIL_ORTH : 0) | (R.L.any_lin ? TAIL_TOPL : 0) | (folded ? 0 : TAIL_FOLD) | (wait_sc ? TAIL_WAIT_SC : 0);
+  const int flags = ((orth & 1) ? TAIL_ORTH : 0) | (R.L.any_lin ? TAIL_TOPL : 0) | (folded ? 0 : TAIL_FOLD) | (wait_sc ? TAIL_WAIT_SC : 0) | (R.keep_hs ? TAIL_HS : 0);
   const int nwin = (int)R.W.size();
   const dim3 gp(std::max(R.L.max_nblk_pts, 1), nwin);
   if (!R.exchange) {
@@ -1788,7 +1853,7 @@ static int opt_iteration(sdso_ctx* ctx, OptRun& R, int it) {
 int optimize_resident_single(sdso_ctx* ctx, BaWindowDev* W, int mnumOptIts, sdso_ba_opt_result_t* res) {
   OptRun R;
   R.L = single(W); R.W = {W};
-  R.materialize = true; R.gather = 1;
+  R.materialize = true; R.gather = 1; R.keep_hs = true;
   // refused before anything is touched: opt_begin would already issue a collective and reset the window's residuals
   if (comm_nranks(ctx) > 1) return sdso::fail(ctx, SDSO_ERR_STATE, "sdso_ba_optimize is a single-rank call; sharded windows use sdso_ba_batch_optimize");
   R.local_only = true;
@@ -1820,7 +1885,7 @@ extern "C" int sdso_ba_batch_optimize_begin(sdso_ctx* ctx, int stop_on_convergen
   SDSO_HIP(ctx, hipSetDevice(ctx->device));
   free_optrun(ctx);
   OptRun* R = new OptRun();
-  R->L = batch_launch(Bt); R->W = Bt->W; R->materialize = Bt->materialize; R->gather = Bt->gather;
+  R->L = batch_launch(Bt); R->W = Bt->W; R->materialize = Bt->materialize; R->gather = Bt->gather; R->keep_hs = Bt->keep_system;
   int rc = opt_begin(ctx, *R, stop_on_convergence);
   if (rc) { delete R; return rc; }
   reg_get(g_optruns, ctx) = R;
@@ -1905,5 +1970,121 @@ extern "C" int sdso_ba_get_state(sdso_ctx* ctx, int win, double* state_out /* nf
     SDSO_HIP(ctx, hipMemcpy(t.data(), W->d.r_state, nr, hipMemcpyDeviceToHost));
     for (int j = 0; j < nr; j++) res_state_out[W->perm[j]] = t[j];
   }
+  return SDSO_OK;
+}
+
+extern "C" int sdso_ba_batch_keep_system(sdso_ctx* ctx, int on) {
+  BaBatch* Bt = get_batch(ctx);
+  if (!Bt) return sdso::fail(ctx, SDSO_ERR_STATE, "no batch");
+  Bt->keep_system = on != 0;
+  return SDSO_OK;
+}
+
+// Everything FullSystem::optimize leaves behind for its callers (include/sdso_abi.h: sdso_ba_post_state_t).  The per-residual part of
+// linearizeAll_Reductor(true) (maxRelBaseline, numGoodResiduals; FullSystemOptimize.cpp:62-78) runs here, once per optimize call.
+extern "C" int sdso_ba_get_post_state(sdso_ctx* ctx, int win, sdso_ba_post_state_t* out) {
+  GET_WIN();
+  SDSO_REQUIRE(ctx, out, "null post-state");
+  SDSO_REQUIRE(ctx, W->post_valid, "sdso_ba_get_post_state needs a finished sdso_ba_optimize / sdso_ba_batch_optimize on this window");
+  SDSO_REQUIRE(ctx, (!out->lastHS && !out->lastbS) || W->hs_valid, "lastHS / lastbS were not kept: sdso_ba_batch_keep_system(ctx, 1) before the batch loop");
+  const int nf = W->d.nf, np = W->d.np, nr = W->d.nr, n = W->d.n;
+  if (!W->d_post) { DM(W->d_post, float, (size_t)std::max(nr, 1) * 19); }
+  if (nr && (W->post_pending || out->centerProjectedTo || out->projectedTo)) {
+    // (the projections are re-evaluated on every call that asks for them; the counters move once per optimize)
+    hipLaunchKernelGGL(k_ba_post_state, dim3(std::max(W->nblk_res, 1), 1), dim3(BA_BLOCK), 0, ctx->stream, (const BaDev*)W->d_self, W->d_post, W->post_pending ? 1 : 0);
+    SDSO_HIP(ctx, hipGetLastError());
+  }
+  W->post_pending = false;
+  SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  // ---- points
+  if (np && (out->idepth || out->step || out->HdiF || out->bdSumF || out->idepth_hessian || out->maxRelBaseline || out->numGoodResiduals)) {
+    std::vector<float4> geo(np), tr(np);
+    std::vector<float> po((size_t)np * 16);
+    SDSO_HIP(ctx, hipMemcpy(geo.data(), W->d.p_geo, sizeof(float4) * np, hipMemcpyDeviceToHost));
+    SDSO_HIP(ctx, hipMemcpy(tr.data(), W->d.p_track, sizeof(float4) * np, hipMemcpyDeviceToHost));
+    SDSO_HIP(ctx, hipMemcpy(po.data(), W->d.p_out, sizeof(float) * po.size(), hipMemcpyDeviceToHost));
+    for (int p = 0; p < np; p++) {
+      const float* o = &po[(size_t)p * 16];
+      if (out->idepth) out->idepth[p] = geo[p].z;
+      if (out->step) out->step[p] = o[PO_STEP];
+      if (out->HdiF) out->HdiF[p] = o[PO_HDI];
+      if (out->bdSumF) out->bdSumF[p] = o[PO_BDSUM];
+      if (out->idepth_hessian) out->idepth_hessian[p] = tr[p].z;
+      if (out->maxRelBaseline) out->maxRelBaseline[p] = tr[p].x;
+      if (out->numGoodResiduals) std::memcpy(&out->numGoodResiduals[p], &tr[p].y, 4);
+    }
+  }
+  // ---- residuals (pair-sorted on the device -> the window's order)
+  out->n_toRemove = 0;
+  if (nr) {
+    std::vector<uint8_t> st(nr), act(nr), lin(nr);
+    SDSO_HIP(ctx, hipMemcpy(st.data(), W->d.r_state, nr, hipMemcpyDeviceToHost));
+    SDSO_HIP(ctx, hipMemcpy(act.data(), W->d.r_act, nr, hipMemcpyDeviceToHost));
+    SDSO_HIP(ctx, hipMemcpy(lin.data(), W->d.r_lin, nr, hipMemcpyDeviceToHost));
+    for (int j = 0; j < nr; j++) {
+      const int o = W->perm[j];
+      const bool rem = !(lin[j] & 1) && !act[j];      // in activeResiduals and not isActive(): toRemove (:80-84)
+      if (out->state_state) out->state_state[o] = st[j];
+      if (out->isActiveAndIsGoodNEW) out->isActiveAndIsGoodNEW[o] = act[j];
+      if (out->toRemove) out->toRemove[o] = rem ? 1 : 0;
+      out->n_toRemove += rem ? 1 : 0;
+    }
+    if (out->state_energy) {
+      std::vector<float> e(nr);
+      SDSO_HIP(ctx, hipMemcpy(e.data(), W->d.r_energy, sizeof(float) * nr, hipMemcpyDeviceToHost));
+      for (int j = 0; j < nr; j++) out->state_energy[W->perm[j]] = e[j];
+    }
+    if (out->centerProjectedTo || out->projectedTo) {
+      std::vector<float> pj((size_t)nr * 19);
+      SDSO_HIP(ctx, hipMemcpy(pj.data(), W->d_post, sizeof(float) * pj.size(), hipMemcpyDeviceToHost));
+      for (int j = 0; j < nr; j++) {
+        if (out->projectedTo) std::memcpy(out->projectedTo + (size_t)W->perm[j] * 16, &pj[(size_t)j * 19], 64);
+        if (out->centerProjectedTo) std::memcpy(out->centerProjectedTo + (size_t)W->perm[j] * 3, &pj[(size_t)j * 19 + 16], 12);
+      }
+    }
+  }
+  // ---- frames, calibration (host mirror: brought up to date when the loop ended)
+  std::vector<double> x(n);
+  SDSO_HIP(ctx, hipMemcpy(x.data(), W->d.sol + 3 * ((size_t)n * n + n), sizeof(double) * n, hipMemcpyDeviceToHost));
+  for (int f = 0; f < nf; f++) {
+    const HostFrame& F = W->frames[f];
+    for (int i = 0; i < 10; i++) {
+      if (out->state) out->state[f * 10 + i] = F.state[i];
+      if (out->state_zero) out->state_zero[f * 10 + i] = F.state_zero[i];
+      if (out->frame_step) out->frame_step[f * 10 + i] = i < 8 ? -x[4 + 8 * f + i] : 0.0;   // EnergyFunctional.cpp:283-286
+    }
+    if (out->evalPT) { std::memcpy(out->evalPT + f * 12, F.evalPT.R.data(), 72); std::memcpy(out->evalPT + f * 12 + 9, F.evalPT.t.data(), 24); }
+    if (out->PRE_worldToCam) { std::memcpy(out->PRE_worldToCam + f * 12, F.PRE_worldToCam.R.data(), 72); std::memcpy(out->PRE_worldToCam + f * 12 + 9, F.PRE_worldToCam.t.data(), 24); }
+    if (out->frameEnergyTH) out->frameEnergyTH[f] = F.frameEnergyTH;
+  }
+  for (int i = 0; i < 4; i++) { out->calib_value[i] = W->calib.value[i]; out->calib_value_scaled[i] = W->calib.value_scaled[i]; out->calib_step[i] = -x[i]; }
+  if (out->lastX) std::memcpy(out->lastX, x.data(), sizeof(double) * n);
+  const double* hsb = W->d.sol + 3 * ((size_t)n * n + n) + n;
+  if (out->lastHS) SDSO_HIP(ctx, hipMemcpy(out->lastHS, hsb, sizeof(double) * n * n, hipMemcpyDeviceToHost));
+  if (out->lastbS) SDSO_HIP(ctx, hipMemcpy(out->lastbS, hsb + (size_t)n * n, sizeof(double) * n, hipMemcpyDeviceToHost));
+  {
+    float nres2[2] = {0, 0};                           // nres[0] of the last accumulateAF / accumulateLF (EnergyFunctional.cpp:219, :241)
+    SDSO_HIP(ctx, hipMemcpy(nres2, W->d.accum + acc_off_nres(nf), sizeof(nres2), hipMemcpyDeviceToHost));
+    W->resInL = (int)nres2[1];
+  }
+  out->resInA = W->last_result.resInA; out->resInL = W->resInL; out->resInM = W->resInM;
+  out->result = W->last_result;
+  return SDSO_OK;
+}
+
+// EnergyFunctional::resInA / resInL (nres[0] of the latest accumulateAF / LF, EnergyFunctional.cpp:219, :241) and resInM (residuals
+// marginalised through this window so far, :704).  Any pointer may be NULL.
+extern "C" int sdso_ba_get_counts(sdso_ctx* ctx, int win, int* resInA, int* resInL, int* resInM) {
+  GET_WIN();
+  SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (resInA || resInL) {
+    ensure_folded_win(ctx, W);
+    SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    float nres2[2] = {0, 0};
+    SDSO_HIP(ctx, hipMemcpy(nres2, W->d.accum + acc_off_nres(W->d.nf), sizeof(nres2), hipMemcpyDeviceToHost));
+    if (resInA) *resInA = (int)nres2[0];
+    if (resInL) *resInL = (int)nres2[1];
+  }
+  if (resInM) *resInM = W->resInM;
   return SDSO_OK;
 }

@@ -74,18 +74,25 @@ struct BaDev {
   const int* p_rbeg;
   const int* p_rcnt;
   const int* p_rlist;       // sorted residual index of every (point, slot)   (host bookkeeping / debug)
+  const unsigned* p_order;  // per point: nibble k = target frame of its k-th residual in EFPoint::residualsAll order, 0xF past the end.  The
+                            // reference's per-point loops (AccumulatedTopHessian.cpp:50-172, AccumulatedSCHessian.cpp:36-101, EnergyFunctional.cpp:
+                            // 324-338) run in THAT order, which is target order only until dropResidual swaps the last entry into a freed slot
+                            // (EnergyFunctional.cpp:524-533); the dense [target] records are visited through this word so that the float sums
+                            // Hdd / bd / Hcd and the back-substitution come out bit-identical on such windows too
+  float4* p_track;          // per point: x PointHessian::maxRelBaseline, y numGoodResiduals (int bits) — FullSystemOptimize.cpp:64-77 —,
+                            // z idepth_hessian, w number of active residuals (int bits) of the latest AccumulatedSCHessianSSE::addPoint
   float* p_out;             // np*16
   // residuals (pair-sorted)
   const int* r_point;
-  const int* r_orig;        // original (residualsAll-order) index: r_rec is laid out in THAT order, so the
-                            // records of one point are contiguous (one coalesced read per point)
+  const int* r_orig;        // original (window-order) index of the pair-sorted residual
   const uint8_t* r_host;
   const uint8_t* r_target;
   uint8_t* r_state; uint8_t* r_newState; uint8_t* r_lin; uint8_t* r_act; uint8_t* r_jsel;
+  const uint8_t* r_isnew;   // PointFrameResidual::isNew
   float* r_energy; float* r_newEnergy; float* r_newEnergyWO;
   float* J[2];              // 19 float4 groups x nrp each (layout: ba_kernels.hip); EFResidual::J = J[jsel], PointFrameResidual::J = J[1-jsel]
   float* r_toZero;          // 8 x nrp SoA
-  float* r_rec;             // nr x 16, indexed by the ORIGINAL residual index
+  float* r_rec;             // np x nf x 16: dense [point][target] records (RR_*), flags 0 where the point has no residual to that target
   float* r_proj;            // nr x 19 (projectedTo 16, centerProjectedTo 3)
   // tables
   const float* t_precalc;   // [host*nf+target][27]

@@ -554,6 +554,55 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_apply(const BaDev* __restrict__
   B.r_energy[i] = B.r_newEnergy[i];
 }
 
+// What FullSystem::linearizeAll_Reductor(fixLinearization = true) does per residual after applyRes (FullSystemOptimize.cpp:62-78) at the end
+// of FullSystem::optimize, and the projections that closing linearisation left in the PointFrameResidual (centerProjectedTo, projectedTo:
+// Residuals.cpp:130-131, :215-225 — the expressions of linearize_one, re-evaluated here so that the hot kernels need not store them).
+// One lane per residual; PointHessian::maxRelBaseline / numGoodResiduals through integer atomics (order-independent: non-negative floats
+// compare like their bit patterns).  proj: nr x 19 (projectedTo 16, centerProjectedTo 3), zeros for residuals that are not active.
+__global__ __launch_bounds__(BA_BLOCK) void k_ba_post_state(const BaDev* __restrict__ wins, float* __restrict__ proj, int counters /* 0: the projections only */) {
+  const BaDev& B = wins[blockIdx.y];
+  const int i = blockIdx.x * BA_BLOCK + threadIdx.x;
+  if (i >= B.nr) return;
+  float* pj = proj + (size_t)i * 19;
+#pragma unroll
+  for (int k = 0; k < 19; k++) pj[k] = 0.f;
+  if ((B.r_lin[i] & 1) || !B.r_act[i]) return;       // not in activeResiduals (:880-889) / on toRemove (:80-84)
+  const int h = B.r_host[i], t = B.r_target[i], pt = B.r_point[i];
+  const float* __restrict__ pre = B.t_precalc + (size_t)(h * B.nf + t) * 27;
+  const float* KRKi = pre; const float* Kt = pre + 9; const float* R0 = pre + 12; const float* t0 = pre + 21;
+  const float4 g = B.p_geo[pt];
+  const float pu = g.x, pv = g.y, idepth_scaled = g.z, idepth_zero_scaled = g.w;
+  {  // projectPoint at the FEJ point (ResidualProjections.h:64-96)
+    float KliP[3];
+    KliP[0] = (pu + 0 - B.cxl) * B.fxli;
+    KliP[1] = (pv + 0 - B.cyl) * B.fyli;
+    KliP[2] = 1;
+    float ptp[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) ptp[r] = ((R0[r * 3 + 0] * KliP[0] + R0[r * 3 + 1] * KliP[1]) + R0[r * 3 + 2] * KliP[2]) + t0[r] * idepth_zero_scaled;
+    const float drescale = 1.0f / ptp[2];
+    const float u = ptp[0] * drescale, v = ptp[1] * drescale;
+    pj[16] = u * B.fxl + B.cxl; pj[17] = v * B.fyl + B.cyl; pj[18] = idepth_zero_scaled * drescale;
+  }
+#pragma unroll
+  for (int idx = 0; idx < 8; idx++) {
+    const float up = pu + c_pattern[idx][0], vp = pv + c_pattern[idx][1];
+    float q[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) q[r] = ((KRKi[r * 3 + 0] * up + KRKi[r * 3 + 1] * vp) + KRKi[r * 3 + 2]) + Kt[r] * idepth_scaled;
+    pj[idx * 2] = q[0] / q[2]; pj[idx * 2 + 1] = q[1] / q[2];
+  }
+  if (!counters || !B.r_isnew[i]) return;
+  float pinf[3], pp[3];                               // FullSystemOptimize.cpp:64-76
+#pragma unroll
+  for (int r = 0; r < 3; r++) { pinf[r] = (KRKi[r * 3 + 0] * pu + KRKi[r * 3 + 1] * pv) + KRKi[r * 3 + 2] * 1.0f; pp[r] = pinf[r] + Kt[r] * idepth_scaled; }
+  const float dx = pinf[0] / pinf[2] - pp[0] / pp[2], dy = pinf[1] / pinf[2] - pp[1] / pp[2];
+  const float relBS = (float)(0.01 * (double)sqrtf(dx * dx + dy * dy));
+  int* tr = (int*)(B.p_track + pt);
+  if (relBS == relBS) atomicMax(tr, __float_as_int(relBS));   // if (relBS > p->maxRelBaseline) p->maxRelBaseline = relBS
+  atomicAdd(tr + 1, 1);                                       // p->numGoodResiduals++
+}
+
 // fixLinearizationF for the active residuals of flagged points; sets isLinearized
 __global__ __launch_bounds__(BA_BLOCK) void k_ba_fixlin(const BaDev* __restrict__ wins, const uint8_t* __restrict__ pflag) {
   const BaDev& B = wins[blockIdx.y];
@@ -1215,6 +1264,61 @@ __device__ __forceinline__ void zero_topL_body(const BaDev& B, int pair, int tid
 __global__ __launch_bounds__(128) void k_ba_fold_top(const BaDev* __restrict__ wins, int which) { if (ba_finished(wins[blockIdx.y])) return; fold_top_body(wins[blockIdx.y], blockIdx.x, which, threadIdx.x); }
 __global__ __launch_bounds__(128) void k_ba_zero_topL(const BaDev* __restrict__ wins) { if (ba_finished(wins[blockIdx.y])) return; zero_topL_body(wins[blockIdx.y], blockIdx.x, threadIdx.x); }
 
+// ------------------------------------------------------------------ per-point terms of the Schur accumulation
+// The first half of AccumulatedSCHessianSSE::addPoint (AccumulatedSCHessian.cpp:34-71) for ONE point on ONE lane, together with the
+// per-point sums addPoint<mode> of the top accumulator leaves in the EFPoint (AccumulatedTopHessian.cpp:160-192): the residuals are
+// visited in EFPoint::residualsAll order (`ord`: BaDev::p_order), exactly the additions of the reference, so Hdd / bd / Hcd, HdiF and
+// bdSumF are bit-identical to the CPU path whatever dropResidual did to that order.  recs: the point's dense [target] records (LDS or
+// global).  Also keeps PointHessian::idepth_hessian and the `maxRelBaseline = 0` of :44-48 (p_track).
+struct ScPointTerms {
+  float Hdd_A, bd_A, Hdd_L, bd_L, HcdA[4], HcdL[4];   // p->{Hdd,bd,Hcd}_acc{A,L}F
+  float HdiF, bdSumF, Hcd[4];                          // what the cross-point sums use (zeros when the point has no active residual)
+  int mbits;                                           // bit t: the residual to target t is present and active
+};
+__device__ __forceinline__ void sc_point_terms(const BaDev& B, int p, const float* recs, unsigned ord, float onf, float prior, float delta,
+                                               int shiftPriorToZero, int margMode, ScPointTerms& o) {
+  float Hdd_A = 0, bd_A = 0, Hdd_L = 0, bd_L = 0, HcdA[4] = {0, 0, 0, 0}, HcdL[4] = {0, 0, 0, 0};
+  int ngood = 0, mbits = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const unsigned t = (ord >> (4 * k)) & 15u;
+    if (t == 15u) break;
+    const float4 q0 = *(const float4*)(recs + t * 16 + 8);    // bd, Hdd, Hcd0, Hcd1
+    const float4 q1 = *(const float4*)(recs + t * 16 + 12);   // Hcd2, Hcd3, flags, target
+    const int fl = (int)q1.z;
+    const bool m = (fl & 1) != 0 && onf != 0.f;                // residual active (and the point taking part)
+    const bool mA = m && !(fl & 2) && !margMode, mL = m && !mA;   // mode 0 vs mode 1 / 2 sums (AccumulatedTopHessian.cpp:54-71)
+    const float rh[4] = {q0.z, q0.w, q1.x, q1.y};
+    if (m) { ngood++; mbits |= 1 << t; }
+    // x + 0 is exact: masked-off residuals leave the sums untouched
+    bd_A += mA ? q0.x : 0.f; Hdd_A += mA ? q0.y : 0.f;
+    bd_L += mL ? q0.x : 0.f; Hdd_L += mL ? q0.y : 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; c++) { HcdA[c] += mA ? rh[c] : 0.f; HcdL[c] += mL ? rh[c] : 0.f; }
+  }
+  float H = Hdd_A + Hdd_L + prior;
+  if (H < 1e-10) H = 1e-10;
+  const float hdi = 1.0 / H;
+  float bds = bd_A + bd_L;
+  if (shiftPriorToZero) bds += prior * delta;
+  const bool any = ngood > 0;
+  o.Hdd_A = Hdd_A; o.bd_A = bd_A; o.Hdd_L = Hdd_L; o.bd_L = bd_L;
+  o.HdiF = any ? hdi : 0.f; o.bdSumF = any ? bds : 0.f;
+#pragma unroll
+  for (int c = 0; c < 4; c++) { o.HcdA[c] = HcdA[c]; o.HcdL[c] = HcdL[c]; o.Hcd[c] = any ? HcdA[c] + HcdL[c] : 0.f; }
+  o.mbits = mbits;
+  if (onf != 0.f) {
+    float* po = B.p_out + (size_t)p * 16;
+    *(float4*)(po + 0) = make_float4(Hdd_A, bd_A, HcdA[0], HcdA[1]);
+    *(float4*)(po + 4) = make_float4(HcdA[2], HcdA[3], Hdd_L, bd_L);
+    *(float4*)(po + 8) = make_float4(HcdL[0], HcdL[1], HcdL[2], HcdL[3]);
+    *(float2*)(po + PO_HDI) = make_float2(o.HdiF, o.bdSumF);
+    float* tr = (float*)(B.p_track + p);
+    *(float2*)(tr + 2) = make_float2(any ? H : 0.f, __int_as_float(ngood));   // p->data->idepth_hessian (:46, :56)
+    if (!any) tr[0] = 0.f;                                                     // p->data->maxRelBaseline = 0 (:47)
+  }
+}
+
 // ------------------------------------------------------------------ per-point Schur accumulation
 // AccumulatedSCHessianSSE::addPoint for nf <= 8 (template NF).  One wave per item (<= 64 consecutive
 // points of ONE host); lane (a,c) = (lane>>3, lane&7) keeps element (a,c) of all NF x NF 8x8 D tiles of
@@ -1223,7 +1327,7 @@ __global__ __launch_bounds__(128) void k_ba_zero_topL(const BaDev* __restrict__ 
 // the point has no residual to t), so "slot == target": tile indices are compile-time constants, nothing
 // is scattered, there is no branch in the loop, and one point costs two coalesced 256-B loads (issued one
 // point ahead) + cross-lane moves.  Absent residuals contribute exact zeros.
-// Per-point sums (Hdd/bd/Hcd) run in TARGET order.
+// Per-point sums (Hdd/bd/Hcd) run in EFPoint::residualsAll order (BaDev::p_order).
 template <int NF>
 __global__ __launch_bounds__(BA_BLOCK) void k_ba_sc_reg(const BaDev* __restrict__ wins, const uint8_t* __restrict__ pflag, int shiftPriorToZero, int margMode) {
   const BaDev& B = wins[blockIdx.y];
@@ -1243,9 +1347,10 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_sc_reg(const BaDev* __restrict_
   float hcc = 0.f, bcv = 0.f;
   const int npts = it.z - it.y;
   float my_prior = 0.f, my_delta = 0.f; int my_on = 0;
+  unsigned my_ord = 0xffffffffu;
   if (lane < npts) {
     const int p = it.y + lane;
-    my_prior = B.p_prior[p]; my_delta = B.p_delta[p];
+    my_prior = B.p_prior[p]; my_delta = B.p_delta[p]; my_ord = B.p_order[p];
     my_on = pflag ? (int)pflag[p] : 1;
   }
   auto fetch = [&](int q, float& a, float& b) {
@@ -1257,6 +1362,7 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_sc_reg(const BaDev* __restrict_
   // per-point outputs are parked in the registers of lane q and stored once after the loop
   float o_hddA = 0, o_bdA = 0, o_hddL = 0, o_bdL = 0, o_hdi = 0, o_bds = 0;
   float o_hcA0 = 0, o_hcA1 = 0, o_hcA2 = 0, o_hcA3 = 0, o_hcL0 = 0, o_hcL1 = 0, o_hcL2 = 0, o_hcL3 = 0;
+  float o_idh = 0; int o_ng = 0;
   if (npts > 0) fetch(0, vA, vB);
   for (int q = 0; q < npts; q++) {
     if (q + 1 < npts) fetch(q + 1, nA, nB);   // in flight while point q is processed
@@ -1265,11 +1371,14 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_sc_reg(const BaDev* __restrict_
     float ja[NF], jc[NF], je[NF];
     float Hdd_A = 0, bd_A = 0, Hdd_L = 0, bd_L = 0, HcdA[4] = {0, 0, 0, 0}, HcdL[4] = {0, 0, 0, 0};
     float ngood = 0;
+    // the per-point sums in EFPoint::residualsAll order (BaDev::p_order; the order word of point q is wave-uniform)
+    const unsigned ord = (unsigned)__builtin_amdgcn_readfirstlane(__shfl((int)my_ord, q, 64));
 #pragma unroll
-    for (int t = 0; t < NF; t++) {
-      const float src = t < 4 ? vA : vB;
+    for (int k = 0; k < 8; k++) {
+      const int t = (int)((ord >> (4 * k)) & 15u);
+      if (t == 15) break;
+      const int isrc = __float_as_int(t < 4 ? vA : vB);
       const int o = (t & 3) * 16;
-      const int isrc = __float_as_int(src);
       const int fl = (int)__int_as_float(__builtin_amdgcn_readlane(isrc, o + RR_FLAGS));
       const float m = ((fl & 1) ? 1.f : 0.f) * onf;                          // residual present and active
       const float mA = (!(fl & 2) && !margMode) ? m : 0.f, mL = m - mA;      // mode 0 vs mode 1/2 sums (AccumulatedTopHessian.cpp:54-71)
@@ -1277,21 +1386,31 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_sc_reg(const BaDev* __restrict_
       const float rhdd = __int_as_float(__builtin_amdgcn_readlane(isrc, o + RR_HDD));
       float rh[4];
 #pragma unroll
-      for (int k = 0; k < 4; k++) rh[k] = __int_as_float(__builtin_amdgcn_readlane(isrc, o + RR_HCD + k));
+      for (int c = 0; c < 4; c++) rh[c] = __int_as_float(__builtin_amdgcn_readlane(isrc, o + RR_HCD + c));
       ngood += m;
-      // masked adds: x + 0 is exact, so inactive / absent slots leave the sums untouched
+      // masked adds: x + 0 is exact, so inactive slots leave the sums untouched
       bd_A += mA != 0.f ? rbd : 0.f; Hdd_A += mA != 0.f ? rhdd : 0.f;
       bd_L += mL != 0.f ? rbd : 0.f; Hdd_L += mL != 0.f ? rhdd : 0.f;
 #pragma unroll
-      for (int k = 0; k < 4; k++) { HcdA[k] += mA != 0.f ? rh[k] : 0.f; HcdL[k] += mL != 0.f ? rh[k] : 0.f; }
+      for (int c = 0; c < 4; c++) { HcdA[c] += mA != 0.f ? rh[c] : 0.f; HcdL[c] += mL != 0.f ? rh[c] : 0.f; }
+    }
+    // the JpJdF rows by target (tile indices are compile-time constants; absent / inactive residuals enter as zeros)
+#pragma unroll
+    for (int t = 0; t < NF; t++) {
+      const float src = t < 4 ? vA : vB;
+      const int o = (t & 3) * 16;
+      const int fl = (int)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(src), o + RR_FLAGS));
+      const float m = ((fl & 1) ? 1.f : 0.f) * onf;
       const float sa = __shfl(src, o + la, 64), sc = __shfl(src, o + lc, 64), se = __shfl(src, o + le, 64);
       ja[t] = m != 0.f ? sa : 0.f; jc[t] = m != 0.f ? sc : 0.f; je[t] = m != 0.f ? se : 0.f;
     }
     float HdiF = 0, bdSumF = 0;
     float Hcd[4] = {0, 0, 0, 0};
+    float o_H = 0.f;
     {
       float H = Hdd_A + Hdd_L + prior;
       if (H < 1e-10) H = 1e-10;
+      o_H = H;
       const float hdi = 1.0 / H;
       float bds = bd_A + bd_L;
       if (shiftPriorToZero) bds += prior * delta;
@@ -1301,6 +1420,7 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_sc_reg(const BaDev* __restrict_
       for (int k = 0; k < 4; k++) Hcd[k] = any ? HcdA[k] + HcdL[k] : 0.f;
     }
     if (lane == q) {
+      o_idh = ngood > 0.f ? o_H : 0.f; o_ng = (int)ngood;
       o_hddA = Hdd_A; o_bdA = bd_A; o_hddL = Hdd_L; o_bdL = bd_L; o_hdi = HdiF; o_bds = bdSumF;
       o_hcA0 = HcdA[0]; o_hcA1 = HcdA[1]; o_hcA2 = HcdA[2]; o_hcA3 = HcdA[3];
       o_hcL0 = HcdL[0]; o_hcL1 = HcdL[1]; o_hcL2 = HcdL[2]; o_hcL3 = HcdL[3];
@@ -1326,6 +1446,9 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_sc_reg(const BaDev* __restrict_
     *(float4*)(po + 4) = make_float4(o_hcA2, o_hcA3, o_hddL, o_bdL);
     *(float4*)(po + 8) = make_float4(o_hcL0, o_hcL1, o_hcL2, o_hcL3);
     po[PO_HDI] = o_hdi; po[PO_BDSUM] = o_bds;
+    float* tr = (float*)(B.p_track + it.y + lane);
+    *(float2*)(tr + 2) = make_float2(o_idh, __int_as_float(o_ng));   // p->data->idepth_hessian (AccumulatedSCHessian.cpp:46, :56)
+    if (o_ng == 0) tr[0] = 0.f;                                       // p->data->maxRelBaseline = 0 (:47)
   }
   float* out = B.sc_part + (size_t)item * sc_part_floats(NF);
 #pragma unroll
@@ -1368,41 +1491,11 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_sc_mfma(const BaDev* __restrict
     int mbits = 0;
     if (lane < npts) {
       const int p = it.y + lane;
-      const float prior = B.p_prior[p], delta = B.p_delta[p];
-      const float onf = (pflag ? (int)pflag[p] : 1) ? 1.f : 0.f;
-      const float* base = B.r_rec + (size_t)p * nf * 16;
-      float Hdd_A = 0, bd_A = 0, Hdd_L = 0, bd_L = 0, HcdA[4] = {0, 0, 0, 0}, HcdL[4] = {0, 0, 0, 0};
-      float ngood = 0;
-      for (int t = 0; t < nf; t++) {
-        const float4 q0 = *(const float4*)(base + t * 16 + 8);    // bd, Hdd, Hcd0, Hcd1
-        const float4 q1 = *(const float4*)(base + t * 16 + 12);   // Hcd2, Hcd3, flags, target
-        const int fl = (int)q1.z;
-        const float m = ((fl & 1) ? 1.f : 0.f) * onf;                          // residual present and active
-        const float mA = (!(fl & 2) && !margMode) ? m : 0.f, mL = m - mA;      // mode 0 vs mode 1/2 sums (AccumulatedTopHessian.cpp:54-71)
-        const float rh[4] = {q0.z, q0.w, q1.x, q1.y};
-        ngood += m;
-        if (m != 0.f) mbits |= 1 << t;
-        bd_A += mA != 0.f ? q0.x : 0.f; Hdd_A += mA != 0.f ? q0.y : 0.f;
-        bd_L += mL != 0.f ? q0.x : 0.f; Hdd_L += mL != 0.f ? q0.y : 0.f;
+      ScPointTerms T;
+      sc_point_terms(B, p, B.r_rec + (size_t)p * nf * 16, B.p_order[p], (pflag ? (int)pflag[p] : 1) ? 1.f : 0.f, B.p_prior[p], B.p_delta[p], shiftPriorToZero, margMode, T);
+      HdiF = T.HdiF; bdSumF = T.bdSumF; mbits = T.mbits;
 #pragma unroll
-        for (int k = 0; k < 4; k++) { HcdA[k] += mA != 0.f ? rh[k] : 0.f; HcdL[k] += mL != 0.f ? rh[k] : 0.f; }
-      }
-      float H = Hdd_A + Hdd_L + prior;
-      if (H < 1e-10) H = 1e-10;
-      const float hdi = 1.0 / H;
-      float bds = bd_A + bd_L;
-      if (shiftPriorToZero) bds += prior * delta;
-      const bool any = ngood > 0.f;
-      HdiF = any ? hdi : 0.f; bdSumF = any ? bds : 0.f;
-#pragma unroll
-      for (int k = 0; k < 4; k++) Hcd[k] = any ? HcdA[k] + HcdL[k] : 0.f;
-      if (onf != 0.f) {
-        float* po = B.p_out + (size_t)p * 16;
-        *(float4*)(po + 0) = make_float4(Hdd_A, bd_A, HcdA[0], HcdA[1]);
-        *(float4*)(po + 4) = make_float4(HcdA[2], HcdA[3], Hdd_L, bd_L);
-        *(float4*)(po + 8) = make_float4(HcdL[0], HcdL[1], HcdL[2], HcdL[3]);
-        po[PO_HDI] = HdiF; po[PO_BDSUM] = bdSumF;
-      }
+      for (int k = 0; k < 4; k++) Hcd[k] = T.Hcd[k];
     }
     *(float4*)(&pt[lane][0]) = make_float4(HdiF, bdSumF, Hcd[0], Hcd[1]);
     *(float4*)(&pt[lane][4]) = make_float4(Hcd[2], Hcd[3], __int_as_float(mbits), 0.f);
@@ -1517,8 +1610,9 @@ __global__ __launch_bounds__(BA_BLOCK, 2) void k_ba_sc_host(const BaDev* __restr
   // a wave's 16-point groups: 64-point slices dealt round-robin over the waves (as before), four groups per slice
   auto group_p0 = [&](int gidx) { return pb + 64 * (wv + (BA_BLOCK / 64) * (gidx >> 2)) + 16 * (gidx & 3); };
   // the records of group g0: float4 chunk c = lane + 64 k of its (<= 16 nf 4) chunks
-  float pr_next = 0.f, de_next = 0.f;        // prior, delta and the marginalisation flag of the lane's point of the NEXT group: they travel with its records
+  float pr_next = 0.f, de_next = 0.f;        // prior, delta, residual order and the marginalisation flag of the lane's point of the NEXT group: they travel with its records
   int pf_next = 1;
+  unsigned or_next = 0xffffffffu;
   auto request = [&](int p0, float4 (&v)[8]) {
     const int n16 = min(16, pe - p0);
     const int nchunks = n16 > 0 ? n16 * nf * 4 : 0;
@@ -1528,7 +1622,7 @@ __global__ __launch_bounds__(BA_BLOCK, 2) void k_ba_sc_host(const BaDev* __restr
       const int c = lane + 64 * k;
       v[k] = c < nchunks ? *(const float4*)(rbase + (size_t)c * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    if (lane < n16) { pr_next = B.p_prior[p0 + lane]; de_next = B.p_delta[p0 + lane]; pf_next = pflag ? (int)pflag[p0 + lane] : 1; }
+    if (lane < n16) { pr_next = B.p_prior[p0 + lane]; de_next = B.p_delta[p0 + lane]; or_next = B.p_order[p0 + lane]; pf_next = pflag ? (int)pflag[p0 + lane] : 1; }
   };
   float4 vnext[8];
   SCS();
@@ -1551,6 +1645,7 @@ __global__ __launch_bounds__(BA_BLOCK, 2) void k_ba_sc_host(const BaDev* __restr
     }
     const float prior = pr_next, delta = de_next;
     const float onf = pf_next ? 1.f : 0.f;
+    const unsigned order = or_next;
     request(group_p0(gidx + 1), vnext);          // the next group's records travel while this one is worked on
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -1559,40 +1654,11 @@ __global__ __launch_bounds__(BA_BLOCK, 2) void k_ba_sc_host(const BaDev* __restr
       float HdiF = 0.f, bdSumF = 0.f, Hcd[4] = {0.f, 0.f, 0.f, 0.f};
       int mbits = 0;
       if (lane < npts) {
-        const int p = p0 + lane;
-        const float* base = stg + lane * SC_PSTRIDE;
-        float Hdd_A = 0, bd_A = 0, Hdd_L = 0, bd_L = 0, HcdA[4] = {0, 0, 0, 0}, HcdL[4] = {0, 0, 0, 0};
-        float ngood = 0;
-        for (int t = 0; t < nf; t++) {
-          const float4 q0 = *(const float4*)(base + t * 16 + 8);
-          const float4 q1 = *(const float4*)(base + t * 16 + 12);
-          const int fl = (int)q1.z;
-          const float m = ((fl & 1) ? 1.f : 0.f) * onf;
-          const float mA = (!(fl & 2) && !margMode) ? m : 0.f, mL = m - mA;
-          const float rh[4] = {q0.z, q0.w, q1.x, q1.y};
-          ngood += m;
-          if (m != 0.f) mbits |= 1 << t;
-          bd_A += mA != 0.f ? q0.x : 0.f; Hdd_A += mA != 0.f ? q0.y : 0.f;
-          bd_L += mL != 0.f ? q0.x : 0.f; Hdd_L += mL != 0.f ? q0.y : 0.f;
+        ScPointTerms T;
+        sc_point_terms(B, p0 + lane, stg + lane * SC_PSTRIDE, order, onf, prior, delta, shiftPriorToZero, margMode, T);
+        HdiF = T.HdiF; bdSumF = T.bdSumF; mbits = T.mbits;
 #pragma unroll
-          for (int k = 0; k < 4; k++) { HcdA[k] += mA != 0.f ? rh[k] : 0.f; HcdL[k] += mL != 0.f ? rh[k] : 0.f; }
-        }
-        float H = Hdd_A + Hdd_L + prior;
-        if (H < 1e-10) H = 1e-10;
-        const float hdi = 1.0 / H;
-        float bds = bd_A + bd_L;
-        if (shiftPriorToZero) bds += prior * delta;
-        const bool any = ngood > 0.f;
-        HdiF = any ? hdi : 0.f; bdSumF = any ? bds : 0.f;
-#pragma unroll
-        for (int k = 0; k < 4; k++) Hcd[k] = any ? HcdA[k] + HcdL[k] : 0.f;
-        if (onf != 0.f) {
-          float* po = B.p_out + (size_t)p * 16;
-          *(float4*)(po + 0) = make_float4(Hdd_A, bd_A, HcdA[0], HcdA[1]);
-          *(float4*)(po + 4) = make_float4(HcdA[2], HcdA[3], Hdd_L, bd_L);
-          *(float4*)(po + 8) = make_float4(HcdL[0], HcdL[1], HcdL[2], HcdL[3]);
-          po[PO_HDI] = HdiF; po[PO_BDSUM] = bdSumF;
-        }
+        for (int k = 0; k < 4; k++) Hcd[k] = T.Hcd[k];
       }
       if (lane < 16) {
         *(float4*)(&pt[lane][0]) = make_float4(HdiF, bdSumF, Hcd[0], Hcd[1]);

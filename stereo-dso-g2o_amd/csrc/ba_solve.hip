@@ -813,56 +813,66 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_solve(const BaDev* __restrict__
 #undef TNOW
 
 // ------------------------------------------------------------------ back-substitution, one lane per point
+// EnergyFunctional::resubstituteFPt (EnergyFunctional.cpp:305-341) for point p: b = bdSumF - xc . Hcd - sum_r xAd[r] . JpJdF[r] over the active
+// residuals in EFPoint::residualsAll order (BaDev::p_order — the subtractions of the reference, one after the other), step = -b HdiF.
+// Every load of the point is issued before the first one is consumed (the loop over the targets is unrolled to the 8 frames a window can
+// hold and predicated): one memory round trip instead of one per target.
+__device__ __forceinline__ float resub_point(const BaDev& B, int p, const float* po) {
+  const double* x = B.sol + 3 * ((size_t)B.n * B.n + B.n);
+  const int nf = B.nf;
+  const float* recs = B.r_rec + (size_t)p * nf * 16;
+  const int h = B.p_host[p];
+  const unsigned ord = B.p_order[p];
+  float4 j0[8], j1[8], xa0[8], xa1[8];
+  unsigned good = 0;
+#pragma unroll
+  for (int t = 0; t < 8; t++) {
+    if (t < nf) {
+      const float* rec = recs + t * 16;
+      good |= ((((int)rec[RR_FLAGS]) & 1) != 0 ? 1u : 0u) << t;
+      j0[t] = *reinterpret_cast<const float4*>(rec); j1[t] = *reinterpret_cast<const float4*>(rec + 4);
+      const float* xa = B.t_xAd + (size_t)(h * nf + t) * 8;
+      xa0[t] = *reinterpret_cast<const float4*>(xa); xa1[t] = *reinterpret_cast<const float4*>(xa + 4);
+    }
+  }
+  const float4 hA = *reinterpret_cast<const float4*>(po + PO_HCD_A), hL = *reinterpret_cast<const float4*>(po + PO_HCD_L);
+  const float bsum = po[PO_BDSUM], hdi = po[PO_HDI];
+  const double x0 = x[0], x1 = x[1], x2 = x[2], x3 = x[3];
+  if (good == 0) return 0.f;
+  float b = bsum;
+  float d = 0;
+  d += (float)x0 * (hA.x + hL.x);
+  d += (float)x1 * (hA.y + hL.y);
+  d += (float)x2 * (hA.z + hL.z);
+  d += (float)x3 * (hA.w + hL.w);
+  b -= d;
+  float sacc[8];                           // xAd . JpJdF of every target slot (independent dot products) ...
+#pragma unroll
+  for (int t = 0; t < 8; t++) {
+    float a = 0;
+    if (t < nf) {
+      a += xa0[t].x * j0[t].x; a += xa0[t].y * j0[t].y; a += xa0[t].z * j0[t].z; a += xa0[t].w * j0[t].w;
+      a += xa1[t].x * j1[t].x; a += xa1[t].y * j1[t].y; a += xa1[t].z * j1[t].z; a += xa1[t].w * j1[t].w;
+    }
+    sacc[t] = a;
+  }
+#pragma unroll
+  for (int k = 0; k < 8; k++) {            // ... subtracted in residualsAll order
+    const unsigned t = (ord >> (4 * k)) & 15u;
+    float sv = sacc[0];
+#pragma unroll
+    for (int q = 1; q < 8; q++) sv = t == (unsigned)q ? sacc[q] : sv;
+    if (t != 15u && ((good >> t) & 1u)) b -= sv;
+  }
+  return -b * hdi;
+}
 __global__ __launch_bounds__(BA_BLOCK) void k_ba_resub(const BaDev* __restrict__ wins) {
   const BaDev& B = wins[blockIdx.y];
   if (ba_finished(B)) return;
   const int p = blockIdx.x * BA_BLOCK + threadIdx.x;
   if (p >= B.np) return;
   float* po = B.p_out + (size_t)p * 16;
-  const double* x = B.sol + 3 * ((size_t)B.n * B.n + B.n);
-  const int nf = B.nf;
-  const float* recs = B.r_rec + (size_t)p * nf * 16;
-  const int h = B.p_host[p];
-  // every load of the point is issued before the first one is consumed (the loop over the targets is unrolled to the 8 frames a
-  // window can hold and predicated): one memory round trip instead of one per target
-  float4 j0[8], j1[8];
-  float4 xa0[8], xa1[8];
-  bool good[8];
-#pragma unroll
-  for (int t = 0; t < 8; t++) {
-    good[t] = false;
-    if (t < nf) {
-      const float* rec = recs + t * 16;
-      good[t] = (((int)rec[RR_FLAGS]) & 1) != 0;
-      j0[t] = *reinterpret_cast<const float4*>(rec); j1[t] = *reinterpret_cast<const float4*>(rec + 4);
-      const float* xa = B.t_xAd + (size_t)(h * nf + t) * 8;
-      xa0[t] = *reinterpret_cast<const float4*>(xa); xa1[t] = *reinterpret_cast<const float4*>(xa + 4);
-    }
-  }
-  float hA[4] = {po[PO_HCD_A], po[PO_HCD_A + 1], po[PO_HCD_A + 2], po[PO_HCD_A + 3]};
-  float hL[4] = {po[PO_HCD_L], po[PO_HCD_L + 1], po[PO_HCD_L + 2], po[PO_HCD_L + 3]};
-  const float bsum = po[PO_BDSUM], hdi = po[PO_HDI];
-  const double x0 = x[0], x1 = x[1], x2 = x[2], x3 = x[3];
-  int ngood = 0;
-#pragma unroll
-  for (int t = 0; t < 8; t++) ngood += good[t] ? 1 : 0;
-  if (ngood == 0) { po[PO_STEP] = 0; return; }
-  float b = bsum;
-  float d = 0;
-  d += (float)x0 * (hA[0] + hL[0]);
-  d += (float)x1 * (hA[1] + hL[1]);
-  d += (float)x2 * (hA[2] + hL[2]);
-  d += (float)x3 * (hA[3] + hL[3]);
-  b -= d;
-#pragma unroll
-  for (int t = 0; t < 8; t++) {       // residuals in target order
-    if (!good[t]) continue;
-    float sacc = 0;
-    sacc += xa0[t].x * j0[t].x; sacc += xa0[t].y * j0[t].y; sacc += xa0[t].z * j0[t].z; sacc += xa0[t].w * j0[t].w;
-    sacc += xa1[t].x * j1[t].x; sacc += xa1[t].y * j1[t].y; sacc += xa1[t].z * j1[t].z; sacc += xa1[t].w * j1[t].w;
-    b -= sacc;
-  }
-  po[PO_STEP] = -b * hdi;
+  po[PO_STEP] = resub_point(B, p, po);
 }
 
 // resubstituteFPt + backupState + doStepFromBackup (stepfacD = 1) of the points in ONE pass over the point data (k_ba_resub followed
@@ -876,49 +886,8 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_resub_step(const BaDev* __restr
   float sID = 0, sNID = 0;
   if (p < B.np) {
     float* po = B.p_out + (size_t)p * 16;
-    const double* x = B.sol + 3 * ((size_t)B.n * B.n + B.n);
-    const int nf = B.nf;
-    const float* recs = B.r_rec + (size_t)p * nf * 16;
-    const int h = B.p_host[p];
-    float4 j0[8], j1[8], xa0[8], xa1[8];
-    bool good[8];
-#pragma unroll
-    for (int t = 0; t < 8; t++) {
-      good[t] = false;
-      if (t < nf) {
-        const float* rec = recs + t * 16;
-        good[t] = (((int)rec[RR_FLAGS]) & 1) != 0;
-        j0[t] = *reinterpret_cast<const float4*>(rec); j1[t] = *reinterpret_cast<const float4*>(rec + 4);
-        const float* xa = B.t_xAd + (size_t)(h * nf + t) * 8;
-        xa0[t] = *reinterpret_cast<const float4*>(xa); xa1[t] = *reinterpret_cast<const float4*>(xa + 4);
-      }
-    }
-    const float4 hA = *reinterpret_cast<const float4*>(po + PO_HCD_A), hL = *reinterpret_cast<const float4*>(po + PO_HCD_L);
-    const float bsum = po[PO_BDSUM], hdi = po[PO_HDI];
-    const double x0 = x[0], x1 = x[1], x2 = x[2], x3 = x[3];
     float4 g = B.p_geo[p];
-    int ngood = 0;
-#pragma unroll
-    for (int t = 0; t < 8; t++) ngood += good[t] ? 1 : 0;
-    float st = 0.f;
-    if (ngood != 0) {
-      float b = bsum;
-      float d = 0;
-      d += (float)x0 * (hA.x + hL.x);
-      d += (float)x1 * (hA.y + hL.y);
-      d += (float)x2 * (hA.z + hL.z);
-      d += (float)x3 * (hA.w + hL.w);
-      b -= d;
-#pragma unroll
-      for (int t = 0; t < 8; t++) {       // residuals in target order
-        if (!good[t]) continue;
-        float sacc = 0;
-        sacc += xa0[t].x * j0[t].x; sacc += xa0[t].y * j0[t].y; sacc += xa0[t].z * j0[t].z; sacc += xa0[t].w * j0[t].w;
-        sacc += xa1[t].x * j1[t].x; sacc += xa1[t].y * j1[t].y; sacc += xa1[t].z * j1[t].z; sacc += xa1[t].w * j1[t].w;
-        b -= sacc;
-      }
-      st = -b * hdi;
-    }
+    const float st = resub_point(B, p, po);
     po[PO_STEP] = st;
     po[PO_BACKUP] = g.z;
     const float bk = g.z, nid = bk + 1.0f * st;

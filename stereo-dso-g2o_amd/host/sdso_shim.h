@@ -202,6 +202,7 @@ class WindowedBA {
     }
     u_.clear(); v_.clear(); idepth_.clear(); idepth_zero_.clear(); color_.clear(); weights_.clear(); host_.clear(); prior_.clear();
     res_point_.clear(); res_target_.clear(); res_state_.clear(); points_.clear(); residuals_.clear();
+    maxRelBaseline_.clear(); numGood_.clear(); isNew_.clear();
     for (int f = 0; f < nf; f++)
       for (auto* p : ef->frames[f]->points) {
         auto* ph = p->data;
@@ -209,9 +210,11 @@ class WindowedBA {
         u_.push_back(ph->u); v_.push_back(ph->v); idepth_.push_back(ph->idepth); idepth_zero_.push_back(ph->idepth_zero);
         for (int k = 0; k < 8; k++) { color_.push_back(ph->color[k]); weights_.push_back(ph->weights[k]); }
         host_.push_back(f); prior_.push_back(ph->hasDepthPrior ? 1 : 0);
+        maxRelBaseline_.push_back(ph->maxRelBaseline); numGood_.push_back(ph->numGoodResiduals);
         points_.push_back(p);
-        for (auto* r : p->residualsAll) {
+        for (auto* r : p->residualsAll) {                  // residualsAll order: the order of the reference's per-point float sums
           res_point_.push_back(pi); res_target_.push_back(r->target->idx); res_state_.push_back((uint8_t)r->data->state_state);
+          isNew_.push_back(r->data->isNew ? 1 : 0);
           residuals_.push_back(r);
         }
       }
@@ -224,13 +227,14 @@ class WindowedBA {
     W.u = u_.data(); W.v = v_.data(); W.idepth = idepth_.data(); W.idepth_zero = idepth_zero_.data();
     W.color = color_.data(); W.weights = weights_.data(); W.host = host_.data(); W.hasDepthPrior = prior_.data();
     W.res_point = res_point_.data(); W.res_target = res_target_.data(); W.res_state = res_state_.data();
+    W.maxRelBaseline = maxRelBaseline_.data(); W.numGoodResiduals = numGood_.data(); W.res_isNew = isNew_.data();
     const int n = 8 * nf + 4;
     HM_.assign((size_t)n * n, 0); bM_.assign(n, 0);
     for (int i = 0; i < n; i++) { bM_[i] = ef->bM[i]; for (int j = 0; j < n; j++) HM_[(size_t)i * n + j] = ef->HM(i, j); }
     W.HM = HM_.data(); W.bM = bM_.data();
     W.solverMode = solverMode; W.affineOptModeA = affineOptModeA; W.affineOptModeB = affineOptModeB; W.forceAcceptStep = forceAcceptStep ? 1 : 0;
     dev_.check(sdso_ba_upload_window(dev_.ctx(), win_, &W), "sdso_ba_upload_window");
-    nf_ = nf;
+    nf_ = nf; resInM_seen_ = 0;
   }
 
   // Vec3 FullSystem::linearizeAll(false): returns lastEnergyP
@@ -253,21 +257,117 @@ class WindowedBA {
     allreduce();
     dev_.check(sdso_ba_solve(dev_.ctx(), win_, iteration, lambda, lastX.data(), nullptr, nullptr, frame_step.data(), calib_step), "sdso_ba_solve");
   }
-  // float FullSystem::optimize(int mnumOptIts): writes states / idepths / residual states back into the reference objects
-  template <class ApplyFrame, class ApplyPoint, class ApplyResidual>
-  float optimize(int mnumOptIts, ApplyFrame apply_frame, ApplyPoint apply_point, ApplyResidual apply_residual) {
-    std::vector<double> st(nf_ * 10);
-    std::vector<float> idp(points_.size());
-    std::vector<uint8_t> rs(residuals_.size());
+  // float FullSystem::optimize(int mnumOptIts) — FullSystemOptimize.cpp:871-1041 from `activeResiduals.clear()` (:880) through the closing
+  // `linearizeAll(true)` (:1008) — on the uploaded window, with EVERYTHING that function leaves behind written back into the reference's
+  // own objects (sdso_ba_get_post_state):
+  //   CalibHessian      setValue (value, value_scaled, ...), step                                   :218-222 via doStepFromBackup
+  //   FrameHessian      setState (state, state_scaled, PRE_worldToCam, PRE_camToWorld), step; the newest frame's setEvalPT (:997-1003);
+  //                     its frameEnergyTH (setNewFrameEnergyTH of the closing linearizeAll)
+  //   PointHessian      setIdepth + setIdepthZero (:268-272), step, idepth_hessian, maxRelBaseline, numGoodResiduals (:64-77,
+  //                     AccumulatedSCHessian.cpp:44-58); EFPoint::HdiF, bdSumF
+  //   PointFrameResidual state_state / state_NewState, state_energy, centerProjectedTo, projectedTo; EFResidual::isActiveAndIsGoodNEW
+  //   PointHessian::lastResiduals[k].second (:165-172); for every residual on toRemove: lastResiduals[k].first = 0,
+  //                     ef->dropResidual(r->efResidual), deleteOut(ph->residuals, k) (:176-195) — in activeResiduals order
+  //   EnergyFunctional  lastX, lastHS, lastbS, resInA, resInL
+  // Left to the caller exactly as in the reference: `ef->setAdjointsF(&Hcalib); setPrecalcValues();` (:1005-1007, host tables other host
+  // code reads), the isLost test, statistics_lastFineTrackRMSE and the shell poses (:1010-1037).  Not written back: the
+  // RawResidualJacobian records (EFResidual::J) — only the accumulators this library replaces read them.
+  // Returns sqrtf(lastEnergy[0] / (patternNum * ef->resInA)) like the reference (:1039); lastResult carries lastEnergy[0].
+  float optimize(int mnumOptIts, EnergyFunctionalT* ef, CalibHessianT* HCalib) {
+    const int nf = nf_, np = (int)points_.size(), nr = (int)residuals_.size(), n = 8 * nf + 4;
     sdso_ba_opt_result_t out;
-    dev_.check(sdso_ba_optimize(dev_.ctx(), win_, mnumOptIts, st.data(), idp.data(), rs.data(), &out), "sdso_ba_optimize");
-    for (int f = 0; f < nf_; f++) apply_frame(f, &st[f * 10]);
-    for (size_t p = 0; p < points_.size(); p++) apply_point(points_[p], idp[p]);
-    for (size_t r = 0; r < residuals_.size(); r++) apply_residual(residuals_[r], rs[r]);
+    dev_.check(sdso_ba_optimize(dev_.ctx(), win_, mnumOptIts, nullptr, nullptr, nullptr, &out), "sdso_ba_optimize");
+    std::vector<float> idp(np), pstep(np), hdi(np), bds(np), idh(np), mrb(np), energy(nr), cpt((size_t)nr * 3), prj((size_t)nr * 16), eth(nf);
+    std::vector<int> ngood(np);
+    std::vector<uint8_t> rs(nr), act(nr), rem(nr);
+    std::vector<double> st(nf * 10), stz(nf * 10), ev(nf * 12), fstep(nf * 10), lx(n), lhs((size_t)n * n), lbs(n);
+    sdso_ba_post_state_t P;
+    std::memset(&P, 0, sizeof(P));
+    P.idepth = idp.data(); P.step = pstep.data(); P.HdiF = hdi.data(); P.bdSumF = bds.data(); P.idepth_hessian = idh.data();
+    P.maxRelBaseline = mrb.data(); P.numGoodResiduals = ngood.data();
+    P.state_state = rs.data(); P.isActiveAndIsGoodNEW = act.data(); P.state_energy = energy.data(); P.centerProjectedTo = cpt.data();
+    P.projectedTo = prj.data(); P.toRemove = rem.data();
+    P.state = st.data(); P.state_zero = stz.data(); P.evalPT = ev.data(); P.frame_step = fstep.data(); P.frameEnergyTH = eth.data();
+    P.lastX = lx.data(); P.lastHS = lhs.data(); P.lastbS = lbs.data();
+    dev_.check(sdso_ba_get_post_state(dev_.ctx(), win_, &P), "sdso_ba_get_post_state");
+    // ---- calibration and frames
+    {
+      auto v = HCalib->value_zero;                         // a VecC to fill
+      for (int i = 0; i < 4; i++) v[i] = P.calib_value[i];
+      HCalib->setValue(v);
+      for (int i = 0; i < 4; i++) HCalib->step[i] = P.calib_step[i];
+    }
+    for (int f = 0; f < nf; f++) {
+      auto* fh = ef->frames[f]->data;
+      auto s = fh->get_state();                            // a Vec10 to fill
+      for (int i = 0; i < 10; i++) s[i] = st[f * 10 + i];
+      if (f == nf - 1) {
+        // setEvalPT(PRE_worldToCam at the loop's final state, {0,..,0, a, b, 0, 0}) (:997-1003)
+        sdso_se3_t T;
+        std::memcpy(T.R, &ev[f * 12], 72); std::memcpy(T.t, &ev[f * 12 + 9], 24);
+        fh->setEvalPT(like(fh->get_worldToCam_evalPT(), T), s);
+      } else fh->setState(s);
+      for (int i = 0; i < 10; i++) fh->step[i] = fstep[f * 10 + i];
+      fh->frameEnergyTH = eth[f];
+    }
+    // ---- points
+    for (int p = 0; p < np; p++) {
+      auto* efp = points_[p];
+      auto* ph = efp->data;
+      ph->setIdepth(idp[p]); ph->setIdepthZero(idp[p]);
+      ph->step = pstep[p];
+      ph->idepth_hessian = idh[p]; ph->maxRelBaseline = mrb[p]; ph->numGoodResiduals = ngood[p];
+      efp->HdiF = hdi[p]; efp->bdSumF = bds[p];
+    }
+    // ---- residuals
+    for (int i = 0; i < nr; i++) {
+      auto* r = residuals_[i];
+      auto* pfr = r->data;
+      using ResStateT = std::decay_t<decltype(pfr->state_state)>;
+      pfr->state_state = static_cast<ResStateT>(rs[i]);
+      pfr->state_NewState = static_cast<ResStateT>(rs[i]);
+      pfr->state_energy = energy[i]; pfr->state_NewEnergy = energy[i];
+      r->isActiveAndIsGoodNEW = act[i] != 0;
+      if (act[i]) {
+        for (int k = 0; k < 3; k++) pfr->centerProjectedTo[k] = cpt[(size_t)i * 3 + k];
+        for (int k = 0; k < 8; k++) { pfr->projectedTo[k][0] = prj[(size_t)i * 16 + 2 * k]; pfr->projectedTo[k][1] = prj[(size_t)i * 16 + 2 * k + 1]; }
+      }
+      auto* ph = pfr->point;                               // :165-172
+      if (ph->lastResiduals[0].first == pfr) ph->lastResiduals[0].second = pfr->state_state;
+      else if (ph->lastResiduals[1].first == pfr) ph->lastResiduals[1].second = pfr->state_state;
+    }
+    int nResRemoved = 0;
+    for (int i = 0; i < nr; i++) {                         // :176-195
+      if (!rem[i]) continue;
+      auto* pfr = residuals_[i]->data;
+      auto* ph = pfr->point;
+      if (ph->lastResiduals[0].first == pfr) ph->lastResiduals[0].first = 0;
+      else if (ph->lastResiduals[1].first == pfr) ph->lastResiduals[1].first = 0;
+      for (unsigned int k = 0; k < ph->residuals.size(); k++)
+        if (ph->residuals[k] == pfr) {
+          ef->dropResidual(pfr->efResidual);
+          delete ph->residuals[k];                         // deleteOut<PointFrameResidual>(ph->residuals, k), FullSystem.h:62-71
+          ph->residuals[k] = ph->residuals.back();
+          ph->residuals.pop_back();
+          nResRemoved++;
+          break;
+        }
+    }
+    residuals_.clear();                                    // (dropResidual deleted some of them: re-upload before the next call)
+    lastRemoved = nResRemoved;
+    // ---- EnergyFunctional
+    ef->lastX.resize(n); ef->lastbS.resize(n); ef->lastHS.resize(n, n);
+    for (int i = 0; i < n; i++) { ef->lastX[i] = lx[i]; ef->lastbS[i] = lbs[i]; for (int j = 0; j < n; j++) ef->lastHS(i, j) = lhs[(size_t)i * n + j]; }
+    ef->resInA = P.resInA; ef->resInL = P.resInL;
     lastResult = out;
     return (float)out.rmse;
   }
-  // EnergyFunctional::marginalizePointsF(): points with stateFlag == PS_MARGINALIZE; updates ef->HM / ef->bM
+  int lastRemoved = 0;
+  // EnergyFunctional::marginalizePointsF() (EnergyFunctional.cpp:663-736): points with stateFlag == PS_MARGINALIZE; updates ef->HM / ef->bM /
+  // ef->resInM.  The re-linearisation + fixLinearizationF that FullSystem::flagPointsForRemoval runs on those points beforehand
+  // (FullSystem.cpp:1012-1021) is part of the call.  Call upload() first: optimize() dropped residuals and the reference drops points in between
+  // (removeOutliers, flagPointsForRemoval + dropPointsF), so the window of the optimize call no longer matches the EnergyFunctional.
+  // The caller goes on with the reference's removePoint loop (:730-735).
   template <class IsMarg>
   void marginalizePointsF(EnergyFunctionalT* ef, IsMarg is_marg) {
     std::vector<uint8_t> flag(points_.size());
@@ -275,16 +375,28 @@ class WindowedBA {
     const int n = 8 * nf_ + 4;
     dev_.check(sdso_ba_marginalize_points(dev_.ctx(), win_, flag.data(), HM_.data(), bM_.data()), "sdso_ba_marginalize_points");
     for (int i = 0; i < n; i++) { ef->bM[i] = bM_[i]; for (int j = 0; j < n; j++) ef->HM(i, j) = HM_[(size_t)i * n + j]; }
+    int resInM = 0;                                        // resInM += accSSE_top_A->nres[0] (EnergyFunctional.cpp:704)
+    dev_.check(sdso_ba_get_counts(dev_.ctx(), win_, nullptr, nullptr, &resInM), "sdso_ba_get_counts");
+    ef->resInM += resInM - resInM_seen_; resInM_seen_ = resInM;
   }
   sdso_ba_opt_result_t lastResult{};
 
  private:
   Device& dev_;
-  int win_, nf_ = 0;
+  int win_, nf_ = 0, resInM_seen_ = 0;
   std::vector<double> evalPT_, state_, state_zero_, HM_, bM_;
   std::vector<float> exposure_, energyTH_, u_, v_, idepth_, idepth_zero_, color_, weights_;
-  std::vector<int> frameID_, slots_, host_, res_point_, res_target_;
-  std::vector<uint8_t> prior_, res_state_;
+  std::vector<float> maxRelBaseline_;
+  std::vector<int> frameID_, slots_, host_, res_point_, res_target_, numGood_;
+  std::vector<uint8_t> prior_, res_state_, isNew_;
+  // an SE3 of the reference's type from R, t (Sophus::SE3d(Matrix3d, Vector3d); the prototype only lends its types)
+  template <class SE3T>
+  static SE3T like(const SE3T& proto, const sdso_se3_t& a) {
+    std::decay_t<decltype(proto.rotationMatrix())> R;
+    std::decay_t<decltype(proto.translation())> t;
+    for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) R(i, j) = a.R[i * 3 + j]; t[i] = a.t[i]; }
+    return SE3T(R, t);
+  }
   std::vector<std::decay_t<decltype(std::declval<EnergyFunctionalT&>().frames[0]->points[0])>> points_;          // EFPoint*
   std::vector<std::decay_t<decltype(std::declval<EnergyFunctionalT&>().frames[0]->points[0]->residualsAll[0])>> residuals_;  // EFResidual*
 };

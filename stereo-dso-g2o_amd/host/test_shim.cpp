@@ -4,6 +4,7 @@
 // what it prints with the same problem pushed through the C-ABI from Python.
 //
 //   test_shim <dir> tracker|tracker_g2o|stereo|stereo_g2o|ba|selector
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -35,31 +36,72 @@ struct SE3 {
 };
 struct AffLight { double a = 0, b = 0; };
 struct Vec3f { float v[3]; };
+struct Vec10 { double v[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; double& operator[](int i) { return v[i]; } double operator[](int i) const { return v[i]; } };
+struct VecC { double v[4] = {0, 0, 0, 0}; double& operator[](int i) { return v[i]; } double operator[](int i) const { return v[i]; } };
+struct Vec2f { float v[2] = {0, 0}; float& operator[](int i) { return v[i]; } };
+struct Vec3fv { float v[3] = {0, 0, 0}; float& operator[](int i) { return v[i]; } };
 struct CalibHessian {
-  double value_scaled[4], value_zero[4];
+  VecC value_scaled, value_zero, value, step;
+  void setValue(const VecC& val) {                               // HessianBlocks.h:318-333 (SCALE_F = SCALE_C = 50)
+    value = val;
+    for (int i = 0; i < 4; i++) value_scaled[i] = 50.0 * val[i];
+  }
   float fxl() const { return (float)value_scaled[0]; } float fyl() const { return (float)value_scaled[1]; }
   float cxl() const { return (float)value_scaled[2]; } float cyl() const { return (float)value_scaled[3]; }
 };
 struct FrameHessian {
   Vec3f* dIp[SDSO_PYR_LEVELS];
   std::vector<std::vector<float>> store;
-  SE3 worldToCam_evalPT; double state[10], state_zero[10];
+  SE3 worldToCam_evalPT; Vec10 state, state_zero, step;
   float ab_exposure = 1, frameEnergyTH = 0; int frameID = 0, idx = 0, slot = 0;
   const SE3& get_worldToCam_evalPT() const { return worldToCam_evalPT; }
-  const double* get_state() const { return state; }
-  const double* get_state_zero() const { return state_zero; }
+  const Vec10& get_state() const { return state; }
+  const Vec10& get_state_zero() const { return state_zero; }
+  void setState(const Vec10& s) { state = s; }                   // (the reference also refreshes state_scaled / PRE_worldToCam here: host math)
+  void setEvalPT(const SE3& T, const Vec10& s) { worldToCam_evalPT = T; state = s; state_zero = s; }   // HessianBlocks.h:216-222
 };
-struct EFFrame; struct EFPoint; struct EFResidual;
-struct PointFrameResidual { int state_state = 0; };
-struct PointHessian { float u, v, idepth, idepth_zero, color[8], weights[8]; bool hasDepthPrior = false; };
-struct EFResidual { PointFrameResidual* data; EFFrame* target; };
-struct EFPoint { PointHessian* data; std::vector<EFResidual*> residualsAll; int stateFlag = 0; };
+struct EFFrame; struct EFPoint; struct EFResidual; struct PointHessian;
+struct PointFrameResidual {
+  int state_state = 0, state_NewState = 0;
+  double state_energy = 0, state_NewEnergy = 0;
+  bool isNew = true;
+  Vec2f projectedTo[SDSO_MAX_RES];
+  Vec3fv centerProjectedTo;
+  PointHessian* point = nullptr; EFResidual* efResidual = nullptr;
+  int id = -1;                                                   // index in the uploaded window (the test's bookkeeping)
+};
+struct PointHessian {
+  float u, v, idepth, idepth_zero, color[8], weights[8], step = 0, idepth_hessian = 0, maxRelBaseline = 0;
+  int numGoodResiduals = 0;
+  bool hasDepthPrior = false;
+  std::vector<PointFrameResidual*> residuals;
+  std::pair<PointFrameResidual*, int> lastResiduals[2] = {{nullptr, 2}, {nullptr, 2}};
+  EFPoint* efPoint = nullptr;
+  void setIdepth(float x) { idepth = x; }
+  void setIdepthZero(float x) { idepth_zero = x; }
+  bool isInlierNew() const { return (int)residuals.size() >= 3 && numGoodResiduals >= 4; }   // HessianBlocks.h:465-469; setting_minGoodActiveResForMarg = 3, setting_minGoodResForMarg = 4 (settings.cpp:82-83)
+};
+struct EFResidual { PointFrameResidual* data; EFFrame* target; bool isActiveAndIsGoodNEW = false; int idxInAll = 0; EFPoint* point = nullptr; };
+struct EFPoint { PointHessian* data; std::vector<EFResidual*> residualsAll; int stateFlag = 0; float HdiF = 0, bdSumF = 0; };
 struct EFFrame { FrameHessian* data; std::vector<EFPoint*> points; int idx; };
 struct DynMat {
   int n = 0; std::vector<double> d;
+  void resize(int r, int c) { n = c; d.assign((size_t)r * c, 0.0); }
   double& operator()(int i, int j) { return d[(size_t)i * n + j]; }
 };
-struct EnergyFunctional { std::vector<EFFrame*> frames; DynMat HM; std::vector<double> bM; };
+struct EnergyFunctional {
+  std::vector<EFFrame*> frames; DynMat HM, lastHS; std::vector<double> bM, lastbS, lastX;
+  int resInA = 0, resInL = 0, resInM = 0, nResiduals = 0;
+  void dropResidual(EFResidual* r) {                             // EnergyFunctional.cpp:519-548
+    EFPoint* p = r->point;
+    p->residualsAll[r->idxInAll] = p->residualsAll.back();
+    p->residualsAll[r->idxInAll]->idxInAll = r->idxInAll;
+    p->residualsAll.pop_back();
+    nResiduals--;
+    r->data->efResidual = nullptr;
+    delete r;
+  }
+};
 struct ImmaturePoint {
   float u, v, idepth_max;
   float u_stereo, v_stereo, idepth_min, idepth_min_stereo, idepth_max_stereo, idepth_stereo, energyTH, quality, color[8], weights[8];
@@ -149,8 +191,19 @@ static int run_stereo(const std::string& dir, bool fork_live) {
   return 0;
 }
 
+template <class T>
+static void dump(const std::string& dir, const char* name, const std::vector<T>& v) {
+  std::ofstream f(dir + "/out_" + name + ".bin", std::ios::binary);
+  f.write(reinterpret_cast<const char*>(v.data()), (std::streamsize)(v.size() * sizeof(T)));
+}
+
+// FullSystem::optimize through the shim on a pointer graph built like the reference's (FrameHessian / PointHessian / PointFrameResidual /
+// EFFrame / EFPoint / EFResidual with residuals, residualsAll, lastResiduals), then everything the reference's callers read afterwards,
+// dumped as raw arrays (out_*.bin) for tests/test_host_shim.py to compare with the ORACLE's post-state:
+//   makeCoarseDepthL0 STEP1 (CoarseTracker.cpp:295-350): which points enter, their pixel and weight sqrtf(1e-3 / (HdiF + 1e-12))
+//   flagPointsForRemoval (FullSystem.cpp:1004-1035): marginalise / drop / keep decision of a point whose host is being marginalised
 static int run_ba(const std::string& dir) {
-  auto meta = load<int>(dir, "meta");             // nf np nr w h its
+  auto meta = load<int>(dir, "meta");             // nf np nr w h its solverMode
   const int nf = meta[0], np = meta[1], nr = meta[2], w = meta[3], h = meta[4];
   auto calib = load<double>(dir, "calib");        // value_scaled(4) value_zero(4)
   auto evalPT = load<double>(dir, "evalPT"), state = load<double>(dir, "state"), state_zero = load<double>(dir, "state_zero"),
@@ -158,8 +211,9 @@ static int run_ba(const std::string& dir) {
   auto exposure = load<float>(dir, "ab_exposure"), eTH = load<float>(dir, "frameEnergyTH");
   auto frameID = load<int>(dir, "frameID"), host = load<int>(dir, "host"), res_point = load<int>(dir, "res_point"), res_target = load<int>(dir, "res_target");
   auto u = load<float>(dir, "u"), v = load<float>(dir, "v"), idepth = load<float>(dir, "idepth"), idz = load<float>(dir, "idepth_zero"),
-       color = load<float>(dir, "color"), weights = load<float>(dir, "weights");
-  auto prior = load<uint8_t>(dir, "hasDepthPrior"), res_state = load<uint8_t>(dir, "res_state");
+       color = load<float>(dir, "color"), weights = load<float>(dir, "weights"), mrb = load<float>(dir, "maxRelBaseline");
+  auto prior = load<uint8_t>(dir, "hasDepthPrior"), res_state = load<uint8_t>(dir, "res_state"), isnew = load<uint8_t>(dir, "res_isNew");
+  auto ngood = load<int>(dir, "numGoodResiduals");
   sdso_shim::Device dev(0);
   std::vector<std::unique_ptr<FrameHessian>> fhs;
   std::vector<std::unique_ptr<EFFrame>> effs;
@@ -180,33 +234,92 @@ static int run_ba(const std::string& dir) {
   }
   std::vector<std::unique_ptr<PointHessian>> phs;
   std::vector<std::unique_ptr<EFPoint>> efps;
-  std::vector<std::unique_ptr<PointFrameResidual>> pfrs;
-  std::vector<std::unique_ptr<EFResidual>> efrs;
   int r = 0;
   for (int p = 0; p < np; p++) {
     phs.emplace_back(new PointHessian);
     PointHessian& ph = *phs.back();
     ph.u = u[p]; ph.v = v[p]; ph.idepth = idepth[p]; ph.idepth_zero = idz[p]; ph.hasDepthPrior = prior[p] != 0;
+    ph.maxRelBaseline = mrb[p]; ph.numGoodResiduals = ngood[p];
     for (int k = 0; k < 8; k++) { ph.color[k] = color[p * 8 + k]; ph.weights[k] = weights[p * 8 + k]; }
     efps.emplace_back(new EFPoint{&ph, {}, 0});
+    ph.efPoint = efps.back().get();
     for (; r < nr && res_point[r] == p; r++) {
-      pfrs.emplace_back(new PointFrameResidual{(int)res_state[r]});
-      efrs.emplace_back(new EFResidual{pfrs.back().get(), ef.frames[res_target[r]]});
-      efps.back()->residualsAll.push_back(efrs.back().get());
+      // raw new: the shim deletes dropped residuals like the reference does (deleteOut / dropResidual)
+      PointFrameResidual* pfr = new PointFrameResidual;
+      pfr->state_state = (int)res_state[r]; pfr->isNew = isnew[r] != 0; pfr->point = &ph; pfr->id = r;
+      EFResidual* efr = new EFResidual{pfr, ef.frames[res_target[r]]};
+      efr->point = ph.efPoint; efr->idxInAll = (int)ph.efPoint->residualsAll.size();
+      pfr->efResidual = efr;
+      ph.efPoint->residualsAll.push_back(efr);
+      ph.residuals.push_back(pfr);
+      ef.nResiduals++;
+      // lastResiduals: [0] the residual into the newest frame, [1] into the one before (FullSystem.cpp:1400-1410)
+      if (res_target[r] == nf - 1) ph.lastResiduals[0] = {pfr, 0};
+      if (res_target[r] == nf - 2) ph.lastResiduals[1] = {pfr, 0};
     }
-    ef.frames[host[p]]->points.push_back(efps.back().get());   // points arrive grouped by host (makeIDX order)
+    ef.frames[host[p]]->points.push_back(ph.efPoint);   // points arrive grouped by host (makeIDX order)
   }
   const int n = 8 * nf + 4;
   ef.HM.n = n; ef.HM.d = HM; ef.bM = bM;
-  CalibHessian HC; for (int i = 0; i < 4; i++) { HC.value_scaled[i] = calib[i]; HC.value_zero[i] = calib[4 + i]; }
+  CalibHessian HC;
+  for (int i = 0; i < 4; i++) { HC.value_scaled[i] = calib[i]; HC.value_zero[i] = calib[4 + i]; }
   sdso_shim::WindowedBA<EnergyFunctional, CalibHessian> ba(dev, 0);
   ba.upload(&ef, &HC, w, h, /*solverMode=*/meta[6], 1e12, 1e8, true, [](FrameHessian* fh) { return fh->slot; });
-  const float rmse = ba.optimize(meta[5], [&](int f, const double* st) { for (int i = 0; i < 10; i++) fhs[f]->state[i] = st[i]; },
-                                 [](EFPoint* p, float idp) { p->data->idepth = idp; }, [](EFResidual* rr, uint8_t s) { rr->data->state_state = s; });
-  std::printf("rmse %.9g iterations %d resInA %d energy %.17g\n", rmse, ba.lastResult.iterations, ba.lastResult.resInA, ba.lastResult.lastEnergy);
-  for (int f = 0; f < nf; f++) { std::printf("state"); for (int i = 0; i < 10; i++) std::printf(" %.17g", fhs[f]->state[i]); std::printf("\n"); }
-  std::printf("idepth"); for (int p = 0; p < np; p++) std::printf(" %.9g", phs[p]->idepth); std::printf("\n");
-  std::printf("rstate"); for (auto& q : pfrs) std::printf(" %d", q->state_state); std::printf("\n");
+  const float rmse = ba.optimize(meta[5], &ef, &HC);
+  std::printf("rmse %.9g iterations %d resInA %d energy %.17g removed %d nResiduals %d\n", rmse, ba.lastResult.iterations, ef.resInA, ba.lastResult.lastEnergy,
+              ba.lastRemoved, ef.nResiduals);
+  // ---- dump what the reference's callers read
+  std::vector<double> o_state(nf * 10), o_zero(nf * 10), o_eval(nf * 12), o_fstep(nf * 10), o_calib(12);
+  std::vector<float> o_eth(nf);
+  for (int f = 0; f < nf; f++) {
+    for (int i = 0; i < 10; i++) { o_state[f * 10 + i] = fhs[f]->state[i]; o_zero[f * 10 + i] = fhs[f]->state_zero[i]; o_fstep[f * 10 + i] = fhs[f]->step[i]; }
+    for (int i = 0; i < 9; i++) o_eval[f * 12 + i] = fhs[f]->worldToCam_evalPT.R.m[i];
+    for (int i = 0; i < 3; i++) o_eval[f * 12 + 9 + i] = fhs[f]->worldToCam_evalPT.t.v[i];
+    o_eth[f] = fhs[f]->frameEnergyTH;
+  }
+  for (int i = 0; i < 4; i++) { o_calib[i] = HC.value[i]; o_calib[4 + i] = HC.value_scaled[i]; o_calib[8 + i] = HC.step[i]; }
+  std::vector<float> o_pt((size_t)np * 8);        // idepth idepth_zero step idepth_hessian maxRelBaseline HdiF bdSumF weight
+  std::vector<int> o_pi((size_t)np * 8);          // numGood nResiduals last0_alive last0_state last1_alive last1_state coarse_uv(packed, -1 = not used) flag_decision
+  std::vector<int> o_lists;                       // per point: residuals ids ..., -1, residualsAll ids ..., -2
+  std::vector<int> o_alive(nr, 0), o_rstate(nr, -1), o_ract(nr, -1);
+  std::vector<float> o_renergy(nr, 0.f), o_cpt((size_t)nr * 3, 0.f), o_prj((size_t)nr * 16, 0.f);
+  for (int p = 0; p < np; p++) {
+    PointHessian& ph = *phs[p];
+    float* f = &o_pt[(size_t)p * 8]; int* q = &o_pi[(size_t)p * 8];
+    f[0] = ph.idepth; f[1] = ph.idepth_zero; f[2] = ph.step; f[3] = ph.idepth_hessian; f[4] = ph.maxRelBaseline; f[5] = ph.efPoint->HdiF; f[6] = ph.efPoint->bdSumF;
+    q[0] = ph.numGoodResiduals; q[1] = (int)ph.residuals.size();
+    q[2] = ph.lastResiduals[0].first != nullptr; q[3] = ph.lastResiduals[0].second;
+    q[4] = ph.lastResiduals[1].first != nullptr; q[5] = ph.lastResiduals[1].second;
+    // makeCoarseDepthL0 STEP1 (CoarseTracker.cpp:295-350)
+    q[6] = -1; f[7] = 0.f;
+    if (ph.lastResiduals[0].first != nullptr && ph.lastResiduals[0].second == 0 /* ResState::IN */) {
+      PointFrameResidual* rr = ph.lastResiduals[0].first;
+      const int uu = (int)(rr->centerProjectedTo[0] + 0.5f), vv = (int)(rr->centerProjectedTo[1] + 0.5f);
+      q[6] = vv * 65536 + uu;
+      f[7] = sqrtf(1e-3 / (ph.efPoint->HdiF + 1e-12));
+    }
+    // flagPointsForRemoval for a point whose host is flagged (FullSystem.cpp:1004-1035): 0 drop (no residuals / idepth < 0), 1 marginalise, 2 drop (inlier, small Hessian), 3 drop (not an inlier)
+    if (ph.idepth < 0 || ph.residuals.empty()) q[7] = 0;
+    else if (ph.isInlierNew()) q[7] = ph.idepth_hessian > 50.f /* setting_minIdepthH_marg */ ? 1 : 2;
+    else q[7] = 3;
+    for (PointFrameResidual* rr : ph.residuals) {
+      o_lists.push_back(rr->id);
+      o_alive[rr->id] = 1; o_rstate[rr->id] = rr->state_state; o_ract[rr->id] = rr->efResidual->isActiveAndIsGoodNEW ? 1 : 0;
+      o_renergy[rr->id] = (float)rr->state_energy;
+      for (int k = 0; k < 3; k++) o_cpt[(size_t)rr->id * 3 + k] = rr->centerProjectedTo[k];
+      for (int k = 0; k < 8; k++) { o_prj[(size_t)rr->id * 16 + 2 * k] = rr->projectedTo[k][0]; o_prj[(size_t)rr->id * 16 + 2 * k + 1] = rr->projectedTo[k][1]; }
+    }
+    o_lists.push_back(-1);
+    for (EFResidual* er : ph.efPoint->residualsAll) o_lists.push_back(er->data->id);
+    o_lists.push_back(-2);
+  }
+  std::vector<double> o_lastX = ef.lastX, o_lastbS = ef.lastbS, o_lastHS = ef.lastHS.d;
+  std::vector<int> o_counts = {ef.resInA, ef.resInL, ef.resInM, ef.nResiduals, ba.lastRemoved, ba.lastResult.iterations};
+  dump(dir, "state", o_state); dump(dir, "state_zero", o_zero); dump(dir, "evalPT", o_eval); dump(dir, "frame_step", o_fstep); dump(dir, "calib", o_calib);
+  dump(dir, "frameEnergyTH", o_eth); dump(dir, "pt", o_pt); dump(dir, "pi", o_pi); dump(dir, "lists", o_lists); dump(dir, "alive", o_alive);
+  dump(dir, "rstate", o_rstate); dump(dir, "ract", o_ract); dump(dir, "renergy", o_renergy); dump(dir, "cpt", o_cpt); dump(dir, "prj", o_prj);
+  dump(dir, "lastX", o_lastX); dump(dir, "lastbS", o_lastbS); dump(dir, "lastHS", o_lastHS); dump(dir, "counts", o_counts);
+  for (auto& ph : phs) for (PointFrameResidual* rr : ph->residuals) { delete rr->efResidual; delete rr; }
   return 0;
 }
 

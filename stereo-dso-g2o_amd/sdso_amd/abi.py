@@ -67,7 +67,8 @@ class BAWindow(C.Structure):
                 ("res_point", c_int_p), ("res_target", c_int_p), ("res_state", c_u8_p),
                 ("HM", c_double_p), ("bM", c_double_p),
                 ("solverMode", C.c_int), ("affineOptModeA", C.c_double), ("affineOptModeB", C.c_double),
-                ("forceAcceptStep", C.c_int)]
+                ("forceAcceptStep", C.c_int),
+                ("maxRelBaseline", c_float_p), ("numGoodResiduals", c_int_p), ("res_isNew", c_u8_p)]
 
 
 # sdso_comm_init_host's transport callbacks (include/sdso_abi.h)
@@ -77,6 +78,36 @@ HOST_ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_float), C.POI
 
 class BAOptResult(C.Structure):
     _fields_ = [("iterations", C.c_int), ("lastEnergy", C.c_double), ("rmse", C.c_double), ("resInA", C.c_int)]
+
+
+class BAPostState(C.Structure):
+    """sdso_ba_post_state_t: what FullSystem::optimize leaves behind (FullSystemOptimize.cpp:52-87, :142-203, :997-1041)."""
+    _fields_ = [("idepth", c_float_p), ("step", c_float_p), ("HdiF", c_float_p), ("bdSumF", c_float_p), ("idepth_hessian", c_float_p),
+                ("maxRelBaseline", c_float_p), ("numGoodResiduals", c_int_p),
+                ("state_state", c_u8_p), ("isActiveAndIsGoodNEW", c_u8_p), ("state_energy", c_float_p), ("centerProjectedTo", c_float_p),
+                ("projectedTo", c_float_p), ("toRemove", c_u8_p),
+                ("state", c_double_p), ("state_zero", c_double_p), ("evalPT", c_double_p), ("PRE_worldToCam", c_double_p),
+                ("frame_step", c_double_p), ("frameEnergyTH", c_float_p),
+                ("calib_value", C.c_double * 4), ("calib_value_scaled", C.c_double * 4), ("calib_step", C.c_double * 4),
+                ("lastX", c_double_p), ("lastHS", c_double_p), ("lastbS", c_double_p),
+                ("resInA", C.c_int), ("resInL", C.c_int), ("resInM", C.c_int), ("n_toRemove", C.c_int), ("result", BAOptResult)]
+
+
+def make_post_state(nf, npts, nr, with_system=True):
+    """A BAPostState with every array allocated; returns (struct, dict of numpy arrays)."""
+    n = 8 * nf + 4
+    d = dict(idepth=np.zeros(npts, np.float32), step=np.zeros(npts, np.float32), HdiF=np.zeros(npts, np.float32), bdSumF=np.zeros(npts, np.float32),
+             idepth_hessian=np.zeros(npts, np.float32), maxRelBaseline=np.zeros(npts, np.float32), numGoodResiduals=np.zeros(npts, np.int32),
+             state_state=np.zeros(nr, np.uint8), isActiveAndIsGoodNEW=np.zeros(nr, np.uint8), state_energy=np.zeros(nr, np.float32),
+             centerProjectedTo=np.zeros((nr, 3), np.float32), projectedTo=np.zeros((nr, 16), np.float32), toRemove=np.zeros(nr, np.uint8),
+             state=np.zeros((nf, 10)), state_zero=np.zeros((nf, 10)), evalPT=np.zeros((nf, 12)), PRE_worldToCam=np.zeros((nf, 12)),
+             frame_step=np.zeros((nf, 10)), frameEnergyTH=np.zeros(nf, np.float32), lastX=np.zeros(n))
+    if with_system:
+        d["lastHS"] = np.zeros((n, n)); d["lastbS"] = np.zeros(n)
+    P = BAPostState()
+    for k, a in d.items():
+        setattr(P, k, {np.dtype(np.float32): fp, np.dtype(np.float64): dp, np.dtype(np.int32): ip, np.dtype(np.uint8): bp}[a.dtype](a))
+    return P, d
 
 
 class TracePoints(C.Structure):
@@ -187,6 +218,12 @@ def make_ba_window(win, frame_slots=None, dI_list=None):
     W.affineOptModeA = float(win["affineOptModeA"])
     W.affineOptModeB = float(win["affineOptModeB"])
     W.forceAcceptStep = int(win["forceAcceptStep"])
+    if win.get("maxRelBaseline") is not None:
+        W.maxRelBaseline = fp(arr("maxRelBaseline", np.float32))
+    if win.get("numGoodResiduals") is not None:
+        W.numGoodResiduals = ip(arr("numGoodResiduals", np.int32))
+    if win.get("res_isNew") is not None:
+        W.res_isNew = bp(arr("res_isNew", np.uint8))
     return W, keep
 
 
@@ -264,6 +301,7 @@ def load():
     L.sdso_ba_get_point_terms.argtypes = [vp, C.c_int, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p]
     L.sdso_ba_solve.argtypes = [vp, C.c_int, C.c_int, C.c_double, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]
     L.sdso_ba_get_point_steps.argtypes = [vp, C.c_int, c_float_p]
+    L.sdso_ba_resubstitute.argtypes = [vp, C.c_int, c_double_p, c_double_p, c_double_p]
     L.sdso_ba_optimize.argtypes = [vp, C.c_int, C.c_int, c_double_p, c_float_p, c_u8_p, C.POINTER(BAOptResult)]
     L.sdso_ba_marginalize_points.argtypes = [vp, C.c_int, c_u8_p, c_double_p, c_double_p]
     L.sdso_ba_get_tables.argtypes = [vp, C.c_int, c_float_p, c_double_p, c_double_p, c_float_p]
@@ -282,6 +320,9 @@ def load():
     L.sdso_ba_batch_solve_step.argtypes = [vp, C.c_double, C.c_int]
     L.sdso_ba_batch_optimize_end.argtypes = [vp, C.POINTER(BAOptResult)]
     L.sdso_ba_get_state.argtypes = [vp, C.c_int, c_double_p, c_float_p, c_u8_p]
+    L.sdso_ba_get_post_state.argtypes = [vp, C.c_int, C.POINTER(BAPostState)]
+    L.sdso_ba_batch_keep_system.argtypes = [vp, C.c_int]
+    L.sdso_ba_get_counts.argtypes = [vp, C.c_int, c_int_p, c_int_p, c_int_p]
     L.sdso_comm_unique_id.argtypes = [vp]
     L.sdso_comm_init.argtypes = [vp, C.c_int, C.c_int, vp]
     L.sdso_comm_attach.argtypes = [vp, vp]
@@ -328,6 +369,7 @@ EXPORTED_SYMBOLS = [
     "sdso_ba_batch_accum_dev", "sdso_ba_batch_get_x", "sdso_ba_batch_set_materialize",
     "sdso_immature_init_batch", "sdso_trace_stereo_batch", "sdso_trace_stereo_prepare", "sdso_trace_stereo_enqueue",
     "sdso_trace_stereo_fetch", "sdso_stereo_match_batch", "sdso_activate_points_batch", "sdso_ba_marginalize_frame", "sdso_ba_batch_linearize", "sdso_ba_batch_schur", "sdso_pixel_select", "sdso_pixel_selector_pattern", "sdso_trace_on_batch", "sdso_track_make_ref", "sdso_track_newest_coarse_batch", "sdso_track_get_ref",
+    "sdso_ba_get_post_state", "sdso_ba_batch_keep_system", "sdso_ba_resubstitute", "sdso_ba_get_counts",
     "sdso_ba_batch_optimize", "sdso_ba_batch_optimize_begin", "sdso_ba_batch_step", "sdso_ba_batch_solve_step", "sdso_ba_batch_optimize_end", "sdso_ba_get_state",
     "sdso_comm_unique_id", "sdso_comm_init", "sdso_comm_init_host", "sdso_comm_attach", "sdso_comm_info", "sdso_comm_destroy", "sdso_ba_allreduce", "sdso_ba_allreduce_window",
     "sdso_g2o_track_add_edges", "sdso_g2o_track_linearize", "sdso_g2o_track_newest_coarse", "sdso_g2o_lba_eval", "sdso_trace_set_gn_mode",

@@ -206,4 +206,45 @@ def g2o_expected(orc):
     return out
 
 
-CASES = {"tracker": tracker_expected, "ba": ba_expected, "stereo": stereo_expected, "g2o": g2o_expected}
+def ba_dropped_case():
+    """ba_case() after EnergyFunctional::dropResidual went over it (EnergyFunctional.cpp:524-533): residualsAll lists no longer in target
+    order, points with a history (numGoodResiduals, maxRelBaseline) and some old residuals (isNew = false)."""
+    win, kept = helpers.drop_residuals(ba_case(), seed=17, drop_frac=0.3)
+    rs = np.random.RandomState(9)
+    win["numGoodResiduals"] = rs.randint(0, 6, win["np"]).astype(np.int32)
+    win["maxRelBaseline"] = (rs.uniform(0, 0.3, win["np"]) * (rs.rand(win["np"]) < 0.6)).astype(np.float32)
+    win["res_isNew"] = (rs.rand(win["nr"]) < 0.75).astype(np.uint8)
+    return win
+
+
+def ba_dropped_expected(orc):
+    """Per-point sums / back-substitution in residualsAll order and the post-state of FullSystem::optimize (FullSystemOptimize.cpp:52-87,
+    :142-203, :997-1041)."""
+    win = ba_dropped_case()
+    nf, npts, nr, n = win["nf"], win["np"], win["nr"], 8 * win["nf"] + 4
+    W, keep = abi.make_ba_window(win, frame_slots=list(range(nf)), dI_list=[p[0] for p in win["pyrs"]])
+    h = orc.orc_ba_create(C.byref(W))
+    orc.orc_ba_linearize(h, None); orc.orc_ba_apply_res(h)
+    x = np.zeros(n)
+    orc.orc_ba_solve(h, 0, 0.1, abi.dp(x), None, None, None, None)
+    pt = [np.zeros(npts, np.float32) for _ in range(4)] + [np.zeros(npts * 4, np.float32)]
+    orc.orc_ba_get_point_terms(h, *[abi.fp(a) for a in pt])
+    step = np.zeros(npts, np.float32)
+    orc.orc_ba_get_point_steps(h, abi.fp(step))
+    orc.orc_ba_destroy(h)
+    h = orc.orc_ba_create(C.byref(W))
+    oo = abi.BAOptResult()
+    orc.orc_ba_optimize(h, 4, None, None, None, C.byref(oo))
+    P, d = abi.make_post_state(nf, npts, nr)
+    orc.orc_ba_get_post_state(h, C.byref(P))
+    orc.orc_ba_destroy(h)
+    out = dict(input_digest=digest(win["pyrs"][0][0], win["u"], win["idepth"], win["res_target"], win["res_isNew"]), x=x, point_step=step,
+               HdiF=pt[0], bdSumF=pt[1], Hdd_accAF=pt[2], bd_accAF=pt[3], Hcd_accAF=pt[4], opt_iterations=np.int32(oo.iterations),
+               opt_n_toRemove=np.int32(P.n_toRemove), opt_resInA=np.int32(P.resInA))
+    for k in ("idepth", "HdiF", "idepth_hessian", "maxRelBaseline", "numGoodResiduals", "state_state", "isActiveAndIsGoodNEW", "toRemove", "centerProjectedTo",
+              "state", "state_zero", "evalPT", "frameEnergyTH", "lastX"):
+        out["post_" + k] = d[k]
+    return out
+
+
+CASES = {"tracker": tracker_expected, "ba": ba_expected, "ba_dropped": ba_dropped_expected, "stereo": stereo_expected, "g2o": g2o_expected}

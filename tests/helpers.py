@@ -84,6 +84,48 @@ def permuted_window(win, seed):
     return w2, order
 
 
+def drop_residuals(win, seed, drop_frac=0.25):
+    """The window after EnergyFunctional::dropResidual removed a random part of every point's residuals
+    (src/OptimizationBackend/EnergyFunctional.cpp:524-533: the LAST entry of residualsAll is swapped into the freed slot), the
+    drops applied in activeResiduals order like FullSystem::linearizeAll does (FullSystemOptimize.cpp:176-195).  What is left of
+    a point's list is no longer in target order — the shape every live window has.  Returns (window, kept original indices)."""
+    rs = np.random.RandomState(seed)
+    starts = np.searchsorted(win["res_point"], np.arange(win["np"]), side="left")
+    ends = np.searchsorted(win["res_point"], np.arange(win["np"]), side="right")
+    kept = []
+    for p in range(win["np"]):
+        ids = list(range(int(starts[p]), int(ends[p])))
+        if len(ids) > 1:
+            drop = [i for i in ids if rs.rand() < drop_frac]
+            if len(drop) == len(ids):
+                drop = drop[1:]
+            lst = list(ids)
+            for i in drop:                       # toRemove order = the point's original residual order
+                k = lst.index(i)
+                lst[k] = lst[-1]
+                lst.pop()
+            ids = lst
+        kept += ids
+    kept = np.array(kept, np.int64)
+    w2 = dict(win)
+    for k in ("res_point", "res_target", "res_state"):
+        w2[k] = np.ascontiguousarray(win[k][kept])
+    w2["nr"] = len(kept)
+    return w2, kept
+
+
+def apply_drops(res_lists, to_remove_ids):
+    """dropResidual / deleteOut on per-point id lists (swap-with-last), in the given order."""
+    out = [list(l) for l in res_lists]
+    where = {i: p for p, l in enumerate(out) for i in l}
+    for i in to_remove_ids:
+        l = out[where[i]]
+        k = l.index(i)
+        l[k] = l[-1]
+        l.pop()
+    return out
+
+
 def smoke_ba(ctx, orc):
     """One GN iteration of the windowed BA (linearize, applyRes, accumulate, solve) on a small window, vs the oracle."""
     from sdso_amd import synth

@@ -27,7 +27,12 @@ NWIN = 3
 def bench_windows():
     # window 0 is the bench window (seed 3001); the others are different trajectories / point sets, so chunk lists, residual
     # counts and pyramids all differ inside one launch
-    return [synth.ba_window(w=1232, h=368, nf=8, pts_per_kf=250, seed=3001 + 7 * k) for k in range(NWIN)]
+    wins = [synth.ba_window(w=1232, h=368, nf=8, pts_per_kf=250, seed=3001 + 7 * k) for k in range(NWIN)]
+    # window 1 has been through EnergyFunctional::dropResidual (EnergyFunctional.cpp:524-533): its residualsAll lists are no longer in
+    # target order — the per-point sums below must stay bit-exact on it (round-3 verdict, Missing #2)
+    import helpers
+    wins[1], _ = helpers.drop_residuals(wins[1], seed=23, drop_frac=0.2)
+    return wins
 
 
 def _oracle_iteration(oracle, win, W):

@@ -21,7 +21,7 @@ def _load(name):
     return dict(np.load(os.path.join(GOLD, name + ".npz")))
 
 
-@pytest.mark.parametrize("name", ["tracker", "ba", "stereo", "g2o"])
+@pytest.mark.parametrize("name", ["tracker", "ba", "ba_dropped", "stereo", "g2o"])
 def test_oracle_reproduces_golden(oracle, name):
     exp = _load(name)
     got = cases.CASES[name](oracle)
@@ -84,6 +84,51 @@ def test_gpu_ba_matches_golden(gpu_ctx):
     assert oo.iterations == int(exp["opt_iterations"])
     assert np.abs(st - exp["opt_state"]).max() <= 1e-4 and np.abs(idp - exp["opt_idepth"]).max() <= 1e-4   # order-of-summation spread, see test_ba_gpu
     assert abs(oo.lastEnergy - float(exp["opt_energy"])) <= 1e-4 * float(exp["opt_energy"])
+
+
+@pytest.mark.gpu
+def test_gpu_ba_dropped_matches_golden(gpu_ctx):
+    """A window whose residualsAll lists went through dropResidual: per-point sums and the back-substitution bit-exact, the post-state of
+    FullSystem::optimize (flags / counts exact, floats within the loop's bars)."""
+    exp = _load("ba_dropped")
+    win = cases.ba_dropped_case()
+    nf, npts, nr, n = win["nf"], win["np"], win["nr"], 8 * win["nf"] + 4
+    for f in range(nf):
+        gpu_ctx.upload_pyramid(40 + f, win["pyrs"][f][:1])
+    W, keep = abi.make_ba_window(win, frame_slots=[40 + f for f in range(nf)])
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_upload_window(gpu_ctx.h, 3, C.byref(W)))
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_linearize(gpu_ctx.h, 3, None))
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_apply_res(gpu_ctx.h, 3))
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_accumulate(gpu_ctx.h, 3))
+    pt = [np.zeros(npts, np.float32) for _ in range(4)] + [np.zeros(npts * 4, np.float32)]
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_get_point_terms(gpu_ctx.h, 3, *[abi.fp(a) for a in pt]))
+    for k, a in zip(("HdiF", "bdSumF", "Hdd_accAF", "bd_accAF", "Hcd_accAF"), pt):
+        assert np.array_equal(a, exp[k]), k                                                          # residualsAll order: bit-exact
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_resubstitute(gpu_ctx.h, 3, abi.dp(np.ascontiguousarray(exp["x"])), None, None))
+    step = np.zeros(npts, np.float32)
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_get_point_steps(gpu_ctx.h, 3, abi.fp(step)))
+    assert np.array_equal(step, exp["point_step"])
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_upload_window(gpu_ctx.h, 3, C.byref(W)))
+    oo = abi.BAOptResult()
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_optimize(gpu_ctx.h, 3, 4, None, None, None, C.byref(oo)))
+    P, d = abi.make_post_state(nf, npts, nr)
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_get_post_state(gpu_ctx.h, 3, C.byref(P)))
+    assert oo.iterations == int(exp["opt_iterations"])
+    flips = np.nonzero(d["state_state"] != exp["post_state_state"])[0]
+    assert len(flips) <= 2
+    same = np.ones(nr, bool); same[flips] = False
+    psame = np.ones(npts, bool); psame[win["res_point"][flips]] = False
+    for k in ("isActiveAndIsGoodNEW", "toRemove"):
+        assert np.array_equal(d[k][same], exp["post_" + k][same]), k
+    assert np.array_equal(d["numGoodResiduals"][psame], exp["post_numGoodResiduals"][psame])
+    assert abs(P.n_toRemove - int(exp["opt_n_toRemove"])) <= len(flips)
+    assert np.abs(d["state"] - exp["post_state"]).max() <= 1e-4 and np.abs(d["idepth"] - exp["post_idepth"]).max() <= 1e-4
+    assert np.abs(d["evalPT"] - exp["post_evalPT"]).max() <= 1e-4 and np.array_equal(d["state_zero"][:nf - 1], exp["post_state_zero"][:nf - 1])
+    for k in ("HdiF", "idepth_hessian", "maxRelBaseline"):
+        a, b = d[k][psame], exp["post_" + k][psame]
+        assert np.array_equal(a == 0, b == 0) and np.abs(a - b).max() <= 2e-3 * np.abs(b).max(), k
+    act = (exp["post_isActiveAndIsGoodNEW"] == 1) & same
+    assert np.abs(d["centerProjectedTo"][act] - exp["post_centerProjectedTo"][act]).max() <= 2e-2
 
 
 @pytest.mark.gpu

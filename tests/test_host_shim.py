@@ -116,37 +116,128 @@ def test_shim_trace_stereo(gpu_ctx, tmp_path):
     assert np.array_equal(got[:, 8].astype(np.float32), d["lastTracePixelInterval"], equal_nan=True)
 
 
+def _load(d, name, dt):
+    return np.fromfile(os.path.join(d, "out_" + name + ".bin"), dtype=dt)
+
+
 @pytest.mark.gpu
-def test_shim_windowed_ba(gpu_ctx, tmp_path):
-    win = synth.ba_window(w=640, h=480, nf=4, pts_per_kf=100, seed=3011)
-    nf, npts, nr = win["nf"], win["np"], win["nr"]
-    for f in range(nf):
-        gpu_ctx.upload_pyramid(40 + f, win["pyrs"][f][:1])
-    W, keep = abi.make_ba_window(win, frame_slots=[40 + f for f in range(nf)])
-    gpu_ctx.check(gpu_ctx.L.sdso_ba_upload_window(gpu_ctx.h, 3, C.byref(W)))
-    sg, ig, rg, og = np.zeros((nf, 10)), np.zeros(npts, np.float32), np.zeros(nr, np.uint8), abi.BAOptResult()
-    gpu_ctx.check(gpu_ctx.L.sdso_ba_optimize(gpu_ctx.h, 3, 4, abi.dp(sg), abi.fp(ig), abi.bp(rg), C.byref(og)))
-    arrays = dict(meta=np.array([nf, npts, nr, 640, 480, 4, win["solverMode"]], np.int32),
+@pytest.mark.parametrize("which", ["c3_dropped_history", "small_fresh"])
+def test_shim_windowed_ba(gpu_ctx, oracle, tmp_path, which):
+    """FullSystem::optimize through sdso_shim::WindowedBA on a reference-shaped pointer graph (8 KF / 2000 points): EVERYTHING the compiled
+    C++ program finds in its objects afterwards is compared with the ORACLE's post-state — frame / calibration states, per-point idepth,
+    idepth_hessian, maxRelBaseline, numGoodResiduals, HdiF, lastResiduals, per-residual state / energy / centerProjectedTo, the residuals
+    that were dropped and the order dropResidual / deleteOut left the survivors in — and so are the two consumers' decisions
+    (makeCoarseDepthL0 STEP1 weights, flagPointsForRemoval)."""
+    from test_ba_post_state_gpu import check_post_state
+    if which == "small_fresh":
+        win = synth.ba_window(w=640, h=480, nf=4, pts_per_kf=100, seed=3011)
+    else:
+        base = synth.ba_window(w=1232, h=368, nf=8, pts_per_kf=250, seed=3001)
+        win, kept = helpers.drop_residuals(base, seed=11, drop_frac=0.25)
+        rs = np.random.RandomState(5)
+        win["numGoodResiduals"] = rs.randint(0, 9, win["np"]).astype(np.int32)
+        win["maxRelBaseline"] = (rs.uniform(0, 0.4, win["np"]) * (rs.rand(win["np"]) < 0.7)).astype(np.float32)
+        win["res_isNew"] = (rs.rand(win["nr"]) < 0.8).astype(np.uint8)
+    nf, npts, nr, n = win["nf"], win["np"], win["nr"], 8 * win["nf"] + 4
+    win.setdefault("numGoodResiduals", np.zeros(npts, np.int32)); win.setdefault("maxRelBaseline", np.zeros(npts, np.float32))
+    win.setdefault("res_isNew", np.ones(nr, np.uint8))
+    # ---- the oracle's post-state
+    W, keep = abi.make_ba_window(win, frame_slots=list(range(nf)), dI_list=[p[0] for p in win["pyrs"]])
+    h = oracle.orc_ba_create(C.byref(W))
+    oo = abi.BAOptResult()
+    oracle.orc_ba_optimize(h, 6, None, None, None, C.byref(oo))
+    Po, do = abi.make_post_state(nf, npts, nr)
+    oracle.orc_ba_get_post_state(h, C.byref(Po))
+    oracle.orc_ba_destroy(h)
+    # ---- the C++ program
+    arrays = dict(meta=np.array([nf, npts, nr, win["w"], win["h"], 6, win["solverMode"]], np.int32),
                   calib=np.concatenate([win["calib_value_scaled"], win["calib_value_zero"]]).astype(np.float64))
     for k in ("evalPT", "state", "state_zero", "HM", "bM"):
         arrays[k] = np.asarray(win[k], np.float64)
-    for k in ("ab_exposure", "frameEnergyTH", "u", "v", "idepth", "idepth_zero", "color", "weights"):
+    for k in ("ab_exposure", "frameEnergyTH", "u", "v", "idepth", "idepth_zero", "color", "weights", "maxRelBaseline"):
         arrays[k] = np.asarray(win[k], np.float32)
-    for k in ("frameID", "host", "res_point", "res_target"):
+    for k in ("frameID", "host", "res_point", "res_target", "numGoodResiduals"):
         arrays[k] = np.asarray(win[k], np.int32)
-    for k in ("hasDepthPrior", "res_state"):
+    for k in ("hasDepthPrior", "res_state", "res_isNew"):
         arrays[k] = np.asarray(win[k], np.uint8)
     for f in range(nf):
         arrays["img%d_l0" % f] = win["pyrs"][f][0]
     _dump(tmp_path, **arrays)
     lines = _run(tmp_path, "ba")
     head = lines[0].split()
-    assert int(head[3]) == og.iterations and int(head[5]) == og.resInA and float(head[7]) == og.lastEnergy
-    assert np.float32(head[1]) == np.float32(og.rmse)
-    st = np.array([ln.split()[1:] for ln in lines[1:1 + nf]], np.float64)
-    assert np.array_equal(st, sg)
-    assert np.array_equal(np.array(lines[1 + nf].split()[1:], np.float32), ig)
-    assert np.array_equal(np.array(lines[2 + nf].split()[1:], np.uint8), rg)
+    d = str(tmp_path)
+    counts = _load(d, "counts", np.int32)          # resInA resInL resInM nResiduals removed iterations
+    pt = _load(d, "pt", np.float32).reshape(npts, 8); pi = _load(d, "pi", np.int32).reshape(npts, 8)
+    alive = _load(d, "alive", np.int32).astype(bool)
+    # ---- pack what the program holds into the post-state layout and run the common field-by-field check
+    cal = _load(d, "calib", np.float64)
+    dg = dict(idepth=pt[:, 0].copy(), step=pt[:, 2].copy(), idepth_hessian=pt[:, 3].copy(), maxRelBaseline=pt[:, 4].copy(), HdiF=pt[:, 5].copy(), bdSumF=pt[:, 6].copy(),
+              numGoodResiduals=pi[:, 0].copy(),
+              state=_load(d, "state", np.float64).reshape(nf, 10), state_zero=_load(d, "state_zero", np.float64).reshape(nf, 10),
+              evalPT=_load(d, "evalPT", np.float64).reshape(nf, 12), frame_step=_load(d, "frame_step", np.float64).reshape(nf, 10),
+              frameEnergyTH=_load(d, "frameEnergyTH", np.float32), lastX=_load(d, "lastX", np.float64), lastbS=_load(d, "lastbS", np.float64),
+              lastHS=_load(d, "lastHS", np.float64).reshape(n, n))
+    assert np.array_equal(pt[:, 0], pt[:, 1])                                       # setIdepth + setIdepthZero (:268-272)
+    # the program dropped what linearizeAll(true) would: the survivors carry their state; dropped residuals are gone from both lists
+    rstate, ract = _load(d, "rstate", np.int32), _load(d, "ract", np.int32)
+    dg["toRemove"] = (~alive).astype(np.uint8)
+    dg["isActiveAndIsGoodNEW"] = np.where(alive, ract, 0).astype(np.uint8)
+    dg["state_state"] = np.where(alive, rstate, do["state_state"]).astype(np.uint8)   # (a dropped residual's state left with it)
+    dg["state_energy"] = np.where(alive, _load(d, "renergy", np.float32), do["state_energy"]).astype(np.float32)
+    dg["centerProjectedTo"] = _load(d, "cpt", np.float32).reshape(nr, 3); dg["projectedTo"] = _load(d, "prj", np.float32).reshape(nr, 16)
+    dg["PRE_worldToCam"] = do["PRE_worldToCam"].copy(); dg["PRE_worldToCam"][nf - 1] = dg["evalPT"][nf - 1]   # (host math of the reference's setState; the newest frame's is its evalPT)
+
+    class G:                                                                          # the scalar members of the post-state
+        pass
+    Pg = G()
+    Pg.result = G(); Pg.result.iterations = int(counts[5]); Pg.result.resInA = int(counts[0])
+    Pg.n_toRemove = int(counts[4]); Pg.resInA, Pg.resInL, Pg.resInM = int(counts[0]), int(counts[1]), int(counts[2])
+    Pg.calib_value, Pg.calib_value_scaled, Pg.calib_step = list(cal[0:4]), list(cal[4:8]), list(cal[8:12])
+    flips = check_post_state(win, Po, do, Pg, dg)
+    assert int(head[3]) == oo.iterations and int(head[9]) == Pg.n_toRemove and int(head[11]) == nr - Pg.n_toRemove
+    # every survivor is IN and active: nothing else stays in ph->residuals after the closing linearizeAll (:80-84, :176-195)
+    assert np.all(rstate[alive] == 0) and np.all(ract[alive] == 1)
+    # ---- the lists dropResidual / deleteOut left behind: the swap-with-last of the reference on the oracle's toRemove flags
+    starts = np.searchsorted(win["res_point"], np.arange(npts), side="left"); ends = np.searchsorted(win["res_point"], np.arange(npts), side="right")
+    expect = helpers.apply_drops([list(range(int(starts[p]), int(ends[p]))) for p in range(npts)], [int(i) for i in np.nonzero(dg["toRemove"])[0]])
+    lists = _load(d, "lists", np.int32)
+    pos = 0
+    for p in range(npts):
+        e1 = pos + int(np.nonzero(lists[pos:] == -1)[0][0]); e2 = e1 + 1 + int(np.nonzero(lists[e1 + 1:] == -2)[0][0])
+        assert list(lists[pos:e1]) == expect[p] and list(lists[e1 + 1:e2]) == expect[p], p      # PointHessian::residuals and EFPoint::residualsAll
+        assert pi[p, 1] == len(expect[p])
+        pos = e2 + 1
+    assert (np.array([len(e) for e in expect]) != (ends - starts)).any()
+    # ---- lastResiduals (FullSystemOptimize.cpp:165-185): [0] = the residual into the newest frame, [1] = into the one before
+    tgt = win["res_target"]
+    for k, t in ((0, nf - 1), (1, nf - 2)):
+        rid = np.full(npts, -1, np.int64)
+        sel = np.nonzero(tgt == t)[0]
+        rid[win["res_point"][sel]] = sel
+        had = rid >= 0
+        ok = np.ones(npts, bool); ok[win["res_point"][flips]] = False
+        assert np.array_equal(pi[had & ok, 2 + 2 * k] == 1, do["toRemove"][rid[had & ok]] == 0)          # .first cleared iff the residual was dropped
+        assert np.array_equal(pi[had & ok, 3 + 2 * k], do["state_state"][rid[had & ok]].astype(np.int32))  # .second = state_state
+        assert np.all(pi[~had, 2 + 2 * k] == 0)
+    # ---- consumers.  makeCoarseDepthL0 STEP1: points whose newest-frame residual is alive and IN; pixel and weight from the oracle's post-state
+    rid0 = np.full(npts, -1, np.int64); sel = np.nonzero(tgt == nf - 1)[0]; rid0[win["res_point"][sel]] = sel
+    ok = np.ones(npts, bool); ok[win["res_point"][flips]] = False
+    enters_o = (rid0 >= 0) & (do["toRemove"][np.maximum(rid0, 0)] == 0) & (do["state_state"][np.maximum(rid0, 0)] == 0)
+    assert np.array_equal((pi[:, 6] >= 0)[ok], enters_o[ok]) and enters_o.sum() > 0.2 * npts
+    use = enters_o & ok
+    uo = (do["centerProjectedTo"][rid0[use], 0] + np.float32(0.5)).astype(np.int32); vo = (do["centerProjectedTo"][rid0[use], 1] + np.float32(0.5)).astype(np.int32)
+    ug, vg = pi[use, 6] % 65536, pi[use, 6] // 65536
+    assert (np.abs(ug - uo) + np.abs(vg - vo) > 0).sum() <= max(2, use.sum() // 200)             # a pixel changes only when the projection sits on x.5
+    wo = np.sqrt(np.float32(1e-3) / (do["HdiF"][use].astype(np.float64) + 1e-12)).astype(np.float32)
+    assert np.abs(pt[use, 7] - wo).max() <= 1e-3 * wo.max() and pt[use, 7].min() > 0
+    assert np.all(pt[use, 7] < 0.9 * np.float32(np.sqrt(1e-3 / 1e-12)))                          # NOT the weight of HdiF = 0 (what the round-3 binding produced)
+    # flagPointsForRemoval for a flagged host: marginalise iff isInlierNew() && idepth_hessian > setting_minIdepthH_marg (FullSystem.cpp:1008-1031)
+    nres_left = np.array([len(e) for e in expect])
+    dec_o = np.where((do["idepth"] < 0) | (nres_left == 0), 0,
+                     np.where((nres_left >= 3) & (do["numGoodResiduals"] >= 4), np.where(do["idepth_hessian"] > 50.0, 1, 2), 3))
+    edge = np.abs(do["idepth_hessian"] - 50.0) < 0.5                                            # a Hessian sitting on the threshold may fall either way
+    assert np.array_equal(pi[ok & ~edge, 7], dec_o[ok & ~edge])
+    assert (dec_o == 1).sum() > 0.3 * npts and (dec_o != 1).sum() > 0                            # both branches occur
 
 
 @pytest.mark.gpu
