@@ -237,7 +237,8 @@ def test_shim_windowed_ba(gpu_ctx, oracle, tmp_path, which):
                      np.where((nres_left >= 3) & (do["numGoodResiduals"] >= 4), np.where(do["idepth_hessian"] > 50.0, 1, 2), 3))
     edge = np.abs(do["idepth_hessian"] - 50.0) < 0.5                                            # a Hessian sitting on the threshold may fall either way
     assert np.array_equal(pi[ok & ~edge, 7], dec_o[ok & ~edge])
-    assert (dec_o == 1).sum() > 0.3 * npts and (dec_o != 1).sum() > 0                            # both branches occur
+    if which != "small_fresh":                                                                  # (a fresh 4-frame window has no point with 4 good residuals yet)
+        assert (dec_o == 1).sum() > 0.3 * npts and (dec_o != 1).sum() > 0                        # both branches occur
 
 
 @pytest.mark.gpu
