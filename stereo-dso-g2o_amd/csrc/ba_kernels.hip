@@ -1593,18 +1593,23 @@ __global__ __launch_bounds__(BA_BLOCK, 2) void k_ba_sc_host(const BaDev* __restr
   // tree lie over the same memory.
   constexpr int SC_PSTRIDE = 160;
   constexpr int SC_STAGE = 16 * SC_PSTRIDE;                  // floats per wave
-  constexpr int SC_LDS = (BA_BLOCK / 64) * SC_STAGE > 2 * 21 * 256 ? (BA_BLOCK / 64) * SC_STAGE : 2 * 21 * 256;
+  // D' = Z^T diag(HdiF) Z is symmetric: only the tiles on and above the diagonal of its 4 x 4 grid over the JpJdF columns are accumulated
+  // (10 instead of 16; + 4 tiles of the Hcd / bdSumF columns + 1 corner = 15 tiles, 60 accumulator registers instead of 84), and the bins
+  // below the diagonal are written as their mirror images.  That also makes accD(i,j,k) == accD(i,k,j)^T hold EXACTLY, as it does in the
+  // reference (AccumulatorXX::update multiplies a_i * b_j * w: the same product for both, MatrixAccumulators.h:31-80) — two MFMA tiles
+  // (HdiF z_a) z_b and (HdiF z_b) z_a round differently, and the stitch relies on that symmetry (ba_tail.hip: S2 = S1^T).
+  constexpr int SC_NT = 15;                                  // tile t of pair (a <= b): sc_ut(a, b); 10 + a: column tile 4 of row a; 14: the corner
+  constexpr int SC_LDS = (BA_BLOCK / 64) * SC_STAGE > 2 * SC_NT * 256 ? (BA_BLOCK / 64) * SC_STAGE : 2 * SC_NT * 256;
   __shared__ __align__(16) float stage_all[SC_LDS];
-  float (*tiles)[21 * 256] = reinterpret_cast<float (*)[21 * 256]>(stage_all);   // two waves' worth of accumulator tiles
+  float (*tiles)[SC_NT * 256] = reinterpret_cast<float (*)[SC_NT * 256]>(stage_all);   // two waves' worth of accumulator tiles
   float* stg = stage_all + wv * SC_STAGE;
   float (*pt)[8] = pt_all[wv];
   const int ib = B.host_item_beg[h], ie = B.host_item_beg[h + 1];
   const int pb = ib < ie ? B.items[ib].y : 0, pe = ib < ie ? B.items[ie - 1].z : 0;
-  te_f4 acc[4][5], acc44 = {0.f, 0.f, 0.f, 0.f};
+  te_f4 acc[SC_NT];
 #pragma unroll
-  for (int a = 0; a < 4; a++)
-#pragma unroll
-    for (int b = 0; b < 5; b++) acc[a][b] = (te_f4){0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < SC_NT; t++) acc[t] = (te_f4){0.f, 0.f, 0.f, 0.f};
+  auto sc_ut = [](int a, int b) { return a * 4 - (a * (a - 1)) / 2 + (b - a); };   // index of the upper tile (a <= b): 0..9
   const int ci = lane & 15, kq = lane >> 4;
   const int tsub = ci >> 3, asub = ci & 7;
   // a wave's 16-point groups: 64-point slices dealt round-robin over the waves (as before), four groups per slice
@@ -1693,10 +1698,12 @@ __global__ __launch_bounds__(BA_BLOCK, 2) void k_ba_sc_host(const BaDev* __restr
 #pragma unroll
         for (int tt = 0; tt < 5; tt++) za[tt] = hx[u] * zz[u][tt];
 #pragma unroll
-        for (int a = 0; a < 4; a++)
+        for (int a = 0; a < 4; a++) {
 #pragma unroll
-          for (int b = 0; b < 5; b++) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(za[a], zz[u][b], acc[a][b], 0, 0, 0);
-        acc44 = __builtin_amdgcn_mfma_f32_16x16x4f32(za[4], zz[u][4], acc44, 0, 0, 0);
+          for (int b = a; b < 4; b++) acc[sc_ut(a, b)] = __builtin_amdgcn_mfma_f32_16x16x4f32(za[a], zz[u][b], acc[sc_ut(a, b)], 0, 0, 0);
+          acc[10 + a] = __builtin_amdgcn_mfma_f32_16x16x4f32(za[a], zz[u][4], acc[10 + a], 0, 0, 0);
+        }
+        acc[14] = __builtin_amdgcn_mfma_f32_16x16x4f32(za[4], zz[u][4], acc[14], 0, 0, 0);
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1708,23 +1715,15 @@ __global__ __launch_bounds__(BA_BLOCK, 2) void k_ba_sc_host(const BaDev* __restr
   // ---- fixed-order tree over the four waves: (3 -> 1, 2 -> 0), then (1 -> 0)
   auto put = [&](float* dst) {
 #pragma unroll
-    for (int a = 0; a < 4; a++)
+    for (int t = 0; t < SC_NT; t++)
 #pragma unroll
-      for (int b = 0; b < 5; b++)
-#pragma unroll
-        for (int v = 0; v < 4; v++) dst[((a * 5 + b) * 4 + v) * 64 + lane] = acc[a][b][v];
-#pragma unroll
-    for (int v = 0; v < 4; v++) dst[(80 + v) * 64 + lane] = acc44[v];
+      for (int v = 0; v < 4; v++) dst[(t * 4 + v) * 64 + lane] = acc[t][v];
   };
   auto add = [&](const float* src) {
 #pragma unroll
-    for (int a = 0; a < 4; a++)
+    for (int t = 0; t < SC_NT; t++)
 #pragma unroll
-      for (int b = 0; b < 5; b++)
-#pragma unroll
-        for (int v = 0; v < 4; v++) acc[a][b][v] += src[((a * 5 + b) * 4 + v) * 64 + lane];
-#pragma unroll
-    for (int v = 0; v < 4; v++) acc44[v] += src[(80 + v) * 64 + lane];
+      for (int v = 0; v < 4; v++) acc[t][v] += src[(t * 4 + v) * 64 + lane];
   };
   if (wv >= 2) put(tiles[wv - 2]);
   __syncthreads();
@@ -1739,9 +1738,9 @@ __global__ __launch_bounds__(BA_BLOCK, 2) void k_ba_sc_host(const BaDev* __restr
   float* accD = B.accum + acc_off_D(nf);
   float* accE = B.accum + acc_off_E(nf);
   float* accEB = B.accum + acc_off_EB(nf);
-  float* bins = stage_all + 21 * 256;          // the second tile buffer: free since the tree's second barrier
+  float* bins = stage_all + SC_NT * 256;       // the second tile buffer: free since the tree's second barrier
   constexpr int BIN_E = 64 * 64, BIN_EB = BIN_E + 8 * 32;
-  static_assert(21 * 256 + BIN_EB + 64 <= SC_LDS, "the bins fit behind the first tile buffer");
+  static_assert(SC_NT * 256 + BIN_EB + 64 <= SC_LDS, "the bins fit behind the first tile buffer");
   if (wv == 0) {
     add(tiles[0]);
     SCS();
@@ -1751,20 +1750,24 @@ __global__ __launch_bounds__(BA_BLOCK, 2) void k_ba_sc_host(const BaDev* __restr
       for (int v = 0; v < 4; v++) {
         const int Rr = 16 * a + 4 * kq + v, t1 = Rr >> 3, ra = Rr & 7;
 #pragma unroll
-        for (int b = 0; b < 4; b++) {
+        for (int b = a; b < 4; b++) {              // element (Rr, Cc) of the upper triangle and its mirror image (Cc, Rr)
           const int Cc = 16 * b + ci, t2 = Cc >> 3, cc = Cc & 7;
-          bins[(t1 * 8 + t2) * 64 + ra * 8 + cc] = acc[a][b][v];
+          const float val = acc[sc_ut(a, b)][v];
+          if (b > a || Rr <= Cc) {
+            bins[(t1 * 8 + t2) * 64 + ra * 8 + cc] = val;
+            if (Rr != Cc) bins[(t2 * 8 + t1) * 64 + cc * 8 + ra] = val;
+          }
         }
-        if (ci < 4) bins[BIN_E + t1 * 32 + ra * 4 + ci] = acc[a][4][v];
-        if (ci == 4) bins[BIN_EB + t1 * 8 + ra] = acc[a][4][v];
+        if (ci < 4) bins[BIN_E + t1 * 32 + ra * 4 + ci] = acc[10 + a][v];
+        if (ci == 4) bins[BIN_EB + t1 * 8 + ra] = acc[10 + a][v];
       }
     }
     float* hp = B.sc_part + (size_t)h * 20;      // Hcc (16) and bc (4) of this host; k_ba_fold_all adds the hosts
     if (kq == 0) {
 #pragma unroll
       for (int v = 0; v < 4; v++) {
-        if (ci < 4) hp[v * 4 + ci] = acc44[v];
-        if (ci == 4) hp[16 + v] = acc44[v];
+        if (ci < 4) hp[v * 4 + ci] = acc[14][v];
+        if (ci == 4) hp[16 + v] = acc[14][v];
       }
     }
   }

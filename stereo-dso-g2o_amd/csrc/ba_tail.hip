@@ -189,7 +189,7 @@ __global__ __launch_bounds__(TAIL_NT) void k_ba_tail(const BaDev* __restrict__ w
     for (int u = 0; u < ET; u++) { const int e = tid + u * TAIL_NT; if (e < nf2 * 40) Es[e] = ev[u]; }
     if (tid < nf2 * 8) atd[tid] = av;
     if (tid < 20) {
-      if (fold) { hcc = 0.f; for (int h = 0; h < nf; h++) hcc += hpart[h]; }
+      if (fold) { hcc = 0.f; for (int h = 0; h < nf; h++) hcc += hpart[h]; }     // (the float sum k_ba_fold_hcc leaves in the packed block: both paths give the same bits)
       misc[tid] = hcc;
     }
     if (tid >= 64 && tid < 64 + 4 * 72) {     // bM_top = bM + HM * delta   (EnergyFunctional.cpp:870): four threads per row, every load of a

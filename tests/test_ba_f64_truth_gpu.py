@@ -130,27 +130,32 @@ def _gauge_free(win, ds):
 
 @pytest.mark.parametrize("which", list(CASES))
 def test_gn_loop_against_f64_truth(gpu_ctx, oracle, which):
-    """All five windows.  The frame states after the loop sit within 1e-4 of the f64-accumulator truth, the idepths within 5e-5.
-    Round 2 attributed the excess over north_star's 1e-5 to the near-singular gauge directions; round 3 measured it
-    (tests/diag/gauge_probe.py, profiles/r03_gauge_probe.txt) and that is NOT where it lives: with frame 0's pose prior only the scale
-    direction is near-singular (one whitened eigenvalue below 1e-4), and the difference projected onto the well-determined subspace is as
-    large as the raw one (device 0.2 .. 8.7e-5 depending on the window, the CPU float path 1.3 .. 2.4e-5, the previous device kernels
-    1.2 .. 4.9e-5: samples of the same float-accumulator noise, whose x-error the 6 iterations carry along).  So the bar stays the
-    absolute one, the CPU float path is held to it too (test_one_iteration...), and what is asserted about the gauge is only that
-    removing it does not make the difference larger.  Every residual whose final state differs from the truth sits at its threshold:
-    the energy one side keeps is within 1e-3 of the value the other side clamps to."""
+    """All five windows: the loop's final states against the f64-accumulator truth.
+
+    What the distance IS (round 4, tests/diag/truth_spread.py over 24 windows, profiles/r04_truth_spread.txt): the float accumulators put
+    an absolute noise floor dx = H^-1 db under the last steps of the loop (b is a sum with cancellation: its float error does not shrink
+    with |b|), and a residual sitting on its outlier threshold flips on one side only.  Per window the distance to the truth therefore
+    scatters between 1e-6 and 2e-4 — for the device AND for the CPU float path, uncorrelated (device median 2.3e-5, CPU 2.4e-5; device
+    worse on 11 of 24 windows, better on 13).  A per-window bar can only be the top of that scatter (3e-4 states); the statement about the
+    kernels is the distribution test below.  Round 3's suspicion that the fused tail kernel adds noise of its own was half right: its
+    `S2 = S1^T` shortcut assumed accD(i,j,k) == accD(i,k,j)^T, which the MFMA tiles only satisfied up to rounding; the Schur kernel now
+    writes the lower tiles as mirror images (exact, as in the reference) and the two tails agree to 1e-9 on every window.
+    Every residual whose final state differs from the truth sits at its threshold: the energy one side keeps is within 1e-3 of the value
+    the other side clamps to."""
     win = CASES[which]
     nf, npts, nr = win["nf"], win["np"], win["nr"]
     for f in range(nf):
         gpu_ctx.upload_pyramid(40 + f, win["pyrs"][f][:1])
     W, keep = abi.make_ba_window(win, frame_slots=[40 + f for f in range(nf)], dI_list=[p[0] for p in win["pyrs"]])
     ns64, ne64, nw64 = np.zeros(nr, np.uint8), np.zeros(nr, np.float32), np.zeros(nr, np.float32)
+    P64, d64 = abi.make_post_state(nf, npts, nr)
     oracle.orc_set_acc64(1)
     try:
         h = oracle.orc_ba_create(C.byref(W))
         s64, i64, r64, o64 = np.zeros((nf, 10)), np.zeros(npts, np.float32), np.zeros(nr, np.uint8), abi.BAOptResult()
         oracle.orc_ba_optimize(h, 6, abi.dp(s64), abi.fp(i64), abi.bp(r64), C.byref(o64))
         oracle.orc_ba_get_linearization(h, None, abi.bp(ns64), abi.fp(ne64), abi.fp(nw64), None, None)     # of the final linearizeAll(true)
+        oracle.orc_ba_get_post_state(h, C.byref(P64))
         oracle.orc_ba_destroy(h)
     finally:
         oracle.orc_set_acc64(0)
@@ -159,18 +164,21 @@ def test_gn_loop_against_f64_truth(gpu_ctx, oracle, which):
     gpu_ctx.check(gpu_ctx.L.sdso_ba_optimize(gpu_ctx.h, 3, 6, abi.dp(s), abi.fp(i), abi.bp(r), C.byref(o)))
     ns, ne, nw = np.zeros(nr, np.uint8), np.zeros(nr, np.float32), np.zeros(nr, np.float32)
     gpu_ctx.check(gpu_ctx.L.sdso_ba_get_linearization(gpu_ctx.h, 3, None, abi.bp(ns), abi.fp(ne), abi.fp(nw), None, None))
+    P, d = abi.make_post_state(nf, npts, nr)
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_get_post_state(gpu_ctx.h, 3, C.byref(P)))
     gpu_ctx.check(gpu_ctx.L.sdso_ba_release_window(gpu_ctx.h, 3))
     assert o.iterations == o64.iterations
     raw = np.abs(s - s64).max()
-    assert raw <= 1e-4, raw
+    assert raw <= 3e-4, raw
     free, gauge = _gauge_free(win, s - s64)
     assert np.abs(free).max() <= raw * (1 + 1e-9) + 1e-12, (np.abs(free).max(), np.abs(gauge).max(), raw)
-    assert np.abs(s[:, 8:] - s64[:, 8:]).max() <= 1e-5
+    # the calibration (CalibHessian::value, unscaled: fx fy cx cy / 50) and the newest frame's evaluation point travel with the states
+    assert np.abs(np.array(P.calib_value[:]) - np.array(P64.calib_value[:])).max() <= 1e-5
+    assert np.abs(d["evalPT"][nf - 1] - d64["evalPT"][nf - 1]).max() <= 3e-4
     di = np.abs(i.astype(np.float64) - i64)
-    # idepths: 5e-5; the window with idepth_noise = 0.3 (points initialised 30 % off) keeps a handful of weakly observed points whose
-    # six-iteration trajectory amplifies the accumulator noise further: <= 2e-4 there, and no more than 1 % of its points above 5e-5
-    assert di.max() <= (2e-4 if which == "noisy" else 5e-5), di.max()
-    assert (di > 5e-5).sum() <= max(1, npts // 100)
+    # idepths: the maximum sits on single weakly observed points (either path: the CPU float path reaches 9e-4 on such points); the bulk
+    # is what the bar is about
+    assert np.percentile(di, 99) <= 5e-5 and di.max() <= 2e-3, (np.percentile(di, 99), di.max())
     flipped = np.nonzero(r != r64)[0]
     assert len(flipped) <= max(2, nr // 2000)
     for j in flipped:
@@ -179,3 +187,24 @@ def test_gn_loop_against_f64_truth(gpu_ctx, oracle, which):
             e_in, th = (nw[j], ne64[j]) if r[j] == 0 else (nw64[j], ne[j])
             assert abs(float(e_in) - float(th)) <= 1e-3 * float(th), (j, e_in, th)
     assert abs(o.lastEnergy - o64.lastEnergy) <= 1e-4 * o64.lastEnergy
+
+
+def test_device_noise_is_the_cpu_float_noise(gpu_ctx, oracle):
+    """The statement about the kernels: over 24 windows (4 .. 8 keyframes, two image sizes, three of them with points initialised 30 % off)
+    the device's distance from the f64-accumulator truth after the 6-iteration loop has the distribution of the CPU float path's distance —
+    the reference's own arithmetic with its own summation order.  Measured on MI355X (profiles/r04_truth_spread.txt): median 2.27e-5
+    against 2.38e-5, mean 4.1e-5 against 3.2e-5, maximum 1.9e-4 against 1.1e-4; SDSO_BA_TAIL=0 gives the same numbers to 1e-9."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "diag"))
+    import truth_spread
+    rows = []
+    for name, win in truth_spread.windows(24):
+        dev, cpu, its = truth_spread.loop_distances(gpu_ctx, oracle, win)
+        assert its[0] == its[2], (name, its)                                 # the device takes the truth's number of iterations
+        rows.append((dev, cpu))
+    sm = truth_spread.summarize(rows)
+    assert sm["dev_median"] <= 1.5 * sm["cpu_median"] + 5e-6, sm
+    assert sm["dev_mean"] <= 2.0 * sm["cpu_mean"], sm
+    assert sm["dev_max"] <= 3e-4 and sm["cpu_max"] <= 3e-4, sm              # the same absolute bar for both
+    assert 6 <= sm["dev_worse"] <= 18, sm                                   # neither path is systematically closer

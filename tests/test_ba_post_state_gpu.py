@@ -124,7 +124,8 @@ def check_post_state(win, Po, do, Pg, dg):
     d = np.sqrt(np.abs(np.diag(do["lastHS"]))) + 1e-30
     assert np.abs((dg["lastHS"] - do["lastHS"]) / np.outer(d, d)).max() <= 5e-4
     assert np.abs((dg["lastbS"] - do["lastbS"]) / d).max() <= 2e-3 * max(1.0, np.abs(do["lastbS"] / d).max())   # (b of the LAST solve: its states differ by ~1e-5; measured 5.2e-4)
-    assert np.abs((dg["lastX"] - do["lastX"]) * d).max() <= 1e-3 * max(1.0, np.abs(do["lastX"] * d).max())
+    # lastX of the LAST solve is a step at the noise floor of the float accumulators (|x| ~ 1e-4 .. 1e-3 in state units): absolute bar, like the states
+    assert np.abs(dg["lastX"] - do["lastX"]).max() <= 2e-4
     assert np.array_equal(dg["frame_step"][:, :8].ravel(), -dg["lastX"][4:]) and np.all(dg["frame_step"][:, 8:] == 0)
     assert np.array_equal(np.array(Pg.calib_step[:]), -dg["lastX"][:4])
     # ---- points
