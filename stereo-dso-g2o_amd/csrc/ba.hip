@@ -390,6 +390,7 @@ static int upload_window_impl(sdso_ctx* ctx, int win, const sdso_ba_window_t* Wi
   PL(d.r_energy, float, nr, false); PL(d.r_newEnergy, float, nr, false); PL(d.r_newEnergyWO, float, nr, false);
   PL(d.J[0], float, (size_t)76 * d.nrp, false); PL(d.J[1], float, (size_t)76 * d.nrp, false); PL(d.r_toZero, float, (size_t)8 * d.nrp, false);
   PL(d.r_rec, float, (size_t)np * nf * 16, false);   // dense [point][target] records
+  PL(d.r_cj, float, (size_t)np * nf * 8, false);     // their JpJdF halves, compact (written by k_ba_sc_host)
   d.r_proj = nullptr;
   // the tables upload_tables refreshes: contiguous, in this order (one staged copy there too)
   PL(W->dt_precalc, float, nf * nf * 27, true); PL(W->dt_adHTdelta, float, nf * nf * 8, true); PL(W->dt_cdelta, float, 4, true);
@@ -534,6 +535,11 @@ static void launch_apply(sdso_ctx* ctx, const BaLaunch& L) {
   hipLaunchKernelGGL(k_ba_apply, dim3(L.max_nblk_res, L.nwin), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr);
 }
 static bool launch_sc_and_folds(sdso_ctx* ctx, const BaLaunch& L, const uint8_t* pflag, bool marg, bool fold_top_too = false, bool defer_fold = false, bool* async_sc = nullptr);
+// which Schur kernel the process runs: 0 one workgroup per host (default; it also leaves BaDev::r_cj / the active-target bits the
+// back-substitution kernels read), 1 per-item MFMA (SDSO_SC_ITEMS), 2 VALU register tiles (SDSO_SC_REG)
+static int sc_variant() { static const int v = getenv("SDSO_SC_REG") ? 2 : getenv("SDSO_SC_ITEMS") ? 1 : 0; return v; }
+#define LAUNCH_RESUB(...) do { if (sc_variant() == 0) hipLaunchKernelGGL(k_ba_resub<true>, __VA_ARGS__); else hipLaunchKernelGGL(k_ba_resub<false>, __VA_ARGS__); } while (0)
+#define LAUNCH_RESUB_STEP(...) do { if (sc_variant() == 0) hipLaunchKernelGGL(k_ba_resub_step<true>, __VA_ARGS__); else hipLaunchKernelGGL(k_ba_resub_step<false>, __VA_ARGS__); } while (0)
 static void launch_accumulate(sdso_ctx* ctx, const BaLaunch& L, const uint8_t* pflag, bool marg) {
   const int nf = L.nf;
   // the folds run even without a single chunk: they are what clears the top bins of the previous call
@@ -569,7 +575,7 @@ static bool side_stream(sdso_ctx* ctx) {
 static bool launch_sc_and_folds(sdso_ctx* ctx, const BaLaunch& L, const uint8_t* pflag, bool marg, bool fold_top_too, bool defer_fold, bool* async_sc) {
   const int nf = L.nf;
   const int shift = marg ? 0 : 1, mm = marg ? 1 : 0;
-  static const int sc_variant = getenv("SDSO_SC_REG") ? 2 : getenv("SDSO_SC_ITEMS") ? 1 : 0;   // 0: one workgroup per host (default); 1: per-item MFMA; 2: VALU register tiles
+  const int sc_variant = sdso::sc_variant();
   if (sc_variant == 0) {
     const bool want_async = async_sc && *async_sc && fold_top_too && defer_fold && !marg && side_stream(ctx);
     if (async_sc) *async_sc = want_async;
@@ -660,7 +666,7 @@ static void launch_solve(sdso_ctx* ctx, const BaLaunch& L, double lambda, int or
   if (tail_enabled()) {
     const int flags = TAIL_HS | ((orth & 1) ? TAIL_ORTH : 0) | ((orth & 2) ? TAIL_LAMBDA_DEV : 0) | (L.any_lin ? TAIL_TOPL : 0) | (folded ? 0 : TAIL_FOLD) | (wait_sc ? TAIL_WAIT_SC : 0);
     launch_tail(ctx, L, lambda, flags);
-    if (L.max_nblk_pts > 0) hipLaunchKernelGGL(k_ba_resub, dim3(L.max_nblk_pts, L.nwin), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr);
+    if (L.max_nblk_pts > 0) LAUNCH_RESUB( dim3(L.max_nblk_pts, L.nwin), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr);
     return;
   }
   if (!folded) launch_fold_deferred(ctx, L);
@@ -673,7 +679,7 @@ static void launch_solve(sdso_ctx* ctx, const BaLaunch& L, double lambda, int or
     const size_t lds = sizeof(double) * ((size_t)n * ((n + 2) & ~1) + 6 * n + 16) + sizeof(int) * n;   // matrix, six vectors (+16 pad), perm
     hipLaunchKernelGGL(k_ba_solve<1>, dim3(1, L.nwin), dim3(BA_BLOCK), lds, ctx->stream, L.d_arr, lambda, orth);
   }
-  if (L.max_nblk_pts > 0) hipLaunchKernelGGL(k_ba_resub, dim3(L.max_nblk_pts, L.nwin), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr);
+  if (L.max_nblk_pts > 0) LAUNCH_RESUB( dim3(L.max_nblk_pts, L.nwin), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr);
 }
 // a Schur kernel still on the side stream whose consumer is not a waiting tail kernel: join it on the main stream and clear the counters
 __global__ void k_ba_clear_sc_done(const BaDev* __restrict__ wins) { wins[blockIdx.x].opt->sc_done = 0; }
@@ -996,7 +1002,7 @@ static int solve_system_host(sdso_ctx* ctx, BaWindowDev* W, int iteration, doubl
         xAd[(size_t)(nf * h + t) * 8 + j] = sh + stt;
       }
   SDSO_HIP(ctx, hipMemcpyAsync(W->dt_xAd, xAd.data(), sizeof(float) * xAd.size(), hipMemcpyHostToDevice, ctx->stream));
-  if (L.max_nblk_pts > 0) hipLaunchKernelGGL(k_ba_resub, dim3(L.max_nblk_pts, 1), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr);
+  if (L.max_nblk_pts > 0) LAUNCH_RESUB( dim3(L.max_nblk_pts, 1), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr);
   SDSO_HIP(ctx, hipGetLastError());
   SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));   // x / lastHS / lastbS / xAd are stack-local
   return SDSO_OK;
@@ -1065,7 +1071,7 @@ extern "C" int sdso_ba_resubstitute(sdso_ctx* ctx, int win, const double* x, dou
       }
   SDSO_HIP(ctx, hipMemcpyAsync(W->dt_xAd, xAd.data(), sizeof(float) * xAd.size(), hipMemcpyHostToDevice, ctx->stream));
   const BaLaunch L = single(W);
-  if (L.max_nblk_pts > 0) hipLaunchKernelGGL(k_ba_resub, dim3(L.max_nblk_pts, 1), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr);
+  if (L.max_nblk_pts > 0) LAUNCH_RESUB( dim3(L.max_nblk_pts, 1), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr);
   SDSO_HIP(ctx, hipGetLastError());
   SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
   for (int i = 0; i < 4; i++) W->calib.step[i] = -x[i];
@@ -1817,13 +1823,13 @@ static int opt_solve_step(sdso_ctx* ctx, OptRun& R, double lambda, int orth, boo
   const dim3 gp(std::max(R.L.max_nblk_pts, 1), nwin);
   if (!R.exchange) {
     launch_tail(ctx, R.L, lambda, flags | TAIL_STEP, R.iteration, 0, R.stop);
-    if (R.L.max_nblk_pts) hipLaunchKernelGGL(k_ba_resub_step, gp, dim3(BA_BLOCK), 0, ctx->stream, R.L.d_arr, R.iteration + 1, (float*)nullptr, 0);
+    if (R.L.max_nblk_pts) LAUNCH_RESUB_STEP( gp, dim3(BA_BLOCK), 0, ctx->stream, R.L.d_arr, R.iteration + 1, (float*)nullptr, 0);
     SDSO_HIP(ctx, hipGetLastError());
     R.iteration++;
     return SDSO_OK;
   }
   launch_tail(ctx, R.L, lambda, flags);
-  if (R.L.max_nblk_pts) hipLaunchKernelGGL(k_ba_resub_step, gp, dim3(BA_BLOCK), 0, ctx->stream, R.L.d_arr, -1, R.B->d_sums, R.sums_stride);
+  if (R.L.max_nblk_pts) LAUNCH_RESUB_STEP( gp, dim3(BA_BLOCK), 0, ctx->stream, R.L.d_arr, -1, R.B->d_sums, R.sums_stride);
   const int rc = opt_consume(ctx, R, 0, false, R.L.max_nblk_pts > 0);
   R.iteration++;
   return rc;

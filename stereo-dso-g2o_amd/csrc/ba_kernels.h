@@ -80,7 +80,7 @@ struct BaDev {
                             // (EnergyFunctional.cpp:524-533); the dense [target] records are visited through this word so that the float sums
                             // Hdd / bd / Hcd and the back-substitution come out bit-identical on such windows too
   float4* p_track;          // per point: x PointHessian::maxRelBaseline, y numGoodResiduals (int bits) — FullSystemOptimize.cpp:64-77 —,
-                            // z idepth_hessian, w number of active residuals (int bits) of the latest AccumulatedSCHessianSSE::addPoint
+                            // z idepth_hessian, w the active residuals of the latest AccumulatedSCHessianSSE::addPoint (bit t: target t; int bits)
   float* p_out;             // np*16
   // residuals (pair-sorted)
   const int* r_point;
@@ -93,6 +93,8 @@ struct BaDev {
   float* J[2];              // 19 float4 groups x nrp each (layout: ba_kernels.hip); EFResidual::J = J[jsel], PointFrameResidual::J = J[1-jsel]
   float* r_toZero;          // 8 x nrp SoA
   float* r_rec;             // np x nf x 16: dense [point][target] records (RR_*), flags 0 where the point has no residual to that target
+  float* r_cj;              // np x nf x 8: the JpJdF halves of r_rec alone, written by k_ba_sc_host while it has the records parked (its launches are
+                            // latency-bound, the stores ride for free) so that the back-substitution streams 32 instead of 64 bytes per (point, target)
   float* r_proj;            // nr x 19 (projectedTo 16, centerProjectedTo 3)
   // tables
   const float* t_precalc;   // [host*nf+target][27]

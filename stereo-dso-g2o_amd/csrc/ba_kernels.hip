@@ -1314,7 +1314,7 @@ __device__ __forceinline__ void sc_point_terms(const BaDev& B, int p, const floa
     *(float4*)(po + 8) = make_float4(HcdL[0], HcdL[1], HcdL[2], HcdL[3]);
     *(float2*)(po + PO_HDI) = make_float2(o.HdiF, o.bdSumF);
     float* tr = (float*)(B.p_track + p);
-    *(float2*)(tr + 2) = make_float2(any ? H : 0.f, __int_as_float(ngood));   // p->data->idepth_hessian (:46, :56)
+    *(float2*)(tr + 2) = make_float2(any ? H : 0.f, __int_as_float(mbits));   // p->data->idepth_hessian (:46, :56); the active targets for k_ba_resub*
     if (!any) tr[0] = 0.f;                                                     // p->data->maxRelBaseline = 0 (:47)
   }
 }
@@ -1447,7 +1447,7 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_sc_reg(const BaDev* __restrict_
     *(float4*)(po + 8) = make_float4(o_hcL0, o_hcL1, o_hcL2, o_hcL3);
     po[PO_HDI] = o_hdi; po[PO_BDSUM] = o_bds;
     float* tr = (float*)(B.p_track + it.y + lane);
-    *(float2*)(tr + 2) = make_float2(o_idh, __int_as_float(o_ng));   // p->data->idepth_hessian (AccumulatedSCHessian.cpp:46, :56)
+    *(float2*)(tr + 2) = make_float2(o_idh, __int_as_float(o_ng));   // p->data->idepth_hessian (AccumulatedSCHessian.cpp:46, :56)  (w: the count — this variant's launches use the records' flags in k_ba_resub*)
     if (o_ng == 0) tr[0] = 0.f;                                       // p->data->maxRelBaseline = 0 (:47)
   }
   float* out = B.sc_part + (size_t)item * sc_part_floats(NF);
@@ -1570,7 +1570,10 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_sc_mfma(const BaDev* __restrict
 // (Round 3 tried the transposed split — wave a owns tile ROW a for all points of the host: 116 VGPRs and 8 KB of LDS, so all 1024
 //  workgroups of a 128-window launch are resident at once instead of two rounds of 512 — and measured it SLOWER, 91 against 72 us: the
 //  kernel is bound by the per-wave chain load -> MFMA over its point groups, which that split makes four times longer.)
-__global__ __launch_bounds__(BA_BLOCK, 2) void k_ba_sc_host(const BaDev* __restrict__ wins, const uint8_t* __restrict__ pflag, int shiftPriorToZero, int margMode, int signal = 0) {
+#ifndef SDSO_SC_OCC
+#define SDSO_SC_OCC 2
+#endif
+__global__ __launch_bounds__(BA_BLOCK, SDSO_SC_OCC) void k_ba_sc_host(const BaDev* __restrict__ wins, const uint8_t* __restrict__ pflag, int shiftPriorToZero, int margMode, int signal = 0) {
   const BaDev& B = wins[blockIdx.y];
   if (ba_finished(B)) return;
   const int nf = B.nf, h = blockIdx.x;
@@ -1645,6 +1648,8 @@ __global__ __launch_bounds__(BA_BLOCK, 2) void k_ba_sc_host(const BaDev* __restr
         if (c < nchunks) {
           const int rec = c >> 2, pl = nf == 8 ? rec >> 3 : rec / nf, t = rec - pl * nf;
           *(float4*)(stg + pl * SC_PSTRIDE + t * 16 + 4 * (c & 3)) = vnext[k];
+          // the JpJdF half of the record into the compact copy the back-substitution streams (BaDev::r_cj)
+          if ((c & 2) == 0) *(float4*)(B.r_cj + ((size_t)p0 * nf + rec) * 8 + 4 * (c & 1)) = vnext[k];
         }
       }
     }

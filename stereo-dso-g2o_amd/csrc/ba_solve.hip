@@ -817,19 +817,22 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_solve(const BaDev* __restrict__
 // residuals in EFPoint::residualsAll order (BaDev::p_order — the subtractions of the reference, one after the other), step = -b HdiF.
 // Every load of the point is issued before the first one is consumed (the loop over the targets is unrolled to the 8 frames a window can
 // hold and predicated): one memory round trip instead of one per target.
+// CJ: the JpJdF rows come from the compact copy k_ba_sc_host left (BaDev::r_cj, 32 bytes per (point, target)) and the active targets from
+// BaDev::p_track — half the bytes of the 64-byte records; false: from the records themselves (the other Schur kernel variants).
+template <bool CJ>
 __device__ __forceinline__ float resub_point(const BaDev& B, int p, const float* po) {
   const double* x = B.sol + 3 * ((size_t)B.n * B.n + B.n);
   const int nf = B.nf;
-  const float* recs = B.r_rec + (size_t)p * nf * 16;
+  const float* recs = CJ ? B.r_cj + (size_t)p * nf * 8 : B.r_rec + (size_t)p * nf * 16;
   const int h = B.p_host[p];
   const unsigned ord = B.p_order[p];
   float4 j0[8], j1[8], xa0[8], xa1[8];
-  unsigned good = 0;
+  unsigned good = CJ ? (unsigned)__float_as_int(((const float*)(B.p_track + p))[3]) : 0u;
 #pragma unroll
   for (int t = 0; t < 8; t++) {
     if (t < nf) {
-      const float* rec = recs + t * 16;
-      good |= ((((int)rec[RR_FLAGS]) & 1) != 0 ? 1u : 0u) << t;
+      const float* rec = recs + t * (CJ ? 8 : 16);
+      if (!CJ) good |= ((((int)rec[RR_FLAGS]) & 1) != 0 ? 1u : 0u) << t;
       j0[t] = *reinterpret_cast<const float4*>(rec); j1[t] = *reinterpret_cast<const float4*>(rec + 4);
       const float* xa = B.t_xAd + (size_t)(h * nf + t) * 8;
       xa0[t] = *reinterpret_cast<const float4*>(xa); xa1[t] = *reinterpret_cast<const float4*>(xa + 4);
@@ -866,19 +869,21 @@ __device__ __forceinline__ float resub_point(const BaDev& B, int p, const float*
   }
   return -b * hdi;
 }
+template <bool CJ>
 __global__ __launch_bounds__(BA_BLOCK) void k_ba_resub(const BaDev* __restrict__ wins) {
   const BaDev& B = wins[blockIdx.y];
   if (ba_finished(B)) return;
   const int p = blockIdx.x * BA_BLOCK + threadIdx.x;
   if (p >= B.np) return;
   float* po = B.p_out + (size_t)p * 16;
-  po[PO_STEP] = resub_point(B, p, po);
+  po[PO_STEP] = resub_point<CJ>(B, p, po);
 }
 
 // resubstituteFPt + backupState + doStepFromBackup (stepfacD = 1) of the points in ONE pass over the point data (k_ba_resub followed
 // by k_ba_points_op op 3), after the fused tail kernel of the resident loop.  expect_iterations >= 0: the window takes part iff its
 // loop has taken exactly that many steps — the tail kernel that just ran may have set `finished` for the NEXT iteration (the break
 // test fires after the step it belongs to); < 0: the plain `finished` test (sharded windows: k_ba_opt_step has not run yet).
+template <bool CJ>
 __global__ __launch_bounds__(BA_BLOCK) void k_ba_resub_step(const BaDev* __restrict__ wins, int expect_iterations, float* __restrict__ sums, int sums_stride) {
   const BaDev& B = wins[blockIdx.y];
   if (expect_iterations >= 0 ? (ba_finished_lin(B) || B.opt->iterations != expect_iterations) : ba_finished(B)) return;
@@ -887,7 +892,7 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_resub_step(const BaDev* __restr
   if (p < B.np) {
     float* po = B.p_out + (size_t)p * 16;
     float4 g = B.p_geo[p];
-    const float st = resub_point(B, p, po);
+    const float st = resub_point<CJ>(B, p, po);
     po[PO_STEP] = st;
     po[PO_BACKUP] = g.z;
     const float bk = g.z, nid = bk + 1.0f * st;

@@ -84,6 +84,21 @@ def permuted_window(win, seed):
     return w2, order
 
 
+def idepths_close(ig, io, bulk, worst=None):
+    """Idepths after a whole GN loop against another implementation of the same loop: the bulk (99th percentile) within `bulk`; the
+    maximum sits on single weakly observed points whose trajectory over the iterations amplifies any rounding difference (either side:
+    the CPU float path reaches 9e-4 from the f64-accumulator truth on such points, profiles/r04_truth_spread.txt) and is only bounded
+    (default 10 x bulk)."""
+    d = np.abs(np.asarray(ig, np.float64) - np.asarray(io, np.float64))
+    worst = 10.0 * bulk if worst is None else worst
+    return bool(np.percentile(d, 99) <= bulk and d.max() <= worst)
+
+
+def counts_close(a, b, nr):
+    """resInA-like counts of two runs of the same loop: equal up to the residuals that sit on an outlier threshold in some iteration"""
+    return abs(int(a) - int(b)) <= max(2, nr // 2000)
+
+
 def drop_residuals(win, seed, drop_frac=0.25):
     """The window after EnergyFunctional::dropResidual removed a random part of every point's residuals
     (src/OptimizationBackend/EnergyFunctional.cpp:524-533: the LAST entry of residualsAll is swapped into the freed slot), the

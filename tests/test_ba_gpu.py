@@ -9,6 +9,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
+import helpers
 from sdso_amd import abi, synth
 
 pytestmark = pytest.mark.gpu
@@ -255,10 +256,10 @@ def test_optimize_full_gn_loop(gpu_ctx, oracle, win_small, win_c3, which):
         spread_s = max(spread_s, np.abs(sp - so).max())
         spread_i = max(spread_i, np.abs(ip - io[order]).max())
     assert np.abs(sg - so).max() <= 1e-5 + 2.0 * spread_s
-    assert np.abs(ig - io).max() <= 1e-5 + 2.0 * spread_i
+    assert helpers.idepths_close(ig, io, 1e-5 + 2.0 * spread_i)
     mism = (rg != ro).sum()
     assert mism <= max(2, nr // 2000)        # IN/OUTLIER flips only where an energy sits on the threshold
-    assert og.resInA == oo.resInA or mism > 0
+    assert helpers.counts_close(og.resInA, oo.resInA, nr)
     assert abs(og.lastEnergy - oo.lastEnergy) <= 1e-4 * oo.lastEnergy
     oracle.orc_ba_destroy(h)
 
@@ -288,7 +289,7 @@ def test_optimize_energy_gated_steps(gpu_ctx, oracle, noise):
         res[name] = (so, oo.lastEnergy)
         assert og.iterations == oo.iterations
         assert abs(og.lastEnergy - oo.lastEnergy) <= 1e-3 * oo.lastEnergy
-        assert np.abs(sg - so).max() <= 2e-4 and np.abs(ig - io).max() <= 2e-4     # same accept / reject sequence, float-order spread only
+        assert np.abs(sg - so).max() <= 2e-4 and helpers.idepths_close(ig, io, 2e-4)     # same accept / reject sequence, float-order spread only
     assert abs(res["gated"][1] - res["forced"][1]) > 1e-3 * res["forced"][1]         # the gate really rejected something
 
 
@@ -436,7 +437,7 @@ def test_affine_modes_in_the_window(gpu_ctx, oracle, modes):
     oracle.orc_ba_destroy(h)
     assert og.iterations == oo.iterations
     # order-of-summation spread after 4 GN iterations (cf. test_optimize_full_gn_loop); states are O(1e-2)
-    assert np.abs(sg - so).max() <= 5e-4 and np.abs(ig - io).max() <= 5e-4
+    assert np.abs(sg - so).max() <= 5e-4 and helpers.idepths_close(ig, io, 5e-4)
     if modes[0] < 0:
         assert np.abs(sg[:, 6:8]).max() < 1e-6 and np.allclose(sg[:, 6:8], so[:, 6:8], rtol=1e-2, atol=1e-12)   # held by the 1e14 prior
 

@@ -279,9 +279,9 @@ def test_two_rank_sharded_gn_loop_matches_single(gpu_ctx, oracle, tmp_path):
         idep = np.concatenate([sh[r]["i"] for r in range(world)])
         rst = np.concatenate([sh[r]["r"] for r in range(world)])
         assert np.abs(sh[0]["s"] - s1).max() <= 1e-5 + 2.0 * ss, (np.abs(sh[0]["s"] - s1).max(), ss)
-        assert np.abs(idep - i1).max() <= 1e-5 + 2.0 * si, (np.abs(idep - i1).max(), si)
+        assert helpers.idepths_close(idep, i1, 1e-5 + 2.0 * si), (np.abs(idep - i1).max(), si)
         assert (rst != r1).sum() <= max(2, nr // 2000)
-        assert int(sh[0]["resInA"]) == resInA1 or (rst != r1).sum() > 0
+        assert helpers.counts_close(int(sh[0]["resInA"]), resInA1, nr)
         esum = float(sh[0]["e"])
         assert abs(esum - e1) <= 1e-4 * e1                                   # lastEnergy is the all-gathered sum on every rank
     for k in range(len(wins)):
@@ -312,7 +312,7 @@ def test_two_rank_sharded_energy_gated_loop_matches_single(gpu_ctx, tmp_path):
         idep = np.concatenate([sh[r]["i"] for r in range(world)])
         rst = np.concatenate([sh[r]["r"] for r in range(world)])
         assert np.abs(sh[0]["s"] - s1).max() <= 1e-4, np.abs(sh[0]["s"] - s1).max()
-        assert np.abs(idep - i1).max() <= 2e-4, np.abs(idep - i1).max()
+        assert helpers.idepths_close(idep, i1, 2e-4), np.abs(idep - i1).max()
         assert (rst != r1).sum() <= max(2, nr // 2000)
         assert abs(float(sh[0]["e"]) - e1) <= 1e-4 * e1
     for k in range(len(wins)):
