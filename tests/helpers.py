@@ -6,25 +6,7 @@ import numpy as np
 from sdso_amd import abi
 
 
-def track_params(prob, coarsest=None, ref_aff=(0.0, 0.0), exposure=(1.0, 1.0), max_its=(10, 20, 50, 50, 50)):
-    p = abi.TrackParams()
-    L = prob["levels"]
-    p.levels = L
-    for l in range(L):
-        p.w[l] = prob["pyr_ref"][l].shape[1]
-        p.h[l] = prob["pyr_ref"][l].shape[0]
-        p.fx[l], p.fy[l], p.cx[l], p.cy[l] = prob["fx"][l], prob["fy"][l], prob["cx"][l], prob["cy"][l]
-    p.ref_exposure, p.new_exposure = exposure
-    p.ref_aff_g2l = abi.Aff(ref_aff[0], ref_aff[1])
-    p.coarsestLvl = (min(L, 5) - 1) if coarsest is None else coarsest
-    for i in range(5):
-        p.minResForAbort[i] = float("nan")
-        p.maxIterations[i] = max_its[i]
-    p.coarseCutoffTH = 20.0
-    p.huberTH = 9.0
-    p.affineOptModeA = 1e12
-    p.affineOptModeB = 1e8
-    return p
+from sdso_amd.params import track_params  # noqa: E402,F401  (one definition: the product's; the tests use it through this module)
 
 
 def oracle_track(L, prob, prm, T0, aff0, fn="orc_track_newest_coarse"):

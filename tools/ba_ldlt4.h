@@ -17,7 +17,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <utility>
-#include "ba_ldlt.h"
+#include "../stereo-dso-g2o_amd/csrc/ba_ldlt.h"
 
 namespace sdso {
 

@@ -9,7 +9,7 @@
 #include <random>
 #include <vector>
 #include "../stereo-dso-g2o_amd/csrc/ba_ldlt.h"
-#include "../stereo-dso-g2o_amd/csrc/ba_ldlt4.h"
+#include "ba_ldlt4.h"
 using namespace sdso;
 
 __global__ __launch_bounds__(64) void k_ldlt(const double* __restrict__ Ms, const double* __restrict__ bs, double* __restrict__ xs, int n, long long* ticks) {
