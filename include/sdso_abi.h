@@ -61,6 +61,12 @@ int sdso_prof_enable(sdso_ctx* ctx, int on);
 int sdso_prof_reset(sdso_ctx* ctx);
 int sdso_prof_read(sdso_ctx* ctx, const char* kernel, double* total_ms, long* launches);
 
+/* Self-test of the device's Lie-group arithmetic (the SE3::exp / product / inverse that the resident tracker LM and GN loops run in
+ * kernels): for n tangents xi (6n; translation first, rotation last, se3.hpp:395-397) T_exp[i] = exp(xi_i), T_inv[i] = exp(xi_i)^-1,
+ * T_mul_next[i] = exp(xi_i) * exp(xi_(i+1 mod n)), each as R (9, row-major) then t (3).  tests/test_oracle_se3.py puts the Sophus
+ * fixtures of thirdparty/Sophus/sophus/test_se3.cpp:40-82 through it. */
+int sdso_selftest_se3(sdso_ctx* ctx, int n, const double* xi, double* T_exp, double* T_inv, double* T_mul_next);
+
 /* ------------------------------------------------------------------ pyramids
  * FrameHessian::dIp[lvl] (src/FullSystem/HessianBlocks.h:107-108): Vector3f {I, dx, dy} per pixel.
  * Images are immutable after FrameHessian::makeImages (HessianBlocks.cpp:141-203), so they are

@@ -154,6 +154,12 @@ int orc_track_newest_coarse(const int* pc_n, const float* const* pc_u, const flo
                             const float* const* dIp, const orc_track_params_t* prm,
                             orc_se3_t* lastToNew, orc_aff_t* aff_g2l, orc_track_result_t* out);
 
+/* CoarseTracker::makeCoarseDepthL0 from STEP1's splat on (CoarseTracker.cpp:352-534): n weighted inverse depths at integer pixels of
+ * lastRef -> pc_n[lvl], pc_u / pc_v / pc_idepth / pc_color[lvl] (caller-allocated, w[lvl]*h[lvl] entries per level) */
+int orc_make_coarse_depth(int levels, const int* w, const int* h, const float* const* dIp, int n, const int* u, const int* v,
+                          const float* new_idepth, const float* weight, int* pc_n, float* const* pc_u, float* const* pc_v,
+                          float* const* pc_idepth, float* const* pc_color);
+
 /* ---- windowed BA (handle based; the handle deep-copies the window description) */
 typedef struct orc_ba orc_ba;
 orc_ba* orc_ba_create(const orc_ba_window_t* W);

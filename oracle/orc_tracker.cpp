@@ -351,3 +351,70 @@ extern "C" int orc_track_newest_coarse(const int* pc_n, const float* const* pc_u
   out->good = 1;
   return 0;
 }
+
+// ---------------------------------------------------------------- CoarseTracker::makeCoarseDepthL0, STEP1's splat .. STEP5
+// src/FullSystem/CoarseTracker.cpp:352-534.  Inputs: what STEP1 computed per active point — the integer pixel (u, v) on lastRef
+// (:307-308), the (stereo-refined) new_idepth and weight = sqrtf(1e-3 / (HdiF + 1e-12)) (:350); dIp = lastRef->dIp (AoS {I, dx, dy}).
+// Outputs: pc_n[lvl] and pc_u / pc_v / pc_idepth / pc_color[lvl] (caller-allocated, w[lvl] * h[lvl] entries each) in the reference's
+// scan order.  The dilation reads idepthl in place: only entries with weightSumsl_bak > 0 are read and only entries with
+// weightSumsl_bak <= 0 are written, so no copy is needed (the reference says so at :404-406).  The one element past the map that
+// :410 / :459 can touch (i + 1 + wl, i + wl at the last scanned index) is treated as "no neighbour" (reading it is undefined in the
+// reference; the product makes the same choice).
+extern "C" int orc_make_coarse_depth(int levels, const int* w, const int* h, const float* const* dIp, int n, const int* u, const int* v,
+                                     const float* new_idepth, const float* weight, int* pc_n, float* const* pc_u, float* const* pc_v,
+                                     float* const* pc_idepth, float* const* pc_color) {
+  std::vector<std::vector<float>> idepth(levels), weightSums(levels), weightSums_bak(levels);
+  for (int l = 0; l < levels; l++) { idepth[l].assign((size_t)w[l] * h[l], 0.f); weightSums[l].assign((size_t)w[l] * h[l], 0.f); weightSums_bak[l].assign((size_t)w[l] * h[l], 0.f); }
+  for (int i = 0; i < n; i++) {                                       // :352-354
+    idepth[0][u[i] + w[0] * v[i]] += new_idepth[i] * weight[i];
+    weightSums[0][u[i] + w[0] * v[i]] += weight[i];
+  }
+  for (int lvl = 1; lvl < levels; lvl++) {                             // STEP2 :360-386
+    const int lvlm1 = lvl - 1, wl = w[lvl], hl = h[lvl], wlm1 = w[lvlm1];
+    float* idepth_l = idepth[lvl].data(); float* weightSums_l = weightSums[lvl].data();
+    const float* idepth_lm = idepth[lvlm1].data(); const float* weightSums_lm = weightSums[lvlm1].data();
+    for (int y = 0; y < hl; y++)
+      for (int x = 0; x < wl; x++) {
+        const int bidx = 2 * x + 2 * y * wlm1;
+        idepth_l[x + y * wl] = idepth_lm[bidx] + idepth_lm[bidx + 1] + idepth_lm[bidx + wlm1] + idepth_lm[bidx + wlm1 + 1];
+        weightSums_l[x + y * wl] = weightSums_lm[bidx] + weightSums_lm[bidx + 1] + weightSums_lm[bidx + wlm1] + weightSums_lm[bidx + wlm1 + 1];
+      }
+  }
+  auto dilate = [&](int lvl, const int offs[4]) {                      // STEP3 :390-441 (diagonal neighbours), STEP4 :445-488 (axis neighbours)
+    const int wh = w[lvl] * h[lvl] - w[lvl], total = w[lvl] * h[lvl];
+    float* weightSumsl = weightSums[lvl].data(); float* weightSumsl_bak = weightSums_bak[lvl].data();
+    std::memcpy(weightSumsl_bak, weightSumsl, (size_t)total * sizeof(float));
+    float* idepthl = idepth[lvl].data();
+    for (int i = w[lvl]; i < wh; i++) {
+      if (weightSumsl_bak[i] <= 0) {
+        float sum = 0, num = 0, numn = 0;
+        for (int k = 0; k < 4; k++) {
+          const int j = i + offs[k];
+          if (j >= 0 && j < total && weightSumsl_bak[j] > 0) { sum += idepthl[j]; num += weightSumsl_bak[j]; numn++; }
+        }
+        if (numn > 0) { idepthl[i] = sum / numn; weightSumsl[i] = num / numn; }
+      }
+    }
+  };
+  for (int lvl = 0; lvl < 2 && lvl < levels; lvl++) { const int wl = w[lvl]; const int offs[4] = {1 + wl, -1 - wl, wl - 1, -wl + 1}; dilate(lvl, offs); }
+  for (int lvl = 2; lvl < levels; lvl++) { const int wl = w[lvl]; const int offs[4] = {1, -1, wl, -wl}; dilate(lvl, offs); }
+  for (int lvl = 0; lvl < levels; lvl++) {                             // STEP5 :492-533
+    float* weightSumsl = weightSums[lvl].data(); float* idepthl = idepth[lvl].data();
+    const float* dIRefl = dIp[lvl];
+    const int wl = w[lvl], hl = h[lvl];
+    int lpc_n = 0;
+    for (int y = 2; y < hl - 2; y++)
+      for (int x = 2; x < wl - 2; x++) {
+        const int i = x + y * wl;
+        if (weightSumsl[i] > 0) {
+          idepthl[i] /= weightSumsl[i];
+          pc_u[lvl][lpc_n] = x; pc_v[lvl][lpc_n] = y; pc_idepth[lvl][lpc_n] = idepthl[i]; pc_color[lvl][lpc_n] = dIRefl[(size_t)i * 3];
+          if (!std::isfinite(pc_color[lvl][lpc_n]) || !(idepthl[i] > 0)) { idepthl[i] = -1; continue; }
+          lpc_n++;
+        } else idepthl[i] = -1;
+        weightSumsl[i] = 1;
+      }
+    pc_n[lvl] = lpc_n;
+  }
+  return 0;
+}

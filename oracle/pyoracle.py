@@ -70,6 +70,8 @@ def load(fast=False, path=None):
     L.orc_track_make_eval.restype = None
     L.orc_track_newest_coarse.argtypes = [c_int_p, C.POINTER(c_float_p), C.POINTER(c_float_p), C.POINTER(c_float_p), C.POINTER(c_float_p),
                                           C.POINTER(c_float_p), C.POINTER(TrackParams), C.POINTER(SE3), C.POINTER(Aff), C.POINTER(TrackResult)]
+    L.orc_make_coarse_depth.argtypes = [C.c_int, c_int_p, c_int_p, C.POINTER(c_float_p), C.c_int, c_int_p, c_int_p, c_float_p, c_float_p, c_int_p,
+                                        C.POINTER(c_float_p), C.POINTER(c_float_p), C.POINTER(c_float_p), C.POINTER(c_float_p)]
     L.orc_ba_create.argtypes = [C.POINTER(BAWindow)]
     L.orc_ba_create.restype = vp
     L.orc_ba_destroy.argtypes = [vp]
@@ -114,3 +116,21 @@ def load(fast=False, path=None):
     L.orc_g2o_lba_eval.argtypes = [C.POINTER(G2oLba), c_double_p, c_double_p, c_u8_p, c_float_p, c_float_p, c_float_p, c_u8_p]
     _libs[name] = L
     return L
+
+
+def make_coarse_depth(L, u, v, new_idepth, weight, ref_pyr):
+    """orc_make_coarse_depth on numpy arrays: a list (per level) of dicts u, v, idepth, color (float32), like the tracker template."""
+    import numpy as np
+    levels = len(ref_pyr)
+    ws = (C.c_int * levels)(*[p.shape[1] for p in ref_pyr]); hs = (C.c_int * levels)(*[p.shape[0] for p in ref_pyr])
+    imgs = [np.ascontiguousarray(p, np.float32) for p in ref_pyr]
+    dI = (c_float_p * levels)(*[a.ctypes.data_as(c_float_p) for a in imgs])
+    out = [[np.zeros(p.shape[0] * p.shape[1], np.float32) for p in ref_pyr] for _ in range(4)]
+    ptrs = [(c_float_p * levels)(*[a.ctypes.data_as(c_float_p) for a in arrs]) for arrs in out]
+    pc_n = (C.c_int * levels)()
+    ui, vi = np.ascontiguousarray(u, np.int32), np.ascontiguousarray(v, np.int32)
+    idp, wgt = np.ascontiguousarray(new_idepth, np.float32), np.ascontiguousarray(weight, np.float32)
+    L.orc_make_coarse_depth(levels, ws, hs, dI, len(ui), ui.ctypes.data_as(c_int_p), vi.ctypes.data_as(c_int_p), idp.ctypes.data_as(c_float_p),
+                            wgt.ctypes.data_as(c_float_p), pc_n, *ptrs)
+    return [dict(u=out[0][l][:pc_n[l]].copy(), v=out[1][l][:pc_n[l]].copy(), idepth=out[2][l][:pc_n[l]].copy(), color=out[3][l][:pc_n[l]].copy())
+            for l in range(levels)]

@@ -334,3 +334,37 @@ extern "C" int sdso_download_pyramid_level(sdso_ctx* ctx, int frame_slot, int lv
   SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return SDSO_OK;
 }
+
+// ------------------------------------------------------------------ self-test of the device Lie-group arithmetic
+#include "host_math.h"
+// k_track_lm and opt_step_body (the resident LM / GN loops) run host_math.h's SE3::exp, product and inverse ON THE DEVICE; this entry
+// point runs exactly those functions in a kernel so that the reference's Sophus fixtures (thirdparty/Sophus/sophus/test_se3.cpp:40-82,
+// tests.hpp:43-200) can be put through the device code as well as through the oracle (tests/test_oracle_se3.py).
+namespace sdso {
+__global__ void k_selftest_se3(int n, const double* __restrict__ xi, double* __restrict__ T, double* __restrict__ Tinv, double* __restrict__ Tmul) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const Se3 E = expSe3(xi + 6 * i);
+  const Se3 I = inverse(E);
+  const Se3 P = E * expSe3(xi + 6 * ((i + 1) % n));
+  for (int k = 0; k < 9; k++) { T[12 * i + k] = E.R[k]; Tinv[12 * i + k] = I.R[k]; Tmul[12 * i + k] = P.R[k]; }
+  for (int k = 0; k < 3; k++) { T[12 * i + 9 + k] = E.t[k]; Tinv[12 * i + 9 + k] = I.t[k]; Tmul[12 * i + 9 + k] = P.t[k]; }
+}
+}  // namespace sdso
+extern "C" int sdso_selftest_se3(sdso_ctx* ctx, int n, const double* xi, double* T_exp, double* T_inv, double* T_mul_next) {
+  if (!ctx) return SDSO_ERR_STATE;
+  SDSO_REQUIRE(ctx, n > 0 && xi && T_exp && T_inv && T_mul_next, "bad arguments");
+  SDSO_HIP(ctx, hipSetDevice(ctx->device));
+  double *d_xi = nullptr, *d_out = nullptr;
+  SDSO_HIP(ctx, hipMalloc(&d_xi, sizeof(double) * 6 * n));
+  if (hipMalloc(&d_out, sizeof(double) * 36 * n) != hipSuccess) { hipFree(d_xi); return sdso::fail(ctx, SDSO_ERR_HIP, "hipMalloc"); }
+  hipMemcpyAsync(d_xi, xi, sizeof(double) * 6 * n, hipMemcpyHostToDevice, ctx->stream);
+  hipLaunchKernelGGL(sdso::k_selftest_se3, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, n, (const double*)d_xi, d_out, d_out + 12 * n, d_out + 24 * n);
+  hipMemcpyAsync(T_exp, d_out, sizeof(double) * 12 * n, hipMemcpyDeviceToHost, ctx->stream);
+  hipMemcpyAsync(T_inv, d_out + 12 * n, sizeof(double) * 12 * n, hipMemcpyDeviceToHost, ctx->stream);
+  hipMemcpyAsync(T_mul_next, d_out + 24 * n, sizeof(double) * 12 * n, hipMemcpyDeviceToHost, ctx->stream);
+  const hipError_t e = hipStreamSynchronize(ctx->stream);
+  hipFree(d_xi); hipFree(d_out);
+  if (e != hipSuccess) return sdso::fail(ctx, SDSO_ERR_HIP, hipGetErrorString(e));
+  return SDSO_OK;
+}

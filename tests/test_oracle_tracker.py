@@ -132,3 +132,26 @@ def test_abort_on_min_res(oracle, prob):
     assert out.good == 0
     assert np.isnan(out.lastResiduals[0]) and not np.isnan(out.lastResiduals[prob["levels"] - 1])
     assert np.array_equal(T.Rt()[0], np.eye(3))           # outputs untouched on abort (CoarseTracker.cpp:1032-1047)
+
+
+def test_make_coarse_depth_oracle_equals_the_generator(oracle):
+    """makeCoarseDepthL0 STEP1-splat .. STEP5 (CoarseTracker.cpp:352-534): the oracle's C++ restatement (the checker of the device
+    kernels) and the numpy generator behind every synthetic tracking problem (sdso_amd/synth.py::make_pc) are two independent
+    restatements of the same loops — identical pc_n, order and floats, including pixels hit by several points and weights != 1."""
+    import pyoracle
+    from sdso_amd import synth
+    prob = synth.tracker_problem(w=320, h=240, npts=500, seed=2107)
+    u, v, idp = prob["points"]
+    rs = np.random.RandomState(8)
+    u = u.astype(np.int32).copy(); v = v.astype(np.int32).copy()
+    for dst, src in ((10, 400), (11, 400), (12, 400), (20, 300), (450, 3)):
+        u[dst], v[dst] = u[src], v[src]
+    wgt = rs.uniform(0.2, 3.0, len(u)).astype(np.float32)
+    idp = (idp * rs.uniform(0.9, 1.1, len(u))).astype(np.float32)
+    a = synth.make_pc(u, v, idp, wgt, prob["pyr_ref"])
+    b = pyoracle.make_coarse_depth(oracle, u, v, idp, wgt, prob["pyr_ref"])
+    assert len(a) == len(b) == prob["levels"]
+    for l in range(prob["levels"]):
+        assert len(a[l]["u"]) == len(b[l]["u"]) > 0
+        for k in ("u", "v", "idepth", "color"):
+            assert np.array_equal(a[l][k], b[l][k]), (l, k)

@@ -181,9 +181,9 @@ def test_make_pyramid_bit_exact(gpu_ctx, oracle, prob_kitti):
     assert np.array_equal(out, prob_kitti["pyr_ref"][2])
 
 
-def test_make_ref_bit_exact_bookkeeping(gpu_ctx):
-    """CoarseTracker::makeCoarseDepthL0 STEP1-5 on the device (sdso_track_make_ref) against the numpy restatement
-    (synth.make_pc, CoarseTracker.cpp:352-534): pc_n of every level, the ORDER of the template points and every float
+def test_make_ref_bit_exact_bookkeeping(gpu_ctx, oracle):
+    """CoarseTracker::makeCoarseDepthL0 STEP1-5 on the device (sdso_track_make_ref) against the oracle's C++ restatement
+    (oracle/orc_tracker.cpp::orc_make_coarse_depth, CoarseTracker.cpp:352-534): pc_n of every level, the ORDER of the template points and every float
     must be identical — this is the tracker's point-index bookkeeping.  The input has pixels hit by 2, 3 and 5 points
     with different weights (the splat must add them in point order)."""
     prob = synth.tracker_problem(w=640, h=480, npts=1500, seed=2031)
@@ -194,7 +194,8 @@ def test_make_ref_bit_exact_bookkeeping(gpu_ctx):
         u[dst], v[dst] = u[src], v[src]                       # collisions, also across the 256-thread / 2048-tile boundaries
     wgt = rs.uniform(0.2, 3.0, len(u)).astype(np.float32)
     idp = (idp * rs.uniform(0.9, 1.1, len(u))).astype(np.float32)
-    exp = synth.make_pc(u, v, idp, wgt, prob["pyr_ref"])
+    import pyoracle
+    exp = pyoracle.make_coarse_depth(oracle, u, v, idp, wgt, prob["pyr_ref"])
     gpu_ctx.upload_pyramid(21, prob["pyr_ref"])
     L = prob["levels"]
     pcn = np.zeros(8, np.int32)
