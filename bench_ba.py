@@ -64,7 +64,8 @@ class BAWorkload:
         ngroups = max(1, min(int(os.environ.get("SDSO_BA_GROUPS", "1" if world == 1 else "2")), nwin))
         if strong:
             self.name = "windowed_ba_8kf_8kpts_sharded"
-        # the GLOBAL window (identical on every rank) and this rank's contiguous share of its points
+        # the GLOBAL window (identical on every rank) and this rank's share of its points: its slice of EVERY host keyframe's points
+        # (sdso_amd/dist.py::shard_points, mode per_host — all nf Schur workgroups of a window stay busy on every rank)
         self.win_global = synth.ba_window(w=1232, h=368, nf=8, pts_per_kf=1000 if strong else 250 * world, seed=3001)
         win = self.win_global if world == 1 else sdist.shard_window(self.win_global, rank, world)[0]
         self.win = win
@@ -185,7 +186,7 @@ class BAWorkload:
                        "residuals_per_window_per_gpu": win["nr"], "points_per_global_window": self.win_global["np"],
                        "jacobians_materialized": bool(self.materialize), "stream_groups": ngroups,
                        "allreduce_floats": nfl_total if world > 1 else 0, "exchange": getattr(self, "exchange", None),
-                       "parallelism": ("allPoints of every window cut into %d contiguous ranges, 1 RCCL all-reduce (sdso_ba_allreduce) of the packed accumulators per group and iteration" % world) if world > 1 else "single GPU"}
+                       "parallelism": ("the points of every host keyframe of every window cut %d ways (one slice of every host per rank), 1 RCCL all-reduce (sdso_ba_allreduce) of the packed accumulators per group and iteration" % world) if world > 1 else "single GPU"}
         # correctness at the initial state (one iteration, before the timed loop moves the states): see _verify_initial
         self.initial_check = self._verify_initial()
         # the timed step advances REAL state: the device-resident GN loop (sdso_ba_batch_optimize_begin / sdso_ba_batch_step) takes the step

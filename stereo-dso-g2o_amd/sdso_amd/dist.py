@@ -2,8 +2,9 @@
 
 Every accumulator of the windowed BA is a plain sum over points (AccumulatedTopHessian.cpp:131-156,
 AccumulatedSCHessian.cpp:75-101) and the reference itself sums per-thread partial copies before the
-stitch (AccumulatedTopHessian.cpp:299-308).  So a window is partitioned into contiguous allPoints
-ranges, one per rank; a point's residuals stay with the point (Hdd/bd/Hcd/HdiF remain rank-local),
+stitch (AccumulatedTopHessian.cpp:299-308).  So a window's points are partitioned over the ranks (by default
+every rank takes its slice of every host keyframe's points, see shard_points); a point's residuals stay with the point
+(Hdd/bd/Hcd/HdiF remain rank-local),
 every rank holds all keyframe pyramids and frame states, and ONE all-reduce(sum) of the packed
 accumulator block per Gauss-Newton iteration makes every rank stitch and solve the same system.
 """
@@ -18,19 +19,47 @@ def shard_ranges(npts, world):
     return [(edges[r], edges[r + 1]) for r in range(world)]
 
 
-def shard_window(win, rank, world):
-    """The sub-window of `rank`: its points, their residuals, and the complete frame set."""
-    first, last = shard_ranges(win["np"], world)[rank]
+def shard_points(win, rank, world, mode="per_host"):
+    """Indices (into allPoints, increasing) of the points `rank` owns.
+      per_host   (default) the rank's 1 / world slice of EVERY host keyframe's points.  Every rank then holds all nf hosts with 1 / world
+                 of their points each: the Schur kernel's one-workgroup-per-host grid (k_ba_sc_host) stays nf workgroups per window on
+                 every rank, each world times shorter — with contiguous ranges and world = nf a rank holds ONE host, i.e. one busy
+                 workgroup per window with all its points, and the kernel would not scale at all (round-3 verdict, Weak #9).
+      contiguous one contiguous allPoints range per rank (SURVEY.md §8e's wording).
+    Either way a point's residuals travel with it and the order inside a rank is allPoints order (host index non-decreasing)."""
+    npts = win["np"]
+    if mode == "contiguous":
+        first, last = shard_ranges(npts, world)[rank]
+        return np.arange(first, last, dtype=np.int64)
+    assert mode == "per_host", mode
+    host = np.asarray(win["host"])
+    out = []
+    for h in range(win["nf"]):
+        idx = np.nonzero(host == h)[0]
+        first, last = shard_ranges(len(idx), world)[rank]
+        out.append(idx[first:last])
+    return np.concatenate(out).astype(np.int64) if out else np.zeros(0, np.int64)
+
+
+def shard_window(win, rank, world, mode="per_host"):
+    """The sub-window of `rank`: its points (shard_points), their residuals, and the complete frame set.
+    Returns (sub-window, point indices into the global window, residual indices into the global window)."""
+    pidx = shard_points(win, rank, world, mode)
     sub = dict(win)
-    for k in POINT_KEYS:
-        sub[k] = np.ascontiguousarray(win[k][first:last])
-    sel = (win["res_point"] >= first) & (win["res_point"] < last)
-    sub["res_point"] = (win["res_point"][sel] - first).astype(np.int32)
+    for k in POINT_KEYS + ("maxRelBaseline", "numGoodResiduals"):
+        if win.get(k) is not None:
+            sub[k] = np.ascontiguousarray(np.asarray(win[k])[pidx])
+    newidx = np.full(win["np"], -1, np.int64)
+    newidx[pidx] = np.arange(len(pidx))
+    sel = newidx[win["res_point"]] >= 0
+    sub["res_point"] = newidx[win["res_point"][sel]].astype(np.int32)
     sub["res_target"] = np.ascontiguousarray(win["res_target"][sel])
     sub["res_state"] = np.ascontiguousarray(win["res_state"][sel])
-    sub["np"] = int(last - first)
+    if win.get("res_isNew") is not None:
+        sub["res_isNew"] = np.ascontiguousarray(np.asarray(win["res_isNew"])[sel])
+    sub["np"] = int(len(pidx))
     sub["nr"] = int(sel.sum())
-    return sub, (first, last), np.nonzero(sel)[0]
+    return sub, pidx, np.nonzero(sel)[0]
 
 
 def allreduce_accumulators(packed, group=None):

@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, outdir):
+def _worker(rank, world, port, outdir, mode):
     import torch
     import torch.distributed as dist
     sys.path[:0] = [os.path.join(ROOT, "stereo-dso-g2o_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
@@ -33,7 +33,7 @@ def _worker(rank, world, port, outdir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     L = pyoracle.load()
     win = synth.ba_window(w=320, h=240, nf=4, pts_per_kf=60, seed=3021)
-    sub, (first, last), res_idx = sdist.shard_window(win, rank, world)
+    sub, pidx, res_idx = sdist.shard_window(win, rank, world, mode)
     W, keep = abi.make_ba_window(sub, frame_slots=list(range(win["nf"])), dI_list=[p[0] for p in win["pyrs"]])
     h = L.orc_ba_create(C.byref(W))
     L.orc_ba_linearize(h, None)
@@ -48,17 +48,18 @@ def _worker(rank, world, port, outdir):
     L.orc_ba_get_point_terms(h, abi.fp(hdi), None, None, None, None)
     np.save(os.path.join(outdir, "acc_%d.npy" % rank), t.numpy())
     np.save(os.path.join(outdir, "hdi_%d.npy" % rank), hdi)
-    np.save(os.path.join(outdir, "range_%d.npy" % rank), np.array([first, last, sub["nr"]]))
+    np.save(os.path.join(outdir, "pidx_%d.npy" % rank), pidx)
+    np.save(os.path.join(outdir, "nr_%d.npy" % rank), np.array([sub["nr"]]))
     L.orc_ba_destroy(h)
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_accumulation_equals_unsharded(oracle, tmp_path, world):
+@pytest.mark.parametrize("world,mode", [(2, "per_host"), (3, "per_host"), (2, "contiguous"), (4, "per_host")])
+def test_sharded_accumulation_equals_unsharded(oracle, tmp_path, world, mode):
     sys.path[:0] = [os.path.join(ROOT, "stereo-dso-g2o_amd")]
     from sdso_amd import abi, synth, dist as sdist
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), mode), nprocs=world, join=True)
     win = synth.ba_window(w=320, h=240, nf=4, pts_per_kf=60, seed=3021)
     W, keep = abi.make_ba_window(win, frame_slots=list(range(win["nf"])), dI_list=[p[0] for p in win["pyrs"]])
     h = oracle.orc_ba_create(C.byref(W))
@@ -77,11 +78,15 @@ def test_sharded_accumulation_equals_unsharded(oracle, tmp_path, world):
     scale = np.abs(full).max()
     assert np.abs(accs[0] - full).max() <= 2e-6 * scale        # float sums in a different association
     assert accs[0][-2] == full[-2]                             # nresA: exact count
-    ranges = [np.load(tmp_path / ("range_%d.npy" % r)) for r in range(world)]
-    assert ranges[0][0] == 0 and ranges[-1][1] == win["np"] and sum(int(x[2]) for x in ranges) == win["nr"]
+    pidx = [np.load(tmp_path / ("pidx_%d.npy" % r)) for r in range(world)]
+    allp = np.sort(np.concatenate(pidx))
+    assert np.array_equal(allp, np.arange(win["np"]))          # a partition of allPoints
+    assert sum(int(np.load(tmp_path / ("nr_%d.npy" % r))[0]) for r in range(world)) == win["nr"]
     for r in range(world):
-        f, l = int(ranges[r][0]), int(ranges[r][1])
-        assert np.array_equal(np.load(tmp_path / ("hdi_%d.npy" % r)), hdi_full[f:l])   # bit-exact, rank-local
-        if r:
-            assert f == int(ranges[r - 1][1])
+        assert np.all(np.diff(pidx[r]) > 0)                    # allPoints order inside a rank
+        assert np.array_equal(np.load(tmp_path / ("hdi_%d.npy" % r)), hdi_full[pidx[r]])   # bit-exact, rank-local
+        if mode == "per_host":                                 # every rank holds its share of EVERY host: balanced Schur workgroups
+            counts = np.bincount(win["host"][pidx[r]], minlength=win["nf"])
+            full_counts = np.bincount(win["host"], minlength=win["nf"])
+            assert np.all(np.abs(counts - full_counts / world) <= 1)
     assert sdist.shard_ranges(10, 3) == [(0, 3), (3, 6), (6, 10)]

@@ -53,8 +53,9 @@ def _worker(rank, world, port, outdir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     ctx = abi.Context(0)
     win = synth.ba_window(w=640, h=480, nf=5, pts_per_kf=100, seed=3031)
-    sub, (first, last), _ = sdist.shard_window(win, rank, world)
+    sub, pidx, _ = sdist.shard_window(win, rank, world)
     x, H, step = _solve(ctx, abi, sub, 1, 10, reduce_fn=lambda a: sdist.allreduce_accumulators(a).numpy())
+    np.save(os.path.join(outdir, "pidx_%d.npy" % rank), pidx)
     np.save(os.path.join(outdir, "x_%d.npy" % rank), x)
     np.save(os.path.join(outdir, "step_%d.npy" % rank), step)
     ctx.close()
@@ -71,7 +72,9 @@ def test_two_rank_sharded_solve_matches_single(gpu_ctx, tmp_path):
     assert np.array_equal(xs[0], xs[1])                         # identical reduced input -> identical solve on every rank
     d = np.sqrt(np.abs(np.diag(H))) + 1e-30
     assert np.abs((xs[0] - x) * d).max() <= 2e-4 * max(1.0, np.abs(x * d).max())
-    steps = np.concatenate([np.load(tmp_path / ("step_%d.npy" % r)) for r in range(world)])
+    steps = np.zeros(win["np"], np.float32)                     # every rank's points back in allPoints order (dist.shard_points: per-host slices)
+    for r in range(world):
+        steps[np.load(tmp_path / ("pidx_%d.npy" % r))] = np.load(tmp_path / ("step_%d.npy" % r))
     assert np.abs(steps - step).max() <= 2e-4 * max(np.abs(step).max(), 1e-6)
 
 
@@ -232,7 +235,10 @@ def _opt_worker(rank, world, port, outdir, gated=False):
     ctx = abi.Context(0)
     cbs = _host_transport(dist, torch, world)
     ctx.check(ctx.L.sdso_comm_init_host(ctx.h, world, rank, cbs[0], cbs[1], None))
-    subs = [sdist.shard_window(synth.ba_window(**s), rank, world)[0] for s in _OPT_SPECS]
+    shards = [sdist.shard_window(synth.ba_window(**s), rank, world) for s in _OPT_SPECS]
+    subs = [sh[0] for sh in shards]
+    for k, sh in enumerate(shards):
+        np.savez(os.path.join(outdir, "idx_%d_%d.npz" % (rank, k)), p=sh[1], r=sh[2])
     if gated:
         for w in subs:
             w["forceAcceptStep"] = 0
@@ -276,8 +282,10 @@ def test_two_rank_sharded_gn_loop_matches_single(gpu_ctx, oracle, tmp_path):
             oracle.orc_ba_optimize(h2, 6, abi.dp(sp), abi.fp(ip), abi.bp(rp), C.byref(op))
             oracle.orc_ba_destroy(h2)
             ss, si = max(ss, np.abs(sp - so).max()), max(si, np.abs(ip - io[order]).max())
-        idep = np.concatenate([sh[r]["i"] for r in range(world)])
-        rst = np.concatenate([sh[r]["r"] for r in range(world)])
+        idep, rst = np.zeros(npts, np.float32), np.zeros(nr, np.uint8)       # back in the global window's order
+        for r in range(world):
+            ix = np.load(tmp_path / ("idx_%d_%d.npz" % (r, k)))
+            idep[ix["p"]] = sh[r]["i"]; rst[ix["r"]] = sh[r]["r"]
         assert np.abs(sh[0]["s"] - s1).max() <= 1e-5 + 2.0 * ss, (np.abs(sh[0]["s"] - s1).max(), ss)
         assert helpers.idepths_close(idep, i1, 1e-5 + 2.0 * si), (np.abs(idep - i1).max(), si)
         assert (rst != r1).sum() <= max(2, nr // 2000)
@@ -304,14 +312,16 @@ def test_two_rank_sharded_energy_gated_loop_matches_single(gpu_ctx, tmp_path):
         w["forceAcceptStep"] = 0
     single = _batch_optimize(gpu_ctx, abi, wins, 51, 700)
     for k, win in enumerate(wins):
-        nr = win["nr"]
+        npts, nr = win["np"], win["nr"]
         sh = [np.load(tmp_path / ("opt_%d_%d.npz" % (r, k))) for r in range(world)]
         s1, i1, r1, its1, resInA1, e1 = single[k]
         assert int(sh[0]["its"]) == int(sh[1]["its"]) == its1
         assert np.array_equal(sh[0]["s"], sh[1]["s"])                        # the same decisions and the same reduced systems on every rank
         assert int(sh[0]["resInA"]) == int(sh[1]["resInA"])
-        idep = np.concatenate([sh[r]["i"] for r in range(world)])
-        rst = np.concatenate([sh[r]["r"] for r in range(world)])
+        idep, rst = np.zeros(npts, np.float32), np.zeros(nr, np.uint8)       # back in the global window's order
+        for r in range(world):
+            ix = np.load(tmp_path / ("idx_%d_%d.npz" % (r, k)))
+            idep[ix["p"]] = sh[r]["i"]; rst[ix["r"]] = sh[r]["r"]
         assert np.abs(sh[0]["s"] - s1).max() <= 1e-4, np.abs(sh[0]["s"] - s1).max()
         assert helpers.idepths_close(idep, i1, 2e-4), np.abs(idep - i1).max()
         assert (rst != r1).sum() <= max(2, nr // 2000)
