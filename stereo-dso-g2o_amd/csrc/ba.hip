@@ -538,8 +538,7 @@ static bool launch_sc_and_folds(sdso_ctx* ctx, const BaLaunch& L, const uint8_t*
 // which Schur kernel the process runs: 0 one workgroup per host (default; it also leaves BaDev::r_cj / the active-target bits the
 // back-substitution kernels read), 1 per-item MFMA (SDSO_SC_ITEMS), 2 VALU register tiles (SDSO_SC_REG)
 static int sc_variant() { static const int v = getenv("SDSO_SC_REG") ? 2 : getenv("SDSO_SC_ITEMS") ? 1 : 0; return v; }
-// SDSO_SC_V1=1: the rounds-1-3 form of the per-host kernel (every wave its own point groups and all tiles; A/B).  Default: k_ba_sc_host2.
-static bool sc_host_v1() { static const bool v = getenv("SDSO_SC_V1") && atoi(getenv("SDSO_SC_V1")) == 1; return v; }
+
 #define LAUNCH_RESUB(...) do { if (sc_variant() == 0) hipLaunchKernelGGL(k_ba_resub<true>, __VA_ARGS__); else hipLaunchKernelGGL(k_ba_resub<false>, __VA_ARGS__); } while (0)
 #define LAUNCH_RESUB_STEP(...) do { if (sc_variant() == 0) hipLaunchKernelGGL(k_ba_resub_step<true>, __VA_ARGS__); else hipLaunchKernelGGL(k_ba_resub_step<false>, __VA_ARGS__); } while (0)
 static void launch_accumulate(sdso_ctx* ctx, const BaLaunch& L, const uint8_t* pflag, bool marg) {
@@ -578,21 +577,24 @@ static bool launch_sc_and_folds(sdso_ctx* ctx, const BaLaunch& L, const uint8_t*
   const int nf = L.nf;
   const int shift = marg ? 0 : 1, mm = marg ? 1 : 0;
   const int sc_variant = sdso::sc_variant();
+  // the launch's common case — no marginalisation pass, no point filter, no linearized residual — takes the kernel's lean per-point loop
+  static const bool no_plain = getenv("SDSO_SC_NOPLAIN") != nullptr;     // (A/B)
+  const bool plain = !marg && !pflag && !L.any_lin && !no_plain;
   if (sc_variant == 0) {
     const bool want_async = async_sc && *async_sc && fold_top_too && defer_fold && !marg && side_stream(ctx);
     if (async_sc) *async_sc = want_async;
     if (want_async) {
       hipEventRecord(ctx->ev_fork, ctx->stream);
       hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0);
-      if (sc_host_v1()) hipLaunchKernelGGL(k_ba_sc_host, dim3(nf, L.nwin), dim3(BA_BLOCK), 0, ctx->stream2, L.d_arr, pflag, shift, mm, 1);
-      else hipLaunchKernelGGL(k_ba_sc_host2, dim3(nf, L.nwin), dim3(BA_BLOCK), 0, ctx->stream2, L.d_arr, pflag, shift, mm, 1);
+      if (plain) hipLaunchKernelGGL(k_ba_sc_host<true>, dim3(nf, L.nwin), dim3(BA_BLOCK), 0, ctx->stream2, L.d_arr, pflag, shift, mm, 1);
+      else hipLaunchKernelGGL(k_ba_sc_host<false>, dim3(nf, L.nwin), dim3(BA_BLOCK), 0, ctx->stream2, L.d_arr, pflag, shift, mm, 1);
       hipEventRecord(ctx->ev_join, ctx->stream2);
       return false;
     }
     {
       ProfScope ps(ctx, "k_ba_sc", 2);
-      if (sc_host_v1()) hipLaunchKernelGGL(k_ba_sc_host, dim3(nf, L.nwin), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr, pflag, shift, mm, 0);
-      else hipLaunchKernelGGL(k_ba_sc_host2, dim3(nf, L.nwin), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr, pflag, shift, mm, 0);
+      if (plain) hipLaunchKernelGGL(k_ba_sc_host<true>, dim3(nf, L.nwin), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr, pflag, shift, mm, 0);
+      else hipLaunchKernelGGL(k_ba_sc_host<false>, dim3(nf, L.nwin), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr, pflag, shift, mm, 0);
     }
     if (fold_top_too && defer_fold) return false;
     if (fold_top_too) hipLaunchKernelGGL(k_ba_fold_all, dim3(1 + 2 * nf * nf, L.nwin), dim3(128), 0, ctx->stream, L.d_arr, 1);

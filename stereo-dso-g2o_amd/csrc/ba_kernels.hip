@@ -548,6 +548,14 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_apply(const BaDev* __restrict__
     *(float4*)(rec) = make_float4(out[0], out[1], out[2], out[3]);
     *(float4*)(rec + 4) = make_float4(out[4], out[5], out[6], out[7]);
   }
+  else {
+    // the record of a residual that is not active holds zeros (like the fused kernel's): the Schur kernel adds / multiplies records without
+    // looking at their flags
+    *(float4*)(rec) = make_float4(0.f, 0.f, 0.f, 0.f);
+    *(float4*)(rec + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    *(float4*)(rec + 8) = make_float4(0.f, 0.f, 0.f, 0.f);
+    rec[12] = 0.f; rec[13] = 0.f;
+  }
   B.r_act[i] = act;
   rec[RR_FLAGS] = (float)act;
   B.r_state[i] = ns;
@@ -1275,6 +1283,11 @@ struct ScPointTerms {
   float HdiF, bdSumF, Hcd[4];                          // what the cross-point sums use (zeros when the point has no active residual)
   int mbits;                                           // bit t: the residual to target t is present and active
 };
+// PLAIN: no marginalisation pass, no point filter, no linearized residual in the launch (every GN iteration of the reference's live flow): all
+// active residuals go to the A sums, and — the record of a residual that is not active holds zeros (k_ba_apply, the fused kernels) — the
+// records are added as they are: x + 0 is exact, so the sums are the reference's to the bit without a select per term (the kernel is bound
+// by instruction issue: this loop on 16 of 64 lanes was half of its vector instructions).
+template <bool PLAIN = false>
 __device__ __forceinline__ void sc_point_terms(const BaDev& B, int p, const float* recs, unsigned ord, float onf, float prior, float delta,
                                                int shiftPriorToZero, int margMode, ScPointTerms& o) {
   float Hdd_A = 0, bd_A = 0, Hdd_L = 0, bd_L = 0, HcdA[4] = {0, 0, 0, 0}, HcdL[4] = {0, 0, 0, 0};
@@ -1286,6 +1299,13 @@ __device__ __forceinline__ void sc_point_terms(const BaDev& B, int p, const floa
     const float4 q0 = *(const float4*)(recs + t * 16 + 8);    // bd, Hdd, Hcd0, Hcd1
     const float4 q1 = *(const float4*)(recs + t * 16 + 12);   // Hcd2, Hcd3, flags, target
     const int fl = (int)q1.z;
+    if (PLAIN) {
+      const int act = fl & 1;
+      ngood += act; mbits |= act << t;
+      bd_A += q0.x; Hdd_A += q0.y;
+      HcdA[0] += q0.z; HcdA[1] += q0.w; HcdA[2] += q1.x; HcdA[3] += q1.y;
+      continue;
+    }
     const bool m = (fl & 1) != 0 && onf != 0.f;                // residual active (and the point taking part)
     const bool mA = m && !(fl & 2) && !margMode, mL = m && !mA;   // mode 0 vs mode 1 / 2 sums (AccumulatedTopHessian.cpp:54-71)
     const float rh[4] = {q0.z, q0.w, q1.x, q1.y};
@@ -1573,6 +1593,7 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_sc_mfma(const BaDev* __restrict
 #ifndef SDSO_SC_OCC
 #define SDSO_SC_OCC 2
 #endif
+template <bool PLAIN>
 __global__ __launch_bounds__(BA_BLOCK, SDSO_SC_OCC) void k_ba_sc_host(const BaDev* __restrict__ wins, const uint8_t* __restrict__ pflag, int shiftPriorToZero, int margMode, int signal = 0) {
   const BaDev& B = wins[blockIdx.y];
   if (ba_finished(B)) return;
@@ -1677,7 +1698,7 @@ __global__ __launch_bounds__(BA_BLOCK, SDSO_SC_OCC) void k_ba_sc_host(const BaDe
       int mbits = 0;
       if (lane < npts) {
         ScPointTerms T;
-        sc_point_terms(B, p0 + lane, stg + lane * SC_PSTRIDE, order, onf, prior, delta, shiftPriorToZero, margMode, T);
+        sc_point_terms<PLAIN>(B, p0 + lane, stg + lane * SC_PSTRIDE, order, onf, prior, delta, shiftPriorToZero, margMode, T);
         HdiF = T.HdiF; bdSumF = T.bdSumF; mbits = T.mbits;
 #pragma unroll
         for (int k = 0; k < 4; k++) Hcd[k] = T.Hcd[k];
@@ -1690,22 +1711,18 @@ __global__ __launch_bounds__(BA_BLOCK, SDSO_SC_OCC) void k_ba_sc_host(const BaDe
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    {  // phase 2: the group's four MFMA operand sets (points 4 u + kq), read from the parked records.  Points past npts carry a zero
-       // mask and zero terms in pt[]: exact no-ops.
+    {  // phase 2: the group's four MFMA operand sets (points 4 u + kq), read from the parked records as they are: the record of a
+       // residual that is not active (or of a target the point does not observe) holds zeros, and a point without an active residual,
+       // outside the marginalisation filter or past npts has HdiF = 0 and zero terms in pt[] — exact no-ops, no select needed.
       float zz[4][5], hx[4];
 #pragma unroll
       for (int u = 0; u < 4; u++) {
         const int q = 4 * u + kq;
         const float4 h0 = *(const float4*)(&pt[q][0]);
         const float4 h1 = *(const float4*)(&pt[q][4]);
-        const int mb = __float_as_int(h1.z);
         const float* base = stg + q * SC_PSTRIDE + asub;
 #pragma unroll
-        for (int tt = 0; tt < 4; tt++) {
-          const int t = 2 * tt + tsub;
-          const float r = base[t * 16];             // (rows of masked-off or absent targets are stale LDS: selected away)
-          zz[u][tt] = ((mb >> t) & 1) ? r : 0.f;
-        }
+        for (int tt = 0; tt < 4; tt++) zz[u][tt] = q < npts ? base[(2 * tt + tsub) * 16] : 0.f;   // (rows past npts are stale LDS)
         zz[u][4] = ci == 0 ? h0.z : ci == 1 ? h0.w : ci == 2 ? h1.x : ci == 3 ? h1.y : ci == 4 ? h0.y : 0.f;
         hx[u] = h0.x;
       }
@@ -1818,205 +1835,5 @@ __global__ __launch_bounds__(BA_BLOCK, SDSO_SC_OCC) void k_ba_sc_host(const BaDe
   }
 }
 
-
-// ------------------------------------------------------------------ Schur accumulation, one workgroup per host frame, tiles split over the waves
-// Round 4.  k_ba_sc_host above gives every wave its own 16-point groups and ALL 15 accumulator tiles (60 + 32 prefetch registers: 202 VGPRs,
-// two waves per SIMD), and ends with a tree over the waves' tiles through LDS: a workgroup is a chain of load -> park -> per-point terms ->
-// 60 MFMAs per 16 points on four independent waves, plus ~40 % of fixed cost (first load, tree, bins).  Here the four waves work on the SAME
-// 32-point group: all 256 threads bring its records in (four 16-byte loads per thread, requested a group ahead) and park them once in LDS,
-// eight lanes of every wave compute the per-point terms of eight points (sc_point_terms: bit-exact), and then every wave accumulates ITS
-// quarter of the tiles over all 32 points — 4 / 4 / 4 / 3 of the 15 tiles, 16 accumulator registers.  No tree: at the end every wave lays
-// its own tiles into the bins (mirror images for the lower triangle as before).  ~100 VGPRs and 22 KB of LDS, so four and more workgroups
-// fit a CU where two did, and a launch of 2048 workgroups is two rounds instead of four.
-// Tile (a, b), a <= b <= 4, of D' = Z^T diag(HdiF) Z (columns 16a.. x 16b..; column tile 4 = Hcd | bdSumF): owner wave and slot
-//   wave 0: (0,0) (0,1) (0,2) (0,3)     wave 1: (1,1) (1,2) (1,3) (0,4)     wave 2: (2,2) (2,3) (1,4) (2,4)     wave 3: (3,3) (3,4) (4,4)
-constexpr int SC2_GROUP = 32;
-__device__ __forceinline__ void sc2_tile(int wv, int k, int& a, int& b) {
-  const int ta[4][4] = {{0, 0, 0, 0}, {1, 1, 1, 0}, {2, 2, 1, 2}, {3, 3, 4, 4}};
-  const int tb[4][4] = {{0, 1, 2, 3}, {1, 2, 3, 4}, {2, 3, 4, 4}, {3, 4, 4, 4}};
-  a = ta[wv][k]; b = tb[wv][k];
-}
-template <int WV>
-__device__ __forceinline__ void sc2_accumulate(const float* stg, const float (*pt)[8], te_f4 (&acc)[4], int lane) {
-  constexpr int SC_PSTRIDE = 160;
-  const int ci = lane & 15, kq = lane >> 4;
-  const int tsub = ci >> 3, asub = ci & 7;
-#pragma unroll
-  for (int u = 0; u < SC2_GROUP / 4; u++) {
-    const int q = 4 * u + kq;
-    const float4 h0 = *(const float4*)(&pt[q][0]);
-    const float4 h1 = *(const float4*)(&pt[q][4]);
-    const int mb = __float_as_int(h1.z);
-    const float* base = stg + q * SC_PSTRIDE + asub;
-    float z[5];
-#pragma unroll
-    for (int tt = 0; tt < 4; tt++) {
-      constexpr bool need[4][4] = {{true, true, true, true}, {true, true, true, true}, {false, true, true, true}, {false, false, false, true}};   // column tiles wave WV reads (as A or B operand)
-      if (need[WV][tt]) {
-        const int t = 2 * tt + tsub;
-        const float r = base[t * 16];             // (rows of masked-off or absent targets are stale LDS: selected away)
-        z[tt] = ((mb >> t) & 1) ? r : 0.f;
-      } else z[tt] = 0.f;
-    }
-    z[4] = ci == 0 ? h0.z : ci == 1 ? h0.w : ci == 2 ? h1.x : ci == 3 ? h1.y : ci == 4 ? h0.y : 0.f;
-    const float hx = h0.x;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      constexpr int ta[4][4] = {{0, 0, 0, 0}, {1, 1, 1, 0}, {2, 2, 1, 2}, {3, 3, 4, 4}};
-      constexpr int tb[4][4] = {{0, 1, 2, 3}, {1, 2, 3, 4}, {2, 3, 4, 4}, {3, 4, 4, 4}};
-      if (WV == 3 && k == 3) continue;            // wave 3 owns three tiles
-      acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(hx * z[ta[WV][k]], z[tb[WV][k]], acc[k], 0, 0, 0);
-    }
-  }
-}
-#ifndef SDSO_SC2_OCC
-#define SDSO_SC2_OCC 3
-#endif
-__global__ __launch_bounds__(BA_BLOCK, SDSO_SC2_OCC) void k_ba_sc_host2(const BaDev* __restrict__ wins, const uint8_t* __restrict__ pflag, int shiftPriorToZero, int margMode, int signal = 0) {
-  const BaDev& B = wins[blockIdx.y];
-  if (ba_finished(B)) return;
-  const int nf = B.nf, h = blockIdx.x;
-  if (h >= nf) return;
-  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  constexpr int SC_PSTRIDE = 160;                                  // floats per parked point: the four point groups of an MFMA operand read land 32 banks apart
-  constexpr int STAGE = SC2_GROUP * SC_PSTRIDE;                    // 5120 floats
-  constexpr int BIN_E = 64 * 64, BIN_EB = BIN_E + 8 * 32;
-  static_assert(BIN_EB + 64 <= STAGE, "the bins lie over the stage");
-  __shared__ __align__(16) float stage[STAGE];
-  __shared__ __align__(16) float pt[SC2_GROUP][8];                // HdiF, bdSumF, Hcd[4], mask bits, -
-  const int ib = B.host_item_beg[h], ie = B.host_item_beg[h + 1];
-  const int pb = ib < ie ? B.items[ib].y : 0, pe = ib < ie ? B.items[ie - 1].z : 0;
-  te_f4 acc[4];
-#pragma unroll
-  for (int k = 0; k < 4; k++) acc[k] = (te_f4){0.f, 0.f, 0.f, 0.f};
-  // the records of group g (<= 32 points x nf x 64 B, contiguous): float4 chunk c = tid + 256 k; the per-point scalars of the group travel on
-  // lanes 0..7 of every wave (point 8 wv + lane)
-  float pr_next = 0.f, de_next = 0.f;
-  int pf_next = 1;
-  unsigned or_next = 0xffffffffu;
-  float4 vnext[4];
-  auto request = [&](int p0) {
-    const int n32 = min(SC2_GROUP, pe - p0);
-    const int nchunks = n32 > 0 ? n32 * nf * 4 : 0;
-    const float* rbase = B.r_rec + (size_t)(n32 > 0 ? p0 : pb) * nf * 16;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int c = tid + 256 * k;
-      vnext[k] = c < nchunks ? *(const float4*)(rbase + (size_t)c * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    const int q = 8 * wv + lane;
-    if (lane < 8 && q < n32) { pr_next = B.p_prior[p0 + q]; de_next = B.p_delta[p0 + q]; or_next = B.p_order[p0 + q]; pf_next = pflag ? (int)pflag[p0 + q] : 1; }
-  };
-  request(pb);
-  for (int p0 = pb; p0 < pe; p0 += SC2_GROUP) {
-    const int npts = min(SC2_GROUP, pe - p0);
-    {  // park: chunk c -> record c / 4 = point * nf + target, floats 4 (c & 3) ..
-      const int nchunks = npts * nf * 4;
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const int c = tid + 256 * k;
-        if (c < nchunks) {
-          const int rec = c >> 2, pl = nf == 8 ? rec >> 3 : rec / nf, t = rec - pl * nf;
-          *(float4*)(stage + pl * SC_PSTRIDE + t * 16 + 4 * (c & 3)) = vnext[k];
-        }
-      }
-    }
-    const float prior = pr_next, delta = de_next;
-    const float onf = pf_next ? 1.f : 0.f;
-    const unsigned order = or_next;
-    request(p0 + SC2_GROUP);                       // the next group's records travel while this one is worked on
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    {  // per-point terms: point 8 wv + lane on lanes 0..7 of every wave
-      const int q = 8 * wv + lane;
-      if (lane < 8) {
-        float HdiF = 0.f, bdSumF = 0.f, Hcd[4] = {0.f, 0.f, 0.f, 0.f};
-        int mbits = 0;
-        if (q < npts) {
-          ScPointTerms T;
-          sc_point_terms(B, p0 + q, stage + q * SC_PSTRIDE, order, onf, prior, delta, shiftPriorToZero, margMode, T);
-          HdiF = T.HdiF; bdSumF = T.bdSumF; mbits = T.mbits;
-#pragma unroll
-          for (int k = 0; k < 4; k++) Hcd[k] = T.Hcd[k];
-        }
-        *(float4*)(&pt[q][0]) = make_float4(HdiF, bdSumF, Hcd[0], Hcd[1]);
-        *(float4*)(&pt[q][4]) = make_float4(Hcd[2], Hcd[3], __int_as_float(mbits), 0.f);
-      }
-      // the JpJdF halves of the parked records -> BaDev::r_cj (the back-substitution's compact copy): two coalesced 16-byte stores per thread,
-      // behind the prefetch loads in program order
-      const int nhalf = npts * nf * 2;
-#pragma unroll
-      for (int k = 0; k < 2; k++) {
-        const int c2 = tid + 256 * k;
-        if (c2 < nhalf) {
-          const int rec = c2 >> 1, pl = nf == 8 ? rec >> 3 : rec / nf, t = rec - pl * nf;
-          const float4 qv = *(const float4*)(stage + pl * SC_PSTRIDE + t * 16 + 4 * (c2 & 1));
-          *(float4*)(B.r_cj + ((size_t)p0 * nf + rec) * 8 + 4 * (c2 & 1)) = qv;
-        }
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    switch (wv) {   // this wave's tiles over the group's eight 4-point steps
-      case 0: sc2_accumulate<0>(stage, pt, acc, lane); break;
-      case 1: sc2_accumulate<1>(stage, pt, acc, lane); break;
-      case 2: sc2_accumulate<2>(stage, pt, acc, lane); break;
-      default: sc2_accumulate<3>(stage, pt, acc, lane); break;
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the next group overwrites the stage and pt[]
-  }
-  // ---- the host's bins: every wave lays its own tiles out in LDS the way the bins lie in memory (over the stage: free since the last
-  // barrier); the lower triangle of D' as mirror images (accD(i,j,k) == accD(i,k,j)^T exactly, see k_ba_sc_host)
-  const int ci = lane & 15, kq = lane >> 4;
-  const int nf2 = nf * nf;
-  float* bins = stage;
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    int a, b;
-    sc2_tile(wv, k, a, b);
-    if (wv == 3 && k == 3) continue;
-#pragma unroll
-    for (int v = 0; v < 4; v++) {
-      const int Rr = 16 * a + 4 * kq + v, t1 = Rr >> 3, ra = Rr & 7;
-      const float val = acc[k][v];
-      if (b < 4) {
-        const int Cc = 16 * b + ci, t2 = Cc >> 3, cc = Cc & 7;
-        if (b > a || Rr <= Cc) {
-          bins[(t1 * 8 + t2) * 64 + ra * 8 + cc] = val;
-          if (Rr != Cc) bins[(t2 * 8 + t1) * 64 + cc * 8 + ra] = val;
-        }
-      } else if (a < 4) {
-        if (ci < 4) bins[BIN_E + t1 * 32 + ra * 4 + ci] = val;
-        if (ci == 4) bins[BIN_EB + t1 * 8 + ra] = val;
-      } else if (kq == 0) {                        // the corner: Hcc (16) and bc (4) of this host; k_ba_fold_all / the tail kernel add the hosts
-        float* hp = B.sc_part + (size_t)h * 20;
-        if (ci < 4) hp[v * 4 + ci] = val;
-        if (ci == 4) hp[16 + v] = val;
-      }
-    }
-  }
-  __syncthreads();
-  float* accD = B.accum + acc_off_D(nf);
-  float* accE = B.accum + acc_off_E(nf);
-  float* accEB = B.accum + acc_off_EB(nf);
-#pragma unroll 4
-  for (int blk = wv; blk < 64; blk += BA_BLOCK / 64) {
-    const int t1 = blk >> 3, t2 = blk & 7;
-    if (t1 < nf && t2 < nf) accD[(size_t)(h + t1 * nf + t2 * nf2) * 64 + lane] = bins[blk * 64 + lane];
-  }
-  {
-    const int idx = 64 * wv + lane, t1 = idx >> 5;
-    if (t1 < nf) accE[(size_t)(h + t1 * nf) * 32 + (idx & 31)] = bins[BIN_E + idx];
-  }
-  if (wv == 1 && (lane >> 3) < nf) accEB[(size_t)(h + (lane >> 3) * nf) * 8 + (lane & 7)] = bins[BIN_EB + lane];
-  if (signal) {
-    // side-stream launch (TAIL_WAIT_SC): every wave's stores are out, released at agent scope, before wave 0 bumps the counter
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (wv == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (lane == 0) __hip_atomic_fetch_add(&B.opt->sc_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-}
 
 }  // namespace sdso
