@@ -1590,12 +1590,9 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_sc_mfma(const BaDev* __restrict
 // (Round 3 tried the transposed split — wave a owns tile ROW a for all points of the host: 116 VGPRs and 8 KB of LDS, so all 1024
 //  workgroups of a 128-window launch are resident at once instead of two rounds of 512 — and measured it SLOWER, 91 against 72 us: the
 //  kernel is bound by the per-wave chain load -> MFMA over its point groups, which that split makes four times longer.)
-#ifndef SDSO_SC_OCC
-#define SDSO_SC_OCC 2
-#endif
 template <bool PLAIN>
-__global__ __launch_bounds__(BA_BLOCK, SDSO_SC_OCC) void k_ba_sc_host(const BaDev* __restrict__ wins, const uint8_t* __restrict__ pflag, int shiftPriorToZero, int margMode, int signal = 0) {
-  const BaDev& B = wins[blockIdx.y];
+__global__ __launch_bounds__(BA_BLOCK, 2) void k_ba_sc_host(const BaDev* __restrict__ wins, const uint8_t* __restrict__ pflag, int shiftPriorToZero, int margMode, int signal = 0) {
+  const BaDev& B = wins[blockIdx.y];       // (by value — all pointers in SGPRs, no scalar re-loads in the loop — measured equal: 131 vs 133 us)
   if (ba_finished(B)) return;
   const int nf = B.nf, h = blockIdx.x;
   if (h >= nf) return;
@@ -1675,7 +1672,8 @@ __global__ __launch_bounds__(BA_BLOCK, SDSO_SC_OCC) void k_ba_sc_host(const BaDe
     const float prior = pr_next, delta = de_next;
     const float onf = pf_next ? 1.f : 0.f;
     const unsigned order = or_next;
-    request(group_p0(gidx + 1), vnext);          // the next group's records travel while this one is worked on
+    request(group_p0(gidx + 1), vnext);          // the next group's records travel while this one is worked on.  (Requested behind this group's
+                                                 // stores instead — so that the wait for them never waits for a younger store — measured equal.)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
