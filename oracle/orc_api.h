@@ -160,6 +160,10 @@ int orc_make_coarse_depth(int levels, const int* w, const int* h, const float* c
                           const float* new_idepth, const float* weight, int* pc_n, float* const* pc_u, float* const* pc_v,
                           float* const* pc_idepth, float* const* pc_color);
 
+/* test instrumentation: smallest relative margin of the LM loop's accept / stop / cut-off-repeat decisions per level of the last
+ * orc_track_newest_coarse call (1e300 where a level took no decision) */
+void orc_track_last_margins(double* out5);
+
 /* ---- windowed BA (handle based; the handle deep-copies the window description) */
 typedef struct orc_ba orc_ba;
 orc_ba* orc_ba_create(const orc_ba_window_t* W);

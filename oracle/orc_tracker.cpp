@@ -217,6 +217,17 @@ extern "C" void orc_track_make_eval(const orc_track_params_t* prm, int lvl, cons
   make_eval(*prm, lvl, T, *aff_g2l, prm->coarseCutoffTH * levelCutoffRepeat, *ev);
 }
 
+// Test instrumentation (not in the reference): the smallest relative margin of the decisions the LM loop took on every level of the LAST
+// call — accept (`resNew[0]/resNew[1] < resOld[0]/resOld[1]`, :1004), stop (`inc.norm() > 1e-3`, :1022) and the cut-off repeat
+// (`resOld[5] > 0.6`, :897).  A path whose float sums differ in the last bits can only take another number of iterations where one of these
+// margins is of the size of that difference (tests/test_tracker_gpu.py::test_cluster_sizes_reproduce_the_iteration_counts).
+static double g_track_margin[5] = {1e300, 1e300, 1e300, 1e300, 1e300};
+extern "C" void orc_track_last_margins(double* out5) { for (int i = 0; i < 5; i++) out5[i] = g_track_margin[i]; }
+static void track_margin(int lvl, double a, double b) {
+  const double m = std::fabs(a - b) / std::max(std::max(std::fabs(a), std::fabs(b)), 1e-300);
+  if (m < g_track_margin[lvl]) g_track_margin[lvl] = m;
+}
+
 // CoarseTracker.cpp:827-1069 with the DSO-native LM of the commented block.
 extern "C" int orc_track_newest_coarse(const int* pc_n, const float* const* pc_u,
                                        const float* const* pc_v, const float* const* pc_idepth,
@@ -228,6 +239,7 @@ extern "C" int orc_track_newest_coarse(const int* pc_n, const float* const* pc_u
   for (int i = 0; i < 3; i++) out->lastFlowIndicators[i] = 1000;
   out->evaluations = 0; out->point_evals = 0; out->good = 0;
   const float lambdaExtrapolationLimit = 0.001f;
+  for (int i = 0; i < 5; i++) g_track_margin[i] = 1e300;
 
   SE3 refToNew_current;
   std::memcpy(refToNew_current.R, lastToNew->R, sizeof(double) * 9);
@@ -247,9 +259,11 @@ extern "C" int orc_track_newest_coarse(const int* pc_n, const float* const* pc_u
       out->evaluations++; out->point_evals += pc_n[lvl];
     };
     eval(refToNew_current, aff_g2l_current, resOld, wb);
+    track_margin(lvl, resOld[5], 0.6);
     while (resOld[5] > 0.6 && levelCutoffRepeat < 50) {  // :897-904
       levelCutoffRepeat *= 2;
       eval(refToNew_current, aff_g2l_current, resOld, wb);
+      track_margin(lvl, resOld[5], 0.6);
     }
     calcGSSSE(wb, ev, H, b);
     float lambda = 0.01;
@@ -311,6 +325,7 @@ extern "C" int orc_track_newest_coarse(const int* pc_n, const float* const* pc_u
       orc_track_eval_t evOld = ev;
       eval(refToNew_new, aff_g2l_new, resNew, wbNew);
       bool accept = (resNew[0] / resNew[1]) < (resOld[0] / resOld[1]);
+      track_margin(lvl, resNew[0] / resNew[1], resOld[0] / resOld[1]);
       if (accept) {
         calcGSSSE(wbNew, ev, H, b);
         for (int i = 0; i < 6; i++) resOld[i] = resNew[i];
@@ -324,6 +339,7 @@ extern "C" int orc_track_newest_coarse(const int* pc_n, const float* const* pc_u
       }
       double nrm = 0; for (int i = 0; i < 8; i++) nrm += inc[i] * inc[i];
       nrm = std::sqrt(nrm);
+      track_margin(lvl, nrm, 1e-3);
       if (!(nrm > 1e-3)) break;
     }
 

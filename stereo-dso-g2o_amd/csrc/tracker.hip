@@ -1142,7 +1142,7 @@ extern "C" int sdso_track_newest_coarse_batch(sdso_ctx* ctx, int nhyp, const int
   LmCluster* dc = (LmCluster*)((char*)ctx->scratch + jobs_bytes);
   // workgroups per hypothesis: as many as keep the whole grid resident at once (the members of a cluster wait for each other; one
   // 512-thread workgroup of this kernel fills a CU), eight at most.  SDSO_TRK_LM_CLUSTER=1 forces single workgroups.
-  static const int g_env = getenv("SDSO_TRK_LM_CLUSTER") ? atoi(getenv("SDSO_TRK_LM_CLUSTER")) : 0;
+  const int g_env = getenv("SDSO_TRK_LM_CLUSTER") ? atoi(getenv("SDSO_TRK_LM_CLUSTER")) : 0;   // (read per call: the tests walk the cluster sizes)
   const int slots8 = 8 * ((nhyp + 7) / 8);
   int G = std::min(LM_MAXG, (ctx->n_cu * 7 / 8) / slots8);   // (an eighth of the CUs stays free: a grid that needs every CU waits on any straggler)
   if (g_env > 0) G = std::min(G, g_env);

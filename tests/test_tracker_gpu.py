@@ -263,6 +263,50 @@ def test_track_hypotheses_in_lock_step(gpu_ctx, oracle, prob_small, prob_kitti):
     assert ngood >= 6
 
 
+def test_cluster_sizes_reproduce_the_iteration_counts(gpu_ctx, oracle, prob_small, prob_kitti, monkeypatch):
+    """k_track_lm spreads a hypothesis over a cluster of G workgroups; G follows the device's occupancy, and the split of the points
+    changes the order of the float sums.  The LM iteration / evaluation counts are bookkeeping the caller sees: for EVERY cluster size
+    1..8, on eight hypotheses in one call, they must be the oracle's — except where the oracle itself sat on a decision threshold: a level
+    whose counts differ must have taken an accept / stop / repeat decision with a relative margin below 1e-5 (the size of the order-of-
+    summation differences in E / n; measured margins of the decisions that do NOT flip: > 1e-4).  Poses agree to 1e-5 either way."""
+    _setup(gpu_ctx, prob_small, 1, 2)
+    _setup(gpu_ctx, prob_kitti, 3, 4)
+    rs = np.random.RandomState(29)
+    hyps = []
+    for k in range(8):
+        prob, r, f = (prob_small, 1, 2) if k % 2 else (prob_kitti, 3, 4)
+        xi = np.zeros(6) if k < 2 else rs.normal(0, [0.02, 0.02, 0.1, 0.003, 0.003, 0.003])
+        hyps.append((prob, r, f, synth.se3_exp(xi)))
+    n = len(hyps)
+    prms = (abi.TrackParams * n)(*[helpers.track_params(h[0]) for h in hyps])
+    ref = []
+    for k, (prob, r, f, T0) in enumerate(hyps):
+        To, affo, outo = helpers.oracle_track(oracle, prob, prms[k], T0, (0.0, 0.0))
+        m = np.zeros(5)
+        oracle.orc_track_last_margins(abi.dp(m))
+        ref.append((To, affo, outo, m))
+    refs = np.array([h[1] for h in hyps], np.int32); frames = np.array([h[2] for h in hyps], np.int32)
+    flips = 0
+    for G in range(1, 9):
+        monkeypatch.setenv("SDSO_TRK_LM_CLUSTER", str(G))
+        Ts = (abi.SE3 * n)(*[abi.SE3.from_Rt(*h[3]) for h in hyps])
+        affs = (abi.Aff * n)(*[abi.Aff(0, 0) for _ in hyps])
+        outs = (abi.TrackResult * n)()
+        gpu_ctx.check(gpu_ctx.L.sdso_track_newest_coarse_batch(gpu_ctx.h, n, abi.ip(refs), abi.ip(frames), prms, Ts, affs, outs))
+        for k in range(n):
+            To, affo, outo, m = ref[k]
+            assert outs[k].good == outo.good, (G, k)
+            R, t = Ts[k].Rt(); Ro, to = To.Rt()
+            assert np.abs(t - to).max() <= 1e-5 and np.abs(R - Ro).max() <= 1e-5, (G, k)
+            if list(outs[k].iterations) != list(outo.iterations) or outs[k].evaluations != outo.evaluations:
+                flips += 1
+                lv = [l for l in range(5) if outs[k].iterations[l] != outo.iterations[l]]
+                # counts can only diverge from the first level on which the oracle took a knife-edge decision
+                assert lv and min(m[l] for l in range(max(lv), 5)) <= 1e-5, (G, k, list(outs[k].iterations), list(outo.iterations), m)
+    monkeypatch.delenv("SDSO_TRK_LM_CLUSTER")
+    assert flips <= 2                                   # (none on these problems at the time of writing)
+
+
 @pytest.mark.parametrize("modes", [(-1.0, -1.0), (0.0, 0.0), (-1.0, 1e8), (1e12, -1.0)])
 def test_track_affine_modes(gpu_ctx, oracle, prob_small, modes):
     """setting_affineOptModeA/B variants (main_dso_pangolin.cpp:315-338: mode 1 sets both 0, mode 2 sets both -1): the LM solves the
