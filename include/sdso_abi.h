@@ -385,6 +385,15 @@ int sdso_ba_batch_set_materialize(sdso_ctx* ctx, int materialize);
 /* 1: every solve of the batch's resident loop also writes EnergyFunctional::lastHS / lastbS (EnergyFunctional.cpp:909-910; log-only in
  * the reference) so that sdso_ba_get_post_state can return them; 0 (default): they are not materialised (37 KB per window and iteration). */
 int sdso_ba_batch_keep_system(sdso_ctx* ctx, int on);
+/* Shape of the exchange of a SHARDED batch inside the resident loop (points of every window cut over the ranks of the ctx's
+ * communicator; the accumulators are sums over points like the reference's per-thread copies, AccumulatedTopHessian.cpp:299-308):
+ *   0 (default)  sdso_ba_allreduce = one all-reduce of the packed block; every rank stitches and solves every window;
+ *   1            sdso_ba_allreduce = one reduce-scatter by window (rank r receives the sums of windows [r*nwin/N, (r+1)*nwin/N)), the
+ *                solve of a window runs on that rank only, and x / xAd / nres of every window go round by one all-gather
+ *                (136 + 8 nf^2 + 2 floats per window) inside sdso_ba_batch_solve_step: half the xGMI bytes per link.
+ * Mode 1 applies when nwin divides by the ranks, the loop is the accepted-step flow and lastHS / lastbS are not kept; otherwise the call
+ * falls back to the all-reduce.  The results are the same bits either way (the sums are the same numbers). */
+int sdso_ba_batch_exchange_mode(sdso_ctx* ctx, int mode);
 /* lambda is subject to the windows' solverMode exactly as in solveSystemF (SOLVER_USE_GN -> 0, SOLVER_FIX_LAMBDA -> 1e-5,
  * EnergyFunctional.cpp:840-846); the members of a batch must share one solverMode. */
 int sdso_ba_batch_solve(sdso_ctx* ctx, double lambda, int orthogonalize_x);

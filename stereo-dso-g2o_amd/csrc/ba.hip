@@ -133,6 +133,8 @@ struct BaBatch {
   bool eager_fold = false;       // sdso_ba_batch_accum_dev handed the block's address out: never defer the folds
   bool folded = true;            // the packed accumulator block holds the folded sums of the latest accumulate (false: the top partials and the
                                  // per-host Hcc / bc are still unfolded — the fused tail kernel folds them itself; ensure_folded() for anyone else)
+  int exchange_mode = 0;         // sdso_ba_batch_exchange_mode: 0 all-reduce + the solve on every rank, 1 reduce-scatter by window + all-gather of x
+  bool scattered = false;        // the latest sdso_ba_allreduce was the reduce-scatter: only this rank's windows hold summed accumulators
   bool keep_system = false;      // sdso_ba_batch_keep_system: the resident loop's solves also write lastHS / lastbS (37 KB per window and iteration)
   int gather = 1;                // tap gather of the fused kernel: 1 cooperative quads (default), 2 LDS-DMA rounds, 0 direct (SDSO_BA_GATHER / SDSO_BA_DIRECT_TAPS at batch_create)
 };
@@ -1395,6 +1397,7 @@ extern "C" int sdso_ba_batch_accumulate(sdso_ctx* ctx) {
   BaBatch* Bt = get_batch(ctx);
   if (!Bt) return sdso::fail(ctx, SDSO_ERR_STATE, "no batch");
   join_sc(ctx, Bt);
+  Bt->scattered = false;
   bool async = batch_async_sc(ctx, Bt);
   Bt->folded = launch_fused(ctx, batch_launch(Bt), Bt->materialize, Bt->gather, 3, batch_defers_fold(ctx, Bt), &async);
   Bt->sc_async = async;
@@ -1417,6 +1420,7 @@ extern "C" int sdso_ba_batch_schur(sdso_ctx* ctx) {
   BaBatch* Bt = get_batch(ctx);
   if (!Bt) return sdso::fail(ctx, SDSO_ERR_STATE, "no batch");
   join_sc(ctx, Bt);
+  Bt->scattered = false;
   bool async = batch_async_sc(ctx, Bt);
   Bt->folded = launch_fused(ctx, batch_launch(Bt), Bt->materialize, Bt->gather, 2, batch_defers_fold(ctx, Bt), &async);
   Bt->sc_async = async;
@@ -1437,6 +1441,7 @@ extern "C" int sdso_ba_batch_set_materialize(sdso_ctx* ctx, int materialize) {
 extern "C" int sdso_ba_batch_solve(sdso_ctx* ctx, double lambda, int orthogonalize_x) {
   BaBatch* Bt = get_batch(ctx);
   if (!Bt) return sdso::fail(ctx, SDSO_ERR_STATE, "no batch");
+  SDSO_REQUIRE(ctx, !Bt->scattered, "the accumulators were reduce-scattered by window (exchange mode 1): sdso_ba_batch_solve_step consumes them");
   // solveSystem's overrides of lambda (EnergyFunctional.cpp:840-846), as in the single-window call
   if (Bt->W[0]->solverMode & SOLVER_USE_GN) lambda = 0;
   if (Bt->W[0]->solverMode & SOLVER_FIX_LAMBDA) lambda = 1e-5;
@@ -1532,6 +1537,7 @@ extern "C" int sdso_ba_marginalize_frame(int nf, int idx, const double* prior8, 
 // ------------------------------------------------------------------ device-resident Gauss-Newton loop (ba_opt.hip)
 namespace sdso {
 int comm_nranks(sdso_ctx* ctx);                                                            // comm.hip
+int comm_rank(sdso_ctx* ctx);                                                              // comm.hip
 bool comm_present(sdso_ctx* ctx);                                                          // comm.hip
 int comm_allgather_floats(sdso_ctx* ctx, const float* send, float* recv, size_t nfloats);  // comm.hip
 int comm_max_int(sdso_ctx* ctx, int* value);                                               // comm.hip
@@ -1543,12 +1549,13 @@ struct OptBufs {
   float* d_gather = nullptr; size_t gather_cap = 0;
   BaOptOut* d_out = nullptr; BaOptOut* h_out = nullptr; size_t out_cap = 0;
   float* d_lpart = nullptr; size_t lpart_cap = 0;
+  float* d_solrec = nullptr; size_t solrec_cap = 0;
 };
 static std::map<sdso_ctx*, OptBufs*> g_optbufs;
 void free_optbufs(sdso_ctx* ctx) {
   OptBufs* b = nullptr;
   if (!reg_take(g_optbufs, ctx, b) || !b) return;
-  hipFree(b->d_sums); hipFree(b->d_pack); hipFree(b->d_gather); hipFree(b->d_out); hipFree(b->d_lpart);
+  hipFree(b->d_sums); hipFree(b->d_pack); hipFree(b->d_gather); hipFree(b->d_out); hipFree(b->d_lpart); hipFree(b->d_solrec);
   if (b->h_out) hipHostFree(b->h_out);
   delete b;
 }
@@ -1834,7 +1841,23 @@ static int opt_solve_step(sdso_ctx* ctx, OptRun& R, double lambda, int orth, boo
     R.iteration++;
     return SDSO_OK;
   }
-  launch_tail(ctx, R.L, lambda, flags);
+  BaBatch* Bt = R.W[0]->in_batch ? get_batch(ctx) : nullptr;
+  if (Bt && Bt->scattered) {
+    // reduce-scatter exchange: this rank holds the summed accumulators of its own windows only — it solves those, and the solutions
+    // (x, xAd, nres: one record per window) go round by all-gather; every rank then steps its own points of every window, as below
+    Bt->scattered = false;
+    const int per = nwin / R.nranks, first = comm_rank(ctx) * per;
+    BaLaunch own = R.L;
+    own.d_arr = R.L.d_arr + first; own.nwin = per;
+    launch_tail(ctx, own, lambda, flags);
+    const size_t rf = (size_t)sol_rec_floats(R.L.n, R.L.nf);
+    int rc = grow(ctx, R.B->d_solrec, R.B->solrec_cap, rf * nwin);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_ba_sol_record, dim3(nwin), dim3(256), 0, ctx->stream, R.L.d_arr, first, per, R.B->d_solrec, 0);
+    if ((rc = comm_allgather_floats(ctx, R.B->d_solrec + rf * first, R.B->d_solrec, rf * per))) return rc;
+    hipLaunchKernelGGL(k_ba_sol_record, dim3(nwin), dim3(256), 0, ctx->stream, R.L.d_arr, first, per, R.B->d_solrec, 1);
+  } else
+    launch_tail(ctx, R.L, lambda, flags);
   if (R.L.max_nblk_pts) LAUNCH_RESUB_STEP( gp, dim3(BA_BLOCK), 0, ctx->stream, R.L.d_arr, -1, R.B->d_sums, R.sums_stride);
   const int rc = opt_consume(ctx, R, 0, false, R.L.max_nblk_pts > 0);
   R.iteration++;
@@ -1879,6 +1902,18 @@ int optimize_resident_single(sdso_ctx* ctx, BaWindowDev* W, int mnumOptIts, sdso
   }
   for (int it = 0; it < N; it++) if ((rc = opt_iteration(ctx, R, it))) return rc;
   return opt_finish(ctx, R, res);
+}
+// sdso_ba_allreduce asks: is this exchange the reduce-scatter by window?  Only inside the accepted-step resident loop of a sharded batch
+// whose windows divide over the ranks, with the fused tail kernel, and without lastHS / lastbS being kept (they exist on the solving
+// rank only); anything else takes the all-reduce, whatever mode the batch carries.
+bool ba_batch_scatter_begin(sdso_ctx* ctx) {
+  BaBatch* Bt = get_batch(ctx);
+  if (!Bt || Bt->exchange_mode != 1 || !tail_enabled() || !reg_has(g_optruns, ctx)) return false;
+  OptRun* R = reg_get(g_optruns, ctx);
+  if (!R || !R->active || !R->exchange || R->gated || R->keep_hs || R->W != Bt->W) return false;
+  if ((int)Bt->W.size() % R->nranks != 0) return false;
+  Bt->scattered = true;
+  return true;
 }
 void free_optrun(sdso_ctx* ctx) {
   OptRun* r = nullptr;
@@ -1982,6 +2017,14 @@ extern "C" int sdso_ba_get_state(sdso_ctx* ctx, int win, double* state_out /* nf
     SDSO_HIP(ctx, hipMemcpy(t.data(), W->d.r_state, nr, hipMemcpyDeviceToHost));
     for (int j = 0; j < nr; j++) res_state_out[W->perm[j]] = t[j];
   }
+  return SDSO_OK;
+}
+
+extern "C" int sdso_ba_batch_exchange_mode(sdso_ctx* ctx, int mode) {
+  BaBatch* Bt = get_batch(ctx);
+  if (!Bt) return sdso::fail(ctx, SDSO_ERR_STATE, "no batch");
+  SDSO_REQUIRE(ctx, mode == 0 || mode == 1, "exchange mode: 0 all-reduce, 1 reduce-scatter by window");
+  Bt->exchange_mode = mode;
   return SDSO_OK;
 }
 

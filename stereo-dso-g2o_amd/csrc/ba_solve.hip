@@ -915,6 +915,35 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_resub_step(const BaDev* __restr
   }
 }
 
+// The solution of a window as one record of floats: x (n doubles), the adjoint products xAd (nf^2 * 8) and the residual count nres of the
+// accumulate — everything the kernels after the solve read of it (k_ba_resub_step: x, xAd; k_ba_opt_step: x, nres).  Sharded windows
+// under the reduce-scatter exchange are solved on one rank each: that rank packs (unpack = 0, its windows [first, first + count)), the
+// records travel by all-gather, every other rank unpacks (unpack = 1, the windows outside that range).  grid.x = windows of the batch.
+__host__ __device__ inline int sol_rec_floats(int n, int nf) { return 2 * n + nf * nf * 8 + 2; }
+__global__ __launch_bounds__(256) void k_ba_sol_record(const BaDev* __restrict__ wins, int first, int count, float* __restrict__ recs, int unpack) {
+  const int w = blockIdx.x;
+  const bool own = w >= first && w < first + count;
+  if (unpack ? own : !own) return;
+  const BaDev& B = wins[w];
+  const int n = B.n, nf = B.nf, tid = threadIdx.x;
+  double* x = B.sol + 3 * ((size_t)n * n + n);
+  float* xAd = const_cast<float*>(B.t_xAd);
+  float* nres = B.accum + acc_off_nres(nf);
+  float* rec = recs + (size_t)w * sol_rec_floats(n, nf);
+  double* rx = (double*)rec;                 // (records are an even number of floats: 8-byte aligned)
+  float* ra = rec + 2 * n;
+  float* rn = ra + nf * nf * 8;
+  if (unpack) {
+    if (tid < n) x[tid] = rx[tid];
+    for (int e = tid; e < nf * nf * 8; e += 256) xAd[e] = ra[e];
+    if (tid < 2) nres[tid] = rn[tid];
+  } else {
+    if (tid < n) rx[tid] = x[tid];
+    for (int e = tid; e < nf * nf * 8; e += 256) ra[e] = xAd[e];
+    if (tid < 2) rn[tid] = nres[tid];
+  }
+}
+
 // FullSystem::backupState / doStepFromBackup / loadSateBackup for the points.  op: 0 backup, 1 step, 2 restore
 // op 3 = backup + step in one pass (the resident loop never restores)
 __global__ __launch_bounds__(BA_BLOCK) void k_ba_points_op(const BaDev* __restrict__ wins, int op, float stepfacD, float* __restrict__ sums /* per block: sumID, sumNID */,

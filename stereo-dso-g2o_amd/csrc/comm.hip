@@ -24,6 +24,7 @@
 namespace sdso {
 void* ba_batch_accum_block(sdso_ctx* ctx, size_t* nfloats);            // ba.hip
 void* ba_window_accum_block(sdso_ctx* ctx, int win, size_t* nfloats);  // ba.hip
+bool ba_batch_scatter_begin(sdso_ctx* ctx);                            // ba.hip: the batch's exchange is the reduce-scatter by window
 
 struct RcclApi {
   void* lib = nullptr;
@@ -32,6 +33,7 @@ struct RcclApi {
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*ReduceScatter)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 // SDSO_RCCL_LIB overrides the library name (a deployment with its own RCCL build; tests force the "not loadable" path with it)
@@ -58,8 +60,9 @@ static RcclApi* rccl_api(std::string* why) {
       api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.lib, "ncclCommDestroy");
       api.AllReduce = (decltype(api.AllReduce))dlsym(api.lib, "ncclAllReduce");
       api.AllGather = (decltype(api.AllGather))dlsym(api.lib, "ncclAllGather");
+      api.ReduceScatter = (decltype(api.ReduceScatter))dlsym(api.lib, "ncclReduceScatter");
       api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.lib, "ncclGetErrorString");
-      if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllReduce || !api.AllGather) { err = "RCCL symbols missing"; api.lib = nullptr; }
+      if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllReduce || !api.AllGather || !api.ReduceScatter) { err = "RCCL symbols missing"; api.lib = nullptr; }
     }
   });
   if (!api.lib) { if (why) *why = err; return nullptr; }
@@ -102,6 +105,7 @@ namespace sdso {
 // used by the resident GN loop (ba.hip): ranks of ctx's communicator (1 without one), the all-gather of the per-rank energy / break-test
 // records, and the max over ranks of a host int (collective, synchronises the ctx stream)
 int comm_nranks(sdso_ctx* ctx) { auto c = comm_of(ctx); return c ? c->nranks : 1; }
+int comm_rank(sdso_ctx* ctx) { auto c = comm_of(ctx); return c ? c->rank : 0; }
 bool comm_present(sdso_ctx* ctx) { return comm_of(ctx) != nullptr; }
 int comm_allgather_floats(sdso_ctx* ctx, const float* send, float* recv, size_t nfloats) {
   auto c = comm_of(ctx);
@@ -239,11 +243,37 @@ static int allreduce_block(sdso_ctx* ctx, void* ptr, size_t nfloats) {
   return SDSO_OK;
 }
 
+// The other shape of the same exchange (sdso_ba_batch_exchange_mode(ctx, 1)): the windows of the batch lie one after the other in the block,
+// so a reduce-scatter hands rank r the SUMMED accumulators of windows [r * nwin / N, (r + 1) * nwin / N) and nothing of the others — half
+// the bytes of the all-reduce on every xGMI link; the solve of a window then runs on one rank only and x comes back by all-gather
+// (ba.hip: opt_solve_step).  In place: rank r's slice of the block is both its send and its receive segment.
+static int reduce_scatter_block(sdso_ctx* ctx, void* ptr, size_t nfloats) {
+  auto c = comm_of(ctx);
+  SDSO_REQUIRE(ctx, c, "no communicator: call sdso_comm_init (or sdso_comm_attach) first");
+  SDSO_REQUIRE(ctx, ptr && nfloats > 0 && nfloats % c->nranks == 0, "the block does not divide over the ranks");
+  SDSO_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t per = nfloats / c->nranks;
+  if (c->host()) {   // the host transport sums every slice; only this rank's comes back, so the rest of the block is left as RCCL leaves it
+    std::lock_guard<std::mutex> hg(c->h_mutex);
+    c->h_send.resize(nfloats);
+    SDSO_HIP(ctx, hipMemcpyAsync(c->h_send.data(), ptr, sizeof(float) * nfloats, hipMemcpyDeviceToHost, ctx->stream));
+    SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (c->h_allreduce(c->h_user, c->h_send.data(), nfloats)) return sdso::fail(ctx, SDSO_ERR_STATE, "the host transport's all-reduce failed");
+    SDSO_HIP(ctx, hipMemcpyAsync((float*)ptr + per * c->rank, c->h_send.data() + per * c->rank, sizeof(float) * per, hipMemcpyHostToDevice, ctx->stream));
+    SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SDSO_OK;
+  }
+  RcclApi* a = rccl_api(nullptr);
+  SDSO_NCCL(ctx, a, a->ReduceScatter(ptr, (float*)ptr + per * c->rank, per, ncclFloat32, ncclSum, c->comm, ctx->stream));
+  return SDSO_OK;
+}
+
 extern "C" int sdso_ba_allreduce(sdso_ctx* ctx) {
   if (!ctx) return SDSO_ERR_STATE;
   size_t n = 0;
   void* p = ba_batch_accum_block(ctx, &n);
   SDSO_REQUIRE(ctx, p, "no batch: sdso_ba_batch_create first");
+  if (ba_batch_scatter_begin(ctx)) return reduce_scatter_block(ctx, p, n);
   return allreduce_block(ctx, p, n);
 }
 

@@ -69,3 +69,38 @@ def allreduce_accumulators(packed, group=None):
     t = packed if isinstance(packed, torch.Tensor) else torch.from_numpy(packed)
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t
+
+
+def window_owner_range(nwin, rank, world):
+    """Windows [first, last) of a batch that `rank` solves under the reduce-scatter exchange (sdso_ba_batch_exchange_mode(ctx, 1)):
+    equal contiguous runs, in batch order — the windows' accumulator blocks lie one after the other, so a run of windows is one
+    segment of the reduce-scatter.  nwin must divide by world (the library falls back to the all-reduce otherwise)."""
+    assert nwin % world == 0, (nwin, world)
+    per = nwin // world
+    return rank * per, (rank + 1) * per
+
+
+def reduce_scatter_windows(blocks, rank, world, group=None):
+    """blocks: [nwin, accum_floats] partial sums of this rank, all windows.  Returns the SUMMED blocks of this rank's windows
+    (window_owner_range).  nccl (= RCCL): one reduce_scatter_tensor; gloo has no reduce-scatter: all-reduce, then the slice."""
+    import torch
+    import torch.distributed as dist
+    t = blocks if isinstance(blocks, torch.Tensor) else torch.from_numpy(blocks)
+    first, last = window_owner_range(t.shape[0], rank, world)
+    if dist.get_backend(group) == "nccl":
+        out = torch.empty_like(t[first:last])
+        dist.reduce_scatter_tensor(out, t.contiguous(), op=dist.ReduceOp.SUM, group=group)
+        return out
+    full = t.clone()
+    dist.all_reduce(full, op=dist.ReduceOp.SUM, group=group)
+    return full[first:last].clone()
+
+
+def allgather_window_records(own, world, group=None):
+    """own: [nwin / world, k] records of this rank's windows (x, xAd, nres of the solve).  Returns [nwin, k] in batch order on every rank."""
+    import torch
+    import torch.distributed as dist
+    t = own if isinstance(own, torch.Tensor) else torch.from_numpy(own)
+    outs = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(outs, t.contiguous(), group=group)
+    return torch.cat(outs, 0)

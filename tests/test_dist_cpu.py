@@ -90,3 +90,58 @@ def test_sharded_accumulation_equals_unsharded(oracle, tmp_path, world, mode):
             full_counts = np.bincount(win["host"], minlength=win["nf"])
             assert np.all(np.abs(counts - full_counts / world) <= 1)
     assert sdist.shard_ranges(10, 3) == [(0, 3), (3, 6), (6, 10)]
+
+
+
+def _scatter_worker(rank, world, port, outdir, nwin):
+    import torch
+    import torch.distributed as dist
+    sys.path[:0] = [os.path.join(ROOT, "stereo-dso-g2o_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
+    import pyoracle
+    from sdso_amd import abi, synth, dist as sdist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    L = pyoracle.load()
+    nf = 4
+    na = abi.accum_floats(nf)
+    blocks = np.zeros((nwin, na), np.float32)
+    for k in range(nwin):
+        win = synth.ba_window(w=320, h=240, nf=nf, pts_per_kf=40, seed=3100 + k)
+        sub = sdist.shard_window(win, rank, world)[0]
+        W, keep = abi.make_ba_window(sub, frame_slots=list(range(nf)), dI_list=[p[0] for p in win["pyrs"]])
+        h = L.orc_ba_create(C.byref(W))
+        L.orc_ba_linearize(h, None)
+        L.orc_ba_apply_res(h)
+        L.orc_ba_accumulate(h)
+        L.orc_ba_get_accumulators(h, abi.fp(blocks[k]))
+        L.orc_ba_destroy(h)
+    # reference shape: all-reduce, every rank looks at every window
+    full = sdist.allreduce_accumulators(blocks.copy()).numpy()
+    # the other shape: reduce-scatter by window, a per-window record from the owner, all-gather
+    own = sdist.reduce_scatter_windows(blocks.copy(), rank, world).numpy()
+    first, last = sdist.window_owner_range(nwin, rank, world)
+    # stand-in for the solve: any deterministic function of a window's summed block (here: f64 sum, the exact residual count, 6 entries)
+    record = lambda b: np.concatenate([[np.float32(b.astype(np.float64).sum()), b[-2]], b[:6]]).astype(np.float32)
+    recs = sdist.allgather_window_records(np.stack([record(b) for b in own]), world).numpy()
+    np.savez(os.path.join(outdir, "sc_%d.npz" % rank), own=own, full=full, recs=recs, want=np.stack([record(b) for b in full]), first=first, last=last)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,nwin", [(2, 4), (3, 3)])
+def test_reduce_scatter_by_window_then_allgather_equals_allreduce(tmp_path, world, nwin):
+    """The data flow of the library's second exchange shape (include/sdso_abi.h: sdso_ba_batch_exchange_mode 1; csrc/comm.hip
+    reduce_scatter_block + ba.hip opt_solve_step) on gloo: rank r ends with the summed blocks of windows [r*nwin/N, (r+1)*nwin/N) — the
+    same bits the all-reduce leaves there — and after the all-gather every rank holds one record per window, in batch order, equal to
+    what it would have computed from the all-reduced block itself."""
+    mp.spawn(_scatter_worker, args=(world, _free_port(), str(tmp_path), nwin), nprocs=world, join=True)
+    outs = [np.load(tmp_path / ("sc_%d.npz" % r)) for r in range(world)]
+    covered = []
+    for r, o in enumerate(outs):
+        first, last = int(o["first"]), int(o["last"])
+        covered += list(range(first, last))
+        assert np.array_equal(o["own"], o["full"][first:last])          # the owner's sums are the all-reduce's
+        assert np.array_equal(o["recs"], o["want"])                     # every rank, every window, batch order
+        assert np.array_equal(o["recs"], outs[0]["recs"])
+        assert o["full"][:, -2].min() > 0                               # (windows with residuals: the count entry is live)
+    assert covered == list(range(nwin))                                 # every window has exactly one owner
