@@ -98,6 +98,10 @@ class BAWorkload:
             G.nwin = len(ids)
             G.ctx.check(G.ctx.L.sdso_ba_batch_create(G.ctx.h, G.nwin, abi.ip(G.ids)))
             G.ctx.check(G.ctx.L.sdso_ba_batch_set_materialize(G.ctx.h, self.materialize))
+            # SDSO_BA_EXCHANGE=scatter: reduce-scatter by window + all-gather of x instead of the all-reduce (include/sdso_abi.h:
+            # sdso_ba_batch_exchange_mode) — half the bytes per xGMI link; same results.  Applies when the group's windows divide by N.
+            self.exchange_mode = 1 if (world > 1 and os.environ.get("SDSO_BA_EXCHANGE", "allreduce") == "scatter") else 0
+            G.ctx.check(G.ctx.L.sdso_ba_batch_exchange_mode(G.ctx.h, self.exchange_mode))
             # (the all-reduce payload; sdso_ba_batch_accum_dev is NOT called here: handing the block's address out makes every
             #  accumulate fold eagerly, and the single-rank step leaves the folds to the fused tail kernel)
             nfl_total += int(G.ctx.L.sdso_ba_accum_floats(nf)) * G.nwin
@@ -186,6 +190,7 @@ class BAWorkload:
                        "residuals_per_window_per_gpu": win["nr"], "points_per_global_window": self.win_global["np"],
                        "jacobians_materialized": bool(self.materialize), "stream_groups": ngroups,
                        "allreduce_floats": nfl_total if world > 1 else 0, "exchange": getattr(self, "exchange", None),
+                       "exchange_shape": ("reduce-scatter by window + all-gather of x" if getattr(self, "exchange_mode", 0) else "all-reduce, solve on every rank") if world > 1 else None,
                        "parallelism": ("the points of every host keyframe of every window cut %d ways (one slice of every host per rank), 1 RCCL all-reduce (sdso_ba_allreduce) of the packed accumulators per group and iteration" % world) if world > 1 else "single GPU"}
         # correctness at the initial state (one iteration, before the timed loop moves the states): see _verify_initial
         self.initial_check = self._verify_initial()
