@@ -805,14 +805,67 @@ __device__ __forceinline__ void lm_wave_ldlt(double a, double rhs, int n, double
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// wave 0 of k_track_lm: finalise the evaluation (calcGSSSE :580-595, calcRes :783-789, the expressions of k_track_finalize), take
-// the LM decisions (lane 0, LmCore::consume_pre), solve for the increment (wave), propose the trial pose (lane 0).  The accepted
-// system lives in the wave's registers — lane 8i + j holds H(i,j) and b(i) — between the evaluations (Hacc / bacc): no copy through LDS.
-// Returns the call's `done`.
-__device__ __forceinline__ bool lm_wave_step(LmCore& core, const float* F, const int* I, double& Hacc, double& bacc) {
+// SE3::exp of host_math.h (expSe3 / expSo3, the same expressions element by element) for a WAVE-UNIFORM tangent: the four
+// trigonometric values it needs — sin, cos of theta / 2 and of theta — come from ONE sincos evaluated on two lanes (lane 0: theta / 2,
+// lane 1: theta) instead of four calls in a row on one lane; everything else is evaluated by every lane on the same numbers.
+__device__ __forceinline__ Se3 lm_exp_se3_wave(const double* xi) {
+  const V3 om{{xi[3], xi[4], xi[5]}};
+  const double th2 = om[0] * om[0] + om[1] * om[1] + om[2] * om[2];
+  const double th = std::sqrt(th2);
+  double sv, cv;
+  sincos((threadIdx.x & 1) ? th : 0.5 * th, &sv, &cv);
+  const double s_half = lm_readlane(sv, 0), c_half = lm_readlane(cv, 0), s_full = lm_readlane(sv, 1), c_full = lm_readlane(cv, 1);
+  double im, re;
+  if (th < kSophusEps) {
+    const double th4 = th2 * th2;
+    im = 0.5 - (1.0 / 48.0) * th2 + (1.0 / 3840.0) * th4;
+    re = 1.0 - 0.5 * th2 + (1.0 / 384.0) * th4;
+  } else {
+    im = s_half / th;
+    re = c_half;
+  }
+  Se3 T;
+  T.R = rotationFromQuat(re, im * om[0], im * om[1], im * om[2]);
+  const M3 Om = skew(om);
+  const M3 Om2 = mul(Om, Om);
+  M3 V;
+  if (th < kSophusEps) {
+    V = T.R;
+  } else {
+    const double a = (1.0 - c_full) / (th * th);
+    const double b = (th - s_full) / (th * th * th);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) V[i] = (i % 4 == 0 ? 1.0 : 0.0) + a * Om[i] + b * Om2[i];
+  }
+  T.t = mul(V, V3{{xi[0], xi[1], xi[2]}});
+  return T;
+}
+
+// wave 0 of k_track_lm, between two evaluations: finalise the sums (calcGSSSE :580-595, calcRes :783-789, the expressions of
+// k_track_finalize), take the LM decisions (LmCore::consume_pre), solve for the increment, propose the trial pose
+// (LmCore::propose_post) and build the request of the next evaluation (fill_eval) — the serial part of a call, 28 times per call.
+// Everything here is WAVE-UNIFORM arithmetic: all 64 lanes evaluate the same scalar expressions on the same numbers (LDS broadcast
+// reads), so the loads of a stage are requested together, nothing waits for one lane's chain of LDS round trips, and only the
+// stores are lane 0's.  (History: decisions, SE3::exp and fill_eval as scalar code of lane 0 / thread 0 with LmCore in LDS between
+// them: 2 150 + 3 830 + 2 150 cycles per evaluation, profiles/r04_lm_stamps.txt.)  The common case — the evaluation is consumed and
+// another LM step is proposed on the same level — runs in this form; what ends a level or repeats an evaluation with a doubled
+// cut-off (five to ten times per call) goes through LmCore's own methods on lane 0, exactly as the host driver runs them.
+// The accepted system lives in the wave's registers — lane 8i + j holds H(i,j) and b(i) — between the evaluations (Hacc / bacc).
+// Returns the call's `done`; otherwise `ev`, `s_lvl` and the call's counters are those of the next evaluation.
+__device__ __forceinline__ bool lm_wave_step(LmCore& core, const float* F, const int* I, double& Hacc, double& bacc, sdso_track_eval_t& ev,
+                                             const float (*s_Ki)[9], const int* s_n, int& s_lvl) {
   const int lane = threadIdx.x & 63;
   const int i = lane >> 3, j = lane & 7;
+  // ---- every LDS input of the decision, requested together
   const int nE = I[0], nSat = I[1], nWarp = I[2], nShift = I[3];
+  const float f45 = F[45], f46 = F[46], f47 = F[47];
+  const int phase = core.phase, lvl = core.lvl, it0 = core.iteration;
+  const float lam0 = core.lambda, lcr = core.levelCutoffRepeat;
+  const double old0 = core.oldres[0], old1 = core.oldres[1];
+  const int maxIt = core.p.maxIterations[lvl];
+  double nrm = 0;
+#pragma unroll
+  for (int r = 0; r < 8; r++) { const double v = core.inc[r]; nrm += v * v; }
   const int npad = (nWarp + 3) & ~3;
   double Hnew, bnew;
   {
@@ -828,27 +881,53 @@ __device__ __forceinline__ bool lm_wave_step(LmCore& core, const float* F, const
     bnew = u;
   }
   LMS(7);
-  int act = 0, take = 0;
-  if (lane == 0) {
-    double res[6];
-    res[0] = (double)F[45];
-    res[1] = (double)nE;
-    res[2] = (double)F[46] / ((double)(float)nShift + 0.1);
-    res[3] = 0;
-    res[4] = (double)F[47] / ((double)(float)nShift + 0.1);
-    res[5] = (double)((float)nSat / (float)nE);
-    bool tk = false;
-    act = core.consume_pre(res, tk);
-    take = tk ? 1 : 0;
+  double res[6];
+  res[0] = (double)f45;
+  res[1] = (double)nE;
+  res[2] = (double)f46 / ((double)(float)nShift + 0.1);
+  res[3] = 0;
+  res[4] = (double)f47 / ((double)(float)nShift + 0.1);
+  res[5] = (double)((float)nSat / (float)nE);
+  // ---- LmCore::consume_pre, the case that proposes another step on this level (uniform); anything else: lane 0, below
+  const float lambdaExtrapolationLimit = 0.001f;
+  bool fast, take, accept = false;
+  float lambda = lam0;
+  int iteration = it0;
+  if (phase == 0) {
+    fast = !(res[5] > 0.6 && lcr < 50) && 0 < maxIt;                                  // :897-904
+    take = true; lambda = 0.01f; iteration = 0;
+  } else {
+    accept = (res[0] / res[1]) < (old0 / old1);                                       // :1004
+    take = accept;
+    if (accept) lambda *= 0.5;
+    else { lambda *= 4; if (lambda < lambdaExtrapolationLimit) lambda = lambdaExtrapolationLimit; }
+    iteration = it0 + 1;
+    fast = std::sqrt(nrm) > 1e-3 && iteration < maxIt;                                // :1022, :927
   }
-  act = __builtin_amdgcn_readfirstlane(act);
-  take = __builtin_amdgcn_readfirstlane(take);
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  int act = 1;
+  if (fast) {
+    if (lane == 0) {
+      if (take) {
+#pragma unroll
+        for (int r = 0; r < 6; r++) core.oldres[r] = res[r];
+      }
+      if (phase == 1 && accept) { core.affCur = core.affNew; core.cur = core.Tnew; }
+      core.lambda = lambda; core.iteration = iteration;
+      core.out.iterations[lvl]++;
+    }
+  } else {
+    int a = 0, t = 0;
+    if (lane == 0) { bool tk = false; a = core.consume_pre(res, tk); t = tk ? 1 : 0; }
+    act = __builtin_amdgcn_readfirstlane(a);
+    take = __builtin_amdgcn_readfirstlane(t) != 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (act) lambda = core.lambda;               // (cannot happen with the predicates above; kept so that the two forms can never disagree silently)
+  }
   LMS(8);
   if (act) {
     if (take) { Hacc = Hnew; bacc = bnew; }
     // LmCore::solve_inc on the wave
-    const double lam1 = 1 + core.lambda;
+    const double lam1 = 1 + lambda;
     double a = Hacc;
     if (i == j) a *= lam1;
     const double nb = -bacc;
@@ -893,15 +972,86 @@ __device__ __forceinline__ bool lm_wave_step(LmCore& core, const float* F, const
       }
     }
     LMS(9);
+    // the state the proposal starts from and the level's constants of the next request, requested together (lane 0's stores above are
+    // behind the wave barrier that ends lm_wave_ldlt)
+    Se3 cur;
+#pragma unroll
+    for (int r = 0; r < 9; r++) cur.R[r] = core.cur.R[r];
+#pragma unroll
+    for (int r = 0; r < 3; r++) cur.t[r] = core.cur.t[r];
+    const sdso_aff_t affCur = core.affCur;
+    const float fxl = core.p.fx[lvl], fyl = core.p.fy[lvl], cxl = core.p.cx[lvl], cyl = core.p.cy[lvl];
+    const int wl = core.p.w[lvl], hl = core.p.h[lvl];
+    float Ki[9];
+#pragma unroll
+    for (int r = 0; r < 9; r++) Ki[r] = s_Ki[lvl][r];
+    const float expR = core.p.ref_exposure, expN = core.p.new_exposure;
+    const double refA = core.p.ref_aff_g2l.a, refB = core.p.ref_aff_g2l.b;
+    const float cutoff = core.p.coarseCutoffTH * core.levelCutoffRepeat, huber = core.p.huberTH;
+    // LmCore::propose_post (:966-1000), uniform
+    float extrapFac = 1;
+    if (lambda < lambdaExtrapolationLimit) extrapFac = sqrtf(sqrtf(lambdaExtrapolationLimit / lambda));
+    double incScaled[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) { incv[r] *= extrapFac; incScaled[r] = incv[r]; }
+#pragma unroll
+    for (int r = 0; r < 3; r++) incScaled[r] *= SCALE_XI_ROT;
+#pragma unroll
+    for (int r = 3; r < 6; r++) incScaled[r] *= SCALE_XI_TRANS;
+    incScaled[6] *= SCALE_A;
+    incScaled[7] *= SCALE_B;
+    double sum = 0;
+#pragma unroll
+    for (int r = 0; r < 8; r++) sum += incScaled[r];
+    if (!std::isfinite(sum)) {
+#pragma unroll
+      for (int r = 0; r < 8; r++) incScaled[r] = 0;
+    }
+    const Se3 Tnew = lm_exp_se3_wave(incScaled) * cur;
+    sdso_aff_t affNew = affCur;
+    affNew.a += incScaled[6];
+    affNew.b += incScaled[7];
+    // fill_eval for (Tnew, affNew)
+    sdso_track_eval_t evl;
+    evl.lvl = lvl; evl.w = wl; evl.h = hl;
+    evl.fx = fxl; evl.fy = fyl; evl.cx = cxl; evl.cy = cyl;
+    float Rf[9];
+#pragma unroll
+    for (int r = 0; r < 9; r++) { evl.Ki[r] = Ki[r]; Rf[r] = (float)Tnew.R[r]; }
+    mul3f(Rf, Ki, evl.RKi);
+#pragma unroll
+    for (int r = 0; r < 3; r++) evl.t[r] = (float)Tnew.t[r];
+    double a2[2];
+    affFromTo(expR, expN, refA, refB, affNew.a, affNew.b, a2);
+    evl.affLL[0] = (float)a2[0]; evl.affLL[1] = (float)a2[1];
+    evl.ref_b0 = (float)refB;
+    evl.cutoffTH = cutoff;
+    evl.huberTH = huber;
     if (lane == 0) {
 #pragma unroll
       for (int r = 0; r < 8; r++) core.inc[r] = incv[r];
-      core.propose_post();
+      core.Tnew = Tnew; core.affNew = affNew;
+      core.phase = 1;
+      core.reqT = Tnew; core.reqAff = affNew;
+      ev = evl;
+      core.out.evaluations++;
+      core.out.point_evals += s_n[lvl];
     }
+    LMS(10);
+    return false;
   }
   LMS(10);
+  // lane 0 has set the next request itself (a new level, a repeated evaluation) or ended the call
   int done = 0;
-  if (lane == 0) done = core.done ? 1 : 0;
+  if (lane == 0) {
+    done = core.done ? 1 : 0;
+    if (!done) {
+      fill_eval(core.p, core.lvl, core.reqT, core.reqAff, core.p.coarseCutoffTH * core.levelCutoffRepeat, ev);
+      s_lvl = core.lvl;
+      core.out.evaluations++;
+      core.out.point_evals += s_n[core.lvl];
+    }
+  }
   return __builtin_amdgcn_readfirstlane(done) != 0;
 }
 
@@ -949,7 +1099,14 @@ __global__ __launch_bounds__(LM_BLOCK) void k_track_lm(LmJob* __restrict__ jobs,
   __shared__ int s_n[SDSO_PYR_LEVELS];
   const int tid = threadIdx.x, wv = tid >> 6;
   const bool leader = g == 0;
-  if (tid < SDSO_PYR_LEVELS) { s_pc[tid] = J.pc[tid]; s_img[tid] = J.img[tid]; s_n[tid] = J.n[tid]; }
+  __shared__ float s_Ki[SDSO_PYR_LEVELS][9];                           // K[lvl]^-1 (fill_eval's inv3f, CoarseTracker.cpp:129-130): per level, not per evaluation
+  if (tid < SDSO_PYR_LEVELS) {
+    s_pc[tid] = J.pc[tid]; s_img[tid] = J.img[tid]; s_n[tid] = J.n[tid];
+    const float K[9] = {J.p.fx[tid], 0, J.p.cx[tid], 0, J.p.fy[tid], J.p.cy[tid], 0, 0, 1};
+    float Ki[9];
+    inv3f(K, Ki);
+    for (int k = 0; k < 9; k++) s_Ki[tid][k] = Ki[k];
+  }
   if (tid == 0) {
     core.init(J.p, J.T, J.aff);                 // every member: the same state machine on the same inputs
     s_done = 0; s_abort = 0;
@@ -968,14 +1125,14 @@ __global__ __launch_bounds__(LM_BLOCK) void k_track_lm(LmJob* __restrict__ jobs,
   for (int u = 0; u < LM_UNROLL; u++) qc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
   const int first = g * LM_BLOCK + tid, stride = G * LM_BLOCK;
   // every trip is one evaluation; the loop ends for all threads together (the flags are read behind a barrier)
+  if (tid == 0) {                               // the first request; every later one is built by wave 0 at the end of lm_wave_step
+    fill_eval(core.p, core.lvl, core.reqT, core.reqAff, core.p.coarseCutoffTH * core.levelCutoffRepeat, ev);
+    s_lvl = core.lvl;
+    core.out.evaluations++;
+    core.out.point_evals += s_n[core.lvl];
+  }
+  __syncthreads();
   for (int e = 1; e <= 1024; e++) {
-    if (tid == 0) {
-      fill_eval(core.p, core.lvl, core.reqT, core.reqAff, core.p.coarseCutoffTH * core.levelCutoffRepeat, ev);
-      s_lvl = core.lvl;
-      core.out.evaluations++;
-      core.out.point_evals += s_n[core.lvl];
-    }
-    __syncthreads();
     LMSL(0);
     const int lvl = s_lvl, n = s_n[lvl];
     if (lvl != qlvl) {                          // (uniform) first evaluation on this level: the points move into registers
@@ -1032,7 +1189,7 @@ __global__ __launch_bounds__(LM_BLOCK) void k_track_lm(LmJob* __restrict__ jobs,
       return;
     }
     LMSL(6);
-    if (wv == 0) { const bool d = lm_wave_step(core, F, I, Hacc, bacc); if (tid == 0) s_done = d ? 1 : 0; }
+    if (wv == 0) { const bool d = lm_wave_step(core, F, I, Hacc, bacc, ev, s_Ki, s_n, s_lvl); if (tid == 0) s_done = d ? 1 : 0; }
     __syncthreads();
     LMSL(11);
     if (s_done) break;                          // (every member reaches the same verdict)
