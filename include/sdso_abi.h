@@ -371,8 +371,9 @@ int sdso_ba_keep_projections(sdso_ctx* ctx, int win, int on);
  *   [all-reduce(sum) of sdso_ba_batch_accum_dev across ranks]
  *   sdso_ba_batch_solve      : stitch + solveSystemF + resubstituteF              (enqueue only)
  *   sdso_ba_batch_get_x      : lastX of every window (synchronises)
- * Windows in the SOLVER_SVD / SOLVER_ORTHOGONALIZE_SYSTEM modes (EnergyFunctional.cpp:876-900, 924-965) are accepted: their solve is
- * host-driven, window by window (sdso_ba_batch_solve then synchronises; sdso_ba_batch_optimize runs sdso_ba_optimize's loop per window). */
+ * Windows in the SOLVER_SVD / SOLVER_ORTHOGONALIZE_SYSTEM modes (EnergyFunctional.cpp:876-900, 924-965) run on the device like the others
+ * (one workgroup per window: projected system, parallel-order Jacobi eigen-decomposition or the pivoted LDL^T; enqueue only, resident
+ * loop included); the members of a batch share one solver branch. */
 int sdso_ba_batch_create(sdso_ctx* ctx, int nwin, const int* wins);
 int sdso_ba_batch_accumulate(sdso_ctx* ctx);
 /* = sdso_ba_batch_linearize (linearizeAll + applyRes + accumulateAF) followed by sdso_ba_batch_schur (accumulateLF/SCF + folds),

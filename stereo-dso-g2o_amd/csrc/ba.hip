@@ -7,6 +7,7 @@
 #include "ba_opt.hip"
 #include "ba_tail.hip"
 #include "ba_host.h"
+#include "ba_solve_alt.hip"   // (after ba_host.h: the SOLVER_* bits and setting_solverModeDelta)
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -121,6 +122,7 @@ struct BaLaunch {
   const BaDev* d_arr; int nwin; int max_nblk_res, max_nblk_pts, max_chunks, max_items, nf, n;
   bool any_lin;   // some window holds linearized residuals -> the mode-1 accumulation has work to do
   bool tiled;     // the windows' t_img are 4x2-tiled level-0 images (same for every window of a launch)
+  bool alt;       // the windows' solverMode takes solveSystemF's SVD / orthogonalised-system branches (ba_solve_alt.hip): never the fused tail kernel
 };
 struct BaBatch {
   std::vector<int> wins;
@@ -268,6 +270,9 @@ static int upload_window_impl(sdso_ctx* ctx, int win, const sdso_ba_window_t* Wi
   d.affA_fixed = Win->affineOptModeA < 0; d.affB_fixed = Win->affineOptModeB < 0;
   d.jfix = getenv("SDSO_BA_JSWAP") && atoi(getenv("SDSO_BA_JSWAP")) ? 0 : 1;
   W->solverMode = Win->solverMode; W->forceAccept = Win->forceAcceptStep; W->affA = Win->affineOptModeA; W->affB = Win->affineOptModeB;
+  d.solver_mode = Win->solverMode;
+  d.have_first_frame = 0;
+  for (int f = 0; f < nf; f++) if (Win->frameID[f] == 0) d.have_first_frame = 1;
   const int n = d.n;
 
   // ---- host mirror
@@ -669,8 +674,16 @@ static void launch_fold_deferred(sdso_ctx* ctx, const BaLaunch& L) {   // what l
 }
 // stitch + solveSystemF (default branch) + resubstitute.  orth bit 0: x -= P x; bit 1: lambda of the window's resident loop.
 // folded = false: the accumulate left the folds to the tail kernel (launch_fused with defer_fold)
+static bool solve_on_host() { return getenv("SDSO_BA_SOLVE_HOST") != nullptr; }   // A/B: the SVD / orthogonalised-system branches through solve_system_host
 static void launch_solve(sdso_ctx* ctx, const BaLaunch& L, double lambda, int orth, bool folded = true, bool wait_sc = false) {
   const int n = L.n;
+  if (L.alt) {   // solveSystemF's SVD / orthogonalised-system branches: stitch, then one workgroup per window (ba_solve_alt.hip)
+    if (!folded) launch_fold_deferred(ctx, L);
+    launch_stitch(ctx, L);
+    hipLaunchKernelGGL(k_ba_solve_alt, dim3(L.nwin), dim3(ALT_NT), 0, ctx->stream, L.d_arr, lambda, orth);
+    if (L.max_nblk_pts > 0) LAUNCH_RESUB( dim3(L.max_nblk_pts, L.nwin), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr);
+    return;
+  }
   if (tail_enabled()) {
     const int flags = TAIL_HS | ((orth & 1) ? TAIL_ORTH : 0) | ((orth & 2) ? TAIL_LAMBDA_DEV : 0) | (L.any_lin ? TAIL_TOPL : 0) | (folded ? 0 : TAIL_FOLD) | (wait_sc ? TAIL_WAIT_SC : 0);
     launch_tail(ctx, L, lambda, flags);
@@ -715,6 +728,7 @@ static BaLaunch single(BaWindowDev* W) {
   L.max_chunks = W->d.nchunks; L.max_items = W->d.nitems; L.nf = W->d.nf; L.n = W->d.n;
   L.any_lin = W->has_lin_cached;
   L.tiled = W->d.tiledT > 0;
+  L.alt = (W->solverMode & (SOLVER_SVD | SOLVER_ORTHOGONALIZE_SYSTEM)) != 0;
   return L;
 }
 
@@ -1018,7 +1032,7 @@ static int solve_system_host(sdso_ctx* ctx, BaWindowDev* W, int iteration, doubl
 static int solve_system(sdso_ctx* ctx, BaWindowDev* W, int iteration, double lambda) {
   if (W->solverMode & SOLVER_USE_GN) lambda = 0;
   if (W->solverMode & SOLVER_FIX_LAMBDA) lambda = 1e-5;
-  if (W->solverMode & (SOLVER_SVD | SOLVER_ORTHOGONALIZE_SYSTEM)) return solve_system_host(ctx, W, iteration, lambda);
+  if ((W->solverMode & (SOLVER_SVD | SOLVER_ORTHOGONALIZE_SYSTEM)) && solve_on_host()) return solve_system_host(ctx, W, iteration, lambda);
   const int orth = (W->solverMode & SOLVER_ORTHOGONALIZE_X) || (iteration >= 2 && (W->solverMode & SOLVER_ORTHOGONALIZE_X_LATER));
   launch_solve(ctx, single(W), lambda, orth ? 1 : 0);
   SDSO_HIP(ctx, hipGetLastError());
@@ -1151,7 +1165,7 @@ extern "C" int sdso_ba_optimize(sdso_ctx* ctx, int win, int mnumOptIts, double* 
   // reference's default) through the fused kernel, the energy-gated flow through the un-fused ones with the decision taken by
   // k_ba_opt_gate.  The SVD / orthogonalised-system solver modes and SDSO_BA_HOST_LOOP=1 (A/B) take the host loop below.
   const bool host_loop = getenv("SDSO_BA_HOST_LOOP") != nullptr;   // read per call: tests flip it
-  if (nf >= 2 && !host_loop && (W->solverMode & (SOLVER_SVD | SOLVER_ORTHOGONALIZE_SYSTEM)) == 0) {
+  if (nf >= 2 && !host_loop && ((W->solverMode & (SOLVER_SVD | SOLVER_ORTHOGONALIZE_SYSTEM)) == 0 || !solve_on_host())) {
     int rc = optimize_resident_single(ctx, W, mnumOptIts, &res);
     if (rc) return rc;
   } else if (nf >= 2) {
@@ -1354,6 +1368,7 @@ extern "C" int sdso_ba_batch_create(sdso_ctx* ctx, int nwin, const int* wins) {
   hipMemcpyAsync(Bt->d_arr, h.data(), sizeof(BaDev) * nwin, hipMemcpyHostToDevice, ctx->stream);
   L.d_arr = Bt->d_arr;
   L.any_lin = false;   // recomputed at every launch (marginalisation may linearize residuals of a member later)
+  L.alt = (Ws[0]->solverMode & (SOLVER_SVD | SOLVER_ORTHOGONALIZE_SYSTEM)) != 0;   // (the members of a batch share one solverMode)
   Bt->L = L;
   if (hipStreamSynchronize(ctx->stream) != hipSuccess) { free_batch(ctx); return sdso::fail(ctx, SDSO_ERR_HIP, "batch descriptor upload failed"); }
   return SDSO_OK;
@@ -1445,10 +1460,10 @@ extern "C" int sdso_ba_batch_solve(sdso_ctx* ctx, double lambda, int orthogonali
   // solveSystem's overrides of lambda (EnergyFunctional.cpp:840-846), as in the single-window call
   if (Bt->W[0]->solverMode & SOLVER_USE_GN) lambda = 0;
   if (Bt->W[0]->solverMode & SOLVER_FIX_LAMBDA) lambda = 1e-5;
-  if (Bt->W[0]->solverMode & (SOLVER_SVD | SOLVER_ORTHOGONALIZE_SYSTEM)) {
-    // solveSystemF's SVD / orthogonalised-system branches (EnergyFunctional.cpp:876-900, 924-965): the batch accumulates in one launch, the
-    // assembly and the eigen-decomposition run on the host window by window (solve_system_host, as for sdso_ba_solve), the back-substitution
-    // on the device.  The host mirrors (deltas, projector) are those of the upload: this is the step-by-step batch API, not the resident loop.
+  if ((Bt->W[0]->solverMode & (SOLVER_SVD | SOLVER_ORTHOGONALIZE_SYSTEM)) && solve_on_host()) {
+    // SDSO_BA_SOLVE_HOST=1 (A/B): solveSystemF's SVD / orthogonalised-system branches (EnergyFunctional.cpp:876-900, 924-965) with the
+    // assembly and the eigen-decomposition on the host, window by window (solve_system_host), the back-substitution on the device.  The
+    // host mirrors (deltas, projector) are those of the upload.  Default: k_ba_solve_alt for the whole batch (launch_solve).
     join_sc(ctx, Bt);
     ensure_folded(ctx, Bt);
     for (BaWindowDev* W : Bt->W) {
@@ -1458,10 +1473,15 @@ extern "C" int sdso_ba_batch_solve(sdso_ctx* ctx, double lambda, int orthogonali
     Bt->sc_async = false;
     return SDSO_OK;
   }
-  if (!tail_enabled()) join_sc(ctx, Bt);
+  const bool no_tail = !tail_enabled() || batch_launch(Bt).alt;
+  if (no_tail) join_sc(ctx, Bt);
+  if (batch_launch(Bt).alt) {   // as the single call spells it for these branches: the argument is "iteration >= 2", the mode decides (EnergyFunctional.cpp:980)
+    const int sm = Bt->W[0]->solverMode;
+    orthogonalize_x = ((sm & SOLVER_ORTHOGONALIZE_X) || (orthogonalize_x && (sm & SOLVER_ORTHOGONALIZE_X_LATER))) ? 1 : 0;
+  }
   launch_solve(ctx, batch_launch(Bt), lambda, orthogonalize_x, Bt->folded, Bt->sc_async);   // (the tail kernel folds for itself: the block stays as it is)
   Bt->sc_async = false;
-  if (!tail_enabled()) Bt->folded = true;
+  if (no_tail) Bt->folded = true;
   SDSO_HIP(ctx, hipGetLastError());
   return SDSO_OK;
 }
@@ -1590,7 +1610,7 @@ static int opt_begin(sdso_ctx* ctx, OptRun& R, int stop_on_convergence) {
   int cap = 1;
   for (BaWindowDev* W : R.W) {
     SDSO_REQUIRE(ctx, (W->forceAccept != 0) == (R.W[0]->forceAccept != 0), "the windows of a resident loop must share setting_forceAceptStep");
-    SDSO_REQUIRE(ctx, (W->solverMode & (SOLVER_SVD | SOLVER_ORTHOGONALIZE_SYSTEM)) == 0, "SOLVER_SVD / SOLVER_ORTHOGONALIZE_SYSTEM windows are optimised through the host loop");
+    SDSO_REQUIRE(ctx, (W->solverMode & (SOLVER_SVD | SOLVER_ORTHOGONALIZE_SYSTEM)) == (R.W[0]->solverMode & (SOLVER_SVD | SOLVER_ORTHOGONALIZE_SYSTEM)), "the windows of a resident loop must share the solver branch");
     cap = std::max(cap, W->d.nr - W->newest_first);
   }
   R.nranks = comm_nranks(ctx);
@@ -1797,7 +1817,7 @@ static int opt_finish(sdso_ctx* ctx, OptRun& R, sdso_ba_opt_result_t* out) {
     r.resInA = resInA[w];
     r.rmse = sqrtf((float)(o.lastEnergy / (8 * resInA[w])));
     if (out) out[w] = r;
-    W->post_valid = true; W->post_pending = true; W->hs_valid = R.keep_hs || R.gated || !tail_enabled(); W->last_result = r;
+    W->post_valid = true; W->post_pending = true; W->hs_valid = R.keep_hs || R.gated || !tail_enabled() || R.L.alt; W->last_result = r;
   }
   R.active = false;
   return SDSO_OK;
@@ -1809,7 +1829,7 @@ static int opt_iterations(int nf, int mnumOptIts) {
   if (nf < 4) mnumOptIts = 15;
   return mnumOptIts;
 }
-static bool batch_defers_fold(sdso_ctx* ctx, BaBatch* Bt) { (void)ctx; return tail_enabled() && !Bt->eager_fold; }
+static bool batch_defers_fold(sdso_ctx* ctx, BaBatch* Bt) { (void)ctx; return tail_enabled() && !Bt->eager_fold && !Bt->L.alt; }
 
 // solveSystem + doStepFromBackup + the loop's host part of iteration R.iteration.  Single rank: ONE launch of the fused tail kernel.
 // Sharded windows: tail kernel (stitch, solve, resubstitute, points' step) -> pack -> all-gather -> k_ba_opt_step, as before.
@@ -1821,12 +1841,12 @@ static bool batch_async_sc(sdso_ctx* ctx, BaBatch* Bt) {
   // (tail 278 instead of 120-190 us), which costs the other batch's linearisation more than the earlier start of the tail gains.
   static const bool on = getenv("SDSO_BA_SC_ASYNC") && atoi(getenv("SDSO_BA_SC_ASYNC")) == 1;
   // the waiting tail workgroups hold one CU each (150 KB of LDS): they must leave most of the chip to the kernel they wait for
-  if (!on || !tail_enabled() || Bt->eager_fold || !reg_has(g_optruns, ctx) || Bt->L.nwin > ctx->n_cu / 2) return false;
+  if (!on || !tail_enabled() || Bt->L.alt || Bt->eager_fold || !reg_has(g_optruns, ctx) || Bt->L.nwin > ctx->n_cu / 2) return false;
   OptRun* R = reg_get(g_optruns, ctx);
   return R && R->active && !R->exchange && !R->gated && R->W == Bt->W;
 }
 static int opt_solve_step(sdso_ctx* ctx, OptRun& R, double lambda, int orth, bool folded, bool wait_sc = false) {
-  if (!tail_enabled()) {
+  if (!tail_enabled() || R.L.alt) {
     launch_solve(ctx, R.L, lambda, orth, folded);
     SDSO_HIP(ctx, hipGetLastError());
     return opt_step(ctx, R);
@@ -1866,7 +1886,7 @@ static int opt_solve_step(sdso_ctx* ctx, OptRun& R, double lambda, int orth, boo
 // one whole GN iteration: accumulate (fused linearisation + Schur part) -> [all-reduce] -> solve + step
 static int opt_iteration(sdso_ctx* ctx, OptRun& R, int it) {
   BaBatch* Bt = R.W[0]->in_batch ? get_batch(ctx) : nullptr;
-  const bool defer = tail_enabled() && !R.exchange && !(Bt && Bt->eager_fold);
+  const bool defer = tail_enabled() && !R.L.alt && !R.exchange && !(Bt && Bt->eager_fold);
   if (Bt) join_sc(ctx, Bt);
   bool async = Bt ? batch_async_sc(ctx, Bt) : false;      // (a single window has nothing to overlap the Schur kernel with)
   bool folded = launch_fused(ctx, R.L, R.materialize, R.gather, 3, defer, &async);
@@ -1908,7 +1928,7 @@ int optimize_resident_single(sdso_ctx* ctx, BaWindowDev* W, int mnumOptIts, sdso
 // rank only); anything else takes the all-reduce, whatever mode the batch carries.
 bool ba_batch_scatter_begin(sdso_ctx* ctx) {
   BaBatch* Bt = get_batch(ctx);
-  if (!Bt || Bt->exchange_mode != 1 || !tail_enabled() || !reg_has(g_optruns, ctx)) return false;
+  if (!Bt || Bt->exchange_mode != 1 || !tail_enabled() || Bt->L.alt || !reg_has(g_optruns, ctx)) return false;
   OptRun* R = reg_get(g_optruns, ctx);
   if (!R || !R->active || !R->exchange || R->gated || R->keep_hs || R->W != Bt->W) return false;
   if ((int)Bt->W.size() % R->nranks != 0) return false;
@@ -1958,7 +1978,7 @@ extern "C" int sdso_ba_batch_solve_step(sdso_ctx* ctx, double lambda, int orthog
   R->L = batch_launch(Bt);
   const bool wait_sc = Bt->sc_async;
   Bt->sc_async = false;
-  if (wait_sc && (!tail_enabled() || R->exchange)) { Bt->sc_async = true; join_sc(ctx, Bt); return opt_solve_step(ctx, *R, lambda, orthogonalize_x ? 1 : 0, Bt->folded); }
+  if (wait_sc && (!tail_enabled() || R->L.alt || R->exchange)) { Bt->sc_async = true; join_sc(ctx, Bt); return opt_solve_step(ctx, *R, lambda, orthogonalize_x ? 1 : 0, Bt->folded); }
   return opt_solve_step(ctx, *R, lambda, orthogonalize_x ? 1 : 0, Bt->folded, wait_sc);
 }
 extern "C" int sdso_ba_batch_optimize_end(sdso_ctx* ctx, sdso_ba_opt_result_t* out) {
@@ -1972,9 +1992,10 @@ extern "C" int sdso_ba_batch_optimize_end(sdso_ctx* ctx, sdso_ba_opt_result_t* o
 }
 extern "C" int sdso_ba_batch_optimize(sdso_ctx* ctx, int mnumOptIts, sdso_ba_opt_result_t* out) {
   if (BaBatch* Bt = get_batch(ctx)) {
-    if (Bt->W[0]->solverMode & (SOLVER_SVD | SOLVER_ORTHOGONALIZE_SYSTEM)) {
-      // the SVD / orthogonalised-system solver modes are host-driven (one round trip per iteration, solve_system_host): the batch call runs
-      // the single-window loop window by window — the same results as sdso_ba_optimize, no batching gain
+    if ((Bt->W[0]->solverMode & (SOLVER_SVD | SOLVER_ORTHOGONALIZE_SYSTEM)) && solve_on_host()) {
+      // SDSO_BA_SOLVE_HOST=1 (A/B): the SVD / orthogonalised-system solver modes host-driven (one round trip per iteration,
+      // solve_system_host) — the batch call runs the single-window host loop window by window.  Default: the resident loop below, with
+      // k_ba_solve_alt in the place of the tail kernel's stitch and solve
       SDSO_HIP(ctx, hipSetDevice(ctx->device));
       free_optrun(ctx);
       join_sc(ctx, Bt);

@@ -117,6 +117,8 @@ struct BaDev {
   float* accum;             // packed accumulators (see sdso_ba_accum_floats)
   double* sol;              // Htop_A n*n | btop_A n | Htop_L n*n | btop_L n | Hsc n*n | bsc n | x n | HS n*n | bS n
   BaOptDev* opt;            // resident optimizer state (ba_opt.hip)
+  int solver_mode;          // setting_solverMode of the window (k_ba_solve_alt: which branch of solveSystemF)
+  int have_first_frame;     // a frame with frameID == 0 is in the window (EnergyFunctional.cpp:881-884: then HT / bT are not projected)
   int finished;             // resident GN loop (k_ba_opt_step): 1 the break test fired (only the linearisation at the final state is
                             // still wanted), 2 the loop has ended; cleared by k_ba_opt_release
 };

@@ -86,7 +86,6 @@ __global__ __launch_bounds__(TAIL_NT) void k_ba_tail(const BaDev* __restrict__ w
   double* vec = (double*)(tail_smem + TailLds::kVec);
   double *bF = vec, *sv = vec + 72, *bp = vec + 144, *xp = vec + 216, *xv = vec + 288, *bMt = vec + 360, *dg = vec + 432, *tmpv = vec + 504;
   int* pos = (int*)(tail_smem + TailLds::kPos);
-  int* perm = pos + 72;
   unsigned long long* keys = (unsigned long long*)(tail_smem + TailLds::kKeys);
   double* atd = (double*)(tail_smem + TailLds::kAtd);
   float* xAd_s = (float*)(tail_smem + TailLds::kXad);

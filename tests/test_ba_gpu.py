@@ -229,6 +229,71 @@ def test_solver_mode_variants(gpu_ctx, oracle, win_small, mode, first_id):
     gpu_ctx.check(gpu_ctx.L.sdso_ba_release_window(gpu_ctx.h, 7))
 
 
+@pytest.mark.parametrize("mode,first_id", [(SVD | FIX_LAMBDA | ORTH_X_LATER, 0), (SVD | CUT7 | FIX_LAMBDA, 0), (ORTH_SYS | FIX_LAMBDA | ORTH_X_LATER, 3), (ORTH_SYS | SVD | FIX_LAMBDA, 0)])
+def test_device_solver_of_the_svd_and_orthogonalised_branches(gpu_ctx, oracle, win_c3, mode, first_id, monkeypatch):
+    """k_ba_solve_alt (csrc/ba_solve_alt.hip: parallel-order Jacobi eigen-decomposition / projected system + register LDL^T on the device)
+    against the host statement of the same arithmetic (solve_system_host behind SDSO_BA_SOLVE_HOST=1, sequential-order Jacobi) on the
+    8-keyframe window, and the whole resident loop in these modes — now without a host round trip per iteration, batch included —
+    against the oracle's loop."""
+    win = dict(win_c3)
+    win["solverMode"] = mode
+    win["frameID"] = (np.arange(win["nf"]) + first_id).astype(np.int32)
+    nf, npts, nr, n = win["nf"], win["np"], win["nr"], 8 * win["nf"] + 4
+    W, keep, h = _both(gpu_ctx, oracle, win, wid=8)
+    _lin_both(gpu_ctx, oracle, win, h, 8)
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_apply_res(gpu_ctx.h, 8))
+    xs = {}
+    for where in ("device", "host"):
+        if where == "host":
+            monkeypatch.setenv("SDSO_BA_SOLVE_HOST", "1")
+        else:
+            monkeypatch.delenv("SDSO_BA_SOLVE_HOST", raising=False)
+        x, H, b = np.zeros(n), np.zeros((n, n)), np.zeros(n)
+        gpu_ctx.check(gpu_ctx.L.sdso_ba_accumulate(gpu_ctx.h, 8))
+        gpu_ctx.check(gpu_ctx.L.sdso_ba_solve(gpu_ctx.h, 8, 2, 0.025, abi.dp(x), abi.dp(H), abi.dp(b), None, None))
+        st = np.zeros(npts, np.float32)
+        gpu_ctx.check(gpu_ctx.L.sdso_ba_get_point_steps(gpu_ctx.h, 8, abi.fp(st)))
+        xs[where] = (x, H, b, st)
+    monkeypatch.delenv("SDSO_BA_SOLVE_HOST", raising=False)
+    (xd, Hd, bd, sd), (xh, Hh, bh, sh) = xs["device"], xs["host"]
+    d = np.sqrt(np.abs(np.diag(Hh))) + 1e-30
+    assert np.abs((Hd - Hh) / np.outer(d, d)).max() <= 1e-12            # the same f64 expressions on the same stitched blocks
+    assert np.abs((bd - bh) / d).max() <= 1e-12 * max(1.0, np.abs(bh / d).max())
+    # x: the same system through a different rotation order (SVD) / the same pivoted LDL^T in a different elimination order; without
+    # frame 0 the projected system is singular along the gauge and x there is set by rounding on both sides
+    tol = 1e-7 if first_id == 0 else 1e-3
+    assert np.abs((xd - xh) * d).max() <= tol * max(1.0, np.abs(xh * d).max()), np.abs((xd - xh) * d).max()
+    assert np.abs(xd).max() > 0 and np.isfinite(xd).all()
+    assert np.abs(sd - sh).max() <= max(tol, 1e-6) * max(np.abs(sh).max(), 1e-6)
+    # the whole loop, device-resident in these modes too: against the oracle's loop with the usual bars
+    so, io, ro, oo = np.zeros((nf, 10)), np.zeros(npts, np.float32), np.zeros(nr, np.uint8), abi.BAOptResult()
+    oracle.orc_ba_destroy(h)
+    h = oracle.orc_ba_create(C.byref(W))                                 # (a fresh window on both sides)
+    oracle.orc_ba_optimize(h, 6, abi.dp(so), abi.fp(io), abi.bp(ro), C.byref(oo))
+    oracle.orc_ba_destroy(h)
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_upload_window(gpu_ctx.h, 8, C.byref(W)))
+    sg, ig, rg, og = np.zeros((nf, 10)), np.zeros(npts, np.float32), np.zeros(nr, np.uint8), abi.BAOptResult()
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_optimize(gpu_ctx.h, 8, 6, abi.dp(sg), abi.fp(ig), abi.bp(rg), C.byref(og)))
+    assert og.iterations == oo.iterations
+    bar = 3e-4 if first_id == 0 else 5e-2                                # (no gauge prior: the states drift along the gauge on both sides)
+    assert np.abs(sg - so).max() <= bar, np.abs(sg - so).max()
+    assert (rg != ro).sum() <= max(2, nr // 1000)
+    # and two such windows as a batch: the resident batch loop equals the single calls
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_upload_window(gpu_ctx.h, 8, C.byref(W)))
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_upload_window(gpu_ctx.h, 9, C.byref(W)))
+    ids = np.array([8, 9], np.int32)
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_batch_create(gpu_ctx.h, 2, abi.ip(ids)))
+    res = (abi.BAOptResult * 2)()
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_batch_optimize(gpu_ctx.h, 6, res))
+    for wid in (8, 9):
+        sb, ib, rb = np.zeros((nf, 10)), np.zeros(npts, np.float32), np.zeros(nr, np.uint8)
+        gpu_ctx.check(gpu_ctx.L.sdso_ba_get_state(gpu_ctx.h, wid, abi.dp(sb), abi.fp(ib), abi.bp(rb)))
+        assert res[wid - 8].iterations == og.iterations
+        assert np.abs(sb - sg).max() <= 1e-9 and np.abs(ib - ig).max() <= 1e-7 and np.array_equal(rb, rg)
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_release_window(gpu_ctx.h, 8))
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_release_window(gpu_ctx.h, 9))
+
+
 @pytest.mark.parametrize("which", ["small", "c3"])
 def test_optimize_full_gn_loop(gpu_ctx, oracle, win_small, win_c3, which):
     win = win_small if which == "small" else win_c3

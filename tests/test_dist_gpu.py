@@ -458,6 +458,8 @@ def _bench_worker(rank, world, port, outdir, scaling):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ["SDSO_DIST_BACKEND"] = "gloo_lib"
+    os.environ["SDSO_BA_EXCHANGE"] = "scatter" if scaling.endswith("_scatter") else "allreduce"
+    scaling = scaling.replace("_scatter", "")
     os.environ["RANK"] = str(rank)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from sdso_amd import abi
@@ -472,21 +474,23 @@ def _bench_worker(rank, world, port, outdir, scaling):
     out = wl.verify()
     out["config"] = wl.config
     if rank == 0:
-        json.dump({k: v for k, v in out.items() if isinstance(v, (int, float, bool, str, dict))}, open(os.path.join(outdir, "out_%s.json" % scaling), "w"))
+        json.dump({k: v for k, v in out.items() if isinstance(v, (int, float, bool, str, dict))}, open(os.path.join(outdir, "out.json"), "w"))
     wl.close()
     ctx.close()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("scaling", ["weak", "strong"])
+@pytest.mark.parametrize("scaling", ["weak", "strong", "weak_scatter"])
 def test_bench_workload_two_ranks_advances_the_same_work(tmp_path, scaling):
     """The first real multi-GPU run must not be able to measure something else than N = 1 does: on two ranks the step is the full one
-    (state_advances), window 0's sharded x equals the unsharded window's, and the GN steps shrink over six iterations."""
+    (state_advances), window 0's sharded x equals the unsharded window's, and the GN steps shrink over six iterations.
+    weak_scatter: the same with SDSO_BA_EXCHANGE=scatter (reduce-scatter by window + all-gather of x inside the timed step)."""
     import json
     world = 2
     mp.spawn(_bench_worker, args=(world, _free_port(), str(tmp_path), scaling), nprocs=world, join=True)
-    out = json.load(open(os.path.join(str(tmp_path), "out_%s.json" % scaling)))
+    out = json.load(open(os.path.join(str(tmp_path), "out.json")))
     assert out["config"]["state_advances"] is True
+    assert ("reduce-scatter" in out["config"]["exchange_shape"]) == scaling.endswith("_scatter")
     assert "host transport" in out["config"]["exchange"]
     assert out["sharded_x_whitened_err"] <= 2e-4
     assert out["max_abs_x"] < out["max_abs_x_initial"]
