@@ -226,7 +226,10 @@ def _batch_optimize(ctx, abi, wins, wid0, slot0, exchange_mode=0):
     return out
 
 
-def _opt_worker(rank, world, port, outdir, gated=False, exchange_mode=0, tag="opt"):
+_OPT_SPECS3 = _OPT_SPECS + [dict(w=640, h=480, nf=8, pts_per_kf=90, seed=3047)]
+
+
+def _opt_worker(rank, world, port, outdir, gated=False, exchange_mode=0, tag="opt", specs=None):
     import torch
     import torch.distributed as dist
     sys.path[:0] = [os.path.join(ROOT, "stereo-dso-g2o_amd")]
@@ -237,7 +240,7 @@ def _opt_worker(rank, world, port, outdir, gated=False, exchange_mode=0, tag="op
     ctx = abi.Context(0)
     cbs = _host_transport(dist, torch, world)
     ctx.check(ctx.L.sdso_comm_init_host(ctx.h, world, rank, cbs[0], cbs[1], None))
-    shards = [sdist.shard_window(synth.ba_window(**s), rank, world) for s in _OPT_SPECS]
+    shards = [sdist.shard_window(synth.ba_window(**s), rank, world) for s in (specs or _OPT_SPECS)]
     subs = [sh[0] for sh in shards]
     for k, sh in enumerate(shards):
         np.savez(os.path.join(outdir, "idx_%d_%d.npz" % (rank, k)), p=sh[1], r=sh[2])
@@ -349,6 +352,30 @@ def test_two_rank_reduce_scatter_by_window_equals_the_allreduce(tmp_path):
             assert np.array_equal(a["s"], b["s"]) and np.array_equal(a["i"], b["i"]) and np.array_equal(a["r"], b["r"])
             assert float(a["e"]) == float(b["e"])
         assert int(np.load(tmp_path / ("rs_0_%d.npz" % k))["its"]) >= 2      # (a loop that stopped at once would prove nothing)
+
+
+@pytest.mark.gpu
+def test_three_ranks_three_windows_both_exchange_shapes(gpu_ctx, tmp_path):
+    """Three ranks (every host keyframe's points cut three ways, one window per rank under the reduce-scatter exchange — a rank count
+    that divides neither the keyframes nor a power of two): both exchange shapes end on the same bits on every rank, and those are the
+    unsharded loop's decisions (iteration counts) with states inside the sharded loop's bar."""
+    from sdso_amd import abi, synth
+    world = 3
+    for mode, tag in ((0, "ar3"), (1, "rs3")):
+        mp.spawn(_opt_worker, args=(world, _free_port(), str(tmp_path), False, mode, tag, _OPT_SPECS3), nprocs=world, join=True)
+    wins = [synth.ba_window(**s) for s in _OPT_SPECS3]
+    single = _batch_optimize(gpu_ctx, abi, wins, 61, 800)
+    for k in range(len(_OPT_SPECS3)):
+        ref = np.load(tmp_path / ("ar3_0_%d.npz" % k))
+        for r in range(world):
+            a, b = np.load(tmp_path / ("ar3_%d_%d.npz" % (r, k))), np.load(tmp_path / ("rs3_%d_%d.npz" % (r, k)))
+            assert int(a["its"]) == int(b["its"]) == int(ref["its"]) and int(a["resInA"]) == int(b["resInA"])
+            assert np.array_equal(a["s"], b["s"]) and np.array_equal(a["i"], b["i"]) and np.array_equal(a["r"], b["r"])
+            assert np.array_equal(a["s"], ref["s"])                           # every rank holds the same frame states
+        assert int(ref["its"]) == single[k][3]
+        assert np.abs(ref["s"] - single[k][0]).max() <= 1e-4, np.abs(ref["s"] - single[k][0]).max()
+    for k in range(len(wins)):
+        gpu_ctx.check(gpu_ctx.L.sdso_ba_release_window(gpu_ctx.h, 61 + k))
 
 
 def _two_comm_worker(rank, world, port, outdir):
