@@ -148,10 +148,19 @@ def check_post_state(win, Po, do, Pg, dg):
     return flips
 
 
-@pytest.mark.parametrize("which", ["fresh", "dropped_with_history"])
-def test_post_state_of_optimize_matches_oracle(gpu_ctx, oracle, win_c3, win_dropped, which):
+@pytest.fixture(scope="module")
+def win_small_dropped():
+    """A younger window (5 keyframes at 640x480, affine parameters free, points started 10 % off) whose lists were dropped from twice"""
+    w = synth.ba_window(w=640, h=480, nf=5, pts_per_kf=150, seed=5113, idepth_noise=0.1)
+    w, _ = helpers.drop_residuals(w, seed=3, drop_frac=0.2)
+    w, _ = helpers.drop_residuals(w, seed=4, drop_frac=0.1)
+    return w
+
+
+@pytest.mark.parametrize("which", ["fresh", "dropped_with_history", "small_dropped_twice"])
+def test_post_state_of_optimize_matches_oracle(gpu_ctx, oracle, win_c3, win_dropped, win_small_dropped, which):
     ctx = gpu_ctx
-    win = dict(win_c3 if which == "fresh" else win_dropped)
+    win = dict(win_c3 if which == "fresh" else win_small_dropped if which == "small_dropped_twice" else win_dropped)
     nf, npts, nr = win["nf"], win["np"], win["nr"]
     if which != "fresh":                        # points with a history: earlier optimize calls left counts / baselines, some residuals are old
         rs = np.random.RandomState(5)
