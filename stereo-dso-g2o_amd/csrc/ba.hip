@@ -587,21 +587,29 @@ static bool launch_sc_and_folds(sdso_ctx* ctx, const BaLaunch& L, const uint8_t*
   // the launch's common case — no marginalisation pass, no point filter, no linearized residual — takes the kernel's lean per-point loop
   static const bool no_plain = getenv("SDSO_SC_NOPLAIN") != nullptr;     // (A/B)
   const bool plain = !marg && !pflag && !L.any_lin && !no_plain;
+  static const int sc_waves = getenv("SDSO_SC_WAVES") && atoi(getenv("SDSO_SC_WAVES")) == 2 ? 2 : 4;    // (A/B: workgroups of two waves)
+#define LAUNCH_SC_HOST(STREAM, SIGNAL) do {                                                                                                             \
+    if (sc_waves == 2) {                                                                                                                                \
+      if (plain) hipLaunchKernelGGL((k_ba_sc_host<true, 2>), dim3(nf, L.nwin), dim3(128), 0, STREAM, L.d_arr, pflag, shift, mm, SIGNAL);               \
+      else hipLaunchKernelGGL((k_ba_sc_host<false, 2>), dim3(nf, L.nwin), dim3(128), 0, STREAM, L.d_arr, pflag, shift, mm, SIGNAL);                    \
+    } else {                                                                                                                                            \
+      if (plain) hipLaunchKernelGGL((k_ba_sc_host<true, 4>), dim3(nf, L.nwin), dim3(BA_BLOCK), 0, STREAM, L.d_arr, pflag, shift, mm, SIGNAL);           \
+      else hipLaunchKernelGGL((k_ba_sc_host<false, 4>), dim3(nf, L.nwin), dim3(BA_BLOCK), 0, STREAM, L.d_arr, pflag, shift, mm, SIGNAL);                \
+    }                                                                                                                                                   \
+  } while (0)
   if (sc_variant == 0) {
     const bool want_async = async_sc && *async_sc && fold_top_too && defer_fold && !marg && side_stream(ctx);
     if (async_sc) *async_sc = want_async;
     if (want_async) {
       hipEventRecord(ctx->ev_fork, ctx->stream);
       hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0);
-      if (plain) hipLaunchKernelGGL(k_ba_sc_host<true>, dim3(nf, L.nwin), dim3(BA_BLOCK), 0, ctx->stream2, L.d_arr, pflag, shift, mm, 1);
-      else hipLaunchKernelGGL(k_ba_sc_host<false>, dim3(nf, L.nwin), dim3(BA_BLOCK), 0, ctx->stream2, L.d_arr, pflag, shift, mm, 1);
+      LAUNCH_SC_HOST(ctx->stream2, 1);
       hipEventRecord(ctx->ev_join, ctx->stream2);
       return false;
     }
     {
       ProfScope ps(ctx, "k_ba_sc", 2);
-      if (plain) hipLaunchKernelGGL(k_ba_sc_host<true>, dim3(nf, L.nwin), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr, pflag, shift, mm, 0);
-      else hipLaunchKernelGGL(k_ba_sc_host<false>, dim3(nf, L.nwin), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr, pflag, shift, mm, 0);
+      LAUNCH_SC_HOST(ctx->stream, 0);
     }
     if (fold_top_too && defer_fold) return false;
     if (fold_top_too) hipLaunchKernelGGL(k_ba_fold_all, dim3(1 + 2 * nf * nf, L.nwin), dim3(128), 0, ctx->stream, L.d_arr, 1);

@@ -1590,8 +1590,11 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_sc_mfma(const BaDev* __restrict
 // (Round 3 tried the transposed split — wave a owns tile ROW a for all points of the host: 116 VGPRs and 8 KB of LDS, so all 1024
 //  workgroups of a 128-window launch are resident at once instead of two rounds of 512 — and measured it SLOWER, 91 against 72 us: the
 //  kernel is bound by the per-wave chain load -> MFMA over its point groups, which that split makes four times longer.)
-template <bool PLAIN>
-__global__ __launch_bounds__(BA_BLOCK, 2) void k_ba_sc_host(const BaDev* __restrict__ wins, const uint8_t* __restrict__ pflag, int shiftPriorToZero, int margMode, int signal = 0) {
+// NW: waves per workgroup.  4 (default).  2 (SDSO_SC_WAVES=2, A/B): half as many waves share a host, so a wave sees twice the point groups
+// (prologue, tree and bins amortise over eight instead of four) and four workgroups instead of two fit a CU.  Measured on MI355X, 256 windows:
+// 142 against 134 us — the per-wave chain load -> terms -> MFMA over its groups is what bounds the kernel, and this doubles it.
+template <bool PLAIN, int NW = 4>
+__global__ __launch_bounds__(64 * NW, 2) void k_ba_sc_host(const BaDev* __restrict__ wins, const uint8_t* __restrict__ pflag, int shiftPriorToZero, int margMode, int signal = 0) {
   const BaDev& B = wins[blockIdx.y];       // (by value — all pointers in SGPRs, no scalar re-loads in the loop — measured equal: 131 vs 133 us)
   if (ba_finished(B)) return;
   const int nf = B.nf, h = blockIdx.x;
@@ -1605,7 +1608,7 @@ __global__ __launch_bounds__(BA_BLOCK, 2) void k_ba_sc_host(const BaDev* __restr
 #define SCS() do { } while (0)
 #endif
   SCS();
-  __shared__ float pt_all[BA_BLOCK / 64][16][8];
+  __shared__ float pt_all[NW][16][8];
   // The records of 16 points (16 x nf x 16 floats, contiguous in r_rec) are brought in ONCE by coalesced 16-byte loads and parked in LDS;
   // both phases read them there.  (Before: phase 1 read floats 8..15 of every record with lane = point and phase 2 floats 0..7 with its
   // own lane layout, straight from memory — every 128-byte line crossed the memory system twice, and the launch, two rounds of 512
@@ -1620,7 +1623,10 @@ __global__ __launch_bounds__(BA_BLOCK, 2) void k_ba_sc_host(const BaDev* __restr
   // reference (AccumulatorXX::update multiplies a_i * b_j * w: the same product for both, MatrixAccumulators.h:31-80) — two MFMA tiles
   // (HdiF z_a) z_b and (HdiF z_b) z_a round differently, and the stitch relies on that symmetry (ba_tail.hip: S2 = S1^T).
   constexpr int SC_NT = 15;                                  // tile t of pair (a <= b): sc_ut(a, b); 10 + a: column tile 4 of row a; 14: the corner
-  constexpr int SC_LDS = (BA_BLOCK / 64) * SC_STAGE > 2 * SC_NT * 256 ? (BA_BLOCK / 64) * SC_STAGE : 2 * SC_NT * 256;
+  constexpr int BIN_E = 64 * 64, BIN_EB = BIN_E + 8 * 32;
+  constexpr int SC_NEED = SC_NT * 256 + BIN_EB + 64;          // one tile buffer + the bins laid out behind it
+  constexpr int SC_LDS0 = NW * SC_STAGE > (NW / 2) * SC_NT * 256 ? NW * SC_STAGE : (NW / 2) * SC_NT * 256;
+  constexpr int SC_LDS = SC_LDS0 > SC_NEED ? SC_LDS0 : SC_NEED;
   __shared__ __align__(16) float stage_all[SC_LDS];
   float (*tiles)[SC_NT * 256] = reinterpret_cast<float (*)[SC_NT * 256]>(stage_all);   // two waves' worth of accumulator tiles
   float* stg = stage_all + wv * SC_STAGE;
@@ -1634,7 +1640,7 @@ __global__ __launch_bounds__(BA_BLOCK, 2) void k_ba_sc_host(const BaDev* __restr
   const int ci = lane & 15, kq = lane >> 4;
   const int tsub = ci >> 3, asub = ci & 7;
   // a wave's 16-point groups: 64-point slices dealt round-robin over the waves (as before), four groups per slice
-  auto group_p0 = [&](int gidx) { return pb + 64 * (wv + (BA_BLOCK / 64) * (gidx >> 2)) + 16 * (gidx & 3); };
+  auto group_p0 = [&](int gidx) { return pb + 64 * (wv + NW * (gidx >> 2)) + 16 * (gidx & 3); };
   // the records of group g0: float4 chunk c = lane + 64 k of its (<= 16 nf 4) chunks
   float pr_next = 0.f, de_next = 0.f;        // prior, delta, residual order and the marginalisation flag of the lane's point of the NEXT group: they travel with its records
   int pf_next = 1;
@@ -1757,10 +1763,12 @@ __global__ __launch_bounds__(BA_BLOCK, 2) void k_ba_sc_host(const BaDev* __restr
 #pragma unroll
       for (int v = 0; v < 4; v++) acc[t][v] += src[(t * 4 + v) * 64 + lane];
   };
-  if (wv >= 2) put(tiles[wv - 2]);
-  __syncthreads();
-  if (wv < 2) add(tiles[wv]);
-  __syncthreads();
+  if constexpr (NW == 4) {
+    if (wv >= 2) put(tiles[wv - 2]);
+    __syncthreads();
+    if (wv < 2) add(tiles[wv]);
+    __syncthreads();
+  }
   if (wv == 1) put(tiles[0]);
   __syncthreads();
   // ---- the host's bins.  acc[a][b][v] = D'[16a + 4*kq + v][16b + ci]: wave 0 lays the finished tiles out in LDS the way the bins lie in
@@ -1771,8 +1779,7 @@ __global__ __launch_bounds__(BA_BLOCK, 2) void k_ba_sc_host(const BaDev* __restr
   float* accE = B.accum + acc_off_E(nf);
   float* accEB = B.accum + acc_off_EB(nf);
   float* bins = stage_all + SC_NT * 256;       // the second tile buffer: free since the tree's second barrier
-  constexpr int BIN_E = 64 * 64, BIN_EB = BIN_E + 8 * 32;
-  static_assert(SC_NT * 256 + BIN_EB + 64 <= SC_LDS, "the bins fit behind the first tile buffer");
+  static_assert(SC_NEED <= SC_LDS, "the bins fit behind the first tile buffer");
   if (wv == 0) {
     add(tiles[0]);
     SCS();
@@ -1805,12 +1812,13 @@ __global__ __launch_bounds__(BA_BLOCK, 2) void k_ba_sc_host(const BaDev* __restr
   }
   __syncthreads();
 #pragma unroll 4
-  for (int blk = wv; blk < 64; blk += BA_BLOCK / 64) {
+  for (int blk = wv; blk < 64; blk += NW) {
     const int t1 = blk >> 3, t2 = blk & 7;
     if (t1 < nf && t2 < nf) accD[(size_t)(h + t1 * nf + t2 * nf2) * 64 + lane] = bins[blk * 64 + lane];
   }
-  {
-    const int idx = 64 * wv + lane, t1 = idx >> 5;
+#pragma unroll
+  for (int idx = 64 * wv + lane; idx < 256; idx += 64 * NW) {
+    const int t1 = idx >> 5;
     if (t1 < nf) accE[(size_t)(h + t1 * nf) * 32 + (idx & 31)] = bins[BIN_E + idx];
   }
   if (wv == 1 && (lane >> 3) < nf) accEB[(size_t)(h + (lane >> 3) * nf) * 8 + (lane & 7)] = bins[BIN_EB + lane];

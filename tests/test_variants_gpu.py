@@ -11,6 +11,7 @@ variables are read once per process: `static const ... getenv`).  Round-2 adviso
                         eight lock-step hypotheses; every other cluster size from 2 to 8 reproduces the oracle's counts on these problems)
   SDSO_TRK_LM_TEST_DROP_MEMBER=1   test hook: the last member of every cluster exits at once (a cluster that is not co-resident)
   SDSO_TRACE_WAVE=1 / SDSO_TRACE_BAND=1   the per-wave traceStereo kernel / its LDS-band variant
+  SDSO_SC_WAVES=2       k_ba_sc_host with two waves per workgroup (four workgroups per CU; measured slower, kept as A/B)
   SDSO_BA_SOLVE_HOST=1  solveSystemF's SVD / orthogonalised-system branches on the host (solve_system_host, rounds 1-3) instead of k_ba_solve_alt"""
 import os
 import subprocess
@@ -28,6 +29,7 @@ VARIANTS = [
     ({"SDSO_BA_TAIL": "0", "SDSO_BA_SOLVE": "2"}, ["tests/test_ba_gpu.py"]),
     ({"SDSO_BA_SOLVE_HOST": "1"}, ["tests/test_ba_gpu.py::test_solver_mode_variants"]),
     ({"SDSO_BA_JSWAP": "1"}, BA),
+    ({"SDSO_SC_WAVES": "2"}, BA),
     ({"SDSO_BA_SC_ASYNC": "1"}, BA),
     ({"SDSO_TRK_HOST_LM": "1"}, ["tests/test_tracker_gpu.py::test_track_newest_coarse_pose_within_1e5", "tests/test_tracker_gpu.py::test_track_hypotheses_in_lock_step",
                                  "tests/test_tracker_gpu.py::test_track_affine_modes"]),
