@@ -1604,8 +1604,13 @@ __global__ __launch_bounds__(64 * NW, 2) void k_ba_sc_host(const BaDev* __restri
   unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   int stn = 0;
 #define SCS() do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); if (stn < 8) st[stn++] = __builtin_amdgcn_s_memtime(); } while (0)
+  unsigned long long sub[6] = {0, 0, 0, 0, 0, 0}, sub_t = 0;     // inside the group loop: wait for the records + park | request + barrier | r_cj | phase 1 | phase 2 | closing barrier
+#define SCSUB(i) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); sub[i] += tn_ - sub_t; sub_t = tn_; } while (0)
+#define SCSUB0() do { sub_t = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define SCS() do { } while (0)
+#define SCSUB(i) do { } while (0)
+#define SCSUB0() do { } while (0)
 #endif
   SCS();
   __shared__ float pt_all[NW][16][8];
@@ -1664,6 +1669,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_ba_sc_host(const BaDev* __restri
     const int p0 = group_p0(gidx);
     if (p0 >= pe) break;
     const int npts = min(16, pe - p0);
+    SCSUB0();
     {  // park the group's records: chunk c -> record c / 4 = point * nf + target, floats 4 (c & 3) ..
       const int nchunks = npts * nf * 4;
 #pragma unroll
@@ -1678,11 +1684,13 @@ __global__ __launch_bounds__(64 * NW, 2) void k_ba_sc_host(const BaDev* __restri
     const float prior = pr_next, delta = de_next;
     const float onf = pf_next ? 1.f : 0.f;
     const unsigned order = or_next;
+    SCSUB(0);
     request(group_p0(gidx + 1), vnext);          // the next group's records travel while this one is worked on.  (Requested behind this group's
                                                  // stores instead — so that the wait for them never waits for a younger store — measured equal.)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    SCSUB(1);
     {  // the JpJdF halves of the parked records -> the compact copy the back-substitution streams (BaDev::r_cj): four fully coalesced 1-KB
        // stores per group, issued BEHIND the prefetch loads (gfx9 counts stores in vmcnt: in front of them the wait for the next group's
        // records would also wait for these stores' acknowledgements)
@@ -1697,6 +1705,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_ba_sc_host(const BaDev* __restri
         }
       }
     }
+    SCSUB(2);
     {  // phase 1: per-point terms, lane = point (identical to k_ba_sc_mfma)
       float HdiF = 0.f, bdSumF = 0.f, Hcd[4] = {0.f, 0.f, 0.f, 0.f};
       int mbits = 0;
@@ -1715,6 +1724,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_ba_sc_host(const BaDev* __restri
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    SCSUB(3);
     {  // phase 2: the group's four MFMA operand sets (points 4 u + kq), read from the parked records as they are: the record of a
        // residual that is not active (or of a target the point does not observe) holds zeros, and a point without an active residual,
        // outside the marginalisation filter or past npts has HdiF = 0 and zero terms in pt[] — exact no-ops, no select needed.
@@ -1745,6 +1755,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_ba_sc_host(const BaDev* __restri
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    SCSUB(4);
     __builtin_amdgcn_wave_barrier();          // the next group overwrites the stage and pt[]
     if (gidx == 0) SCS();
   }
@@ -1829,6 +1840,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_ba_sc_host(const BaDev* __restri
   if ((blockIdx.x == 0 || blockIdx.x == 5) && (blockIdx.y == 0 || blockIdx.y == 100) && lane == 0)
     printf("sc_host (%d,%d) ticks: prologue %llu  first records %llu  group 0 %llu  other groups %llu  wave tree %llu  bins %llu | total %llu  (points %d)\n", blockIdx.x, blockIdx.y,
            st[1] - st[0], st[2] - st[1], st[3] - st[2], st[4] - st[3], st[5] - st[4], st[6] - st[5], st[6] - st[0], pe - pb);
+  if ((blockIdx.x == 0 || blockIdx.x == 5) && (blockIdx.y == 0 || blockIdx.y == 100) && lane == 0)
+    printf("sc_host (%d,%d) inside the group loop, all groups of wave 0: wait + park %llu  request + barrier %llu  r_cj %llu  phase 1 %llu  phase 2 %llu\n", blockIdx.x, blockIdx.y, sub[0], sub[1], sub[2], sub[3], sub[4]);
 #endif
   if (signal) {
     // side-stream launch: tell the tail kernel (already resident, polling) that this host's bins, Hcc partial and per-point terms are
