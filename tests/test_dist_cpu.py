@@ -54,7 +54,7 @@ def _worker(rank, world, port, outdir, mode):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,mode", [(2, "per_host"), (3, "per_host"), (2, "contiguous"), (4, "per_host")])
+@pytest.mark.parametrize("world,mode", [(2, "per_host"), (3, "per_host"), (2, "contiguous"), (4, "per_host"), (8, "per_host")])
 def test_sharded_accumulation_equals_unsharded(oracle, tmp_path, world, mode):
     sys.path[:0] = [os.path.join(ROOT, "stereo-dso-g2o_amd")]
     from sdso_amd import abi, synth, dist as sdist
