@@ -227,3 +227,62 @@ def test_post_state_after_batch_optimize(gpu_ctx, oracle, win_c3, win_dropped):
         oracle.orc_ba_destroy(hs[k][2])
     for k in ids:
         ctx.check(ctx.L.sdso_ba_release_window(ctx.h, int(k)))
+
+
+def test_post_state_of_ragged_windows(gpu_ctx, oracle):
+    """The shapes the reference produces in between: a host keyframe without points, points whose residuals are all gone (they wait for
+    flagPointsForRemoval), a window without any point.  The bookkeeping of linearizeAll(true) / addPointSC on them: a point without an
+    active residual has HdiF = idepth_hessian = 0 and maxRelBaseline reset (AccumulatedSCHessian.cpp:44-48), contributes no count, and
+    the call works on empty arrays."""
+    ctx = gpu_ctx
+    base = synth.ba_window(w=320, h=240, nf=4, pts_per_kf=30, seed=3074)
+
+    def strip(win, keep_pts=None, drop_res=None, empty=False):
+        win = dict(win)
+        if keep_pts is not None:
+            idx = np.nonzero(keep_pts)[0]
+            remap = -np.ones(win["np"], np.int64); remap[idx] = np.arange(len(idx))
+            rk = keep_pts[win["res_point"]]
+            for k in ("u", "v", "idepth", "idepth_zero", "color", "weights", "host", "hasDepthPrior"):
+                win[k] = win[k][idx]
+            win["res_point"] = remap[win["res_point"][rk]].astype(np.int32); win["res_target"] = win["res_target"][rk]; win["res_state"] = win["res_state"][rk]
+            win["np"], win["nr"] = len(idx), int(rk.sum())
+        if drop_res is not None:
+            for k in ("res_point", "res_target", "res_state"):
+                win[k] = win[k][~drop_res]
+            win["nr"] = int((~drop_res).sum())
+        if empty:
+            for k in ("u", "v", "idepth", "idepth_zero", "host", "hasDepthPrior", "color", "weights", "res_point", "res_target", "res_state"):
+                win[k] = win[k][:0]
+            win["np"] = win["nr"] = 0
+        return win
+    bare = np.arange(0, base["np"], 3)
+    cases = [("empty_host", strip(base, keep_pts=base["host"] != 1)),
+             ("points_without_residuals", strip(base, drop_res=np.isin(base["res_point"], bare))),
+             ("no_points", strip(base, empty=True))]
+    for name, win in cases:
+        nf, npts, nr = win["nf"], win["np"], win["nr"]
+        win["maxRelBaseline"] = np.full(npts, 0.25, np.float32)                     # a history, so that the reset is visible
+        win["numGoodResiduals"] = np.full(npts, 2, np.int32)
+        W, keep, h = _upload_both(ctx, oracle, win, wid=5, slot0=60)
+        Po, do, Pg, dg = _post_both(ctx, oracle, win, 5, 4, h)
+        assert Pg.result.iterations == Po.result.iterations, name
+        assert (Pg.resInA, Pg.resInL, Pg.resInM, Pg.n_toRemove) == (Po.resInA, Po.resInL, Po.resInM, Po.n_toRemove) or nr > 0, name
+        if nr:
+            flips = dg["state_state"] != do["state_state"]
+            assert flips.sum() <= 2, name
+            ok = ~flips
+            assert np.array_equal(dg["toRemove"][ok], do["toRemove"][ok]) and np.array_equal(dg["isActiveAndIsGoodNEW"][ok], do["isActiveAndIsGoodNEW"][ok]), name
+            pt_ok = np.ones(npts, bool); pt_ok[win["res_point"][flips]] = False
+            assert np.array_equal(dg["numGoodResiduals"][pt_ok], do["numGoodResiduals"][pt_ok]), name
+            assert np.array_equal(dg["idepth_hessian"][pt_ok] == 0, do["idepth_hessian"][pt_ok] == 0), name
+            assert np.array_equal(dg["maxRelBaseline"][pt_ok] == 0, do["maxRelBaseline"][pt_ok] == 0), name
+            assert np.abs(dg["state"] - do["state"]).max() <= 2e-4, name
+        if name == "points_without_residuals":
+            assert not dg["HdiF"][bare].any() and not dg["idepth_hessian"][bare].any() and not dg["maxRelBaseline"][bare].any()
+            assert np.array_equal(dg["numGoodResiduals"][bare], win["numGoodResiduals"][bare])                  # untouched history
+            assert np.array_equal(dg["idepth"][bare], win["idepth"][bare])                                      # and no step (EnergyFunctional.cpp:305-309)
+        if name == "no_points":
+            assert (Pg.resInA, Pg.n_toRemove) == (0, 0) and np.isfinite(dg["state"]).all()
+        oracle.orc_ba_destroy(h)
+        ctx.check(ctx.L.sdso_ba_release_window(ctx.h, 5))
