@@ -190,7 +190,8 @@ def test_gn_loop_against_f64_truth(gpu_ctx, oracle, which):
 
 
 def test_device_noise_is_the_cpu_float_noise(gpu_ctx, oracle):
-    """The statement about the kernels: over 24 windows (4 .. 8 keyframes, two image sizes, three of them with points initialised 30 % off)
+    """The statement about the kernels: over 18 windows (4 .. 8 keyframes, two image sizes, two of them with points initialised 30 % off; the
+    first 18 of tests/diag/truth_spread.py's 24 — the suite has to fit the GPU box's time limit, the diagnostic runs them all)
     the device's distance from the f64-accumulator truth after the 6-iteration loop has the distribution of the CPU float path's distance —
     the reference's own arithmetic with its own summation order.  Measured on MI355X (profiles/r04_truth_spread.txt): median 2.27e-5
     against 2.38e-5, mean 4.1e-5 against 3.2e-5, maximum 1.9e-4 against 1.1e-4; SDSO_BA_TAIL=0 gives the same numbers to 1e-9."""
@@ -199,7 +200,7 @@ def test_device_noise_is_the_cpu_float_noise(gpu_ctx, oracle):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "diag"))
     import truth_spread
     rows = []
-    for name, win in truth_spread.windows(24):
+    for name, win in truth_spread.windows(18):
         dev, cpu, its = truth_spread.loop_distances(gpu_ctx, oracle, win)
         assert its[0] == its[2], (name, its)                                 # the device takes the truth's number of iterations
         rows.append((dev, cpu))
@@ -207,4 +208,4 @@ def test_device_noise_is_the_cpu_float_noise(gpu_ctx, oracle):
     assert sm["dev_median"] <= 1.5 * sm["cpu_median"] + 5e-6, sm
     assert sm["dev_mean"] <= 2.0 * sm["cpu_mean"], sm
     assert sm["dev_max"] <= 3e-4 and sm["cpu_max"] <= 3e-4, sm              # the same absolute bar for both
-    assert 6 <= sm["dev_worse"] <= 18, sm                                   # neither path is systematically closer
+    assert 4 <= sm["dev_worse"] <= 14, sm                                   # neither path is systematically closer (measured: 8 of 18)
