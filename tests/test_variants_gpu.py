@@ -26,12 +26,12 @@ BA = ["tests/test_ba_resident_gpu.py::test_batch_resident_loop", "tests/test_ba_
       "tests/test_ba_fused_gpu.py::test_fused_batch_matches_oracle_at_bench_config"]
 BA_LIGHT = [BA[0], BA[2]]        # the batch loop and the fused kernel at the bench configuration (the suite has to fit the GPU box's time limit)
 VARIANTS = [
-    ({"SDSO_BA_TAIL": "0"}, BA + ["tests/test_ba_gpu.py", "-k", "not device_solver_of_the_svd"]),
-    ({"SDSO_BA_TAIL": "0", "SDSO_BA_SOLVE": "2"}, ["tests/test_ba_gpu.py"]),
+    ({"SDSO_BA_TAIL": "0"}, BA + ["tests/test_ba_gpu.py", "-k", "resident or fused or accumulate_solve or optimize_full_gn_loop or energy_gated or tables_linearize_apply or ragged or batch_equals_single or marginalize_points"]),
+    ({"SDSO_BA_TAIL": "0", "SDSO_BA_SOLVE": "2"}, ["tests/test_ba_gpu.py", "-k", "accumulate_solve or optimize_full_gn_loop"]),
     ({"SDSO_BA_SOLVE_HOST": "1"}, ["tests/test_ba_gpu.py::test_solver_mode_variants"]),
     ({"SDSO_BA_JSWAP": "1"}, BA_LIGHT),
     ({"SDSO_SC_WAVES": "2"}, BA_LIGHT[1:]),
-    ({"SDSO_BA_SC_ASYNC": "1"}, BA),
+    ({"SDSO_BA_SC_ASYNC": "1"}, BA_LIGHT),
     ({"SDSO_TRK_HOST_LM": "1"}, ["tests/test_tracker_gpu.py::test_track_newest_coarse_pose_within_1e5", "tests/test_tracker_gpu.py::test_track_hypotheses_in_lock_step",
                                  "tests/test_tracker_gpu.py::test_track_affine_modes"]),
     ({"SDSO_TRK_LM_CLUSTER": "1"}, ["tests/test_tracker_gpu.py::test_track_newest_coarse_pose_within_1e5", "tests/test_tracker_gpu.py::test_track_hypotheses_in_lock_step",
