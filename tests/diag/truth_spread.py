@@ -17,11 +17,18 @@ import pyoracle  # noqa: E402
 
 
 def windows(n):
+    """The n seeded windows, rendered on a few host threads (numpy releases the GIL; same arrays as one after the other: every window has
+    its own RandomState)"""
+    from concurrent.futures import ThreadPoolExecutor
     shapes = [(640, 480, 5, 120), (640, 480, 4, 80), (640, 480, 6, 150), (1232, 368, 8, 250), (640, 480, 7, 100), (1232, 368, 8, 120)]
-    for k in range(n):
+
+    def gen(k):
         w, h, nf, ppk = shapes[k % len(shapes)]
         kw = dict(idepth_noise=0.3, state_noise=1e-2) if k % 7 == 6 else {}
-        yield "w%02d_nf%d%s" % (k, nf, "_noisy" if kw else ""), synth.ba_window(w=w, h=h, nf=nf, pts_per_kf=ppk, seed=5001 + 13 * k, **kw)
+        return "w%02d_nf%d%s" % (k, nf, "_noisy" if kw else ""), synth.ba_window(w=w, h=h, nf=nf, pts_per_kf=ppk, seed=5001 + 13 * k, **kw)
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        for item in ex.map(gen, range(n)):
+            yield item
 
 
 def loop_distances(ctx, oracle, win, its=6):
