@@ -178,3 +178,15 @@ def smoke_stereo(ctx, orc):
     for k in ("idepth_min_stereo", "idepth_max_stereo", "idepth_stereo", "lastTraceUV"):
         assert np.array_equal(do[k], dg[k], equal_nan=True), k
     print("smoke stereo ok: good", int((sg == 0).sum()), "of", n)
+
+
+def gen_windows(specs):
+    """synth.ba_window(**spec) for every spec, rendered on a few host threads (numpy releases the GIL; every window has its own
+    RandomState, so the arrays are those of one call after the other)"""
+    from concurrent.futures import ThreadPoolExecutor
+    from sdso_amd import synth
+    specs = list(specs)
+    if len(specs) <= 1:
+        return [synth.ba_window(**s) for s in specs]
+    with ThreadPoolExecutor(max_workers=min(4, len(specs))) as ex:
+        return list(ex.map(lambda s: synth.ba_window(**s), specs))

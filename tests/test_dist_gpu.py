@@ -240,7 +240,9 @@ def _opt_worker(rank, world, port, outdir, gated=False, exchange_mode=0, tag="op
     ctx = abi.Context(0)
     cbs = _host_transport(dist, torch, world)
     ctx.check(ctx.L.sdso_comm_init_host(ctx.h, world, rank, cbs[0], cbs[1], None))
-    shards = [sdist.shard_window(synth.ba_window(**s), rank, world) for s in (specs or _OPT_SPECS)]
+    sys.path[:0] = [os.path.join(ROOT, "tests")]
+    import helpers
+    shards = [sdist.shard_window(w, rank, world) for w in helpers.gen_windows(specs or _OPT_SPECS)]
     subs = [sh[0] for sh in shards]
     for k, sh in enumerate(shards):
         np.savez(os.path.join(outdir, "idx_%d_%d.npz" % (rank, k)), p=sh[1], r=sh[2])
@@ -263,7 +265,8 @@ def test_two_rank_sharded_gn_loop_matches_single(gpu_ctx, oracle, tmp_path):
     import helpers
     world = 2
     mp.spawn(_opt_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
-    wins = [synth.ba_window(**s) for s in _OPT_SPECS]
+    import helpers
+    wins = helpers.gen_windows(_OPT_SPECS)
     single = _batch_optimize(gpu_ctx, abi, wins, 41, 600)
     for k, win in enumerate(wins):
         nf, npts, nr = win["nf"], win["np"], win["nr"]
@@ -312,7 +315,8 @@ def test_two_rank_sharded_energy_gated_loop_matches_single(gpu_ctx, tmp_path):
     import helpers
     world = 2
     mp.spawn(_opt_worker, args=(world, _free_port(), str(tmp_path), True), nprocs=world, join=True)
-    wins = [synth.ba_window(**s) for s in _OPT_SPECS]
+    import helpers
+    wins = helpers.gen_windows(_OPT_SPECS)
     for w in wins:
         w["forceAcceptStep"] = 0
     single = _batch_optimize(gpu_ctx, abi, wins, 51, 700)
@@ -347,7 +351,8 @@ def test_three_ranks_three_windows_both_exchange_shapes(gpu_ctx, tmp_path):
     world = 3
     for mode, tag in ((0, "ar3"), (1, "rs3")):
         mp.spawn(_opt_worker, args=(world, _free_port(), str(tmp_path), False, mode, tag, _OPT_SPECS3), nprocs=world, join=True)
-    wins = [synth.ba_window(**s) for s in _OPT_SPECS3]
+    import helpers
+    wins = helpers.gen_windows(_OPT_SPECS3)
     single = _batch_optimize(gpu_ctx, abi, wins, 61, 800)
     for k in range(len(_OPT_SPECS3)):
         ref = np.load(tmp_path / ("ar3_0_%d.npz" % k))
@@ -369,8 +374,9 @@ def _two_comm_worker(rank, world, port, outdir):
     import threading
     import torch
     import torch.distributed as dist
-    sys.path[:0] = [os.path.join(ROOT, "stereo-dso-g2o_amd")]
+    sys.path[:0] = [os.path.join(ROOT, "stereo-dso-g2o_amd"), os.path.join(ROOT, "tests")]
     from sdso_amd import abi, synth, dist as sdist
+    import helpers
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -390,7 +396,7 @@ def _two_comm_worker(rank, world, port, outdir):
         ctxs.append(ctx); cbs.append(cb)
         # both batches hold both windows, in opposite order: the same work, different collectives in flight at any one time
         specs = _OPT_SPECS if g == 0 else _OPT_SPECS[::-1]
-        subs.append([sdist.shard_window(synth.ba_window(**s), rank, world)[0] for s in specs])
+        subs.append([sdist.shard_window(w, rank, world)[0] for w in helpers.gen_windows(specs)])
     outs, errs = [None, None], []
 
     def run(g):
@@ -434,7 +440,8 @@ def test_resident_loop_through_rccl_one_rank(monkeypatch):
     sdso_ba_batch_optimize takes the multi-rank path — ncclAllReduce(max) of the pack capacity, per iteration ncclAllReduce of the
     accumulators, k_ba_opt_pack and ncclAllGather of the energy records — and must reproduce the plain single-rank run bit for bit."""
     from sdso_amd import abi, synth
-    wins = [synth.ba_window(**s) for s in _OPT_SPECS]
+    import helpers
+    wins = helpers.gen_windows(_OPT_SPECS)
     outs = {}
     for mode in ("plain", "rccl", "rccl_scatter"):
         ctx = abi.Context(0)
