@@ -400,6 +400,12 @@ int sdso_ba_batch_exchange_mode(sdso_ctx* ctx, int mode);
 int sdso_ba_batch_solve(sdso_ctx* ctx, double lambda, int orthogonalize_x);
 int sdso_ba_batch_accum_dev(sdso_ctx* ctx, void** dev_ptr, long* nfloats);
 int sdso_ba_batch_get_x(sdso_ctx* ctx, double* x /* nwin*(8nf+4) */);
+/* EnergyFunctional::accumulateAF_MT / accumulateLF_MT / accumulateSCF_MT (EnergyFunctional.cpp:212-269) as the reference's callers see
+ * them: the STITCHED systems (AccumulatedTopHessianSSE::stitchDoubleMT without / with priors, AccumulatedTopHessian.h:95-148;
+ * AccumulatedSCHessianSSE::stitchDoubleMT, AccumulatedSCHessian.h:96-135) of the accumulators sdso_ba_accumulate left: (8nf+4)^2
+ * row-major + (8nf+4) doubles each, any pointer may be NULL.  solveSystemF adds them up (:856-868); the fused kernels never
+ * materialise them, this call runs the stitch kernels on demand (synchronises). */
+int sdso_ba_get_stitched(sdso_ctx* ctx, int win, double* HA, double* bA, double* HL, double* bL, double* Hsc, double* bsc);
 
 /* FullSystem::optimize (FullSystemOptimize.cpp:871-1041, DSO-native loop) for EVERY window of the batch, device-resident: the host
  * logic between the kernel phases — backupState / doStepFromBackup (:207-351), FrameHessian::setState, setPrecalcValues

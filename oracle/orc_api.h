@@ -192,6 +192,9 @@ int orc_ba_get_point_terms(orc_ba* h, float* HdiF, float* bdSumF, float* Hdd_acc
                            float* Hcd_accAF);
 int orc_ba_solve(orc_ba* h, int iteration, double lambda, double* x, double* HS, double* bS,
                  double* frame_step, double* calib_step);
+/* accumulate{AF,LF,SCF}_MT (EnergyFunctional.cpp:212-269): the stitched top-A (no priors), top-L (with priors) and Schur systems of the
+ * accumulators as they stand after orc_ba_accumulate; n x n row-major + n each, any pointer may be NULL */
+int orc_ba_get_stitched(orc_ba* h, double* HA, double* bA, double* HL, double* bL, double* Hsc, double* bsc);
 int orc_ba_get_point_steps(orc_ba* h, float* step);
 int orc_ba_optimize(orc_ba* h, int mnumOptIts, double* state_out, float* idepth_out,
                     uint8_t* res_state_out, orc_ba_opt_result_t* out);

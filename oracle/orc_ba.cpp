@@ -1479,6 +1479,22 @@ extern "C" int orc_ba_solve(orc_ba* h, int iteration, double lambda, double* x, 
   if (calib_step) for (int i = 0; i < 4; i++) calib_step[i] = h->HCalib.step[i];
   return 0;
 }
+// EnergyFunctional::accumulateAF_MT / accumulateLF_MT / accumulateSCF_MT (EnergyFunctional.cpp:212-269): the three stitched systems
+// solveSystemF adds up (:856-868) — top A without priors, top L with priors, Schur complement — of the accumulators as they stand
+extern "C" int orc_ba_get_stitched(orc_ba* h, double* HA, double* bA, double* HL, double* bL, double* Hsc, double* bsc) {
+  const int n = 4 + h->nf * 8;
+  MatX A, L, S;
+  VecX a, l, sv;
+  h->stitchTop(false, A, a, false);
+  h->stitchTop(true, L, l, true);
+  h->stitchSC(S, sv);
+  auto put = [n](const MatX& M, const VecX& v, double* Ho, double* bo) {
+    if (Ho) for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) Ho[(size_t)i * n + j] = M(i, j);
+    if (bo) for (int i = 0; i < n; i++) bo[i] = v[i];
+  };
+  put(A, a, HA, bA); put(L, l, HL, bL); put(S, sv, Hsc, bsc);
+  return 0;
+}
 extern "C" int orc_ba_get_point_steps(orc_ba* h, float* step) { for (int i = 0; i < h->np; i++) step[i] = h->points[i].step; return 0; }
 extern "C" int orc_ba_optimize(orc_ba* h, int mnumOptIts, double* state_out, float* idepth_out, uint8_t* res_state_out, orc_ba_opt_result_t* out) {
   orc_ba_opt_result_t tmp;

@@ -72,6 +72,7 @@ def load(fast=False, path=None):
                                           C.POINTER(c_float_p), C.POINTER(TrackParams), C.POINTER(SE3), C.POINTER(Aff), C.POINTER(TrackResult)]
     L.orc_make_coarse_depth.argtypes = [C.c_int, c_int_p, c_int_p, C.POINTER(c_float_p), C.c_int, c_int_p, c_int_p, c_float_p, c_float_p, c_int_p,
                                         C.POINTER(c_float_p), C.POINTER(c_float_p), C.POINTER(c_float_p), C.POINTER(c_float_p)]
+    L.orc_ba_get_stitched.argtypes = [vp] + [c_double_p] * 6
     L.orc_track_last_margins.argtypes = [c_double_p]
     L.orc_track_last_margins.restype = None
     L.orc_ba_create.argtypes = [C.POINTER(BAWindow)]

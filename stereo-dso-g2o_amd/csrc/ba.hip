@@ -1078,6 +1078,26 @@ extern "C" int sdso_ba_solve(sdso_ctx* ctx, int win, int iteration, double lambd
   return SDSO_OK;
 }
 
+extern "C" int sdso_ba_get_stitched(sdso_ctx* ctx, int win, double* HA, double* bA, double* HL, double* bL, double* Hsc, double* bsc) {
+  GET_WIN();
+  SDSO_REQUIRE(ctx, W->accumulated, "sdso_ba_get_stitched needs sdso_ba_accumulate first");
+  ensure_folded_win(ctx, W);
+  launch_stitch(ctx, single(W));
+  SDSO_HIP(ctx, hipGetLastError());
+  const int n = W->d.n;
+  const size_t blk = (size_t)n * n + n;
+  std::vector<double> st(3 * blk);
+  SDSO_HIP(ctx, hipMemcpyAsync(st.data(), W->d.sol, sizeof(double) * st.size(), hipMemcpyDeviceToHost, ctx->stream));
+  SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  double* Hs[3] = {HA, HL, Hsc};
+  double* bs[3] = {bA, bL, bsc};
+  for (int k = 0; k < 3; k++) {
+    if (Hs[k]) std::memcpy(Hs[k], st.data() + k * blk, sizeof(double) * n * n);
+    if (bs[k]) std::memcpy(bs[k], st.data() + k * blk + (size_t)n * n, sizeof(double) * n);
+  }
+  return SDSO_OK;
+}
+
 // EnergyFunctional::resubstituteF_MT (EnergyFunctional.cpp:272-341) for a caller-supplied x: frame / calibration steps = -x, xAd from the
 // float adjoints (:283-292), then resubstituteFPt for every point on the device
 extern "C" int sdso_ba_resubstitute(sdso_ctx* ctx, int win, const double* x, double* frame_step, double* calib_step) {

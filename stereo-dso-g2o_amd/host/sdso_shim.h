@@ -257,6 +257,15 @@ class WindowedBA {
     allreduce();
     dev_.check(sdso_ba_solve(dev_.ctx(), win_, iteration, lambda, lastX.data(), nullptr, nullptr, frame_step.data(), calib_step), "sdso_ba_solve");
   }
+  // void EnergyFunctional::accumulateAF_MT(MatXX& H, VecX& b, bool MT) / accumulateLF_MT / accumulateSCF_MT (EnergyFunctional.cpp:212-269,
+  // EnergyFunctional.h:103-105): what the reference's callers get back is the STITCHED system of AccumulatedTopHessianSSE::stitchDoubleMT
+  // (mode 0 without priors, mode 1 with priors) / AccumulatedSCHessianSSE::stitchDoubleMT.  The device accumulates all three in one pass
+  // (sdso_ba_accumulate) and its solver never materialises them; these members run the stitch kernels on demand.  MatXX / VecX: anything
+  // with resize(rows[, cols]) and operator()(i[, j]) — Eigen's, or the stand-ins of host/test_shim.cpp.  `MT` is ignored.
+  void accumulateAll() { dev_.check(sdso_ba_accumulate(dev_.ctx(), win_), "sdso_ba_accumulate"); allreduce(); }
+  template <class MatXX, class VecX> void accumulateAF_MT(MatXX& H, VecX& b, bool /*MT*/) { stitched_(0, H, b); }
+  template <class MatXX, class VecX> void accumulateLF_MT(MatXX& H, VecX& b, bool /*MT*/) { stitched_(1, H, b); }
+  template <class MatXX, class VecX> void accumulateSCF_MT(MatXX& H, VecX& b, bool /*MT*/) { stitched_(2, H, b); }
   // float FullSystem::optimize(int mnumOptIts) — FullSystemOptimize.cpp:871-1041 from `activeResiduals.clear()` (:880) through the closing
   // `linearizeAll(true)` (:1008) — on the uploaded window, with EVERYTHING that function leaves behind written back into the reference's
   // own objects (sdso_ba_get_post_state):
@@ -382,6 +391,16 @@ class WindowedBA {
   sdso_ba_opt_result_t lastResult{};
 
  private:
+  template <class MatXX, class VecX> void stitched_(int which, MatXX& H, VecX& b) {
+    const int n = 8 * nf_ + 4;
+    std::vector<double> Hs((size_t)n * n), bs(n);
+    double* Hp[3] = {nullptr, nullptr, nullptr};
+    double* bp[3] = {nullptr, nullptr, nullptr};
+    Hp[which] = Hs.data(); bp[which] = bs.data();
+    dev_.check(sdso_ba_get_stitched(dev_.ctx(), win_, Hp[0], bp[0], Hp[1], bp[1], Hp[2], bp[2]), "sdso_ba_get_stitched");
+    H.resize(n, n); b.resize(n);
+    for (int i = 0; i < n; i++) { b(i) = bs[i]; for (int j = 0; j < n; j++) H(i, j) = Hs[(size_t)i * n + j]; }
+  }
   Device& dev_;
   int win_, nf_ = 0, resInM_seen_ = 0;
   std::vector<double> evalPT_, state_, state_zero_, HM_, bM_;

@@ -89,6 +89,11 @@ struct DynMat {
   void resize(int r, int c) { n = c; d.assign((size_t)r * c, 0.0); }
   double& operator()(int i, int j) { return d[(size_t)i * n + j]; }
 };
+struct DynVec {
+  std::vector<double> d;
+  void resize(int r) { d.assign((size_t)r, 0.0); }
+  double& operator()(int i) { return d[(size_t)i]; }
+};
 struct EnergyFunctional {
   std::vector<EFFrame*> frames; DynMat HM, lastHS; std::vector<double> bM, lastbS, lastX;
   int resInA = 0, resInL = 0, resInM = 0, nResiduals = 0;
@@ -319,6 +324,13 @@ static int run_ba(const std::string& dir) {
   dump(dir, "frameEnergyTH", o_eth); dump(dir, "pt", o_pt); dump(dir, "pi", o_pi); dump(dir, "lists", o_lists); dump(dir, "alive", o_alive);
   dump(dir, "rstate", o_rstate); dump(dir, "ract", o_ract); dump(dir, "renergy", o_renergy); dump(dir, "cpt", o_cpt); dump(dir, "prj", o_prj);
   dump(dir, "lastX", o_lastX); dump(dir, "lastbS", o_lastbS); dump(dir, "lastHS", o_lastHS); dump(dir, "counts", o_counts);
+  // EnergyFunctional::accumulate{AF,LF,SCF}_MT at the state optimize() left (EnergyFunctional.cpp:212-269): the three stitched systems
+  ba.linearizeAll(); ba.applyRes(); ba.accumulateAll();
+  DynMat H3[3]; DynVec b3[3];
+  ba.accumulateAF_MT(H3[0], b3[0], false); ba.accumulateLF_MT(H3[1], b3[1], false); ba.accumulateSCF_MT(H3[2], b3[2], false);
+  std::vector<double> o_st;
+  for (int k = 0; k < 3; k++) { o_st.insert(o_st.end(), H3[k].d.begin(), H3[k].d.end()); o_st.insert(o_st.end(), b3[k].d.begin(), b3[k].d.end()); }
+  dump(dir, "stitched", o_st);
   for (auto& ph : phs) for (PointFrameResidual* rr : ph->residuals) { delete rr->efResidual; delete rr; }
   return 0;
 }

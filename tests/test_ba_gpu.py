@@ -294,6 +294,44 @@ def test_device_solver_of_the_svd_and_orthogonalised_branches(gpu_ctx, oracle, w
     gpu_ctx.check(gpu_ctx.L.sdso_ba_release_window(gpu_ctx.h, 9))
 
 
+def test_stitched_systems_of_the_three_accumulations(gpu_ctx, oracle, win_c3):
+    """EnergyFunctional::accumulateAF_MT / accumulateLF_MT / accumulateSCF_MT (EnergyFunctional.cpp:212-269) return the STITCHED systems
+    (AccumulatedTopHessian.h:95-148 without / with priors, AccumulatedSCHessian.h:96-135); sdso_ba_get_stitched hands them out.  Same
+    state on both sides: the stitch bars of the default branch per block, exact symmetry, and the sum solveSystemF forms from them
+    (HL + HM + HA - Hsc = lastHS, :906-909) to rounding."""
+    win = dict(win_c3)
+    W, keep, h = _both(gpu_ctx, oracle, win, wid=11)
+    n = 8 * win["nf"] + 4
+    _lin_both(gpu_ctx, oracle, win, h, 11)
+    oracle.orc_ba_apply_res(h); oracle.orc_ba_accumulate(h)
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_apply_res(gpu_ctx.h, 11))
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_accumulate(gpu_ctx.h, 11))
+    so = [(np.zeros((n, n)), np.zeros(n)) for _ in range(3)]
+    sg = [(np.zeros((n, n)), np.zeros(n)) for _ in range(3)]
+    oracle.orc_ba_get_stitched(h, *[abi.dp(a) for pair in so for a in pair])
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_get_stitched(gpu_ctx.h, 11, *[abi.dp(a) for pair in sg for a in pair]))
+    x, HS, bS = np.zeros(n), np.zeros((n, n)), np.zeros(n)
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_solve(gpu_ctx.h, 11, 0, 0.1, abi.dp(x), abi.dp(HS), abi.dp(bS), None, None))
+    d = np.sqrt(np.abs(np.diag(HS))) + 1e-30
+    for k, name in enumerate(("A", "L", "SC")):
+        (Hg, bg), (Ho, bo) = sg[k], so[k]
+        assert np.array_equal(Hg, Hg.T) or np.abs(Hg - Hg.T).max() <= 1e-12 * np.abs(Hg).max(), name
+        assert np.abs((Hg - Ho) / np.outer(d, d)).max() <= 1e-4, (name, np.abs((Hg - Ho) / np.outer(d, d)).max())
+        assert np.abs((bg - bo) / d).max() <= 1e-4 * max(1.0, np.abs(bo / d).max()), name
+        assert np.abs(Hg).max() > 0, name
+    HM = np.asarray(win["HM"], np.float64).reshape(n, n)
+    total = sg[1][0] + HM + sg[0][0] - sg[2][0]
+    assert np.abs((total - HS) / np.outer(d, d)).max() <= 1e-9
+    # partial requests and the precondition
+    only = np.zeros((n, n))
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_get_stitched(gpu_ctx.h, 11, None, None, None, None, abi.dp(only), None))
+    assert np.array_equal(only, sg[2][0])
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_upload_window(gpu_ctx.h, 11, C.byref(W)))
+    assert gpu_ctx.L.sdso_ba_get_stitched(gpu_ctx.h, 11, abi.dp(only), None, None, None, None, None) == -1      # nothing accumulated yet
+    oracle.orc_ba_destroy(h)
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_release_window(gpu_ctx.h, 11))
+
+
 @pytest.mark.parametrize("which", ["small", "c3"])
 def test_optimize_full_gn_loop(gpu_ctx, oracle, win_small, win_c3, which):
     win = win_small if which == "small" else win_c3

@@ -148,6 +148,10 @@ def test_shim_windowed_ba(gpu_ctx, oracle, tmp_path, which):
     oracle.orc_ba_optimize(h, 6, None, None, None, C.byref(oo))
     Po, do = abi.make_post_state(nf, npts, nr)
     oracle.orc_ba_get_post_state(h, C.byref(Po))
+    # EnergyFunctional::accumulate{AF,LF,SCF}_MT at the state the loop left: the three stitched systems (the shim's members of the same name)
+    oracle.orc_ba_linearize(h, None); oracle.orc_ba_apply_res(h); oracle.orc_ba_accumulate(h)
+    st_o = [(np.zeros((n, n)), np.zeros(n)) for _ in range(3)]
+    oracle.orc_ba_get_stitched(h, *[abi.dp(a) for pair in st_o for a in pair])
     oracle.orc_ba_destroy(h)
     # ---- the C++ program
     arrays = dict(meta=np.array([nf, npts, nr, win["w"], win["h"], 6, win["solverMode"]], np.int32),
@@ -194,6 +198,19 @@ def test_shim_windowed_ba(gpu_ctx, oracle, tmp_path, which):
     Pg.n_toRemove = int(counts[4]); Pg.resInA, Pg.resInL, Pg.resInM = int(counts[0]), int(counts[1]), int(counts[2])
     Pg.calib_value, Pg.calib_value_scaled, Pg.calib_step = list(cal[0:4]), list(cal[4:8]), list(cal[8:12])
     flips = check_post_state(win, Po, do, Pg, dg)
+    # accumulateAF_MT / accumulateLF_MT / accumulateSCF_MT through the shim: H, b of the top-A, top-L (priors) and Schur systems, each at its
+    # own side's final state (they differ by the loop bars)
+    st = _load(d, "stitched", np.float64).reshape(3, n * n + n)
+    dd = np.sqrt(np.abs(np.diag(do["lastHS"]))) + 1e-30
+    for k, name in enumerate(("A", "L", "SC")):
+        Hs, bs = st[k, :n * n].reshape(n, n), st[k, n * n:]
+        Ho, bo = st_o[k]
+        assert np.abs(Hs - Hs.T).max() <= 1e-9 * max(1.0, np.abs(Hs).max()), name
+        assert np.abs((Hs - Ho) / np.outer(dd, dd)).max() <= 2e-3, (name, np.abs((Hs - Ho) / np.outer(dd, dd)).max())
+        # (b at two final states ~1e-5 apart, a flipped residual included: tests/test_ba_gpu.py::test_stitched_systems_of_the_three_accumulations
+        #  holds the same-state bars, 1e-4)
+        assert np.abs((bs - bo) / dd).max() <= 2e-2 * max(1.0, np.abs(bo / dd).max()), (name, np.abs((bs - bo) / dd).max())
+    assert np.abs(st[0, :n * n]).max() > 0 and np.abs(st[2, :n * n]).max() > 0
     assert int(head[3]) == oo.iterations and int(head[9]) == Pg.n_toRemove and int(head[11]) == nr - Pg.n_toRemove
     # every survivor is IN and active: nothing else stays in ph->residuals after the closing linearizeAll (:80-84, :176-195)
     assert np.all(rstate[alive] == 0) and np.all(ract[alive] == 1)
