@@ -235,6 +235,81 @@ def side_run(cls, ctx, args, rank, steps=30, warmup=5):
     return out
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: N child processes of this same command line, one per GPU
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set as torch.distributed.run would), started from a parent that has not
+    imported torch or made a HIP call.  Rank 0's stdout (the ONE JSON line) is relayed; any child that fails fails the run."""
+    import socket
+    import subprocess
+    backend = os.environ.get("SDSO_DIST_BACKEND", "nccl")
+    if backend == "nccl":
+        # one rank per device: counted without initialising HIP in this process (sysfs render nodes of the KFD topology)
+        ndev = _count_gpus()
+        if ndev is not None and ndev < n:
+            raise SystemExit("bench.py: --gpus %d but only %d GPU(s) visible on this node (SDSO_DIST_BACKEND=gloo_lib rehearses "
+                             "N ranks on fewer devices through the library's host transport)" % (n, ndev))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    import threading
+    buf = []
+    rd = threading.Thread(target=lambda: buf.append(procs[0].stdout.read()), daemon=True)
+    rd.start()
+    # a rank that dies leaves the others in a rendezvous or a collective: end exactly the processes started here
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs):
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            break
+        time.sleep(0.2)
+    rcs = []
+    for p in procs:
+        try:
+            rcs.append(p.wait(timeout=30))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            rcs.append(p.wait())
+    rd.join(timeout=10)
+    out0 = (buf[0] if buf else b"").decode()
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        print("bench.py: rank(s) failed: %s" % ", ".join("rank %d rc %d" % b for b in bad), file=sys.stderr, flush=True)
+        return 1
+    if not any(l.startswith("{") for l in out0.splitlines()):
+        print("bench.py: rank 0 printed no JSON line", file=sys.stderr, flush=True)
+        return 1
+    return 0
+
+
+def _count_gpus():
+    """GPUs of this node from the KFD topology in sysfs (no HIP call: the launcher must stay free of GPU state)."""
+    vis = os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("ROCR_VISIBLE_DEVICES"))
+    try:
+        n = 0
+        for d in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+            for line in open(d):
+                if line.startswith("simd_count") and int(line.split()[1]) > 0:
+                    n += 1
+        if n == 0:
+            return None
+        if vis is not None and vis.strip() != "":
+            n = min(n, len([v for v in vis.split(",") if v.strip() != ""]))
+        return n
+    except (OSError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -246,6 +321,17 @@ def main():
     ap.add_argument("--scaling", default=os.environ.get("SDSO_BENCH_SCALING", "weak"), choices=["weak", "strong"],
                     help="BA at --gpus N: weak = 2000 points per window and rank (default); strong = BASELINE configs[4], 8000 points per window cut N ways")
     args = ap.parse_args()
+
+    # --gpus N is a statement about the run, not a hint: either this process IS one of N ranks (the driver's
+    # `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`, WORLD_SIZE = N), or it is asked for N ranks and
+    # starts them itself — before torch or HIP is touched in this process, which stays a plain relay.  Anything else fails loudly:
+    # a line with "n_gpus": 1 must never come out of a command that said --gpus 8.
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))
+    if env_world is not None and int(env_world) != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%s — start it as `python bench.py --gpus N` (it launches its own ranks) or "
+                         "`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`" % (args.gpus, env_world))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -59,7 +59,6 @@ struct BaWindowDev {
                                 // sdso_ba_get_linearization reads the records from there
   // post-state of FullSystem::optimize (sdso_ba_get_post_state)
   bool post_valid = false;      // an optimize call has ended on this window
-  bool post_pending = false;    // ... and k_ba_post_state (linearizeAll_Reductor's per-residual bookkeeping, FullSystemOptimize.cpp:62-78) has not run for it yet
   bool hs_valid = false;        // the last solveSystemF of that call wrote lastHS / lastbS
   sdso_ba_opt_result_t last_result{0, 0, 0, 0};
   float* d_post = nullptr;      // nr x 19: projectedTo, centerProjectedTo of the closing linearisation
@@ -1287,7 +1286,18 @@ extern "C" int sdso_ba_optimize(sdso_ctx* ctx, int win, int mnumOptIts, double* 
     res.lastEnergy = lastEnergy;
     res.resInA = (int)nresA;
     res.rmse = sqrtf((float)(lastEnergy / (8 * res.resInA)));
-    W->post_valid = true; W->post_pending = true; W->hs_valid = true; W->last_result = res;
+    // linearizeAll_Reductor(true)'s per-residual bookkeeping (maxRelBaseline, numGoodResiduals; FullSystemOptimize.cpp:62-78): once per optimize, now
+    if (nr) hipLaunchKernelGGL(k_ba_post_state, dim3(std::max(W->nblk_res, 1), 1), dim3(BA_BLOCK), 0, ctx->stream, (const BaDev*)W->d_self, (float*)nullptr, 1);
+    SDSO_HIP(ctx, hipGetLastError());
+    {
+      float nres2[2] = {0, 0};
+      SDSO_HIP(ctx, hipMemcpy(nres2, W->d.accum + acc_off_nres(nf), sizeof(nres2), hipMemcpyDeviceToHost));
+      W->resInL = (int)nres2[1];
+    }
+    W->post_valid = true; W->hs_valid = true; W->last_result = res;
+  } else {
+    // fewer than two keyframes: the reference returns 0 before touching anything (FullSystemOptimize.cpp:873-874)
+    W->post_valid = true; W->hs_valid = false; W->last_result = res; W->resInL = 0;
   }
   SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (state_out) for (int f = 0; f < nf; f++) for (int i = 0; i < 10; i++) state_out[f * 10 + i] = W->frames[f].state[i];
@@ -1629,6 +1639,8 @@ struct OptRun {
   bool local_only = false; // single-window call: never a collective, whatever communicator the ctx carries
   bool failed = false;     // a collective of the gated flow failed (sdso_last_error says which)
   bool keep_hs = false;    // every solve also writes lastHS / lastbS (EnergyFunctional.cpp:909-910): sdso_ba_get_post_state hands them out
+  bool scatter_local = false;  // this rank's view: the batch asks for the reduce-scatter exchange and its loop can take it
+  bool scatter = false;    // ... and every rank agreed (opt_begin)
   OptBufs* B = nullptr;
 };
 
@@ -1647,6 +1659,16 @@ static int opt_begin(sdso_ctx* ctx, OptRun& R, int stop_on_convergence) {
   R.gated = !R.W[0]->forceAccept;
   if (R.exchange) { int rc = comm_max_int(ctx, &cap); if (rc) return rc; }
   R.cap = cap;
+  // shape of the accumulators' exchange: one decision for the whole loop, the same on every rank or an error (never mismatched collectives)
+  R.scatter = false;
+  if (R.exchange) {
+    const int want = (R.scatter_local && !R.gated && !R.keep_hs && tail_enabled() && !R.L.alt && nwin % R.nranks == 0) ? 1 : 0;
+    int hi = want, lo = -want;
+    int rc = comm_max_int(ctx, &hi); if (rc) return rc;
+    rc = comm_max_int(ctx, &lo); if (rc) return rc;
+    SDSO_REQUIRE(ctx, hi == -lo, "the ranks disagree on the shape of the accumulators' exchange (sdso_ba_batch_exchange_mode / sdso_ba_batch_keep_system / SDSO_BA_TAIL differ between ranks)");
+    R.scatter = want != 0;
+  }
   R.sums_stride = 2 * (R.L.max_nblk_pts + 1);
   if (!reg_has(g_optbufs, ctx)) reg_get(g_optbufs, ctx) = new OptBufs();
   OptBufs* B = reg_get(g_optbufs, ctx);
@@ -1834,18 +1856,23 @@ static int opt_finish(sdso_ctx* ctx, OptRun& R, sdso_ba_opt_result_t* out) {
   mark_linearized(R.W, false);
   hipLaunchKernelGGL(k_ba_apply, dim3(R.L.max_nblk_res, nwin), dim3(BA_BLOCK), 0, ctx->stream, R.L.d_arr);
   if ((rc = opt_consume(ctx, R, 1, true, false))) return rc;
+  // linearizeAll_Reductor(true)'s per-residual bookkeeping (maxRelBaseline, numGoodResiduals; FullSystemOptimize.cpp:62-78) belongs to THIS
+  // optimize call: it runs now, once, for every window — not when (and if) somebody asks for the post-state
+  hipLaunchKernelGGL(k_ba_post_state, dim3(R.L.max_nblk_res, nwin), dim3(BA_BLOCK), 0, ctx->stream, R.L.d_arr, (float*)nullptr, 1);
+  SDSO_HIP(ctx, hipGetLastError());
   if ((rc = opt_collect(ctx, R))) return rc;
   for (int w = 0; w < nwin; w++) {
     BaWindowDev* W = R.W[w];
     const BaOptOut& o = R.B->h_out[w];
     W->frames[nf - 1].frameEnergyTH = o.frameTH_new;
+    W->resInL = o.resInL;
     sdso_ba_opt_result_t r;
     r.iterations = its[w];
     r.lastEnergy = o.lastEnergy;
     r.resInA = resInA[w];
     r.rmse = sqrtf((float)(o.lastEnergy / (8 * resInA[w])));
     if (out) out[w] = r;
-    W->post_valid = true; W->post_pending = true; W->hs_valid = R.keep_hs || R.gated || !tail_enabled() || R.L.alt; W->last_result = r;
+    W->post_valid = true; W->hs_valid = R.keep_hs || R.gated || !tail_enabled() || R.L.alt; W->last_result = r;
   }
   R.active = false;
   return SDSO_OK;
@@ -1954,14 +1981,16 @@ int optimize_resident_single(sdso_ctx* ctx, BaWindowDev* W, int mnumOptIts, sdso
 // sdso_ba_allreduce asks: is this exchange the reduce-scatter by window?  Only inside the accepted-step resident loop of a sharded batch
 // whose windows divide over the ranks, with the fused tail kernel, and without lastHS / lastbS being kept (they exist on the solving
 // rank only); anything else takes the all-reduce, whatever mode the batch carries.
-bool ba_batch_scatter_begin(sdso_ctx* ctx) {
+// The decision itself is taken ONCE, in sdso_ba_batch_optimize_begin, from this rank's state AND agreed on by all ranks (opt_begin:
+// ranks that disagree — another exchange mode, SDSO_BA_TAIL, keep_system — would issue ncclReduceScatter against ncclAllReduce and hang).
+bool ba_batch_scatter_wanted(sdso_ctx* ctx) {
   BaBatch* Bt = get_batch(ctx);
-  if (!Bt || Bt->exchange_mode != 1 || !tail_enabled() || Bt->L.alt || !reg_has(g_optruns, ctx)) return false;
+  if (!Bt || !reg_has(g_optruns, ctx)) return false;
   OptRun* R = reg_get(g_optruns, ctx);
-  if (!R || !R->active || !R->exchange || R->gated || R->keep_hs || R->W != Bt->W) return false;
-  if ((int)Bt->W.size() % R->nranks != 0) return false;
-  Bt->scattered = true;
-  return true;
+  return R && R->active && R->scatter && R->W == Bt->W;
+}
+void ba_batch_scatter_done(sdso_ctx* ctx) {
+  if (BaBatch* Bt = get_batch(ctx)) Bt->scattered = true;
 }
 void free_optrun(sdso_ctx* ctx) {
   OptRun* r = nullptr;
@@ -1981,6 +2010,7 @@ extern "C" int sdso_ba_batch_optimize_begin(sdso_ctx* ctx, int stop_on_convergen
   free_optrun(ctx);
   OptRun* R = new OptRun();
   R->L = batch_launch(Bt); R->W = Bt->W; R->materialize = Bt->materialize; R->gather = Bt->gather; R->keep_hs = Bt->keep_system;
+  R->scatter_local = Bt->exchange_mode == 1;
   int rc = opt_begin(ctx, *R, stop_on_convergence);
   if (rc) { delete R; return rc; }
   reg_get(g_optruns, ctx) = R;
@@ -2092,13 +2122,12 @@ extern "C" int sdso_ba_get_post_state(sdso_ctx* ctx, int win, sdso_ba_post_state
   SDSO_REQUIRE(ctx, W->post_valid, "sdso_ba_get_post_state needs a finished sdso_ba_optimize / sdso_ba_batch_optimize on this window");
   SDSO_REQUIRE(ctx, (!out->lastHS && !out->lastbS) || W->hs_valid, "lastHS / lastbS were not kept: sdso_ba_batch_keep_system(ctx, 1) before the batch loop");
   const int nf = W->d.nf, np = W->d.np, nr = W->d.nr, n = W->d.n;
-  if (!W->d_post) { DM(W->d_post, float, (size_t)std::max(nr, 1) * 19); }
-  if (nr && (W->post_pending || out->centerProjectedTo || out->projectedTo)) {
-    // (the projections are re-evaluated on every call that asks for them; the counters move once per optimize)
-    hipLaunchKernelGGL(k_ba_post_state, dim3(std::max(W->nblk_res, 1), 1), dim3(BA_BLOCK), 0, ctx->stream, (const BaDev*)W->d_self, W->d_post, W->post_pending ? 1 : 0);
+  if (nr && (out->centerProjectedTo || out->projectedTo)) {
+    // (the projections are re-evaluated on every call that asks for them; the counters moved when the optimize call ended)
+    if (!W->d_post) { DM(W->d_post, float, (size_t)std::max(nr, 1) * 19); }
+    hipLaunchKernelGGL(k_ba_post_state, dim3(std::max(W->nblk_res, 1), 1), dim3(BA_BLOCK), 0, ctx->stream, (const BaDev*)W->d_self, W->d_post, 0);
     SDSO_HIP(ctx, hipGetLastError());
   }
-  W->post_pending = false;
   SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
   // ---- points
   if (np && (out->idepth || out->step || out->HdiF || out->bdSumF || out->idepth_hessian || out->maxRelBaseline || out->numGoodResiduals)) {
@@ -2166,11 +2195,7 @@ extern "C" int sdso_ba_get_post_state(sdso_ctx* ctx, int win, sdso_ba_post_state
   const double* hsb = W->d.sol + 3 * ((size_t)n * n + n) + n;
   if (out->lastHS) SDSO_HIP(ctx, hipMemcpy(out->lastHS, hsb, sizeof(double) * n * n, hipMemcpyDeviceToHost));
   if (out->lastbS) SDSO_HIP(ctx, hipMemcpy(out->lastbS, hsb + (size_t)n * n, sizeof(double) * n, hipMemcpyDeviceToHost));
-  {
-    float nres2[2] = {0, 0};                           // nres[0] of the last accumulateAF / accumulateLF (EnergyFunctional.cpp:219, :241)
-    SDSO_HIP(ctx, hipMemcpy(nres2, W->d.accum + acc_off_nres(nf), sizeof(nres2), hipMemcpyDeviceToHost));
-    W->resInL = (int)nres2[1];
-  }
+  // (resInL: nres[0] of the last accumulateLF, EnergyFunctional.cpp:241 — recorded when the optimize call ended, next to resInA)
   out->resInA = W->last_result.resInA; out->resInL = W->resInL; out->resInM = W->resInM;
   out->result = W->last_result;
   return SDSO_OK;

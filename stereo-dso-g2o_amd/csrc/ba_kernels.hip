@@ -571,7 +571,9 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_post_state(const BaDev* __restr
   const BaDev& B = wins[blockIdx.y];
   const int i = blockIdx.x * BA_BLOCK + threadIdx.x;
   if (i >= B.nr) return;
-  float* pj = proj + (size_t)i * 19;
+  if (!proj && !counters) return;
+  float scratch[19];
+  float* pj = proj ? proj + (size_t)i * 19 : scratch;   // proj == nullptr: the counters only (the end of an optimize call)
 #pragma unroll
   for (int k = 0; k < 19; k++) pj[k] = 0.f;
   if ((B.r_lin[i] & 1) || !B.r_act[i]) return;       // not in activeResiduals (:880-889) / on toRemove (:80-84)

@@ -571,7 +571,7 @@ struct BaOptOut {
   double calib_value[4];
   double lastEnergy;
   float frameTH_new;
-  int iterations, resInA, pad;
+  int iterations, resInA, resInL;   // resInL: nres[0] of the loop's last accumulateLF (EnergyFunctional.cpp:241), read when the loop ends
 };
 __global__ __launch_bounds__(128) void k_ba_opt_release(const BaDev* __restrict__ wins, BaOptOut* __restrict__ out) {
   BaDev& B = const_cast<BaDev&>(wins[blockIdx.x]);
@@ -581,7 +581,7 @@ __global__ __launch_bounds__(128) void k_ba_opt_release(const BaDev* __restrict_
   if (tid < 80) R.state[tid / 10][tid % 10] = O.state[tid / 10][tid % 10];
   if (tid >= 96 && tid < 100) R.calib_value[tid - 96] = O.calib_value[tid - 96];
   if (tid == 127) {
-    R.lastEnergy = O.lastEnergy; R.frameTH_new = O.frameTH_new; R.iterations = O.iterations; R.resInA = O.resInA; R.pad = 0;
+    R.lastEnergy = O.lastEnergy; R.frameTH_new = O.frameTH_new; R.iterations = O.iterations; R.resInA = O.resInA; R.resInL = (int)B.accum[acc_off_nres(B.nf) + 1];
     O.phase = 0;
     B.finished = 0;
   }

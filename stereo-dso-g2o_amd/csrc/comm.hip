@@ -24,7 +24,8 @@
 namespace sdso {
 void* ba_batch_accum_block(sdso_ctx* ctx, size_t* nfloats);            // ba.hip
 void* ba_window_accum_block(sdso_ctx* ctx, int win, size_t* nfloats);  // ba.hip
-bool ba_batch_scatter_begin(sdso_ctx* ctx);                            // ba.hip: the batch's exchange is the reduce-scatter by window
+bool ba_batch_scatter_wanted(sdso_ctx* ctx);                           // ba.hip: the batch's exchange is the reduce-scatter by window (agreed on by all ranks at optimize_begin)
+void ba_batch_scatter_done(sdso_ctx* ctx);                             // ba.hip: ... and it has been enqueued: only this rank's windows hold summed accumulators
 
 struct RcclApi {
   void* lib = nullptr;
@@ -273,7 +274,11 @@ extern "C" int sdso_ba_allreduce(sdso_ctx* ctx) {
   size_t n = 0;
   void* p = ba_batch_accum_block(ctx, &n);
   SDSO_REQUIRE(ctx, p, "no batch: sdso_ba_batch_create first");
-  if (ba_batch_scatter_begin(ctx)) return reduce_scatter_block(ctx, p, n);
+  if (ba_batch_scatter_wanted(ctx)) {
+    const int rc = reduce_scatter_block(ctx, p, n);
+    if (rc == SDSO_OK) ba_batch_scatter_done(ctx);      // a failed exchange leaves the batch as it was (sdso_ba_batch_solve still refuses nothing)
+    return rc;
+  }
   return allreduce_block(ctx, p, n);
 }
 

@@ -285,6 +285,7 @@ class WindowedBA {
   float optimize(int mnumOptIts, EnergyFunctionalT* ef, CalibHessianT* HCalib) {
     const int nf = nf_, np = (int)points_.size(), nr = (int)residuals_.size(), n = 8 * nf + 4;
     sdso_ba_opt_result_t out;
+    if (nf < 2) { lastResult = sdso_ba_opt_result_t{0, 0, 0, 0}; lastRemoved = 0; return 0.f; }   // `if(frameHessians.size() < 2) return 0;` (:873-874): nothing is touched
     dev_.check(sdso_ba_optimize(dev_.ctx(), win_, mnumOptIts, nullptr, nullptr, nullptr, &out), "sdso_ba_optimize");
     std::vector<float> idp(np), pstep(np), hdi(np), bds(np), idh(np), mrb(np), energy(nr), cpt((size_t)nr * 3), prj((size_t)nr * 16), eth(nf);
     std::vector<int> ngood(np);
@@ -332,6 +333,7 @@ class WindowedBA {
     for (int i = 0; i < nr; i++) {
       auto* r = residuals_[i];
       auto* pfr = r->data;
+      if (r->isLinearized) continue;                       // not in activeResiduals (:880-889): optimize() never touches it
       using ResStateT = std::decay_t<decltype(pfr->state_state)>;
       pfr->state_state = static_cast<ResStateT>(rs[i]);
       pfr->state_NewState = static_cast<ResStateT>(rs[i]);
@@ -347,7 +349,7 @@ class WindowedBA {
     }
     int nResRemoved = 0;
     for (int i = 0; i < nr; i++) {                         // :176-195
-      if (!rem[i]) continue;
+      if (!rem[i] || residuals_[i]->isLinearized) continue;
       auto* pfr = residuals_[i]->data;
       auto* ph = pfr->point;
       if (ph->lastResiduals[0].first == pfr) ph->lastResiduals[0].first = 0;

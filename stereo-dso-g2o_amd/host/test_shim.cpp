@@ -81,7 +81,7 @@ struct PointHessian {
   void setIdepthZero(float x) { idepth_zero = x; }
   bool isInlierNew() const { return (int)residuals.size() >= 3 && numGoodResiduals >= 4; }   // HessianBlocks.h:465-469; setting_minGoodActiveResForMarg = 3, setting_minGoodResForMarg = 4 (settings.cpp:82-83)
 };
-struct EFResidual { PointFrameResidual* data; EFFrame* target; bool isActiveAndIsGoodNEW = false; int idxInAll = 0; EFPoint* point = nullptr; };
+struct EFResidual { PointFrameResidual* data; EFFrame* target; bool isActiveAndIsGoodNEW = false; int idxInAll = 0; EFPoint* point = nullptr; bool isLinearized = false; };
 struct EFPoint { PointHessian* data; std::vector<EFResidual*> residualsAll; int stateFlag = 0; float HdiF = 0, bdSumF = 0; };
 struct EFFrame { FrameHessian* data; std::vector<EFPoint*> points; int idx; };
 struct DynMat {

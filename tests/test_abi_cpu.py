@@ -105,3 +105,19 @@ def test_selector_random_pattern_is_glibc_rand(oracle):
     oracle.orc_selector_random_pattern(n, abi.bp(a))
     assert L.sdso_pixel_selector_pattern(n, abi.bp(b)) == 0
     assert np.array_equal(a, b) and len(np.unique(a)) == 256
+
+
+def test_bench_gpus_flag_is_honoured_or_refused():
+    """`bench.py --gpus N` must never print a line for another N: with WORLD_SIZE set to something else it refuses before touching
+    torch; with no launcher it starts N ranks itself, and when they cannot run (this container has no GPU) the command fails."""
+    import subprocess
+    import sys
+    bench = os.path.join(ROOT, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    r = subprocess.run([sys.executable, bench, "--gpus", "2"], env=dict(env, WORLD_SIZE="4"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert r.returncode != 0 and b"WORLD_SIZE=4" in r.stderr and b"{" not in r.stdout
+    import torch
+    if not torch.cuda.is_available():
+        r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "1"], env=dict(env, SDSO_DIST_BACKEND="gloo_lib"),
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        assert r.returncode != 0 and b"rank(s) failed" in r.stderr and b"{" not in r.stdout

@@ -465,50 +465,32 @@ def test_resident_loop_through_rccl_one_rank(monkeypatch):
             assert a[5] == b[5]
 
 
-# ------------------------------------------------------------------ the bench workload itself on two ranks (rehearsal of `bench.py --gpus 2`)
-def _bench_worker(rank, world, port, outdir, scaling):
-    """bench_ba.BAWorkload exactly as bench.py builds it at N = 2 — library all-reduce, fused tail kernel, pack / all-gather / k_ba_opt_step,
-    states advancing — over the library's host transport (gloo underneath: two ranks cannot open RCCL on one device)."""
-    import json
-    import types
-    import torch.distributed as dist
-    sys.path[:0] = [ROOT, os.path.join(ROOT, "stereo-dso-g2o_amd")]
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    os.environ["SDSO_DIST_BACKEND"] = "gloo_lib"
-    os.environ["SDSO_BA_EXCHANGE"] = "scatter" if scaling.endswith("_scatter") else "allreduce"
-    scaling = scaling.replace("_scatter", "")
-    os.environ["RANK"] = str(rank)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    from sdso_amd import abi
-    import bench_ba
-    ctx = abi.Context(0)
-    args = types.SimpleNamespace(batch=4, scaling=scaling)
-    wl = bench_ba.BAWorkload(ctx, args, rank, world, device=0)
-    xs = []
-    for _ in range(6):
-        wl.step()
-    wl.sync()
-    out = wl.verify()
-    out["config"] = wl.config
-    if rank == 0:
-        json.dump({k: v for k, v in out.items() if isinstance(v, (int, float, bool, str, dict))}, open(os.path.join(outdir, "out.json"), "w"))
-    wl.close()
-    ctx.close()
-    dist.destroy_process_group()
-
-
+# ------------------------------------------------------------------ `bench.py --gpus 2` itself, as a command
 @pytest.mark.parametrize("scaling", ["weak", "strong", "weak_scatter"])
-def test_bench_workload_two_ranks_advances_the_same_work(tmp_path, scaling):
-    """The first real multi-GPU run must not be able to measure something else than N = 1 does: on two ranks the step is the full one
-    (state_advances), window 0's sharded x equals the unsharded window's, and the GN steps shrink over six iterations.
-    weak_scatter: the same with SDSO_BA_EXCHANGE=scatter (reduce-scatter by window + all-gather of x inside the timed step)."""
+def test_bench_command_two_ranks_advances_the_same_work(scaling):
+    """`python3 bench.py --gpus 2` with NO launcher around it: main() must start its two ranks itself (round-4 verdict: the flag was
+    parsed and ignored, so the first real scaling run would have measured one GPU) and print ONE line that says n_gpus 2.  The step
+    is the full one (state_advances), window 0's sharded x equals the unsharded window's, the GN steps shrink.  Two ranks cannot
+    open RCCL on the one device of the test box: SDSO_DIST_BACKEND=gloo_lib runs the library's exchange over its host transport.
+    weak_scatter: SDSO_BA_EXCHANGE=scatter (reduce-scatter by window + all-gather of x inside the timed step)."""
     import json
-    world = 2
-    mp.spawn(_bench_worker, args=(world, _free_port(), str(tmp_path), scaling), nprocs=world, join=True)
-    out = json.load(open(os.path.join(str(tmp_path), "out.json")))
-    assert out["config"]["state_advances"] is True
-    assert ("reduce-scatter" in out["config"]["exchange_shape"]) == scaling.endswith("_scatter")
-    assert "host transport" in out["config"]["exchange"]
-    assert out["sharded_x_whitened_err"] <= 2e-4
-    assert out["max_abs_x"] < out["max_abs_x_initial"]
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["SDSO_DIST_BACKEND"] = "gloo_lib"
+    env["SDSO_BA_EXCHANGE"] = "scatter" if scaling.endswith("_scatter") else "allreduce"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "3", "--batch", "4",
+           "--scaling", scaling.replace("_scatter", "")]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout.decode()[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3
+    assert out["scaling"] == scaling.replace("_scatter", "")
+    cfg, extra = out["config"], out["extra"]
+    assert cfg["state_advances"] is True and cfg["allreduce_floats"] > 0
+    assert ("reduce-scatter" in cfg["exchange_shape"]) == scaling.endswith("_scatter")
+    assert "host transport" in cfg["exchange"]
+    assert extra["sharded_x_whitened_err"] <= 2e-4
+    assert extra["max_abs_x"] < extra["max_abs_x_initial"]
+    assert out["roofline"]["launches"] > 0 and out["value"] > 0
