@@ -55,6 +55,7 @@ struct BaWindowDev {
   bool in_batch = false;
   bool accumulated = false;
   bool has_lin_cached = false;  // some residual of the window is linearized (updated wherever h_lin changes)
+  bool l_dirty = false;         // p_out's L sums (linearised / marginalised residuals) may be non-zero: the next plain Schur launch clears them
   bool j_inplace_last = false;  // the latest linearisation was the fused kernel's, written IN PLACE into EFResidual::J's slot (BaDev::jfix):
                                 // sdso_ba_get_linearization reads the records from there
   // post-state of FullSystem::optimize (sdso_ba_get_post_state)
@@ -122,6 +123,7 @@ struct BaLaunch {
   bool any_lin;   // some window holds linearized residuals -> the mode-1 accumulation has work to do
   bool tiled;     // the windows' t_img are 4x2-tiled level-0 images (same for every window of a launch)
   bool alt;       // the windows' solverMode takes solveSystemF's SVD / orthogonalised-system branches (ba_solve_alt.hip): never the fused tail kernel
+  std::vector<BaWindowDev*> Ws;   // the windows behind d_arr (host bookkeeping of a launch: BaWindowDev::l_dirty)
 };
 struct BaBatch {
   std::vector<int> wins;
@@ -130,14 +132,12 @@ struct BaBatch {
   float* d_accum = nullptr;
   BaLaunch L;
   bool materialize = true;
-  bool sc_async = false;         // the Schur kernel of the latest accumulate is on the side stream and has not been consumed by a tail kernel
   bool eager_fold = false;       // sdso_ba_batch_accum_dev handed the block's address out: never defer the folds
   bool folded = true;            // the packed accumulator block holds the folded sums of the latest accumulate (false: the top partials and the
                                  // per-host Hcc / bc are still unfolded — the fused tail kernel folds them itself; ensure_folded() for anyone else)
   int exchange_mode = 0;         // sdso_ba_batch_exchange_mode: 0 all-reduce + the solve on every rank, 1 reduce-scatter by window + all-gather of x
   bool scattered = false;        // the latest sdso_ba_allreduce was the reduce-scatter: only this rank's windows hold summed accumulators
   bool keep_system = false;      // sdso_ba_batch_keep_system: the resident loop's solves also write lastHS / lastbS (37 KB per window and iteration)
-  int gather = 1;                // tap gather of the fused kernel: 1 cooperative quads (default), 2 LDS-DMA rounds, 0 direct (SDSO_BA_GATHER / SDSO_BA_DIRECT_TAPS at batch_create)
 };
 static std::map<sdso_ctx*, BaBatch*> g_batches;
 void free_optrun(sdso_ctx* ctx);    // the resident GN loop's bookkeeping (end of this file)
@@ -146,7 +146,6 @@ int optimize_resident_single(sdso_ctx* ctx, BaWindowDev* W, int mnumOptIts, sdso
 // Dissolve the ctx's batch: every member window gets its own accumulator block back (host descriptor and its device copy),
 // so later per-window calls never touch the freed batch block.
 static void free_batch(sdso_ctx* ctx) {
-  if (ctx->stream2) hipStreamSynchronize(ctx->stream2);
   BaBatch* taken = nullptr;
   free_optrun(ctx);   // a resident loop over the batch ends with it
   if (!reg_take(g_batches, ctx, taken) || !taken) return;
@@ -306,16 +305,16 @@ static int upload_window_impl(sdso_ctx* ctx, int win, const sdso_ba_window_t* Wi
   std::vector<int> rhost(nr);
   for (int p = 1; p < np; p++) SDSO_REQUIRE(ctx, Win->host[p] >= Win->host[p - 1], "points must be in allPoints order (host index non-decreasing)");
   for (int p = 0; p < np; p++) SDSO_REQUIRE(ctx, Win->host[p] >= 0 && Win->host[p] < nf, "point host out of range");
-  std::vector<int> rbeg(np, 0), rcnt(np, 0);
+  std::vector<int> rbeg(np + 1, 0), rcnt(np, 0);
   for (int i = 0; i < nr; i++) {
     const int p = Win->res_point[i];
     SDSO_REQUIRE(ctx, p >= 0 && p < np && (i == 0 || p >= Win->res_point[i - 1]), "residuals must be grouped by point in point order");
     SDSO_REQUIRE(ctx, Win->res_target[i] >= 0 && Win->res_target[i] < nf, "residual target out of range");
     rhost[i] = Win->host[p];
-    if (rcnt[p] == 0) rbeg[p] = i;
     rcnt[p]++;
     SDSO_REQUIRE(ctx, rcnt[p] <= SDSO_MAX_RES, "more than MAX_RES_PER_POINT residuals on a point");
   }
+  for (int p = 0; p < np; p++) rbeg[p + 1] = rbeg[p] + rcnt[p];     // (residuals are grouped by point: a point's first residual, nr behind the last)
   {  // every validation runs before the first H2D copy: the staging vectors below must outlive the copies
     std::vector<uint8_t> seen((size_t)np * nf, 0);
     for (int o = 0; o < nr; o++) {
@@ -357,9 +356,8 @@ static int upload_window_impl(sdso_ctx* ctx, int win, const sdso_ba_window_t* Wi
     }
     pair_beg[nf * nf] = (int)chunks.size();
   }
-  // SC items per host (tunable for experiments: SDSO_SC_PTS in [1,64])
-  int sc_pts = getenv("SDSO_SC_REG") ? BA_SC_PTS : 64;
-  if (const char* e = getenv("SDSO_SC_PTS")) sc_pts = std::max(1, std::min(64, atoi(e)));
+  // point ranges per host, in 64-point items (the Schur kernel deals 64-point slices to its waves)
+  const int sc_pts = 64;
   std::vector<int4> items;
   std::vector<int> host_beg(nf + 1, 0);
   {
@@ -387,7 +385,7 @@ static int upload_window_impl(sdso_ctx* ctx, int win, const sdso_ba_window_t* Wi
   float4* p_geo; float *p_color, *p_weights, *p_prior, *p_delta, *p_out; int *p_host, *p_rbeg, *p_rcnt, *p_rlist;
   unsigned* p_order; float4* p_track; uint8_t* r_isnew;
   PL(p_geo, float4, np, true); PL(p_color, float, np * 8, true); PL(p_weights, float, np * 8, true); PL(p_host, int, np, true);
-  PL(p_prior, float, np, true); PL(p_delta, float, np, true); PL(p_rbeg, int, np, true); PL(p_rcnt, int, np, true); PL(p_rlist, int, nr, true);
+  PL(p_prior, float, np, true); PL(p_delta, float, np, true); PL(p_rbeg, int, np + 1, true); PL(p_rcnt, int, np, true); PL(p_rlist, int, nr, true);
   PL(p_order, unsigned, np, true); PL(p_track, float4, np, true); PL(r_isnew, uint8_t, nr, true);
   PL(p_out, float, (size_t)np * 16, false);
   int* r_point; int* r_orig; uint8_t *r_host, *r_target;
@@ -395,8 +393,8 @@ static int upload_window_impl(sdso_ctx* ctx, int win, const sdso_ba_window_t* Wi
   PL(d.r_state, uint8_t, nr, true); PL(d.r_newState, uint8_t, nr, false); PL(d.r_lin, uint8_t, nr, false); PL(d.r_act, uint8_t, nr, false); PL(d.r_jsel, uint8_t, nr, false);
   PL(d.r_energy, float, nr, false); PL(d.r_newEnergy, float, nr, false); PL(d.r_newEnergyWO, float, nr, false);
   PL(d.J[0], float, (size_t)76 * d.nrp, false); PL(d.J[1], float, (size_t)76 * d.nrp, false); PL(d.r_toZero, float, (size_t)8 * d.nrp, false);
-  PL(d.r_rec, float, (size_t)np * nf * 16, false);   // dense [point][target] records
-  PL(d.r_cj, float, (size_t)np * nf * 8, false);     // their JpJdF halves, compact (written by k_ba_sc_host)
+  PL(d.r_rec, float, (size_t)(nr + 16) * 16, false);  // per-residual records of the Schur part, window order (ba_kernels.h)
+  PL(d.r_cj, float, (size_t)(nr + 16) * 8, false);    // their JpJdF halves, compact (written by k_ba_sc_host)
   d.r_proj = nullptr;
   // the tables upload_tables refreshes: contiguous, in this order (one staged copy there too)
   PL(W->dt_precalc, float, nf * nf * 27, true); PL(W->dt_adHTdelta, float, nf * nf * 8, true); PL(W->dt_cdelta, float, 4, true);
@@ -407,7 +405,7 @@ static int upload_window_impl(sdso_ctx* ctx, int win, const sdso_ba_window_t* Wi
   const float4** d_img; PL(d_img, const float4*, nf, true);
   int4* d_chunks; int* d_pair_beg; int4* d_items; int* d_host_beg;
   PL(d_chunks, int4, chunks.size(), true); PL(d_pair_beg, int, nf * nf + 1, true); PL(d_items, int4, items.size(), true); PL(d_host_beg, int, nf + 1, true);
-  PL(d.top_part, float, (size_t)d.nchunks * 92, false); PL(d.sc_part, float, std::max((size_t)d.nitems * sc_part_floats(nf), (size_t)nf * 20), false);
+  PL(d.top_part, float, (size_t)d.nchunks * 92, false); PL(d.sc_part, float, (size_t)nf * 20, false);
   PL(d.e_part, double, std::max(W->nblk_res, d.nchunks) + 1, false);
   PL(d.accum, float, acc_floats(nf), false);
   PL(d.sol, double, sol_doubles(n, nf), false);
@@ -478,7 +476,7 @@ static int upload_window_impl(sdso_ctx* ctx, int win, const sdso_ba_window_t* Wi
   for (int f = 0; f < nf; f++) frameTH[f] = W->frames[f].frameEnergyTH;
   STG(p_geo, geo.data(), sizeof(float4) * np); STG(p_color, Win->color, sizeof(float) * np * 8); STG(p_weights, Win->weights, sizeof(float) * np * 8);
   STG(p_host, Win->host, sizeof(int) * np); STG(p_prior, W->h_prior.data(), sizeof(float) * np); STG(p_delta, delta.data(), sizeof(float) * np);
-  STG(p_rbeg, rbeg.data(), sizeof(int) * np); STG(p_rcnt, rcnt.data(), sizeof(int) * np); STG(p_rlist, rlist.data(), sizeof(int) * nr);
+  STG(p_rbeg, rbeg.data(), sizeof(int) * (np + 1)); STG(p_rcnt, rcnt.data(), sizeof(int) * np); STG(p_rlist, rlist.data(), sizeof(int) * nr);
   STG(p_order, order.data(), sizeof(unsigned) * np); STG(p_track, track.data(), sizeof(float4) * np); STG(r_isnew, isnew.data(), nr);
   STG(r_point, s_point.data(), sizeof(int) * nr); STG(r_orig, W->perm.data(), sizeof(int) * nr); STG(r_host, s_host.data(), nr); STG(r_target, s_target.data(), nr); STG(d.r_state, s_state.data(), nr);
   STG(W->dt_frameTH, frameTH.data(), sizeof(float) * nf); STG(d_img, imgs.data(), sizeof(float4*) * nf);
@@ -540,13 +538,10 @@ static void launch_linearize(sdso_ctx* ctx, const BaLaunch& L) {
 static void launch_apply(sdso_ctx* ctx, const BaLaunch& L) {
   hipLaunchKernelGGL(k_ba_apply, dim3(L.max_nblk_res, L.nwin), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr);
 }
-static bool launch_sc_and_folds(sdso_ctx* ctx, const BaLaunch& L, const uint8_t* pflag, bool marg, bool fold_top_too = false, bool defer_fold = false, bool* async_sc = nullptr);
-// which Schur kernel the process runs: 0 one workgroup per host (default; it also leaves BaDev::r_cj / the active-target bits the
-// back-substitution kernels read), 1 per-item MFMA (SDSO_SC_ITEMS), 2 VALU register tiles (SDSO_SC_REG)
-static int sc_variant() { static const int v = getenv("SDSO_SC_REG") ? 2 : getenv("SDSO_SC_ITEMS") ? 1 : 0; return v; }
-
-#define LAUNCH_RESUB(...) do { if (sc_variant() == 0) hipLaunchKernelGGL(k_ba_resub<true>, __VA_ARGS__); else hipLaunchKernelGGL(k_ba_resub<false>, __VA_ARGS__); } while (0)
-#define LAUNCH_RESUB_STEP(...) do { if (sc_variant() == 0) hipLaunchKernelGGL(k_ba_resub_step<true>, __VA_ARGS__); else hipLaunchKernelGGL(k_ba_resub_step<false>, __VA_ARGS__); } while (0)
+static bool launch_sc_and_folds(sdso_ctx* ctx, const BaLaunch& L, const uint8_t* pflag, bool marg, bool fold_top_too = false, bool defer_fold = false);
+// the back-substitution kernels read the points' L sums (p_out[8..13]) only when linearised residuals exist in the launch
+#define LAUNCH_RESUB(L_, ...) do { if ((L_).any_lin) hipLaunchKernelGGL(k_ba_resub<true>, __VA_ARGS__); else hipLaunchKernelGGL(k_ba_resub<false>, __VA_ARGS__); } while (0)
+#define LAUNCH_RESUB_STEP(L_, ...) do { if ((L_).any_lin) hipLaunchKernelGGL(k_ba_resub_step<true>, __VA_ARGS__); else hipLaunchKernelGGL(k_ba_resub_step<false>, __VA_ARGS__); } while (0)
 static void launch_accumulate(sdso_ctx* ctx, const BaLaunch& L, const uint8_t* pflag, bool marg) {
   const int nf = L.nf;
   // the folds run even without a single chunk: they are what clears the top bins of the previous call
@@ -566,88 +561,38 @@ static void launch_accumulate(sdso_ctx* ctx, const BaLaunch& L, const uint8_t* p
   }
   launch_sc_and_folds(ctx, L, pflag, marg);
 }
-// returns false when the folds were left to the fused tail kernel (defer_fold: only the default Schur kernel, only together with the top fold)
-// the side stream of the resident loop (see sdso_ctx::stream2)
-static bool side_stream(sdso_ctx* ctx) {
-  if (ctx->stream2) return true;
-  if (hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess) { ctx->stream2 = nullptr; return false; }
-  if (hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
-    hipStreamDestroy(ctx->stream2); ctx->stream2 = nullptr; return false;
-  }
-  return true;
-}
-// async_sc != nullptr and *async_sc on entry: put the Schur kernel on the side stream (behind an event recorded now on the main stream) with
-// its completion signalled in-kernel — the caller launches the tail kernel with TAIL_WAIT_SC next, on the main stream, so that it is
-// resident before the other batch's linearisation floods the chip.  Only together with a deferred fold; *async_sc says what happened.
-static bool launch_sc_and_folds(sdso_ctx* ctx, const BaLaunch& L, const uint8_t* pflag, bool marg, bool fold_top_too, bool defer_fold, bool* async_sc) {
+// The Schur kernel (one workgroup per host frame and window) and what is left to fold afterwards: Hcc / bc over the hosts, and — with
+// fold_top_too — the top partials of the fused kernel.  Returns false when those folds were left to the fused tail kernel (defer_fold).
+static bool launch_sc_and_folds(sdso_ctx* ctx, const BaLaunch& L, const uint8_t* pflag, bool marg, bool fold_top_too, bool defer_fold) {
   const int nf = L.nf;
   const int shift = marg ? 0 : 1, mm = marg ? 1 : 0;
-  const int sc_variant = sdso::sc_variant();
   // the launch's common case — no marginalisation pass, no point filter, no linearized residual — takes the kernel's lean per-point loop
-  static const bool no_plain = getenv("SDSO_SC_NOPLAIN") != nullptr;     // (A/B)
-  const bool plain = !marg && !pflag && !L.any_lin && !no_plain;
-  static const int sc_waves = getenv("SDSO_SC_WAVES") && atoi(getenv("SDSO_SC_WAVES")) == 2 ? 2 : 4;    // (A/B: workgroups of two waves)
-#define LAUNCH_SC_HOST(STREAM, SIGNAL) do {                                                                                                             \
-    if (sc_waves == 2) {                                                                                                                                \
-      if (plain) hipLaunchKernelGGL((k_ba_sc_host<true, 2>), dim3(nf, L.nwin), dim3(128), 0, STREAM, L.d_arr, pflag, shift, mm, SIGNAL);               \
-      else hipLaunchKernelGGL((k_ba_sc_host<false, 2>), dim3(nf, L.nwin), dim3(128), 0, STREAM, L.d_arr, pflag, shift, mm, SIGNAL);                    \
-    } else {                                                                                                                                            \
-      if (plain) hipLaunchKernelGGL((k_ba_sc_host<true, 4>), dim3(nf, L.nwin), dim3(BA_BLOCK), 0, STREAM, L.d_arr, pflag, shift, mm, SIGNAL);           \
-      else hipLaunchKernelGGL((k_ba_sc_host<false, 4>), dim3(nf, L.nwin), dim3(BA_BLOCK), 0, STREAM, L.d_arr, pflag, shift, mm, SIGNAL);                \
-    }                                                                                                                                                   \
-  } while (0)
-  if (sc_variant == 0) {
-    const bool want_async = async_sc && *async_sc && fold_top_too && defer_fold && !marg && side_stream(ctx);
-    if (async_sc) *async_sc = want_async;
-    if (want_async) {
-      hipEventRecord(ctx->ev_fork, ctx->stream);
-      hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0);
-      LAUNCH_SC_HOST(ctx->stream2, 1);
-      hipEventRecord(ctx->ev_join, ctx->stream2);
-      return false;
-    }
-    {
-      ProfScope ps(ctx, "k_ba_sc", 2);
-      LAUNCH_SC_HOST(ctx->stream, 0);
-    }
-    if (fold_top_too && defer_fold) return false;
-    if (fold_top_too) hipLaunchKernelGGL(k_ba_fold_all, dim3(1 + 2 * nf * nf, L.nwin), dim3(128), 0, ctx->stream, L.d_arr, 1);
-    else hipLaunchKernelGGL(k_ba_fold_hcc, dim3(1, L.nwin), dim3(64), 0, ctx->stream, L.d_arr);
-    return true;
+  const bool plain = !marg && !pflag && !L.any_lin;
+  int clear_l = 0;
+  for (BaWindowDev* W : L.Ws) {
+    if (plain && W->l_dirty) clear_l = 1;
+    W->l_dirty = !plain;          // (a plain launch with clear_l zeroes the L sums of every point it visits: all of them)
   }
-  if (L.max_items > 0) {
+  {
     ProfScope ps(ctx, "k_ba_sc", 2);
-    const dim3 grid((L.max_items + BA_BLOCK / 64 - 1) / (BA_BLOCK / 64), L.nwin), blk(BA_BLOCK);
-    if (sc_variant == 1) {
-      hipLaunchKernelGGL(k_ba_sc_mfma, grid, blk, 0, ctx->stream, L.d_arr, pflag, shift, mm);
-    } else {
-      switch (nf) {
-#define SC_CASE(N) case N: hipLaunchKernelGGL(k_ba_sc_reg<N>, grid, blk, 0, ctx->stream, L.d_arr, pflag, shift, mm); break;
-        SC_CASE(1) SC_CASE(2) SC_CASE(3) SC_CASE(4) SC_CASE(5) SC_CASE(6) SC_CASE(7) SC_CASE(8)
-#undef SC_CASE
-        default: break;   // nf <= 8 is enforced at upload
-      }
-    }
+    if (plain) hipLaunchKernelGGL(k_ba_sc_host<true>, dim3(nf, L.nwin), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr, pflag, shift, mm, clear_l);
+    else hipLaunchKernelGGL(k_ba_sc_host<false>, dim3(nf, L.nwin), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr, pflag, shift, mm, 0);
   }
-  if (fold_top_too) hipLaunchKernelGGL(k_ba_fold_all, dim3(nf * nf * nf + 3 * nf * nf + 1, L.nwin), dim3(128), 0, ctx->stream, L.d_arr, 0);
-  else hipLaunchKernelGGL(k_ba_fold_sc, dim3(nf * nf * nf + nf * nf + 1, L.nwin), dim3(64), 0, ctx->stream, L.d_arr);
+  if (fold_top_too && defer_fold) return false;
+  if (fold_top_too) hipLaunchKernelGGL(k_ba_fold_all, dim3(1 + 2 * nf * nf, L.nwin), dim3(128), 0, ctx->stream, L.d_arr);
+  else hipLaunchKernelGGL(k_ba_fold_hcc, dim3(1, L.nwin), dim3(64), 0, ctx->stream, L.d_arr);
   return true;
 }
 // linearizeAll + applyRes + accumulateAF in one kernel, then the (normally empty) linearized pass and the Schur part
 // returns false when the folds were deferred to the tail kernel (defer_fold)
-static bool launch_fused(sdso_ctx* ctx, const BaLaunch& L, bool materialize, int gather, int part = 3 /* bit 0: linearize+top, bit 1: Schur+folds */, bool defer_fold = false, bool* async_sc = nullptr) {
+static bool launch_fused(sdso_ctx* ctx, const BaLaunch& L, bool materialize, int part = 3 /* bit 0: linearize+top, bit 1: Schur+folds */, bool defer_fold = false) {
   const int nf = L.nf;
   if ((part & 1) && L.max_chunks > 0) {
     {
       const dim3 g(L.max_chunks, L.nwin), b(BA_BLOCK);
-      // gather: 0 one residual's 32 taps on one lane, 1 cooperative quad gather, 2 LDS-DMA rounds (tiled images)
-      const int gm = (gather == 2 && !L.tiled) ? 1 : gather;
 #define LT(K) launch_timed(ctx, "k_ba_lin_fused", 1, K, g, b, (const BaDev*)L.d_arr)
-#define LF(M, T) do { if (gm == 0) LT((k_ba_lin_fused<M, T, 0>)); else LT((k_ba_lin_fused<M, T, 1>)); } while (0)
-      if (gm == 2) { if (materialize) LT((k_ba_lin_dma<true>)); else LT((k_ba_lin_dma<false>)); }
-      else if (materialize) { if (L.tiled) LF(true, true); else LF(true, false); }
-      else { if (L.tiled) LF(false, true); else LF(false, false); }
-#undef LF
+      if (materialize) { if (L.tiled) LT((k_ba_lin_fused<true, true>)); else LT((k_ba_lin_fused<true, false>)); }
+      else { if (L.tiled) LT((k_ba_lin_fused<false, true>)); else LT((k_ba_lin_fused<false, false>)); }
 #undef LT
     }
     if (L.any_lin) {
@@ -657,8 +602,7 @@ static bool launch_fused(sdso_ctx* ctx, const BaLaunch& L, bool materialize, int
     }
   }
   // without linearized residuals the top partials are folded together with the Schur partials, after the Schur kernel
-  if (part & 2) return launch_sc_and_folds(ctx, L, nullptr, false, !L.any_lin, defer_fold, async_sc);
-  if (async_sc) *async_sc = false;
+  if (part & 2) return launch_sc_and_folds(ctx, L, nullptr, false, !L.any_lin, defer_fold);
   return true;
 }
 // stitchDouble of the three accumulator groups: the Schur pre-products, then one wave per output tile
@@ -677,49 +621,34 @@ static void launch_tail(sdso_ctx* ctx, const BaLaunch& L, double lambda, int fla
   else hipLaunchKernelGGL(k_ba_tail<0>, dim3(L.nwin), dim3(TAIL_NT), 0, ctx->stream, L.d_arr, lambda, flags, iteration, last, stop);
 }
 static void launch_fold_deferred(sdso_ctx* ctx, const BaLaunch& L) {   // what launch_fused left out under defer_fold
-  hipLaunchKernelGGL(k_ba_fold_all, dim3(1 + 2 * L.nf * L.nf, L.nwin), dim3(128), 0, ctx->stream, L.d_arr, 1);
+  hipLaunchKernelGGL(k_ba_fold_all, dim3(1 + 2 * L.nf * L.nf, L.nwin), dim3(128), 0, ctx->stream, L.d_arr);
 }
 // stitch + solveSystemF (default branch) + resubstitute.  orth bit 0: x -= P x; bit 1: lambda of the window's resident loop.
 // folded = false: the accumulate left the folds to the tail kernel (launch_fused with defer_fold)
 static bool solve_on_host() { return getenv("SDSO_BA_SOLVE_HOST") != nullptr; }   // A/B: the SVD / orthogonalised-system branches through solve_system_host
-static void launch_solve(sdso_ctx* ctx, const BaLaunch& L, double lambda, int orth, bool folded = true, bool wait_sc = false) {
+static void launch_solve(sdso_ctx* ctx, const BaLaunch& L, double lambda, int orth, bool folded = true) {
   const int n = L.n;
   if (L.alt) {   // solveSystemF's SVD / orthogonalised-system branches: stitch, then one workgroup per window (ba_solve_alt.hip)
     if (!folded) launch_fold_deferred(ctx, L);
     launch_stitch(ctx, L);
     hipLaunchKernelGGL(k_ba_solve_alt, dim3(L.nwin), dim3(ALT_NT), 0, ctx->stream, L.d_arr, lambda, orth);
-    if (L.max_nblk_pts > 0) LAUNCH_RESUB( dim3(L.max_nblk_pts, L.nwin), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr);
+    if (L.max_nblk_pts > 0) LAUNCH_RESUB(L, dim3(L.max_nblk_pts, L.nwin), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr);
     return;
   }
   if (tail_enabled()) {
-    const int flags = TAIL_HS | ((orth & 1) ? TAIL_ORTH : 0) | ((orth & 2) ? TAIL_LAMBDA_DEV : 0) | (L.any_lin ? TAIL_TOPL : 0) | (folded ? 0 : TAIL_FOLD) | (wait_sc ? TAIL_WAIT_SC : 0);
+    const int flags = TAIL_HS | ((orth & 1) ? TAIL_ORTH : 0) | ((orth & 2) ? TAIL_LAMBDA_DEV : 0) | (L.any_lin ? TAIL_TOPL : 0) | (folded ? 0 : TAIL_FOLD);
     launch_tail(ctx, L, lambda, flags);
-    if (L.max_nblk_pts > 0) LAUNCH_RESUB( dim3(L.max_nblk_pts, L.nwin), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr);
+    if (L.max_nblk_pts > 0) LAUNCH_RESUB(L, dim3(L.max_nblk_pts, L.nwin), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr);
     return;
   }
   if (!folded) launch_fold_deferred(ctx, L);
   launch_stitch(ctx, L);
-  static const int solve_ver = getenv("SDSO_BA_SOLVE") ? atoi(getenv("SDSO_BA_SOLVE")) : 1;   // 2: lane = original row, nothing exchanged (A/B)
-  if (solve_ver == 2) {
-    const size_t lds2 = sizeof(double) * ((size_t)n * ((n + 2) & ~1) + 6 * n + 32 + (n * (n + 1)) / 2 + 2) + sizeof(int) * n;   // factor, vectors, packed system, pivot rows
-    hipLaunchKernelGGL(k_ba_solve<2>, dim3(1, L.nwin), dim3(BA_BLOCK), lds2, ctx->stream, L.d_arr, lambda, orth);
-  } else {
-    const size_t lds = sizeof(double) * ((size_t)n * ((n + 2) & ~1) + 6 * n + 16) + sizeof(int) * n;   // matrix, six vectors (+16 pad), perm
-    hipLaunchKernelGGL(k_ba_solve<1>, dim3(1, L.nwin), dim3(BA_BLOCK), lds, ctx->stream, L.d_arr, lambda, orth);
-  }
-  if (L.max_nblk_pts > 0) LAUNCH_RESUB( dim3(L.max_nblk_pts, L.nwin), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr);
-}
-// a Schur kernel still on the side stream whose consumer is not a waiting tail kernel: join it on the main stream and clear the counters
-__global__ void k_ba_clear_sc_done(const BaDev* __restrict__ wins) { wins[blockIdx.x].opt->sc_done = 0; }
-static void join_sc(sdso_ctx* ctx, BaBatch* Bt) {
-  if (!Bt || !Bt->sc_async) return;
-  hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0);
-  hipLaunchKernelGGL(k_ba_clear_sc_done, dim3(Bt->L.nwin), dim3(1), 0, ctx->stream, Bt->L.d_arr);
-  Bt->sc_async = false;
+  const size_t lds = sizeof(double) * ((size_t)n * ((n + 2) & ~1) + 6 * n + 16) + sizeof(int) * n;   // matrix, six vectors (+16 pad), perm
+  hipLaunchKernelGGL(k_ba_solve, dim3(1, L.nwin), dim3(BA_BLOCK), lds, ctx->stream, L.d_arr, lambda, orth);
+  if (L.max_nblk_pts > 0) LAUNCH_RESUB(L, dim3(L.max_nblk_pts, L.nwin), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr);
 }
 // the packed block of a batch whose latest accumulate deferred its folds: fold now (anyone but the tail kernel reads folded sums)
 static void ensure_folded(sdso_ctx* ctx, BaBatch* Bt) {
-  join_sc(ctx, Bt);
   if (!Bt || Bt->folded) return;
   launch_fold_deferred(ctx, Bt->L);
   Bt->folded = true;
@@ -736,6 +665,7 @@ static BaLaunch single(BaWindowDev* W) {
   L.any_lin = W->has_lin_cached;
   L.tiled = W->d.tiledT > 0;
   L.alt = (W->solverMode & (SOLVER_SVD | SOLVER_ORTHOGONALIZE_SYSTEM)) != 0;
+  L.Ws = {W};
   return L;
 }
 
@@ -867,10 +797,10 @@ extern "C" int sdso_ba_get_residual_state(sdso_ctx* ctx, int win, uint8_t* state
   std::vector<uint8_t> t(nr);
   if (state && nr) { SDSO_HIP(ctx, hipMemcpy(t.data(), W->d.r_state, nr, hipMemcpyDeviceToHost)); for (int j = 0; j < nr; j++) state[W->perm[j]] = t[j]; }
   if (isActive && nr) { SDSO_HIP(ctx, hipMemcpy(t.data(), W->d.r_act, nr, hipMemcpyDeviceToHost)); for (int j = 0; j < nr; j++) isActive[W->perm[j]] = t[j]; }
-  if (JpJdF && nr) {
-    std::vector<float> rec((size_t)W->d.np * W->d.nf * 16);
+  if (JpJdF && nr) {   // (the records lie in the window's order)
+    std::vector<float> rec((size_t)nr * 16);
     SDSO_HIP(ctx, hipMemcpy(rec.data(), W->d.r_rec, sizeof(float) * rec.size(), hipMemcpyDeviceToHost));
-    for (int j = 0; j < nr; j++) std::memcpy(JpJdF + (size_t)W->perm[j] * 8, &rec[((size_t)W->h_point[j] * W->d.nf + W->h_target[j]) * 16], 32);
+    for (int o = 0; o < nr; o++) std::memcpy(JpJdF + (size_t)o * 8, &rec[(size_t)o * 16], 32);
   }
   return SDSO_OK;
 }
@@ -1031,7 +961,7 @@ static int solve_system_host(sdso_ctx* ctx, BaWindowDev* W, int iteration, doubl
         xAd[(size_t)(nf * h + t) * 8 + j] = sh + stt;
       }
   SDSO_HIP(ctx, hipMemcpyAsync(W->dt_xAd, xAd.data(), sizeof(float) * xAd.size(), hipMemcpyHostToDevice, ctx->stream));
-  if (L.max_nblk_pts > 0) LAUNCH_RESUB( dim3(L.max_nblk_pts, 1), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr);
+  if (L.max_nblk_pts > 0) LAUNCH_RESUB(L, dim3(L.max_nblk_pts, 1), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr);
   SDSO_HIP(ctx, hipGetLastError());
   SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));   // x / lastHS / lastbS / xAd are stack-local
   return SDSO_OK;
@@ -1120,7 +1050,7 @@ extern "C" int sdso_ba_resubstitute(sdso_ctx* ctx, int win, const double* x, dou
       }
   SDSO_HIP(ctx, hipMemcpyAsync(W->dt_xAd, xAd.data(), sizeof(float) * xAd.size(), hipMemcpyHostToDevice, ctx->stream));
   const BaLaunch L = single(W);
-  if (L.max_nblk_pts > 0) LAUNCH_RESUB( dim3(L.max_nblk_pts, 1), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr);
+  if (L.max_nblk_pts > 0) LAUNCH_RESUB(L, dim3(L.max_nblk_pts, 1), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr);
   SDSO_HIP(ctx, hipGetLastError());
   SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
   for (int i = 0; i < 4; i++) W->calib.step[i] = -x[i];
@@ -1386,8 +1316,6 @@ extern "C" int sdso_ba_batch_create(sdso_ctx* ctx, int nwin, const int* wins) {
   BaBatch* Bt = new BaBatch();
   Bt->d_arr = d_arr; Bt->d_accum = d_accum; Bt->W = Ws;
   Bt->wins.assign(wins, wins + nwin);
-  if (const char* e = getenv("SDSO_BA_GATHER")) Bt->gather = std::max(0, std::min(2, atoi(e)));
-  if (getenv("SDSO_BA_DIRECT_TAPS")) Bt->gather = 0;
   reg_get(g_batches, ctx) = Bt;
   hipMemsetAsync(Bt->d_accum, 0, sizeof(float) * af * nwin, ctx->stream);
   std::vector<BaDev> h(nwin);
@@ -1407,6 +1335,7 @@ extern "C" int sdso_ba_batch_create(sdso_ctx* ctx, int nwin, const int* wins) {
   L.d_arr = Bt->d_arr;
   L.any_lin = false;   // recomputed at every launch (marginalisation may linearize residuals of a member later)
   L.alt = (Ws[0]->solverMode & (SOLVER_SVD | SOLVER_ORTHOGONALIZE_SYSTEM)) != 0;   // (the members of a batch share one solverMode)
+  L.Ws = Ws;
   Bt->L = L;
   if (hipStreamSynchronize(ctx->stream) != hipSuccess) { free_batch(ctx); return sdso::fail(ctx, SDSO_ERR_HIP, "batch descriptor upload failed"); }
   return SDSO_OK;
@@ -1441,7 +1370,6 @@ void* ba_window_accum_block(sdso_ctx* ctx, int win, size_t* nfloats) {
 namespace sdso {
 struct OptRun;
 static bool batch_defers_fold(sdso_ctx* ctx, BaBatch* Bt);   // below, next to the resident loop
-static bool batch_async_sc(sdso_ctx* ctx, BaBatch* Bt);
 }
 // phase 1 of one GN iteration for every window of the batch: linearize + applyRes + accumulate A/L/SC (enqueue only).
 // Inside a single-rank resident loop (sdso_ba_batch_optimize_begin) the folds of the partial sums are left to the fused tail kernel of
@@ -1449,11 +1377,8 @@ static bool batch_async_sc(sdso_ctx* ctx, BaBatch* Bt);
 extern "C" int sdso_ba_batch_accumulate(sdso_ctx* ctx) {
   BaBatch* Bt = get_batch(ctx);
   if (!Bt) return sdso::fail(ctx, SDSO_ERR_STATE, "no batch");
-  join_sc(ctx, Bt);
   Bt->scattered = false;
-  bool async = batch_async_sc(ctx, Bt);
-  Bt->folded = launch_fused(ctx, batch_launch(Bt), Bt->materialize, Bt->gather, 3, batch_defers_fold(ctx, Bt), &async);
-  Bt->sc_async = async;
+  Bt->folded = launch_fused(ctx, batch_launch(Bt), Bt->materialize, 3, batch_defers_fold(ctx, Bt));
   mark_linearized(Bt->W, Bt->materialize);
   SDSO_HIP(ctx, hipGetLastError());
   return SDSO_OK;
@@ -1464,7 +1389,7 @@ extern "C" int sdso_ba_batch_accumulate(sdso_ctx* ctx) {
 extern "C" int sdso_ba_batch_linearize(sdso_ctx* ctx) {
   BaBatch* Bt = get_batch(ctx);
   if (!Bt) return sdso::fail(ctx, SDSO_ERR_STATE, "no batch");
-  launch_fused(ctx, batch_launch(Bt), Bt->materialize, Bt->gather, 1);
+  launch_fused(ctx, batch_launch(Bt), Bt->materialize, 1);
   mark_linearized(Bt->W, Bt->materialize);
   SDSO_HIP(ctx, hipGetLastError());
   return SDSO_OK;
@@ -1472,11 +1397,8 @@ extern "C" int sdso_ba_batch_linearize(sdso_ctx* ctx) {
 extern "C" int sdso_ba_batch_schur(sdso_ctx* ctx) {
   BaBatch* Bt = get_batch(ctx);
   if (!Bt) return sdso::fail(ctx, SDSO_ERR_STATE, "no batch");
-  join_sc(ctx, Bt);
   Bt->scattered = false;
-  bool async = batch_async_sc(ctx, Bt);
-  Bt->folded = launch_fused(ctx, batch_launch(Bt), Bt->materialize, Bt->gather, 2, batch_defers_fold(ctx, Bt), &async);
-  Bt->sc_async = async;
+  Bt->folded = launch_fused(ctx, batch_launch(Bt), Bt->materialize, 2, batch_defers_fold(ctx, Bt));
   SDSO_HIP(ctx, hipGetLastError());
   return SDSO_OK;
 }
@@ -1502,23 +1424,19 @@ extern "C" int sdso_ba_batch_solve(sdso_ctx* ctx, double lambda, int orthogonali
     // SDSO_BA_SOLVE_HOST=1 (A/B): solveSystemF's SVD / orthogonalised-system branches (EnergyFunctional.cpp:876-900, 924-965) with the
     // assembly and the eigen-decomposition on the host, window by window (solve_system_host), the back-substitution on the device.  The
     // host mirrors (deltas, projector) are those of the upload.  Default: k_ba_solve_alt for the whole batch (launch_solve).
-    join_sc(ctx, Bt);
     ensure_folded(ctx, Bt);
     for (BaWindowDev* W : Bt->W) {
       const int rc = solve_system_host(ctx, W, orthogonalize_x ? 2 : 0, lambda);   // (iteration >= 2 is how the single call spells ORTHOGONALIZE_X_LATER)
       if (rc) return rc;
     }
-    Bt->sc_async = false;
     return SDSO_OK;
   }
   const bool no_tail = !tail_enabled() || batch_launch(Bt).alt;
-  if (no_tail) join_sc(ctx, Bt);
   if (batch_launch(Bt).alt) {   // as the single call spells it for these branches: the argument is "iteration >= 2", the mode decides (EnergyFunctional.cpp:980)
     const int sm = Bt->W[0]->solverMode;
     orthogonalize_x = ((sm & SOLVER_ORTHOGONALIZE_X) || (orthogonalize_x && (sm & SOLVER_ORTHOGONALIZE_X_LATER))) ? 1 : 0;
   }
-  launch_solve(ctx, batch_launch(Bt), lambda, orthogonalize_x, Bt->folded, Bt->sc_async);   // (the tail kernel folds for itself: the block stays as it is)
-  Bt->sc_async = false;
+  launch_solve(ctx, batch_launch(Bt), lambda, orthogonalize_x, Bt->folded);   // (the tail kernel folds for itself: the block stays as it is)
   if (no_tail) Bt->folded = true;
   SDSO_HIP(ctx, hipGetLastError());
   return SDSO_OK;
@@ -1630,7 +1548,7 @@ template <class T> static int grow(sdso_ctx* ctx, T*& p, size_t& cap, size_t wan
 struct OptRun {
   BaLaunch L{};
   std::vector<BaWindowDev*> W;
-  bool materialize = true; int gather = 1;
+  bool materialize = true;
   int cap = 0, nranks = 1, sums_stride = 0, iteration = 0, stop = 1;
   bool exchange = false;   // pack + all-gather between the ranks (always when nranks > 1)
   bool gated = false;      // energy-gated flow (setting_forceAceptStep = false): un-fused kernels + k_ba_opt_gate
@@ -1812,7 +1730,7 @@ static int opt_finish(sdso_ctx* ctx, OptRun& R, sdso_ba_opt_result_t* out) {
   const int nwin = (int)R.W.size(), nf = R.L.nf;
   int rc = SDSO_OK;
   if (!R.gated) {   // (the gated loop leaves every window linearised at its final state)
-    launch_fused(ctx, R.L, R.materialize, R.gather, 1);
+    launch_fused(ctx, R.L, R.materialize, 1);
     mark_linearized(R.W, R.materialize);
     if ((rc = opt_consume(ctx, R, 1, false, false))) return rc;
   }
@@ -1889,29 +1807,18 @@ static bool batch_defers_fold(sdso_ctx* ctx, BaBatch* Bt) { (void)ctx; return ta
 // solveSystem + doStepFromBackup + the loop's host part of iteration R.iteration.  Single rank: ONE launch of the fused tail kernel.
 // Sharded windows: tail kernel (stitch, solve, resubstitute, points' step) -> pack -> all-gather -> k_ba_opt_step, as before.
 static std::map<sdso_ctx*, OptRun*> g_optruns;   // the batch loop in flight between sdso_ba_batch_optimize_begin and _end
-static bool batch_async_sc(sdso_ctx* ctx, BaBatch* Bt) {
-  // SDSO_BA_SC_ASYNC=1 (experiment, off by default): the Schur kernel goes to the side stream inside a single-rank resident loop, where
-  // the next thing on the main stream is the tail kernel that waits for it in-kernel.  Measured on MI355X (profiles/r03_ab_sc_async.txt):
-  // 0.66-0.69 ms per step against 0.60 in order — the waiting workgroups hold 64 CUs for the event latency + the whole Schur kernel
-  // (tail 278 instead of 120-190 us), which costs the other batch's linearisation more than the earlier start of the tail gains.
-  static const bool on = getenv("SDSO_BA_SC_ASYNC") && atoi(getenv("SDSO_BA_SC_ASYNC")) == 1;
-  // the waiting tail workgroups hold one CU each (150 KB of LDS): they must leave most of the chip to the kernel they wait for
-  if (!on || !tail_enabled() || Bt->L.alt || Bt->eager_fold || !reg_has(g_optruns, ctx) || Bt->L.nwin > ctx->n_cu / 2) return false;
-  OptRun* R = reg_get(g_optruns, ctx);
-  return R && R->active && !R->exchange && !R->gated && R->W == Bt->W;
-}
-static int opt_solve_step(sdso_ctx* ctx, OptRun& R, double lambda, int orth, bool folded, bool wait_sc = false) {
+static int opt_solve_step(sdso_ctx* ctx, OptRun& R, double lambda, int orth, bool folded) {
   if (!tail_enabled() || R.L.alt) {
     launch_solve(ctx, R.L, lambda, orth, folded);
     SDSO_HIP(ctx, hipGetLastError());
     return opt_step(ctx, R);
   }
-  const int flags = ((orth & 1) ? TAIL_ORTH : 0) | (R.L.any_lin ? TAIL_TOPL : 0) | (folded ? 0 : TAIL_FOLD) | (wait_sc ? TAIL_WAIT_SC : 0) | (R.keep_hs ? TAIL_HS : 0);
+  const int flags = ((orth & 1) ? TAIL_ORTH : 0) | (R.L.any_lin ? TAIL_TOPL : 0) | (folded ? 0 : TAIL_FOLD) | (R.keep_hs ? TAIL_HS : 0);
   const int nwin = (int)R.W.size();
   const dim3 gp(std::max(R.L.max_nblk_pts, 1), nwin);
   if (!R.exchange) {
     launch_tail(ctx, R.L, lambda, flags | TAIL_STEP, R.iteration, 0, R.stop);
-    if (R.L.max_nblk_pts) LAUNCH_RESUB_STEP( gp, dim3(BA_BLOCK), 0, ctx->stream, R.L.d_arr, R.iteration + 1, (float*)nullptr, 0);
+    if (R.L.max_nblk_pts) LAUNCH_RESUB_STEP(R.L, gp, dim3(BA_BLOCK), 0, ctx->stream, R.L.d_arr, R.iteration + 1, (float*)nullptr, 0);
     SDSO_HIP(ctx, hipGetLastError());
     R.iteration++;
     return SDSO_OK;
@@ -1933,7 +1840,7 @@ static int opt_solve_step(sdso_ctx* ctx, OptRun& R, double lambda, int orth, boo
     hipLaunchKernelGGL(k_ba_sol_record, dim3(nwin), dim3(256), 0, ctx->stream, R.L.d_arr, first, per, R.B->d_solrec, 1);
   } else
     launch_tail(ctx, R.L, lambda, flags);
-  if (R.L.max_nblk_pts) LAUNCH_RESUB_STEP( gp, dim3(BA_BLOCK), 0, ctx->stream, R.L.d_arr, -1, R.B->d_sums, R.sums_stride);
+  if (R.L.max_nblk_pts) LAUNCH_RESUB_STEP(R.L, gp, dim3(BA_BLOCK), 0, ctx->stream, R.L.d_arr, -1, R.B->d_sums, R.sums_stride);
   const int rc = opt_consume(ctx, R, 0, false, R.L.max_nblk_pts > 0);
   R.iteration++;
   return rc;
@@ -1942,9 +1849,7 @@ static int opt_solve_step(sdso_ctx* ctx, OptRun& R, double lambda, int orth, boo
 static int opt_iteration(sdso_ctx* ctx, OptRun& R, int it) {
   BaBatch* Bt = R.W[0]->in_batch ? get_batch(ctx) : nullptr;
   const bool defer = tail_enabled() && !R.L.alt && !R.exchange && !(Bt && Bt->eager_fold);
-  if (Bt) join_sc(ctx, Bt);
-  bool async = Bt ? batch_async_sc(ctx, Bt) : false;      // (a single window has nothing to overlap the Schur kernel with)
-  bool folded = launch_fused(ctx, R.L, R.materialize, R.gather, 3, defer, &async);
+  bool folded = launch_fused(ctx, R.L, R.materialize, 3, defer);
   mark_linearized(R.W, R.materialize);
   if (Bt) Bt->folded = folded;
   if (R.exchange) {
@@ -1957,13 +1862,13 @@ static int opt_iteration(sdso_ctx* ctx, OptRun& R, int it) {
   if (sm & SOLVER_USE_GN) lambda = 0;
   if (sm & SOLVER_FIX_LAMBDA) lambda = 1e-5;
   const int orth = (sm & SOLVER_ORTHOGONALIZE_X) || (it >= 2 && (sm & SOLVER_ORTHOGONALIZE_X_LATER));
-  return opt_solve_step(ctx, R, lambda, orth ? 1 : 0, folded, async);
+  return opt_solve_step(ctx, R, lambda, orth ? 1 : 0, folded);
 }
 
 int optimize_resident_single(sdso_ctx* ctx, BaWindowDev* W, int mnumOptIts, sdso_ba_opt_result_t* res) {
   OptRun R;
   R.L = single(W); R.W = {W};
-  R.materialize = true; R.gather = 1; R.keep_hs = true;
+  R.materialize = true; R.keep_hs = true;
   // refused before anything is touched: opt_begin would already issue a collective and reset the window's residuals
   if (comm_nranks(ctx) > 1) return sdso::fail(ctx, SDSO_ERR_STATE, "sdso_ba_optimize is a single-rank call; sharded windows use sdso_ba_batch_optimize");
   R.local_only = true;
@@ -2009,7 +1914,7 @@ extern "C" int sdso_ba_batch_optimize_begin(sdso_ctx* ctx, int stop_on_convergen
   SDSO_HIP(ctx, hipSetDevice(ctx->device));
   free_optrun(ctx);
   OptRun* R = new OptRun();
-  R->L = batch_launch(Bt); R->W = Bt->W; R->materialize = Bt->materialize; R->gather = Bt->gather; R->keep_hs = Bt->keep_system;
+  R->L = batch_launch(Bt); R->W = Bt->W; R->materialize = Bt->materialize; R->keep_hs = Bt->keep_system;
   R->scatter_local = Bt->exchange_mode == 1;
   int rc = opt_begin(ctx, *R, stop_on_convergence);
   if (rc) { delete R; return rc; }
@@ -2034,10 +1939,7 @@ extern "C" int sdso_ba_batch_solve_step(sdso_ctx* ctx, double lambda, int orthog
   if (Bt->W[0]->solverMode & SOLVER_USE_GN) lambda = 0;
   if (Bt->W[0]->solverMode & SOLVER_FIX_LAMBDA) lambda = 1e-5;
   R->L = batch_launch(Bt);
-  const bool wait_sc = Bt->sc_async;
-  Bt->sc_async = false;
-  if (wait_sc && (!tail_enabled() || R->L.alt || R->exchange)) { Bt->sc_async = true; join_sc(ctx, Bt); return opt_solve_step(ctx, *R, lambda, orthogonalize_x ? 1 : 0, Bt->folded); }
-  return opt_solve_step(ctx, *R, lambda, orthogonalize_x ? 1 : 0, Bt->folded, wait_sc);
+  return opt_solve_step(ctx, *R, lambda, orthogonalize_x ? 1 : 0, Bt->folded);
 }
 extern "C" int sdso_ba_batch_optimize_end(sdso_ctx* ctx, sdso_ba_opt_result_t* out) {
   if (!ctx || !reg_has(g_optruns, ctx)) return sdso::fail(ctx, SDSO_ERR_STATE, "sdso_ba_batch_optimize_begin first");
@@ -2056,12 +1958,11 @@ extern "C" int sdso_ba_batch_optimize(sdso_ctx* ctx, int mnumOptIts, sdso_ba_opt
       // k_ba_solve_alt in the place of the tail kernel's stitch and solve
       SDSO_HIP(ctx, hipSetDevice(ctx->device));
       free_optrun(ctx);
-      join_sc(ctx, Bt);
       for (size_t i = 0; i < Bt->wins.size(); i++) {
         const int rc = sdso_ba_optimize(ctx, Bt->wins[i], mnumOptIts, nullptr, nullptr, nullptr, out ? &out[i] : nullptr);
         if (rc) return rc;
       }
-      Bt->folded = true; Bt->sc_async = false;
+      Bt->folded = true;
       return SDSO_OK;
     }
   }

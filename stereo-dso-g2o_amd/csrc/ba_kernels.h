@@ -22,9 +22,11 @@ constexpr int BA_SC_PTS = 32;      // points per SC wave item (<= 64)
 constexpr int J_RESF = 0, J_XI0 = 8, J_XI1 = 14, J_C0 = 20, J_C1 = 24, J_DD = 28, J_IDX0 = 30, J_IDX1 = 38, J_AB0 = 46, J_AB1 = 54,
               J_IDX2 = 62, J_ABIDX = 66, J_AB2 = 70;
 // p_out record (16 floats per point)
-constexpr int PO_HDD_A = 0, PO_BD_A = 1, PO_HCD_A = 2, PO_HDD_L = 6, PO_BD_L = 7, PO_HCD_L = 8, PO_HDI = 12, PO_BDSUM = 13, PO_STEP = 14, PO_BACKUP = 15;
-// r_rec record (16 floats per residual): JpJdF[8], bd, Hdd, Hcd[4], flags, target
-constexpr int RR_BD = 8, RR_HDD = 9, RR_HCD = 10, RR_FLAGS = 14, RR_TARGET = 15;
+// [0..7] is what a plain Gauss-Newton iteration writes (one 32-byte piece per point), [8..13] the sums of the linearised / marginalised
+// residuals (zero unless such residuals exist), [14..15] the back-substitution's own
+constexpr int PO_HCD_A = 0, PO_HDD_A = 4, PO_BD_A = 5, PO_HDI = 6, PO_BDSUM = 7, PO_HCD_L = 8, PO_HDD_L = 12, PO_BD_L = 13, PO_STEP = 14, PO_BACKUP = 15;
+// r_rec record (16 floats per residual): JpJdF[8], bd, Hdd, Hcd[4], flags (bit 0 active, bit 1 linearized), -
+constexpr int RR_BD = 8, RR_HDD = 9, RR_HCD = 10, RR_FLAGS = 14;
 
 // Device-resident state of FullSystem::optimize's Gauss-Newton loop for one window (ba_opt.hip): what the reference keeps in
 // FrameHessian (state / state_backup / state_zero / worldToCam_evalPT / PRE_worldToCam, HessianBlocks.h:120-190) and
@@ -49,9 +51,6 @@ struct BaOptDev {
   // what loadSateBackup + setPrecalcValues restore on a rejected step
   float bk_precalc[64 * 27], bk_adHTdelta[64 * 8], bk_cdelta[4], bk_calib[6];
   double bk_prior[8 * 16 + 4 + 8 * 8 + 4];
-  // hand-off from the Schur kernel on the side stream to the fused tail kernel (ba_tail.hip, TAIL_WAIT_SC): every host workgroup
-  // of k_ba_sc_host adds one when its bins are written; the tail waits for nf of them and clears the word
-  int sc_done;
 };
 
 struct BaDev {
@@ -71,7 +70,7 @@ struct BaDev {
   const int* p_host;
   float* p_prior;
   float* p_delta;
-  const int* p_rbeg;
+  const int* p_rbeg;        // np + 1: first residual (window order) of every point; p_rbeg[np] = nr
   const int* p_rcnt;
   const int* p_rlist;       // sorted residual index of every (point, slot)   (host bookkeeping / debug)
   const unsigned* p_order;  // per point: nibble k = target frame of its k-th residual in EFPoint::residualsAll order, 0xF past the end.  The
@@ -92,9 +91,15 @@ struct BaDev {
   float* r_energy; float* r_newEnergy; float* r_newEnergyWO;
   float* J[2];              // 19 float4 groups x nrp each (layout: ba_kernels.hip); EFResidual::J = J[jsel], PointFrameResidual::J = J[1-jsel]
   float* r_toZero;          // 8 x nrp SoA
-  float* r_rec;             // np x nf x 16: dense [point][target] records (RR_*), flags 0 where the point has no residual to that target
-  float* r_cj;              // np x nf x 8: the JpJdF halves of r_rec alone, written by k_ba_sc_host while it has the records parked (its launches are
-                            // latency-bound, the stores ride for free) so that the back-substitution streams 32 instead of 64 bytes per (point, target)
+  // Per-residual records of the Schur part, in the WINDOW's residual order (grouped by point, EFPoint::residualsAll order inside a point:
+  // record o belongs to point res_point[o]; point p owns records [p_rbeg[p], p_rbeg[p + 1]), nibble k of p_order[p] names the target of its
+  // k-th record) — no slot for a target the point does not observe.  Zeros where the residual is not active (the sums add / multiply
+  // records without looking at flags).  One 64-byte piece per residual: the linearisation's scattered store stays ONE half line (two
+  // 32-byte pieces in two arrays cost k_ba_lin_fused 6 %: measured, profiles/README.md round 5).
+  float* r_rec;             // nr x 16: EFResidual::JpJdF (EnergyFunctionalStructs.cpp:37-51), then RR_*: the residual's terms of Hdd / bd / Hcd
+                            // (AccumulatedTopHessian.cpp:160-172) and its flags
+  float* r_cj;              // nr x 8: the JpJdF halves alone, written by k_ba_sc_host while it has the records in LDS (its launches are latency-
+                            // bound, the coalesced stores ride along) so that the back-substitution streams 32 instead of 64 bytes per residual
   float* r_proj;            // nr x 19 (projectedTo 16, centerProjectedTo 3)
   // tables
   const float* t_precalc;   // [host*nf+target][27]
@@ -112,7 +117,7 @@ struct BaDev {
   const int4* items;        // {host, pbeg, pend, 0}
   const int* host_item_beg; // nf+1
   float* top_part;          // nchunks x 92 (91 sums + count)
-  float* sc_part;           // nitems x SC_PART
+  float* sc_part;           // nf x 20: Hcc (16) and bc (4) of every host's Schur workgroup; the fold adds the hosts
   double* e_part;           // energy partials of linearize (per workgroup)
   float* accum;             // packed accumulators (see sdso_ba_accum_floats)
   double* sol;              // Htop_A n*n | btop_A n | Htop_L n*n | btop_L n | Hsc n*n | bsc n | x n | HS n*n | bS n
@@ -141,7 +146,6 @@ __host__ __device__ inline size_t j_off(int S, int i, int g) {
 #endif
 }
 
-__host__ __device__ inline int sc_part_floats(int nf) { return nf * nf * 64 + nf * 32 + nf * 8 + 16 + 4; }
 __host__ __device__ inline size_t acc_off_topA(int nf) { return 0; }
 __host__ __device__ inline size_t acc_off_topL(int nf) { return (size_t)nf * nf * 91; }
 __host__ __device__ inline size_t acc_off_D(int nf) { return (size_t)nf * nf * 91 * 2; }

@@ -464,42 +464,6 @@ __device__ __forceinline__ double linearize_coop(const BaDev& B, int i, bool liv
   B.r_newEnergy[i] = energyLeft;
   return (double)energyLeft;
 }
-// ------------------------------------------------------------------ linearize with the taps brought in by LDS-DMA
-// Third gather scheme (GATHER = 2, 4x2-tiled images): the 32 taps of a residual are fetched by `global_load_lds_dwordx4`
-// (one 16-byte pixel per lane, written by the memory pipeline straight into LDS — no destination VGPRs, nothing to wait for at
-// issue).  A ROUND is one pattern pixel of all 64 residuals of the wave: 4 instructions, lane = (residual % 16, corner) so that the
-// four corners of a bilinear sample sit on neighbouring lanes (one or two 128-byte lines per quad, as in the cooperative gather),
-// 4 KiB of LDS.  DM_DEPTH rounds are in flight per wave; while they travel the wave interpolates and does the per-pixel arithmetic
-// of the round that has landed ON THE RESIDUAL'S OWN LANE (four ds_read_b128 of its 64 contiguous bytes, then exactly
-// interp33's expression) and stores that pixel's Jacobian group: no coordinate / sample stage, no quad shuffles, and a third
-// fewer vector instructions than the cooperative scheme (which spends 32 x ~40 instructions per wave on redundant weights).
-// The compiler cannot track the LDS dependency of the DMA finer than `s_waitcnt vmcnt(0)`, so the ring is read with inline
-// assembly behind a counted wait: vector-memory operations complete in issue order, hence `vmcnt(4 x rounds issued later)` is a
-// sufficient wait for round p whatever stores were issued in between (they only make the wait earlier than necessary).
-constexpr int DM_DEPTH = 3;
-constexpr int DM_ROUND_FLOATS = 4 * 64 * 4;
-constexpr int DM_WAVE_FLOATS = DM_DEPTH * DM_ROUND_FLOATS;     // 12 KiB per wave
-template <int N>
-__device__ __forceinline__ void dm_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-// one round: xy = (int)Ku | (int)Kv << 16 of THIS lane's residual for the round's pattern pixel (0 for a dead lane: pixel (0,0))
-__device__ __forceinline__ void dm_issue_round(const float4* __restrict__ img, int Tw, int xy, float* slot) {
-  const int lane = threadIdx.x & 63;
-#pragma unroll
-  for (int q = 0; q < 4; q++) {
-    const int v = __shfl(xy, 16 * q + (lane >> 2), 64);
-    const int x = (v & 0xffff) + (lane & 1), y = (v >> 16) + ((lane >> 1) & 1);
-    const float4* a = img + tiled_index(x, y, Tw);
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)a, (__attribute__((address_space(3))) void*)(slot + q * 256), 16, 0, 0);
-  }
-}
-// the four corner pixels of this lane's sample: 64 contiguous bytes at slot + 16 * lane floats (instruction lane/16, its lanes 4*(lane%16)..+3)
-__device__ __forceinline__ void dm_read_taps(const float* slot_lane, te_f4& p00, te_f4& p10, te_f4& p01, te_f4& p11) {
-  const unsigned addr = (unsigned)(unsigned long)(const __attribute__((address_space(3))) float*)slot_lane;
-  asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:32\n\tds_read_b128 %3, %4 offset:48\n\ts_waitcnt lgkmcnt(0)"
-               : "=&v"(p00), "=&v"(p10), "=&v"(p01), "=&v"(p11)
-               : "v"(addr)
-               : "memory");
-}
 #undef SETQ
 
 template <bool TILED>
@@ -523,7 +487,8 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_apply(const BaDev* __restrict__
   if (ba_gate_skip(B, cond)) return;
   const int i = blockIdx.x * BA_BLOCK + threadIdx.x;
   if (i >= B.nr) return;
-  float* rec = B.r_rec + ((size_t)B.r_point[i] * B.nf + B.r_target[i]) * 16;
+  float* jp = B.r_rec + (size_t)B.r_orig[i] * 16;
+  float* tm = jp + 8;
   if (B.r_lin[i]) return;
   const uint8_t st = B.r_state[i];
   if (st == 1) return;  // can never go back from OOB
@@ -545,19 +510,19 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_apply(const BaDev* __restrict__
     for (int k = 0; k < 6; k++) out[k] = xi0[k] * v0 + xi1[k] * v1;
     out[6] = ai.x * jdd0 + ai.y * jdd1;
     out[7] = ai.z * jdd0 + ai.w * jdd1;
-    *(float4*)(rec) = make_float4(out[0], out[1], out[2], out[3]);
-    *(float4*)(rec + 4) = make_float4(out[4], out[5], out[6], out[7]);
+    *(float4*)(jp) = make_float4(out[0], out[1], out[2], out[3]);
+    *(float4*)(jp + 4) = make_float4(out[4], out[5], out[6], out[7]);
   }
   else {
-    // the record of a residual that is not active holds zeros (like the fused kernel's): the Schur kernel adds / multiplies records without
+    // the records of a residual that is not active hold zeros (like the fused kernel's): the Schur kernel adds / multiplies records without
     // looking at their flags
-    *(float4*)(rec) = make_float4(0.f, 0.f, 0.f, 0.f);
-    *(float4*)(rec + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
-    *(float4*)(rec + 8) = make_float4(0.f, 0.f, 0.f, 0.f);
-    rec[12] = 0.f; rec[13] = 0.f;
+    *(float4*)(jp) = make_float4(0.f, 0.f, 0.f, 0.f);
+    *(float4*)(jp + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    *(float4*)(tm) = make_float4(0.f, 0.f, 0.f, 0.f);
+    tm[4] = 0.f; tm[5] = 0.f;
   }
   B.r_act[i] = act;
-  rec[RR_FLAGS] = (float)act;
+  jp[RR_FLAGS] = (float)act;
   B.r_state[i] = ns;
   B.r_energy[i] = B.r_newEnergy[i];
 }
@@ -643,7 +608,7 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_fixlin(const BaDev* __restrict_
     B.r_toZero[k * S + i] = rtz;
   }
   B.r_lin[i] = 1;
-  B.r_rec[((size_t)pt * B.nf + B.r_target[i]) * 16 + RR_FLAGS] = 3.f;  // active | linearized
+  B.r_rec[(size_t)B.r_orig[i] * 16 + RR_FLAGS] = 3.f;  // active | linearized
 }
 
 // resetOOB + isLinearized=false for the residuals of flagged points (FullSystem.cpp:1012-1016)
@@ -659,16 +624,13 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_unmask(const BaDev* __restrict_
   const int i = blockIdx.x * BA_BLOCK + threadIdx.x;
   if (i < B.nr) B.r_lin[i] &= 1;
 }
-// upload: state_NewState = OUTLIER, state_NewEnergyWithOutlier = -1 (Residuals.cpp:40-52), and the target of every existing
-// (point, target) slot of the dense per-point records
+// upload: state_NewState = OUTLIER, state_NewEnergyWithOutlier = -1 (Residuals.cpp:40-52)
 __global__ __launch_bounds__(BA_BLOCK) void k_ba_init_res(const BaDev* __restrict__ wins) {
   const BaDev& B = wins[blockIdx.y];
   const int i = blockIdx.x * BA_BLOCK + threadIdx.x;
   if (i >= B.nr) return;
   B.r_newState[i] = 2;
   B.r_newEnergyWO[i] = -1.f;
-  const int t = B.r_target[i];
-  B.r_rec[((size_t)B.r_point[i] * B.nf + t) * 16 + RR_TARGET] = (float)t;
 }
 // resetOOB for every non-linearized residual (FullSystemOptimize.cpp:886-892)
 __global__ __launch_bounds__(BA_BLOCK) void k_ba_reset_all(const BaDev* __restrict__ wins) {
@@ -773,6 +735,7 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_accum_top(const BaDev* __restri
     float jl[76];
     load_J(B.J[B.r_jsel[i]], S, i, jl);
     const int pt = B.r_point[i];
+    (void)pt;
     float resApprox[8];
     if (mode == 0) {
 #pragma unroll
@@ -823,7 +786,7 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_accum_top(const BaDev* __restri
     const float a10 = JV(J_IDX2 + 2);
     const float q0 = a * jdd0 + b * jdd1;
     const float q1 = a10 * jdd0 + c * jdd1;
-    float* rec = B.r_rec + ((size_t)pt * B.nf + ch.x / B.nf) * 16;   // pair = host + target*nf
+    float* rec = B.r_rec + (size_t)B.r_orig[i] * 16;
     rec[RR_BD] = JI_r0 * jdd0 + JI_r1 * jdd1;
     rec[RR_HDD] = q0 * jdd0 + q1 * jdd1;
 #pragma unroll
@@ -841,11 +804,11 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_accum_top(const BaDev* __restri
 // Linearized residuals are untouched (their accumulation is the separate mode-1 pass).
 // Workgroups per CU: four without the Jacobian stores (124 VGPRs, 40 KB of LDS each); with them the kernel needs 152 VGPRs
 // (capping it at 128 spills 22-38 of them and loses more than the fourth wave per SIMD gains), so three.
-// GATHER: 0 = every lane fetches the 32 taps of its own residual (A/B: SDSO_BA_DIRECT_TAPS); 1 = cooperative quad gather
-// (linearize_coop), the library's default.  k_ba_lin_dma below (LDS-DMA rounds, tiled images) is a third, equally fast variant.
-template <bool MATERIALIZE, bool TILED, int GATHER = 1>
+// The 32 taps of a residual come in through the cooperative quad gather (linearize_coop).  (Rounds 1-4 kept two more gathers for A/B — one
+// residual's taps on one lane, and LDS-DMA rounds; both lost or tied, profiles/README.md.)
+template <bool MATERIALIZE, bool TILED>
 __global__ __launch_bounds__(BA_BLOCK, (MATERIALIZE ? 3 : 4)) void k_ba_lin_fused(const BaDev* __restrict__ wins) {
-  constexpr bool COOP = GATHER == 1;
+  constexpr bool COOP = true;
   // by-value copy first: every pointer of the descriptor is read before the kernel's first store, so the
   // compiler can prove them global (global_load / s_load instead of flat_load) and keep them in SGPRs
   const BaDev B = wins[blockIdx.y];
@@ -876,13 +839,8 @@ __global__ __launch_bounds__(BA_BLOCK, (MATERIALIZE ? 3 : 4)) void k_ba_lin_fuse
     __syncthreads();   // the reduction below reuses the stage of all waves
   }
   if (live) {
-    if (GATHER == 0) {
-      st = B.r_state[i];
-      e = linearize_one<MATERIALIZE, 2, TILED>(B, i, pair % B.nf, pair / B.nf, jl, ns, rs5, B.jfix == 1);
-    }
-    const int pt = B.r_point[i];
-    float* rec = B.r_rec + ((size_t)pt * B.nf + pair / B.nf) * 16;
-    // the 64-byte record of this (point, target): written once, whole, at the end (four 16-byte stores of one line)
+    float* rec = B.r_rec + (size_t)B.r_orig[i] * 16;
+    // the 64-byte record of this residual (BaDev::r_rec): written once, whole, at the end (four 16-byte stores of one half line)
     float o8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, rbd = 0.f, rhdd = 0.f, rhcd[4] = {0.f, 0.f, 0.f, 0.f};
     uint8_t act = 0;
     if (st != 1) {  // applyRes(true): OOB is sticky
@@ -922,283 +880,17 @@ __global__ __launch_bounds__(BA_BLOCK, (MATERIALIZE ? 3 : 4)) void k_ba_lin_fuse
 #pragma unroll
       for (int k = 0; k < 4; k++) rhcd[k] = x[k] * q0 + y[k] * q1;
     }
-    if (st != 1) {   // (a sticky-OOB residual keeps the record its last applyRes wrote: flags 0)
+    if (st != 1) {   // (a sticky-OOB residual keeps the records its last applyRes wrote: flags 0)
       *(float4*)(rec) = make_float4(o8[0], o8[1], o8[2], o8[3]);
       *(float4*)(rec + 4) = make_float4(o8[4], o8[5], o8[6], o8[7]);
       *(float4*)(rec + 8) = make_float4(rbd, rhdd, rhcd[0], rhcd[1]);
-      *(float4*)(rec + 12) = make_float4(rhcd[2], rhcd[3], (float)act, (float)(pair / B.nf));
+      *(float4*)(rec + 12) = make_float4(rhcd[2], rhcd[3], (float)act, 0.f);
     }
   }
   e = block_sum_d(e, lds);
   if (threadIdx.x == 0) B.e_part[blockIdx.x] = e;
   __syncthreads();
   top_emit(B, x, y, a, b, c, TR00, TR10, TR01, TR11, TR02, TR12, br, on, red);
-}
-
-// ------------------------------------------------------------------ fused linearize + applyRes + accumulateAF, taps by LDS-DMA
-// A/B variant of the fused kernel (SDSO_BA_GATHER=2, 4x2-tiled level-0 images; measured equal to the cooperative gather of
-// k_ba_lin_fused<.,.,1>, which stays the default).  Same work per workgroup as k_ba_lin_fused — one chunk of <= 256
-// residuals of ONE (host,target) pair — organised around what the profile of its predecessor showed: a workgroup lived ~60 us for
-// ~3.5 k instructions per wave, i.e. it sat in a chain of a dozen DEPENDENT memory round trips at three waves per SIMD.
-//   * prologue: every per-residual input is fetched by two batches of independent, unconditional loads (indices / states, then the
-//     point), lanes past the end of the chunk read the chunk's first residual; the OOB / sticky-state decisions become flags;
-//   * taps: LDS-DMA rounds (see dm_issue_round above), DM_DEPTH pixel rounds in flight per wave, interpolation and the per-pixel
-//     arithmetic on the residual's own lane while the next rounds travel; `s_waitcnt vmcnt(N)` with N = exactly the younger
-//     vector-memory operations (later rounds + the record stores issued since), given through the builtin so that the compiler's
-//     own scoreboard knows when the last DMA has landed and does not drain the record stores before the reduction;
-//   * the record stores are `global_store ... nt` straight from the registers of the pixel just finished (one live quad);
-//   * workgroup barriers wait for LDS traffic only (wg_barrier<true>): the Jacobian records keep streaming out underneath the
-//     energy sum and the MFMA reduction of the 91 top sums.
-// Per-residual arithmetic is expression for expression that of linearize_one: every output stays bit-identical.
-template <int VM>
-__device__ __forceinline__ void dm_wait_builtin() {
-  static_assert(VM >= 0 && VM < 64, "vmcnt is a 6-bit field");
-  __builtin_amdgcn_s_waitcnt(0x0F70 | (VM & 15) | ((VM >> 4) << 14));   // vmcnt(VM), expcnt / lgkmcnt untouched
-}
-template <bool MATERIALIZE>
-__global__ __launch_bounds__(BA_BLOCK, 3) void k_ba_lin_dma(const BaDev* __restrict__ wins) {
-  // explicit address spaces: global_* instead of flat_* (flat operations complete out of order, so every use of a flat load
-  // would force `s_waitcnt vmcnt(0)` and drain the record stores), s_load for the wave-uniform tables
-#define GP(T, p) ((__attribute__((address_space(1))) T*)(p))
-#define CP(T, p) ((const __attribute__((address_space(4))) T*)(p))
-  const BaDev B = wins[blockIdx.y];
-  if (ba_finished_lin(B)) return;
-  if ((int)blockIdx.x >= B.nchunks) return;
-  typedef int te_i4 __attribute__((ext_vector_type(4)));
-  const te_i4 ch = CP(te_i4, B.chunks)[blockIdx.x];          // {pair, start, count, -}
-  const int pair = __builtin_amdgcn_readfirstlane(ch.x);
-  const int nf = B.nf, h = pair % nf, t = pair / nf;
-  constexpr int STAGE_FLOATS = (BA_BLOCK / 64) * DM_WAVE_FLOATS;
-  constexpr int RED_FLOATS = TE_LDS_FLOATS > STAGE_FLOATS ? TE_LDS_FLOATS : STAGE_FLOATS;
-  __shared__ float red[RED_FLOATS];     // the DMA rings of the four waves, then the MFMA panels of the reduction
-  double* const lds = (double*)red;
-  float* const ring = red + (threadIdx.x >> 6) * DM_WAVE_FLOATS;
-  const bool inb = (int)threadIdx.x < ch.z;
-  const int i = ch.y + (inb ? (int)threadIdx.x : 0);
-  // ---- batch 1: indices and states (independent loads)
-  const uint8_t lin = GP(const uint8_t, B.r_lin)[i], st = GP(const uint8_t, B.r_state)[i], jsel = GP(const uint8_t, B.r_jsel)[i];
-  const int pt = GP(const int, B.r_point)[i];
-  const float e_old = GP(const float, B.r_energy)[i], ne_old = GP(const float, B.r_newEnergy)[i];
-  const __attribute__((address_space(4))) float* pre = CP(float, B.t_precalc) + (size_t)(h * nf + t) * 27;   // wave-uniform: SGPRs
-  const float affLL0 = pre[24], affLL1 = pre[25], b0 = pre[26];
-  const float4* __restrict__ dIl = (const float4*)CP(unsigned long long, B.t_img)[t];
-  const float th = fmaxf(GP(const float, B.t_frameTH)[h], GP(const float, B.t_frameTH)[t]);
-  // ---- batch 2: the point
-  const te_f4 g = GP(const te_f4, B.p_geo)[pt];
-  const te_f4 c0 = GP(const te_f4, B.p_color)[2 * (size_t)pt], c1 = GP(const te_f4, B.p_color)[2 * (size_t)pt + 1];
-  const te_f4 w0 = GP(const te_f4, B.p_weights)[2 * (size_t)pt], w1 = GP(const te_f4, B.p_weights)[2 * (size_t)pt + 1];
-  const bool live = inb && !lin;                     // linearizeAll skips linearized residuals (FullSystemOptimize.cpp:52-87)
-  const float color[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-  const float weights[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
-  const float pu = g.x, pv = g.y, idepth_scaled = g.z, idepth_zero_scaled = g.w;
-  const float fxl = B.fxl, fyl = B.fyl, cxl = B.cxl, cyl = B.cyl, fxli = B.fxli, fyli = B.fyli;
-  const auto KRKi = pre; const auto Kt = pre + 9; const auto R0 = pre + 12; const auto t0 = pre + 21;
-  // projectPoint (ResidualProjections.h:64-96) at the FEJ point
-  float KliP[3];
-  KliP[0] = (pu + 0 - cxl) * fxli;
-  KliP[1] = (pv + 0 - cyl) * fyli;
-  KliP[2] = 1;
-  float ptp[3];
-#pragma unroll
-  for (int r = 0; r < 3; r++) ptp[r] = ((R0[r * 3 + 0] * KliP[0] + R0[r * 3 + 1] * KliP[1]) + R0[r * 3 + 2] * KliP[2]) + t0[r] * idepth_zero_scaled;
-  const float drescale = 1.0f / ptp[2];
-  const float new_idepth = idepth_zero_scaled * drescale;
-  const float u = ptp[0] * drescale;
-  const float v = ptp[1] * drescale;
-  const float Ku0 = u * fxl + cxl;
-  const float Kv0 = v * fyl + cyl;
-  // a residual is sampled when it is live, not sticky-OOB (Residuals.cpp:88-91), its centre projects into the image (:96-100) and
-  // so do all 8 pattern pixels (:215-225)
-  bool comp = live && st != 1 && (drescale > 0) && (Ku0 > 1.1f && Kv0 > 1.1f && Ku0 < B.wM3 && Kv0 < B.hM3);
-  float Kus[8], Kvs[8];
-#pragma unroll
-  for (int idx = 0; idx < 8; idx++) {
-    const float up = pu + c_pattern[idx][0], vp = pv + c_pattern[idx][1];
-    float q[3];
-#pragma unroll
-    for (int r = 0; r < 3; r++) q[r] = ((KRKi[r * 3 + 0] * up + KRKi[r * 3 + 1] * vp) + KRKi[r * 3 + 2]) + Kt[r] * idepth_scaled;
-    Kus[idx] = q[0] / q[2];
-    Kvs[idx] = q[1] / q[2];
-    if (!(Kus[idx] > 1.1f && Kvs[idx] > 1.1f && Kus[idx] < B.wM3 && Kvs[idx] < B.hM3)) comp = false;
-  }
-  __attribute__((address_space(1))) float* const J = MATERIALIZE ? (__attribute__((address_space(1))) float*)((jsel != 0) != (B.jfix != 0) ? B.J[0] : B.J[1]) : nullptr;   // (jfix: in place, see ba_kernels.h)
-  const int S = B.nrp;
-#define JSTORE(grp, a, b, c, d)                                                                                                      \
-  do {                                                                                                                               \
-    if (MATERIALIZE) __builtin_nontemporal_store((te_f4){a, b, c, d}, (__attribute__((address_space(1))) te_f4*)(J + j_off(S, i, (grp)))); \
-  } while (0)
-  float JIdxJIdx_00 = 0, JIdxJIdx_11 = 0, JIdxJIdx_10 = 0;
-  float JabJIdx_00 = 0, JabJIdx_01 = 0, JabJIdx_10 = 0, JabJIdx_11 = 0;
-  float JabJab_00 = 0, JabJab_01 = 0, JabJab_11 = 0;
-  float wJI2_sum = 0, energyLeft = 0;
-  float JI_r0 = 0, JI_r1 = 0, Jab_r0 = 0, Jab_r1 = 0, rr = 0;      // addPoint<0>'s per-pixel sums with resApprox = resF (AccumulatedTopHessian.cpp:119-128)
-  float jab1[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  bool nonfinite = false;
-  if (__ballot(comp) != 0ull) {      // (wave-uniform)
-    int xy[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) xy[k] = comp ? ((int)Kus[k] | ((int)Kvs[k] << 16)) : 0;
-    const int Tw = B.tiledT;
-    const float* my = ring + 16 * (threadIdx.x & 63);
-#pragma unroll
-    for (int p = 0; p < DM_DEPTH; p++) dm_issue_round(dIl, Tw, xy[p], ring + p * DM_ROUND_FLOATS);
-#pragma unroll
-    for (int idx = 0; idx < 8; idx++) {
-      // vector-memory operations younger than round idx: the rounds issued after it, and (when the records are materialised) the
-      // record stores issued since it was issued — exec is non-zero here (some lane samples), so each of those was one instruction
-      constexpr int D1 = DM_DEPTH - 1;
-      const int later = (7 - idx < D1 ? 7 - idx : D1);
-      const int stores = MATERIALIZE ? (idx < DM_DEPTH ? idx : DM_DEPTH) : 0;
-      switch (4 * later + stores) {
-#define DMW(N) case N: dm_wait_builtin<N>(); break;
-        DMW(0) DMW(1) DMW(2) DMW(3) DMW(4) DMW(5) DMW(6) DMW(7) DMW(8) DMW(9) DMW(10) DMW(11) DMW(12) DMW(13) DMW(14) DMW(15)
-#undef DMW
-        default: dm_wait_builtin<0>(); break;
-      }
-      te_f4 p00, p10, p01, p11;
-      dm_read_taps(my + (idx % DM_DEPTH) * DM_ROUND_FLOATS, p00, p10, p01, p11);
-      if (idx + DM_DEPTH < 8) dm_issue_round(dIl, Tw, xy[idx + DM_DEPTH], ring + (idx % DM_DEPTH) * DM_ROUND_FLOATS);   // the slot has just been read
-      // getInterpolatedElement33 (same expression and order as interp33)
-      const float x = Kus[idx], y = Kvs[idx];
-      const int ix = (int)x;
-      const int iy = (int)y;
-      const float dx = x - ix;
-      const float dy = y - iy;
-      const float dxdy = dx * dy;
-      const float w11 = dxdy, w01 = dy - dxdy, w10 = dx - dxdy, w00 = 1 - dx - dy + dxdy;
-      float3 hit;
-      hit.x = w11 * p11.x + w01 * p01.x + w10 * p10.x + w00 * p00.x;
-      hit.y = w11 * p11.y + w01 * p01.y + w10 * p10.y + w00 * p00.y;
-      hit.z = w11 * p11.z + w01 * p01.z + w10 * p10.z + w00 * p00.z;
-      if (!isfinite(hit.x)) nonfinite = true;
-      const float residual = hit.x - (affLL0 * color[idx] + affLL1);
-      const float drdA = (color[idx] - b0);
-      float wgt = sqrtf(kOutlierTHSumComponent / (kOutlierTHSumComponent + (hit.y * hit.y + hit.z * hit.z)));
-      wgt = 0.5f * (wgt + weights[idx]);
-      float hw = fabsf(residual) < kHuberTH ? 1 : kHuberTH / fabsf(residual);
-      energyLeft += wgt * wgt * hw * residual * residual * (2 - hw);
-      if (hw < 1) hw = sqrtf(hw);
-      hw = hw * wgt;
-      hit.y *= hw;
-      hit.z *= hw;
-      const float ra = residual * hw, ja0 = B.affA_fixed ? 0.f : drdA * hw;
-      jab1[idx] = B.affB_fixed ? 0.f : hw;
-      if (comp) JSTORE(6 + idx, ra, hit.y, hit.z, ja0);        // resF, JIdx[0], JIdx[1], JabF[0]
-      JI_r0 += ra * hit.y; JI_r1 += ra * hit.z;
-      Jab_r0 += ra * ja0; Jab_r1 += ra * jab1[idx];
-      rr += ra * ra;
-      JIdxJIdx_00 += hit.y * hit.y;
-      JIdxJIdx_11 += hit.z * hit.z;
-      JIdxJIdx_10 += hit.y * hit.z;
-      JabJIdx_00 += drdA * hw * hit.y;
-      JabJIdx_01 += drdA * hw * hit.z;
-      JabJIdx_10 += hw * hit.y;
-      JabJIdx_11 += hw * hit.z;
-      JabJab_00 += drdA * drdA * hw * hw;
-      JabJab_01 += drdA * hw * hw;
-      JabJab_11 += hw * hw;
-      wJI2_sum += hw * hw * (hit.y * hit.y + hit.z * hit.z);
-    }
-  }
-  const bool done = comp && !nonfinite;             // linearize ran to its end (Residuals.cpp:302-336)
-  // ---- geometric Jacobians at the FEJ point (Residuals.cpp:135-185) and the rest of the record
-  float xv[10], yv[10], jdd0 = 0.f, jdd1 = 0.f;
-#pragma unroll
-  for (int k = 0; k < 10; k++) { xv[k] = 0.f; yv[k] = 0.f; }
-  int ns = 1;
-  if (done) {
-    float d_C_x[4], d_C_y[4];
-    const float d_d_x = drescale * (t0[0] - t0[2] * u) * SCALE_IDEPTH * fxl;
-    const float d_d_y = drescale * (t0[1] - t0[2] * v) * SCALE_IDEPTH * fyl;
-    d_C_x[2] = drescale * (R0[6] * u - R0[0]);
-    d_C_x[3] = fxl * drescale * (R0[7] * u - R0[1]) * fyli;
-    d_C_x[0] = KliP[0] * d_C_x[2];
-    d_C_x[1] = KliP[1] * d_C_x[3];
-    d_C_y[2] = fyl * drescale * (R0[6] * v - R0[3]) * fxli;
-    d_C_y[3] = drescale * (R0[7] * v - R0[4]);
-    d_C_y[0] = KliP[0] * d_C_y[2];
-    d_C_y[1] = KliP[1] * d_C_y[3];
-    d_C_x[0] = (d_C_x[0] + u) * SCALE_F;
-    d_C_x[1] *= SCALE_F;
-    d_C_x[2] = (d_C_x[2] + 1) * SCALE_C;
-    d_C_x[3] *= SCALE_C;
-    d_C_y[0] *= SCALE_F;
-    d_C_y[1] = (d_C_y[1] + v) * SCALE_F;
-    d_C_y[2] *= SCALE_C;
-    d_C_y[3] = (d_C_y[3] + 1) * SCALE_C;
-#pragma unroll
-    for (int k = 0; k < 4; k++) { xv[k] = d_C_x[k]; yv[k] = d_C_y[k]; }
-    xv[4] = new_idepth * fxl; xv[5] = 0; xv[6] = -new_idepth * u * fxl; xv[7] = -u * v * fxl; xv[8] = (1 + u * u) * fxl; xv[9] = -v * fxl;
-    yv[4] = 0; yv[5] = new_idepth * fyl; yv[6] = -new_idepth * v * fyl; yv[7] = -(1 + v * v) * fyl; yv[8] = u * v * fyl; yv[9] = u * fyl;
-    jdd0 = d_d_x; jdd1 = d_d_y;
-    JSTORE(0, xv[4], xv[5], xv[6], xv[7]);                    // Jpdxi[0][0..3]
-    JSTORE(1, xv[8], xv[9], yv[4], yv[5]);                    // Jpdxi[0][4..5], Jpdxi[1][0..1]
-    JSTORE(2, yv[6], yv[7], yv[8], yv[9]);                    // Jpdxi[1][2..5]
-    JSTORE(3, xv[0], xv[1], xv[2], xv[3]);
-    JSTORE(4, yv[0], yv[1], yv[2], yv[3]);
-    JSTORE(5, jdd0, jdd1, 0.f, 0.f);
-    JSTORE(14, jab1[0], jab1[1], jab1[2], jab1[3]);
-    JSTORE(15, jab1[4], jab1[5], jab1[6], jab1[7]);
-    JSTORE(16, JIdxJIdx_00, JIdxJIdx_10, JIdxJIdx_10, JIdxJIdx_11);
-    JSTORE(17, JabJIdx_00, JabJIdx_01, JabJIdx_10, JabJIdx_11);
-    JSTORE(18, JabJab_00, JabJab_01, JabJab_01, JabJab_11);
-    ns = (energyLeft > th || wJI2_sum < 2) ? 2 : 0;           // OUTLIER / IN (Residuals.cpp:325-332)
-  }
-#undef JSTORE
-  const float e_new = ns == 2 ? th : energyLeft;              // state_NewEnergy when linearize ran through
-  double e = 0;
-  bool on = false;
-  float a = 0, b = 0, c = 0, TR00 = 0, TR10 = 0, TR01 = 0, TR11 = 0, TR02 = 0, TR12 = 0;
-  float br[6] = {0, 0, 0, 0, 0, 0};
-  if (live) {
-    GP(float, B.r_newEnergyWO)[i] = done ? energyLeft : -1.f;
-    GP(uint8_t, B.r_newState)[i] = (uint8_t)ns;
-    if (done) GP(float, B.r_newEnergy)[i] = e_new;
-    e = done ? (double)e_new : (double)e_old;
-    if (st != 1) {                                            // applyRes(true): OOB is sticky (Residuals.cpp:367-385)
-      __attribute__((address_space(1))) te_f4* rec = GP(te_f4, B.r_rec) + ((size_t)pt * nf + t) * 4;
-      float o8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, rbd = 0.f, rhdd = 0.f, rhcd[4] = {0.f, 0.f, 0.f, 0.f};
-      const uint8_t act = ns == 0;
-      if (act) {                                              // takeDataF (EnergyFunctionalStructs.cpp:37-51), then addPoint<0>
-        if (MATERIALIZE && !B.jfix) GP(uint8_t, B.r_jsel)[i] = jsel ^ 1;
-        const float v0 = JIdxJIdx_00 * jdd0 + JIdxJIdx_10 * jdd1;
-        const float v1 = JIdxJIdx_10 * jdd0 + JIdxJIdx_11 * jdd1;
-#pragma unroll
-        for (int k = 0; k < 6; k++) o8[k] = xv[4 + k] * v0 + yv[4 + k] * v1;
-        o8[6] = JabJIdx_00 * jdd0 + JabJIdx_01 * jdd1;
-        o8[7] = JabJIdx_10 * jdd0 + JabJIdx_11 * jdd1;
-        on = true;
-        a = JIdxJIdx_00; b = JIdxJIdx_10; c = JIdxJIdx_11;
-        TR00 = JabJIdx_00; TR10 = JabJIdx_01; TR01 = JabJIdx_10; TR11 = JabJIdx_11;
-        TR02 = JI_r0; TR12 = JI_r1;
-        br[0] = JabJab_00; br[1] = JabJab_01; br[2] = Jab_r0; br[3] = JabJab_11; br[4] = Jab_r1; br[5] = rr;
-        const float q0 = a * jdd0 + b * jdd1;
-        const float q1 = JIdxJIdx_10 * jdd0 + c * jdd1;
-        rbd = JI_r0 * jdd0 + JI_r1 * jdd1;
-        rhdd = q0 * jdd0 + q1 * jdd1;
-#pragma unroll
-        for (int k = 0; k < 4; k++) rhcd[k] = xv[k] * q0 + yv[k] * q1;
-      }
-      GP(uint8_t, B.r_act)[i] = act;
-      GP(uint8_t, B.r_state)[i] = (uint8_t)ns;
-      GP(float, B.r_energy)[i] = done ? e_new : ne_old;        // state_energy = state_NewEnergy
-      rec[0] = (te_f4){o8[0], o8[1], o8[2], o8[3]};
-      rec[1] = (te_f4){o8[4], o8[5], o8[6], o8[7]};
-      rec[2] = (te_f4){rbd, rhdd, rhcd[0], rhcd[1]};
-      rec[3] = (te_f4){rhcd[2], rhcd[3], (float)act, (float)t};
-    }
-  }
-  if (!on) {
-#pragma unroll
-    for (int k = 0; k < 10; k++) { xv[k] = 0.f; yv[k] = 0.f; }
-  }
-  wg_barrier<true>();     // every wave is done with its ring: the reductions reuse the space
-  e = block_sum_d<true>(e, lds);
-  if (threadIdx.x == 0) GP(double, B.e_part)[blockIdx.x] = e;
-  wg_barrier<true>();
-#undef GP
-#undef CP
-  top_emit<true>(B, xv, yv, a, b, c, TR00, TR10, TR01, TR11, TR02, TR12, br, on, red);
 }
 
 // ------------------------------------------------------------------ linearised energy (EnergyFunctional::calcLEnergyPt, EnergyFunctional.cpp:354-417)
@@ -1274,370 +966,55 @@ __device__ __forceinline__ void zero_topL_body(const BaDev& B, int pair, int tid
 __global__ __launch_bounds__(128) void k_ba_fold_top(const BaDev* __restrict__ wins, int which) { if (ba_finished(wins[blockIdx.y])) return; fold_top_body(wins[blockIdx.y], blockIdx.x, which, threadIdx.x); }
 __global__ __launch_bounds__(128) void k_ba_zero_topL(const BaDev* __restrict__ wins) { if (ba_finished(wins[blockIdx.y])) return; zero_topL_body(wins[blockIdx.y], blockIdx.x, threadIdx.x); }
 
-// ------------------------------------------------------------------ per-point terms of the Schur accumulation
-// The first half of AccumulatedSCHessianSSE::addPoint (AccumulatedSCHessian.cpp:34-71) for ONE point on ONE lane, together with the
-// per-point sums addPoint<mode> of the top accumulator leaves in the EFPoint (AccumulatedTopHessian.cpp:160-192): the residuals are
-// visited in EFPoint::residualsAll order (`ord`: BaDev::p_order), exactly the additions of the reference, so Hdd / bd / Hcd, HdiF and
-// bdSumF are bit-identical to the CPU path whatever dropResidual did to that order.  recs: the point's dense [target] records (LDS or
-// global).  Also keeps PointHessian::idepth_hessian and the `maxRelBaseline = 0` of :44-48 (p_track).
-struct ScPointTerms {
-  float Hdd_A, bd_A, Hdd_L, bd_L, HcdA[4], HcdL[4];   // p->{Hdd,bd,Hcd}_acc{A,L}F
-  float HdiF, bdSumF, Hcd[4];                          // what the cross-point sums use (zeros when the point has no active residual)
-  int mbits;                                           // bit t: the residual to target t is present and active
-};
-// PLAIN: no marginalisation pass, no point filter, no linearized residual in the launch (every GN iteration of the reference's live flow): all
-// active residuals go to the A sums, and — the record of a residual that is not active holds zeros (k_ba_apply, the fused kernels) — the
-// records are added as they are: x + 0 is exact, so the sums are the reference's to the bit without a select per term (the kernel is bound
-// by instruction issue: this loop on 16 of 64 lanes was half of its vector instructions).
-template <bool PLAIN = false>
-__device__ __forceinline__ void sc_point_terms(const BaDev& B, int p, const float* recs, unsigned ord, float onf, float prior, float delta,
-                                               int shiftPriorToZero, int margMode, ScPointTerms& o) {
-  float Hdd_A = 0, bd_A = 0, Hdd_L = 0, bd_L = 0, HcdA[4] = {0, 0, 0, 0}, HcdL[4] = {0, 0, 0, 0};
-  int ngood = 0, mbits = 0;
-#pragma unroll
-  for (int k = 0; k < 8; k++) {
-    const unsigned t = (ord >> (4 * k)) & 15u;
-    if (t == 15u) break;
-    const float4 q0 = *(const float4*)(recs + t * 16 + 8);    // bd, Hdd, Hcd0, Hcd1
-    const float4 q1 = *(const float4*)(recs + t * 16 + 12);   // Hcd2, Hcd3, flags, target
-    const int fl = (int)q1.z;
-    if (PLAIN) {
-      const int act = fl & 1;
-      ngood += act; mbits |= act << t;
-      bd_A += q0.x; Hdd_A += q0.y;
-      HcdA[0] += q0.z; HcdA[1] += q0.w; HcdA[2] += q1.x; HcdA[3] += q1.y;
-      continue;
-    }
-    const bool m = (fl & 1) != 0 && onf != 0.f;                // residual active (and the point taking part)
-    const bool mA = m && !(fl & 2) && !margMode, mL = m && !mA;   // mode 0 vs mode 1 / 2 sums (AccumulatedTopHessian.cpp:54-71)
-    const float rh[4] = {q0.z, q0.w, q1.x, q1.y};
-    if (m) { ngood++; mbits |= 1 << t; }
-    // x + 0 is exact: masked-off residuals leave the sums untouched
-    bd_A += mA ? q0.x : 0.f; Hdd_A += mA ? q0.y : 0.f;
-    bd_L += mL ? q0.x : 0.f; Hdd_L += mL ? q0.y : 0.f;
-#pragma unroll
-    for (int c = 0; c < 4; c++) { HcdA[c] += mA ? rh[c] : 0.f; HcdL[c] += mL ? rh[c] : 0.f; }
-  }
-  float H = Hdd_A + Hdd_L + prior;
-  if (H < 1e-10) H = 1e-10;
-  const float hdi = 1.0 / H;
-  float bds = bd_A + bd_L;
-  if (shiftPriorToZero) bds += prior * delta;
-  const bool any = ngood > 0;
-  o.Hdd_A = Hdd_A; o.bd_A = bd_A; o.Hdd_L = Hdd_L; o.bd_L = bd_L;
-  o.HdiF = any ? hdi : 0.f; o.bdSumF = any ? bds : 0.f;
-#pragma unroll
-  for (int c = 0; c < 4; c++) { o.HcdA[c] = HcdA[c]; o.HcdL[c] = HcdL[c]; o.Hcd[c] = any ? HcdA[c] + HcdL[c] : 0.f; }
-  o.mbits = mbits;
-  if (onf != 0.f) {
-    float* po = B.p_out + (size_t)p * 16;
-    *(float4*)(po + 0) = make_float4(Hdd_A, bd_A, HcdA[0], HcdA[1]);
-    *(float4*)(po + 4) = make_float4(HcdA[2], HcdA[3], Hdd_L, bd_L);
-    *(float4*)(po + 8) = make_float4(HcdL[0], HcdL[1], HcdL[2], HcdL[3]);
-    *(float2*)(po + PO_HDI) = make_float2(o.HdiF, o.bdSumF);
-    float* tr = (float*)(B.p_track + p);
-    *(float2*)(tr + 2) = make_float2(any ? H : 0.f, __int_as_float(mbits));   // p->data->idepth_hessian (:46, :56); the active targets for k_ba_resub*
-    if (!any) tr[0] = 0.f;                                                     // p->data->maxRelBaseline = 0 (:47)
-  }
-}
-
-// ------------------------------------------------------------------ per-point Schur accumulation
-// AccumulatedSCHessianSSE::addPoint for nf <= 8 (template NF).  One wave per item (<= 64 consecutive
-// points of ONE host); lane (a,c) = (lane>>3, lane&7) keeps element (a,c) of all NF x NF 8x8 D tiles of
-// that host in VGPRs, lanes 0..31 / 0..7 the E / EB rows.
-// The per-residual records of a point form a dense [target] table (r_rec[p][t], 64 B each, flags 0 when
-// the point has no residual to t), so "slot == target": tile indices are compile-time constants, nothing
-// is scattered, there is no branch in the loop, and one point costs two coalesced 256-B loads (issued one
-// point ahead) + cross-lane moves.  Absent residuals contribute exact zeros.
-// Per-point sums (Hdd/bd/Hcd) run in EFPoint::residualsAll order (BaDev::p_order).
-template <int NF>
-__global__ __launch_bounds__(BA_BLOCK) void k_ba_sc_reg(const BaDev* __restrict__ wins, const uint8_t* __restrict__ pflag, int shiftPriorToZero, int margMode) {
-  const BaDev& B = wins[blockIdx.y];
-  if (ba_finished(B)) return;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int item = blockIdx.x * (BA_BLOCK / 64) + wv;
-  if (item >= B.nitems) return;
-  const int4 it = B.items[item];
-  const int la = lane >> 3, lc = lane & 7, le = (lane >> 2) & 7;
-  float D[NF][NF], E[NF], EB[NF];
-#pragma unroll
-  for (int i = 0; i < NF; i++) {
-    E[i] = 0.f; EB[i] = 0.f;
-#pragma unroll
-    for (int j = 0; j < NF; j++) D[i][j] = 0.f;
-  }
-  float hcc = 0.f, bcv = 0.f;
-  const int npts = it.z - it.y;
-  float my_prior = 0.f, my_delta = 0.f; int my_on = 0;
-  unsigned my_ord = 0xffffffffu;
-  if (lane < npts) {
-    const int p = it.y + lane;
-    my_prior = B.p_prior[p]; my_delta = B.p_delta[p]; my_ord = B.p_order[p];
-    my_on = pflag ? (int)pflag[p] : 1;
-  }
-  auto fetch = [&](int q, float& a, float& b) {
-    const float* base = B.r_rec + (size_t)(it.y + q) * NF * 16;
-    a = lane < NF * 16 ? base[lane] : 0.f;
-    b = lane + 64 < NF * 16 ? base[lane + 64] : 0.f;
-  };
-  float vA = 0.f, vB = 0.f, nA = 0.f, nB = 0.f;
-  // per-point outputs are parked in the registers of lane q and stored once after the loop
-  float o_hddA = 0, o_bdA = 0, o_hddL = 0, o_bdL = 0, o_hdi = 0, o_bds = 0;
-  float o_hcA0 = 0, o_hcA1 = 0, o_hcA2 = 0, o_hcA3 = 0, o_hcL0 = 0, o_hcL1 = 0, o_hcL2 = 0, o_hcL3 = 0;
-  float o_idh = 0; int o_ng = 0;
-  if (npts > 0) fetch(0, vA, vB);
-  for (int q = 0; q < npts; q++) {
-    if (q + 1 < npts) fetch(q + 1, nA, nB);   // in flight while point q is processed
-    const float prior = __shfl(my_prior, q, 64), delta = __shfl(my_delta, q, 64);
-    const float onf = __shfl(my_on, q, 64) ? 1.f : 0.f;
-    float ja[NF], jc[NF], je[NF];
-    float Hdd_A = 0, bd_A = 0, Hdd_L = 0, bd_L = 0, HcdA[4] = {0, 0, 0, 0}, HcdL[4] = {0, 0, 0, 0};
-    float ngood = 0;
-    // the per-point sums in EFPoint::residualsAll order (BaDev::p_order; the order word of point q is wave-uniform)
-    const unsigned ord = (unsigned)__builtin_amdgcn_readfirstlane(__shfl((int)my_ord, q, 64));
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-      const int t = (int)((ord >> (4 * k)) & 15u);
-      if (t == 15) break;
-      const int isrc = __float_as_int(t < 4 ? vA : vB);
-      const int o = (t & 3) * 16;
-      const int fl = (int)__int_as_float(__builtin_amdgcn_readlane(isrc, o + RR_FLAGS));
-      const float m = ((fl & 1) ? 1.f : 0.f) * onf;                          // residual present and active
-      const float mA = (!(fl & 2) && !margMode) ? m : 0.f, mL = m - mA;      // mode 0 vs mode 1/2 sums (AccumulatedTopHessian.cpp:54-71)
-      const float rbd = __int_as_float(__builtin_amdgcn_readlane(isrc, o + RR_BD));
-      const float rhdd = __int_as_float(__builtin_amdgcn_readlane(isrc, o + RR_HDD));
-      float rh[4];
-#pragma unroll
-      for (int c = 0; c < 4; c++) rh[c] = __int_as_float(__builtin_amdgcn_readlane(isrc, o + RR_HCD + c));
-      ngood += m;
-      // masked adds: x + 0 is exact, so inactive slots leave the sums untouched
-      bd_A += mA != 0.f ? rbd : 0.f; Hdd_A += mA != 0.f ? rhdd : 0.f;
-      bd_L += mL != 0.f ? rbd : 0.f; Hdd_L += mL != 0.f ? rhdd : 0.f;
-#pragma unroll
-      for (int c = 0; c < 4; c++) { HcdA[c] += mA != 0.f ? rh[c] : 0.f; HcdL[c] += mL != 0.f ? rh[c] : 0.f; }
-    }
-    // the JpJdF rows by target (tile indices are compile-time constants; absent / inactive residuals enter as zeros)
-#pragma unroll
-    for (int t = 0; t < NF; t++) {
-      const float src = t < 4 ? vA : vB;
-      const int o = (t & 3) * 16;
-      const int fl = (int)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(src), o + RR_FLAGS));
-      const float m = ((fl & 1) ? 1.f : 0.f) * onf;
-      const float sa = __shfl(src, o + la, 64), sc = __shfl(src, o + lc, 64), se = __shfl(src, o + le, 64);
-      ja[t] = m != 0.f ? sa : 0.f; jc[t] = m != 0.f ? sc : 0.f; je[t] = m != 0.f ? se : 0.f;
-    }
-    float HdiF = 0, bdSumF = 0;
-    float Hcd[4] = {0, 0, 0, 0};
-    float o_H = 0.f;
-    {
-      float H = Hdd_A + Hdd_L + prior;
-      if (H < 1e-10) H = 1e-10;
-      o_H = H;
-      const float hdi = 1.0 / H;
-      float bds = bd_A + bd_L;
-      if (shiftPriorToZero) bds += prior * delta;
-      const bool any = ngood > 0.f;
-      HdiF = any ? hdi : 0.f; bdSumF = any ? bds : 0.f;
-#pragma unroll
-      for (int k = 0; k < 4; k++) Hcd[k] = any ? HcdA[k] + HcdL[k] : 0.f;
-    }
-    if (lane == q) {
-      o_idh = ngood > 0.f ? o_H : 0.f; o_ng = (int)ngood;
-      o_hddA = Hdd_A; o_bdA = bd_A; o_hddL = Hdd_L; o_bdL = bd_L; o_hdi = HdiF; o_bds = bdSumF;
-      o_hcA0 = HcdA[0]; o_hcA1 = HcdA[1]; o_hcA2 = HcdA[2]; o_hcA3 = HcdA[3];
-      o_hcL0 = HcdL[0]; o_hcL1 = HcdL[1]; o_hcL2 = HcdL[2]; o_hcL3 = HcdL[3];
-    }
-    // ngood == 0 => HdiF = 0 and every ja/jc/je is 0: all updates below add exact zeros
-    hcc += (HdiF * Hcd[(lane >> 2) & 3]) * Hcd[lane & 3];
-    bcv += (bdSumF * HdiF) * Hcd[lane & 3];
-    const float hb = HdiF * bdSumF;
-    const float hc = Hcd[lane & 3];
-#pragma unroll
-    for (int t1 = 0; t1 < NF; t1++) {
-      const float wl = HdiF * ja[t1];
-#pragma unroll
-      for (int t2 = 0; t2 < NF; t2++) D[t1][t2] = D[t1][t2] + wl * jc[t2];
-      E[t1] = E[t1] + (HdiF * je[t1]) * hc;
-      EB[t1] = EB[t1] + hb * jc[t1];
-    }
-    vA = nA; vB = nB;
-  }
-  if (lane < npts && my_on) {
-    float* po = B.p_out + (size_t)(it.y + lane) * 16;
-    *(float4*)(po + 0) = make_float4(o_hddA, o_bdA, o_hcA0, o_hcA1);
-    *(float4*)(po + 4) = make_float4(o_hcA2, o_hcA3, o_hddL, o_bdL);
-    *(float4*)(po + 8) = make_float4(o_hcL0, o_hcL1, o_hcL2, o_hcL3);
-    po[PO_HDI] = o_hdi; po[PO_BDSUM] = o_bds;
-    float* tr = (float*)(B.p_track + it.y + lane);
-    *(float2*)(tr + 2) = make_float2(o_idh, __int_as_float(o_ng));   // p->data->idepth_hessian (AccumulatedSCHessian.cpp:46, :56)  (w: the count — this variant's launches use the records' flags in k_ba_resub*)
-    if (o_ng == 0) tr[0] = 0.f;                                       // p->data->maxRelBaseline = 0 (:47)
-  }
-  float* out = B.sc_part + (size_t)item * sc_part_floats(NF);
-#pragma unroll
-  for (int t1 = 0; t1 < NF; t1++) {
-#pragma unroll
-    for (int t2 = 0; t2 < NF; t2++) out[(t1 * NF + t2) * 64 + lane] = D[t1][t2];
-    if (lane < 32) out[NF * NF * 64 + t1 * 32 + lane] = E[t1];
-    if (lane < 8) out[NF * NF * 64 + NF * 32 + t1 * 8 + lane] = EB[t1];
-  }
-  const int per_wave = NF * NF * 64 + NF * 32 + NF * 8;
-  if (lane < 16) out[per_wave + lane] = hcc;
-  if (lane < 4) out[per_wave + 16 + lane] = bcv;
-}
-
-
-// ------------------------------------------------------------------ per-point Schur accumulation on the matrix cores
-// All Schur sums of a host are ONE symmetric product over its points,
-//     D' = Z^T diag(HdiF) Z,   Z[p] = [ JpJdF of target 0..7 (64) | Hcd (4) | bdSumF (1) ]  (69 columns, padded to 80):
-//     accD[t1][t2] = D'[8t1.., 8t2..],  accE[t1] = D'[8t1.., 64..67],  accEB[t1] = D'[8t1.., 68],  accHcc = D'[64..67, 64..67],
-//     accbc = D'[64..67, 68]                                                     (AccumulatedSCHessian.cpp:75-101).
-// One wave per item (<= 64 consecutive points of one host).  Phase 1, lane = point: the per-point terms
-// (Hdd/bd/Hcd sums in target-slot order, HdiF, bdSumF — unchanged arithmetic, bit-exact with the CPU path) go to
-// p_out and to a small LDS table.  Phase 2, 4 points per step: lane (i, k) = (lane%16, lane/16) loads column
-// 16*tt+i of point 4g+k for the 5 column tiles and 21 v_mfma_f32_16x16x4_f32 accumulate the 4x5 (+1) output tiles
-// in 84 VGPRs.  Absent / inactive residuals enter as exact zeros.  Only the order of the cross-point float sums
-// differs from the CPU path (and the product HdiF*J1*J2 is fused in the MFMA: one rounding less).
-__global__ __launch_bounds__(BA_BLOCK) void k_ba_sc_mfma(const BaDev* __restrict__ wins, const uint8_t* __restrict__ pflag, int shiftPriorToZero, int margMode) {
-  const BaDev& B = wins[blockIdx.y];
-  if (ba_finished(B)) return;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int item = blockIdx.x * (BA_BLOCK / 64) + wv;
-  __shared__ float pt_all[BA_BLOCK / 64][64][8];   // HdiF, bdSumF, Hcd[4], mask bits, -
-  if (item >= B.nitems) return;                    // (no block-level barrier below: waves are independent)
-  float (*pt)[8] = pt_all[wv];
-  const int4 it = B.items[item];
-  const int nf = B.nf, npts = it.z - it.y;
-  // ---- phase 1: per-point terms
-  {
-    float HdiF = 0.f, bdSumF = 0.f, Hcd[4] = {0.f, 0.f, 0.f, 0.f};
-    int mbits = 0;
-    if (lane < npts) {
-      const int p = it.y + lane;
-      ScPointTerms T;
-      sc_point_terms(B, p, B.r_rec + (size_t)p * nf * 16, B.p_order[p], (pflag ? (int)pflag[p] : 1) ? 1.f : 0.f, B.p_prior[p], B.p_delta[p], shiftPriorToZero, margMode, T);
-      HdiF = T.HdiF; bdSumF = T.bdSumF; mbits = T.mbits;
-#pragma unroll
-      for (int k = 0; k < 4; k++) Hcd[k] = T.Hcd[k];
-    }
-    *(float4*)(&pt[lane][0]) = make_float4(HdiF, bdSumF, Hcd[0], Hcd[1]);
-    *(float4*)(&pt[lane][4]) = make_float4(Hcd[2], Hcd[3], __int_as_float(mbits), 0.f);
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  // ---- phase 2: D' += Z^T diag(HdiF) Z, four points per step
-  te_f4 acc[4][5], acc44 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int a = 0; a < 4; a++)
-#pragma unroll
-    for (int b = 0; b < 5; b++) acc[a][b] = (te_f4){0.f, 0.f, 0.f, 0.f};
-  const int ci = lane & 15, kq = lane >> 4;
-  const int tsub = ci >> 3, asub = ci & 7;
-  for (int g = 0; g < npts; g += 4) {
-    const int q = g + kq;                      // q < 64 always: rows of points >= npts hold zeros (HdiF = 0, mask = 0)
-    const float4 h0 = *(const float4*)(&pt[q][0]);
-    const float4 h1 = *(const float4*)(&pt[q][4]);
-    const int mb = __float_as_int(h1.z);
-    const float* base = B.r_rec + (size_t)(it.y + (q < npts ? q : 0)) * nf * 16 + asub;
-    float z[5], za[5];
-#pragma unroll
-    for (int tt = 0; tt < 4; tt++) {
-      const int t = 2 * tt + tsub;
-      z[tt] = ((mb >> t) & 1) ? base[t * 16] : 0.f;
-    }
-    z[4] = ci == 0 ? h0.z : ci == 1 ? h0.w : ci == 2 ? h1.x : ci == 3 ? h1.y : ci == 4 ? h0.y : 0.f;
-#pragma unroll
-    for (int tt = 0; tt < 5; tt++) za[tt] = h0.x * z[tt];
-#pragma unroll
-    for (int a = 0; a < 4; a++)
-#pragma unroll
-      for (int b = 0; b < 5; b++) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(za[a], z[b], acc[a][b], 0, 0, 0);
-    acc44 = __builtin_amdgcn_mfma_f32_16x16x4f32(za[4], z[4], acc44, 0, 0, 0);
-  }
-  // ---- phase 3: tiles -> the partial layout k_ba_fold_sc expects.  acc[a][b][v] = D'[16a + 4*kq + v][16b + ci]
-  float* out = B.sc_part + (size_t)item * sc_part_floats(nf);
-  const int nf2 = nf * nf;
-#pragma unroll
-  for (int a = 0; a < 4; a++) {
-#pragma unroll
-    for (int v = 0; v < 4; v++) {
-      const int R = 16 * a + 4 * kq + v, t1 = R >> 3, ra = R & 7;
-      if (t1 < nf) {
-#pragma unroll
-        for (int b = 0; b < 4; b++) {
-          const int C = 16 * b + ci, t2 = C >> 3, cc = C & 7;
-          if (t2 < nf) out[(t1 * nf + t2) * 64 + ra * 8 + cc] = acc[a][b][v];
-        }
-        if (ci < 4) out[nf2 * 64 + t1 * 32 + ra * 4 + ci] = acc[a][4][v];
-        if (ci == 4) out[nf2 * 64 + nf * 32 + t1 * 8 + ra] = acc[a][4][v];
-      }
-    }
-  }
-  const int per_wave = nf2 * 64 + nf * 32 + nf * 8;
-  if (kq == 0) {
-#pragma unroll
-    for (int v = 0; v < 4; v++) {
-      if (ci < 4) out[per_wave + v * 4 + ci] = acc44[v];
-      if (ci == 4) out[per_wave + 16 + v] = acc44[v];
-    }
-  }
-}
-
-
 // ------------------------------------------------------------------ Schur accumulation, one workgroup per host frame
-// Same arithmetic as k_ba_sc_mfma (phase 1 per-point terms, phase 2 Z^T diag(HdiF) Z on the matrix cores), but the four waves
-// of a workgroup share ALL points of one host (64-point slices dealt round-robin), add their 21 accumulator tiles through LDS
-// in a fixed order (3+2 -> 1+0 -> 0) and wave 0 writes the host's accD / accE / accEB bins straight into the packed accumulator
-// block: no per-item partials in HBM and no fold pass.  Only Hcc / bc (sums over ALL hosts) leave a 20-float partial per host.
-// (Round 3 tried the transposed split — wave a owns tile ROW a for all points of the host: 116 VGPRs and 8 KB of LDS, so all 1024
-//  workgroups of a 128-window launch are resident at once instead of two rounds of 512 — and measured it SLOWER, 91 against 72 us: the
-//  kernel is bound by the per-wave chain load -> MFMA over its point groups, which that split makes four times longer.)
-// NW: waves per workgroup.  4 (default).  2 (SDSO_SC_WAVES=2, A/B): half as many waves share a host, so a wave sees twice the point groups
-// (prologue, tree and bins amortise over eight instead of four) and four workgroups instead of two fit a CU.  Measured on MI355X, 256 windows:
-// 142 against 134 us — the per-wave chain load -> terms -> MFMA over its groups is what bounds the kernel, and this doubles it.
-template <bool PLAIN, int NW = 4>
-__global__ __launch_bounds__(64 * NW, 2) void k_ba_sc_host(const BaDev* __restrict__ wins, const uint8_t* __restrict__ pflag, int shiftPriorToZero, int margMode, int signal = 0) {
-  const BaDev& B = wins[blockIdx.y];       // (by value — all pointers in SGPRs, no scalar re-loads in the loop — measured equal: 131 vs 133 us)
+// AccumulatedSCHessianSSE::addPoint (AccumulatedSCHessian.cpp:34-103) for all points of ONE host frame of ONE window, together with the
+// per-point sums addPoint<mode> of the top accumulator leaves in the EFPoint (AccumulatedTopHessian.cpp:160-192).
+//
+// The four waves of the workgroup share the host's points (64-point slices dealt round-robin, 16-point groups inside a slice).  A group's
+// records — the contiguous stretch [p_rbeg[p0], p_rbeg[p0 + 16]) of BaDev::r_rec, 64 bytes per residual, no padding for targets a point does
+// not observe — travel straight into LDS by `global_load_lds_dwordx4` (no destination registers, nothing to park), one group ahead of the
+// arithmetic, and are split on the way: the DMA takes a global address per lane and writes lane-contiguous LDS, so the JpJdF halves land in
+// one buffer (double-buffered: phase 2 of group g reads it while group g + 1 arrives) and the term halves in another (single: phase 1 is
+// done with it before the next DMA is issued).  The JpJdF halves also go back out, compact, for the back-substitution (BaDev::r_cj).
+//   phase 1  per-point terms on ALL 64 lanes: lane = (point, j), j = 0 {bd, Hdd}, 1 {Hcd0, Hcd1}, 2 {Hcd2, Hcd3}, 3 {flags}.  A lane walks
+//            its float pair of the point's (<= 8) records in EFPoint::residualsAll order — which IS the order the records lie in — so Hdd / bd /
+//            Hcd, HdiF and bdSumF are the reference's additions one after the other, bit for bit, whatever dropResidual did to that order
+//            (EnergyFunctional.cpp:524-533); the eight LDS reads of a lane are independent and issued together.  Lane 3 also builds the
+//            point's target -> record map (a word of nibbles) for phase 2.  The quad exchanges H / `any` by DPP and stores the point's 32 bytes
+//            of BaDev::p_out ([8..13], the sums of linearised / marginalised residuals, only when such residuals exist or their stale values
+//            have to be cleared) and idepth_hessian / the active-record mask / `maxRelBaseline = 0` (:44-48) in BaDev::p_track.
+//   phase 2  Z^T diag(HdiF) Z on the matrix cores (fp32 MFMA 16x16x4, K = 4 points), Z = [JpJdF of target 0..7 | Hcd | bdSumF] (69 columns):
+//            only the 15 tiles on and above the diagonal of the 5 x 5 tile grid are accumulated (60 accumulator registers); the bins below the
+//            diagonal are written as mirror images, which makes accD(i,j,k) == accD(i,k,j)^T hold EXACTLY as it does in the reference
+//            (AccumulatorXX::update multiplies a_i * b_j * w: the same product for both, MatrixAccumulators.h:31-80) — the stitch relies on it
+//            (ba_tail.hip: S2 = S1^T).  Absent targets, residuals that are not active and points without an active residual are exact zeros.
+// The waves' tiles are added through LDS in a fixed order (3+2 -> 1+0 -> 0), laid out the way the bins lie in memory and written by all
+// four waves as whole 256-byte blocks straight into the packed accumulator block: no per-item partials in HBM, no fold pass.  Only Hcc / bc
+// (sums over ALL hosts) leave a 20-float partial per host.
+// PLAIN: no marginalisation pass, no point filter, no linearized residual in the launch (every GN iteration of the reference's live flow):
+// all active residuals go to the A sums, and the records of a residual that is not active hold zeros — x + 0 is exact — so no flag is read
+// on the value lanes.  clearL: also store zeros into the L sums of p_out (a launch with linearised residuals left values there).
+// Three workgroups per CU: <= 168 VGPRs, 51 KB of LDS.
+constexpr int SCH_REC = 1024;                         // floats of one record buffer: 16 points x 8 records x 8 floats
+constexpr int SCH_WAVE = 3 * SCH_REC + 16 * 8;        // two JpJdF buffers (double-buffered), one term buffer, the points' phase-2 operands
+template <bool PLAIN>
+__global__ __launch_bounds__(BA_BLOCK, 3) void k_ba_sc_host(const BaDev* __restrict__ wins, const uint8_t* __restrict__ pflag, int shiftPriorToZero, int margMode, int clearL) {
+  constexpr int NW = BA_BLOCK / 64;
+  const BaDev& B = wins[blockIdx.y];
   if (ba_finished(B)) return;
   const int nf = B.nf, h = blockIdx.x;
   if (h >= nf) return;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-#ifdef SDSO_SC_STAMPS   // diagnostic build: shader-clock ticks of wave 0 of workgroup (0, 0) per phase, printed
-  unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  int stn = 0;
-#define SCS() do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); if (stn < 8) st[stn++] = __builtin_amdgcn_s_memtime(); } while (0)
-  unsigned long long sub[6] = {0, 0, 0, 0, 0, 0}, sub_t = 0;     // inside the group loop: wait for the records + park | request + barrier | r_cj | phase 1 | phase 2 | closing barrier
-#define SCSUB(i) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); sub[i] += tn_ - sub_t; sub_t = tn_; } while (0)
-#define SCSUB0() do { sub_t = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define SCS() do { } while (0)
-#define SCSUB(i) do { } while (0)
-#define SCSUB0() do { } while (0)
-#endif
-  SCS();
-  __shared__ float pt_all[NW][16][8];
-  // The records of 16 points (16 x nf x 16 floats, contiguous in r_rec) are brought in ONCE by coalesced 16-byte loads and parked in LDS;
-  // both phases read them there.  (Before: phase 1 read floats 8..15 of every record with lane = point and phase 2 floats 0..7 with its
-  // own lane layout, straight from memory — every 128-byte line crossed the memory system twice, and the launch, two rounds of 512
-  // resident workgroups, ran at the rate those 2 x 131 MB stream: the stamps showed each phase at ~16 us per round.)
-  // 160 floats per point: the four point groups of an MFMA operand read (kq) land 32 banks apart.  The accumulator tiles of the final
-  // tree lie over the same memory.
-  constexpr int SC_PSTRIDE = 160;
-  constexpr int SC_STAGE = 16 * SC_PSTRIDE;                  // floats per wave
-  // D' = Z^T diag(HdiF) Z is symmetric: only the tiles on and above the diagonal of its 4 x 4 grid over the JpJdF columns are accumulated
-  // (10 instead of 16; + 4 tiles of the Hcd / bdSumF columns + 1 corner = 15 tiles, 60 accumulator registers instead of 84), and the bins
-  // below the diagonal are written as their mirror images.  That also makes accD(i,j,k) == accD(i,k,j)^T hold EXACTLY, as it does in the
-  // reference (AccumulatorXX::update multiplies a_i * b_j * w: the same product for both, MatrixAccumulators.h:31-80) — two MFMA tiles
-  // (HdiF z_a) z_b and (HdiF z_b) z_a round differently, and the stitch relies on that symmetry (ba_tail.hip: S2 = S1^T).
   constexpr int SC_NT = 15;                                  // tile t of pair (a <= b): sc_ut(a, b); 10 + a: column tile 4 of row a; 14: the corner
   constexpr int BIN_E = 64 * 64, BIN_EB = BIN_E + 8 * 32;
   constexpr int SC_NEED = SC_NT * 256 + BIN_EB + 64;          // one tile buffer + the bins laid out behind it
-  constexpr int SC_LDS0 = NW * SC_STAGE > (NW / 2) * SC_NT * 256 ? NW * SC_STAGE : (NW / 2) * SC_NT * 256;
+  constexpr int SC_LDS0 = NW * SCH_WAVE > (NW / 2) * SC_NT * 256 ? NW * SCH_WAVE : (NW / 2) * SC_NT * 256;
   constexpr int SC_LDS = SC_LDS0 > SC_NEED ? SC_LDS0 : SC_NEED;
   __shared__ __align__(16) float stage_all[SC_LDS];
-  float (*tiles)[SC_NT * 256] = reinterpret_cast<float (*)[SC_NT * 256]>(stage_all);   // two waves' worth of accumulator tiles
-  float* stg = stage_all + wv * SC_STAGE;
-  float (*pt)[8] = pt_all[wv];
+  float (*tiles)[SC_NT * 256] = reinterpret_cast<float (*)[SC_NT * 256]>(stage_all);   // two waves' worth of accumulator tiles (after the loop)
+  float* const bufA = stage_all + wv * SCH_WAVE;             // [2][SCH_REC]
+  float* const bufT = bufA + 2 * SCH_REC;
+  float (*pt)[8] = reinterpret_cast<float (*)[8]>(bufT + SCH_REC);
   const int ib = B.host_item_beg[h], ie = B.host_item_beg[h + 1];
   const int pb = ib < ie ? B.items[ib].y : 0, pe = ib < ie ? B.items[ie - 1].z : 0;
   te_f4 acc[SC_NT];
@@ -1646,99 +1023,155 @@ __global__ __launch_bounds__(64 * NW, 2) void k_ba_sc_host(const BaDev* __restri
   auto sc_ut = [](int a, int b) { return a * 4 - (a * (a - 1)) / 2 + (b - a); };   // index of the upper tile (a <= b): 0..9
   const int ci = lane & 15, kq = lane >> 4;
   const int tsub = ci >> 3, asub = ci & 7;
-  // a wave's 16-point groups: 64-point slices dealt round-robin over the waves (as before), four groups per slice
+  const int pl = lane >> 2, jq = lane & 3;                   // phase 1: point of the group, float pair of the term record
+  // a wave's 16-point groups: 64-point slices dealt round-robin over the waves, four groups per slice
   auto group_p0 = [&](int gidx) { return pb + 64 * (wv + NW * (gidx >> 2)) + 16 * (gidx & 3); };
-  // the records of group g0: float4 chunk c = lane + 64 k of its (<= 16 nf 4) chunks
-  float pr_next = 0.f, de_next = 0.f;        // prior, delta, residual order and the marginalisation flag of the lane's point of the NEXT group: they travel with its records
-  int pf_next = 1;
-  unsigned or_next = 0xffffffffu;
-  auto request = [&](int p0, float4 (&v)[8]) {
-    const int n16 = min(16, pe - p0);
-    const int nchunks = n16 > 0 ? n16 * nf * 4 : 0;
-    const float* rbase = B.r_rec + (size_t)(n16 > 0 ? p0 : pb) * nf * 16;
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-      const int c = lane + 64 * k;
-      v[k] = c < nchunks ? *(const float4*)(rbase + (size_t)c * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  // what a group needs beside its records, fetched one group ahead: the first record of its points (lane L: point min(L, npts), so lane 16
+  // and everything past the group's end holds the END of its stretch) and, in the phase-1 layout, prior / delta / order / filter of the point
+  struct GroupIn { int rb; float prior, delta; unsigned order; int on; };
+  auto fetch_in = [&](int p0, GroupIn& g) {
+    const int npts = min(16, pe - p0);
+    g.rb = 0; g.prior = 0.f; g.delta = 0.f; g.order = 0xffffffffu; g.on = 0;
+    if (npts <= 0) return;
+    g.rb = B.p_rbeg[p0 + min(lane, npts)];
+    if (pl < npts) {
+      g.prior = B.p_prior[p0 + pl]; g.delta = B.p_delta[p0 + pl]; g.order = B.p_order[p0 + pl];
+      g.on = pflag ? (int)pflag[p0 + pl] : 1;
     }
-    if (lane < n16) { pr_next = B.p_prior[p0 + lane]; de_next = B.p_delta[p0 + lane]; or_next = B.p_order[p0 + lane]; pf_next = pflag ? (int)pflag[p0 + lane] : 1; }
   };
-  float4 vnext[8];
-  SCS();
-  request(group_p0(0), vnext);
-  SCS();
+  // records [r0, r0 + nrec) -> LDS: 16-byte piece c (record c / 2, half c % 2) of the JpJdF halves lands at float 4 c of dstA, of the term
+  // halves at float 4 c of dstT
+  auto dma_records = [&](int r0, int nrec, float* dstA, float* dstT) {
+    const int npieces = nrec * 2;
+    const float* g = B.r_rec + (size_t)r0 * 16;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int c = lane + 64 * k;
+      if (64 * k < npieces) {      // (wave-uniform)
+        if (c < npieces) {
+          const float* src = g + (size_t)(c >> 1) * 16 + 4 * (c & 1);
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(dstA + 256 * k), 16, 0, 0);
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 8), (__attribute__((address_space(3))) void*)(dstT + 256 * k), 16, 0, 0);
+        }
+      }
+    }
+  };
+  GroupIn gcur, gnext;
+  fetch_in(group_p0(0), gcur);
+  {
+    const int r0 = __builtin_amdgcn_readlane(gcur.rb, 0), r1 = __builtin_amdgcn_readlane(gcur.rb, 16);
+    if (group_p0(0) < pe) dma_records(r0, r1 - r0, bufA, bufT);
+  }
+  fetch_in(group_p0(1), gnext);
   for (int gidx = 0;; gidx++) {
     const int p0 = group_p0(gidx);
     if (p0 >= pe) break;
     const int npts = min(16, pe - p0);
-    SCSUB0();
-    {  // park the group's records: chunk c -> record c / 4 = point * nf + target, floats 4 (c & 3) ..
-      const int nchunks = npts * nf * 4;
-#pragma unroll
-      for (int k = 0; k < 8; k++) {
-        const int c = lane + 64 * k;
-        if (c < nchunks) {
-          const int rec = c >> 2, pl = nf == 8 ? rec >> 3 : rec / nf, t = rec - pl * nf;
-          *(float4*)(stg + pl * SC_PSTRIDE + t * 16 + 4 * (c & 3)) = vnext[k];
-        }
-      }
-    }
-    const float prior = pr_next, delta = de_next;
-    const float onf = pf_next ? 1.f : 0.f;
-    const unsigned order = or_next;
-    SCSUB(0);
-    request(group_p0(gidx + 1), vnext);          // the next group's records travel while this one is worked on.  (Requested behind this group's
-                                                 // stores instead — so that the wait for them never waits for a younger store — measured equal.)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    float* const curA = bufA + (gidx & 1) * SCH_REC;
+    const int r0 = __builtin_amdgcn_readlane(gcur.rb, 0);
+    // this group's records (and the inputs of the next one) have landed; the LDS-DMA is invisible to the compiler's own scoreboard
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    SCSUB(1);
-    {  // the JpJdF halves of the parked records -> the compact copy the back-substitution streams (BaDev::r_cj): four fully coalesced 1-KB
-       // stores per group, issued BEHIND the prefetch loads (gfx9 counts stores in vmcnt: in front of them the wait for the next group's
-       // records would also wait for these stores' acknowledgements)
-      const int nhalf = npts * nf * 2;
+    {  // the JpJdF halves, compact, for the back-substitution: coalesced 1-KB stores straight from the stage
+      const int npieces = (__builtin_amdgcn_readlane(gcur.rb, 16) - r0) * 2;
+      float* dst = B.r_cj + (size_t)r0 * 8;
 #pragma unroll
       for (int k = 0; k < 4; k++) {
-        const int c2 = lane + 64 * k;
-        if (c2 < nhalf) {
-          const int rec = c2 >> 1, pl = nf == 8 ? rec >> 3 : rec / nf, t = rec - pl * nf;
-          const float4 q = *(const float4*)(stg + pl * SC_PSTRIDE + t * 16 + 4 * (c2 & 1));
-          *(float4*)(B.r_cj + ((size_t)p0 * nf + rec) * 8 + 4 * (c2 & 1)) = q;
+        const int c = lane + 64 * k;
+        if (c < npieces) *(float4*)(dst + (size_t)c * 4) = *(const float4*)(curA + c * 4);
+      }
+    }
+    {  // ---- phase 1
+      const int base = __shfl(gcur.rb, pl, 64) - r0;           // first record of the lane's point inside the stage
+      const int cnt = 8 - (__clz((int)~gcur.order) >> 2);           // its records: the nibbles of `order` that are not 0xF (targets are < 8)
+      const bool onp = gcur.on != 0;
+      float ax = 0.f, ay = 0.f, lx = 0.f, ly = 0.f;            // A and L sums of the lane's float pair
+      int ngood = 0, mbits = 0;
+      unsigned inv = 0xffffffffu;                              // nibble t: the record of the point's residual to target t
+      float2 v[8];
+      float fl[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const float* rec = bufT + (base + (k < cnt ? k : 0)) * 8;
+        v[k] = *(const float2*)(rec + 2 * jq);
+        fl[k] = PLAIN ? 0.f : rec[RR_FLAGS - 8];
+      }
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const bool in = k < cnt;
+        const unsigned t = (gcur.order >> (4 * k)) & 15u;
+        if (PLAIN) {
+          // (jq == 3: v.x is the flags word; the value lanes add records as they are — zeros where the residual is not active)
+          const int act = in ? ((int)v[k].x & 1) : 0;
+          ngood += act; mbits |= act << k;
+          ax += in ? v[k].x : 0.f; ay += in ? v[k].y : 0.f;
+        } else {
+          const int f = in ? (int)fl[k] : 0;
+          const bool m = (f & 1) != 0 && onp;                  // residual active (and the point taking part)
+          const bool mA = m && !(f & 2) && !margMode, mL = m && !mA;   // mode 0 vs mode 1 / 2 sums (AccumulatedTopHessian.cpp:54-71)
+          if (m) { ngood++; mbits |= 1 << k; }
+          // x + 0 is exact: masked-off residuals leave the sums untouched
+          ax += mA ? v[k].x : 0.f; ay += mA ? v[k].y : 0.f;
+          lx += mL ? v[k].x : 0.f; ly += mL ? v[k].y : 0.f;
+        }
+        if (in) inv = (inv & ~(15u << (4 * t))) | ((unsigned)k << (4 * t));
+      }
+      // lane 0 of the quad: bd (x), Hdd (y)
+      float H = ay + ly + gcur.prior;
+      if (H < 1e-10) H = 1e-10;
+      const float hdi = 1.0 / H;
+      float bds = ax + lx;
+      if (shiftPriorToZero) bds += gcur.prior * gcur.delta;
+      const bool any = __builtin_amdgcn_mov_dpp(ngood, 0xff, 0xf, 0xf, true) > 0;     // quad lane 3 counted the active residuals
+      const float H0 = quad_bcast<0>(H);
+      if (pl < npts && onp) {
+        float* po = B.p_out + (size_t)(p0 + pl) * 16;
+        if (jq == 0) *(float4*)(po + PO_HDD_A) = make_float4(ay, ax, any ? hdi : 0.f, any ? bds : 0.f);
+        else if (jq < 3) *(float2*)(po + PO_HCD_A + 2 * (jq - 1)) = make_float2(ax, ay);
+        else {
+          float* tr = (float*)(B.p_track + p0 + pl);
+          *(float2*)(tr + 2) = make_float2(any ? H0 : 0.f, __int_as_float(mbits));   // p->data->idepth_hessian (:46, :56); the active records for k_ba_resub*
+          if (!any) tr[0] = 0.f;                                                       // p->data->maxRelBaseline = 0 (:47)
+        }
+        if (!PLAIN || clearL) {
+          if (jq == 0) *(float2*)(po + PO_HDD_L) = make_float2(ly, lx);
+          else if (jq < 3) *(float2*)(po + PO_HCD_L + 2 * (jq - 1)) = make_float2(lx, ly);
         }
       }
+      // the point's operands of phase 2: HdiF, bdSumF, Hcd[4] (zeros without an active residual), the target -> record map, its first record
+      float2 o2;
+      if (jq == 0) o2 = make_float2(any ? hdi : 0.f, any ? bds : 0.f);
+      else if (jq < 3) o2 = make_float2(any ? ax + lx : 0.f, any ? ay + ly : 0.f);
+      else o2 = make_float2(__int_as_float((int)inv), __int_as_float(base));
+      *(float2*)(&pt[pl][2 * jq]) = o2;
     }
-    SCSUB(2);
-    {  // phase 1: per-point terms, lane = point (identical to k_ba_sc_mfma)
-      float HdiF = 0.f, bdSumF = 0.f, Hcd[4] = {0.f, 0.f, 0.f, 0.f};
-      int mbits = 0;
-      if (lane < npts) {
-        ScPointTerms T;
-        sc_point_terms<PLAIN>(B, p0 + lane, stg + lane * SC_PSTRIDE, order, onf, prior, delta, shiftPriorToZero, margMode, T);
-        HdiF = T.HdiF; bdSumF = T.bdSumF; mbits = T.mbits;
-#pragma unroll
-        for (int k = 0; k < 4; k++) Hcd[k] = T.Hcd[k];
-      }
-      if (lane < 16) {
-        *(float4*)(&pt[lane][0]) = make_float4(HdiF, bdSumF, Hcd[0], Hcd[1]);
-        *(float4*)(&pt[lane][4]) = make_float4(Hcd[2], Hcd[3], __int_as_float(mbits), 0.f);
-      }
-    }
+    // the term buffer and (since the last iteration's phase 2) the other JpJdF buffer are free: the next group's records may come
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    SCSUB(3);
-    {  // phase 2: the group's four MFMA operand sets (points 4 u + kq), read from the parked records as they are: the record of a
-       // residual that is not active (or of a target the point does not observe) holds zeros, and a point without an active residual,
-       // outside the marginalisation filter or past npts has HdiF = 0 and zero terms in pt[] — exact no-ops, no select needed.
+    {
+      const int pn = group_p0(gidx + 1);
+      if (pn < pe) {
+        const int n0 = __builtin_amdgcn_readlane(gnext.rb, 0), n1 = __builtin_amdgcn_readlane(gnext.rb, 16);
+        dma_records(n0, n1 - n0, bufA + ((gidx + 1) & 1) * SCH_REC, bufT);
+      }
+    }
+    GroupIn gnn;
+    fetch_in(group_p0(gidx + 2), gnn);
+    {  // ---- phase 2: the group's four MFMA operand sets (points 4 u + kq)
       float zz[4][5], hx[4];
 #pragma unroll
       for (int u = 0; u < 4; u++) {
         const int q = 4 * u + kq;
         const float4 h0 = *(const float4*)(&pt[q][0]);
         const float4 h1 = *(const float4*)(&pt[q][4]);
-        const float* base = stg + q * SC_PSTRIDE + asub;
+        const unsigned inv = (unsigned)__float_as_int(h1.z);
+        const float* rb = curA + __float_as_int(h1.w) * 8 + asub;
 #pragma unroll
-        for (int tt = 0; tt < 4; tt++) zz[u][tt] = q < npts ? base[(2 * tt + tsub) * 16] : 0.f;   // (rows past npts are stale LDS)
+        for (int tt = 0; tt < 4; tt++) {
+          const unsigned k = (inv >> (4 * (2 * tt + tsub))) & 15u;
+          zz[u][tt] = k == 15u ? 0.f : rb[k * 8];
+        }
         zz[u][4] = ci == 0 ? h0.z : ci == 1 ? h0.w : ci == 2 ? h1.x : ci == 3 ? h1.y : ci == 4 ? h0.y : 0.f;
         hx[u] = h0.x;
       }
@@ -1756,13 +1189,12 @@ __global__ __launch_bounds__(64 * NW, 2) void k_ba_sc_host(const BaDev* __restri
         acc[14] = __builtin_amdgcn_mfma_f32_16x16x4f32(za[4], zz[u][4], acc[14], 0, 0, 0);
       }
     }
+    gcur = gnext; gnext = gnn;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    SCSUB(4);
-    __builtin_amdgcn_wave_barrier();          // the next group overwrites the stage and pt[]
-    if (gidx == 0) SCS();
+    __builtin_amdgcn_wave_barrier();          // the next group overwrites pt[]
   }
-  SCS();
-  __syncthreads();                            // the tiles lie over the other waves' stages
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();                            // the tiles lie over the waves' stages
   // ---- fixed-order tree over the four waves: (3 -> 1, 2 -> 0), then (1 -> 0)
   auto put = [&](float* dst) {
 #pragma unroll
@@ -1776,17 +1208,14 @@ __global__ __launch_bounds__(64 * NW, 2) void k_ba_sc_host(const BaDev* __restri
 #pragma unroll
       for (int v = 0; v < 4; v++) acc[t][v] += src[(t * 4 + v) * 64 + lane];
   };
-  if constexpr (NW == 4) {
-    if (wv >= 2) put(tiles[wv - 2]);
-    __syncthreads();
-    if (wv < 2) add(tiles[wv]);
-    __syncthreads();
-  }
+  if (wv >= 2) put(tiles[wv - 2]);
+  __syncthreads();
+  if (wv < 2) add(tiles[wv]);
+  __syncthreads();
   if (wv == 1) put(tiles[0]);
   __syncthreads();
   // ---- the host's bins.  acc[a][b][v] = D'[16a + 4*kq + v][16b + ci]: wave 0 lays the finished tiles out in LDS the way the bins lie in
-  // memory (64-float blocks per (t1, t2)), then all four waves write them out, one 256-byte block per store (from the accumulator
-  // layout a store covered eight 32-byte pieces of four blocks, 84 such stores on one wave: 9 k of the kernel's 75 k cycles)
+  // memory (64-float blocks per (t1, t2)), then all four waves write them out, one 256-byte block per store
   const int nf2 = nf * nf;
   float* accD = B.accum + acc_off_D(nf);
   float* accE = B.accum + acc_off_E(nf);
@@ -1795,7 +1224,6 @@ __global__ __launch_bounds__(64 * NW, 2) void k_ba_sc_host(const BaDev* __restri
   static_assert(SC_NEED <= SC_LDS, "the bins fit behind the first tile buffer");
   if (wv == 0) {
     add(tiles[0]);
-    SCS();
 #pragma unroll
     for (int a = 0; a < 4; a++) {
 #pragma unroll
@@ -1814,7 +1242,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_ba_sc_host(const BaDev* __restri
         if (ci == 4) bins[BIN_EB + t1 * 8 + ra] = acc[10 + a][v];
       }
     }
-    float* hp = B.sc_part + (size_t)h * 20;      // Hcc (16) and bc (4) of this host; k_ba_fold_all adds the hosts
+    float* hp = B.sc_part + (size_t)h * 20;      // Hcc (16) and bc (4) of this host; the fold adds the hosts
     if (kq == 0) {
 #pragma unroll
       for (int v = 0; v < 4; v++) {
@@ -1835,26 +1263,6 @@ __global__ __launch_bounds__(64 * NW, 2) void k_ba_sc_host(const BaDev* __restri
     if (t1 < nf) accE[(size_t)(h + t1 * nf) * 32 + (idx & 31)] = bins[BIN_E + idx];
   }
   if (wv == 1 && (lane >> 3) < nf) accEB[(size_t)(h + (lane >> 3) * nf) * 8 + (lane & 7)] = bins[BIN_EB + lane];
-  if (signal) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }   // (every wave's stores are out before wave 0 signals)
-  if (wv != 0) return;
-  SCS();
-#ifdef SDSO_SC_STAMPS
-  if ((blockIdx.x == 0 || blockIdx.x == 5) && (blockIdx.y == 0 || blockIdx.y == 100) && lane == 0)
-    printf("sc_host (%d,%d) ticks: prologue %llu  first records %llu  group 0 %llu  other groups %llu  wave tree %llu  bins %llu | total %llu  (points %d)\n", blockIdx.x, blockIdx.y,
-           st[1] - st[0], st[2] - st[1], st[3] - st[2], st[4] - st[3], st[5] - st[4], st[6] - st[5], st[6] - st[0], pe - pb);
-  if ((blockIdx.x == 0 || blockIdx.x == 5) && (blockIdx.y == 0 || blockIdx.y == 100) && lane == 0)
-    printf("sc_host (%d,%d) inside the group loop, all groups of wave 0: wait + park %llu  request + barrier %llu  r_cj %llu  phase 1 %llu  phase 2 %llu\n", blockIdx.x, blockIdx.y, sub[0], sub[1], sub[2], sub[3], sub[4]);
-#endif
-  if (signal) {
-    // side-stream launch: tell the tail kernel (already resident, polling) that this host's bins, Hcc partial and per-point terms are
-    // in memory.  The other waves' p_out stores were drained before the workgroup barriers above (__syncthreads waits for vmcnt(0));
-    // this wave drains its own, releases at agent scope (L2 write-back) and only then bumps the counter.
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0) __hip_atomic_fetch_add(&B.opt->sc_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
 }
-
 
 }  // namespace sdso

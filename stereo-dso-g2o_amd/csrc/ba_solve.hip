@@ -11,40 +11,7 @@
 
 namespace sdso {
 
-// ------------------------------------------------------------------ fold of the Schur partials
-// grid.x = nf^3 (D bins, 64 threads each) + nf^2 (E/EB per pair) + 1 (Hcc, bc)
-__device__ __forceinline__ void fold_sc_body(const BaDev& B, int b, int lane) {
-  const int nf = B.nf, nf2 = nf * nf, nf3 = nf2 * nf;
-  const int pf = sc_part_floats(nf);
-  if (b < nf3) {
-    // accD[h + t1*nf + t2*nf^2] <- items of host h, tile (t1,t2)
-    const int h = b % nf, t1 = (b / nf) % nf, t2 = b / nf2;
-    float s = 0;
-    for (int it = B.host_item_beg[h]; it < B.host_item_beg[h + 1]; it++) s += B.sc_part[(size_t)it * pf + (t1 * nf + t2) * 64 + lane];
-    B.accum[acc_off_D(nf) + (size_t)b * 64 + lane] = s;
-    return;
-  }
-  b -= nf3;
-  if (b < nf2) {
-    const int h = b % nf, t1 = b / nf;
-    if (lane < 40) {
-      const int off = lane < 32 ? nf2 * 64 + t1 * 32 + lane : nf2 * 64 + nf * 32 + t1 * 8 + (lane - 32);
-      float s = 0;
-      for (int it = B.host_item_beg[h]; it < B.host_item_beg[h + 1]; it++) s += B.sc_part[(size_t)it * pf + off];
-      if (lane < 32) B.accum[acc_off_E(nf) + (size_t)b * 32 + lane] = s;
-      else B.accum[acc_off_EB(nf) + (size_t)b * 8 + (lane - 32)] = s;
-    }
-    return;
-  }
-  if (lane < 20) {
-    const int off = nf2 * 64 + nf * 32 + nf * 8 + lane;
-    float s = 0;
-    for (int it = 0; it < B.nitems; it++) s += B.sc_part[(size_t)it * pf + off];
-    B.accum[acc_off_Hcc(nf) + lane] = s;  // Hcc 16 then bc 4 are contiguous
-  }
-}
-
-__global__ __launch_bounds__(64) void k_ba_fold_sc(const BaDev* __restrict__ wins) { if (ba_finished(wins[blockIdx.y])) return; fold_sc_body(wins[blockIdx.y], blockIdx.x, threadIdx.x); }
+// ------------------------------------------------------------------ folds
 // Hcc / bc after k_ba_sc_host: nf per-host partials of 20 floats
 __device__ __forceinline__ void fold_hcc_hosts(const BaDev& B, int lane) {
   if (lane < 20) {
@@ -55,16 +22,15 @@ __device__ __forceinline__ void fold_hcc_hosts(const BaDev& B, int lane) {
 }
 __global__ __launch_bounds__(64) void k_ba_fold_hcc(const BaDev* __restrict__ wins) { if (ba_finished(wins[blockIdx.y])) return; fold_hcc_hosts(wins[blockIdx.y], threadIdx.x); }
 // every fold of one accumulate phase in ONE launch (the usual case: no linearized residuals, topL is just cleared):
-// grid.x = [nf^3 + nf^2 + 1 Schur bins | nf^2 top-A pairs | nf^2 top-L pairs], 128 threads
-// host_sc != 0: the Schur bins were written by k_ba_sc_host, only Hcc / bc remain (grid.x = 1 + 2 nf^2)
-__global__ __launch_bounds__(128) void k_ba_fold_all(const BaDev* __restrict__ wins, int host_sc) {
+// grid.x = [1: Hcc / bc of the hosts' Schur workgroups | nf^2 top-A pairs | nf^2 top-L pairs], 128 threads
+__global__ __launch_bounds__(128) void k_ba_fold_all(const BaDev* __restrict__ wins) {
   const BaDev& B = wins[blockIdx.y];
   if (ba_finished(B)) return;
-  const int nf = B.nf, nf2 = nf * nf, nsc = host_sc ? 1 : nf2 * nf + nf2 + 1;
+  const int nf2 = B.nf * B.nf;
   const int b = blockIdx.x;
-  if (b < nsc) { if (host_sc) fold_hcc_hosts(B, threadIdx.x); else if (threadIdx.x < 64) fold_sc_body(B, b, threadIdx.x); }
-  else if (b < nsc + nf2) fold_top_body(B, b - nsc, 0, threadIdx.x);
-  else zero_topL_body(B, b - nsc - nf2, threadIdx.x);
+  if (b < 1) fold_hcc_hosts(B, threadIdx.x);
+  else if (b < 1 + nf2) fold_top_body(B, b - 1, 0, threadIdx.x);
+  else zero_topL_body(B, b - 1 - nf2, threadIdx.x);
 }
 
 // ------------------------------------------------------------------ stitch
@@ -349,11 +315,7 @@ __global__ __launch_bounds__(64 * ST_WAVES) void k_ba_stitch(const BaDev* __rest
 #define TNOW() 0ull
 #endif
 // orthogonalize_x bit 1: lambda of the window's resident GN loop (BaOptDev::lambda, energy-gated flow) instead of the argument
-// VER 1: lane = POSITION (rows of L exchanged physically when a pivot is chosen).  VER 2: lane = ORIGINAL row for the whole factorisation —
-// nothing is ever exchanged (the pivot order is bookkeeping in registers: done / step / Eigen position for ties), L and the packed
-// upper triangle of As live in separate arrays, and the four rows past the 64th take their dot products cooperatively (all lanes, 16
-// interleaved partial sums per row, tree-reduced) instead of a second full-wave stream.
-template <int VER>
+// lane = POSITION (rows of L exchanged physically when a pivot is chosen).
 __global__ __launch_bounds__(BA_BLOCK) void k_ba_solve(const BaDev* __restrict__ wins, double lambda, int orthogonalize_x) {
   const BaDev& B = wins[blockIdx.y];
   if (ba_finished(B)) return;
@@ -373,9 +335,7 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_solve(const BaDev* __restrict__
   double* Dg = yv + n;            // n
   double* xv = Dg + n;            // n
   double* wq = xv + n;            // n  d_q L_kq of the current pivot row (+ 16 zeros: the dot products run in trips of 16)
-  double* Ap = wq + n + 32;       // VER 2 (its w has 32 zeros behind it: trips of 32): n(n+1)/2 (+2)  As, upper triangle packed by original index: As(i,j), i <= j, at ap(i,j)
-  int* perm = VER == 2 ? (int*)(Ap + (n * (n + 1)) / 2 + 2) : (int*)(wq + n + 16); // n  VER 1: original index at a position; VER 2: row pivoted at a step
-  auto ap = [n](int i, int j) { return (i * (2 * n - i + 1)) / 2 + (j - i); };
+  int* perm = (int*)(wq + n + 16); // n  original index at a position
   const size_t blk = (size_t)n * n + n;
   const double* HA = B.sol; const double* bA = HA + (size_t)n * n;
   const double* HL = B.sol + blk; const double* bL = HL + (size_t)n * n;
@@ -395,42 +355,7 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_solve(const BaDev* __restrict__
     bF[i] = v;
     lastbS[i] = v;
   }
-  if constexpr (VER == 2) {
-    // SVecI from the diagonal of HFinal_top - H_sc/(1+lambda) first (:967), then one pass over the matrix: lastHS to memory, the scaled
-    // upper triangle into LDS
-    for (int i = tid; i < n; i += BA_BLOCK) {
-      const int e = i * n + i;
-      double v = HL[e] + B.t_HM[e] + HA[e];
-      v *= (1 + lambda);
-      v -= HS[e] * f;
-      sv[i] = 1.0 / sqrt(v + 10);
-    }
-    for (int i = tid; i < n * ld; i += BA_BLOCK) Lm[i] = 0.0;    // (the dot products read past the columns written so far, times exact zeros of w)
-    for (int i = tid; i < n + 32; i += BA_BLOCK) wq[i] = 0.0;
-    for (int i = tid; i < n; i += BA_BLOCK) { yv[i] = 0.0; Dg[i] = 0.0; xv[i] = 0.0; perm[i] = i; }
-    __syncthreads();
-    for (int e0 = tid; e0 < n * n; e0 += 4 * BA_BLOCK) {
-      double hl[4], hm[4], ha[4], hs[4];
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const int e = e0 + u * BA_BLOCK, ec = e < n * n ? e : 0;
-        hl[u] = HL[ec]; hm[u] = B.t_HM[ec]; ha[u] = HA[ec]; hs[u] = HS[ec];
-      }
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const int e = e0 + u * BA_BLOCK;
-        if (e < n * n) {
-          const int i = e / n, j = e - i * n;
-          double v = hl[u] + hm[u] + ha[u];
-          lastHS[e] = v - hs[u];                 // :909
-          if (i == j) v *= (1 + lambda);         // :914-916
-          v -= hs[u] * f;                        // :918
-          if (i <= j) Ap[ap(i, j)] = sv[i] * v * sv[j];
-        }
-      }
-    }
-    for (int i = tid; i < n; i += BA_BLOCK) bF[i] = sv[i] * bF[i];
-  } else {
+  {
   for (int e0 = tid; e0 < n * n; e0 += 4 * BA_BLOCK) {       // four elements per trip, loads first
     double hl[4], hm[4], ha[4], hs[4];
 #pragma unroll
@@ -465,175 +390,7 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_solve(const BaDev* __restrict__
   __syncthreads();
   STAMP(1);
 
-  if (VER == 2 && wv == 0) {
-    const int r0 = lane, r1 = lane + 64;          // ORIGINAL rows of this lane, for the whole factorisation (r1 only while r1 < n)
-    const bool has0 = r0 < n, has1 = r1 < n;
-    const int q0c = has0 ? r0 : 0, q1c = has1 ? r1 : 0;
-    const bool any1 = n > 64;                     // (wave-uniform) rows past the 64th exist
-    double d0 = has0 ? Ap[ap(r0, r0)] : 0.0, d1 = has1 ? Ap[ap(r1, r1)] : 0.0;   // running diagonal of the lane's rows
-    bool done0 = !has0, done1 = !has1;            // row already pivoted (or absent)
-    int pos0 = r0, pos1 = r1;                     // Eigen's position of a not yet pivoted row (only decides ties of |d|)
-    int stp0 = n, stp1 = n;                       // pivot step of the row (n: not yet)
-    double pv0 = 0.0, pv1 = 0.0;                  // its pivot d_k
-    auto rl = [](double v, int src) {             // value of lane `src` (wave-uniform index)
-      const unsigned long long u = __double_as_longlong(v);
-      const unsigned lo = __builtin_amdgcn_readlane((unsigned)u, src), hi = __builtin_amdgcn_readlane((unsigned)(u >> 32), src);
-      return __longlong_as_double(((unsigned long long)hi << 32) | lo);
-    };
-    // the rows past the 64th: lane l works for row 64 + (l >> 4) on the terms q = 16 t + (l & 15) — the 16 partial sums of a row sit in
-    // one 16-lane DPP row and are added with row rotations (no LDS round trip)
-    const int crow = 64 + (lane >> 4), cchunk = lane & 15;
-    const bool chas = crow < n;
-    const double* crowp = Lm + (chas ? crow : 0) * ld;
-    for (int k = 0; k < n; k++) {
-      unsigned long long tq = TNOW();
-      (void)tq;
-      // ---- pivot: the not yet pivoted row with the largest |d|; ties go to the smallest position, like Eigen's first maximum
-      const unsigned long long k0 = !done0 ? (unsigned long long)__double_as_longlong(fabs(d0)) : 0ull;
-      const unsigned long long k1 = !done1 ? (unsigned long long)__double_as_longlong(fabs(d1)) : 0ull;
-      unsigned long long m = k0 > k1 ? k0 : k1;
-#define ROR_MAX(CTRL)                                                                                   \
-      {                                                                                                 \
-        const unsigned lo = __builtin_amdgcn_update_dpp(0, (unsigned)m, CTRL, 0xf, 0xf, false);         \
-        const unsigned hi = __builtin_amdgcn_update_dpp(0, (unsigned)(m >> 32), CTRL, 0xf, 0xf, false); \
-        const unsigned long long o = ((unsigned long long)hi << 32) | lo;                               \
-        m = o > m ? o : m;                                                                              \
-      }
-      ROR_MAX(0x128) ROR_MAX(0x124) ROR_MAX(0x122) ROR_MAX(0x121)
-#undef ROR_MAX
-      unsigned long long mx;
-      {
-        unsigned long long rm[4];
-#pragma unroll
-        for (int row = 0; row < 4; row++) {
-          const unsigned lo = __builtin_amdgcn_readlane((unsigned)m, 16 * row), hi = __builtin_amdgcn_readlane((unsigned)(m >> 32), 16 * row);
-          rm[row] = ((unsigned long long)hi << 32) | lo;
-        }
-        const unsigned long long m01 = rm[0] > rm[1] ? rm[0] : rm[1], m23 = rm[2] > rm[3] ? rm[2] : rm[3];
-        mx = m01 > m23 ? m01 : m23;
-      }
-      const bool t0 = !done0 && k0 == mx, t1 = !done1 && k1 == mx;
-      unsigned long long b0 = __ballot(t0), b1 = __ballot(t1);
-      if (__popcll(b0) + __popcll(b1) > 1) {      // a tie: the smallest position wins
-        int best = t0 ? pos0 : 0x7fffffff;
-        if (t1 && pos1 < best) best = pos1;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { const int ob = __shfl_xor(best, o, 64); best = ob < best ? ob : best; }
-        b0 = __ballot(t0 && pos0 == best); b1 = __ballot(t1 && pos1 == best);
-      }
-      const int pl = b0 ? __ffsll((long long)b0) - 1 : __ffsll((long long)b1) - 1;   // lane of the pivot row
-      const bool ps1 = !b0;                                                            // ... in its second slot
-      const int pk = pl + (ps1 ? 64 : 0);                                              // the pivot row (original index)
-      const double dk = ps1 ? rl(d1, pl) : rl(d0, pl);
-      const int ppos = ps1 ? __builtin_amdgcn_readlane(pos1, pl) : __builtin_amdgcn_readlane(pos0, pl);
-      // Eigen exchanges positions k and ppos: the row sitting at position k moves to ppos
-      if (!done0 && pos0 == k) pos0 = ppos;
-      if (!done1 && pos1 == k) pos1 = ppos;
-      if (lane == pl) { if (ps1) { done1 = true; stp1 = k; pv1 = dk; pos1 = k; } else { done0 = true; stp0 = k; pv0 = dk; pos0 = k; } }
-      if (lane == pl) { Dg[k] = dk; perm[k] = pk; }
-      ACCUM(0, tq); tq = TNOW();
-      ACCUM(1, tq); tq = TNOW();
-      // ---- w_q = d_q L(pk, q) for q < k (worker lane q), then the column: c_i = As(i, pk) - sum_q L(i, q) w_q
-      {
-        const double a0 = Lm[pk * ld + q0c], a1 = Lm[pk * ld + q1c];
-        if (has0 && r0 < k) wq[r0] = Dg[r0] * a0;
-        if (has1 && r1 < k) wq[r1] = Dg[r1] * a1;
-      }
-      wave_sync();
-      ACCUM(2, tq); tq = TNOW();
-      double c0 = Ap[r0 < pk ? ap(q0c, pk) : ap(pk, q0c)], c0b = 0.0;
-      const double* row0 = Lm + q0c * ld;
-      for (int q = 0; q < k; q += 16) {            // sixteen terms per trip; beyond k the products are exact zeros (w is zero there).  (Trips of 32
-        double lv[16], wv8[16];                    //  were slower, 143 k against 127 k ticks: the phase is bound by the LDS instructions it issues)
-#pragma unroll
-        for (int u = 0; u < 16; u++) { lv[u] = row0[q + u]; wv8[u] = wq[q + u]; }
-#pragma unroll
-        for (int u = 0; u < 16; u += 2) { c0 = __builtin_fma(-lv[u], wv8[u], c0); c0b = __builtin_fma(-lv[u + 1], wv8[u + 1], c0b); }
-      }
-      c0 += c0b;
-      double c1 = 0.0;
-      if (any1) {                                  // rows 64..: 16 interleaved partial sums per row, added up over the lanes l, l^4, l^8, ...
-        // (n <= 80: five terms per lane cover every q < k; beyond k the products are exact zeros — all ten loads go out together)
-        double cv[5], cw[5];
-#pragma unroll
-        for (int t = 0; t < 5; t++) { cv[t] = crowp[cchunk + 16 * t]; cw[t] = wq[cchunk + 16 * t]; }
-        double part = 0.0;
-#pragma unroll
-        for (int t = 0; t < 5; t++) part = __builtin_fma(cv[t], cw[t], part);
-#define ROR_ADD(CTRL)                                                                                                     \
-        {                                                                                                                 \
-          const unsigned long long u = __double_as_longlong(part);                                                       \
-          const unsigned lo = __builtin_amdgcn_update_dpp(0, (unsigned)u, CTRL, 0xf, 0xf, false);                         \
-          const unsigned hi = __builtin_amdgcn_update_dpp(0, (unsigned)(u >> 32), CTRL, 0xf, 0xf, false);                 \
-          part += __longlong_as_double(((unsigned long long)hi << 32) | lo);                                              \
-        }
-        ROR_ADD(0x128) ROR_ADD(0x124) ROR_ADD(0x122) ROR_ADD(0x121)   // row_ror:8,4,2,1: every lane of a row holds the row's sum
-#undef ROR_ADD
-        {   // lane r (0..3) takes the sum of DPP row r
-          const double t1 = rl(part, 16), t2 = rl(part, 32), t3 = rl(part, 48);
-          part = lane == 1 ? t1 : lane == 2 ? t2 : lane == 3 ? t3 : part;
-        }
-        if (has1) c1 = Ap[r1 < pk ? ap(r1, pk) : ap(pk, r1)] - part;    // lanes 0..3: r1 = 64 + lane
-      }
-      ACCUM(3, tq); tq = TNOW();
-      // ---- L(i, k), running diagonal (A(i,i) -= (L_ik d_k) L_ik) for the rows not yet pivoted
-      if (dk != 0.0) {
-        const bool fold = !any1 || k >= 4;         // one division stream: lanes whose first row is done divide for their second row
-        const bool second = fold && !done1 && done0;
-        const double l = (second ? c1 : c0) / dk;
-        if (second) { Lm[r1 * ld + k] = l; d1 = d1 - (l * dk) * l; }
-        else if (!done0) { Lm[r0 * ld + k] = l; d0 = d0 - (l * dk) * l; }
-        if (!done1 && !second) { const double l2 = c1 / dk; Lm[r1 * ld + k] = l2; d1 = d1 - (l2 * dk) * l2; }
-      } else {
-        if (!done0) Lm[r0 * ld + k] = 0;
-        if (!done1) Lm[r1 * ld + k] = 0;
-      }
-      wave_sync();
-      ACCUM(4, tq);
-    }
-    STAMP(2);
-    // ---- triangular solves in pivot order; lane owns the unknowns of its rows
-    double y0 = has0 ? bF[r0] : 0.0, y1 = has1 ? bF[r1] : 0.0;
-    for (int j0 = 0; j0 < n; j0 += 8) {   // forward, column sweep: y[i] -= L(i,j) y[j] for the rows pivoted after step j (j ascending like the reference)
-      double a0[8], a1[8];
-      int pj[8];
-#pragma unroll
-      for (int u = 0; u < 8; u++) { a0[u] = Lm[q0c * ld + j0 + u]; a1[u] = Lm[q1c * ld + j0 + u]; pj[u] = perm[j0 + u < n ? j0 + u : 0]; }
-#pragma unroll
-      for (int u = 0; u < 8; u++) {
-        const int j = j0 + u;
-        if (j < n) {
-          const int pr = __builtin_amdgcn_readfirstlane(pj[u]);
-          const double yj = pr < 64 ? rl(y0, pr) : rl(y1, pr - 64);
-          if (has0 && stp0 > j) y0 -= a0[u] * yj;
-          if (has1 && stp1 > j) y1 -= a1[u] * yj;
-        }
-      }
-    }
-    if (has0) y0 = pv0 != 0.0 ? y0 / pv0 : 0.0;
-    if (has1) y1 = pv1 != 0.0 ? y1 / pv1 : 0.0;
-    const int s0c = has0 ? stp0 : 0, s1c = has1 ? stp1 : 0;
-    for (int j0 = n - 1; j0 >= 0; j0 -= 8) {  // backward, column sweep: y[i] -= L(j,i) y[j] for the rows pivoted before step j
-      double a0[8], a1[8];
-      int pj[8];
-#pragma unroll
-      for (int u = 0; u < 8; u++) { const int j = j0 - u < 0 ? 0 : j0 - u; pj[u] = perm[j]; a0[u] = Lm[pj[u] * ld + s0c]; a1[u] = Lm[pj[u] * ld + s1c]; }
-#pragma unroll
-      for (int u = 0; u < 8; u++) {
-        const int j = j0 - u;
-        if (j >= 0) {
-          const int pr = __builtin_amdgcn_readfirstlane(pj[u]);
-          const double yj = pr < 64 ? rl(y0, pr) : rl(y1, pr - 64);
-          if (has0 && stp0 < j) y0 -= a0[u] * yj;
-          if (has1 && stp1 < j) y1 -= a1[u] * yj;
-        }
-      }
-    }
-    if (has0) xv[r0] = y0;
-    if (has1) xv[r1] = y1;
-    STAMP(3);
-  }
-  if (VER == 1 && wv == 0) {
+  if (wv == 0) {
     const int r0 = lane, r1 = lane + 64;          // positions of this lane (r1 only while r1 < n)
     const bool has0 = r0 < n, has1 = r1 < n;
     const int q0c = has0 ? r0 : 0, q1c = has1 ? r1 : 0;          // clamped: loads stay unconditional and in bounds
@@ -814,31 +571,32 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_solve(const BaDev* __restrict__
 
 // ------------------------------------------------------------------ back-substitution, one lane per point
 // EnergyFunctional::resubstituteFPt (EnergyFunctional.cpp:305-341) for point p: b = bdSumF - xc . Hcd - sum_r xAd[r] . JpJdF[r] over the active
-// residuals in EFPoint::residualsAll order (BaDev::p_order — the subtractions of the reference, one after the other), step = -b HdiF.
-// Every load of the point is issued before the first one is consumed (the loop over the targets is unrolled to the 8 frames a window can
-// hold and predicated): one memory round trip instead of one per target.
-// CJ: the JpJdF rows come from the compact copy k_ba_sc_host left (BaDev::r_cj, 32 bytes per (point, target)) and the active targets from
-// BaDev::p_track — half the bytes of the 64-byte records; false: from the records themselves (the other Schur kernel variants).
-template <bool CJ>
+// residuals in EFPoint::residualsAll order — the order the point's records lie in BaDev::r_cj, their targets in the nibbles of p_order — the
+// subtractions of the reference one after the other; step = -b HdiF.  The active records are the bits the Schur kernel left in p_track.
+// Every load of the point is issued before the first one is consumed (the loop is unrolled to the 8 residuals a point can hold and
+// predicated): one memory round trip instead of one per residual.  WITH_L: the point's L sums (linearised / marginalised residuals) exist.
+template <bool WITH_L>
 __device__ __forceinline__ float resub_point(const BaDev& B, int p, const float* po) {
   const double* x = B.sol + 3 * ((size_t)B.n * B.n + B.n);
   const int nf = B.nf;
-  const float* recs = CJ ? B.r_cj + (size_t)p * nf * 8 : B.r_rec + (size_t)p * nf * 16;
+  const float* recs = B.r_cj + (size_t)B.p_rbeg[p] * 8;
   const int h = B.p_host[p];
   const unsigned ord = B.p_order[p];
+  const int cnt = 8 - (__clz((int)~ord) >> 2);    // the nibbles of `ord` that are not 0xF (targets are < 8: the top bit of a used nibble is clear)
   float4 j0[8], j1[8], xa0[8], xa1[8];
-  unsigned good = CJ ? (unsigned)__float_as_int(((const float*)(B.p_track + p))[3]) : 0u;
+  const unsigned good = (unsigned)__float_as_int(((const float*)(B.p_track + p))[3]);
 #pragma unroll
-  for (int t = 0; t < 8; t++) {
-    if (t < nf) {
-      const float* rec = recs + t * (CJ ? 8 : 16);
-      if (!CJ) good |= ((((int)rec[RR_FLAGS]) & 1) != 0 ? 1u : 0u) << t;
-      j0[t] = *reinterpret_cast<const float4*>(rec); j1[t] = *reinterpret_cast<const float4*>(rec + 4);
-      const float* xa = B.t_xAd + (size_t)(h * nf + t) * 8;
-      xa0[t] = *reinterpret_cast<const float4*>(xa); xa1[t] = *reinterpret_cast<const float4*>(xa + 4);
+  for (int k = 0; k < 8; k++) {
+    if (k < cnt) {
+      const float* rec = recs + k * 8;
+      j0[k] = *reinterpret_cast<const float4*>(rec); j1[k] = *reinterpret_cast<const float4*>(rec + 4);
+      const float* xa = B.t_xAd + (size_t)(h * nf + (int)((ord >> (4 * k)) & 15u)) * 8;
+      xa0[k] = *reinterpret_cast<const float4*>(xa); xa1[k] = *reinterpret_cast<const float4*>(xa + 4);
     }
   }
-  const float4 hA = *reinterpret_cast<const float4*>(po + PO_HCD_A), hL = *reinterpret_cast<const float4*>(po + PO_HCD_L);
+  const float4 hA = *reinterpret_cast<const float4*>(po + PO_HCD_A);
+  float4 hL = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (WITH_L) hL = *reinterpret_cast<const float4*>(po + PO_HCD_L);
   const float bsum = po[PO_BDSUM], hdi = po[PO_HDI];
   const double x0 = x[0], x1 = x[1], x2 = x[2], x3 = x[3];
   if (good == 0) return 0.f;
@@ -849,41 +607,32 @@ __device__ __forceinline__ float resub_point(const BaDev& B, int p, const float*
   d += (float)x2 * (hA.z + hL.z);
   d += (float)x3 * (hA.w + hL.w);
   b -= d;
-  float sacc[8];                           // xAd . JpJdF of every target slot (independent dot products) ...
 #pragma unroll
-  for (int t = 0; t < 8; t++) {
-    float a = 0;
-    if (t < nf) {
-      a += xa0[t].x * j0[t].x; a += xa0[t].y * j0[t].y; a += xa0[t].z * j0[t].z; a += xa0[t].w * j0[t].w;
-      a += xa1[t].x * j1[t].x; a += xa1[t].y * j1[t].y; a += xa1[t].z * j1[t].z; a += xa1[t].w * j1[t].w;
+  for (int k = 0; k < 8; k++) {            // xAd . JpJdF of every record, subtracted in residualsAll order
+    if (k < cnt) {
+      float a = 0;
+      a += xa0[k].x * j0[k].x; a += xa0[k].y * j0[k].y; a += xa0[k].z * j0[k].z; a += xa0[k].w * j0[k].w;
+      a += xa1[k].x * j1[k].x; a += xa1[k].y * j1[k].y; a += xa1[k].z * j1[k].z; a += xa1[k].w * j1[k].w;
+      if ((good >> k) & 1u) b -= a;
     }
-    sacc[t] = a;
-  }
-#pragma unroll
-  for (int k = 0; k < 8; k++) {            // ... subtracted in residualsAll order
-    const unsigned t = (ord >> (4 * k)) & 15u;
-    float sv = sacc[0];
-#pragma unroll
-    for (int q = 1; q < 8; q++) sv = t == (unsigned)q ? sacc[q] : sv;
-    if (t != 15u && ((good >> t) & 1u)) b -= sv;
   }
   return -b * hdi;
 }
-template <bool CJ>
+template <bool WITH_L>
 __global__ __launch_bounds__(BA_BLOCK) void k_ba_resub(const BaDev* __restrict__ wins) {
   const BaDev& B = wins[blockIdx.y];
   if (ba_finished(B)) return;
   const int p = blockIdx.x * BA_BLOCK + threadIdx.x;
   if (p >= B.np) return;
   float* po = B.p_out + (size_t)p * 16;
-  po[PO_STEP] = resub_point<CJ>(B, p, po);
+  po[PO_STEP] = resub_point<WITH_L>(B, p, po);
 }
 
 // resubstituteFPt + backupState + doStepFromBackup (stepfacD = 1) of the points in ONE pass over the point data (k_ba_resub followed
 // by k_ba_points_op op 3), after the fused tail kernel of the resident loop.  expect_iterations >= 0: the window takes part iff its
 // loop has taken exactly that many steps — the tail kernel that just ran may have set `finished` for the NEXT iteration (the break
 // test fires after the step it belongs to); < 0: the plain `finished` test (sharded windows: k_ba_opt_step has not run yet).
-template <bool CJ>
+template <bool WITH_L>
 __global__ __launch_bounds__(BA_BLOCK) void k_ba_resub_step(const BaDev* __restrict__ wins, int expect_iterations, float* __restrict__ sums, int sums_stride) {
   const BaDev& B = wins[blockIdx.y];
   if (expect_iterations >= 0 ? (ba_finished_lin(B) || B.opt->iterations != expect_iterations) : ba_finished(B)) return;
@@ -892,7 +641,7 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_resub_step(const BaDev* __restr
   if (p < B.np) {
     float* po = B.p_out + (size_t)p * 16;
     float4 g = B.p_geo[p];
-    const float st = resub_point<CJ>(B, p, po);
+    const float st = resub_point<WITH_L>(B, p, po);
     po[PO_STEP] = st;
     po[PO_BACKUP] = g.z;
     const float bk = g.z, nid = bk + 1.0f * st;

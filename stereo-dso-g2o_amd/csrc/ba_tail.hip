@@ -37,7 +37,6 @@ constexpr int TAIL_STEP = 16;       // the loop's host part (opt_step_body), sin
 constexpr int TAIL_ORTH = 32;       // x -= P x
 constexpr int TAIL_LAMBDA_DEV = 64; // lambda of the window's resident loop (energy-gated flow)
 constexpr int TAIL_TOPL = 128;      // the linearised (L) top sums are not zero: read them from the packed block
-constexpr int TAIL_WAIT_SC = 256;   // the Schur kernel runs on the side stream: wait for its nf host workgroups (BaOptDev::sc_done) first
 
 // LDS layout (bytes); the big regions are reused by phases that do not overlap
 struct TailLds {
@@ -107,21 +106,6 @@ __global__ __launch_bounds__(TAIL_NT) void k_ba_tail(const BaDev* __restrict__ w
   TSTAMP(0);
 
   if (!ba_finished(B)) {     // (a window whose break test fired only consumes the energies of its final linearisation: P8)
-  if (flags & TAIL_WAIT_SC) {
-    // This kernel was launched BEFORE the Schur accumulation it consumes (which runs on the side stream, behind an event): its
-    // workgroups take their CUs while the chip is still empty instead of queueing behind the next batch's linearisation, and wait here.
-    // k_ba_sc_host never waits on anything, so it always completes; the poll is bounded all the same (~0.5 s) and a timeout poisons x.
-    if (tid == 0) {
-      int* cnt = &B.opt->sc_done;
-      int spins = 0;
-      while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nf && ++spins < (1 << 19)) __builtin_amdgcn_s_sleep(32);
-      misc[40] = spins < (1 << 19) ? 0.f : 1.f;
-      __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __syncthreads();           // (one L1 invalidate per CU: the waves of this workgroup share it)
-  }
   if (flags & TAIL_LAMBDA_DEV) lambda = B.opt->lambda;
   const double f = (double)1.0f / (1 + lambda);
   const double* adH = B.t_adHost;
@@ -490,7 +474,6 @@ __global__ __launch_bounds__(TAIL_NT) void k_ba_tail(const BaDev* __restrict__ w
   }
   {
     double* xout = B.sol + 3 * ((size_t)n * n + n);
-    if ((flags & TAIL_WAIT_SC) && misc[40] != 0.f && tid < n) xv[tid] = __builtin_nan("");   // the Schur kernel never signalled: make it visible
     if (tid < n) xout[tid] = xv[tid];
     // xAd[nf*h+t] = xF(h)^T adHostF[h+nf*t] + xF(t)^T adTargetF[h+nf*t]   (:289-291), float arithmetic
     float* xAd = const_cast<float*>(B.t_xAd);

@@ -149,9 +149,6 @@ extern "C" void sdso_ctx_destroy(sdso_ctx* ctx) {
   if (ctx->gammaB) hipFree(ctx->gammaB);
   if (ctx->scratch) hipFree(ctx->scratch);
   if (ctx->pinned) hipHostFree(ctx->pinned);
-  if (ctx->stream2) { hipStreamSynchronize(ctx->stream2); hipStreamDestroy(ctx->stream2); }
-  if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
-  if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
   hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -159,7 +156,6 @@ extern "C" const char* sdso_last_error(const sdso_ctx* ctx) { return ctx ? ctx->
 extern "C" void* sdso_ctx_stream(sdso_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 extern "C" int sdso_ctx_sync(sdso_ctx* ctx) {
   if (!ctx) return SDSO_ERR_STATE;
-  if (ctx->stream2) SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream2));
   SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return SDSO_OK;
 }

@@ -55,10 +55,6 @@ struct TrackBatch;   // tracker.hip
 struct sdso_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
-  // side stream of the BA resident loop: the Schur accumulation of a batch runs there, beside the fused tail kernel that was launched
-  // on `stream` ahead of it and waits for it in-kernel (ba.hip: launch_sc_async); created on first use
-  hipStream_t stream2 = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   std::string err;
   std::map<int, sdso::PyramidDev> pyr;
   std::map<int, sdso::RefDev> refs;

@@ -5,8 +5,7 @@ BASELINE configs[2] shape (1232x368, distinct pyramids, 4x2-tiled images, cooper
 Everything the fused kernel writes is read back per window and compared with the oracle's linearizeAll + applyRes + accumulate +
 solveSystemF on the same window: the RawResidualJacobian records it materialises (EFResidual::J of applied residuals,
 PointFrameResidual::J of the others), residual states / energies, JpJdF and the per-point terms bit-exact; the packed accumulators
-<= 3e-5 of their block maximum; x <= 2e-4 in the whitened metric.  Variants: Jacobians kept in registers (materialize = 0) and the
-LDS-DMA tap gather (SDSO_BA_GATHER=2, k_ba_lin_dma) and the one-residual-per-lane gather (SDSO_BA_DIRECT_TAPS)."""
+<= 3e-5 of their block maximum; x <= 2e-4 in the whitened metric.  Variant: Jacobians kept in registers (materialize = 0)."""
 import ctypes as C
 import os
 
@@ -71,28 +70,20 @@ def _gpu_readback(ctx, win, wid, materialize):
     return g
 
 
-@pytest.mark.parametrize("variant", ["materialize", "registers", "dma_gather", "dma_registers", "direct_taps"])
+@pytest.mark.parametrize("variant", ["materialize", "registers"])
 def test_fused_batch_matches_oracle_at_bench_config(gpu_ctx, oracle, bench_windows, variant):
     ctx = gpu_ctx
     materialize = "registers" not in variant
-    if variant == "direct_taps":
-        os.environ["SDSO_BA_DIRECT_TAPS"] = "1"
-    if variant.startswith("dma"):
-        os.environ["SDSO_BA_GATHER"] = "2"                                          # k_ba_lin_dma: taps by LDS-DMA rounds (default 1: cooperative quads)
-    try:
-        ids, Ws = [], []
-        for k, win in enumerate(bench_windows):
-            slots = [700 + 10 * k + f for f in range(win["nf"])]
-            for f in range(win["nf"]):
-                ctx.upload_pyramid(slots[f], win["pyrs"][f][:1])
-            W, keep = abi.make_ba_window(win, frame_slots=slots, dI_list=[p[0] for p in win["pyrs"]])
-            ctx.check(ctx.L.sdso_ba_upload_window(ctx.h, 70 + k, C.byref(W)))
-            ids.append(70 + k); Ws.append((W, keep))
-        ids = np.array(ids, np.int32)
-        ctx.check(ctx.L.sdso_ba_batch_create(ctx.h, len(ids), abi.ip(ids)))
-    finally:
-        os.environ.pop("SDSO_BA_DIRECT_TAPS", None)
-        os.environ.pop("SDSO_BA_GATHER", None)
+    ids, Ws = [], []
+    for k, win in enumerate(bench_windows):
+        slots = [700 + 10 * k + f for f in range(win["nf"])]
+        for f in range(win["nf"]):
+            ctx.upload_pyramid(slots[f], win["pyrs"][f][:1])
+        W, keep = abi.make_ba_window(win, frame_slots=slots, dI_list=[p[0] for p in win["pyrs"]])
+        ctx.check(ctx.L.sdso_ba_upload_window(ctx.h, 70 + k, C.byref(W)))
+        ids.append(70 + k); Ws.append((W, keep))
+    ids = np.array(ids, np.int32)
+    ctx.check(ctx.L.sdso_ba_batch_create(ctx.h, len(ids), abi.ip(ids)))
     ctx.check(ctx.L.sdso_ba_batch_set_materialize(ctx.h, int(materialize)))
     ctx.check(ctx.L.sdso_ba_batch_accumulate(ctx.h))
     ctx.check(ctx.L.sdso_ba_batch_solve(ctx.h, 1e-5, 0))

@@ -1,9 +1,7 @@
 """The A/B variants the library keeps behind environment variables, each through the parity tests of its path in a subprocess (the
 variables are read once per process: `static const ... getenv`).  Round-2 advisor finding: no in-suite test exercised them.
   SDSO_BA_TAIL=0        the separate fold / stitch / solve / resubstitute / step kernels instead of the fused tail kernel
-  SDSO_BA_SOLVE=2       with the above: k_ba_solve<2> (lane = original row)
   SDSO_BA_JSWAP=1       the fused linearisation writes the other Jacobian buffer and swaps (takeDataF) instead of refreshing in place
-  SDSO_BA_SC_ASYNC=1    Schur kernel on the side stream, in-kernel hand-off to the tail kernel
   SDSO_TRK_HOST_LM=1    the tracker's LM driver on the host (lock-step evaluations) instead of k_track_lm
   SDSO_TRK_LM_CLUSTER=1 / 2   k_track_lm with one workgroup per hypothesis (the fallback when a cluster is not co-resident) / clusters of two
                         (the split of the points changes the order of the float sums: a hypothesis that sits on an LM accept / stop threshold
@@ -11,7 +9,6 @@ variables are read once per process: `static const ... getenv`).  Round-2 adviso
                         eight lock-step hypotheses; every other cluster size from 2 to 8 reproduces the oracle's counts on these problems)
   SDSO_TRK_LM_TEST_DROP_MEMBER=1   test hook: the last member of every cluster exits at once (a cluster that is not co-resident)
   SDSO_TRACE_WAVE=1 / SDSO_TRACE_BAND=1   the per-wave traceStereo kernel / its LDS-band variant
-  SDSO_SC_WAVES=2       k_ba_sc_host with two waves per workgroup (four workgroups per CU; measured slower, kept as A/B)
   SDSO_BA_SOLVE_HOST=1  solveSystemF's SVD / orthogonalised-system branches on the host (solve_system_host, rounds 1-3) instead of k_ba_solve_alt"""
 import os
 import subprocess
@@ -27,11 +24,8 @@ BA = ["tests/test_ba_resident_gpu.py::test_batch_resident_loop", "tests/test_ba_
 BA_LIGHT = [BA[0], BA[2]]        # the batch loop and the fused kernel at the bench configuration (the suite has to fit the GPU box's time limit)
 VARIANTS = [
     ({"SDSO_BA_TAIL": "0"}, BA + ["tests/test_ba_gpu.py", "-k", "resident or fused or accumulate_solve or optimize_full_gn_loop or energy_gated or tables_linearize_apply or ragged or batch_equals_single or marginalize_points"]),
-    ({"SDSO_BA_TAIL": "0", "SDSO_BA_SOLVE": "2"}, ["tests/test_ba_gpu.py", "-k", "accumulate_solve or optimize_full_gn_loop"]),
     ({"SDSO_BA_SOLVE_HOST": "1"}, ["tests/test_ba_gpu.py::test_solver_mode_variants"]),
     ({"SDSO_BA_JSWAP": "1"}, BA_LIGHT),
-    ({"SDSO_SC_WAVES": "2"}, BA_LIGHT[1:]),
-    ({"SDSO_BA_SC_ASYNC": "1"}, BA_LIGHT),
     ({"SDSO_TRK_HOST_LM": "1"}, ["tests/test_tracker_gpu.py::test_track_newest_coarse_pose_within_1e5", "tests/test_tracker_gpu.py::test_track_hypotheses_in_lock_step",
                                  "tests/test_tracker_gpu.py::test_track_affine_modes"]),
     ({"SDSO_TRK_LM_CLUSTER": "1"}, ["tests/test_tracker_gpu.py::test_track_newest_coarse_pose_within_1e5", "tests/test_tracker_gpu.py::test_track_hypotheses_in_lock_step",
