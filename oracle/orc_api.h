@@ -200,6 +200,8 @@ int orc_ba_optimize(orc_ba* h, int mnumOptIts, double* state_out, float* idepth_
                     uint8_t* res_state_out, orc_ba_opt_result_t* out);
 /* the post-state of the last orc_ba_optimize: FullSystemOptimize.cpp:52-87, :142-203, :997-1041, AccumulatedSCHessian.cpp:34-60 */
 int orc_ba_get_post_state(orc_ba* h, orc_ba_post_state_t* out);
+/* lastX of every GN iteration of the latest orc_ba_optimize (iteration-major, 8nf+4 doubles each); returns the number of iterations */
+int orc_ba_get_x_trace(orc_ba* h, double* x, int cap_iterations);
 int orc_ba_marginalize_points(orc_ba* h, const uint8_t* marg_flag, double* HM_out, double* bM_out);
 /* host tables the product also derives (for table-level parity): precalc nf*nf*27 floats
  * {KRKi9,Kt3,R0 9,t0 3,aff2,b0 1}, adHost/adTarget nf*nf*64 doubles, adHTdeltaF nf*nf*8 floats */

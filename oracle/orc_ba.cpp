@@ -318,6 +318,7 @@ struct orc_ba {
   ~orc_ba() { delete red; }
   MatX lastHS;
   VecX lastbS, lastX;
+  std::vector<VecX> xTrace;   // lastX of every solveSystemF of the latest optimize() (test infrastructure: per-iteration parity of the pose updates)
   std::vector<VecX> lastNullspaces_pose, lastNullspaces_scale;
 
   // ---------------------------------------------------------------- host tables
@@ -1218,6 +1219,7 @@ struct orc_ba {
     if (nf < 3) mnumOptIts = 20;
     if (nf < 4) mnumOptIts = 15;
     for (Residual& r : res) if (!r.isLinearized) r.resetOOB();
+    xTrace.clear();
     double lastEnergy = linearizeAll(false);
     double lastEnergyL = calcLEnergy();
     double lastEnergyM = calcMEnergy();
@@ -1229,6 +1231,7 @@ struct orc_ba {
       backupState();
       getNullspaces();
       solveSystemF(iteration, lambda);
+      xTrace.push_back(lastX);
       bool canbreak = doStepFromBackup(stepsize, stepsize, stepsize, stepsize, stepsize);
       double newEnergy = linearizeAll(false);
       double newEnergyL = calcLEnergy();
@@ -1503,6 +1506,12 @@ extern "C" int orc_ba_optimize(orc_ba* h, int mnumOptIts, double* state_out, flo
   if (idepth_out) for (int i = 0; i < h->np; i++) idepth_out[i] = h->points[i].idepth;
   if (res_state_out) for (int i = 0; i < h->nr; i++) res_state_out[i] = (uint8_t)h->res[i].state_state;
   return 0;
+}
+// lastX (8nf+4 doubles) of every Gauss-Newton iteration of the latest orc_ba_optimize, iteration-major; returns the number of iterations
+extern "C" int orc_ba_get_x_trace(orc_ba* h, double* x, int cap_iterations) {
+  const int n = 4 + 8 * h->nf, its = (int)h->xTrace.size();
+  for (int it = 0; it < its && it < cap_iterations; it++) for (int i = 0; i < n; i++) x[(size_t)it * n + i] = h->xTrace[it][i];
+  return its;
 }
 extern "C" int orc_ba_get_post_state(orc_ba* h, orc_ba_post_state_t* o) {
   const int nf = h->nf, n = 4 + 8 * nf;

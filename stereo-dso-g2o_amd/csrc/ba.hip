@@ -370,6 +370,13 @@ static int upload_window_impl(sdso_ctx* ctx, int win, const sdso_ba_window_t* Wi
     }
     host_beg[nf] = (int)items.size();
   }
+  {
+    int p = 0;
+    for (int h = 0; h <= 8; h++) {
+      d.host_pt_beg[h] = p;
+      while (h < nf && p < np && Win->host[p] == h) p++;
+    }
+  }
   d.nchunks = (int)chunks.size();
   d.nitems = (int)items.size();
   W->nblk_res = (nr + BA_BLOCK - 1) / BA_BLOCK;

@@ -116,6 +116,7 @@ struct BaDev {
   const int* pair_chunk_beg;  // nf*nf+1
   const int4* items;        // {host, pbeg, pend, 0}
   const int* host_item_beg; // nf+1
+  int host_pt_beg[9];       // points of host h: [host_pt_beg[h], host_pt_beg[h + 1]) (points are in allPoints order: grouped by host)
   float* top_part;          // nchunks x 92 (91 sums + count)
   float* sc_part;           // nf x 20: Hcc (16) and bc (4) of every host's Schur workgroup; the fold adds the hosts
   double* e_part;           // energy partials of linearize (per workgroup)

@@ -1005,18 +1005,29 @@ __global__ __launch_bounds__(BA_BLOCK, 3) void k_ba_sc_host(const BaDev* __restr
   const int nf = B.nf, h = blockIdx.x;
   if (h >= nf) return;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#ifdef SDSO_SC_STAMPS   // diagnostic build (tools/mk_variant.sh scst -DSDSO_SC_STAMPS): shader-clock ticks of wave 0 of two workgroups per phase, printed
+  unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int stn = 0;
+#define SCS() do { if (stn < 8) st[stn++] = __builtin_amdgcn_s_memtime(); } while (0)
+  unsigned long long sub[6] = {0, 0, 0, 0, 0, 0}, sub_t = 0;     // inside the group loop: wait for the records | r_cj | phase 1 | DMA issue + inputs | phase 2
+#define SCSUB(i) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); sub[i] += tn_ - sub_t; sub_t = tn_; } while (0)
+#define SCSUB0() do { sub_t = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SCS() do { } while (0)
+#define SCSUB(i) do { } while (0)
+#define SCSUB0() do { } while (0)
+#endif
+  SCS();
   constexpr int SC_NT = 15;                                  // tile t of pair (a <= b): sc_ut(a, b); 10 + a: column tile 4 of row a; 14: the corner
   constexpr int BIN_E = 64 * 64, BIN_EB = BIN_E + 8 * 32;
-  constexpr int SC_NEED = SC_NT * 256 + BIN_EB + 64;          // one tile buffer + the bins laid out behind it
-  constexpr int SC_LDS0 = NW * SCH_WAVE > (NW / 2) * SC_NT * 256 ? NW * SCH_WAVE : (NW / 2) * SC_NT * 256;
-  constexpr int SC_LDS = SC_LDS0 > SC_NEED ? SC_LDS0 : SC_NEED;
+  constexpr int SC_NEED = 2 * SC_NT * 256 + BIN_EB + 64;      // two tile buffers + the bins laid out behind them
+  constexpr int SC_LDS = NW * SCH_WAVE > SC_NEED ? NW * SCH_WAVE : SC_NEED;
   __shared__ __align__(16) float stage_all[SC_LDS];
   float (*tiles)[SC_NT * 256] = reinterpret_cast<float (*)[SC_NT * 256]>(stage_all);   // two waves' worth of accumulator tiles (after the loop)
   float* const bufA = stage_all + wv * SCH_WAVE;             // [2][SCH_REC]
   float* const bufT = bufA + 2 * SCH_REC;
   float (*pt)[8] = reinterpret_cast<float (*)[8]>(bufT + SCH_REC);
-  const int ib = B.host_item_beg[h], ie = B.host_item_beg[h + 1];
-  const int pb = ib < ie ? B.items[ib].y : 0, pe = ib < ie ? B.items[ie - 1].z : 0;
+  const int pb = B.host_pt_beg[h], pe = B.host_pt_beg[h + 1];     // (in the descriptor itself: no dependent round trip before the first DMA)
   te_f4 acc[SC_NT];
 #pragma unroll
   for (int t = 0; t < SC_NT; t++) acc[t] = (te_f4){0.f, 0.f, 0.f, 0.f};
@@ -1063,15 +1074,18 @@ __global__ __launch_bounds__(BA_BLOCK, 3) void k_ba_sc_host(const BaDev* __restr
     if (group_p0(0) < pe) dma_records(r0, r1 - r0, bufA, bufT);
   }
   fetch_in(group_p0(1), gnext);
+  SCS();
   for (int gidx = 0;; gidx++) {
     const int p0 = group_p0(gidx);
     if (p0 >= pe) break;
     const int npts = min(16, pe - p0);
     float* const curA = bufA + (gidx & 1) * SCH_REC;
     const int r0 = __builtin_amdgcn_readlane(gcur.rb, 0);
+    SCSUB0();
     // this group's records (and the inputs of the next one) have landed; the LDS-DMA is invisible to the compiler's own scoreboard
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
+    SCSUB(0);
     {  // the JpJdF halves, compact, for the back-substitution: coalesced 1-KB stores straight from the stage
       const int npieces = (__builtin_amdgcn_readlane(gcur.rb, 16) - r0) * 2;
       float* dst = B.r_cj + (size_t)r0 * 8;
@@ -1081,6 +1095,7 @@ __global__ __launch_bounds__(BA_BLOCK, 3) void k_ba_sc_host(const BaDev* __restr
         if (c < npieces) *(float4*)(dst + (size_t)c * 4) = *(const float4*)(curA + c * 4);
       }
     }
+    SCSUB(1);
     {  // ---- phase 1
       const int base = __shfl(gcur.rb, pl, 64) - r0;           // first record of the lane's point inside the stage
       const int cnt = 8 - (__clz((int)~gcur.order) >> 2);           // its records: the nibbles of `order` that are not 0xF (targets are < 8)
@@ -1149,6 +1164,7 @@ __global__ __launch_bounds__(BA_BLOCK, 3) void k_ba_sc_host(const BaDev* __restr
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    SCSUB(2);
     {
       const int pn = group_p0(gidx + 1);
       if (pn < pe) {
@@ -1158,6 +1174,7 @@ __global__ __launch_bounds__(BA_BLOCK, 3) void k_ba_sc_host(const BaDev* __restr
     }
     GroupIn gnn;
     fetch_in(group_p0(gidx + 2), gnn);
+    SCSUB(3);
     {  // ---- phase 2: the group's four MFMA operand sets (points 4 u + kq)
       float zz[4][5], hx[4];
 #pragma unroll
@@ -1192,7 +1209,9 @@ __global__ __launch_bounds__(BA_BLOCK, 3) void k_ba_sc_host(const BaDev* __restr
     gcur = gnext; gnext = gnn;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();          // the next group overwrites pt[]
+    SCSUB(4);
   }
+  SCS();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();                            // the tiles lie over the waves' stages
   // ---- fixed-order tree over the four waves: (3 -> 1, 2 -> 0), then (1 -> 0)
@@ -1212,42 +1231,42 @@ __global__ __launch_bounds__(BA_BLOCK, 3) void k_ba_sc_host(const BaDev* __restr
   __syncthreads();
   if (wv < 2) add(tiles[wv]);
   __syncthreads();
-  if (wv == 1) put(tiles[0]);
+  if (wv < 2) put(tiles[wv]);                 // (0 + 2) and (1 + 3)
   __syncthreads();
-  // ---- the host's bins.  acc[a][b][v] = D'[16a + 4*kq + v][16b + ci]: wave 0 lays the finished tiles out in LDS the way the bins lie in
-  // memory (64-float blocks per (t1, t2)), then all four waves write them out, one 256-byte block per store
+  // ---- the host's bins.  Tile element e = (t * 4 + v) * 64 + lane' is D'[16a + 4*kq + v][16b + ci] (lane' = 16 kq + ci): all four waves add
+  // the two halves ((0 + 2) + (1 + 3): the order the tree always had) and lay the sums out in LDS the way the bins lie in memory (64-float
+  // blocks per (t1, t2)), then write them out, one 256-byte block per store
   const int nf2 = nf * nf;
   float* accD = B.accum + acc_off_D(nf);
   float* accE = B.accum + acc_off_E(nf);
   float* accEB = B.accum + acc_off_EB(nf);
-  float* bins = stage_all + SC_NT * 256;       // the second tile buffer: free since the tree's second barrier
-  static_assert(SC_NEED <= SC_LDS, "the bins fit behind the first tile buffer");
-  if (wv == 0) {
-    add(tiles[0]);
-#pragma unroll
-    for (int a = 0; a < 4; a++) {
-#pragma unroll
-      for (int v = 0; v < 4; v++) {
-        const int Rr = 16 * a + 4 * kq + v, t1 = Rr >> 3, ra = Rr & 7;
-#pragma unroll
-        for (int b = a; b < 4; b++) {              // element (Rr, Cc) of the upper triangle and its mirror image (Cc, Rr)
-          const int Cc = 16 * b + ci, t2 = Cc >> 3, cc = Cc & 7;
-          const float val = acc[sc_ut(a, b)][v];
-          if (b > a || Rr <= Cc) {
-            bins[(t1 * 8 + t2) * 64 + ra * 8 + cc] = val;
-            if (Rr != Cc) bins[(t2 * 8 + t1) * 64 + cc * 8 + ra] = val;
-          }
-        }
-        if (ci < 4) bins[BIN_E + t1 * 32 + ra * 4 + ci] = acc[10 + a][v];
-        if (ci == 4) bins[BIN_EB + t1 * 8 + ra] = acc[10 + a][v];
-      }
-    }
+  float* bins = stage_all + 2 * SC_NT * 256;
+  static_assert(SC_NEED <= SC_LDS, "the bins fit behind the tile buffers");
+  SCS();
+  {
     float* hp = B.sc_part + (size_t)h * 20;      // Hcc (16) and bc (4) of this host; the fold adds the hosts
-    if (kq == 0) {
 #pragma unroll
-      for (int v = 0; v < 4; v++) {
-        if (ci < 4) hp[v * 4 + ci] = acc[14][v];
-        if (ci == 4) hp[16 + v] = acc[14][v];
+    for (int j = 0; j < SC_NT; j++) {
+      const int e = (int)threadIdx.x + BA_BLOCK * j;          // BA_BLOCK = 256 = one tile: j is the tile, the thread its (v, lane')
+      const float val = tiles[0][e] + tiles[1][e];
+      const int v = (e >> 6) & 3, ll = e & 63, kq2 = ll >> 4, ci2 = ll & 15;
+      if (j < 10) {
+        int a = 0, jj = j;                                   // sc_ut^-1: rows of 4, 3, 2, 1 upper tiles
+        while (jj >= 4 - a) { jj -= 4 - a; a++; }
+        const int b = a + jj;
+        const int Rr = 16 * a + 4 * kq2 + v, t1 = Rr >> 3, ra = Rr & 7;
+        const int Cc = 16 * b + ci2, t2 = Cc >> 3, cc = Cc & 7;
+        if (b > a || Rr <= Cc) {                             // element (Rr, Cc) of the upper triangle and its mirror image (Cc, Rr)
+          bins[(t1 * 8 + t2) * 64 + ra * 8 + cc] = val;
+          if (Rr != Cc) bins[(t2 * 8 + t1) * 64 + cc * 8 + ra] = val;
+        }
+      } else if (j < 14) {
+        const int Rr = 16 * (j - 10) + 4 * kq2 + v, t1 = Rr >> 3, ra = Rr & 7;
+        if (ci2 < 4) bins[BIN_E + t1 * 32 + ra * 4 + ci2] = val;
+        if (ci2 == 4) bins[BIN_EB + t1 * 8 + ra] = val;
+      } else if (kq2 == 0) {
+        if (ci2 < 4) hp[v * 4 + ci2] = val;
+        if (ci2 == 4) hp[16 + v] = val;
       }
     }
   }
@@ -1263,6 +1282,15 @@ __global__ __launch_bounds__(BA_BLOCK, 3) void k_ba_sc_host(const BaDev* __restr
     if (t1 < nf) accE[(size_t)(h + t1 * nf) * 32 + (idx & 31)] = bins[BIN_E + idx];
   }
   if (wv == 1 && (lane >> 3) < nf) accEB[(size_t)(h + (lane >> 3) * nf) * 8 + (lane & 7)] = bins[BIN_EB + lane];
+#ifdef SDSO_SC_STAMPS
+  if (wv == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SCS();
+    if ((blockIdx.x == 0 || blockIdx.x == 5) && (blockIdx.y == 0 || blockIdx.y == 100) && lane == 0)
+      printf("sc_host (%d,%d) ticks: prologue %llu  group loop %llu  wave tree %llu  bins %llu | total %llu  (points %d)  loop: wait %llu  r_cj %llu  phase 1 %llu  dma + inputs %llu  phase 2 %llu\n",
+             blockIdx.x, blockIdx.y, st[1] - st[0], st[2] - st[1], st[3] - st[2], st[4] - st[3], st[4] - st[0], pe - pb, sub[0], sub[1], sub[2], sub[3], sub[4]);
+  }
+#endif
 }
 
 }  // namespace sdso

@@ -31,8 +31,32 @@ def windows(n):
             yield item
 
 
-def loop_distances(ctx, oracle, win, its=6):
-    """(device - truth, cpu_f32 - truth) as (max |state|, max |idepth|) pairs, and the iteration counts"""
+STATE_SCALE = np.array([0.5, 0.5, 0.5, 1.0, 1.0, 1.0, 10.0, 1000.0])   # state_scaled = SCALE * state (HessianBlocks.h:54-61)
+
+
+def device_x_trace(ctx, wid, n, its):
+    """lastX of every iteration of the resident loop, one iteration at a time on a one-window batch (the kernels of sdso_ba_optimize)"""
+    ids = np.array([wid], np.int32)
+    ctx.check(ctx.L.sdso_ba_batch_create(ctx.h, 1, abi.ip(ids)))
+    ctx.check(ctx.L.sdso_ba_batch_optimize_begin(ctx.h, 1))
+    xg = np.zeros((its, n))
+    for it in range(its):
+        ctx.check(ctx.L.sdso_ba_batch_accumulate(ctx.h))
+        ctx.check(ctx.L.sdso_ba_batch_solve_step(ctx.h, 0.1 * 0.25 ** it, 1 if it >= 2 else 0))
+        ctx.check(ctx.L.sdso_ba_batch_get_x(ctx.h, abi.dp(xg[it:it + 1])))
+    og = (abi.BAOptResult * 1)()
+    ctx.check(ctx.L.sdso_ba_batch_optimize_end(ctx.h, og))
+    return xg, og[0].iterations
+
+
+def pose_update_errors(x, xref, nf, its):
+    """per iteration: max over frames of |x - xref| * SCALE on the six pose entries (the units the pose moves in)"""
+    return [float(np.abs((x[it, 4:] - xref[it, 4:]).reshape(nf, 8) * STATE_SCALE)[:, :6].max()) for it in range(its)]
+
+
+def loop_distances(ctx, oracle, win, its=6, traces=None):
+    """(device - truth, cpu_f32 - truth) as (max |state|, max |idepth|) pairs, and the iteration counts.  traces: a dict that receives the
+    per-iteration distance of the pose updates from the truth's ("dev", "cpu": lists over the iterations all three loops ran)"""
     nf, npts, nr = win["nf"], win["np"], win["nr"]
     for f in range(nf):
         ctx.upload_pyramid(40 + f, win["pyrs"][f][:1])
@@ -44,15 +68,23 @@ def loop_distances(ctx, oracle, win, its=6):
             h = oracle.orc_ba_create(C.byref(W))
             s, i, o = np.zeros((nf, 10)), np.zeros(npts, np.float32), abi.BAOptResult()
             oracle.orc_ba_optimize(h, its, abi.dp(s), abi.fp(i), None, C.byref(o))
+            xt = np.zeros((8, 8 * nf + 4))
+            oracle.orc_ba_get_x_trace(h, abi.dp(xt), 8)
             oracle.orc_ba_destroy(h)
         finally:
             oracle.orc_set_acc64(0)
-        res[mode] = (s, i, o.iterations)
+        res[mode] = (s, i, o.iterations, xt)
     ctx.check(ctx.L.sdso_ba_upload_window(ctx.h, 3, C.byref(W)))
     s, i, o = np.zeros((nf, 10)), np.zeros(npts, np.float32), abi.BAOptResult()
     ctx.check(ctx.L.sdso_ba_optimize(ctx.h, 3, its, abi.dp(s), abi.fp(i), None, C.byref(o)))
+    if traces is not None:
+        ctx.check(ctx.L.sdso_ba_upload_window(ctx.h, 3, C.byref(W)))
+        xg, itg = device_x_trace(ctx, 3, 8 * nf + 4, its if nf >= 4 else 15)
+        common = min(itg, res["f32"][2], res["f64"][2], its)
+        traces["dev"] = pose_update_errors(xg, res["f64"][3], nf, common)
+        traces["cpu"] = pose_update_errors(res["f32"][3], res["f64"][3], nf, common)
     ctx.check(ctx.L.sdso_ba_release_window(ctx.h, 3))
-    s64, i64, it64 = res["f64"]
+    s64, i64, it64 = res["f64"][:3]
     dev = (np.abs(s - s64).max(), np.abs(i.astype(np.float64) - i64).max())
     cpu = (np.abs(res["f32"][0] - s64).max(), np.abs(res["f32"][1].astype(np.float64) - i64).max())
     return dev, cpu, (o.iterations, res["f32"][2], it64)
