@@ -413,6 +413,14 @@ def main():
                          "kernel_avg_ms": avg_ms, "launches": klaunch, "algorithmic_bytes_per_unit": wl.bytes_per_unit},
             "extra": extra,
         }
+        tr = out["roofline"]["traffic"]
+        if tr and avg_ms > 0:
+            # what the counters say about the bound: the kernel's REAL HBM traffic (128-byte lines of sparse 16-byte taps, the records) over
+            # its duration, next to the rate a plain device copy reaches on this part (profiles/r02_copy_bw.json: 4.84 TB/s read + write)
+            out["roofline"]["traffic_rate_GBps"] = tr / (avg_ms * 1e-3) / 1e9
+            out["roofline"]["bound_note"] = ("hbm: the launch moves %.2fx its algorithmic bytes at %.2f TB/s, i.e. at or above the 4.84 TB/s a device copy "
+                                             "reaches here; SQ counters (profiles/) show the waves waiting on memory, not on issue" % (
+                                                 tr / (per_launch_units * wl.bytes_per_unit), tr / (avg_ms * 1e-3) / 1e12))
         out["extra"]["host_enqueue_ms_per_step"] = t_enq / args.steps * 1e3
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = wl.cpu_baseline()

@@ -359,6 +359,14 @@ int sdso_ba_marginalize_points(sdso_ctx* ctx, int win, const uint8_t* marg_flag,
 int sdso_ba_marginalize_frame(int nf, int idx, const double* prior8, const double* delta_prior8,
                               const double* HM_in, const double* bM_in, double* HM_out, double* bM_out);
 
+/* EnergyFunctional::calcLEnergyF_MT (EnergyFunctional.cpp:420-442; EnergyFunctional.h:82) and calcMEnergyF (:344-351; .h:83) at the
+ * window's current state: the values themselves (FullSystem::calcLEnergy / calcMEnergy return 0 under setting_forceAceptStep before
+ * they ever call these, FullSystemOptimize.cpp:374-376, :1056).  Either pointer may be NULL. */
+int sdso_ba_calc_energies(sdso_ctx* ctx, int win, double* EL, double* EM);
+/* What EnergyFunctional::setDeltaF (EnergyFunctional.cpp:173-207; .h:75) leaves behind at the window's current state: cDeltaF (4),
+ * EFFrame::delta and delta_prior (nf*8 each), EFPoint::deltaF (np); adHTdeltaF comes with sdso_ba_get_tables.  Any pointer may be NULL. */
+int sdso_ba_get_deltas(sdso_ctx* ctx, int win, float* cDeltaF, double* frame_delta, double* frame_delta_prior, float* point_deltaF);
+
 /* keep projectedTo / centerProjectedTo of PointFrameResidual (Residuals.h:96-99) for
  * sdso_ba_get_linearization; off by default (76 B of extra stores per residual). */
 int sdso_ba_keep_projections(sdso_ctx* ctx, int win, int on);
@@ -404,7 +412,9 @@ int sdso_ba_batch_get_x(sdso_ctx* ctx, double* x /* nwin*(8nf+4) */);
  * them: the STITCHED systems (AccumulatedTopHessianSSE::stitchDoubleMT without / with priors, AccumulatedTopHessian.h:95-148;
  * AccumulatedSCHessianSSE::stitchDoubleMT, AccumulatedSCHessian.h:96-135) of the accumulators sdso_ba_accumulate left: (8nf+4)^2
  * row-major + (8nf+4) doubles each, any pointer may be NULL.  solveSystemF adds them up (:856-868); the fused kernels never
- * materialise them, this call runs the stitch kernels on demand (synchronises). */
+ * materialise them, this call runs the stitch kernels on demand (synchronises).  Right after sdso_ba_marginalize_points the same call
+ * returns what marginalizePointsF stitches (EnergyFunctional.cpp:707-717): HA / bA = M, Mb of accSSE_top_A->stitchDouble(.., false, false)
+ * over addPoint<2> of the flagged points, Hsc / bsc = Msc, Mbsc. */
 int sdso_ba_get_stitched(sdso_ctx* ctx, int win, double* HA, double* bA, double* HL, double* bL, double* Hsc, double* bsc);
 
 /* FullSystem::optimize (FullSystemOptimize.cpp:871-1041, DSO-native loop) for EVERY window of the batch, device-resident: the host

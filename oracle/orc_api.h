@@ -202,6 +202,9 @@ int orc_ba_optimize(orc_ba* h, int mnumOptIts, double* state_out, float* idepth_
 int orc_ba_get_post_state(orc_ba* h, orc_ba_post_state_t* out);
 /* lastX of every GN iteration of the latest orc_ba_optimize (iteration-major, 8nf+4 doubles each); returns the number of iterations */
 int orc_ba_get_x_trace(orc_ba* h, double* x, int cap_iterations);
+/* calcLEnergyF_MT / calcMEnergyF (EnergyFunctional.cpp:420-442, :344-351) and what setDeltaF leaves behind (:173-207) */
+int orc_ba_calc_energies(orc_ba* h, double* EL, double* EM);
+int orc_ba_get_deltas(orc_ba* h, float* cDeltaF, double* frame_delta, double* frame_delta_prior, float* point_deltaF);
 int orc_ba_marginalize_points(orc_ba* h, const uint8_t* marg_flag, double* HM_out, double* bM_out);
 /* host tables the product also derives (for table-level parity): precalc nf*nf*27 floats
  * {KRKi9,Kt3,R0 9,t0 3,aff2,b0 1}, adHost/adTarget nf*nf*64 doubles, adHTdeltaF nf*nf*8 floats */

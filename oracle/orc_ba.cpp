@@ -1563,6 +1563,23 @@ extern "C" int orc_ba_marginalize_points(orc_ba* h, const uint8_t* marg_flag, do
   if (bM_out) for (int i = 0; i < n; i++) bM_out[i] = h->bM[i];
   return 0;
 }
+// EnergyFunctional::calcLEnergyF_MT / calcMEnergyF (EnergyFunctional.cpp:420-442, :344-351) at the current state, whatever forceAcceptStep says
+extern "C" int orc_ba_calc_energies(orc_ba* h, double* EL, double* EM) {
+  if (EL) *EL = h->calcLEnergyF();
+  if (EM) *EM = h->calcMEnergyF();
+  return 0;
+}
+// what setDeltaF leaves behind (EnergyFunctional.cpp:173-207): cDeltaF, EFFrame::delta / delta_prior, EFPoint::deltaF
+extern "C" int orc_ba_get_deltas(orc_ba* h, float* cDeltaF, double* frame_delta, double* frame_delta_prior, float* point_deltaF) {
+  if (cDeltaF) for (int i = 0; i < 4; i++) cDeltaF[i] = h->cDeltaF[i];
+  for (int f = 0; f < h->nf; f++)
+    for (int i = 0; i < 8; i++) {
+      if (frame_delta) frame_delta[f * 8 + i] = h->frames[f].delta[i];
+      if (frame_delta_prior) frame_delta_prior[f * 8 + i] = h->frames[f].delta_prior[i];
+    }
+  if (point_deltaF) for (int i = 0; i < h->np; i++) point_deltaF[i] = h->points[i].deltaF;
+  return 0;
+}
 extern "C" int orc_ba_get_tables(orc_ba* h, float* precalc, double* adHost, double* adTarget, float* adHTdeltaF) {
   int nf = h->nf;
   if (precalc)

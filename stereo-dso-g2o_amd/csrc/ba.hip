@@ -54,6 +54,7 @@ struct BaWindowDev {
   float* accum_own = nullptr;   // the window's own packed accumulator block (d.accum points into the batch block while batched)
   bool in_batch = false;
   bool accumulated = false;
+  bool marg_accumulated = false;  // the packed block holds the sums of the latest sdso_ba_marginalize_points (addPoint<2> + the Schur addPoint of the flagged points)
   bool has_lin_cached = false;  // some residual of the window is linearized (updated wherever h_lin changes)
   bool l_dirty = false;         // p_out's L sums (linearised / marginalised residuals) may be non-zero: the next plain Schur launch clears them
   bool j_inplace_last = false;  // the latest linearisation was the fused kernel's, written IN PLACE into EFResidual::J's slot (BaDev::jfix):
@@ -816,7 +817,7 @@ extern "C" int sdso_ba_accumulate(sdso_ctx* ctx, int win) {
   GET_WIN();
   launch_accumulate(ctx, single(W), nullptr, false);
   SDSO_HIP(ctx, hipGetLastError());
-  W->accumulated = true;
+  W->accumulated = true; W->marg_accumulated = false;
   return SDSO_OK;
 }
 
@@ -1016,7 +1017,7 @@ extern "C" int sdso_ba_solve(sdso_ctx* ctx, int win, int iteration, double lambd
 
 extern "C" int sdso_ba_get_stitched(sdso_ctx* ctx, int win, double* HA, double* bA, double* HL, double* bL, double* Hsc, double* bsc) {
   GET_WIN();
-  SDSO_REQUIRE(ctx, W->accumulated, "sdso_ba_get_stitched needs sdso_ba_accumulate first");
+  SDSO_REQUIRE(ctx, W->accumulated || W->marg_accumulated, "sdso_ba_get_stitched needs sdso_ba_accumulate (or sdso_ba_marginalize_points) first");
   ensure_folded_win(ctx, W);
   launch_stitch(ctx, single(W));
   SDSO_HIP(ctx, hipGetLastError());
@@ -1089,9 +1090,9 @@ extern "C" int sdso_ba_get_tables(sdso_ctx* ctx, int win, float* precalc, double
 
 // EnergyFunctional::calcLEnergyF_MT (EnergyFunctional.cpp:420-442) and calcMEnergyF (:344-351); both are 0 under
 // setting_forceAceptStep (FullSystemOptimize.cpp:374-376, :1056)
-static int calc_energies(sdso_ctx* ctx, BaWindowDev* W, double* EL, double* EM) {
+static int calc_energies(sdso_ctx* ctx, BaWindowDev* W, double* EL, double* EM, bool always = false) {
   *EL = 0; *EM = 0;
-  if (W->forceAccept) return SDSO_OK;
+  if (W->forceAccept && !always) return SDSO_OK;
   const int nf = W->d.nf, n = W->d.n;
   const int nblk = W->d.nchunks + W->nblk_pts;
   double E = 0;
@@ -1111,11 +1112,41 @@ static int calc_energies(sdso_ctx* ctx, BaWindowDev* W, double* EL, double* EM) 
   }
   *EL = E;
   std::vector<double> delta(n);                               // getStitchedDeltaF (:1021-1032)
-  for (int i = 0; i < 4; i++) delta[i] = W->calib.value_minus_value_zero[i];
+  for (int i = 0; i < 4; i++) delta[i] = (double)W->tab.cDeltaF[i];       // d.head<CPARS>() = cDeltaF.cast<double>()
   for (int f = 0; f < nf; f++) for (int i = 0; i < 8; i++) delta[4 + 8 * f + i] = W->frames[f].delta[i];
   double em = 0;
   for (int i = 0; i < n; i++) { double s = 0; for (int k = 0; k < n; k++) s += W->HM[(size_t)i * n + k] * delta[k]; em += delta[i] * (2 * W->bM[i] + s); }
   *EM = em;
+  return SDSO_OK;
+}
+
+// EnergyFunctional::calcLEnergyF_MT (EnergyFunctional.cpp:420-442) and calcMEnergyF (:344-351) as members a caller may invoke: the values
+// themselves, whatever setting_forceAceptStep says (that test lives in FullSystem::calcLEnergy / calcMEnergy, FullSystemOptimize.cpp:374-376)
+extern "C" int sdso_ba_calc_energies(sdso_ctx* ctx, int win, double* EL, double* EM) {
+  GET_WIN();
+  double el = 0, em = 0;
+  const int rc = calc_energies(ctx, W, &el, &em, true);
+  if (rc) return rc;
+  if (EL) *EL = el;
+  if (EM) *EM = em;
+  return SDSO_OK;
+}
+
+// What EnergyFunctional::setDeltaF leaves in the reference's objects (EnergyFunctional.cpp:173-207) at the window's current state:
+// cDeltaF (4 floats), EFFrame::delta / delta_prior (nf*8 doubles each), EFPoint::deltaF (np floats).  Any pointer may be NULL.
+extern "C" int sdso_ba_get_deltas(sdso_ctx* ctx, int win, float* cDeltaF, double* frame_delta, double* frame_delta_prior, float* point_deltaF) {
+  GET_WIN();
+  const int nf = W->d.nf, np = W->d.np;
+  if (cDeltaF) for (int i = 0; i < 4; i++) cDeltaF[i] = W->tab.cDeltaF[i];
+  for (int f = 0; f < nf; f++)
+    for (int i = 0; i < 8; i++) {
+      if (frame_delta) frame_delta[f * 8 + i] = W->frames[f].delta[i];
+      if (frame_delta_prior) frame_delta_prior[f * 8 + i] = W->frames[f].delta_prior[i];
+    }
+  if (point_deltaF && np) {
+    SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    SDSO_HIP(ctx, hipMemcpy(point_deltaF, W->d.p_delta, sizeof(float) * np, hipMemcpyDeviceToHost));
+  }
   return SDSO_OK;
 }
 
@@ -1294,6 +1325,7 @@ extern "C" int sdso_ba_marginalize_points(sdso_ctx* ctx, int win, const uint8_t*
   if (HM_out) std::memcpy(HM_out, W->HM.data(), sizeof(double) * n * n);
   if (bM_out) std::memcpy(bM_out, W->bM.data(), sizeof(double) * n);
   W->accumulated = false;
+  W->marg_accumulated = true;
   return SDSO_OK;
 }
 
@@ -1875,7 +1907,11 @@ static int opt_iteration(sdso_ctx* ctx, OptRun& R, int it) {
 int optimize_resident_single(sdso_ctx* ctx, BaWindowDev* W, int mnumOptIts, sdso_ba_opt_result_t* res) {
   OptRun R;
   R.L = single(W); R.W = {W};
-  R.materialize = true; R.keep_hs = true;
+  // RawResidualJacobian records on demand: nothing inside the loop reads the records of a residual that is being re-linearised (the
+  // accumulators take them from registers; linearised residuals keep the records fixLinearizationF saw), and the closing
+  // linearizeAll(true) — k_ba_linearize + k_ba_apply in opt_finish — writes the records of the final state, which is what
+  // PointFrameResidual::J / EFResidual::J hold when FullSystem::optimize returns.  296 B less store traffic per residual and iteration.
+  R.materialize = false; R.keep_hs = true;
   // refused before anything is touched: opt_begin would already issue a collective and reset the window's residuals
   if (comm_nranks(ctx) > 1) return sdso::fail(ctx, SDSO_ERR_STATE, "sdso_ba_optimize is a single-rank call; sharded windows use sdso_ba_batch_optimize");
   R.local_only = true;

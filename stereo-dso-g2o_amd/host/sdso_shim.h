@@ -15,14 +15,22 @@
 //   void EnergyFunctional::marginalizePointsF()                                                                      OptimizationBackend/EnergyFunctional.h:69
 //   float FullSystem::optimize(int mnumOptIts)                                                                       FullSystem/FullSystemOptimize.cpp:871
 //   ImmaturePointStatus ImmaturePoint::traceStereo(FrameHessian* frame, Mat33f K, bool mode_right)                   FullSystem/ImmaturePoint.h:89
+//   void CoarseTracker::setCoarseTrackingRef(std::vector<FrameHessian*>, FrameHessian* fh_right, CalibHessian)        FullSystem/CoarseTracker.h:71-72
+//   void CoarseTracker::setCTRefForFirstFrame(std::vector<FrameHessian*>)                                           FullSystem/CoarseTracker.cpp:794-805
+//   double PointFrameResidual::linearize(CalibHessian*) / void applyRes(bool)                                        FullSystem/Residuals.h:103, :113
+//   AccumulatedTopHessianSSE::{setZero, addPoint<mode>, addPointsInternal<mode>, stitchDouble, stitchDoubleMT}        OptimizationBackend/AccumulatedTopHessian.h:66-97, :162-169
+//   AccumulatedSCHessianSSE::{setZero, addPoint, addPointsInternal, stitchDouble, stitchDoubleMT}                     OptimizationBackend/AccumulatedSCHessian.h:66-96, :155-160
+//   EnergyFunctional::{calcLEnergyF_MT, calcMEnergyF, setDeltaF, setAdjointsF}                                       OptimizationBackend/EnergyFunctional.h:75-86
 #pragma once
 #include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <type_traits>
 #include <utility>
+#include <functional>
 #include <stdexcept>
 #include <string>
+#include <unordered_map>
 #include <vector>
 #include "../../include/sdso_abi.h"
 
@@ -131,7 +139,86 @@ class CoarseTracker {
     refFrameID = refFrameID_;
     firstCoarseRMSE = -1;
   }
-  // bool trackNewestCoarse(FrameHessian* newFrameHessian, SE3& lastToNew_out, AffLight& aff_g2l_out, int coarsestLvl, Vec5 minResForAbort)
+  // void setCoarseTrackingRef(std::vector<FrameHessian*> frameHessians, FrameHessian* fh_right, CalibHessian Hcalib) — CoarseTracker.h:71-72,
+  // CoarseTracker.cpp:807-826 with makeCoarseDepthL0 (:275-534) entirely on the device.  STEP1 (:288-356): every point whose residual into
+  // the newest keyframe is IN is re-observed by static stereo — ImmaturePoint at the rounded centerProjectedTo on fh_target, traceStereo
+  // into fh_right with the interval [0.1, 1.9] * centerProjectedTo[2], and where that is IPS_GOOD back again from lastTraceUV —
+  // (sdso_stereo_match_batch: ONE launch chain for all points), the accept rule of :329-341 picks idepth_stereo or centerProjectedTo[2],
+  // weight = sqrtf(1e-3 / (HdiF + 1e-12)); STEP2-5 = sdso_track_make_ref.  `slot_of` maps a FrameHessian to the pyramid slot it was
+  // uploaded to; `baseline` is the global of util/settings.h that traceStereo reads (ImmaturePoint.cpp:101).
+  std::function<int(const void*)> slot_of;
+  float baseline = 0.f;
+  int pc_n[SDSO_PYR_LEVELS] = {0, 0, 0, 0, 0, 0};
+  template <class FrameHessianT, class CalibHessianT>
+  void setCoarseTrackingRef(std::vector<FrameHessianT*> frameHessians, FrameHessianT* fh_right, CalibHessianT Hcalib) {
+    if (frameHessians.empty() || !slot_of) throw Error("setCoarseTrackingRef: no frames / slot_of not set");
+    FrameHessianT* lastRef = frameHessians.back();           // (= fh_target of makeCoarseDepthL0)
+    std::vector<float> fu, fv, imin, imax, cpt2, wgt;
+    for (FrameHessianT* fh : frameHessians)
+      for (auto* ph : fh->pointHessians) {
+        if (ph->lastResiduals[0].first != 0 && (int)ph->lastResiduals[0].second == 0 /* ResState::IN */) {
+          auto* r = ph->lastResiduals[0].first;
+          const int u = r->centerProjectedTo[0] + 0.5f;      // :303-304
+          const int v = r->centerProjectedTo[1] + 0.5f;
+          fu.push_back((float)u); fv.push_back((float)v);
+          imin.push_back(r->centerProjectedTo[2] * 0.1f);     // :311-312
+          imax.push_back(r->centerProjectedTo[2] * 1.9f);
+          cpt2.push_back(r->centerProjectedTo[2]);
+          wgt.push_back(sqrtf(1e-3 / (ph->efPoint->HdiF + 1e-12)));   // :350
+        }
+      }
+    const int n = (int)fu.size();
+    std::vector<uint8_t> sf(n), sb(n);
+    std::vector<float> ids(n), buv((size_t)n * 2);
+    if (n) {
+      sdso_stereo_match_t m;
+      std::memset(&m, 0, sizeof(m));
+      m.n = n; m.u = fu.data(); m.v = fv.data();
+      m.idepth_min_stereo = imin.data(); m.idepth_max_stereo = imax.data();
+      m.back_idepth_min_stereo = imin.data(); m.back_idepth_max_stereo = imax.data();   // :323-324
+      m.status_fwd = sf.data(); m.status_back = sb.data(); m.idepth_stereo = ids.data(); m.back_uv = buv.data();
+      const float K4[4] = {Hcalib.fxl(), Hcalib.fyl(), Hcalib.cxl(), Hcalib.cyl()};
+      dev_.check(sdso_stereo_match_batch(dev_.ctx(), slot_of(lastRef), slot_of(fh_right), K4, baseline, 1, &m), "sdso_stereo_match_batch");
+    }
+    std::vector<int> iu(n), iv(n);
+    std::vector<float> nid(n);
+    for (int i = 0; i < n; i++) {
+      iu[i] = (int)fu[i]; iv[i] = (int)fv[i];
+      float new_idepth = cpt2[i];
+      if (sf[i] == 0 /* IPS_GOOD */) {
+        const float depth = 1.0f / ids[i];
+        const float u_delta = std::fabs(fu[i] - buv[(size_t)i * 2]);
+        if (u_delta < 1 && depth > 0 && depth < 50) new_idepth = ids[i];            // :329-332
+      }
+      nid[i] = new_idepth;
+    }
+    installRef_(lastRef, n, iu.data(), iv.data(), nid.data(), wgt.data());
+  }
+  // void setCTRefForFirstFrame(std::vector<FrameHessian*> frameHessians) — CoarseTracker.cpp:794-805 with makeCoarseDepthForFirstFrame
+  // (:138-271): the first keyframe's own points at int(u + 0.5f), their idepth, no stereo refinement; STEP2-5 are makeCoarseDepthL0's.
+  template <class FrameHessianT>
+  void setCTRefForFirstFrame(std::vector<FrameHessianT*> frameHessians) {
+    if (frameHessians.empty() || !slot_of) throw Error("setCTRefForFirstFrame: no frames / slot_of not set");
+    FrameHessianT* lastRef = frameHessians.back();
+    std::vector<int> iu, iv;
+    std::vector<float> nid, wgt;
+    for (auto* ph : lastRef->pointHessians) {
+      const int u = ph->u + 0.5f;                            // :144-145
+      const int v = ph->v + 0.5f;
+      iu.push_back(u); iv.push_back(v); nid.push_back(ph->idepth);
+      wgt.push_back(sqrtf(1e-3 / (ph->efPoint->HdiF + 1e-12)));
+    }
+    installRef_(lastRef, (int)iu.size(), iu.data(), iv.data(), nid.data(), wgt.data());
+  }
+  // bool trackNewestCoarse(FrameHessian* newFrameHessian, SE3& lastToNew_out, AffLight& aff_g2l_out, int coarsestLvl, Vec5 minResForAbort,
+  //                        IOWrap::Output3DWrapper* wrap = 0) — CoarseTracker.h:62-66 verbatim (the debug wrapper is not used)
+  template <class FrameHessianT, class Vec5T>
+  bool trackNewestCoarse(FrameHessianT* newFrameHessian, SE3T& lastToNew_out, AffLightT& aff_g2l_out, int coarsestLvl, Vec5T minResForAbort,
+                         void* /*wrap*/ = nullptr) {
+    if (!slot_of) throw Error("trackNewestCoarse: slot_of not set");
+    return trackNewestCoarse(slot_of(newFrameHessian), newFrameHessian->ab_exposure, lastToNew_out, aff_g2l_out, coarsestLvl, minResForAbort);
+  }
+  // bool trackNewestCoarse(...) with the frame given by its pyramid slot
   template <class Vec5T>
   bool trackNewestCoarse(int newFrame_slot, float newFrame_ab_exposure, SE3T& lastToNew_out, AffLightT& aff_g2l_out, int coarsestLvl,
                          const Vec5T& minResForAbort) {
@@ -171,8 +258,18 @@ class CoarseTracker {
   int refFrameID = -1;
   sdso_track_result_t lastStats{};
   sdso_track_params_t& params() { return prm_; }
+  AffLightT lastRef_aff_g2l{};
 
  private:
+  template <class FrameHessianT>
+  void installRef_(FrameHessianT* lastRef, int n, const int* u, const int* v, const float* new_idepth, const float* weight) {
+    dev_.check(sdso_track_make_ref(dev_.ctx(), ref_slot_, slot_of(lastRef), n, u, v, new_idepth, weight, pc_n), "sdso_track_make_ref");
+    refFrameID = lastRef->shell->id;                         // :821-825
+    lastRef_aff_g2l = lastRef->aff_g2l();
+    prm_.ref_exposure = lastRef->ab_exposure;
+    prm_.ref_aff_g2l.a = lastRef_aff_g2l.a; prm_.ref_aff_g2l.b = lastRef_aff_g2l.b;
+    firstCoarseRMSE = -1;
+  }
   Device& dev_;
   int ref_slot_;
   sdso_track_params_t prm_;
@@ -235,12 +332,62 @@ class WindowedBA {
     W.solverMode = solverMode; W.affineOptModeA = affineOptModeA; W.affineOptModeB = affineOptModeB; W.forceAcceptStep = forceAcceptStep ? 1 : 0;
     dev_.check(sdso_ba_upload_window(dev_.ctx(), win_, &W), "sdso_ba_upload_window");
     nf_ = nf; resInM_seen_ = 0;
+    ef_ = ef;
+    res_index_.clear(); point_index_.clear();
+    for (size_t i = 0; i < residuals_.size(); i++) res_index_[residuals_[i]->data] = (int)i;
+    for (size_t i = 0; i < points_.size(); i++) point_index_[points_[i]] = (int)i;
+    lin_valid_ = app_valid_ = acc_valid_ = marg_valid_ = false;
   }
 
   // Vec3 FullSystem::linearizeAll(false): returns lastEnergyP
-  double linearizeAll() { double e = 0; dev_.check(sdso_ba_linearize(dev_.ctx(), win_, &e), "sdso_ba_linearize"); return e; }
+  double linearizeAll() {
+    double e = 0;
+    dev_.check(sdso_ba_linearize(dev_.ctx(), win_, &e), "sdso_ba_linearize");
+    lin_valid_ = app_valid_ = acc_valid_ = marg_valid_ = false;
+    return e;
+  }
   // applyRes_Reductor(true, ...)
-  void applyRes() { dev_.check(sdso_ba_apply_res(dev_.ctx(), win_), "sdso_ba_apply_res"); }
+  void applyRes() { dev_.check(sdso_ba_apply_res(dev_.ctx(), win_), "sdso_ba_apply_res"); app_valid_ = acc_valid_ = marg_valid_ = false; }
+
+  // double PointFrameResidual::linearize(CalibHessian* HCalib) (Residuals.h:103, Residuals.cpp:83-336) and void applyRes(bool copyJacobians)
+  // (Residuals.h:113, Residuals.cpp:367-385) PER OBJECT, the way linearizeAll_Reductor / applyRes_Reductor call them
+  // (FullSystemOptimize.cpp:52-96): the device linearises / applies the whole window at the first call after a change and every call
+  // hands its own residual's results out — state_NewEnergy, state_NewEnergyWithOutlier, state_NewState; then state_state, state_energy,
+  // EFResidual::isActiveAndIsGoodNEW.  A linearised residual (EFResidual::isLinearized) is not touched, as in the reference's loops.
+  template <class PointFrameResidualT>
+  double linearize(PointFrameResidualT* r, CalibHessianT* /*HCalib*/) {
+    if (!lin_valid_) {
+      const int nr = (int)residuals_.size();
+      linearizeAll();
+      l_state_.assign(nr, 0); l_energy_.assign(nr, 0.f); l_energyWO_.assign(nr, 0.f);
+      dev_.check(sdso_ba_get_linearization(dev_.ctx(), win_, nullptr, l_state_.data(), l_energy_.data(), l_energyWO_.data(), nullptr, nullptr), "sdso_ba_get_linearization");
+      lin_valid_ = true;
+    }
+    const int i = index_of_(r);
+    using ResStateT = std::decay_t<decltype(r->state_NewState)>;
+    r->state_NewState = static_cast<ResStateT>(l_state_[i]);
+    r->state_NewEnergyWithOutlier = l_energyWO_[i];
+    // (an OOB residual returns its old state_energy without touching state_NewEnergy: Residuals.cpp:88-91, :226)
+    if (l_state_[i] == 1) return r->state_energy;
+    r->state_NewEnergy = l_energy_[i];
+    return r->state_NewEnergy;
+  }
+  template <class PointFrameResidualT>
+  void applyRes(PointFrameResidualT* r, bool /*copyJacobians*/) {
+    if (!app_valid_) {
+      const int nr = (int)residuals_.size();
+      applyRes();
+      a_state_.assign(nr, 0); a_act_.assign(nr, 0);
+      dev_.check(sdso_ba_get_residual_state(dev_.ctx(), win_, a_state_.data(), a_act_.data(), nullptr), "sdso_ba_get_residual_state");
+      app_valid_ = true;
+    }
+    const int i = index_of_(r);
+    using ResStateT = std::decay_t<decltype(r->state_state)>;
+    if ((int)r->state_state == 1) return;                     // `if(state_state == ResState::OOB) return;` — can never go back from OOB
+    r->state_state = static_cast<ResStateT>(a_state_[i]);
+    r->state_energy = r->state_NewEnergy;
+    r->efResidual->isActiveAndIsGoodNEW = a_act_[i] != 0;
+  }
   // EnergyFunctional::solveSystemF(iteration, lambda, HCalib): fills lastX; frame / calib / point steps are fetched below
   // Multi-GPU: when this process holds only a contiguous range of allPoints, sum the packed accumulators over the
   // ranks before the stitch — what stitchDoubleMT does with the per-thread copies (AccumulatedTopHessian.cpp:299-308), across GPUs.
@@ -253,16 +400,113 @@ class WindowedBA {
   void solveSystemF(int iteration, double lambda, std::vector<double>& lastX, std::vector<double>& frame_step, double calib_step[4]) {
     const int n = 8 * nf_ + 4;
     lastX.assign(n, 0); frame_step.assign(nf_ * 8, 0);
-    dev_.check(sdso_ba_accumulate(dev_.ctx(), win_), "sdso_ba_accumulate");
-    allreduce();
+    ensureAccumulated();
     dev_.check(sdso_ba_solve(dev_.ctx(), win_, iteration, lambda, lastX.data(), nullptr, nullptr, frame_step.data(), calib_step), "sdso_ba_solve");
   }
+  // void EnergyFunctional::solveSystemF(int iteration, double lambda, CalibHessian* HCalib) — EnergyFunctional.h:74, EnergyFunctional.cpp:838-995
+  // with resubstituteF_MT (:272-341) — verbatim: everything the reference's function leaves in its objects is written into them:
+  //   ef->lastX, lastHS, lastbS (:909-910, :992); ef->resInA / resInL (:219, :241); HCalib->step = -x.head<CPARS>() (:279);
+  //   every EFFrame::data->step.head<8>() = -x.segment<8>(CPARS + 8 idx), tail<2>() = 0 (:283-286);
+  //   every PointHessian::step (:336-338), EFPoint::HdiF / bdSumF (AccumulatedSCHessian.cpp:58-65)
+  void solveSystemF(int iteration, double lambda, CalibHessianT* HCalib) {
+    const int n = 8 * nf_ + 4, np = (int)points_.size();
+    std::vector<double> x(n), HS((size_t)n * n), bS(n), fstep(nf_ * 8);
+    double cstep[4];
+    ensureAccumulated();
+    dev_.check(sdso_ba_solve(dev_.ctx(), win_, iteration, lambda, x.data(), HS.data(), bS.data(), fstep.data(), cstep), "sdso_ba_solve");
+    ef_->lastX.resize(n); ef_->lastbS.resize(n); ef_->lastHS.resize(n, n);
+    for (int i = 0; i < n; i++) { ef_->lastX[i] = x[i]; ef_->lastbS[i] = bS[i]; for (int j = 0; j < n; j++) ef_->lastHS(i, j) = HS[(size_t)i * n + j]; }
+    for (int i = 0; i < 4; i++) HCalib->step[i] = cstep[i];
+    for (int f = 0; f < nf_; f++) {
+      auto* fh = ef_->frames[f]->data;
+      for (int i = 0; i < 8; i++) fh->step[i] = fstep[f * 8 + i];
+      fh->step[8] = 0; fh->step[9] = 0;
+    }
+    std::vector<float> pstep(np), hdi(np), bds(np);
+    if (np) {
+      dev_.check(sdso_ba_get_point_steps(dev_.ctx(), win_, pstep.data()), "sdso_ba_get_point_steps");
+      dev_.check(sdso_ba_get_point_terms(dev_.ctx(), win_, hdi.data(), bds.data(), nullptr, nullptr, nullptr), "sdso_ba_get_point_terms");
+    }
+    for (int p = 0; p < np; p++) { points_[p]->data->step = pstep[p]; points_[p]->HdiF = hdi[p]; points_[p]->bdSumF = bds[p]; }
+    int ra = 0, rl = 0;
+    dev_.check(sdso_ba_get_counts(dev_.ctx(), win_, &ra, &rl, nullptr), "sdso_ba_get_counts");
+    ef_->resInA = ra; ef_->resInL = rl;
+  }
+  // double EnergyFunctional::calcLEnergyF_MT() / double calcMEnergyF() — EnergyFunctional.h:82-83, EnergyFunctional.cpp:420-442, :344-351
+  double calcLEnergyF_MT() { double el = 0; dev_.check(sdso_ba_calc_energies(dev_.ctx(), win_, &el, nullptr), "sdso_ba_calc_energies"); return el; }
+  double calcMEnergyF() { double em = 0; dev_.check(sdso_ba_calc_energies(dev_.ctx(), win_, nullptr, &em), "sdso_ba_calc_energies"); return em; }
+  // void EnergyFunctional::setAdjointsF(CalibHessian* Hcalib) — EnergyFunctional.h:86, EnergyFunctional.cpp:41-119: the window's adjoints
+  // (computed at upload / whenever the device loop moved the states) into ef->adHost / adTarget / adHostF / adTargetF, [h + t * nFrames]
+  void setAdjointsF(CalibHessianT* /*Hcalib*/) {
+    const int nf = nf_;
+    std::vector<double> aH((size_t)nf * nf * 64), aT((size_t)nf * nf * 64);
+    dev_.check(sdso_ba_get_tables(dev_.ctx(), win_, nullptr, aH.data(), aT.data(), nullptr), "sdso_ba_get_tables");
+    using M88 = std::remove_pointer_t<decltype(ef_->adHost)>;
+    using M88f = std::remove_pointer_t<decltype(ef_->adHostF)>;
+    if (ef_->adHost != 0) delete[] ef_->adHost;
+    if (ef_->adTarget != 0) delete[] ef_->adTarget;
+    if (ef_->adHostF != 0) delete[] ef_->adHostF;
+    if (ef_->adTargetF != 0) delete[] ef_->adTargetF;
+    ef_->adHost = new M88[nf * nf]; ef_->adTarget = new M88[nf * nf]; ef_->adHostF = new M88f[nf * nf]; ef_->adTargetF = new M88f[nf * nf];
+    for (int k = 0; k < nf * nf; k++)
+      for (int i = 0; i < 8; i++)
+        for (int j = 0; j < 8; j++) {
+          ef_->adHost[k](i, j) = aH[(size_t)k * 64 + i * 8 + j]; ef_->adTarget[k](i, j) = aT[(size_t)k * 64 + i * 8 + j];
+          ef_->adHostF[k](i, j) = (float)aH[(size_t)k * 64 + i * 8 + j]; ef_->adTargetF[k](i, j) = (float)aT[(size_t)k * 64 + i * 8 + j];
+        }
+  }
+  // void EnergyFunctional::setDeltaF(CalibHessian* HCalib) — EnergyFunctional.h:75, EnergyFunctional.cpp:173-207: adHTdeltaF[h + t * nFrames],
+  // cDeltaF, EFFrame::delta / delta_prior, EFPoint::deltaF
+  void setDeltaF(CalibHessianT* /*HCalib*/) {
+    const int nf = nf_, np = (int)points_.size();
+    std::vector<float> adhtd((size_t)nf * nf * 8), pd(np);
+    std::vector<double> fd(nf * 8), fdp(nf * 8);
+    float cd[4];
+    dev_.check(sdso_ba_get_tables(dev_.ctx(), win_, nullptr, nullptr, nullptr, adhtd.data()), "sdso_ba_get_tables");
+    dev_.check(sdso_ba_get_deltas(dev_.ctx(), win_, cd, fd.data(), fdp.data(), pd.data()), "sdso_ba_get_deltas");
+    using M18f = std::remove_pointer_t<decltype(ef_->adHTdeltaF)>;
+    if (ef_->adHTdeltaF != 0) delete[] ef_->adHTdeltaF;
+    ef_->adHTdeltaF = new M18f[nf * nf];
+    for (int k = 0; k < nf * nf; k++) for (int j = 0; j < 8; j++) ef_->adHTdeltaF[k](0, j) = adhtd[(size_t)k * 8 + j];
+    for (int i = 0; i < 4; i++) ef_->cDeltaF[i] = cd[i];
+    for (int f = 0; f < nf; f++) for (int i = 0; i < 8; i++) { ef_->frames[f]->delta[i] = fd[f * 8 + i]; ef_->frames[f]->delta_prior[i] = fdp[f * 8 + i]; }
+    for (int p = 0; p < np; p++) points_[p]->deltaF = pd[p];
+  }
+  // the device pass behind accumulateAF_MT + accumulateLF_MT + accumulateSCF_MT: runs once per linearised / applied state
+  void ensureAccumulated() {
+    if (acc_valid_) return;
+    dev_.check(sdso_ba_accumulate(dev_.ctx(), win_), "sdso_ba_accumulate");
+    allreduce();
+    acc_valid_ = true; marg_valid_ = false;
+  }
+  // marginalizePointsF's device pass for the points the accumulator façades collected (addPoint<2>): see AccumulatedTopHessianSSE below
+  // (type-erased form for the accumulator façade, which holds the points as `const void*`)
+  void ensureMarginalizedErased(const std::vector<const void*>& flagged) {
+    if (marg_valid_) return;
+    std::vector<uint8_t> flag(points_.size(), 0);
+    for (const void* p : flagged) flag[point_index_.at(p)] = 1;
+    const int before = countOf(2);
+    dev_.check(sdso_ba_marginalize_points(dev_.ctx(), win_, flag.data(), HM_.data(), bM_.data()), "sdso_ba_marginalize_points");
+    last_marg_res_ = countOf(2) - before;
+    marg_valid_ = true; acc_valid_ = lin_valid_ = app_valid_ = false;
+  }
+  void requireMarginalized() const { if (!marg_valid_) throw Error("AccumulatedSCHessianSSE: the marginalisation pass has not run (stitch the top accumulator first, EnergyFunctional.cpp:707-708)"); }
+  int lastMargResiduals() const { return last_marg_res_; }
+  const std::vector<double>& HM() const { return HM_; }
+  const std::vector<double>& bM() const { return bM_; }
+  template <class MatXX, class VecX> void stitchedSystem(int which, MatXX& H, VecX& b) { stitched_(which, H, b); }
+  int countOf(int which) {                                    // 0 resInA, 1 resInL, 2 residuals marginalised through this window so far
+    int c[3] = {0, 0, 0};
+    dev_.check(sdso_ba_get_counts(dev_.ctx(), win_, &c[0], &c[1], &c[2]), "sdso_ba_get_counts");
+    return c[which];
+  }
+  int nFrames() const { return nf_; }
   // void EnergyFunctional::accumulateAF_MT(MatXX& H, VecX& b, bool MT) / accumulateLF_MT / accumulateSCF_MT (EnergyFunctional.cpp:212-269,
   // EnergyFunctional.h:103-105): what the reference's callers get back is the STITCHED system of AccumulatedTopHessianSSE::stitchDoubleMT
   // (mode 0 without priors, mode 1 with priors) / AccumulatedSCHessianSSE::stitchDoubleMT.  The device accumulates all three in one pass
   // (sdso_ba_accumulate) and its solver never materialises them; these members run the stitch kernels on demand.  MatXX / VecX: anything
   // with resize(rows[, cols]) and operator()(i[, j]) — Eigen's, or the stand-ins of host/test_shim.cpp.  `MT` is ignored.
-  void accumulateAll() { dev_.check(sdso_ba_accumulate(dev_.ctx(), win_), "sdso_ba_accumulate"); allreduce(); }
+  void accumulateAll() { acc_valid_ = false; ensureAccumulated(); }
   template <class MatXX, class VecX> void accumulateAF_MT(MatXX& H, VecX& b, bool /*MT*/) { stitched_(0, H, b); }
   template <class MatXX, class VecX> void accumulateLF_MT(MatXX& H, VecX& b, bool /*MT*/) { stitched_(1, H, b); }
   template <class MatXX, class VecX> void accumulateSCF_MT(MatXX& H, VecX& b, bool /*MT*/) { stitched_(2, H, b); }
@@ -285,6 +529,7 @@ class WindowedBA {
   float optimize(int mnumOptIts, EnergyFunctionalT* ef, CalibHessianT* HCalib) {
     const int nf = nf_, np = (int)points_.size(), nr = (int)residuals_.size(), n = 8 * nf + 4;
     sdso_ba_opt_result_t out;
+    lin_valid_ = app_valid_ = acc_valid_ = marg_valid_ = false;
     if (nf < 2) { lastResult = sdso_ba_opt_result_t{0, 0, 0, 0}; lastRemoved = 0; return 0.f; }   // `if(frameHessians.size() < 2) return 0;` (:873-874): nothing is touched
     dev_.check(sdso_ba_optimize(dev_.ctx(), win_, mnumOptIts, nullptr, nullptr, nullptr, &out), "sdso_ba_optimize");
     std::vector<float> idp(np), pstep(np), hdi(np), bds(np), idh(np), mrb(np), energy(nr), cpt((size_t)nr * 3), prj((size_t)nr * 16), eth(nf);
@@ -385,6 +630,7 @@ class WindowedBA {
     for (size_t p = 0; p < points_.size(); p++) flag[p] = is_marg(points_[p]) ? 1 : 0;
     const int n = 8 * nf_ + 4;
     dev_.check(sdso_ba_marginalize_points(dev_.ctx(), win_, flag.data(), HM_.data(), bM_.data()), "sdso_ba_marginalize_points");
+    marg_valid_ = true; acc_valid_ = lin_valid_ = app_valid_ = false;
     for (int i = 0; i < n; i++) { ef->bM[i] = bM_[i]; for (int j = 0; j < n; j++) ef->HM(i, j) = HM_[(size_t)i * n + j]; }
     int resInM = 0;                                        // resInM += accSSE_top_A->nres[0] (EnergyFunctional.cpp:704)
     dev_.check(sdso_ba_get_counts(dev_.ctx(), win_, nullptr, nullptr, &resInM), "sdso_ba_get_counts");
@@ -403,8 +649,19 @@ class WindowedBA {
     H.resize(n, n); b.resize(n);
     for (int i = 0; i < n; i++) { b(i) = bs[i]; for (int j = 0; j < n; j++) H(i, j) = Hs[(size_t)i * n + j]; }
   }
+  template <class PointFrameResidualT> int index_of_(PointFrameResidualT* r) const {
+    auto it = res_index_.find(r);
+    if (it == res_index_.end()) throw Error("residual is not part of the uploaded window");
+    return it->second;
+  }
   Device& dev_;
   int win_, nf_ = 0, resInM_seen_ = 0;
+  EnergyFunctionalT* ef_ = nullptr;
+  int last_marg_res_ = 0;
+  bool lin_valid_ = false, app_valid_ = false, acc_valid_ = false, marg_valid_ = false;
+  std::unordered_map<const void*, int> res_index_, point_index_;
+  std::vector<uint8_t> l_state_, a_state_, a_act_;
+  std::vector<float> l_energy_, l_energyWO_;
   std::vector<double> evalPT_, state_, state_zero_, HM_, bM_;
   std::vector<float> exposure_, energyTH_, u_, v_, idepth_, idepth_zero_, color_, weights_;
   std::vector<float> maxRelBaseline_;
@@ -420,6 +677,92 @@ class WindowedBA {
   }
   std::vector<std::decay_t<decltype(std::declval<EnergyFunctionalT&>().frames[0]->points[0])>> points_;          // EFPoint*
   std::vector<std::decay_t<decltype(std::declval<EnergyFunctionalT&>().frames[0]->points[0]->residualsAll[0])>> residuals_;  // EFResidual*
+};
+
+// =================================================================================== accumulators
+// AccumulatedTopHessianSSE / AccumulatedSCHessianSSE with the reference's member signatures (AccumulatedTopHessian.h:66-97, :162-169;
+// AccumulatedSCHessian.h:66-96, :155-160) over the device window.  The device forms all three accumulations of a linearised state in one
+// pass (k_ba_lin_fused / k_ba_accum_top + k_ba_sc_host), so setZero / addPoint<mode> / addPointsInternal<mode> are BOOKKEEPING — which mode
+// the caller is accumulating, and for mode 2 (marginalizePointsF, EnergyFunctional.cpp:663-736) which points it passes — and the stitch
+// members return the stitched systems of that pass (sdso_ba_get_stitched):
+//   top, mode 0 : stitchDouble[MT](H, b, EF, usePrior = false, ..)   accumulateAF_MT  (EnergyFunctional.cpp:212-232)
+//   top, mode 1 : stitchDouble[MT](H, b, EF, usePrior = true, ..)    accumulateLF_MT  (:236-254)
+//   top, mode 2 : stitchDouble(M, Mb, EF, false, false)               marginalizePointsF (:707): runs sdso_ba_marginalize_points for the collected points
+//   bottom      : stitchDouble[MT](H, b, EF, ..)                      accumulateSCF_MT (:256-269) / marginalizePointsF (:708)
+// `tid` / `min` / `max` / `stats` / the IndexThreadReduce pointer are accepted and ignored (a GPU backend is free to ignore tid).
+template <class BA>
+class AccumulatedTopHessianSSE {
+ public:
+  explicit AccumulatedTopHessianSSE(BA& ba) : ba_(ba) { for (int i = 0; i < 6; i++) { nframes[i] = 0; nres[i] = 0; } }
+  int nframes[6];   // NUM_THREADS (util/NumType.h:38)
+  int nres[6];
+  template <class StatsT = void>
+  void setZero(int nFrames, int /*min*/ = 0, int /*max*/ = 1, StatsT* /*stats*/ = 0, int tid = 0) {
+    nframes[tid] = nFrames; nres[tid] = 0; mode_ = -1; flagged_.clear();
+  }
+  template <int mode, class EFPointT, class EFT>
+  void addPoint(EFPointT* p, EFT const* /*ef*/, int /*tid*/ = 0) {
+    static_assert(mode >= 0 && mode <= 2, "addPoint<mode>: 0 active, 1 linearized, 2 marginalize");
+    if (mode_ != -1 && mode_ != mode) throw Error("AccumulatedTopHessianSSE: one mode per setZero");
+    mode_ = mode;
+    if (mode == 2) flagged_.push_back(p);
+  }
+  template <int mode, class EFPointT, class EFT, class StatsT = void>
+  void addPointsInternal(std::vector<EFPointT*>* points, EFT const* ef, int min = 0, int max = 1, StatsT* /*stats*/ = 0, int tid = 0) {
+    for (int i = min; i < max; i++) addPoint<mode>((*points)[i], ef, tid);
+  }
+  template <class MatXX, class VecX, class EFT>
+  void stitchDouble(MatXX& H, VecX& b, EFT const* /*EF*/, bool usePrior, bool /*useDelta*/, int /*tid*/ = 0) { stitch_(H, b, usePrior); }
+  template <class RedT, class MatXX, class VecX, class EFT>
+  void stitchDoubleMT(RedT* /*red*/, MatXX& H, VecX& b, EFT const* /*EF*/, bool usePrior, bool /*MT*/) { stitch_(H, b, usePrior); }
+  const std::vector<const void*>& flagged() const { return flagged_; }
+
+ private:
+  template <class MatXX, class VecX> void stitch_(MatXX& H, VecX& b, bool usePrior) {
+    if (mode_ == 2) {
+      if (usePrior) throw Error("AccumulatedTopHessianSSE: the marginalisation stitch is called without priors (EnergyFunctional.cpp:707)");
+      ba_.ensureMarginalizedErased(flagged_);
+      ba_.stitchedSystem(0, H, b);
+      nres[0] = ba_.lastMargResiduals();
+      return;
+    }
+    // mode 0 is stitched without the priors, mode 1 with them — the only combinations the reference forms (EnergyFunctional.cpp:218, :240)
+    const int which = mode_ == 1 ? 1 : 0;
+    if (usePrior != (which == 1)) throw Error("AccumulatedTopHessianSSE: accumulateAF_MT stitches without priors, accumulateLF_MT with them");
+    ba_.ensureAccumulated();
+    ba_.stitchedSystem(which, H, b);
+    nres[0] = ba_.countOf(which);
+  }
+  BA& ba_;
+  int mode_ = -1;
+  std::vector<const void*> flagged_;
+};
+template <class BA>
+class AccumulatedSCHessianSSE {
+ public:
+  explicit AccumulatedSCHessianSSE(BA& ba) : ba_(ba) { for (int i = 0; i < 6; i++) nframes[i] = 0; }
+  int nframes[6];
+  template <class StatsT = void>
+  void setZero(int n, int /*min*/ = 0, int /*max*/ = 1, StatsT* /*stats*/ = 0, int tid = 0) { nframes[tid] = n; marg_ = false; }
+  template <class EFPointT>
+  void addPoint(EFPointT* /*p*/, bool shiftPriorToZero, int /*tid*/ = 0) { if (!shiftPriorToZero) marg_ = true; }   // (false only in marginalizePointsF, :700)
+  template <class EFPointT, class StatsT = void>
+  void addPointsInternal(std::vector<EFPointT*>* points, bool shiftPriorToZero, int min = 0, int max = 1, StatsT* /*stats*/ = 0, int tid = 0) {
+    for (int i = min; i < max; i++) addPoint((*points)[i], shiftPriorToZero, tid);
+  }
+  template <class MatXX, class VecX, class EFT>
+  void stitchDouble(MatXX& H, VecX& b, EFT const* /*EF*/, int /*tid*/ = 0) { stitch_(H, b); }
+  template <class RedT, class MatXX, class VecX, class EFT>
+  void stitchDoubleMT(RedT* /*red*/, MatXX& H, VecX& b, EFT const* /*EF*/, bool /*MT*/) { stitch_(H, b); }
+
+ private:
+  template <class MatXX, class VecX> void stitch_(MatXX& H, VecX& b) {
+    if (marg_) ba_.requireMarginalized();     // the top accumulator's stitch (called first, :707-708) ran the device pass
+    else ba_.ensureAccumulated();
+    ba_.stitchedSystem(2, H, b);
+  }
+  BA& ba_;
+  bool marg_ = false;
 };
 
 // =================================================================================== ImmaturePoint

@@ -3,7 +3,7 @@
 // writes a problem as raw arrays into a directory, runs this program on the GPU box and compares
 // what it prints with the same problem pushed through the C-ABI from Python.
 //
-//   test_shim <dir> tracker|tracker_g2o|stereo|stereo_g2o|ba|selector
+//   test_shim <dir> tracker|tracker_g2o|tracker_ref|stereo|stereo_g2o|ba|ba_members|selector
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -49,11 +49,16 @@ struct CalibHessian {
   float fxl() const { return (float)value_scaled[0]; } float fyl() const { return (float)value_scaled[1]; }
   float cxl() const { return (float)value_scaled[2]; } float cyl() const { return (float)value_scaled[3]; }
 };
+struct PointHessian;
+struct FrameShell { int id = 0; };
 struct FrameHessian {
   Vec3f* dIp[SDSO_PYR_LEVELS];
   std::vector<std::vector<float>> store;
   SE3 worldToCam_evalPT; Vec10 state, state_zero, step;
   float ab_exposure = 1, frameEnergyTH = 0; int frameID = 0, idx = 0, slot = 0;
+  std::vector<PointHessian*> pointHessians;                      // HessianBlocks.h:125
+  FrameShell shellStore; FrameShell* shell = &shellStore;
+  AffLight aff; AffLight aff_g2l() const { return aff; }         // HessianBlocks.h:185
   const SE3& get_worldToCam_evalPT() const { return worldToCam_evalPT; }
   const Vec10& get_state() const { return state; }
   const Vec10& get_state_zero() const { return state_zero; }
@@ -63,7 +68,7 @@ struct FrameHessian {
 struct EFFrame; struct EFPoint; struct EFResidual; struct PointHessian;
 struct PointFrameResidual {
   int state_state = 0, state_NewState = 0;
-  double state_energy = 0, state_NewEnergy = 0;
+  double state_energy = 0, state_NewEnergy = 0, state_NewEnergyWithOutlier = 0;
   bool isNew = true;
   Vec2f projectedTo[SDSO_MAX_RES];
   Vec3fv centerProjectedTo;
@@ -82,8 +87,12 @@ struct PointHessian {
   bool isInlierNew() const { return (int)residuals.size() >= 3 && numGoodResiduals >= 4; }   // HessianBlocks.h:465-469; setting_minGoodActiveResForMarg = 3, setting_minGoodResForMarg = 4 (settings.cpp:82-83)
 };
 struct EFResidual { PointFrameResidual* data; EFFrame* target; bool isActiveAndIsGoodNEW = false; int idxInAll = 0; EFPoint* point = nullptr; bool isLinearized = false; };
-struct EFPoint { PointHessian* data; std::vector<EFResidual*> residualsAll; int stateFlag = 0; float HdiF = 0, bdSumF = 0; };
-struct EFFrame { FrameHessian* data; std::vector<EFPoint*> points; int idx; };
+struct EFPoint { PointHessian* data; std::vector<EFResidual*> residualsAll; int stateFlag = 0; float HdiF = 0, bdSumF = 0, deltaF = 0; };
+struct Vec8 { double v[8] = {0, 0, 0, 0, 0, 0, 0, 0}; double& operator[](int i) { return v[i]; } };
+struct EFFrame { FrameHessian* data; std::vector<EFPoint*> points; int idx; Vec8 delta, delta_prior; };
+struct Mat88 { double m[64]; double& operator()(int i, int j) { return m[i * 8 + j]; } };
+struct Mat88f { float m[64]; float& operator()(int i, int j) { return m[i * 8 + j]; } };
+struct Mat18f { float m[8]; float& operator()(int, int j) { return m[j]; } };
 struct DynMat {
   int n = 0; std::vector<double> d;
   void resize(int r, int c) { n = c; d.assign((size_t)r * c, 0.0); }
@@ -97,6 +106,10 @@ struct DynVec {
 struct EnergyFunctional {
   std::vector<EFFrame*> frames; DynMat HM, lastHS; std::vector<double> bM, lastbS, lastX;
   int resInA = 0, resInL = 0, resInM = 0, nResiduals = 0;
+  Mat88 *adHost = 0, *adTarget = 0; Mat88f *adHostF = 0, *adTargetF = 0; Mat18f* adHTdeltaF = 0;   // EnergyFunctional.h:115-135
+  float cDeltaF[4] = {0, 0, 0, 0};
+  std::vector<EFPoint*> allPoints;
+  ~EnergyFunctional() { delete[] adHost; delete[] adTarget; delete[] adHostF; delete[] adTargetF; delete[] adHTdeltaF; }
   void dropResidual(EFResidual* r) {                             // EnergyFunctional.cpp:519-548
     EFPoint* p = r->point;
     p->residualsAll[r->idxInAll] = p->residualsAll.back();
@@ -165,6 +178,77 @@ static int run_tracker(const std::string& dir, bool fork_live) {
   return 0;
 }
 
+template <class T>
+static void dump(const std::string& dir, const char* name, const std::vector<T>& v);
+
+// CoarseTracker::setCoarseTrackingRef(frameHessians, fh_right, Hcalib) and setCTRefForFirstFrame(frameHessians) with the reference's
+// signatures on a small pointer graph: frames with pointHessians whose lastResiduals[0] / centerProjectedTo / efPoint->HdiF are what
+// FullSystem::optimize left.  The template levels come back through sdso_track_get_ref and are dumped for tests/test_host_shim.py, which
+// rebuilds them from the oracle (ImmaturePoint ctor, traceStereo there and back, the accept rule, orc_make_coarse_depth).
+static int run_tracker_ref(const std::string& dir) {
+  auto meta = load<int>(dir, "meta");             // levels w0 h0 n nframes
+  auto kf = load<float>(dir, "K");                // fx fy cx cy baseline
+  const int levels = meta[0], w0 = meta[1], h0 = meta[2], n = meta[3], nfr = meta[4];
+  auto cpt = load<float>(dir, "cpt"), hdi = load<float>(dir, "HdiF"), pu = load<float>(dir, "pu"), pv = load<float>(dir, "pv"), pid = load<float>(dir, "pidepth");
+  auto rstate = load<int>(dir, "rstate"), frame_of = load<int>(dir, "frame_of");
+  auto has_last = load<uint8_t>(dir, "has_last");
+  sdso_shim::Device dev(0);
+  std::vector<std::unique_ptr<FrameHessian>> fhs;
+  FrameHessian right;
+  int w[SDSO_PYR_LEVELS], h[SDSO_PYR_LEVELS];
+  for (int l = 0; l < levels; l++) { w[l] = w0 >> l; h[l] = h0 >> l; }
+  for (int f = 0; f < nfr; f++) { fhs.emplace_back(new FrameHessian); fhs.back()->slot = 20 + f; fhs.back()->shellStore.id = 100 + f; fhs.back()->ab_exposure = 1.f + 0.01f * f; }
+  FrameHessian& target = *fhs.back();
+  target.aff.a = 0.02; target.aff.b = 1.5;
+  load_pyramid(dir, "left", target, levels);
+  dev.uploadFrame(target.slot, &target, levels, w, h);
+  load_pyramid(dir, "right", right, 1);
+  right.slot = 40;
+  dev.uploadFrame(right.slot, &right, 1, w, h);
+  std::vector<std::unique_ptr<PointHessian>> phs;
+  std::vector<std::unique_ptr<EFPoint>> efps;
+  std::vector<std::unique_ptr<PointFrameResidual>> pfrs;
+  for (int i = 0; i < n; i++) {
+    phs.emplace_back(new PointHessian);
+    PointHessian& ph = *phs.back();
+    ph.u = pu[i]; ph.v = pv[i]; ph.idepth = pid[i];
+    efps.emplace_back(new EFPoint{&ph, {}, 0});
+    ph.efPoint = efps.back().get();
+    ph.efPoint->HdiF = hdi[i];
+    pfrs.emplace_back(new PointFrameResidual);
+    for (int k = 0; k < 3; k++) pfrs.back()->centerProjectedTo[k] = cpt[(size_t)i * 3 + k];
+    ph.lastResiduals[0] = {has_last[i] ? pfrs.back().get() : nullptr, rstate[i]};
+    fhs[frame_of[i]]->pointHessians.push_back(&ph);
+  }
+  CalibHessian HC;
+  for (int i = 0; i < 4; i++) HC.value_scaled[i] = HC.value_zero[i] = kf[i];
+  std::vector<FrameHessian*> frameHessians;
+  for (auto& f : fhs) frameHessians.push_back(f.get());
+  std::vector<int> o_pcn;
+  for (int variant = 0; variant < 2; variant++) {
+    sdso_shim::CoarseTracker<SE3, AffLight, Mat33, Vec3> tracker(dev, 5 + variant);
+    tracker.makeK(&HC, levels, w0, h0);
+    tracker.slot_of = [](const void* fh) { return static_cast<const FrameHessian*>(fh)->slot; };
+    tracker.baseline = kf[4];
+    if (variant == 0) tracker.setCoarseTrackingRef(frameHessians, &right, HC);
+    else tracker.setCTRefForFirstFrame(frameHessians);
+    if (tracker.refFrameID != target.shell->id || tracker.lastRef_aff_g2l.a != target.aff.a || tracker.firstCoarseRMSE != -1) { std::fprintf(stderr, "bookkeeping of setCoarseTrackingRef\n"); return 1; }
+    for (int l = 0; l < levels; l++) {
+      const int pn = tracker.pc_n[l];
+      o_pcn.push_back(pn);
+      std::vector<float> pc((size_t)4 * pn);
+      int got = 0;
+      dev.check(sdso_track_get_ref(dev.ctx(), 5 + variant, l, &got, pc.data(), pc.data() + pn, pc.data() + 2 * (size_t)pn, pc.data() + 3 * (size_t)pn), "sdso_track_get_ref");
+      if (got != pn) { std::fprintf(stderr, "pc_n mismatch\n"); return 1; }
+      char nm[32]; std::snprintf(nm, sizeof nm, "pc_%d_l%d", variant, l);
+      dump(dir, nm, pc);
+    }
+  }
+  dump(dir, "pcn", o_pcn);
+  std::printf("tracker_ref ok\n");
+  return 0;
+}
+
 static int run_stereo(const std::string& dir, bool fork_live) {
   auto meta = load<int>(dir, "meta");             // w, h, n, mode_right
   auto kf = load<float>(dir, "K");                // fx fy cx cy baseline
@@ -207,67 +291,86 @@ static void dump(const std::string& dir, const char* name, const std::vector<T>&
 // dumped as raw arrays (out_*.bin) for tests/test_host_shim.py to compare with the ORACLE's post-state:
 //   makeCoarseDepthL0 STEP1 (CoarseTracker.cpp:295-350): which points enter, their pixel and weight sqrtf(1e-3 / (HdiF + 1e-12))
 //   flagPointsForRemoval (FullSystem.cpp:1004-1035): marginalise / drop / keep decision of a point whose host is being marginalised
-static int run_ba(const std::string& dir) {
-  auto meta = load<int>(dir, "meta");             // nf np nr w h its solverMode
-  const int nf = meta[0], np = meta[1], nr = meta[2], w = meta[3], h = meta[4];
-  auto calib = load<double>(dir, "calib");        // value_scaled(4) value_zero(4)
-  auto evalPT = load<double>(dir, "evalPT"), state = load<double>(dir, "state"), state_zero = load<double>(dir, "state_zero"),
-       HM = load<double>(dir, "HM"), bM = load<double>(dir, "bM");
-  auto exposure = load<float>(dir, "ab_exposure"), eTH = load<float>(dir, "frameEnergyTH");
-  auto frameID = load<int>(dir, "frameID"), host = load<int>(dir, "host"), res_point = load<int>(dir, "res_point"), res_target = load<int>(dir, "res_target");
-  auto u = load<float>(dir, "u"), v = load<float>(dir, "v"), idepth = load<float>(dir, "idepth"), idz = load<float>(dir, "idepth_zero"),
-       color = load<float>(dir, "color"), weights = load<float>(dir, "weights"), mrb = load<float>(dir, "maxRelBaseline");
-  auto prior = load<uint8_t>(dir, "hasDepthPrior"), res_state = load<uint8_t>(dir, "res_state"), isnew = load<uint8_t>(dir, "res_isNew");
-  auto ngood = load<int>(dir, "numGoodResiduals");
-  sdso_shim::Device dev(0);
+// the pointer graph of one window, built like the reference's (FrameHessian / PointHessian / PointFrameResidual / EFFrame / EFPoint /
+// EFResidual with residuals, residualsAll, lastResiduals) from the raw arrays tests/test_host_shim.py wrote
+struct BaGraph {
+  std::vector<int> meta;
+  int nf = 0, np = 0, nr = 0, w = 0, h = 0;
   std::vector<std::unique_ptr<FrameHessian>> fhs;
   std::vector<std::unique_ptr<EFFrame>> effs;
-  EnergyFunctional ef;
-  int wv[1] = {w}, hv[1] = {h};
-  for (int f = 0; f < nf; f++) {
-    fhs.emplace_back(new FrameHessian);
-    FrameHessian& fh = *fhs.back();
-    char nm[32]; std::snprintf(nm, sizeof nm, "img%d", f);
-    load_pyramid(dir, nm, fh, 1);
-    for (int i = 0; i < 9; i++) fh.worldToCam_evalPT.R.m[i] = evalPT[f * 12 + i];
-    for (int i = 0; i < 3; i++) fh.worldToCam_evalPT.t.v[i] = evalPT[f * 12 + 9 + i];
-    for (int i = 0; i < 10; i++) { fh.state[i] = state[f * 10 + i]; fh.state_zero[i] = state_zero[f * 10 + i]; }
-    fh.ab_exposure = exposure[f]; fh.frameEnergyTH = eTH[f]; fh.frameID = frameID[f]; fh.idx = f; fh.slot = 10 + f;
-    dev.uploadFrame(fh.slot, &fh, 1, wv, hv);
-    effs.emplace_back(new EFFrame{&fh, {}, f});
-    ef.frames.push_back(effs.back().get());
-  }
   std::vector<std::unique_ptr<PointHessian>> phs;
   std::vector<std::unique_ptr<EFPoint>> efps;
-  int r = 0;
-  for (int p = 0; p < np; p++) {
-    phs.emplace_back(new PointHessian);
-    PointHessian& ph = *phs.back();
-    ph.u = u[p]; ph.v = v[p]; ph.idepth = idepth[p]; ph.idepth_zero = idz[p]; ph.hasDepthPrior = prior[p] != 0;
-    ph.maxRelBaseline = mrb[p]; ph.numGoodResiduals = ngood[p];
-    for (int k = 0; k < 8; k++) { ph.color[k] = color[p * 8 + k]; ph.weights[k] = weights[p * 8 + k]; }
-    efps.emplace_back(new EFPoint{&ph, {}, 0});
-    ph.efPoint = efps.back().get();
-    for (; r < nr && res_point[r] == p; r++) {
-      // raw new: the shim deletes dropped residuals like the reference does (deleteOut / dropResidual)
-      PointFrameResidual* pfr = new PointFrameResidual;
-      pfr->state_state = (int)res_state[r]; pfr->isNew = isnew[r] != 0; pfr->point = &ph; pfr->id = r;
-      EFResidual* efr = new EFResidual{pfr, ef.frames[res_target[r]]};
-      efr->point = ph.efPoint; efr->idxInAll = (int)ph.efPoint->residualsAll.size();
-      pfr->efResidual = efr;
-      ph.efPoint->residualsAll.push_back(efr);
-      ph.residuals.push_back(pfr);
-      ef.nResiduals++;
-      // lastResiduals: [0] the residual into the newest frame, [1] into the one before (FullSystem.cpp:1400-1410)
-      if (res_target[r] == nf - 1) ph.lastResiduals[0] = {pfr, 0};
-      if (res_target[r] == nf - 2) ph.lastResiduals[1] = {pfr, 0};
-    }
-    ef.frames[host[p]]->points.push_back(ph.efPoint);   // points arrive grouped by host (makeIDX order)
-  }
-  const int n = 8 * nf + 4;
-  ef.HM.n = n; ef.HM.d = HM; ef.bM = bM;
+  std::vector<PointFrameResidual*> pfrs;                        // window order
+  std::vector<int> host;
+  EnergyFunctional ef;
   CalibHessian HC;
-  for (int i = 0; i < 4; i++) { HC.value_scaled[i] = calib[i]; HC.value_zero[i] = calib[4 + i]; }
+  void build(const std::string& dir, sdso_shim::Device& dev) {
+    meta = load<int>(dir, "meta");             // nf np nr w h its solverMode
+    nf = meta[0]; np = meta[1]; nr = meta[2]; w = meta[3]; h = meta[4];
+    auto calib = load<double>(dir, "calib");        // value_scaled(4) value_zero(4)
+    auto evalPT = load<double>(dir, "evalPT"), state = load<double>(dir, "state"), state_zero = load<double>(dir, "state_zero"),
+         HM = load<double>(dir, "HM"), bM = load<double>(dir, "bM");
+    auto exposure = load<float>(dir, "ab_exposure"), eTH = load<float>(dir, "frameEnergyTH");
+    auto frameID = load<int>(dir, "frameID"), res_point = load<int>(dir, "res_point"), res_target = load<int>(dir, "res_target");
+    host = load<int>(dir, "host");
+    auto u = load<float>(dir, "u"), v = load<float>(dir, "v"), idepth = load<float>(dir, "idepth"), idz = load<float>(dir, "idepth_zero"),
+         color = load<float>(dir, "color"), weights = load<float>(dir, "weights"), mrb = load<float>(dir, "maxRelBaseline");
+    auto prior = load<uint8_t>(dir, "hasDepthPrior"), res_state = load<uint8_t>(dir, "res_state"), isnew = load<uint8_t>(dir, "res_isNew");
+    auto ngood = load<int>(dir, "numGoodResiduals");
+    int wv[1] = {w}, hv[1] = {h};
+    for (int f = 0; f < nf; f++) {
+      fhs.emplace_back(new FrameHessian);
+      FrameHessian& fh = *fhs.back();
+      char nm[32]; std::snprintf(nm, sizeof nm, "img%d", f);
+      load_pyramid(dir, nm, fh, 1);
+      for (int i = 0; i < 9; i++) fh.worldToCam_evalPT.R.m[i] = evalPT[f * 12 + i];
+      for (int i = 0; i < 3; i++) fh.worldToCam_evalPT.t.v[i] = evalPT[f * 12 + 9 + i];
+      for (int i = 0; i < 10; i++) { fh.state[i] = state[f * 10 + i]; fh.state_zero[i] = state_zero[f * 10 + i]; }
+      fh.ab_exposure = exposure[f]; fh.frameEnergyTH = eTH[f]; fh.frameID = frameID[f]; fh.idx = f; fh.slot = 10 + f;
+      dev.uploadFrame(fh.slot, &fh, 1, wv, hv);
+      effs.emplace_back(new EFFrame{&fh, {}, f});
+      ef.frames.push_back(effs.back().get());
+    }
+    int r = 0;
+    for (int p = 0; p < np; p++) {
+      phs.emplace_back(new PointHessian);
+      PointHessian& ph = *phs.back();
+      ph.u = u[p]; ph.v = v[p]; ph.idepth = idepth[p]; ph.idepth_zero = idz[p]; ph.hasDepthPrior = prior[p] != 0;
+      ph.maxRelBaseline = mrb[p]; ph.numGoodResiduals = ngood[p];
+      for (int k = 0; k < 8; k++) { ph.color[k] = color[p * 8 + k]; ph.weights[k] = weights[p * 8 + k]; }
+      efps.emplace_back(new EFPoint{&ph, {}, 0});
+      ph.efPoint = efps.back().get();
+      for (; r < nr && res_point[r] == p; r++) {
+        // raw new: the shim deletes dropped residuals like the reference does (deleteOut / dropResidual)
+        PointFrameResidual* pfr = new PointFrameResidual;
+        pfr->state_state = (int)res_state[r]; pfr->isNew = isnew[r] != 0; pfr->point = &ph; pfr->id = r;
+        EFResidual* efr = new EFResidual{pfr, ef.frames[res_target[r]]};
+        efr->point = ph.efPoint; efr->idxInAll = (int)ph.efPoint->residualsAll.size();
+        pfr->efResidual = efr;
+        ph.efPoint->residualsAll.push_back(efr);
+        ph.residuals.push_back(pfr);
+        pfrs.push_back(pfr);
+        ef.nResiduals++;
+        // lastResiduals: [0] the residual into the newest frame, [1] into the one before (FullSystem.cpp:1400-1410)
+        if (res_target[r] == nf - 1) ph.lastResiduals[0] = {pfr, 0};
+        if (res_target[r] == nf - 2) ph.lastResiduals[1] = {pfr, 0};
+      }
+      ef.frames[host[p]]->points.push_back(ph.efPoint);   // points arrive grouped by host (makeIDX order)
+      ef.allPoints.push_back(ph.efPoint);
+    }
+    const int n = 8 * nf + 4;
+    ef.HM.n = n; ef.HM.d = HM; ef.bM = bM;
+    for (int i = 0; i < 4; i++) { HC.value_scaled[i] = calib[i]; HC.value_zero[i] = calib[4 + i]; }
+  }
+  ~BaGraph() { for (auto& ph : phs) for (PointFrameResidual* rr : ph->residuals) { delete rr->efResidual; delete rr; } }
+};
+
+static int run_ba(const std::string& dir) {
+  sdso_shim::Device dev(0);
+  BaGraph G;
+  G.build(dir, dev);
+  const int nf = G.nf, np = G.np, nr = G.nr, w = G.w, h = G.h;
+  auto& meta = G.meta; auto& fhs = G.fhs; auto& phs = G.phs; EnergyFunctional& ef = G.ef; CalibHessian& HC = G.HC;
   sdso_shim::WindowedBA<EnergyFunctional, CalibHessian> ba(dev, 0);
   ba.upload(&ef, &HC, w, h, /*solverMode=*/meta[6], 1e12, 1e8, true, [](FrameHessian* fh) { return fh->slot; });
   const float rmse = ba.optimize(meta[5], &ef, &HC);
@@ -331,7 +434,92 @@ static int run_ba(const std::string& dir) {
   std::vector<double> o_st;
   for (int k = 0; k < 3; k++) { o_st.insert(o_st.end(), H3[k].d.begin(), H3[k].d.end()); o_st.insert(o_st.end(), b3[k].d.begin(), b3[k].d.end()); }
   dump(dir, "stitched", o_st);
-  for (auto& ph : phs) for (PointFrameResidual* rr : ph->residuals) { delete rr->efResidual; delete rr; }
+  return 0;
+}
+
+// The members the round-4 verdict found missing from the shim, driven the way the reference's own bodies drive them:
+//   linearizeAll_Reductor / applyRes_Reductor: PointFrameResidual::linearize(&HCalib) and applyRes(true) per object (FullSystemOptimize.cpp:52-96)
+//   setAdjointsF / setDeltaF (EnergyFunctional.cpp:41-119, :173-207)
+//   accumulateAF_MT / accumulateLF_MT / accumulateSCF_MT through AccumulatedTopHessianSSE / AccumulatedSCHessianSSE (:212-269)
+//   solveSystemF(iteration, lambda, &HCalib) writing into the objects (:838-995, :272-341); calcLEnergyF_MT / calcMEnergyF (:344-442)
+//   marginalizePointsF's accumulator calls (:663-736) for the points of the oldest keyframe
+static int run_ba_members(const std::string& dir) {
+  sdso_shim::Device dev(0);
+  BaGraph G;
+  G.build(dir, dev);
+  const int nf = G.nf, np = G.np, nr = G.nr, n = 8 * nf + 4;
+  EnergyFunctional& ef = G.ef; CalibHessian& HC = G.HC;
+  using BA = sdso_shim::WindowedBA<EnergyFunctional, CalibHessian>;
+  BA ba(dev, 0);
+  ba.upload(&ef, &HC, G.w, G.h, /*solverMode=*/G.meta[6], 1e12, 1e8, true, [](FrameHessian* fh) { return fh->slot; });
+  // ---- linearizeAll(false) + applyRes, object by object
+  double E = 0;
+  for (PointFrameResidual* r : G.pfrs) E += ba.linearize(r, &HC);
+  for (PointFrameResidual* r : G.pfrs) ba.applyRes(r, true);
+  std::vector<int> o_ns(nr), o_st(nr), o_act(nr);
+  std::vector<double> o_ne(nr), o_nw(nr), o_en(nr);
+  for (int i = 0; i < nr; i++) {
+    PointFrameResidual* r = G.pfrs[i];
+    o_ns[i] = r->state_NewState; o_st[i] = r->state_state; o_act[i] = r->efResidual->isActiveAndIsGoodNEW ? 1 : 0;
+    o_ne[i] = r->state_NewEnergy; o_nw[i] = r->state_NewEnergyWithOutlier; o_en[i] = r->state_energy;
+  }
+  dump(dir, "m_newState", o_ns); dump(dir, "m_state", o_st); dump(dir, "m_act", o_act); dump(dir, "m_newEnergy", o_ne); dump(dir, "m_newEnergyWO", o_nw); dump(dir, "m_energy", o_en);
+  // ---- setAdjointsF / setDeltaF
+  ba.setAdjointsF(&HC); ba.setDeltaF(&HC);
+  std::vector<double> o_ad((size_t)nf * nf * 128), o_fd(nf * 16);
+  std::vector<float> o_adf((size_t)nf * nf * 128), o_htd((size_t)nf * nf * 8), o_pd(np), o_cd(ef.cDeltaF, ef.cDeltaF + 4);
+  for (int k = 0; k < nf * nf; k++) {
+    for (int e = 0; e < 64; e++) { o_ad[(size_t)k * 128 + e] = ef.adHost[k].m[e]; o_ad[(size_t)k * 128 + 64 + e] = ef.adTarget[k].m[e];
+                                   o_adf[(size_t)k * 128 + e] = ef.adHostF[k].m[e]; o_adf[(size_t)k * 128 + 64 + e] = ef.adTargetF[k].m[e]; }
+    for (int j = 0; j < 8; j++) o_htd[(size_t)k * 8 + j] = ef.adHTdeltaF[k].m[j];
+  }
+  for (int f = 0; f < nf; f++) for (int i = 0; i < 8; i++) { o_fd[f * 16 + i] = ef.frames[f]->delta[i]; o_fd[f * 16 + 8 + i] = ef.frames[f]->delta_prior[i]; }
+  for (int p = 0; p < np; p++) o_pd[p] = G.efps[p]->deltaF;
+  dump(dir, "m_adjoints", o_ad); dump(dir, "m_adjointsF", o_adf); dump(dir, "m_adHTdeltaF", o_htd); dump(dir, "m_frame_delta", o_fd); dump(dir, "m_point_delta", o_pd); dump(dir, "m_cDeltaF", o_cd);
+  // ---- the three accumulations through the accumulator classes (bodies of accumulateAF_MT / LF_MT / SCF_MT)
+  sdso_shim::AccumulatedTopHessianSSE<BA> accSSE_top_A(ba), accSSE_top_L(ba);
+  sdso_shim::AccumulatedSCHessianSSE<BA> accSSE_bot(ba);
+  DynMat H3[3]; DynVec b3[3];
+  const int nAll = (int)ef.allPoints.size();
+  accSSE_top_A.setZero(nf);
+  for (EFFrame* f : ef.frames) for (EFPoint* p : f->points) accSSE_top_A.addPoint<0>(p, &ef);            // the MT == false branch (:225-230)
+  accSSE_top_A.stitchDoubleMT((void*)nullptr, H3[0], b3[0], &ef, false, false);
+  ef.resInA = accSSE_top_A.nres[0];
+  accSSE_top_L.setZero(nf);
+  accSSE_top_L.addPointsInternal<1>(&ef.allPoints, &ef, 0, nAll);                                            // the MT == true branch (:238-241)
+  accSSE_top_L.stitchDoubleMT((void*)nullptr, H3[1], b3[1], &ef, true, true);
+  ef.resInL = accSSE_top_L.nres[0];
+  accSSE_bot.setZero(nf);
+  accSSE_bot.addPointsInternal(&ef.allPoints, true, 0, nAll);
+  accSSE_bot.stitchDoubleMT((void*)nullptr, H3[2], b3[2], &ef, true);
+  std::vector<double> o_st3;
+  for (int k = 0; k < 3; k++) { o_st3.insert(o_st3.end(), H3[k].d.begin(), H3[k].d.end()); o_st3.insert(o_st3.end(), b3[k].d.begin(), b3[k].d.end()); }
+  dump(dir, "m_stitched", o_st3);
+  // ---- solveSystemF(iteration, lambda, &HCalib) and the energies
+  ba.solveSystemF(0, 1e-1, &HC);
+  std::vector<double> o_x = ef.lastX, o_bS = ef.lastbS, o_HS = ef.lastHS.d, o_fs(nf * 10), o_cs(HC.step.v, HC.step.v + 4);
+  std::vector<float> o_ps(np * 3);
+  for (int f = 0; f < nf; f++) for (int i = 0; i < 10; i++) o_fs[f * 10 + i] = G.fhs[f]->step[i];
+  for (int p = 0; p < np; p++) { o_ps[p * 3] = G.phs[p]->step; o_ps[p * 3 + 1] = G.efps[p]->HdiF; o_ps[p * 3 + 2] = G.efps[p]->bdSumF; }
+  dump(dir, "m_lastX", o_x); dump(dir, "m_lastbS", o_bS); dump(dir, "m_lastHS", o_HS); dump(dir, "m_frame_step", o_fs); dump(dir, "m_calib_step", o_cs); dump(dir, "m_point_step", o_ps);
+  std::vector<double> o_e = {E, ba.calcLEnergyF_MT(), ba.calcMEnergyF(), (double)ef.resInA, (double)ef.resInL};
+  // ---- marginalizePointsF's accumulator calls for the points hosted in the oldest keyframe (EnergyFunctional.cpp:680-717)
+  DynMat M, Msc; DynVec Mb, Mbsc;
+  accSSE_bot.setZero(nf); accSSE_top_A.setZero(nf);
+  int nflag = 0;
+  for (int p = 0; p < np; p++)
+    if (G.host[p] == 0) { accSSE_top_A.addPoint<2>(G.efps[p].get(), &ef); accSSE_bot.addPoint(G.efps[p].get(), false); nflag++; }
+  accSSE_top_A.stitchDouble(M, Mb, &ef, false, false);
+  accSSE_bot.stitchDouble(Msc, Mbsc, &ef);
+  ef.resInM += accSSE_top_A.nres[0];
+  std::vector<double> o_marg;
+  o_marg.insert(o_marg.end(), M.d.begin(), M.d.end()); o_marg.insert(o_marg.end(), Mb.d.begin(), Mb.d.end());
+  o_marg.insert(o_marg.end(), Msc.d.begin(), Msc.d.end()); o_marg.insert(o_marg.end(), Mbsc.d.begin(), Mbsc.d.end());
+  o_marg.insert(o_marg.end(), ba.HM().begin(), ba.HM().end()); o_marg.insert(o_marg.end(), ba.bM().begin(), ba.bM().end());
+  dump(dir, "m_marg", o_marg);
+  o_e.push_back(ba.calcLEnergyF_MT()); o_e.push_back(ba.calcMEnergyF()); o_e.push_back((double)ef.resInM); o_e.push_back((double)nflag);
+  dump(dir, "m_energies", o_e);
+  std::printf("members ok: E %.9g resInA %d resInL %d resInM %d flagged %d n %d\n", E, ef.resInA, ef.resInL, ef.resInM, nflag, n);
   return 0;
 }
 
@@ -368,6 +556,8 @@ int main(int argc, char** argv) {
     if (what == "stereo") return run_stereo(argv[1], false);
     if (what == "stereo_g2o") return run_stereo(argv[1], true);
     if (what == "ba") return run_ba(argv[1]);
+    if (what == "ba_members") return run_ba_members(argv[1]);
+    if (what == "tracker_ref") return run_tracker_ref(argv[1]);
     if (what == "selector") return run_selector(argv[1]);
   } catch (const std::exception& e) { std::fprintf(stderr, "error: %s\n", e.what()); return 1; }
   return 2;

@@ -285,3 +285,199 @@ def test_shim_selector_and_marginalize_frame(gpu_ctx, tmp_path):
     assert gpu_ctx.L.sdso_ba_marginalize_frame(2, 0, abi.dp(prior), abi.dp(dprior), abi.dp(HM), abi.dp(bM), abi.dp(Ho), abi.dp(bo)) == 0
     g = lines[1].split()
     assert int(g[1]) == 144 and int(g[2]) == 12 and float(g[3]) == Ho[0, 0] and float(g[4]) == bo[11]
+
+
+def _ba_arrays(win):
+    nf, npts, nr = win["nf"], win["np"], win["nr"]
+    arrays = dict(meta=np.array([nf, npts, nr, win["w"], win["h"], 6, win["solverMode"]], np.int32),
+                  calib=np.concatenate([win["calib_value_scaled"], win["calib_value_zero"]]).astype(np.float64))
+    for k in ("evalPT", "state", "state_zero", "HM", "bM"):
+        arrays[k] = np.asarray(win[k], np.float64)
+    for k in ("ab_exposure", "frameEnergyTH", "u", "v", "idepth", "idepth_zero", "color", "weights", "maxRelBaseline"):
+        arrays[k] = np.asarray(win[k], np.float32)
+    for k in ("frameID", "host", "res_point", "res_target", "numGoodResiduals"):
+        arrays[k] = np.asarray(win[k], np.int32)
+    for k in ("hasDepthPrior", "res_state", "res_isNew"):
+        arrays[k] = np.asarray(win[k], np.uint8)
+    for f in range(nf):
+        arrays["img%d_l0" % f] = win["pyrs"][f][0]
+    return arrays
+
+
+@pytest.mark.gpu
+def test_shim_energy_functional_members(oracle, tmp_path):
+    """The members the round-4 verdict found missing from the shim, with the reference's signatures, driven by the bodies of the reference's
+    own callers (host/test_shim.cpp::run_ba_members) on an 8-keyframe / 2000-point window and compared with the ORACLE:
+      PointFrameResidual::linearize(CalibHessian*) / applyRes(bool) per object   (Residuals.h:103, :113; FullSystemOptimize.cpp:52-96)
+      EnergyFunctional::setAdjointsF / setDeltaF                                   (EnergyFunctional.cpp:41-119, :173-207)
+      AccumulatedTopHessianSSE / AccumulatedSCHessianSSE::{setZero, addPoint<mode>, addPointsInternal<mode>, stitchDouble[MT]}
+                                                                                   (accumulateAF/LF/SCF_MT :212-269; marginalizePointsF :663-736)
+      EnergyFunctional::solveSystemF(int, double, CalibHessian*) writing into the objects (:838-995, :272-341)
+      EnergyFunctional::calcLEnergyF_MT / calcMEnergyF                             (:344-442)"""
+    base = synth.ba_window(w=1232, h=368, nf=8, pts_per_kf=250, seed=3001)
+    win, kept = helpers.drop_residuals(base, seed=11, drop_frac=0.25)
+    nf, npts, nr, n = win["nf"], win["np"], win["nr"], 8 * win["nf"] + 4
+    rs = np.random.RandomState(9)
+    A = rs.normal(0, 1, (n, n))
+    win["HM"] = (A @ A.T) * 1e3                  # a marginalisation prior, so that calcMEnergyF is not trivially zero
+    win["bM"] = rs.normal(0, 1e2, n)
+    win.setdefault("numGoodResiduals", np.zeros(npts, np.int32)); win.setdefault("maxRelBaseline", np.zeros(npts, np.float32))
+    win.setdefault("res_isNew", np.ones(nr, np.uint8))
+    # ---- the oracle, step by step
+    W, keep = abi.make_ba_window(win, frame_slots=list(range(nf)), dI_list=[p[0] for p in win["pyrs"]])
+    h = oracle.orc_ba_create(C.byref(W))
+    Eo = C.c_double(0)
+    oracle.orc_ba_linearize(h, C.byref(Eo))
+    ns, ne, nw = np.zeros(nr, np.uint8), np.zeros(nr, np.float32), np.zeros(nr, np.float32)
+    oracle.orc_ba_get_linearization(h, None, abi.bp(ns), abi.fp(ne), abi.fp(nw), None, None)
+    oracle.orc_ba_apply_res(h)
+    st, act = np.zeros(nr, np.uint8), np.zeros(nr, np.uint8)
+    oracle.orc_ba_get_residual_state(h, abi.bp(st), abi.bp(act), None)
+    adH, adT, htd = np.zeros((nf * nf, 64)), np.zeros((nf * nf, 64)), np.zeros((nf * nf, 8), np.float32)
+    oracle.orc_ba_get_tables(h, None, abi.dp(adH), abi.dp(adT), abi.fp(htd))
+    cd, fd, fdp, pd = np.zeros(4, np.float32), np.zeros((nf, 8)), np.zeros((nf, 8)), np.zeros(npts, np.float32)
+    oracle.orc_ba_get_deltas(h, abi.fp(cd), abi.dp(fd), abi.dp(fdp), abi.fp(pd))
+    oracle.orc_ba_accumulate(h)
+    st_o = [(np.zeros((n, n)), np.zeros(n)) for _ in range(3)]
+    oracle.orc_ba_get_stitched(h, *[abi.dp(a) for pair in st_o for a in pair])
+    xo, HSo, bSo, fso, cso = np.zeros(n), np.zeros((n, n)), np.zeros(n), np.zeros((nf, 8)), np.zeros(4)
+    oracle.orc_ba_solve(h, 0, 1e-1, abi.dp(xo), abi.dp(HSo), abi.dp(bSo), abi.dp(fso), abi.dp(cso))
+    pso = np.zeros(npts, np.float32)
+    oracle.orc_ba_get_point_steps(h, abi.fp(pso))
+    pto = [np.zeros(npts, np.float32) for _ in range(4)] + [np.zeros(npts * 4, np.float32)]
+    oracle.orc_ba_get_point_terms(h, *[abi.fp(a) for a in pto])
+    EL0, EM0, EL1, EM1 = C.c_double(0), C.c_double(0), C.c_double(0), C.c_double(0)
+    oracle.orc_ba_calc_energies(h, C.byref(EL0), C.byref(EM0))
+    flag = (win["host"] == 0).astype(np.uint8)
+    HMo, bMo = np.zeros((n, n)), np.zeros(n)
+    oracle.orc_ba_marginalize_points(h, abi.bp(flag), abi.dp(HMo), abi.dp(bMo))
+    oracle.orc_ba_calc_energies(h, C.byref(EL1), C.byref(EM1))
+    Po, do = abi.make_post_state(nf, npts, nr)
+    oracle.orc_ba_get_post_state(h, C.byref(Po))
+    oracle.orc_ba_destroy(h)
+    # ---- the C++ program
+    _dump(tmp_path, **_ba_arrays(win))
+    lines = _run(tmp_path, "ba_members")
+    assert lines[-1].startswith("members ok")
+    d = str(tmp_path)
+    m = lambda name, dt: _load(d, "m_" + name, dt)      # noqa: E731
+    # per-object linearize / applyRes: decisions and energies of every residual, bit for bit
+    assert np.array_equal(m("newState", np.int32), ns) and np.array_equal(m("state", np.int32), st) and np.array_equal(m("act", np.int32), act)
+    lin = ns != 1
+    assert np.array_equal(m("newEnergy", np.float64)[lin], ne[lin].astype(np.float64)) and np.array_equal(m("newEnergyWO", np.float64), nw.astype(np.float64))
+    en = m("energies", np.float64)     # E, EL, EM, resInA, resInL | EL, EM after the marginalisation, resInM, flagged
+    assert abs(en[0] - Eo.value) <= 1e-6 * Eo.value
+    # adjoints and deltas: host tables, identical
+    ad = m("adjoints", np.float64).reshape(nf * nf, 2, 64)
+    assert np.array_equal(ad[:, 0], adH) and np.array_equal(ad[:, 1], adT)
+    adf = m("adjointsF", np.float32).reshape(nf * nf, 2, 64)
+    assert np.array_equal(adf[:, 0], adH.astype(np.float32)) and np.array_equal(adf[:, 1], adT.astype(np.float32))
+    assert np.array_equal(m("adHTdeltaF", np.float32).reshape(nf * nf, 8), htd) and np.array_equal(m("cDeltaF", np.float32), cd)
+    fdg = m("frame_delta", np.float64).reshape(nf, 2, 8)
+    assert np.array_equal(fdg[:, 0], fd) and np.array_equal(fdg[:, 1], fdp) and np.array_equal(m("point_delta", np.float32), pd)
+    # the stitched systems of the three accumulator objects
+    blk = n * n + n
+    stg = m("stitched", np.float64)
+    dsc = np.sqrt(np.abs(np.diag(st_o[0][0] + st_o[1][0]))) + 1e-30
+    for k, name in enumerate(("A", "L", "SC")):
+        Hg, bg = stg[k * blk:k * blk + n * n].reshape(n, n), stg[k * blk + n * n:(k + 1) * blk]
+        Ho, bo = st_o[k]
+        assert np.abs((Hg - Ho) / np.outer(dsc, dsc)).max() <= 1e-4, name
+        assert np.abs((bg - bo) / dsc).max() <= 1e-4 * max(1.0, np.abs(bo / dsc).max()), name
+        assert np.abs(Hg).max() > 0, name
+    assert int(en[3]) == int(act.sum()) and int(en[4]) == 0
+    # solveSystemF into the objects
+    dd = np.sqrt(np.abs(np.diag(HSo))) + 1e-30
+    sc = max(1.0, np.abs(xo * dd).max())
+    xg = m("lastX", np.float64)
+    assert np.abs((xg - xo) * dd).max() / sc <= 2e-4
+    assert np.abs((m("lastHS", np.float64).reshape(n, n) - HSo) / np.outer(dd, dd)).max() <= 1e-4
+    fsg = m("frame_step", np.float64).reshape(nf, 10)
+    assert np.array_equal(fsg[:, :8].ravel(), -xg[4:]) and not fsg[:, 8:].any()              # step.head<8>() = -x.segment<8>(..), tail<2>() = 0
+    assert np.array_equal(m("calib_step", np.float64), -xg[:4])
+    psg = m("point_step", np.float32).reshape(npts, 3)
+    assert np.array_equal(psg[:, 1], pto[0]) and np.array_equal(psg[:, 2], pto[1])           # EFPoint::HdiF, bdSumF: bit-exact per-point terms
+    assert helpers.idepths_close(psg[:, 0], pso, 2e-4 * max(1.0, float(np.abs(pso).max())))
+    # the energies, before and after the marginalisation linearised the oldest keyframe's points
+    for got, ref in ((en[1], EL0.value), (en[2], EM0.value), (en[5], EL1.value), (en[6], EM1.value)):
+        assert abs(got - ref) <= 1e-5 * max(1.0, abs(ref)), (got, ref)
+    assert abs(EL1.value - EL0.value) > 0 and int(en[8]) == int(flag.sum())
+    # marginalizePointsF through the accumulator objects: M, Msc as stitched, and the prior the device keeps = the oracle's HM / bM
+    mg = m("marg", np.float64)
+    M, Mb, Msc, Mbsc, HMg, bMg = mg[:n * n].reshape(n, n), mg[n * n:blk], mg[blk:blk + n * n].reshape(n, n), mg[blk + n * n:2 * blk], mg[2 * blk:2 * blk + n * n].reshape(n, n), mg[2 * blk + n * n:]
+    dm = np.sqrt(np.abs(np.diag(HMo))) + 1e-30
+    assert np.abs((HMg - HMo) / np.outer(dm, dm)).max() <= 1e-4 and np.abs((bMg - bMo) / dm).max() <= 1e-4 * max(1.0, np.abs(bMo / dm).max())
+    HM0 = np.asarray(win["HM"], np.float64).reshape(n, n)
+    assert np.abs((HM0 + 0.25 * (M - Msc) - HMg) / np.outer(dm, dm)).max() <= 1e-9          # HM += setting_margWeightFac * (M - Msc)  (:727)
+    assert np.abs((np.asarray(win["bM"]) + 0.25 * (Mb - Mbsc) - bMg) / dm).max() <= 1e-9 * max(1.0, np.abs(bMg / dm).max())
+    assert int(en[7]) == Po.resInM and Po.resInM > 0
+
+
+@pytest.mark.gpu
+def test_shim_set_coarse_tracking_ref(oracle, tmp_path):
+    """CoarseTracker::setCoarseTrackingRef(std::vector<FrameHessian*>, FrameHessian* fh_right, CalibHessian) — CoarseTracker.h:71-72 — and
+    setCTRefForFirstFrame(std::vector<FrameHessian*>) — CoarseTracker.cpp:794-805 — with the reference's signatures on a pointer graph:
+    makeCoarseDepthL0 STEP1 (:288-356: the static-stereo re-observation of every point whose last residual is IN, there and back, the
+    accept rule, the inverse-covariance weight) and STEP2-5 run on the device; the template levels must equal, bit for bit and in
+    order, what the oracle builds from the same points (ImmaturePoint ctor, traceStereo L->R, ctor at lastTraceUV, traceStereo R->L,
+    orc_make_coarse_depth)."""
+    from test_stereo import _oracle_init, _oracle_trace
+    import pyoracle
+    pr = synth.stereo_problem(w=640, h=480, npts=1800, seed=4011)
+    L = abi.load().sdso_pyramid_levels(640, 480)
+    n = len(pr["u"])
+    rs = np.random.RandomState(7)
+    left = [np.ascontiguousarray(a) for a in pr["pyr_l"][:L]]
+    right0 = np.ascontiguousarray(pr["pyr_r"][0])
+    # what FullSystem::optimize left on the points: centerProjectedTo (sub-pixel position in the newest keyframe, idepth there),
+    # lastResiduals[0] (some absent, some not IN), efPoint->HdiF
+    cpt = np.stack([pr["u"] + rs.uniform(-0.45, 0.45, n), pr["v"] + rs.uniform(-0.45, 0.45, n), pr["idepth_true"] * rs.uniform(0.8, 1.25, n)], axis=1).astype(np.float32)
+    has_last = (rs.rand(n) < 0.9).astype(np.uint8)
+    rstate = np.where(rs.rand(n) < 0.85, 0, rs.randint(1, 3, n)).astype(np.int32)
+    hdi = (1.0 / rs.uniform(50, 5000, n)).astype(np.float32)
+    frame_of = rs.randint(0, 3, n).astype(np.int32)
+    K = np.array(pr["K"], np.float32); bl = float(pr["calib"]["baseline"])
+    sel = np.nonzero((has_last == 1) & (rstate == 0))[0]
+    # ---- expected, from the oracle
+    ui = (cpt[sel, 0] + np.float32(0.5)).astype(np.int32); vi = (cpt[sel, 1] + np.float32(0.5)).astype(np.int32)
+    uf, vf = ui.astype(np.float32), vi.astype(np.float32)
+    imin, imax = (cpt[sel, 2] * np.float32(0.1)).astype(np.float32), (cpt[sel, 2] * np.float32(1.9)).astype(np.float32)
+    co, wo, go, eo = _oracle_init(oracle, pr, left[0], uf, vf)
+    Pf, dfw = abi.make_trace_points(len(sel), uf, vf, co, wo, go, eo, imin, imax)
+    sf = _oracle_trace(oracle, pr, right0, Pf, 1)
+    good = np.nonzero(sf == 0)[0]
+    ub, vb = dfw["lastTraceUV"][good, 0].copy(), dfw["lastTraceUV"][good, 1].copy()
+    c2, w2, g2, e2 = _oracle_init(oracle, pr, right0, ub, vb)
+    Pb, db = abi.make_trace_points(len(good), ub, vb, c2, w2, g2, e2, imin[good], imax[good])
+    _oracle_trace(oracle, pr, left[0], Pb, 0)
+    new_idepth = cpt[sel, 2].copy()
+    ids = dfw["idepth_stereo"][good]
+    with np.errstate(divide="ignore"):
+        depth = np.float32(1.0) / ids
+    ok = (np.abs(uf[good] - db["lastTraceUV"][:, 0]) < 1) & (depth > 0) & (depth < 50)
+    new_idepth[good[ok]] = ids[ok]
+    assert ok.sum() > 0.3 * len(sel) and (~ok).sum() + (sf != 0).sum() > 0                 # both branches of the accept rule are taken
+    weight = np.sqrt((1e-3 / (hdi[sel].astype(np.float64) + 1e-12)).astype(np.float32)).astype(np.float32)
+    # (the reference iterates frame by frame, point by point: the splat order — which decides the float sums of colliding pixels)
+    order = np.concatenate([np.nonzero(frame_of[sel] == f)[0] for f in range(3)])
+    exp0 = pyoracle.make_coarse_depth(oracle, ui[order], vi[order], new_idepth[order], weight[order], left)
+    lastf = np.nonzero(frame_of == 2)[0]
+    pu, pv, pid = (pr["u"] + rs.uniform(-0.4, 0.4, n)).astype(np.float32), (pr["v"] + rs.uniform(-0.4, 0.4, n)).astype(np.float32), pr["idepth_true"].astype(np.float32)
+    w1 = np.sqrt((1e-3 / (hdi[lastf].astype(np.float64) + 1e-12)).astype(np.float32)).astype(np.float32)
+    exp1 = pyoracle.make_coarse_depth(oracle, (pu[lastf] + np.float32(0.5)).astype(np.int32), (pv[lastf] + np.float32(0.5)).astype(np.int32), pid[lastf], w1, left)
+    # ---- the C++ program
+    arrays = dict(meta=np.array([L, 640, 480, n, 3], np.int32), K=np.array(list(K) + [bl], np.float32), cpt=cpt, HdiF=hdi, pu=pu, pv=pv, pidepth=pid,
+                  rstate=rstate, frame_of=frame_of, has_last=has_last, right_l0=right0)
+    for l in range(L):
+        arrays["left_l%d" % l] = left[l]
+    _dump(tmp_path, **arrays)
+    lines = _run(tmp_path, "tracker_ref")
+    assert lines[-1] == "tracker_ref ok"
+    pcn = _load(str(tmp_path), "pcn", np.int32).reshape(2, L)
+    for variant, exp in enumerate((exp0, exp1)):
+        for l in range(L):
+            npc = len(exp[l]["u"])
+            assert pcn[variant, l] == npc and npc > 0, (variant, l)
+            got = _load(str(tmp_path), "pc_%d_l%d" % (variant, l), np.float32).reshape(4, npc)
+            for a, k in zip(got, ("u", "v", "idepth", "color")):
+                assert np.array_equal(a, exp[l][k]), (variant, l, k)
