@@ -355,7 +355,8 @@ int sdso_ba_marginalize_points(sdso_ctx* ctx, int win, const uint8_t* marg_flag,
 
 /* EnergyFunctional::marginalizeFrame (EnergyFunctional.cpp:554-660): remove keyframe `idx` (EFFrame::idx) from the
  * marginalisation prior.  prior8 / delta_prior8 are EFFrame::prior / delta_prior.  HM_in (8nf+4)^2, bM_in 8nf+4 ->
- * HM_out (8(nf-1)+4)^2, bM_out.  ~70x70 double algebra once per keyframe: runs on the host, needs no ctx. */
+ * HM_out (8(nf-1)+4)^2, bM_out.  Host statement of the algebra on caller-owned arrays (no ctx); the device path is
+ * sdso_ba_marginalize_frame_dev below. */
 int sdso_ba_marginalize_frame(int nf, int idx, const double* prior8, const double* delta_prior8,
                               const double* HM_in, const double* bM_in, double* HM_out, double* bM_out);
 
@@ -366,6 +367,14 @@ int sdso_ba_calc_energies(sdso_ctx* ctx, int win, double* EL, double* EM);
 /* What EnergyFunctional::setDeltaF (EnergyFunctional.cpp:173-207; .h:75) leaves behind at the window's current state: cDeltaF (4),
  * EFFrame::delta and delta_prior (nf*8 each), EFPoint::deltaF (np); adHTdeltaF comes with sdso_ba_get_tables.  Any pointer may be NULL. */
 int sdso_ba_get_deltas(sdso_ctx* ctx, int win, float* cDeltaF, double* frame_delta, double* frame_delta_prior, float* point_deltaF);
+
+/* The same on the DEVICE-resident prior of an uploaded window: HM / bM as sdso_ba_marginalize_points left them on the device go through
+ * the marginalisation of keyframe `idx` in one kernel (its EFFrame::prior / delta_prior are the window's own) and stay there; HM_out
+ * (8(nf-1)+4)^2 / bM_out are optional host copies.  sdso_ba_adopt_prior(win, from_win) hands that prior to the next window — device to
+ * device, the rows / columns of frames beyond it zero, as EnergyFunctional::insertFrame resizes HM / bM (EnergyFunctional.cpp:468-476);
+ * upload `win` with HM = bM = NULL first.  The prior then never leaves the device between two keyframes. */
+int sdso_ba_marginalize_frame_dev(sdso_ctx* ctx, int win, int idx, double* HM_out, double* bM_out);
+int sdso_ba_adopt_prior(sdso_ctx* ctx, int win, int from_win);
 
 /* keep projectedTo / centerProjectedTo of PointFrameResidual (Residuals.h:96-99) for
  * sdso_ba_get_linearization; off by default (76 B of extra stores per residual). */

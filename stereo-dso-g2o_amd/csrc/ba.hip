@@ -30,7 +30,10 @@ struct BaWindowDev {
   std::vector<HostFrame> frames;
   HostTables tab;
   Dense P;
-  std::vector<double> HM, bM;
+  std::vector<double> HM, bM;    // host mirror of the marginalisation prior; the MASTER copy is the device's (dt_HM / dt_bM): see hm_host_valid
+  bool hm_host_valid = true;     // false: a device kernel changed the prior since the mirror was filled (sync_prior_host brings it up to date)
+  double* d_marg = nullptr;      // the prior after sdso_ba_marginalize_frame_dev: (n - 8)^2 + (n - 8) doubles, adopted by the next window
+  int marg_dim = 0;              // its dimension (0: none)
   int solverMode = 0, forceAccept = 1;
   double affA = 0, affB = 0;
   std::vector<int> perm, inv;     // sorted -> original, original -> sorted
@@ -210,6 +213,17 @@ static int upload_tables(sdso_ctx* ctx, BaWindowDev* W, bool adjoints, bool sync
   put(W->d_self, &W->d, sizeof(BaDev));
   SDSO_HIP(ctx, hipMemcpyAsync(W->tbl_first, stage, W->tbl_bytes, hipMemcpyHostToDevice, ctx->stream));
   if (sync) SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SDSO_OK;
+}
+
+// host mirror of the marginalisation prior <- device (the kernels that change it leave the mirror stale)
+static int sync_prior_host(sdso_ctx* ctx, BaWindowDev* W) {
+  if (W->hm_host_valid) return SDSO_OK;
+  const int n = W->d.n;
+  SDSO_HIP(ctx, hipMemcpyAsync(W->HM.data(), W->dt_HM, sizeof(double) * n * n, hipMemcpyDeviceToHost, ctx->stream));
+  SDSO_HIP(ctx, hipMemcpyAsync(W->bM.data(), W->dt_bM, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+  SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  W->hm_host_valid = true;
   return SDSO_OK;
 }
 
@@ -874,6 +888,7 @@ namespace sdso {
 // eigen-decomposition stands in for Eigen::JacobiSVD of the symmetric matrix), x / lastHS / lastbS go back for the
 // back-substitution kernel.  Single-window path only; the batch entry points keep the default branch.
 static int solve_system_host(sdso_ctx* ctx, BaWindowDev* W, int iteration, double lambda) {
+  { const int rcs = sync_prior_host(ctx, W); if (rcs) return rcs; }
   const BaLaunch L = single(W);
   const int nf = L.nf, n = L.n;
   launch_stitch(ctx, L);
@@ -1111,6 +1126,7 @@ static int calc_energies(sdso_ctx* ctx, BaWindowDev* W, double* EL, double* EM, 
     E += Ept;
   }
   *EL = E;
+  { const int rcs = sync_prior_host(ctx, W); if (rcs) return rcs; }
   std::vector<double> delta(n);                               // getStitchedDeltaF (:1021-1032)
   for (int i = 0; i < 4; i++) delta[i] = (double)W->tab.cDeltaF[i];       // d.head<CPARS>() = cDeltaF.cast<double>()
   for (int f = 0; f < nf; f++) for (int i = 0; i < 8; i++) delta[4 + 8 * f + i] = W->frames[f].delta[i];
@@ -1302,10 +1318,11 @@ extern "C" int sdso_ba_marginalize_points(sdso_ctx* ctx, int win, const uint8_t*
   launch_accumulate(ctx, L, W->d_pflag, true);
   launch_stitch(ctx, L);
   SDSO_HIP(ctx, hipGetLastError());
-  const size_t blk = (size_t)n * n + n;
-  std::vector<double> MA(blk), MS(blk);
-  SDSO_HIP(ctx, hipMemcpyAsync(MA.data(), W->d.sol, sizeof(double) * blk, hipMemcpyDeviceToHost, ctx->stream));
-  SDSO_HIP(ctx, hipMemcpyAsync(MS.data(), W->d.sol + 2 * blk, sizeof(double) * blk, hipMemcpyDeviceToHost, ctx->stream));
+  // HM += setting_margWeightFac * (M - Msc), bM likewise (:727-728): on the device copy, which is the master — the prior stays resident
+  // from here through sdso_ba_marginalize_frame_dev into the next window (sdso_ba_adopt_prior); the host mirror follows on demand
+  hipLaunchKernelGGL(k_ba_prior_add, dim3(8, 1), dim3(256), 0, ctx->stream, L.d_arr, (double)(0.5f * 0.5f));   // setting_margWeightFac
+  SDSO_HIP(ctx, hipGetLastError());
+  W->hm_host_valid = false;
   std::vector<uint8_t> lin(nr);
   if (nr) SDSO_HIP(ctx, hipMemcpyAsync(lin.data(), W->d.r_lin, nr, hipMemcpyDeviceToHost, ctx->stream));
   SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1316,14 +1333,12 @@ extern "C" int sdso_ba_marginalize_points(sdso_ctx* ctx, int win, const uint8_t*
     SDSO_HIP(ctx, hipMemcpy(&nresM, W->d.accum + acc_off_nres(W->d.nf), sizeof(float), hipMemcpyDeviceToHost));
     W->resInM += (int)nresM;
   }
-  const float fac = 0.5f * 0.5f;  // setting_margWeightFac
-  for (size_t i = 0; i < (size_t)n * n; i++) W->HM[i] += fac * (MA[i] - MS[i]);
-  for (int i = 0; i < n; i++) W->bM[i] += fac * (MA[(size_t)n * n + i] - MS[(size_t)n * n + i]);
-  H2D(W->dt_HM, W->HM.data(), sizeof(double) * n * n);
-  H2D(W->dt_bM, W->bM.data(), sizeof(double) * n);
-  SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  if (HM_out) std::memcpy(HM_out, W->HM.data(), sizeof(double) * n * n);
-  if (bM_out) std::memcpy(bM_out, W->bM.data(), sizeof(double) * n);
+  if (HM_out || bM_out) {
+    const int rcs = sync_prior_host(ctx, W);
+    if (rcs) return rcs;
+    if (HM_out) std::memcpy(HM_out, W->HM.data(), sizeof(double) * n * n);
+    if (bM_out) std::memcpy(bM_out, W->bM.data(), sizeof(double) * n);
+  }
   W->accumulated = false;
   W->marg_accumulated = true;
   return SDSO_OK;
@@ -1546,6 +1561,52 @@ extern "C" int sdso_ba_marginalize_frame(int nf, int idx, const double* prior8, 
   }
   for (int i = 0; i < odim; i++) { b[i] = S[i] * b[i]; for (int j = 0; j < odim; j++) H[(size_t)i * odim + j] = S[i] * H[(size_t)i * odim + j] * S[j]; }
   for (int r = 0; r < ndim; r++) { bM_out[r] = b[r]; for (int c = 0; c < ndim; c++) HM_out[(size_t)r * ndim + c] = 0.5 * (H[(size_t)r * odim + c] + H[(size_t)c * odim + r]); }
+  return SDSO_OK;
+}
+
+// EnergyFunctional::marginalizeFrame (EnergyFunctional.cpp:554-660) on the window's DEVICE-resident prior (k_ba_marg_frame): what
+// sdso_ba_marginalize_points left in dt_HM / dt_bM goes through the frame's marginalisation without visiting the host; the result stays in
+// the window (BaWindowDev::d_marg) until the next window adopts it (sdso_ba_adopt_prior).  prior / delta_prior are the frame's own
+// (EFFrame::prior, delta_prior = the host mirror's, as uploaded / as the resident loop left them).  HM_out / bM_out: optional copies.
+extern "C" int sdso_ba_marginalize_frame_dev(sdso_ctx* ctx, int win, int idx, double* HM_out, double* bM_out) {
+  GET_WIN();
+  const int nf = W->d.nf, n = W->d.n, m = n - 8;
+  SDSO_REQUIRE(ctx, idx >= 0 && idx < nf, "frame index out of range");
+  if (!W->d_marg) { DM(W->d_marg, double, (size_t)n * n + n); }
+  double pr[16];
+  for (int i = 0; i < 8; i++) { pr[i] = W->frames[idx].prior[i]; pr[8 + i] = W->frames[idx].delta_prior[i]; }
+  int rc = ensure_scratch(ctx, sizeof(pr));
+  if (rc) return rc;
+  SDSO_HIP(ctx, hipMemcpyAsync(ctx->scratch, pr, sizeof(pr), hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_ba_marg_frame, dim3(1), dim3(256), 0, ctx->stream, (const BaDev*)W->d_self, idx, (const double*)ctx->scratch, W->d_marg);
+  SDSO_HIP(ctx, hipGetLastError());
+  W->marg_dim = m;
+  SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));     // (pr is stack-local)
+  if (HM_out) SDSO_HIP(ctx, hipMemcpy(HM_out, W->d_marg, sizeof(double) * m * m, hipMemcpyDeviceToHost));
+  if (bM_out) SDSO_HIP(ctx, hipMemcpy(bM_out, W->d_marg + (size_t)m * m, sizeof(double) * m, hipMemcpyDeviceToHost));
+  return SDSO_OK;
+}
+
+// The next window takes over the prior sdso_ba_marginalize_frame_dev left in `from_win`: device to device, the new keyframe's 8 rows /
+// columns zero — what EnergyFunctional::insertFrame does to HM / bM (EnergyFunctional.cpp:468-476: conservativeResize + setZero of the new
+// rows and columns).  `win` must have been uploaded with HM = bM = NULL (zeros) and hold at least as many frames as the prior covers.
+__global__ __launch_bounds__(256) void k_ba_prior_adopt(double* __restrict__ HM, double* __restrict__ bM, int n, const double* __restrict__ src, int m) {
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < n * n + n; e += gridDim.x * 256) {
+    if (e < n * n) { const int i = e / n, j = e - i * n; HM[e] = (i < m && j < m) ? src[(size_t)i * m + j] : 0.0; }
+    else { const int i = e - n * n; bM[i] = i < m ? src[(size_t)m * m + i] : 0.0; }
+  }
+}
+extern "C" int sdso_ba_adopt_prior(sdso_ctx* ctx, int win, int from_win) {
+  GET_WIN();
+  BaWindowDev* F = find_win(ctx, from_win);
+  SDSO_REQUIRE(ctx, F && F->d_marg && F->marg_dim > 0, "the source window holds no marginalised prior (sdso_ba_marginalize_frame_dev first)");
+  SDSO_REQUIRE(ctx, F != W, "a window cannot adopt its own prior");
+  const int n = W->d.n, m = F->marg_dim;
+  SDSO_REQUIRE(ctx, m <= n, "the prior covers more frames than the window holds");
+  hipLaunchKernelGGL(k_ba_prior_adopt, dim3(8), dim3(256), 0, ctx->stream, W->dt_HM, W->dt_bM, n, (const double*)F->d_marg, m);
+  SDSO_HIP(ctx, hipGetLastError());
+  W->hm_host_valid = false;
+  W->accumulated = false;
   return SDSO_OK;
 }
 

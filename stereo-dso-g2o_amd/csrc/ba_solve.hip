@@ -693,6 +693,91 @@ __global__ __launch_bounds__(256) void k_ba_sol_record(const BaDev* __restrict__
   }
 }
 
+// ------------------------------------------------------------------ the marginalisation prior, resident
+// EnergyFunctional::marginalizePointsF's last lines (EnergyFunctional.cpp:727-728): HM += setting_margWeightFac * (M - Msc), bM likewise, on the
+// DEVICE copy of the prior — M / Mb and Msc / Mbsc are blocks 0 and 2 of BaDev::sol, where the stitch kernels just put them.
+__global__ __launch_bounds__(256) void k_ba_prior_add(const BaDev* __restrict__ wins, double fac) {
+  const BaDev& B = wins[blockIdx.y];
+  const int n = B.n;
+  const size_t blk = (size_t)n * n + n;
+  const double* MA = B.sol; const double* MS = B.sol + 2 * blk;
+  double* HM = const_cast<double*>(B.t_HM); double* bM = const_cast<double*>(B.t_bM);
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < n * n + n; e += gridDim.x * 256) {
+    if (e < n * n) HM[e] += fac * (MA[e] - MS[e]);
+    else bM[e - n * n] += fac * (MA[e] - MS[e]);
+  }
+}
+
+// EnergyFunctional::marginalizeFrame (EnergyFunctional.cpp:554-660) on the device-resident prior of one window: the frame's 8 rows / columns
+// go to the end (step 1), its prior is added (step 2), the system is scaled by 1 / sqrt(|diag| + 10), the 8 x 8 corner inverted, the Schur
+// complement taken and the scaling undone (step 3), the result symmetrised.  One 256-thread workgroup, everything f64 in LDS; every sum
+// runs over its 8 terms in index order, the inverse is the partial-pivoting elimination of sdso_ba_marginalize_frame (the host statement
+// of the same function: bit-identical results).  pr8: EFFrame::prior (8) then delta_prior (8).  out: (n - 8)^2 row-major, then n - 8.
+constexpr int MF_MAXN = 68;
+__global__ __launch_bounds__(256) void k_ba_marg_frame(const BaDev* __restrict__ wins, int idx, const double* __restrict__ pr8, double* __restrict__ out) {
+  const BaDev& B = wins[0];
+  const int odim = B.n, ndim = odim - 8, tid = threadIdx.x;
+  __shared__ double H[MF_MAXN * MF_MAXN], b[MF_MAXN], S[MF_MAXN], Si[MF_MAXN], bli[(MF_MAXN - 8) * 8], inv[64];
+  __shared__ int ord[MF_MAXN];
+  if (tid < odim) {
+    const int lo = idx * 8 + 4;
+    ord[tid] = tid < lo ? tid : tid < ndim ? tid + 8 : lo + (tid - ndim);     // the others keep their order, the frame's 8 follow
+  }
+  __syncthreads();
+  for (int e = tid; e < odim * odim; e += 256) { const int i = e / odim, j = e - i * odim; H[e] = B.t_HM[(size_t)ord[i] * odim + ord[j]]; }
+  if (tid < odim) b[tid] = B.t_bM[ord[tid]];
+  __syncthreads();
+  if (tid < 8) { H[(ndim + tid) * odim + ndim + tid] += pr8[tid]; b[ndim + tid] += pr8[tid] * pr8[8 + tid]; }
+  __syncthreads();
+  if (tid < odim) { S[tid] = sqrt(fabs(H[tid * odim + tid]) + 10); Si[tid] = 1.0 / S[tid]; }
+  __syncthreads();
+  for (int e = tid; e < odim * odim; e += 256) { const int i = e / odim, j = e - i * odim; H[e] = Si[i] * H[e] * Si[j]; }
+  if (tid < odim) b[tid] = Si[tid] * b[tid];
+  __syncthreads();
+  if (tid == 0) {   // hpi = 0.5f * (hpi + hpi); hpi = hpi.inverse(); hpi = 0.5f * (hpi + hpi)   (:617-620)
+    double A[8][8], iv[8][8];
+    for (int i = 0; i < 8; i++) for (int j = 0; j < 8; j++) { const double v = H[(ndim + i) * odim + ndim + j]; A[i][j] = 0.5f * (v + v); iv[i][j] = i == j; }
+    for (int k = 0; k < 8; k++) {
+      int pv = k;
+      for (int i = k + 1; i < 8; i++) if (fabs(A[i][k]) > fabs(A[pv][k])) pv = i;
+      if (pv != k) for (int j = 0; j < 8; j++) { const double t1 = A[k][j]; A[k][j] = A[pv][j]; A[pv][j] = t1; const double t2 = iv[k][j]; iv[k][j] = iv[pv][j]; iv[pv][j] = t2; }
+      const double d = A[k][k];
+      for (int j = 0; j < 8; j++) { A[k][j] /= d; iv[k][j] /= d; }
+      for (int i = 0; i < 8; i++) {
+        if (i == k) continue;
+        const double f = A[i][k];
+        if (f == 0) continue;
+        for (int j = 0; j < 8; j++) { A[i][j] -= f * A[k][j]; iv[i][j] -= f * iv[k][j]; }
+      }
+    }
+    for (int i = 0; i < 8; i++) for (int j = 0; j < 8; j++) inv[i * 8 + j] = 0.5f * (iv[i][j] + iv[i][j]);
+  }
+  __syncthreads();
+  for (int e = tid; e < ndim * 8; e += 256) {          // bli = bottomLeft^T * hpi
+    const int r = e >> 3, c = e & 7;
+    double s = 0;
+    for (int k = 0; k < 8; k++) s += H[(ndim + k) * odim + r] * inv[k * 8 + c];
+    bli[e] = s;
+  }
+  __syncthreads();
+  for (int e = tid; e < ndim * ndim; e += 256) {
+    const int r = e / ndim, c = e - r * ndim;
+    double s = 0;
+    for (int k = 0; k < 8; k++) s += bli[r * 8 + k] * H[(ndim + k) * odim + c];
+    H[r * odim + c] -= s;
+  }
+  if (tid < ndim) {
+    double s = 0;
+    for (int k = 0; k < 8; k++) s += bli[tid * 8 + k] * b[ndim + k];
+    b[tid] -= s;
+  }
+  __syncthreads();
+  for (int e = tid; e < ndim * ndim; e += 256) { const int r = e / ndim, c = e - r * ndim; H[r * odim + c] = S[r] * H[r * odim + c] * S[c]; }
+  __syncthreads();
+  for (int e = tid; e < ndim * ndim; e += 256) { const int r = e / ndim, c = e - r * ndim; out[e] = 0.5 * (H[r * odim + c] + H[c * odim + r]); }
+  if (tid < ndim) out[(size_t)ndim * ndim + tid] = S[tid] * b[tid];
+}
+
 // FullSystem::backupState / doStepFromBackup / loadSateBackup for the points.  op: 0 backup, 1 step, 2 restore
 // op 3 = backup + step in one pass (the resident loop never restores)
 __global__ __launch_bounds__(BA_BLOCK) void k_ba_points_op(const BaDev* __restrict__ wins, int op, float stepfacD, float* __restrict__ sums /* per block: sumID, sumNID */,

@@ -327,6 +327,8 @@ def load():
     L.sdso_ba_batch_exchange_mode.argtypes = [vp, C.c_int]
     L.sdso_ba_get_counts.argtypes = [vp, C.c_int, c_int_p, c_int_p, c_int_p]
     L.sdso_ba_calc_energies.argtypes = [vp, C.c_int, c_double_p, c_double_p]
+    L.sdso_ba_marginalize_frame_dev.argtypes = [vp, C.c_int, C.c_int, c_double_p, c_double_p]
+    L.sdso_ba_adopt_prior.argtypes = [vp, C.c_int, C.c_int]
     L.sdso_ba_get_deltas.argtypes = [vp, C.c_int, c_float_p, c_double_p, c_double_p, c_float_p]
     L.sdso_comm_unique_id.argtypes = [vp]
     L.sdso_comm_init.argtypes = [vp, C.c_int, C.c_int, vp]
@@ -374,7 +376,7 @@ EXPORTED_SYMBOLS = [
     "sdso_ba_batch_accum_dev", "sdso_ba_batch_get_x", "sdso_ba_batch_set_materialize",
     "sdso_immature_init_batch", "sdso_trace_stereo_batch", "sdso_trace_stereo_prepare", "sdso_trace_stereo_enqueue",
     "sdso_trace_stereo_fetch", "sdso_stereo_match_batch", "sdso_activate_points_batch", "sdso_ba_marginalize_frame", "sdso_ba_batch_linearize", "sdso_ba_batch_schur", "sdso_pixel_select", "sdso_pixel_selector_pattern", "sdso_trace_on_batch", "sdso_track_make_ref", "sdso_track_newest_coarse_batch", "sdso_track_get_ref",
-    "sdso_ba_get_post_state", "sdso_ba_batch_keep_system", "sdso_ba_get_stitched", "sdso_ba_batch_exchange_mode", "sdso_ba_resubstitute", "sdso_ba_get_counts", "sdso_ba_calc_energies", "sdso_ba_get_deltas",
+    "sdso_ba_get_post_state", "sdso_ba_batch_keep_system", "sdso_ba_get_stitched", "sdso_ba_batch_exchange_mode", "sdso_ba_resubstitute", "sdso_ba_get_counts", "sdso_ba_calc_energies", "sdso_ba_get_deltas", "sdso_ba_marginalize_frame_dev", "sdso_ba_adopt_prior",
     "sdso_ba_batch_optimize", "sdso_ba_batch_optimize_begin", "sdso_ba_batch_step", "sdso_ba_batch_solve_step", "sdso_ba_batch_optimize_end", "sdso_ba_get_state",
     "sdso_comm_unique_id", "sdso_comm_init", "sdso_comm_init_host", "sdso_comm_attach", "sdso_comm_info", "sdso_comm_destroy", "sdso_ba_allreduce", "sdso_ba_allreduce_window",
     "sdso_g2o_track_add_edges", "sdso_g2o_track_linearize", "sdso_g2o_track_newest_coarse", "sdso_g2o_lba_eval", "sdso_trace_set_gn_mode",

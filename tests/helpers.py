@@ -111,6 +111,36 @@ def drop_residuals(win, seed, drop_frac=0.25):
     return w2, kept
 
 
+def drop_frame(win, idx):
+    """The window after keyframe `idx` left it (EnergyFunctional::marginalizeFrame step 4, EnergyFunctional.cpp:631-641, once
+    its points are gone): the frame, the points it hosted and every residual into it are removed, later frames move up.
+    HM / bM are left to the caller (they change dimension)."""
+    nf = win["nf"]
+    keep_f = [f for f in range(nf) if f != idx]
+    remap = {f: k for k, f in enumerate(keep_f)}
+    keep_p = np.nonzero(win["host"] != idx)[0]
+    pmap = -np.ones(win["np"], np.int64)
+    pmap[keep_p] = np.arange(len(keep_p))
+    keep_r = np.nonzero((pmap[win["res_point"]] >= 0) & (win["res_target"] != idx))[0]
+    w2 = dict(win)
+    w2["nf"] = nf - 1
+    for k in ("evalPT", "state", "state_zero", "ab_exposure", "frameEnergyTH", "frameID"):
+        w2[k] = np.ascontiguousarray(np.asarray(win[k])[keep_f])
+    w2["pyrs"] = [win["pyrs"][f] for f in keep_f]
+    for k in ("u", "v", "idepth", "idepth_zero", "color", "weights", "hasDepthPrior"):
+        w2[k] = np.ascontiguousarray(win[k][keep_p])
+    w2["host"] = np.array([remap[int(h)] for h in win["host"][keep_p]], np.int32)
+    w2["res_point"] = pmap[win["res_point"][keep_r]].astype(np.int32)
+    w2["res_target"] = np.array([remap[int(t)] for t in win["res_target"][keep_r]], np.int32)
+    w2["res_state"] = np.ascontiguousarray(win["res_state"][keep_r])
+    w2["np"], w2["nr"] = len(keep_p), len(keep_r)
+    for k in ("numGoodResiduals", "maxRelBaseline", "res_isNew"):
+        w2.pop(k, None)
+    n2 = 8 * (nf - 1) + 4
+    w2["HM"] = np.zeros((n2, n2)); w2["bM"] = np.zeros(n2)
+    return w2
+
+
 def apply_drops(res_lists, to_remove_ids):
     """dropResidual / deleteOut on per-point id lists (swap-with-last), in the given order."""
     out = [list(l) for l in res_lists]

@@ -180,3 +180,75 @@ def test_marginalize_in_batch_member(gpu_ctx, oracle, win_c3):
         assert np.abs((xg - xo) * d).max() <= 2e-4 * max(1.0, np.abs(xo * d).max())
     gpu_ctx.check(gpu_ctx.L.sdso_ba_release_window(gpu_ctx.h, 3))
     oracle.orc_ba_destroy(h)
+
+
+def test_marginalize_frame_on_the_device_resident_prior(gpu_ctx, oracle, win_c3):
+    """EnergyFunctional::marginalizeFrame (EnergyFunctional.cpp:554-660) inside the window's life on the device: HM / bM stay resident from
+    sdso_ba_marginalize_points through sdso_ba_marginalize_frame_dev into the next window (sdso_ba_adopt_prior) — no host copy on the way.
+      (1) the kernel against orc_marginalize_frame on the SAME input (the device's own prior after the points' marginalisation, with the
+          frame's EFFrame::prior / delta_prior): <= 1e-9 whitened (the 8 x 8 corner carries the 1e10 .. 1e14 priors of the first keyframe
+          and the two elimination orders of its inverse round differently — the bar tests/test_abi_cpu.py holds the host statement
+          to), exactly symmetric, and IDENTICAL, bit for bit, to the library's host statement of the same algebra;
+      (2) the chain marginalise points -> marginalise frame -> next window -> solve equals the host chain (prior copied out, host algebra,
+          uploaded with the next window): the same x;
+      (3) the whole chain against the ORACLE's chain at the loop bars (the points' marginalisation carries float accumulation)."""
+    import helpers
+    ctx = gpu_ctx
+    win = dict(win_c3)
+    nf, npts, nr, n = win["nf"], win["np"], win["nr"], 8 * win["nf"] + 4
+    m = n - 8
+    A = np.random.RandomState(5).normal(size=(n, 6))
+    win["HM"] = (A @ A.T) * 1e4
+    win["bM"] = np.random.RandomState(6).normal(size=n) * 1e2
+    flag = (win["host"] == 0).astype(np.uint8)            # marginalizeFrame asserts fh->points.size() == 0: all of its points go first
+    W, keep, h = _both(ctx, oracle, win, wid=21)
+    _lin_both(ctx, oracle, win, h, 21)
+    oracle.orc_ba_apply_res(h); ctx.check(ctx.L.sdso_ba_apply_res(ctx.h, 21))
+    _accumulate_both(ctx, oracle, win, h, 21)
+    HMo, bMo = np.zeros((n, n)), np.zeros(n)
+    oracle.orc_ba_marginalize_points(h, abi.bp(flag), abi.dp(HMo), abi.dp(bMo))
+    ctx.check(ctx.L.sdso_ba_marginalize_points(ctx.h, 21, abi.bp(flag), None, None))       # (no copy out: the prior stays on the device)
+    Hg, bg = np.zeros((m, m)), np.zeros(m)
+    ctx.check(ctx.L.sdso_ba_marginalize_frame_dev(ctx.h, 21, 0, abi.dp(Hg), abi.dp(bg)))
+    # EFFrame::prior of the frame with frameID 0 (settings.cpp:44-48) and delta_prior = its state (EnergyFunctionalStructs.cpp:59-61)
+    assert win["frameID"][0] == 0
+    prior = np.array([1e10] * 3 + [1e11] * 3 + [1e14, 1e14], np.float32).astype(np.float64)      # (the settings are floats: 1e11f = 99999997952)
+    dprior = np.ascontiguousarray(np.asarray(win["state"], np.float64).reshape(nf, 10)[0, :8])
+    # (1) the same input through the oracle and through the library's host statement
+    HMd, bMd = np.zeros((n, n)), np.zeros(n)
+    ctx.check(ctx.L.sdso_ba_marginalize_points(ctx.h, 21, abi.bp(np.zeros(npts, np.uint8)), abi.dp(HMd), abi.dp(bMd)))   # nothing flagged: HM unchanged, copied out
+    Ho, bo, Hh, bh = np.zeros((m, m)), np.zeros(m), np.zeros((m, m)), np.zeros(m)
+    assert oracle.orc_marginalize_frame(nf, 0, abi.dp(prior), abi.dp(dprior), abi.dp(HMd), abi.dp(bMd), abi.dp(Ho), abi.dp(bo)) == 0
+    assert ctx.L.sdso_ba_marginalize_frame(nf, 0, abi.dp(prior), abi.dp(dprior), abi.dp(HMd), abi.dp(bMd), abi.dp(Hh), abi.dp(bh)) == 0
+    d = np.sqrt(np.abs(np.diag(Ho))) + 1e-300
+    assert np.abs((Hg - Ho) / np.outer(d, d)).max() <= 1e-9 and np.abs((bg - bo) / d).max() <= 1e-9 * max(1.0, np.abs(bo / d).max())
+    assert np.array_equal(Hg, Hg.T) and np.array_equal(Hg, Hh) and np.array_equal(bg, bh)
+    # (3) against the oracle's own chain
+    Hoo, boo = np.zeros((m, m)), np.zeros(m)
+    oracle.orc_marginalize_frame(nf, 0, abi.dp(prior), abi.dp(dprior), abi.dp(HMo), abi.dp(bMo), abi.dp(Hoo), abi.dp(boo))
+    live = np.abs(np.diag(Hoo)) > 0
+    do = np.sqrt(np.abs(np.diag(Hoo))) + 1e-300
+    assert np.abs(((Hg - Hoo) / np.outer(do, do))[np.ix_(live, live)]).max() <= 1e-4
+    oracle.orc_ba_destroy(h)
+    # (2) the next window: the seven remaining keyframes; the device chain adopts the prior, the host chain uploads it
+    w2 = helpers.drop_frame(win, 0)
+    n2 = 8 * w2["nf"] + 4
+    assert n2 == m
+    xs = []
+    for chain in ("device", "host"):
+        wk = dict(w2)
+        if chain == "host":
+            wk["HM"], wk["bM"] = Hh.copy(), bh.copy()
+        for f in range(wk["nf"]):
+            ctx.upload_pyramid(60 + f, wk["pyrs"][f][:1])
+        W2, keep2 = abi.make_ba_window(wk, frame_slots=[60 + f for f in range(wk["nf"])], dI_list=[p[0] for p in wk["pyrs"]])
+        ctx.check(ctx.L.sdso_ba_upload_window(ctx.h, 22, C.byref(W2)))
+        if chain == "device":
+            ctx.check(ctx.L.sdso_ba_adopt_prior(ctx.h, 22, 21))
+        ctx.check(ctx.L.sdso_ba_linearize(ctx.h, 22, None)); ctx.check(ctx.L.sdso_ba_apply_res(ctx.h, 22)); ctx.check(ctx.L.sdso_ba_accumulate(ctx.h, 22))
+        x, HS = np.zeros(n2), np.zeros((n2, n2))
+        ctx.check(ctx.L.sdso_ba_solve(ctx.h, 22, 0, 0.1, abi.dp(x), abi.dp(HS), None, None, None))
+        xs.append((x, HS))
+    assert np.abs(xs[0][0]).max() > 0 and np.array_equal(xs[0][0], xs[1][0]) and np.array_equal(xs[0][1], xs[1][1])
+    assert ctx.L.sdso_ba_adopt_prior(ctx.h, 22, 22) == -1 and ctx.L.sdso_ba_marginalize_frame_dev(ctx.h, 22, 9, None, None) == -1
+    ctx.check(ctx.L.sdso_ba_release_window(ctx.h, 21)); ctx.check(ctx.L.sdso_ba_release_window(ctx.h, 22))
