@@ -29,6 +29,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "stereo-dso-g2o_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))     # synth.py: the synthetic-input generators (test / bench infrastructure)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 # PMC passes of this same command (tools/profile_round.sh + tools/make_traffic.py); the latest round's file
@@ -64,7 +65,8 @@ class TrackerWorkload:
     bytes_per_unit = 64.0  # 16 B template point + 4 taps x 12 B
 
     def __init__(self, ctx, args, rank):
-        from sdso_amd import abi, synth
+        from sdso_amd import abi
+        import synth
         self.ctx, self.abi = ctx, abi
         t0 = time.time()
         prob = synth.tracker_problem(w=1232, h=368, npts=2000, seed=2002 + rank)
@@ -141,7 +143,8 @@ class TraceWorkload:
     bytes_per_unit = 132.0 + 1232 * 368 * 12.0 / 20000.0
 
     def __init__(self, ctx, args, rank):
-        from sdso_amd import abi, synth
+        from sdso_amd import abi
+        import synth
         self.ctx, self.abi = ctx, abi
         pr = synth.stereo_problem(w=1232, h=368, npts=args.batch or 20000, seed=4001 + rank)
         self.pr = pr
@@ -201,7 +204,51 @@ class TraceWorkload:
                 "sample": "%.0f s per leg of 20k-point batches, oracle -O3 -march=native" % budget_s}
 
 
+class MatchWorkload:
+    """The L->R->L pattern every caller of traceStereo runs (FullSystem::stereoMatch FullSystem.cpp:581-613, makeCoarseDepthL0
+    CoarseTracker.cpp:295-347) through the BOUNDARY call sdso_stereo_match_batch: host point arrays in, statuses / idepths / uvs out —
+    ImmaturePoint ctor, trace, ctor at lastTraceUV, trace back, chained on the device.  The step includes the call's H2D / D2H copies
+    (it is the boundary's rate, not a kernel's); unit = matched point (two traces, two constructors)."""
+    name = "stereo_match_lrl_kitti1232x368"
+    kernel = "k_trace_stereo"
+    unit = "points/s"
+    bytes_per_unit = 2 * (132.0 + 1232 * 368 * 12.0 / 20000.0)
+
+    def __init__(self, ctx, args, rank):
+        from sdso_amd import abi
+        import synth
+        self.ctx, self.abi = ctx, abi
+        pr = synth.stereo_problem(w=1232, h=368, npts=args.batch or 20000, seed=4001 + rank)
+        ctx.upload_pyramid(80, [np.ascontiguousarray(pr["pyr_l"][0])]); ctx.upload_pyramid(81, [np.ascontiguousarray(pr["pyr_r"][0])])
+        n = len(pr["u"])
+        self.K = np.array(pr["K"], np.float32); self.bl = float(pr["calib"]["baseline"])
+        self.u, self.v = np.ascontiguousarray(pr["u"], np.float32), np.ascontiguousarray(pr["v"], np.float32)
+        self.out = dict(status_fwd=np.zeros(n, np.uint8), status_back=np.zeros(n, np.uint8), idepth_stereo=np.zeros(n, np.float32), back_uv=np.zeros((n, 2), np.float32))
+        M = abi.StereoMatch()
+        M.n = n; M.u = abi.fp(self.u); M.v = abi.fp(self.v)
+        for k, a in self.out.items():
+            setattr(M, k, abi.bp(a) if a.dtype == np.uint8 else abi.fp(a))
+        self.M = M
+        self.units_per_step = n
+        self.config = {"workload": self.name, "points": n, "includes_host_copies": True, "parallelism": "replicas"}
+
+    def step(self):
+        self.ctx.check(self.ctx.L.sdso_stereo_match_batch(self.ctx.h, 80, 81, self.abi.fp(self.K), self.bl, 1, C.byref(self.M)))
+
+    def verify(self):
+        sf, sb = self.out["status_fwd"], self.out["status_back"]
+        good = sf == 0
+        with np.errstate(divide="ignore"):
+            ok = good & (sb == 0) & (np.abs(self.u - self.out["back_uv"][:, 0]) < 1) & (1.0 / self.out["idepth_stereo"] > 0) & (1.0 / self.out["idepth_stereo"] < 70)
+        assert ok.mean() > 0.3
+        return {"forward_good_fraction": float(good.mean()), "accepted_fraction": float(ok.mean())}
+
+    def cpu_baseline(self, budget_s=6.0):
+        return {"value": None, "unit": self.unit, "cores": 0, "kind": "port", "sample": "not timed for this workload: see --workload trace"}
+
+
 WORKLOADS = {"tracker": TrackerWorkload, "trace": TraceWorkload}
+ALL_WORKLOADS = dict(WORKLOADS, match=MatchWorkload)
 
 
 def side_run(cls, ctx, args, rank, steps=30, warmup=5):
@@ -230,8 +277,7 @@ def side_run(cls, ctx, args, rank, steps=30, warmup=5):
         # on-chip roofline of the tap gathers (MI355X_MICROARCH.md: L2 ~34.5 TB/s aggregate; LDS ds_read_b32 ~75 TB/s aggregate):
         # 4-byte taps per second against what the cache hierarchy / the LDS array could deliver
         taps = wl.taps_per_step / (avg * 1e-3)
-        out["onchip"] = {"taps_per_s": taps, "tap_bytes_GBps": taps * 4 / 1e9, "frac_of_l2_rate": taps * 4 / 34.5e12, "frac_of_lds_b32_rate": taps * 4 / 75e12,
-                         "lds_band_variant": os.environ.get("SDSO_TRACE_BAND") is not None}
+        out["onchip"] = {"taps_per_s": taps, "tap_bytes_GBps": taps * 4 / 1e9, "frac_of_l2_rate": taps * 4 / 34.5e12, "frac_of_lds_b32_rate": taps * 4 / 75e12}
     return out
 
 
@@ -315,7 +361,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default=os.environ.get("SDSO_BENCH_WORKLOAD", "ba"), choices=["ba", "tracker", "trace"])
+    ap.add_argument("--workload", default=os.environ.get("SDSO_BENCH_WORKLOAD", "ba"), choices=["ba", "tracker", "trace", "match"])
     ap.add_argument("--batch", type=int, default=0, help="independent problems (frames / windows / pairs) per step and GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--scaling", default=os.environ.get("SDSO_BENCH_SCALING", "weak"), choices=["weak", "strong"],
@@ -356,7 +402,7 @@ def main():
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from sdso_amd import abi
     ctx = abi.Context(local_rank)
-    wl = WORKLOADS[args.workload](ctx, args, rank) if args.workload != "ba" else None
+    wl = ALL_WORKLOADS[args.workload](ctx, args, rank) if args.workload != "ba" else None
     if wl is None:
         from bench_ba import BAWorkload
         wl = BAWorkload(ctx, args, rank, world, device=local_rank)
@@ -413,6 +459,14 @@ def main():
                          "kernel_avg_ms": avg_ms, "launches": klaunch, "algorithmic_bytes_per_unit": wl.bytes_per_unit},
             "extra": extra,
         }
+        if args.workload in ("trace", "match"):
+            # SQ / cache counters of this kernel (profiles/r05_trace_*): taps are served on chip (L1 / L2 hit rates there), HBM sees the
+            # image once and the point state; the kernel is bound by instruction issue and the latency chain of its phases
+            out["roofline"]["bound_note"] = ("not an HBM-bound kernel at this size: `frac` is its compulsory bytes over the HBM peak; the tap rate against "
+                                             "the on-chip rates is in extra.onchip / profiles/r05_trace_cache_summary.txt")
+            if getattr(wl, "taps_per_step", 0) and avg_ms > 0:
+                taps = wl.taps_per_step / (avg_ms * 1e-3)
+                out["extra"]["onchip"] = {"taps_per_s": taps, "tap_bytes_GBps": taps * 4 / 1e9, "frac_of_l2_rate": taps * 4 / 34.5e12, "frac_of_lds_b32_rate": taps * 4 / 75e12}
         tr = out["roofline"]["traffic"]
         if tr and avg_ms > 0:
             # what the counters say about the bound: the kernel's REAL HBM traffic (128-byte lines of sparse 16-byte taps, the records) over
@@ -424,7 +478,8 @@ def main():
         out["extra"]["host_enqueue_ms_per_step"] = t_enq / args.steps * 1e3
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = wl.cpu_baseline()
-            out["extra"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+            if out["cpu_baseline"].get("value"):
+                out["extra"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
         if args.workload == "ba" and world == 1 and not args.no_cpu_baseline and os.environ.get("SDSO_BENCH_SKIP_OTHERS") != "1":
             # the two other units of BASELINE.json's metric family, measured the same way in short runs (informational; the
             # headline `value` / `roofline` above are the BA workload's)

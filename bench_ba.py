@@ -45,7 +45,8 @@ class BAWorkload:
 
     def __init__(self, ctx, args, rank, world, device=0):
         import torch
-        from sdso_amd import abi, synth
+        from sdso_amd import abi
+        import synth
         self.ctx, self.abi, self.world, self.torch = ctx, abi, world, torch
         t0 = time.time()
         from sdso_amd import dist as sdist

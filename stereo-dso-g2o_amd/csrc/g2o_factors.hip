@@ -1,4 +1,4 @@
-// The fork's LIVE factors on the device (S3 lives in stereo.hip as k_trace_stereo<1>).
+// The fork's LIVE factors on the device (S3 lives in stereo.hip as k_trace_stereo_blk<1, .>).
 //
 //   EdgeSE3PosePhotoDSO              src/FullSystem/dso_g2o_edge.cpp:395-500, graph build CoarseTracker.cpp:600-792
 //   EdgeLBASE3PosePhotoIdepthCamDSO  src/FullSystem/dso_g2o_edge.cpp:5-282,   graph build FullSystemOptimize.cpp:455-542

@@ -74,326 +74,16 @@ __global__ __launch_bounds__(256) void k_immature_init(const float4* __restrict_
   energyTH[p] = bad ? NAN : e;
 }
 
-// BAND (A/B variant, SDSO_TRACE_BAND=1): the survey's design — the wave first stages the (numSteps + 6) x 6 band of the intensity plane
-// that its search touches in LDS (12 coalesced row-segment loads instead of 32 gathers per lane) and takes the 8 x 4 taps of every step
-// from there.  Same floats, same expression: bit-identical outputs.  Measured equal to the L1-served gathers: the kernel
-// is bound by the latency chain of a wave, not by the tap rate of either path.
-constexpr int kBandW = 112, kBandH = 6;
-// getInterpolatedElement31 (interp31_plane's expression) on the LDS band
-__device__ __forceinline__ float interp31_band(const float* band, int off, float x, float y) {
-  const int ix = (int)x;
-  const int iy = (int)y;
-  const float dx = x - ix;
-  const float dy = y - iy;
-  const float dxdy = dx * dy;
-  const float* bp = band + (ix + iy * kBandW - off);
-  return dxdy * bp[1 + kBandW] + (dy - dxdy) * bp[kBandW] + (dx - dxdy) * bp[1] + (1 - dx - dy + dxdy) * bp[0];
-}
-template <int GN_MODE, bool BAND = false, int MINB = 1>
-__global__ __launch_bounds__(256, MINB) void k_trace_stereo(TraceDev T) {
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int i = blockIdx.x * 4 + wv;
-  if (i >= T.n) return;
-  if (T.skip && T.skip[i]) { if (lane == 0 && T.status) T.status[i] = 255; return; }
-  __shared__ float s_err[4][128];
-  __shared__ float s_band[BAND ? 4 : 1][BAND ? kBandH * kBandW : 1];
-  volatile float* errors = s_err[wv];
-  const float4* __restrict__ dI = T.img;
-  const int wG0 = T.w, hG0 = T.h;
-  const float u_stereo = T.u_stereo[i], v_stereo = T.v_stereo[i];
-  float idepth_min_stereo = T.idepth_min_stereo[i], idepth_max_stereo = T.idepth_max_stereo[i];
-  const float* color = T.color + (size_t)i * 8;
-  const float* weights = T.weights + (size_t)i * 8;
-  const float* gradH = T.gradH + (size_t)i * 4;
-  const float idepth_min = T.idepth_min[i], energyTH = T.energyTH[i];
-  float quality = T.quality[i];
-  const uint8_t prevStatus = T.lastTraceStatus[i];
-
-  auto finish = [&](int st, float uvx, float uvy, float interval, bool writeUV) {
-    if (lane == 0) {
-      T.lastTraceStatus[i] = (uint8_t)st;
-      if (T.status) T.status[i] = (uint8_t)st;
-      if (writeUV) { T.lastTraceUV[i * 2] = uvx; T.lastTraceUV[i * 2 + 1] = uvy; T.lastTracePixelInterval[i] = interval; }
-      T.quality[i] = quality;
-    }
-  };
-
-  const float bl0 = T.mode_right ? -T.baseline : T.baseline;
-  float Kt[3];
-  Kt[0] = (T.fx * bl0 + 0.0f * 0.0f) + T.cx * 0.0f;
-  Kt[1] = (0.0f * bl0 + T.fy * 0.0f) + T.cy * 0.0f;
-  Kt[2] = (0.0f * bl0 + 0.0f * 0.0f) + 1.0f * 0.0f;
-  const float bf = -T.fx * bl0;
-  float pr[3];
-  pr[0] = (1.0f * u_stereo + 0.0f * v_stereo) + 0.0f * 1.0f;
-  pr[1] = (0.0f * u_stereo + 1.0f * v_stereo) + 0.0f * 1.0f;
-  pr[2] = (0.0f * u_stereo + 0.0f * v_stereo) + 1.0f * 1.0f;
-  float ptpMin[3];
-#pragma unroll
-  for (int k = 0; k < 3; k++) ptpMin[k] = pr[k] + Kt[k] * idepth_min_stereo;
-  const float uMin = ptpMin[0] / ptpMin[2];
-  const float vMin = ptpMin[1] / ptpMin[2];
-  if (!(uMin > 4 && vMin > 4 && uMin < wG0 - 5 && vMin < hG0 - 5)) { finish(IPS_OOB, -1, -1, 0, true); return; }
-
-  float dist, uMax, vMax, ptpMax[3];
-  const float maxPixSearch = (wG0 + hG0) * kMaxPixSearch;
-  const bool finiteMax = isfinite(idepth_max_stereo);
-  if (finiteMax) {
-#pragma unroll
-    for (int k = 0; k < 3; k++) ptpMax[k] = pr[k] + Kt[k] * idepth_max_stereo;
-    uMax = ptpMax[0] / ptpMax[2];
-    vMax = ptpMax[1] / ptpMax[2];
-    if (!(uMax > 4 && vMax > 4 && uMax < wG0 - 5 && vMax < hG0 - 5)) { finish(IPS_OOB, -1, -1, 0, true); return; }
-    dist = (uMin - uMax) * (uMin - uMax) + (vMin - vMax) * (vMin - vMax);
-    dist = sqrtf(dist);
-    if (dist < kTraceSlackInterval) { finish(IPS_SKIPPED, 0, 0, 0, false); return; }
-  } else {
-    dist = maxPixSearch;
-#pragma unroll
-    for (int k = 0; k < 3; k++) ptpMax[k] = pr[k] + Kt[k] * 0.01f;
-    uMax = ptpMax[0] / ptpMax[2];
-    vMax = ptpMax[1] / ptpMax[2];
-    const float ddx = uMax - uMin;
-    const float ddy = vMax - vMin;
-    const float d = 1.0f / sqrtf(ddx * ddx + ddy * ddy);
-    uMax = uMin + dist * ddx * d;
-    vMax = vMin + dist * ddy * d;
-    if (!(uMax > 4 && vMax > 4 && uMax < wG0 - 5 && vMax < hG0 - 5)) { finish(IPS_OOB, -1, -1, 0, true); return; }
-  }
-  if (!(idepth_min < 0 || (ptpMin[2] > 0.75 && ptpMin[2] < 1.5))) { finish(IPS_OOB, -1, -1, 0, true); return; }
-
-  float dx = kTraceStepsize * (uMax - uMin);
-  float dy = kTraceStepsize * (vMax - vMin);
-  const float a = (dx * gradH[0] + dy * gradH[2]) * dx + (dx * gradH[1] + dy * gradH[3]) * dy;
-  const float b = (dy * gradH[0] + (-dx) * gradH[2]) * dy + (dy * gradH[1] + (-dx) * gradH[3]) * (-dx);
-  float errorInPixel = 0.2f + 0.2f * (a + b) / a;
-  if (errorInPixel * kTraceMinImprovement > dist && finiteMax) { finish(IPS_BADCONDITION, 0, 0, 0, false); return; }
-  if (errorInPixel > 10) errorInPixel = 10;
-  dx /= dist;
-  dy /= dist;
-  if (dist > maxPixSearch) {
-    uMax = uMin + maxPixSearch * dx;
-    vMax = vMin + maxPixSearch * dy;
-    dist = maxPixSearch;
-  }
-  int numSteps = 1.9999f + dist / kTraceStepsize;
-  const float randShift = uMin * 1000 - floorf(uMin * 1000);
-  const float ptx0 = uMin - randShift * dx;
-  const float pty0 = vMin - randShift * dy;
-  if (!isfinite(dx) || !isfinite(dy)) { finish(IPS_OOB, -1, -1, 0, true); return; }
-  if (numSteps >= 100) numSteps = 99;
-
-  // ---- discrete search: lane = step (ptx is the reference's running sum ptx += dx)
-  float myE[2] = {1e30f, 1e30f}, myX[2] = {0, 0}, myY[2] = {0, 0};
-#pragma unroll
-  for (int pass = 0; pass < 2; pass++) {
-    const int s = pass * 64 + lane;
-    if (s < numSteps) {
-      float ptx = ptx0, pty = pty0;
-      for (int k = 0; k < s; k++) { ptx += dx; pty += dy; }
-      myX[pass] = ptx; myY[pass] = pty;
-    }
-  }
-  // BAND: bounding box of every tap of the wave (wave-uniform); staged only when it fits the LDS band (always for rectified stereo:
-  // dy == 0 and numSteps <= 99), otherwise the wave falls back to the gathers
-  bool banded = false;
-  int bandOff = 0;
-  if constexpr (BAND) {
-    int xlo = 1 << 30, xhi = -(1 << 30), ylo = 1 << 30, yhi = -(1 << 30);
-#pragma unroll
-    for (int pass = 0; pass < 2; pass++) {
-      const int s = pass * 64 + lane;
-      if (s < numSteps) {
-        xlo = min(xlo, (int)(myX[pass] + (float)-2)); xhi = max(xhi, (int)(myX[pass] + (float)2) + 1);
-        ylo = min(ylo, (int)(myY[pass] + (float)-2)); yhi = max(yhi, (int)(myY[pass] + (float)2) + 1);
-      }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      xlo = min(xlo, __shfl_xor(xlo, o, 64)); xhi = max(xhi, __shfl_xor(xhi, o, 64));
-      ylo = min(ylo, __shfl_xor(ylo, o, 64)); yhi = max(yhi, __shfl_xor(yhi, o, 64));
-    }
-    const int bw = xhi - xlo + 1, bh = yhi - ylo + 1;
-    banded = bw >= 1 && bw <= kBandW && bh >= 1 && bh <= kBandH && xlo >= 0 && ylo >= 0 && xhi < wG0 && yhi < hG0;
-    if (banded) {
-      float* band = s_band[wv];
-      for (int r = 0; r < bh; r++)
-        for (int c = lane; c < bw; c += 64) band[r * kBandW + c] = T.plane[(size_t)(ylo + r) * wG0 + xlo + c];
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      bandOff = ylo * kBandW + xlo;            // the tap of pixel (ix, iy) sits at band[ix + iy * kBandW - bandOff]
-    }
-  }
-#pragma unroll
-  for (int pass = 0; pass < 2; pass++) {
-    const int s = pass * 64 + lane;
-    if (s < numSteps) {
-      const float ptx = myX[pass], pty = myY[pass];
-      float energy = 0;
-#pragma unroll
-      for (int idx = 0; idx < 8; idx++) {
-        const float tx = (float)(ptx + (float)c_pat[idx][0]), ty = (float)(pty + (float)c_pat[idx][1]);
-        float hitColor;
-        if (BAND && banded) hitColor = interp31_band(s_band[wv], bandOff, tx, ty);
-        else hitColor = interp31_plane(T.plane, tx, ty, wG0);
-        if (!isfinite(hitColor)) { energy += 1e5; continue; }
-        const float residual = hitColor - (float)(1.0f * color[idx] + 0.0f);
-        const float hw = fabsf(residual) < kHuberTH ? 1 : kHuberTH / fabsf(residual);
-        energy += hw * residual * residual * (2 - hw);
-      }
-      errors[s] = energy;
-      myE[pass] = energy;
-    }
-  }
-  // first minimum (the reference takes strictly smaller energies only, in step order)
-  float bE = 1e10f; int bI = -1; float bX = 0, bY = 0;
-#pragma unroll
-  for (int pass = 0; pass < 2; pass++) {
-    const int s = pass * 64 + lane;
-    if (s < numSteps && myE[pass] < bE) { bE = myE[pass]; bI = s; bX = myX[pass]; bY = myY[pass]; }
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const float oE = __shfl_xor(bE, o, 64); const int oI = __shfl_xor(bI, o, 64);
-    const float oX = __shfl_xor(bX, o, 64), oY = __shfl_xor(bY, o, 64);
-    const bool take = (oI >= 0) && (bI < 0 || oE < bE || (oE == bE && oI < bI));
-    if (take) { bE = oE; bI = oI; bX = oX; bY = oY; }
-  }
-  float bestU = bX, bestV = bY, bestEnergy = bE;
-  const int bestIdx = bI;
-  if (bestIdx < 0) { bestU = 0; bestV = 0; bestEnergy = 1e10f; }
-  float secondBest = 1e10f;
-#pragma unroll
-  for (int pass = 0; pass < 2; pass++) {
-    const int s = pass * 64 + lane;
-    if (s < numSteps && (s < bestIdx - kMinTraceTestRadius || s > bestIdx + kMinTraceTestRadius) && myE[pass] < secondBest) secondBest = myE[pass];
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) secondBest = fminf(secondBest, __shfl_xor(secondBest, o, 64));
-  const float newQuality = secondBest / bestEnergy;
-  if (newQuality < quality || numSteps > 10) quality = newQuality;
-
-  if constexpr (GN_MODE == 1) {
-    // ---- fork-live refinement (ImmaturePoint.cpp:309-412): VertexUVDSO at (bestU, bestV) in double, 8 EdgeTracePointUVDSO
-    // (dso_g2o_edge.cpp:571-619) with Huber(9), one undamped g2o Gauss-Newton step per pass, update clamped by
-    // VertexUVDSO::oplusImpl (dso_g2o_vertex.cpp:73-88).  Pattern pixel idx on lane idx, summed in order.
-    double U = bestU, V = bestV;
-    const double ddx = dx, ddy = dy;
-    if (kTraceGNIterations > 0) bestEnergy = 1e5;
-    for (int it = 0; it < kTraceGNIterations; it++) {
-      double e = 0, J = 0;
-      float te = 0;
-      if (lane < 8) {
-        if (!((U - 2) < 0 || (U + 3) > (wG0 - 3) || (V - 2) < 0 || (V + 3) > (hG0 - 3))) {
-          const float3 hit = interp33(dI, (float)(U + (float)c_pat[lane][0]), (float)(V + (float)c_pat[lane][1]), wG0);
-          if (isfinite(hit.x)) {
-            e = hit.x - (1.0f * (double)color[lane] + 0.0f);
-            J = ddx * hit.y + ddy * hit.z;
-          }
-        }
-        const float residual = e;
-        const float hw = fabsf(residual) < kHuberTH ? 1 : kHuberTH / fabsf(residual);
-        te = weights[lane] * weights[lane] * hw * residual * residual * (2 - hw);
-      }
-      const double e2 = e * e;
-      const double rho1 = e2 <= (double)kHuberTH * kHuberTH ? 1. : kHuberTH / sqrt(e2);
-      const double tb = rho1 * J * e, tH = J * rho1 * J;
-      float energy = 0;
-      double Hs = 0, bs = 0;
-#pragma unroll
-      for (int idx = 0; idx < 8; idx++) {
-        energy += lane_bcast(te, idx);
-        bs -= __shfl(tb, idx, 64);
-        Hs += __shfl(tH, idx, 64);
-      }
-      if (Hs != 0) {
-        double update = bs / Hs;
-        if (update < -0.5) update = -0.5;
-        else if (update > 0.5) update = 0.5;
-        else if (!isfinite(update)) update = 0;
-        U += update * ddx;
-        V += update * ddy;
-      }
-      if (!(energy > bestEnergy)) bestEnergy = energy;
-    }
-    bestU = U;
-    bestV = V;
-  } else {
-  // ---- DSO-native GN (ImmaturePoint.cpp:707-769): pattern pixel idx on lane idx, summed in order
-  float uBak = bestU, vBak = bestV, stepBack = 0;
-  const float gnstepsize = 1;
-  if (kTraceGNIterations > 0) bestEnergy = 1e5;
-  for (int it = 0; it < kTraceGNIterations; it++) {
-    float tH = 0, tb = 0, te = 0;
-    bool nan = false;
-    if (lane < 8) {
-      const float3 hit = interp33(dI, (float)(bestU + (float)c_pat[lane][0]), (float)(bestV + (float)c_pat[lane][1]), wG0);
-      if (!isfinite(hit.x)) nan = true;
-      else {
-        const float residual = hit.x - (1.0f * color[lane] + 0.0f);
-        const float dResdDist = dx * hit.y + dy * hit.z;
-        const float hw = fabsf(residual) < kHuberTH ? 1 : kHuberTH / fabsf(residual);
-        tH = hw * dResdDist * dResdDist;
-        tb = hw * residual * dResdDist;
-        te = weights[lane] * weights[lane] * hw * residual * residual * (2 - hw);
-      }
-    }
-    float H = 1, bb = 0, energy = 0;
-#pragma unroll
-    for (int idx = 0; idx < 8; idx++) {
-      const float h_ = lane_bcast(tH, idx), b_ = lane_bcast(tb, idx), e_ = lane_bcast(te, idx);
-      const int nn = lane_bcast((int)nan, idx);
-      if (nn) { energy += 1e5; continue; }
-      H += h_; bb += b_; energy += e_;
-    }
-    if (energy > bestEnergy) {
-      stepBack *= 0.5;
-      bestU = uBak + stepBack * dx;
-      bestV = vBak + stepBack * dy;
-    } else {
-      float step = -gnstepsize * bb / H;
-      if (step < -0.5) step = -0.5;
-      else if (step > 0.5) step = 0.5;
-      if (!isfinite(step)) step = 0;
-      uBak = bestU;
-      vBak = bestV;
-      stepBack = step;
-      bestU += step * dx;
-      bestV += step * dy;
-      bestEnergy = energy;
-    }
-    if (fabsf(stepBack) < kTraceGNThreshold) break;
-  }
-  }
-
-  if (!(bestEnergy < energyTH * kTraceExtraSlack)) {
-    finish(prevStatus == IPS_OUTLIER ? IPS_OOB : IPS_OUTLIER, -1, -1, 0, true);
-    return;
-  }
-  if (dx * dx > dy * dy) {
-    idepth_min_stereo = (pr[2] * (bestU - errorInPixel * dx) - pr[0]) / (Kt[0] - Kt[2] * (bestU - errorInPixel * dx));
-    idepth_max_stereo = (pr[2] * (bestU + errorInPixel * dx) - pr[0]) / (Kt[0] - Kt[2] * (bestU + errorInPixel * dx));
-  } else {
-    idepth_min_stereo = (pr[2] * (bestV - errorInPixel * dy) - pr[1]) / (Kt[1] - Kt[2] * (bestV - errorInPixel * dy));
-    idepth_max_stereo = (pr[2] * (bestV + errorInPixel * dy) - pr[1]) / (Kt[1] - Kt[2] * (bestV + errorInPixel * dy));
-  }
-  if (idepth_min_stereo > idepth_max_stereo) { const float t = idepth_min_stereo; idepth_min_stereo = idepth_max_stereo; idepth_max_stereo = t; }
-  if (lane == 0) { T.idepth_min_stereo[i] = idepth_min_stereo; T.idepth_max_stereo[i] = idepth_max_stereo; }
-  if (!isfinite(idepth_min_stereo) || !isfinite(idepth_max_stereo) || (idepth_max_stereo < 0)) { finish(IPS_OUTLIER, -1, -1, 0, true); return; }
-  if (lane == 0) T.idepth_stereo[i] = (u_stereo - bestU) / bf;
-  finish(IPS_GOOD, bestU, bestV, 2 * errorInPixel, true);
-}
-
-// ImmaturePoint::traceStereo, block organisation (default): a 256-thread workgroup owns 64 points.
+// ImmaturePoint::traceStereo (ImmaturePoint.cpp:94-451), block organisation: a 256-thread workgroup owns PTS (16) points.
 //   phase 1  thread t < 64 : the search geometry of point t, one LANE per point (the reference's scalar code; every early exit of
 //                            ImmaturePoint.cpp:118-238 is a per-lane exit) -> numSteps, start, direction in LDS
-//   phase 2  wave w        : the discrete searches of points 16w .. 16w+15, one after the other, lanes = steps (as in the per-wave kernel)
+//   phase 2  wave w        : the discrete searches of its points, one after the other, lanes = steps
 //   phase 3  thread t < 64 : sub-pixel refinement of point t with the 8 pattern pixels in a serial loop (the reference's order by
 //                            construction), interval update, outputs
-// The per-wave kernel above spends every instruction of the geometry at 1 / 64 and of the refinement at 8 / 64 lanes and is VALU-issue
-// bound (1 350 VALU instructions per point); here those parts run 64 points per instruction: ~750 per point.  Same expressions, same
-// operation order: bit-identical outputs.
+// (Rounds 1-3 ran one wave per point — every instruction of the geometry at 1 / 64 and of the refinement at 8 / 64 lanes, VALU-issue bound
+// at 1 350 VALU instructions per point — and kept that kernel, an LDS-band variant of it and an 8-waves-per-SIMD build for A/B until
+// round 5: 52-57 us against 33 us per 20 000 points, profiles/README.md.)  Same expressions, same operation order as the reference:
+// bit-identical outputs.
 // value of lane 8 (lane / 8) + K of a group of eight lanes (ds_swizzle_b32, bit mode: and 0x18, or K, inside each half of the wave)
 template <int K>
 __device__ __forceinline__ float tr_bcast8(float v) { return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x18 | (K << 5))); }
@@ -1001,25 +691,12 @@ extern "C" int sdso_trace_stereo_prepare(sdso_ctx* ctx, int frame_slot, const fl
   SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return SDSO_OK;
 }
-// k_trace_stereo in the ctx's refinement mode; SDSO_TRACE_BAND=1 selects the LDS-band A/B variant (read per launch)
+// the traceStereo kernel in the ctx's refinement mode (0 DSO-native GN, 1 the fork's g2o passes)
 static void launch_trace_stereo(sdso_ctx* ctx, const TraceDev& T, bool timed = false /* the benchmarked enqueue: the kernel's own duration under the name k_trace_stereo */) {
-  const dim3 g((T.n + 3) / 4), b(256);
-  const bool band = getenv("SDSO_TRACE_BAND") != nullptr;
-  // default: the block organisation (64 points per workgroup); SDSO_TRACE_WAVE=1 (or one of the A/B variants below) selects the
-  // one-wave-per-point kernel
-  if (!band && !getenv("SDSO_TRACE_OCC") && !getenv("SDSO_TRACE_WAVE")) {
-    const char* e = getenv("SDSO_TRACE_PTS");
-    const int pts = e ? atoi(e) : 16;
-#define TB(G, P) do { if (timed) launch_timed(ctx, "k_trace_stereo", 1, (k_trace_stereo_blk<G, P>), dim3((T.n + P - 1) / P), b, T); else hipLaunchKernelGGL((k_trace_stereo_blk<G, P>), dim3((T.n + P - 1) / P), b, 0, ctx->stream, T); } while (0)
-    if (ctx->gn_mode == 1) { if (pts == 64) TB(1, 64); else if (pts == 32) TB(1, 32); else if (pts == 8) TB(1, 8); else TB(1, 16); }
-    else { if (pts == 64) TB(0, 64); else if (pts == 32) TB(0, 32); else if (pts == 8) TB(0, 8); else TB(0, 16); }
-#undef TB
-    return;
-  }
-  ProfScope ps(ctx, "k_trace_stereo", timed ? 1 : 1000);        // (the A/B variants: bracketed)
-  if (getenv("SDSO_TRACE_OCC") && ctx->gn_mode == 0 && !band) { hipLaunchKernelGGL((k_trace_stereo<0, false, 8>), g, b, 0, ctx->stream, T); return; }
-  if (ctx->gn_mode == 1) { if (band) hipLaunchKernelGGL((k_trace_stereo<1, true>), g, b, 0, ctx->stream, T); else hipLaunchKernelGGL((k_trace_stereo<1, false>), g, b, 0, ctx->stream, T); }
-  else { if (band) hipLaunchKernelGGL((k_trace_stereo<0, true>), g, b, 0, ctx->stream, T); else hipLaunchKernelGGL((k_trace_stereo<0, false>), g, b, 0, ctx->stream, T); }
+  constexpr int P = 16;
+  const dim3 g((T.n + P - 1) / P), b(256);
+  if (ctx->gn_mode == 1) { if (timed) launch_timed(ctx, "k_trace_stereo", 1, (k_trace_stereo_blk<1, P>), g, b, T); else hipLaunchKernelGGL((k_trace_stereo_blk<1, P>), g, b, 0, ctx->stream, T); }
+  else { if (timed) launch_timed(ctx, "k_trace_stereo", 1, (k_trace_stereo_blk<0, P>), g, b, T); else hipLaunchKernelGGL((k_trace_stereo_blk<0, P>), g, b, 0, ctx->stream, T); }
 }
 extern "C" int sdso_trace_stereo_enqueue(sdso_ctx* ctx) {
   if (!ctx || !reg_has(g_trace, ctx)) return sdso::fail(ctx, SDSO_ERR_STATE, "no prepared trace batch");

@@ -1304,9 +1304,13 @@ extern "C" int sdso_track_newest_coarse_batch(sdso_ctx* ctx, int nhyp, const int
   int G = std::min(LM_MAXG, (ctx->n_cu * 7 / 8) / slots8);   // (an eighth of the CUs stays free: a grid that needs every CU waits on any straggler)
   if (g_env > 0) G = std::min(G, g_env);
   if (G < 2) G = 1;
-  // test hook (tests/test_tracker_gpu.py): the first attempt loses one member of every cluster, with a short spin limit — the call
-  // must come back through the single-workgroup repetition with the single-workgroup result
+#ifdef SDSO_TEST_HOOKS
+  // test hook, compiled into libsdso_hip_hooks.so only (csrc/Makefile; tests/test_variants_gpu.py): the first attempt loses one member of
+  // every cluster, with a short spin limit — the call must come back through the single-workgroup repetition with its result
   const bool drop = getenv("SDSO_TRK_LM_TEST_DROP_MEMBER") != nullptr;
+#else
+  const bool drop = false;
+#endif
   for (int attempt = 0; attempt < 2; attempt++) {
     for (int k = 0; k < nhyp; k++) { hj[k].T = lastToNew[k]; hj[k].aff = aff_g2l[k]; hj[k].out.evaluations = -1; }   // (-1 until member 0 reports)
     SDSO_HIP(ctx, hipMemcpyAsync(dj, hj, sizeof(LmJob) * nhyp, hipMemcpyHostToDevice, ctx->stream));

@@ -5,7 +5,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in ("stereo-dso-g2o_amd", "oracle", "tests"):
     sys.path.insert(0, os.path.join(ROOT, p))
-from sdso_amd import abi, synth
+from sdso_amd import abi
+import synth
 import pyoracle, helpers
 
 orc = pyoracle.load(fast=True)

@@ -13,7 +13,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in ("stereo-dso-g2o_amd", "oracle", "tests"):
     sys.path.insert(0, os.path.join(ROOT, p))
-from sdso_amd import abi, synth  # noqa: E402
+from sdso_amd import abi  # noqa: E402
+import synth
 import pyoracle  # noqa: E402  (reported CPU baseline only)
 import test_stereo as ts  # noqa: E402
 

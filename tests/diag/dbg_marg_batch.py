@@ -8,7 +8,8 @@ import numpy as np
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 for p in ("stereo-dso-g2o_amd", "oracle", "tests"):
     sys.path.insert(0, os.path.join(ROOT, p))
-from sdso_amd import abi, synth  # noqa: E402
+from sdso_amd import abi  # noqa: E402
+import synth
 import pyoracle  # noqa: E402
 
 oracle = pyoracle.load()

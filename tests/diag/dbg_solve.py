@@ -4,7 +4,8 @@ ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 for p in ("stereo-dso-g2o_amd", "oracle", "tests"):
     sys.path.insert(0, os.path.join(ROOT, p))
 import pyoracle
-from sdso_amd import abi, synth
+from sdso_amd import abi
+import synth
 orc = pyoracle.load()
 ctx = abi.Context(0)
 for (w, h, nf, ppk) in ((640, 480, 5, 60), (1232, 368, 8, 250)):

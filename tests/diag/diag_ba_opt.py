@@ -4,7 +4,8 @@ import ctypes as C, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [os.path.join(ROOT, "stereo-dso-g2o_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
-from sdso_amd import abi, synth
+from sdso_amd import abi
+import synth
 import pyoracle
 
 def permuted(win, seed):

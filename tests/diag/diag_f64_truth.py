@@ -6,7 +6,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 for p in ("stereo-dso-g2o_amd", "oracle", "tests"):
     sys.path.insert(0, os.path.join(ROOT, p))
 import pyoracle
-from sdso_amd import abi, synth
+from sdso_amd import abi
+import synth
 import test_oracle_ba as T
 orc = pyoracle.load()
 ctx = abi.Context(0)

@@ -5,7 +5,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 for p in ("stereo-dso-g2o_amd", "oracle", "tests"):
     sys.path.insert(0, os.path.join(ROOT, p))
 import pyoracle
-from sdso_amd import abi, synth
+from sdso_amd import abi
+import synth
 orc = pyoracle.load()
 ctx = abi.Context(0)
 cases = {"small": synth.ba_window(w=640, h=480, nf=5, pts_per_kf=120, seed=3001),

@@ -12,7 +12,8 @@ import numpy as np
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 for p in ("stereo-dso-g2o_amd", "oracle", "tests"):
     sys.path.insert(0, os.path.join(ROOT, p))
-from sdso_amd import abi, synth  # noqa: E402
+from sdso_amd import abi  # noqa: E402
+import synth
 import pyoracle  # noqa: E402
 
 
@@ -96,15 +97,30 @@ def summarize(rows):
                 dev_mean=float(dev.mean()), cpu_mean=float(cpu.mean()), dev_worse=int((dev > cpu).sum()))
 
 
+def summarize_updates(upd):
+    """upd: (name, device errors per iteration, cpu errors per iteration).  The per-iteration distance of the pose UPDATE from the truth's."""
+    dev = np.array([d for _, dv, _ in upd for d in dv]); cpu = np.array([c for _, _, cv in upd for c in cv])
+    d0 = np.array([dv[0] for _, dv, _ in upd]); c0 = np.array([cv[0] for _, _, cv in upd])
+    return dict(n=int(len(dev)), dev_median=float(np.median(dev)), cpu_median=float(np.median(cpu)), dev_max=float(dev.max()), cpu_max=float(cpu.max()),
+                dev_farther_by_5e6=int((dev > cpu + 5e-6).sum()), cpu_farther_by_5e6=int((cpu > dev + 5e-6).sum()),
+                first_dev_median=float(np.median(d0)), first_cpu_median=float(np.median(c0)), first_dev_max=float(d0.max()), first_cpu_max=float(c0.max()),
+                first_dev_farther=int((d0 > c0).sum()), first_n=int(len(d0)))
+
+
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 24
     oracle = pyoracle.load()
     ctx = abi.Context(0)
     rows = []
     print("# tail = %s" % ("round-2 kernels (SDSO_BA_TAIL=0)" if os.environ.get("SDSO_BA_TAIL") == "0" else "k_ba_tail (default)"))
+    upd = []
     for name, win in windows(n):
-        dev, cpu, its = loop_distances(ctx, oracle, win)
+        tr = {}
+        dev, cpu, its = loop_distances(ctx, oracle, win, traces=tr)
         rows.append((dev, cpu))
+        upd.append((name, tr["dev"], tr["cpu"]))
         print("%-16s its dev/cpu/truth %d/%d/%d   states: device %.2e  cpu-f32 %.2e   idepths: device %.2e  cpu-f32 %.2e" % (name, its[0], its[1], its[2], dev[0], cpu[0], dev[1], cpu[1]), flush=True)
+        print("%-16s pose updates vs the truth's, per iteration   device %s   cpu-f32 %s" % ("", " ".join("%.1e" % v for v in tr["dev"]), " ".join("%.1e" % v for v in tr["cpu"])), flush=True)
     print("summary", summarize(rows))
+    print("updates", summarize_updates(upd))
     ctx.close()

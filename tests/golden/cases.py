@@ -9,7 +9,8 @@ import hashlib
 import numpy as np
 
 import helpers
-from sdso_amd import abi, synth
+from sdso_amd import abi
+import synth
 
 
 def digest(*arrays):

@@ -155,7 +155,7 @@ def apply_drops(res_lists, to_remove_ids):
 
 def smoke_ba(ctx, orc):
     """One GN iteration of the windowed BA (linearize, applyRes, accumulate, solve) on a small window, vs the oracle."""
-    from sdso_amd import synth
+    import synth
     win = synth.ba_window(w=320, h=240, nf=4, pts_per_kf=60, seed=3031)
     nf, nr, n = win["nf"], win["nr"], 8 * win["nf"] + 4
     for f in range(nf):
@@ -188,7 +188,7 @@ def smoke_ba(ctx, orc):
 
 def smoke_stereo(ctx, orc):
     """ImmaturePoint ctor + traceStereo on a small stereo pair, bit-exact vs the oracle."""
-    from sdso_amd import synth
+    import synth
     pr = synth.stereo_problem(w=320, h=240, npts=400, seed=4031)
     left = np.ascontiguousarray(pr["pyr_l"][0]); right = np.ascontiguousarray(pr["pyr_r"][0])
     ctx.upload_pyramid(80, [left]); ctx.upload_pyramid(81, [right])
@@ -214,7 +214,7 @@ def gen_windows(specs):
     """synth.ba_window(**spec) for every spec, rendered on a few host threads (numpy releases the GIL; every window has its own
     RandomState, so the arrays are those of one call after the other)"""
     from concurrent.futures import ThreadPoolExecutor
-    from sdso_amd import synth
+    import synth
     specs = list(specs)
     if len(specs) <= 1:
         return [synth.ba_window(**s) for s in specs]

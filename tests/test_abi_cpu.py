@@ -8,7 +8,8 @@ import numpy as np
 import pytest
 
 import helpers
-from sdso_amd import abi, synth
+from sdso_amd import abi
+import synth
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 

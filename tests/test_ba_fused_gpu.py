@@ -12,7 +12,8 @@ import os
 import numpy as np
 import pytest
 
-from sdso_amd import abi, synth
+from sdso_amd import abi
+import synth
 from test_ba_gpu import _check_accum
 
 SDSO_ERR_STATE = -4   # include/sdso_abi.h:36

@@ -12,7 +12,8 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from sdso_amd import abi, synth
+from sdso_amd import abi
+import synth
 from test_ba_gpu import _both, _lin_both, _check_lin, _accumulate_both, _check_accum
 
 pytestmark = pytest.mark.gpu

@@ -10,7 +10,8 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from sdso_amd import abi, synth
+from sdso_amd import abi
+import synth
 import helpers
 
 pytestmark = pytest.mark.gpu

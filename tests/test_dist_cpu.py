@@ -27,7 +27,8 @@ def _worker(rank, world, port, outdir, mode):
     import torch.distributed as dist
     sys.path[:0] = [os.path.join(ROOT, "stereo-dso-g2o_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
     import pyoracle
-    from sdso_amd import abi, synth, dist as sdist
+    from sdso_amd import abi, dist as sdist
+    import synth
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -57,7 +58,8 @@ def _worker(rank, world, port, outdir, mode):
 @pytest.mark.parametrize("world,mode", [(2, "per_host"), (3, "per_host"), (2, "contiguous"), (4, "per_host"), (8, "per_host")])
 def test_sharded_accumulation_equals_unsharded(oracle, tmp_path, world, mode):
     sys.path[:0] = [os.path.join(ROOT, "stereo-dso-g2o_amd")]
-    from sdso_amd import abi, synth, dist as sdist
+    from sdso_amd import abi, dist as sdist
+    import synth
     port = _free_port()
     mp.spawn(_worker, args=(world, port, str(tmp_path), mode), nprocs=world, join=True)
     win = synth.ba_window(w=320, h=240, nf=4, pts_per_kf=60, seed=3021)
@@ -98,7 +100,8 @@ def _scatter_worker(rank, world, port, outdir, nwin):
     import torch.distributed as dist
     sys.path[:0] = [os.path.join(ROOT, "stereo-dso-g2o_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
     import pyoracle
-    from sdso_amd import abi, synth, dist as sdist
+    from sdso_amd import abi, dist as sdist
+    import synth
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)

@@ -47,7 +47,8 @@ def _solve(ctx, abi, win, wid, slot0, reduce_fn=None):
 def _worker(rank, world, port, outdir):
     import torch.distributed as dist
     sys.path[:0] = [os.path.join(ROOT, "stereo-dso-g2o_amd")]
-    from sdso_amd import abi, synth, dist as sdist
+    from sdso_amd import abi, dist as sdist
+    import synth
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -63,7 +64,8 @@ def _worker(rank, world, port, outdir):
 
 
 def test_two_rank_sharded_solve_matches_single(gpu_ctx, tmp_path):
-    from sdso_amd import abi, synth, dist as sdist
+    from sdso_amd import abi, dist as sdist
+    import synth
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     win = synth.ba_window(w=640, h=480, nf=5, pts_per_kf=100, seed=3031)
@@ -84,7 +86,8 @@ def test_accumulator_block_is_aliased_by_torch(gpu_ctx):
     """bench.py all-reduces the packed accumulators IN PLACE through a torch tensor built on the library's device pointer
     (__cuda_array_interface__) on the ctx stream.  The tensor must alias the block, not copy it."""
     import torch
-    from sdso_amd import abi, synth
+    from sdso_amd import abi
+    import synth
     win = synth.ba_window(w=320, h=240, nf=4, pts_per_kf=40, seed=3091)
     nf = win["nf"]
     for f in range(nf):
@@ -118,7 +121,8 @@ def test_library_allreduce_one_rank_is_identity():
     """The RCCL exchange inside the library (sdso_comm_* / sdso_ba_allreduce, csrc/comm.hip): a 1-rank communicator's sum is the
     identity, bit for bit, on the batch block and on one window's block; a second ctx of the process attaches to the same
     communicator; without a communicator the call is refused (SDSO_ERR_STATE), never silently skipped."""
-    from sdso_amd import abi, synth
+    from sdso_amd import abi
+    import synth
     ctx, ctx2 = abi.Context(0), abi.Context(0)
     try:
         L = ctx.L
@@ -233,7 +237,8 @@ def _opt_worker(rank, world, port, outdir, gated=False, exchange_mode=0, tag="op
     import torch
     import torch.distributed as dist
     sys.path[:0] = [os.path.join(ROOT, "stereo-dso-g2o_amd")]
-    from sdso_amd import abi, synth, dist as sdist
+    from sdso_amd import abi, dist as sdist
+    import synth
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -261,7 +266,8 @@ def test_two_rank_sharded_gn_loop_matches_single(gpu_ctx, oracle, tmp_path):
     accumulators and one all-gather of the newest-frame energies / break-test sums) takes the decisions of the unsharded window on every
     rank: same iteration count, same quantile thresholds (through the residual states), states / idepths within 1e-5 + twice the
     oracle's own order-of-summation spread."""
-    from sdso_amd import abi, synth
+    from sdso_amd import abi
+    import synth
     import helpers
     world = 2
     mp.spawn(_opt_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
@@ -311,7 +317,8 @@ def test_two_rank_sharded_energy_gated_loop_matches_single(gpu_ctx, tmp_path):
     residual energies and calcLEnergy parts, and the gate reads them rank by rank — so both ranks take the same accept / reject decisions
     (identical states on every rank) and they are the decisions of the unsharded window (same iteration count, states / idepths within the
     sharded accepted-step loop's bars)."""
-    from sdso_amd import abi, synth
+    from sdso_amd import abi
+    import synth
     import helpers
     world = 2
     mp.spawn(_opt_worker, args=(world, _free_port(), str(tmp_path), True), nprocs=world, join=True)
@@ -347,7 +354,8 @@ def test_three_ranks_three_windows_both_exchange_shapes(gpu_ctx, tmp_path):
     them), the fused tail kernel solves that window, and x / xAd / nres travel to the other ranks by all-gather.  The sums are the same
     numbers and the solve is deterministic, so every rank must end on the bits of the all-reduce run — states, idepths, residual
     states, iteration counts — and those are the unsharded loop's decisions with states inside the sharded loop's bar."""
-    from sdso_amd import abi, synth
+    from sdso_amd import abi
+    import synth
     world = 3
     for mode, tag in ((0, "ar3"), (1, "rs3")):
         mp.spawn(_opt_worker, args=(world, _free_port(), str(tmp_path), False, mode, tag, _OPT_SPECS3), nprocs=world, join=True)
@@ -375,7 +383,8 @@ def _two_comm_worker(rank, world, port, outdir):
     import torch
     import torch.distributed as dist
     sys.path[:0] = [os.path.join(ROOT, "stereo-dso-g2o_amd"), os.path.join(ROOT, "tests")]
-    from sdso_amd import abi, synth, dist as sdist
+    from sdso_amd import abi, dist as sdist
+    import synth
     import helpers
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -439,7 +448,8 @@ def test_resident_loop_through_rccl_one_rank(monkeypatch):
     """The RCCL collectives of the resident loop on the one GPU this box has: with a 1-rank communicator and SDSO_OPT_FORCE_EXCHANGE=1
     sdso_ba_batch_optimize takes the multi-rank path — ncclAllReduce(max) of the pack capacity, per iteration ncclAllReduce of the
     accumulators, k_ba_opt_pack and ncclAllGather of the energy records — and must reproduce the plain single-rank run bit for bit."""
-    from sdso_amd import abi, synth
+    from sdso_amd import abi
+    import synth
     import helpers
     wins = helpers.gen_windows(_OPT_SPECS)
     outs = {}

@@ -154,7 +154,7 @@ def test_gpu_stereo_matches_golden(gpu_ctx):
 @pytest.mark.gpu
 def test_gpu_g2o_factors_match_golden(gpu_ctx):
     """The fork's live factors against the frozen oracle outputs: per-edge doubles bit-exact, sums over edges to 1e-12."""
-    from sdso_amd import synth
+    import synth
     exp = _load("g2o")
     prob, prm, _ = cases.tracker_case()
     assert np.array_equal(exp["input_digest"], cases.digest(prob["pyr_new"][0], prob["pc"][0]["u"], prob["pc"][0]["idepth"]))

@@ -12,7 +12,8 @@ import numpy as np
 import pytest
 
 import helpers
-from sdso_amd import abi, synth
+from sdso_amd import abi
+import synth
 
 HOST = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "stereo-dso-g2o_amd", "host")
 EXE = os.path.join(HOST, "test_shim")

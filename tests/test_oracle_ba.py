@@ -22,7 +22,8 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from sdso_amd import abi, synth
+from sdso_amd import abi
+import synth
 
 PAT = synth.PATTERN.astype(np.float64)
 SC = np.array([0.5, 0.5, 0.5, 1.0, 1.0, 1.0, 10.0, 1000.0])          # SCALE_XI_TRANS x3, SCALE_XI_ROT x3, SCALE_A, SCALE_B  (HessianBlocks.h:54-61)

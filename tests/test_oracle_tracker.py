@@ -10,7 +10,8 @@ import numpy as np
 import pytest
 
 import helpers
-from sdso_amd import abi, synth
+from sdso_amd import abi
+import synth
 
 
 @pytest.fixture(scope="module")
@@ -139,7 +140,7 @@ def test_make_coarse_depth_oracle_equals_the_generator(oracle):
     kernels) and the numpy generator behind every synthetic tracking problem (sdso_amd/synth.py::make_pc) are two independent
     restatements of the same loops — identical pc_n, order and floats, including pixels hit by several points and weights != 1."""
     import pyoracle
-    from sdso_amd import synth
+    import synth
     prob = synth.tracker_problem(w=320, h=240, npts=500, seed=2107)
     u, v, idp = prob["points"]
     rs = np.random.RandomState(8)

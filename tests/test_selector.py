@@ -4,7 +4,8 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from sdso_amd import abi, synth
+from sdso_amd import abi
+import synth
 
 
 def _frame(w, h, seed):

@@ -7,7 +7,8 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from sdso_amd import abi, synth
+from sdso_amd import abi
+import synth
 
 FIELDS = ("idepth_min_stereo", "idepth_max_stereo", "idepth_stereo", "quality", "lastTraceStatus", "lastTraceUV", "lastTracePixelInterval")
 

@@ -9,7 +9,8 @@ import numpy as np
 import pytest
 
 import helpers
-from sdso_amd import abi, synth
+from sdso_amd import abi
+import synth
 
 pytestmark = pytest.mark.gpu
 

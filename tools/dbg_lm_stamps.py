@@ -4,7 +4,8 @@ import numpy as np
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 for p in ("stereo-dso-g2o_amd", "oracle", "tests"):
     sys.path.insert(0, os.path.join(ROOT, p))
-from sdso_amd import abi, synth
+from sdso_amd import abi
+import synth
 import helpers
 ctx = abi.Context(0)
 NP = int(os.environ.get("NPTS", "2000"))

@@ -9,7 +9,8 @@ import numpy as np
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 for p in ("stereo-dso-g2o_amd", "oracle", "tests"):
     sys.path.insert(0, os.path.join(ROOT, p))
-from sdso_amd import abi, synth  # noqa: E402
+from sdso_amd import abi  # noqa: E402
+import synth
 
 ctx = abi.Context(0)
 win = dict(synth.ba_window(w=1232, h=368, nf=8, pts_per_kf=250, seed=3021))
