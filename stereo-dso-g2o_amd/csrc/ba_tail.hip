@@ -329,102 +329,161 @@ __global__ __launch_bounds__(TAIL_NT) void k_ba_tail(const BaDev* __restrict__ w
       }
       return hv;
     };
-    const int njobs = nf2 + nf + 1;
-    // diagonal tiles first (they are the long ones: one per wave), then the rest round-robin
-#ifdef SDSO_TAIL_STAMPS
-    unsigned long long tj[4] = {0, 0, 0, 0}, tj0 = __builtin_amdgcn_s_memtime();   // wave 0's jobs by kind: diagonal tile, off-diagonal, frame-calibration, calibration
-#endif
-    for (int jj = wv; jj < njobs; jj += TAIL_NT / 64) {
-#ifdef SDSO_TAIL_STAMPS
-      if (jj != wv) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long tn = __builtin_amdgcn_s_memtime(); const int pj = jj - TAIL_NT / 64; tj[pj < nf ? 0 : pj < nf2 ? 1 : pj < nf2 + nf ? 2 : 3] += tn - tj0; tj0 = tn; }
-#endif
-      int tile;
-      if (jj < nf) tile = jj * (nf + 1);                       // (x, x)
-      else if (jj < nf2) { const int o = jj - nf; const int x = o / (nf - 1), r = o % (nf - 1); const int y = r < x ? r : r + 1; tile = x + nf * y; }
-      else tile = jj;
-      if (tile < nf2) {
-        const int x = tile % nf, y = tile / nf;
-        const double hm = B.t_HM[(size_t)(4 + x * 8 + a) * n + (4 + y * 8 + c)];      // requested first, consumed last
-        double dv[8];
+    // ---- block row x of the system on wave x (round 5; rounds 3-4 ran one JOB per tile and wave, each rebuilding its operands through
+    // run-time acc13 index arithmetic and cross-row shuffles: 64 k of the kernel's 156 k cycles).  Lane (a, c) owns element (a, c) of every
+    // tile (x, y), y = 0 .. nf - 1, of the frame-calibration strip (c < 5) and keeps, for the whole row:
+    //   W1 = (AH_p F_p)[a][c], p = (host x, target y): row a of adHost(p) times column c of the pair's frame block — the operand of
+    //        H[x,y] += AH F AT^T (x != y), of the pair's share of H[x,x] += AH F AH^T (its row a sits in the lane's own group of
+    //        eight: ds_swizzle broadcasts, no LDS memory round trip) and, with the calibration / residual columns, of H[x,c] += AH X, b[x] += AH r;
+    //   W2 = (AH_q F_q)[c][a], q = (host y, target x): the transposed partner H[y,x]^T that the reference adds into the same block
+    //        (AccumulatedTopHessian.h:134-147);
+    //   the target-side terms AT F AT^T, AT X (adTarget is diagonal) of pair q, and the Schur terms of the same pairs.
+    // Index tables into the 91 packed sums are per-lane constants (registers); the next tile's global operands (HM element, the eight accD
+    // values of its AT D AT term) are requested before the current tile's arithmetic.
+    // value of lane 8 (lane / 8) + K of the lane's group of eight (ds_swizzle_b32, bit mode: and 0x18, or K, inside each half of the wave;
+    // the LDS crossbar without a memory access — gfx9 has no DPP8)
+    auto bcast8 = [](double v, auto kk) {
+      constexpr int pat = 0x18 | (decltype(kk)::value << 5);
+      const unsigned long long u = __double_as_longlong(v);
+      const unsigned lo = (unsigned)__builtin_amdgcn_ds_swizzle((int)(unsigned)u, pat), hi = (unsigned)__builtin_amdgcn_ds_swizzle((int)(unsigned)(u >> 32), pat);
+      return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+    };
+    if (wv < nf) {
+      const int x = wv;
+      const int colx = c < 4 ? c : 12;
+      int iFc[8], iFa[8], iX[8];
 #pragma unroll
-        for (int i = 0; i < 8; i++) dv[i] = i < nf ? (double)accD[(size_t)(i + nf * x + nf2 * y) * 64 + lane] : 0.0;
-        const double oA = top_ff(accA, x, y, false);
-        double oL = topL ? top_ff(accL, x, y, true) : 0.0;
-        if (x == y && a == c) oL += prior[x * 8 + a];
-        // Schur complement (AccumulatedSCHessian.cpp:151-171, factored as in k_ba_stitch)
-        double oS = S1[(size_t)(x + nf * y) * 64 + lane] * at(x, y, c);
-        oS += at(y, x, a) * S1[(size_t)(y + nf * x) * 64 + c * 8 + a];
+      for (int nn = 0; nn < 8; nn++) { iFc[nn] = acc13_index(4 + nn, 4 + c); iFa[nn] = acc13_index(4 + nn, 4 + a); iX[nn] = acc13_index(4 + nn, colx); }
+      const int iFac = acc13_index(4 + a, 4 + c), iXa = acc13_index(4 + a, colx);
+      double atx_a[8];                                           // at(i, x, a): adTarget diagonal of pair (host i, target x), row a
 #pragma unroll
-        for (int i = 0; i < 8; i++) if (i < nf) oS += at(i, x, a) * dv[i] * at(i, y, c);
-        if (x == y)
+      for (int i = 0; i < 8; i++) atx_a[i] = i < nf ? at(i, x, a) : 0.0;
+      double dgA = 0, dgS = 0, hvA = 0, hvS = 0;                 // running sums of the diagonal tile (top, Schur) and of the strip (top, Schur)
+      double hmDiag = 0;                                         // the diagonal tile's element of HM (the tile is finished after the row)
+      double hmN = B.t_HM[(size_t)(4 + x * 8 + a) * n + (4 + 0 * 8 + c)];
+      float dvN[8];
 #pragma unroll
-          for (int k = 0; k < nf; k++) {
-            const double* s1 = S1 + (size_t)(x + nf * k) * 64 + a * 8;
-            const double* R = adHs + (size_t)(x + nf * k) * 64 + c * 8;
-            double s = 0;
+      for (int i = 0; i < 8; i++) dvN[i] = i < nf ? accD[(size_t)(i + nf * x + nf2 * 0) * 64 + lane] : 0.f;
 #pragma unroll
-            for (int nn = 0; nn < 8; nn++) s += s1[nn] * R[nn];
-            oS += s;
+      for (int y = 0; y < 8; y++) {
+        if (y < nf) {
+          const double hm = hmN;
+          float dv[8];
+#pragma unroll
+          for (int i = 0; i < 8; i++) dv[i] = dvN[i];
+          if (y + 1 < nf) {
+            hmN = B.t_HM[(size_t)(4 + x * 8 + a) * n + (4 + (y + 1) * 8 + c)];
+#pragma unroll
+            for (int i = 0; i < 8; i++) if (i < nf) dvN[i] = accD[(size_t)(i + nf * x + nf2 * (y + 1)) * 64 + lane];
           }
-        finish(4 + x * 8 + a, 4 + y * 8 + c, oA, oL, oS, hm);
-      } else if (tile < nf2 + nf) {
-        const int x = tile - nf2;
-        const double hA = top_fc(accA, x, false);
-        double hL = topL ? top_fc(accL, x, true) : 0.0;
-        double hS = 0;
-        if (c < 5) {
+          const int pp = x + nf * y, qq = y + nf * x;
+          const double* AHp = adHs + (size_t)pp * 64;
+          const float* ap = accA + (size_t)pp * 92;
+          const float* aq = accA + (size_t)qq * 92;
+          double AHa[8], AHc[8];
 #pragma unroll
-          for (int k = 0; k < 2 * nf; k++) {
-            const int i = k < nf ? x : k - nf, j = k < nf ? k : x;   // pair (i host, j target); frame x is host (AH) or target (AT)
-            const int ij = i + nf * j;
+          for (int m = 0; m < 8; m++) { AHa[m] = AHp[a * 8 + m]; AHc[m] = AHp[c * 8 + m]; }
+          double W1 = 0, V1 = 0, sd = 0;
+#pragma unroll
+          for (int m = 0; m < 8; m++) W1 += AHa[m] * (double)ap[iFc[m]];
+          if (c < 5) {
+#pragma unroll
+            for (int m = 0; m < 8; m++) V1 += AHa[m] * (double)ap[iX[m]];
+          }
+          hvA += V1;
+          // the pair's share of H[x,x] += AH F AH^T: sum_m W1[a][m] AH[c][m]
+          dgA += bcast8(W1, std::integral_constant<int, 0>()) * AHc[0];
+          dgA += bcast8(W1, std::integral_constant<int, 1>()) * AHc[1];
+          dgA += bcast8(W1, std::integral_constant<int, 2>()) * AHc[2];
+          dgA += bcast8(W1, std::integral_constant<int, 3>()) * AHc[3];
+          dgA += bcast8(W1, std::integral_constant<int, 4>()) * AHc[4];
+          dgA += bcast8(W1, std::integral_constant<int, 5>()) * AHc[5];
+          dgA += bcast8(W1, std::integral_constant<int, 6>()) * AHc[6];
+          dgA += bcast8(W1, std::integral_constant<int, 7>()) * AHc[7];
+          // ... and of the Schur complement's H[x,x] += sum_k S1(x,k) AH(x,k)^T (AccumulatedSCHessian.cpp:151-171)
+          {
+            const double* s1 = S1 + (size_t)pp * 64 + a * 8;
+#pragma unroll
+            for (int m = 0; m < 8; m++) sd += s1[m] * AHc[m];
+            dgS += sd;
+          }
+          // frame-calibration strip, Schur side: H[x,c] += AH E, b[x] += AH EB of pair p; AT E, AT EB of pair q
+          if (c < 5) {
             double s = 0;
-            if (k < nf) {
-              const double* Am = adHs + (size_t)ij * 64;
 #pragma unroll
-              for (int kk = 0; kk < 8; kk++) s += Am[a * 8 + kk] * (double)(c < 4 ? accE[(size_t)ij * 32 + kk * 4 + c] : accEB[(size_t)ij * 8 + kk]);
-            } else s = at(i, j, a) * (double)(c < 4 ? accE[(size_t)ij * 32 + a * 4 + c] : accEB[(size_t)ij * 8 + a]);
-            hS += s;
+            for (int m = 0; m < 8; m++) s += AHa[m] * (double)(c < 4 ? accE[(size_t)pp * 32 + m * 4 + c] : accEB[(size_t)pp * 8 + m]);
+            hvS += s;
+          }
+          const double at_pc = at(x, y, c);                     // adTarget diagonal of pair p at c
+          const double at_qa = atx_a[y], at_qc = at(y, x, c);   // ... of pair q at a, c
+          // target-side terms of pair q = (host y, target x) into the diagonal tile and the strip
+          dgA += at_qa * (double)aq[iFac] * at_qc;
+          if (c < 5) { hvA += at_qa * (double)aq[iXa]; hvS += at_qa * (double)(c < 4 ? accE[(size_t)qq * 32 + a * 4 + c] : accEB[(size_t)qq * 8 + a]); }
+          // the tile's AT D AT term
+          double dS = 0;
+#pragma unroll
+          for (int i = 0; i < 8; i++) if (i < nf) dS += atx_a[i] * (double)dv[i] * at(i, y, c);
+          if (y != x) {
+            const double* AHq = adHs + (size_t)qq * 64;
+            double W2 = 0;
+#pragma unroll
+            for (int m = 0; m < 8; m++) W2 += AHq[c * 8 + m] * (double)aq[iFa[m]];
+            const double z1 = W1 * at_pc, z2 = W2 * at_qa;
+            const double oA = x < y ? z1 + z2 : z2 + z1;          // M(lo,hi) first, then M(hi,lo)^T: the order the CPU adds them in
+            const double oL = topL ? top_ff(accL, x, y, true) : 0.0;
+            double oS = S1[(size_t)pp * 64 + lane] * at_pc;
+            oS += at_qa * S1[(size_t)qq * 64 + c * 8 + a];
+            oS += dS;
+            finish(4 + x * 8 + a, 4 + y * 8 + c, oA, oL, oS, hm);
+          } else {
+            // the diagonal tile is finished after the row: keep its pair term, Schur pair terms and the HM element
+            dgA += W1 * at_pc;
+            dgS += S1[(size_t)pp * 64 + lane] * at_pc + at_qa * S1[(size_t)qq * 64 + c * 8 + a] + dS;
+            hmDiag = hm;
           }
         }
+      }
+      {
+        double oL = topL ? top_ff(accL, x, x, true) : 0.0;
+        if (a == c) oL += prior[x * 8 + a];
+        finish(4 + x * 8 + a, 4 + x * 8 + c, dgA, oL, dgS, hmDiag);
+      }
+      {   // the strip: H[x, calibration] (c < 4) and b[x] (c == 4)
+        double hL = topL ? top_fc(accL, x, true) : 0.0;
         const int i = 4 + x * 8 + a;
         if (c < 4) {
-          double v = hL + B.t_HM[(size_t)i * n + c] + hA;
-          if (wr_hs) { lastHS[(size_t)i * n + c] = v - hS; lastHS[(size_t)c * n + i] = (hL + B.t_HM[(size_t)c * n + i] + hA) - hS; }
-          v -= hS * f;
+          const double hmic = B.t_HM[(size_t)i * n + c], hmci = B.t_HM[(size_t)c * n + i];
+          double v = hL + hmic + hvA;
+          if (wr_hs) { lastHS[(size_t)i * n + c] = v - hvS; lastHS[(size_t)c * n + i] = (hL + hmci + hvA) - hvS; }
+          v -= hvS * f;
           M[i * LDLT_LD + c] = v;
-          M[c * LDLT_LD + i] = (hL + B.t_HM[(size_t)c * n + i] + hA) - hS * f;
+          M[c * LDLT_LD + i] = (hL + hmci + hvA) - hvS * f;
         } else if (c == 4) {
           hL += prior[x * 8 + a] * prior[nf * 8 + x * 8 + a];
-          const double v = hL + bMt[i] + hA - hS;            // bFinal = bL + bM_top + bA - b_sc      (:907)
+          const double v = hL + bMt[i] + hvA - hvS;            // bFinal = bL + bM_top + bA - b_sc      (:907)
           bF[i] = v;
           if (wr_hs) lastbS[i] = v;
         }
-      } else if (lane < 20) {                                  // calibration block and its b
-        const int r = lane < 16 ? lane >> 2 : lane - 16, colx = lane < 16 ? (lane & 3) : 12;
-        double sA = 0, sL = 0;
-#pragma unroll 16
-        for (int p = 0; p < nf2; p++) sA += tail_acc13(accA + p * 92, r, colx);
-        if (topL) for (int p = 0; p < nf2; p++) sL += tail_acc13(accL + (size_t)p * 91, r, colx);
-        const double sS = (double)misc[lane];                  // Hcc (16) then bc (4)
-        if (lane < 16) {
-          if (r == colx) sL += prior[nf * 16 + r];
-          finish(r, colx, sA, sL, sS, B.t_HM[(size_t)r * n + colx]);
-        } else {
-          sL += prior[nf * 16 + r] * (double)B.t_cdelta[r];
-          const double v = sL + bMt[r] + sA - sS;
-          bF[r] = v;
-          if (wr_hs) lastbS[r] = v;
-        }
       }
     }
-#ifdef SDSO_TAIL_STAMPS
-    if (threadIdx.x == 0 && !(flags & TAIL_STEP)) {
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      const unsigned long long tn = __builtin_amdgcn_s_memtime();
-      tj[3] += tn - tj0;                       // (wave 0's last job is the calibration block)
-      for (int i = 0; i < 4; i++) tjk[i] = tj[i];
+    if (wv == (nf < TAIL_NT / 64 ? nf : 0) && lane < 20) {       // calibration block and its b: a wave without a frame row, wave 0 for the full window
+      const int r = lane < 16 ? lane >> 2 : lane - 16, colc = lane < 16 ? (lane & 3) : 12;
+      const int ic = acc13_index(r, colc);
+      double sA = 0, sL = 0;
+#pragma unroll 16
+      for (int p = 0; p < nf2; p++) sA += (double)accA[p * 92 + ic];
+      if (topL) for (int p = 0; p < nf2; p++) sL += (double)accL[(size_t)p * 91 + ic];
+      const double sS = (double)misc[lane];                  // Hcc (16) then bc (4)
+      if (lane < 16) {
+        if (r == colc) sL += prior[nf * 16 + r];
+        finish(r, colc, sA, sL, sS, B.t_HM[(size_t)r * n + colc]);
+      } else {
+        sL += prior[nf * 16 + r] * (double)B.t_cdelta[r];
+        const double v = sL + bMt[r] + sA - sS;
+        bF[r] = v;
+        if (wr_hs) lastbS[r] = v;
+      }
     }
-#endif
   }
   __syncthreads();
   TSTAMP(3);
