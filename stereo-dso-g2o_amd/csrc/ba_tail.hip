@@ -64,6 +64,7 @@ struct TailLds {
 
 #ifdef SDSO_TAIL_STAMPS   // diagnostic build only (make EXTRA=-DSDSO_TAIL_STAMPS, tools/dbg_tail_stamps.py): x[0..] carry cycle counts of the phases
 #define TSTAMP(i) do { if (threadIdx.x == 0) tstamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+__device__ double tail_dbg_stamps[1024][12];   // with the loop's host part (TAIL_STEP): phases incl. P7 per workgroup, read by sdso_dbg_tail_stamps
 #else
 #define TSTAMP(i) do { } while (0)
 #endif
@@ -563,7 +564,20 @@ __global__ __launch_bounds__(TAIL_NT) void k_ba_tail(const BaDev* __restrict__ w
   if (flags & TAIL_STEP) {
     __syncthreads();
     opt_step_body<TAIL_NT>(Bw, B, OS, nullptr, 1, 0, iteration, last, stop_on_convergence, 1.0f, 0, misc + 22, 1, xv, nres_f, blockIdx.x, gridDim.x, ba_finished(B) ? nullptr : (const OptPre*)(misc + 44));
+#ifdef SDSO_TAIL_STAMPS
+    __syncthreads();
+    TSTAMP(9);
+    if (threadIdx.x == 0 && blockIdx.x < 1024) {
+      for (int i = 0; i < 8; i++) tail_dbg_stamps[blockIdx.x][i] = (double)(tstamps[i + 1] - tstamps[i]);
+      tail_dbg_stamps[blockIdx.x][8] = (double)(tstamps[9] - tstamps[8]);
+    }
+#endif
   }
 }
 
 }  // namespace sdso
+#ifdef SDSO_TAIL_STAMPS
+extern "C" int sdso_dbg_tail_stamps(double* out, int nwin) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sdso::tail_dbg_stamps), sizeof(double) * 12 * nwin, 0, hipMemcpyDeviceToHost);
+}
+#endif

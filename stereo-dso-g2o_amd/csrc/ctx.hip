@@ -148,6 +148,7 @@ extern "C" void sdso_ctx_destroy(sdso_ctx* ctx) {
   release_comm(ctx);
   if (ctx->gammaB) hipFree(ctx->gammaB);
   if (ctx->scratch) hipFree(ctx->scratch);
+  if (ctx->lm_clusters) hipFree(ctx->lm_clusters);
   if (ctx->pinned) hipHostFree(ctx->pinned);
   hipStreamDestroy(ctx->stream);
   delete ctx;

@@ -63,6 +63,10 @@ struct sdso_ctx {
   // generic scratch
   void* scratch = nullptr;
   size_t scratch_bytes = 0;
+  // k_track_lm's cluster records: written by that kernel only, with tags that grow from call to call (no clearing between calls)
+  void* lm_clusters = nullptr;
+  size_t lm_clusters_bytes = 0;
+  int lm_epoch = 0;
   void* pinned = nullptr;
   size_t pinned_bytes = 0;
   int n_cu = 256;

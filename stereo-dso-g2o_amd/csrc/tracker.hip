@@ -1064,12 +1064,13 @@ __device__ __forceinline__ bool lm_wave_step(LmCore& core, const float* F, const
 // evaluation (a leader that gathers the partials and publishes the next request needs two: 0.355 against 0.31 ms per call).
 // A partial travels as 64-bit {word, evaluation number} pairs written and polled by single relaxed agent-scope atomics: a reader that sees
 // the tag of evaluation e has that evaluation's word — no flag, no fence, one round trip (≈ 0.7 us on one XCD, tools/handoff_bench.hip).
-// Two buffers alternate: a member can be one evaluation ahead of a slow reader of its previous partial, never two.
+// Two buffers alternate: a member can be one evaluation ahead of a slow reader of its previous partial, never two.  The tags grow from call
+// to call (e_base): the records are never cleared between calls — whatever an earlier call left carries a smaller tag.
 // Every spin is bounded (a member that never became resident — the device was shared — ends the call with out.evaluations = -1 and
 // the host repeats it with G = 1, which needs no co-residency).  Member 0 reports the result.
 constexpr int LM_MAXG = 8;
 constexpr int LM_SPIN_LIMIT = 1 << 21;
-struct LmCluster {                                           // zeroed before the launch; the first evaluation is number 1
+struct LmCluster {                                           // zeroed when allocated; a call's first evaluation is number e_base + 1
   unsigned long long part[2][LM_MAXG][64];
 };
 __device__ __forceinline__ void lm_put(unsigned long long* slot, unsigned word, int e) {
@@ -1079,7 +1080,8 @@ __device__ __forceinline__ unsigned long long lm_get(const unsigned long long* s
   return __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__global__ __launch_bounds__(LM_BLOCK) void k_track_lm(LmJob* __restrict__ jobs, LmCluster* __restrict__ clusters, int nhyp, int G, int spin_limit, int drop_member /* test hook: member G - 1 of every cluster never answers */) {
+__global__ __launch_bounds__(LM_BLOCK) void k_track_lm(LmJob* __restrict__ jobs, LmCluster* __restrict__ clusters, int nhyp, int G, int spin_limit, int drop_member /* test hook: member G - 1 of every cluster never answers */,
+                                                       int solo_n /* levels of at most this many points are not shared */, int e_base /* this call's evaluations carry the tags e_base + 1 .. */) {
   // hypothesis c, member g: for G > 1 the members of a cluster share blockIdx % 8 (one XCD, one L2); speed only, any placement is correct
   int c = blockIdx.x, g = 0;
   if (G > 1) { const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3; g = j % G; c = (j / G) * 8 + xcd; }
@@ -1123,7 +1125,10 @@ __global__ __launch_bounds__(LM_BLOCK) void k_track_lm(LmJob* __restrict__ jobs,
   int qlvl = -1;
 #pragma unroll
   for (int u = 0; u < LM_UNROLL; u++) qc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-  const int first = g * LM_BLOCK + tid, stride = G * LM_BLOCK;
+  // A level whose points fit ONE trip of one workgroup (LM_UNROLL points per thread: the coarse levels, more than half of a call's
+  // evaluations) is evaluated by every member in full, in the single workgroup's order: the members hold the same sums without the
+  // exchange — which costs more (5 k cycles at G = 8) than those points do.  solo_n == 0 (SDSO_TRK_LM_SOLO=0): every level is shared.
+  int first = g * LM_BLOCK + tid, stride = G * LM_BLOCK;
   // every trip is one evaluation; the loop ends for all threads together (the flags are read behind a barrier)
   if (tid == 0) {                               // the first request; every later one is built by wave 0 at the end of lm_wave_step
     fill_eval(core.p, core.lvl, core.reqT, core.reqAff, core.p.coarseCutoffTH * core.levelCutoffRepeat, ev);
@@ -1132,10 +1137,13 @@ __global__ __launch_bounds__(LM_BLOCK) void k_track_lm(LmJob* __restrict__ jobs,
     core.out.point_evals += s_n[core.lvl];
   }
   __syncthreads();
+  int shared_evals = 0;
   for (int e = 1; e <= 1024; e++) {
     LMSL(0);
     const int lvl = s_lvl, n = s_n[lvl];
+    const bool shared_lvl = G > 1 && n > solo_n;
     if (lvl != qlvl) {                          // (uniform) first evaluation on this level: the points move into registers
+      first = shared_lvl ? g * LM_BLOCK + tid : tid; stride = shared_lvl ? G * LM_BLOCK : LM_BLOCK;
       const float4* __restrict__ pc = s_pc[lvl];
       if (first < n) {
 #pragma unroll
@@ -1163,17 +1171,17 @@ __global__ __launch_bounds__(LM_BLOCK) void k_track_lm(LmJob* __restrict__ jobs,
 #pragma unroll
       for (int w = 1; w < LM_BLOCK / 64; w++) mine += sF[w][tid];
     }
-    if (G > 1 && tid < TRK_NF + TRK_NI) {       // publish this member's partial, collect the others', add all of them in member order
-      unsigned long long (*buf)[64] = C.part[e & 1];
+    if (shared_lvl && tid < TRK_NF + TRK_NI) {  // publish this member's partial, collect the others', add all of them in member order
+      unsigned long long (*buf)[64] = C.part[shared_evals & 1];   // (alternating over the SHARED evaluations: between two uses of a buffer lies an exchange on the other one)
       const float own = mine;
-      lm_put(&buf[g][tid], __float_as_uint(own), e);
+      lm_put(&buf[g][tid], __float_as_uint(own), e_base + e);
       unsigned long long v[LM_MAXG];
       bool all = false;
       for (int spins = 0; spins < spin_limit && !all; spins++) {
         all = true;
 #pragma unroll
         for (int m = 0; m < LM_MAXG; m++)
-          if (m < G && m != g) { v[m] = lm_get(&buf[m][tid]); all = all && (int)(v[m] >> 32) == e; }
+          if (m < G && m != g) { v[m] = lm_get(&buf[m][tid]); all = all && (int)(v[m] >> 32) == e_base + e; }
         if (!all) __builtin_amdgcn_s_sleep(1);
       }
       if (!all) s_abort = 1;
@@ -1182,6 +1190,7 @@ __global__ __launch_bounds__(LM_BLOCK) void k_track_lm(LmJob* __restrict__ jobs,
       for (int m = 0; m < LM_MAXG; m++) if (m < G) tot = m == 0 ? (g == 0 ? own : __uint_as_float((unsigned)v[0])) : tot + (m == g ? own : __uint_as_float((unsigned)v[m]));
       mine = tot;
     }
+    if (shared_lvl) shared_evals++;
     if (tid < TRK_NF) F[tid] = mine; else if (tid < TRK_NF + TRK_NI) I[tid - TRK_NF] = (int)mine;
     __syncthreads();
     if (s_abort) {                              // a member never answered (every member notices): member 0 gives the call back to the host
@@ -1283,12 +1292,26 @@ extern "C" int sdso_track_newest_coarse_batch(sdso_ctx* ctx, int nhyp, const int
     SDSO_REQUIRE(ctx, prms[k].coarsestLvl >= 0 && prms[k].coarsestLvl < 5 && prms[k].coarsestLvl < prms[k].levels, "coarsestLvl out of range");  // assert :853
   static const bool host_lm = getenv("SDSO_TRK_HOST_LM") != nullptr;
   if (host_lm) return track_newest_coarse_host(ctx, nhyp, ref_slots, frame_slots, prms, lastToNew, aff_g2l, outs);
-  // resident driver: jobs through pinned memory, one launch, one synchronisation
+  // resident driver: jobs through pinned memory, one launch, one synchronisation.  The cluster records are the library's own allocation
+  // and are never cleared between calls (tags, see LmCluster).  (The kernel reading the jobs in pinned host memory directly, without
+  // the two copies, measured the same 0.305 ms per call: tools/time_track.py, round 5.)
   int rc = ensure_pinned(ctx, sizeof(LmJob) * (size_t)nhyp);
   if (rc) return rc;
   const size_t jobs_bytes = (sizeof(LmJob) * (size_t)nhyp + 255) & ~(size_t)255;
-  rc = ensure_scratch(ctx, jobs_bytes + sizeof(LmCluster) * (size_t)nhyp);
+  rc = ensure_scratch(ctx, jobs_bytes);
   if (rc) return rc;
+  if (ctx->lm_clusters_bytes < sizeof(LmCluster) * (size_t)nhyp || ctx->lm_epoch > (1 << 30)) {
+    SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->lm_clusters_bytes < sizeof(LmCluster) * (size_t)nhyp) {
+      if (ctx->lm_clusters) SDSO_HIP(ctx, hipFree(ctx->lm_clusters));
+      ctx->lm_clusters = nullptr; ctx->lm_clusters_bytes = 0;
+      const size_t want = sizeof(LmCluster) * (size_t)std::max(nhyp, 8);
+      SDSO_HIP(ctx, hipMalloc(&ctx->lm_clusters, want));
+      ctx->lm_clusters_bytes = want;
+    }
+    SDSO_HIP(ctx, hipMemsetAsync(ctx->lm_clusters, 0, ctx->lm_clusters_bytes, ctx->stream));
+    ctx->lm_epoch = 0;
+  }
   LmJob* hj = (LmJob*)ctx->pinned;
   for (int k = 0; k < nhyp; k++) {
     rc = resolve_job(ctx, ref_slots[k], frame_slots[k], prms[k], hj[k]);
@@ -1296,7 +1319,7 @@ extern "C" int sdso_track_newest_coarse_batch(sdso_ctx* ctx, int nhyp, const int
   }
   if (ctx->tb) ctx->tb->nprob = 0;   // (a prepared evaluation batch keeps its own buffers; nothing shared)
   LmJob* dj = (LmJob*)ctx->scratch;
-  LmCluster* dc = (LmCluster*)((char*)ctx->scratch + jobs_bytes);
+  LmCluster* dc = (LmCluster*)ctx->lm_clusters;
   // workgroups per hypothesis: as many as keep the whole grid resident at once (the members of a cluster wait for each other; one
   // 512-thread workgroup of this kernel fills a CU), eight at most.  SDSO_TRK_LM_CLUSTER=1 forces single workgroups.
   const int g_env = getenv("SDSO_TRK_LM_CLUSTER") ? atoi(getenv("SDSO_TRK_LM_CLUSTER")) : 0;   // (read per call: the tests walk the cluster sizes)
@@ -1304,6 +1327,7 @@ extern "C" int sdso_track_newest_coarse_batch(sdso_ctx* ctx, int nhyp, const int
   int G = std::min(LM_MAXG, (ctx->n_cu * 7 / 8) / slots8);   // (an eighth of the CUs stays free: a grid that needs every CU waits on any straggler)
   if (g_env > 0) G = std::min(G, g_env);
   if (G < 2) G = 1;
+  const int solo_n = getenv("SDSO_TRK_LM_SOLO") ? atoi(getenv("SDSO_TRK_LM_SOLO")) : LM_UNROLL * LM_BLOCK;
 #ifdef SDSO_TEST_HOOKS
   // test hook, compiled into libsdso_hip_hooks.so only (csrc/Makefile; tests/test_variants_gpu.py): the first attempt loses one member of
   // every cluster, with a short spin limit — the call must come back through the single-workgroup repetition with its result
@@ -1314,10 +1338,11 @@ extern "C" int sdso_track_newest_coarse_batch(sdso_ctx* ctx, int nhyp, const int
   for (int attempt = 0; attempt < 2; attempt++) {
     for (int k = 0; k < nhyp; k++) { hj[k].T = lastToNew[k]; hj[k].aff = aff_g2l[k]; hj[k].out.evaluations = -1; }   // (-1 until member 0 reports)
     SDSO_HIP(ctx, hipMemcpyAsync(dj, hj, sizeof(LmJob) * nhyp, hipMemcpyHostToDevice, ctx->stream));
-    if (G > 1) SDSO_HIP(ctx, hipMemsetAsync(dc, 0, sizeof(LmCluster) * (size_t)nhyp, ctx->stream));
+    const int e_base = ctx->lm_epoch;
+    ctx->lm_epoch += 1040;             // (a call has at most 1024 evaluations)
     {
       ProfScope ps(ctx, "k_track_lm");
-      hipLaunchKernelGGL(k_track_lm, dim3(G > 1 ? slots8 * G : nhyp), dim3(LM_BLOCK), 0, ctx->stream, dj, dc, nhyp, G, drop ? 1 << 12 : LM_SPIN_LIMIT, drop && G > 1 ? 1 : 0);
+      hipLaunchKernelGGL(k_track_lm, dim3(G > 1 ? slots8 * G : nhyp), dim3(LM_BLOCK), 0, ctx->stream, dj, dc, nhyp, G, drop ? 1 << 12 : LM_SPIN_LIMIT, drop && G > 1 ? 1 : 0, solo_n, e_base);
     }
     SDSO_HIP(ctx, hipGetLastError());
     SDSO_HIP(ctx, hipMemcpyAsync(hj, dj, sizeof(LmJob) * nhyp, hipMemcpyDeviceToHost, ctx->stream));

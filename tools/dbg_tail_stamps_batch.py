@@ -29,5 +29,17 @@ for nwin in (1, 64, 256):
         x = np.zeros((nwin, 68))
         ctx.check(ctx.L.sdso_ba_batch_get_x(ctx.h, abi.dp(x)))
     m = x[:, :8].mean(axis=0)
+    if hasattr(ctx.L, "sdso_dbg_tail_stamps"):     # the loop's form: solve + step in one launch (TAIL_STEP), the phases incl. the step part
+        ctx.check(ctx.L.sdso_ba_batch_optimize_begin(ctx.h, 0))
+        for it in range(3):
+            ctx.check(ctx.L.sdso_ba_batch_accumulate(ctx.h))
+            ctx.check(ctx.L.sdso_ba_batch_solve_step(ctx.h, 1e-1 * 0.25 ** it, 0))
+        ctx.check(ctx.L.sdso_ba_batch_optimize_end(ctx.h, None))
+        st = np.zeros((nwin, 12))
+        ctx.L.sdso_dbg_tail_stamps.argtypes = [C.c_void_p, C.c_int]
+        assert ctx.L.sdso_dbg_tail_stamps(st.ctypes.data_as(C.c_void_p), nwin) == 0
+        ms = st.mean(axis=0)
+        print("%3d windows, in the loop (third iteration): " % nwin + "  ".join("%s %d" % (nm, v) for nm, v in zip(names + ("step part (P7)",), ms[:9]))
+              + "  | sum %d" % ms[:9].sum(), flush=True)
     print("%3d windows, mean s_memtime ticks per phase: " % nwin + "  ".join("%s %d" % (nm, v) for nm, v in zip(names, m)) + "  | sum %d (max over windows %d)" % (m.sum(), x[:, :8].sum(axis=1).max()), flush=True)
 ctx.close()
