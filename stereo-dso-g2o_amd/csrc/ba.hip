@@ -336,6 +336,8 @@ static int upload_window_impl(sdso_ctx* ctx, int win, const sdso_ba_window_t* Wi
       const size_t slot = (size_t)Win->res_point[o] * nf + Win->res_target[o];
       SDSO_REQUIRE(ctx, !seen[slot], "two residuals of one point observe the same target frame");
       seen[slot] = 1;
+      // (the reference never creates one: `if(fh != point->host)`, FullSystemOptPoint.cpp:74; the Schur kernel has no column for it)
+      SDSO_REQUIRE(ctx, Win->res_target[o] != rhost[o], "a residual observes its own host frame");
     }
   }
   W->perm.resize(nr); W->inv.resize(nr);
@@ -597,8 +599,16 @@ static bool launch_sc_and_folds(sdso_ctx* ctx, const BaLaunch& L, const uint8_t*
   }
   {
     ProfScope ps(ctx, "k_ba_sc", 2);
-    if (plain) hipLaunchKernelGGL(k_ba_sc_host<true>, dim3(nf, L.nwin), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr, pflag, shift, mm, clear_l);
-    else hipLaunchKernelGGL(k_ba_sc_host<false>, dim3(nf, L.nwin), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr, pflag, shift, mm, 0);
+    // a wave per host (see the kernel) once the workgroups-per-host form would need more than two and a half rounds of three workgroups per
+    // CU (measured, µs, workgroup / wave form: 64 windows 34 / 66, 128: 60 / 69, 192: 76 / 93, 256: 104 / 100 — profiles/r05_sc_batch_ab.txt);
+    // SDSO_BA_SC_WPH=0 / 1 forces one form (A/B)
+    static const int wph_env = getenv("SDSO_BA_SC_WPH") ? atoi(getenv("SDSO_BA_SC_WPH")) : -1;
+    const bool wph = wph_env >= 0 ? wph_env != 0 : 2 * nf * L.nwin > 15 * ctx->n_cu;
+    const dim3 g(wph ? (nf + BA_BLOCK / 64 - 1) / (BA_BLOCK / 64) : nf, L.nwin);
+    if (plain) { if (wph) hipLaunchKernelGGL((k_ba_sc_host<true, true>), g, dim3(BA_BLOCK), 0, ctx->stream, L.d_arr, pflag, shift, mm, clear_l);
+                 else hipLaunchKernelGGL((k_ba_sc_host<true, false>), g, dim3(BA_BLOCK), 0, ctx->stream, L.d_arr, pflag, shift, mm, clear_l); }
+    else { if (wph) hipLaunchKernelGGL((k_ba_sc_host<false, true>), g, dim3(BA_BLOCK), 0, ctx->stream, L.d_arr, pflag, shift, mm, 0);
+           else hipLaunchKernelGGL((k_ba_sc_host<false, false>), g, dim3(BA_BLOCK), 0, ctx->stream, L.d_arr, pflag, shift, mm, 0); }
   }
   if (fold_top_too && defer_fold) return false;
   if (fold_top_too) hipLaunchKernelGGL(k_ba_fold_all, dim3(1 + 2 * nf * nf, L.nwin), dim3(128), 0, ctx->stream, L.d_arr);

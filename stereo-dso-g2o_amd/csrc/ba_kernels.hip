@@ -997,14 +997,20 @@ __global__ __launch_bounds__(128) void k_ba_zero_topL(const BaDev* __restrict__ 
 // Three workgroups per CU: <= 168 VGPRs, 51 KB of LDS.
 constexpr int SCH_REC = 1024;                         // floats of one record buffer: 16 points x 8 records x 8 floats
 constexpr int SCH_WAVE = 3 * SCH_REC + 16 * 8;        // two JpJdF buffers (double-buffered), one term buffer, the points' phase-2 operands
-template <bool PLAIN>
+// WPH ("wave per host", the form of a large batch): every WAVE takes a whole host frame — all its 16-point groups in a row — and a workgroup
+// four hosts of one window.  The host's sums never leave the wave's accumulators: no tree over the waves, no barrier; the bins go from the
+// registers straight to memory (every (t1, t2) block of 256 bytes is covered by the four stores of one tile; the blocks below the diagonal
+// as float4s of the mirrored tile; the five tiles ON the diagonal are mirrored through 1 KB of the wave's stage first).  A batch of 256
+// windows is 2 048 waves on 3 072 slots — one round — where 2 048 workgroups on 768 slots need three: 116 -> see DESIGN.md §4.  A single
+// window keeps the workgroup per host (a quarter of the latency).
+template <bool PLAIN, bool WPH>
 __global__ __launch_bounds__(BA_BLOCK, 3) void k_ba_sc_host(const BaDev* __restrict__ wins, const uint8_t* __restrict__ pflag, int shiftPriorToZero, int margMode, int clearL) {
   constexpr int NW = BA_BLOCK / 64;
   const BaDev& B = wins[blockIdx.y];
   if (ba_finished(B)) return;
-  const int nf = B.nf, h = blockIdx.x;
-  if (h >= nf) return;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int nf = B.nf, h = WPH ? (int)blockIdx.x * NW + wv : (int)blockIdx.x;
+  if (h >= nf) return;                       // (WPH: a wave of its own — the form has no workgroup barrier)
 #ifdef SDSO_SC_STAMPS   // diagnostic build (tools/mk_variant.sh scst -DSDSO_SC_STAMPS): shader-clock ticks of wave 0 of two workgroups per phase, printed
   unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   int stn = 0;
@@ -1018,12 +1024,10 @@ __global__ __launch_bounds__(BA_BLOCK, 3) void k_ba_sc_host(const BaDev* __restr
 #define SCSUB0() do { } while (0)
 #endif
   SCS();
-  constexpr int SC_NT = 15;                                  // tile t of pair (a <= b): sc_ut(a, b); 10 + a: column tile 4 of row a; 14: the corner
-  constexpr int BIN_E = 64 * 64, BIN_EB = BIN_E + 8 * 32;
-  constexpr int SC_NEED = 2 * SC_NT * 256 + BIN_EB + 64;      // two tile buffers + the bins laid out behind them
+  constexpr int SC_NT = 10;                                  // tile t of pair (a <= b) of the 4 x 4 tile grid: sc_ut(a, b)
+  constexpr int SC_NEED = 2 * SC_NT * 256;                    // the tree's two tile buffers
   constexpr int SC_LDS = NW * SCH_WAVE > SC_NEED ? NW * SCH_WAVE : SC_NEED;
   __shared__ __align__(16) float stage_all[SC_LDS];
-  float (*tiles)[SC_NT * 256] = reinterpret_cast<float (*)[SC_NT * 256]>(stage_all);   // two waves' worth of accumulator tiles (after the loop)
   float* const bufA = stage_all + wv * SCH_WAVE;             // [2][SCH_REC]
   float* const bufT = bufA + 2 * SCH_REC;
   float (*pt)[8] = reinterpret_cast<float (*)[8]>(bufT + SCH_REC);
@@ -1036,7 +1040,7 @@ __global__ __launch_bounds__(BA_BLOCK, 3) void k_ba_sc_host(const BaDev* __restr
   const int tsub = ci >> 3, asub = ci & 7;
   const int pl = lane >> 2, jq = lane & 3;                   // phase 1: point of the group, float pair of the term record
   // a wave's 16-point groups: 64-point slices dealt round-robin over the waves, four groups per slice
-  auto group_p0 = [&](int gidx) { return pb + 64 * (wv + NW * (gidx >> 2)) + 16 * (gidx & 3); };
+  auto group_p0 = [&](int gidx) { return WPH ? pb + 16 * gidx : pb + 64 * (wv + NW * (gidx >> 2)) + 16 * (gidx & 3); };
   // what a group needs beside its records, fetched one group ahead: the first record of its points (lane L: point min(L, npts), so lane 16
   // and everything past the group's end holds the END of its stretch) and, in the phase-1 layout, prior / delta / order / filter of the point
   struct GroupIn { int rb; float prior, delta; unsigned order; int on; };
@@ -1175,35 +1179,55 @@ __global__ __launch_bounds__(BA_BLOCK, 3) void k_ba_sc_host(const BaDev* __restr
     GroupIn gnn;
     fetch_in(group_p0(gidx + 2), gnn);
     SCSUB(3);
-    {  // ---- phase 2: the group's four MFMA operand sets (points 4 u + kq)
-      float zz[4][5], hx[4];
+    {  // ---- phase 2: the group's four MFMA operand sets (points 4 u + kq).  Column 16 tt + ci of Z: compact target 2 tt + tsub (the
+       // targets without the host itself, which no residual of these points observes), element asub; the last eight columns: Hcd, bdSumF
+      float zz[4][4], hx[4];
+      // three straight stages — the points' words, the sixteen record words, the products — with the scheduler kept from sinking a read
+      // next to its use (left alone it waits for sixteen LDS round trips one after the other instead of two).  Every lane reads ONE word
+      // per tile column, unconditionally (a load under a condition becomes a branch with its own wait): the record of its target — any
+      // record when the point does not observe it, masked afterwards — or, on the special lanes of the last tile column, the point's
+      // Hcd / bdSumF word in pt[]
+      unsigned invs[4];
+      int bases[4];
 #pragma unroll
       for (int u = 0; u < 4; u++) {
         const int q = 4 * u + kq;
-        const float4 h0 = *(const float4*)(&pt[q][0]);
-        const float4 h1 = *(const float4*)(&pt[q][4]);
-        const unsigned inv = (unsigned)__float_as_int(h1.z);
-        const float* rb = curA + __float_as_int(h1.w) * 8 + asub;
-#pragma unroll
-        for (int tt = 0; tt < 4; tt++) {
-          const unsigned k = (inv >> (4 * (2 * tt + tsub))) & 15u;
-          zz[u][tt] = k == 15u ? 0.f : rb[k * 8];
-        }
-        zz[u][4] = ci == 0 ? h0.z : ci == 1 ? h0.w : ci == 2 ? h1.x : ci == 3 ? h1.y : ci == 4 ? h0.y : 0.f;
-        hx[u] = h0.x;
+        hx[u] = pt[q][0];
+        const float2 ib = *(const float2*)(&pt[q][6]);
+        invs[u] = (unsigned)__float_as_int(ib.x); bases[u] = __float_as_int(ib.y);
       }
+      __builtin_amdgcn_sched_barrier(0);
+      bool oks[4][4];
 #pragma unroll
       for (int u = 0; u < 4; u++) {
-        float za[5];
+        const int q = 4 * u + kq;
+        const float* rb = curA + bases[u] * 8 + asub;
 #pragma unroll
-        for (int tt = 0; tt < 5; tt++) za[tt] = hx[u] * zz[u][tt];
+        for (int tt = 0; tt < 4; tt++) {
+          const int tp = 2 * tt + tsub, t = tp + (tp >= h ? 1 : 0);       // (tp = 7 is the special block: its lanes take the other address)
+          const unsigned k = (invs[u] >> (4 * (t & 7))) & 15u;
+          const float* ad = rb + (k & 7u) * 8;
+          bool ok = k != 15u;
+          if (tt == 3) { ad = tsub ? &pt[q][asub < 4 ? 2 + asub : 1] : ad; ok = tsub ? asub <= 4 : ok; }
+          zz[u][tt] = *ad;
+          oks[u][tt] = ok;
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+#pragma unroll
+        for (int tt = 0; tt < 4; tt++) zz[u][tt] = oks[u][tt] ? zz[u][tt] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        float za[4];
+#pragma unroll
+        for (int tt = 0; tt < 4; tt++) za[tt] = hx[u] * zz[u][tt];
 #pragma unroll
         for (int a = 0; a < 4; a++) {
 #pragma unroll
           for (int b = a; b < 4; b++) acc[sc_ut(a, b)] = __builtin_amdgcn_mfma_f32_16x16x4f32(za[a], zz[u][b], acc[sc_ut(a, b)], 0, 0, 0);
-          acc[10 + a] = __builtin_amdgcn_mfma_f32_16x16x4f32(za[a], zz[u][4], acc[10 + a], 0, 0, 0);
         }
-        acc[14] = __builtin_amdgcn_mfma_f32_16x16x4f32(za[4], zz[u][4], acc[14], 0, 0, 0);
       }
     }
     gcur = gnext; gnext = gnn;
@@ -1213,8 +1237,83 @@ __global__ __launch_bounds__(BA_BLOCK, 3) void k_ba_sc_host(const BaDev* __restr
   }
   SCS();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // ---- the host's bins from ONE wave's accumulators (WPH: this wave's; otherwise wave 0's after the tree), straight from the registers:
+  // acc[t][v] of lane (kq, ci) is D[16 a + 4 kq + v][16 b + ci] of tile (a, b).  Every (t1, t2) block of 256 bytes is covered by the four
+  // stores of its tile; the blocks below the diagonal are float4s of the mirrored tile; a tile ON the diagonal is mirrored through 1 KB of
+  // LDS first: D(r, c) and D(c, r) differ in the last bit ((w z_r) z_c against (w z_c) z_r), and the stitch relies on
+  // accD(h, i, j) == accD(h, j, i)^T exactly.  The blocks of the host's own (absent) target are zeros.
+  auto store_bins = [&](float* T /* 16 x 17 floats of LDS of this wave */) {
+    const int nf2 = nf * nf;
+    float* accD = B.accum + acc_off_D(nf);
+    float* accE = B.accum + acc_off_E(nf);
+    float* accEB = B.accum + acc_off_EB(nf);
+    const int ro = 4 * (kq & 1), cc = ci & 7;                 // row (+ v) and column inside an 8 x 8 block
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+      const int t1p = 2 * a + (kq >> 1), t1 = t1p + (t1p >= h ? 1 : 0);
+#pragma unroll
+      for (int b = a; b < 4; b++) {
+        const int t2p = 2 * b + (ci >> 3), t2 = t2p + (t2p >= h ? 1 : 0);
+        te_f4 d = acc[sc_ut(a, b)];
+        if (a == b) {
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int v = 0; v < 4; v++) T[(4 * kq + v) * 17 + ci] = d[v];
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+          for (int v = 0; v < 4; v++) { const float m = T[ci * 17 + 4 * kq + v]; d[v] = (4 * kq + v > ci) ? m : d[v]; }
+        }
+        if (t1p < 7 && t1 < nf) {
+          if (t2p < 7) {
+            if (t2 < nf) {
+              float* blk = accD + (size_t)(h + t1 * nf + t2 * nf2) * 64 + cc;
+#pragma unroll
+              for (int v = 0; v < 4; v++) blk[(ro + v) * 8] = d[v];
+              if (a != b) *(float4*)(accD + (size_t)(h + t2 * nf + t1 * nf2) * 64 + cc * 8 + ro) = make_float4(d[0], d[1], d[2], d[3]);   // the mirror image
+            }
+          } else if (cc < 4) {                                 // the special block's columns: Hcd ...
+#pragma unroll
+            for (int v = 0; v < 4; v++) accE[(size_t)(h + t1 * nf) * 32 + (ro + v) * 4 + cc] = d[v];
+          } else if (cc == 4) {                                // ... and bdSumF
+#pragma unroll
+            for (int v = 0; v < 4; v++) accEB[(size_t)(h + t1 * nf) * 8 + ro + v] = d[v];
+          }
+        } else if (b == 3 && t1p == 7 && t2p == 7 && ro == 0) {   // special x special: Hcc (16) and bc (4) of this host; the fold adds the hosts
+          float* hp = B.sc_part + (size_t)h * 20;
+          if (cc < 4) {
+#pragma unroll
+            for (int v = 0; v < 4; v++) hp[v * 4 + cc] = d[v];
+          } else if (cc == 4) {
+#pragma unroll
+            for (int v = 0; v < 4; v++) hp[16 + v] = d[v];
+          }
+        }
+      }
+    }
+    // the host's own target: 2 nf - 1 blocks of accD, one of accE and accEB
+    for (int k = 0; k < 2 * nf; k++) {
+      const int t = k >> 1;
+      if ((k & 1) && t == h) continue;
+      const int t1 = (k & 1) ? t : h, t2 = (k & 1) ? h : t;
+      accD[(size_t)(h + t1 * nf + t2 * nf2) * 64 + lane] = 0.f;
+    }
+    if (lane < 32) accE[(size_t)(h + h * nf) * 32 + lane] = 0.f;
+    else if (lane < 40) accEB[(size_t)(h + h * nf) * 8 + lane - 32] = 0.f;
+  };
+  if (WPH) {
+    store_bins(bufA);
+#ifdef SDSO_SC_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SCS();
+    if ((h == 0 || h == 5) && (blockIdx.y == 0 || blockIdx.y == 100) && lane == 0)
+      printf("sc_host wave-per-host (%d,%d) ticks: prologue %llu  group loop %llu  bins %llu | total %llu  (points %d)  loop: wait %llu  r_cj %llu  phase 1 %llu  dma + inputs %llu  phase 2 %llu\n",
+             h, blockIdx.y, st[1] - st[0], st[2] - st[1], st[3] - st[2], st[3] - st[0], pe - pb, sub[0], sub[1], sub[2], sub[3], sub[4]);
+#endif
+    return;
+  }
   __syncthreads();                            // the tiles lie over the waves' stages
-  // ---- fixed-order tree over the four waves: (3 -> 1, 2 -> 0), then (1 -> 0)
+  // ---- fixed-order tree over the four waves: (3 -> 1, 2 -> 0), then (1 -> 0); wave 0 writes the bins
+  float (*tiles)[SC_NT * 256] = reinterpret_cast<float (*)[SC_NT * 256]>(stage_all);
   auto put = [&](float* dst) {
 #pragma unroll
     for (int t = 0; t < SC_NT; t++)
@@ -1231,57 +1330,17 @@ __global__ __launch_bounds__(BA_BLOCK, 3) void k_ba_sc_host(const BaDev* __restr
   __syncthreads();
   if (wv < 2) add(tiles[wv]);
   __syncthreads();
-  if (wv < 2) put(tiles[wv]);                 // (0 + 2) and (1 + 3)
+  if (wv == 1) put(tiles[1]);                 // (1 + 3)
   __syncthreads();
-  // ---- the host's bins.  Tile element e = (t * 4 + v) * 64 + lane' is D'[16a + 4*kq + v][16b + ci] (lane' = 16 kq + ci): all four waves add
-  // the two halves ((0 + 2) + (1 + 3): the order the tree always had) and lay the sums out in LDS the way the bins lie in memory (64-float
-  // blocks per (t1, t2)), then write them out, one 256-byte block per store
-  const int nf2 = nf * nf;
-  float* accD = B.accum + acc_off_D(nf);
-  float* accE = B.accum + acc_off_E(nf);
-  float* accEB = B.accum + acc_off_EB(nf);
-  float* bins = stage_all + 2 * SC_NT * 256;
-  static_assert(SC_NEED <= SC_LDS, "the bins fit behind the tile buffers");
   SCS();
-  {
-    float* hp = B.sc_part + (size_t)h * 20;      // Hcc (16) and bc (4) of this host; the fold adds the hosts
+  if (wv == 0) {
+    // (0 + 2) + (1 + 3): the order the tree always had
 #pragma unroll
-    for (int j = 0; j < SC_NT; j++) {
-      const int e = (int)threadIdx.x + BA_BLOCK * j;          // BA_BLOCK = 256 = one tile: j is the tile, the thread its (v, lane')
-      const float val = tiles[0][e] + tiles[1][e];
-      const int v = (e >> 6) & 3, ll = e & 63, kq2 = ll >> 4, ci2 = ll & 15;
-      if (j < 10) {
-        int a = 0, jj = j;                                   // sc_ut^-1: rows of 4, 3, 2, 1 upper tiles
-        while (jj >= 4 - a) { jj -= 4 - a; a++; }
-        const int b = a + jj;
-        const int Rr = 16 * a + 4 * kq2 + v, t1 = Rr >> 3, ra = Rr & 7;
-        const int Cc = 16 * b + ci2, t2 = Cc >> 3, cc = Cc & 7;
-        if (b > a || Rr <= Cc) {                             // element (Rr, Cc) of the upper triangle and its mirror image (Cc, Rr)
-          bins[(t1 * 8 + t2) * 64 + ra * 8 + cc] = val;
-          if (Rr != Cc) bins[(t2 * 8 + t1) * 64 + cc * 8 + ra] = val;
-        }
-      } else if (j < 14) {
-        const int Rr = 16 * (j - 10) + 4 * kq2 + v, t1 = Rr >> 3, ra = Rr & 7;
-        if (ci2 < 4) bins[BIN_E + t1 * 32 + ra * 4 + ci2] = val;
-        if (ci2 == 4) bins[BIN_EB + t1 * 8 + ra] = val;
-      } else if (kq2 == 0) {
-        if (ci2 < 4) hp[v * 4 + ci2] = val;
-        if (ci2 == 4) hp[16 + v] = val;
-      }
-    }
-  }
-  __syncthreads();
-#pragma unroll 4
-  for (int blk = wv; blk < 64; blk += NW) {
-    const int t1 = blk >> 3, t2 = blk & 7;
-    if (t1 < nf && t2 < nf) accD[(size_t)(h + t1 * nf + t2 * nf2) * 64 + lane] = bins[blk * 64 + lane];
-  }
+    for (int t = 0; t < SC_NT; t++)
 #pragma unroll
-  for (int idx = 64 * wv + lane; idx < 256; idx += 64 * NW) {
-    const int t1 = idx >> 5;
-    if (t1 < nf) accE[(size_t)(h + t1 * nf) * 32 + (idx & 31)] = bins[BIN_E + idx];
+      for (int v = 0; v < 4; v++) acc[t][v] += tiles[1][(t * 4 + v) * 64 + lane];
+    store_bins(tiles[0]);
   }
-  if (wv == 1 && (lane >> 3) < nf) accEB[(size_t)(h + (lane >> 3) * nf) * 8 + (lane & 7)] = bins[BIN_EB + lane];
 #ifdef SDSO_SC_STAMPS
   if (wv == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
