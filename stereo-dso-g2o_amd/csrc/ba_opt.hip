@@ -175,16 +175,42 @@ __device__ inline float opt_wave_select(const float* v, int n, int k, unsigned* 
   }
   return __uint_as_float(prefix);
 }
-__device__ inline void opt_pre_wave(const BaDev& B, OptPreSmem& P, OptPre* out) {
+// The energies of the residuals into the newest frame (-1: not one of them), requested by ALL threads of the workgroup in one go — kU per
+// thread in registers — and parked in P.en later (opt_pre_park): a single wave walking them was a chain of 25 dependent round trips,
+// the longest thing beside the factorisation once a whole batch shares HBM.
+template <int NT>
+struct OptPreRegs { static constexpr int kU = OptPreSmem::kStage / NT; float e[kU]; };
+template <int NT>
+__device__ __forceinline__ void opt_pre_request(const BaDev& B, OptPreRegs<NT>& R) {
+  const int first = B.opt->newest_first, cap = max(B.nr - first, 0), nf = B.nf;
+#pragma unroll
+  for (int u = 0; u < OptPreRegs<NT>::kU; u++) {
+    const int j = (int)threadIdx.x + u * NT, i = first + j;
+    R.e[u] = -1.f;
+    if (cap <= OptPreSmem::kStage && j < cap) R.e[u] = (B.r_target[i] == nf - 1 && !B.r_lin[i]) ? B.r_newEnergyWO[i] : -1.f;
+  }
+}
+template <int NT>
+__device__ __forceinline__ void opt_pre_park(const BaDev& B, OptPreSmem& P, const OptPreRegs<NT>& R) {
+  const int cap = max(B.nr - B.opt->newest_first, 0);
+  if (cap > OptPreSmem::kStage) return;
+#pragma unroll
+  for (int u = 0; u < OptPreRegs<NT>::kU; u++) { const int j = (int)threadIdx.x + u * NT; if (j < cap) P.en[j] = R.e[u]; }
+}
+__device__ inline void opt_pre_wave(const BaDev& B, OptPreSmem& P, OptPre* out, bool parked = false) {
   const BaOptDev& O = *B.opt;
   const int lane = threadIdx.x & 63, nf = B.nf;
   const int first = O.newest_first, cap = max(B.nr - first, 0);
   if (cap > OptPreSmem::kStage) { if (lane == 0) out->valid = 0.f; return; }
   int cnt = 0;
   for (int j = lane; j < cap; j += 64) {
-    const int i = first + j;
-    const float e = (B.r_target[i] == nf - 1 && !B.r_lin[i]) ? B.r_newEnergyWO[i] : -1.f;
-    P.en[j] = e;
+    float e;
+    if (parked) e = P.en[j];
+    else {
+      const int i = first + j;
+      e = (B.r_target[i] == nf - 1 && !B.r_lin[i]) ? B.r_newEnergyWO[i] : -1.f;
+      P.en[j] = e;
+    }
     cnt += e >= 0 ? 1 : 0;
   }
   double esum = 0;

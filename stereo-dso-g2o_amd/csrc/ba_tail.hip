@@ -115,6 +115,26 @@ __global__ __launch_bounds__(TAIL_NT) void k_ba_tail(const BaDev* __restrict__ w
   // ------------------------------------------------------------------ P1
   {
     const bool fold = (flags & TAIL_FOLD) != 0;
+    // everything that does not hang on the chunk ranges is requested FIRST and parked after the fold below ("request everything, then
+    // park it": written as separate loops each of these was a round trip of its own — the LDS store of a loop waits for its load — five
+    // in a row; requested behind the fold they were a third round trip after its two)
+    constexpr int GT = 8, ET = 5;                              // 4096 adHost doubles / 2560 accE+EB floats over 512 threads
+    double gv[GT]; float ev[ET], hcc = 0.f, hpart[8];
+    double av = 0.0;
+#pragma unroll
+    for (int u = 0; u < GT; u++) { const int e = tid + u * TAIL_NT; gv[u] = e < nf2 * 64 ? adH[e] : 0.0; }
+#pragma unroll
+    for (int u = 0; u < ET; u++) { const int e = tid + u * TAIL_NT; ev[u] = e < nf2 * 40 ? accum[acc_off_E(nf) + e] : 0.f; }   // accE (nf2 x 32) and accEB (nf2 x 8) are contiguous
+    if (tid < nf2 * 8) av = adT[(size_t)(tid >> 3) * 64 + (tid & 7) * 9];
+    if (tid < 20) {
+      if (fold) {
+#pragma unroll
+        for (int h = 0; h < 8; h++) hpart[h] = h < nf ? B.sc_part[(size_t)h * 20 + tid] : 0.f;
+      } else hcc = accum[acc_off_Hcc(nf) + tid];
+    }
+    float nid = 0.f;                          // sum |idepth| of the points as they stand: the break test's sumNID (doStepFromBackup sums the
+    if (flags & TAIL_STEP)                    //   BACKUP values, FullSystemOptimize.cpp:262 — known before the step is taken)
+      for (int p = tid; p < B.np; p += TAIL_NT) nid += fabsf(B.p_geo[p].z);
     // the fold of the top partials: a thread's trips are independent, but each is two dependent global round trips (chunk range of the
     // pair, then the partial) — 12 trips in a row were the longest part of this phase.  The chunk ranges go to LDS first, then every
     // trip's first partial is requested before any is consumed (a pair has one chunk unless it holds more than 256 residuals).
@@ -148,25 +168,6 @@ __global__ __launch_bounds__(TAIL_NT) void k_ba_tail(const BaDev* __restrict__ w
         }
       }
     }
-    // the remaining stages as "request everything, then park it": written as separate loops each of them was a round trip of its own
-    // (the LDS store of a loop waits for its load), five in a row
-    constexpr int GT = 8, ET = 5;                              // 4096 adHost doubles / 2560 accE+EB floats over 512 threads
-    double gv[GT]; float ev[ET], hcc = 0.f, hpart[8];
-    double av = 0.0;
-#pragma unroll
-    for (int u = 0; u < GT; u++) { const int e = tid + u * TAIL_NT; gv[u] = e < nf2 * 64 ? adH[e] : 0.0; }
-#pragma unroll
-    for (int u = 0; u < ET; u++) { const int e = tid + u * TAIL_NT; ev[u] = e < nf2 * 40 ? accum[acc_off_E(nf) + e] : 0.f; }   // accE (nf2 x 32) and accEB (nf2 x 8) are contiguous
-    if (tid < nf2 * 8) av = adT[(size_t)(tid >> 3) * 64 + (tid & 7) * 9];
-    if (tid < 20) {
-      if (fold) {
-#pragma unroll
-        for (int h = 0; h < 8; h++) hpart[h] = h < nf ? B.sc_part[(size_t)h * 20 + tid] : 0.f;
-      } else hcc = accum[acc_off_Hcc(nf) + tid];
-    }
-    float nid = 0.f;                          // sum |idepth| of the points as they stand: the break test's sumNID (doStepFromBackup sums the
-    if (flags & TAIL_STEP)                    //   BACKUP values, FullSystemOptimize.cpp:262 — known before the step is taken)
-      for (int p = tid; p < B.np; p += TAIL_NT) nid += fabsf(B.p_geo[p].z);
 #pragma unroll
     for (int u = 0; u < GT; u++) { const int e = tid + u * TAIL_NT; if (e < nf2 * 64) G[e] = gv[u]; }
 #pragma unroll
@@ -489,6 +490,8 @@ __global__ __launch_bounds__(TAIL_NT) void k_ba_tail(const BaDev* __restrict__ w
   __syncthreads();
   TSTAMP(3);
   // ------------------------------------------------------------------ P3: SVecI (:967) and Eigen's pivot order of the scaled system
+  OptPreRegs<TAIL_NT> pre_regs;                // (the energies the idle wave of P5 sorts: requested here, parked behind As at the end of P4)
+  if (flags & TAIL_STEP) opt_pre_request<TAIL_NT>(B, pre_regs);
   if (tid < 72) {
     double s = 0, d = 0;
     if (tid < n) { const double mii = M[tid * LDLT_LD + tid]; s = 1.0 / sqrt(mii + 10); d = s * mii * s; }
@@ -509,13 +512,14 @@ __global__ __launch_bounds__(TAIL_NT) void k_ba_tail(const BaDev* __restrict__ w
     }
   }
   if (tid < n) bp[pos[tid]] = sv[tid] * bF[tid];
+  if (flags & TAIL_STEP) opt_pre_park<TAIL_NT>(B, *(OptPreSmem*)(tail_smem + TailLds::kPre), pre_regs);
   __syncthreads();
   TSTAMP(5);
   // ------------------------------------------------------------------ P5: wave 0 factorises and solves; wave 1 meanwhile does the part of the
   // loop's host part that does not need x (energies of the linearisation, their 70 % quantile, the energy sum)
   OptPre* pre = (OptPre*)(misc + 44);
   if (wv == 0) ldlt_solve_regs(As, bp, M /* L^T */, col, xp, n);
-  else if (wv == 1 && (flags & TAIL_STEP)) opt_pre_wave(B, *(OptPreSmem*)(tail_smem + TailLds::kPre), pre);
+  else if (wv == 1 && (flags & TAIL_STEP)) opt_pre_wave(B, *(OptPreSmem*)(tail_smem + TailLds::kPre), pre, true);
   __syncthreads();
   TSTAMP(6);
   // ------------------------------------------------------------------ P6: x = SVecI * solve(...) (:976), x -= P x (:980-984, :824-826)
