@@ -322,11 +322,11 @@ class BAWorkload:
         if os.environ.get("SDSO_BENCH_SECONDARY", "1") == "1":
             for G in self.groups:
                 G.ctx.check(G.ctx.L.sdso_prof_enable(G.ctx.h, 2))
-            base = {k: self.prof_read(k) for k in ("k_ba_sc", "k_ba_tail")}
+            base = {k: self.prof_read(k) for k in ("k_ba_sc", "k_ba_tail", "k_ba_resub")}
             for _ in range(5):
                 self.step()
             self.sync()
-            for k in ("k_ba_sc", "k_ba_tail"):
+            for k in ("k_ba_sc", "k_ba_tail", "k_ba_resub"):
                 ms, n = self.prof_read(k)
                 out[k + "_avg_ms"] = (ms - base[k][0]) / max(n - base[k][1], 1)
             for G in self.groups:

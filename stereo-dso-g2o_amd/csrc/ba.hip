@@ -1928,7 +1928,7 @@ static int opt_solve_step(sdso_ctx* ctx, OptRun& R, double lambda, int orth, boo
   const dim3 gp(std::max(R.L.max_nblk_pts, 1), nwin);
   if (!R.exchange) {
     launch_tail(ctx, R.L, lambda, flags | TAIL_STEP, R.iteration, 0, R.stop);
-    if (R.L.max_nblk_pts) LAUNCH_RESUB_STEP(R.L, gp, dim3(BA_BLOCK), 0, ctx->stream, R.L.d_arr, R.iteration + 1, (float*)nullptr, 0);
+    if (R.L.max_nblk_pts) { ProfScope ps(ctx, "k_ba_resub", 2); LAUNCH_RESUB_STEP(R.L, gp, dim3(BA_BLOCK), 0, ctx->stream, R.L.d_arr, R.iteration + 1, (float*)nullptr, 0); }
     SDSO_HIP(ctx, hipGetLastError());
     R.iteration++;
     return SDSO_OK;
