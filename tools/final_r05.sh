@@ -13,6 +13,7 @@ timeout -k 10 300 python bench.py --workload trace --steps 50 2>/dev/null | tail
 echo bench done
 timeout -k 10 300 python tests/diag/bench_latency.py > gpurun_out/r05_latency.json 2>gpurun_out/r05_latency.err
 timeout -k 10 200 python tools/time_optimize.py > gpurun_out/r05_optimize_times.txt 2>&1
+timeout -k 10 100 python tools/time_track.py > gpurun_out/r05_time_track_final.txt 2>&1
 echo latency done
 bash tools/profile_r05.sh > gpurun_out/profile_r05.log 2>&1
 echo profiles done
