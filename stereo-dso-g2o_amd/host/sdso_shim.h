@@ -795,6 +795,16 @@ inline void traceStereoAll(Device& dev, std::vector<ImmaturePointT*>& pts, int f
   }
 }
 
+// The member itself, ONE point (ImmaturePoint.h:89): `ImmaturePointStatus ImmaturePoint::traceStereo(FrameHessian* frame, Mat33f K,
+// bool mode_right)` becomes `return sdso_shim::traceStereo(dev, this, slot_of(frame), K, baseline, mode_right);` — same state changes on
+// the point, same return value.  A launch per point: the callers' loops (FullSystem.cpp:581-613, :667-725) want traceStereoAll.
+template <class ImmaturePointT, class Mat33fT>
+inline auto traceStereo(Device& dev, ImmaturePointT* p, int frame_slot, const Mat33fT& K, float baseline, bool mode_right) -> decltype(p->lastTraceStatus) {
+  std::vector<ImmaturePointT*> one{p};
+  std::vector<uint8_t> st;
+  traceStereoAll(dev, one, frame_slot, K, baseline, mode_right, st);
+  return static_cast<decltype(p->lastTraceStatus)>(st[0]);
+}
 
 // =================================================================================== per-keyframe steps
 // PixelSelector (src/FullSystem/PixelSelector2.h): int makeMaps(const FrameHessian* fh, float* map_out, float density,
@@ -838,6 +848,22 @@ inline void traceOnAll(Device& dev, std::vector<ImmaturePointT*>& pts, const std
     p->lastTraceStatus = static_cast<decltype(p->lastTraceStatus)>(lts[i]);
     p->lastTraceUV[0] = uv[2 * i]; p->lastTraceUV[1] = uv[2 * i + 1]; p->lastTracePixelInterval = itv[i];
   }
+}
+
+// The member itself, ONE point (ImmaturePoint.h:90): `ImmaturePointStatus ImmaturePoint::traceOn(FrameHessian* frame, Mat33f
+// hostToFrame_KRKi, Vec3f hostToFrame_Kt, Vec2f hostToFrame_affine, CalibHessian* HCalib, bool debugPrint)` becomes
+// `return sdso_shim::traceOn(dev, this, slot_of(frame), KRKi, Kt, aff);` (HCalib is not read by the DSO-native body; debugPrint prints).
+template <class ImmaturePointT, class Mat33fT, class Vec3fT, class Vec2fT>
+inline auto traceOn(Device& dev, ImmaturePointT* p, int frame_slot, const Mat33fT& hostToFrame_KRKi, const Vec3fT& hostToFrame_Kt,
+                    const Vec2fT& hostToFrame_affine) -> decltype(p->lastTraceStatus) {
+  sdso_trace_geom_t g;
+  for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) g.KRKi[r * 3 + c] = hostToFrame_KRKi(r, c);
+  for (int r = 0; r < 3; r++) g.Kt[r] = hostToFrame_Kt[r];
+  g.aff[0] = hostToFrame_affine[0]; g.aff[1] = hostToFrame_affine[1];
+  std::vector<ImmaturePointT*> one{p};
+  std::vector<uint8_t> st;
+  traceOnAll(dev, one, std::vector<int>{0}, std::vector<sdso_trace_geom_t>{g}, frame_slot, st);
+  return static_cast<decltype(p->lastTraceStatus)>(st[0]);
 }
 
 // EnergyFunctional::marginalizeFrame's algebra (EnergyFunctional.cpp:554-660) on plain row-major arrays

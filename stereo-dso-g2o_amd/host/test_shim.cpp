@@ -6,6 +6,7 @@
 //   test_shim <dir> tracker|tracker_g2o|tracker_ref|stereo|stereo_g2o|ba|ba_members|selector
 #include <cmath>
 #include <cstdio>
+#include <cstring>
 #include <cstdlib>
 #include <fstream>
 #include <memory>
@@ -129,6 +130,11 @@ struct Vec5 { double v[5]; double operator[](int i) const { return v[i]; } };
 // compile the temporal-trace wrapper against the stand-in as well (it is exercised through the C-ABI in tests/test_stereo.py)
 template void sdso_shim::traceOnAll<ImmaturePoint>(sdso_shim::Device&, std::vector<ImmaturePoint*>&, const std::vector<int>&, const std::vector<sdso_trace_geom_t>&, int,
                                                    std::vector<uint8_t>&);
+
+struct Vec3fc { float v[3]; float operator[](int i) const { return v[i]; } };
+struct Vec2fc { float v[2]; float operator[](int i) const { return v[i]; } };
+// ... and ImmaturePoint::traceOn's one-point form (ImmaturePoint.h:90)
+template int sdso_shim::traceOn<ImmaturePoint, Mat33f, Vec3fc, Vec2fc>(sdso_shim::Device&, ImmaturePoint*, int, const Mat33f&, const Vec3fc&, const Vec2fc&);
 
 static void load_pyramid(const std::string& dir, const char* prefix, FrameHessian& fh, int levels) {
   fh.store.resize(levels);
@@ -273,7 +279,19 @@ static int run_stereo(const std::string& dir, bool fork_live) {
   Mat33f K{{kf[0], 0, kf[2], 0, kf[1], kf[3], 0, 0, 1}};
   std::vector<uint8_t> status;
   dev.setForkLiveTraceRefinement(fork_live);
+  std::vector<ImmaturePoint> fresh(store.begin(), store.begin() + std::min(n, 24));     // (before the call: the member form below starts from the same state)
   sdso_shim::traceStereoAll(dev, pts, 3, K, kf[4], meta[3] != 0, status);
+  // ImmaturePoint::traceStereo as the member it is — one point per call — must be the batch's result for that point, bit for bit
+  for (size_t i = 0; i < fresh.size(); i++) {
+    const int st = sdso_shim::traceStereo(dev, &fresh[i], 3, K, kf[4], meta[3] != 0);
+    const ImmaturePoint &a = fresh[i], &b = store[i];
+    if (st != (int)status[i] || a.lastTraceStatus != b.lastTraceStatus || std::memcmp(&a.idepth_min_stereo, &b.idepth_min_stereo, 4) || std::memcmp(&a.idepth_max_stereo, &b.idepth_max_stereo, 4) ||
+        std::memcmp(&a.idepth_stereo, &b.idepth_stereo, 4) || std::memcmp(&a.quality, &b.quality, 4) || std::memcmp(a.lastTraceUV, b.lastTraceUV, 8) ||
+        std::memcmp(&a.lastTracePixelInterval, &b.lastTracePixelInterval, 4)) {
+      std::fprintf(stderr, "traceStereo (one point) differs from traceStereoAll at point %zu\n", i);
+      return 3;
+    }
+  }
   for (int i = 0; i < n; i++)
     std::printf("%d %d %.9g %.9g %.9g %.9g %.9g %.9g %.9g\n", (int)status[i], store[i].lastTraceStatus, store[i].idepth_min_stereo, store[i].idepth_max_stereo,
                 store[i].idepth_stereo, store[i].quality, store[i].lastTraceUV[0], store[i].lastTraceUV[1], store[i].lastTracePixelInterval);
