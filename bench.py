@@ -475,6 +475,11 @@ def main():
             out["roofline"]["bound_note"] = ("hbm: the launch moves %.2fx its algorithmic bytes at %.2f TB/s, i.e. at or above the 4.84 TB/s a device copy "
                                              "reaches here; SQ counters (profiles/) show the waves waiting on memory, not on issue" % (
                                                  tr / (per_launch_units * wl.bytes_per_unit), tr / (avg_ms * 1e-3) / 1e12))
+            if args.workload == "ba":
+                # what the waves wait for is the LATENCY of the taps' misses, not their volume: 13 % fewer lines fetched (four shifted tile
+                # grids, best grid per residual) left the kernel 1.5 % slower (profiles/r05_tile_grids_ab.txt)
+                out["roofline"]["bound_note"] += ("; memory latency under the CUs' miss queues rather than bytes: fetching 13 %% fewer lines did not "
+                                                  "shorten it (profiles/r05_tile_grids_ab.txt)")
         out["extra"]["host_enqueue_ms_per_step"] = t_enq / args.steps * 1e3
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = wl.cpu_baseline()
