@@ -7,6 +7,8 @@ variables are read once per process: `static const ... getenv`).  Round-2 adviso
                         (the split of the points changes the order of the float sums: a hypothesis that sits on an LM accept / stop threshold
                         can take one iteration more or fewer — seen once with clusters of three, 10 against 9 iterations on level 1 of one of the
                         eight lock-step hypotheses; every other cluster size from 2 to 8 reproduces the oracle's counts on these problems)
+  SDSO_TRK_LM_SOLO=0 / 1000000   k_track_lm with every level shared by the cluster / with every level evaluated by every member in full (default: levels of
+                        at most 2048 points are not shared)
   SDSO_TRK_LM_TEST_DROP_MEMBER=1   test hook, compiled into libsdso_hip_hooks.so only (csrc/Makefile: -DSDSO_TEST_HOOKS): the last member of
                         every cluster exits at once (a cluster that is not co-resident); the product library does not read the variable
   SDSO_BA_SOLVE_HOST=1  solveSystemF's SVD / orthogonalised-system branches on the host (solve_system_host, rounds 1-3) instead of k_ba_solve_alt
@@ -35,6 +37,9 @@ VARIANTS = [
                                     "tests/test_tracker_gpu.py::test_track_affine_modes"]),
     ({"SDSO_TRK_LM_CLUSTER": "2"}, ["tests/test_tracker_gpu.py::test_track_newest_coarse_pose_within_1e5", "tests/test_tracker_gpu.py::test_track_hypotheses_in_lock_step",
                                     "tests/test_tracker_gpu.py::test_track_affine_modes"]),
+    # every level shared by the cluster (the round-4 form; by default the coarse levels are evaluated by every member in full) and every level solo
+    ({"SDSO_TRK_LM_SOLO": "0"}, ["tests/test_tracker_gpu.py::test_track_newest_coarse_pose_within_1e5", "tests/test_tracker_gpu.py::test_track_hypotheses_in_lock_step"]),
+    ({"SDSO_TRK_LM_SOLO": "1000000"}, ["tests/test_tracker_gpu.py::test_track_newest_coarse_pose_within_1e5", "tests/test_tracker_gpu.py::test_track_hypotheses_in_lock_step"]),
     # a cluster that loses a member: the kernel gives the call back after a bounded wait, the library repeats it with single workgroups
     ({"SDSO_TRK_LM_TEST_DROP_MEMBER": "1", "SDSO_LIB_PATH": os.path.join(ROOT, "stereo-dso-g2o_amd", "csrc", "libsdso_hip_hooks.so")}, ["tests/test_tracker_gpu.py::test_track_newest_coarse_pose_within_1e5", "tests/test_tracker_gpu.py::test_track_hypotheses_in_lock_step"]),
 ]
