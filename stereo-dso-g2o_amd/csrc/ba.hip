@@ -1927,8 +1927,13 @@ static int opt_solve_step(sdso_ctx* ctx, OptRun& R, double lambda, int orth, boo
   const int nwin = (int)R.W.size();
   const dim3 gp(std::max(R.L.max_nblk_pts, 1), nwin);
   if (!R.exchange) {
-    launch_tail(ctx, R.L, lambda, flags | TAIL_STEP, R.iteration, 0, R.stop);
-    if (R.L.max_nblk_pts) { ProfScope ps(ctx, "k_ba_resub", 2); LAUNCH_RESUB_STEP(R.L, gp, dim3(BA_BLOCK), 0, ctx->stream, R.L.d_arr, R.iteration + 1, (float*)nullptr, 0); }
+    // the points' back-substitution and step inside the tail kernel (TAIL_RESUB) once every CU has a tail workgroup anyway: 143 -> 132 us
+    // for the two at 256 windows; below that the separate kernel spreads a window's points over idle CUs (one window: 0.64 against
+    // 0.70 ms per optimize).  SDSO_BA_TAIL_RESUB=0 / 1 forces one form (A/B)
+    static const int fuse_env = getenv("SDSO_BA_TAIL_RESUB") ? atoi(getenv("SDSO_BA_TAIL_RESUB")) : -1;
+    const bool fuse_resub = fuse_env >= 0 ? fuse_env != 0 : nwin >= ctx->n_cu;
+    launch_tail(ctx, R.L, lambda, flags | TAIL_STEP | (fuse_resub ? TAIL_RESUB : 0), R.iteration, 0, R.stop);
+    if (R.L.max_nblk_pts && !fuse_resub) { ProfScope ps(ctx, "k_ba_resub", 2); LAUNCH_RESUB_STEP(R.L, gp, dim3(BA_BLOCK), 0, ctx->stream, R.L.d_arr, R.iteration + 1, (float*)nullptr, 0); }
     SDSO_HIP(ctx, hipGetLastError());
     R.iteration++;
     return SDSO_OK;

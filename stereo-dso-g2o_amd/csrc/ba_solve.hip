@@ -575,9 +575,12 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_solve(const BaDev* __restrict__
 // subtractions of the reference one after the other; step = -b HdiF.  The active records are the bits the Schur kernel left in p_track.
 // Every load of the point is issued before the first one is consumed (the loop is unrolled to the 8 residuals a point can hold and
 // predicated): one memory round trip instead of one per residual.  WITH_L: the point's L sums (linearised / marginalised residuals) exist.
+// x_cal / xAd: the solution's calibration part and the adjoint products where the caller has them (the fused tail kernel: in LDS);
+// nullptr: where the solve left them in global memory
 template <bool WITH_L>
-__device__ __forceinline__ float resub_point(const BaDev& B, int p, const float* po) {
-  const double* x = B.sol + 3 * ((size_t)B.n * B.n + B.n);
+__device__ __forceinline__ float resub_point(const BaDev& B, int p, const float* po, const double* x_cal = nullptr, const float* xAd = nullptr) {
+  const double* x = x_cal ? x_cal : B.sol + 3 * ((size_t)B.n * B.n + B.n);
+  const float* xAd_tab = xAd ? xAd : B.t_xAd;
   const int nf = B.nf;
   const float* recs = B.r_cj + (size_t)B.p_rbeg[p] * 8;
   const int h = B.p_host[p];
@@ -590,7 +593,7 @@ __device__ __forceinline__ float resub_point(const BaDev& B, int p, const float*
     if (k < cnt) {
       const float* rec = recs + k * 8;
       j0[k] = *reinterpret_cast<const float4*>(rec); j1[k] = *reinterpret_cast<const float4*>(rec + 4);
-      const float* xa = B.t_xAd + (size_t)(h * nf + (int)((ord >> (4 * k)) & 15u)) * 8;
+      const float* xa = xAd_tab + (size_t)(h * nf + (int)((ord >> (4 * k)) & 15u)) * 8;
       xa0[k] = *reinterpret_cast<const float4*>(xa); xa1[k] = *reinterpret_cast<const float4*>(xa + 4);
     }
   }
@@ -628,6 +631,21 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_resub(const BaDev* __restrict__
   po[PO_STEP] = resub_point<WITH_L>(B, p, po);
 }
 
+// one point of k_ba_resub_step: resubstituteFPt, backupState, doStepFromBackup (stepfacD = 1); sID / sNID: its terms of the break test's sums
+template <bool WITH_L>
+__device__ __forceinline__ void resub_step_point(const BaDev& B, int p, const double* x_cal, const float* xAd, float& sID, float& sNID) {
+  float* po = B.p_out + (size_t)p * 16;
+  float4 g = B.p_geo[p];
+  const float st = resub_point<WITH_L>(B, p, po, x_cal, xAd);
+  po[PO_STEP] = st;
+  po[PO_BACKUP] = g.z;
+  const float bk = g.z, nid = bk + 1.0f * st;
+  g.z = nid; g.w = nid;     // setIdepth + setIdepthZero
+  B.p_geo[p] = g;
+  B.p_delta[p] = nid - nid;
+  sID = st * st; sNID = fabsf(bk);
+}
+
 // resubstituteFPt + backupState + doStepFromBackup (stepfacD = 1) of the points in ONE pass over the point data (k_ba_resub followed
 // by k_ba_points_op op 3), after the fused tail kernel of the resident loop.  expect_iterations >= 0: the window takes part iff its
 // loop has taken exactly that many steps — the tail kernel that just ran may have set `finished` for the NEXT iteration (the break
@@ -638,18 +656,7 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_resub_step(const BaDev* __restr
   if (expect_iterations >= 0 ? (ba_finished_lin(B) || B.opt->iterations != expect_iterations) : ba_finished(B)) return;
   const int p = blockIdx.x * BA_BLOCK + threadIdx.x;
   float sID = 0, sNID = 0;
-  if (p < B.np) {
-    float* po = B.p_out + (size_t)p * 16;
-    float4 g = B.p_geo[p];
-    const float st = resub_point<WITH_L>(B, p, po);
-    po[PO_STEP] = st;
-    po[PO_BACKUP] = g.z;
-    const float bk = g.z, nid = bk + 1.0f * st;
-    g.z = nid; g.w = nid;     // setIdepth + setIdepthZero
-    B.p_geo[p] = g;
-    B.p_delta[p] = nid - nid;
-    sID = st * st; sNID = fabsf(bk);
-  }
+  if (p < B.np) resub_step_point<WITH_L>(B, p, nullptr, nullptr, sID, sNID);
   if (sums) {
     __shared__ float r0[BA_BLOCK / 64], r1[BA_BLOCK / 64];
     const float a = wave_sum(sID), b = wave_sum(sNID);

@@ -37,6 +37,7 @@ constexpr int TAIL_STEP = 16;       // the loop's host part (opt_step_body), sin
 constexpr int TAIL_ORTH = 32;       // x -= P x
 constexpr int TAIL_LAMBDA_DEV = 64; // lambda of the window's resident loop (energy-gated flow)
 constexpr int TAIL_TOPL = 128;      // the linearised (L) top sums are not zero: read them from the packed block
+constexpr int TAIL_RESUB = 256;     // with TAIL_STEP, last == 0: the points' back-substitution and step too (k_ba_resub_step's work, by this workgroup)
 
 // LDS layout (bytes); the big regions are reused by phases that do not overlap
 struct TailLds {
@@ -564,6 +565,15 @@ __global__ __launch_bounds__(TAIL_NT) void k_ba_tail(const BaDev* __restrict__ w
   }
 #endif
   }  // !ba_finished
+  // ------------------------------------------------------------------ P6b: resubstituteF_MT + the points' backupState / doStepFromBackup for this window,
+  // x and xAd straight from LDS — k_ba_resub_step's pass (one launch fewer per iteration; a workgroup starts on its points the moment its
+  // own x exists).  Only when this call takes the step: the window's break test has not fired (phase 1 consumes energies only).
+  if ((flags & TAIL_RESUB) && !ba_finished(B) && B.opt->phase != 1) {
+    const double* xc = xv;
+    float a_, b_;
+    if (flags & TAIL_TOPL) { for (int p = tid; p < B.np; p += TAIL_NT) resub_step_point<true>(B, p, xc, xAd_s, a_, b_); }
+    else { for (int p = tid; p < B.np; p += TAIL_NT) resub_step_point<false>(B, p, xc, xAd_s, a_, b_); }
+  }
   // ------------------------------------------------------------------ P7
   if (flags & TAIL_STEP) {
     __syncthreads();

@@ -12,6 +12,7 @@ variables are read once per process: `static const ... getenv`).  Round-2 adviso
   SDSO_TRK_LM_TEST_DROP_MEMBER=1   test hook, compiled into libsdso_hip_hooks.so only (csrc/Makefile: -DSDSO_TEST_HOOKS): the last member of
                         every cluster exits at once (a cluster that is not co-resident); the product library does not read the variable
   SDSO_BA_SOLVE_HOST=1  solveSystemF's SVD / orthogonalised-system branches on the host (solve_system_host, rounds 1-3) instead of k_ba_solve_alt
+  SDSO_BA_TAIL_RESUB=1  the points' back-substitution and step inside k_ba_tail (the form the library takes for batches of at least one window per CU)
   SDSO_BA_SC_WPH=1      k_ba_sc_host with one WAVE per host frame — the form the library takes by itself for batches beyond 240 windows (the bench) —
                         on the small batches and single windows of the parity tests (ragged windows, hosts without points, nf < 8, marginalisation)"""
 import os
@@ -29,6 +30,7 @@ BA_LIGHT = [BA[0], BA[2]]        # the batch loop and the fused kernel at the be
 VARIANTS = [
     ({"SDSO_BA_TAIL": "0"}, BA + ["tests/test_ba_gpu.py", "-k", "resident or fused or accumulate_solve or optimize_full_gn_loop or energy_gated or tables_linearize_apply or ragged or batch_equals_single or marginalize_points"]),
     ({"SDSO_BA_SOLVE_HOST": "1"}, ["tests/test_ba_gpu.py::test_solver_mode_variants"]),
+    ({"SDSO_BA_TAIL_RESUB": "1"}, BA + ["tests/test_ba_gpu.py", "-k", "resident or fused or optimize_full_gn_loop or batch_equals_single or pose_updates"]),
     ({"SDSO_BA_SC_WPH": "1"}, BA + ["tests/test_ba_marg_gpu.py", "tests/test_ba_gpu.py", "-k", "resident or fused or accumulate_solve or optimize_full_gn_loop or tables_linearize_apply or ragged or batch_equals_single or marginalize or stitched"]),
     ({"SDSO_BA_JSWAP": "1"}, BA_LIGHT),
     ({"SDSO_TRK_HOST_LM": "1"}, ["tests/test_tracker_gpu.py::test_track_newest_coarse_pose_within_1e5", "tests/test_tracker_gpu.py::test_track_hypotheses_in_lock_step",
