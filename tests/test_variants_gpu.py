@@ -30,7 +30,8 @@ BA_LIGHT = [BA[0], BA[2]]        # the batch loop and the fused kernel at the be
 VARIANTS = [
     ({"SDSO_BA_TAIL": "0"}, BA + ["tests/test_ba_gpu.py", "-k", "resident or fused or accumulate_solve or optimize_full_gn_loop or energy_gated or tables_linearize_apply or ragged or batch_equals_single or marginalize_points"]),
     ({"SDSO_BA_SOLVE_HOST": "1"}, ["tests/test_ba_gpu.py::test_solver_mode_variants"]),
-    ({"SDSO_BA_TAIL_RESUB": "1"}, BA + ["tests/test_ba_gpu.py", "-k", "resident or fused or optimize_full_gn_loop or batch_equals_single or pose_updates"]),
+    ({"SDSO_BA_TAIL_RESUB": "1"}, ["tests/test_ba_resident_gpu.py", "tests/test_ba_fused_gpu.py", "tests/test_ba_gpu.py", "-k",
+                                   "resident or fused or lifetime or gated or optimize_full_gn_loop or batch_equals_single or pose_updates or ragged or affine_modes"]),
     ({"SDSO_BA_SC_WPH": "1"}, BA + ["tests/test_ba_marg_gpu.py", "tests/test_ba_gpu.py", "-k", "resident or fused or accumulate_solve or optimize_full_gn_loop or tables_linearize_apply or ragged or batch_equals_single or marginalize or stitched"]),
     ({"SDSO_BA_JSWAP": "1"}, BA_LIGHT),
     ({"SDSO_TRK_HOST_LM": "1"}, ["tests/test_tracker_gpu.py::test_track_newest_coarse_pose_within_1e5", "tests/test_tracker_gpu.py::test_track_hypotheses_in_lock_step",
