@@ -331,6 +331,14 @@ class BAWorkload:
                 out[k + "_avg_ms"] = (ms - base[k][0]) / max(n - base[k][1], 1)
             for G in self.groups:
                 G.ctx.check(G.ctx.L.sdso_prof_enable(G.ctx.h, 0))
+            # the Schur kernel against ITS roofline (24 B per point + 32 B per residual of it, i.e. what the reference's addPoint
+            # reads): per launch of this rank's windows
+            if out.get("k_ba_sc_avg_ms", 0) > 0:
+                nwin = sum(G.nwin for G in self.groups)
+                alg = (24.0 * self.win["np"] + 32.0 * self.win["nr"]) * nwin / max(len(self.groups), 1)
+                gbps = alg / (out["k_ba_sc_avg_ms"] * 1e-3) / 1e9
+                out["k_ba_sc_roofline"] = {"bound": "hbm", "algorithmic_bytes_per_launch": alg, "achieved": gbps, "peak": 8000.0, "unit": "GB/s",
+                                           "frac": gbps / 8000.0, "note": "PMC traffic per launch: profiles/rNN_ba_rocprof_summary.txt (k_ba_sc_host: 2*FETCH + WRITE)"}
         # The second unit of SURVEY §8d, measured the same way in a few extra steps: the records stay in registers (464 B per point-residual
         # instead of 760: nothing downstream of the linearisation reads RawResidualJacobian — the library's own resident loop,
         # sdso_ba_optimize, runs this way and materialises them in its closing linearizeAll only).  The headline above keeps the 760-B unit.
