@@ -429,7 +429,7 @@ static int upload_window_impl(sdso_ctx* ctx, int win, const sdso_ba_window_t* Wi
   const float4** d_img; PL(d_img, const float4*, nf, true);
   int4* d_chunks; int* d_pair_beg; int4* d_items; int* d_host_beg;
   PL(d_chunks, int4, chunks.size(), true); PL(d_pair_beg, int, nf * nf + 1, true); PL(d_items, int4, items.size(), true); PL(d_host_beg, int, nf + 1, true);
-  PL(d.top_part, float, (size_t)d.nchunks * 92, false); PL(d.sc_part, float, (size_t)nf * 20, false);
+  PL(d.top_part, double, (size_t)d.nchunks * 92, false); PL(d.sc_part, float, (size_t)nf * 20, false);
   PL(d.e_part, double, std::max(W->nblk_res, d.nchunks) + 1, false);
   PL(d.accum, float, acc_floats(nf), false);
   PL(d.sol, double, sol_doubles(n, nf), false);

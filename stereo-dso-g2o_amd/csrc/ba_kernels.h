@@ -117,7 +117,7 @@ struct BaDev {
   const int4* items;        // {host, pbeg, pend, 0}
   const int* host_item_beg; // nf+1
   int host_pt_beg[9];       // points of host h: [host_pt_beg[h], host_pt_beg[h + 1]) (points are in allPoints order: grouped by host)
-  float* top_part;          // nchunks x 92 (91 sums + count)
+  double* top_part;         // nchunks x 92 (91 sums + count), f64: rounded to float once, when a pair's chunks are folded
   float* sc_part;           // nf x 20: Hcc (16) and bc (4) of every host's Schur workgroup; the fold adds the hosts
   double* e_part;           // energy partials of linearize (per workgroup)
   float* accum;             // packed accumulators (see sdso_ba_accum_floats)

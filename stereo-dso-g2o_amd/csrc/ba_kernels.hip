@@ -650,12 +650,33 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_reset_all(const BaDev* __restri
 // plus a constant-1 row per half that turns the last three columns into plain sums: a 12 x 16 x (2*64) product
 // per wave.  Summing 92 values over 64 lanes with shuffles costs ~1100 issue slots per residual; instead every
 // lane parks its 26 values per half in a wave-private LDS panel (row stride 68 floats: conflict-free for the
-// lane-contiguous writes and for the (row = lane%16, k = lane/16) reads) and 2 x 16 v_mfma_f32_16x16x4_f32
-// (full fp32) do the reduction.  Only the ORDER of the cross-residual float sums differs from the CPU path.
+// lane-contiguous writes and for the (row = lane%16, k = lane/16) reads) and the matrix cores do the reduction.
+//
+// The CROSS-RESIDUAL sums run in f64 (round 6): 2 x 16 v_mfma_f64_16x16x4_f64 per wave on the float operands converted exactly, two
+// interleaved accumulators, the waves' tiles added in f64, top_part in f64, ONE rounding to float when the pair's chunks have been
+// folded into the packed block.  The reference limits the growth of these float sums with its three-tier carry (MatrixAccumulators.h:
+// 872-903) and its thread partials (AccumulatedTopHessian.cpp:299-308); a 128-term fmaf chain per wave (rounds 1-5) sat as far from an
+// order-independent sum as the CPU path does but not on the same side, and north_star's 1e-5 on the pose update is at that distance
+// (profiles/r05_truth_updates.txt).  In f64 the device's sums ARE the order-independent value up to one float rounding; what is left
+// between device and CPU is the CPU float path's own distance from it (profiles/r06_truth_updates.txt).  The per-residual operands
+// (v0 / v1 included) stay the float expressions they were: their roundings do not accumulate.
 constexpr int TE_STRIDE = 68;
 constexpr int TE_ROWS = 26;
 constexpr int TE_WAVE_FLOATS = TE_ROWS * TE_STRIDE;
 constexpr int TE_LDS_FLOATS = (BA_BLOCK / 64) * TE_WAVE_FLOATS;
+typedef double te_d4 __attribute__((ext_vector_type(4)));
+// How the cross-residual / cross-point sums are carried (compile-time, A/B: tools/mk_variant.sh <name> -DSDSO_ACC_MODE=k; measured on the
+// 24 windows of tests/diag/truth_spread.py and the 256-window step, profiles/r06_acc_modes.txt):
+//   1 (default)  v_mfma_f64_16x16x4_f64 throughout: first pose update 1.4e-6 (median) from the f64-accumulator truth, the CPU float path
+//                1.3e-5; +8 us on k_ba_lin_fused, +10 us on k_ba_sc_host per 256-window step (the f64 form runs at half the fp32 rate);
+//   2            fp32 MFMA over 16-term chains from a zero accumulator, the chains added in f64 on the VALU: free in time, but a chain's
+//                error grows with its partial sums, not with its length alone — 6.4e-6, half way;
+//   0            one fp32 chain per wave (rounds 1-5): 1.1e-5.
+#ifndef SDSO_ACC_MODE
+#define SDSO_ACC_MODE 1
+#endif
+constexpr int ACC_MODE = SDSO_ACC_MODE;
+static_assert(TE_LDS_FLOATS * 4 >= ((BA_BLOCK / 64) * 256 + BA_BLOCK / 64) * 8, "the waves' f64 tiles lie over the panels");
 
 template <bool LDS_ONLY = false>
 __device__ __forceinline__ void top_emit(const BaDev& B, const float* x, const float* y, float a, float b, float c, float TR00, float TR10, float TR01,
@@ -664,7 +685,8 @@ __device__ __forceinline__ void top_emit(const BaDev& B, const float* x, const f
   float* S = stage + wv * TE_WAVE_FLOATS;
   const int m = lane & 15, kq = lane >> 4;
   const int mu = m < 10 ? m : 9;
-  te_f4 acc = {0.f, 0.f, 0.f, 0.f};
+  te_d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};   // ACC_MODE 1: D[i][j], i = lane/16 + 4 v; otherwise i = 4 (lane/16) + v
+  te_f4 accf = {0.f, 0.f, 0.f, 0.f};
   const unsigned long long onmask = __ballot(on);
 #pragma unroll
   for (int ph = 0; ph < 2; ph++) {
@@ -680,20 +702,46 @@ __device__ __forceinline__ void top_emit(const BaDev& B, const float* x, const f
     for (int q = 0; q < 3; q++) S[(23 + q) * TE_STRIDE + lane] = br[3 * ph + q];
     wg_barrier<LDS_ONLY>();
     const float one = (m == 10 + ph) ? 1.f : 0.f;
+    if (ACC_MODE == 1) {
 #pragma unroll
-    for (int s4 = 0; s4 < 16; s4++) {
-      float av = S[mu * TE_STRIDE + 4 * s4 + kq];
-      av = m < 10 ? av : one;
-      const float bv = S[(10 + m) * TE_STRIDE + 4 * s4 + kq];
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+      for (int s4 = 0; s4 < 16; s4 += 2) {
+        float av0 = S[mu * TE_STRIDE + 4 * s4 + kq], av1 = S[mu * TE_STRIDE + 4 * s4 + 4 + kq];
+        av0 = m < 10 ? av0 : one; av1 = m < 10 ? av1 : one;
+        const float bv0 = S[(10 + m) * TE_STRIDE + 4 * s4 + kq], bv1 = S[(10 + m) * TE_STRIDE + 4 * s4 + 4 + kq];
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64((double)av0, (double)bv0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64((double)av1, (double)bv1, acc1, 0, 0, 0);
+      }
+    } else {
+      // four chains of four steps (16 residuals each), two in flight; a chain's result joins the f64 sum while the next ones run
+      te_f4 ch[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        ch[q] = (te_f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s4 = 4 * q; s4 < 4 * q + 4; s4++) {
+          float av = S[mu * TE_STRIDE + 4 * s4 + kq];
+          av = m < 10 ? av : one;
+          const float bv = S[(10 + m) * TE_STRIDE + 4 * s4 + kq];
+          if (ACC_MODE == 0) accf = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, accf, 0, 0, 0);
+          else ch[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, ch[q], 0, 0, 0);
+        }
+      }
+      if (ACC_MODE == 2) {
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+#pragma unroll
+          for (int v = 0; v < 4; v++) acc0[v] += (double)ch[q][v];
+      }
     }
     wg_barrier<LDS_ONLY>();
   }
-  // D[i][j]: i = 4*(lane/16) + v, j = lane%16
-  float* R = stage;
+  double* R = (double*)stage;
 #pragma unroll
-  for (int v = 0; v < 4; v++) R[wv * 256 + (4 * kq + v) * 16 + m] = acc[v];
-  if (lane == 0) R[(BA_BLOCK / 64) * 256 + wv] = (float)__popcll(onmask);
+  for (int v = 0; v < 4; v++) {
+    if (ACC_MODE == 1) R[wv * 256 + (kq + 4 * v) * 16 + m] = acc0[v] + acc1[v];
+    else R[wv * 256 + (4 * kq + v) * 16 + m] = ACC_MODE == 0 ? (double)accf[v] : acc0[v];
+  }
+  if (lane == 0) R[(BA_BLOCK / 64) * 256 + wv] = (double)__popcll(onmask);
   wg_barrier<LDS_ONLY>();
   if (threadIdx.x < 92) {
     const int t = threadIdx.x;
@@ -703,7 +751,7 @@ __device__ __forceinline__ void top_emit(const BaDev& B, const float* x, const f
     else if (t < 88) off = 10 * 16 + 13 + (t - 85);
     else if (t < 91) off = 11 * 16 + 13 + (t - 88);
     else off = (BA_BLOCK / 64) * 256;   // count slots follow the tiles
-    float s = R[off];
+    double s = R[off];
 #pragma unroll
     for (int w = 1; w < BA_BLOCK / 64; w++) s += R[off + (t < 91 ? w * 256 : w)];
     B.top_part[(size_t)blockIdx.x * 92 + t] = s;
@@ -948,14 +996,14 @@ __device__ __forceinline__ void fold_top_body(const BaDev& B, int pair, int whic
   const int cb = B.pair_chunk_beg[pair], ce = B.pair_chunk_beg[pair + 1];
   float* out = B.accum + (which ? acc_off_topL(B.nf) : acc_off_topA(B.nf)) + (size_t)pair * 91;
   if (tid < 91) {
-    float s = 0;
+    double s = 0;
     for (int ck = cb; ck < ce; ck++) s += B.top_part[(size_t)ck * 92 + tid];
-    out[tid] = s;
+    out[tid] = (float)s;
   }
   if (pair == 0 && tid == 127) {
-    float s = 0;
+    double s = 0;
     for (int ck = 0; ck < B.nchunks; ck++) s += B.top_part[(size_t)ck * 92 + 91];
-    B.accum[acc_off_nres(B.nf) + which] = s;
+    B.accum[acc_off_nres(B.nf) + which] = (float)s;
   }
 }
 __device__ __forceinline__ void zero_topL_body(const BaDev& B, int pair, int tid) {
@@ -1004,7 +1052,7 @@ constexpr int SCH_WAVE = 3 * SCH_REC + 16 * 8;        // two JpJdF buffers (doub
 // windows is 2 048 waves on 3 072 slots — one round — where 2 048 workgroups on 768 slots need three: 116 -> see DESIGN.md §4.  A single
 // window keeps the workgroup per host (a quarter of the latency).
 template <bool PLAIN, bool WPH>
-__global__ __launch_bounds__(BA_BLOCK, 3) void k_ba_sc_host(const BaDev* __restrict__ wins, const uint8_t* __restrict__ pflag, int shiftPriorToZero, int margMode, int clearL) {
+__global__ __launch_bounds__(BA_BLOCK, 2) void k_ba_sc_host(const BaDev* __restrict__ wins, const uint8_t* __restrict__ pflag, int shiftPriorToZero, int margMode, int clearL) {
   constexpr int NW = BA_BLOCK / 64;
   const BaDev& B = wins[blockIdx.y];
   if (ba_finished(B)) return;
@@ -1025,16 +1073,20 @@ __global__ __launch_bounds__(BA_BLOCK, 3) void k_ba_sc_host(const BaDev* __restr
 #endif
   SCS();
   constexpr int SC_NT = 10;                                  // tile t of pair (a <= b) of the 4 x 4 tile grid: sc_ut(a, b)
-  constexpr int SC_NEED = 2 * SC_NT * 256;                    // the tree's two tile buffers
+  constexpr int SC_NEED = 2 * 2 * SC_NT * 256;                // the tree's two tile buffers (f64)
   constexpr int SC_LDS = NW * SCH_WAVE > SC_NEED ? NW * SCH_WAVE : SC_NEED;
   __shared__ __align__(16) float stage_all[SC_LDS];
   float* const bufA = stage_all + wv * SCH_WAVE;             // [2][SCH_REC]
   float* const bufT = bufA + 2 * SCH_REC;
   float (*pt)[8] = reinterpret_cast<float (*)[8]>(bufT + SCH_REC);
   const int pb = B.host_pt_beg[h], pe = B.host_pt_beg[h + 1];     // (in the descriptor itself: no dependent round trip before the first DMA)
-  te_f4 acc[SC_NT];
+  // the sums over the points are carried in f64 like the top sums (top_emit, ACC_MODE): a group's 16 points are one short fp32 MFMA chain
+  // per tile, the groups' tiles are added in f64 (mode 1: f64 MFMAs on the float operands converted exactly, (w z_a) z_b with the
+  // product w z_a exact); ONE rounding to float when the bins are written
+  te_d4 acc[SC_NT];
+  te_f4 grp[SC_NT];                              // mode 2: the tiles of one group; mode 0: the running float sums
 #pragma unroll
-  for (int t = 0; t < SC_NT; t++) acc[t] = (te_f4){0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < SC_NT; t++) { acc[t] = (te_d4){0.0, 0.0, 0.0, 0.0}; grp[t] = (te_f4){0.f, 0.f, 0.f, 0.f}; }
   auto sc_ut = [](int a, int b) { return a * 4 - (a * (a - 1)) / 2 + (b - a); };   // index of the upper tile (a <= b): 0..9
   const int ci = lane & 15, kq = lane >> 4;
   const int tsub = ci >> 3, asub = ci & 7;
@@ -1218,15 +1270,39 @@ __global__ __launch_bounds__(BA_BLOCK, 3) void k_ba_sc_host(const BaDev* __restr
       for (int u = 0; u < 4; u++)
 #pragma unroll
         for (int tt = 0; tt < 4; tt++) zz[u][tt] = oks[u][tt] ? zz[u][tt] : 0.f;
+      if (ACC_MODE == 1) {
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
-        float za[4];
+        for (int u = 0; u < 4; u++) {
+          double za[4], zd[4];
 #pragma unroll
-        for (int tt = 0; tt < 4; tt++) za[tt] = hx[u] * zz[u][tt];
+          for (int tt = 0; tt < 4; tt++) { zd[tt] = (double)zz[u][tt]; za[tt] = (double)hx[u] * zd[tt]; }
 #pragma unroll
-        for (int a = 0; a < 4; a++) {
+          for (int a = 0; a < 4; a++) {
 #pragma unroll
-          for (int b = a; b < 4; b++) acc[sc_ut(a, b)] = __builtin_amdgcn_mfma_f32_16x16x4f32(za[a], zz[u][b], acc[sc_ut(a, b)], 0, 0, 0);
+            for (int b = a; b < 4; b++) acc[sc_ut(a, b)] = __builtin_amdgcn_mfma_f64_16x16x4f64(za[a], zd[b], acc[sc_ut(a, b)], 0, 0, 0);
+          }
+        }
+      } else {
+        if (ACC_MODE == 2) {
+#pragma unroll
+          for (int t = 0; t < SC_NT; t++) grp[t] = (te_f4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          float za[4];
+#pragma unroll
+          for (int tt = 0; tt < 4; tt++) za[tt] = hx[u] * zz[u][tt];
+#pragma unroll
+          for (int a = 0; a < 4; a++) {
+#pragma unroll
+            for (int b = a; b < 4; b++) grp[sc_ut(a, b)] = __builtin_amdgcn_mfma_f32_16x16x4f32(za[a], zz[u][b], grp[sc_ut(a, b)], 0, 0, 0);
+          }
+        }
+        if (ACC_MODE == 2) {
+#pragma unroll
+          for (int t = 0; t < SC_NT; t++)
+#pragma unroll
+            for (int v = 0; v < 4; v++) acc[t][v] += (double)grp[t][v];
         }
       }
     }
@@ -1237,11 +1313,18 @@ __global__ __launch_bounds__(BA_BLOCK, 3) void k_ba_sc_host(const BaDev* __restr
   }
   SCS();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  // ---- the host's bins from ONE wave's accumulators (WPH: this wave's; otherwise wave 0's after the tree), straight from the registers:
-  // acc[t][v] of lane (kq, ci) is D[16 a + 4 kq + v][16 b + ci] of tile (a, b).  Every (t1, t2) block of 256 bytes is covered by the four
-  // stores of its tile; the blocks below the diagonal are float4s of the mirrored tile; a tile ON the diagonal is mirrored through 1 KB of
-  // LDS first: D(r, c) and D(c, r) differ in the last bit ((w z_r) z_c against (w z_c) z_r), and the stitch relies on
-  // accD(h, i, j) == accD(h, j, i)^T exactly.  The blocks of the host's own (absent) target are zeros.
+  if (ACC_MODE == 0) {
+#pragma unroll
+    for (int t = 0; t < SC_NT; t++)
+#pragma unroll
+      for (int v = 0; v < 4; v++) acc[t][v] = (double)grp[t][v];
+  }
+  // ---- the host's bins from ONE wave's accumulators (WPH: this wave's; otherwise wave 0's after the tree), rounded to float: d[v] of lane
+  // (kq, ci) = D[16 a + 4 kq + v][16 b + ci] of tile (a, b) — four consecutive rows per lane (ACC_MODE 1: the f64 MFMA leaves rows
+  // kq + 4 v on a lane; its tiles are turned through 1 KB of LDS into that layout first).  Every (t1, t2) block of 256 bytes is covered by
+  // the four stores of its tile; the blocks below the diagonal are float4s of the mirrored tile; a tile ON the diagonal takes its lower
+  // triangle from the mirror image too: D(r, c) and D(c, r) differ in the last bit ((w z_r) z_c against (w z_c) z_r), and the stitch relies
+  // on accD(h, i, j) == accD(h, j, i)^T exactly.  The blocks of the host's own (absent) target are zeros.
   auto store_bins = [&](float* T /* 16 x 17 floats of LDS of this wave */) {
     const int nf2 = nf * nf;
     float* accD = B.accum + acc_off_D(nf);
@@ -1254,14 +1337,25 @@ __global__ __launch_bounds__(BA_BLOCK, 3) void k_ba_sc_host(const BaDev* __restr
 #pragma unroll
       for (int b = a; b < 4; b++) {
         const int t2p = 2 * b + (ci >> 3), t2 = t2p + (t2p >= h ? 1 : 0);
-        te_f4 d = acc[sc_ut(a, b)];
-        if (a == b) {
-          __builtin_amdgcn_wave_barrier();
+        te_f4 d;
+        {
+          const te_d4 dd = acc[sc_ut(a, b)];
 #pragma unroll
-          for (int v = 0; v < 4; v++) T[(4 * kq + v) * 17 + ci] = d[v];
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          for (int v = 0; v < 4; v++) d[v] = (float)dd[v];
+          if (ACC_MODE == 1 || a == b) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-          for (int v = 0; v < 4; v++) { const float m = T[ci * 17 + 4 * kq + v]; d[v] = (4 * kq + v > ci) ? m : d[v]; }
+            for (int v = 0; v < 4; v++) T[(ACC_MODE == 1 ? kq + 4 * v : 4 * kq + v) * 17 + ci] = d[v];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (ACC_MODE == 1) {
+#pragma unroll
+              for (int v = 0; v < 4; v++) d[v] = T[(4 * kq + v) * 17 + ci];
+            }
+            if (a == b) {
+#pragma unroll
+              for (int v = 0; v < 4; v++) { const float m = T[ci * 17 + 4 * kq + v]; d[v] = (4 * kq + v > ci) ? m : d[v]; }
+            }
+          }
         }
         if (t1p < 7 && t1 < nf) {
           if (t2p < 7) {
@@ -1313,14 +1407,14 @@ __global__ __launch_bounds__(BA_BLOCK, 3) void k_ba_sc_host(const BaDev* __restr
   }
   __syncthreads();                            // the tiles lie over the waves' stages
   // ---- fixed-order tree over the four waves: (3 -> 1, 2 -> 0), then (1 -> 0); wave 0 writes the bins
-  float (*tiles)[SC_NT * 256] = reinterpret_cast<float (*)[SC_NT * 256]>(stage_all);
-  auto put = [&](float* dst) {
+  double (*tiles)[SC_NT * 256] = reinterpret_cast<double (*)[SC_NT * 256]>(stage_all);
+  auto put = [&](double* dst) {
 #pragma unroll
     for (int t = 0; t < SC_NT; t++)
 #pragma unroll
       for (int v = 0; v < 4; v++) dst[(t * 4 + v) * 64 + lane] = acc[t][v];
   };
-  auto add = [&](const float* src) {
+  auto add = [&](const double* src) {
 #pragma unroll
     for (int t = 0; t < SC_NT; t++)
 #pragma unroll
@@ -1339,7 +1433,7 @@ __global__ __launch_bounds__(BA_BLOCK, 3) void k_ba_sc_host(const BaDev* __restr
     for (int t = 0; t < SC_NT; t++)
 #pragma unroll
       for (int v = 0; v < 4; v++) acc[t][v] += tiles[1][(t * 4 + v) * 64 + lane];
-    store_bins(tiles[0]);
+    store_bins((float*)tiles[0]);
   }
 #ifdef SDSO_SC_STAMPS
   if (wv == 0) {

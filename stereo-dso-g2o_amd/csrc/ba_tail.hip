@@ -144,28 +144,28 @@ __global__ __launch_bounds__(TAIL_NT) void k_ba_tail(const BaDev* __restrict__ w
     __syncthreads();
     constexpr int FT = 12;                                   // 64 pairs x 92 sums over 512 threads
     for (int e0 = tid; e0 < nf2 * 92; e0 += FT * TAIL_NT) {
-      float first[FT];
+      double first[FT];                                      // (top_part is f64: a pair's chunks are added in f64, rounded to float once)
       int cbv[FT], cev[FT];
 #pragma unroll
       for (int u = 0; u < FT; u++) {
         const int e = e0 + u * TAIL_NT;
-        first[u] = 0.f; cbv[u] = 0; cev[u] = 0;
+        first[u] = 0.0; cbv[u] = 0; cev[u] = 0;
         if (e < nf2 * 92) {
           const int pair = e / 92, k = e - pair * 92;
           if (fold) {
             cbv[u] = pcb[pair]; cev[u] = pcb[pair + 1];
             if (cbv[u] < cev[u]) first[u] = B.top_part[(size_t)cbv[u] * 92 + k];
-          } else if (k < 91) first[u] = accum[acc_off_topA(nf) + (size_t)pair * 91 + k];
+          } else if (k < 91) first[u] = (double)accum[acc_off_topA(nf) + (size_t)pair * 91 + k];
         }
       }
 #pragma unroll
       for (int u = 0; u < FT; u++) {
         const int e = e0 + u * TAIL_NT;
         if (e < nf2 * 92) {
-          float s = first[u];
+          double s = first[u];
           const int k = e % 92;
           for (int ck = cbv[u] + 1; ck < cev[u]; ck++) s += B.top_part[(size_t)ck * 92 + k];
-          accA[e] = s;
+          accA[e] = (float)s;
         }
       }
     }

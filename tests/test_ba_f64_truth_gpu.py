@@ -3,12 +3,14 @@ double — the float summation order of the CPU path and of the GPU path both di
 
 The float oracle the other BA tests compare with is itself one sample of float-accumulation noise; against it the bars are
 3e-5 (accumulators) / 1e-4 (stitched H) / 2e-4 (x).  Against the truth they can be stated as what they are:
-  * packed accumulators: device max relative error <= 3e-6 per bin block, and its rms no worse than 2x the float CPU path's
-    (measured on MI355X: device 1.3e-6 max / 1e-8..1e-7 rms, CPU float 1.8e-6 max / 1.2e-8..1.7e-7 rms — the MFMA block
-    reductions are tree sums, the CPU adds sequentially);
-  * stitched H (whitened): <= 1e-6 (device 1.5e-7, CPU float 2.8e-7);
-  * x of one GN iteration (whitened by the truth system, relative to its largest step): <= 6e-5.  Device 0.6..2.5e-5, CPU float
-    0.3..3.4e-5: neither path is consistently closer — the system is near-singular along the scale gauge and amplifies either noise;
+  * packed accumulators: device max relative error <= 3e-7 per bin block and its rms below the float CPU path's (round 6: the device
+    carries these sums in f64 on the matrix cores and rounds ONCE to the packed block's floats — measured on MI355X, tests/diag/
+    acc_errors.py -> profiles/r06_acc_errors.txt: device 1.4e-8..2.3e-7 max / 3e-9..6e-8 rms, CPU float 5e-8..1.8e-6 max / 1.2e-8..1.8e-7 rms;
+    rounds 1-5 with fp32 MFMA chains: 1.3e-6 max);
+  * stitched H (whitened): <= 1e-7 (device 2.4e-8..3.8e-8, CPU float 1.5e-7..2.8e-7);
+  * x of one GN iteration (whitened by the truth system, relative to its largest step): device <= 1e-5 (measured 0.3..5.1e-6: what the
+    one float rounding of the packed block leaves), CPU float <= 6e-5 (1.2e-6..3.4e-5 — the system is near-singular along the scale
+    gauge and amplifies the float sums' noise);
   * states / idepths after the whole GN loop: <= 1e-4 / 5e-5 from the truth loop with the same iteration count (device <= 4.9e-5 /
     2.4e-5, CPU float <= 4.8e-5 / 1.1e-5; the idepth maximum sits on single weakly observed points)."""
 import ctypes as C
@@ -100,18 +102,18 @@ def test_one_iteration_against_f64_truth(gpu_ctx, oracle, which, path):
         ec = (acc32[o0:o0 + cnt * w].reshape(-1, w) - T) / m
         live = np.abs(T).max(axis=1) > 0
         if live.any():
-            assert np.abs(eg[live]).max() <= 3e-6, (name, np.abs(eg[live]).max())
+            assert np.abs(eg[live]).max() <= 3e-7, (name, np.abs(eg[live]).max())
             rg, rc = np.sqrt((eg[live] ** 2).mean()), np.sqrt((ec[live] ** 2).mean())
-            assert rg <= 2.0 * rc + 2e-8, (name, rg, rc)                   # the device sums are no noisier than the CPU float sums
+            assert rg <= rc, (name, rg, rc)                                # f64 sums rounded once: closer than the CPU float sums, section by section
         assert not np.abs(ag[o0:o0 + cnt * w].reshape(-1, w)[~live]).any()  # bins empty in the truth are empty on the device
         o0 += cnt * w
     assert np.array_equal(ag[o0:o0 + 2].astype(np.float64), acc64[o0:o0 + 2])      # residual counts
     d = np.sqrt(np.abs(np.diag(H64))) + 1e-30
     sc = max(1.0, np.abs(x64 * d).max())
-    assert np.abs((Hg - H64) / np.outer(d, d)).max() <= 1e-6
+    assert np.abs((Hg - H64) / np.outer(d, d)).max() <= 1e-7
     eg, ec = np.abs((xg - x64) * d).max() / sc, np.abs((x32 - x64) * d).max() / sc
-    assert eg <= 6e-5, (eg, ec)
-    assert ec <= 6e-5, (eg, ec)                                             # the same bar holds for the CPU float path: it is the noise floor, not slack
+    assert eg <= 1e-5, (eg, ec)
+    assert ec <= 6e-5, (eg, ec)                                             # the CPU float path: its summation order's noise, amplified by the gauge
     assert np.abs(sg - st64).max() <= 2e-4 * max(np.abs(st64).max(), 1e-6)
 
 
@@ -192,10 +194,16 @@ def test_gn_loop_against_f64_truth(gpu_ctx, oracle, which):
 
 def test_device_noise_is_the_cpu_float_noise(gpu_ctx, oracle):
     """The statement about the kernels: over 18 windows (4 .. 8 keyframes, two image sizes, two of them with points initialised 30 % off; the
-    first 18 of tests/diag/truth_spread.py's 24 — the suite has to fit the GPU box's time limit, the diagnostic runs them all)
-    the device's distance from the f64-accumulator truth after the 6-iteration loop has the distribution of the CPU float path's distance —
-    the reference's own arithmetic with its own summation order.  Measured on MI355X (profiles/r04_truth_spread.txt): median 2.27e-5
-    against 2.38e-5, mean 4.1e-5 against 3.2e-5, maximum 1.9e-4 against 1.1e-4; SDSO_BA_TAIL=0 gives the same numbers to 1e-9."""
+    first 18 of tests/diag/truth_spread.py's 24 — the suite has to fit the GPU box's time limit, the diagnostic runs them all) the device is
+    NO FARTHER from the f64-accumulator truth than the CPU float path — the reference's own arithmetic with its own summation order.
+
+    Rounds 1-5 summed in fp32 MFMA chains and the two float paths scattered around the truth alike (profiles/r05_truth_updates.txt: first
+    update 1.13e-5 / 1.31e-5 median, but 6.8e-5 / 3.1e-5 maximum: the round-5 verdict's asymmetry).  From round 6 the cross-residual and
+    cross-point sums run in f64 on the matrix cores (csrc/ba_kernels.hip ACC_MODE 1) and what is left is the solve's own floor.  Measured on
+    MI355X over the 24 windows (profiles/r06_truth_updates.txt, profiles/r06_acc_modes.txt): first update median 1.39e-6 against the CPU's
+    1.31e-5, maximum 2.39e-5 against 3.09e-5; device farther than the CPU + 5e-6 in 3 of 141 updates, the CPU farther than the device + 5e-6
+    in 30; final states median 7.5e-6 against 2.4e-5, device worse on 3 windows of 24; the two maxima (1.17e-4 / 1.12e-4) are one window
+    (w06_noisy) whose distance is residuals flipping on their outlier threshold, the same on both paths."""
     import os
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "diag"))
@@ -209,23 +217,20 @@ def test_device_noise_is_the_cpu_float_noise(gpu_ctx, oracle):
         upd.append((name, tr["dev"], tr["cpu"]))
     # The pose UPDATE of every Gauss-Newton iteration against the truth's, in the units the pose moves in (x * SCALE, translation and
     # rotation entries of every frame).  Iteration 0 starts from the same state on all three paths: there the statement is about the
-    # accumulation and the solve alone.  The round-4 verdict asked for `|x_dev - x_f64| <= |x_cpu32 - x_f64| + 5e-6` window by window,
-    # iteration by iteration; measured over 24 windows x <= 6 iterations (profiles/r05_truth_updates.txt) that bar fails in 17 of 141
-    # cases — and the mirrored bar, the CPU float path no farther than the device + 5e-6, fails in 20: the two float paths scatter
-    # around the truth the same way (medians 1.10e-6 / 0.96e-6; first update 1.13e-5 / 1.31e-5, device farther in 13 of 24), one
-    # window is one sample.  profiles/r05_x_noise_blocks.txt traces a window's excess to single sections of the packed block (the b
-    # columns: accEB, the r column of topA) — sums with cancellation, whose float error is the same on both paths in rms
-    # (test_one_iteration_against_f64_truth) and lands on x with either sign.  So the statement is about the DISTRIBUTION, with the
-    # cases that break the per-window bar named in the message:
+    # accumulation and the solve alone.
     us = truth_spread.summarize_updates(upd)
     bad = [(name, it, d, c) for name, dv, cv in upd for it, (d, c) in enumerate(zip(dv, cv)) if d > c + 5e-6]
     msg = "%s; device farther than the CPU float path + 5e-6 (window, iteration, device, cpu): %s" % (us, bad)
-    assert us["dev_median"] <= 1.5 * us["cpu_median"] + 1e-6, msg
-    assert us["dev_farther_by_5e6"] <= us["cpu_farther_by_5e6"] + max(3, us["n"] // 10), msg       # neither path is systematically closer
-    assert us["first_dev_median"] <= 1.5 * us["first_cpu_median"] + 5e-6 and us["first_dev_max"] <= 1e-4, msg
-    assert us["dev_max"] <= 2e-4 and us["cpu_max"] <= 2e-4, msg
+    # the round-5 verdict's bars, as stated there
+    assert us["first_dev_max"] <= us["first_cpu_max"] + 5e-6, msg
+    assert us["first_dev_median"] <= 0.5 * us["first_cpu_median"], msg                        # measured 0.11x
+    first_within = sum(1 for _, dv, _ in upd if dv[0] <= 1e-5)
+    assert first_within >= len(upd) - 2, (first_within, msg)                                  # north_star's 1e-5, against the truth, on iteration 0
+    assert us["dev_median"] <= us["cpu_median"] + 2e-7, msg
+    assert us["dev_farther_by_5e6"] <= max(4, us["n"] // 20) and us["dev_farther_by_5e6"] <= us["cpu_farther_by_5e6"], msg
+    assert us["dev_max"] <= us["cpu_max"] + 1e-5 and us["cpu_max"] <= 2e-4, msg
     sm = truth_spread.summarize(rows)
-    assert sm["dev_median"] <= 1.5 * sm["cpu_median"] + 5e-6, sm
-    assert sm["dev_mean"] <= 2.0 * sm["cpu_mean"], sm
-    assert sm["dev_max"] <= 3e-4 and sm["cpu_max"] <= 3e-4, sm              # the same absolute bar for both
-    assert 4 <= sm["dev_worse"] <= 14, sm                                   # neither path is systematically closer (measured: 8 of 18)
+    assert sm["dev_median"] <= sm["cpu_median"], sm
+    assert sm["dev_mean"] <= sm["cpu_mean"], sm
+    assert sm["dev_max"] <= sm["cpu_max"] + 1e-5 and sm["cpu_max"] <= 3e-4, sm              # (both maxima: the threshold flips of one noisy window)
+    assert sm["dev_worse"] <= len(rows) // 3, sm                                            # measured: 3 of 18

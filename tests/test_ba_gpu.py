@@ -377,13 +377,17 @@ def test_pose_updates_of_every_gn_iteration_c3(gpu_ctx, oracle, win_c3):
     Gauss-Newton iteration: the loop of FullSystem::optimize (FullSystemOptimize.cpp:871-1041) runs on the device one iteration at a time
     (sdso_ba_batch_optimize_begin / accumulate / solve_step on a one-window batch: the kernels of the resident loop) and on the oracle
     (orc_ba_get_x_trace: lastX of every solveSystemF), each along its OWN trajectory from the same uploaded state.  For every iteration the
-    update of every frame is compared in the units the pose moves in (x * SCALE).  FIXED bars: translation and rotation entries
-    |dx| <= 1e-5 from the second iteration on (measured on MI355X: 4.5e-6, 3.2e-7, 6.1e-7) and <= 2e-5 on the first (measured 1.39e-5:
-    that update is the large one — the window starts 1e-3 off — and the float accumulators of BOTH paths carry their noise into it;
-    tests/test_ba_f64_truth_gpu.py holds the device's first update within 1e-5 of the f64-accumulator truth and no farther from it than
-    the CPU float path's + 5e-6); the affine a (scaled, dimensionless) <= 1e-5, b (scaled: intensity levels of 0..255) <= 1e-3.  After
-    the loop every frame's pose state is within a FIXED 2e-5 of the oracle's (measured 8.2e-6), next to the spread-relative bar of
-    test_optimize_full_gn_loop.  A failure names the iteration and the residuals whose final state differs."""
+    update of every frame is compared in the units the pose moves in (x * SCALE).  FIXED bars:
+      * against the reference arithmetic with its sums carried in f64 (orc_set_acc64: the float summation ORDER of the CPU path out of the
+        reference value): translation and rotation entries |dx| <= 1e-5 on EVERY iteration, the first included (measured on MI355X,
+        round 6: 1.5e-7 on the first).  The device carries its cross-residual / cross-point sums in f64 on the matrix cores (ba_kernels.hip,
+        ACC_MODE 1), so this is the comparison in which only the reference's per-residual arithmetic is left;
+      * against the reference's float path as it is (4-byte accumulators, sequential): <= 1e-5 from the second iteration on and <= 2e-5 on
+        the first — that distance is the CPU float path's OWN distance from the order-independent sums (1.2e-5 on this window, median
+        1.3e-5 over 24 windows against the device's 1.4e-6: profiles/r06_truth_updates.txt), asserted below to be exactly that;
+      * the affine a (scaled, dimensionless) <= 1e-5, b (scaled: intensity levels of 0..255) <= 1e-3.  After the loop every frame's pose
+        state is within a FIXED 2e-5 of the float oracle's, next to the spread-relative bar of test_optimize_full_gn_loop.
+    A failure names the iteration and the residuals whose final state differs."""
     ctx, win = gpu_ctx, win_c3
     W, keep, h = _both(ctx, oracle, win, wid=13)
     nf, npts, nr, n = win["nf"], win["np"], win["nr"], 8 * win["nf"] + 4
@@ -393,6 +397,17 @@ def test_pose_updates_of_every_gn_iteration_c3(gpu_ctx, oracle, win_c3):
     its_o = oracle.orc_ba_get_x_trace(h, abi.dp(xo), 8)
     oracle.orc_ba_destroy(h)
     assert its_o == oo.iterations and its_o >= 2
+    # the same loop with every accumulator sum of the restatement in double
+    oracle.orc_set_acc64(1)
+    try:
+        h64 = oracle.orc_ba_create(C.byref(W))
+        s64, i64, o64 = np.zeros((nf, 10)), np.zeros(npts, np.float32), abi.BAOptResult()
+        oracle.orc_ba_optimize(h64, 6, abi.dp(s64), abi.fp(i64), None, C.byref(o64))
+        x64 = np.zeros((8, n))
+        its_64 = oracle.orc_ba_get_x_trace(h64, abi.dp(x64), 8)
+        oracle.orc_ba_destroy(h64)
+    finally:
+        oracle.orc_set_acc64(0)
     ids = np.array([13], np.int32)
     ctx.check(ctx.L.sdso_ba_batch_create(ctx.h, 1, abi.ip(ids)))
     ctx.check(ctx.L.sdso_ba_batch_optimize_begin(ctx.h, 1))
@@ -412,13 +427,24 @@ def test_pose_updates_of_every_gn_iteration_c3(gpu_ctx, oracle, win_c3):
         d = np.abs((xg[it, 4:] - xo[it, 4:]).reshape(nf, 8) * _STATE_SCALE)
         report.append((it, float(d[:, :6].max()), float(d[:, 6].max()), float(d[:, 7].max())))
     msg = "per iteration (it, pose, a, b): %s; residuals whose final state differs: %s" % (report, flipped.tolist())
+    truth, cpu_own = [], []
+    for it in range(min(its_o, its_64)):
+        truth.append(float(np.abs((xg[it, 4:] - x64[it, 4:]).reshape(nf, 8) * _STATE_SCALE)[:, :6].max()))
+        cpu_own.append(float(np.abs((xo[it, 4:] - x64[it, 4:]).reshape(nf, 8) * _STATE_SCALE)[:, :6].max()))
+    msg += "; pose update vs the f64-accumulator truth per iteration: device %s, CPU float path %s" % (truth, cpu_own)
+    assert og[0].iterations == o64.iterations, msg
+    for it, dpose in enumerate(truth):
+        assert dpose <= 1e-5, msg                      # north_star's bar, every iteration, against the order-independent reference value
     for it, dpose, da, db in report:
-        assert dpose <= (2e-5 if it == 0 else 1e-5) and da <= 1e-5 and db <= 1e-3, msg
+        # against the float oracle the first update's distance is the CPU path's own summation noise: the device is within 1e-5 of the truth
+        # (above), so |device - cpu| <= |cpu - truth| + 1e-5, and it stays under the 2e-5 of rounds 4-5
+        assert dpose <= (min(2e-5, cpu_own[0] + 1e-5) if it == 0 else 1e-5) and da <= 1e-5 and db <= 1e-3, msg
     dstate = np.abs(sg - so)[:, :8] * _STATE_SCALE
     assert dstate[:, :6].max() <= 2e-5, (float(dstate[:, :6].max()), msg)
     assert dstate[:, 6].max() <= 2e-5 and dstate[:, 7].max() <= 2e-3, (dstate[:, 6:].max(axis=0).tolist(), msg)
     assert len(flipped) <= max(2, nr // 2000)
     ctx.check(ctx.L.sdso_ba_release_window(ctx.h, 13))
+    print("pose updates at configs[2]:", msg)
 
 
 @pytest.mark.parametrize("noise", [dict(), dict(idepth_noise=0.3, state_noise=1e-2)])
