@@ -202,6 +202,8 @@ int orc_ba_optimize(orc_ba* h, int mnumOptIts, double* state_out, float* idepth_
 int orc_ba_get_post_state(orc_ba* h, orc_ba_post_state_t* out);
 /* lastX of every GN iteration of the latest orc_ba_optimize (iteration-major, 8nf+4 doubles each); returns the number of iterations */
 int orc_ba_get_x_trace(orc_ba* h, double* x, int cap_iterations);
+/* the loop's stepsize of every iteration (SOLVER_STEPMOMENTUM, FullSystemOptimize.cpp:936-948); returns the number of iterations */
+int orc_ba_get_step_trace(orc_ba* h, float* stepsize, int cap_iterations);
 /* calcLEnergyF_MT / calcMEnergyF (EnergyFunctional.cpp:420-442, :344-351) and what setDeltaF leaves behind (:173-207) */
 int orc_ba_calc_energies(orc_ba* h, double* EL, double* EM);
 int orc_ba_get_deltas(orc_ba* h, float* cDeltaF, double* frame_delta, double* frame_delta_prior, float* point_deltaF);

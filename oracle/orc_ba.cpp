@@ -10,6 +10,7 @@
 //   src/FullSystem/FullSystemOptimize.cpp:52-370, 871-1041, 1087-1147   GN driver, nullspaces
 //   src/FullSystem/FullSystem.cpp:1004-1021, 1633-1644            flagPointsForRemoval core, setPrecalcValues
 #include "orc_api.h"
+#include <limits>
 #include <pthread.h>
 #include <sched.h>
 #include "orc_math.h"
@@ -144,7 +145,7 @@ struct RawJ {  // RawResidualJacobian.h:32-65, flattened in the ABI's field orde
 static_assert(sizeof(RawJ) == 74 * 4, "RawJ must be 74 floats");
 
 struct Calib {
-  double value_zero[4], value_scaled[4], value[4], step[4], value_backup[4], value_minus_value_zero[4];
+  double value_zero[4], value_scaled[4], value[4], step[4], value_backup[4], value_minus_value_zero[4], step_backup[4] = {0, 0, 0, 0};
   float value_scaledf[4], value_scaledi[4];
   float fxl() const { return value_scaledf[0]; }
   float fyl() const { return value_scaledf[1]; }
@@ -180,7 +181,7 @@ struct Calib {
 
 struct Frame {
   SE3 worldToCam_evalPT;
-  double state_zero[10], state_scaled[10], state[10], step[10], state_backup[10];
+  double state_zero[10], state_scaled[10], state[10], step[10], state_backup[10], step_backup[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   SE3 PRE_worldToCam, PRE_camToWorld;
   float ab_exposure, frameEnergyTH;
   int frameID;
@@ -264,7 +265,7 @@ struct Point {
   float color[8], weights[8];
   int host;
   bool hasDepthPrior;
-  float step, idepth_backup;
+  float step, idepth_backup, step_backup = 0;
   float idepth_hessian, maxRelBaseline;
   int numGoodResiduals;
   int rbeg, rend;
@@ -318,6 +319,7 @@ struct orc_ba {
   ~orc_ba() { delete red; }
   MatX lastHS;
   VecX lastbS, lastX;
+  std::vector<float> stepTrace;  // the loop's stepsize of every iteration (SOLVER_STEPMOMENTUM; 1 otherwise)
   std::vector<VecX> xTrace;   // lastX of every solveSystemF of the latest optimize() (test infrastructure: per-iteration parity of the pose updates)
   std::vector<VecX> lastNullspaces_pose, lastNullspaces_scale;
 
@@ -1162,7 +1164,13 @@ struct orc_ba {
   }
 
   // ---------------------------------------------------------------- GN driver (FullSystemOptimize.cpp)
-  void backupState() {  // :309-351 (non-momentum branch)
+  void backupState(bool backupLastStep) {  // :309-351
+    if (solverMode & SOLVER_MOMENTUM) {    // :311-345: the previous iteration's steps are kept (zeros before the first one)
+      for (int i = 0; i < 4; i++) { HCalib.step_backup[i] = backupLastStep ? HCalib.step[i] : 0.0; HCalib.value_backup[i] = HCalib.value[i]; }
+      for (Frame& f : frames) for (int i = 0; i < 10; i++) { f.step_backup[i] = backupLastStep ? f.step[i] : 0.0; f.state_backup[i] = f.state[i]; }
+      for (Point& p : points) { p.idepth_backup = p.idepth; p.step_backup = backupLastStep ? p.step : 0.f; }
+      return;
+    }
     for (int i = 0; i < 4; i++) HCalib.value_backup[i] = HCalib.value[i];
     for (Frame& f : frames) for (int i = 0; i < 10; i++) f.state_backup[i] = f.state[i];
     for (Point& p : points) p.idepth_backup = p.idepth;
@@ -1174,6 +1182,36 @@ struct orc_ba {
     for (int i = 6; i < 10; i++) pstepfac[i] = stepfacA;
     float sumA = 0, sumB = 0, sumT = 0, sumR = 0, sumID = 0, numID = 0, sumNID = 0;
     double nv[4];
+    if (solverMode & SOLVER_MOMENTUM) {   // :225-251: the whole new step plus half of the previous one (poses and points), no step factors
+      for (int i = 0; i < 4; i++) nv[i] = HCalib.value_backup[i] + HCalib.step[i];
+      HCalib.setValue(nv);
+      for (int fi = 0; fi < nf; fi++) {
+        Frame& fh = frames[fi];
+        double step[10], ns[10];
+        for (int i = 0; i < 10; i++) step[i] = fh.step[i];
+        for (int i = 0; i < 6; i++) step[i] += 0.5f * fh.step_backup[i];
+        for (int i = 0; i < 10; i++) ns[i] = fh.state_backup[i] + step[i];
+        fh.setState(ns);
+        sumA += step[6] * step[6];
+        sumB += step[7] * step[7];
+        sumT += step[0] * step[0] + step[1] * step[1] + step[2] * step[2];
+        sumR += step[3] * step[3] + step[4] * step[4] + step[5] * step[5];
+        for (Point& ph : points) {
+          if (ph.host != fi) continue;
+          const float pstep = ph.step + 0.5f * (ph.step_backup);
+          ph.setIdepth(ph.idepth_backup + pstep);
+          sumID += pstep * pstep;
+          sumNID += fabsf(ph.idepth_backup);
+          numID++;
+          ph.setIdepthZero(ph.idepth_backup + pstep);
+        }
+      }
+      sumA /= nf; sumB /= nf; sumR /= nf; sumT /= nf;
+      sumID /= numID; sumNID /= numID;
+      setPrecalcValues();
+      return sqrtf(sumA) < 0.0005 * setting_thOptIterations && sqrtf(sumB) < 0.00005 * setting_thOptIterations &&
+             sqrtf(sumR) < 0.00005 * setting_thOptIterations && sqrtf(sumT) * sumNID < 0.00005 * setting_thOptIterations;
+    }
     for (int i = 0; i < 4; i++) nv[i] = HCalib.value_backup[i] + stepfacC * HCalib.step[i];
     HCalib.setValue(nv);
     for (int fi = 0; fi < nf; fi++) {
@@ -1226,12 +1264,29 @@ struct orc_ba {
     applyAll();
     double lambda = 1e-1;
     float stepsize = 1;
+    const int nx = 4 + 8 * nf;
+    VecX previousX(nx, std::numeric_limits<double>::quiet_NaN());
+    stepTrace.clear();
     for (int iteration = 0; iteration < mnumOptIts; iteration++) {
       out->iterations++;
-      backupState();
+      backupState(iteration != 0);
       getNullspaces();
       solveSystemF(iteration, lambda);
       xTrace.push_back(lastX);
+      {  // :933-948
+        double dot = 0, n0 = 0, n1 = 0;
+        for (int i = 0; i < nx; i++) { dot += previousX[i] * lastX[i]; n0 += previousX[i] * previousX[i]; n1 += lastX[i] * lastX[i]; }
+        const double incDirChange = (1e-20 + dot) / (1e-20 + std::sqrt(n0) * std::sqrt(n1));
+        previousX = lastX;
+        if (std::isfinite(incDirChange) && (solverMode & SOLVER_STEPMOMENTUM)) {
+          float newStepsize = exp(incDirChange * 1.4);
+          if (incDirChange < 0 && stepsize > 1) stepsize = 1;
+          stepsize = sqrtf(sqrtf(newStepsize * stepsize * stepsize * stepsize));
+          if (stepsize > 2) stepsize = 2;
+          if (stepsize < 0.25) stepsize = 0.25;
+        }
+        stepTrace.push_back(stepsize);
+      }
       bool canbreak = doStepFromBackup(stepsize, stepsize, stepsize, stepsize, stepsize);
       double newEnergy = linearizeAll(false);
       double newEnergyL = calcLEnergy();
@@ -1294,10 +1349,22 @@ struct orc_ba {
     stitchSC(Msc, Mbsc);
     resInM += nresA;
     int n = 4 + nf * 8;
+    MatX H(n, n); VecX b(n);
     for (int i = 0; i < n; i++) {
-      for (int j = 0; j < n; j++) HM(i, j) += setting_margWeightFac * (M(i, j) - Msc(i, j));
-      bM[i] += setting_margWeightFac * (Mb[i] - Mbsc[i]);
+      for (int j = 0; j < n; j++) H(i, j) = M(i, j) - Msc(i, j);
+      b[i] = Mb[i] - Mbsc[i];
     }
+    if (solverMode & (SOLVER_ORTHOGONALIZE_POINTMARG | SOLVER_ORTHOGONALIZE_FULL)) getNullspaces();   // FullSystem.cpp:1453-1456, right before marginalizePointsF
+    if (solverMode & SOLVER_ORTHOGONALIZE_POINTMARG) {   // EnergyFunctional.cpp:711-723
+      bool haveFirstFrame = false;
+      for (Frame& f : frames) if (f.frameID == 0) haveFirstFrame = true;
+      if (!haveFirstFrame) orthogonalize(&b, &H);
+    }
+    for (int i = 0; i < n; i++) {
+      for (int j = 0; j < n; j++) HM(i, j) += setting_margWeightFac * H(i, j);
+      bM[i] += setting_margWeightFac * b[i];
+    }
+    if (solverMode & SOLVER_ORTHOGONALIZE_FULL) orthogonalize(&bM, &HM);   // :730-731
   }
 };
 
@@ -1511,6 +1578,12 @@ extern "C" int orc_ba_optimize(orc_ba* h, int mnumOptIts, double* state_out, flo
 extern "C" int orc_ba_get_x_trace(orc_ba* h, double* x, int cap_iterations) {
   const int n = 4 + 8 * h->nf, its = (int)h->xTrace.size();
   for (int it = 0; it < its && it < cap_iterations; it++) for (int i = 0; i < n; i++) x[(size_t)it * n + i] = h->xTrace[it][i];
+  return its;
+}
+// the loop's stepsize of every iteration of the latest orc_ba_optimize (FullSystemOptimize.cpp:936-948; 1 without SOLVER_STEPMOMENTUM)
+extern "C" int orc_ba_get_step_trace(orc_ba* h, float* stepsize, int cap_iterations) {
+  const int its = (int)h->stepTrace.size();
+  for (int it = 0; it < its && it < cap_iterations; it++) stepsize[it] = h->stepTrace[it];
   return its;
 }
 extern "C" int orc_ba_get_post_state(orc_ba* h, orc_ba_post_state_t* o) {

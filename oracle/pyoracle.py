@@ -98,6 +98,7 @@ def load(fast=False, path=None):
     L.orc_ba_marginalize_points.argtypes = [vp, c_u8_p, c_double_p, c_double_p]
     L.orc_ba_get_post_state.argtypes = [vp, C.POINTER(BAPostState)]
     L.orc_ba_get_x_trace.argtypes = [vp, C.POINTER(C.c_double), C.c_int]
+    L.orc_ba_get_step_trace.argtypes = [vp, C.POINTER(C.c_float), C.c_int]
     L.orc_ba_calc_energies.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.orc_ba_get_deltas.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_float)]
     L.orc_ba_get_tables.argtypes = [vp, c_float_p, c_double_p, c_double_p, c_float_p]

@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstring>
 #include <numeric>
+#include <limits>
 #include <functional>
 #include <chrono>
 #include <atomic>
@@ -258,9 +259,8 @@ static int upload_window_impl(sdso_ctx* ctx, int win, const sdso_ba_window_t* Wi
   SDSO_REQUIRE(ctx, Win->evalPT && Win->state && Win->state_zero && Win->ab_exposure && Win->frameEnergyTH && Win->frameID && Win->frame_slot, "null frame arrays");
   SDSO_REQUIRE(ctx, np == 0 || (Win->u && Win->v && Win->idepth && Win->idepth_zero && Win->color && Win->weights && Win->host && Win->hasDepthPrior), "null point arrays");
   SDSO_REQUIRE(ctx, nr == 0 || (Win->res_point && Win->res_target && Win->res_state), "null residual arrays");
-  // bits solveSystemF never reads (ORTHOGONALIZE_POINTMARG / _FULL, MOMENTUM) or that only the un-compiled driver uses (STEPMOMENTUM)
-  const int unsupported = SOLVER_ORTHOGONALIZE_POINTMARG | SOLVER_ORTHOGONALIZE_FULL | SOLVER_MOMENTUM | SOLVER_STEPMOMENTUM;
-  SDSO_REQUIRE(ctx, (Win->solverMode & unsupported) == 0, "solverMode bit not supported (ORTHOGONALIZE_POINTMARG / ORTHOGONALIZE_FULL / MOMENTUM / STEPMOMENTUM)");
+  // (every bit of setting_solverMode has its branch: solveSystemF's in launch_solve, STEPMOMENTUM / MOMENTUM in the GN loops, ORTHOGONALIZE_POINTMARG /
+  // _FULL in sdso_ba_marginalize_points)
   const bool timing = getenv("SDSO_BA_UPLOAD_TIMING") != nullptr;   // phase times of the upload on stderr (diagnostic)
   auto t_prev = std::chrono::steady_clock::now();
   auto mark = [&](const char* what) {
@@ -411,7 +411,7 @@ static int upload_window_impl(sdso_ctx* ctx, int win, const sdso_ba_window_t* Wi
   PL(p_geo, float4, np, true); PL(p_color, float, np * 8, true); PL(p_weights, float, np * 8, true); PL(p_host, int, np, true);
   PL(p_prior, float, np, true); PL(p_delta, float, np, true); PL(p_rbeg, int, np + 1, true); PL(p_rcnt, int, np, true); PL(p_rlist, int, nr, true);
   PL(p_order, unsigned, np, true); PL(p_track, float4, np, true); PL(r_isnew, uint8_t, nr, true);
-  PL(p_out, float, (size_t)np * 16, false);
+  PL(p_out, float, (size_t)np * 16, false); PL(d.p_stepbk, float, np, false);
   int* r_point; int* r_orig; uint8_t *r_host, *r_target;
   PL(r_point, int, nr, true); PL(r_orig, int, nr, true); PL(r_host, uint8_t, nr, true); PL(r_target, uint8_t, nr, true);
   PL(d.r_state, uint8_t, nr, true); PL(d.r_newState, uint8_t, nr, false); PL(d.r_lin, uint8_t, nr, false); PL(d.r_act, uint8_t, nr, false); PL(d.r_jsel, uint8_t, nr, false);
@@ -1201,14 +1201,18 @@ extern "C" int sdso_ba_optimize(sdso_ctx* ctx, int win, int mnumOptIts, double* 
     if (rc) return rc;
     launch_apply(ctx, L);
     double lambda = 1e-1;
-    const float stepsize = 1;
-    std::vector<double> x;
+    float stepsize = 1;
+    const bool momentum = (W->solverMode & SOLVER_MOMENTUM) != 0;
+    std::vector<double> x, previousX(W->d.n, std::numeric_limits<double>::quiet_NaN());
     std::vector<float> sums(2 * (W->nblk_pts + 1));
     for (int iteration = 0; iteration < mnumOptIts; iteration++) {
       res.iterations++;
-      // backupState (:309-351)
+      // backupState(iteration != 0) (:309-351); SOLVER_MOMENTUM also keeps the previous steps (the points': k_ba_resub, which looks at the
+      // iteration count of the window's BaOptDev)
       for (int i = 0; i < 4; i++) W->calib.value_backup[i] = W->calib.value[i];
-      for (HostFrame& f : W->frames) for (int i = 0; i < 10; i++) f.state_backup[i] = f.state[i];
+      for (HostFrame& f : W->frames) for (int i = 0; i < 10; i++) { f.step_backup[i] = (momentum && iteration != 0) ? f.step[i] : 0.0; f.state_backup[i] = f.state[i]; }
+      W->h_opt.iterations = iteration;
+      H2D(&W->d_opt->iterations, &W->h_opt.iterations, sizeof(int));
       if (L.max_nblk_pts) hipLaunchKernelGGL(k_ba_points_op, dim3(L.max_nblk_pts, 1), dim3(BA_BLOCK), 0, ctx->stream, L.d_arr, 0, 0.f, (float*)nullptr);
       // solveSystem
       launch_accumulate(ctx, L, nullptr, false);
@@ -1216,19 +1220,34 @@ extern "C" int sdso_ba_optimize(sdso_ctx* ctx, int win, int mnumOptIts, double* 
       if (rc) return rc;
       rc = fetch_x(ctx, W, x);
       if (rc) return rc;
+      {  // incDirChange and the step size (:933-948)
+        double dot = 0, n0 = 0, n1 = 0;
+        for (int i = 0; i < W->d.n; i++) { dot += previousX[i] * x[i]; n0 += previousX[i] * previousX[i]; n1 += x[i] * x[i]; }
+        const double incDirChange = (1e-20 + dot) / (1e-20 + std::sqrt(n0) * std::sqrt(n1));
+        previousX = x;
+        if (std::isfinite(incDirChange) && (W->solverMode & SOLVER_STEPMOMENTUM)) {
+          const float newStepsize = (float)std::exp(incDirChange * 1.4);
+          if (incDirChange < 0 && stepsize > 1) stepsize = 1;
+          stepsize = sqrtf(sqrtf(newStepsize * stepsize * stepsize * stepsize));
+          if (stepsize > 2) stepsize = 2;
+          if (stepsize < 0.25f) stepsize = 0.25f;
+        }
+      }
       // doStepFromBackup (:207-305)
       double nv[4];
-      for (int i = 0; i < 4; i++) nv[i] = W->calib.value_backup[i] + stepsize * W->calib.step[i];
+      for (int i = 0; i < 4; i++) nv[i] = W->calib.value_backup[i] + (momentum ? 1.0f : stepsize) * W->calib.step[i];
       W->calib.setValue(nv);
       float sumA = 0, sumB = 0, sumT = 0, sumR = 0;
       for (HostFrame& fh : W->frames) {
-        double ns[10];
-        for (int i = 0; i < 10; i++) ns[i] = fh.state_backup[i] + (double)stepsize * fh.step[i];
+        double ns[10], st[10];
+        for (int i = 0; i < 10; i++) st[i] = fh.step[i];
+        if (momentum) for (int i = 0; i < 6; i++) st[i] += 0.5f * fh.step_backup[i];     // :231
+        for (int i = 0; i < 10; i++) ns[i] = fh.state_backup[i] + (momentum ? 1.0 : (double)stepsize) * st[i];
         fh.setState(ns);
-        sumA += fh.step[6] * fh.step[6];
-        sumB += fh.step[7] * fh.step[7];
-        sumT += fh.step[0] * fh.step[0] + fh.step[1] * fh.step[1] + fh.step[2] * fh.step[2];
-        sumR += fh.step[3] * fh.step[3] + fh.step[4] * fh.step[4] + fh.step[5] * fh.step[5];
+        sumA += st[6] * st[6];
+        sumB += st[7] * st[7];
+        sumT += st[0] * st[0] + st[1] * st[1] + st[2] * st[2];
+        sumR += st[3] * st[3] + st[4] * st[4] + st[5] * st[5];
       }
       float sumNID = 0, numID = (float)np;
       if (L.max_nblk_pts) {
@@ -1330,6 +1349,10 @@ extern "C" int sdso_ba_marginalize_points(sdso_ctx* ctx, int win, const uint8_t*
   SDSO_HIP(ctx, hipGetLastError());
   // HM += setting_margWeightFac * (M - Msc), bM likewise (:727-728): on the device copy, which is the master — the prior stays resident
   // from here through sdso_ba_marginalize_frame_dev into the next window (sdso_ba_adopt_prior); the host mirror follows on demand
+  if (W->solverMode & (SOLVER_ORTHOGONALIZE_POINTMARG | SOLVER_ORTHOGONALIZE_FULL))     // (:707-731; POINTMARG only when frame 0 has left the window)
+    hipLaunchKernelGGL(k_ba_prior_orth, dim3(1, 1), dim3(256), 0, ctx->stream, L.d_arr, (double)(0.5f * 0.5f),
+                       ((W->solverMode & SOLVER_ORTHOGONALIZE_POINTMARG) && !W->d.have_first_frame) ? 1 : 0, (W->solverMode & SOLVER_ORTHOGONALIZE_FULL) ? 1 : 0);
+  else
   hipLaunchKernelGGL(k_ba_prior_add, dim3(8, 1), dim3(256), 0, ctx->stream, L.d_arr, (double)(0.5f * 0.5f));   // setting_margWeightFac
   SDSO_HIP(ctx, hipGetLastError());
   W->hm_host_valid = false;
@@ -1669,6 +1692,7 @@ struct OptRun {
   bool keep_hs = false;    // every solve also writes lastHS / lastbS (EnergyFunctional.cpp:909-910): sdso_ba_get_post_state hands them out
   bool scatter_local = false;  // this rank's view: the batch asks for the reduce-scatter exchange and its loop can take it
   bool scatter = false;    // ... and every rank agreed (opt_begin)
+  int momentum = 0;        // SOLVER_STEPMOMENTUM / SOLVER_MOMENTUM bits of the windows: k_ba_opt_momentum between solve and step, never the fused step
   OptBufs* B = nullptr;
 };
 
@@ -1679,8 +1703,10 @@ static int opt_begin(sdso_ctx* ctx, OptRun& R, int stop_on_convergence) {
   for (BaWindowDev* W : R.W) {
     SDSO_REQUIRE(ctx, (W->forceAccept != 0) == (R.W[0]->forceAccept != 0), "the windows of a resident loop must share setting_forceAceptStep");
     SDSO_REQUIRE(ctx, (W->solverMode & (SOLVER_SVD | SOLVER_ORTHOGONALIZE_SYSTEM)) == (R.W[0]->solverMode & (SOLVER_SVD | SOLVER_ORTHOGONALIZE_SYSTEM)), "the windows of a resident loop must share the solver branch");
+    SDSO_REQUIRE(ctx, (W->solverMode & (SOLVER_MOMENTUM | SOLVER_STEPMOMENTUM)) == (R.W[0]->solverMode & (SOLVER_MOMENTUM | SOLVER_STEPMOMENTUM)), "the windows of a resident loop must share SOLVER_MOMENTUM / SOLVER_STEPMOMENTUM");
     cap = std::max(cap, W->d.nr - W->newest_first);
   }
+  R.momentum = R.W[0]->solverMode & (SOLVER_MOMENTUM | SOLVER_STEPMOMENTUM);
   R.nranks = comm_nranks(ctx);
   // SDSO_OPT_FORCE_EXCHANGE: take the pack / all-gather path on a 1-rank communicator too (tests: the collectives of a 1-GPU box)
   R.exchange = !R.local_only && (R.nranks > 1 || (comm_present(ctx) && getenv("SDSO_OPT_FORCE_EXCHANGE") != nullptr));
@@ -1690,7 +1716,7 @@ static int opt_begin(sdso_ctx* ctx, OptRun& R, int stop_on_convergence) {
   // shape of the accumulators' exchange: one decision for the whole loop, the same on every rank or an error (never mismatched collectives)
   R.scatter = false;
   if (R.exchange) {
-    const int want = (R.scatter_local && !R.gated && !R.keep_hs && tail_enabled() && !R.L.alt && nwin % R.nranks == 0) ? 1 : 0;
+    const int want = (R.scatter_local && !R.gated && !R.keep_hs && tail_enabled() && !R.L.alt && !R.momentum && nwin % R.nranks == 0) ? 1 : 0;
     int hi = want, lo = -want;
     int rc = comm_max_int(ctx, &hi); if (rc) return rc;
     rc = comm_max_int(ctx, &lo); if (rc) return rc;
@@ -1729,6 +1755,8 @@ static int opt_begin(sdso_ctx* ctx, OptRun& R, int stop_on_convergence) {
     for (int i = 0; i < 4; i++) { O.calib_value[i] = W->calib.value[i]; O.calib_backup[i] = W->calib.value[i]; O.calib_zero[i] = W->calib.value_zero[i]; }
     O.newest_first = W->newest_first;
     O.lambda = 1e-1;
+    O.stepsize = 1;                                                               // FullSystemOptimize.cpp:928
+    for (double& v : O.previousX) v = std::numeric_limits<double>::quiet_NaN();   // :929
     H2D(W->d_opt, &W->h_opt, sizeof(BaOptDev));
   }
   hipLaunchKernelGGL(k_ba_reset_all, dim3(R.L.max_nblk_res, nwin), dim3(BA_BLOCK), 0, ctx->stream, R.L.d_arr);
@@ -1757,7 +1785,8 @@ static int opt_consume(sdso_ctx* ctx, OptRun& R, int last, bool unfused, bool wi
 // after the solve of one iteration: doStepFromBackup for points, frames and calibration, tables, break test
 static int opt_step(sdso_ctx* ctx, OptRun& R) {
   const int nwin = (int)R.W.size();
-  if (R.L.max_nblk_pts) hipLaunchKernelGGL(k_ba_points_op, dim3(R.L.max_nblk_pts, nwin), dim3(BA_BLOCK), 0, ctx->stream, R.L.d_arr, 3, 1.0f, R.B->d_sums, R.sums_stride);
+  if (R.momentum) hipLaunchKernelGGL(k_ba_opt_momentum, dim3(1, nwin), dim3(128), 0, ctx->stream, R.L.d_arr);   // the stepsize / the kept previous step of this iteration
+  if (R.L.max_nblk_pts) hipLaunchKernelGGL(k_ba_points_op, dim3(R.L.max_nblk_pts, nwin), dim3(BA_BLOCK), 0, ctx->stream, R.L.d_arr, 3, R.momentum ? -1.0f : 1.0f, R.B->d_sums, R.sums_stride);
   int rc = opt_consume(ctx, R, 0, false, R.L.max_nblk_pts > 0);
   R.iteration++;
   return rc;
@@ -1809,7 +1838,8 @@ static int opt_gated_iteration(sdso_ctx* ctx, OptRun& R, int it) {
   else if (sm & SOLVER_USE_GN) lambda = 0;
   else flags |= 2;                                             // the loop's own lambda, kept on the device (it depends on the decisions)
   launch_solve(ctx, R.L, lambda, flags);
-  if (R.L.max_nblk_pts) hipLaunchKernelGGL(k_ba_points_op, gp, b, 0, ctx->stream, R.L.d_arr, 1, 1.0f, R.B->d_sums, R.sums_stride, 0);
+  if (R.momentum) hipLaunchKernelGGL(k_ba_opt_momentum, dim3(1, nwin), dim3(128), 0, ctx->stream, R.L.d_arr);
+  if (R.L.max_nblk_pts) hipLaunchKernelGGL(k_ba_points_op, gp, b, 0, ctx->stream, R.L.d_arr, 1, R.momentum ? -1.0f : 1.0f, R.B->d_sums, R.sums_stride, 0);
   if (R.exchange) {                                            // the break-test sums of every rank's points: pack -> all-gather -> step
     const int rc = opt_consume(ctx, R, 2, true, R.L.max_nblk_pts > 0);
     if (rc) return rc;
@@ -1918,7 +1948,7 @@ static bool batch_defers_fold(sdso_ctx* ctx, BaBatch* Bt) { (void)ctx; return ta
 // Sharded windows: tail kernel (stitch, solve, resubstitute, points' step) -> pack -> all-gather -> k_ba_opt_step, as before.
 static std::map<sdso_ctx*, OptRun*> g_optruns;   // the batch loop in flight between sdso_ba_batch_optimize_begin and _end
 static int opt_solve_step(sdso_ctx* ctx, OptRun& R, double lambda, int orth, bool folded) {
-  if (!tail_enabled() || R.L.alt) {
+  if (!tail_enabled() || R.L.alt || R.momentum) {   // (momentum: the stepsize / the kept step come between the solve and the step — opt_step)
     launch_solve(ctx, R.L, lambda, orth, folded);
     SDSO_HIP(ctx, hipGetLastError());
     return opt_step(ctx, R);

@@ -14,10 +14,7 @@ namespace sdso {
 constexpr float kInitialRotPrior = 1e11f, kInitialTransPrior = 1e10f, kInitialAffBPrior = 1e14f, kInitialAffAPrior = 1e14f;
 constexpr float kInitialCalibHessian = 5e9f;
 constexpr double kSolverModeDelta = 0.00001;
-constexpr int SOLVER_SVD_CUT7 = 16;
-constexpr int SOLVER_SVD = 1, SOLVER_ORTHOGONALIZE_SYSTEM = 2, SOLVER_ORTHOGONALIZE_POINTMARG = 4, SOLVER_ORTHOGONALIZE_FULL = 8,
-              SOLVER_REMOVE_POSEPRIOR = 32, SOLVER_USE_GN = 64, SOLVER_FIX_LAMBDA = 128, SOLVER_ORTHOGONALIZE_X = 256,
-              SOLVER_MOMENTUM = 512, SOLVER_STEPMOMENTUM = 1024, SOLVER_ORTHOGONALIZE_X_LATER = 2048;
+// (the SOLVER_* bits of setting_solverMode: ba_kernels.h — the kernels read some of them too)
 
 struct HostCalib {
   double value_zero[4], value_scaled[4], value[4], step[4] = {0, 0, 0, 0}, value_backup[4], value_minus_value_zero[4];
@@ -46,7 +43,7 @@ struct HostCalib {
 
 struct HostFrame {
   Se3 evalPT, PRE_worldToCam, PRE_camToWorld;
-  double state_zero[10], state_scaled[10], state[10], step[10], state_backup[10];
+  double state_zero[10], state_scaled[10], state[10], step[10], state_backup[10], step_backup[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   float ab_exposure = 1, frameEnergyTH = 512;
   int frameID = 0, frame_slot = -1;
   double ns_pose[6][6], ns_scale[6];

@@ -16,6 +16,12 @@
 
 namespace sdso {
 
+// setting_solverMode bits (src/util/settings.h:32-43)
+constexpr int SOLVER_SVD_CUT7 = 16;
+constexpr int SOLVER_SVD = 1, SOLVER_ORTHOGONALIZE_SYSTEM = 2, SOLVER_ORTHOGONALIZE_POINTMARG = 4, SOLVER_ORTHOGONALIZE_FULL = 8,
+              SOLVER_REMOVE_POSEPRIOR = 32, SOLVER_USE_GN = 64, SOLVER_FIX_LAMBDA = 128, SOLVER_ORTHOGONALIZE_X = 256,
+              SOLVER_MOMENTUM = 512, SOLVER_STEPMOMENTUM = 1024, SOLVER_ORTHOGONALIZE_X_LATER = 2048;
+
 constexpr int BA_BLOCK = 256;
 constexpr int BA_CHUNK = 256;      // residuals per accumulate workgroup
 constexpr int BA_SC_PTS = 32;      // points per SC wave item (<= 64)
@@ -51,6 +57,11 @@ struct BaOptDev {
   // what loadSateBackup + setPrecalcValues restore on a rejected step
   float bk_precalc[64 * 27], bk_adHTdelta[64 * 8], bk_cdelta[4], bk_calib[6];
   double bk_prior[8 * 16 + 4 + 8 * 8 + 4];
+  // ---- SOLVER_STEPMOMENTUM / SOLVER_MOMENTUM (k_ba_opt_momentum, ba_opt.hip)
+  float stepsize;                    // the loop's stepsize (FullSystemOptimize.cpp:928, :936-948); 1 unless SOLVER_STEPMOMENTUM moves it
+  double previousX[72];              // ef->lastX of the previous iteration (:929, :934), NaN before the first
+  double x_backup[72];               // -step_backup of the frames and the calibration: the previous iteration's x, zeros in the first
+                                     // (backupState(iteration != 0), :311-345)
 };
 
 struct BaDev {
@@ -81,6 +92,8 @@ struct BaDev {
   float4* p_track;          // per point: x PointHessian::maxRelBaseline, y numGoodResiduals (int bits) — FullSystemOptimize.cpp:64-77 —,
                             // z idepth_hessian, w the active residuals of the latest AccumulatedSCHessianSSE::addPoint (bit t: target t; int bits)
   float* p_out;             // np*16
+  float* p_stepbk;          // np: PointHessian::step_backup (SOLVER_MOMENTUM, FullSystemOptimize.cpp:311-345): the step the latest back-substitution
+                            // replaced — written by k_ba_resub itself, zeros in a loop's first iteration
   // residuals (pair-sorted)
   const int* r_point;
   const int* r_orig;        // original (window-order) index of the pair-sorted residual

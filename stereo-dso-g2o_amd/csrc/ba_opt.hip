@@ -281,6 +281,15 @@ __device__ __forceinline__ void opt_step_body(BaDev& Bw, const BaDev& B, OptStep
     }
   }
   const int p_its = O.iterations;
+  // SOLVER_STEPMOMENTUM: the loop's own stepsize; SOLVER_MOMENTUM: the whole step plus half of the previous one on the poses, no step
+  // factor (doStepFromBackup, FullSystemOptimize.cpp:225-236) — both left in BaOptDev by k_ba_opt_momentum, which ran after the solve
+  const bool momentum = (B.solver_mode & SOLVER_MOMENTUM) != 0;
+  if (B.solver_mode & (SOLVER_MOMENTUM | SOLVER_STEPMOMENTUM)) stepsize = momentum ? 1.0f : O.stepsize;
+  double p_xb[6] = {0, 0, 0, 0, 0, 0};
+  if (momentum && tid < nf) {
+#pragma unroll
+    for (int i = 0; i < 6; i++) p_xb[i] = O.x_backup[4 + 8 * tid + i];
+  }
 
   // ---- setNewFrameEnergyTH over every rank's residuals into the newest frame
   // (the fused tail kernel has done this part on an idle wave beside the factorisation: pre)
@@ -358,7 +367,8 @@ __device__ __forceinline__ void opt_step_body(BaDev& Bw, const BaDev& B, OptStep
     double ns[10], sc[10];
 #pragma unroll
     for (int i = 0; i < 10; i++) {
-      const double st = i < 8 ? -p_x[i < 8 ? i : 0] : 0.0;     // step = -x (EnergyFunctional.cpp:978-985)
+      double st = i < 8 ? -p_x[i < 8 ? i : 0] : 0.0;           // step = -x (EnergyFunctional.cpp:978-985)
+      if (momentum && i < 6) st += 0.5f * -p_xb[i];            // step.head<6>() += 0.5f * step_backup.head<6>()
       if (i < 8) S.step[f][i] = st;
       ns[i] = p_st[i] + (double)stepsize * st;
     }
@@ -475,6 +485,38 @@ __device__ __forceinline__ void opt_step_body(BaDev& Bw, const BaDev& B, OptStep
 }
 
 
+// SOLVER_STEPMOMENTUM / SOLVER_MOMENTUM, between the solve and the step of one iteration (one workgroup per window, after x is in B.sol):
+//   incDirChange = (1e-20 + previousX . lastX) / (1e-20 + |previousX| |lastX|), previousX = lastX        FullSystemOptimize.cpp:933-934
+//   stepsize <- (exp(1.4 incDirChange) stepsize^3)^(1/4), reset to 1 on a direction change, kept in [0.25, 2]   :936-948 (STEPMOMENTUM only)
+//   x_backup = the previous iteration's x (frames' / calibration's step_backup = -x_backup), zeros in the first  :311-345
+__global__ __launch_bounds__(128) void k_ba_opt_momentum(const BaDev* __restrict__ wins) {
+  const BaDev& B = wins[blockIdx.y];
+  if (ba_finished(B)) return;
+  BaOptDev& O = *B.opt;
+  const int n = B.n, tid = threadIdx.x;
+  const double* x = B.sol + 3 * ((size_t)n * n + n);
+  __shared__ double xs[72], ps[72];
+  if (tid < n) { xs[tid] = x[tid]; ps[tid] = O.previousX[tid]; }
+  __syncthreads();
+  if (tid == 0) {
+    double dot = 0, n0 = 0, n1 = 0;
+    for (int i = 0; i < n; i++) { dot += ps[i] * xs[i]; n0 += ps[i] * ps[i]; n1 += xs[i] * xs[i]; }
+    const double incDirChange = (1e-20 + dot) / (1e-20 + sqrt(n0) * sqrt(n1));
+    float stepsize = O.stepsize;
+    if (isfinite(incDirChange) && (B.solver_mode & SOLVER_STEPMOMENTUM)) {
+      const float newStepsize = (float)exp(incDirChange * 1.4);
+      if (incDirChange < 0 && stepsize > 1) stepsize = 1;
+      stepsize = sqrtf(sqrtf(newStepsize * stepsize * stepsize * stepsize));
+      if (stepsize > 2) stepsize = 2;
+      if (stepsize < 0.25f) stepsize = 0.25f;
+    }
+    O.stepsize = stepsize;
+  }
+  if (tid < n) {
+    O.x_backup[tid] = O.iterations != 0 ? ps[tid] : 0.0;
+    O.previousX[tid] = xs[tid];
+  }
+}
 
 __global__ __launch_bounds__(256) void k_ba_opt_step(const BaDev* __restrict__ wins, const float* __restrict__ gathered, int nranks, int cap, int iteration, int last,
                                                      int stop_on_convergence, float stepsize, int unfused_parts, const float* __restrict__ sums, int sums_stride) {

@@ -628,6 +628,10 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_resub(const BaDev* __restrict__
   const int p = blockIdx.x * BA_BLOCK + threadIdx.x;
   if (p >= B.np) return;
   float* po = B.p_out + (size_t)p * 16;
+  // SOLVER_MOMENTUM: backupState keeps the step this back-substitution replaces (ph->step_backup = ph->step, zero before a loop's first
+  // iteration: FullSystemOptimize.cpp:311-345).  Kept HERE, where the old step is overwritten, so that every flow that solves has it.
+  // (Windows with that bit never take the fused k_ba_resub_step / TAIL_RESUB forms: opt_solve_step.)
+  if (B.solver_mode & SOLVER_MOMENTUM) B.p_stepbk[p] = B.opt->iterations != 0 ? po[PO_STEP] : 0.f;
   po[PO_STEP] = resub_point<WITH_L>(B, p, po);
 }
 
@@ -715,6 +719,39 @@ __global__ __launch_bounds__(256) void k_ba_prior_add(const BaDev* __restrict__ 
   }
 }
 
+// The same with setting_solverMode's nullspace bits (EnergyFunctional.cpp:707-731): H = M - Msc, b = Mb - Mbsc; SOLVER_ORTHOGONALIZE_POINTMARG
+// (a window without frame 0 only): orthogonalize(&b, &H) — b -= P b, H -= (P H) P with the gauge projector P = NNpiTS (:775-835; BaDev::t_P, built
+// from the nullspaces of the window's current evaluation points, as FullSystem.cpp:1453 refreshes them right before marginalizePointsF) —;
+// HM += fac H, bM += fac b; SOLVER_ORTHOGONALIZE_FULL: orthogonalize(&bM, &HM).  One 256-thread workgroup per window, f64 in LDS.
+__global__ __launch_bounds__(256) void k_ba_prior_orth(const BaDev* __restrict__ wins, double fac, int orth_marg, int orth_full) {
+  const BaDev& B = wins[blockIdx.y];
+  const int n = B.n, tid = threadIdx.x;
+  const size_t blk = (size_t)n * n + n;
+  const double* MA = B.sol; const double* MS = B.sol + 2 * blk;
+  const double* P = B.t_P;
+  double* HM = const_cast<double*>(B.t_HM); double* bM = const_cast<double*>(B.t_bM);
+  constexpr int NM = 68;
+  __shared__ double H[NM * NM], T[NM * NM], b[NM], pb[NM];
+  auto project = [&]() {   // b -= P b;  H -= (P H) P
+    for (int e = tid; e < n * n; e += 256) { const int i = e / n, j = e - i * n; double s = 0; for (int k = 0; k < n; k++) s += P[(size_t)i * n + k] * H[k * n + j]; T[e] = s; }
+    if (tid < n) { double s = 0; for (int k = 0; k < n; k++) s += P[(size_t)tid * n + k] * b[k]; pb[tid] = s; }
+    __syncthreads();
+    for (int e = tid; e < n * n; e += 256) { const int i = e / n, j = e - i * n; double s = 0; for (int k = 0; k < n; k++) s += T[i * n + k] * P[(size_t)k * n + j]; H[e] -= s; }
+    if (tid < n) b[tid] -= pb[tid];
+    __syncthreads();
+  };
+  for (int e = tid; e < n * n; e += 256) H[e] = MA[e] - MS[e];
+  if (tid < n) b[tid] = MA[(size_t)n * n + tid] - MS[(size_t)n * n + tid];
+  __syncthreads();
+  if (orth_marg) project();
+  for (int e = tid; e < n * n; e += 256) H[e] = HM[e] + fac * H[e];
+  if (tid < n) b[tid] = bM[tid] + fac * b[tid];
+  __syncthreads();
+  if (orth_full) project();
+  for (int e = tid; e < n * n; e += 256) HM[e] = H[e];
+  if (tid < n) bM[tid] = b[tid];
+}
+
 // EnergyFunctional::marginalizeFrame (EnergyFunctional.cpp:554-660) on the device-resident prior of one window: the frame's 8 rows / columns
 // go to the end (step 1), its prior is added (step 2), the system is scaled by 1 / sqrt(|diag| + 10), the 8 x 8 corner inverted, the Schur
 // complement taken and the scaling undone (step 3), the result symmetrised.  One 256-thread workgroup, everything f64 in LDS; every sum
@@ -786,7 +823,8 @@ __global__ __launch_bounds__(256) void k_ba_marg_frame(const BaDev* __restrict__
 }
 
 // FullSystem::backupState / doStepFromBackup / loadSateBackup for the points.  op: 0 backup, 1 step, 2 restore
-// op 3 = backup + step in one pass (the resident loop never restores)
+// op 3 = backup + step in one pass (the resident loop never restores).  stepfacD < 0: the window's own stepsize (BaOptDev::stepsize,
+// SOLVER_STEPMOMENTUM).  SOLVER_MOMENTUM (FullSystemOptimize.cpp:238-250): step + 0.5f * step_backup, no step factor.
 __global__ __launch_bounds__(BA_BLOCK) void k_ba_points_op(const BaDev* __restrict__ wins, int op, float stepfacD, float* __restrict__ sums /* per block: sumID, sumNID */,
                                                            int sums_stride = 0 /* floats between the windows' sums */, int cond = 0) {
   const BaDev& B = wins[blockIdx.y];
@@ -800,8 +838,11 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_points_op(const BaDev* __restri
     if (op == 0) po[PO_BACKUP] = g.z;
     else if (op == 1 || op == 3) {
       if (op == 3) po[PO_BACKUP] = g.z;
-      const float st = po[PO_STEP], bk = op == 3 ? g.z : po[PO_BACKUP];
-      const float nid = bk + stepfacD * st;
+      float st = po[PO_STEP];
+      const float bk = op == 3 ? g.z : po[PO_BACKUP];
+      float fac = stepfacD < 0 ? B.opt->stepsize : stepfacD;
+      if (B.solver_mode & SOLVER_MOMENTUM) { st = st + 0.5f * (B.p_stepbk[p]); fac = 1.0f; }
+      const float nid = bk + fac * st;
       g.z = nid; g.w = nid;     // setIdepth + setIdepthZero
       B.p_geo[p] = g;
       B.p_delta[p] = nid - nid;

@@ -483,3 +483,86 @@ def test_float_accumulators_sit_within_float_rounding_of_double_accumulation(ora
     d = np.sqrt(np.abs(np.diag(Hd)))
     assert np.abs((xf - xd) * d).max() < 2e-4 * max(1.0, np.abs(xd * d).max())
     assert np.abs(xf - xd).max() > 0                                          # the mode really changes the arithmetic
+
+
+# ------------------------------------------------------------------ 7. the solver-mode bits outside solveSystemF (round 6)
+MOMENTUM, STEPMOMENTUM, ORTH_POINTMARG, ORTH_FULL = 512, 1024, 4, 8
+
+
+def _oracle_optimize(oracle, win, its):
+    W, keep = abi.make_ba_window(win, frame_slots=list(range(win["nf"])), dI_list=[p[0] for p in win["pyrs"]])
+    h = oracle.orc_ba_create(C.byref(W))
+    s, i, o = np.zeros((win["nf"], 10)), np.zeros(win["np"], np.float32), abi.BAOptResult()
+    oracle.orc_ba_optimize(h, its, abi.dp(s), abi.fp(i), None, C.byref(o))
+    st = np.zeros(32, np.float32)
+    ns = oracle.orc_ba_get_step_trace(h, st.ctypes.data_as(C.POINTER(C.c_float)), 32)
+    oracle.orc_ba_destroy(h)
+    return s, i, o, st[:ns]
+
+
+@pytest.mark.parametrize("bit", [MOMENTUM, STEPMOMENTUM])
+def test_momentum_bits_leave_the_first_iteration_alone_and_act_from_the_second(oracle, win_small, bit):
+    """SOLVER_MOMENTUM adds half of the PREVIOUS step (zero before the first iteration, FullSystemOptimize.cpp:327-343); SOLVER_STEPMOMENTUM
+    scales by a stepsize that stays 1 while previousX is NaN (:929-938).  One iteration therefore ends exactly where the default mode's
+    does; from the second on the trajectories differ, the stepsize stays inside [0.25, 2] and the loop still descends."""
+    base = dict(win_small); base["solverMode"] = FIX_LAMBDA | ORTH_X_LATER
+    mod = dict(base); mod["solverMode"] = base["solverMode"] | bit
+    # (nf = 5: FullSystem::optimize keeps mnumOptIts as given only from four keyframes on, :875-876)
+    s1, i1, o1, st1 = _oracle_optimize(oracle, base, 1)
+    m1, j1, p1, mt1 = _oracle_optimize(oracle, mod, 1)
+    assert o1.iterations == p1.iterations == 1
+    assert np.array_equal(s1, m1) and np.array_equal(i1, j1) and mt1[0] == 1.0
+    s4, i4, o4, st4 = _oracle_optimize(oracle, base, 4)
+    m4, j4, p4, mt4 = _oracle_optimize(oracle, mod, 4)
+    assert np.abs(s4 - m4).max() > 1e-7
+    assert np.all(st4 == 1.0)
+    assert mt4.min() >= 0.25 and mt4.max() <= 2.0
+    if bit == STEPMOMENTUM:
+        assert np.abs(mt4[1:] - 1.0).max() > 0.01, mt4
+    assert p4.lastEnergy <= 1.02 * o1.lastEnergy                          # still a descent
+
+
+@pytest.mark.parametrize("first_id", [0, 3])
+def test_marginalize_points_with_the_nullspace_bits(oracle, win_small, first_id):
+    """EnergyFunctional::marginalizePointsF (EnergyFunctional.cpp:707-731): SOLVER_ORTHOGONALIZE_POINTMARG projects the marginalised points'
+    H, b off the seven gauge directions when frame 0 is not in the window (and is the plain statement when it is); SOLVER_ORTHOGONALIZE_FULL
+    projects the whole prior.  Checked against gauge vectors that do not come from the oracle (gauge_vectors: poses alone)."""
+    base = dict(win_small)
+    nf, npts, n = base["nf"], base["np"], 4 + 8 * base["nf"]
+    base["frameID"] = (np.arange(nf) + first_id).astype(np.int32)
+    A = np.random.RandomState(5).normal(size=(n, 6))
+    base["HM"] = (A @ A.T) * 1e9                                          # as large as the marginalised points' H, and not gauge-free
+    base["bM"] = np.random.RandomState(6).normal(size=n) * 1e6
+    flag = (base["host"] <= 1).astype(np.uint8)
+    N = gauge_vectors(base)
+    out = {}
+    for name, bits in (("plain", 0), ("marg", ORTH_POINTMARG), ("full", ORTH_FULL)):
+        win = dict(base); win["solverMode"] = FIX_LAMBDA | ORTH_X_LATER | bits
+        h, keep, J, ns, ne, nw, act, e = oracle_linearize(oracle, win)
+        oracle.orc_ba_accumulate(h)
+        HM, bM = np.zeros((n, n)), np.zeros(n)
+        oracle.orc_ba_marginalize_points(h, abi.bp(flag), abi.dp(HM), abi.dp(bM))
+        oracle.orc_ba_destroy(h)
+        out[name] = (HM, bM)
+    HM0 = np.array(base["HM"])
+    dH = out["plain"][0] - HM0
+    lead = np.abs(dH).max()
+    assert lead > 0
+    P = N @ np.linalg.pinv(N)                                              # projector onto the span of the analytic gauge vectors
+    Q = np.eye(n) - P
+    if first_id == 0:
+        assert np.array_equal(out["marg"][0], out["plain"][0]) and np.array_equal(out["marg"][1], out["plain"][1])
+    else:
+        # the marginalised points' H is gauge-free by construction up to float (no pose prior in it), so the projection moves it by
+        # rounding-sized amounts only: the bit runs (not the same bits), and its result is the projected plain statement
+        dm = out["marg"][0] - HM0
+        assert not np.array_equal(out["marg"][0], out["plain"][0])
+        assert np.abs(dm - (dH - P @ dH @ P)).max() <= 1e-4 * lead            # *H -= NNpiTS * *H * NNpiTS (:826)
+        assert np.abs(N.T @ dm @ N).max() <= 1e-4 * lead
+    # the whole prior projected: the (deliberately not gauge-free) HM0 loses its gauge part.  The oracle's nullspaces are central differences
+    # (FrameHessian::setStateZero), 1e-6 off the analytic vectors, hence 1e-4
+    HF, bF = out["full"]
+    big = np.abs(out["plain"][0]).max()
+    assert np.abs(HF - (out["plain"][0] - P @ out["plain"][0] @ P)).max() <= 1e-4 * big          # H -= P H P (:826), b -= P b (:823)
+    assert np.abs(bF - Q @ out["plain"][1]).max() <= 1e-4 * np.abs(out["plain"][1]).max()
+    assert np.abs(N.T @ out["plain"][0] @ N).max() > 1e-2 * big and np.abs(N.T @ HF @ N).max() <= 1e-4 * big
