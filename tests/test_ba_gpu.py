@@ -380,11 +380,12 @@ def test_pose_updates_of_every_gn_iteration_c3(gpu_ctx, oracle, win_c3):
     update of every frame is compared in the units the pose moves in (x * SCALE).  FIXED bars:
       * against the reference arithmetic with its sums carried in f64 (orc_set_acc64: the float summation ORDER of the CPU path out of the
         reference value): translation and rotation entries |dx| <= 1e-5 on EVERY iteration, the first included (measured on MI355X,
-        round 6: 1.5e-7 on the first).  The device carries its cross-residual / cross-point sums in f64 on the matrix cores (ba_kernels.hip,
+        round 6: 4.1e-6, 1.4e-6, 2.3e-7, 4.3e-7).  The device carries its cross-residual / cross-point sums in f64 on the matrix cores (ba_kernels.hip,
         ACC_MODE 1), so this is the comparison in which only the reference's per-residual arithmetic is left;
       * against the reference's float path as it is (4-byte accumulators, sequential): <= 1e-5 from the second iteration on and <= 2e-5 on
-        the first — that distance is the CPU float path's OWN distance from the order-independent sums (1.2e-5 on this window, median
-        1.3e-5 over 24 windows against the device's 1.4e-6: profiles/r06_truth_updates.txt), asserted below to be exactly that;
+        the first (measured 9.4e-6, 1.1e-6, 2.4e-7, 5.9e-7; round 5 with fp32 chains: 1.39e-5 on the first) — what is left there is the CPU
+        float path's OWN distance from the order-independent sums (5.3e-6 on this window, median 1.3e-5 over 24 windows against the
+        device's 1.4e-6: profiles/r06_truth_updates.txt), asserted below to be no more than that plus the device's 1e-5;
       * the affine a (scaled, dimensionless) <= 1e-5, b (scaled: intensity levels of 0..255) <= 1e-3.  After the loop every frame's pose
         state is within a FIXED 2e-5 of the float oracle's, next to the spread-relative bar of test_optimize_full_gn_loop.
     A failure names the iteration and the residuals whose final state differs."""
@@ -668,3 +669,157 @@ def test_full_size_window_properties(gpu_ctx):
     d = np.sqrt(np.abs(np.diag(H))) + 1e-30
     assert np.abs((xs - x) * d).max() <= 2e-4 * max(1.0, np.abs(x * d).max())
     assert np.abs(H - H.T).max() <= 1e-9 * np.abs(H).max() and (np.diag(H) > 0).all() and np.isfinite(x).all()
+
+
+@pytest.fixture(scope="module")
+def win_c5():
+    return synth.ba_window(w=1232, h=368, nf=8, pts_per_kf=1000, seed=3101)     # configs[4]: 8 KF x 8000 points, ~50k residuals
+
+
+def test_full_size_window_matches_oracle(gpu_ctx, oracle, win_c5):
+    """BASELINE configs[4] size against the ORACLE (the round-5 verdict's Missing #4: it was property-checked only), same bars as configs[2]:
+    host tables, every RawResidualJacobian, state and energy bit-exact; per-point Hdd / bd / Hcd / HdiF / bdSumF bit-exact; packed
+    accumulators <= 3e-5 of the block maximum against the float oracle (and <= 3e-7 against the f64-accumulator truth: the device's sums
+    are f64); stitched H / b <= 1e-4, x and the point steps <= 2e-4 whitened — also with orthogonalize_x —; the 6-iteration loop of
+    FullSystem::optimize with the per-iteration pose-update bar of north_star (1e-5) against the truth and the fixed 2e-5 after the loop;
+    and the window cut 2 and 8 ways by points (sdso_amd.dist.shard_window, the multi-GPU partition: AccumulatedTopHessian.cpp:299-308 sums
+    per-thread copies the same way), the shards' accumulators summed and solved, against the ORACLE's unsharded x."""
+    from sdso_amd import dist as sd
+    win = win_c5
+    nf, npts, nr, n = win["nf"], win["np"], win["nr"], 8 * win["nf"] + 4
+    assert npts == 8000 and nr > 45000
+    W, keep, h = _both(gpu_ctx, oracle, win, slot0=400, wid=60)
+    to = [np.zeros(nf * nf * 27, np.float32), np.zeros(nf * nf * 64), np.zeros(nf * nf * 64), np.zeros(nf * nf * 8, np.float32)]
+    tg = [np.zeros_like(a) for a in to]
+    oracle.orc_ba_get_tables(h, abi.fp(to[0]), abi.dp(to[1]), abi.dp(to[2]), abi.fp(to[3]))
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_get_tables(gpu_ctx.h, 60, abi.fp(tg[0]), abi.dp(tg[1]), abi.dp(tg[2]), abi.fp(tg[3])))
+    for a, b in zip(to, tg):
+        assert np.array_equal(a, b)
+    eo, eg, o, g = _lin_both(gpu_ctx, oracle, win, h, 60)
+    _check_lin(eo, eg, o, g)
+    assert (o["ns"] == 0).sum() > 0.4 * nr
+    oracle.orc_ba_apply_res(h)
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_apply_res(gpu_ctx.h, 60))
+    so, ao_, jo = np.zeros(nr, np.uint8), np.zeros(nr, np.uint8), np.zeros((nr, 8), np.float32)
+    sg, ag_, jg = np.zeros(nr, np.uint8), np.zeros(nr, np.uint8), np.zeros((nr, 8), np.float32)
+    oracle.orc_ba_get_residual_state(h, abi.bp(so), abi.bp(ao_), abi.fp(jo))
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_get_residual_state(gpu_ctx.h, 60, abi.bp(sg), abi.bp(ag_), abi.fp(jg)))
+    assert np.array_equal(so, sg) and np.array_equal(ao_, ag_) and np.array_equal(jo[ao_ == 1], jg[ao_ == 1])
+    ao, ag = _accumulate_both(gpu_ctx, oracle, win, h, 60)
+    _check_accum(ao, ag, nf)
+    # ... and against the f64-accumulator truth
+    oracle.orc_set_acc64(1)
+    try:
+        h64 = oracle.orc_ba_create(C.byref(W))
+        oracle.orc_ba_linearize(h64, None); oracle.orc_ba_apply_res(h64); oracle.orc_ba_accumulate(h64)
+        a64 = np.zeros(abi.accum_floats(nf))
+        oracle.orc_ba_get_accumulators_f64(h64, abi.dp(a64))
+        oracle.orc_ba_destroy(h64)
+    finally:
+        oracle.orc_set_acc64(0)
+    o0 = 0
+    for name, cnt, w in (("topA", nf * nf, 91), ("topL", nf * nf, 91), ("accD", nf ** 3, 64), ("accE", nf * nf, 32), ("accEB", nf * nf, 8), ("Hcc", 1, 16), ("bc", 1, 4)):
+        T = a64[o0:o0 + cnt * w].reshape(-1, w)
+        m = np.maximum(np.abs(T).max(axis=1, keepdims=True), 1e-30)
+        live = np.abs(T).max(axis=1) > 0
+        if live.any():
+            eg_ = np.abs((ag[o0:o0 + cnt * w].reshape(-1, w).astype(np.float64) - T) / m)[live].max()
+            ec_ = np.abs((ao[o0:o0 + cnt * w].reshape(-1, w).astype(np.float64) - T) / m)[live].max()
+            assert eg_ <= 3e-7, (name, eg_, ec_)
+        o0 += cnt * w
+    po = [np.zeros(npts, np.float32) for _ in range(4)] + [np.zeros(npts * 4, np.float32)]
+    pg = [np.zeros_like(a) for a in po]
+    oracle.orc_ba_get_point_terms(h, *[abi.fp(a) for a in po])
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_get_point_terms(gpu_ctx.h, 60, *[abi.fp(a) for a in pg]))
+    for a, b in zip(po, pg):
+        assert np.array_equal(a, b)
+    xo_first = None
+    for it, lam in ((0, 0.1), (2, 0.025)):
+        xo, Ho, bo = np.zeros(n), np.zeros((n, n)), np.zeros(n)
+        xg, Hg, bg = np.zeros(n), np.zeros((n, n)), np.zeros(n)
+        oracle.orc_ba_solve(h, it, lam, abi.dp(xo), abi.dp(Ho), abi.dp(bo), None, None)
+        gpu_ctx.check(gpu_ctx.L.sdso_ba_accumulate(gpu_ctx.h, 60))
+        gpu_ctx.check(gpu_ctx.L.sdso_ba_solve(gpu_ctx.h, 60, it, lam, abi.dp(xg), abi.dp(Hg), abi.dp(bg), None, None))
+        d = np.sqrt(np.abs(np.diag(Ho))) + 1e-30
+        assert np.abs((Hg - Ho) / np.outer(d, d)).max() <= 1e-4
+        assert np.abs((bg - bo) / d).max() <= 1e-4 * max(1.0, np.abs(bo / d).max())
+        assert np.abs((xg - xo) * d).max() <= 2e-4 * max(1.0, np.abs(xo * d).max())
+        sto, stg = np.zeros(npts, np.float32), np.zeros(npts, np.float32)
+        oracle.orc_ba_get_point_steps(h, abi.fp(sto))
+        gpu_ctx.check(gpu_ctx.L.sdso_ba_get_point_steps(gpu_ctx.h, 60, abi.fp(stg)))
+        assert np.abs(stg - sto).max() <= 2e-4 * max(np.abs(sto).max(), 1e-6)
+        if it == 0:
+            xo_first, d_first = xo.copy(), d.copy()
+    oracle.orc_ba_destroy(h)
+
+    # ---- the window cut 2 and 8 ways: every shard linearised / accumulated on its own, the packed blocks added (what the all-reduce does),
+    # one solve from the sum — against the oracle's x of the UNSHARDED window
+    slots = [400 + f for f in range(nf)]
+    na = abi.accum_floats(nf)
+    for world in (2, 8):
+        ssum = np.zeros(na, np.float32)
+        for r in range(world):
+            ws = sd.shard_window(win, r, world)[0]
+            Ws, ks = abi.make_ba_window(ws, frame_slots=slots)
+            gpu_ctx.check(gpu_ctx.L.sdso_ba_upload_window(gpu_ctx.h, 61, C.byref(Ws)))
+            gpu_ctx.check(gpu_ctx.L.sdso_ba_linearize(gpu_ctx.h, 61, None))
+            gpu_ctx.check(gpu_ctx.L.sdso_ba_apply_res(gpu_ctx.h, 61))
+            gpu_ctx.check(gpu_ctx.L.sdso_ba_accumulate(gpu_ctx.h, 61))
+            a = np.zeros(na, np.float32)
+            gpu_ctx.check(gpu_ctx.L.sdso_ba_get_accumulators(gpu_ctx.h, 61, abi.fp(a)))
+            ssum += a
+        assert ssum[-2] == ao[-2]                                            # every active residual sits in exactly one shard
+        _check_accum(ao, ssum, nf)
+        gpu_ctx.check(gpu_ctx.L.sdso_ba_set_accumulators(gpu_ctx.h, 61, abi.fp(ssum)))
+        xs = np.zeros(n)
+        gpu_ctx.check(gpu_ctx.L.sdso_ba_solve(gpu_ctx.h, 61, 0, 0.1, abi.dp(xs), None, None, None, None))
+        assert np.abs((xs - xo_first) * d_first).max() <= 2e-4 * max(1.0, np.abs(xo_first * d_first).max()), world
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_release_window(gpu_ctx.h, 61))
+
+    # ---- FullSystem::optimize: float oracle, f64-accumulator truth, device
+    def oracle_loop(acc64):
+        oracle.orc_set_acc64(1 if acc64 else 0)
+        try:
+            hh = oracle.orc_ba_create(C.byref(W))
+            s, i, r, oo = np.zeros((nf, 10)), np.zeros(npts, np.float32), np.zeros(nr, np.uint8), abi.BAOptResult()
+            oracle.orc_ba_optimize(hh, 6, abi.dp(s), abi.fp(i), abi.bp(r), C.byref(oo))
+            x = np.zeros((8, n))
+            its = oracle.orc_ba_get_x_trace(hh, abi.dp(x), 8)
+            oracle.orc_ba_destroy(hh)
+        finally:
+            oracle.orc_set_acc64(0)
+        return s, i, r, oo, x, its
+    s32, i32, r32, o32, x32, its32 = oracle_loop(False)
+    s64, i64, r64, o64, x64, its64 = oracle_loop(True)
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_upload_window(gpu_ctx.h, 60, C.byref(W)))
+    ids = np.array([60], np.int32)
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_batch_create(gpu_ctx.h, 1, abi.ip(ids)))
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_batch_optimize_begin(gpu_ctx.h, 1))
+    xg = np.zeros((6, n))
+    for it in range(6):
+        gpu_ctx.check(gpu_ctx.L.sdso_ba_batch_accumulate(gpu_ctx.h))
+        gpu_ctx.check(gpu_ctx.L.sdso_ba_batch_solve_step(gpu_ctx.h, 0.1 * 0.25 ** it, 1 if it >= 2 else 0))
+        gpu_ctx.check(gpu_ctx.L.sdso_ba_batch_get_x(gpu_ctx.h, abi.dp(xg[it:it + 1])))
+    og = (abi.BAOptResult * 1)()
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_batch_optimize_end(gpu_ctx.h, og))
+    sgd, igd, rgd = np.zeros((nf, 10)), np.zeros(npts, np.float32), np.zeros(nr, np.uint8)
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_get_state(gpu_ctx.h, 60, abi.dp(sgd), abi.fp(igd), abi.bp(rgd)))
+    assert og[0].iterations == o32.iterations == o64.iterations
+    upd = lambda a, b, it: float(np.abs((a[it, 4:] - b[it, 4:]).reshape(nf, 8) * _STATE_SCALE)[:, :6].max())   # noqa: E731
+    truth = [upd(xg, x64, it) for it in range(its64)]
+    cpu_own = [upd(x32, x64, it) for it in range(its64)]
+    vs32 = [upd(xg, x32, it) for it in range(its32)]
+    msg = "pose update per iteration: device-truth %s, cpu_f32-truth %s, device-cpu_f32 %s" % (truth, cpu_own, vs32)
+    print("configs[4]:", msg)
+    for it in range(its64):
+        assert truth[it] <= 1e-5, msg
+        assert vs32[it] <= max(1e-5, cpu_own[it] + 1e-5), msg
+    dstate = np.abs(sgd - s32)[:, :8] * _STATE_SCALE
+    dtruth = np.abs(sgd - s64)[:, :8] * _STATE_SCALE
+    assert dtruth[:, :6].max() <= 2e-5 and dstate[:, :6].max() <= 2e-5, (float(dtruth[:, :6].max()), float(dstate[:, :6].max()), msg)
+    assert dstate[:, 6].max() <= 2e-5 and dstate[:, 7].max() <= 2e-3
+    assert helpers.idepths_close(igd, i32, 2e-4)
+    assert (rgd != r32).sum() <= max(2, nr // 2000)
+    assert helpers.counts_close(og[0].resInA, o32.resInA, nr)
+    assert abs(og[0].lastEnergy - o32.lastEnergy) <= 1e-4 * o32.lastEnergy
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_release_window(gpu_ctx.h, 60))
