@@ -187,10 +187,16 @@ class BAWorkload:
                     self.exchange = "sdso_ba_allreduce (RCCL communicator owned by libsdso_hip.so)"
         self.nwin = nwin
         self.units_per_step = nwin * win["nr"]
+        # what the LIBRARY's communicator says (sdso_comm_info), not what the launcher's environment says: 0 without a communicator
+        nr_, rk_ = C.c_int(0), C.c_int(-1)
+        ctx.check(ctx.L.sdso_comm_info(ctx.h, C.byref(nr_), C.byref(rk_)))
+        self.comm_ranks = int(nr_.value)
+        self.exchange_floats = nfl_total if world > 1 else 0
         self.config = {"workload": self.name, "windows_per_step": nwin, "keyframes": nf, "points_per_window_per_gpu": win["np"],
                        "residuals_per_window_per_gpu": win["nr"], "points_per_global_window": self.win_global["np"],
                        "jacobians_materialized": bool(self.materialize), "stream_groups": ngroups,
                        "allreduce_floats": nfl_total if world > 1 else 0, "exchange": getattr(self, "exchange", None),
+                       "rccl_ranks": self.comm_ranks, "launcher_world_size": world,
                        "exchange_shape": ("reduce-scatter by window + all-gather of x" if getattr(self, "exchange_mode", 0) else "all-reduce, solve on every rank") if world > 1 else None,
                        "parallelism": ("the points of every host keyframe of every window cut %d ways (one slice of every host per rank), 1 RCCL all-reduce (sdso_ba_allreduce) of the packed accumulators per group and iteration" % world) if world > 1 else "single GPU"}
         # correctness at the initial state (one iteration, before the timed loop moves the states): see _verify_initial
@@ -297,6 +303,8 @@ class BAWorkload:
             d = np.sqrt(np.abs(np.diag(Hr))) + 1e-30
             err = float(np.abs((x0 - xr) * d).max() / max(1.0, np.abs(xr * d).max()))
             out["sharded_x_whitened_err" if self.world > 1 else "fused_vs_unfused_x_whitened_err"] = err
+            if self.world == 1:
+                out["sharded_x_whitened_err"] = 0.0      # (one rank holds the whole window: the key exists on every N)
             assert err <= 2e-4, "x of window 0 differs from the unsharded / un-fused reference solve: %g" % err
         return out
 
@@ -322,13 +330,25 @@ class BAWorkload:
         if os.environ.get("SDSO_BENCH_SECONDARY", "1") == "1":
             for G in self.groups:
                 G.ctx.check(G.ctx.L.sdso_prof_enable(G.ctx.h, 2))
-            base = {k: self.prof_read(k) for k in ("k_ba_sc", "k_ba_tail", "k_ba_resub")}
-            for _ in range(5):
+            names = ("k_ba_sc", "k_ba_tail", "k_ba_resub", "sdso_ba_allreduce")
+            base = {k: self.prof_read(k) for k in names}
+            nextra = 5
+            for _ in range(nextra):
                 self.step()
             self.sync()
-            for k in ("k_ba_sc", "k_ba_tail", "k_ba_resub"):
+            for k in names[:3]:
                 ms, n = self.prof_read(k)
-                out[k + "_avg_ms"] = (ms - base[k][0]) / max(n - base[k][1], 1)
+                # (no launch of its own: from one window per CU on the points' back-substitution and step run inside k_ba_tail — TAIL_RESUB)
+                out[k + "_avg_ms"] = (ms - base[k][0]) / (n - base[k][1]) if n > base[k][1] else None
+            if out.get("k_ba_resub_avg_ms") is None:
+                out["k_ba_resub_note"] = "fused into k_ba_tail (TAIL_RESUB: one tail workgroup per CU or more)"
+            # the exchange of the packed accumulators: bytes this rank hands to the collective per step (all stream groups) and the HIP-event
+            # time of sdso_ba_allreduce on the ctx streams per step; zeros on one rank (no communicator, nothing is exchanged) — the same
+            # keys on every N, so that an N = 1 line of a scaling series reads like the others
+            ms, n = self.prof_read("sdso_ba_allreduce")
+            out["exchange_bytes_per_step"] = 4 * self.exchange_floats
+            out["exchange_ms_per_step"] = (ms - base["sdso_ba_allreduce"][0]) / nextra if self.world > 1 else 0.0
+            out["exchange_calls_per_step"] = (n - base["sdso_ba_allreduce"][1]) / nextra if self.world > 1 else 0
             for G in self.groups:
                 G.ctx.check(G.ctx.L.sdso_prof_enable(G.ctx.h, 0))
             # the Schur kernel against ITS roofline (24 B per point + 32 B per residual of it, i.e. what the reference's addPoint

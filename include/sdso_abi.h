@@ -372,7 +372,11 @@ int sdso_ba_get_deltas(sdso_ctx* ctx, int win, float* cDeltaF, double* frame_del
  * the marginalisation of keyframe `idx` in one kernel (its EFFrame::prior / delta_prior are the window's own) and stay there; HM_out
  * (8(nf-1)+4)^2 / bM_out are optional host copies.  sdso_ba_adopt_prior(win, from_win) hands that prior to the next window — device to
  * device, the rows / columns of frames beyond it zero, as EnergyFunctional::insertFrame resizes HM / bM (EnergyFunctional.cpp:468-476);
- * upload `win` with HM = bM = NULL first.  The prior then never leaves the device between two keyframes. */
+ * upload `win` with HM = bM = NULL first.  The prior then never leaves the device between two keyframes.
+ * Several frames leaving at one keyframe (FullSystem.cpp:1470-1476 marginalises every flagged frame in a loop): a call that follows another
+ * one with no sdso_ba_marginalize_points in between continues from that result, `idx` then counting the frames the prior still covers
+ * (EFFrame::idx after the earlier frame was erased); outputs are (8k+4)^2 / 8k+4 for the k frames left.  sdso_ba_adopt_prior fails (-1)
+ * unless the adopting window's leading frames are exactly those k frames, in order (by frameID), and it was uploaded with a zero prior. */
 int sdso_ba_marginalize_frame_dev(sdso_ctx* ctx, int win, int idx, double* HM_out, double* bM_out);
 int sdso_ba_adopt_prior(sdso_ctx* ctx, int win, int from_win);
 

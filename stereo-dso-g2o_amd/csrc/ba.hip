@@ -33,8 +33,12 @@ struct BaWindowDev {
   Dense P;
   std::vector<double> HM, bM;    // host mirror of the marginalisation prior; the MASTER copy is the device's (dt_HM / dt_bM): see hm_host_valid
   bool hm_host_valid = true;     // false: a device kernel changed the prior since the mirror was filled (sync_prior_host brings it up to date)
-  double* d_marg = nullptr;      // the prior after sdso_ba_marginalize_frame_dev: (n - 8)^2 + (n - 8) doubles, adopted by the next window
+  double* d_marg = nullptr;      // the prior after sdso_ba_marginalize_frame_dev: marg_dim^2 + marg_dim doubles, adopted by the next window
+  double* d_marg2 = nullptr;     // (the other half of the ping-pong when several frames leave at one keyframe)
   int marg_dim = 0;              // its dimension (0: none)
+  std::vector<int> marg_frames;  // the window's frames that prior still covers, in order (indices into `frames`)
+  bool marg_chain = false;       // the next sdso_ba_marginalize_frame_dev continues from d_marg (no sdso_ba_marginalize_points since the last one)
+  bool prior_pristine = false;   // uploaded with HM = bM = NULL and untouched since: what sdso_ba_adopt_prior requires of the adopting window
   int solverMode = 0, forceAccept = 1;
   double affA = 0, affB = 0;
   std::vector<int> perm, inv;     // sorted -> original, original -> sorted
@@ -261,7 +265,7 @@ static int upload_window_impl(sdso_ctx* ctx, int win, const sdso_ba_window_t* Wi
   SDSO_REQUIRE(ctx, nr == 0 || (Win->res_point && Win->res_target && Win->res_state), "null residual arrays");
   // (every bit of setting_solverMode has its branch: solveSystemF's in launch_solve, STEPMOMENTUM / MOMENTUM in the GN loops, ORTHOGONALIZE_POINTMARG /
   // _FULL in sdso_ba_marginalize_points)
-  const bool timing = getenv("SDSO_BA_UPLOAD_TIMING") != nullptr;   // phase times of the upload on stderr (diagnostic)
+  const bool timing = dbg_env("SDSO_BA_UPLOAD_TIMING") != nullptr;   // phase times of the upload on stderr (diagnostic)
   auto t_prev = std::chrono::steady_clock::now();
   auto mark = [&](const char* what) {
     if (!timing) return;
@@ -272,7 +276,7 @@ static int upload_window_impl(sdso_ctx* ctx, int win, const sdso_ba_window_t* Wi
   int rc = sdso_ba_release_window(ctx, win);
   if (rc) return rc;
   mark("release of the old window");
-  const bool use_tiled = getenv("SDSO_BA_ROWMAJOR") == nullptr;   // 4x2-tiled level-0 images for the linearisation (default)
+  const bool use_tiled = dbg_env("SDSO_BA_ROWMAJOR") == nullptr;   // 4x2-tiled level-0 images for the linearisation (default)
 
   BaWindowDev* W = new BaWindowDev();
   ctx->wins[win] = W;
@@ -281,7 +285,7 @@ static int upload_window_impl(sdso_ctx* ctx, int win, const sdso_ba_window_t* Wi
   d.nf = nf; d.np = np; d.nr = nr; d.nrp = (nr + 63) & ~63; d.w = Win->w; d.h = Win->h; d.n = 8 * nf + 4;
   d.wM3 = (float)(Win->w - 3); d.hM3 = (float)(Win->h - 3);
   d.affA_fixed = Win->affineOptModeA < 0; d.affB_fixed = Win->affineOptModeB < 0;
-  d.jfix = getenv("SDSO_BA_JSWAP") && atoi(getenv("SDSO_BA_JSWAP")) ? 0 : 1;
+  d.jfix = dbg_env("SDSO_BA_JSWAP") && atoi(dbg_env("SDSO_BA_JSWAP")) ? 0 : 1;
   W->solverMode = Win->solverMode; W->forceAccept = Win->forceAcceptStep; W->affA = Win->affineOptModeA; W->affB = Win->affineOptModeB;
   d.solver_mode = Win->solverMode;
   d.have_first_frame = 0;
@@ -314,6 +318,7 @@ static int upload_window_impl(sdso_ctx* ctx, int win, const sdso_ba_window_t* Wi
   W->HM.assign((size_t)n * n, 0.0); W->bM.assign(n, 0.0);
   if (Win->HM) std::memcpy(W->HM.data(), Win->HM, sizeof(double) * n * n);
   if (Win->bM) std::memcpy(W->bM.data(), Win->bM, sizeof(double) * n);
+  W->prior_pristine = std::all_of(W->HM.begin(), W->HM.end(), [](double v) { return v == 0.0; }) && std::all_of(W->bM.begin(), W->bM.end(), [](double v) { return v == 0.0; });
 
   mark("host mirror of the frames");
   // ---- validate + sort residuals by (host,target) pair, stable
@@ -602,7 +607,7 @@ static bool launch_sc_and_folds(sdso_ctx* ctx, const BaLaunch& L, const uint8_t*
     // a wave per host (see the kernel) once the workgroups-per-host form would need more than two and a half rounds of three workgroups per
     // CU (measured, µs, workgroup / wave form: 64 windows 34 / 66, 128: 60 / 69, 192: 76 / 93, 256: 104 / 100 — profiles/r05_sc_batch_ab.txt);
     // SDSO_BA_SC_WPH=0 / 1 forces one form (A/B)
-    static const int wph_env = getenv("SDSO_BA_SC_WPH") ? atoi(getenv("SDSO_BA_SC_WPH")) : -1;
+    static const int wph_env = dbg_env("SDSO_BA_SC_WPH") ? atoi(dbg_env("SDSO_BA_SC_WPH")) : -1;
     const bool wph = wph_env >= 0 ? wph_env != 0 : 2 * nf * L.nwin > 15 * ctx->n_cu;
     const dim3 g(wph ? (nf + BA_BLOCK / 64 - 1) / (BA_BLOCK / 64) : nf, L.nwin);
     if (plain) { if (wph) hipLaunchKernelGGL((k_ba_sc_host<true, true>), g, dim3(BA_BLOCK), 0, ctx->stream, L.d_arr, pflag, shift, mm, clear_l);
@@ -646,7 +651,7 @@ static void launch_stitch(sdso_ctx* ctx, const BaLaunch& L) {
   hipLaunchKernelGGL(k_ba_stitch<0>, sg, sb, 0, ctx->stream, L.d_arr);
 }
 // the fused tail kernel (ba_tail.hip); SDSO_BA_TAIL=0 keeps the chain of separate kernels (A/B)
-static bool tail_enabled() { static const bool on = !(getenv("SDSO_BA_TAIL") && atoi(getenv("SDSO_BA_TAIL")) == 0); return on; }
+static bool tail_enabled() { static const bool on = !(dbg_env("SDSO_BA_TAIL") && atoi(dbg_env("SDSO_BA_TAIL")) == 0); return on; }
 static void launch_tail(sdso_ctx* ctx, const BaLaunch& L, double lambda, int flags, int iteration = 0, int last = 0, int stop = 0) {
   ProfScope ps(ctx, "k_ba_tail", 2);
   if (L.nf == 8) hipLaunchKernelGGL(k_ba_tail<8>, dim3(L.nwin), dim3(TAIL_NT), 0, ctx->stream, L.d_arr, lambda, flags, iteration, last, stop);
@@ -657,7 +662,7 @@ static void launch_fold_deferred(sdso_ctx* ctx, const BaLaunch& L) {   // what l
 }
 // stitch + solveSystemF (default branch) + resubstitute.  orth bit 0: x -= P x; bit 1: lambda of the window's resident loop.
 // folded = false: the accumulate left the folds to the tail kernel (launch_fused with defer_fold)
-static bool solve_on_host() { return getenv("SDSO_BA_SOLVE_HOST") != nullptr; }   // A/B: the SVD / orthogonalised-system branches through solve_system_host
+static bool solve_on_host() { return dbg_env("SDSO_BA_SOLVE_HOST") != nullptr; }   // A/B: the SVD / orthogonalised-system branches through solve_system_host
 static void launch_solve(sdso_ctx* ctx, const BaLaunch& L, double lambda, int orth, bool folded = true) {
   const int n = L.n;
   if (L.alt) {   // solveSystemF's SVD / orthogonalised-system branches: stitch, then one workgroup per window (ba_solve_alt.hip)
@@ -1185,7 +1190,7 @@ extern "C" int sdso_ba_optimize(sdso_ctx* ctx, int win, int mnumOptIts, double* 
   // The whole loop runs on the device (ba_opt.hip) without a host round trip: the accepted-step flow (setting_forceAceptStep, the
   // reference's default) through the fused kernel, the energy-gated flow through the un-fused ones with the decision taken by
   // k_ba_opt_gate.  The SVD / orthogonalised-system solver modes and SDSO_BA_HOST_LOOP=1 (A/B) take the host loop below.
-  const bool host_loop = getenv("SDSO_BA_HOST_LOOP") != nullptr;   // read per call: tests flip it
+  const bool host_loop = dbg_env("SDSO_BA_HOST_LOOP") != nullptr;   // read per call: tests flip it
   if (nf >= 2 && !host_loop && ((W->solverMode & (SOLVER_SVD | SOLVER_ORTHOGONALIZE_SYSTEM)) == 0 || !solve_on_host())) {
     int rc = optimize_resident_single(ctx, W, mnumOptIts, &res);
     if (rc) return rc;
@@ -1356,6 +1361,8 @@ extern "C" int sdso_ba_marginalize_points(sdso_ctx* ctx, int win, const uint8_t*
   hipLaunchKernelGGL(k_ba_prior_add, dim3(8, 1), dim3(256), 0, ctx->stream, L.d_arr, (double)(0.5f * 0.5f));   // setting_margWeightFac
   SDSO_HIP(ctx, hipGetLastError());
   W->hm_host_valid = false;
+  W->prior_pristine = false;
+  W->marg_chain = false;            // the resident prior changed: the next marginalizeFrame starts from it again
   std::vector<uint8_t> lin(nr);
   if (nr) SDSO_HIP(ctx, hipMemcpyAsync(lin.data(), W->d.r_lin, nr, hipMemcpyDeviceToHost, ctx->stream));
   SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1603,16 +1610,27 @@ extern "C" int sdso_ba_marginalize_frame(int nf, int idx, const double* prior8, 
 // (EFFrame::prior, delta_prior = the host mirror's, as uploaded / as the resident loop left them).  HM_out / bM_out: optional copies.
 extern "C" int sdso_ba_marginalize_frame_dev(sdso_ctx* ctx, int win, int idx, double* HM_out, double* bM_out) {
   GET_WIN();
-  const int nf = W->d.nf, n = W->d.n, m = n - 8;
-  SDSO_REQUIRE(ctx, idx >= 0 && idx < nf, "frame index out of range");
-  if (!W->d_marg) { DM(W->d_marg, double, (size_t)n * n + n); }
+  const int nf = W->d.nf, n = W->d.n;
+  // Several frames may leave at one keyframe (FullSystem.cpp:1470-1476 calls marginalizeFrame for every flagged frame, each on the prior
+  // the previous one left): a call that follows another one — with no sdso_ba_marginalize_points in between — continues from that result,
+  // and `idx` then counts the frames the prior still covers, as the reference's frames[] does after the earlier frame was erased.
+  if (!W->marg_chain) { W->marg_frames.resize(nf); std::iota(W->marg_frames.begin(), W->marg_frames.end(), 0); }
+  const int cur = (int)W->marg_frames.size(), odim = 8 * cur + 4, m = odim - 8;
+  SDSO_REQUIRE(ctx, idx >= 0 && idx < cur, "frame index out of range (it counts the frames the prior still covers)");
+  if (!W->d_marg) { DM(W->d_marg, double, (size_t)n * n + n); DM(W->d_marg2, double, (size_t)n * n + n); }
+  const HostFrame& Fm = W->frames[W->marg_frames[idx]];
   double pr[16];
-  for (int i = 0; i < 8; i++) { pr[i] = W->frames[idx].prior[i]; pr[8 + i] = W->frames[idx].delta_prior[i]; }
+  for (int i = 0; i < 8; i++) { pr[i] = Fm.prior[i]; pr[8 + i] = Fm.delta_prior[i]; }
   int rc = ensure_scratch(ctx, sizeof(pr));
   if (rc) return rc;
   SDSO_HIP(ctx, hipMemcpyAsync(ctx->scratch, pr, sizeof(pr), hipMemcpyHostToDevice, ctx->stream));
-  hipLaunchKernelGGL(k_ba_marg_frame, dim3(1), dim3(256), 0, ctx->stream, (const BaDev*)W->d_self, idx, (const double*)ctx->scratch, W->d_marg);
+  const double* srcH = W->marg_chain ? W->d_marg : W->dt_HM;
+  const double* srcb = W->marg_chain ? W->d_marg + (size_t)odim * odim : W->dt_bM;
+  hipLaunchKernelGGL(k_ba_marg_frame, dim3(1), dim3(256), 0, ctx->stream, srcH, srcb, odim, idx, (const double*)ctx->scratch, W->d_marg2);
   SDSO_HIP(ctx, hipGetLastError());
+  std::swap(W->d_marg, W->d_marg2);
+  W->marg_frames.erase(W->marg_frames.begin() + idx);
+  W->marg_chain = true;
   W->marg_dim = m;
   SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));     // (pr is stack-local)
   if (HM_out) SDSO_HIP(ctx, hipMemcpy(HM_out, W->d_marg, sizeof(double) * m * m, hipMemcpyDeviceToHost));
@@ -1622,7 +1640,8 @@ extern "C" int sdso_ba_marginalize_frame_dev(sdso_ctx* ctx, int win, int idx, do
 
 // The next window takes over the prior sdso_ba_marginalize_frame_dev left in `from_win`: device to device, the new keyframe's 8 rows /
 // columns zero — what EnergyFunctional::insertFrame does to HM / bM (EnergyFunctional.cpp:468-476: conservativeResize + setZero of the new
-// rows and columns).  `win` must have been uploaded with HM = bM = NULL (zeros) and hold at least as many frames as the prior covers.
+// rows and columns).  `win` must have been uploaded with HM = bM = NULL (zeros) and its LEADING frames must be the frames the prior covers,
+// in the same order (checked by frameID): a prior attached to other frames is an error, never a silent result.
 __global__ __launch_bounds__(256) void k_ba_prior_adopt(double* __restrict__ HM, double* __restrict__ bM, int n, const double* __restrict__ src, int m) {
   for (int e = blockIdx.x * 256 + threadIdx.x; e < n * n + n; e += gridDim.x * 256) {
     if (e < n * n) { const int i = e / n, j = e - i * n; HM[e] = (i < m && j < m) ? src[(size_t)i * m + j] : 0.0; }
@@ -1634,12 +1653,17 @@ extern "C" int sdso_ba_adopt_prior(sdso_ctx* ctx, int win, int from_win) {
   BaWindowDev* F = find_win(ctx, from_win);
   SDSO_REQUIRE(ctx, F && F->d_marg && F->marg_dim > 0, "the source window holds no marginalised prior (sdso_ba_marginalize_frame_dev first)");
   SDSO_REQUIRE(ctx, F != W, "a window cannot adopt its own prior");
-  const int n = W->d.n, m = F->marg_dim;
-  SDSO_REQUIRE(ctx, m <= n, "the prior covers more frames than the window holds");
+  const int n = W->d.n, m = F->marg_dim, k = (int)F->marg_frames.size();
+  SDSO_REQUIRE(ctx, m == 8 * k + 4 && m <= n, "the prior covers more frames than the window holds");
+  SDSO_REQUIRE(ctx, W->prior_pristine, "the adopting window must have been uploaded with HM = bM = NULL and not have changed its prior since");
+  for (int i = 0; i < k; i++)
+    SDSO_REQUIRE(ctx, W->frames[i].frameID == F->frames[F->marg_frames[i]].frameID, "the window's leading frames are not the frames the prior covers (frameID mismatch)");
   hipLaunchKernelGGL(k_ba_prior_adopt, dim3(8), dim3(256), 0, ctx->stream, W->dt_HM, W->dt_bM, n, (const double*)F->d_marg, m);
   SDSO_HIP(ctx, hipGetLastError());
   W->hm_host_valid = false;
   W->accumulated = false;
+  W->prior_pristine = false;
+  W->marg_chain = false;
   return SDSO_OK;
 }
 
@@ -1709,7 +1733,7 @@ static int opt_begin(sdso_ctx* ctx, OptRun& R, int stop_on_convergence) {
   R.momentum = R.W[0]->solverMode & (SOLVER_MOMENTUM | SOLVER_STEPMOMENTUM);
   R.nranks = comm_nranks(ctx);
   // SDSO_OPT_FORCE_EXCHANGE: take the pack / all-gather path on a 1-rank communicator too (tests: the collectives of a 1-GPU box)
-  R.exchange = !R.local_only && (R.nranks > 1 || (comm_present(ctx) && getenv("SDSO_OPT_FORCE_EXCHANGE") != nullptr));
+  R.exchange = !R.local_only && (R.nranks > 1 || (comm_present(ctx) && dbg_env("SDSO_OPT_FORCE_EXCHANGE") != nullptr));
   R.gated = !R.W[0]->forceAccept;
   if (R.exchange) { int rc = comm_max_int(ctx, &cap); if (rc) return rc; }
   R.cap = cap;
@@ -1960,7 +1984,7 @@ static int opt_solve_step(sdso_ctx* ctx, OptRun& R, double lambda, int orth, boo
     // the points' back-substitution and step inside the tail kernel (TAIL_RESUB) once every CU has a tail workgroup anyway: 143 -> 132 us
     // for the two at 256 windows; below that the separate kernel spreads a window's points over idle CUs (one window: 0.64 against
     // 0.70 ms per optimize).  SDSO_BA_TAIL_RESUB=0 / 1 forces one form (A/B)
-    static const int fuse_env = getenv("SDSO_BA_TAIL_RESUB") ? atoi(getenv("SDSO_BA_TAIL_RESUB")) : -1;
+    static const int fuse_env = dbg_env("SDSO_BA_TAIL_RESUB") ? atoi(dbg_env("SDSO_BA_TAIL_RESUB")) : -1;
     const bool fuse_resub = fuse_env >= 0 ? fuse_env != 0 : nwin >= ctx->n_cu;
     launch_tail(ctx, R.L, lambda, flags | TAIL_STEP | (fuse_resub ? TAIL_RESUB : 0), R.iteration, 0, R.stop);
     if (R.L.max_nblk_pts && !fuse_resub) { ProfScope ps(ctx, "k_ba_resub", 2); LAUNCH_RESUB_STEP(R.L, gp, dim3(BA_BLOCK), 0, ctx->stream, R.L.d_arr, R.iteration + 1, (float*)nullptr, 0); }

@@ -756,11 +756,13 @@ __global__ __launch_bounds__(256) void k_ba_prior_orth(const BaDev* __restrict__
 // go to the end (step 1), its prior is added (step 2), the system is scaled by 1 / sqrt(|diag| + 10), the 8 x 8 corner inverted, the Schur
 // complement taken and the scaling undone (step 3), the result symmetrised.  One 256-thread workgroup, everything f64 in LDS; every sum
 // runs over its 8 terms in index order, the inverse is the partial-pivoting elimination of sdso_ba_marginalize_frame (the host statement
-// of the same function: bit-identical results).  pr8: EFFrame::prior (8) then delta_prior (8).  out: (n - 8)^2 row-major, then n - 8.
+// of the same function: bit-identical results).  HMs / bMs: the prior it starts from, odim x odim row-major and odim — the window's resident
+// prior, or the result of the previous call when several frames leave at one keyframe (FullSystem.cpp:1470-1476 marginalises every
+// flagged frame in a loop).  idx: the frame's position among the frames that prior covers.  pr8: EFFrame::prior (8) then delta_prior (8).
+// out: (odim - 8)^2 row-major, then odim - 8.
 constexpr int MF_MAXN = 68;
-__global__ __launch_bounds__(256) void k_ba_marg_frame(const BaDev* __restrict__ wins, int idx, const double* __restrict__ pr8, double* __restrict__ out) {
-  const BaDev& B = wins[0];
-  const int odim = B.n, ndim = odim - 8, tid = threadIdx.x;
+__global__ __launch_bounds__(256) void k_ba_marg_frame(const double* __restrict__ HMs, const double* __restrict__ bMs, int odim, int idx, const double* __restrict__ pr8, double* __restrict__ out) {
+  const int ndim = odim - 8, tid = threadIdx.x;
   __shared__ double H[MF_MAXN * MF_MAXN], b[MF_MAXN], S[MF_MAXN], Si[MF_MAXN], bli[(MF_MAXN - 8) * 8], inv[64];
   __shared__ int ord[MF_MAXN];
   if (tid < odim) {
@@ -768,8 +770,8 @@ __global__ __launch_bounds__(256) void k_ba_marg_frame(const BaDev* __restrict__
     ord[tid] = tid < lo ? tid : tid < ndim ? tid + 8 : lo + (tid - ndim);     // the others keep their order, the frame's 8 follow
   }
   __syncthreads();
-  for (int e = tid; e < odim * odim; e += 256) { const int i = e / odim, j = e - i * odim; H[e] = B.t_HM[(size_t)ord[i] * odim + ord[j]]; }
-  if (tid < odim) b[tid] = B.t_bM[ord[tid]];
+  for (int e = tid; e < odim * odim; e += 256) { const int i = e / odim, j = e - i * odim; H[e] = HMs[(size_t)ord[i] * odim + ord[j]]; }
+  if (tid < odim) b[tid] = bMs[ord[tid]];
   __syncthreads();
   if (tid < 8) { H[(ndim + tid) * odim + ndim + tid] += pr8[tid]; b[ndim + tid] += pr8[tid] * pr8[8 + tid]; }
   __syncthreads();

@@ -274,6 +274,7 @@ extern "C" int sdso_ba_allreduce(sdso_ctx* ctx) {
   size_t n = 0;
   void* p = ba_batch_accum_block(ctx, &n);
   SDSO_REQUIRE(ctx, p, "no batch: sdso_ba_batch_create first");
+  ProfScope ps(ctx, "sdso_ba_allreduce", 2);   // (level-2 profiling: HIP events around the exchange on the ctx stream — bench.py's extra.exchange_ms_per_step)
   if (ba_batch_scatter_wanted(ctx)) {
     const int rc = reduce_scatter_block(ctx, p, n);
     if (rc == SDSO_OK) ba_batch_scatter_done(ctx);      // a failed exchange leaves the batch as it was (sdso_ba_batch_solve still refuses nothing)

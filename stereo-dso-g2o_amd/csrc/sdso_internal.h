@@ -116,6 +116,13 @@ inline int fail(sdso_ctx* ctx, int code, const std::string& msg) {
 
 int ensure_scratch(sdso_ctx* ctx, size_t bytes);
 // Bracket the launches of one named kernel with HIP events when profiling is enabled.
+// The A/B and diagnostic switches of the library (SDSO_BA_*, SDSO_TRK_*, SDSO_OPT_*, SDSO_PROF_BRACKET) exist only under SDSO_DEBUG_ENV=1,
+// which is read ONCE per process: without it no environment variable changes what the library computes or launches, and no call reads
+// the environment.  (tests/conftest.py sets the gate: the variant tests flip switches per call; bench.py does not.)
+inline const char* dbg_env(const char* name) {
+  static const bool on = [] { const char* g = getenv("SDSO_DEBUG_ENV"); return g && atoi(g) != 0; }();
+  return on ? getenv(name) : nullptr;
+}
 struct ProfScope {
   sdso_ctx* ctx;
   hipEvent_t a = nullptr, b = nullptr;
@@ -137,7 +144,7 @@ struct ProfScope {
 // SDSO_PROF_BRACKET=1: the old record / launch / record bracket.
 template <typename K, typename... A>
 inline void launch_timed(sdso_ctx* ctx, const char* name, int level, K kernel, const dim3& grid, const dim3& block, A... args) {
-  static const bool bracket = getenv("SDSO_PROF_BRACKET") != nullptr;
+  static const bool bracket = dbg_env("SDSO_PROF_BRACKET") != nullptr;
   if (ctx->prof_on >= level && !bracket) {
     hipEvent_t ea = nullptr, eb = nullptr;
     hipEventCreate(&ea); hipEventCreate(&eb);

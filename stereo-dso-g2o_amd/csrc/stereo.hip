@@ -868,13 +868,13 @@ extern "C" int sdso_stereo_match_batch(sdso_ctx* ctx, int slot_a, int slot_b, co
   hipLaunchKernelGGL(k_match_prepare, g1, b1, 0, ctx->stream, n, d_in[0], d_in[1], d_in[2], d_in[3], A.T);
   hipLaunchKernelGGL(k_immature_init, g1, b1, 0, ctx->stream, ia->second.d[0], w, n, (const float*)A.T.u_stereo, (const float*)A.T.v_stereo,
                      (float*)A.T.color, (float*)A.T.weights, (float*)A.T.gradH, (float*)A.T.energyTH);
-  launch_trace_stereo(ctx, A.T);
+  launch_trace_stereo(ctx, A.T, true);      // (timed under k_trace_stereo when profiling is on: the match chain's two traces)
   hipLaunchKernelGGL(k_match_back_points, g1, b1, 0, ctx->stream, n, A.T, Bk.T, skip, d_in[4], d_in[5]);
   hipLaunchKernelGGL(k_immature_init, g1, b1, 0, ctx->stream, ib->second.d[0], w, n, (const float*)Bk.T.u_stereo, (const float*)Bk.T.v_stereo,
                      (float*)Bk.T.color, (float*)Bk.T.weights, (float*)Bk.T.gradH, (float*)Bk.T.energyTH);
   TraceDev Tb = Bk.T;
   Tb.skip = skip;
-  launch_trace_stereo(ctx, Tb);
+  launch_trace_stereo(ctx, Tb, true);
   SDSO_HIP(ctx, hipGetLastError());
 #define DN(dst, src, cnt) if (dst) SDSO_HIP(ctx, hipMemcpyAsync((dst), (src), sizeof(float) * (size_t)(cnt), hipMemcpyDeviceToHost, ctx->stream))
   DN(M->idepth_stereo, A.T.idepth_stereo, n); DN(M->idepth_min_out, A.T.idepth_min_stereo, n); DN(M->idepth_max_out, A.T.idepth_max_stereo, n);

@@ -420,7 +420,7 @@ static int choose_gx(const sdso_ctx* ctx, int nprob, int maxn) {
   // few, fat workgroups: the per-workgroup epilogue (48-value reduction, partial stores) is amortised over several
   // loop trips (measured on 640 problems: gx 10 -> 65 us, 4 -> 62 us, 1 -> 71 us)
   int gx = std::max(1, std::min(by_points, target));
-  if (const char* e = getenv("SDSO_TRK_GX")) gx = std::max(1, std::min(by_points, atoi(e)));   // experiment
+  if (const char* e = dbg_env("SDSO_TRK_GX")) gx = std::max(1, std::min(by_points, atoi(e)));   // experiment
   return gx;
 }
 
@@ -1290,7 +1290,7 @@ extern "C" int sdso_track_newest_coarse_batch(sdso_ctx* ctx, int nhyp, const int
   SDSO_REQUIRE(ctx, nhyp > 0 && ref_slots && frame_slots && prms && lastToNew && aff_g2l && outs, "null argument");
   for (int k = 0; k < nhyp; k++)
     SDSO_REQUIRE(ctx, prms[k].coarsestLvl >= 0 && prms[k].coarsestLvl < 5 && prms[k].coarsestLvl < prms[k].levels, "coarsestLvl out of range");  // assert :853
-  static const bool host_lm = getenv("SDSO_TRK_HOST_LM") != nullptr;
+  static const bool host_lm = dbg_env("SDSO_TRK_HOST_LM") != nullptr;
   if (host_lm) return track_newest_coarse_host(ctx, nhyp, ref_slots, frame_slots, prms, lastToNew, aff_g2l, outs);
   // resident driver: jobs through pinned memory, one launch, one synchronisation.  The cluster records are the library's own allocation
   // and are never cleared between calls (tags, see LmCluster).  (The kernel reading the jobs in pinned host memory directly, without
@@ -1322,16 +1322,16 @@ extern "C" int sdso_track_newest_coarse_batch(sdso_ctx* ctx, int nhyp, const int
   LmCluster* dc = (LmCluster*)ctx->lm_clusters;
   // workgroups per hypothesis: as many as keep the whole grid resident at once (the members of a cluster wait for each other; one
   // 512-thread workgroup of this kernel fills a CU), eight at most.  SDSO_TRK_LM_CLUSTER=1 forces single workgroups.
-  const int g_env = getenv("SDSO_TRK_LM_CLUSTER") ? atoi(getenv("SDSO_TRK_LM_CLUSTER")) : 0;   // (read per call: the tests walk the cluster sizes)
+  const int g_env = dbg_env("SDSO_TRK_LM_CLUSTER") ? atoi(dbg_env("SDSO_TRK_LM_CLUSTER")) : 0;   // (read per call: the tests walk the cluster sizes)
   const int slots8 = 8 * ((nhyp + 7) / 8);
   int G = std::min(LM_MAXG, (ctx->n_cu * 7 / 8) / slots8);   // (an eighth of the CUs stays free: a grid that needs every CU waits on any straggler)
   if (g_env > 0) G = std::min(G, g_env);
   if (G < 2) G = 1;
-  const int solo_n = getenv("SDSO_TRK_LM_SOLO") ? atoi(getenv("SDSO_TRK_LM_SOLO")) : LM_UNROLL * LM_BLOCK;
+  const int solo_n = dbg_env("SDSO_TRK_LM_SOLO") ? atoi(dbg_env("SDSO_TRK_LM_SOLO")) : LM_UNROLL * LM_BLOCK;
 #ifdef SDSO_TEST_HOOKS
   // test hook, compiled into libsdso_hip_hooks.so only (csrc/Makefile; tests/test_variants_gpu.py): the first attempt loses one member of
   // every cluster, with a short spin limit — the call must come back through the single-workgroup repetition with its result
-  const bool drop = getenv("SDSO_TRK_LM_TEST_DROP_MEMBER") != nullptr;
+  const bool drop = dbg_env("SDSO_TRK_LM_TEST_DROP_MEMBER") != nullptr;
 #else
   const bool drop = false;
 #endif

@@ -3,6 +3,10 @@ import sys
 
 import pytest
 
+# the library's A/B / diagnostic switches (SDSO_BA_*, SDSO_TRK_* ...) exist only behind this gate, read once per process (csrc/sdso_internal.h:
+# dbg_env); the variant tests flip such switches, so the test processes — and the subprocesses they start — run with it on
+os.environ.setdefault("SDSO_DEBUG_ENV", "1")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "stereo-dso-g2o_amd"))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))

@@ -1,6 +1,7 @@
 """resident loop vs host-driven loop vs oracle (f32 / f64 sums) at configs[2] with a momentum bit: final pose states."""
 import ctypes as C
 import os
+os.environ.setdefault("SDSO_DEBUG_ENV", "1")   # the library reads its A/B switches only behind this gate
 import sys
 
 import numpy as np

@@ -5,6 +5,7 @@ Prints one line per window and the summary the test asserts on (tests/test_ba_f6
   python tests/diag/truth_spread.py [n_windows]     (SDSO_BA_TAIL=0: the round-2 tail kernels)"""
 import ctypes as C
 import os
+os.environ.setdefault("SDSO_DEBUG_ENV", "1")   # the library reads its A/B switches only behind this gate
 import sys
 
 import numpy as np

@@ -156,10 +156,11 @@ def test_solve_requires_accumulate_and_arg_errors(gpu_ctx, oracle, win_small):
     x = np.zeros(n)
     assert gpu_ctx.L.sdso_ba_solve(gpu_ctx.h, 5, 0, 0.1, abi.dp(x), None, None, None, None) == -1
     assert gpu_ctx.L.sdso_ba_linearize(gpu_ctx.h, 999, None) == -1
-    bad = dict(win_small)
-    bad["solverMode"] = 128 | 512  # SOLVER_MOMENTUM: a bit solveSystemF never reads -> refused, not silently ignored
-    Wb, kb = abi.make_ba_window(bad, frame_slots=[40 + f for f in range(bad["nf"])])
-    assert gpu_ctx.L.sdso_ba_upload_window(gpu_ctx.h, 6, C.byref(Wb)) == -1
+    ok = dict(win_small)
+    ok["solverMode"] = 128 | 512 | 1024 | 4 | 8  # the bits outside solveSystemF are accepted since round 6 (tests/test_ba_solver_bits_gpu.py)
+    Wb, kb = abi.make_ba_window(ok, frame_slots=[40 + f for f in range(ok["nf"])])
+    assert gpu_ctx.L.sdso_ba_upload_window(gpu_ctx.h, 6, C.byref(Wb)) == 0
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_release_window(gpu_ctx.h, 6))
     bad = dict(win_small)
     bad["host"] = win_small["host"][::-1].copy()      # not in allPoints order
     Wb, kb = abi.make_ba_window(bad, frame_slots=[40 + f for f in range(bad["nf"])])

@@ -253,3 +253,62 @@ def test_marginalize_frame_on_the_device_resident_prior(gpu_ctx, oracle, win_c3)
     assert np.abs(xs[0][0]).max() > 0 and np.array_equal(xs[0][0], xs[1][0]) and np.array_equal(xs[0][1], xs[1][1])
     assert ctx.L.sdso_ba_adopt_prior(ctx.h, 22, 22) == -1 and ctx.L.sdso_ba_marginalize_frame_dev(ctx.h, 22, 9, None, None) == -1
     ctx.check(ctx.L.sdso_ba_release_window(ctx.h, 21)); ctx.check(ctx.L.sdso_ba_release_window(ctx.h, 22))
+
+
+def test_two_frames_leave_at_one_keyframe_on_the_device(gpu_ctx, win_c3):
+    """FullSystem::makeKeyFrame marginalises EVERY flagged frame (FullSystem.cpp:1470-1476), each on the prior the previous call left and with
+    EFFrame::idx counted after the earlier erase.  On the device: two sdso_ba_marginalize_frame_dev calls in a row chain on the resident
+    result, bit-identical to two calls of the host statement (sdso_ba_marginalize_frame); sdso_ba_marginalize_points in between restarts
+    from the window's prior; sdso_ba_adopt_prior checks by frameID that the adopting window's leading frames are the surviving ones
+    (round-5 advisor finding: a prior attached to other frames was accepted silently)."""
+    import helpers
+    ctx = gpu_ctx
+    win = dict(win_c3)
+    nf, npts, n = win["nf"], win["np"], 8 * win["nf"] + 4
+    A = np.random.RandomState(15).normal(size=(n, 9))
+    win["HM"] = (A @ A.T) * 1e4
+    win["bM"] = np.random.RandomState(16).normal(size=n) * 1e2
+    for f in range(nf):
+        ctx.upload_pyramid(40 + f, win["pyrs"][f][:1])
+    W, keep = abi.make_ba_window(win, frame_slots=[40 + f for f in range(nf)], dI_list=[p[0] for p in win["pyrs"]])
+    ctx.check(ctx.L.sdso_ba_upload_window(ctx.h, 23, C.byref(W)))
+    st = np.asarray(win["state"], np.float64).reshape(nf, 10)
+    prior0 = np.array([1e10] * 3 + [1e11] * 3 + [1e14, 1e14], np.float32).astype(np.float64)      # frameID 0 (HessianBlocks.h:239-265)
+    assert win["frameID"][0] == 0 and win["frameID"][3] != 0
+    priork = np.zeros(8)
+    priork[6:] = [win["affineOptModeA"], win["affineOptModeB"]]                                    # setting_affineOptModeA / B as the window carries them (HessianBlocks.h:250-258)
+    # frame 0 leaves, then the frame that was at index 3 (index 2 of what is left)
+    m1, m2 = n - 8, n - 16
+    H1, b1, H2, b2 = np.zeros((m1, m1)), np.zeros(m1), np.zeros((m2, m2)), np.zeros(m2)
+    ctx.check(ctx.L.sdso_ba_marginalize_frame_dev(ctx.h, 23, 0, abi.dp(H1), abi.dp(b1)))
+    assert ctx.L.sdso_ba_marginalize_frame_dev(ctx.h, 23, 7, None, None) == -1                      # seven frames are left: indices 0..6
+    ctx.check(ctx.L.sdso_ba_marginalize_frame_dev(ctx.h, 23, 2, abi.dp(H2), abi.dp(b2)))
+    Hh1, bh1, Hh2, bh2 = np.zeros((m1, m1)), np.zeros(m1), np.zeros((m2, m2)), np.zeros(m2)
+    HM0, bM0 = np.ascontiguousarray(win["HM"], np.float64), np.ascontiguousarray(win["bM"], np.float64)
+    assert ctx.L.sdso_ba_marginalize_frame(nf, 0, abi.dp(prior0), abi.dp(np.ascontiguousarray(st[0, :8])), abi.dp(HM0), abi.dp(bM0), abi.dp(Hh1), abi.dp(bh1)) == 0
+    assert ctx.L.sdso_ba_marginalize_frame(nf - 1, 2, abi.dp(priork), abi.dp(np.ascontiguousarray(st[3, :8])), abi.dp(Hh1), abi.dp(bh1), abi.dp(Hh2), abi.dp(bh2)) == 0
+    assert np.array_equal(H1, Hh1) and np.array_equal(b1, bh1)
+    assert np.array_equal(H2, Hh2) and np.array_equal(b2, bh2) and np.abs(H2).max() > 0
+    # the next window: the six surviving keyframes (+ nothing new); leading frames checked by frameID
+    w2 = helpers.drop_frame(helpers.drop_frame(win, 0), 2)
+    for f in range(w2["nf"]):
+        ctx.upload_pyramid(60 + f, w2["pyrs"][f][:1])
+    W2, keep2 = abi.make_ba_window(w2, frame_slots=[60 + f for f in range(w2["nf"])], dI_list=[p[0] for p in w2["pyrs"]])
+    ctx.check(ctx.L.sdso_ba_upload_window(ctx.h, 24, C.byref(W2)))
+    ctx.check(ctx.L.sdso_ba_adopt_prior(ctx.h, 24, 23))
+    assert ctx.L.sdso_ba_adopt_prior(ctx.h, 24, 23) == -1                                           # its prior is no longer the uploaded zero
+    HMa, bMa = np.zeros((m2, m2)), np.zeros(m2)
+    ctx.check(ctx.L.sdso_ba_marginalize_points(ctx.h, 24, abi.bp(np.zeros(w2["np"], np.uint8)), abi.dp(HMa), abi.dp(bMa)))   # nothing flagged: the prior, copied out
+    assert np.array_equal(HMa, H2) and np.array_equal(bMa, b2)
+    # a window whose leading frames are NOT the survivors (frame 1 dropped instead of frame 0) is refused
+    w3 = helpers.drop_frame(helpers.drop_frame(win, 1), 2)
+    W3, keep3 = abi.make_ba_window(w3, frame_slots=[60 + f for f in range(w3["nf"])], dI_list=[p[0] for p in w3["pyrs"]])
+    ctx.check(ctx.L.sdso_ba_upload_window(ctx.h, 25, C.byref(W3)))
+    assert ctx.L.sdso_ba_adopt_prior(ctx.h, 25, 23) == -1
+    # sdso_ba_marginalize_points restarts the chain from the window's own prior
+    ctx.check(ctx.L.sdso_ba_marginalize_points(ctx.h, 23, abi.bp(np.zeros(npts, np.uint8)), None, None))
+    H1b, b1b = np.zeros((m1, m1)), np.zeros(m1)
+    ctx.check(ctx.L.sdso_ba_marginalize_frame_dev(ctx.h, 23, 0, abi.dp(H1b), abi.dp(b1b)))
+    assert np.array_equal(H1b, H1) and np.array_equal(b1b, b1)
+    for wid in (23, 24, 25):
+        ctx.check(ctx.L.sdso_ba_release_window(ctx.h, wid))

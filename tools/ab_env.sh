@@ -1,5 +1,6 @@
 #!/bin/bash
 # A/B of environment variants of the default BA bench: tools/ab_env.sh "VAR=1 VAR2=x" "..." ; prints ms/step and the kernel averages (HIP events)
+export SDSO_DEBUG_ENV=1   # the library reads its A/B switches only behind this gate
 for spec in "$@"; do
   env $spec SDSO_BENCH_SKIP_OTHERS=1 timeout -k 10 200 python bench.py --steps 30 --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys

@@ -1,5 +1,6 @@
 #!/bin/bash
 # step time of the default BA bench against the number of stream groups / the chaining of their accumulate phases
+export SDSO_DEBUG_ENV=1   # the library reads its A/B switches only behind this gate
 mkdir -p gpurun_out
 for g in ${GROUPS_LIST:-1 2 3 4}; do
   for nc in 0 1; do

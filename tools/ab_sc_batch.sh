@@ -1,4 +1,5 @@
 for b in 64 96 128 192; do for w in 1 0; do
+export SDSO_DEBUG_ENV=1   # the library reads its A/B switches only behind this gate
 SDSO_BA_SC_WPH=$w SDSO_BENCH_SKIP_OTHERS=1 timeout -k 10 200 python bench.py --steps 30 --batch $b --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); e=d['extra']

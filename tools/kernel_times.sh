@@ -1,5 +1,6 @@
 #!/bin/bash
 # per-kernel average durations of the default bench (rocprofv3 --kernel-trace --stats), printed as a short table
+export SDSO_DEBUG_ENV=1   # the library reads its A/B switches only behind this gate
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/kt_$1
 shift

@@ -1,5 +1,6 @@
 #!/bin/bash
 # kernel table of the default BA bench (two groups) and of the single-stream run: tools/kt_quick.sh
+export SDSO_DEBUG_ENV=1   # the library reads its A/B switches only behind this gate
 root=${GRAFT_REPO_ROOT:-/root/repo}
 export TMPDIR=/tmp
 cd /tmp

@@ -1,5 +1,6 @@
 #!/bin/bash
 # durations of the successive k_ba_lin_fused launches of the default bench under rocprofv3 --kernel-trace: tools/lin_durations.sh tag [ENV=..]
+export SDSO_DEBUG_ENV=1   # the library reads its A/B switches only behind this gate
 cd /tmp && export TMPDIR=/tmp
 tag=$1; shift
 OUT=$GRAFT_REPO_ROOT/gpurun_out/ld_$tag

@@ -2,6 +2,7 @@
 upload included / excluded) and a batch of windows through sdso_ba_batch_optimize."""
 import ctypes as C
 import os
+os.environ.setdefault("SDSO_DEBUG_ENV", "1")   # the library reads its A/B switches only behind this gate
 import sys
 import time
 
