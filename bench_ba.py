@@ -82,6 +82,12 @@ class BAWorkload:
         for g in range(ngroups):
             G = _Group()
             G.ctx = ctx if g == 0 else abi.Context(device)
+            # SDSO_BA_CUMASK="k[,stride]": k CUs of every group's ctx for its Schur + tail kernels (aux stream), the rest for the linearisations
+            # (sdso_ctx_partition_cus) — with two or more chained groups the tail of one runs beside the linearisation of the next
+            cm = os.environ.get("SDSO_BA_CUMASK")
+            if cm:
+                kk = [int(v) for v in cm.split(",")]
+                G.ctx.check(G.ctx.L.sdso_ctx_partition_cus(G.ctx.h, kk[0], kk[1] if len(kk) > 1 else 0))
             lo, hi = g * nwin // ngroups, (g + 1) * nwin // ngroups
             ids = []
             for k in range(lo, hi):
@@ -195,6 +201,7 @@ class BAWorkload:
         self.config = {"workload": self.name, "windows_per_step": nwin, "keyframes": nf, "points_per_window_per_gpu": win["np"],
                        "residuals_per_window_per_gpu": win["nr"], "points_per_global_window": self.win_global["np"],
                        "jacobians_materialized": bool(self.materialize), "stream_groups": ngroups,
+                       "cu_partition": os.environ.get("SDSO_BA_CUMASK") or None,
                        "allreduce_floats": nfl_total if world > 1 else 0, "exchange": getattr(self, "exchange", None),
                        "rccl_ranks": self.comm_ranks, "launcher_world_size": world,
                        "exchange_shape": ("reduce-scatter by window + all-gather of x" if getattr(self, "exchange_mode", 0) else "all-reduce, solve on every rank") if world > 1 else None,

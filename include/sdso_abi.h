@@ -51,6 +51,12 @@ const char* sdso_last_error(const sdso_ctx* ctx);
 /* the HIP stream (hipStream_t) all kernels of this ctx are launched on */
 void* sdso_ctx_stream(sdso_ctx* ctx);
 int sdso_ctx_sync(sdso_ctx* ctx);
+/* Split the device's CUs between two streams of the ctx (hipExtStreamCreateWithCUMask): aux_cus of them for the Schur accumulation and the
+ * fused tail kernel of a batch's GN iteration (sdso_ba_batch_schur / sdso_ba_batch_solve_step), the rest for everything else — so that the
+ * tail of one ctx's batch owns its CUs while another ctx's linearisation streams on the others.  stride 0: the lowest CU indices; stride s:
+ * an equal share out of every s indices.  aux_cus 0 removes the partition.  Streams are re-created: call before sdso_ctx_stream is used.
+ * No counterpart in the reference (a schedule); results are bit-identical with and without it. */
+int sdso_ctx_partition_cus(sdso_ctx* ctx, int aux_cus, int stride);
 
 /* Optional kernel timing with HIP events recorded on the ctx stream around launches.  on = 1: the dominant kernel of each workload
  * ("k_track_eval", "k_track_lm", "k_ba_lin_fused", "k_ba_linearize", "k_trace_stereo", ...); on = 2: also the secondary ones

@@ -608,7 +608,8 @@ static bool launch_sc_and_folds(sdso_ctx* ctx, const BaLaunch& L, const uint8_t*
     // CU (measured, µs, workgroup / wave form: 64 windows 34 / 66, 128: 60 / 69, 192: 76 / 93, 256: 104 / 100 — profiles/r05_sc_batch_ab.txt);
     // SDSO_BA_SC_WPH=0 / 1 forces one form (A/B)
     static const int wph_env = dbg_env("SDSO_BA_SC_WPH") ? atoi(dbg_env("SDSO_BA_SC_WPH")) : -1;
-    const bool wph = wph_env >= 0 ? wph_env != 0 : 2 * nf * L.nwin > 15 * ctx->n_cu;
+    const int cus = (ctx->aux && ctx->stream == ctx->aux) ? ctx->aux_cus : ctx->n_cu;     // the CUs this launch may use (CU-partitioned ctx: the aux share)
+    const bool wph = wph_env >= 0 ? wph_env != 0 : 2 * nf * L.nwin > 10 * cus;   // (two workgroups per CU since the f64 accumulators: 2.5 rounds)
     const dim3 g(wph ? (nf + BA_BLOCK / 64 - 1) / (BA_BLOCK / 64) : nf, L.nwin);
     if (plain) { if (wph) hipLaunchKernelGGL((k_ba_sc_host<true, true>), g, dim3(BA_BLOCK), 0, ctx->stream, L.d_arr, pflag, shift, mm, clear_l);
                  else hipLaunchKernelGGL((k_ba_sc_host<true, false>), g, dim3(BA_BLOCK), 0, ctx->stream, L.d_arr, pflag, shift, mm, clear_l); }
@@ -1480,6 +1481,24 @@ extern "C" int sdso_ba_batch_accumulate(sdso_ctx* ctx) {
 // the two halves of sdso_ba_batch_accumulate as separate enqueues, for callers that overlap batches on several streams: the
 // bandwidth-bound linearisation of one batch is best followed immediately by the linearisation of the next one, with the Schur
 // accumulation and the folds of the first running underneath it
+// CU-partitioned ctx (sdso_ctx_partition_cus): the launches inside the scope go to the ctx's aux stream, ordered behind everything the main
+// stream holds so far; at the end of the scope the main stream is ordered behind them again (its next consumer — the next linearisation of
+// THIS batch — needs their results anyway; another ctx's linearisation, on its own stream with the same large CU mask, does not wait).
+struct AuxScope {
+  sdso_ctx* ctx; hipStream_t main = nullptr;
+  explicit AuxScope(sdso_ctx* c) : ctx(c) {
+    if (!ctx->aux) return;
+    hipEventRecord(ctx->ev_main, ctx->stream);
+    hipStreamWaitEvent(ctx->aux, ctx->ev_main, 0);
+    main = ctx->stream; ctx->stream = ctx->aux;
+  }
+  ~AuxScope() {
+    if (!main) return;
+    hipEventRecord(ctx->ev_aux, ctx->aux);
+    ctx->stream = main;
+    hipStreamWaitEvent(ctx->stream, ctx->ev_aux, 0);
+  }
+};
 extern "C" int sdso_ba_batch_linearize(sdso_ctx* ctx) {
   BaBatch* Bt = get_batch(ctx);
   if (!Bt) return sdso::fail(ctx, SDSO_ERR_STATE, "no batch");
@@ -1492,6 +1511,7 @@ extern "C" int sdso_ba_batch_schur(sdso_ctx* ctx) {
   BaBatch* Bt = get_batch(ctx);
   if (!Bt) return sdso::fail(ctx, SDSO_ERR_STATE, "no batch");
   Bt->scattered = false;
+  AuxScope aux(ctx);
   Bt->folded = launch_fused(ctx, batch_launch(Bt), Bt->materialize, 2, batch_defers_fold(ctx, Bt));
   SDSO_HIP(ctx, hipGetLastError());
   return SDSO_OK;
@@ -1985,7 +2005,7 @@ static int opt_solve_step(sdso_ctx* ctx, OptRun& R, double lambda, int orth, boo
     // for the two at 256 windows; below that the separate kernel spreads a window's points over idle CUs (one window: 0.64 against
     // 0.70 ms per optimize).  SDSO_BA_TAIL_RESUB=0 / 1 forces one form (A/B)
     static const int fuse_env = dbg_env("SDSO_BA_TAIL_RESUB") ? atoi(dbg_env("SDSO_BA_TAIL_RESUB")) : -1;
-    const bool fuse_resub = fuse_env >= 0 ? fuse_env != 0 : nwin >= ctx->n_cu;
+    const bool fuse_resub = fuse_env >= 0 ? fuse_env != 0 : nwin >= (ctx->aux ? ctx->aux_cus : ctx->n_cu);   // (the CUs this launch may use)
     launch_tail(ctx, R.L, lambda, flags | TAIL_STEP | (fuse_resub ? TAIL_RESUB : 0), R.iteration, 0, R.stop);
     if (R.L.max_nblk_pts && !fuse_resub) { ProfScope ps(ctx, "k_ba_resub", 2); LAUNCH_RESUB_STEP(R.L, gp, dim3(BA_BLOCK), 0, ctx->stream, R.L.d_arr, R.iteration + 1, (float*)nullptr, 0); }
     SDSO_HIP(ctx, hipGetLastError());
@@ -2112,6 +2132,7 @@ extern "C" int sdso_ba_batch_solve_step(sdso_ctx* ctx, double lambda, int orthog
   if (Bt->W[0]->solverMode & SOLVER_USE_GN) lambda = 0;
   if (Bt->W[0]->solverMode & SOLVER_FIX_LAMBDA) lambda = 1e-5;
   R->L = batch_launch(Bt);
+  AuxScope aux(ctx);
   return opt_solve_step(ctx, *R, lambda, orthogonalize_x ? 1 : 0, Bt->folded);
 }
 extern "C" int sdso_ba_batch_optimize_end(sdso_ctx* ctx, sdso_ba_opt_result_t* out) {

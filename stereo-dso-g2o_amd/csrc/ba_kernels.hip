@@ -676,6 +676,10 @@ typedef double te_d4 __attribute__((ext_vector_type(4)));
 #define SDSO_ACC_MODE 1
 #endif
 constexpr int ACC_MODE = SDSO_ACC_MODE;
+#ifndef SDSO_ACC_MODE_SC
+#define SDSO_ACC_MODE_SC SDSO_ACC_MODE
+#endif
+constexpr int ACC_MODE_SC = SDSO_ACC_MODE_SC;      // the Schur kernel's own choice (A/B: top sums in f64 MFMA, Schur sums in short fp32 chains)
 static_assert(TE_LDS_FLOATS * 4 >= ((BA_BLOCK / 64) * 256 + BA_BLOCK / 64) * 8, "the waves' f64 tiles lie over the panels");
 
 template <bool LDS_ONLY = false>
@@ -1080,7 +1084,7 @@ __global__ __launch_bounds__(BA_BLOCK, 2) void k_ba_sc_host(const BaDev* __restr
   float* const bufT = bufA + 2 * SCH_REC;
   float (*pt)[8] = reinterpret_cast<float (*)[8]>(bufT + SCH_REC);
   const int pb = B.host_pt_beg[h], pe = B.host_pt_beg[h + 1];     // (in the descriptor itself: no dependent round trip before the first DMA)
-  // the sums over the points are carried in f64 like the top sums (top_emit, ACC_MODE): a group's 16 points are one short fp32 MFMA chain
+  // the sums over the points are carried in f64 like the top sums (top_emit, ACC_MODE_SC): a group's 16 points are one short fp32 MFMA chain
   // per tile, the groups' tiles are added in f64 (mode 1: f64 MFMAs on the float operands converted exactly, (w z_a) z_b with the
   // product w z_a exact); ONE rounding to float when the bins are written
   te_d4 acc[SC_NT];
@@ -1270,7 +1274,7 @@ __global__ __launch_bounds__(BA_BLOCK, 2) void k_ba_sc_host(const BaDev* __restr
       for (int u = 0; u < 4; u++)
 #pragma unroll
         for (int tt = 0; tt < 4; tt++) zz[u][tt] = oks[u][tt] ? zz[u][tt] : 0.f;
-      if (ACC_MODE == 1) {
+      if (ACC_MODE_SC == 1) {
 #pragma unroll
         for (int u = 0; u < 4; u++) {
           double za[4], zd[4];
@@ -1283,7 +1287,7 @@ __global__ __launch_bounds__(BA_BLOCK, 2) void k_ba_sc_host(const BaDev* __restr
           }
         }
       } else {
-        if (ACC_MODE == 2) {
+        if (ACC_MODE_SC == 2) {
 #pragma unroll
           for (int t = 0; t < SC_NT; t++) grp[t] = (te_f4){0.f, 0.f, 0.f, 0.f};
         }
@@ -1298,7 +1302,7 @@ __global__ __launch_bounds__(BA_BLOCK, 2) void k_ba_sc_host(const BaDev* __restr
             for (int b = a; b < 4; b++) grp[sc_ut(a, b)] = __builtin_amdgcn_mfma_f32_16x16x4f32(za[a], zz[u][b], grp[sc_ut(a, b)], 0, 0, 0);
           }
         }
-        if (ACC_MODE == 2) {
+        if (ACC_MODE_SC == 2) {
 #pragma unroll
           for (int t = 0; t < SC_NT; t++)
 #pragma unroll
@@ -1313,14 +1317,14 @@ __global__ __launch_bounds__(BA_BLOCK, 2) void k_ba_sc_host(const BaDev* __restr
   }
   SCS();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (ACC_MODE == 0) {
+  if (ACC_MODE_SC == 0) {
 #pragma unroll
     for (int t = 0; t < SC_NT; t++)
 #pragma unroll
       for (int v = 0; v < 4; v++) acc[t][v] = (double)grp[t][v];
   }
   // ---- the host's bins from ONE wave's accumulators (WPH: this wave's; otherwise wave 0's after the tree), rounded to float: d[v] of lane
-  // (kq, ci) = D[16 a + 4 kq + v][16 b + ci] of tile (a, b) — four consecutive rows per lane (ACC_MODE 1: the f64 MFMA leaves rows
+  // (kq, ci) = D[16 a + 4 kq + v][16 b + ci] of tile (a, b) — four consecutive rows per lane (ACC_MODE_SC 1: the f64 MFMA leaves rows
   // kq + 4 v on a lane; its tiles are turned through 1 KB of LDS into that layout first).  Every (t1, t2) block of 256 bytes is covered by
   // the four stores of its tile; the blocks below the diagonal are float4s of the mirrored tile; a tile ON the diagonal takes its lower
   // triangle from the mirror image too: D(r, c) and D(c, r) differ in the last bit ((w z_r) z_c against (w z_c) z_r), and the stitch relies
@@ -1342,12 +1346,12 @@ __global__ __launch_bounds__(BA_BLOCK, 2) void k_ba_sc_host(const BaDev* __restr
           const te_d4 dd = acc[sc_ut(a, b)];
 #pragma unroll
           for (int v = 0; v < 4; v++) d[v] = (float)dd[v];
-          if (ACC_MODE == 1 || a == b) {
+          if (ACC_MODE_SC == 1 || a == b) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-            for (int v = 0; v < 4; v++) T[(ACC_MODE == 1 ? kq + 4 * v : 4 * kq + v) * 17 + ci] = d[v];
+            for (int v = 0; v < 4; v++) T[(ACC_MODE_SC == 1 ? kq + 4 * v : 4 * kq + v) * 17 + ci] = d[v];
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (ACC_MODE == 1) {
+            if (ACC_MODE_SC == 1) {
 #pragma unroll
               for (int v = 0; v < 4; v++) d[v] = T[(4 * kq + v) * 17 + ci];
             }

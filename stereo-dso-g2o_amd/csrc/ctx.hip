@@ -134,6 +134,9 @@ extern "C" void sdso_ctx_destroy(sdso_ctx* ctx) {
   if (!ctx) return;
   hipSetDevice(ctx->device);
   hipStreamSynchronize(ctx->stream);
+  if (ctx->aux) { hipStreamSynchronize(ctx->aux); hipStreamDestroy(ctx->aux); ctx->aux = nullptr; }
+  if (ctx->ev_main) hipEventDestroy(ctx->ev_main);
+  if (ctx->ev_aux) hipEventDestroy(ctx->ev_aux);
   for (auto& kv : ctx->pyr)
     { for (int l = 0; l < kv.second.levels; l++) hipFree(kv.second.d[l]); if (kv.second.tiled0) hipFree(kv.second.tiled0); if (kv.second.plane0) hipFree(kv.second.plane0); }
   for (auto& kv : ctx->refs)
@@ -155,6 +158,43 @@ extern "C" void sdso_ctx_destroy(sdso_ctx* ctx) {
 }
 extern "C" const char* sdso_last_error(const sdso_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
 extern "C" void* sdso_ctx_stream(sdso_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+// Split the device's CUs between the ctx's two streams (hipExtStreamCreateWithCUMask): the first `aux_cus` of every `stride` CU indices
+// belong to `aux`, the rest to `stream`.  Both streams are created anew (call it before sdso_ctx_stream is handed to anyone); aux_cus = 0
+// removes the partition.  The 234 us that follow the linearisation in a GN iteration (Schur accumulation: 2 waves per SIMD; fused tail:
+// one 150-KB-LDS workgroup per window) cannot co-reside with linearisation workgroups on a CU, so under plain streams two batches
+// only take turns; with a partition the tail of one batch owns its CUs while the other batch's linearisation streams on the rest.
+extern "C" int sdso_ctx_partition_cus(sdso_ctx* ctx, int aux_cus, int stride) {
+  if (!ctx) return SDSO_ERR_STATE;
+  SDSO_HIP(ctx, hipSetDevice(ctx->device));
+  SDSO_REQUIRE(ctx, aux_cus >= 0 && aux_cus < ctx->n_cu && stride >= 0, "bad CU partition");
+  SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->aux) { SDSO_HIP(ctx, hipStreamSynchronize(ctx->aux)); hipStreamDestroy(ctx->aux); ctx->aux = nullptr; }
+  if (ctx->ev_main) { hipEventDestroy(ctx->ev_main); ctx->ev_main = nullptr; }
+  if (ctx->ev_aux) { hipEventDestroy(ctx->ev_aux); ctx->ev_aux = nullptr; }
+  hipStreamDestroy(ctx->stream); ctx->stream = nullptr;
+  ctx->aux_cus = aux_cus;
+  if (aux_cus == 0) {
+    SDSO_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    return SDSO_OK;
+  }
+  const int ncu = ctx->n_cu, words = (ncu + 31) / 32;
+  std::vector<uint32_t> ma(words, 0u), mm(words, 0u);
+  // stride = 0: the lowest aux_cus indices; otherwise the first (aux_cus * stride / ncu) indices of every `stride` (e.g. stride 32 with
+  // aux_cus 32 on 256 CUs: 4 CUs out of every 32 — an equal share of every XCD whichever way the indices run over the XCDs)
+  const int per = stride ? std::max(1, aux_cus * stride / ncu) : 0;
+  int given = 0;
+  for (int c = 0; c < ncu; c++) {
+    const bool a = stride ? ((c % stride) < per && given < aux_cus) : c < aux_cus;
+    if (a) { ma[c >> 5] |= 1u << (c & 31); given++; } else mm[c >> 5] |= 1u << (c & 31);
+  }
+  SDSO_HIP(ctx, hipExtStreamCreateWithCUMask(&ctx->stream, words, mm.data()));
+  SDSO_HIP(ctx, hipExtStreamCreateWithCUMask(&ctx->aux, words, ma.data()));
+  SDSO_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_main, hipEventDisableTiming));
+  SDSO_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_aux, hipEventDisableTiming));
+  ctx->aux_cus = given;
+  return SDSO_OK;
+}
 extern "C" int sdso_ctx_sync(sdso_ctx* ctx) {
   if (!ctx) return SDSO_ERR_STATE;
   SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -70,6 +70,12 @@ struct sdso_ctx {
   void* pinned = nullptr;
   size_t pinned_bytes = 0;
   int n_cu = 256;
+  // CU partition (sdso_ctx_partition_cus): `stream` is masked to the large share of the CUs, `aux` to the small one; inside a batch's
+  // resident GN loop the linearisation runs on `stream`, the Schur accumulation and the fused tail kernel on `aux` — next to the
+  // linearisation of ANOTHER ctx's batch whose stream carries the same large mask.  aux == nullptr: no partition (everything on `stream`).
+  hipStream_t aux = nullptr;
+  hipEvent_t ev_main = nullptr, ev_aux = nullptr;
+  int aux_cus = 0;
   int gn_mode = 0;   // traceStereo refinement: 0 DSO-native, 1 fork-live g2o GN (sdso_trace_set_gn_mode)
   float* gammaB = nullptr;   // device copy of CalibHessian::B (256 floats) for the gamma-weighted absSquaredGrad; null = identity response
   // device buffers of released BA windows, kept for the next upload (a window is re-uploaded for every keyframe)

@@ -353,9 +353,11 @@ class WindowedBA {
   // (Residuals.h:113, Residuals.cpp:367-385) PER OBJECT, the way linearizeAll_Reductor / applyRes_Reductor call them
   // (FullSystemOptimize.cpp:52-96): the device linearises / applies the whole window at the first call after a change and every call
   // hands its own residual's results out — state_NewEnergy, state_NewEnergyWithOutlier, state_NewState; then state_state, state_energy,
-  // EFResidual::isActiveAndIsGoodNEW.  A linearised residual (EFResidual::isLinearized) is not touched, as in the reference's loops.
+  // EFResidual::isActiveAndIsGoodNEW.  A linearised residual (EFResidual::isLinearized) is not touched — the reference's loops run over
+  // activeResiduals, which holds none (FullSystemOptimize.cpp:880-889) —: both members return before any write.
   template <class PointFrameResidualT>
   double linearize(PointFrameResidualT* r, CalibHessianT* /*HCalib*/) {
+    if (r->efResidual->isLinearized) return 0.0;
     if (!lin_valid_) {
       const int nr = (int)residuals_.size();
       linearizeAll();
@@ -373,7 +375,13 @@ class WindowedBA {
     return r->state_NewEnergy;
   }
   template <class PointFrameResidualT>
-  void applyRes(PointFrameResidualT* r, bool /*copyJacobians*/) {
+  void applyRes(PointFrameResidualT* r, bool copyJacobians) {
+    if (r->efResidual->isLinearized) return;
+    if (!copyJacobians) {   // Residuals.cpp:382-384 alone: setState(state_NewState); state_energy = state_NewEnergy — no OOB test, isActiveAndIsGoodNEW untouched
+      r->state_state = r->state_NewState;
+      r->state_energy = r->state_NewEnergy;
+      return;
+    }
     if (!app_valid_) {
       const int nr = (int)residuals_.size();
       applyRes();

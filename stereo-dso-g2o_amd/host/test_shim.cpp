@@ -481,6 +481,21 @@ static int run_ba_members(const std::string& dir) {
     o_ns[i] = r->state_NewState; o_st[i] = r->state_state; o_act[i] = r->efResidual->isActiveAndIsGoodNEW ? 1 : 0;
     o_ne[i] = r->state_NewEnergy; o_nw[i] = r->state_NewEnergyWithOutlier; o_en[i] = r->state_energy;
   }
+  {  // the two object-level branches of Residuals.cpp:367-385 that do not go to the device: applyRes(false) moves state_state / state_energy
+     // only (no OOB return, isActiveAndIsGoodNEW untouched); a linearised residual is left alone by linearize and applyRes alike
+    PointFrameResidual probe = *G.pfrs[0];
+    EFResidual ep = *G.pfrs[0]->efResidual;
+    probe.efResidual = &ep;
+    probe.state_state = 1 /* OOB */; probe.state_NewState = 2; probe.state_NewEnergy = 42.0; probe.state_energy = 1.0; ep.isActiveAndIsGoodNEW = true;
+    ba.applyRes(&probe, false);
+    if (probe.state_state != 2 || probe.state_energy != 42.0 || !ep.isActiveAndIsGoodNEW) { std::fprintf(stderr, "applyRes(r, false) semantics\n"); return 1; }
+    ep.isLinearized = true;
+    probe.state_state = 0; probe.state_NewState = 2; probe.state_energy = 3.0; probe.state_NewEnergy = 5.0; probe.state_NewEnergyWithOutlier = 7.0;
+    const double e0 = ba.linearize(&probe, &HC);
+    ba.applyRes(&probe, true);
+    if (e0 != 0.0 || probe.state_state != 0 || probe.state_NewState != 2 || probe.state_energy != 3.0 || probe.state_NewEnergy != 5.0 || probe.state_NewEnergyWithOutlier != 7.0) {
+      std::fprintf(stderr, "a linearised residual was touched\n"); return 1; }
+  }
   dump(dir, "m_newState", o_ns); dump(dir, "m_state", o_st); dump(dir, "m_act", o_act); dump(dir, "m_newEnergy", o_ne); dump(dir, "m_newEnergyWO", o_nw); dump(dir, "m_energy", o_en);
   // ---- setAdjointsF / setDeltaF
   ba.setAdjointsF(&HC); ba.setDeltaF(&HC);

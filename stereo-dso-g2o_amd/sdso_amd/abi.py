@@ -266,6 +266,7 @@ def load():
     L.sdso_ctx_stream.argtypes = [vp]
     L.sdso_ctx_stream.restype = vp
     L.sdso_ctx_sync.argtypes = [vp]
+    L.sdso_ctx_partition_cus.argtypes = [vp, C.c_int, C.c_int]
     L.sdso_prof_enable.argtypes = [vp, C.c_int]
     L.sdso_selftest_se3.argtypes = [vp, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p]
     L.sdso_prof_reset.argtypes = [vp]
@@ -362,7 +363,7 @@ def load():
 
 
 EXPORTED_SYMBOLS = [
-    "sdso_ctx_create", "sdso_ctx_destroy", "sdso_last_error", "sdso_ctx_stream", "sdso_ctx_sync",
+    "sdso_ctx_create", "sdso_ctx_destroy", "sdso_last_error", "sdso_ctx_stream", "sdso_ctx_sync", "sdso_ctx_partition_cus",
     "sdso_prof_enable", "sdso_prof_reset", "sdso_prof_read", "sdso_selftest_se3",
     "sdso_pyramid_levels", "sdso_upload_pyramid", "sdso_make_pyramid", "sdso_set_gamma", "sdso_gamma_from_binv", "sdso_download_pyramid_level", "sdso_download_abs_grad",
     "sdso_release_pyramid", "sdso_track_set_ref", "sdso_track_release_ref", "sdso_track_make_eval",

@@ -278,3 +278,87 @@ def test_resident_loop_degenerate_windows(gpu_ctx, oracle, monkeypatch):
             assert np.abs(res[0][1] - res[1][1]).max() <= 2e-5 and helpers.idepths_close(res[0][1], io, 2e-4), name
         if nr:
             assert (res[0][2] != ro).sum() <= 2, name
+
+
+def test_batch_of_one_window_per_cu_takes_the_auto_selected_forms(gpu_ctx, oracle):
+    """From one window per CU on (256 on MI355X) the library switches forms BY ITSELF: the Schur kernel to a wave per host frame (launch_sc_and_folds:
+    2 nf nwin > 10 CUs) and the tail kernel takes the points' back-substitution and step too (TAIL_RESUB: nwin >= CUs).  The other parity
+    tests reach those forms through the SDSO_BA_SC_WPH / SDSO_BA_TAIL_RESUB overrides only (round-5 advisor finding); this one reaches them
+    on the DEFAULT path: 264 copies of one small 8-keyframe window as ONE batch, no override, every copy against the oracle's loop on that
+    window and bit-identical to the single-window call (which takes the workgroup-per-host Schur form and the separate points kernel)."""
+    import os
+    assert not any(k in os.environ for k in ("SDSO_BA_SC_WPH", "SDSO_BA_TAIL_RESUB", "SDSO_BA_TAIL"))
+    win = synth.ba_window(w=640, h=480, nf=8, pts_per_kf=40, seed=3301)
+    nf, npts, nr = win["nf"], win["np"], win["nr"]
+    for f in range(nf):
+        gpu_ctx.upload_pyramid(40 + f, win["pyrs"][f][:1])
+    W, keep = abi.make_ba_window(win, frame_slots=[40 + f for f in range(nf)], dI_list=[p[0] for p in win["pyrs"]])
+    h = oracle.orc_ba_create(C.byref(W))
+    so, io, ro, oo = np.zeros((nf, 10)), np.zeros(npts, np.float32), np.zeros(nr, np.uint8), abi.BAOptResult()
+    oracle.orc_ba_optimize(h, 6, abi.dp(so), abi.fp(io), abi.bp(ro), C.byref(oo))
+    oracle.orc_ba_destroy(h)
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_upload_window(gpu_ctx.h, 299, C.byref(W)))
+    ss, is_, rs, os_ = np.zeros((nf, 10)), np.zeros(npts, np.float32), np.zeros(nr, np.uint8), abi.BAOptResult()
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_optimize(gpu_ctx.h, 299, 6, abi.dp(ss), abi.fp(is_), abi.bp(rs), C.byref(os_)))
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_release_window(gpu_ctx.h, 299))
+    nwin = 264
+    ids = np.arange(300, 300 + nwin, dtype=np.int32)
+    for wid in ids:
+        gpu_ctx.check(gpu_ctx.L.sdso_ba_upload_window(gpu_ctx.h, int(wid), C.byref(W)))
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_batch_create(gpu_ctx.h, nwin, abi.ip(ids)))
+    res = (abi.BAOptResult * nwin)()
+    gpu_ctx.check(gpu_ctx.L.sdso_ba_batch_optimize(gpu_ctx.h, 6, res))
+    assert os_.iterations == oo.iterations
+    scale = np.array([0.5, 0.5, 0.5, 1.0, 1.0, 1.0, 10.0, 1000.0])
+    for k in (0, 1, 127, 255, 256, nwin - 1):
+        s, i, r = np.zeros((nf, 10)), np.zeros(npts, np.float32), np.zeros(nr, np.uint8)
+        gpu_ctx.check(gpu_ctx.L.sdso_ba_get_state(gpu_ctx.h, int(ids[k]), abi.dp(s), abi.fp(i), abi.bp(r)))
+        assert res[k].iterations == oo.iterations
+        d = np.abs(s - so)[:, :8] * scale
+        # (320 points: the scale direction is weakly held and carries the CPU float path's own summation noise — the spread-relative bar
+        #  of tests/test_ba_gpu.py::test_optimize_full_gn_loop's small window, as a fixed number)
+        assert d[:, :6].max() <= 2e-4 and d[:, 6].max() <= 2e-5 and d[:, 7].max() <= 2e-3, (k, d.max(axis=0))
+        assert (r != ro).sum() <= 2
+        # the batch's forms against the single call's: the per-point and per-residual arithmetic is the same statement for statement, the
+        # cross-point sums run in f64 in either form -> the same window to rounding of the packed floats
+        assert np.abs(s - ss).max() <= 1e-6 and np.abs(i - is_).max() <= 1e-5 and (r != rs).sum() <= 2, (k, np.abs(s - ss).max())
+    for wid in ids:
+        gpu_ctx.check(gpu_ctx.L.sdso_ba_release_window(gpu_ctx.h, int(wid)))
+
+
+def test_cu_partitioned_ctx_gives_the_same_windows(oracle):
+    """sdso_ctx_partition_cus: the Schur accumulation and the fused tail kernel of a batch's GN iterations on an aux stream that owns 64 CUs,
+    the linearisation on the other 192 (hipExtStreamCreateWithCUMask; measured as a schedule in profiles/r06_cumask_ab.txt and NOT adopted
+    by bench.py: it loses).  A schedule must not change a bit: the same batch through the same split calls on a plain ctx and on a
+    partitioned one ends on identical states, idepths and residual states."""
+    win = synth.ba_window(w=640, h=480, nf=6, pts_per_kf=80, seed=3401)
+    nf, npts, nr = win["nf"], win["np"], win["nr"]
+    out = []
+    for part in (0, 64):
+        ctx = abi.Context(0)
+        try:
+            if part:
+                ctx.check(ctx.L.sdso_ctx_partition_cus(ctx.h, part, 32))
+            for f in range(nf):
+                ctx.upload_pyramid(40 + f, win["pyrs"][f][:1])
+            W, keep = abi.make_ba_window(win, frame_slots=[40 + f for f in range(nf)])
+            ids = np.arange(500, 504, dtype=np.int32)
+            for wid in ids:
+                ctx.check(ctx.L.sdso_ba_upload_window(ctx.h, int(wid), C.byref(W)))
+            ctx.check(ctx.L.sdso_ba_batch_create(ctx.h, len(ids), abi.ip(ids)))
+            ctx.check(ctx.L.sdso_ba_batch_optimize_begin(ctx.h, 1))
+            for it in range(5):
+                ctx.check(ctx.L.sdso_ba_batch_linearize(ctx.h))
+                ctx.check(ctx.L.sdso_ba_batch_schur(ctx.h))
+                ctx.check(ctx.L.sdso_ba_batch_solve_step(ctx.h, 0.1 * 0.25 ** it, 1 if it >= 2 else 0))
+            res = (abi.BAOptResult * len(ids))()
+            ctx.check(ctx.L.sdso_ba_batch_optimize_end(ctx.h, res))
+            s, i, r = np.zeros((nf, 10)), np.zeros(npts, np.float32), np.zeros(nr, np.uint8)
+            ctx.check(ctx.L.sdso_ba_get_state(ctx.h, 503, abi.dp(s), abi.fp(i), abi.bp(r)))
+            out.append((s, i, r, res[3].iterations, res[3].lastEnergy))
+        finally:
+            ctx.close()
+    a, b = out
+    assert a[3] == b[3] and a[3] >= 2 and a[4] == b[4]
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    assert np.abs(a[0]).max() > 0

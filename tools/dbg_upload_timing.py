@@ -1,5 +1,6 @@
 """Phase times of sdso_ba_upload_window (SDSO_BA_UPLOAD_TIMING=1) on the 8KF / 2000-point bench window."""
 import ctypes as C, os, sys
+os.environ.setdefault("SDSO_DEBUG_ENV", "1")   # the library reads its A/B switches only behind this gate
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 for p in ("stereo-dso-g2o_amd", "oracle", "tests"):
     sys.path.insert(0, os.path.join(ROOT, p))

@@ -1,6 +1,7 @@
 """Single-call latency of sdso_track_newest_coarse (1232x368, 2000 points) under the environment it is started with (SDSO_TRK_LM_SOLO,
 SDSO_TRK_LM_CLUSTER), and of 8 / 64 hypotheses in one launch.  Prints one line."""
 import ctypes as C, os, sys, time
+os.environ.setdefault("SDSO_DEBUG_ENV", "1")   # the library reads its A/B switches only behind this gate
 import numpy as np
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 for p in ("stereo-dso-g2o_amd", "oracle", "tests"):
