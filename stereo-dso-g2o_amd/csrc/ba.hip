@@ -93,24 +93,38 @@ static int dmalloc(sdso_ctx* ctx, BaWindowDev* W, void** p, size_t bytes, bool z
 }
 // pinned host staging of the ctx (window uploads, table refreshes): grown on demand, released with the ctx's windows.  The caller
 // synchronises the stream before the next reservation is written.
-struct StageBuf { char* p = nullptr; size_t cap = 0; };
+// Two buffers taken in turn, each with an event that marks the last copy enqueued from it (stage_commit): a caller that commits need not
+// synchronise the stream — the buffer is only waited for when its turn comes again, two reservations later.  A caller that does not commit
+// synchronises the stream itself before the ctx reserves again (upload_tables, opt_finish).
+struct StageBuf { char* p[2] = {nullptr, nullptr}; size_t cap[2] = {0, 0}; hipEvent_t ev[2] = {nullptr, nullptr}; bool busy[2] = {false, false}; int cur = 0; };
 static std::map<sdso_ctx*, StageBuf> g_stage;
 static int stage_reserve(sdso_ctx* ctx, size_t bytes, char** out) {
   StageBuf& b = reg_get(g_stage, ctx);
-  if (bytes > b.cap) {
-    SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (b.p) hipHostFree(b.p);
-    b.p = nullptr; b.cap = 0;
+  b.cur ^= 1;
+  const int k = b.cur;
+  if (b.busy[k]) { SDSO_HIP(ctx, hipEventSynchronize(b.ev[k])); b.busy[k] = false; }
+  if (bytes > b.cap[k]) {
+    if (b.p[k]) { SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream)); hipHostFree(b.p[k]); }
+    b.p[k] = nullptr; b.cap[k] = 0;
     const size_t want = (bytes * 3 / 2 + 4095) & ~(size_t)4095;
-    SDSO_HIP(ctx, hipHostMalloc((void**)&b.p, want));
-    b.cap = want;
+    SDSO_HIP(ctx, hipHostMalloc((void**)&b.p[k], want));
+    b.cap[k] = want;
   }
-  *out = b.p;
+  *out = b.p[k];
+  return SDSO_OK;
+}
+static int stage_commit(sdso_ctx* ctx) {      // everything that reads the latest reservation has been enqueued on ctx->stream
+  StageBuf& b = reg_get(g_stage, ctx);
+  const int k = b.cur;
+  if (!b.ev[k]) SDSO_HIP(ctx, hipEventCreateWithFlags(&b.ev[k], hipEventDisableTiming));
+  SDSO_HIP(ctx, hipEventRecord(b.ev[k], ctx->stream));
+  b.busy[k] = true;
   return SDSO_OK;
 }
 static void stage_free(sdso_ctx* ctx) {
   StageBuf b;
-  if (reg_take(g_stage, ctx, b) && b.p) hipHostFree(b.p);
+  if (!reg_take(g_stage, ctx, b)) return;
+  for (int k = 0; k < 2; k++) { if (b.ev[k]) hipEventDestroy(b.ev[k]); if (b.p[k]) hipHostFree(b.p[k]); }
 }
 #define DM(ptr, T, count)                                                   \
   do {                                                                      \
@@ -321,59 +335,60 @@ static int upload_window_impl(sdso_ctx* ctx, int win, const sdso_ba_window_t* Wi
   W->prior_pristine = std::all_of(W->HM.begin(), W->HM.end(), [](double v) { return v == 0.0; }) && std::all_of(W->bM.begin(), W->bM.end(), [](double v) { return v == 0.0; });
 
   mark("host mirror of the frames");
-  // ---- validate + sort residuals by (host,target) pair, stable
-  std::vector<int> rhost(nr);
-  for (int p = 1; p < np; p++) SDSO_REQUIRE(ctx, Win->host[p] >= Win->host[p - 1], "points must be in allPoints order (host index non-decreasing)");
-  for (int p = 0; p < np; p++) SDSO_REQUIRE(ctx, Win->host[p] >= 0 && Win->host[p] < nf, "point host out of range");
-  std::vector<int> rbeg(np + 1, 0), rcnt(np, 0);
-  for (int i = 0; i < nr; i++) {
-    const int p = Win->res_point[i];
-    SDSO_REQUIRE(ctx, p >= 0 && p < np && (i == 0 || p >= Win->res_point[i - 1]), "residuals must be grouped by point in point order");
-    SDSO_REQUIRE(ctx, Win->res_target[i] >= 0 && Win->res_target[i] < nf, "residual target out of range");
-    rhost[i] = Win->host[p];
-    rcnt[p]++;
-    SDSO_REQUIRE(ctx, rcnt[p] <= SDSO_MAX_RES, "more than MAX_RES_PER_POINT residuals on a point");
+  // ---- validate + sort residuals by (host,target) pair, stable.  Two passes over the residuals (validation + keys + counts, then the
+  // placement with the sorted arrays written on the way) — a keyframe's upload is on the caller's critical path (round 5: ten passes and a
+  // np x nf scratch array were 66 of its 160 us)
+  for (int p = 0; p < np; p++) {
+    SDSO_REQUIRE(ctx, Win->host[p] >= 0 && Win->host[p] < nf, "point host out of range");
+    SDSO_REQUIRE(ctx, p == 0 || Win->host[p] >= Win->host[p - 1], "points must be in allPoints order (host index non-decreasing)");
   }
-  for (int p = 0; p < np; p++) rbeg[p + 1] = rbeg[p] + rcnt[p];     // (residuals are grouped by point: a point's first residual, nr behind the last)
-  {  // every validation runs before the first H2D copy: the staging vectors below must outlive the copies
-    std::vector<uint8_t> seen((size_t)np * nf, 0);
-    for (int o = 0; o < nr; o++) {
-      const size_t slot = (size_t)Win->res_point[o] * nf + Win->res_target[o];
-      SDSO_REQUIRE(ctx, !seen[slot], "two residuals of one point observe the same target frame");
-      seen[slot] = 1;
+  std::vector<int> rbeg(np + 1, 0), rcnt(np, 0);
+  std::vector<uint8_t> rkey(nr);
+  int cnt[65] = {0};
+  {  // every validation runs before the first H2D copy
+    int cur = -1; unsigned seen = 0;       // the targets the current point's residuals have named so far
+    for (int i = 0; i < nr; i++) {
+      const int p = Win->res_point[i], t = Win->res_target[i];
+      SDSO_REQUIRE(ctx, p >= 0 && p < np && p >= cur, "residuals must be grouped by point in point order");
+      SDSO_REQUIRE(ctx, t >= 0 && t < nf, "residual target out of range");
+      if (p != cur) { cur = p; seen = 0; }
+      SDSO_REQUIRE(ctx, !((seen >> t) & 1u), "two residuals of one point observe the same target frame");
+      seen |= 1u << t;
+      const int h = Win->host[p];
       // (the reference never creates one: `if(fh != point->host)`, FullSystemOptPoint.cpp:74; the Schur kernel has no column for it)
-      SDSO_REQUIRE(ctx, Win->res_target[o] != rhost[o], "a residual observes its own host frame");
+      SDSO_REQUIRE(ctx, t != h, "a residual observes its own host frame");
+      SDSO_REQUIRE(ctx, ++rcnt[p] <= SDSO_MAX_RES, "more than MAX_RES_PER_POINT residuals on a point");
+      const int key = h + t * nf;           // htIDX (nf^2 <= 64 keys)
+      rkey[i] = (uint8_t)key;
+      cnt[key + 1]++;
     }
   }
+  for (int p = 0; p < np; p++) rbeg[p + 1] = rbeg[p] + rcnt[p];     // (residuals are grouped by point: a point's first residual, nr behind the last)
+  for (int k = 0; k < nf * nf; k++) cnt[k + 1] += cnt[k];
+  int pair_first[65];
+  for (int k = 0; k <= nf * nf; k++) pair_first[k] = cnt[k];          // first sorted residual of every pair (the chunk lists below)
   W->perm.resize(nr); W->inv.resize(nr);
-  {  // stable counting sort by htIDX = host + target * nf (nf^2 <= 64 keys)
-    std::vector<int> cnt(nf * nf + 1, 0);
-    for (int i = 0; i < nr; i++) cnt[rhost[i] + Win->res_target[i] * nf + 1]++;
-    for (int k = 0; k < nf * nf; k++) cnt[k + 1] += cnt[k];
-    for (int i = 0; i < nr; i++) W->perm[cnt[rhost[i] + Win->res_target[i] * nf]++] = i;
-  }
-  for (int j = 0; j < nr; j++) W->inv[W->perm[j]] = j;
   std::vector<int> s_point(nr);
   std::vector<uint8_t> s_host(nr), s_target(nr), s_state(nr);
-  for (int j = 0; j < nr; j++) {
-    const int o = W->perm[j];
-    s_point[j] = Win->res_point[o]; s_host[j] = (uint8_t)rhost[o]; s_target[j] = (uint8_t)Win->res_target[o]; s_state[j] = Win->res_state[o];
+  for (int i = 0; i < nr; i++) {            // stable counting sort: placement, the inverse and the sorted arrays in one pass
+    const int key = rkey[i], j = cnt[key]++;
+    W->perm[j] = i; W->inv[i] = j;
+    s_point[j] = Win->res_point[i]; s_target[j] = (uint8_t)Win->res_target[i]; s_host[j] = (uint8_t)(key - s_target[j] * nf); s_state[j] = Win->res_state[i];
   }
   W->h_target = s_target;
   W->h_point = s_point;
-  W->newest_first = nr;
-  for (int j = 0; j < nr; j++) if (s_target[j] == nf - 1) { W->newest_first = j; break; }
+  W->newest_first = nr > 0 && nf > 0 ? pair_first[(nf - 1) * nf] : nr;    // first pair-sorted residual whose target is the newest frame (keys host + target * nf)
+  if (W->newest_first > nr) W->newest_first = nr;
   W->h_lin.assign(nr, 0);
   W->has_lin_cached = false;
   // chunks per pair
   std::vector<int4> chunks;
   std::vector<int> pair_beg(nf * nf + 1, 0);
   {
-    int j = 0;
+    chunks.reserve(nf * nf + nr / BA_CHUNK + 1);
     for (int pair = 0; pair < nf * nf; pair++) {
       pair_beg[pair] = (int)chunks.size();
-      int start = j;
-      while (j < nr && s_host[j] + s_target[j] * nf == pair) j++;
+      const int start = pair_first[pair], j = pair_first[pair + 1];
       for (int s = start; s < j; s += BA_CHUNK) chunks.push_back(make_int4(pair, s, std::min(BA_CHUNK, j - s), 0));
     }
     pair_beg[nf * nf] = (int)chunks.size();
@@ -530,8 +545,10 @@ static int upload_window_impl(sdso_ctx* ctx, int win, const sdso_ba_window_t* Wi
   // per-residual record: target in slot 15, newState OUTLIER, newEnergyWO -1
   if (nr) hipLaunchKernelGGL(k_ba_init_res, dim3(W->nblk_res), dim3(BA_BLOCK), 0, ctx->stream, W->d_self);
   SDSO_HIP(ctx, hipGetLastError());
-  SDSO_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the staging buffer is the ctx's: free for the next upload
-  mark("copy + clear + init kernel");
+  // no synchronisation: the upload is ENQUEUED (copy, clear, init kernel) and whatever the caller does next on this ctx queues behind it;
+  // the staging buffer is marked in flight (round 5 waited here: 38 of the call's 160 us)
+  { const int rcc = stage_commit(ctx); if (rcc) return rcc; }
+  mark("copy + clear + init kernel (enqueue)");
   return SDSO_OK;
 }
 // a window that failed half-way through its upload must not stay registered (later calls would launch on null arrays)

@@ -393,6 +393,35 @@ __device__ __forceinline__ double linearize_coop(const BaDev& B, int i, bool liv
     energyLeft += wgt * wgt * hw * residual * residual * (2 - hw);
     if (hw < 1) hw = sqrtf(hw);
     hw = hw * wgt;
+#ifdef SDSO_LIN_PK
+    // A/B (round 6, verdict item 5b): the (dx, dy) pairs of the per-pixel sums as two-float vectors -> v_pk_mul_f32 / v_pk_add_f32.  Every product
+    // and every sum is the scalar statement's, in its order (contraction is off: no packed fma): bit-identical.  profiles/r06_lin_pk_ab.txt
+    typedef float pk2 __attribute__((ext_vector_type(2)));
+    pk2 hyz = {hit.y, hit.z};
+    hyz = hyz * hw;
+    hit.y = hyz.x; hit.z = hyz.y;
+    SETQ(6 + idx, residual * hw, hit.y, hit.z, B.affA_fixed ? 0.f : drdA * hw);   // resF, JIdx[0], JIdx[1], JabF[0]
+    jab1[idx] = B.affB_fixed ? 0.f : hw;
+    if (KEEP == 2) {
+      const float ra = residual * hw;
+      const pk2 r01 = (pk2){rs[0], rs[1]} + ra * hyz;
+      rs[0] = r01.x; rs[1] = r01.y;
+      rs[2] += ra * (B.affA_fixed ? 0.f : drdA * hw); rs[3] += ra * jab1[idx];
+      rs[4] += ra * ra;
+    }
+    const pk2 sq = hyz * hyz;
+    const pk2 jj = (pk2){JIdxJIdx_00, JIdxJIdx_11} + sq;
+    JIdxJIdx_00 = jj.x; JIdxJIdx_11 = jj.y;
+    JIdxJIdx_10 += hit.y * hit.z;
+    const pk2 a0 = (pk2){JabJIdx_00, JabJIdx_01} + (drdA * hw) * hyz;
+    JabJIdx_00 = a0.x; JabJIdx_01 = a0.y;
+    const pk2 a1 = (pk2){JabJIdx_10, JabJIdx_11} + hw * hyz;
+    JabJIdx_10 = a1.x; JabJIdx_11 = a1.y;
+    JabJab_00 += drdA * drdA * hw * hw;
+    JabJab_01 += drdA * hw * hw;
+    JabJab_11 += hw * hw;
+    wJI2_sum += hw * hw * (sq.x + sq.y);
+#else
     hit.y *= hw;
     hit.z *= hw;
     SETQ(6 + idx, residual * hw, hit.y, hit.z, B.affA_fixed ? 0.f : drdA * hw);   // resF, JIdx[0], JIdx[1], JabF[0]
@@ -414,6 +443,7 @@ __device__ __forceinline__ double linearize_coop(const BaDev& B, int i, bool liv
     JabJab_01 += drdA * hw * hw;
     JabJab_11 += hw * hw;
     wJI2_sum += hw * hw * (hit.y * hit.y + hit.z * hit.z);
+#endif
   }
   }
   }
