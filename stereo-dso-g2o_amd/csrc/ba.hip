@@ -621,12 +621,12 @@ static bool launch_sc_and_folds(sdso_ctx* ctx, const BaLaunch& L, const uint8_t*
   }
   {
     ProfScope ps(ctx, "k_ba_sc", 2);
-    // a wave per host (see the kernel) once the workgroups-per-host form would need more than two and a half rounds of three workgroups per
-    // CU (measured, µs, workgroup / wave form: 64 windows 34 / 66, 128: 60 / 69, 192: 76 / 93, 256: 104 / 100 — profiles/r05_sc_batch_ab.txt);
+    // a wave per host (see the kernel) once the workgroups-per-host form would need more than three rounds of two workgroups per CU;
     // SDSO_BA_SC_WPH=0 / 1 forces one form (A/B)
     static const int wph_env = dbg_env("SDSO_BA_SC_WPH") ? atoi(dbg_env("SDSO_BA_SC_WPH")) : -1;
     const int cus = (ctx->aux && ctx->stream == ctx->aux) ? ctx->aux_cus : ctx->n_cu;     // the CUs this launch may use (CU-partitioned ctx: the aux share)
-    const bool wph = wph_env >= 0 ? wph_env != 0 : 2 * nf * L.nwin > 10 * cus;   // (two workgroups per CU since the f64 accumulators: 2.5 rounds)
+    const bool wph = wph_env >= 0 ? wph_env != 0 : 2 * nf * L.nwin > 13 * cus;   // (round 6, two workgroups per CU since the f64 accumulators — µs,
+                                                                                   //  workgroup / wave form: 128 windows 70 / 76, 192: 101 / 108, 224: 122 / 111, 256: 136 / 120: profiles/r06_sc_batch_ab.txt)
     const dim3 g(wph ? (nf + BA_BLOCK / 64 - 1) / (BA_BLOCK / 64) : nf, L.nwin);
     if (plain) { if (wph) hipLaunchKernelGGL((k_ba_sc_host<true, true>), g, dim3(BA_BLOCK), 0, ctx->stream, L.d_arr, pflag, shift, mm, clear_l);
                  else hipLaunchKernelGGL((k_ba_sc_host<true, false>), g, dim3(BA_BLOCK), 0, ctx->stream, L.d_arr, pflag, shift, mm, clear_l); }

@@ -287,7 +287,8 @@ def test_batch_of_one_window_per_cu_takes_the_auto_selected_forms(gpu_ctx, oracl
     on the DEFAULT path: 264 copies of one small 8-keyframe window as ONE batch, no override, every copy against the oracle's loop on that
     window and bit-identical to the single-window call (which takes the workgroup-per-host Schur form and the separate points kernel)."""
     import os
-    assert not any(k in os.environ for k in ("SDSO_BA_SC_WPH", "SDSO_BA_TAIL_RESUB", "SDSO_BA_TAIL"))
+    if any(k in os.environ for k in ("SDSO_BA_SC_WPH", "SDSO_BA_TAIL_RESUB", "SDSO_BA_TAIL")):
+        pytest.skip("this test is about the DEFAULT path (tests/test_variants_gpu.py runs this file under overrides)")
     win = synth.ba_window(w=640, h=480, nf=8, pts_per_kf=40, seed=3301)
     nf, npts, nr = win["nf"], win["np"], win["nr"]
     for f in range(nf):
