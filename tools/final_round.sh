@@ -17,6 +17,6 @@ timeout -k 10 300 python tests/diag/bench_latency.py > gpurun_out/${tag}_latency
 timeout -k 10 200 python tools/time_optimize.py > gpurun_out/${tag}_optimize_times.txt 2>&1
 timeout -k 10 100 python tools/time_track.py > gpurun_out/${tag}_time_track_final.txt 2>&1
 echo latency done
-bash tools/profile_all.sh $tag > gpurun_out/profile_${tag}.log 2>&1
+if [ "${SKIP_PROFILES:-0}" != "1" ]; then bash tools/profile_all.sh $tag > gpurun_out/profile_${tag}.log 2>&1; fi
 echo profiles done
 ls gpurun_out | wc -l
