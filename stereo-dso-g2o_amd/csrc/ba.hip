@@ -644,7 +644,11 @@ static bool launch_fused(sdso_ctx* ctx, const BaLaunch& L, bool materialize, int
   const int nf = L.nf;
   if ((part & 1) && L.max_chunks > 0) {
     {
+#ifdef SDSO_LIN_PERSIST
+      const dim3 g((L.max_chunks + 1) / 2, L.nwin), b(BA_BLOCK);      // A/B: two chunks per (persistent) workgroup
+#else
       const dim3 g(L.max_chunks, L.nwin), b(BA_BLOCK);
+#endif
 #define LT(K) launch_timed(ctx, "k_ba_lin_fused", 1, K, g, b, (const BaDev*)L.d_arr)
       if (materialize) { if (L.tiled) LT((k_ba_lin_fused<true, true>)); else LT((k_ba_lin_fused<true, false>)); }
       else { if (L.tiled) LT((k_ba_lin_fused<false, true>)); else LT((k_ba_lin_fused<false, false>)); }

@@ -310,8 +310,10 @@ __device__ __forceinline__ void coop_gather_hits(const float4* __restrict__ img,
   }
   cg_wave_sync();
 }
+// what a persistent workgroup requested for this chunk while it worked on the previous one (SDSO_LIN_PERSIST): r_state, r_point, p_geo
+struct LinPre { int st, pt; float4 geo; };
 template <bool STORE, int KEEP, bool TILED>
-__device__ __forceinline__ double linearize_coop(const BaDev& B, int i, bool live, int h, int t, float* jl, int& ns_out, float* rs, float* wstage) {
+__device__ __forceinline__ double linearize_coop(const BaDev& B, int i, bool live, int h, int t, float* jl, int& ns_out, float* rs, float* wstage, const LinPre* have = nullptr) {
   ns_out = 1;
   bool dead = !live;
   double ret = 0;
@@ -331,11 +333,15 @@ __device__ __forceinline__ double linearize_coop(const BaDev& B, int i, bool liv
   float* __restrict__ J = nullptr;
   if (!dead) do {
   B.r_newEnergyWO[i] = -1.f;
-  const uint8_t st = B.r_state[i];
+  const uint8_t st = have ? (uint8_t)have->st : B.r_state[i];
   if (st == 1) { B.r_newState[i] = 1; ret = (double)B.r_energy[i]; dead = true; break; }
-  const int pt = B.r_point[i];
+  const int pt = have ? have->pt : B.r_point[i];
   const float* KRKi = pre; const float* Kt = pre + 9; const float* R0 = pre + 12; const float* t0 = pre + 21;
-  const float4 g = B.p_geo[pt];
+#if defined(SDSO_LIN_PERSIST) && SDSO_LIN_PERSIST < 2
+  const float4 g = B.p_geo[pt];                  // (light form: only the chunk descriptor, r_state and r_point are requested ahead)
+#else
+  const float4 g = have ? have->geo : B.p_geo[pt];
+#endif
   const float pu = g.x, pv = g.y, idepth_scaled = g.z, idepth_zero_scaled = g.w;
   J = STORE ? ((B.r_jsel[i] != 0) != (B.jfix != 0) ? B.J[0] : B.J[1]) : nullptr;   // jfix: EFResidual::J refreshed in place (ba_kernels.h)
   const float fxl = B.fxl, fyl = B.fyl, cxl = B.cxl, cyl = B.cyl, fxli = B.fxli, fyli = B.fyli;
@@ -714,7 +720,8 @@ static_assert(TE_LDS_FLOATS * 4 >= ((BA_BLOCK / 64) * 256 + BA_BLOCK / 64) * 8, 
 
 template <bool LDS_ONLY = false>
 __device__ __forceinline__ void top_emit(const BaDev& B, const float* x, const float* y, float a, float b, float c, float TR00, float TR10, float TR01,
-                                         float TR11, float TR02, float TR12, const float* br, bool on, float* stage) {
+                                         float TR11, float TR02, float TR12, const float* br, bool on, float* stage, int chunk = -1 /* default: blockIdx.x */) {
+  if (chunk < 0) chunk = (int)blockIdx.x;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   float* S = stage + wv * TE_WAVE_FLOATS;
   const int m = lane & 15, kq = lane >> 4;
@@ -788,7 +795,7 @@ __device__ __forceinline__ void top_emit(const BaDev& B, const float* x, const f
     double s = R[off];
 #pragma unroll
     for (int w = 1; w < BA_BLOCK / 64; w++) s += R[off + (t < 91 ? w * 256 : w)];
-    B.top_part[(size_t)blockIdx.x * 92 + t] = s;
+    B.top_part[(size_t)chunk * 92 + t] = s;
   }
 }
 
@@ -896,13 +903,41 @@ __global__ __launch_bounds__(BA_BLOCK, (MATERIALIZE ? 3 : 4)) void k_ba_lin_fuse
   const BaDev B = wins[blockIdx.y];
   if (ba_finished_lin(B)) return;
   if ((int)blockIdx.x >= B.nchunks) return;
-  const int4 ch = B.chunks[blockIdx.x];
-  const int pair = __builtin_amdgcn_readfirstlane(ch.x);   // one (host,target) per workgroup: precalc, image, thresholds are wave-uniform
-  const int i = ch.y + threadIdx.x;
   constexpr int STAGE_FLOATS = (BA_BLOCK / 64) * (COOP ? CG_WAVE_FLOATS : 0);
   constexpr int RED_FLOATS = TE_LDS_FLOATS > STAGE_FLOATS ? TE_LDS_FLOATS : STAGE_FLOATS;
   __shared__ float red[RED_FLOATS];    // the gather stage of the linearisation, then the MFMA panels of the reduction
   double* const lds = (double*)red;    // (the energy reduction runs between the two uses; 40 KB in all = four workgroups per CU)
+#ifdef SDSO_LIN_PERSIST
+  // A/B (round 6, verdict item 5a): a persistent workgroup walks the chunks blockIdx.x, blockIdx.x + gridDim.x, ... of its window (launched with
+  // half the chunks as grid: two chunks per workgroup) and requests the NEXT chunk's descriptor, r_state / r_lin / r_point at the top of the current
+  // one and its p_geo once the current chunk's taps are through — three dependent round trips of the next chunk under the current one's work.
+  int4 chN = B.chunks[blockIdx.x];
+  bool liveN = false; LinPre preN{1, 0, make_float4(0.f, 0.f, 0.f, 0.f)};
+  {
+    const int i0 = chN.y + threadIdx.x;
+    liveN = (int)threadIdx.x < chN.z && !B.r_lin[i0];
+    if (liveN) { preN.st = B.r_state[i0]; preN.pt = B.r_point[i0]; }
+#if SDSO_LIN_PERSIST >= 2
+    if (liveN) preN.geo = B.p_geo[preN.pt];
+#endif
+  }
+  for (int chunk = blockIdx.x; chunk < B.nchunks; chunk += gridDim.x) {
+  const int4 ch = chN;
+  const bool live = liveN;
+  const LinPre preC = preN;
+  const int nxt = chunk + (int)gridDim.x;
+  if (nxt < B.nchunks) {
+    chN = B.chunks[nxt];
+    const int in = chN.y + threadIdx.x;
+    liveN = (int)threadIdx.x < chN.z && !B.r_lin[in];
+    if (liveN) { preN.st = B.r_state[in]; preN.pt = B.r_point[in]; }
+  }
+#else
+  const int chunk = blockIdx.x;
+  const int4 ch = B.chunks[blockIdx.x];
+#endif
+  const int pair = __builtin_amdgcn_readfirstlane(ch.x);   // one (host,target) per workgroup: precalc, image, thresholds are wave-uniform
+  const int i = ch.y + threadIdx.x;
   float x[10], y[10], a = 0, b = 0, c = 0;
   float TR00 = 0, TR10 = 0, TR01 = 0, TR11 = 0, TR02 = 0, TR12 = 0;
   float br[6] = {0, 0, 0, 0, 0, 0};
@@ -910,14 +945,24 @@ __global__ __launch_bounds__(BA_BLOCK, (MATERIALIZE ? 3 : 4)) void k_ba_lin_fuse
   for (int k = 0; k < 10; k++) { x[k] = 0; y[k] = 0; }
   bool on = false;
   double e = 0;
+#ifndef SDSO_LIN_PERSIST
   const bool live = (int)threadIdx.x < ch.z && !B.r_lin[i];
+#endif
   float jl[76];
   float rs5[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
   int ns = 1;
   uint8_t st = 1;
   if (COOP) {
+#ifdef SDSO_LIN_PERSIST
+    if (live) st = (uint8_t)preC.st;
+    e = linearize_coop<MATERIALIZE, 2, TILED>(B, i, live, pair % B.nf, pair / B.nf, jl, ns, rs5, red + (threadIdx.x >> 6) * CG_WAVE_FLOATS, &preC);
+#if SDSO_LIN_PERSIST >= 2
+    if (nxt < B.nchunks && liveN) preN.geo = B.p_geo[preN.pt];      // (the next chunk's point index arrived long ago)
+#endif
+#else
     if (live) st = B.r_state[i];
     e = linearize_coop<MATERIALIZE, 2, TILED>(B, i, live, pair % B.nf, pair / B.nf, jl, ns, rs5, red + (threadIdx.x >> 6) * CG_WAVE_FLOATS);
+#endif
     __syncthreads();   // the reduction below reuses the stage of all waves
   }
   if (live) {
@@ -970,9 +1015,13 @@ __global__ __launch_bounds__(BA_BLOCK, (MATERIALIZE ? 3 : 4)) void k_ba_lin_fuse
     }
   }
   e = block_sum_d(e, lds);
-  if (threadIdx.x == 0) B.e_part[blockIdx.x] = e;
+  if (threadIdx.x == 0) B.e_part[chunk] = e;
   __syncthreads();
-  top_emit(B, x, y, a, b, c, TR00, TR10, TR01, TR11, TR02, TR12, br, on, red);
+  top_emit(B, x, y, a, b, c, TR00, TR10, TR01, TR11, TR02, TR12, br, on, red, chunk);
+#ifdef SDSO_LIN_PERSIST
+  __syncthreads();   // the next chunk's gather stage lies over the panels
+  }
+#endif
 }
 
 // ------------------------------------------------------------------ linearised energy (EnergyFunctional::calcLEnergyPt, EnergyFunctional.cpp:354-417)
