@@ -1114,8 +1114,9 @@ __global__ __launch_bounds__(128) void k_ba_zero_topL(const BaDev* __restrict__ 
 //            point's target -> record map (a word of nibbles) for phase 2.  The quad exchanges H / `any` by DPP and stores the point's 32 bytes
 //            of BaDev::p_out ([8..13], the sums of linearised / marginalised residuals, only when such residuals exist or their stale values
 //            have to be cleared) and idepth_hessian / the active-record mask / `maxRelBaseline = 0` (:44-48) in BaDev::p_track.
-//   phase 2  Z^T diag(HdiF) Z on the matrix cores (fp32 MFMA 16x16x4, K = 4 points), Z = [JpJdF of target 0..7 | Hcd | bdSumF] (69 columns):
-//            only the 15 tiles on and above the diagonal of the 5 x 5 tile grid are accumulated (60 accumulator registers); the bins below the
+//   phase 2  Z^T diag(HdiF) Z on the matrix cores (v_mfma_f64_16x16x4_f64 since round 6 — ACC_MODE_SC —, K = 4 points), Z = [JpJdF of the 7 targets a
+//            point can observe (never its host) | Hcd | bdSumF] (61 columns in a 4 x 4 grid of 16-column tiles): only the 10 tiles on and above the
+//            diagonal are accumulated (80 accumulator registers in f64); the bins below the
 //            diagonal are written as mirror images, which makes accD(i,j,k) == accD(i,k,j)^T hold EXACTLY as it does in the reference
 //            (AccumulatorXX::update multiplies a_i * b_j * w: the same product for both, MatrixAccumulators.h:31-80) — the stitch relies on it
 //            (ba_tail.hip: S2 = S1^T).  Absent targets, residuals that are not active and points without an active residual are exact zeros.
@@ -1125,7 +1126,7 @@ __global__ __launch_bounds__(128) void k_ba_zero_topL(const BaDev* __restrict__ 
 // PLAIN: no marginalisation pass, no point filter, no linearized residual in the launch (every GN iteration of the reference's live flow):
 // all active residuals go to the A sums, and the records of a residual that is not active hold zeros — x + 0 is exact — so no flag is read
 // on the value lanes.  clearL: also store zeros into the L sums of p_out (a launch with linearised residuals left values there).
-// Three workgroups per CU: <= 168 VGPRs, 51 KB of LDS.
+// Two workgroups per CU: 217 VGPRs (the f64 tiles), 51 KB of LDS.
 constexpr int SCH_REC = 1024;                         // floats of one record buffer: 16 points x 8 records x 8 floats
 constexpr int SCH_WAVE = 3 * SCH_REC + 16 * 8;        // two JpJdF buffers (double-buffered), one term buffer, the points' phase-2 operands
 // WPH ("wave per host", the form of a large batch): every WAVE takes a whole host frame — all its 16-point groups in a row — and a workgroup
