@@ -895,6 +895,14 @@ __global__ __launch_bounds__(BA_BLOCK) void k_ba_accum_top(const BaDev* __restri
 // (capping it at 128 spills 22-38 of them and loses more than the fourth wave per SIMD gains), so three.
 // The 32 taps of a residual come in through the cooperative quad gather (linearize_coop).  (Rounds 1-4 kept two more gathers for A/B — one
 // residual's taps on one lane, and LDS-DMA rounds; both lost or tied, profiles/README.md.)
+// The workgroup barriers behind the linearisation exchange data through LDS only (the gather stage handed over to the reduction's panels, the
+// energy sum, the waves' tiles).  -DSDSO_LIN_LDS_BARRIERS=1 makes them wait for the wave's LDS traffic only, not for its outstanding
+// Jacobian-record stores (`__syncthreads()` is s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier) — measured: no difference (0.772-0.777 against
+// 0.770-0.774 ms, profiles/r06_lin_barriers_ab.txt: two other workgroups per CU run under a wave's wait), so the plain barriers stay.
+#ifndef SDSO_LIN_LDS_BARRIERS
+#define SDSO_LIN_LDS_BARRIERS 0
+#endif
+constexpr bool LIN_LDS_BARRIERS = SDSO_LIN_LDS_BARRIERS != 0;
 template <bool MATERIALIZE, bool TILED>
 __global__ __launch_bounds__(BA_BLOCK, (MATERIALIZE ? 3 : 4)) void k_ba_lin_fused(const BaDev* __restrict__ wins) {
   constexpr bool COOP = true;
@@ -963,7 +971,7 @@ __global__ __launch_bounds__(BA_BLOCK, (MATERIALIZE ? 3 : 4)) void k_ba_lin_fuse
     if (live) st = B.r_state[i];
     e = linearize_coop<MATERIALIZE, 2, TILED>(B, i, live, pair % B.nf, pair / B.nf, jl, ns, rs5, red + (threadIdx.x >> 6) * CG_WAVE_FLOATS);
 #endif
-    __syncthreads();   // the reduction below reuses the stage of all waves
+    wg_barrier<LIN_LDS_BARRIERS>();   // the reduction below reuses the stage of all waves
   }
   if (live) {
     float* rec = B.r_rec + (size_t)B.r_orig[i] * 16;
@@ -1014,10 +1022,10 @@ __global__ __launch_bounds__(BA_BLOCK, (MATERIALIZE ? 3 : 4)) void k_ba_lin_fuse
       *(float4*)(rec + 12) = make_float4(rhcd[2], rhcd[3], (float)act, 0.f);
     }
   }
-  e = block_sum_d(e, lds);
+  e = block_sum_d<LIN_LDS_BARRIERS>(e, lds);
   if (threadIdx.x == 0) B.e_part[chunk] = e;
-  __syncthreads();
-  top_emit(B, x, y, a, b, c, TR00, TR10, TR01, TR11, TR02, TR12, br, on, red, chunk);
+  wg_barrier<LIN_LDS_BARRIERS>();
+  top_emit<LIN_LDS_BARRIERS>(B, x, y, a, b, c, TR00, TR10, TR01, TR11, TR02, TR12, br, on, red, chunk);
 #ifdef SDSO_LIN_PERSIST
   __syncthreads();   // the next chunk's gather stage lies over the panels
   }
