@@ -56,3 +56,42 @@ def test_variant_passes_the_parity_tests_of_its_path(env, targets):
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-1500:])
     assert " passed" in r.stdout
+
+
+_GATE_PROBE = r"""
+import ctypes as C, os, sys
+import numpy as np
+ROOT = sys.argv[1]
+for p in ("stereo-dso-g2o_amd", "tests"):
+    sys.path.insert(0, os.path.join(ROOT, p))
+from sdso_amd import abi
+import synth
+ctx = abi.Context(0)
+win = synth.ba_window(w=640, h=480, nf=5, pts_per_kf=60, seed=3501)
+for f in range(win["nf"]):
+    ctx.upload_pyramid(40 + f, win["pyrs"][f][:1])
+W, keep = abi.make_ba_window(win, frame_slots=[40 + f for f in range(win["nf"])])
+ctx.check(ctx.L.sdso_ba_upload_window(ctx.h, 1, C.byref(W)))
+ctx.check(ctx.L.sdso_prof_reset(ctx.h)); ctx.check(ctx.L.sdso_prof_enable(ctx.h, 2))
+s, i, r, o = np.zeros((win["nf"], 10)), np.zeros(win["np"], np.float32), np.zeros(win["nr"], np.uint8), abi.BAOptResult()
+ctx.check(ctx.L.sdso_ba_optimize(ctx.h, 1, 4, abi.dp(s), abi.fp(i), abi.bp(r), C.byref(o)))
+print("TAIL_LAUNCHES", ctx.prof_read("k_ba_tail")[1])
+ctx.close()
+"""
+
+
+def test_ab_switches_exist_only_behind_the_debug_gate():
+    """csrc/sdso_internal.h::dbg_env: the library looks at its A/B variables only when the process runs with SDSO_DEBUG_ENV=1 (read once).
+    SDSO_BA_TAIL=0 replaces the fused tail kernel by the chain of separate kernels — with the gate on; without it the variable is never read and
+    the fused kernel runs (round-5 verdict, Weak #8: switches in the product library, some read per call)."""
+    base = {k: v for k, v in os.environ.items() if not k.startswith("SDSO_")}
+    out = {}
+    for gate in ("0", "1"):
+        e = dict(base, SDSO_BA_TAIL="0")
+        if gate == "1":
+            e["SDSO_DEBUG_ENV"] = "1"
+        r = subprocess.run([sys.executable, "-c", _GATE_PROBE, ROOT], env=e, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[gate] = int([l for l in r.stdout.splitlines() if l.startswith("TAIL_LAUNCHES")][0].split()[1])
+    assert out["0"] > 0, out          # gate off: the variable is ignored, the fused tail kernel ran
+    assert out["1"] == 0, out         # gate on: the round-2 chain of kernels instead
